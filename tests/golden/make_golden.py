@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""
+Generates the golden fixtures under tests/golden/ by RUNNING THE REFERENCE in the dev container.
+
+  python tests/golden/make_golden.py            # needs /root/reference; never runs on the GPU box
+
+What is imported from /root/reference, and how:
+  * ghn3/graphormer.py  -- imported UNMODIFIED by file path (torch-only module).  Produces
+                           ``graphormer_*.npz``: a true oracle for SURVEY rows A4-A8.
+  * ghn3 (package)      -- imported with stand-in modules for the third-party packages that are not
+                           installed in this image (``ppuda``, ``torchvision``, ``h5py``); the ppuda
+                           base classes (GHN, ConvDecoder, ShapeEncoder, MLP, named_layered_modules)
+                           are the restatement in oracle/ppuda_base.py.  The reference's own
+                           ``GHN3.forward / _map_net_params / _tile_params / _normalize /
+                           _set_params / ConvDecoder3.forward / GraphBatch`` then run as shipped.
+                           Produces ``ghn3_tiny_*.npz`` and ``tile_cases.npz``.
+
+Only data (inputs, expected outputs) is written; no reference source text is stored.
+GHN weights are NOT stored: both this script and the tests rebuild them with
+``tests/golden/recipe.py::seeded_state_dict`` (numpy RandomState, stable bit stream).
+"""
+
+import importlib.util
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+REF = '/root/reference'
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+from oracle import ppuda_base                              # noqa: E402
+import recipe                                              # noqa: E402
+
+
+# ------------------------------------------------------------------------------------------------
+# stand-ins for packages absent from the image
+# ------------------------------------------------------------------------------------------------
+
+def install_standins():
+    import transformers, transformers.pytorch_utils        # noqa: F401  must precede the torchvision stub
+
+    def mod(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    class _Stub(nn.Module):
+        pass
+
+    names = ['Inception3', 'SwinTransformer', 'VisionTransformer', 'SqueezeNet']
+    vt = mod('torchvision.models.vision_transformer', Encoder=type('Encoder', (nn.Module,), {}))
+    cn = mod('torchvision.models.convnext', LayerNorm2d=type('LayerNorm2d', (nn.Module,), {}))
+    tvm = mod('torchvision.models', vision_transformer=vt, convnext=cn,
+              **{n: type(n, (nn.Module,), {}) for n in names})
+    tvt = mod('torchvision.transforms')
+    mod('torchvision', models=tvm, transforms=tvt)
+    mod('h5py')
+
+    mod('ppuda')
+    mod('ppuda.ghn')
+    mod('ppuda.ghn.nn', GHN=ppuda_base.GHN, ConvDecoder=ppuda_base.ConvDecoder)
+
+    class AvgrageMeter:
+        pass
+
+    mod('ppuda.utils', capacity=ppuda_base.capacity, AvgrageMeter=AvgrageMeter, accuracy=None, init=None,
+        rand_choice=None, infer=None, adjust_net=None)
+    mod('ppuda.deepnets1m')
+    mod('ppuda.deepnets1m.net', named_layered_modules=ppuda_base.named_layered_modules,
+        get_cell_ind=lambda *a, **k: 0, Network=type('Network', (nn.Module,), {}),
+        AuxiliaryHeadImageNet=_Stub, AuxiliaryHeadCIFAR=_Stub, drop_path=None, _is_none=lambda x: x is None)
+    mod('ppuda.deepnets1m.ops', parse_op_ks=None, PosEnc=type('PosEnc', (nn.Module,), {}))
+    mod('ppuda.deepnets1m.genotypes', PRIMITIVES_DEEPNETS1M=ppuda_base.PRIMITIVES_DEEPNETS1M, from_dict=None)
+    mod('ppuda.deepnets1m.loader', DeepNets1M=object, NetBatchSampler=object, MAX_NODES_BATCH=2200)
+
+
+def load_reference_graphormer():
+    spec = importlib.util.spec_from_file_location('_ref_graphormer', os.path.join(REF, 'ghn3', 'graphormer.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m.create_transformer(nn.Module, nn.Linear, nn.GELU, nn.ReLU, nn.LayerNorm, nn.Dropout, nn.Identity,
+                                nn.Sequential)
+
+
+# ------------------------------------------------------------------------------------------------
+# 1. Graphormer goldens (reference graphormer.py unmodified)
+# ------------------------------------------------------------------------------------------------
+
+def make_graphormer_goldens():
+    types_ = load_reference_graphormer()
+    Layer = types_['TransformerLayer']
+    out = {}
+    for tag, (C, H, N, B) in {'c32': (32, 4, 12, 2), 'c48': (48, 16, 70, 1)}.items():
+        rs = np.random.RandomState(1234 + C)
+        l0 = Layer(dim=C, edge_dim=2, num_heads=H, mlp_ratio=4, return_edges=True)
+        l0.centrality_embed_in = nn.Embedding(101, C)
+        l0.centrality_embed_out = nn.Embedding(101, C)
+        l0.input_dist_embed = nn.Embedding(1001, C)
+        l1 = Layer(dim=C, edge_dim=0, num_heads=H, mlp_ratio=4, return_edges=False)
+        for li, layer in enumerate((l0, l1)):
+            sd = recipe.seeded_state_dict({k: tuple(v.shape) for k, v in layer.state_dict().items()},
+                                          seed=100 * C + li)
+            layer.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        n_nodes = [N, max(3, N - 5)][:B]
+        A = np.zeros((B, N, N), dtype=np.int64)
+        for b in range(B):
+            A[b, :n_nodes[b], :n_nodes[b]] = recipe.random_dag_spd(n_nodes[b], seed=77 + b + C, cutoff=50)
+        x = rs.standard_normal((B, N, C)).astype(np.float32)
+        node_mask = np.zeros((B, N, 1), dtype=bool)
+        for b in range(B):
+            node_mask[b, :n_nodes[b]] = True
+        mask = torch.from_numpy(node_mask) & torch.from_numpy(node_mask).permute(0, 2, 1)
+        with torch.no_grad():
+            y0, bias, _ = l0(torch.from_numpy(x.copy()), torch.from_numpy(A), mask)
+            y1 = l1(y0.clone(), bias, mask)
+        out[tag + '/x'] = x
+        out[tag + '/A'] = A.astype(np.int16)
+        out[tag + '/n_nodes'] = np.asarray(n_nodes, dtype=np.int64)
+        out[tag + '/cfg'] = np.asarray([C, H, N, B], dtype=np.int64)
+        out[tag + '/y0'] = y0.numpy()
+        out[tag + '/bias'] = bias.numpy()
+        out[tag + '/y1'] = y1.numpy()
+    np.savez_compressed(os.path.join(HERE, 'graphormer_layers.npz'), **out)
+    print('graphormer_layers.npz', {k: v.shape for k, v in out.items()})
+
+
+# ------------------------------------------------------------------------------------------------
+# 2. Full GHN-3 forward (+ gradient summaries) on the tiny config, reference GHN3 class
+# ------------------------------------------------------------------------------------------------
+
+def make_ghn3_goldens():
+    install_standins()
+    sys.path.insert(0, REF)
+    import ghn3                                              # noqa: F401  the reference package
+    from ghn3.nn import GHN3
+    from ghn3.graph import Graph, GraphBatch
+    Encoder = sys.modules['torchvision.models.vision_transformer'].Encoder
+
+    cfg = recipe.TINY_CFG
+    torch.manual_seed(0)
+    ghn = GHN3(**cfg, debug_level=0)
+    shapes = {k: tuple(v.shape) for k, v in ghn.state_dict().items()}
+    sd = recipe.seeded_state_dict(shapes, seed=recipe.TINY_SEED)
+    ghn.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    n_params = sum(p.numel() for p in ghn.parameters())
+
+    out = {'meta/n_params': np.asarray([n_params], dtype=np.int64)}
+    names_sorted = sorted(shapes)
+    out['meta/state_keys'] = np.asarray(names_sorted)
+    out['meta/state_shapes'] = np.asarray([str(shapes[k]) for k in names_sorted])
+
+    for case, spec_ids in recipe.TINY_CASES.items():
+        specs = [recipe.TINY_NETS[i] for i in spec_ids]
+        nets = [recipe.build_torch_net(s, encoder_cls=Encoder) for s in specs]
+        graphs = []
+        for s in specs:
+            node_feat, node_info, A = recipe.graph_arrays(s)
+            graphs.append(Graph(node_feat=torch.from_numpy(node_feat), node_info=node_info,
+                                A=torch.from_numpy(A), dense=True))
+        batch = GraphBatch(graphs, dense=True)
+        ghn.train()
+        ghn.zero_grad()
+        torch.manual_seed(5)
+        nets_out, emb = ghn(nets, batch, return_embeddings=True, keep_grads=True,
+                            bn_track_running_stats=True, reduce_graph=False)
+        loss = 0
+        for b, net in enumerate(nets_out):
+            for name, p in recipe.named_predicted(net):
+                out['%s/pred/%d/%s' % (case, b, name)] = p.detach().numpy()
+                q = p[:, 1:] if p.dim() == 3 else p            # Q3: skip the random class-token row
+                loss = loss + torch.norm(q, p='fro')
+        out[case + '/emb'] = emb.detach().numpy()
+        out[case + '/loss'] = np.asarray([loss.item()], dtype=np.float64)
+        loss.backward()
+        for k, p in ghn.named_parameters():
+            g = p.grad
+            assert g is not None, k
+            idx = recipe.sample_indices(g.numel(), 8, seed=len(k))
+            out['%s/grad/%s' % (case, k)] = np.concatenate(
+                [[g.norm().item(), g.sum().item()], g.reshape(-1)[idx].numpy()]).astype(np.float64)
+    np.savez_compressed(os.path.join(HERE, 'ghn3_tiny.npz'), **out)
+    print('ghn3_tiny.npz: %d arrays, GHN params %d' % (len(out), n_params))
+
+    # ---- tile / normalise case table, straight from the reference methods --------------------
+    tc = {}
+    rs = np.random.RandomState(99)
+    for i, (src, tgt) in enumerate(recipe.TILE_CASES):
+        w = rs.standard_normal(src).astype(np.float32)
+        torch.manual_seed(11)
+        t = ghn._tile_params(torch.from_numpy(w), tgt)
+        tc['%d/w' % i] = w
+        tc['%d/tiled' % i] = t.numpy()
+        for is_w in (0, 1):
+            tc['%d/norm%d' % (i, is_w)] = ghn._normalize(nn.Identity(), t, bool(is_w)).numpy()
+    np.savez_compressed(os.path.join(HERE, 'tile_cases.npz'), **tc)
+    print('tile_cases.npz: %d arrays' % len(tc))
+
+    # ---- structure pin: parameter counts of the four released variants ------------------------
+    counts = {}
+    for name, (hid, layers, heads) in recipe.VARIANTS.items():
+        if hid > 128:
+            # count without allocating: shapes follow from the tiny model's key set
+            counts[name] = recipe.count_params(hid, layers, heads, 1000)
+        else:
+            m = GHN3(max_shape=(hid, hid, 16, 16), num_classes=1000, hid=hid, heads=heads, layers=layers,
+                     weight_norm=True, ve=True, layernorm=True)
+            counts[name] = sum(p.numel() for p in m.parameters())
+            assert counts[name] == recipe.count_params(hid, layers, heads, 1000), name
+    print('variant parameter counts:', counts)
+    assert counts['ghn3xlm16'] == 654365184, counts     # examples/ghn_all_pytorch.ipynb:109
+
+
+if __name__ == '__main__':
+    torch.set_num_threads(4)
+    make_graphormer_goldens()
+    make_ghn3_goldens()

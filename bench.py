@@ -1,0 +1,206 @@
+#!/usr/bin/env python3
+"""
+bench.py -- predicted-params/sec of the GHN-3 hot path (GHN fwd+bwd) on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--model ghn3xlm16] [--nodes 256] [--compute f32]
+
+One "step" = one pass of the hot path over one batch of synthetic graphs per GPU:
+    GHN3 forward (Graphormer + decoders + tile/normalise -> all target-network weights)
+  + loss = sum_t ||p_t||_F over the predicted tensors (the reference's predparam_wd term, trainer.py:288-294)
+  + backward through the whole GHN (gradients of all GHN parameters in one flat fp32 buffer)
+  + for N > 1: mean all-reduce of that gradient buffer over RCCL/xGMI (the DDP exchange of trainer.py:136).
+Inputs (graph tensors, index tables, GHN weights) are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+MODELS = {  # name: (hid, layers, heads)
+    'ghn3tm8': (64, 3, 8), 'ghn3sm8': (128, 5, 16), 'ghn3lm8': (256, 12, 16), 'ghn3xlm16': (384, 24, 16)}
+PEAK_TFLOPS = {'f32': 157.3, 'f16': 2500.0, 'bf16': 2500.0}   # MI355X_MICROARCH.md: dense MFMA peaks
+
+
+def model_cfg(name):
+    hid, layers, heads = MODELS[name]
+    return dict(max_shape=(hid, hid, 16, 16), num_classes=1000, hid=hid, heads=heads, layers=layers,
+                weight_norm=True, ve=True, layernorm=True)
+
+
+def cpu_baseline(model, sample_nodes, seed):
+    """Oracle (CPU restatement of the reference algorithm incl. its per-group Python loops) timed on the host."""
+    from oracle import ghn3_ref as R
+    from ghn3_amd.synthetic import synthetic_batch
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    torch.manual_seed(0)
+    oracle = R.GHN3Ref(**model_cfg(model))
+    gb, nets = synthetic_batch([sample_nodes], seed)
+    go = R.GraphBatchRef([R.GraphRef(g.node_feat, g.node_info, g._Adj) for g in gb.graphs])
+    n_pred = sum(n.num_params() for n in nets)
+
+    def step():
+        oracle.zero_grad(set_to_none=True)
+        _, pred = oracle(nets, go, keep_grads=True)
+        loss = sum(torch.norm(t, p='fro') for (_, _, _, t) in pred)
+        loss.backward()
+    t0 = time.time()
+    step()
+    t1 = time.time() - t0
+    times = [t1]
+    if t1 < 10:
+        for _ in range(2):
+            t0 = time.time()
+            step()
+            times.append(time.time() - t0)
+    t = float(np.median(times))
+    return {'value': n_pred / t, 'unit': 'predicted-params/s', 'cores': cores, 'kind': 'port',
+            'sample': '%s fwd+bwd (sum of Frobenius norms loss), one synthetic %d-node graph (%d predicted params), '
+                      'fp32, torch %s CPU ops, %d threads, %.1f s per step'
+                      % (model, sample_nodes, n_pred, torch.__version__, cores, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--model', default='ghn3xlm16')
+    ap.add_argument('--nodes', type=int, default=256)
+    ap.add_argument('--graphs-per-gpu', type=int, default=1)
+    ap.add_argument('--compute', default=os.environ.get('GHN3_COMPUTE', 'f32'), choices=['f32', 'f16', 'bf16'])
+    ap.add_argument('--cpu-sample-nodes', type=int, default=32)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--profile-ops', action='store_true', help='print per-op-kind time of one extra step')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the GHN-3 path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    if world > 1:
+        dist.init_process_group('nccl', rank=rank, world_size=world)
+
+    from ghn3_amd import GHN3, _lib as L
+    from ghn3_amd.synthetic import synthetic_batch
+    from ghn3_amd.ddp_utils import all_reduce_flat_grads
+
+    torch.manual_seed(0)                                   # identical random-init GHN weights on every rank
+    ghn = GHN3(**model_cfg(args.model), compute=args.compute).to(dev)
+    ghn.train()
+    seeds = args.nodes * 1000 + rank * args.graphs_per_gpu
+    gb, nets = synthetic_batch([args.nodes] * args.graphs_per_gpu, seeds)
+    plan = ghn.compile(nets, gb, training=True)
+    prog = plan.program
+    n_pred = sum(p['numel'] for p in prog.predicted)
+    f_norm, b_norm = prog.norm_ops(1.0)
+    ctx = L.context(local_rank)
+    ctx.set_compute_type(args.compute)
+    stream = torch.cuda.current_stream().cuda_stream
+    dout = torch.empty(prog.out_numel, dtype=torch.float32, device=dev)
+
+    def step():
+        ghn._run_forward(plan)
+        ghn._fill_bufs(plan, out=plan.out, dout=dout)
+        ctx.run(f_norm, prog.problems, plan.bufs, stream)
+        ctx.run(b_norm, prog.problems, plan.bufs, stream)
+        ghn._run_backward(plan, dout)
+        if world > 1:
+            all_reduce_flat_grads(plan.gflat)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    ctx.profile(2)
+    ctx.profile_read_tags(reset=True)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    tags = ctx.profile_read_tags(reset=True)
+    ctx.profile(0)
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    n_all = torch.tensor([float(n_pred)], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t_all, op=dist.ReduceOp.MAX)
+        dist.all_reduce(n_all, op=dist.ReduceOp.SUM)
+    elapsed = float(t_all.item())
+    total_pred = float(n_all.item())
+
+    op_breakdown = None
+    if args.profile_ops and rank == 0:
+        ctx.profile(1)
+        ctx.profile_read(reset=True)
+        step()
+        torch.cuda.synchronize()
+        op_breakdown = ctx.profile_read(reset=True)
+        ctx.profile(0)
+
+    if rank == 0:
+        ms_per_step = 1e3 * elapsed / args.steps
+        # roofline of the dominant kernel family: the decoder W2 GEMM (forward, dgrad, wgrad).  Algorithmic
+        # FLOPs = 2*rows*8C*(o*i) per parameter group (only the W2 rows a group consumes), DESIGN.md 4.
+        dom = [prog.TAG_D3_FWD, prog.TAG_D3_DGRAD, prog.TAG_D3_WGRAD]
+        fl = sum(prog.tag_flops.get(t, 0.0) for t in dom)                   # per step
+        ms = sum(tags.get(t, (0.0, 0))[0] for t in dom) / args.steps        # per step
+        achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        peak = PEAK_TFLOPS[args.compute]
+        detail = {}
+        for t, (tms, cnt) in sorted(tags.items()):
+            name = prog.TAG_NAMES.get(t, str(t))
+            detail[name] = {'ms_per_step': round(tms / args.steps, 4), 'launch_groups_per_step': cnt // args.steps}
+            if t in prog.tag_flops and tms > 0:
+                detail[name]['tflops'] = round(prog.tag_flops[t] / (tms / args.steps * 1e-3) / 1e12, 2)
+        out = {
+            'metric': 'predicted-params/sec (GHN fwd+bwd), %s, %d-node graphs' % (args.model, args.nodes),
+            'value': total_pred * args.steps / elapsed,
+            'unit': 'predicted-params/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': ms_per_step,
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': args.compute, 'data': 'synthetic',
+            'config': {'workload': '%s fwd+bwd, %d synthetic %d-node graph(s) per GPU (seed %d+), %d predicted '
+                                   'params per GPU, loss = sum of Frobenius norms of the predicted tensors'
+                                   % (args.model, args.graphs_per_gpu, args.nodes, args.nodes * 1000, n_pred),
+                       'ghn_params': int(ghn._flat_numel), 'decoder_rows': int(prog.M),
+                       'parallelism': 'dp%d' % world, 'index_mode': ghn.index_mode},
+            'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
+                         'frac': achieved / peak, 'traffic': None,
+                         'kernel': 'decoder W2 grouped GEMM (fwd + dgrad + wgrad), %s MFMA operands' % args.compute,
+                         'algorithmic_gflop_per_step': fl / 1e9, 'kernel_ms_per_step': ms, 'kernels': detail},
+        }
+        if op_breakdown is not None:
+            out['op_breakdown_ms'] = {k: round(v[0], 3) for k, v in op_breakdown.items()}
+        if not args.no_cpu_baseline:
+            try:
+                out['cpu_baseline'] = cpu_baseline(args.model, args.cpu_sample_nodes, 32000)
+            except Exception as e:                                   # never lose the GPU line
+                out['cpu_baseline'] = {'value': None, 'error': repr(e)}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -1,0 +1,177 @@
+"""
+ctypes binding of libghn3_hip.so (include/ghn3_hip.h).  The library is the only compute path of this
+package: importing works anywhere (so that host logic can be tested on CPU), but every compute entry
+point raises if the shared object or a GPU is missing -- there is no CPU fallback.
+"""
+
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'lib', 'libghn3_hip.so')
+ABI_VERSION = 3
+
+# ---- numpy mirrors of the C structs -------------------------------------------------------------
+REF_DT = np.dtype([('buf', '<i4'), ('_pad', '<i4'), ('off', '<i8')])
+_REF_NAMES = ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather')
+_INT_NAMES = ('M', 'N', 'K', 'lda', 'ldb', 'ldc', 'a_mode', 'b_mode', 'a_q', 'a_s', 'b_q', 'b_s', 'c_q', 'c_s',
+              'bias_q', 'bias_s', 'bias_stride', 'act', 'dact', 'flags')
+PROBLEM_DT = np.dtype([(n, REF_DT) for n in _REF_NAMES] + [(n, '<i4') for n in _INT_NAMES] +
+                      [('alpha', '<f4'), ('_pad', '<i4')])
+TILE_DT = np.dtype([('dst_off', '<i8'), ('src_off', '<i8'), ('S', '<i8', 4), ('T', '<i4', 4), ('E', '<i4', 4),
+                    ('R', '<i4', 4), ('src_buf', '<i4'), ('mode', '<i4'), ('scale', '<f4'), ('_pad', '<i4')])
+OP_DT = np.dtype([('kind', '<i4'), ('flags', '<i4'), ('i', '<i8', 8), ('f', '<f4', 4), ('r', REF_DT, 14)])
+assert REF_DT.itemsize == 16 and PROBLEM_DT.itemsize == 248 and TILE_DT.itemsize == 112 and OP_DT.itemsize == 312
+
+MODE_ROW, MODE_COL = 0, 1
+ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
+DACT_NONE, DACT_RELU, DACT_GELU = 0, 1, 2
+GEMM_ACCUM = 1
+CT_F32, CT_F16, CT_BF16 = 0, 1, 2
+COMPUTE_TYPES = {'f32': CT_F32, 'f16': CT_F16, 'bf16': CT_BF16}
+
+(OP_NOP, OP_GEMM, OP_GRAPH_PROLOGUE, OP_EMBED_NODES, OP_EDGE_HIDDEN, OP_BIAS_GATHER, OP_LAYERNORM_FWD,
+ OP_ATTN_FWD, OP_TILE_FWD, OP_PARAM_NORM_FWD, OP_PARAM_NORM_BWD, OP_TILE_BWD, OP_COLSUM, OP_ROWSEG_SUM,
+ OP_LAYERNORM_BWD, OP_LN_PARAM_GRAD, OP_ATTN_BWD, OP_BIAS_HIST, OP_EDGE_HIDDEN_BWD, OP_EMBED_BWD, OP_MEMSET0,
+ OP_ADD, OP_KIND_COUNT) = range(23)
+OP_NAMES = ['nop', 'gemm', 'graph_prologue', 'embed_nodes', 'edge_hidden', 'bias_gather', 'layernorm_fwd',
+            'attn_fwd', 'tile_fwd', 'param_norm_fwd', 'param_norm_bwd', 'tile_bwd', 'colsum', 'rowseg_sum',
+            'layernorm_bwd', 'ln_param_grad', 'attn_bwd', 'bias_hist', 'edge_hidden_bwd', 'embed_bwd', 'memset0',
+            'add']
+
+EXPORTS = ['ghn3_abi_version', 'ghn3_last_error', 'ghn3_ctx_create', 'ghn3_ctx_destroy',
+           'ghn3_ctx_set_compute_type', 'ghn3_run', 'ghn3_event_create', 'ghn3_event_record',
+           'ghn3_event_elapsed_ms', 'ghn3_event_destroy', 'ghn3_profile_enable', 'ghn3_profile_read',
+           'ghn3_profile_read_tags']
+OPFLAG_TIMED = 0x100
+
+_lib = None
+_lock = threading.Lock()
+
+
+class Ghn3Error(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library (no GPU needed) and declare prototypes."""
+    global _lib
+    with _lock:
+        if _lib is not None:
+            return _lib
+        if not os.path.exists(LIB_PATH):
+            raise Ghn3Error('%s is missing: build it with `python -m ghn3_amd.build` (hipcc, gfx950). '
+                            'ghn3_amd has no CPU fallback.' % LIB_PATH)
+        lib = ctypes.CDLL(LIB_PATH)
+        lib.ghn3_abi_version.restype = ctypes.c_int
+        lib.ghn3_last_error.restype = ctypes.c_char_p
+        lib.ghn3_ctx_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        lib.ghn3_ctx_destroy.argtypes = [ctypes.c_void_p]
+        lib.ghn3_ctx_destroy.restype = None
+        lib.ghn3_ctx_set_compute_type.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.ghn3_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
+                                 ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+        lib.ghn3_event_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
+        lib.ghn3_event_record.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.ghn3_event_elapsed_ms.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+        lib.ghn3_event_destroy.argtypes = [ctypes.c_void_p]
+        lib.ghn3_profile_enable.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.ghn3_profile_read.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        lib.ghn3_profile_read_tags.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+        if lib.ghn3_abi_version() != ABI_VERSION:
+            raise Ghn3Error('libghn3_hip.so ABI %d != expected %d: rebuild' % (lib.ghn3_abi_version(), ABI_VERSION))
+        _lib = lib
+        return lib
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise Ghn3Error('%s failed (%d): %s' % (what, rc, load().ghn3_last_error().decode()))
+
+
+class Context:
+    """One per process and device (one process per GPU)."""
+
+    def __init__(self):
+        lib = load()
+        h = ctypes.c_void_p()
+        _check(lib.ghn3_ctx_create(ctypes.byref(h)), 'ghn3_ctx_create')
+        self._h = h
+        self._lib = lib
+
+    def set_compute_type(self, name):
+        _check(self._lib.ghn3_ctx_set_compute_type(self._h, COMPUTE_TYPES[name]), 'ghn3_ctx_set_compute_type')
+
+    def run(self, ops, problems, buf_ptrs, stream):
+        """ops: OP_DT array; problems: PROBLEM_DT array; buf_ptrs: uint64 array of device pointers."""
+        assert ops.dtype == OP_DT and problems.dtype == PROBLEM_DT and buf_ptrs.dtype == np.uint64
+        rc = self._lib.ghn3_run(self._h, ops.ctypes.data, len(ops),
+                                problems.ctypes.data if len(problems) else None, len(problems),
+                                buf_ptrs.ctypes.data, len(buf_ptrs), ctypes.c_void_p(stream))
+        _check(rc, 'ghn3_run')
+
+    def profile(self, mode):
+        """0 off, 1 every op (synchronising), 2 only ops flagged OPFLAG_TIMED (no sync until read_tags)."""
+        _check(self._lib.ghn3_profile_enable(self._h, int(mode)), 'ghn3_profile_enable')
+
+    def profile_read_tags(self, reset=True):
+        ms = np.zeros(256, dtype=np.float64)
+        n = np.zeros(256, dtype=np.int64)
+        _check(self._lib.ghn3_profile_read_tags(self._h, ms.ctypes.data, n.ctypes.data, int(reset)),
+               'ghn3_profile_read_tags')
+        return {k: (float(ms[k]), int(n[k])) for k in range(256) if n[k]}
+
+    def profile_read(self, reset=True):
+        ms = np.zeros(OP_KIND_COUNT, dtype=np.float64)
+        n = np.zeros(OP_KIND_COUNT, dtype=np.int64)
+        _check(self._lib.ghn3_profile_read(self._h, ms.ctypes.data, n.ctypes.data, int(reset)), 'ghn3_profile_read')
+        return {OP_NAMES[k]: (float(ms[k]), int(n[k])) for k in range(1, OP_KIND_COUNT) if n[k]}
+
+    def __del__(self):
+        try:
+            if self._h:
+                self._lib.ghn3_ctx_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+_ctx = {}
+
+
+def context(device_index=0):
+    import torch
+    if not torch.cuda.is_available():
+        raise Ghn3Error('ghn3_amd needs an MI355X (HIP device); no CPU fallback exists. '
+                        'Use oracle/ only as a test checker.')
+    if device_index not in _ctx:
+        with torch.cuda.device(device_index):
+            _ctx[device_index] = Context()
+    return _ctx[device_index]
+
+
+class Event:
+    """HIP event on an explicit stream (torch.cuda.Event only sees torch's current stream)."""
+
+    def __init__(self):
+        self._lib = load()
+        h = ctypes.c_void_p()
+        _check(self._lib.ghn3_event_create(ctypes.byref(h)), 'ghn3_event_create')
+        self._h = h
+
+    def record(self, stream):
+        _check(self._lib.ghn3_event_record(self._h, ctypes.c_void_p(stream)), 'ghn3_event_record')
+
+    def elapsed_ms(self, stop):
+        ms = ctypes.c_float()
+        _check(self._lib.ghn3_event_elapsed_ms(self._h, stop._h, ctypes.byref(ms)), 'ghn3_event_elapsed_ms')
+        return ms.value
+
+    def __del__(self):
+        try:
+            self._lib.ghn3_event_destroy(self._h)
+        except Exception:
+            pass

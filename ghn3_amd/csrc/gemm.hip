@@ -1,0 +1,501 @@
+// Grouped MFMA GEMM for gfx950 (MI355X).  See include/ghn3_hip.h for the operand / epilogue contract.
+//
+// Replaces every F.linear / nn.Linear on the GHN-3 path (ghn3/graphormer.py:38-44,97-99,121,141;
+// ghn3/nn.py:283-299,738-758) and their autograd backward (dgrad / wgrad), including the row-subset
+// decoder GEMMs that only touch the W2 / Wfc rows a parameter group consumes.
+//
+// Structure (both compute types): 256 threads = 4 waves (2 x 2), block tile BM x BN, each wave owns
+// (BM/2) x (BN/2) as a grid of 32 x 32 MFMA tiles accumulated in fp32.  Operands stay fp32 in HBM; tiles
+// are staged global -> registers -> LDS (double buffered, one barrier per K-tile) so that the gather /
+// strided addressing and the optional fp32 -> f16/bf16 conversion happen in the staging pass.
+//   * F32 : v_mfma_f32_32x32x2_f32, exact fp32 (157 TF peak)            -- parity mode, BK = 32
+//   * F16 / BF16 : v_mfma_f32_32x32x16_{f16,bf16} (2.5 PF peak)         -- throughput mode, BK = 64
+// LDS images: ROW-mode operand  [rows][BK + pad]  (pad 1 float / 8 halfs -> conflict-free fragment reads)
+//             COL-mode operand  f32: [BK][rows + 4] ; 16-bit: register-transposed into [rows][BK + 8].
+
+#include "ghn3_internal.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+#define ROWM GHN3_MODE_ROW
+#define COLM GHN3_MODE_COL
+
+__device__ __forceinline__ int map_row(int r, const int* gather, int q, int s) {
+    if (gather) r = gather[r];
+    if (q > 0) r = (r / q) * s + (r % q);
+    return r;
+}
+
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
+}
+
+__device__ __forceinline__ const GemmProbDev* find_problem(const GemmProbDev* probs, int n_probs, int bid) {
+    int lo = 0, hi = n_probs - 1;
+    while (lo < hi) {
+        int mid = (lo + hi + 1) >> 1;
+        if (probs[mid].tile_start <= bid) lo = mid; else hi = mid - 1;
+    }
+    return probs + lo;
+}
+
+// Epilogue shared by all variants.  acc tile layout (32x32 MFMA C/D): col = lane & 31,
+// row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(const GemmProbDev* P, f32x16 (&acc)[TM][TN], int m_base, int n_base, int lane) {
+    const int M = P->M, N = P->N, ldc = P->ldc;
+    float* __restrict__ C = P->C;
+    const float* __restrict__ bias = P->bias;
+    const float* __restrict__ residual = P->residual;
+    const float* __restrict__ aux_in = P->aux_in;
+    float* __restrict__ aux_out = P->aux_out;
+    const int* cg = P->c_gather;
+    const int cq = P->c_q, cs = P->c_s;
+    const int act = P->act, dact = P->dact;
+    const bool accum = (P->flags & GHN3_GEMM_ACCUM) != 0;
+    const float alpha = P->alpha;
+    const int l31 = lane & 31, lhi = lane >> 5;
+#pragma unroll
+    for (int tn = 0; tn < TN; ++tn) {
+        const int col = n_base + tn * 32 + l31;
+        const bool col_ok = col < N;
+        float bv = 0.f;
+        if (bias && col_ok) {
+            int bi = col;
+            if (P->bias_q > 0) bi = (col / P->bias_q) * P->bias_s + (col % P->bias_q);
+            bv = bias[(int64_t)bi * P->bias_stride];
+        }
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+                if (row < M && col_ok) {
+                    const int64_t ci = (int64_t)map_row(row, cg, cq, cs) * ldc + col;
+                    float v = acc[tm][tn][r] * alpha + bv;
+                    if (aux_out) aux_out[ci] = v;
+                    if (act == GHN3_ACT_RELU) v = fmaxf(v, 0.f);
+                    else if (act == GHN3_ACT_GELU) v = gelu_f(v);
+                    if (dact == GHN3_DACT_RELU) v = (aux_in[ci] > 0.f) ? v : 0.f;
+                    else if (dact == GHN3_DACT_GELU) v *= gelu_grad_f(aux_in[ci]);
+                    if (residual) v += residual[ci];
+                    if (accum) v += C[ci];
+                    C[ci] = v;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 operands: v_mfma_f32_32x32x2_f32
+// ------------------------------------------------------------------------------------------------
+template <int ROWS, int MODE> struct F32Tile {
+    static constexpr int BK = 32;
+    static constexpr int LD = (MODE == ROWM) ? (BK + 1) : (ROWS + 4);
+    static constexpr int SIZE = (MODE == ROWM) ? ROWS * (BK + 1) : BK * (ROWS + 4);
+    static constexpr int NV = ROWS / 32;                 // float4 per thread per K-tile
+    static constexpr int F4_PER_ROW = ROWS / 4;          // COL mode
+    static constexpr int RPP = 256 / F4_PER_ROW;         // COL mode: k rows per pass
+};
+
+template <int ROWS, int MODE>
+struct F32Loader {
+    using T = F32Tile<ROWS, MODE>;
+    const float* base; const int* gather; int q, s, ld;
+    int lim_rows, lim_k;          // logical extents (rows = M or N ; k = K)
+    int r0;                       // tile origin along rows
+    // ROW mode state
+    const float* ptr[T::NV]; bool ok[T::NV]; int kc, rr;
+    // COL mode state
+    int mc, kr; bool ok_m;
+
+    __device__ __forceinline__ void init(const float* b, const int* g, int q_, int s_, int ld_, int rows, int K,
+                                         int origin, int tid) {
+        base = b; gather = g; q = q_; s = s_; ld = ld_; lim_rows = rows; lim_k = K; r0 = origin;
+        if (MODE == ROWM) {
+            kc = tid & 7; rr = tid >> 3;
+#pragma unroll
+            for (int i = 0; i < T::NV; ++i) {
+                int m = r0 + rr + 32 * i;
+                ok[i] = m < lim_rows;
+                int r = map_row(ok[i] ? m : 0, gather, q, s);
+                ptr[i] = base + (int64_t)r * ld + kc * 4;
+            }
+        } else {
+            mc = tid % T::F4_PER_ROW; kr = tid / T::F4_PER_ROW;
+            ok_m = (r0 + mc * 4) < lim_rows;
+        }
+    }
+    __device__ __forceinline__ void load(int kt, float4 (&v)[T::NV]) const {
+        if (MODE == ROWM) {
+            const int k = kt * T::BK + kc * 4;
+#pragma unroll
+            for (int i = 0; i < T::NV; ++i) {
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok[i] && k < lim_k) {
+                    x = *reinterpret_cast<const float4*>(ptr[i] + kt * T::BK);
+                    if (k + 1 >= lim_k) x.y = 0.f;
+                    if (k + 2 >= lim_k) x.z = 0.f;
+                    if (k + 3 >= lim_k) x.w = 0.f;
+                }
+                v[i] = x;
+            }
+        } else {
+            const int m = r0 + mc * 4;
+#pragma unroll
+            for (int i = 0; i < T::NV; ++i) {
+                const int k = kt * T::BK + kr + T::RPP * i;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok_m && k < lim_k) {
+                    const int r = map_row(k, gather, q, s);
+                    x = *reinterpret_cast<const float4*>(base + (int64_t)r * ld + m);
+                    if (m + 1 >= lim_rows) x.y = 0.f;
+                    if (m + 2 >= lim_rows) x.z = 0.f;
+                    if (m + 3 >= lim_rows) x.w = 0.f;
+                }
+                v[i] = x;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(float* lds, const float4 (&v)[T::NV]) const {
+        if (MODE == ROWM) {
+#pragma unroll
+            for (int i = 0; i < T::NV; ++i) {
+                float* p = lds + (rr + 32 * i) * T::LD + kc * 4;
+                p[0] = v[i].x; p[1] = v[i].y; p[2] = v[i].z; p[3] = v[i].w;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < T::NV; ++i)
+                *reinterpret_cast<float4*>(lds + (kr + T::RPP * i) * T::LD + mc * 4) = v[i];
+        }
+    }
+};
+
+template <int BM, int BN, int AM, int BMD>
+__global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
+    using TA = F32Tile<BM, AM>;
+    using TB = F32Tile<BN, BMD>;
+    constexpr int BK = 32;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr int STAGE = TA::SIZE + TB::SIZE;
+
+    const GemmProbDev* P = find_problem(probs, n_probs, blockIdx.x);
+    const int t = blockIdx.x - P->tile_start;
+    const int m0 = (t % P->tiles_m) * BM, n0 = (t / P->tiles_m) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int K = P->K;
+
+    F32Loader<BM, AM> la; F32Loader<BN, BMD> lb;
+    la.init(P->A, P->a_gather, P->a_q, P->a_s, P->lda, P->M, K, m0, tid);
+    lb.init(P->B, P->b_gather, P->b_q, P->b_s, P->ldb, P->N, K, n0, tid);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (K + BK - 1) / BK;
+    float4 ra[TA::NV], rb[TB::NV];
+    la.load(0, ra); lb.load(0, rb);
+    la.store(smem, ra); lb.store(smem + TA::SIZE, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1) < nk;
+        if (more) { la.load(kt + 1, ra); lb.load(kt + 1, rb); }
+        const float* a_s = smem + cur * STAGE;
+        const float* b_s = a_s + TA::SIZE;
+#pragma unroll 4
+        for (int kk = 0; kk < BK; kk += 2) {
+            float af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = (AM == ROWM) ? a_s[(wm0 + i * 32 + l31) * TA::LD + kk + lhi]
+                                     : a_s[(kk + lhi) * TA::LD + wm0 + i * 32 + l31];
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = (BMD == ROWM) ? b_s[(wn0 + j * 32 + l31) * TB::LD + kk + lhi]
+                                      : b_s[(kk + lhi) * TB::LD + wn0 + j * 32 + l31];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) {
+            float* nx = smem + (cur ^ 1) * STAGE;
+            la.store(nx, ra); lb.store(nx + TA::SIZE, rb);
+        }
+        __syncthreads();
+    }
+    epilogue<TM, TN>(P, acc, m0 + wm0, n0 + wn0, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 16-bit operands (converted from fp32 while staging): v_mfma_f32_32x32x16_{f16,bf16}
+// LDS image for both modes: [rows][BK + 8] 16-bit elements (BK = 64).
+// Fragment: lane l holds 8 consecutive k at k = kk + (l >> 5) * 8 for row (l & 31).
+// ------------------------------------------------------------------------------------------------
+template <int CT> __device__ __forceinline__ unsigned short cvt16(float x);
+template <> __device__ __forceinline__ unsigned short cvt16<GHN3_CT_F16>(float x) {
+    _Float16 h = (_Float16)x;
+    return __builtin_bit_cast(unsigned short, h);
+}
+template <> __device__ __forceinline__ unsigned short cvt16<GHN3_CT_BF16>(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    u += 0x7fffu + ((u >> 16) & 1u);          // round to nearest even (inputs are finite)
+    return (unsigned short)(u >> 16);
+}
+
+template <int ROWS, int MODE, int CT>
+struct H16Loader {
+    static constexpr int BK = 64;
+    static constexpr int LD = BK + 8;                     // in 16-bit elements (144 B rows)
+    static constexpr int SIZE = ROWS * LD;                // 16-bit elements
+    // ROW: thread -> (row = tid/8 + 32 i, 8 k at kc*8), i < ROWS/32, 2 float4 each
+    // COL: thread -> micro tile 4 rows x 8 k: kg = tid & 7, mg = tid >> 3 (mg < ROWS/4), 8 float4
+    static constexpr int NV = (MODE == ROWM) ? (ROWS / 32) * 2 : 8;
+    const float* base; const int* gather; int q, s, ld, lim_rows, lim_k, r0;
+    const float* ptr[ROWS / 32]; bool ok[ROWS / 32]; int kc, rr;
+    int kg, mg; bool ok_m, active;
+
+    __device__ __forceinline__ void init(const float* b, const int* g, int q_, int s_, int ld_, int rows, int K,
+                                         int origin, int tid) {
+        base = b; gather = g; q = q_; s = s_; ld = ld_; lim_rows = rows; lim_k = K; r0 = origin;
+        if (MODE == ROWM) {
+            kc = tid & 7; rr = tid >> 3;
+#pragma unroll
+            for (int i = 0; i < ROWS / 32; ++i) {
+                int m = r0 + rr + 32 * i;
+                ok[i] = m < lim_rows;
+                int r = map_row(ok[i] ? m : 0, gather, q, s);
+                ptr[i] = base + (int64_t)r * ld + kc * 8;
+            }
+        } else {
+            kg = tid & 7; mg = tid >> 3;
+            active = mg < ROWS / 4;
+            ok_m = active && (r0 + mg * 4) < lim_rows;
+        }
+    }
+    __device__ __forceinline__ void load(int kt, float4 (&v)[NV]) const {
+        if (MODE == ROWM) {
+            const int k = kt * BK + kc * 8;
+#pragma unroll
+            for (int i = 0; i < ROWS / 32; ++i) {
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                    const int kh = k + 4 * h;
+                    if (ok[i] && kh < lim_k) {
+                        x = *reinterpret_cast<const float4*>(ptr[i] + kt * BK + 4 * h);
+                        if (kh + 1 >= lim_k) x.y = 0.f;
+                        if (kh + 2 >= lim_k) x.z = 0.f;
+                        if (kh + 3 >= lim_k) x.w = 0.f;
+                    }
+                    v[i * 2 + h] = x;
+                }
+            }
+        } else {
+            const int m = r0 + mg * 4;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int k = kt * BK + kg * 8 + j;
+                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (ok_m && k < lim_k) {
+                    const int r = map_row(k, gather, q, s);
+                    x = *reinterpret_cast<const float4*>(base + (int64_t)r * ld + m);
+                    if (m + 1 >= lim_rows) x.y = 0.f;
+                    if (m + 2 >= lim_rows) x.z = 0.f;
+                    if (m + 3 >= lim_rows) x.w = 0.f;
+                }
+                v[j] = x;
+            }
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short* lds, const float4 (&v)[NV]) const {
+        if (MODE == ROWM) {
+#pragma unroll
+            for (int i = 0; i < ROWS / 32; ++i) {
+                u16x8 h;
+                h[0] = cvt16<CT>(v[2 * i].x); h[1] = cvt16<CT>(v[2 * i].y);
+                h[2] = cvt16<CT>(v[2 * i].z); h[3] = cvt16<CT>(v[2 * i].w);
+                h[4] = cvt16<CT>(v[2 * i + 1].x); h[5] = cvt16<CT>(v[2 * i + 1].y);
+                h[6] = cvt16<CT>(v[2 * i + 1].z); h[7] = cvt16<CT>(v[2 * i + 1].w);
+                *reinterpret_cast<u16x8*>(lds + (rr + 32 * i) * LD + kc * 8) = h;
+            }
+        } else if (active) {
+            u16x8 h0, h1, h2, h3;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                h0[j] = cvt16<CT>(v[j].x); h1[j] = cvt16<CT>(v[j].y);
+                h2[j] = cvt16<CT>(v[j].z); h3[j] = cvt16<CT>(v[j].w);
+            }
+            unsigned short* p = lds + (mg * 4) * LD + kg * 8;
+            *reinterpret_cast<u16x8*>(p) = h0;
+            *reinterpret_cast<u16x8*>(p + LD) = h1;
+            *reinterpret_cast<u16x8*>(p + 2 * LD) = h2;
+            *reinterpret_cast<u16x8*>(p + 3 * LD) = h3;
+        }
+    }
+};
+
+template <int CT>
+__device__ __forceinline__ f32x16 mfma16(u16x8 a, u16x8 b, f32x16 c) {
+    if (CT == GHN3_CT_F16)
+        return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int BM, int BN, int AM, int BMD, int CT>
+__global__ __launch_bounds__(256) void gemm_h16_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
+    using LA = H16Loader<BM, AM, CT>;
+    using LB = H16Loader<BN, BMD, CT>;
+    constexpr int BK = 64, LD = LA::LD;
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    unsigned short* sm16 = reinterpret_cast<unsigned short*>(smem);
+    constexpr int STAGE = LA::SIZE + LB::SIZE;
+
+    const GemmProbDev* P = find_problem(probs, n_probs, blockIdx.x);
+    const int t = blockIdx.x - P->tile_start;
+    const int m0 = (t % P->tiles_m) * BM, n0 = (t / P->tiles_m) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int K = P->K;
+
+    LA la; LB lb;
+    la.init(P->A, P->a_gather, P->a_q, P->a_s, P->lda, P->M, K, m0, tid);
+    lb.init(P->B, P->b_gather, P->b_q, P->b_s, P->ldb, P->N, K, n0, tid);
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nk = (K + BK - 1) / BK;
+    float4 ra[LA::NV], rb[LB::NV];
+    la.load(0, ra); lb.load(0, rb);
+    la.store(sm16, ra); lb.store(sm16 + LA::SIZE, rb);
+    __syncthreads();
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1) < nk;
+        if (more) { la.load(kt + 1, ra); lb.load(kt + 1, rb); }
+        const unsigned short* a_s = sm16 + cur * STAGE;
+        const unsigned short* b_s = a_s + LA::SIZE;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            u16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const u16x8*>(a_s + (wm0 + i * 32 + l31) * LD + kk + lhi * 8);
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const u16x8*>(b_s + (wn0 + j * 32 + l31) * LD + kk + lhi * 8);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = mfma16<CT>(af[i], bf[j], acc[i][j]);
+        }
+        if (more) {
+            unsigned short* nx = sm16 + (cur ^ 1) * STAGE;
+            la.store(nx, ra); lb.store(nx + LA::SIZE, rb);
+        }
+        __syncthreads();
+    }
+    epilogue<TM, TN>(P, acc, m0 + wm0, n0 + wn0, lane);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+typedef void (*gemm_fn)(const GemmProbDev*, int);
+
+template <int BM, int BN, int AM, int BMD> static size_t f32_lds() {
+    return 2 * (size_t)(F32Tile<BM, AM>::SIZE + F32Tile<BN, BMD>::SIZE) * sizeof(float);
+}
+template <int BM, int BN> static size_t h16_lds() {
+    return 2 * (size_t)(BM + BN) * (64 + 8) * sizeof(unsigned short);
+}
+
+struct GemmVariant { gemm_fn fn; size_t lds; };
+
+template <int BM, int BN, int AM, int BMD> static GemmVariant f32_variant() {
+    return GemmVariant{(gemm_fn)gemm_f32_kernel<BM, BN, AM, BMD>, f32_lds<BM, BN, AM, BMD>()};
+}
+template <int BM, int BN, int AM, int BMD, int CT> static GemmVariant h16_variant() {
+    return GemmVariant{(gemm_fn)gemm_h16_kernel<BM, BN, AM, BMD, CT>, h16_lds<BM, BN>()};
+}
+
+// [ctype][tile(0:64,1:128)][a_mode][b_mode]
+static GemmVariant g_variants[3][2][2][2];
+static bool g_gemm_ready = false;
+
+#define FILL_F32(T, TI)                                              \
+    g_variants[GHN3_CT_F32][TI][0][0] = f32_variant<T, T, ROWM, ROWM>(); \
+    g_variants[GHN3_CT_F32][TI][0][1] = f32_variant<T, T, ROWM, COLM>(); \
+    g_variants[GHN3_CT_F32][TI][1][0] = f32_variant<T, T, COLM, ROWM>(); \
+    g_variants[GHN3_CT_F32][TI][1][1] = f32_variant<T, T, COLM, COLM>();
+#define FILL_H16(T, TI, CT)                                              \
+    g_variants[CT][TI][0][0] = h16_variant<T, T, ROWM, ROWM, CT>(); \
+    g_variants[CT][TI][0][1] = h16_variant<T, T, ROWM, COLM, CT>(); \
+    g_variants[CT][TI][1][0] = h16_variant<T, T, COLM, ROWM, CT>(); \
+    g_variants[CT][TI][1][1] = h16_variant<T, T, COLM, COLM, CT>();
+
+int ghn3_gemm_init() {
+    if (g_gemm_ready) return GHN3_OK;
+    FILL_F32(64, 0)
+    FILL_F32(128, 1)
+    FILL_H16(64, 0, GHN3_CT_F16)
+    FILL_H16(128, 1, GHN3_CT_F16)
+    FILL_H16(64, 0, GHN3_CT_BF16)
+    FILL_H16(128, 1, GHN3_CT_BF16)
+    for (int c = 0; c < 3; ++c)
+        for (int t = 0; t < 2; ++t)
+            for (int a = 0; a < 2; ++a)
+                for (int b = 0; b < 2; ++b) {
+                    GemmVariant& v = g_variants[c][t][a][b];
+                    if (v.lds > 48 * 1024) {
+                        hipError_t e = hipFuncSetAttribute((const void*)v.fn,
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)v.lds);
+                        if (e != hipSuccess) {
+                            ghn3_set_error("hipFuncSetAttribute(gemm lds=%zu): %s", v.lds, hipGetErrorString(e));
+                            return GHN3_E_HIP;
+                        }
+                    }
+                }
+    g_gemm_ready = true;
+    return GHN3_OK;
+}
+
+int ghn3_gemm_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode, int tile,
+                     int ctype, hipStream_t stream) {
+    if (n_probs <= 0 || total_tiles <= 0) return GHN3_OK;
+    if (ctype < 0 || ctype > 2 || (tile != 64 && tile != 128)) {
+        ghn3_set_error("gemm: bad ctype/tile %d/%d", ctype, tile);
+        return GHN3_E_ARG;
+    }
+    const GemmVariant& v = g_variants[ctype][tile == 128][a_mode][b_mode];
+    hipLaunchKernelGGL(v.fn, dim3(total_tiles), dim3(256), v.lds, stream, d_probs, n_probs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ghn3_set_error("gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
+    return GHN3_OK;
+}

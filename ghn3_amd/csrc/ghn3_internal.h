@@ -1,0 +1,68 @@
+// Internal declarations shared by the HIP translation units of libghn3_hip.so (not part of the ABI).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "ghn3_hip.h"
+
+// Resolved GEMM problem (absolute device pointers); lives in device memory for the launch.
+struct GemmProbDev {
+    const float* A; const float* B; float* C;
+    const float* bias; const float* residual; const float* aux_in; float* aux_out;
+    const int* a_gather; const int* b_gather; const int* c_gather;
+    int M, N, K, lda, ldb, ldc;
+    int a_q, a_s, b_q, b_s, c_q, c_s;
+    int bias_q, bias_s, bias_stride;
+    int act, dact, flags;
+    float alpha;
+    int tile_start;      // first tile id of this problem inside its launch
+    int tiles_m;         // number of tiles along M
+    int _pad;
+};
+
+
+int ghn3_gemm_init();
+// launches one grouped GEMM: all problems share (a_mode, b_mode, tile).  d_probs is device memory.
+int ghn3_gemm_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode,
+                     int tile, int ctype, hipStream_t stream);
+
+int ghn3_attn_init();
+int ghn3_attn_fwd(float* out, const float* qkv, const float* bias, float* P, const int* n_nodes,
+                  int B, int N, int C, int H, hipStream_t s);
+int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P, const float* O, float* dS,
+                  float* dBias, const int* n_nodes, int B, int N, int C, int H, hipStream_t s);
+
+int ghn3_graph_prologue(const int64_t* A, int* deg_in, int* deg_out, int* dist0, int* pair,
+                        int B, int N, int V, hipStream_t s);
+int ghn3_embed_nodes(float* x, const int* node_type, const int* shape_idx, const int* n_nodes, const int* node_off,
+                     const float* E_type, const float* E_ch, const float* E_sp, const float* E_in,
+                     const float* E_out, const float* E_dist, const int* deg_in, const int* deg_out,
+                     const int* dist0, int B, int N, int C, hipStream_t s);
+int ghn3_embed_bwd(const float* dx, const int* node_type, const int* shape_idx, const int* n_nodes,
+                   const int* node_off, float* dE_type, float* dE_ch, float* dE_sp, float* dE_in, float* dE_out,
+                   float* dE_dist, const int* deg_in, const int* deg_out, const int* dist0,
+                   int B, int N, int C, hipStream_t s);
+int ghn3_edge_hidden(float* hid, const float* Pfw, const float* Pbw, int V, int C, hipStream_t s);
+int ghn3_edge_hidden_bwd(float* dPfw, float* dPbw, float* dhid, const float* hid, int V, int C, hipStream_t s);
+int ghn3_bias_gather(float* bias, const float* T, const int* pair, int B, int N, int H, hipStream_t s);
+int ghn3_bias_hist(float* dT, const float* dBias, const int* pair, int B, int N, int H, int V, hipStream_t s);
+int ghn3_layernorm_fwd(float* y, const float* x, const float* g, const float* b, float* mean, float* rstd,
+                       int rows, int C, float eps, hipStream_t s);
+int ghn3_layernorm_bwd(float* dx, const float* dy, const float* x, const float* g, const float* mean,
+                       const float* rstd, const float* res, int rows, int C, hipStream_t s);
+int ghn3_ln_param_grad(float* dg, float* db, const float* dy, const float* x, const float* mean,
+                       const float* rstd, int rows, int C, int accum, hipStream_t s);
+int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d_desc, int n_desc,
+                  int64_t total, const int64_t* blocks, hipStream_t s);
+int ghn3_tile_bwd(const float* dflat, const float* const* srcs, float* const* dsrcs,
+                  const ghn3_tile_desc* d_desc, int n_desc, int64_t total, const int64_t* blocks, hipStream_t s);
+int ghn3_param_norm_fwd(float* loss, const float* flat, const int64_t* seg_off, float* norms, int n_seg,
+                        hipStream_t s);
+int ghn3_param_norm_bwd(float* dflat, const float* flat, const int64_t* seg_off, const float* norms, int n_seg,
+                        float g, hipStream_t s);
+int ghn3_colsum(float* out, const float* X, int M, int N, int ld, int q, int sdim, int stride, int accum,
+                const int* gather, hipStream_t s);
+int ghn3_rowseg_sum(float* out, const float* X, const int* seg_ptr, const int* idx, int rows, int C, int ldx,
+                    int ldo, int accum, hipStream_t s);
+int ghn3_add(float* dst, const float* src, int64_t n, hipStream_t s);
+
+void ghn3_set_error(const char* fmt, ...);

@@ -1,0 +1,419 @@
+// libghn3_hip.so runtime: context, program executor (ghn3_run), GEMM problem staging, timing helpers.
+// The executor is the MI355X-native replacement for the Python/ATen dispatch of GHN3.forward
+// (ghn3/nn.py:247-328): one host call launches the whole forward (or backward) as a fixed kernel sequence
+// on one HIP stream, with no device synchronisation and no allocation.
+
+#include "ghn3_internal.h"
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+#include <algorithm>
+
+static thread_local char g_err[512] = "";
+
+void ghn3_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" const char* ghn3_last_error(void) { return g_err; }
+extern "C" int ghn3_abi_version(void) { return GHN3_ABI_VERSION; }
+
+#define HIPCHK(expr)                                                                  \
+    do {                                                                              \
+        hipError_t e_ = (expr);                                                       \
+        if (e_ != hipSuccess) {                                                       \
+            ghn3_set_error("%s failed: %s", #expr, hipGetErrorString(e_));            \
+            return GHN3_E_HIP;                                                        \
+        }                                                                             \
+    } while (0)
+
+static const int kStageSlots = 4;
+
+struct ghn3_ctx {
+    // ring of staging slots for resolved GEMM problem tables
+    GemmProbDev* h_stage[kStageSlots];
+    GemmProbDev* d_stage[kStageSlots];
+    hipEvent_t ev[kStageSlots];
+    bool ev_used[kStageSlots];
+    size_t cap;            // problems per slot
+    int next;
+    int ctype;             // compute type for GEMM operands
+    // profiling: 0 off, 1 = every op bracketed + synchronised (diagnostic), 2 = only ops carrying
+    // GHN3_OPFLAG_TIMED get an event pair from a pool, no synchronisation until ghn3_profile_read
+    int profile;
+    double ms[GHN3_OP_KIND_COUNT];
+    int64_t launches[GHN3_OP_KIND_COUNT];
+    hipEvent_t pe0, pe1;
+    std::vector<hipEvent_t>* pool;     // pairs
+    std::vector<int>* pool_tag;
+    size_t pool_used;                  // pairs in use
+    double tag_ms[256];
+    int64_t tag_n[256];
+};
+
+static int ctx_reserve(ghn3_ctx* c, size_t n) {
+    if (n <= c->cap) return GHN3_OK;
+    size_t cap = std::max<size_t>(n, 1024);
+    for (int i = 0; i < kStageSlots; ++i) {
+        if (c->ev_used[i]) { HIPCHK(hipEventSynchronize(c->ev[i])); c->ev_used[i] = false; }
+        if (c->h_stage[i]) HIPCHK(hipHostFree(c->h_stage[i]));
+        if (c->d_stage[i]) HIPCHK(hipFree(c->d_stage[i]));
+        c->h_stage[i] = nullptr; c->d_stage[i] = nullptr;
+        HIPCHK(hipHostMalloc((void**)&c->h_stage[i], cap * sizeof(GemmProbDev), hipHostMallocDefault));
+        HIPCHK(hipMalloc((void**)&c->d_stage[i], cap * sizeof(GemmProbDev)));
+    }
+    c->cap = cap;
+    return GHN3_OK;
+}
+
+extern "C" int ghn3_ctx_create(ghn3_ctx** out) {
+    if (!out) return GHN3_E_ARG;
+    int ndev = 0;
+    HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) { ghn3_set_error("no HIP device"); return GHN3_E_HIP; }
+    ghn3_ctx* c = new ghn3_ctx();
+    memset(c, 0, sizeof(*c));
+    c->pool = new std::vector<hipEvent_t>();
+    c->pool_tag = new std::vector<int>();
+    for (int i = 0; i < kStageSlots; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+    HIPCHK(hipEventCreate(&c->pe0));
+    HIPCHK(hipEventCreate(&c->pe1));
+    int rc = ghn3_gemm_init();
+    if (rc) return rc;
+    rc = ghn3_attn_init();
+    if (rc) return rc;
+    rc = ctx_reserve(c, 1024);
+    if (rc) return rc;
+    *out = c;
+    return GHN3_OK;
+}
+
+extern "C" void ghn3_ctx_destroy(ghn3_ctx* c) {
+    if (!c) return;
+    for (int i = 0; i < kStageSlots; ++i) {
+        if (c->ev_used[i]) hipEventSynchronize(c->ev[i]);
+        if (c->h_stage[i]) hipHostFree(c->h_stage[i]);
+        if (c->d_stage[i]) hipFree(c->d_stage[i]);
+        hipEventDestroy(c->ev[i]);
+    }
+    hipEventDestroy(c->pe0);
+    hipEventDestroy(c->pe1);
+    for (hipEvent_t e : *c->pool) hipEventDestroy(e);
+    delete c->pool;
+    delete c->pool_tag;
+    delete c;
+}
+
+extern "C" int ghn3_ctx_set_compute_type(ghn3_ctx* c, int ctype) {
+    if (!c) return GHN3_E_NOCTX;
+    if (ctype < 0 || ctype > 2) { ghn3_set_error("bad compute type %d", ctype); return GHN3_E_ARG; }
+    c->ctype = ctype;
+    return GHN3_OK;
+}
+
+extern "C" int ghn3_profile_enable(ghn3_ctx* c, int mode) {
+    if (!c) return GHN3_E_NOCTX;
+    c->profile = mode;
+    return GHN3_OK;
+}
+static int drain_pool(ghn3_ctx* c) {
+    for (size_t k = 0; k < c->pool_used; ++k) {
+        hipEvent_t e0 = (*c->pool)[2 * k], e1 = (*c->pool)[2 * k + 1];
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        const int tag = (*c->pool_tag)[k] & 255;
+        c->tag_ms[tag] += ms;
+        c->tag_n[tag] += 1;
+    }
+    c->pool_used = 0;
+    return GHN3_OK;
+}
+extern "C" int ghn3_profile_read(ghn3_ctx* c, double* ms, int64_t* launches, int reset) {
+    if (!c) return GHN3_E_NOCTX;
+    for (int i = 0; i < GHN3_OP_KIND_COUNT; ++i) {
+        if (ms) ms[i] = c->ms[i];
+        if (launches) launches[i] = c->launches[i];
+        if (reset) { c->ms[i] = 0; c->launches[i] = 0; }
+    }
+    return GHN3_OK;
+}
+extern "C" int ghn3_profile_read_tags(ghn3_ctx* c, double* ms256, int64_t* n256, int reset) {
+    if (!c) return GHN3_E_NOCTX;
+    int rc = drain_pool(c);
+    if (rc) return rc;
+    for (int i = 0; i < 256; ++i) {
+        if (ms256) ms256[i] = c->tag_ms[i];
+        if (n256) n256[i] = c->tag_n[i];
+        if (reset) { c->tag_ms[i] = 0; c->tag_n[i] = 0; }
+    }
+    return GHN3_OK;
+}
+
+// ---- reference resolution -----------------------------------------------------------------------
+struct Resolver {
+    void* const* bufs; int n_bufs; bool bad;
+    template <typename T> T* get(const ghn3_ref& r) {
+        if (r.buf < 0) return nullptr;
+        if (r.buf >= n_bufs || bufs[r.buf] == nullptr) { bad = true; return nullptr; }
+        return reinterpret_cast<T*>(reinterpret_cast<char*>(bufs[r.buf]) + r.off);
+    }
+};
+
+static int pick_tile(const ghn3_gemm_problem& p, int forced) {
+    if (forced == 64 || forced == 128) return forced;
+    const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (p.M >= 96 && p.N >= 96 && t128 >= 192) return 128;
+    return 64;
+}
+
+struct Launch { int a_mode, b_mode, tile, first, count, tiles; };
+
+extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_gemm_problem* problems, int n_problems,
+                        void* const* bufs, int n_bufs, void* stream_) {
+    if (!c) return GHN3_E_NOCTX;
+    if (n_ops < 0 || (n_ops > 0 && !ops) || n_bufs < 0) { ghn3_set_error("ghn3_run: bad arguments"); return GHN3_E_ARG; }
+    hipStream_t stream = (hipStream_t)stream_;
+    Resolver R{bufs, n_bufs, false};
+
+    // ---- 1. resolve every GEMM op into launch groups inside one staging slot --------------------
+    std::vector<std::vector<Launch>> op_launches(n_ops);
+    size_t need = 0;
+    for (int k = 0; k < n_ops; ++k)
+        if (ops[k].kind == GHN3_OP_GEMM) need += (size_t)ops[k].i[1];
+    GemmProbDev* hs = nullptr; GemmProbDev* ds = nullptr;
+    if (need > 0) {
+        int rc = ctx_reserve(c, need);
+        if (rc) return rc;
+        const int slot = c->next;
+        c->next = (c->next + 1) % kStageSlots;
+        if (c->ev_used[slot]) { HIPCHK(hipEventSynchronize(c->ev[slot])); c->ev_used[slot] = false; }
+        hs = c->h_stage[slot]; ds = c->d_stage[slot];
+        size_t pos = 0;
+        for (int k = 0; k < n_ops; ++k) {
+            if (ops[k].kind != GHN3_OP_GEMM) continue;
+            const int first = (int)ops[k].i[0], cnt = (int)ops[k].i[1], forced = (int)ops[k].i[2];
+            if (first < 0 || cnt < 0 || first + cnt > n_problems) {
+                ghn3_set_error("op %d: GEMM problem range [%d,%d) outside table of %d", k, first, first + cnt, n_problems);
+                return GHN3_E_ARG;
+            }
+            // bucket by (a_mode, b_mode, tile)
+            for (int am = 0; am < 2; ++am)
+                for (int bm = 0; bm < 2; ++bm)
+                    for (int tl = 64; tl <= 128; tl += 64) {
+                        Launch L{am, bm, tl, (int)pos, 0, 0};
+                        for (int q = first; q < first + cnt; ++q) {
+                            const ghn3_gemm_problem& p = problems[q];
+                            if (p.M <= 0 || p.N <= 0) continue;
+                            if (p.a_mode != am || p.b_mode != bm || pick_tile(p, forced) != tl) continue;
+                            if (p.K < 0 || (p.lda & 3) || (p.ldb & 3) || (p.A.off & 15) || (p.B.off & 15)) {
+                                ghn3_set_error("op %d problem %d: operands must be 16-byte aligned with ld %% 4 == 0 "
+                                               "(lda=%d ldb=%d)", k, q, p.lda, p.ldb);
+                                return GHN3_E_ARG;
+                            }
+                            GemmProbDev& g = hs[pos++];
+                            g.A = R.get<const float>(p.A); g.B = R.get<const float>(p.B); g.C = R.get<float>(p.C);
+                            g.bias = R.get<const float>(p.bias); g.residual = R.get<const float>(p.residual);
+                            g.aux_in = R.get<const float>(p.aux_in); g.aux_out = R.get<float>(p.aux_out);
+                            g.a_gather = R.get<const int>(p.a_gather); g.b_gather = R.get<const int>(p.b_gather);
+                            g.c_gather = R.get<const int>(p.c_gather);
+                            g.M = p.M; g.N = p.N; g.K = p.K; g.lda = p.lda; g.ldb = p.ldb; g.ldc = p.ldc;
+                            g.a_q = p.a_q; g.a_s = p.a_s; g.b_q = p.b_q; g.b_s = p.b_s; g.c_q = p.c_q; g.c_s = p.c_s;
+                            g.bias_q = p.bias_q; g.bias_s = p.bias_s; g.bias_stride = p.bias_stride ? p.bias_stride : 1;
+                            g.act = p.act; g.dact = p.dact; g.flags = p.flags; g.alpha = p.alpha;
+                            if (!g.A || !g.B || !g.C || (p.dact != GHN3_DACT_NONE && !g.aux_in)) {
+                                ghn3_set_error("op %d problem %d: missing A/B/C/aux_in buffer", k, q);
+                                return GHN3_E_ARG;
+                            }
+                            g.tile_start = L.tiles;
+                            g.tiles_m = (p.M + tl - 1) / tl;
+                            L.tiles += g.tiles_m * ((p.N + tl - 1) / tl);
+                            L.count++;
+                        }
+                        if (L.count > 0) op_launches[k].push_back(L);
+                    }
+        }
+        if (R.bad) { ghn3_set_error("ghn3_run: a GEMM problem references an absent buffer"); return GHN3_E_ARG; }
+        HIPCHK(hipMemcpyAsync(ds, hs, pos * sizeof(GemmProbDev), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipEventRecord(c->ev[slot], stream));
+        c->ev_used[slot] = true;
+    }
+
+    // ---- 2. launch ops in order ------------------------------------------------------------------
+    for (int k = 0; k < n_ops; ++k) {
+        const ghn3_op& o = ops[k];
+        int rc = GHN3_OK;
+        R.bad = false;
+        const bool timed = c->profile == 2 && (o.flags & GHN3_OPFLAG_TIMED);
+        if (c->profile == 1) HIPCHK(hipEventRecord(c->pe0, stream));
+        if (timed) {
+            if (c->pool_used >= 8192) { int rc2 = drain_pool(c); if (rc2) return rc2; }
+            if (c->pool->size() < 2 * (c->pool_used + 1)) {
+                hipEvent_t e0, e1;
+                HIPCHK(hipEventCreate(&e0));
+                HIPCHK(hipEventCreate(&e1));
+                c->pool->push_back(e0); c->pool->push_back(e1);
+                c->pool_tag->push_back(0);
+            }
+            (*c->pool_tag)[c->pool_used] = (o.flags >> 16) & 255;
+            HIPCHK(hipEventRecord((*c->pool)[2 * c->pool_used], stream));
+        }
+        switch (o.kind) {
+        case GHN3_OP_NOP: break;
+        case GHN3_OP_GEMM:
+            for (const Launch& L : op_launches[k]) {
+                rc = ghn3_gemm_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, L.tile,
+                                      (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, stream);
+                if (rc) break;
+            }
+            break;
+        case GHN3_OP_GRAPH_PROLOGUE:
+            rc = ghn3_graph_prologue(R.get<const int64_t>(o.r[0]), R.get<int>(o.r[1]), R.get<int>(o.r[2]),
+                                     R.get<int>(o.r[3]), R.get<int>(o.r[4]), (int)o.i[0], (int)o.i[1], (int)o.i[2],
+                                     stream);
+            break;
+        case GHN3_OP_EMBED_NODES:
+            rc = ghn3_embed_nodes(R.get<float>(o.r[0]), R.get<const int>(o.r[1]), R.get<const int>(o.r[2]),
+                                  R.get<const int>(o.r[3]), R.get<const int>(o.r[4]), R.get<const float>(o.r[5]),
+                                  R.get<const float>(o.r[6]), R.get<const float>(o.r[7]), R.get<const float>(o.r[8]),
+                                  R.get<const float>(o.r[9]), R.get<const float>(o.r[10]), R.get<const int>(o.r[11]),
+                                  R.get<const int>(o.r[12]), R.get<const int>(o.r[13]), (int)o.i[0], (int)o.i[1],
+                                  (int)o.i[2], stream);
+            break;
+        case GHN3_OP_EMBED_BWD:
+            rc = ghn3_embed_bwd(R.get<const float>(o.r[0]), R.get<const int>(o.r[1]), R.get<const int>(o.r[2]),
+                                R.get<const int>(o.r[3]), R.get<const int>(o.r[4]), R.get<float>(o.r[5]),
+                                R.get<float>(o.r[6]), R.get<float>(o.r[7]), R.get<float>(o.r[8]), R.get<float>(o.r[9]),
+                                R.get<float>(o.r[10]), R.get<const int>(o.r[11]), R.get<const int>(o.r[12]),
+                                R.get<const int>(o.r[13]), (int)o.i[0], (int)o.i[1], (int)o.i[2], stream);
+            break;
+        case GHN3_OP_EDGE_HIDDEN:
+            rc = ghn3_edge_hidden(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const float>(o.r[2]),
+                                  (int)o.i[0], (int)o.i[1], stream);
+            break;
+        case GHN3_OP_EDGE_HIDDEN_BWD:
+            rc = ghn3_edge_hidden_bwd(R.get<float>(o.r[0]), R.get<float>(o.r[1]), R.get<float>(o.r[2]),
+                                      R.get<const float>(o.r[3]), (int)o.i[0], (int)o.i[1], stream);
+            break;
+        case GHN3_OP_BIAS_GATHER:
+            rc = ghn3_bias_gather(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const int>(o.r[2]),
+                                  (int)o.i[0], (int)o.i[1], (int)o.i[2], stream);
+            break;
+        case GHN3_OP_BIAS_HIST:
+            rc = ghn3_bias_hist(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const int>(o.r[2]),
+                                (int)o.i[0], (int)o.i[1], (int)o.i[2], (int)o.i[3], stream);
+            break;
+        case GHN3_OP_LAYERNORM_FWD:
+            rc = ghn3_layernorm_fwd(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const float>(o.r[2]),
+                                    R.get<const float>(o.r[3]), R.get<float>(o.r[4]), R.get<float>(o.r[5]),
+                                    (int)o.i[0], (int)o.i[1], o.f[0], stream);
+            break;
+        case GHN3_OP_LAYERNORM_BWD:
+            rc = ghn3_layernorm_bwd(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const float>(o.r[2]),
+                                    R.get<const float>(o.r[3]), R.get<const float>(o.r[4]), R.get<const float>(o.r[5]),
+                                    R.get<const float>(o.r[6]), (int)o.i[0], (int)o.i[1], stream);
+            break;
+        case GHN3_OP_LN_PARAM_GRAD:
+            rc = ghn3_ln_param_grad(R.get<float>(o.r[0]), R.get<float>(o.r[1]), R.get<const float>(o.r[2]),
+                                    R.get<const float>(o.r[3]), R.get<const float>(o.r[4]), R.get<const float>(o.r[5]),
+                                    (int)o.i[0], (int)o.i[1], (int)o.i[2], stream);
+            break;
+        case GHN3_OP_ATTN_FWD:
+            rc = ghn3_attn_fwd(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const float>(o.r[2]),
+                               R.get<float>(o.r[3]), R.get<const int>(o.r[4]), (int)o.i[0], (int)o.i[1], (int)o.i[2],
+                               (int)o.i[3], stream);
+            break;
+        case GHN3_OP_ATTN_BWD:
+            rc = ghn3_attn_bwd(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const float>(o.r[2]),
+                               R.get<const float>(o.r[3]), R.get<const float>(o.r[4]), R.get<float>(o.r[5]),
+                               R.get<float>(o.r[6]), R.get<const int>(o.r[7]), (int)o.i[0], (int)o.i[1], (int)o.i[2],
+                               (int)o.i[3], stream);
+            break;
+        case GHN3_OP_TILE_FWD: {
+            const float* srcs[6];
+            for (int j = 0; j < 6; ++j) srcs[j] = R.get<const float>(o.r[1 + j]);
+            const ghn3_tile_desc* dd = R.get<const ghn3_tile_desc>(o.r[7]);
+            rc = ghn3_tile_fwd(R.get<float>(o.r[0]), srcs, dd, (int)o.i[0], o.i[1],
+                               reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(dd) + o.i[2]), stream);
+            break;
+        }
+        case GHN3_OP_TILE_BWD: {
+            const float* srcs[6]; float* dsrcs[6];
+            for (int j = 0; j < 6; ++j) { srcs[j] = R.get<const float>(o.r[1 + j]); dsrcs[j] = R.get<float>(o.r[8 + j]); }
+            const ghn3_tile_desc* dd = R.get<const ghn3_tile_desc>(o.r[7]);
+            rc = ghn3_tile_bwd(R.get<const float>(o.r[0]), srcs, dsrcs, dd, (int)o.i[0], o.i[1],
+                               reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(dd) + o.i[2]), stream);
+            break;
+        }
+        case GHN3_OP_PARAM_NORM_FWD:
+            rc = ghn3_param_norm_fwd(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const int64_t>(o.r[2]),
+                                     R.get<float>(o.r[3]), (int)o.i[0], stream);
+            break;
+        case GHN3_OP_PARAM_NORM_BWD:
+            rc = ghn3_param_norm_bwd(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const int64_t>(o.r[2]),
+                                     R.get<const float>(o.r[3]), (int)o.i[0], o.f[0], stream);
+            break;
+        case GHN3_OP_COLSUM:
+            rc = ghn3_colsum(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), (int)o.i[0], (int)o.i[1], (int)o.i[2],
+                             (int)o.i[3], (int)o.i[4], (int)o.i[5] ? (int)o.i[5] : 1, (int)o.i[6],
+                             R.get<const int>(o.r[2]), stream);
+            break;
+        case GHN3_OP_ROWSEG_SUM:
+            rc = ghn3_rowseg_sum(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const int>(o.r[2]),
+                                 R.get<const int>(o.r[3]), (int)o.i[0], (int)o.i[1], (int)o.i[2], (int)o.i[3],
+                                 (int)o.i[4], stream);
+            break;
+        case GHN3_OP_MEMSET0: {
+            void* p = R.get<void>(o.r[0]);
+            if (p && o.i[0] > 0) HIPCHK(hipMemsetAsync(p, 0, (size_t)o.i[0], stream));
+            break;
+        }
+        case GHN3_OP_ADD:
+            rc = ghn3_add(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), o.i[0], stream);
+            break;
+        default:
+            ghn3_set_error("op %d: unknown kind %d", k, o.kind);
+            return GHN3_E_ARG;
+        }
+        if (rc) return rc;
+        if (R.bad) { ghn3_set_error("op %d (kind %d): reference to an absent buffer", k, o.kind); return GHN3_E_ARG; }
+        if (timed) {
+            HIPCHK(hipEventRecord((*c->pool)[2 * c->pool_used + 1], stream));
+            c->pool_used++;
+        }
+        if (c->profile == 1) {
+            HIPCHK(hipEventRecord(c->pe1, stream));
+            HIPCHK(hipEventSynchronize(c->pe1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, c->pe0, c->pe1));
+            c->ms[o.kind] += ms;
+            c->launches[o.kind] += 1;
+        }
+    }
+    return GHN3_OK;
+}
+
+// ---- timing helpers -----------------------------------------------------------------------------
+extern "C" int ghn3_event_create(void** ev) {
+    hipEvent_t e;
+    HIPCHK(hipEventCreate(&e));
+    *ev = (void*)e;
+    return GHN3_OK;
+}
+extern "C" int ghn3_event_record(void* ev, void* stream) {
+    HIPCHK(hipEventRecord((hipEvent_t)ev, (hipStream_t)stream));
+    return GHN3_OK;
+}
+extern "C" int ghn3_event_elapsed_ms(void* start, void* stop, float* ms) {
+    HIPCHK(hipEventSynchronize((hipEvent_t)stop));
+    HIPCHK(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return GHN3_OK;
+}
+extern "C" int ghn3_event_destroy(void* ev) {
+    HIPCHK(hipEventDestroy((hipEvent_t)ev));
+    return GHN3_OK;
+}

@@ -1,0 +1,136 @@
+"""
+Host-side graph containers: the input format of the hot path.
+
+Mirrors the interface of /root/reference/ghn3/graph.py:38-352 for the dense (Graphormer) layout:
+``Graph(node_feat=, node_info=, A=, dense=True)`` and ``GraphBatch(graphs, dense=True)`` with
+``to_device / on_device / to_dense / to_sparse / __len__ / __getitem__ / __iter__`` and the fields
+``node_feat (B,N,1) int64, edges (B,N,N) int64, mask (B,N,1) bool, n_nodes (B,) int64, node_info, net_args,
+nets``.  Building a graph from an arbitrary ``nn.Module`` (graph.py:392-908: autograd walk + virtual edges)
+is the "next" row f1 of SURVEY 8 and is not part of this package yet.
+"""
+
+import numpy as np
+import torch
+
+
+class Graph:
+    r"""
+    Container for a computational graph of a neural network (explicit-arrays constructor of graph.py:292-352).
+
+    :param node_feat: (N,1) int64 primitive ids (order of ppuda PRIMITIVES_DEEPNETS1M)
+    :param node_info: per cell, list of (node_ind, param_name, primitive_name, shape, is_last_weight, is_last_bias)
+    :param A: (N,N) int64 shortest-path adjacency (0 = no edge, values <= ve_cutoff)
+    """
+
+    def __init__(self, model=None, node_feat=None, node_info=None, A=None, edges=None, net_args=None, net_idx=None,
+                 ve_cutoff=50, dense=True, **kwargs):
+        if model is not None:
+            raise NotImplementedError(
+                'ghn3_amd.Graph(model) -- automatic graph construction (reference ghn3/graph.py:392-908) is not '
+                'implemented yet; pass node_feat/node_info/A (e.g. from ghn3_amd.synthetic or a saved fixture).')
+        assert dense, 'only the dense (Graphormer / GHN-3) layout is supported'
+        assert node_feat is not None and A is not None and node_info is not None
+        self.model = None
+        self.n_nodes = len(node_feat)
+        self.node_feat = torch.as_tensor(node_feat, dtype=torch.long).view(-1, 1)
+        self.node_info = node_info
+        self._Adj = torch.as_tensor(A, dtype=torch.long)
+        assert self._Adj.shape == (self.n_nodes, self.n_nodes), self._Adj.shape
+        self.net_args = net_args
+        self.net_idx = net_idx
+
+
+class GraphBatch:
+    r"""Container for a batch of Graph objects (graph.py:38-279, dense path)."""
+
+    def __init__(self, graphs, dense=True):
+        assert dense, 'only dense=True (GHN-3) is supported'
+        self.n_nodes, self.node_feat, self.node_info, self.edges, self.net_args, self.net_inds = [], [], [], [], [], []
+        self.graphs = graphs
+        self.dense = dense
+        self.mask = []
+        self.max_edge = None
+        if graphs is not None:
+            if not isinstance(graphs, (list, tuple)):
+                graphs = [graphs]
+            for graph in graphs:
+                self.append(graph)
+
+    def append(self, graph):
+        self.n_nodes.append(len(graph.node_feat))
+        self.node_feat.append(graph.node_feat)
+        self.edges.append(graph._Adj)
+        self.node_info.append(graph.node_info)
+        self.net_args.append(graph.net_args)
+        self.net_inds.append(graph.net_idx)
+        if hasattr(graph, 'net'):
+            if not hasattr(self, 'nets'):
+                self.nets = []
+            self.nets.append(graph.net)
+
+    def _cat(self):
+        """graph.py:243-269: pad + stack on the host."""
+        if isinstance(self.node_feat, torch.Tensor):
+            return
+        n = [int(v) for v in self.n_nodes]
+        B, m = len(n), max(n)
+        node_feat = torch.zeros(B, m, 1, dtype=torch.long)
+        edges = torch.zeros(B, m, m, dtype=torch.long)
+        mask = torch.zeros(B, m, 1, dtype=torch.bool)
+        for b in range(B):
+            node_feat[b, :n[b]] = self.node_feat[b]
+            edges[b, :n[b], :n[b]] = self.edges[b]
+            mask[b, :n[b]] = True
+        self.max_edge = int(edges.max()) if edges.numel() else 0
+        self._n_nodes_host = n
+        self._node_type_host = np.concatenate([np.asarray(x[:, 0]) for x in self.node_feat]).astype(np.int32)
+        self.n_nodes = torch.tensor(n, dtype=torch.long)
+        self.node_feat, self.edges, self.mask = node_feat, edges, mask
+
+    def to_device(self, device):
+        if isinstance(device, (tuple, list)):
+            device = device[0]
+        self._cat()
+        self.n_nodes = self.n_nodes.to(device, non_blocking=True)
+        self.node_feat = self.node_feat.to(device, non_blocking=True)
+        self.edges = self.edges.to(device, non_blocking=True)
+        self.mask = self.mask.to(device, non_blocking=True)
+        return self
+
+    def on_device(self, device):
+        if isinstance(device, (tuple, list)):
+            device = device[0]
+        return isinstance(self.n_nodes, torch.Tensor) and isinstance(self.node_feat, torch.Tensor) and \
+            self.node_feat.device == torch.device(device)
+
+    def host_n_nodes(self):
+        """Node counts as Python ints without a device sync (the reference syncs at nn.py:615, graph.py:175)."""
+        if not hasattr(self, '_n_nodes_host'):
+            self._cat()
+        return self._n_nodes_host
+
+    def to_dense(self, x=None):
+        if x is None:
+            x = self.node_feat
+        n = self.host_n_nodes()
+        B, M, C = len(n), max(n), x.shape[-1]
+        out = torch.zeros(B, M, C, device=x.device, dtype=x.dtype)
+        offset = [0]
+        for b in range(B):
+            out[b, :n[b]] = x[offset[-1]: offset[-1] + n[b]]
+            offset.append(offset[-1] + n[b])
+        return out, offset
+
+    def to_sparse(self, x):
+        n = self.host_n_nodes()
+        return torch.cat([x[b, :n[b]] for b in range(len(n))])
+
+    def __getitem__(self, idx):
+        return self.graphs[idx]
+
+    def __len__(self):
+        return len(self.n_nodes)
+
+    def __iter__(self):
+        for graph in self.graphs:
+            yield graph

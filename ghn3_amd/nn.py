@@ -1,0 +1,386 @@
+"""
+GHN-3 model on MI355X: host-side mirror of /root/reference/ghn3/nn.py (``from_pretrained``, ``GHN3``) whose
+forward/backward run as hand-written HIP kernels through libghn3_hip.so.
+
+Same constructor arguments, ``forward`` signature, state-dict key layout and assignment semantics as the
+reference (nn.py:31-125, 128-351, 508-552), so it drops into the train_ghn_ddp.py / eval_ghn.py call
+sequences.  The module holds parameters only; no torch op touches them on the hot path.  There is no CPU
+path: calling ``forward`` without a HIP device raises.
+"""
+
+import os
+import math
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import bookkeeping as bk
+from .graph import Graph, GraphBatch
+from .program import Program, param_names
+
+
+def log(*args, **kwargs):
+    rank = int(os.environ.get('RANK', '0'))
+    if rank == 0:
+        print(*args, **kwargs)
+
+
+# ---------------------------------------------------------------------------------------------------
+# parameter containers with the reference's module tree (names only; never called)
+# ---------------------------------------------------------------------------------------------------
+class _Holder(nn.Module):
+    pass
+
+
+def _graphormer_layer(dim, heads, layer0, mlp_ratio=4):
+    m = _Holder()
+    m.ln1 = nn.LayerNorm(dim)
+    m.attn = _Holder()
+    m.attn.to_qkv = nn.Linear(dim, 3 * dim, bias=False)
+    m.attn.to_out = nn.Sequential(nn.Linear(dim, dim), nn.Identity())
+    if layer0:
+        m.attn.edge_embed = _Holder()
+        m.attn.edge_embed.embed = nn.Embedding(257, dim)             # graphormer.py:95-96
+        m.attn.proj_e = nn.Sequential(nn.Linear(2 * dim, dim), nn.ReLU(), nn.Linear(dim, heads))
+    m.ln2 = nn.LayerNorm(dim)
+    m.ff = _Holder()
+    m.ff.net = nn.Sequential(nn.Linear(dim, mlp_ratio * dim), nn.GELU(), nn.Identity(),
+                             nn.Linear(mlp_ratio * dim, dim), nn.Identity())
+    m.max_degree, m.max_input_dist = 100, 1000                           # graphormer.py:196-197
+    return m
+
+
+class ConvDecoder3(nn.Module):
+    """Parameter layout of nn.py:716-733 (fc -> conv.0 -> conv.2, class_layer_predictor)."""
+
+    def __init__(self, in_features, hid, out_shape, num_classes):
+        super().__init__()
+        self.out_shape = out_shape
+        self.num_classes = num_classes
+        s2 = int(out_shape[2] * out_shape[3])
+        self.fc = nn.Sequential(nn.Linear(in_features, hid[0] * s2), nn.ReLU())
+        self.conv = nn.Sequential(nn.Linear(hid[0], hid[1]), nn.ReLU(),
+                                  nn.Linear(hid[1], int(out_shape[0] * out_shape[1])), nn.Identity())
+        self.class_layer_predictor = nn.Sequential(nn.ReLU(), nn.Linear(out_shape[0], num_classes))
+
+
+class SequentialMultipleInOut(nn.Sequential):
+    """Name kept for drop-in imports (nn.py:765-780); the layers execute inside the HIP program."""
+    pass
+
+
+# ---------------------------------------------------------------------------------------------------
+class _Plan:
+    """A compiled batch: Program + device-resident index blob + workspace."""
+
+    def __init__(self, ghn, program, edges, nets):
+        self.program = program
+        self.edges = edges
+        self.nets = nets
+        dev = ghn.device
+        self.idx = torch.from_numpy(program.idx_blob).to(dev)
+        self.ws = torch.empty(program.ws_bytes, dtype=torch.uint8, device=dev)
+        self.scal = torch.zeros(256 + 4 * max(program.n_seg, 1) + 64, dtype=torch.uint8, device=dev)
+        self.bufs = np.zeros(program.n_bufs, dtype=np.uint64)
+        self.sizes = [p['numel'] for p in program.predicted]
+        self.tok = None
+        self.out = None
+
+
+class _GHN3Function(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, ghn, plan, *params):
+        out = ghn._run_forward(plan)
+        ctx.ghn, ctx.plan = ghn, plan
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        grads = ctx.ghn._run_backward(ctx.plan, dout.contiguous())
+        return (None, None) + tuple(grads)
+
+
+class GHN3(nn.Module):
+    r"""
+    Transformer-based Graph HyperNetwork (GHN-3); see the reference class at nn.py:128.
+
+    Extra keyword arguments (not in the reference):
+      index_mode   'reference' (default; reproduces quirk Q1 of SURVEY 3.2 for B > 1) or 'correct'
+      compute      'f32' (default: exact fp32 MFMA), 'f16' or 'bf16' operand type for the decoder GEMMs
+    """
+
+    def __init__(self, max_shape, num_classes, hid, heads=8, layers=3, is_ghn2=False, pretrained=False, **kwargs):
+        super().__init__()
+        if is_ghn2:
+            raise NotImplementedError('GHN-2 (GatedGNN) checkpoints are outside the GHN-3 hot path')
+        kwargs.pop('act_layer', None)
+        hypernet = kwargs.pop('hypernet', 'gatedgnn')
+        decoder = kwargs.pop('decoder', 'conv')
+        assert decoder == 'conv', decoder
+        self.weight_norm = kwargs.pop('weight_norm', False)
+        self.ve = kwargs.pop('ve', False)
+        self.layernorm = kwargs.pop('layernorm', False)
+        self.debug_level = kwargs.pop('debug_level', 0)
+        self.index_mode = kwargs.pop('index_mode', 'reference')
+        self.compute = kwargs.pop('compute', 'f32')
+        assert not kwargs, 'unknown arguments %s' % list(kwargs)
+        if not self.weight_norm or not self.layernorm:
+            raise NotImplementedError('weight_norm=False / layernorm=False are not supported '
+                                      '(every released GHN-3 uses True for both)')
+        assert len(max_shape) == 4, max_shape
+        self.max_shape = tuple(int(v) for v in max_shape)
+        self.num_classes = num_classes
+        self.hid, self.heads, self.layers = hid, heads, layers
+        self._is_ghn2 = False
+
+        if self.layernorm:
+            self.ln = nn.LayerNorm(hid)
+        self.embed = nn.Embedding(len(bk.PRIMITIVES_DEEPNETS1M), hid)
+        vocab = bk.ShapeVocab(num_classes, self.max_shape)
+        self.shape_enc = _Holder()
+        self.shape_enc.embed_spatial = nn.Embedding(vocab.n_sp + 1, hid // 4)
+        self.shape_enc.embed_channel = nn.Embedding(vocab.n_ch + 1, hid // 4)
+        self.gnn = SequentialMultipleInOut(*[_graphormer_layer(hid, heads, layer0=(l == 0)) for l in range(layers)])
+        self.gnn[0].centrality_embed_in = nn.Embedding(101, hid)
+        self.gnn[0].centrality_embed_out = nn.Embedding(101, hid)
+        self.gnn[0].input_dist_embed = nn.Embedding(1001, hid)
+        self.decoder = ConvDecoder3(hid, (hid * 4, hid * 8), self.max_shape, num_classes)
+        max_ch = max(self.max_shape[:2])
+        self.decoder_1d = _Holder()
+        self.decoder_1d.fc = nn.Sequential(nn.Linear(hid, hid * 2), nn.ReLU(), nn.Linear(hid * 2, 2 * max_ch),
+                                           nn.Identity())
+        self.bias_class = nn.Sequential(nn.ReLU(), nn.Linear(max_ch, num_classes))
+        # nn.py:167-170: small init of the last decoder layers, transformer-style embedding init
+        for m in (self.decoder_1d.fc[-2], self.decoder.conv[-2], self.decoder.class_layer_predictor[-1]):
+            m.weight.data /= 5.0
+            m.bias.data *= 0
+        for m in self.modules():
+            if isinstance(m, nn.Embedding):
+                nn.init.trunc_normal_(m.weight.data, std=m.weight.shape[1] ** (-0.5))
+        self._names = param_names(layers)
+        self._flat = None
+        self._flatten()
+
+    # ------------------------------------------------------------------ parameter storage
+    def _slot_params(self):
+        named = dict(self.named_parameters())
+        return [named[n] for n in self._names]
+
+    def _flatten(self):
+        """All parameters become views of one flat fp32 buffer (slot order, 64-float aligned)."""
+        ps = self._slot_params()
+        offs, total = [], 0
+        for p in ps:
+            offs.append(total)
+            total += (p.numel() + 63) // 64 * 64
+        dev = ps[0].device
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        for p, o in zip(ps, offs):
+            flat[o:o + p.numel()].copy_(p.data.reshape(-1).to(torch.float32))
+            p.data = flat[o:o + p.numel()].view(p.shape)
+        self._flat, self._offs, self._flat_numel = flat, np.asarray(offs, dtype=np.int64), total
+        self._plans = {}
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._flatten()
+        return out
+
+    def load_state_dict(self, state_dict, strict=True):
+        sd = dict(state_dict)
+        # HF checkpoints keep the three layer-0 embeddings at the top level (nn.py:87,174-184)
+        for k in ('centrality_embed_in', 'centrality_embed_out', 'input_dist_embed'):
+            if k + '.weight' in sd:
+                sd['gnn.0.' + k + '.weight'] = sd.pop(k + '.weight')
+        return super().load_state_dict(sd, strict=strict)
+
+    def fix_embed_layers(self):
+        return  # the embeddings already live under gnn.0 (nn.py:174-184)
+
+    def is_dense(self):
+        return True
+
+    @property
+    def device(self):
+        return self.embed.weight.device
+
+    # ------------------------------------------------------------------ compile / run
+    def compile(self, nets, graphs, predict_class_layers=True, reduce_graph=False, training=None):
+        """Host bookkeeping for one batch (nn.py:242 _map_net_params + all shape logic) -> _Plan."""
+        dev = self.device
+        if dev.type != 'cuda':
+            raise L.Ghn3Error('GHN3 runs on an MI355X only: move the model with .to("cuda") (no CPU path; the '
+                              'CPU oracle under oracle/ is test infrastructure)')
+        if isinstance(graphs, Graph) or isinstance(graphs, (list, tuple)):
+            graphs = GraphBatch([graphs] if isinstance(graphs, Graph) else list(graphs), dense=True)
+        if not graphs.on_device(dev):
+            graphs.to_device(dev)
+        assert graphs.dense, 'GraphBatch must be created with dense=True for GHN-3'
+        training = self.training if training is None else training
+        cfg = dict(hid=self.hid, heads=self.heads, layers=self.layers, num_classes=self.num_classes,
+                   max_shape=self.max_shape)
+        prog = Program(cfg, graphs.node_info, graphs.host_n_nodes(), graphs._node_type_host, graphs.max_edge,
+                       nets, index_mode=self.index_mode, training=training,
+                       predict_class_layers=predict_class_layers, reduce_graph=reduce_graph,
+                       layernorm=self.layernorm)
+        plan = _Plan(self, prog, graphs.edges, nets)
+        plan.graphs = graphs
+        return plan
+
+    def _fill_bufs(self, plan, out=None, dout=None, gflat=None):
+        prog = plan.program
+        P = prog.P
+        b = plan.bufs
+        base = self._flat.data_ptr()
+        b[:P] = (base + 4 * self._offs).astype(np.uint64)
+        if gflat is not None:
+            b[P:2 * P] = (gflat.data_ptr() + 4 * self._offs).astype(np.uint64)
+            b[prog.xbuf(prog.X_GRADFLAT)] = gflat.data_ptr()
+        b[prog.xbuf(prog.X_WS)] = plan.ws.data_ptr()
+        b[prog.xbuf(prog.X_IDX)] = plan.idx.data_ptr()
+        b[prog.xbuf(prog.X_EDGES)] = plan.edges.data_ptr()
+        b[prog.xbuf(prog.X_SCAL)] = plan.scal.data_ptr()
+        if plan.tok is not None:
+            b[prog.xbuf(prog.X_TOK)] = plan.tok.data_ptr()
+        if out is not None:
+            b[prog.xbuf(prog.X_OUT)] = out.data_ptr()
+        if dout is not None:
+            b[prog.xbuf(prog.X_DOUT)] = dout.data_ptr()
+
+    def _ctx(self):
+        ctx = L.context(self.device.index or 0)
+        ctx.set_compute_type(self.compute)
+        return ctx
+
+    def _run_forward(self, plan):
+        prog = plan.program
+        dev = self.device
+        out = torch.empty(prog.out_numel, dtype=torch.float32, device=dev)
+        # Q3: random class-token rows of positional encodings (nn.py:446)
+        plan.tok = torch.normal(0.0, 0.02, (prog.tok_floats,), device=dev)
+        self._fill_bufs(plan, out=out)
+        self._ctx().run(prog.fwd_ops, prog.problems, plan.bufs, torch.cuda.current_stream().cuda_stream)
+        plan.out = out
+        return out
+
+    def _run_backward(self, plan, dout):
+        prog = plan.program
+        if len(prog.bwd_ops) == 0:
+            raise L.Ghn3Error('this plan was compiled without a backward program (training=False)')
+        gflat = torch.empty(self._flat_numel, dtype=torch.float32, device=self.device)
+        self._fill_bufs(plan, out=plan.out, dout=dout, gflat=gflat)
+        prog.bwd_ops[prog.memset_grad_op]['i'][0] = 4 * self._flat_numel
+        self._ctx().run(prog.bwd_ops, prog.problems, plan.bufs, torch.cuda.current_stream().cuda_stream)
+        plan.gflat = gflat
+        ps = self._slot_params()
+        return [gflat[o:o + p.numel()].view(p.shape) for p, o in zip(ps, self._offs)]
+
+    def embeddings(self, plan):
+        """Node embeddings after the last Graphormer layer + LayerNorm, (B*N_max, C) (nn.py:259-263)."""
+        prog = plan.program
+        off = prog._ws_names['xe']
+        n = prog.B * prog.N * prog.C
+        return plan.ws[off:off + 4 * n].view(torch.float32).view(prog.B * prog.N, prog.C)
+
+    # ------------------------------------------------------------------ reference API
+    def forward(self, nets_torch, graphs=None, return_embeddings=False, predict_class_layers=True,
+                bn_track_running_stats=True, keep_grads=False, reduce_graph=False):
+        r"""Predict parameters for a list of >=1 networks (signature of nn.py:186-193)."""
+        is_lst = isinstance(nets_torch, (list, tuple))
+        if not is_lst:
+            nets_torch = [nets_torch]
+        if graphs is None:
+            raise NotImplementedError('graphs=None needs automatic graph construction (ghn3/graph.py:392-908), '
+                                      'which is not part of this package yet; pass a Graph / GraphBatch')
+        keep = self.training if keep_grads is None else keep_grads
+        plan = self.compile(nets_torch, graphs, predict_class_layers=predict_class_layers, reduce_graph=reduce_graph,
+                            training=bool(keep and torch.is_grad_enabled()))
+        if keep and torch.is_grad_enabled():
+            flat = _GHN3Function.apply(self, plan, *self._slot_params())
+        else:
+            with torch.no_grad():
+                flat = self._run_forward(plan)
+        self.assign(plan, flat, keep_grads=keep)
+        if bn_track_running_stats is None:
+            bn_track_running_stats = self.training
+        if not bn_track_running_stats:
+            def bn_set_train(module):
+                if isinstance(module, nn.BatchNorm2d):
+                    module.track_running_stats = False
+                    module.training = True
+            for net in nets_torch:
+                if isinstance(net, nn.Module):
+                    net.apply(bn_set_train)
+        self.last_plan = plan
+        out = nets_torch if is_lst else nets_torch[0]
+        return (out, self.embeddings(plan)) if return_embeddings else out
+
+    def assign(self, plan, flat, keep_grads):
+        """nn.py:508-552 _set_params for every predicted tensor (views of the flat output buffer)."""
+        preds = plan.program.predicted
+        for p in preds:
+            t = flat[p['offset']:p['offset'] + p['numel']].view(p['shape'])
+            m, key = p['module'], p['attr']
+            target = getattr(m, key, None)
+            if keep_grads or not isinstance(target, nn.Parameter):
+                if isinstance(target, (list, tuple)) or not isinstance(m, nn.Module):
+                    setattr(m, key, t)
+                else:
+                    m.__dict__[key] = t
+                    m._parameters[key] = t
+            else:
+                target.data = t
+
+
+def from_pretrained(ghn3_name='ghn3xlm16.pt', **kwargs):
+    """
+    Loads a GHN-3 checkpoint (nn.py:31-125).  Local files are tried first (the reference's local fallback is
+    unreachable offline); otherwise the HuggingFace hub is queried like the reference does.
+    Returns the model in training mode, on CPU.
+    """
+    assert ghn3_name is not None, 'GHN ckpt must be specified'
+    ghn_config = None
+    if os.path.exists(ghn3_name):
+        state_dict = torch.load(ghn3_name, map_location='cpu')
+        if isinstance(state_dict, dict) and 'state_dict' in state_dict:
+            ghn_config = state_dict.get('config', None)
+            state_dict = state_dict['state_dict']
+    else:
+        import joblib
+        from huggingface_hub import hf_hub_download
+        state_dict = joblib.load(hf_hub_download(repo_id='SamsungSAILMontreal/ghn3', filename=ghn3_name))
+    if any(k.find('gnn.gru.') >= 0 for k in state_dict):
+        raise NotImplementedError('GHN-2 checkpoints are not supported')
+    extra = {k: kwargs.pop(k) for k in ('index_mode', 'compute', 'debug_level') if k in kwargs}
+    if ghn_config is None:
+        num_classes = kwargs.pop('num_classes', 10)
+        layers = kwargs.pop('layers', 0)
+        hid = kwargs.pop('hid', 32)
+        layernorm = kwargs.pop('layernorm', False)
+        max_shape = kwargs.pop('max_shape', 64)
+        for name, p in state_dict.items():
+            if name.find('class_layer_predictor') >= 0:
+                num_classes = len(p)
+                break
+        s = 16 if num_classes >= 1000 else 11
+        for name, p in state_dict.items():
+            if name.endswith('ln.weight'):
+                layernorm = True
+            elif name.endswith('embed.weight'):
+                hid = p.shape[-1]
+            elif name.endswith('decoder.conv.2.weight'):
+                max_shape = int(len(p) ** 0.5)
+            elif name.endswith('shape_enc.embed_spatial.weight'):
+                s = 11 if len(p) == 9 else 16
+            elif name.endswith('ln1.weight') and name.find('gnn.') >= 0:
+                layers += 1
+        ghn_config = {'hid': hid,
+                      'max_shape': max_shape if isinstance(max_shape, tuple) else (max_shape, max_shape, s, s),
+                      'num_classes': num_classes, 'heads': 16 if hid > 64 else 8, 'layers': layers,
+                      'weight_norm': True, 've': True, 'layernorm': layernorm}
+    else:
+        ghn_config = {k: v for k, v in ghn_config.items() if k not in ('is_ghn2', 'pretrained')}
+    ghn = GHN3(**ghn_config, **extra, **kwargs)
+    ghn.load_state_dict(state_dict)
+    return ghn

@@ -1,0 +1,861 @@
+"""
+Compiles one batch of graphs + target networks into the op programs libghn3_hip.so executes
+(include/ghn3_hip.h): a forward program (GHN3.forward, /root/reference/ghn3/nn.py:247-328) and, in
+training, the matching backward program (what torch autograd would run for the same lines).
+
+Everything here is host-side shape bookkeeping (numpy); no tensor math.  The compiled object holds
+  * ops / GEMM problem tables (numpy structured arrays mirroring the C structs)
+  * the workspace layout (byte offsets into one device buffer) and its size
+  * an index blob (int32/int64 arrays + tile descriptors) uploaded once per batch
+  * the list of predicted tensors (module, attribute, shape, offset into the flat output)
+"""
+
+import math
+import numpy as np
+
+from . import _lib as L
+from . import bookkeeping as bk
+
+ALIGN = 256
+
+
+def global_param_names():
+    return ['ln.weight', 'ln.bias', 'embed.weight', 'shape_enc.embed_spatial.weight',
+            'shape_enc.embed_channel.weight', 'gnn.0.centrality_embed_in.weight',
+            'gnn.0.centrality_embed_out.weight', 'gnn.0.input_dist_embed.weight',
+            'gnn.0.attn.edge_embed.embed.weight', 'gnn.0.attn.proj_e.0.weight', 'gnn.0.attn.proj_e.0.bias',
+            'gnn.0.attn.proj_e.2.weight', 'gnn.0.attn.proj_e.2.bias',
+            'decoder.fc.0.weight', 'decoder.fc.0.bias', 'decoder.conv.0.weight', 'decoder.conv.0.bias',
+            'decoder.conv.2.weight', 'decoder.conv.2.bias', 'decoder.class_layer_predictor.1.weight',
+            'decoder.class_layer_predictor.1.bias', 'decoder_1d.fc.0.weight', 'decoder_1d.fc.0.bias',
+            'decoder_1d.fc.2.weight', 'decoder_1d.fc.2.bias', 'bias_class.1.weight', 'bias_class.1.bias']
+
+
+LAYER_PARAM_NAMES = ['ln1.weight', 'ln1.bias', 'attn.to_qkv.weight', 'attn.to_out.0.weight', 'attn.to_out.0.bias',
+                     'ln2.weight', 'ln2.bias', 'ff.net.0.weight', 'ff.net.0.bias', 'ff.net.3.weight',
+                     'ff.net.3.bias']
+
+
+def param_names(layers):
+    names = global_param_names()
+    for l in range(layers):
+        names += ['gnn.%d.%s' % (l, n) for n in LAYER_PARAM_NAMES]
+    return names
+
+
+def round_up(x, m):
+    return (x + m - 1) // m * m
+
+
+class Program:
+    """See module docstring.  cfg: dict(hid, heads, layers, num_classes, max_shape)."""
+
+    # extra buffer slots after the 2*P parameter / gradient pointers
+    X_WS, X_IDX, X_EDGES, X_OUT, X_DOUT, X_TOK, X_SCAL, X_GRADFLAT, X_COUNT = range(9)
+
+    def __init__(self, cfg, node_infos, n_nodes, node_types, max_edge, nets, index_mode='reference',
+                 training=True, predict_class_layers=True, reduce_graph=False, layernorm=True):
+        self.cfg = cfg
+        self.C = C = int(cfg['hid'])
+        self.H = int(cfg['heads'])
+        self.Lyr = int(cfg['layers'])
+        self.K = int(cfg['num_classes'])
+        self.max_shape = tuple(int(v) for v in cfg['max_shape'])
+        self.S = self.max_shape[2]                    # decoder spatial size (16)
+        assert self.max_shape[2] == self.max_shape[3]
+        self.layernorm = layernorm
+        self.training = training
+        self.index_mode = index_mode
+        self.names = param_names(self.Lyr)
+        self.P = len(self.names)
+        self.slot = {n: i for i, n in enumerate(self.names)}
+        self.B = len(n_nodes)
+        self.n_nodes = [int(v) for v in n_nodes]
+        self.N = max(self.n_nodes)
+        self.V = int(max_edge) + 1
+        if self.V + 1 > 257:
+            raise ValueError('shortest-path length %d exceeds the 257-row edge embedding (graphormer.py:95-96)'
+                             % max_edge)
+        if self.N > 1024:
+            raise ValueError('graphs with more than 1024 nodes are not supported (got %d)' % self.N)
+        self._ops, self._probs = [], []
+        self.tag_flops = {}
+        self._ws = 0
+        self._ws_names = {}
+        self._idx_chunks, self._idx_size = [], 0
+
+        self.param_groups, self.params_map = bk.map_net_params(node_infos, self.n_nodes, nets, self.max_shape,
+                                                               reduce_graph=reduce_graph)
+        vocab = bk.ShapeVocab(self.K, self.max_shape)
+        total_nodes = sum(self.n_nodes)
+        self.shape_idx = vocab.indices(total_nodes, self.params_map, predict_class_layers)
+        self.node_types = np.asarray(node_types, dtype=np.int32)
+        assert len(self.node_types) == total_nodes
+        self.predict_class_layers = predict_class_layers
+
+        self._layout_decoder()
+        self._build_forward()
+        self.fwd_ops = self._finish_ops()
+        self.n_fwd_problems = len(self._probs)
+        if training:
+            self._build_backward()
+            self.bwd_ops = self._finish_ops()
+        else:
+            self.bwd_ops = np.zeros(0, dtype=L.OP_DT)
+        self.problems = np.array(self._probs, dtype=L.PROBLEM_DT) if self._probs else np.zeros(0, dtype=L.PROBLEM_DT)
+        self.ws_bytes = round_up(self._ws + 1024, ALIGN)
+        self.idx_blob = np.zeros(max(self._idx_size, 16), dtype=np.uint8)
+        for off, raw in self._idx_chunks:
+            self.idx_blob[off:off + len(raw)] = raw
+        self.n_bufs = 2 * self.P + self.X_COUNT
+
+    # ------------------------------------------------------------------ small helpers
+    def xbuf(self, which):
+        return 2 * self.P + which
+
+    def pref(self, name, off_floats=0):
+        return (self.slot[name], 4 * off_floats)
+
+    def gref(self, name, off_floats=0):
+        return (self.P + self.slot[name], 4 * off_floats)
+
+    def ws(self, name, nbytes):
+        if name in self._ws_names:
+            return self._ws_names[name]
+        off = self._ws
+        self._ws = round_up(self._ws + max(int(nbytes), 4), ALIGN)
+        self._ws_names[name] = off
+        return off
+
+    def wsf(self, name, nfloats):
+        """workspace region of nfloats floats (plus slack for vector over-reads); returns a ref."""
+        return (self.xbuf(self.X_WS), self.ws(name, 4 * (int(nfloats) + 64)))
+
+    def wref(self, name, off_floats=0):
+        return (self.xbuf(self.X_WS), self._ws_names[name] + 4 * off_floats)
+
+    def idx(self, arr):
+        raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
+        off = round_up(self._idx_size, 16)
+        self._idx_chunks.append((off, raw))
+        self._idx_size = off + len(raw)
+        return (self.xbuf(self.X_IDX), off)
+
+    NONE = (-1, 0)
+
+    def op(self, kind, refs=(), ints=(), floats=(), flags=0):
+        o = np.zeros((), dtype=L.OP_DT)
+        o['kind'] = kind
+        o['flags'] = flags
+        for k, v in enumerate(ints):
+            o['i'][k] = int(v)
+        for k, v in enumerate(floats):
+            o['f'][k] = float(v)
+        r = o['r']
+        r['buf'][:] = -1
+        for k, ref in enumerate(refs):
+            r['buf'][k], r['off'][k] = ref
+        self._ops.append(o)
+
+    def _finish_ops(self):
+        out = np.array(self._ops, dtype=L.OP_DT) if self._ops else np.zeros(0, dtype=L.OP_DT)
+        self._ops = []
+        return out
+
+    def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, bias=None, bias_q=0,
+             bias_s=0, bias_stride=1, act=L.ACT_NONE, dact=L.DACT_NONE, aux_in=None, aux_out=None, residual=None,
+             a_gather=None, b_gather=None, c_gather=None, a_qs=(0, 0), b_qs=(0, 0), c_qs=(0, 0), accum=False,
+             alpha=1.0):
+        p = np.zeros((), dtype=L.PROBLEM_DT)
+        for name, ref in (('A', A), ('B', B), ('C', C), ('bias', bias), ('residual', residual), ('aux_in', aux_in),
+                          ('aux_out', aux_out), ('a_gather', a_gather), ('b_gather', b_gather),
+                          ('c_gather', c_gather)):
+            ref = self.NONE if ref is None else ref
+            p[name]['buf'], p[name]['off'] = ref
+        for name, v in (('M', M), ('N', N), ('K', K), ('lda', lda), ('ldb', ldb), ('ldc', ldc), ('a_mode', a_mode),
+                        ('b_mode', b_mode), ('a_q', a_qs[0]), ('a_s', a_qs[1]), ('b_q', b_qs[0]), ('b_s', b_qs[1]),
+                        ('c_q', c_qs[0]), ('c_s', c_qs[1]), ('bias_q', bias_q), ('bias_s', bias_s),
+                        ('bias_stride', bias_stride), ('act', act), ('dact', dact),
+                        ('flags', L.GEMM_ACCUM if accum else 0)):
+            p[name] = int(v)
+        p['alpha'] = alpha
+        self._probs.append(p)
+        return len(self._probs) - 1
+
+    # timing tags (ghn3_profile_enable mode 2): the decoder kernels that dominate the step
+    TAG_D3_FWD, TAG_D3_DGRAD, TAG_D3_WGRAD, TAG_D2_FWD, TAG_D1_FWD, TAG_TILE_FWD, TAG_TILE_BWD, TAG_D2_BWD, \
+        TAG_D1_BWD = range(1, 10)
+    TAG_NAMES = {1: 'w2_fwd', 2: 'w2_dgrad', 3: 'w2_wgrad', 4: 'w0_fwd', 5: 'fc_fwd', 6: 'tile_fwd', 7: 'tile_bwd',
+                 8: 'w0_bwd', 9: 'fc_bwd'}
+
+    def gemm_op(self, first, count=None, tile=0, ctype=None, tag=0):
+        if count is None:
+            count = len(self._probs) - first
+        if count > 0:
+            flags = 0 if ctype is None else 1 + ctype
+            if tag:
+                flags |= L.OPFLAG_TIMED | (tag << 16)
+                fl = sum(2.0 * int(p['M']) * int(p['N']) * int(p['K']) for p in self._probs[first:first + count])
+                self.tag_flops[tag] = self.tag_flops.get(tag, 0.0) + fl
+            self.op(L.OP_GEMM, ints=(first, count, tile), flags=flags)
+
+    # ------------------------------------------------------------------ decoder layout (host bookkeeping)
+    def _src_row(self, ind):
+        """xe row read for sparse-flat node index `ind` (quirk Q1: reference reads dense-flat row `ind`)."""
+        if self.index_mode == 'reference':
+            return ind
+        b, off = 0, 0
+        while ind >= off + self.n_nodes[b]:
+            off += self.n_nodes[b]
+            b += 1
+        return b * self.N + (ind - off)
+
+    def _layout_decoder(self):
+        C, S = self.C, self.S
+        ms = self.max_shape
+        half = S // 2
+        self.conv_groups, self.oned_plain, self.oned_clsb = [], [], []
+        row = 0
+        for key, inds in self.param_groups.items():
+            if len(inds) == 0:
+                continue
+            if len(key) == 4 or (len(key) == 2 and key[1] > 0):
+                if len(key) == 4:
+                    if key[2] > S or key[3] > S:
+                        raise NotImplementedError('kernel %s larger than the %dx%d decoder grid needs the bilinear '
+                                                  'interpolation branch of nn.py:751-753' % (str(key), S, S))
+                    kh, kw = int(key[2]), int(key[3])
+                    o_g, i_g = min(int(key[0]), ms[0]), min(int(key[1]), ms[1])
+                    g = dict(kind='conv', key=key, inds=list(inds), o=o_g, i=i_g, i_ld=i_g, kh=kh, kw=kw,
+                             cols=o_g * i_g)
+                else:
+                    kh = kw = 1
+                    i_true = min(int(key[1]), ms[1])
+                    i_ld = round_up(i_true, 4)
+                    g = dict(kind='cls', key=key, inds=list(inds), o=ms[0], i=i_true, i_ld=i_ld, kh=1, kw=1,
+                             cols=ms[0] * i_ld)
+                g['hw'] = kh * kw
+                y0, x0 = max(0, half - kh // 2), max(0, half - kw // 2)
+                g['pos'] = np.asarray([(y0 + y) * S + (x0 + x) for y in range(kh) for x in range(kw)],
+                                      dtype=np.int32)
+                g['ld'] = round_up(g['cols'], 4)
+                g['row0'] = row
+                g['rows'] = len(inds) * g['hw']
+                row += g['rows']
+                self.conv_groups.append(g)
+            else:
+                if len(key) == 2 and key[1] < 0:
+                    self.oned_clsb.append((key, list(inds)))
+                else:
+                    self.oned_plain.append((key, list(inds)))
+        self.M = row
+        # per-row arrays
+        self.row_src = np.zeros(self.M, dtype=np.int32)
+        self.row_pos = np.zeros(self.M, dtype=np.int32)
+        for g in self.conv_groups:
+            for n_idx, ind in enumerate(g['inds']):
+                r = g['row0'] + n_idx * g['hw']
+                self.row_src[r:r + g['hw']] = self._src_row(ind)
+                self.row_pos[r:r + g['hw']] = g['pos']
+        # 1-D nodes: plain first, then last-bias (cls-b) nodes
+        self.oned_index = {}                # sparse-flat node index -> row in the 1-D buffers
+        rows = []
+        for _, inds in self.oned_plain:
+            for ind in inds:
+                self.oned_index[ind] = len(rows)
+                rows.append(self._src_row(ind))
+        self.n1_plain = len(rows)
+        for _, inds in self.oned_clsb:
+            for ind in inds:
+                self.oned_index[ind] = len(rows)
+                rows.append(self._src_row(ind))
+        self.n1 = len(rows)
+        self.n1_clsb = self.n1 - self.n1_plain
+        self.oned_src = np.asarray(rows, dtype=np.int32)
+
+    # ------------------------------------------------------------------ forward
+    def _build_forward(self):
+        C, H, B, N, V, K = self.C, self.H, self.B, self.N, self.V, self.K
+        rows = B * N
+        F = 4
+        ldT = round_up(H, 4)
+        ldK = round_up(K, 4)
+        self.ldT, self.ldK = ldT, ldK
+        train = self.training
+
+        node_off = np.cumsum([0] + self.n_nodes[:-1]).astype(np.int32)
+        r_types = self.idx(self.node_types)
+        r_shape = self.idx(self.shape_idx.astype(np.int32))
+        r_nn = self.idx(np.asarray(self.n_nodes, dtype=np.int32))
+        r_noff = self.idx(node_off)
+        self.r_nn = r_nn
+
+        deg_in = (self.xbuf(self.X_WS), self.ws('deg_in', 4 * rows))
+        deg_out = (self.xbuf(self.X_WS), self.ws('deg_out', 4 * rows))
+        dist0 = (self.xbuf(self.X_WS), self.ws('dist0', 4 * rows))
+        pair = (self.xbuf(self.X_WS), self.ws('pair', 4 * rows * N))
+        self.r_graph = (r_types, r_shape, r_nn, r_noff, deg_in, deg_out, dist0, pair)
+
+        self.op(L.OP_GRAPH_PROLOGUE, refs=((self.xbuf(self.X_EDGES), 0), deg_in, deg_out, dist0, pair),
+                ints=(B, N, V))
+        x0 = self.wsf('x0', rows * C)
+        self.op(L.OP_EMBED_NODES,
+                refs=(x0, r_types, r_shape, r_nn, r_noff, self.pref('embed.weight'),
+                      self.pref('shape_enc.embed_channel.weight'), self.pref('shape_enc.embed_spatial.weight'),
+                      self.pref('gnn.0.centrality_embed_in.weight'), self.pref('gnn.0.centrality_embed_out.weight'),
+                      self.pref('gnn.0.input_dist_embed.weight'), deg_in, deg_out, dist0),
+                ints=(B, N, C))
+
+        # ---- edge bias table (layer 0), graphormer.py:115-117 factorised --------------------------
+        Pfw, Pbw = self.wsf('Pfw', V * C), self.wsf('Pbw', V * C)
+        hid = self.wsf('hid', V * V * C)
+        T = self.wsf('T', V * V * ldT)
+        bias = self.wsf('bias', B * H * N * N)
+        E = 'gnn.0.attn.edge_embed.embed.weight'
+        W0e, b0e = 'gnn.0.attn.proj_e.0.weight', 'gnn.0.attn.proj_e.0.bias'
+        W2e, b2e = 'gnn.0.attn.proj_e.2.weight', 'gnn.0.attn.proj_e.2.bias'
+        p0 = self.gemm(self.pref(E, 2 * C), self.pref(W0e, 0), Pfw, V, C, C, C, 2 * C, C)
+        self.gemm(self.pref(E, 2 * C), self.pref(W0e, C), Pbw, V, C, C, C, 2 * C, C, bias=self.pref(b0e))
+        self.gemm_op(p0)
+        self.op(L.OP_EDGE_HIDDEN, refs=(hid, Pfw, Pbw), ints=(V, C))
+        p0 = self.gemm(hid, self.pref(W2e), T, V * V, H, C, C, C, ldT, bias=self.pref(b2e))
+        self.gemm_op(p0)
+        self.op(L.OP_BIAS_GATHER, refs=(bias, T, pair), ints=(B, N, H))
+
+        # ---- Graphormer layers --------------------------------------------------------------------
+        x_in = x0
+        for l in range(self.Lyr):
+            pre = 'gnn.%d.' % l
+            sfx = '_%d' % l
+            h1 = self.wsf('h1' + sfx, rows * C)
+            m1, r1 = self.wsf('m1' + sfx, rows), self.wsf('r1' + sfx, rows)
+            qkv = self.wsf('qkv' + sfx, rows * 3 * C)
+            Pm = self.wsf('P' + sfx, B * H * N * N) if train else None
+            o = self.wsf('o' + sfx, rows * C)
+            xmid = self.wsf('xmid' + sfx, rows * C)
+            h2 = self.wsf('h2' + sfx, rows * C)
+            m2, r2 = self.wsf('m2' + sfx, rows), self.wsf('r2' + sfx, rows)
+            z = self.wsf('z' + sfx, rows * 4 * C)
+            f = self.wsf('f' + sfx, rows * 4 * C)
+            x_out = self.wsf('x%d' % (l + 1), rows * C)
+            self.op(L.OP_LAYERNORM_FWD, refs=(h1, x_in, self.pref(pre + 'ln1.weight'), self.pref(pre + 'ln1.bias'),
+                                              m1, r1), ints=(rows, C), floats=(1e-5,))
+            p0 = self.gemm(h1, self.pref(pre + 'attn.to_qkv.weight'), qkv, rows, 3 * C, C, C, C, 3 * C)
+            self.gemm_op(p0)
+            self.op(L.OP_ATTN_FWD, refs=(o, qkv, bias, Pm if Pm is not None else self.NONE, r_nn),
+                    ints=(B, N, C, H))
+            p0 = self.gemm(o, self.pref(pre + 'attn.to_out.0.weight'), xmid, rows, C, C, C, C, C,
+                           bias=self.pref(pre + 'attn.to_out.0.bias'), residual=x_in)
+            self.gemm_op(p0)
+            self.op(L.OP_LAYERNORM_FWD, refs=(h2, xmid, self.pref(pre + 'ln2.weight'), self.pref(pre + 'ln2.bias'),
+                                              m2, r2), ints=(rows, C), floats=(1e-5,))
+            p0 = self.gemm(h2, self.pref(pre + 'ff.net.0.weight'), f, rows, 4 * C, C, C, C, 4 * C,
+                           bias=self.pref(pre + 'ff.net.0.bias'), act=L.ACT_GELU, aux_out=z if train else None)
+            self.gemm_op(p0)
+            p0 = self.gemm(f, self.pref(pre + 'ff.net.3.weight'), x_out, rows, C, 4 * C, 4 * C, 4 * C, C,
+                           bias=self.pref(pre + 'ff.net.3.bias'), residual=xmid)
+            self.gemm_op(p0)
+            x_in = x_out
+        xe = self.wsf('xe', rows * C)
+        mf, rf = self.wsf('mf', rows), self.wsf('rf', rows)
+        if self.layernorm:
+            self.op(L.OP_LAYERNORM_FWD, refs=(xe, x_in, self.pref('ln.weight'), self.pref('ln.bias'), mf, rf),
+                    ints=(rows, C), floats=(1e-5,))
+        else:
+            self._ws_names['xe'] = self._ws_names['x%d' % self.Lyr]
+            xe = x_in
+        self.r_xe = xe
+
+        # ---- decoders -------------------------------------------------------------------------------
+        self._build_decoder_forward(xe)
+
+    def _build_decoder_forward(self, xe):
+        C, K, S = self.C, self.K, self.S
+        S2 = S * S
+        M, ldK = self.M, self.ldK
+        ms = self.max_shape
+        Wfc, bfc = 'decoder.fc.0.weight', 'decoder.fc.0.bias'
+        W0, b0 = 'decoder.conv.0.weight', 'decoder.conv.0.bias'
+        W2, b2 = 'decoder.conv.2.weight', 'decoder.conv.2.bias'
+        Wc, bc = 'decoder.class_layer_predictor.1.weight', 'decoder.class_layer_predictor.1.bias'
+        if M > 0:
+            t = self.wsf('t', M * 4 * C)
+            u = self.wsf('u', M * 8 * C)
+            # D1: fc, one problem per used position of the 16x16 grid (row subset of Wfc)
+            self.d1 = []
+            p0 = len(self._probs)
+            for p in np.unique(self.row_pos):
+                rws = np.nonzero(self.row_pos == p)[0].astype(np.int32)
+                r_rows = self.idx(rws)
+                r_src = self.idx(self.row_src[rws])
+                self.d1.append((int(p), len(rws), r_rows, r_src))
+                self.gemm(xe, self.pref(Wfc, int(p) * C), t, len(rws), 4 * C, C, C, S2 * C, 4 * C,
+                          bias=self.pref(bfc, int(p)), bias_stride=S2, act=L.ACT_RELU, a_gather=r_src,
+                          c_gather=r_rows)
+            self.gemm_op(p0, tag=self.TAG_D1_FWD)
+            # D2
+            p0 = self.gemm(t, self.pref(W0), u, M, 8 * C, 4 * C, 4 * C, 4 * C, 8 * C, bias=self.pref(b0),
+                           act=L.ACT_RELU)
+            self.gemm_op(p0, tag=self.TAG_D2_FWD)
+            # D3: only the W2 rows (o' < o, i' < i) each group consumes; all groups in one launch
+            p0 = len(self._probs)
+            tiles_floats = 0
+            for g in self.conv_groups:
+                g['tile_off'] = tiles_floats
+                tiles_floats += round_up(g['rows'] * g['ld'], 64)
+            self.tiles_floats = tiles_floats
+            tiles = self.wsf('tiles', tiles_floats)
+            for g in self.conv_groups:
+                self.gemm((u[0], u[1] + 4 * g['row0'] * 8 * C), self.pref(W2), self.wref('tiles', g['tile_off']),
+                          g['rows'], g['cols'], 8 * C, 8 * C, 8 * C, g['ld'], b_qs=(g['i_ld'], ms[1]),
+                          bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1],
+                          act=L.ACT_RELU if g['kind'] == 'cls' else L.ACT_NONE)
+            self.gemm_op(p0, tag=self.TAG_D3_FWD)
+            # classifier head (nn.py:755-758): out[i'][k] = sum_o' relu(tile[o'][i']) Wcls[k][o'] + bcls[k]
+            n_cls_rows = sum(g['rows'] * g['i_ld'] for g in self.conv_groups if g['kind'] == 'cls')
+            if n_cls_rows:
+                clsout = self.wsf('clsout', n_cls_rows * ldK)
+                p0 = len(self._probs)
+                off = 0
+                for g in self.conv_groups:
+                    if g['kind'] != 'cls':
+                        continue
+                    g['cls_off'] = []
+                    for n_idx in range(len(g['inds'])):
+                        g['cls_off'].append(off)
+                        self.gemm(self.wref('tiles', g['tile_off'] + n_idx * g['ld']), self.pref(Wc),
+                                  self.wref('clsout', off), g['i'], K, ms[0], g['i_ld'], ms[0], ldK,
+                                  a_mode=L.MODE_COL, bias=self.pref(bc))
+                        off += g['i_ld'] * ldK
+                self.gemm_op(p0)
+        # 1-D decoder (nn.py:286-295)
+        if self.n1 > 0:
+            W1, b1 = 'decoder_1d.fc.0.weight', 'decoder_1d.fc.0.bias'
+            W2d, b2d = 'decoder_1d.fc.2.weight', 'decoder_1d.fc.2.bias'
+            Wb, bb = 'bias_class.1.weight', 'bias_class.1.bias'
+            mc = max(self.max_shape[:2])
+            self.mc = mc
+            r_src1 = self.idx(self.oned_src)
+            self.r_src1 = r_src1
+            h1d = self.wsf('h1d', self.n1 * 2 * C)
+            w1d = self.wsf('w1d', self.n1 * 2 * mc)
+            p0 = self.gemm(xe, self.pref(W1), h1d, self.n1, 2 * C, C, C, C, 2 * C, bias=self.pref(b1),
+                           act=L.ACT_RELU, a_gather=r_src1)
+            self.gemm_op(p0)
+            p0 = len(self._probs)
+            if self.n1_plain:
+                self.gemm(h1d, self.pref(W2d), w1d, self.n1_plain, 2 * mc, 2 * C, 2 * C, 2 * C, 2 * mc,
+                          bias=self.pref(b2d))
+            if self.n1_clsb:
+                self.gemm(self.wref('h1d', self.n1_plain * 2 * C), self.pref(W2d),
+                          self.wref('w1d', self.n1_plain * 2 * mc), self.n1_clsb, 2 * mc, 2 * C, 2 * C, 2 * C, 2 * mc,
+                          bias=self.pref(b2d), act=L.ACT_RELU)
+            self.gemm_op(p0)
+            if self.n1_clsb:
+                cbout = self.wsf('cbout', self.n1_clsb * ldK)
+                p0 = self.gemm(self.wref('w1d', self.n1_plain * 2 * mc + mc), self.pref(Wb), cbout, self.n1_clsb, K,
+                               mc, 2 * mc, mc, ldK, bias=self.pref(bb))
+                self.gemm_op(p0)
+        self._build_tile_descriptors()
+
+    # ------------------------------------------------------------------ tile / normalise descriptors
+    def _build_tile_descriptors(self):
+        C, K, ldK = self.C, self.K, self.ldK
+        mc = max(self.max_shape[:2])
+        descs, predicted = [], []
+        out_off = 0
+        tok_off = 0
+        group_of = {}
+        for g in self.conv_groups:
+            for n_idx, ind in enumerate(g['inds']):
+                group_of[ind] = (g, n_idx)
+        clsb_row = {}
+        for ind, r in self.oned_index.items():
+            if r >= self.n1_plain:
+                clsb_row[ind] = r - self.n1_plain
+
+        def add(dst_off, src_buf, src_off, T, E, Sd, R, mode, scale):
+            d = np.zeros((), dtype=L.TILE_DT)
+            d['dst_off'], d['src_off'], d['src_buf'], d['mode'], d['scale'] = dst_off, src_off, src_buf, mode, scale
+            d['T'], d['E'], d['S'], d['R'] = T, E, Sd, R
+            for k in range(4):
+                assert 1 <= d['E'][k] <= d['T'][k] and d['E'][k] <= d['R'][k], (T, E, R)
+            descs.append(d)
+
+        for key, inds in self.param_groups.items():
+            if len(inds) == 0:
+                continue
+            is_cls = (len(key) == 2 and key[1] != 0)
+            if is_cls and not self.predict_class_layers:
+                continue
+            for ind in inds:
+                matched, _, w_ind = self.params_map[ind]
+                if w_ind is None:
+                    continue
+                m, sz, is_w = matched['module'], tuple(matched['sz']), matched['is_w']
+                for it in range(2 if (len(sz) == 1 and is_w) else 1):
+                    w_flag = bool(is_w) and not it
+                    attr = bk.target_attr(m, w_flag)
+                    tgt = getattr(m, attr, None)
+                    if it == 1 and tgt is None:
+                        continue                     # norm layer without bias
+                    tile_t = sz                       # _tile_params target (nn.py:325); norm-layer bias shares it
+                    # nn.py:526-528: a 2-D tile assigned to a 4-D (O,I,1,1) parameter is unsqueezed
+                    t_assign = bk._sz(tgt) if tgt is not None else tile_t
+                    mode, scale = bk.norm_rule(tile_t, w_flag)
+                    numel = int(np.prod(tile_t))
+                    dst = out_off
+                    out_off = round_up(out_off + numel, 16)
+                    predicted.append(dict(node=ind, module=m, attr=attr, shape=tuple(t_assign),
+                                          tile_shape=tuple(tile_t), offset=dst, numel=numel, is_w=w_flag))
+                    t = tile_t
+                    if len(key) == 4:
+                        g, n_idx = group_of[ind]
+                        base = g['tile_off'] + n_idx * g['hw'] * g['ld']
+                        kh, kw, ld = g['kh'], g['kw'], g['ld']
+                        if len(t) == 4:
+                            if (t[2], t[3]) != (kh, kw):
+                                raise NotImplementedError('target kernel %s vs group key %s' % (str(t), str(key)))
+                            add(dst, 0, base, (t[0], t[1], kh, kw), (min(t[0], g['o']), min(t[1], g['i']), kh, kw),
+                                (g['i'], 1, kw * ld, ld), (g['o'], g['i'], kh, kw), mode, scale)
+                        elif len(t) == 2:
+                            cy, cx = kh // 2, kw // 2
+                            add(dst, 0, base + (cy * kw + cx) * ld, (t[0], t[1], 1, 1),
+                                (min(t[0], g['o']), min(t[1], g['i']), 1, 1), (g['i'], 1, 0, 0),
+                                (g['o'], g['i'], 1, 1), mode, scale)
+                            if g['hw'] != 1:
+                                raise NotImplementedError('2-D target from a %dx%d tile' % (kh, kw))
+                        elif len(t) == 3:
+                            # positional encoding (nn.py:442-446): rows 1.. from the tile, row 0 random (Q3)
+                            hw = g['hw']
+                            L1, D = t[1], t[2]
+                            if t[0] != 1 or L1 - 1 > hw or g['o'] != 1:
+                                raise NotImplementedError('3-D target %s from key %s' % (str(t), str(key)))
+                            i_e = min(D, g['i'])
+                            add(dst + D, 0, base, (1, L1 - 1, D, 1), (1, L1 - 1, i_e, 1), (0, ld, 1, 0),
+                                (1, hw, g['i'], 1), mode, scale)
+                            add(dst, 4, tok_off, (1, 1, D, 1), (1, 1, i_e, 1), (0, 0, 1, 0), (1, 1, i_e, 1), mode,
+                                scale)
+                            predicted[-1]['tok'] = (tok_off, i_e)
+                            tok_off += round_up(i_e, 4)
+                        else:
+                            raise NotImplementedError('1-D target from a 4-D tile')
+                    elif len(key) == 2 and key[1] > 0:
+                        g, n_idx = group_of[ind]
+                        base = g['cls_off'][n_idx]
+                        if len(t) == 4 and (t[2], t[3]) != (1, 1):
+                            raise NotImplementedError('classifier target %s' % str(t))
+                        add(dst, 1, base, (t[0], t[1], 1, 1), (min(t[0], K), min(t[1], g['i']), 1, 1),
+                            (1, ldK, 0, 0), (K, g['i'], 1, 1), mode, scale)
+                    elif len(key) == 2 and key[1] < 0:
+                        r = clsb_row[ind]
+                        assert len(t) == 1
+                        add(dst, 3, r * ldK, (1, t[0], 1, 1), (1, min(t[0], K), 1, 1), (0, 1, 0, 0), (1, K, 1, 1),
+                            mode, scale)
+                    else:
+                        r = self.oned_index[ind]
+                        if len(t) == 1:
+                            half = (1 - int(bool(is_w)) + it)
+                            add(dst, 2, r * 2 * mc + half * mc, (1, t[0], 1, 1), (1, min(t[0], mc), 1, 1),
+                                (0, 1, 0, 0), (1, mc, 1, 1), mode, scale)
+                        elif len(t) == 3:
+                            if t[1] > 1 and t[2] > 1:
+                                raise NotImplementedError('3-D target %s from the 1-D decoder' % str(t))
+                            add(dst, 2, r * 2 * mc, (t[0], t[1], t[2], 1), (min(t[0], 2 * mc), 1, 1, 1),
+                                (1, 0, 0, 0), (2 * mc, 1, 1, 1), mode, scale)
+                        else:
+                            raise NotImplementedError('target %s from the 1-D decoder' % str(t))
+        self.predicted = predicted
+        self.out_numel = max(out_off, 16)
+        self.tok_floats = max(tok_off, 4)
+        self.n_desc = len(descs)
+        CH = 2048
+        fwd_blocks, bwd_blocks = [], []
+        for k, d in enumerate(descs):
+            n_f = int(np.prod(d['T'].astype(np.int64)))
+            n_b = int(np.prod(d['R'].astype(np.int64)))
+            fwd_blocks += [(k, s) for s in range(0, n_f, CH)]
+            bwd_blocks += [(k, s) for s in range(0, n_b, CH)]
+        desc_arr = np.array(descs, dtype=L.TILE_DT) if descs else np.zeros(1, dtype=L.TILE_DT)
+        fb = np.asarray(fwd_blocks, dtype=np.int64).reshape(-1, 2)
+        bb = np.asarray(bwd_blocks, dtype=np.int64).reshape(-1, 2)
+        raw = np.concatenate([desc_arr.view(np.uint8).reshape(-1), fb.view(np.uint8).reshape(-1),
+                              bb.view(np.uint8).reshape(-1)])
+        self.r_desc = self.idx(raw)
+        self.fwd_blk = (len(fb), desc_arr.nbytes)
+        self.bwd_blk = (len(bb), desc_arr.nbytes + fb.nbytes)
+        seg = np.asarray([[p['offset'], p['offset'] + p['numel']] for p in predicted], dtype=np.int64).reshape(-1, 2)
+        self.r_seg = self.idx(seg if len(seg) else np.zeros((1, 2), dtype=np.int64))
+        self.n_seg = len(predicted)
+        srcs = self._tile_sources(False)
+        if self.n_desc:
+            self.op(L.OP_TILE_FWD, refs=[(self.xbuf(self.X_OUT), 0)] + srcs + [self.r_desc],
+                    ints=(self.n_desc, self.fwd_blk[0], self.fwd_blk[1]),
+                    flags=L.OPFLAG_TIMED | (self.TAG_TILE_FWD << 16))
+
+    def _tile_sources(self, grad):
+        pre = 'd_' if grad else ''
+        out = []
+        for name in ('tiles', 'clsout', 'w1d', 'cbout'):
+            nm = pre + name
+            out.append(self.wref(nm) if nm in self._ws_names else self.NONE)
+        if grad:
+            out.append(self.wsf('d_tok', self.tok_floats))
+        else:
+            out.append((self.xbuf(self.X_TOK), 0))
+        out.append(self.NONE)
+        return out
+
+    # ------------------------------------------------------------------ loss used by bench / tests
+    def norm_ops(self, upstream=1.0):
+        """(forward ops, backward ops) of sum_t ||p_t||_F over all predicted tensors (trainer.py:288-294)."""
+        scal = self.xbuf(self.X_SCAL)
+        f_ops, b_ops = [], []
+        saved = self._ops
+        self._ops = []
+        self.op(L.OP_MEMSET0, refs=((scal, 0),), ints=(4,))
+        self.op(L.OP_PARAM_NORM_FWD, refs=((scal, 0), (self.xbuf(self.X_OUT), 0), self.r_seg, (scal, 256)),
+                ints=(self.n_seg,))
+        f_ops = self._finish_ops()
+        self.op(L.OP_PARAM_NORM_BWD, refs=((self.xbuf(self.X_DOUT), 0), (self.xbuf(self.X_OUT), 0), self.r_seg,
+                                           (scal, 256)), ints=(self.n_seg,), floats=(upstream,))
+        b_ops = self._finish_ops()
+        self._ops = saved
+        return f_ops, b_ops
+
+    # ------------------------------------------------------------------ backward
+    def _colsum(self, out, X, M, N, ld, q=0, s=0, stride=1, gather=None):
+        self.op(L.OP_COLSUM, refs=(out, X, gather if gather is not None else self.NONE),
+                ints=(M, N, ld, q, s, stride, 1))
+
+    def _build_backward(self):
+        C, H, B, N, V, K = self.C, self.H, self.B, self.N, self.V, self.K
+        rows = B * N
+        ldT, ldK = self.ldT, self.ldK
+        ms = self.max_shape
+        S2 = self.S * self.S
+        M, n1 = self.M, self.n1
+        (r_types, r_shape, r_nn, r_noff, deg_in, deg_out, dist0, pair) = self.r_graph
+        xe = self.r_xe
+        # gradients of all GHN parameters start at zero; every parameter-gradient op accumulates
+        self.op(L.OP_MEMSET0, refs=((self.xbuf(self.X_GRADFLAT), 0),), ints=(-1,))   # size patched at run time
+        self.memset_grad_op = 0
+
+        d_rows = self.wsf('d_xrows', (M + n1) * C)
+        # ---- tile backward -------------------------------------------------------------------------
+        if M > 0:
+            self.wsf('d_tiles', self.tiles_floats)
+            if 'clsout' in self._ws_names:
+                n_cls = sum(g['rows'] * g['i_ld'] for g in self.conv_groups if g['kind'] == 'cls')
+                self.wsf('d_clsout', n_cls * ldK)
+                self.op(L.OP_MEMSET0, refs=(self.wref('d_clsout'),), ints=(4 * n_cls * ldK,))
+        if n1 > 0:
+            mc = self.mc
+            self.wsf('d_w1d', n1 * 2 * mc)
+            self.op(L.OP_MEMSET0, refs=(self.wref('d_w1d'),), ints=(4 * n1 * 2 * mc,))
+            if self.n1_clsb:
+                self.wsf('d_cbout', self.n1_clsb * ldK)
+                self.op(L.OP_MEMSET0, refs=(self.wref('d_cbout'),), ints=(4 * self.n1_clsb * ldK,))
+        if self.n_desc:
+            self.op(L.OP_TILE_BWD, refs=[(self.xbuf(self.X_DOUT), 0)] + self._tile_sources(False) + [self.r_desc] +
+                    self._tile_sources(True), ints=(self.n_desc, self.bwd_blk[0], self.bwd_blk[1]),
+                    flags=L.OPFLAG_TIMED | (self.TAG_TILE_BWD << 16))
+
+        Wfc, bfc = 'decoder.fc.0.weight', 'decoder.fc.0.bias'
+        W0, b0 = 'decoder.conv.0.weight', 'decoder.conv.0.bias'
+        W2, b2 = 'decoder.conv.2.weight', 'decoder.conv.2.bias'
+        Wc, bc = 'decoder.class_layer_predictor.1.weight', 'decoder.class_layer_predictor.1.bias'
+        if M > 0:
+            t, u = self.wref('t'), self.wref('u')
+            d_t = self.wsf('d_t', M * 4 * C)
+            d_u = self.wsf('d_u', M * 8 * C)
+            # classifier head backward
+            for g in self.conv_groups:
+                if g['kind'] != 'cls':
+                    continue
+                # the head dgrad writes columns i' < i only; the pad columns (i <= i' < i_ld) must read as zero
+                self.op(L.OP_MEMSET0, refs=(self.wref('d_tiles', g['tile_off']),), ints=(4 * g['rows'] * g['ld'],))
+                p0 = len(self._probs)
+                for n_idx in range(len(g['inds'])):
+                    tile_n = self.wref('tiles', g['tile_off'] + n_idx * g['ld'])
+                    dtile_n = self.wref('d_tiles', g['tile_off'] + n_idx * g['ld'])
+                    dout_n = self.wref('d_clsout', g['cls_off'][n_idx])
+                    # d relu(tile)[o'][i'] = sum_k dout[i'][k] Wcls[k][o'], masked by tile > 0
+                    self.gemm(self.pref(Wc), dout_n, dtile_n, ms[0], g['i'], K, ms[0], ldK, g['i_ld'],
+                              a_mode=L.MODE_COL, b_mode=L.MODE_ROW, dact=L.DACT_RELU, aux_in=tile_n)
+                self.gemm_op(p0)
+                for n_idx in range(len(g['inds'])):
+                    tile_n = self.wref('tiles', g['tile_off'] + n_idx * g['ld'])
+                    dout_n = self.wref('d_clsout', g['cls_off'][n_idx])
+                    p0 = self.gemm(dout_n, tile_n, self.gref(Wc), K, ms[0], g['i'], ldK, g['i_ld'], ms[0],
+                                   a_mode=L.MODE_COL, b_mode=L.MODE_ROW, accum=True)
+                    self.gemm_op(p0)
+                    self._colsum(self.gref(bc), dout_n, g['i'], K, ldK)
+            # D3 backward: d_u = (d_tiles . W2sub) * (u > 0)   -- all groups, one launch
+            p0 = len(self._probs)
+            for g in self.conv_groups:
+                self.gemm(self.wref('d_tiles', g['tile_off']), self.pref(W2), (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),
+                          g['rows'], 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
+                          b_qs=(g['i_ld'], ms[1]), dact=L.DACT_RELU, aux_in=(u[0], u[1] + 4 * g['row0'] * 8 * C))
+            self.gemm_op(p0, tag=self.TAG_D3_DGRAD)
+            # dW2[rows of the group] += d_tiles^T u ; groups overlap in W2 rows -> one launch per group
+            for g in self.conv_groups:
+                p0 = self.gemm(self.wref('d_tiles', g['tile_off']), (u[0], u[1] + 4 * g['row0'] * 8 * C),
+                               self.gref(W2), g['cols'], 8 * C, g['rows'], g['ld'], 8 * C, 8 * C,
+                               a_mode=L.MODE_COL, b_mode=L.MODE_COL, c_qs=(g['i_ld'], ms[1]), accum=True)
+                self.gemm_op(p0, tag=self.TAG_D3_WGRAD)
+                self._colsum(self.gref(b2), self.wref('d_tiles', g['tile_off']), g['rows'], g['cols'], g['ld'],
+                             q=g['i_ld'], s=ms[1])
+            # D2 backward
+            p0 = self.gemm(d_u, t, self.gref(W0), 8 * C, 4 * C, M, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_COL,
+                           b_mode=L.MODE_COL, accum=True)
+            self.gemm(d_u, self.pref(W0), d_t, M, 4 * C, 8 * C, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_ROW,
+                      b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=t)
+            self.gemm_op(p0, tag=self.TAG_D2_BWD)
+            self._colsum(self.gref(b0), d_u, M, 8 * C, 8 * C)
+            # D1 backward (per used position)
+            p0 = len(self._probs)
+            for (p, cnt, r_rows, r_src) in self.d1:
+                self.gemm(d_t, xe, self.gref(Wfc, p * C), 4 * C, C, cnt, 4 * C, C, S2 * C, a_mode=L.MODE_COL,
+                          b_mode=L.MODE_COL, a_gather=r_rows, b_gather=r_src, accum=True)
+                self.gemm(d_t, self.pref(Wfc, p * C), d_rows, cnt, C, 4 * C, 4 * C, S2 * C, C, a_mode=L.MODE_ROW,
+                          b_mode=L.MODE_COL, a_gather=r_rows, c_gather=r_rows)
+            self.gemm_op(p0, tag=self.TAG_D1_BWD)
+            for (p, cnt, r_rows, r_src) in self.d1:
+                self._colsum(self.gref(bfc, p), d_t, cnt, 4 * C, 4 * C, stride=S2, gather=r_rows)
+        if n1 > 0:
+            mc = self.mc
+            W1, b1 = 'decoder_1d.fc.0.weight', 'decoder_1d.fc.0.bias'
+            W2d, b2d = 'decoder_1d.fc.2.weight', 'decoder_1d.fc.2.bias'
+            Wb, bb = 'bias_class.1.weight', 'bias_class.1.bias'
+            h1d, w1d, d_w1d = self.wref('h1d'), self.wref('w1d'), self.wref('d_w1d')
+            d_h1d = self.wsf('d_h1d', n1 * 2 * C)
+            if self.n1_clsb:
+                cb0 = self.n1_plain
+                d_cb = self.wref('d_cbout')
+                w_cb = self.wref('w1d', cb0 * 2 * mc + mc)
+                p0 = self.gemm(d_cb, self.pref(Wb), self.wref('d_w1d', cb0 * 2 * mc + mc), self.n1_clsb, mc, K, ldK,
+                               mc, 2 * mc, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=w_cb)
+                self.gemm(d_cb, w_cb, self.gref(Wb), K, mc, self.n1_clsb, ldK, 2 * mc, mc, a_mode=L.MODE_COL,
+                          b_mode=L.MODE_COL, accum=True)
+                self.gemm_op(p0)
+                self._colsum(self.gref(bb), d_cb, self.n1_clsb, K, ldK)
+            p0 = self.gemm(d_w1d, h1d, self.gref(W2d), 2 * mc, 2 * C, n1, 2 * mc, 2 * C, 2 * C, a_mode=L.MODE_COL,
+                           b_mode=L.MODE_COL, accum=True)
+            self.gemm(d_w1d, self.pref(W2d), d_h1d, n1, 2 * C, 2 * mc, 2 * mc, 2 * C, 2 * C, a_mode=L.MODE_ROW,
+                      b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=h1d)
+            self.gemm_op(p0)
+            self._colsum(self.gref(b2d), d_w1d, n1, 2 * mc, 2 * mc)
+            p0 = self.gemm(d_h1d, xe, self.gref(W1), 2 * C, C, n1, 2 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
+                           b_gather=self.r_src1, accum=True)
+            self.gemm(d_h1d, self.pref(W1), (d_rows[0], d_rows[1] + 4 * M * C), n1, C, 2 * C, 2 * C, C, C,
+                      a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+            self.gemm_op(p0)
+            self._colsum(self.gref(b1), d_h1d, n1, 2 * C, 2 * C)
+        # ---- d_xe[row] = sum of the decoder rows that read it (deterministic gather-sum) -----------------
+        all_src = np.concatenate([self.row_src, self.oned_src]) if (M + n1) else np.zeros(0, dtype=np.int32)
+        order = np.argsort(all_src, kind='stable').astype(np.int32)
+        counts = np.bincount(all_src, minlength=rows)[:rows]
+        seg_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
+        d_xe = self.wsf('d_xe', rows * C)
+        self.op(L.OP_ROWSEG_SUM, refs=(d_xe, d_rows, self.idx(seg_ptr), self.idx(order)), ints=(rows, C, C, C, 0))
+
+        # ---- final LayerNorm ----------------------------------------------------------------------------
+        dxa, dxb = self.wsf('dxa', rows * C), self.wsf('dxb', rows * C)
+        dh = self.wsf('dh', rows * C)
+        dz = self.wsf('dz', rows * 4 * C)
+        do = self.wsf('do', rows * C)
+        dqkv = self.wsf('dqkv', rows * 3 * C)
+        dS = self.wsf('dS', B * H * N * N)
+        dBias = self.wsf('dBias', B * H * N * N)
+        self.op(L.OP_MEMSET0, refs=(dBias,), ints=(4 * B * H * N * N,))
+        xL = self.wref('x%d' % self.Lyr)
+        if self.layernorm:
+            self.op(L.OP_LAYERNORM_BWD, refs=(dxa, d_xe, xL, self.pref('ln.weight'), self.wref('mf'), self.wref('rf'),
+                                              self.NONE), ints=(rows, C))
+            self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref('ln.weight'), self.gref('ln.bias'), d_xe, xL,
+                                              self.wref('mf'), self.wref('rf')), ints=(rows, C, 1))
+            g_cur = dxa
+        else:
+            g_cur = d_xe
+        other = dxb
+        # ---- Graphormer layers, reversed ----------------------------------------------------------------
+        bias = self.wref('bias')
+        for l in reversed(range(self.Lyr)):
+            pre = 'gnn.%d.' % l
+            sfx = '_%d' % l
+            x_in = self.wref('x%d' % l)
+            h1, qkv, Pm, o = self.wref('h1' + sfx), self.wref('qkv' + sfx), self.wref('P' + sfx), self.wref('o' + sfx)
+            xmid, h2, z, f = self.wref('xmid' + sfx), self.wref('h2' + sfx), self.wref('z' + sfx), self.wref('f' + sfx)
+            m1, r1, m2, r2 = self.wref('m1' + sfx), self.wref('r1' + sfx), self.wref('m2' + sfx), self.wref('r2' + sfx)
+            W3, W1f, Wo, Wq = pre + 'ff.net.3.weight', pre + 'ff.net.0.weight', pre + 'attn.to_out.0.weight', \
+                pre + 'attn.to_qkv.weight'
+            # FFN second linear: x_out = xmid + f W3^T + b3
+            p0 = self.gemm(g_cur, f, self.gref(W3), C, 4 * C, rows, C, 4 * C, 4 * C, a_mode=L.MODE_COL,
+                           b_mode=L.MODE_COL, accum=True)
+            self.gemm(g_cur, self.pref(W3), dz, rows, 4 * C, C, C, 4 * C, 4 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
+                      dact=L.DACT_GELU, aux_in=z)
+            self.gemm_op(p0)
+            self._colsum(self.gref(pre + 'ff.net.3.bias'), g_cur, rows, C, C)
+            # FFN first linear
+            p0 = self.gemm(dz, h2, self.gref(W1f), 4 * C, C, rows, 4 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
+                           accum=True)
+            self.gemm(dz, self.pref(W1f), dh, rows, C, 4 * C, 4 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+            self.gemm_op(p0)
+            self._colsum(self.gref(pre + 'ff.net.0.bias'), dz, rows, 4 * C, 4 * C)
+            # LN2 (+ residual branch gradient g_cur)
+            self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln2.weight'), self.gref(pre + 'ln2.bias'), dh, xmid,
+                                              m2, r2), ints=(rows, C, 1))
+            self.op(L.OP_LAYERNORM_BWD, refs=(other, dh, xmid, self.pref(pre + 'ln2.weight'), m2, r2, g_cur),
+                    ints=(rows, C))
+            g_mid = other
+            # attention output projection: xmid = x_in + o Wo^T + bo
+            p0 = self.gemm(g_mid, o, self.gref(Wo), C, C, rows, C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
+                           accum=True)
+            self.gemm(g_mid, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+            self.gemm_op(p0)
+            self._colsum(self.gref(pre + 'attn.to_out.0.bias'), g_mid, rows, C, C)
+            self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, dS, dBias, r_nn), ints=(B, N, C, H))
+            p0 = self.gemm(dqkv, h1, self.gref(Wq), 3 * C, C, rows, 3 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
+                           accum=True)
+            self.gemm(dqkv, self.pref(Wq), dh, rows, C, 3 * C, 3 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+            self.gemm_op(p0)
+            self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln1.weight'), self.gref(pre + 'ln1.bias'), dh, x_in,
+                                              m1, r1), ints=(rows, C, 1))
+            self.op(L.OP_LAYERNORM_BWD, refs=(g_cur, dh, x_in, self.pref(pre + 'ln1.weight'), m1, r1, g_mid),
+                    ints=(rows, C))
+            # g_cur now holds d x_l ; `other` is free again
+        # ---- layer-0 edge bias: histogram -> table MLP backward ------------------------------------------
+        E = 'gnn.0.attn.edge_embed.embed.weight'
+        W0e, b0e = 'gnn.0.attn.proj_e.0.weight', 'gnn.0.attn.proj_e.0.bias'
+        W2e, b2e = 'gnn.0.attn.proj_e.2.weight', 'gnn.0.attn.proj_e.2.bias'
+        dT = self.wsf('dT', V * V * ldT)
+        dhid = self.wsf('dhid', V * V * C)
+        dPfw, dPbw = self.wsf('dPfw', V * C), self.wsf('dPbw', V * C)
+        hid = self.wref('hid')
+        self.op(L.OP_MEMSET0, refs=(dT,), ints=(4 * V * V * ldT,))
+        self.op(L.OP_BIAS_HIST, refs=(dT, dBias, pair), ints=(B, N, H, V))
+        p0 = self.gemm(dT, hid, self.gref(W2e), H, C, V * V, ldT, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
+                       accum=True)
+        self.gemm(dT, self.pref(W2e), dhid, V * V, C, H, ldT, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+        self.gemm_op(p0)
+        self._colsum(self.gref(b2e), dT, V * V, H, ldT)
+        self.op(L.OP_EDGE_HIDDEN_BWD, refs=(dPfw, dPbw, dhid, hid), ints=(V, C))
+        p0 = self.gemm(dPfw, self.pref(E, 2 * C), self.gref(W0e, 0), C, C, V, C, C, 2 * C, a_mode=L.MODE_COL,
+                       b_mode=L.MODE_COL, accum=True)
+        self.gemm(dPbw, self.pref(E, 2 * C), self.gref(W0e, C), C, C, V, C, C, 2 * C, a_mode=L.MODE_COL,
+                  b_mode=L.MODE_COL, accum=True)
+        self.gemm(dPfw, self.pref(W0e, 0), self.gref(E, 2 * C), V, C, C, C, 2 * C, C, a_mode=L.MODE_ROW,
+                  b_mode=L.MODE_COL, accum=True)
+        self.gemm_op(p0)
+        p0 = self.gemm(dPbw, self.pref(W0e, C), self.gref(E, 2 * C), V, C, C, C, 2 * C, C, a_mode=L.MODE_ROW,
+                       b_mode=L.MODE_COL, accum=True)
+        self.gemm_op(p0)
+        self._colsum(self.gref(b0e), dPbw, V, C, C)
+        # ---- node embeddings ---------------------------------------------------------------------------------
+        self.op(L.OP_EMBED_BWD,
+                refs=(g_cur, r_types, r_shape, r_nn, r_noff, self.gref('embed.weight'),
+                      self.gref('shape_enc.embed_channel.weight'), self.gref('shape_enc.embed_spatial.weight'),
+                      self.gref('gnn.0.centrality_embed_in.weight'), self.gref('gnn.0.centrality_embed_out.weight'),
+                      self.gref('gnn.0.input_dist_embed.weight'), deg_in, deg_out, dist0),
+                ints=(B, N, C))

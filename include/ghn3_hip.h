@@ -1,0 +1,212 @@
+/*
+ * ghn3_hip.h -- C ABI of libghn3_hip.so: the MI355X (gfx950) implementation of the GHN-3
+ * parameter-prediction hot path (Graphormer over computational-graph node embeddings + weight-tile
+ * decoders, forward and backward).
+ *
+ * The reference (SamsungSAILMontreal/ghn3) has no FFI layer: its boundary for this path is the Python
+ * API `GHN3.forward` (/root/reference/ghn3/nn.py:186-349).  This header therefore defines the ABI that
+ * a `GHN3.forward` replacement binds (ghn3_amd/nn.py does so through ctypes; INTEGRATION.md shows the
+ * stub a reference maintainer would add).  Every entry point is `extern "C"`, takes plain pointers and
+ * sizes, returns 0 on success or a negative GHN3_E_* code, never throws, never allocates device memory
+ * and never synchronises the device (except ghn3_event_* helpers, which say so).
+ *
+ * Execution model: the host compiles one batch of graphs into a flat array of fixed-size `ghn3_op`
+ * records (a "program").  Buffers are named by index into a per-call pointer table, so one program is
+ * replayed every step with fresh output / gradient buffers.  `ghn3_run` launches the program's HIP
+ * kernels on the given stream, in order.  Each op kind replaces a specific sequence of ATen calls in the
+ * reference; the citation is on the enum value.
+ */
+#ifndef GHN3_HIP_H
+#define GHN3_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GHN3_ABI_VERSION 3
+
+/* ---- error codes -------------------------------------------------------------------------------- */
+#define GHN3_OK            0
+#define GHN3_E_ARG        -1   /* malformed op / problem (message via ghn3_last_error) */
+#define GHN3_E_LIMIT      -2   /* a documented size limit is exceeded (e.g. N > 1024 nodes)  */
+#define GHN3_E_HIP        -3   /* a HIP runtime call failed */
+#define GHN3_E_NOCTX      -4
+
+/* ---- buffer references ---------------------------------------------------------------------------- */
+/* A reference names `bufs[buf] + off` where off is in BYTES.  buf < 0 means "absent" (NULL). */
+typedef struct ghn3_ref {
+    int32_t buf;
+    int32_t _pad;
+    int64_t off;
+} ghn3_ref;
+
+/* ---- grouped GEMM --------------------------------------------------------------------------------
+ * C(m,n) = epilogue( alpha * sum_k A(m,k) * B(k,n) )           fp32 in HBM, fp32 accumulate.
+ *
+ * Operand addressing.  An operand is a row-major stored matrix X with leading dimension ld (floats).
+ *   ROW mode (k-contiguous):  A(m,k) = X[rmap(m)][k]        B(k,n) = X[rmap(n)][k]
+ *   COL mode (k-strided)   :  A(m,k) = X[rmap(k)][m]        B(k,n) = X[rmap(k)][n]
+ * rmap(r) = gather ? gather[r] : r ;  then  r -> (r / q) * s + (r % q)  when q > 0.
+ * C(m,n) = Y[cmap(m)][n] with the same two-stage map.  ld and the byte offsets must be multiples of 4
+ * floats (16 B) for ROW/COL vector loads; M, N, K are arbitrary.
+ *
+ * Epilogue order: acc*alpha -> +bias[bidx(n)] -> save pre-activation (aux_out) -> activation ->
+ *                 *dact(aux_in) -> +residual -> (+= C when GHN3_GEMM_ACCUM) -> store.
+ *   bidx(n) = ((n / bias_q) * bias_s + n % bias_q) * bias_stride   (bias_q == 0: n * bias_stride)
+ */
+enum { GHN3_MODE_ROW = 0, GHN3_MODE_COL = 1 };
+enum { GHN3_ACT_NONE = 0, GHN3_ACT_RELU = 1, GHN3_ACT_GELU = 2 };
+/* multiply by a derivative evaluated at aux_in(m,n) (same layout/map as C) */
+enum { GHN3_DACT_NONE = 0, GHN3_DACT_RELU = 1 /* aux_in > 0 */, GHN3_DACT_GELU = 2 /* gelu'(aux_in) */ };
+#define GHN3_GEMM_ACCUM 1u
+
+typedef struct ghn3_gemm_problem {
+    ghn3_ref A, B, C;
+    ghn3_ref bias, residual, aux_in, aux_out;
+    ghn3_ref a_gather, b_gather, c_gather;     /* int32 index arrays */
+    int32_t M, N, K;
+    int32_t lda, ldb, ldc;
+    int32_t a_mode, b_mode;
+    int32_t a_q, a_s, b_q, b_s, c_q, c_s;
+    int32_t bias_q, bias_s, bias_stride;
+    int32_t act, dact, flags;
+    float alpha;
+    int32_t _pad;
+} ghn3_gemm_problem;
+
+/* ---- tile / normalise descriptors  (nn.py:422-506 _tile_params, 554-592 _normalize, 508-552 _set_params)
+ * dst[a,b,c,d] = f( src[src_off + (a%E0)*S0 + (b%E1)*S1 + (c%E2)*S2 + (d%E3)*S3] )
+ * f: mode 0  x*scale          (fan-in scaling, nn.py:571-583; scale 1 for positional encodings 566-569)
+ *    mode 1  2*sigmoid(x/2)   (1-D weights, nn.py:588)
+ *    mode 2  tanh(x/5)        (1-D biases,  nn.py:590)
+ */
+typedef struct ghn3_tile_desc {
+    int64_t dst_off;        /* element offset into the flat predicted-parameter buffer */
+    int64_t src_off;        /* element offset into the source buffer */
+    int64_t S[4];           /* source strides (elements) */
+    int32_t T[4];           /* target extents (leading dims padded with 1) */
+    int32_t E[4];           /* modulo extents: E[i] <= T[i]; the consumed source region is E0 x E1 x E2 x E3 */
+    int32_t R[4];           /* full source-region extents (>= E): backward writes zeros outside E */
+    int32_t src_buf;        /* index into the op's source table r[1..] */
+    int32_t mode;
+    float scale;
+    int32_t _pad;
+} ghn3_tile_desc;
+
+/* ---- ops ------------------------------------------------------------------------------------------- */
+enum ghn3_op_kind {
+    GHN3_OP_NOP = 0,
+    /* i: first_problem, n_problems, tile(0 auto / 64 / 128), n_tiles_total (filled by host or 0) */
+    GHN3_OP_GEMM = 1,                 /* every nn.Linear / F.linear on the path */
+    /* graphormer.py:229-237 -- degree counts of A==1, A[0,:], fw/bw pair index
+     * r0=A(int64 B,N,N) r1=deg_in r2=deg_out r3=dist0 (int32 B,N) r4=pair (int32 B,N,N); i: B,N,V */
+    GHN3_OP_GRAPH_PROLOGUE = 2,
+    /* nn.py:248-253 + graphormer.py:230-235: type/shape/centrality/input-dist embeddings, dense pad, mask
+     * r0=x out (B,N,C) r1=node_type r2=shape_idx(4 per node) r3=n_nodes r4=node_off (int32)
+     * r5..r9 = tables E_type,E_ch,E_sp,E_in,E_out r10=E_dist r11=deg_in r12=deg_out r13=dist0; i: B,N,C */
+    GHN3_OP_EMBED_NODES = 3,
+    /* graphormer.py:115-117 factorised: hid[fw*V+bw][c] = relu(Pfw[fw][c] + Pbw[bw][c])
+     * r0=hid r1=Pfw r2=Pbw ; i: V,C */
+    GHN3_OP_EDGE_HIDDEN = 4,
+    /* bias[b,h,i,j] = T[pair[b,i,j]][h] ; r0=bias r1=T r2=pair ; i: B,N,H */
+    GHN3_OP_BIAS_GATHER = 5,
+    /* F.layer_norm ; r0=y r1=x r2=gamma r3=beta r4=mean r5=rstd ; i: rows,C ; f0=eps */
+    GHN3_OP_LAYERNORM_FWD = 6,
+    /* graphormer.py:121-140 ; r0=out(B*N,C) r1=qkv(B*N,3C) r2=bias(B,H,N,N) r3=P save or absent r4=n_nodes
+     * i: B,N,C,H */
+    GHN3_OP_ATTN_FWD = 7,
+    /* r0=flat out, r1..r6 = sources, r7 = descriptors (device)
+     * i: n_desc, n_work_blocks, byte offset from r7 to the int64 (descriptor, start) work-block table */
+    GHN3_OP_TILE_FWD = 8,
+    /* sum over predicted tensors of ||p||_F (trainer.py:97-98,288-294)
+     * r0=loss(1 float, accumulated) r1=flat r2=seg_off(int64 (begin,end) pairs) r3=norms(n floats) ; i: n_seg */
+    GHN3_OP_PARAM_NORM_FWD = 9,
+    /* r0=dflat r1=flat r2=seg_off r3=norms ; i: n_seg ; f0 = upstream grad */
+    GHN3_OP_PARAM_NORM_BWD = 10,
+    /* r0=dflat, r1..r6 = source buffers (values), r7=desc, r8..r13 = source-grad buffers
+     * i: n_desc, n_work_blocks, byte offset from r7 to the backward work-block table */
+    GHN3_OP_TILE_BWD = 11,
+    /* column sums: out[omap(n)] += sum_m X[g(m)][n] ; r0=out r1=X r2=row gather (int32) or absent
+     * i: M,N,ld,q,s,stride,accum(must be 1) ; omap(n) = ((n/q)*s + n%q)*stride (q == 0: n*stride) */
+    GHN3_OP_COLSUM = 12,
+    /* segmented row sum: out[r][:] (+)= sum_{t in seg(r)} X[idx[t]][:]
+     * r0=out r1=X r2=seg_ptr(int32 rows+1) r3=idx(int32) ; i: rows,C,ldx,ldo,accum */
+    GHN3_OP_ROWSEG_SUM = 13,
+    /* r0=dx r1=dy r2=x r3=gamma r4=mean r5=rstd r6=residual grad or absent ; i: rows,C */
+    GHN3_OP_LAYERNORM_BWD = 14,
+    /* r0=dgamma r1=dbeta r2=dy r3=x r4=mean r5=rstd ; i: rows,C,accum */
+    GHN3_OP_LN_PARAM_GRAD = 15,
+    /* r0=dqkv r1=dO r2=qkv r3=P r4=O r5=dS scratch r6=dBias (accumulated) r7=n_nodes ; i: B,N,C,H */
+    GHN3_OP_ATTN_BWD = 16,
+    /* dT[p][h] += sum_{pair==p} dBias[b,h,i,j] ; r0=dT r1=dBias r2=pair ; i: B,N,H,V */
+    GHN3_OP_BIAS_HIST = 17,
+    /* r0=dPfw r1=dPbw r2=dhid(in, masked in place) r3=hid ; i: V,C */
+    GHN3_OP_EDGE_HIDDEN_BWD = 18,
+    /* scatter-add of dx(B,N,C) into the six embedding tables; refs as EMBED_NODES with r0=dx and
+     * r5..r10 = table gradients */
+    GHN3_OP_EMBED_BWD = 19,
+    /* r0=dst ; i0 = bytes */
+    GHN3_OP_MEMSET0 = 20,
+    /* r0=dst r1=src ; i0 = n floats ; dst += src */
+    GHN3_OP_ADD = 21,
+    GHN3_OP_KIND_COUNT
+};
+
+typedef struct ghn3_op {
+    int32_t kind;
+    int32_t flags;
+    int64_t i[8];
+    float f[4];
+    ghn3_ref r[14];
+} ghn3_op;
+
+typedef struct ghn3_ctx ghn3_ctx;
+
+/* Library identity. */
+int ghn3_abi_version(void);
+const char* ghn3_last_error(void);
+
+/* Context: owns a small pinned+device staging area for resolved GEMM problem tables. */
+int ghn3_ctx_create(ghn3_ctx** out);
+void ghn3_ctx_destroy(ghn3_ctx* ctx);
+
+/* Arithmetic type of the MFMA operands of GHN3_OP_GEMM (accumulation is always fp32; operands stay fp32
+ * in HBM and are converted while staged through LDS).  A GEMM op may override the context default with
+ * (op.flags & 0xff) = 1 + GHN3_CT_*; 0 keeps the default. */
+enum { GHN3_CT_F32 = 0, GHN3_CT_F16 = 1, GHN3_CT_BF16 = 2 };
+int ghn3_ctx_set_compute_type(ghn3_ctx* ctx, int ctype);
+
+/*
+ * Run ops[0..n_ops) on `stream`.  `problems` is the host array the GEMM ops index into; `bufs` is the
+ * table of device pointers the refs index into.  Replaces the body of GHN3.forward after
+ * _map_net_params (nn.py:247-328) and, for backward programs, the autograd graph of the same lines.
+ * `stream` is a hipStream_t passed as void*.
+ */
+int ghn3_run(ghn3_ctx* ctx, const ghn3_op* ops, int n_ops,
+             const ghn3_gemm_problem* problems, int n_problems,
+             void* const* bufs, int n_bufs, void* stream);
+
+/* Timing helper for bench.py: HIP events on `stream` (torch.cuda.Event only sees torch's current stream).
+ * ghn3_event_elapsed_ms synchronises on the stop event. */
+int ghn3_event_create(void** ev);
+int ghn3_event_record(void* ev, void* stream);
+int ghn3_event_elapsed_ms(void* start, void* stop, float* ms);
+int ghn3_event_destroy(void* ev);
+
+/* Per-op timing with HIP events on the run's stream.
+ *   mode 1: every op is bracketed and synchronised (diagnostic; perturbs timing) -> ghn3_profile_read
+ *   mode 2: only ops whose flags carry GHN3_OPFLAG_TIMED get an event pair from a pool, nothing is
+ *           synchronised until ghn3_profile_read_tags; the tag is (op.flags >> 16) & 255. */
+#define GHN3_OPFLAG_TIMED 0x100
+int ghn3_profile_enable(ghn3_ctx* ctx, int mode);
+int ghn3_profile_read(ghn3_ctx* ctx, double* ms_per_kind /* [GHN3_OP_KIND_COUNT] */,
+                      int64_t* launches_per_kind, int reset);
+int ghn3_profile_read_tags(ghn3_ctx* ctx, double* ms_per_tag /* [256] */, int64_t* n_per_tag /* [256] */,
+                           int reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GHN3_HIP_H */

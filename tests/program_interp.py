@@ -1,0 +1,408 @@
+"""
+TEST INFRASTRUCTURE: a numpy interpreter of the ghn3_op programs (include/ghn3_hip.h semantics).
+
+It lets the CPU test-suite validate the host-side compiler (ghn3_amd/program.py: op order, buffer offsets,
+GEMM addressing modes, tile descriptors, the whole backward program) against the oracle without a GPU.  It is
+never imported by the package and is not a fallback: ghn3_amd raises without libghn3_hip.so + a HIP device.
+"""
+
+import math
+import numpy as np
+from scipy.special import erf
+
+from ghn3_amd import _lib as L
+
+
+class Interp:
+    def __init__(self, bufs):
+        """bufs: list of numpy uint8 arrays (or None), indexed like the device pointer table."""
+        self.bufs = bufs
+
+    # ---- memory views -----------------------------------------------------------------------------
+    def view(self, ref, dtype, count):
+        buf, off = int(ref['buf']), int(ref['off'])
+        if buf < 0:
+            return None
+        b = self.bufs[buf]
+        assert b is not None, 'absent buffer %d' % buf
+        item = np.dtype(dtype).itemsize
+        assert off % item == 0
+        out = b[off:off + count * item].view(dtype)
+        assert len(out) == count, (buf, off, count, len(b))
+        return out
+
+    def fview(self, ref, count):
+        return self.view(ref, np.float32, count)
+
+    def tail(self, ref, dtype):
+        buf, off = int(ref['buf']), int(ref['off'])
+        if buf < 0:
+            return None
+        b = self.bufs[buf]
+        n = (len(b) - off) // np.dtype(dtype).itemsize
+        return b[off:off + n * np.dtype(dtype).itemsize].view(dtype)
+
+    # ---- ops -----------------------------------------------------------------------------------------
+    def run(self, ops, problems):
+        for o in ops:
+            kind = int(o['kind'])
+            getattr(self, 'op_' + L.OP_NAMES[kind])(o, problems)
+
+    def op_nop(self, o, problems):
+        pass
+
+    @staticmethod
+    def _rowmap(r, g, q, s):
+        r = np.asarray(r, dtype=np.int64)
+        if g is not None:
+            r = g[r].astype(np.int64)
+        if q > 0:
+            r = (r // q) * s + (r % q)
+        return r
+
+    def op_gemm(self, o, problems):
+        first, cnt = int(o['i'][0]), int(o['i'][1])
+        for p in problems[first:first + cnt]:
+            M, N, K = int(p['M']), int(p['N']), int(p['K'])
+            if M <= 0 or N <= 0:
+                continue
+            lda, ldb, ldc = int(p['lda']), int(p['ldb']), int(p['ldc'])
+            XA, XB, Y = self.tail(p['A'], np.float32), self.tail(p['B'], np.float32), self.tail(p['C'], np.float32)
+            ga, gb, gc = (self.tail(p[n], np.int32) for n in ('a_gather', 'b_gather', 'c_gather'))
+            assert lda % 4 == 0 and ldb % 4 == 0 and int(p['A']['off']) % 16 == 0 and int(p['B']['off']) % 16 == 0
+            if int(p['a_mode']) == L.MODE_ROW:
+                ra = self._rowmap(np.arange(M), ga, int(p['a_q']), int(p['a_s']))
+                A = XA[(ra[:, None] * lda + np.arange(K)[None, :])]
+            else:
+                ra = self._rowmap(np.arange(K), ga, int(p['a_q']), int(p['a_s']))
+                A = XA[(ra[None, :] * lda + np.arange(M)[:, None])]
+            if int(p['b_mode']) == L.MODE_ROW:
+                rb = self._rowmap(np.arange(N), gb, int(p['b_q']), int(p['b_s']))
+                Bm = XB[(rb[None, :] * ldb + np.arange(K)[:, None])]
+            else:
+                rb = self._rowmap(np.arange(K), gb, int(p['b_q']), int(p['b_s']))
+                Bm = XB[(rb[:, None] * ldb + np.arange(N)[None, :])]
+            v = (A.astype(np.float64) @ Bm.astype(np.float64)) * float(p['alpha'])
+            rc = self._rowmap(np.arange(M), gc, int(p['c_q']), int(p['c_s']))
+            ci = rc[:, None] * ldc + np.arange(N)[None, :]
+            if int(p['bias']['buf']) >= 0:
+                bias = self.tail(p['bias'], np.float32)
+                n = np.arange(N)
+                bi = n
+                if int(p['bias_q']) > 0:
+                    bi = (n // int(p['bias_q'])) * int(p['bias_s']) + n % int(p['bias_q'])
+                stride = int(p['bias_stride']) or 1
+                v = v + bias[bi * stride].astype(np.float64)[None, :]
+            if int(p['aux_out']['buf']) >= 0:
+                self.tail(p['aux_out'], np.float32)[ci] = v.astype(np.float32)
+            act = int(p['act'])
+            if act == L.ACT_RELU:
+                v = np.maximum(v, 0)
+            elif act == L.ACT_GELU:
+                v = 0.5 * v * (1 + erf(v / math.sqrt(2)))
+            dact = int(p['dact'])
+            if dact != L.DACT_NONE:
+                z = self.tail(p['aux_in'], np.float32)[ci].astype(np.float64)
+                if dact == L.DACT_RELU:
+                    v = np.where(z > 0, v, 0.0)
+                else:
+                    v = v * (0.5 * (1 + erf(z / math.sqrt(2))) + z * np.exp(-0.5 * z * z) / math.sqrt(2 * math.pi))
+            if int(p['residual']['buf']) >= 0:
+                v = v + self.tail(p['residual'], np.float32)[ci]
+            if int(p['flags']) & L.GEMM_ACCUM:
+                v = v + Y[ci]
+            Y[ci] = v.astype(np.float32)
+
+    def op_graph_prologue(self, o, problems):
+        B, N, V = (int(v) for v in o['i'][:3])
+        A = self.view(o['r'][0], np.int64, B * N * N).reshape(B, N, N)
+        one = (A == 1)
+        self.view(o['r'][1], np.int32, B * N)[:] = np.minimum(one.sum(1), 100).reshape(-1)
+        self.view(o['r'][2], np.int32, B * N)[:] = np.minimum(one.sum(2), 100).reshape(-1)
+        self.view(o['r'][3], np.int32, B * N)[:] = np.clip(A[:, 0, :], 0, 1000).reshape(-1)
+        f = np.clip(A, 0, V - 1)
+        self.view(o['r'][4], np.int32, B * N * N)[:] = (f * V + f.transpose(0, 2, 1)).reshape(-1)
+
+    def _embed_common(self, o):
+        B, N, C = (int(v) for v in o['i'][:3])
+        n_nodes = self.view(o['r'][3], np.int32, B)
+        total = int(n_nodes.sum())
+        types = self.view(o['r'][1], np.int32, total)
+        shp = self.view(o['r'][2], np.int32, 4 * total).reshape(total, 4)
+        noff = self.view(o['r'][4], np.int32, B)
+        deg_in = self.view(o['r'][11], np.int32, B * N)
+        deg_out = self.view(o['r'][12], np.int32, B * N)
+        dist0 = self.view(o['r'][13], np.int32, B * N)
+        return B, N, C, n_nodes, types, shp, noff, deg_in, deg_out, dist0
+
+    def op_embed_nodes(self, o, problems):
+        B, N, C, n_nodes, types, shp, noff, deg_in, deg_out, dist0 = self._embed_common(o)
+        cq = C // 4
+        x = self.fview(o['r'][0], B * N * C).reshape(B * N, C)
+        T = [self.tail(o['r'][k], np.float32) for k in range(5, 11)]
+        Et, Ech, Esp = T[0].reshape(-1, C), T[1].reshape(-1, cq), T[2].reshape(-1, cq)
+        Ein, Eout, Ed = T[3].reshape(-1, C), T[4].reshape(-1, C), T[5].reshape(-1, C)
+        for b in range(B):
+            for i in range(N):
+                row = b * N + i
+                if i >= n_nodes[b]:
+                    x[row] = 0
+                    continue
+                s = noff[b] + i
+                v = Et[types[s]] + np.concatenate([Ech[shp[s, 0]], Ech[shp[s, 1]], Esp[shp[s, 2]], Esp[shp[s, 3]]])
+                v = v + Ein[deg_in[row]]
+                v = v + Eout[deg_out[row]]
+                v = v + Ed[dist0[row]]
+                x[row] = v
+
+    def op_embed_bwd(self, o, problems):
+        B, N, C, n_nodes, types, shp, noff, deg_in, deg_out, dist0 = self._embed_common(o)
+        cq = C // 4
+        dx = self.fview(o['r'][0], B * N * C).reshape(B * N, C)
+        T = [self.tail(o['r'][k], np.float32) for k in range(5, 11)]
+
+        def tab(t, w):
+            n = len(t) // w
+            return t[:n * w].reshape(n, w)
+        Et, Ech, Esp, Ein, Eout, Ed = tab(T[0], C), tab(T[1], cq), tab(T[2], cq), tab(T[3], C), tab(T[4], C), \
+            tab(T[5], C)
+        for b in range(B):
+            for i in range(int(n_nodes[b])):
+                row = b * N + i
+                s = noff[b] + i
+                g = dx[row]
+                Et[types[s]] += g
+                Ech[shp[s, 0]] += g[:cq]
+                Ech[shp[s, 1]] += g[cq:2 * cq]
+                Esp[shp[s, 2]] += g[2 * cq:3 * cq]
+                Esp[shp[s, 3]] += g[3 * cq:]
+                Ein[deg_in[row]] += g
+                Eout[deg_out[row]] += g
+                Ed[dist0[row]] += g
+
+    def op_edge_hidden(self, o, problems):
+        V, C = int(o['i'][0]), int(o['i'][1])
+        Pfw = self.fview(o['r'][1], V * C).reshape(V, C)
+        Pbw = self.fview(o['r'][2], V * C).reshape(V, C)
+        hid = self.fview(o['r'][0], V * V * C).reshape(V, V, C)
+        hid[:] = np.maximum(Pfw[:, None, :] + Pbw[None, :, :], 0)
+
+    def op_edge_hidden_bwd(self, o, problems):
+        V, C = int(o['i'][0]), int(o['i'][1])
+        dhid = self.fview(o['r'][2], V * V * C).reshape(V, V, C)
+        hid = self.fview(o['r'][3], V * V * C).reshape(V, V, C)
+        dhid[:] = np.where(hid > 0, dhid, 0)
+        self.fview(o['r'][0], V * C).reshape(V, C)[:] = dhid.sum(1)
+        self.fview(o['r'][1], V * C).reshape(V, C)[:] = dhid.sum(0)
+
+    def op_bias_gather(self, o, problems):
+        B, N, H = (int(v) for v in o['i'][:3])
+        ldT = (H + 3) // 4 * 4
+        pair = self.view(o['r'][2], np.int32, B * N * N).reshape(B, N, N)
+        T = self.tail(o['r'][1], np.float32)
+        bias = self.fview(o['r'][0], B * H * N * N).reshape(B, H, N, N)
+        for h in range(H):
+            bias[:, h] = T[pair.astype(np.int64) * ldT + h]
+
+    def op_bias_hist(self, o, problems):
+        B, N, H, V = (int(v) for v in o['i'][:4])
+        ldT = (H + 3) // 4 * 4
+        pair = self.view(o['r'][2], np.int32, B * N * N).reshape(-1).astype(np.int64)
+        dB = self.fview(o['r'][1], B * H * N * N).reshape(B, H, N * N)
+        dT = self.fview(o['r'][0], V * V * ldT)
+        for h in range(H):
+            np.add.at(dT, pair * ldT + h, dB[:, h, :].reshape(-1))
+
+    def op_layernorm_fwd(self, o, problems):
+        rows, C = int(o['i'][0]), int(o['i'][1])
+        x = self.fview(o['r'][1], rows * C).reshape(rows, C).astype(np.float64)
+        g, b = self.fview(o['r'][2], C), self.fview(o['r'][3], C)
+        mu = x.mean(1)
+        var = x.var(1)
+        rs = 1.0 / np.sqrt(var + float(o['f'][0]))
+        self.fview(o['r'][0], rows * C).reshape(rows, C)[:] = ((x - mu[:, None]) * rs[:, None] * g + b)
+        if int(o['r'][4]['buf']) >= 0:
+            self.fview(o['r'][4], rows)[:] = mu
+            self.fview(o['r'][5], rows)[:] = rs
+
+    def op_layernorm_bwd(self, o, problems):
+        rows, C = int(o['i'][0]), int(o['i'][1])
+        dy = self.fview(o['r'][1], rows * C).reshape(rows, C).astype(np.float64)
+        x = self.fview(o['r'][2], rows * C).reshape(rows, C).astype(np.float64)
+        g = self.fview(o['r'][3], C).astype(np.float64)
+        mu, rs = self.fview(o['r'][4], rows).astype(np.float64), self.fview(o['r'][5], rows).astype(np.float64)
+        xh = (x - mu[:, None]) * rs[:, None]
+        dg = dy * g
+        dx = rs[:, None] * (dg - dg.mean(1, keepdims=True) - xh * (dg * xh).mean(1, keepdims=True))
+        if int(o['r'][6]['buf']) >= 0:
+            dx = dx + self.fview(o['r'][6], rows * C).reshape(rows, C)
+        self.fview(o['r'][0], rows * C).reshape(rows, C)[:] = dx
+
+    def op_ln_param_grad(self, o, problems):
+        rows, C = int(o['i'][0]), int(o['i'][1])
+        dy = self.fview(o['r'][2], rows * C).reshape(rows, C).astype(np.float64)
+        x = self.fview(o['r'][3], rows * C).reshape(rows, C).astype(np.float64)
+        mu, rs = self.fview(o['r'][4], rows), self.fview(o['r'][5], rows)
+        xh = (x - mu[:, None]) * rs[:, None]
+        dgm, dbt = self.fview(o['r'][0], C), self.fview(o['r'][1], C)
+        if not int(o['i'][2]):
+            dgm[:] = 0
+            dbt[:] = 0
+        dgm += (dy * xh).sum(0)
+        dbt += dy.sum(0)
+
+    def _attn_common(self, o, nn_ref):
+        B, N, C, H = (int(v) for v in o['i'][:4])
+        d = C // H
+        n_nodes = self.view(nn_ref, np.int32, B)
+        valid = np.arange(N)[None, :] < n_nodes[:, None]
+        mask = valid[:, :, None] & valid[:, None, :]
+        return B, N, C, H, d, mask
+
+    def op_attn_fwd(self, o, problems):
+        B, N, C, H, d, mask = self._attn_common(o, o['r'][4])
+        qkv = self.fview(o['r'][1], B * N * 3 * C).reshape(B, N, 3, H, d).astype(np.float64)
+        q, k, v = (qkv[:, :, j].transpose(0, 2, 1, 3) for j in range(3))
+        s = (q @ k.transpose(0, 1, 3, 2)) * d ** -0.5
+        if int(o['r'][2]['buf']) >= 0:
+            s = s + self.fview(o['r'][2], B * H * N * N).reshape(B, H, N, N)
+        s = np.where(mask[:, None], s, -32768.0)
+        s = s - s.max(-1, keepdims=True)
+        p = np.exp(s)
+        p = p / p.sum(-1, keepdims=True)
+        if int(o['r'][3]['buf']) >= 0:
+            self.fview(o['r'][3], B * H * N * N).reshape(B, H, N, N)[:] = p
+        out = (p @ v).transpose(0, 2, 1, 3).reshape(B * N, C)
+        self.fview(o['r'][0], B * N * C).reshape(B * N, C)[:] = out
+
+    def op_attn_bwd(self, o, problems):
+        B, N, C, H, d, mask = self._attn_common(o, o['r'][7])
+        scale = d ** -0.5
+        qkv = self.fview(o['r'][2], B * N * 3 * C).reshape(B, N, 3, H, d).astype(np.float64)
+        q, k, v = (qkv[:, :, j].transpose(0, 2, 1, 3) for j in range(3))
+        P = self.fview(o['r'][3], B * H * N * N).reshape(B, H, N, N).astype(np.float64)
+        dO = self.fview(o['r'][1], B * N * C).reshape(B, N, H, d).transpose(0, 2, 1, 3).astype(np.float64)
+        dV = P.transpose(0, 1, 3, 2) @ dO
+        dP = dO @ v.transpose(0, 1, 3, 2)
+        dS = P * (dP - (P * dP).sum(-1, keepdims=True))
+        dS = np.where(mask[:, None], dS, 0.0)
+        dQ = (dS @ k) * scale
+        dK = (dS.transpose(0, 1, 3, 2) @ q) * scale
+        self.fview(o['r'][5], B * H * N * N).reshape(B, H, N, N)[:] = dS
+        if int(o['r'][6]['buf']) >= 0:
+            self.fview(o['r'][6], B * H * N * N).reshape(B, H, N, N)[:] += dS.astype(np.float32)
+        out = self.fview(o['r'][0], B * N * 3 * C).reshape(B, N, 3, H, d)
+        out[:, :, 0] = dQ.transpose(0, 2, 1, 3)
+        out[:, :, 1] = dK.transpose(0, 2, 1, 3)
+        out[:, :, 2] = dV.transpose(0, 2, 1, 3)
+
+    @staticmethod
+    def _norm(v, mode, scale):
+        if mode == 0:
+            return v * scale
+        if mode == 1:
+            return 2.0 / (1.0 + np.exp(-0.5 * v))
+        return np.tanh(0.2 * v)
+
+    @staticmethod
+    def _norm_grad(v, mode, scale):
+        if mode == 0:
+            return np.full_like(v, scale)
+        if mode == 1:
+            sg = 1.0 / (1.0 + np.exp(-0.5 * v))
+            return sg * (1 - sg)
+        th = np.tanh(0.2 * v)
+        return 0.2 * (1 - th * th)
+
+    def _descs(self, o):
+        n = int(o['i'][0])
+        return self.view(o['r'][7], np.uint8, n * L.TILE_DT.itemsize).view(L.TILE_DT)
+
+    def op_tile_fwd(self, o, problems):
+        flat = self.tail(o['r'][0], np.float32)
+        srcs = [self.tail(o['r'][1 + k], np.float32) for k in range(6)]
+        for D in self._descs(o):
+            T, E, S = D['T'].astype(np.int64), D['E'].astype(np.int64), D['S'].astype(np.int64)
+            idx = [np.arange(T[k]) % E[k] for k in range(4)]
+            so = (idx[0][:, None, None, None] * S[0] + idx[1][None, :, None, None] * S[1] +
+                  idx[2][None, None, :, None] * S[2] + idx[3][None, None, None, :] * S[3]) + int(D['src_off'])
+            v = srcs[int(D['src_buf'])][so.reshape(-1)].astype(np.float64)
+            n = int(np.prod(T))
+            flat[int(D['dst_off']):int(D['dst_off']) + n] = self._norm(v, int(D['mode']), float(D['scale']))
+
+    def op_tile_bwd(self, o, problems):
+        g = self.tail(o['r'][0], np.float32)
+        srcs = [self.tail(o['r'][1 + k], np.float32) for k in range(6)]
+        dsrcs = [self.tail(o['r'][8 + k], np.float32) for k in range(6)]
+        for D in self._descs(o):
+            T, E, S, R = (D[k].astype(np.int64) for k in ('T', 'E', 'S', 'R'))
+            n = int(np.prod(T))
+            gt = g[int(D['dst_off']):int(D['dst_off']) + n].astype(np.float64).reshape(T)
+            acc = np.zeros(tuple(R), dtype=np.float64)
+            sub = np.zeros(tuple(E), dtype=np.float64)
+            idx = [np.arange(T[k]) % E[k] for k in range(4)]
+            np.add.at(sub, (idx[0][:, None, None, None], idx[1][None, :, None, None], idx[2][None, None, :, None],
+                            idx[3][None, None, None, :]), gt)
+            acc[:E[0], :E[1], :E[2], :E[3]] = sub
+            ar = [np.arange(R[k]) for k in range(4)]
+            so = (ar[0][:, None, None, None] * S[0] + ar[1][None, :, None, None] * S[1] +
+                  ar[2][None, None, :, None] * S[2] + ar[3][None, None, None, :] * S[3]) + int(D['src_off'])
+            sv = srcs[int(D['src_buf'])][so.reshape(-1)].astype(np.float64).reshape(tuple(R))
+            acc = acc * self._norm_grad(sv, int(D['mode']), float(D['scale']))
+            inside = np.zeros(tuple(R), dtype=bool)
+            inside[:E[0], :E[1], :E[2], :E[3]] = True
+            acc = np.where(inside, acc, 0.0)
+            dsrcs[int(D['src_buf'])][so.reshape(-1)] = acc.reshape(-1).astype(np.float32)
+
+    def op_param_norm_fwd(self, o, problems):
+        n = int(o['i'][0])
+        flat = self.tail(o['r'][1], np.float32)
+        seg = self.view(o['r'][2], np.int64, 2 * n).reshape(n, 2)
+        norms = self.fview(o['r'][3], n)
+        for s in range(n):
+            norms[s] = np.sqrt((flat[seg[s, 0]:seg[s, 1]].astype(np.float64) ** 2).sum())
+        self.fview(o['r'][0], 1)[0] += norms.astype(np.float64).sum()
+
+    def op_param_norm_bwd(self, o, problems):
+        n = int(o['i'][0])
+        flat = self.tail(o['r'][1], np.float32)
+        dflat = self.tail(o['r'][0], np.float32)
+        seg = self.view(o['r'][2], np.int64, 2 * n).reshape(n, 2)
+        norms = self.fview(o['r'][3], n)
+        for s in range(n):
+            k = float(o['f'][0]) / norms[s] if norms[s] > 0 else 0.0
+            dflat[seg[s, 0]:seg[s, 1]] = flat[seg[s, 0]:seg[s, 1]] * k
+
+    def op_colsum(self, o, problems):
+        M, N, ld, q, s, stride, accum = (int(v) for v in o['i'][:7])
+        assert accum == 1
+        X = self.tail(o['r'][1], np.float32)
+        g = self.tail(o['r'][2], np.int32)
+        rows = np.arange(M) if g is None else g[:M].astype(np.int64)
+        sums = X[rows[:, None] * ld + np.arange(N)[None, :]].astype(np.float64).sum(0)
+        n = np.arange(N)
+        oi = ((n // q) * s + n % q) if q > 0 else n
+        out = self.tail(o['r'][0], np.float32)
+        np.add.at(out, oi * (stride or 1), sums.astype(np.float32))
+
+    def op_rowseg_sum(self, o, problems):
+        rows, C, ldx, ldo, accum = (int(v) for v in o['i'][:5])
+        seg = self.view(o['r'][2], np.int32, rows + 1)
+        idx = self.tail(o['r'][3], np.int32)
+        X = self.tail(o['r'][1], np.float32)
+        out = self.tail(o['r'][0], np.float32)
+        for r in range(rows):
+            acc = out[r * ldo:r * ldo + C].astype(np.float64) if accum else np.zeros(C)
+            for t in range(seg[r], seg[r + 1]):
+                acc = acc + X[int(idx[t]) * ldx:int(idx[t]) * ldx + C]
+            out[r * ldo:r * ldo + C] = acc
+
+    def op_memset0(self, o, problems):
+        n = int(o['i'][0])
+        b = self.bufs[int(o['r'][0]['buf'])]
+        off = int(o['r'][0]['off'])
+        b[off:off + n] = 0
+
+    def op_add(self, o, problems):
+        n = int(o['i'][0])
+        self.fview(o['r'][0], n)[:] += self.fview(o['r'][1], n)

@@ -1,0 +1,142 @@
+"""
+CPU tests of the host-side compiler: the op programs emitted by ghn3_amd/program.py are executed by the
+numpy interpreter in tests/program_interp.py (test infrastructure, same semantics as include/ghn3_hip.h)
+and compared with the oracle.  This validates op order, workspace offsets, GEMM addressing modes, tile
+descriptors and the complete backward program without a GPU.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from oracle import ghn3_ref as R
+from program_interp import Interp
+from util_parity import rel_l2
+
+from ghn3_amd import GHN3, Graph, GraphBatch, _lib as L
+from ghn3_amd.program import Program
+
+
+def _build(cfg, seed, index_mode):
+    oracle = R.GHN3Ref(**cfg, index_mode=index_mode)
+    shapes = {k: tuple(v.shape) for k, v in oracle.state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in recipe.seeded_state_dict(shapes, seed=seed).items()}
+    oracle.load_state_dict(sd)
+    hip = GHN3(**cfg, index_mode=index_mode)
+    hip.load_state_dict(sd)
+    return hip, oracle
+
+
+def _run_program(hip, nets, gb, training=True):
+    gb._cat()
+    cfg = dict(hid=hip.hid, heads=hip.heads, layers=hip.layers, num_classes=hip.num_classes,
+               max_shape=hip.max_shape)
+    prog = Program(cfg, gb.node_info, gb.host_n_nodes(), gb._node_type_host, gb.max_edge, nets,
+                   index_mode=hip.index_mode, training=training)
+    P = prog.P
+    pflat = hip._flat.detach().numpy().copy().view(np.uint8)
+    gflat = np.zeros(hip._flat_numel, dtype=np.float32).view(np.uint8)
+    bufs = [None] * prog.n_bufs
+    for k, off in enumerate(hip._offs):
+        bufs[k] = pflat[4 * int(off):]
+        bufs[P + k] = gflat[4 * int(off):]
+    bufs[prog.xbuf(prog.X_WS)] = np.zeros(prog.ws_bytes, dtype=np.uint8)
+    bufs[prog.xbuf(prog.X_IDX)] = prog.idx_blob.copy()
+    bufs[prog.xbuf(prog.X_EDGES)] = np.ascontiguousarray(gb.edges.numpy()).view(np.uint8).reshape(-1)
+    bufs[prog.xbuf(prog.X_OUT)] = np.zeros(prog.out_numel, dtype=np.float32).view(np.uint8)
+    bufs[prog.xbuf(prog.X_DOUT)] = np.zeros(prog.out_numel, dtype=np.float32).view(np.uint8)
+    bufs[prog.xbuf(prog.X_TOK)] = (0.02 * np.random.RandomState(0).standard_normal(prog.tok_floats)
+                                   ).astype(np.float32).view(np.uint8)
+    bufs[prog.xbuf(prog.X_SCAL)] = np.zeros(256 + 4 * max(prog.n_seg, 1) + 64, dtype=np.uint8)
+    bufs[prog.xbuf(prog.X_GRADFLAT)] = gflat
+    it = Interp(bufs)
+    it.run(prog.fwd_ops, prog.problems)
+    return prog, it, bufs, gflat
+
+
+def _tiny(case):
+    specs = [recipe.TINY_NETS[i] for i in recipe.TINY_CASES[case]]
+    nets_h = [recipe.build_torch_net(s) for s in specs]
+    nets_o = [recipe.build_torch_net(s) for s in specs]
+    gh, go = [], []
+    for s in specs:
+        nf, info, A = recipe.graph_arrays(s)
+        gh.append(Graph(node_feat=nf, node_info=info, A=A))
+        go.append(R.GraphRef(torch.from_numpy(nf), info, torch.from_numpy(A)))
+    return nets_h, GraphBatch(gh, dense=True), nets_o, R.GraphBatchRef(go)
+
+
+@pytest.mark.parametrize('case,index_mode', [('b1', 'reference'), ('b2', 'reference'), ('b2', 'correct')])
+def test_compiled_programs_reproduce_oracle_forward_and_backward(case, index_mode):
+    hip, oracle = _build(recipe.TINY_CFG, recipe.TINY_SEED, index_mode)
+    nets_h, gb_h, nets_o, gb_o = _tiny(case)
+    prog, it, bufs, gflat = _run_program(hip, nets_h, gb_h)
+    out = bufs[prog.xbuf(prog.X_OUT)].view(np.float32)
+    oracle.train()
+    _, pred_o = oracle(nets_o, gb_o, keep_grads=True)
+    assert len(pred_o) == len(prog.predicted)
+    loss_o = 0
+    for k, (ind, attr, m, t) in enumerate(pred_o):
+        p = prog.predicted[k]
+        assert p['node'] == ind and p['attr'] == attr and tuple(p['tile_shape']) == tuple(t.shape)
+        got = out[p['offset']:p['offset'] + p['numel']].reshape(p['tile_shape'])
+        ref = t.detach().numpy()
+        if ref.ndim == 3:
+            got, ref = got[:, 1:], ref[:, 1:]
+        assert rel_l2(got, ref) < 1e-5, (k, attr, ref.shape, rel_l2(got, ref))
+        q = t[:, 1:] if t.dim() == 3 else t
+        loss_o = loss_o + torch.norm(q, p='fro')
+    # backward: upstream gradient = d(sum of Frobenius norms)/d(out), random row of pos-enc excluded
+    dout = bufs[prog.xbuf(prog.X_DOUT)].view(np.float32)
+    for p in prog.predicted:
+        v = out[p['offset']:p['offset'] + p['numel']].reshape(p['tile_shape']).astype(np.float64)
+        g = np.zeros_like(v)
+        if v.ndim == 3:
+            g[:, 1:] = v[:, 1:] / np.linalg.norm(v[:, 1:])
+        else:
+            g = v / np.linalg.norm(v)
+        dout[p['offset']:p['offset'] + p['numel']] = g.reshape(-1)
+    prog.bwd_ops[prog.memset_grad_op]['i'][0] = len(gflat)
+    it.run(prog.bwd_ops, prog.problems)
+    loss_o.backward()
+    po = dict(oracle.named_parameters())
+    g32 = gflat.view(np.float32)
+    for name, off in zip(prog.names, hip._offs):
+        ref = po[name].grad.numpy()
+        got = g32[int(off):int(off) + ref.size].reshape(ref.shape)
+        # (the edge-MLP output bias has an analytically zero gradient: softmax is shift invariant)
+        err = float(np.linalg.norm(got.astype(np.float64) - ref))
+        assert err < 5e-5 * float(np.linalg.norm(ref)) + 1e-6, (name, err, float(np.linalg.norm(ref)))
+
+
+def test_param_norm_ops():
+    hip, oracle = _build(recipe.TINY_CFG, recipe.TINY_SEED, 'reference')
+    nets_h, gb_h, _, _ = _tiny('b1')
+    prog, it, bufs, gflat = _run_program(hip, nets_h, gb_h)
+    f_ops, b_ops = prog.norm_ops(1.0)
+    it.run(f_ops, prog.problems)
+    out = bufs[prog.xbuf(prog.X_OUT)].view(np.float32)
+    expect = sum(np.linalg.norm(out[p['offset']:p['offset'] + p['numel']].astype(np.float64))
+                 for p in prog.predicted)
+    loss = bufs[prog.xbuf(prog.X_SCAL)][:4].view(np.float32)[0]
+    assert abs(loss - expect) < 1e-4 * expect
+    it.run(b_ops, prog.problems)
+    dout = bufs[prog.xbuf(prog.X_DOUT)].view(np.float32)
+    p = prog.predicted[3]
+    v = out[p['offset']:p['offset'] + p['numel']].astype(np.float64)
+    np.testing.assert_allclose(dout[p['offset']:p['offset'] + p['numel']], v / np.linalg.norm(v), rtol=1e-5,
+                               atol=1e-7)
+
+
+def test_synthetic_program_and_counts():
+    from ghn3_amd.synthetic import synthetic_batch
+    gb, nets = synthetic_batch([40, 31], 777)
+    gb._cat()
+    cfg = dict(hid=32, heads=8, layers=2, num_classes=1000, max_shape=(32, 32, 16, 16))
+    prog = Program(cfg, gb.node_info, gb.host_n_nodes(), gb._node_type_host, gb.max_edge, nets)
+    assert sum(p['numel'] for p in prog.predicted) == sum(n.num_params() for n in nets)
+    assert prog.B == 2 and prog.N == 40
+    # every GEMM operand obeys the ABI alignment rules
+    for p in prog.problems:
+        assert p['lda'] % 4 == 0 and p['ldb'] % 4 == 0 and p['A']['off'] % 16 == 0 and p['B']['off'] % 16 == 0

@@ -1,0 +1,54 @@
+"""World-size-2 gloo tests of the data-parallel exchange (one process per rank, like one process per GPU)."""
+
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from ghn3_amd.ddp_utils import setup_ddp, all_reduce_flat_grads, avg_ddp_metric, is_ddp, get_ddp_rank, clean_ddp
+    from ghn3_amd.synthetic import synthetic_batch
+    args = setup_ddp()
+    assert args.ddp and is_ddp() and get_ddp_rank() == rank and args.world_size == world
+    # the flat gradient buffer: chunked async all-reduce must equal the mean over ranks, for odd sizes too
+    n = 1000003
+    g = torch.arange(n, dtype=torch.float32) * (rank + 1)
+    all_reduce_flat_grads(g, chunk_bytes=1 << 20)
+    expect = torch.arange(n, dtype=torch.float32) * (sum(range(1, world + 1)) / world)
+    ok_grad = bool(torch.allclose(g, expect, rtol=1e-6))
+    m = avg_ddp_metric(torch.tensor(float(rank + 1)))
+    ok_metric = abs(m.item() - (world + 1) / 2) < 1e-6
+    # per-rank synthetic graph streams are disjoint and deterministic (seed = N*1000 + rank)
+    gb, nets = synthetic_batch([24], 24000 + rank)
+    sig = int(sum(n_.num_params() for n_ in nets))
+    sigs = [None] * world
+    dist.all_gather_object(sigs, sig)
+    ret[rank] = (ok_grad, ok_metric, sigs)
+    clean_ddp()
+
+
+def test_flat_gradient_allreduce_and_metric_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        ok_grad, ok_metric, sigs = ret[r]
+        assert ok_grad and ok_metric
+        assert len(set(sigs)) == world, sigs        # different target nets per rank

@@ -109,7 +109,6 @@ def main():
     n_pred = sum(p['numel'] for p in prog.predicted)
     f_norm, b_norm = prog.norm_ops(1.0)
     ctx = L.context(local_rank)
-    ctx.set_compute_type(args.compute)
     stream = torch.cuda.current_stream().cuda_stream
     dout = torch.empty(prog.out_numel, dtype=torch.float32, device=dev)
 

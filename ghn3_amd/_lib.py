@@ -30,6 +30,7 @@ MODE_ROW, MODE_COL = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 DACT_NONE, DACT_RELU, DACT_GELU = 0, 1, 2
 GEMM_ACCUM = 1
+GEMM_BIASGRAD = 2
 CT_F32, CT_F16, CT_BF16 = 0, 1, 2
 COMPUTE_TYPES = {'f32': CT_F32, 'f16': CT_F16, 'bf16': CT_BF16}
 

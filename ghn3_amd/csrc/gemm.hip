@@ -15,6 +15,16 @@
 
 #include "ghn3_internal.h"
 
+// Pointers read from the problem table are generic ("flat") to the compiler; flat loads tick BOTH vmcnt and
+// lgkmcnt, so every LDS wait would also drain the global prefetch.  All global accesses therefore go through
+// explicit address-space-1 pointers (global_load / global_store).
+#define GAS __attribute__((address_space(1)))
+typedef const float GAS* gcf;
+typedef float GAS* gf;
+typedef const int GAS* gci;
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef const f32x4 GAS* gcf4;
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -23,7 +33,7 @@ typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 #define ROWM GHN3_MODE_ROW
 #define COLM GHN3_MODE_COL
 
-__device__ __forceinline__ int map_row(int r, const int* gather, int q, int s) {
+__device__ __forceinline__ int map_row(int r, gci gather, int q, int s) {
     if (gather) r = gather[r];
     if (q > 0) r = (r / q) * s + (r % q);
     return r;
@@ -43,17 +53,32 @@ __device__ __forceinline__ const GemmProbDev* find_problem(const GemmProbDev* pr
     return probs + lo;
 }
 
+// Tile order.  Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private
+// L2).  All m-tiles of one n-tile read the same B rows (the streamed weight rows), so they are given block
+// ids that are congruent mod 8: n_tile = ((t / 8) / tiles_m) * 8 + t % 8, m_tile = (t / 8) % tiles_m.
+// tile_start of every problem is a multiple of 8 and the n-tile count is padded to a multiple of 8 (surplus
+// blocks exit), so the B panel is fetched into one L2 instead of up to eight.
+template <int BM, int BN>
+__device__ __forceinline__ bool tile_origin(const GemmProbDev* P, int t, int& m0, int& n0) {
+    const int tiles_m = P->tiles_m;
+    const int grp = t >> 3;
+    const int nt = (grp / tiles_m) * 8 + (t & 7);
+    m0 = (grp % tiles_m) * BM;
+    n0 = nt * BN;
+    return n0 < P->N;
+}
+
 // Epilogue shared by all variants.  acc tile layout (32x32 MFMA C/D): col = lane & 31,
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
 template <int TM, int TN>
 __device__ __forceinline__ void epilogue(const GemmProbDev* P, f32x16 (&acc)[TM][TN], int m_base, int n_base, int lane) {
     const int M = P->M, N = P->N, ldc = P->ldc;
-    float* __restrict__ C = P->C;
-    const float* __restrict__ bias = P->bias;
-    const float* __restrict__ residual = P->residual;
-    const float* __restrict__ aux_in = P->aux_in;
-    float* __restrict__ aux_out = P->aux_out;
-    const int* cg = P->c_gather;
+    gf C = (gf)P->C;
+    gcf bias = (gcf)P->bias;
+    gcf residual = (gcf)P->residual;
+    gcf aux_in = (gcf)P->aux_in;
+    gf aux_out = (gf)P->aux_out;
+    gci cg = (gci)P->c_gather;
     const int cq = P->c_q, cs = P->c_s;
     const int act = P->act, dact = P->dact;
     const bool accum = (P->flags & GHN3_GEMM_ACCUM) != 0;
@@ -64,7 +89,7 @@ __device__ __forceinline__ void epilogue(const GemmProbDev* P, f32x16 (&acc)[TM]
         const int col = n_base + tn * 32 + l31;
         const bool col_ok = col < N;
         float bv = 0.f;
-        if (bias && col_ok) {
+        if (bias && col_ok && !(P->flags & GHN3_GEMM_BIASGRAD)) {
             int bi = col;
             if (P->bias_q > 0) bi = (col / P->bias_q) * P->bias_s + (col % P->bias_q);
             bv = bias[(int64_t)bi * P->bias_stride];
@@ -106,17 +131,17 @@ template <int ROWS, int MODE> struct F32Tile {
 template <int ROWS, int MODE>
 struct F32Loader {
     using T = F32Tile<ROWS, MODE>;
-    const float* base; const int* gather; int q, s, ld;
+    gcf base; gci gather; int q, s, ld;
     int lim_rows, lim_k;          // logical extents (rows = M or N ; k = K)
     int r0;                       // tile origin along rows
     // ROW mode state
-    const float* ptr[T::NV]; bool ok[T::NV]; int kc, rr;
+    gcf ptr[T::NV]; bool ok[T::NV]; int kc, rr;
     // COL mode state
     int mc, kr; bool ok_m;
 
     __device__ __forceinline__ void init(const float* b, const int* g, int q_, int s_, int ld_, int rows, int K,
                                          int origin, int tid) {
-        base = b; gather = g; q = q_; s = s_; ld = ld_; lim_rows = rows; lim_k = K; r0 = origin;
+        base = (gcf)b; gather = (gci)g; q = q_; s = s_; ld = ld_; lim_rows = rows; lim_k = K; r0 = origin;
         if (MODE == ROWM) {
             kc = tid & 7; rr = tid >> 3;
 #pragma unroll
@@ -131,18 +156,15 @@ struct F32Loader {
             ok_m = (r0 + mc * 4) < lim_rows;
         }
     }
-    __device__ __forceinline__ void load(int kt, float4 (&v)[T::NV]) const {
+    // load() only ISSUES the global loads (no use of the results: the tail masking that would force an
+    // s_waitcnt right behind every load is applied in store(), after the MFMA loop of the current tile).
+    __device__ __forceinline__ void load(int kt, f32x4 (&v)[T::NV]) const {
         if (MODE == ROWM) {
             const int k = kt * T::BK + kc * 4;
 #pragma unroll
             for (int i = 0; i < T::NV; ++i) {
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (ok[i] && k < lim_k) {
-                    x = *reinterpret_cast<const float4*>(ptr[i] + kt * T::BK);
-                    if (k + 1 >= lim_k) x.y = 0.f;
-                    if (k + 2 >= lim_k) x.z = 0.f;
-                    if (k + 3 >= lim_k) x.w = 0.f;
-                }
+                f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                if (ok[i] && k < lim_k) x = *reinterpret_cast<gcf4>(ptr[i] + kt * T::BK);
                 v[i] = x;
             }
         } else {
@@ -150,29 +172,39 @@ struct F32Loader {
 #pragma unroll
             for (int i = 0; i < T::NV; ++i) {
                 const int k = kt * T::BK + kr + T::RPP * i;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                f32x4 x = {0.f, 0.f, 0.f, 0.f};
                 if (ok_m && k < lim_k) {
                     const int r = map_row(k, gather, q, s);
-                    x = *reinterpret_cast<const float4*>(base + (int64_t)r * ld + m);
-                    if (m + 1 >= lim_rows) x.y = 0.f;
-                    if (m + 2 >= lim_rows) x.z = 0.f;
-                    if (m + 3 >= lim_rows) x.w = 0.f;
+                    x = *reinterpret_cast<gcf4>(base + (int64_t)r * ld + m);
                 }
                 v[i] = x;
             }
         }
     }
-    __device__ __forceinline__ void store(float* lds, const float4 (&v)[T::NV]) const {
+    __device__ __forceinline__ void mask_tail(int kt, f32x4& x) const {
+        // elements beyond the logical extent along the contiguous dimension read as zero
+        const int c0 = (MODE == ROWM) ? kt * T::BK + kc * 4 : r0 + mc * 4;
+        const int lim = (MODE == ROWM) ? lim_k : lim_rows;
+        if (c0 + 3 >= lim) {
+            if (c0 + 1 >= lim) x.y = 0.f;
+            if (c0 + 2 >= lim) x.z = 0.f;
+            if (c0 + 3 >= lim) x.w = 0.f;
+        }
+    }
+    __device__ __forceinline__ void store(float* lds, f32x4 (&v)[T::NV], int kt) const {
         if (MODE == ROWM) {
 #pragma unroll
             for (int i = 0; i < T::NV; ++i) {
+                mask_tail(kt, v[i]);
                 float* p = lds + (rr + 32 * i) * T::LD + kc * 4;
                 p[0] = v[i].x; p[1] = v[i].y; p[2] = v[i].z; p[3] = v[i].w;
             }
         } else {
 #pragma unroll
-            for (int i = 0; i < T::NV; ++i)
-                *reinterpret_cast<float4*>(lds + (kr + T::RPP * i) * T::LD + mc * 4) = v[i];
+            for (int i = 0; i < T::NV; ++i) {
+                mask_tail(kt, v[i]);
+                *reinterpret_cast<f32x4*>(lds + (kr + T::RPP * i) * T::LD + mc * 4) = v[i];
+            }
         }
     }
 };
@@ -188,7 +220,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmProbDev* __rest
 
     const GemmProbDev* P = find_problem(probs, n_probs, blockIdx.x);
     const int t = blockIdx.x - P->tile_start;
-    const int m0 = (t % P->tiles_m) * BM, n0 = (t / P->tiles_m) * BN;
+    int m0, n0;
+    if (!tile_origin<BM, BN>(P, t, m0, n0)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -207,9 +240,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmProbDev* __rest
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (K + BK - 1) / BK;
-    float4 ra[TA::NV], rb[TB::NV];
+    // fused bias gradient (wgrad problems): row sums of the COL-mode A tile, done by the n-tile-0 blocks
+    const bool do_bg = (AM == COLM) && (P->flags & GHN3_GEMM_BIASGRAD) && n0 == 0;
+    float bg = 0.f;
+    f32x4 ra[TA::NV], rb[TB::NV];
     la.load(0, ra); lb.load(0, rb);
-    la.store(smem, ra); lb.store(smem + TA::SIZE, rb);
+    la.store(smem, ra, 0); lb.store(smem + TA::SIZE, rb, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
@@ -217,6 +253,12 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmProbDev* __rest
         if (more) { la.load(kt + 1, ra); lb.load(kt + 1, rb); }
         const float* a_s = smem + cur * STAGE;
         const float* b_s = a_s + TA::SIZE;
+        if (AM == COLM) {
+            if (do_bg && tid < BM) {
+#pragma unroll 8
+                for (int kk = 0; kk < BK; ++kk) bg += a_s[kk * TA::LD + tid];
+            }
+        }
 #pragma unroll 4
         for (int kk = 0; kk < BK; kk += 2) {
             float af[TM], bf[TN];
@@ -236,9 +278,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmProbDev* __rest
         }
         if (more) {
             float* nx = smem + (cur ^ 1) * STAGE;
-            la.store(nx, ra); lb.store(nx + TA::SIZE, rb);
+            la.store(nx, ra, kt + 1); lb.store(nx + TA::SIZE, rb, kt + 1);
         }
         __syncthreads();
+    }
+    if (do_bg && tid < BM && m0 + tid < P->M) {
+        gf dbias = (gf)P->bias;
+        const int64_t bi = (int64_t)map_row(m0 + tid, (gci)P->c_gather, P->c_q, P->c_s) * P->bias_stride;
+        dbias[bi] += bg;
     }
     epilogue<TM, TN>(P, acc, m0 + wm0, n0 + wn0, lane);
 }
@@ -259,6 +306,11 @@ template <> __device__ __forceinline__ unsigned short cvt16<GHN3_CT_BF16>(float 
     return (unsigned short)(u >> 16);
 }
 
+template <int CT> __device__ __forceinline__ float cvt_back(unsigned short h) {
+    if (CT == GHN3_CT_F16) return (float)__builtin_bit_cast(_Float16, h);
+    return __builtin_bit_cast(float, ((unsigned)h) << 16);
+}
+
 template <int ROWS, int MODE, int CT>
 struct H16Loader {
     static constexpr int BK = 64;
@@ -267,13 +319,13 @@ struct H16Loader {
     // ROW: thread -> (row = tid/8 + 32 i, 8 k at kc*8), i < ROWS/32, 2 float4 each
     // COL: thread -> micro tile 4 rows x 8 k: kg = tid & 7, mg = tid >> 3 (mg < ROWS/4), 8 float4
     static constexpr int NV = (MODE == ROWM) ? (ROWS / 32) * 2 : 8;
-    const float* base; const int* gather; int q, s, ld, lim_rows, lim_k, r0;
-    const float* ptr[ROWS / 32]; bool ok[ROWS / 32]; int kc, rr;
+    gcf base; gci gather; int q, s, ld, lim_rows, lim_k, r0;
+    gcf ptr[ROWS / 32]; bool ok[ROWS / 32]; int kc, rr;
     int kg, mg; bool ok_m, active;
 
     __device__ __forceinline__ void init(const float* b, const int* g, int q_, int s_, int ld_, int rows, int K,
                                          int origin, int tid) {
-        base = b; gather = g; q = q_; s = s_; ld = ld_; lim_rows = rows; lim_k = K; r0 = origin;
+        base = (gcf)b; gather = (gci)g; q = q_; s = s_; ld = ld_; lim_rows = rows; lim_k = K; r0 = origin;
         if (MODE == ROWM) {
             kc = tid & 7; rr = tid >> 3;
 #pragma unroll
@@ -289,21 +341,15 @@ struct H16Loader {
             ok_m = active && (r0 + mg * 4) < lim_rows;
         }
     }
-    __device__ __forceinline__ void load(int kt, float4 (&v)[NV]) const {
+    __device__ __forceinline__ void load(int kt, f32x4 (&v)[NV]) const {
         if (MODE == ROWM) {
             const int k = kt * BK + kc * 8;
 #pragma unroll
             for (int i = 0; i < ROWS / 32; ++i) {
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
-                    float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
-                    const int kh = k + 4 * h;
-                    if (ok[i] && kh < lim_k) {
-                        x = *reinterpret_cast<const float4*>(ptr[i] + kt * BK + 4 * h);
-                        if (kh + 1 >= lim_k) x.y = 0.f;
-                        if (kh + 2 >= lim_k) x.z = 0.f;
-                        if (kh + 3 >= lim_k) x.w = 0.f;
-                    }
+                    f32x4 x = {0.f, 0.f, 0.f, 0.f};
+                    if (ok[i] && k + 4 * h < lim_k) x = *reinterpret_cast<gcf4>(ptr[i] + kt * BK + 4 * h);
                     v[i * 2 + h] = x;
                 }
             }
@@ -312,22 +358,28 @@ struct H16Loader {
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int k = kt * BK + kg * 8 + j;
-                float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+                f32x4 x = {0.f, 0.f, 0.f, 0.f};
                 if (ok_m && k < lim_k) {
                     const int r = map_row(k, gather, q, s);
-                    x = *reinterpret_cast<const float4*>(base + (int64_t)r * ld + m);
-                    if (m + 1 >= lim_rows) x.y = 0.f;
-                    if (m + 2 >= lim_rows) x.z = 0.f;
-                    if (m + 3 >= lim_rows) x.w = 0.f;
+                    x = *reinterpret_cast<gcf4>(base + (int64_t)r * ld + m);
                 }
                 v[j] = x;
             }
         }
     }
-    __device__ __forceinline__ void store(unsigned short* lds, const float4 (&v)[NV]) const {
+    __device__ __forceinline__ void mask_tail(int c0, int lim, f32x4& x) const {
+        if (c0 + 3 >= lim) {
+            if (c0 + 1 >= lim) x.y = 0.f;
+            if (c0 + 2 >= lim) x.z = 0.f;
+            if (c0 + 3 >= lim) x.w = 0.f;
+        }
+    }
+    __device__ __forceinline__ void store(unsigned short* lds, f32x4 (&v)[NV], int kt) const {
         if (MODE == ROWM) {
 #pragma unroll
             for (int i = 0; i < ROWS / 32; ++i) {
+                mask_tail(kt * BK + kc * 8, lim_k, v[2 * i]);
+                mask_tail(kt * BK + kc * 8 + 4, lim_k, v[2 * i + 1]);
                 u16x8 h;
                 h[0] = cvt16<CT>(v[2 * i].x); h[1] = cvt16<CT>(v[2 * i].y);
                 h[2] = cvt16<CT>(v[2 * i].z); h[3] = cvt16<CT>(v[2 * i].w);
@@ -339,6 +391,7 @@ struct H16Loader {
             u16x8 h0, h1, h2, h3;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
+                mask_tail(r0 + mg * 4, lim_rows, v[j]);
                 h0[j] = cvt16<CT>(v[j].x); h1[j] = cvt16<CT>(v[j].y);
                 h2[j] = cvt16<CT>(v[j].z); h3[j] = cvt16<CT>(v[j].w);
             }
@@ -371,7 +424,8 @@ __global__ __launch_bounds__(256) void gemm_h16_kernel(const GemmProbDev* __rest
 
     const GemmProbDev* P = find_problem(probs, n_probs, blockIdx.x);
     const int t = blockIdx.x - P->tile_start;
-    const int m0 = (t % P->tiles_m) * BM, n0 = (t / P->tiles_m) * BN;
+    int m0, n0;
+    if (!tile_origin<BM, BN>(P, t, m0, n0)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
@@ -390,9 +444,11 @@ __global__ __launch_bounds__(256) void gemm_h16_kernel(const GemmProbDev* __rest
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const int nk = (K + BK - 1) / BK;
-    float4 ra[LA::NV], rb[LB::NV];
+    const bool do_bg = (AM == COLM) && (P->flags & GHN3_GEMM_BIASGRAD) && n0 == 0;
+    float bg = 0.f;
+    f32x4 ra[LA::NV], rb[LB::NV];
     la.load(0, ra); lb.load(0, rb);
-    la.store(sm16, ra); lb.store(sm16 + LA::SIZE, rb);
+    la.store(sm16, ra, 0); lb.store(sm16 + LA::SIZE, rb, 0);
     __syncthreads();
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
@@ -400,6 +456,16 @@ __global__ __launch_bounds__(256) void gemm_h16_kernel(const GemmProbDev* __rest
         if (more) { la.load(kt + 1, ra); lb.load(kt + 1, rb); }
         const unsigned short* a_s = sm16 + cur * STAGE;
         const unsigned short* b_s = a_s + LA::SIZE;
+        if (AM == COLM) {
+            if (do_bg && tid < BM) {
+#pragma unroll
+                for (int kk = 0; kk < BK; kk += 8) {
+                    const u16x8 h = *reinterpret_cast<const u16x8*>(a_s + tid * LD + kk);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bg += cvt_back<CT>(h[e]);
+                }
+            }
+        }
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             u16x8 af[TM], bf[TN];
@@ -417,9 +483,14 @@ __global__ __launch_bounds__(256) void gemm_h16_kernel(const GemmProbDev* __rest
         }
         if (more) {
             unsigned short* nx = sm16 + (cur ^ 1) * STAGE;
-            la.store(nx, ra); lb.store(nx + LA::SIZE, rb);
+            la.store(nx, ra, kt + 1); lb.store(nx + LA::SIZE, rb, kt + 1);
         }
         __syncthreads();
+    }
+    if (do_bg && tid < BM && m0 + tid < P->M) {
+        gf dbias = (gf)P->bias;
+        const int64_t bi = (int64_t)map_row(m0 + tid, (gci)P->c_gather, P->c_q, P->c_s) * P->bias_stride;
+        dbias[bi] += bg;
     }
     epilogue<TM, TN>(P, acc, m0 + wm0, n0 + wn0, lane);
 }

@@ -225,13 +225,17 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             g.a_q = p.a_q; g.a_s = p.a_s; g.b_q = p.b_q; g.b_s = p.b_s; g.c_q = p.c_q; g.c_s = p.c_s;
                             g.bias_q = p.bias_q; g.bias_s = p.bias_s; g.bias_stride = p.bias_stride ? p.bias_stride : 1;
                             g.act = p.act; g.dact = p.dact; g.flags = p.flags; g.alpha = p.alpha;
+                            if ((p.flags & GHN3_GEMM_BIASGRAD) && (p.a_mode != GHN3_MODE_COL || !g.bias)) {
+                                ghn3_set_error("op %d problem %d: BIASGRAD needs a COL-mode A and a bias ref", k, q);
+                                return GHN3_E_ARG;
+                            }
                             if (!g.A || !g.B || !g.C || (p.dact != GHN3_DACT_NONE && !g.aux_in)) {
                                 ghn3_set_error("op %d problem %d: missing A/B/C/aux_in buffer", k, q);
                                 return GHN3_E_ARG;
                             }
-                            g.tile_start = L.tiles;
+                            g.tile_start = L.tiles;               // always a multiple of 8 (XCD-aware order)
                             g.tiles_m = (p.M + tl - 1) / tl;
-                            L.tiles += g.tiles_m * ((p.N + tl - 1) / tl);
+                            L.tiles += g.tiles_m * ((((p.N + tl - 1) / tl) + 7) / 8 * 8);
                             L.count++;
                         }
                         if (L.count > 0) op_launches[k].push_back(L);

@@ -107,7 +107,9 @@ class GHN3(nn.Module):
 
     Extra keyword arguments (not in the reference):
       index_mode   'reference' (default; reproduces quirk Q1 of SURVEY 3.2 for B > 1) or 'correct'
-      compute      'f32' (default: exact fp32 MFMA), 'f16' or 'bf16' operand type for the decoder GEMMs
+      compute      MFMA operand type of the decoder GEMMs (fc / W0 / W2, forward and backward):
+                   'f32' (default: exact fp32 MFMA), 'f16' or 'bf16' (fp32 accumulate, fp32 in HBM).
+                   The Graphormer and the small heads always run exact fp32.
     """
 
     def __init__(self, max_shape, num_classes, hid, heads=8, layers=3, is_ghn2=False, pretrained=False, **kwargs):
@@ -223,7 +225,7 @@ class GHN3(nn.Module):
         prog = Program(cfg, graphs.node_info, graphs.host_n_nodes(), graphs._node_type_host, graphs.max_edge,
                        nets, index_mode=self.index_mode, training=training,
                        predict_class_layers=predict_class_layers, reduce_graph=reduce_graph,
-                       layernorm=self.layernorm)
+                       layernorm=self.layernorm, decoder_ctype=L.COMPUTE_TYPES[self.compute])
         plan = _Plan(self, prog, graphs.edges, nets)
         plan.graphs = graphs
         return plan
@@ -250,7 +252,7 @@ class GHN3(nn.Module):
 
     def _ctx(self):
         ctx = L.context(self.device.index or 0)
-        ctx.set_compute_type(self.compute)
+        ctx.set_compute_type('f32')          # everything but the decoder GEMMs (Program.decoder_ctype) is fp32
         return ctx
 
     def _run_forward(self, plan):

@@ -54,8 +54,11 @@ class Program:
     X_WS, X_IDX, X_EDGES, X_OUT, X_DOUT, X_TOK, X_SCAL, X_GRADFLAT, X_COUNT = range(9)
 
     def __init__(self, cfg, node_infos, n_nodes, node_types, max_edge, nets, index_mode='reference',
-                 training=True, predict_class_layers=True, reduce_graph=False, layernorm=True):
+                 training=True, predict_class_layers=True, reduce_graph=False, layernorm=True, decoder_ctype=None):
         self.cfg = cfg
+        # MFMA operand type of the decoder GEMMs (fc / W0 / W2, forward and backward): None = context default.
+        # The Graphormer, the edge MLP and the small heads always multiply in exact fp32.
+        self.decoder_ctype = decoder_ctype
         self.C = C = int(cfg['hid'])
         self.H = int(cfg['heads'])
         self.Lyr = int(cfg['layers'])
@@ -165,7 +168,11 @@ class Program:
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, bias=None, bias_q=0,
              bias_s=0, bias_stride=1, act=L.ACT_NONE, dact=L.DACT_NONE, aux_in=None, aux_out=None, residual=None,
              a_gather=None, b_gather=None, c_gather=None, a_qs=(0, 0), b_qs=(0, 0), c_qs=(0, 0), accum=False,
-             alpha=1.0):
+             alpha=1.0, dbias=None, dbias_stride=1):
+        # dbias: fused bias gradient of a wgrad problem (GHN3_GEMM_BIASGRAD): dbias[cmap(m)*stride] += sum_k A(m,k)
+        if dbias is not None:
+            assert bias is None and a_mode == L.MODE_COL
+            bias, bias_stride = dbias, dbias_stride
         p = np.zeros((), dtype=L.PROBLEM_DT)
         for name, ref in (('A', A), ('B', B), ('C', C), ('bias', bias), ('residual', residual), ('aux_in', aux_in),
                           ('aux_out', aux_out), ('a_gather', a_gather), ('b_gather', b_gather),
@@ -176,7 +183,7 @@ class Program:
                         ('b_mode', b_mode), ('a_q', a_qs[0]), ('a_s', a_qs[1]), ('b_q', b_qs[0]), ('b_s', b_qs[1]),
                         ('c_q', c_qs[0]), ('c_s', c_qs[1]), ('bias_q', bias_q), ('bias_s', bias_s),
                         ('bias_stride', bias_stride), ('act', act), ('dact', dact),
-                        ('flags', L.GEMM_ACCUM if accum else 0)):
+                        ('flags', (L.GEMM_ACCUM if accum else 0) | (L.GEMM_BIASGRAD if dbias is not None else 0))):
             p[name] = int(v)
         p['alpha'] = alpha
         self._probs.append(p)
@@ -192,6 +199,8 @@ class Program:
         if count is None:
             count = len(self._probs) - first
         if count > 0:
+            if tag and ctype is None:
+                ctype = self.decoder_ctype
             flags = 0 if ctype is None else 1 + ctype
             if tag:
                 flags |= L.OPFLAG_TIMED | (tag << 16)
@@ -239,15 +248,32 @@ class Program:
                 g['pos'] = np.asarray([(y0 + y) * S + (x0 + x) for y in range(kh) for x in range(kw)],
                                       dtype=np.int32)
                 g['ld'] = round_up(g['cols'], 4)
-                g['row0'] = row
                 g['rows'] = len(inds) * g['hw']
-                row += g['rows']
                 self.conv_groups.append(g)
             else:
                 if len(key) == 2 and key[1] < 0:
                     self.oned_clsb.append((key, list(inds)))
                 else:
                     self.oned_plain.append((key, list(inds)))
+        # The W2 GEMM of a group depends only on (o, i): parameter groups that differ just in the kernel size
+        # (1x1, 3x3, 5x5, 7x7 ...) are stacked along M into one GEMM problem ("gemm group").  This removes most
+        # of the tile-quantisation waste of the reference's per-key grouping (many groups have < 32 rows).
+        order = sorted(range(len(self.conv_groups)),
+                       key=lambda k: (self.conv_groups[k]['kind'] == 'cls', -self.conv_groups[k]['cols'],
+                                      self.conv_groups[k]['o'], self.conv_groups[k]['i_ld'], k))
+        self.conv_groups = [self.conv_groups[k] for k in order]
+        self.gemm_groups = []
+        for g in self.conv_groups:
+            g['row0'] = row
+            row += g['rows']
+            last = self.gemm_groups[-1] if self.gemm_groups else None
+            if last is not None and g['kind'] == 'conv' and last['kind'] == 'conv' and \
+                    (last['o'], last['i_ld']) == (g['o'], g['i_ld']):
+                last['rows'] += g['rows']
+                last['members'].append(g)
+            else:
+                self.gemm_groups.append(dict(kind=g['kind'], o=g['o'], i=g['i'], i_ld=g['i_ld'], cols=g['cols'],
+                                             ld=g['ld'], row0=g['row0'], rows=g['rows'], members=[g]))
         self.M = row
         # per-row arrays
         self.row_src = np.zeros(self.M, dtype=np.int32)
@@ -400,12 +426,14 @@ class Program:
             # D3: only the W2 rows (o' < o, i' < i) each group consumes; all groups in one launch
             p0 = len(self._probs)
             tiles_floats = 0
-            for g in self.conv_groups:
-                g['tile_off'] = tiles_floats
-                tiles_floats += round_up(g['rows'] * g['ld'], 64)
+            for gg in self.gemm_groups:
+                gg['tile_off'] = tiles_floats
+                for g in gg['members']:
+                    g['tile_off'] = tiles_floats + (g['row0'] - gg['row0']) * gg['ld']
+                tiles_floats += round_up(gg['rows'] * gg['ld'], 64)
             self.tiles_floats = tiles_floats
             tiles = self.wsf('tiles', tiles_floats)
-            for g in self.conv_groups:
+            for g in self.gemm_groups:
                 self.gemm((u[0], u[1] + 4 * g['row0'] * 8 * C), self.pref(W2), self.wref('tiles', g['tile_off']),
                           g['rows'], g['cols'], 8 * C, 8 * C, 8 * C, g['ld'], b_qs=(g['i_ld'], ms[1]),
                           bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1],
@@ -688,41 +716,37 @@ class Program:
                     tile_n = self.wref('tiles', g['tile_off'] + n_idx * g['ld'])
                     dout_n = self.wref('d_clsout', g['cls_off'][n_idx])
                     p0 = self.gemm(dout_n, tile_n, self.gref(Wc), K, ms[0], g['i'], ldK, g['i_ld'], ms[0],
-                                   a_mode=L.MODE_COL, b_mode=L.MODE_ROW, accum=True)
+                                   a_mode=L.MODE_COL, b_mode=L.MODE_ROW, accum=True, dbias=self.gref(bc))
                     self.gemm_op(p0)
-                    self._colsum(self.gref(bc), dout_n, g['i'], K, ldK)
             # D3 backward: d_u = (d_tiles . W2sub) * (u > 0)   -- all groups, one launch
             p0 = len(self._probs)
-            for g in self.conv_groups:
+            for g in self.gemm_groups:
                 self.gemm(self.wref('d_tiles', g['tile_off']), self.pref(W2), (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),
                           g['rows'], 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
                           b_qs=(g['i_ld'], ms[1]), dact=L.DACT_RELU, aux_in=(u[0], u[1] + 4 * g['row0'] * 8 * C))
             self.gemm_op(p0, tag=self.TAG_D3_DGRAD)
             # dW2[rows of the group] += d_tiles^T u ; groups overlap in W2 rows -> one launch per group
-            for g in self.conv_groups:
+            for g in self.gemm_groups:
                 p0 = self.gemm(self.wref('d_tiles', g['tile_off']), (u[0], u[1] + 4 * g['row0'] * 8 * C),
                                self.gref(W2), g['cols'], 8 * C, g['rows'], g['ld'], 8 * C, 8 * C,
-                               a_mode=L.MODE_COL, b_mode=L.MODE_COL, c_qs=(g['i_ld'], ms[1]), accum=True)
+                               a_mode=L.MODE_COL, b_mode=L.MODE_COL, c_qs=(g['i_ld'], ms[1]), accum=True,
+                               dbias=self.gref(b2))
                 self.gemm_op(p0, tag=self.TAG_D3_WGRAD)
-                self._colsum(self.gref(b2), self.wref('d_tiles', g['tile_off']), g['rows'], g['cols'], g['ld'],
-                             q=g['i_ld'], s=ms[1])
             # D2 backward
             p0 = self.gemm(d_u, t, self.gref(W0), 8 * C, 4 * C, M, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_COL,
-                           b_mode=L.MODE_COL, accum=True)
+                           b_mode=L.MODE_COL, accum=True, dbias=self.gref(b0))
             self.gemm(d_u, self.pref(W0), d_t, M, 4 * C, 8 * C, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_ROW,
                       b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=t)
             self.gemm_op(p0, tag=self.TAG_D2_BWD)
-            self._colsum(self.gref(b0), d_u, M, 8 * C, 8 * C)
             # D1 backward (per used position)
             p0 = len(self._probs)
             for (p, cnt, r_rows, r_src) in self.d1:
                 self.gemm(d_t, xe, self.gref(Wfc, p * C), 4 * C, C, cnt, 4 * C, C, S2 * C, a_mode=L.MODE_COL,
-                          b_mode=L.MODE_COL, a_gather=r_rows, b_gather=r_src, accum=True)
+                          b_mode=L.MODE_COL, a_gather=r_rows, b_gather=r_src, accum=True,
+                          dbias=self.gref(bfc, p), dbias_stride=S2)
                 self.gemm(d_t, self.pref(Wfc, p * C), d_rows, cnt, C, 4 * C, 4 * C, S2 * C, C, a_mode=L.MODE_ROW,
                           b_mode=L.MODE_COL, a_gather=r_rows, c_gather=r_rows)
             self.gemm_op(p0, tag=self.TAG_D1_BWD)
-            for (p, cnt, r_rows, r_src) in self.d1:
-                self._colsum(self.gref(bfc, p), d_t, cnt, 4 * C, 4 * C, stride=S2, gather=r_rows)
         if n1 > 0:
             mc = self.mc
             W1, b1 = 'decoder_1d.fc.0.weight', 'decoder_1d.fc.0.bias'
@@ -737,21 +761,18 @@ class Program:
                 p0 = self.gemm(d_cb, self.pref(Wb), self.wref('d_w1d', cb0 * 2 * mc + mc), self.n1_clsb, mc, K, ldK,
                                mc, 2 * mc, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=w_cb)
                 self.gemm(d_cb, w_cb, self.gref(Wb), K, mc, self.n1_clsb, ldK, 2 * mc, mc, a_mode=L.MODE_COL,
-                          b_mode=L.MODE_COL, accum=True)
+                          b_mode=L.MODE_COL, accum=True, dbias=self.gref(bb))
                 self.gemm_op(p0)
-                self._colsum(self.gref(bb), d_cb, self.n1_clsb, K, ldK)
             p0 = self.gemm(d_w1d, h1d, self.gref(W2d), 2 * mc, 2 * C, n1, 2 * mc, 2 * C, 2 * C, a_mode=L.MODE_COL,
-                           b_mode=L.MODE_COL, accum=True)
+                           b_mode=L.MODE_COL, accum=True, dbias=self.gref(b2d))
             self.gemm(d_w1d, self.pref(W2d), d_h1d, n1, 2 * C, 2 * mc, 2 * mc, 2 * C, 2 * C, a_mode=L.MODE_ROW,
                       b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=h1d)
             self.gemm_op(p0)
-            self._colsum(self.gref(b2d), d_w1d, n1, 2 * mc, 2 * mc)
             p0 = self.gemm(d_h1d, xe, self.gref(W1), 2 * C, C, n1, 2 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
-                           b_gather=self.r_src1, accum=True)
+                           b_gather=self.r_src1, accum=True, dbias=self.gref(b1))
             self.gemm(d_h1d, self.pref(W1), (d_rows[0], d_rows[1] + 4 * M * C), n1, C, 2 * C, 2 * C, C, C,
                       a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
             self.gemm_op(p0)
-            self._colsum(self.gref(b1), d_h1d, n1, 2 * C, 2 * C)
         # ---- d_xe[row] = sum of the decoder rows that read it (deterministic gather-sum) -----------------
         all_src = np.concatenate([self.row_src, self.oned_src]) if (M + n1) else np.zeros(0, dtype=np.int32)
         order = np.argsort(all_src, kind='stable').astype(np.int32)
@@ -792,17 +813,15 @@ class Program:
                 pre + 'attn.to_qkv.weight'
             # FFN second linear: x_out = xmid + f W3^T + b3
             p0 = self.gemm(g_cur, f, self.gref(W3), C, 4 * C, rows, C, 4 * C, 4 * C, a_mode=L.MODE_COL,
-                           b_mode=L.MODE_COL, accum=True)
+                           b_mode=L.MODE_COL, accum=True, dbias=self.gref(pre + 'ff.net.3.bias'))
             self.gemm(g_cur, self.pref(W3), dz, rows, 4 * C, C, C, 4 * C, 4 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
                       dact=L.DACT_GELU, aux_in=z)
             self.gemm_op(p0)
-            self._colsum(self.gref(pre + 'ff.net.3.bias'), g_cur, rows, C, C)
             # FFN first linear
             p0 = self.gemm(dz, h2, self.gref(W1f), 4 * C, C, rows, 4 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
-                           accum=True)
+                           accum=True, dbias=self.gref(pre + 'ff.net.0.bias'))
             self.gemm(dz, self.pref(W1f), dh, rows, C, 4 * C, 4 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
             self.gemm_op(p0)
-            self._colsum(self.gref(pre + 'ff.net.0.bias'), dz, rows, 4 * C, 4 * C)
             # LN2 (+ residual branch gradient g_cur)
             self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln2.weight'), self.gref(pre + 'ln2.bias'), dh, xmid,
                                               m2, r2), ints=(rows, C, 1))
@@ -811,10 +830,9 @@ class Program:
             g_mid = other
             # attention output projection: xmid = x_in + o Wo^T + bo
             p0 = self.gemm(g_mid, o, self.gref(Wo), C, C, rows, C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
-                           accum=True)
+                           accum=True, dbias=self.gref(pre + 'attn.to_out.0.bias'))
             self.gemm(g_mid, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
             self.gemm_op(p0)
-            self._colsum(self.gref(pre + 'attn.to_out.0.bias'), g_mid, rows, C, C)
             self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, dS, dBias, r_nn), ints=(B, N, C, H))
             p0 = self.gemm(dqkv, h1, self.gref(Wq), 3 * C, C, rows, 3 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
                            accum=True)
@@ -836,22 +854,20 @@ class Program:
         self.op(L.OP_MEMSET0, refs=(dT,), ints=(4 * V * V * ldT,))
         self.op(L.OP_BIAS_HIST, refs=(dT, dBias, pair), ints=(B, N, H, V))
         p0 = self.gemm(dT, hid, self.gref(W2e), H, C, V * V, ldT, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
-                       accum=True)
+                       accum=True, dbias=self.gref(b2e))
         self.gemm(dT, self.pref(W2e), dhid, V * V, C, H, ldT, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
         self.gemm_op(p0)
-        self._colsum(self.gref(b2e), dT, V * V, H, ldT)
         self.op(L.OP_EDGE_HIDDEN_BWD, refs=(dPfw, dPbw, dhid, hid), ints=(V, C))
         p0 = self.gemm(dPfw, self.pref(E, 2 * C), self.gref(W0e, 0), C, C, V, C, C, 2 * C, a_mode=L.MODE_COL,
                        b_mode=L.MODE_COL, accum=True)
         self.gemm(dPbw, self.pref(E, 2 * C), self.gref(W0e, C), C, C, V, C, C, 2 * C, a_mode=L.MODE_COL,
-                  b_mode=L.MODE_COL, accum=True)
+                  b_mode=L.MODE_COL, accum=True, dbias=self.gref(b0e))
         self.gemm(dPfw, self.pref(W0e, 0), self.gref(E, 2 * C), V, C, C, C, 2 * C, C, a_mode=L.MODE_ROW,
                   b_mode=L.MODE_COL, accum=True)
         self.gemm_op(p0)
         p0 = self.gemm(dPbw, self.pref(W0e, C), self.gref(E, 2 * C), V, C, C, C, 2 * C, C, a_mode=L.MODE_ROW,
                        b_mode=L.MODE_COL, accum=True)
         self.gemm_op(p0)
-        self._colsum(self.gref(b0e), dPbw, V, C, C)
         # ---- node embeddings ---------------------------------------------------------------------------------
         self.op(L.OP_EMBED_BWD,
                 refs=(g_cur, r_types, r_shape, r_nn, r_noff, self.gref('embed.weight'),

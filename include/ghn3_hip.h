@@ -61,6 +61,10 @@ enum { GHN3_ACT_NONE = 0, GHN3_ACT_RELU = 1, GHN3_ACT_GELU = 2 };
 /* multiply by a derivative evaluated at aux_in(m,n) (same layout/map as C) */
 enum { GHN3_DACT_NONE = 0, GHN3_DACT_RELU = 1 /* aux_in > 0 */, GHN3_DACT_GELU = 2 /* gelu'(aux_in) */ };
 #define GHN3_GEMM_ACCUM 1u
+/* wgrad problems (a_mode == COL): `bias` names the bias GRADIENT; the kernel adds the row sums of A,
+ * dbias[cmap(m) * bias_stride] += sum_k A(m,k), and applies no bias to C.  At most one problem of a launch
+ * may touch a given dbias element. */
+#define GHN3_GEMM_BIASGRAD 2u
 
 typedef struct ghn3_gemm_problem {
     ghn3_ref A, B, C;

@@ -77,6 +77,13 @@ def run_gemm_case(ctx, M, N, K, a_mode, b_mode, tile=0, ctype=L.CT_F32, gather=F
         v = v + resid[c_idx][:, :N]
     if accum:
         v = v + C0[c_idx][:, :N]
+    bias_expected = None
+    if epilogue == 'biasgrad':
+        assert a_mode == L.MODE_COL
+        bias_stride = 2
+        bias = rs.standard_normal(c_rows * 2 + 7).astype(np.float32)
+        bias_expected = bias.astype(np.float64).copy()
+        np.add.at(bias_expected, c_idx * bias_stride, A.sum(1))
     expected = C0.astype(np.float64).copy()
     expected[c_idx, :N] = v
 
@@ -92,7 +99,7 @@ def run_gemm_case(ctx, M, N, K, a_mode, b_mode, tile=0, ctype=L.CT_F32, gather=F
     for name in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather'):
         p[name]['buf'] = -1
     p['A']['buf'], p['B']['buf'], p['C']['buf'] = 0, 1, 2
-    if epilogue in ('bias_relu', 'full', 'gelu', 'dgelu', 'drelu'):
+    if epilogue in ('bias_relu', 'full', 'gelu', 'dgelu', 'drelu', 'biasgrad'):
         p['bias']['buf'] = 3
     if epilogue == 'full':
         p['residual']['buf'] = 4
@@ -109,7 +116,7 @@ def run_gemm_case(ctx, M, N, K, a_mode, b_mode, tile=0, ctype=L.CT_F32, gather=F
     p['bias_stride'] = bias_stride
     p['act'] = {'bias_relu': L.ACT_RELU, 'gelu': L.ACT_GELU, 'full': L.ACT_GELU}.get(epilogue, L.ACT_NONE)
     p['dact'] = {'drelu': L.DACT_RELU, 'dgelu': L.DACT_GELU}.get(epilogue, L.DACT_NONE)
-    p['flags'] = L.GEMM_ACCUM if accum else 0
+    p['flags'] = (L.GEMM_ACCUM if accum else 0) | (L.GEMM_BIASGRAD if epilogue == 'biasgrad' else 0)
     p['alpha'] = alpha
     op = np.zeros(1, dtype=L.OP_DT)
     op['kind'] = L.OP_GEMM
@@ -120,6 +127,8 @@ def run_gemm_case(ctx, M, N, K, a_mode, b_mode, tile=0, ctype=L.CT_F32, gather=F
     torch.cuda.synchronize()
     got = dC.cpu().numpy()
     extra_out = None
+    if bias_expected is not None:
+        extra_out = (dbias.cpu().numpy(), bias_expected)
     if aux_out_expected is not None:
         e2 = np.zeros_like(expected)
         e2[c_idx, :N] = aux_out_expected
@@ -140,4 +149,8 @@ CASES += [
     dict(M=65, N=129, K=40, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=64, epilogue='drelu', qs_map=True),
     dict(M=9, N=1000, K=384, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, tile=0, epilogue='gelu'),
     dict(M=1, N=5, K=3, a_mode=L.MODE_COL, b_mode=L.MODE_ROW, tile=0),
+    dict(M=300, N=200, K=150, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=128, epilogue='biasgrad', accum=True),
+    dict(M=70, N=33, K=45, a_mode=L.MODE_COL, b_mode=L.MODE_ROW, tile=64, epilogue='biasgrad', gather=True),
+    dict(M=1100, N=1300, K=64, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, tile=128),
+    dict(M=40, N=2100, K=40, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, tile=64),
 ]

@@ -85,7 +85,11 @@ class Interp:
             v = (A.astype(np.float64) @ Bm.astype(np.float64)) * float(p['alpha'])
             rc = self._rowmap(np.arange(M), gc, int(p['c_q']), int(p['c_s']))
             ci = rc[:, None] * ldc + np.arange(N)[None, :]
-            if int(p['bias']['buf']) >= 0:
+            if int(p['flags']) & L.GEMM_BIASGRAD:
+                assert int(p['a_mode']) == L.MODE_COL
+                db = self.tail(p['bias'], np.float32)
+                np.add.at(db, rc * (int(p['bias_stride']) or 1), A.astype(np.float64).sum(1).astype(np.float32))
+            elif int(p['bias']['buf']) >= 0:
                 bias = self.tail(p['bias'], np.float32)
                 n = np.arange(N)
                 bi = n

@@ -3,9 +3,14 @@
 // Replaces ghn3/graphormer.py:121-140:
 //     attn = (q @ k^T) * d^-0.5 + edge_bias ; attn.masked_fill(~mask, -2**15) ; softmax ; attn @ v
 // and its autograd backward.  Head dims on this path are tiny (d = 8..24) and N <= ~10^3, so the
-// score / PV products run as fp32 VALU FMAs with one query row per wavefront and one key per lane
-// (64-wide rows of the score matrix live in registers); K, then V, of one (graph, head) are staged through
-// LDS with an odd row stride (conflict-free column walks).  The row softmax is a wave-level reduction.
+// products run as exact fp32 VALU FMAs:
+//   * scores: one query row per wavefront, one key per lane (the 64-wide slices of a score row live in
+//     registers); K of one (graph, head) is staged through LDS with an odd row stride (conflict-free walks);
+//     the row softmax is a wave-level reduction (2 scalars per row).
+//   * P.V (and dS.K in the backward): the normalised row is parked in LDS and the wave switches to an
+//     (output column e, key parity g) lane mapping, so no d-wide cross-lane reduction is needed.
+//   * every global->LDS staging loop keeps 8 loads in flight per thread (latency-bound otherwise: one
+//     workgroup per CU at N = 256).
 // The probabilities are written once (B,H,N,N) for the backward pass.
 //
 // Mask semantics (quirks Q5/Q6): pair mask = valid(i) & valid(j); masked scores are set to -32768 (not
@@ -13,9 +18,8 @@
 
 #include "ghn3_internal.h"
 
-#define ATT_ROWS_PER_WAVE 4
-#define ATT_ROWS_PER_BLOCK 16
 #define ATT_DMAX 32
+#define ATT_WAVES 4
 
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
@@ -28,33 +32,83 @@ __device__ __forceinline__ float wave_sum(float v) {
     return v;
 }
 
-template <int NT>
+// Stage one head slice X[j][e] = src[j * row_stride + e] (j < N, e < d) into LDS with row stride lds_ld.
+__device__ __forceinline__ void stage_head(float* __restrict__ dst, const float* __restrict__ src, int N, int d,
+                                           int row_stride, int lds_ld, int tid) {
+    const int total = N * d;
+    constexpr int U = 8;
+    for (int b0 = tid; b0 < total; b0 += 256 * U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = b0 + u * 256;
+            const int j = idx / d, e = idx - j * d;
+            v[u] = idx < total ? src[(size_t)j * row_stride + e] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int idx = b0 + u * 256;
+            const int j = idx / d, e = idx - j * d;
+            if (idx < total) dst[j * lds_ld + e] = v[u];
+        }
+    }
+}
+
+// out[r][e] = sum_j Prow[r][j] * X[j][e] for the RW rows of this wave; lane = e + 32 * g, g = key parity.
+template <int RW>
+__device__ __forceinline__ void rows_times_matrix(const float* __restrict__ prow, int p_ld,
+                                                  const float* __restrict__ X, int x_ld, int N, int d, int lane,
+                                                  float (&out)[RW]) {
+    const int e = lane & 31, g = lane >> 5;
+    float acc[RW];
+#pragma unroll
+    for (int r = 0; r < RW; ++r) acc[r] = 0.f;
+    if (e < d) {
+        for (int j = g; j < N; j += 2) {
+            const float x = X[j * x_ld + e];
+#pragma unroll
+            for (int r = 0; r < RW; ++r) acc[r] += prow[r * p_ld + j] * x;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < RW; ++r) out[r] = acc[r] + __shfl_xor(acc[r], 32, 64);
+}
+
+template <int NT, int RW>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, const float* __restrict__ qkv,
                                                        const float* __restrict__ bias, float* __restrict__ Psave,
                                                        const int* __restrict__ n_nodes, int N, int C, int H,
                                                        float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int d = C / H, ldk = d | 1;
+    float* KV = sm;                                   // N x ldk (K, later V)
+    float* Ps = sm + (size_t)N * ldk;                 // ATT_WAVES * RW rows of N (+1 pad)
+    const int p_ld = N + 1;
     const int b = blockIdx.z, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nb = n_nodes[b];
     const float* base = qkv + (size_t)b * N * 3 * C;
     const size_t bh = ((size_t)b * H + h) * N;
+    const int row0 = (blockIdx.x * ATT_WAVES + w) * RW;
+    float* myP = Ps + (size_t)w * RW * p_ld;
 
-    for (int idx = tid; idx < N * d; idx += 256) {
-        int j = idx / d, e = idx - j * d;
-        sm[j * ldk + e] = base[(size_t)j * 3 * C + C + h * d + e];
-    }
+    stage_head(KV, base + C + h * d, N, d, 3 * C, ldk, tid);
     __syncthreads();
 
-    float p[ATT_ROWS_PER_WAVE][NT];
 #pragma unroll
-    for (int r = 0; r < ATT_ROWS_PER_WAVE; ++r) {
-        const int i = blockIdx.x * ATT_ROWS_PER_BLOCK + w * ATT_ROWS_PER_WAVE + r;
+    for (int r = 0; r < RW; ++r) {
+        const int i = row0 + r;
         if (i < N) {
             float q[ATT_DMAX];
 #pragma unroll
             for (int e = 0; e < ATT_DMAX; ++e) q[e] = (e < d) ? base[(size_t)i * 3 * C + h * d + e] : 0.f;
+            float bv[NT];
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                const int j = lane + 64 * t;
+                bv[t] = (bias && j < N) ? bias[(bh + i) * N + j] : 0.f;
+            }
+            float p[NT];
             float mx = -INFINITY;
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
@@ -62,15 +116,14 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, 
                 float s = -INFINITY;
                 if (j < N) {
                     s = 0.f;
-                    const float* kr = sm + j * ldk;
+                    const float* kr = KV + j * ldk;
 #pragma unroll
                     for (int e = 0; e < ATT_DMAX; ++e)
                         if (e < d) s += q[e] * kr[e];
-                    s = s * scale;
-                    if (bias) s += bias[(bh + i) * N + j];
+                    s = s * scale + bv[t];
                     if (!(i < nb && j < nb)) s = -32768.f;
                 }
-                p[r][t] = s;
+                p[t] = s;
                 mx = fmaxf(mx, s);
             }
             mx = wave_max(mx);
@@ -78,8 +131,8 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, 
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int j = lane + 64 * t;
-                float e_ = (j < N) ? __expf(p[r][t] - mx) : 0.f;
-                p[r][t] = e_;
+                const float e_ = (j < N) ? __expf(p[t] - mx) : 0.f;
+                p[t] = e_;
                 sum += e_;
             }
             sum = wave_sum(sum);
@@ -87,44 +140,26 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, 
 #pragma unroll
             for (int t = 0; t < NT; ++t) {
                 const int j = lane + 64 * t;
-                p[r][t] *= inv;
-                if (Psave && j < N) Psave[(bh + i) * N + j] = p[r][t];
+                if (j < N) {
+                    const float pv = p[t] * inv;
+                    myP[r * p_ld + j] = pv;
+                    if (Psave) Psave[(bh + i) * N + j] = pv;
+                }
             }
+        } else {
+            for (int j = lane; j < N; j += 64) myP[r * p_ld + j] = 0.f;
         }
     }
     __syncthreads();
-    for (int idx = tid; idx < N * d; idx += 256) {
-        int j = idx / d, e = idx - j * d;
-        sm[j * ldk + e] = base[(size_t)j * 3 * C + 2 * C + h * d + e];
-    }
+    stage_head(KV, base + 2 * C + h * d, N, d, 3 * C, ldk, tid);
     __syncthreads();
+    float o[RW];
+    rows_times_matrix<RW>(myP, p_ld, KV, ldk, N, d, lane, o);
+    if (lane < d) {
 #pragma unroll
-    for (int r = 0; r < ATT_ROWS_PER_WAVE; ++r) {
-        const int i = blockIdx.x * ATT_ROWS_PER_BLOCK + w * ATT_ROWS_PER_WAVE + r;
-        if (i < N) {
-            float acc[ATT_DMAX];
-#pragma unroll
-            for (int e = 0; e < ATT_DMAX; ++e) acc[e] = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int j = lane + 64 * t;
-                if (j < N) {
-                    const float* vr = sm + j * ldk;
-                    const float pv = p[r][t];
-#pragma unroll
-                    for (int e = 0; e < ATT_DMAX; ++e)
-                        if (e < d) acc[e] += pv * vr[e];
-                }
-            }
-            float mine = 0.f;
-#pragma unroll
-            for (int e = 0; e < ATT_DMAX; ++e) {
-                if (e < d) {
-                    float s_ = wave_sum(acc[e]);
-                    if (lane == e) mine = s_;
-                }
-            }
-            if (lane < d) out[((size_t)b * N + i) * C + h * d + lane] = mine;
+        for (int r = 0; r < RW; ++r) {
+            const int i = row0 + r;
+            if (i < N) out[((size_t)b * N + i) * C + h * d + lane] = o[r];
         }
     }
 }
@@ -133,7 +168,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, 
 // backward, pass 1 (row-wise): dP = dO V^T ; dS = P * (dP - rowsum(P*dP)) with masked entries zeroed ;
 // dQ = scale * dS K ; dBias += dS ; dS stored for pass 2.
 // ------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int RW>
 __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(float* __restrict__ dqkv, const float* __restrict__ dO,
                                                             const float* __restrict__ qkv,
                                                             const float* __restrict__ P, float* __restrict__ dS,
@@ -142,74 +177,78 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(float* __restrict__ 
                                                             float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     const int d = C / H, ldk = d | 1;
-    float* Ks = sm;                 // N x ldk
+    float* Ks = sm;
     float* Vs = sm + (size_t)N * ldk;
+    float* Ds = Vs + (size_t)N * ldk;                 // ATT_WAVES * RW rows of dS
+    const int p_ld = N + 1;
     const int b = blockIdx.z, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int nb = n_nodes[b];
     const float* base = qkv + (size_t)b * N * 3 * C;
     const size_t bh = ((size_t)b * H + h) * N;
-    for (int idx = tid; idx < N * d; idx += 256) {
-        int j = idx / d, e = idx - j * d;
-        Ks[j * ldk + e] = base[(size_t)j * 3 * C + C + h * d + e];
-        Vs[j * ldk + e] = base[(size_t)j * 3 * C + 2 * C + h * d + e];
-    }
+    const int row0 = (blockIdx.x * ATT_WAVES + w) * RW;
+    float* myD = Ds + (size_t)w * RW * p_ld;
+    stage_head(Ks, base + C + h * d, N, d, 3 * C, ldk, tid);
+    stage_head(Vs, base + 2 * C + h * d, N, d, 3 * C, ldk, tid);
     __syncthreads();
-#pragma unroll 1
-    for (int r = 0; r < ATT_ROWS_PER_WAVE; ++r) {
-        const int i = blockIdx.x * ATT_ROWS_PER_BLOCK + w * ATT_ROWS_PER_WAVE + r;
-        if (i >= N) continue;
-        float g[ATT_DMAX];
 #pragma unroll
-        for (int e = 0; e < ATT_DMAX; ++e) g[e] = (e < d) ? dO[((size_t)b * N + i) * C + h * d + e] : 0.f;
-        float pr[NT], dp[NT];
-        float delta = 0.f;
+    for (int r = 0; r < RW; ++r) {
+        const int i = row0 + r;
+        if (i < N) {
+            float g[ATT_DMAX];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int j = lane + 64 * t;
-            float pv = 0.f, dv = 0.f;
-            if (j < N) {
-                pv = P[(bh + i) * N + j];
-                const float* vr = Vs + j * ldk;
+            for (int e = 0; e < ATT_DMAX; ++e) g[e] = (e < d) ? dO[((size_t)b * N + i) * C + h * d + e] : 0.f;
+            float pr[NT], dp[NT];
 #pragma unroll
-                for (int e = 0; e < ATT_DMAX; ++e)
-                    if (e < d) dv += g[e] * vr[e];
+            for (int t = 0; t < NT; ++t) {
+                const int j = lane + 64 * t;
+                pr[t] = (j < N) ? P[(bh + i) * N + j] : 0.f;
             }
-            pr[t] = pv; dp[t] = dv;
-            delta += pv * dv;
-        }
-        delta = wave_sum(delta);
-        float dq[ATT_DMAX];
+            float delta = 0.f;
 #pragma unroll
-        for (int e = 0; e < ATT_DMAX; ++e) dq[e] = 0.f;
+            for (int t = 0; t < NT; ++t) {
+                const int j = lane + 64 * t;
+                float dv = 0.f;
+                if (j < N) {
+                    const float* vr = Vs + j * ldk;
 #pragma unroll
-        for (int t = 0; t < NT; ++t) {
-            const int j = lane + 64 * t;
-            if (j < N) {
-                float ds = pr[t] * (dp[t] - delta);
-                if (!(i < nb && j < nb)) ds = 0.f;          // masked_fill blocks the gradient
-                dS[(bh + i) * N + j] = ds;
-                if (dBias) dBias[(bh + i) * N + j] += ds;
-                const float* kr = Ks + j * ldk;
-#pragma unroll
-                for (int e = 0; e < ATT_DMAX; ++e)
-                    if (e < d) dq[e] += ds * kr[e];
+                    for (int e = 0; e < ATT_DMAX; ++e)
+                        if (e < d) dv += g[e] * vr[e];
+                }
+                dp[t] = dv;
+                delta += pr[t] * dv;
             }
-        }
-        float mine = 0.f;
+            delta = wave_sum(delta);
 #pragma unroll
-        for (int e = 0; e < ATT_DMAX; ++e) {
-            if (e < d) {
-                float s_ = wave_sum(dq[e]);
-                if (lane == e) mine = s_;
+            for (int t = 0; t < NT; ++t) {
+                const int j = lane + 64 * t;
+                if (j < N) {
+                    float ds = pr[t] * (dp[t] - delta);
+                    if (!(i < nb && j < nb)) ds = 0.f;          // masked_fill blocks the gradient
+                    myD[r * p_ld + j] = ds;
+                    dS[(bh + i) * N + j] = ds;
+                    if (dBias) dBias[(bh + i) * N + j] += ds;
+                }
             }
+        } else {
+            for (int j = lane; j < N; j += 64) myD[r * p_ld + j] = 0.f;
         }
-        if (lane < d) dqkv[((size_t)b * N + i) * 3 * C + h * d + lane] = mine * scale;
+    }
+    // wave-local LDS hand-off (each wave reads back only its own rows)
+    __syncthreads();
+    float dq[RW];
+    rows_times_matrix<RW>(myD, p_ld, Ks, ldk, N, d, lane, dq);
+    if (lane < d) {
+#pragma unroll
+        for (int r = 0; r < RW; ++r) {
+            const int i = row0 + r;
+            if (i < N) dqkv[((size_t)b * N + i) * 3 * C + h * d + lane] = dq[r] * scale;
+        }
     }
 }
 
 // backward, pass 2 (column-wise, one key per lane): dV[j] = sum_i P[i][j] dO[i] ; dK[j] = scale sum_i dS[i][j] Q[i].
-// A block owns 64 keys; its 4 waves split the query rows and reduce through LDS.
+// A block owns 64 keys; its 4 waves split the query rows (4 rows per step, loads batched) and reduce via LDS.
 __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(float* __restrict__ dqkv, const float* __restrict__ dO,
                                                             const float* __restrict__ qkv,
                                                             const float* __restrict__ P, const float* __restrict__ dS,
@@ -218,30 +257,37 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(float* __restrict__ 
     const int d = C / H;
     float* Qs = sm;                       // N x d   (row-broadcast reads)
     float* Gs = sm + (size_t)N * d;       // N x d   dO
-    float* red = Gs + (size_t)N * d;      // 4 waves x 64 lanes x 2d
+    float* red = Gs + (size_t)N * d;      // 4 waves x 64 lanes x (2d+1)
     const int b = blockIdx.z, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* base = qkv + (size_t)b * N * 3 * C;
     const size_t bh = ((size_t)b * H + h) * N;
-    for (int idx = tid; idx < N * d; idx += 256) {
-        int i = idx / d, e = idx - i * d;
-        Qs[idx] = base[(size_t)i * 3 * C + h * d + e];
-        Gs[idx] = dO[((size_t)b * N + i) * C + h * d + e];
-    }
+    stage_head(Qs, base + h * d, N, d, 3 * C, d, tid);
+    stage_head(Gs, dO + (size_t)b * N * C + h * d, N, d, C, d, tid);
     __syncthreads();
     const int j = blockIdx.x * 64 + lane;
     float dv[ATT_DMAX], dk[ATT_DMAX];
 #pragma unroll
     for (int e = 0; e < ATT_DMAX; ++e) { dv[e] = 0.f; dk[e] = 0.f; }
     if (j < N) {
-        for (int i = w; i < N; i += 4) {
-            const float pv = P[(bh + i) * N + j];
-            const float ds = dS[(bh + i) * N + j];
-            const float* qr = Qs + i * d;
-            const float* gr = Gs + i * d;
+        constexpr int U = 4;
+        for (int i0 = w * U; i0 < N; i0 += ATT_WAVES * U) {
+            float pv[U], ds[U];
 #pragma unroll
-            for (int e = 0; e < ATT_DMAX; ++e)
-                if (e < d) { dv[e] += pv * gr[e]; dk[e] += ds * qr[e]; }
+            for (int u = 0; u < U; ++u) {
+                const int i = i0 + u;
+                pv[u] = (i < N) ? P[(bh + i) * N + j] : 0.f;
+                ds[u] = (i < N) ? dS[(bh + i) * N + j] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int i = min(i0 + u, N - 1);
+                const float* qr = Qs + i * d;
+                const float* gr = Gs + i * d;
+#pragma unroll
+                for (int e = 0; e < ATT_DMAX; ++e)
+                    if (e < d) { dv[e] += pv[u] * gr[e]; dk[e] += ds[u] * qr[e]; }
+            }
         }
     }
     const int ld2 = 2 * d + 1;
@@ -250,14 +296,13 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(float* __restrict__ 
     for (int e = 0; e < ATT_DMAX; ++e)
         if (e < d) { my[e] = dv[e]; my[d + e] = dk[e]; }
     __syncthreads();
-    // 256 threads: thread -> (key lane l, slice): sum over the 4 waves
     for (int idx = tid; idx < 64 * 2 * d; idx += 256) {
         const int l = idx / (2 * d), c = idx - l * (2 * d);
         const int jj = blockIdx.x * 64 + l;
         if (jj < N) {
             float s_ = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < 4; ++ww) s_ += red[((size_t)ww * 64 + l) * ld2 + c];
+            for (int ww = 0; ww < ATT_WAVES; ++ww) s_ += red[((size_t)ww * 64 + l) * ld2 + c];
             if (c < d) dqkv[((size_t)b * N + jj) * 3 * C + 2 * C + h * d + c] = s_;            // dV
             else dqkv[((size_t)b * N + jj) * 3 * C + C + h * d + (c - d)] = s_ * scale;          // dK
         }
@@ -270,10 +315,17 @@ typedef void (*attn_bwd_fn)(float*, const float*, const float*, const float*, fl
                             int, float);
 static const int kMaxLds = 160 * 1024;
 
+struct AttnCfg { attn_fwd_fn fwd; attn_bwd_fn bwd; int rw; };
+static AttnCfg pick(int N) {
+    if (N <= 256) return {attn_fwd_kernel<4, 4>, attn_bwd_rows_kernel<4, 4>, 4};
+    if (N <= 512) return {attn_fwd_kernel<8, 4>, attn_bwd_rows_kernel<8, 4>, 4};
+    return {attn_fwd_kernel<16, 2>, attn_bwd_rows_kernel<16, 2>, 2};
+}
+
 int ghn3_attn_init() {
-    const void* fns[] = {(const void*)attn_fwd_kernel<4>, (const void*)attn_fwd_kernel<8>,
-                         (const void*)attn_fwd_kernel<16>, (const void*)attn_bwd_rows_kernel<4>,
-                         (const void*)attn_bwd_rows_kernel<8>, (const void*)attn_bwd_rows_kernel<16>,
+    const void* fns[] = {(const void*)attn_fwd_kernel<4, 4>, (const void*)attn_fwd_kernel<8, 4>,
+                         (const void*)attn_fwd_kernel<16, 2>, (const void*)attn_bwd_rows_kernel<4, 4>,
+                         (const void*)attn_bwd_rows_kernel<8, 4>, (const void*)attn_bwd_rows_kernel<16, 2>,
                          (const void*)attn_bwd_cols_kernel};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
@@ -295,13 +347,14 @@ int ghn3_attn_fwd(float* out, const float* qkv, const float* bias, float* P, con
                   int H, hipStream_t s) {
     int rc = check_dims(N, C, H);
     if (rc) return rc;
+    const AttnCfg cfg = pick(N);
     const int d = C / H, ldk = d | 1;
-    const size_t lds = (size_t)N * ldk * sizeof(float);
-    if (lds > (size_t)kMaxLds) { ghn3_set_error("attention fwd: LDS %zu too large", lds); return GHN3_E_LIMIT; }
+    const size_t lds = ((size_t)N * ldk + (size_t)ATT_WAVES * cfg.rw * (N + 1)) * sizeof(float);
+    if (lds > (size_t)kMaxLds) { ghn3_set_error("attention fwd: LDS %zu too large (N=%d d=%d)", lds, N, d); return GHN3_E_LIMIT; }
     const float scale = 1.0f / sqrtf((float)d);
-    dim3 grid((N + ATT_ROWS_PER_BLOCK - 1) / ATT_ROWS_PER_BLOCK, H, B);
-    attn_fwd_fn fn = N <= 256 ? attn_fwd_kernel<4> : (N <= 512 ? attn_fwd_kernel<8> : attn_fwd_kernel<16>);
-    hipLaunchKernelGGL(fn, grid, dim3(256), lds, s, out, qkv, bias, P, n_nodes, N, C, H, scale);
+    const int rpb = ATT_WAVES * cfg.rw;
+    dim3 grid((N + rpb - 1) / rpb, H, B);
+    hipLaunchKernelGGL(cfg.fwd, grid, dim3(256), lds, s, out, qkv, bias, P, n_nodes, N, C, H, scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("attn fwd launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;
@@ -312,18 +365,18 @@ int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P
     (void)O;
     int rc = check_dims(N, C, H);
     if (rc) return rc;
+    const AttnCfg cfg = pick(N);
     const int d = C / H, ldk = d | 1;
     const float scale = 1.0f / sqrtf((float)d);
-    const size_t lds1 = (size_t)2 * N * ldk * sizeof(float);
-    const size_t lds2 = ((size_t)2 * N * d + 4 * 64 * (2 * d + 1)) * sizeof(float);
+    const size_t lds1 = ((size_t)2 * N * ldk + (size_t)ATT_WAVES * cfg.rw * (N + 1)) * sizeof(float);
+    const size_t lds2 = ((size_t)2 * N * d + ATT_WAVES * 64 * (2 * d + 1)) * sizeof(float);
     if (lds1 > (size_t)kMaxLds || lds2 > (size_t)kMaxLds) {
         ghn3_set_error("attention bwd: LDS %zu/%zu too large (N=%d d=%d)", lds1, lds2, N, d);
         return GHN3_E_LIMIT;
     }
-    dim3 grid((N + ATT_ROWS_PER_BLOCK - 1) / ATT_ROWS_PER_BLOCK, H, B);
-    attn_bwd_fn fn = N <= 256 ? attn_bwd_rows_kernel<4>
-                              : (N <= 512 ? attn_bwd_rows_kernel<8> : attn_bwd_rows_kernel<16>);
-    hipLaunchKernelGGL(fn, grid, dim3(256), lds1, s, dqkv, dO, qkv, P, dS, dBias, n_nodes, N, C, H, scale);
+    const int rpb = ATT_WAVES * cfg.rw;
+    dim3 grid((N + rpb - 1) / rpb, H, B);
+    hipLaunchKernelGGL(cfg.bwd, grid, dim3(256), lds1, s, dqkv, dO, qkv, P, dS, dBias, n_nodes, N, C, H, scale);
     dim3 grid2((N + 63) / 64, H, B);
     hipLaunchKernelGGL(attn_bwd_cols_kernel, grid2, dim3(256), lds2, s, dqkv, dO, qkv, P, dS, N, C, H, scale);
     hipError_t e = hipGetLastError();

@@ -578,6 +578,29 @@ int ghn3_rowseg_sum(float* out, const float* X, const int* seg_ptr, const int* i
     return launch_ok("rowseg_sum");
 }
 
+// X[m][n] *= dact(aux[m][n]) in place (deferred epilogue of a split-K dgrad)
+__global__ __launch_bounds__(256) void dact_kernel(float* __restrict__ X, const float* __restrict__ aux, int M, int N,
+                                                   int ld, int dact) {
+    const int64_t total = (int64_t)M * N;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t m = e / N;
+        const int64_t o = m * ld + (e - m * N);
+        const float z = aux[o];
+        float v = X[o];
+        if (dact == GHN3_DACT_RELU) v = z > 0.f ? v : 0.f;
+        else if (dact == GHN3_DACT_GELU)
+            v *= 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
+        X[o] = v;
+    }
+}
+int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, hipStream_t s) {
+    if (M <= 0 || N <= 0) return GHN3_OK;
+    int64_t blocks = ((int64_t)M * N + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(dact_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, aux, M, N, ld, dact);
+    return launch_ok("dact");
+}
+
 __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) dst[e] += src[e];
 }

@@ -56,16 +56,24 @@ __device__ __forceinline__ const GemmProbDev* find_problem(const GemmProbDev* pr
 // Tile order.  Blocks are dispatched round-robin over the 8 XCDs (block b -> XCD b % 8, each with a private
 // L2).  All m-tiles of one n-tile read the same B rows (the streamed weight rows), so they are given block
 // ids that are congruent mod 8: n_tile = ((t / 8) / tiles_m) * 8 + t % 8, m_tile = (t / 8) % tiles_m.
-// tile_start of every problem is a multiple of 8 and the n-tile count is padded to a multiple of 8 (surplus
-// blocks exit), so the B panel is fetched into one L2 instead of up to eight.
+// tile_start of every problem is a multiple of 8 and the inner tile count is padded to a multiple of 8 (surplus
+// blocks exit), so the streamed panel is fetched into one L2 instead of up to eight.  With split-K
+// (ksplit > 1) the tile grid is replicated per K chunk and partial sums are added to C atomically.
 template <int BM, int BN>
-__device__ __forceinline__ bool tile_origin(const GemmProbDev* P, int t, int& m0, int& n0) {
-    const int tiles_m = P->tiles_m;
+__device__ __forceinline__ bool tile_origin(const GemmProbDev* P, int t, int& m0, int& n0, int& kz) {
+    // order 0: B is the streamed operand (M <= N side small): m-tiles of one n-tile share an XCD;
+    // order 1: A is the streamed operand: n-tiles of one m-tile share an XCD.
+    const int tiles_m = P->tiles_m, tiles_n = P->tiles_n;
+    const int per_split = P->order ? ((tiles_m + 7) / 8 * 8) * tiles_n : tiles_m * ((tiles_n + 7) / 8 * 8);
+    kz = t / per_split;
+    t -= kz * per_split;
     const int grp = t >> 3;
-    const int nt = (grp / tiles_m) * 8 + (t & 7);
-    m0 = (grp % tiles_m) * BM;
+    int mt, nt;
+    if (P->order) { mt = (grp / tiles_n) * 8 + (t & 7); nt = grp % tiles_n; }
+    else { nt = (grp / tiles_m) * 8 + (t & 7); mt = grp % tiles_m; }
+    m0 = mt * BM;
     n0 = nt * BN;
-    return n0 < P->N;
+    return m0 < P->M && n0 < P->N;
 }
 
 // Epilogue shared by all variants.  acc tile layout (32x32 MFMA C/D): col = lane & 31,
@@ -82,6 +90,7 @@ __device__ __forceinline__ void epilogue(const GemmProbDev* P, f32x16 (&acc)[TM]
     const int cq = P->c_q, cs = P->c_s;
     const int act = P->act, dact = P->dact;
     const bool accum = (P->flags & GHN3_GEMM_ACCUM) != 0;
+    const bool split = P->ksplit > 1;
     const float alpha = P->alpha;
     const int l31 = lane & 31, lhi = lane >> 5;
 #pragma unroll
@@ -101,6 +110,11 @@ __device__ __forceinline__ void epilogue(const GemmProbDev* P, f32x16 (&acc)[TM]
                 const int row = m_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
                 if (row < M && col_ok) {
                     const int64_t ci = (int64_t)map_row(row, cg, cq, cs) * ldc + col;
+                    if (split) {      // partial sum of one K chunk: C was zeroed by the host program
+                        __hip_atomic_fetch_add(C + ci, acc[tm][tn][r] * alpha, __ATOMIC_RELAXED,
+                                               __HIP_MEMORY_SCOPE_AGENT);
+                        continue;
+                    }
                     float v = acc[tm][tn][r] * alpha + bv;
                     if (aux_out) aux_out[ci] = v;
                     if (act == GHN3_ACT_RELU) v = fmaxf(v, 0.f);
@@ -220,12 +234,14 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmProbDev* __rest
 
     const GemmProbDev* P = find_problem(probs, n_probs, blockIdx.x);
     const int t = blockIdx.x - P->tile_start;
-    int m0, n0;
-    if (!tile_origin<BM, BN>(P, t, m0, n0)) return;
+    int m0, n0, kz;
+    if (!tile_origin<BM, BN>(P, t, m0, n0, kz)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int K = P->K;
+    const int kt0 = kz * (P->k_chunk / BK);
+    const int K = (P->ksplit > 1) ? min(P->K, (kz + 1) * P->k_chunk) : P->K;
+    if (kt0 * BK >= K && P->ksplit > 1) return;
 
     F32Loader<BM, AM> la; F32Loader<BN, BMD> lb;
     la.init(P->A, P->a_gather, P->a_q, P->a_s, P->lda, P->M, K, m0, tid);
@@ -244,11 +260,11 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmProbDev* __rest
     const bool do_bg = (AM == COLM) && (P->flags & GHN3_GEMM_BIASGRAD) && n0 == 0;
     float bg = 0.f;
     f32x4 ra[TA::NV], rb[TB::NV];
-    la.load(0, ra); lb.load(0, rb);
-    la.store(smem, ra, 0); lb.store(smem + TA::SIZE, rb, 0);
+    la.load(kt0, ra); lb.load(kt0, rb);
+    la.store(smem, ra, kt0); lb.store(smem + TA::SIZE, rb, kt0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
         const bool more = (kt + 1) < nk;
         if (more) { la.load(kt + 1, ra); lb.load(kt + 1, rb); }
         const float* a_s = smem + cur * STAGE;
@@ -285,7 +301,8 @@ __global__ __launch_bounds__(256) void gemm_f32_kernel(const GemmProbDev* __rest
     if (do_bg && tid < BM && m0 + tid < P->M) {
         gf dbias = (gf)P->bias;
         const int64_t bi = (int64_t)map_row(m0 + tid, (gci)P->c_gather, P->c_q, P->c_s) * P->bias_stride;
-        dbias[bi] += bg;
+        if (P->ksplit > 1) __hip_atomic_fetch_add(dbias + bi, bg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else dbias[bi] += bg;
     }
     epilogue<TM, TN>(P, acc, m0 + wm0, n0 + wn0, lane);
 }
@@ -424,12 +441,14 @@ __global__ __launch_bounds__(256) void gemm_h16_kernel(const GemmProbDev* __rest
 
     const GemmProbDev* P = find_problem(probs, n_probs, blockIdx.x);
     const int t = blockIdx.x - P->tile_start;
-    int m0, n0;
-    if (!tile_origin<BM, BN>(P, t, m0, n0)) return;
+    int m0, n0, kz;
+    if (!tile_origin<BM, BN>(P, t, m0, n0, kz)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
     const int l31 = lane & 31, lhi = lane >> 5;
-    const int K = P->K;
+    const int kt0 = kz * (P->k_chunk / BK);
+    const int K = (P->ksplit > 1) ? min(P->K, (kz + 1) * P->k_chunk) : P->K;
+    if (kt0 * BK >= K && P->ksplit > 1) return;
 
     LA la; LB lb;
     la.init(P->A, P->a_gather, P->a_q, P->a_s, P->lda, P->M, K, m0, tid);
@@ -447,11 +466,11 @@ __global__ __launch_bounds__(256) void gemm_h16_kernel(const GemmProbDev* __rest
     const bool do_bg = (AM == COLM) && (P->flags & GHN3_GEMM_BIASGRAD) && n0 == 0;
     float bg = 0.f;
     f32x4 ra[LA::NV], rb[LB::NV];
-    la.load(0, ra); lb.load(0, rb);
-    la.store(sm16, ra, 0); lb.store(sm16 + LA::SIZE, rb, 0);
+    la.load(kt0, ra); lb.load(kt0, rb);
+    la.store(sm16, ra, kt0); lb.store(sm16 + LA::SIZE, rb, kt0);
     __syncthreads();
-    for (int kt = 0; kt < nk; ++kt) {
-        const int cur = kt & 1;
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
         const bool more = (kt + 1) < nk;
         if (more) { la.load(kt + 1, ra); lb.load(kt + 1, rb); }
         const unsigned short* a_s = sm16 + cur * STAGE;
@@ -490,7 +509,8 @@ __global__ __launch_bounds__(256) void gemm_h16_kernel(const GemmProbDev* __rest
     if (do_bg && tid < BM && m0 + tid < P->M) {
         gf dbias = (gf)P->bias;
         const int64_t bi = (int64_t)map_row(m0 + tid, (gci)P->c_gather, P->c_q, P->c_s) * P->bias_stride;
-        dbias[bi] += bg;
+        if (P->ksplit > 1) __hip_atomic_fetch_add(dbias + bi, bg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else dbias[bi] += bg;
     }
     epilogue<TM, TN>(P, acc, m0 + wm0, n0 + wn0, lane);
 }

@@ -14,8 +14,10 @@ struct GemmProbDev {
     int bias_q, bias_s, bias_stride;
     int act, dact, flags;
     float alpha;
-    int tile_start;      // first tile id of this problem inside its launch
-    int tiles_m;         // number of tiles along M
+    int tile_start;      // first tile id of this problem inside its launch (multiple of 8)
+    int tiles_m, tiles_n;
+    int ksplit, k_chunk; // split-K: K range [z*k_chunk, (z+1)*k_chunk) per replica z < ksplit
+    int order;           // 0: m-tiles innermost (B streamed), 1: n-tiles innermost (A streamed)
     int _pad;
 };
 
@@ -64,5 +66,6 @@ int ghn3_colsum(float* out, const float* X, int M, int N, int ld, int q, int sdi
 int ghn3_rowseg_sum(float* out, const float* X, const int* seg_ptr, const int* idx, int rows, int C, int ldx,
                     int ldo, int accum, hipStream_t s);
 int ghn3_add(float* dst, const float* src, int64_t n, hipStream_t s);
+int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, hipStream_t s);
 
 void ghn3_set_error(const char* fmt, ...);

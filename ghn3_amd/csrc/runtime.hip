@@ -235,7 +235,20 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             }
                             g.tile_start = L.tiles;               // always a multiple of 8 (XCD-aware order)
                             g.tiles_m = (p.M + tl - 1) / tl;
-                            L.tiles += g.tiles_m * ((((p.N + tl - 1) / tl) + 7) / 8 * 8);
+                            g.tiles_n = (p.N + tl - 1) / tl;
+                            g.order = (int64_t)p.M > (int64_t)p.N ? 1 : 0;   // stream the larger operand once
+                            g.ksplit = p.ksplit > 1 ? p.ksplit : 1;
+                            g.k_chunk = ((p.K + g.ksplit - 1) / g.ksplit + 63) / 64 * 64;
+                            if (g.ksplit > 1 && (p.bias.buf >= 0 || p.act || p.dact || p.residual.buf >= 0 ||
+                                                 p.aux_out.buf >= 0)) {
+                                ghn3_set_error("op %d problem %d: split-K allows no epilogue but alpha", k, q);
+                                return GHN3_E_ARG;
+                            }
+                            {
+                                const int per_split = g.order ? ((g.tiles_m + 7) / 8 * 8) * g.tiles_n
+                                                              : g.tiles_m * ((g.tiles_n + 7) / 8 * 8);
+                                L.tiles += per_split * g.ksplit;
+                            }
                             L.count++;
                         }
                         if (L.count > 0) op_launches[k].push_back(L);
@@ -378,6 +391,10 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         }
         case GHN3_OP_ADD:
             rc = ghn3_add(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), o.i[0], stream);
+            break;
+        case GHN3_OP_DACT:
+            rc = ghn3_dact(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), (int)o.i[0], (int)o.i[1], (int)o.i[2],
+                           (int)o.i[3], stream);
             break;
         default:
             ghn3_set_error("op %d: unknown kind %d", k, o.kind);

@@ -272,11 +272,27 @@ class GHN3(nn.Module):
             raise L.Ghn3Error('this plan was compiled without a backward program (training=False)')
         gflat = torch.empty(self._flat_numel, dtype=torch.float32, device=self.device)
         self._fill_bufs(plan, out=plan.out, dout=dout, gflat=gflat)
-        prog.bwd_ops[prog.memset_grad_op]['i'][0] = 4 * self._flat_numel
+        self._patch_grad_memsets(prog)
         self._ctx().run(prog.bwd_ops, prog.problems, plan.bufs, torch.cuda.current_stream().cuda_stream)
         plan.gflat = gflat
         ps = self._slot_params()
         return [gflat[o:o + p.numel()].view(p.shape) for p, o in zip(ps, self._offs)]
+
+    def _patch_grad_memsets(self, prog):
+        """Zero the flat gradient buffer except tensors the backward program fully overwrites."""
+        k = prog.memset_grad_op
+        total = 4 * self._flat_numel
+        ops = prog.bwd_ops
+        if prog.grad_no_memset:
+            name = prog.grad_no_memset[0]
+            slot = prog.slot[name]
+            beg = 4 * int(self._offs[slot])
+            end = 4 * int(self._offs[slot + 1]) if slot + 1 < len(self._offs) else total
+            ops[k]['r'][0]['off'], ops[k]['i'][0] = 0, beg
+            ops[k + 1]['r'][0]['off'], ops[k + 1]['i'][0] = end, total - end
+        else:
+            ops[k]['r'][0]['off'], ops[k]['i'][0] = 0, total
+            ops[k + 1]['r'][0]['off'], ops[k + 1]['i'][0] = 0, 0
 
     def embeddings(self, plan):
         """Node embeddings after the last Graphormer layer + LayerNorm, (B*N_max, C) (nn.py:259-263)."""

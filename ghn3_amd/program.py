@@ -168,7 +168,7 @@ class Program:
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, bias=None, bias_q=0,
              bias_s=0, bias_stride=1, act=L.ACT_NONE, dact=L.DACT_NONE, aux_in=None, aux_out=None, residual=None,
              a_gather=None, b_gather=None, c_gather=None, a_qs=(0, 0), b_qs=(0, 0), c_qs=(0, 0), accum=False,
-             alpha=1.0, dbias=None, dbias_stride=1):
+             alpha=1.0, dbias=None, dbias_stride=1, ksplit=1):
         # dbias: fused bias gradient of a wgrad problem (GHN3_GEMM_BIASGRAD): dbias[cmap(m)*stride] += sum_k A(m,k)
         if dbias is not None:
             assert bias is None and a_mode == L.MODE_COL
@@ -186,6 +186,7 @@ class Program:
                         ('flags', (L.GEMM_ACCUM if accum else 0) | (L.GEMM_BIASGRAD if dbias is not None else 0))):
             p[name] = int(v)
         p['alpha'] = alpha
+        p['ksplit'] = ksplit
         self._probs.append(p)
         return len(self._probs) - 1
 
@@ -666,8 +667,12 @@ class Program:
         (r_types, r_shape, r_nn, r_noff, deg_in, deg_out, dist0, pair) = self.r_graph
         xe = self.r_xe
         # gradients of all GHN parameters start at zero; every parameter-gradient op accumulates
-        self.op(L.OP_MEMSET0, refs=((self.xbuf(self.X_GRADFLAT), 0),), ints=(-1,))   # size patched at run time
+        # two memset ranges over the flat gradient buffer, patched at run time (offset, bytes): everything except
+        # the parameters listed in grad_no_memset (tensors the backward fully overwrites)
+        self.op(L.OP_MEMSET0, refs=((self.xbuf(self.X_GRADFLAT), 0),), ints=(-1,))
+        self.op(L.OP_MEMSET0, refs=((self.xbuf(self.X_GRADFLAT), 0),), ints=(-1,))
         self.memset_grad_op = 0
+        self.grad_no_memset = []
 
         d_rows = self.wsf('d_xrows', (M + n1) * C)
         # ---- tile backward -------------------------------------------------------------------------
@@ -718,18 +723,28 @@ class Program:
                     p0 = self.gemm(dout_n, tile_n, self.gref(Wc), K, ms[0], g['i'], ldK, g['i_ld'], ms[0],
                                    a_mode=L.MODE_COL, b_mode=L.MODE_ROW, accum=True, dbias=self.gref(bc))
                     self.gemm_op(p0)
-            # D3 backward: d_u = (d_tiles . W2sub) * (u > 0)   -- all groups, one launch
+            # D3 backward: d_u = (d_tiles . W2sub) * (u > 0)   -- all groups, one launch.  The reduction runs over
+            # the o*i columns of a group (up to C^2 = 147456) while M x N is only rows x 8C, so the K range is
+            # split into chunks (partial sums added atomically into the zeroed d_u) to fill the 256 CUs; the ReLU
+            # mask is applied afterwards in place.
+            self.op(L.OP_MEMSET0, refs=(d_u,), ints=(4 * M * 8 * C,))
             p0 = len(self._probs)
             for g in self.gemm_groups:
+                tiles = ((g['rows'] + 127) // 128) * ((8 * C + 127) // 128)
+                ks = int(max(1, min(64, (1024 + tiles - 1) // tiles, g['cols'] // 1024)))
                 self.gemm(self.wref('d_tiles', g['tile_off']), self.pref(W2), (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),
                           g['rows'], 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
-                          b_qs=(g['i_ld'], ms[1]), dact=L.DACT_RELU, aux_in=(u[0], u[1] + 4 * g['row0'] * 8 * C))
+                          b_qs=(g['i_ld'], ms[1]), ksplit=max(ks, 2))
             self.gemm_op(p0, tag=self.TAG_D3_DGRAD)
+            self.op(L.OP_DACT, refs=(d_u, u), ints=(M, 8 * C, 8 * C, L.DACT_RELU))
             # dW2[rows of the group] += d_tiles^T u ; groups overlap in W2 rows -> one launch per group
-            for g in self.gemm_groups:
+            for gi, g in enumerate(self.gemm_groups):
+                full = gi == 0 and g['o'] == ms[0] and g['i_ld'] == ms[1] and g['kind'] == 'conv'
+                if full:
+                    self.grad_no_memset.append(W2)      # every row of dW2 is written by this problem
                 p0 = self.gemm(self.wref('d_tiles', g['tile_off']), (u[0], u[1] + 4 * g['row0'] * 8 * C),
                                self.gref(W2), g['cols'], 8 * C, g['rows'], g['ld'], 8 * C, 8 * C,
-                               a_mode=L.MODE_COL, b_mode=L.MODE_COL, c_qs=(g['i_ld'], ms[1]), accum=True,
+                               a_mode=L.MODE_COL, b_mode=L.MODE_COL, c_qs=(g['i_ld'], ms[1]), accum=not full,
                                dbias=self.gref(b2))
                 self.gemm_op(p0, tag=self.TAG_D3_WGRAD)
             # D2 backward

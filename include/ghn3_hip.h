@@ -77,7 +77,8 @@ typedef struct ghn3_gemm_problem {
     int32_t bias_q, bias_s, bias_stride;
     int32_t act, dact, flags;
     float alpha;
-    int32_t _pad;
+    int32_t ksplit;     /* > 1: split the K range into `ksplit` chunks whose partial sums are ADDED atomically to C
+                         * (the program must zero C first; no epilogue but alpha is allowed) */
 } ghn3_gemm_problem;
 
 /* ---- tile / normalise descriptors  (nn.py:422-506 _tile_params, 554-592 _normalize, 508-552 _set_params)
@@ -155,6 +156,9 @@ enum ghn3_op_kind {
     GHN3_OP_MEMSET0 = 20,
     /* r0=dst r1=src ; i0 = n floats ; dst += src */
     GHN3_OP_ADD = 21,
+    /* in place: X[m][n] *= dact(aux[m][n]) ; r0=X r1=aux ; i: M,N,ld, dact (GHN3_DACT_*) -- the deferred
+     * epilogue of a split-K dgrad GEMM */
+    GHN3_OP_DACT = 22,
     GHN3_OP_KIND_COUNT
 };
 

@@ -113,7 +113,7 @@ class Interp:
                     v = v * (0.5 * (1 + erf(z / math.sqrt(2))) + z * np.exp(-0.5 * z * z) / math.sqrt(2 * math.pi))
             if int(p['residual']['buf']) >= 0:
                 v = v + self.tail(p['residual'], np.float32)[ci]
-            if int(p['flags']) & L.GEMM_ACCUM:
+            if int(p['flags']) & L.GEMM_ACCUM or int(p['ksplit']) > 1:
                 v = v + Y[ci]
             Y[ci] = v.astype(np.float32)
 
@@ -406,6 +406,17 @@ class Interp:
         b = self.bufs[int(o['r'][0]['buf'])]
         off = int(o['r'][0]['off'])
         b[off:off + n] = 0
+
+    def op_dact(self, o, problems):
+        M, N, ld, dact = (int(v) for v in o['i'][:4])
+        X = self.tail(o['r'][0], np.float32)
+        aux = self.tail(o['r'][1], np.float32)
+        ii = np.arange(M)[:, None] * ld + np.arange(N)[None, :]
+        z = aux[ii].astype(np.float64)
+        if dact == L.DACT_RELU:
+            X[ii] = np.where(z > 0, X[ii], 0.0)
+        else:
+            X[ii] = X[ii] * (0.5 * (1 + erf(z / math.sqrt(2))) + z * np.exp(-0.5 * z * z) / math.sqrt(2 * math.pi))
 
     def op_add(self, o, problems):
         n = int(o['i'][0])

@@ -97,7 +97,8 @@ def test_compiled_programs_reproduce_oracle_forward_and_backward(case, index_mod
         else:
             g = v / np.linalg.norm(v)
         dout[p['offset']:p['offset'] + p['numel']] = g.reshape(-1)
-    prog.bwd_ops[prog.memset_grad_op]['i'][0] = len(gflat)
+    gflat[:] = 0x7f                      # poison: the backward program must zero / overwrite everything
+    hip._patch_grad_memsets(prog)
     it.run(prog.bwd_ops, prog.problems)
     loss_o.backward()
     po = dict(oracle.named_parameters())

@@ -74,13 +74,13 @@ __device__ __forceinline__ void rows_times_matrix(const float* __restrict__ prow
     for (int r = 0; r < RW; ++r) out[r] = acc[r] + __shfl_xor(acc[r], 32, 64);
 }
 
-template <int NT, int RW>
+template <int NT, int RW, int DT>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, const float* __restrict__ qkv,
                                                        const float* __restrict__ bias, float* __restrict__ Psave,
                                                        const int* __restrict__ n_nodes, int N, int C, int H,
                                                        float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int d = C / H, ldk = d | 1;
+    const int d = DT ? DT : C / H, ldk = d | 1;      // DT > 0: head dim known at compile time
     float* KV = sm;                                   // N x ldk (K, later V)
     float* Ps = sm + (size_t)N * ldk;                 // ATT_WAVES * RW rows of N (+1 pad)
     const int p_ld = N + 1;
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, 
 // backward, pass 1 (row-wise): dP = dO V^T ; dS = P * (dP - rowsum(P*dP)) with masked entries zeroed ;
 // dQ = scale * dS K ; dBias += dS ; dS stored for pass 2.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int RW>
+template <int NT, int RW, int DT>
 __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(float* __restrict__ dqkv, const float* __restrict__ dO,
                                                             const float* __restrict__ qkv,
                                                             const float* __restrict__ P, float* __restrict__ dS,
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(float* __restrict__ 
                                                             const int* __restrict__ n_nodes, int N, int C, int H,
                                                             float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int d = C / H, ldk = d | 1;
+    const int d = DT ? DT : C / H, ldk = d | 1;
     float* Ks = sm;
     float* Vs = sm + (size_t)N * ldk;
     float* Ds = Vs + (size_t)N * ldk;                 // ATT_WAVES * RW rows of dS
@@ -248,22 +248,33 @@ __global__ __launch_bounds__(256) void attn_bwd_rows_kernel(float* __restrict__ 
 }
 
 // backward, pass 2 (column-wise, one key per lane): dV[j] = sum_i P[i][j] dO[i] ; dK[j] = scale sum_i dS[i][j] Q[i].
-// A block owns 64 keys; its 4 waves split the query rows (4 rows per step, loads batched) and reduce via LDS.
-__global__ __launch_bounds__(256) void attn_bwd_cols_kernel(float* __restrict__ dqkv, const float* __restrict__ dO,
-                                                            const float* __restrict__ qkv,
-                                                            const float* __restrict__ P, const float* __restrict__ dS,
-                                                            int N, int C, int H, float scale) {
+// A block owns 64 keys; its 16 waves split the query rows (4 rows per step, loads batched) and combine their
+// partial sums with LDS float atomics.
+#define COLS_WAVES 16
+template <int DT>
+__global__ __launch_bounds__(1024) void attn_bwd_cols_kernel(float* __restrict__ dqkv, const float* __restrict__ dO,
+                                                             const float* __restrict__ qkv,
+                                                             const float* __restrict__ P, const float* __restrict__ dS,
+                                                             int N, int C, int H, float scale) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int d = C / H;
+    const int d = DT ? DT : C / H;
     float* Qs = sm;                       // N x d   (row-broadcast reads)
     float* Gs = sm + (size_t)N * d;       // N x d   dO
-    float* red = Gs + (size_t)N * d;      // 4 waves x 64 lanes x (2d+1)
+    float* red = Gs + (size_t)N * d;      // 64 lanes x (2d+1)
+    const int ld2 = 2 * d + 1;
     const int b = blockIdx.z, h = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const float* base = qkv + (size_t)b * N * 3 * C;
     const size_t bh = ((size_t)b * H + h) * N;
-    stage_head(Qs, base + h * d, N, d, 3 * C, d, tid);
-    stage_head(Gs, dO + (size_t)b * N * C + h * d, N, d, C, d, tid);
+    {
+        const int total = N * d;
+        for (int idx = tid; idx < total; idx += 1024) {
+            const int i = idx / d, e = idx - i * d;
+            Qs[idx] = base[(size_t)i * 3 * C + h * d + e];
+            Gs[idx] = dO[((size_t)b * N + i) * C + h * d + e];
+        }
+        for (int idx = tid; idx < 64 * ld2; idx += 1024) red[idx] = 0.f;
+    }
     __syncthreads();
     const int j = blockIdx.x * 64 + lane;
     float dv[ATT_DMAX], dk[ATT_DMAX];
@@ -271,7 +282,7 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(float* __restrict__ 
     for (int e = 0; e < ATT_DMAX; ++e) { dv[e] = 0.f; dk[e] = 0.f; }
     if (j < N) {
         constexpr int U = 4;
-        for (int i0 = w * U; i0 < N; i0 += ATT_WAVES * U) {
+        for (int i0 = w * U; i0 < N; i0 += COLS_WAVES * U) {
             float pv[U], ds[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -289,20 +300,17 @@ __global__ __launch_bounds__(256) void attn_bwd_cols_kernel(float* __restrict__ 
                     if (e < d) { dv[e] += pv[u] * gr[e]; dk[e] += ds[u] * qr[e]; }
             }
         }
-    }
-    const int ld2 = 2 * d + 1;
-    float* my = red + ((size_t)w * 64 + lane) * ld2;
+        float* my = red + (size_t)lane * ld2;
 #pragma unroll
-    for (int e = 0; e < ATT_DMAX; ++e)
-        if (e < d) { my[e] = dv[e]; my[d + e] = dk[e]; }
+        for (int e = 0; e < ATT_DMAX; ++e)
+            if (e < d) { atomicAdd(&my[e], dv[e]); atomicAdd(&my[d + e], dk[e]); }
+    }
     __syncthreads();
-    for (int idx = tid; idx < 64 * 2 * d; idx += 256) {
+    for (int idx = tid; idx < 64 * 2 * d; idx += 1024) {
         const int l = idx / (2 * d), c = idx - l * (2 * d);
         const int jj = blockIdx.x * 64 + l;
         if (jj < N) {
-            float s_ = 0.f;
-#pragma unroll
-            for (int ww = 0; ww < ATT_WAVES; ++ww) s_ += red[((size_t)ww * 64 + l) * ld2 + c];
+            const float s_ = red[(size_t)l * ld2 + c];
             if (c < d) dqkv[((size_t)b * N + jj) * 3 * C + 2 * C + h * d + c] = s_;            // dV
             else dqkv[((size_t)b * N + jj) * 3 * C + C + h * d + (c - d)] = s_ * scale;          // dK
         }
@@ -315,23 +323,41 @@ typedef void (*attn_bwd_fn)(float*, const float*, const float*, const float*, fl
                             int, float);
 static const int kMaxLds = 160 * 1024;
 
-struct AttnCfg { attn_fwd_fn fwd; attn_bwd_fn bwd; int rw; };
-static AttnCfg pick(int N) {
-    if (N <= 256) return {attn_fwd_kernel<4, 4>, attn_bwd_rows_kernel<4, 4>, 4};
-    if (N <= 512) return {attn_fwd_kernel<8, 4>, attn_bwd_rows_kernel<8, 4>, 4};
-    return {attn_fwd_kernel<16, 2>, attn_bwd_rows_kernel<16, 2>, 2};
+typedef void (*attn_cols_fn)(float*, const float*, const float*, const float*, const float*, int, int, int, float);
+struct AttnCfg { attn_fwd_fn fwd; attn_bwd_fn bwd; attn_cols_fn cols; int rw; };
+
+template <int DT> static AttnCfg pick_n(int N) {
+    if (N <= 256) return {attn_fwd_kernel<4, 4, DT>, attn_bwd_rows_kernel<4, 4, DT>, attn_bwd_cols_kernel<DT>, 4};
+    if (N <= 512) return {attn_fwd_kernel<8, 4, DT>, attn_bwd_rows_kernel<8, 4, DT>, attn_bwd_cols_kernel<DT>, 4};
+    return {attn_fwd_kernel<16, 2, DT>, attn_bwd_rows_kernel<16, 2, DT>, attn_bwd_cols_kernel<DT>, 2};
+}
+static AttnCfg pick(int N, int d) {
+    switch (d) {                      // head dims of the released GHN-3 models: 8 (T, S), 16 (L), 24 (XL)
+    case 8: return pick_n<8>(N);
+    case 16: return pick_n<16>(N);
+    case 24: return pick_n<24>(N);
+    default: return pick_n<0>(N);
+    }
 }
 
-int ghn3_attn_init() {
-    const void* fns[] = {(const void*)attn_fwd_kernel<4, 4>, (const void*)attn_fwd_kernel<8, 4>,
-                         (const void*)attn_fwd_kernel<16, 2>, (const void*)attn_bwd_rows_kernel<4, 4>,
-                         (const void*)attn_bwd_rows_kernel<8, 4>, (const void*)attn_bwd_rows_kernel<16, 2>,
-                         (const void*)attn_bwd_cols_kernel};
+template <int DT> static int set_attrs() {
+    const void* fns[] = {(const void*)attn_fwd_kernel<4, 4, DT>, (const void*)attn_fwd_kernel<8, 4, DT>,
+                         (const void*)attn_fwd_kernel<16, 2, DT>, (const void*)attn_bwd_rows_kernel<4, 4, DT>,
+                         (const void*)attn_bwd_rows_kernel<8, 4, DT>, (const void*)attn_bwd_rows_kernel<16, 2, DT>,
+                         (const void*)attn_bwd_cols_kernel<DT>};
     for (const void* f : fns) {
         hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
         if (e != hipSuccess) { ghn3_set_error("attn hipFuncSetAttribute: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     }
     return GHN3_OK;
+}
+
+int ghn3_attn_init() {
+    int rc = set_attrs<0>();
+    if (!rc) rc = set_attrs<8>();
+    if (!rc) rc = set_attrs<16>();
+    if (!rc) rc = set_attrs<24>();
+    return rc;
 }
 
 static int check_dims(int N, int C, int H) {
@@ -347,8 +373,8 @@ int ghn3_attn_fwd(float* out, const float* qkv, const float* bias, float* P, con
                   int H, hipStream_t s) {
     int rc = check_dims(N, C, H);
     if (rc) return rc;
-    const AttnCfg cfg = pick(N);
     const int d = C / H, ldk = d | 1;
+    const AttnCfg cfg = pick(N, d);
     const size_t lds = ((size_t)N * ldk + (size_t)ATT_WAVES * cfg.rw * (N + 1)) * sizeof(float);
     if (lds > (size_t)kMaxLds) { ghn3_set_error("attention fwd: LDS %zu too large (N=%d d=%d)", lds, N, d); return GHN3_E_LIMIT; }
     const float scale = 1.0f / sqrtf((float)d);
@@ -365,11 +391,11 @@ int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P
     (void)O;
     int rc = check_dims(N, C, H);
     if (rc) return rc;
-    const AttnCfg cfg = pick(N);
     const int d = C / H, ldk = d | 1;
+    const AttnCfg cfg = pick(N, d);
     const float scale = 1.0f / sqrtf((float)d);
     const size_t lds1 = ((size_t)2 * N * ldk + (size_t)ATT_WAVES * cfg.rw * (N + 1)) * sizeof(float);
-    const size_t lds2 = ((size_t)2 * N * d + ATT_WAVES * 64 * (2 * d + 1)) * sizeof(float);
+    const size_t lds2 = ((size_t)2 * N * d + 64 * (2 * d + 1)) * sizeof(float);
     if (lds1 > (size_t)kMaxLds || lds2 > (size_t)kMaxLds) {
         ghn3_set_error("attention bwd: LDS %zu/%zu too large (N=%d d=%d)", lds1, lds2, N, d);
         return GHN3_E_LIMIT;
@@ -378,7 +404,7 @@ int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P
     dim3 grid((N + rpb - 1) / rpb, H, B);
     hipLaunchKernelGGL(cfg.bwd, grid, dim3(256), lds1, s, dqkv, dO, qkv, P, dS, dBias, n_nodes, N, C, H, scale);
     dim3 grid2((N + 63) / 64, H, B);
-    hipLaunchKernelGGL(attn_bwd_cols_kernel, grid2, dim3(256), lds2, s, dqkv, dO, qkv, P, dS, N, C, H, scale);
+    hipLaunchKernelGGL(cfg.cols, grid2, dim3(1024), lds2, s, dqkv, dO, qkv, P, dS, N, C, H, scale);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("attn bwd launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

@@ -105,25 +105,42 @@ __device__ __forceinline__ void epilogue(const GemmProbDev* P, f32x16 (&acc)[TM]
         }
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
+            // Pass 1: addresses + every read of this 32x32 sub-tile (old C, aux_in, residual) issued back to
+            // back, so the 16 elements cost one memory round trip instead of 16 dependent ones.
+            int64_t ci[16];
+            bool ok[16];
+            float cold[16], auxv[16], resv[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m_base + tm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-                if (row < M && col_ok) {
-                    const int64_t ci = (int64_t)map_row(row, cg, cq, cs) * ldc + col;
-                    if (split) {      // partial sum of one K chunk: C was zeroed by the host program
-                        __hip_atomic_fetch_add(C + ci, acc[tm][tn][r] * alpha, __ATOMIC_RELAXED,
+                ok[r] = row < M && col_ok;
+                ci[r] = (int64_t)map_row(ok[r] ? row : 0, cg, cq, cs) * ldc + (col_ok ? col : 0);
+            }
+            if (split) {      // partial sum of one K chunk: C was zeroed by the host program
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (ok[r])
+                        __hip_atomic_fetch_add(C + ci[r], acc[tm][tn][r] * alpha, __ATOMIC_RELAXED,
                                                __HIP_MEMORY_SCOPE_AGENT);
-                        continue;
-                    }
+                continue;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                cold[r] = (accum && ok[r]) ? C[ci[r]] : 0.f;
+                auxv[r] = (dact != GHN3_DACT_NONE && ok[r]) ? aux_in[ci[r]] : 0.f;
+                resv[r] = (residual && ok[r]) ? residual[ci[r]] : 0.f;
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                if (ok[r]) {
                     float v = acc[tm][tn][r] * alpha + bv;
-                    if (aux_out) aux_out[ci] = v;
+                    if (aux_out) aux_out[ci[r]] = v;
                     if (act == GHN3_ACT_RELU) v = fmaxf(v, 0.f);
                     else if (act == GHN3_ACT_GELU) v = gelu_f(v);
-                    if (dact == GHN3_DACT_RELU) v = (aux_in[ci] > 0.f) ? v : 0.f;
-                    else if (dact == GHN3_DACT_GELU) v *= gelu_grad_f(aux_in[ci]);
-                    if (residual) v += residual[ci];
-                    if (accum) v += C[ci];
-                    C[ci] = v;
+                    if (dact == GHN3_DACT_RELU) v = (auxv[r] > 0.f) ? v : 0.f;
+                    else if (dact == GHN3_DACT_GELU) v *= gelu_grad_f(auxv[r]);
+                    v += resv[r] + cold[r];
+                    C[ci[r]] = v;
                 }
             }
         }

@@ -27,6 +27,9 @@ int ghn3_gemm_init();
 int ghn3_gemm_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode,
                      int tile, int ctype, hipStream_t stream);
 
+int ghn3_gemm_small_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode,
+                           hipStream_t stream);
+
 int ghn3_attn_init();
 int ghn3_attn_fwd(float* out, const float* qkv, const float* bias, float* P, const int* n_nodes,
                   int B, int N, int C, int H, hipStream_t s);

@@ -164,9 +164,13 @@ struct Resolver {
     }
 };
 
+// tile code 32 = the latency-optimised small-problem kernel (gemm_small.hip, exact fp32): chosen when a problem
+// cannot fill the chip with 64x64 tiles and its K loop is short enough for one workgroup to split four ways.
 static int pick_tile(const ghn3_gemm_problem& p, int forced) {
-    if (forced == 64 || forced == 128) return forced;
-    const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128);
+    if (forced == 32 || forced == 64 || forced == 128) return forced;
+    const int64_t t64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
+    if (p.ksplit <= 1 && t64 <= 640 && p.K <= 8192) return 32;
+    const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.ksplit > 1 ? p.ksplit : 1);
     if (p.M >= 96 && p.N >= 96 && t128 >= 192) return 128;
     return 64;
 }
@@ -204,7 +208,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             // bucket by (a_mode, b_mode, tile)
             for (int am = 0; am < 2; ++am)
                 for (int bm = 0; bm < 2; ++bm)
-                    for (int tl = 64; tl <= 128; tl += 64) {
+                    for (int tl = 32; tl <= 128; tl *= 2) {
                         Launch L{am, bm, tl, (int)pos, 0, 0};
                         for (int q = first; q < first + cnt; ++q) {
                             const ghn3_gemm_problem& p = problems[q];
@@ -244,7 +248,9 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                 ghn3_set_error("op %d problem %d: split-K allows no epilogue but alpha", k, q);
                                 return GHN3_E_ARG;
                             }
-                            {
+                            if (tl == 32) {
+                                L.tiles += g.tiles_m * g.tiles_n;          // plain m-fastest order, no padding
+                            } else {
                                 const int per_split = g.order ? ((g.tiles_m + 7) / 8 * 8) * g.tiles_n
                                                               : g.tiles_m * ((g.tiles_n + 7) / 8 * 8);
                                 L.tiles += per_split * g.ksplit;
@@ -283,8 +289,11 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         case GHN3_OP_NOP: break;
         case GHN3_OP_GEMM:
             for (const Launch& L : op_launches[k]) {
-                rc = ghn3_gemm_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, L.tile,
-                                      (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, stream);
+                if (L.tile == 32)
+                    rc = ghn3_gemm_small_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, stream);
+                else
+                    rc = ghn3_gemm_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, L.tile,
+                                          (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, stream);
                 if (rc) break;
             }
             break;

@@ -154,3 +154,16 @@ CASES += [
     dict(M=1100, N=1300, K=64, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, tile=128),
     dict(M=40, N=2100, K=40, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, tile=64),
 ]
+# the 32x32 split-K-in-workgroup kernel (tile code 32), every addressing mode and epilogue
+for a_mode in (L.MODE_ROW, L.MODE_COL):
+    for b_mode in (L.MODE_ROW, L.MODE_COL):
+        CASES.append(dict(M=100, N=77, K=391, a_mode=a_mode, b_mode=b_mode, tile=32))
+        CASES.append(dict(M=33, N=65, K=19, a_mode=a_mode, b_mode=b_mode, tile=32, gather=True, accum=True))
+CASES += [
+    dict(M=256, N=1152, K=384, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, tile=32, epilogue='full', gather=True),
+    dict(M=256, N=384, K=1536, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, tile=32, epilogue='dgelu'),
+    dict(M=384, N=1536, K=256, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=32, epilogue='biasgrad', accum=True),
+    dict(M=70, N=40, K=130, a_mode=L.MODE_COL, b_mode=L.MODE_ROW, tile=32, epilogue='drelu', qs_map=True),
+    dict(M=50, N=90, K=70, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, tile=32, epilogue='bias_relu', qs_map=True),
+    dict(M=2, N=3, K=1, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, tile=32),
+]

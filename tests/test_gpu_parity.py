@@ -215,3 +215,31 @@ def test_size_independent_properties_at_scale():
             break
     n_pred = sum(p['numel'] for p in plan.program.predicted)
     assert n_pred == nets[0].num_params()
+
+
+@pytest.mark.parametrize('hid,heads,nodes', [(96, 4, [40]), (64, 4, [70, 33]), (48, 16, [30])])
+def test_head_dims_of_released_models(hid, heads, nodes):
+    """Head dims 24 (ghn3xlm16), 16 (ghn3lm8) and an odd one (3) through the specialised attention kernels and
+    the small-GEMM kernel: forward + backward vs the oracle, B = 1 and a ragged B = 2 batch."""
+    cfg = dict(max_shape=(hid, hid, 16, 16), num_classes=100, hid=hid, heads=heads, layers=2, weight_norm=True,
+               ve=True, layernorm=True)
+    hip, oracle = make_models(cfg, 11)
+    nets_h, gb_h, nets_o, gb_o = synthetic_case(nodes, 9100)
+    hip.train()
+    nets_h = hip(nets_h, gb_h, keep_grads=True)
+    loss = sum(torch.norm(p, p='fro') for net in nets_h for p in net.parameters())
+    loss.backward()
+    torch.cuda.synchronize()
+    oracle.train()
+    nets_o, pred_o = oracle(nets_o, gb_o, keep_grads=True)
+    loss_o = sum(torch.norm(t, p='fro') for (_, _, _, t) in pred_o)
+    loss_o.backward()
+    pred_h = predicted_dict_hip(hip.last_plan, hip.last_plan.out)
+    for k, (ind, attr, m, t) in enumerate(pred_o):
+        e = rel_l2(pred_h[k].detach().cpu(), t.detach())
+        assert e < 2e-5, (k, attr, tuple(t.shape), e)
+    po = dict(oracle.named_parameters())
+    for k, p in hip.named_parameters():
+        go = po[k].grad
+        err = float((p.grad.cpu().double() - go.double()).norm())
+        assert err < 3e-4 * float(go.norm()) + 1e-5, (k, err, float(go.norm()))

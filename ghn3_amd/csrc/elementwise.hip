@@ -379,29 +379,60 @@ __device__ __forceinline__ float norm_grad(float v, int mode, float scale) {
 struct SrcTable { const float* p[6]; };
 struct DstTable { float* p[6]; };
 
+// Mixed-radix "odometer": an element index is decoded into its 4 digits once per thread; every further element
+// of the thread (stride 256) adds the pre-decoded digits of 256 with carries, so the steady state has no integer
+// division (the HBM-bound tile kernels were ALU-bound on 64-bit div/mod before).
+struct Odo {
+    int d[4];      // digits, d[3] fastest
+    int T[4];      // radices
+    int s[4];      // digits of the stride
+    __device__ __forceinline__ void init(unsigned e, unsigned stride, int t0, int t1, int t2, int t3) {
+        T[0] = t0; T[1] = t1; T[2] = t2; T[3] = t3;
+        unsigned q = e;
+        d[3] = q % t3; q /= t3; d[2] = q % t2; q /= t2; d[1] = q % t1; d[0] = q / t1;
+        q = stride;
+        s[3] = q % t3; q /= t3; s[2] = q % t2; q /= t2; s[1] = q % t1; s[0] = q / t1;
+    }
+    __device__ __forceinline__ void step() {
+        int c = 0;
+#pragma unroll
+        for (int k = 3; k >= 1; --k) {
+            int v = d[k] + s[k] + c;
+            c = v >= T[k];
+            d[k] = c ? v - T[k] : v;
+        }
+        d[0] += s[0] + c;
+    }
+};
+
 __global__ __launch_bounds__(256) void tile_fwd_kernel(float* __restrict__ flat, SrcTable srcs,
                                                        const ghn3_tile_desc* __restrict__ desc,
                                                        const int64_t* __restrict__ blocks) {
     const int64_t di = blocks[2 * (size_t)blockIdx.x];
-    const int64_t start = blocks[2 * (size_t)blockIdx.x + 1];
+    const unsigned start = (unsigned)blocks[2 * (size_t)blockIdx.x + 1];
     const ghn3_tile_desc* D = desc + di;
-    const int T1 = D->T[1], T2 = D->T[2], T3 = D->T[3];
-    const int64_t numel = (int64_t)D->T[0] * T1 * T2 * T3;
-    const int64_t end = min(numel, start + TILE_CHUNK);
+    const int T0 = D->T[0], T1 = D->T[1], T2 = D->T[2], T3 = D->T[3];
+    const unsigned numel = (unsigned)T0 * T1 * T2 * T3;
+    const unsigned end = min(numel, start + TILE_CHUNK);
     const float* src = srcs.p[D->src_buf] + D->src_off;
     float* dst = flat + D->dst_off;
     const int E0 = D->E[0], E1 = D->E[1], E2 = D->E[2], E3 = D->E[3];
-    const int64_t S0 = D->S[0], S1 = D->S[1], S2 = D->S[2], S3 = D->S[3];
+    const bool w0 = E0 != T0, w1 = E1 != T1, w2 = E2 != T2, w3 = E3 != T3;   // does the dimension wrap (tile)?
+    const int S0 = (int)D->S[0], S1 = (int)D->S[1], S2 = (int)D->S[2], S3 = (int)D->S[3];
     const int mode = D->mode;
     const float scale = D->scale;
-    for (int64_t e = start + threadIdx.x; e < end; e += 256) {
-        int64_t r = e;
-        const int d3 = (int)(r % T3); r /= T3;
-        const int d2 = (int)(r % T2); r /= T2;
-        const int d1 = (int)(r % T1);
-        const int d0 = (int)(r / T1);
-        const float v = src[(d0 % E0) * S0 + (d1 % E1) * S1 + (d2 % E2) * S2 + (d3 % E3) * S3];
-        dst[e] = norm_apply(v, mode, scale);
+    Odo o;
+    unsigned e = start + threadIdx.x;
+    o.init(e, 256, T0, T1, T2, T3);
+#pragma unroll 2
+    for (; e < end; e += 256) {
+        const int m0 = w0 ? o.d[0] % E0 : o.d[0];
+        const int m1 = w1 ? o.d[1] % E1 : o.d[1];
+        const int m2 = w2 ? o.d[2] % E2 : o.d[2];
+        const int m3 = w3 ? o.d[3] % E3 : o.d[3];
+        const int64_t so = (int64_t)m0 * S0 + (int64_t)m1 * S1 + (int64_t)m2 * S2 + (int64_t)m3 * S3;
+        dst[e] = norm_apply(src[so], mode, scale);
+        o.step();
     }
 }
 
@@ -422,26 +453,26 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
                                                        const ghn3_tile_desc* __restrict__ desc,
                                                        const int64_t* __restrict__ blocks) {
     const int64_t di = blocks[2 * (size_t)blockIdx.x];
-    const int64_t start = blocks[2 * (size_t)blockIdx.x + 1];
+    const unsigned start = (unsigned)blocks[2 * (size_t)blockIdx.x + 1];
     const ghn3_tile_desc* D = desc + di;
     const int R0 = D->R[0], R1 = D->R[1], R2 = D->R[2], R3 = D->R[3];
-    const int64_t numel = (int64_t)R0 * R1 * R2 * R3;
-    const int64_t end = min(numel, start + TILE_CHUNK);
+    const unsigned numel = (unsigned)R0 * R1 * R2 * R3;
+    const unsigned end = min(numel, start + TILE_CHUNK);
     const float* src = srcs.p[D->src_buf] + D->src_off;
     float* dsrc = dsrcs.p[D->src_buf] + D->src_off;
     const float* g = dflat + D->dst_off;
     const int T0 = D->T[0], T1 = D->T[1], T2 = D->T[2], T3 = D->T[3];
     const int E0 = D->E[0], E1 = D->E[1], E2 = D->E[2], E3 = D->E[3];
-    const int64_t S0 = D->S[0], S1 = D->S[1], S2 = D->S[2], S3 = D->S[3];
+    const int S0 = (int)D->S[0], S1 = (int)D->S[1], S2 = (int)D->S[2], S3 = (int)D->S[3];
     const int mode = D->mode;
     const float scale = D->scale;
-    for (int64_t e = start + threadIdx.x; e < end; e += 256) {
-        int64_t r = e;
-        const int a1 = (int)(r % R1); r /= R1;
-        const int a3 = (int)(r % R3); r /= R3;
-        const int a2 = (int)(r % R2);
-        const int a0 = (int)(r / R2);
-        const int64_t so = a0 * S0 + a1 * S1 + a2 * S2 + a3 * S3;
+    // iteration order over the source region: a1 fastest, then a3, a2, a0  -> odometer digits (a0, a2, a3, a1)
+    Odo o;
+    unsigned e = start + threadIdx.x;
+    o.init(e, 256, R0, R2, R3, R1);
+    for (; e < end; e += 256) {
+        const int a0 = o.d[0], a2 = o.d[1], a3 = o.d[2], a1 = o.d[3];
+        const int64_t so = (int64_t)a0 * S0 + (int64_t)a1 * S1 + (int64_t)a2 * S2 + (int64_t)a3 * S3;
         float acc = 0.f;
         if (a0 < E0 && a1 < E1 && a2 < E2 && a3 < E3) {
             for (int t0 = a0; t0 < T0; t0 += E0)
@@ -452,6 +483,7 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
             acc *= norm_grad(src[so], mode, scale);
         }
         dsrc[so] = acc;
+        o.step();
     }
 }
 
@@ -479,7 +511,13 @@ __global__ __launch_bounds__(256) void param_sq_kernel(const float* __restrict__
     float acc = 0.f;
     for (int64_t c0 = b0 + (int64_t)blockIdx.x * NORM_CHUNK; c0 < b1; c0 += (int64_t)gridDim.x * NORM_CHUNK) {
         const int64_t c1 = min(b1, c0 + NORM_CHUNK);
-        for (int64_t e = c0 + threadIdx.x; e < c1; e += 256) { const float v = flat[e]; acc += v * v; }
+        const int64_t n4 = (c1 - c0) >> 2;                       // segments start 64-byte aligned
+        const float4* f4 = reinterpret_cast<const float4*>(flat + c0);
+        for (int64_t q = threadIdx.x; q < n4; q += 256) {
+            const float4 v = f4[q];
+            acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        }
+        for (int64_t e = c0 + 4 * n4 + threadIdx.x; e < c1; e += 256) { const float v = flat[e]; acc += v * v; }
     }
     acc = wsum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -519,7 +557,15 @@ __global__ __launch_bounds__(256) void param_norm_bwd_kernel(float* __restrict__
     const float k = nrm > 0.f ? g / nrm : 0.f;
     for (int64_t c0 = b0 + (int64_t)blockIdx.x * NORM_CHUNK; c0 < b1; c0 += (int64_t)gridDim.x * NORM_CHUNK) {
         const int64_t c1 = min(b1, c0 + NORM_CHUNK);
-        for (int64_t e = c0 + threadIdx.x; e < c1; e += 256) dflat[e] = flat[e] * k;
+        const int64_t n4 = (c1 - c0) >> 2;
+        const float4* f4 = reinterpret_cast<const float4*>(flat + c0);
+        float4* d4 = reinterpret_cast<float4*>(dflat + c0);
+        for (int64_t q = threadIdx.x; q < n4; q += 256) {
+            float4 v = f4[q];
+            v.x *= k; v.y *= k; v.z *= k; v.w *= k;
+            d4[q] = v;
+        }
+        for (int64_t e = c0 + 4 * n4 + threadIdx.x; e < c1; e += 256) dflat[e] = flat[e] * k;
     }
 }
 int ghn3_param_norm_bwd(float* dflat, const float* flat, const int64_t* seg_off, const float* norms, int n_seg,

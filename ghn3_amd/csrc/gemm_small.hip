@@ -4,11 +4,11 @@
 // K, N in {C, 3C, 4C}: a few hundred MFLOP each, far too little to fill 256 CUs with 64x64 / 128x128 tiles,
 // and with a K loop that is latency- rather than throughput-bound.  This kernel trades tile reuse for
 // parallelism and short dependency chains:
-//   * one workgroup = one 32 x 32 output tile; its 4 waves split the K range (split-K inside the workgroup,
-//     combined through 16 KB of LDS), so a C = 384 projection runs 24 MFMA steps per wave instead of 192;
+//   * one workgroup = one 32 x 32 output tile; its 16 waves split the K range (split-K inside the workgroup,
+//     combined through 64 KB of LDS), so a C = 384 projection is ONE 32-deep chunk (12 MFMA steps) per wave and a
+//     4C = 1536 reduction three: the per-wave dependency chain is 1-3 memory round trips instead of 12-48;
 //   * operands go global -> registers -> v_mfma_f32_32x32x2_f32 directly (no LDS staging): a ROW-mode operand
 //     row is read as float4 by the two half-wave lanes that need it, a COL-mode operand as coalesced dwords;
-//   * the next 32-deep K chunk is in flight while the current one feeds the MFMAs.
 // Same operand / epilogue contract as the tiled kernels (include/ghn3_hip.h), exact fp32.
 
 #include "ghn3_internal.h"
@@ -24,6 +24,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #define ROWM GHN3_MODE_ROW
 #define COLM GHN3_MODE_COL
 #define KC 32            // K chunk per pipeline stage (16 MFMA steps)
+#define SW 16            // waves per workgroup = K slices
 
 __device__ __forceinline__ int s_map_row(int r, gci gather, int q, int s) {
     if (gather) r = gather[r];
@@ -71,26 +72,22 @@ struct SmallOperand {
             }
         }
     }
-    __device__ __forceinline__ void extract(int k0, float (&v)[KC / 2]) const {
+    // element consumed by MFMA step st of the chunk that starts at k0
+    __device__ __forceinline__ float value(int st, int k0) const {
         if (MODE == ROWM) {
-#pragma unroll
-            for (int st = 0; st < KC / 2; ++st) {
-                const f32x4 x = raw4[st >> 1];
-                const float lo = (st & 1) ? x.z : x.x, hi = (st & 1) ? x.w : x.y;
-                const float val = h ? hi : lo;
-                v[st] = (k0 + 2 * st + h < k_end) ? val : 0.f;
-            }
-        } else {
-#pragma unroll
-            for (int st = 0; st < KC / 2; ++st) v[st] = raw1[st];
+            const f32x4 x = raw4[st >> 1];
+            const float lo = (st & 1) ? x.z : x.x, hi = (st & 1) ? x.w : x.y;
+            const float val = h ? hi : lo;
+            return (k0 + 2 * st + h < k_end) ? val : 0.f;
         }
+        return raw1[st];
     }
 };
 
 template <int AM, int BMD>
-__global__ __launch_bounds__(256) void gemm_small_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
-    __shared__ float red[4][16][64];
-    __shared__ float bgs[4][64];
+__global__ __launch_bounds__(1024) void gemm_small_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
+    __shared__ float red[SW][16][64];
+    __shared__ float bgs[SW][64];
     int lo = 0, hi_ = n_probs - 1;
     while (lo < hi_) {
         int mid = (lo + hi_ + 1) >> 1;
@@ -102,7 +99,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmProbDev* __re
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int M = P->M, N = P->N, K = P->K;
     // K slice of this wave (multiple of 4 so that ROW-mode float4 loads stay aligned)
-    const int slice = (((K + 3) / 4) + 3) / 4 * 4;
+    const int slice = (((K + SW - 1) / SW) + 3) / 4 * 4;
     const int kb = w * slice;
     const int ke = min(K, kb + slice);
 
@@ -116,17 +113,14 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmProbDev* __re
     float bg = 0.f;
     const bool do_bg = (AM == COLM) && (P->flags & GHN3_GEMM_BIASGRAD) && n0 == 0;
 
-    if (kb < ke) {
-        oa.issue(kb); ob.issue(kb);
-        for (int k0 = kb; k0 < ke; k0 += KC) {
-            float av[KC / 2], bv[KC / 2];
-            oa.extract(k0, av); ob.extract(k0, bv);
-            if (k0 + KC < ke) { oa.issue(k0 + KC); ob.issue(k0 + KC); }
+    // 16 waves per workgroup (4 per SIMD) hide the load latency of one another; a wave runs 1-3 chunks.
+    for (int k0 = kb; k0 < ke; k0 += KC) {
+        oa.issue(k0); ob.issue(k0);
 #pragma unroll
-            for (int st = 0; st < KC / 2; ++st) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[st], bv[st], acc, 0, 0, 0);
-                if (AM == COLM) bg += av[st];
-            }
+        for (int st = 0; st < KC / 2; ++st) {
+            const float a = oa.value(st, k0), b = ob.value(st, k0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+            if (AM == COLM) bg += a;
         }
     }
 #pragma unroll
@@ -137,7 +131,7 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmProbDev* __re
     if (do_bg && tid < 32 && m0 + tid < M) {
         float sum = 0.f;
 #pragma unroll
-        for (int ww = 0; ww < 4; ++ww) sum += bgs[ww][tid] + bgs[ww][tid + 32];
+        for (int ww = 0; ww < SW; ++ww) sum += bgs[ww][tid] + bgs[ww][tid + 32];
         gf dbias = (gf)P->bias;
         dbias[(int64_t)s_map_row(m0 + tid, (gci)P->c_gather, P->c_q, P->c_s) * P->bias_stride] += sum;
     }
@@ -151,16 +145,17 @@ __global__ __launch_bounds__(256) void gemm_small_kernel(const GemmProbDev* __re
     const bool accum = (P->flags & GHN3_GEMM_ACCUM) != 0;
     const bool use_bias = bias && !(P->flags & GHN3_GEMM_BIASGRAD);
     const float alpha = P->alpha;
-#pragma unroll
-    for (int qd = 0; qd < 4; ++qd) {
-        const int e = tid + 256 * qd;
+    {
+        const int e = tid;                      // 1024 threads = 32 x 32 outputs
         const int rl = e >> 5, cl = e & 31;
         const int row = m0 + rl, col = n0 + cl;
         if (row < M && col < N) {
             const int hh = (rl >> 2) & 1;
             const int r = (rl & 3) + 4 * (rl >> 3);
             const int ln = cl + 32 * hh;
-            float v = (red[0][r][ln] + red[1][r][ln]) + (red[2][r][ln] + red[3][r][ln]);
+            float v = 0.f;
+#pragma unroll
+            for (int ww = 0; ww < SW; ++ww) v += red[ww][r][ln];
             v *= alpha;
             if (use_bias) {
                 int bi = col;
@@ -188,7 +183,7 @@ static small_fn g_small[2][2] = {
 int ghn3_gemm_small_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode,
                            hipStream_t stream) {
     if (n_probs <= 0 || total_tiles <= 0) return GHN3_OK;
-    hipLaunchKernelGGL(g_small[a_mode][b_mode], dim3(total_tiles), dim3(256), 0, stream, d_probs, n_probs);
+    hipLaunchKernelGGL(g_small[a_mode][b_mode], dim3(total_tiles), dim3(64 * SW), 0, stream, d_probs, n_probs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("small gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

@@ -166,10 +166,12 @@ struct Resolver {
 
 // tile code 32 = the latency-optimised small-problem kernel (gemm_small.hip, exact fp32): chosen when a problem
 // cannot fill the chip with 64x64 tiles and its K loop is short enough for one workgroup to split four ways.
-static int pick_tile(const ghn3_gemm_problem& p, int forced) {
+static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
     if (forced == 32 || forced == 64 || forced == 128) return forced;
-    const int64_t t64 = (int64_t)((p.M + 63) / 64) * ((p.N + 63) / 64);
-    if (p.ksplit <= 1 && t64 <= 640 && p.K <= 8192) return 32;
+    // op_t64 = 64x64 tiles of ALL problems launched together with this one: a grouped launch that already fills
+    // the chip keeps the tiled kernels (better operand reuse); a lone small problem takes the latency kernel.
+    const double flops = 2.0 * p.M * p.N * (double)p.K;
+    if (p.ksplit <= 1 && op_t64 <= 640 && flops <= 4e9 && p.K <= 8192) return 32;
     const int64_t t128 = (int64_t)((p.M + 127) / 128) * ((p.N + 127) / 128) * (p.ksplit > 1 ? p.ksplit : 1);
     if (p.M >= 96 && p.N >= 96 && t128 >= 192) return 128;
     return 64;
@@ -205,6 +207,9 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                 ghn3_set_error("op %d: GEMM problem range [%d,%d) outside table of %d", k, first, first + cnt, n_problems);
                 return GHN3_E_ARG;
             }
+            int64_t op_t64 = 0;
+            for (int q = first; q < first + cnt; ++q)
+                op_t64 += (int64_t)((problems[q].M + 63) / 64) * ((problems[q].N + 63) / 64);
             // bucket by (a_mode, b_mode, tile)
             for (int am = 0; am < 2; ++am)
                 for (int bm = 0; bm < 2; ++bm)
@@ -213,7 +218,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                         for (int q = first; q < first + cnt; ++q) {
                             const ghn3_gemm_problem& p = problems[q];
                             if (p.M <= 0 || p.N <= 0) continue;
-                            if (p.a_mode != am || p.b_mode != bm || pick_tile(p, forced) != tl) continue;
+                            if (p.a_mode != am || p.b_mode != bm || pick_tile(p, forced, op_t64) != tl) continue;
                             if (p.K < 0 || (p.lda & 3) || (p.ldb & 3) || (p.A.off & 15) || (p.B.off & 15)) {
                                 ghn3_set_error("op %d problem %d: operands must be 16-byte aligned with ld %% 4 == 0 "
                                                "(lda=%d ldb=%d)", k, q, p.lda, p.ldb);

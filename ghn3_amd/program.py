@@ -248,7 +248,9 @@ class Program:
                 y0, x0 = max(0, half - kh // 2), max(0, half - kw // 2)
                 g['pos'] = np.asarray([(y0 + y) * S + (x0 + x) for y in range(kh) for x in range(kw)],
                                       dtype=np.int32)
-                g['ld'] = round_up(g['cols'], 4)
+                # leading dimension of the tile buffer: +64 floats so that rows are never a power-of-two apart
+                # (the wgrad reads this buffer k-strided; 2^n strides alias onto the same HBM channels)
+                g['ld'] = round_up(g['cols'], 4) + 64
                 g['rows'] = len(inds) * g['hw']
                 self.conv_groups.append(g)
             else:

@@ -209,6 +209,16 @@ class Program:
                 self.tag_flops[tag] = self.tag_flops.get(tag, 0.0) + fl
             self.op(L.OP_GEMM, ints=(first, count, tile), flags=flags)
 
+    @staticmethod
+    def _row_parts(rows):
+        """Split a stacked row range into a 128-multiple part and a short remainder (<= 64 rows) so that the
+        128x128 tiles waste no MFMA rows on the tail (533 rows -> 512 + 21 instead of 5 x 128 = 640)."""
+        main = rows // 128 * 128
+        rem = rows - main
+        if main >= 128 and 0 < rem <= 64:
+            return [(0, main), (main, rem)]
+        return [(0, rows)]
+
     # ------------------------------------------------------------------ decoder layout (host bookkeeping)
     def _src_row(self, ind):
         """xe row read for sparse-flat node index `ind` (quirk Q1: reference reads dense-flat row `ind`)."""
@@ -437,10 +447,12 @@ class Program:
             self.tiles_floats = tiles_floats
             tiles = self.wsf('tiles', tiles_floats)
             for g in self.gemm_groups:
-                self.gemm((u[0], u[1] + 4 * g['row0'] * 8 * C), self.pref(W2), self.wref('tiles', g['tile_off']),
-                          g['rows'], g['cols'], 8 * C, 8 * C, 8 * C, g['ld'], b_qs=(g['i_ld'], ms[1]),
-                          bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1],
-                          act=L.ACT_RELU if g['kind'] == 'cls' else L.ACT_NONE)
+                for (r0, nr) in self._row_parts(g['rows']):
+                    self.gemm((u[0], u[1] + 4 * (g['row0'] + r0) * 8 * C), self.pref(W2),
+                              self.wref('tiles', g['tile_off'] + r0 * g['ld']),
+                              nr, g['cols'], 8 * C, 8 * C, 8 * C, g['ld'], b_qs=(g['i_ld'], ms[1]),
+                              bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1],
+                              act=L.ACT_RELU if g['kind'] == 'cls' else L.ACT_NONE)
             self.gemm_op(p0, tag=self.TAG_D3_FWD)
             # classifier head (nn.py:755-758): out[i'][k] = sum_o' relu(tile[o'][i']) Wcls[k][o'] + bcls[k]
             n_cls_rows = sum(g['rows'] * g['i_ld'] for g in self.conv_groups if g['kind'] == 'cls')
@@ -732,11 +744,13 @@ class Program:
             self.op(L.OP_MEMSET0, refs=(d_u,), ints=(4 * M * 8 * C,))
             p0 = len(self._probs)
             for g in self.gemm_groups:
-                tiles = ((g['rows'] + 127) // 128) * ((8 * C + 127) // 128)
-                ks = int(max(1, min(64, (1024 + tiles - 1) // tiles, g['cols'] // 1024)))
-                self.gemm(self.wref('d_tiles', g['tile_off']), self.pref(W2), (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),
-                          g['rows'], 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
-                          b_qs=(g['i_ld'], ms[1]), ksplit=max(ks, 2))
+                for (r0, nr) in self._row_parts(g['rows']):
+                    tiles = ((nr + 127) // 128) * ((8 * C + 127) // 128)
+                    ks = int(max(2, min(64, (2048 + tiles - 1) // tiles, g['cols'] // 1024)))
+                    self.gemm(self.wref('d_tiles', g['tile_off'] + r0 * g['ld']), self.pref(W2),
+                              (d_u[0], d_u[1] + 4 * (g['row0'] + r0) * 8 * C),
+                              nr, 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
+                              b_qs=(g['i_ld'], ms[1]), ksplit=ks)
             self.gemm_op(p0, tag=self.TAG_D3_DGRAD)
             self.op(L.OP_DACT, refs=(d_u, u), ints=(M, 8 * C, 8 * C, L.DACT_RELU))
             # dW2[rows of the group] += d_tiles^T u ; groups overlap in W2 rows -> one launch per group
@@ -748,7 +762,8 @@ class Program:
                                self.gref(W2), g['cols'], 8 * C, g['rows'], g['ld'], 8 * C, 8 * C,
                                a_mode=L.MODE_COL, b_mode=L.MODE_COL, c_qs=(g['i_ld'], ms[1]), accum=not full,
                                dbias=self.gref(b2))
-                self.gemm_op(p0, tag=self.TAG_D3_WGRAD)
+                # short reduction (K = rows of the group): 64x64 tiles beat 128x128 here (tests/gemm_bench.py)
+                self.gemm_op(p0, tile=64 if g['rows'] <= 1024 else 0, tag=self.TAG_D3_WGRAD)
             # D2 backward
             p0 = self.gemm(d_u, t, self.gref(W0), 8 * C, 4 * C, M, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_COL,
                            b_mode=L.MODE_COL, accum=True, dbias=self.gref(b0))
@@ -828,16 +843,15 @@ class Program:
             m1, r1, m2, r2 = self.wref('m1' + sfx), self.wref('r1' + sfx), self.wref('m2' + sfx), self.wref('r2' + sfx)
             W3, W1f, Wo, Wq = pre + 'ff.net.3.weight', pre + 'ff.net.0.weight', pre + 'attn.to_out.0.weight', \
                 pre + 'attn.to_qkv.weight'
+            # The four dgrad GEMMs form the dependent chain of the layer; the four wgrad GEMMs (+ fused bias
+            # gradients) are off the critical path and are issued as ONE grouped launch at the end of the layer,
+            # while all their operands (g_cur, dz, g_mid, dqkv and the saved activations) are still alive.
             # FFN second linear: x_out = xmid + f W3^T + b3
-            p0 = self.gemm(g_cur, f, self.gref(W3), C, 4 * C, rows, C, 4 * C, 4 * C, a_mode=L.MODE_COL,
-                           b_mode=L.MODE_COL, accum=True, dbias=self.gref(pre + 'ff.net.3.bias'))
-            self.gemm(g_cur, self.pref(W3), dz, rows, 4 * C, C, C, 4 * C, 4 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
-                      dact=L.DACT_GELU, aux_in=z)
+            p0 = self.gemm(g_cur, self.pref(W3), dz, rows, 4 * C, C, C, 4 * C, 4 * C, a_mode=L.MODE_ROW,
+                           b_mode=L.MODE_COL, dact=L.DACT_GELU, aux_in=z)
             self.gemm_op(p0)
             # FFN first linear
-            p0 = self.gemm(dz, h2, self.gref(W1f), 4 * C, C, rows, 4 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
-                           accum=True, dbias=self.gref(pre + 'ff.net.0.bias'))
-            self.gemm(dz, self.pref(W1f), dh, rows, C, 4 * C, 4 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+            p0 = self.gemm(dz, self.pref(W1f), dh, rows, C, 4 * C, 4 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
             self.gemm_op(p0)
             # LN2 (+ residual branch gradient g_cur)
             self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln2.weight'), self.gref(pre + 'ln2.bias'), dh, xmid,
@@ -846,14 +860,20 @@ class Program:
                     ints=(rows, C))
             g_mid = other
             # attention output projection: xmid = x_in + o Wo^T + bo
-            p0 = self.gemm(g_mid, o, self.gref(Wo), C, C, rows, C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
-                           accum=True, dbias=self.gref(pre + 'attn.to_out.0.bias'))
-            self.gemm(g_mid, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+            p0 = self.gemm(g_mid, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
             self.gemm_op(p0)
             self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, dS, dBias, r_nn), ints=(B, N, C, H))
-            p0 = self.gemm(dqkv, h1, self.gref(Wq), 3 * C, C, rows, 3 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
-                           accum=True)
-            self.gemm(dqkv, self.pref(Wq), dh, rows, C, 3 * C, 3 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+            p0 = self.gemm(dqkv, self.pref(Wq), dh, rows, C, 3 * C, 3 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+            self.gemm_op(p0)
+            # deferred weight gradients of the layer, one launch
+            p0 = self.gemm(g_cur, f, self.gref(W3), C, 4 * C, rows, C, 4 * C, 4 * C, a_mode=L.MODE_COL,
+                           b_mode=L.MODE_COL, accum=True, dbias=self.gref(pre + 'ff.net.3.bias'))
+            self.gemm(dz, h2, self.gref(W1f), 4 * C, C, rows, 4 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
+                      accum=True, dbias=self.gref(pre + 'ff.net.0.bias'))
+            self.gemm(g_mid, o, self.gref(Wo), C, C, rows, C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
+                      accum=True, dbias=self.gref(pre + 'attn.to_out.0.bias'))
+            self.gemm(dqkv, h1, self.gref(Wq), 3 * C, C, rows, 3 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
+                      accum=True)
             self.gemm_op(p0)
             self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln1.weight'), self.gref(pre + 'ln1.bias'), dh, x_in,
                                               m1, r1), ints=(rows, C, 1))

@@ -41,7 +41,9 @@ def cpu_baseline(model, sample_nodes, seed):
     """Oracle (CPU restatement of the reference algorithm incl. its per-group Python loops) timed on the host."""
     from oracle import ghn3_ref as R
     from ghn3_amd.synthetic import synthetic_batch
-    cores = os.cpu_count() or 1
+    # torch's CPU GEMMs stop scaling (and the many small per-group ops get slower) beyond a few dozen threads;
+    # 256 threads measured 168 s per step where 16 take a fraction of it, so the baseline uses <= 16 threads.
+    cores = min(os.cpu_count() or 1, int(os.environ.get('GHN3_CPU_THREADS', '16')))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     oracle = R.GHN3Ref(**model_cfg(model))

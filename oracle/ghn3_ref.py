@@ -398,8 +398,8 @@ def set_params(module, key, tensor, keep_grads):
     if len(sz_target) == 4 and tensor.dim() == 2:
         tensor = tensor.unsqueeze(2).unsqueeze(3)
     if keep_grads:
-        if isinstance(target, (list, tuple)):
-            setattr(module, key, tensor)
+        if isinstance(target, (list, tuple)) or not isinstance(module, nn.Module):
+            setattr(module, key, tensor)         # light modules (shape lists, light_ops.py:236-240)
         else:
             module.__dict__[key] = tensor
             module._parameters[key] = tensor

@@ -12,7 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libghn3_hip.so')
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 # ---- numpy mirrors of the C structs -------------------------------------------------------------
 REF_DT = np.dtype([('buf', '<i4'), ('_pad', '<i4'), ('off', '<i8')])
@@ -20,28 +20,34 @@ _REF_NAMES = ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather'
 _INT_NAMES = ('M', 'N', 'K', 'lda', 'ldb', 'ldc', 'a_mode', 'b_mode', 'a_q', 'a_s', 'b_q', 'b_s', 'c_q', 'c_s',
               'bias_q', 'bias_s', 'bias_stride', 'act', 'dact', 'flags')
 PROBLEM_DT = np.dtype([(n, REF_DT) for n in _REF_NAMES] + [(n, '<i4') for n in _INT_NAMES] +
-                      [('alpha', '<f4'), ('ksplit', '<i4')])
+                      [('alpha', '<f4'), ('ksplit', '<i4'), ('b_kq', '<i4'), ('b_ks', '<i4')])
 TILE_DT = np.dtype([('dst_off', '<i8'), ('src_off', '<i8'), ('S', '<i8', 4), ('T', '<i4', 4), ('E', '<i4', 4),
                     ('R', '<i4', 4), ('src_buf', '<i4'), ('mode', '<i4'), ('scale', '<f4'), ('_pad', '<i4')])
+CAST_DT = np.dtype([('src_off', '<i8'), ('dst_off', '<i8'), ('dstT_off', '<i8'), ('rows', '<i4'), ('cols', '<i4'),
+                    ('ld_src', '<i4'), ('ld_dst', '<i4'), ('ld_dstT', '<i4'), ('flags', '<u4'), ('bias_q', '<i4'),
+                    ('bias_s', '<i4'), ('block_start', '<i4'), ('_pad', '<i4')])
 OP_DT = np.dtype([('kind', '<i4'), ('flags', '<i4'), ('i', '<i8', 8), ('f', '<f4', 4), ('r', REF_DT, 14)])
-assert REF_DT.itemsize == 16 and PROBLEM_DT.itemsize == 248 and TILE_DT.itemsize == 112 and OP_DT.itemsize == 312
+assert REF_DT.itemsize == 16 and PROBLEM_DT.itemsize == 256 and TILE_DT.itemsize == 112 and OP_DT.itemsize == 312
+assert CAST_DT.itemsize == 64
 
 MODE_ROW, MODE_COL = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
 DACT_NONE, DACT_RELU, DACT_GELU = 0, 1, 2
 GEMM_ACCUM = 1
 GEMM_BIASGRAD = 2
+GEMM_OP16 = 4
+CAST_STRAIGHT, CAST_TRANSPOSED, CAST_STRAIGHT_BF16, CAST_TRANSPOSED_BF16, CAST_COLSUM = 1, 2, 4, 8, 16
 CT_F32, CT_F16, CT_BF16 = 0, 1, 2
 COMPUTE_TYPES = {'f32': CT_F32, 'f16': CT_F16, 'bf16': CT_BF16}
 
 (OP_NOP, OP_GEMM, OP_GRAPH_PROLOGUE, OP_EMBED_NODES, OP_EDGE_HIDDEN, OP_BIAS_GATHER, OP_LAYERNORM_FWD,
  OP_ATTN_FWD, OP_TILE_FWD, OP_PARAM_NORM_FWD, OP_PARAM_NORM_BWD, OP_TILE_BWD, OP_COLSUM, OP_ROWSEG_SUM,
  OP_LAYERNORM_BWD, OP_LN_PARAM_GRAD, OP_ATTN_BWD, OP_BIAS_HIST, OP_EDGE_HIDDEN_BWD, OP_EMBED_BWD, OP_MEMSET0,
- OP_ADD, OP_DACT, OP_KIND_COUNT) = range(24)
+ OP_ADD, OP_DACT, OP_CAST16, OP_KIND_COUNT) = range(25)
 OP_NAMES = ['nop', 'gemm', 'graph_prologue', 'embed_nodes', 'edge_hidden', 'bias_gather', 'layernorm_fwd',
             'attn_fwd', 'tile_fwd', 'param_norm_fwd', 'param_norm_bwd', 'tile_bwd', 'colsum', 'rowseg_sum',
             'layernorm_bwd', 'ln_param_grad', 'attn_bwd', 'bias_hist', 'edge_hidden_bwd', 'embed_bwd', 'memset0',
-            'add', 'dact']
+            'add', 'dact', 'cast16']
 
 EXPORTS = ['ghn3_abi_version', 'ghn3_last_error', 'ghn3_ctx_create', 'ghn3_ctx_destroy',
            'ghn3_ctx_set_compute_type', 'ghn3_run', 'ghn3_event_create', 'ghn3_event_record',

@@ -657,3 +657,117 @@ int ghn3_add(float* dst, const float* src, int64_t n, hipStream_t s) {
     hipLaunchKernelGGL(add_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dst, src, n);
     return launch_ok("add");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// GHN3_OP_CAST16: fp32 -> f16 / bf16 operand copies for the 16-bit-operand GEMM (gemm.hip gemm_h16d_kernel).
+// One workgroup = one 64 x 64 source tile: read once (float4, coalesced), converted, written straight (128-byte row
+// segments) and / or transposed through LDS (128-byte column segments); source elements outside rows x cols read as
+// zero, which produces the zero K padding the GEMM relies on.  The optional column sum (fp32) is the bias gradient.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned short cast_f16(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
+__device__ __forceinline__ unsigned short cast_bf16(float x) {
+    unsigned u = __builtin_bit_cast(unsigned, x);
+    u += 0x7fffu + ((u >> 16) & 1u);              // round to nearest even (finite inputs)
+    return (unsigned short)(u >> 16);
+}
+typedef unsigned short us4 __attribute__((ext_vector_type(4)));
+typedef unsigned short us8 __attribute__((ext_vector_type(8)));
+
+__global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                     const ghn3_cast_desc* __restrict__ descs, int n_desc,
+                                                     float* __restrict__ dbias) {
+    __shared__ unsigned short tr[64][66];          // transposed-copy staging (already converted)
+    __shared__ float csum[16][64];
+    int lo = 0, hi = n_desc - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (descs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+    }
+    const ghn3_cast_desc D = descs[lo];
+    const int t = blockIdx.x - D.block_start;
+    const int tiles_c = (D.cols + 63) >> 6;
+    const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
+    const int tid = threadIdx.x;
+    const int c4 = (tid & 15) * 4, rr = tid >> 4;
+    const float* S = src + D.src_off;
+    const bool st = D.flags & GHN3_CAST_STRAIGHT, trn = D.flags & GHN3_CAST_TRANSPOSED;
+    const bool st_bf = D.flags & GHN3_CAST_STRAIGHT_BF16, tr_bf = D.flags & GHN3_CAST_TRANSPOSED_BF16;
+
+    float4 v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = r0 + rr + 16 * i, c = c0 + c4;
+        float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < D.rows) {
+            const float* p = S + (int64_t)r * D.ld_src + c;
+            if (c + 3 < D.cols) x = *reinterpret_cast<const float4*>(p);
+            else {
+                if (c < D.cols) x.x = p[0];
+                if (c + 1 < D.cols) x.y = p[1];
+                if (c + 2 < D.cols) x.z = p[2];
+            }
+        }
+        v[i] = x;
+    }
+    if (st) {
+        unsigned short* Dd = dst + D.dst_off;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = r0 + rr + 16 * i;
+            if (r >= D.rows) continue;
+            us4 h;
+            if (st_bf) { h[0] = cast_bf16(v[i].x); h[1] = cast_bf16(v[i].y); h[2] = cast_bf16(v[i].z); h[3] = cast_bf16(v[i].w); }
+            else { h[0] = cast_f16(v[i].x); h[1] = cast_f16(v[i].y); h[2] = cast_f16(v[i].z); h[3] = cast_f16(v[i].w); }
+            *reinterpret_cast<us4*>(Dd + (int64_t)r * D.ld_dst + c0 + c4) = h;
+        }
+    }
+    if (D.flags & GHN3_CAST_COLSUM) {
+        csum[rr][c4] = v[0].x + v[1].x + v[2].x + v[3].x;
+        csum[rr][c4 + 1] = v[0].y + v[1].y + v[2].y + v[3].y;
+        csum[rr][c4 + 2] = v[0].z + v[1].z + v[2].z + v[3].z;
+        csum[rr][c4 + 3] = v[0].w + v[1].w + v[2].w + v[3].w;
+    }
+    if (trn) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rr + 16 * i;
+            if (tr_bf) {
+                tr[r][c4] = cast_bf16(v[i].x); tr[r][c4 + 1] = cast_bf16(v[i].y);
+                tr[r][c4 + 2] = cast_bf16(v[i].z); tr[r][c4 + 3] = cast_bf16(v[i].w);
+            } else {
+                tr[r][c4] = cast_f16(v[i].x); tr[r][c4 + 1] = cast_f16(v[i].y);
+                tr[r][c4 + 2] = cast_f16(v[i].z); tr[r][c4 + 3] = cast_f16(v[i].w);
+            }
+        }
+    }
+    __syncthreads();
+    if (trn) {
+        unsigned short* Dt = dst + D.dstT_off;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = tid + 256 * i;
+            const int col = p >> 3, rp = (p & 7) * 8;
+            if (c0 + col >= D.cols) continue;
+            us8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = tr[rp + e][col];
+            *reinterpret_cast<us8*>(Dt + (int64_t)(c0 + col) * D.ld_dstT + r0 + rp) = h;
+        }
+    }
+    if ((D.flags & GHN3_CAST_COLSUM) && tid < 64 && c0 + tid < D.cols) {
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < 16; ++w) s += csum[w][tid];
+        int c = c0 + tid;
+        if (D.bias_q > 0) c = (c / D.bias_q) * D.bias_s + c % D.bias_q;
+        atomicAdd(dbias + c, s);
+    }
+}
+
+int ghn3_cast16(const float* src, void* dst, const ghn3_cast_desc* d_desc, int n_desc, int total_blocks, float* dbias,
+                hipStream_t s) {
+    if (n_desc <= 0 || total_blocks <= 0) return GHN3_OK;
+    hipLaunchKernelGGL(cast16_kernel, dim3(total_blocks), dim3(256), 0, s, src, (unsigned short*)dst, d_desc, n_desc,
+                       dbias);
+    return launch_ok("cast16");
+}

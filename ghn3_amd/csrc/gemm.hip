@@ -35,7 +35,15 @@ typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ int map_row(int r, gci gather, int q, int s) {
     if (gather) r = gather[r];
-    if (q > 0) r = (r / q) * s + (r % q);
+    if (q > 0) {
+        // (r / q) * s + r % q through a float reciprocal (exact after the correction steps for 0 <= r < 2^24, the
+        // range the host enforces): ~8 VALU instructions instead of the ~40 of an integer division
+        int d = (int)((float)r * __builtin_amdgcn_rcpf((float)q));
+        int m = r - d * q;
+        if (m < 0) { m += q; --d; } else if (m >= q) { m -= q; ++d; }
+        if (m < 0) { m += q; --d; } else if (m >= q) { m -= q; ++d; }
+        r = d * s + m;
+    }
     return r;
 }
 
@@ -145,6 +153,156 @@ __device__ __forceinline__ void epilogue(const GemmProbDev* P, f32x16 (&acc)[TM]
             }
         }
     }
+}
+
+// Row-vector epilogue: the accumulators of a wave's (TM*32) x 64 sub-tile are transposed through a wave-private LDS
+// region (32 x 68 floats) so that every lane owns 4 CONSECUTIVE columns of a row: all reads (old C, aux_in,
+// residual) and writes (C, aux_out) become 16-byte accesses of 256-byte row segments instead of one dword per lane
+// (dword stores are store-issue bound: the 64 KB output of a 128 x 128 tile cost more than its whole K loop).
+// Same epilogue semantics as epilogue<>; needs ldc % 4 == 0 and 16-byte aligned C / aux / residual (the caller
+// checks and falls back).  `stage` = this wave's LDS region of 32 * 68 floats.
+typedef f32x4 GAS* gf4;
+struct RowsEpi {
+    int M, N, ldc, cq, cs, act, dact, ncol, col, c4, rsub, l31, lhi;
+    gf C; gcf residual, aux_in; gf aux_out; gci cg;
+    bool accum; float alpha; f32x4 bv;
+    float* stage;
+};
+// one 32 x 64 row block (accumulators a[0..1]) whose first row is `row0`; JB = row groups per read batch
+template <int JB>
+__device__ __forceinline__ void epilogue_rows_block(const RowsEpi& E, const f32x16 (&a)[2], int row0) {
+    constexpr int LD = 68;
+    float* stage = E.stage;
+#pragma unroll
+    for (int tn = 0; tn < 2; ++tn)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            stage[((r & 3) + 8 * (r >> 2) + 4 * E.lhi) * LD + tn * 32 + E.l31] = a[tn][r];
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    const bool full = E.ncol == 4;
+    // batches of JB row groups: every read of a batch is issued before its first use (one memory round trip per
+    // batch) while the live registers stay at 4 x JB float4 next to the accumulators
+#pragma unroll
+    for (int jb = 0; jb < 8; jb += JB) {
+        f32x4 v[JB], cold[JB], auxv[JB], resv[JB];
+        int64_t ci[JB];
+        bool ok[JB];
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const int rl = E.rsub + 4 * (jb + j);
+            v[j] = *reinterpret_cast<const f32x4*>(stage + rl * LD + E.c4);
+            const int row = row0 + rl;
+            ok[j] = row < E.M && E.ncol > 0;
+            ci[j] = (int64_t)map_row(ok[j] ? row : 0, E.cg, E.cq, E.cs) * E.ldc + (E.ncol > 0 ? E.col : 0);
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            cold[j] = z; auxv[j] = z; resv[j] = z;
+            if (ok[j] && full) {
+                if (E.accum) cold[j] = *reinterpret_cast<gcf4>(E.C + ci[j]);
+                if (E.dact != GHN3_DACT_NONE) auxv[j] = *reinterpret_cast<gcf4>(E.aux_in + ci[j]);
+                if (E.residual) resv[j] = *reinterpret_cast<gcf4>(E.residual + ci[j]);
+            } else if (ok[j]) {
+                for (int e = 0; e < E.ncol; ++e) {
+                    if (E.accum) cold[j][e] = E.C[ci[j] + e];
+                    if (E.dact != GHN3_DACT_NONE) auxv[j][e] = E.aux_in[ci[j] + e];
+                    if (E.residual) resv[j][e] = E.residual[ci[j] + e];
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JB; ++j) {
+            if (!ok[j]) continue;
+            f32x4 pre, o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float x = v[j][e] * E.alpha + E.bv[e];
+                pre[e] = x;
+                if (E.act == GHN3_ACT_RELU) x = fmaxf(x, 0.f);
+                else if (E.act == GHN3_ACT_GELU) x = gelu_f(x);
+                if (E.dact == GHN3_DACT_RELU) x = (auxv[j][e] > 0.f) ? x : 0.f;
+                else if (E.dact == GHN3_DACT_GELU) x *= gelu_grad_f(auxv[j][e]);
+                o[e] = x + resv[j][e] + cold[j][e];
+            }
+            if (full) {
+                if (E.aux_out) *reinterpret_cast<gf4>(E.aux_out + ci[j]) = pre;
+                *reinterpret_cast<gf4>(E.C + ci[j]) = o;
+            } else {
+                for (int e = 0; e < E.ncol; ++e) {
+                    if (E.aux_out) E.aux_out[ci[j] + e] = pre[e];
+                    E.C[ci[j] + e] = o[e];
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();                           // the next row block overwrites the stage
+}
+
+template <int TM>
+__device__ __forceinline__ void epilogue_rows(const GemmProbDev* P, f32x16 (&acc)[TM][2], int m_base, int n_base,
+                                              int lane, float* stage) {
+    RowsEpi E;
+    E.M = P->M; E.N = P->N; E.ldc = P->ldc; E.cq = P->c_q; E.cs = P->c_s; E.act = P->act; E.dact = P->dact;
+    E.C = (gf)P->C; E.residual = (gcf)P->residual; E.aux_in = (gcf)P->aux_in; E.aux_out = (gf)P->aux_out;
+    E.cg = (gci)P->c_gather;
+    E.accum = (P->flags & GHN3_GEMM_ACCUM) != 0;
+    E.alpha = P->alpha;
+    E.l31 = lane & 31; E.lhi = lane >> 5;
+    E.c4 = (lane & 15) * 4; E.rsub = lane >> 4;               // this lane's 4 columns / row inside a 4-row group
+    E.col = n_base + E.c4;
+    E.ncol = min(4, E.N - E.col);                              // valid columns of this lane (<= 0: none)
+    E.stage = stage;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    E.bv = z;
+    gcf bias = (gcf)P->bias;
+    if (bias && !(P->flags & GHN3_GEMM_BIASGRAD)) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (e < E.ncol) {
+                int bi = E.col + e;
+                if (P->bias_q > 0) bi = (bi / P->bias_q) * P->bias_s + (bi % P->bias_q);
+                E.bv[e] = bias[(int64_t)bi * P->bias_stride];
+            }
+        }
+    }
+    // static indices only: a dynamically indexed accumulator array would live in scratch memory
+    constexpr int JB = TM > 2 ? 2 : 4;
+    if constexpr (TM >= 1) epilogue_rows_block<JB>(E, acc[0], m_base);
+    if constexpr (TM >= 2) epilogue_rows_block<JB>(E, acc[1], m_base + 32);
+    if constexpr (TM >= 3) epilogue_rows_block<JB>(E, acc[2], m_base + 64);
+    if constexpr (TM >= 4) epilogue_rows_block<JB>(E, acc[3], m_base + 96);
+}
+
+// split-K partial sums: plain dword atomics straight from the accumulator layout (32 lanes on one 128-byte line)
+__device__ __forceinline__ void epilogue_split_block(const GemmProbDev* P, const f32x16& a, int row0, int col, int lhi) {
+    if (col >= P->N) return;
+    gf C = (gf)P->C;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row < P->M)
+            __hip_atomic_fetch_add(C + (int64_t)map_row(row, (gci)P->c_gather, P->c_q, P->c_s) * P->ldc + col,
+                                   a[r] * P->alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+template <int TM>
+__device__ __forceinline__ void epilogue_split(const GemmProbDev* P, f32x16 (&acc)[TM][2], int m_base, int n_base,
+                                               int lane) {
+    const int l31 = lane & 31, lhi = lane >> 5;
+#define GHN3_SPLIT_ROW(I)                                                                   \
+    if constexpr (TM > I) {                                                                 \
+        epilogue_split_block(P, acc[I][0], m_base + 32 * I, n_base + l31, lhi);             \
+        epilogue_split_block(P, acc[I][1], m_base + 32 * I, n_base + 32 + l31, lhi);        \
+    }
+    GHN3_SPLIT_ROW(0) GHN3_SPLIT_ROW(1) GHN3_SPLIT_ROW(2) GHN3_SPLIT_ROW(3)
+#undef GHN3_SPLIT_ROW
+}
+__device__ __forceinline__ bool rows_epilogue_ok(const GemmProbDev* P) {
+    const uintptr_t bits = (uintptr_t)P->C | (uintptr_t)P->aux_in | (uintptr_t)P->aux_out | (uintptr_t)P->residual;
+    return (P->ldc & 3) == 0 && (bits & 15) == 0;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -533,9 +691,145 @@ __global__ __launch_bounds__(256) void gemm_h16_kernel(const GemmProbDev* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+// 16-bit operands ALREADY in HBM (GHN3_GEMM_OP16): both operands k-contiguous (ROW mode), staged with the
+// LDS-DMA path (global_load_lds_dwordx4: 16 B per lane, no VGPR round trip, no conversion in the loop).
+//   block tile 128 x 128 x 64, 4 waves (2 x 2) of 64 x 64, v_mfma_f32_32x32x16_{f16,bf16}, fp32 accumulate.
+//   LDS image per operand and stage: 128 rows x 128 B, written lane-linearly by the DMA; the 16-byte slot s of
+//   row r holds global k-chunk (s ^ (r & 7)) -- the swizzle is applied to the per-lane SOURCE address and to the
+//   fragment reads (rule 21 of the CDNA guide), which makes the ds_read_b128 fragment reads conflict free.
+//   Rows beyond M/N are clamped to the last valid row (their results are never stored); the K range must be
+//   zero padded to a multiple of 64 in the 16-bit copies (the host allocates them that way).
+//   The B operand may carry a k-map (kq, ks): physical k = (k / kq) * ks + k % kq with kq % 64 == 0 -- the
+//   row-subset structure of the decoder W2 weights seen from the reduction side (dgrad).
+// ------------------------------------------------------------------------------------------------
+#define LAS __attribute__((address_space(3)))
+typedef const unsigned short GAS* gch;
+
+// WGM x WGN waves, each owning a (BM / WGM) x 64 sub-tile.  Instantiated as 128 x 128 (2 x 2 waves, 2 blocks / CU)
+// and 256 x 256 (2 x 4 waves, 1 block / CU): the loop is bound by the L2 -> LDS rate (~17 B/clk/CU measured), so
+// the flop rate scales with the tile's arithmetic intensity BM BN / (BM + BN) -- 64 vs 128 flop/B.
+template <int CT, int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_h16d_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
+    constexpr int BK = 64;
+    constexpr int NT = 64 * WGM * WGN;               // threads
+    constexpr int TM = BM / WGM / 32, TN = 2;
+    static_assert(BN / WGN == 64, "a wave owns 64 columns (epilogue_rows)");
+    constexpr int OPA = BM * BK * 2, OPB = BN * BK * 2;   // bytes per operand image
+    constexpr int STAGE = OPA + OPB;
+    constexpr int PA = BM * 8 / NT, PB = BN * 8 / NT;     // 16-byte pieces per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* sm = reinterpret_cast<char*>(smem);
+
+    const GemmProbDev* P = find_problem(probs, n_probs, blockIdx.x);
+    const int t = blockIdx.x - P->tile_start;
+    int m0, n0, kz;
+    if (!tile_origin<BM, BN>(P, t, m0, n0, kz)) return;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WGN) * (BM / WGM), wn0 = (wave % WGN) * 64;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int kt0 = kz * (P->k_chunk / BK);
+    const int K = (P->ksplit > 1) ? min(P->K, (kz + 1) * P->k_chunk) : P->K;
+    if (kt0 * BK >= K && P->ksplit > 1) return;
+    const int nk = (K + BK - 1) / BK;
+
+    // per-lane source pointers: piece p = tid + NT i -> LDS row p / 8, slot p % 8, global chunk slot ^ (row & 7)
+    gch pa[PA], pb[PB];
+    int ck;                                          // k offset of this lane's chunk: the same for all its pieces
+    {
+        gch A = (gch)P->A; gch B = (gch)P->B;
+        gci ag = (gci)P->a_gather; gci bg = (gci)P->b_gather;
+        const int slot = tid & 7, rbase = tid >> 3;  // NT / 8 rows per pass, (row & 7) == (rbase & 7) for every i
+        ck = (slot ^ (rbase & 7)) * 8;
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int ra = min(m0 + rbase + (NT / 8) * i, P->M - 1);
+            pa[i] = A + (int64_t)map_row(ra, ag, P->a_q, P->a_s) * P->lda + ck;
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int rb = min(n0 + rbase + (NT / 8) * i, P->N - 1);
+            pb[i] = B + (int64_t)map_row(rb, bg, P->b_q, P->b_s) * P->ldb;
+        }
+    }
+    const int kq = P->kq, ks = P->ks;
+    const float inv_kq = kq > 0 ? 1.0f / (float)kq : 0.f;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto issue = [&](int kt, int stage) {
+        const int k0 = kt * BK;
+        int kb = k0 + ck;
+        if (kq > 0) {                                  // k-map of B: (k / kq) * ks + k % kq   (k < 2^24)
+            int qd = (int)((float)kb * inv_kq);
+            int rm = kb - qd * kq;
+            if (rm < 0) { rm += kq; --qd; } else if (rm >= kq) { rm -= kq; ++qd; }
+            kb = qd * ks + rm;
+        }
+        LAS char* la = (LAS char*)(sm + stage * STAGE);
+        // wave-uniform LDS base: the 64 lanes of a wave write 64 consecutive 16-byte pieces
+#pragma unroll
+        for (int i = 0; i < PA; ++i)
+            __builtin_amdgcn_global_load_lds((const void GAS*)(pa[i] + k0), (LAS void*)(la + (wave * 64 + NT * i) * 16),
+                                             16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < PB; ++i)
+            __builtin_amdgcn_global_load_lds((const void GAS*)(pb[i] + kb),
+                                             (LAS void*)(la + OPA + (wave * 64 + NT * i) * 16), 16, 0, 0);
+    };
+
+    issue(kt0, 0);
+    for (int kt = kt0; kt < nk; ++kt) {
+        const int cur = (kt - kt0) & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                               // tile kt is in LDS for every wave; stage cur^1 is free
+        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
+        const char* a_s = sm + cur * STAGE;
+        const char* b_s = a_s + OPA;
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {         // 4 MFMA k-steps of 16
+            u16x8 af[TM], bf[TN];
+            const int slot = kk * 2 + lhi;             // 16-byte k chunk wanted by this lane
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm0 + i * 32 + l31;
+                af[i] = *reinterpret_cast<const u16x8*>(a_s + row * 128 + ((slot ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int row = wn0 + j * 32 + l31;
+                bf[j] = *reinterpret_cast<const u16x8*>(b_s + row * 128 + ((slot ^ (row & 7)) << 4));
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = mfma16<CT>(af[i], bf[j], acc[i][j]);
+        }
+    }
+    // (the host only routes problems with ldc % 4 == 0 and 16-byte aligned C / aux / residual to this kernel)
+    if (P->ksplit > 1) {
+        epilogue_split<TM>(P, acc, m0 + wm0, n0 + wn0, lane);
+    } else {
+        __syncthreads();                               // every wave is done with the operand stages
+        epilogue_rows<TM>(P, acc, m0 + wm0, n0 + wn0, lane, smem + wave * (32 * 68));
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 typedef void (*gemm_fn)(const GemmProbDev*, int);
+static constexpr int H16D_LDS_128 = 2 * (128 + 128) * 64 * 2;      // 64 KB: two stages of A + B images
+static constexpr int H16D_LDS_256 = 2 * (256 + 256) * 64 * 2;      // 128 KB
+static gemm_fn g_h16d[2][2] = {
+    {gemm_h16d_kernel<GHN3_CT_F16, 128, 128, 2, 2>, gemm_h16d_kernel<GHN3_CT_BF16, 128, 128, 2, 2>},
+    {gemm_h16d_kernel<GHN3_CT_F16, 256, 256, 2, 4>, gemm_h16d_kernel<GHN3_CT_BF16, 256, 256, 2, 4>}};
 
 template <int BM, int BN, int AM, int BMD> static size_t f32_lds() {
     return 2 * (size_t)(F32Tile<BM, AM>::SIZE + F32Tile<BN, BMD>::SIZE) * sizeof(float);
@@ -590,7 +884,29 @@ int ghn3_gemm_init() {
                         }
                     }
                 }
+    for (int big = 0; big < 2; ++big)
+        for (int ct = 0; ct < 2; ++ct) {
+            hipError_t e = hipFuncSetAttribute((const void*)g_h16d[big][ct], hipFuncAttributeMaxDynamicSharedMemorySize,
+                                               big ? H16D_LDS_256 : H16D_LDS_128);
+            if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(h16d): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
+        }
     g_gemm_ready = true;
+    return GHN3_OK;
+}
+
+int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int tile, int ctype,
+                          hipStream_t stream) {
+    if (n_probs <= 0 || total_tiles <= 0) return GHN3_OK;
+    if ((ctype != GHN3_CT_F16 && ctype != GHN3_CT_BF16) || (tile != 128 && tile != 256)) {
+        ghn3_set_error("16-bit-operand GEMM needs compute type f16 or bf16 (got %d) and tile 128 / 256 (got %d)", ctype,
+                       tile);
+        return GHN3_E_ARG;
+    }
+    const int big = tile == 256;
+    hipLaunchKernelGGL(g_h16d[big][ctype == GHN3_CT_BF16], dim3(total_tiles), dim3(big ? 512 : 256),
+                       big ? H16D_LDS_256 : H16D_LDS_128, stream, d_probs, n_probs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ghn3_set_error("h16d gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;
 }
 

@@ -18,6 +18,7 @@ struct GemmProbDev {
     int tiles_m, tiles_n;
     int ksplit, k_chunk; // split-K: K range [z*k_chunk, (z+1)*k_chunk) per replica z < ksplit
     int order;           // 0: m-tiles innermost (B streamed), 1: n-tiles innermost (A streamed)
+    int kq, ks;          // 16-bit-operand kernel: k-map of B (kq == 0: identity)
     int _pad;
 };
 
@@ -27,6 +28,8 @@ int ghn3_gemm_init();
 int ghn3_gemm_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode,
                      int tile, int ctype, hipStream_t stream);
 
+int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int tile, int ctype,
+                          hipStream_t stream);
 int ghn3_gemm_small_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode,
                            hipStream_t stream);
 
@@ -69,6 +72,8 @@ int ghn3_colsum(float* out, const float* X, int M, int N, int ld, int q, int sdi
 int ghn3_rowseg_sum(float* out, const float* X, const int* seg_ptr, const int* idx, int rows, int C, int ldx,
                     int ldo, int accum, hipStream_t s);
 int ghn3_add(float* dst, const float* src, int64_t n, hipStream_t s);
+int ghn3_cast16(const float* src, void* dst, const ghn3_cast_desc* d_desc, int n_desc, int total_blocks, float* dbias,
+                hipStream_t s);
 int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, hipStream_t s);
 
 void ghn3_set_error(const char* fmt, ...);

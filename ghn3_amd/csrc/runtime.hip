@@ -167,6 +167,14 @@ struct Resolver {
 // tile code 32 = the latency-optimised small-problem kernel (gemm_small.hip, exact fp32): chosen when a problem
 // cannot fill the chip with 64x64 tiles and its K loop is short enough for one workgroup to split four ways.
 static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
+    if (p.flags & GHN3_GEMM_OP16) {
+        // tile codes 16 / 24 = the 16-bit-operand kernel with 128 x 128 / 256 x 256 tiles.  The big tile has twice
+        // the arithmetic intensity but runs one 512-thread block per CU: it needs enough tiles to fill the chip.
+        if (forced == 16 || forced == 24) return forced;
+        const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) * (p.ksplit > 1 ? p.ksplit : 1);
+        const double eff = ((double)p.M / (((p.M + 255) / 256) * 256.0)) * ((double)p.N / (((p.N + 255) / 256) * 256.0));
+        return (t256 >= 200 && eff >= 0.8) ? 24 : 16;
+    }
     if (forced == 32 || forced == 64 || forced == 128) return forced;
     // op_t64 = 64x64 tiles of ALL problems launched together with this one: a grouped launch that already fills
     // the chip keeps the tiled kernels (better operand reuse); a lone small problem takes the latency kernel.
@@ -213,12 +221,26 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             // bucket by (a_mode, b_mode, tile)
             for (int am = 0; am < 2; ++am)
                 for (int bm = 0; bm < 2; ++bm)
-                    for (int tl = 32; tl <= 128; tl *= 2) {
+                    for (int tl : {16, 24, 32, 64, 128}) {
                         Launch L{am, bm, tl, (int)pos, 0, 0};
+                        const int te = tl == 16 ? 128 : tl == 24 ? 256 : tl;        // tile edge
                         for (int q = first; q < first + cnt; ++q) {
                             const ghn3_gemm_problem& p = problems[q];
                             if (p.M <= 0 || p.N <= 0) continue;
                             if (p.a_mode != am || p.b_mode != bm || pick_tile(p, forced, op_t64) != tl) continue;
+                            if ((tl == 16 || tl == 24) && (p.a_mode != GHN3_MODE_ROW || p.b_mode != GHN3_MODE_ROW || (p.lda & 7) ||
+                                             (p.ldb & 7) || (p.b_kq & 7) || (p.flags & GHN3_GEMM_BIASGRAD) ||
+                                             p.K >= (1 << 24) || (p.ldc & 3) || (p.C.off & 15) ||
+                                             (p.aux_in.off & 15) || (p.aux_out.off & 15) || (p.residual.off & 15))) {
+                                ghn3_set_error("op %d problem %d: 16-bit operands need ROW/ROW modes, ld %% 8 == 0, "
+                                               "b_kq %% 8 == 0, K < 2^24, no BIASGRAD, ldc %% 4 == 0 and 16-byte "
+                                               "aligned C / aux / residual", k, q);
+                                return GHN3_E_ARG;
+                            }
+                            if (p.M >= (1 << 24) || p.N >= (1 << 24) || p.K >= (1 << 24)) {
+                                ghn3_set_error("op %d problem %d: M, N, K must be below 2^24", k, q);
+                                return GHN3_E_LIMIT;
+                            }
                             if (p.K < 0 || (p.lda & 3) || (p.ldb & 3) || (p.A.off & 15) || (p.B.off & 15)) {
                                 ghn3_set_error("op %d problem %d: operands must be 16-byte aligned with ld %% 4 == 0 "
                                                "(lda=%d ldb=%d)", k, q, p.lda, p.ldb);
@@ -243,8 +265,9 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                 return GHN3_E_ARG;
                             }
                             g.tile_start = L.tiles;               // always a multiple of 8 (XCD-aware order)
-                            g.tiles_m = (p.M + tl - 1) / tl;
-                            g.tiles_n = (p.N + tl - 1) / tl;
+                            g.tiles_m = (p.M + te - 1) / te;
+                            g.tiles_n = (p.N + te - 1) / te;
+                            g.kq = (tl == 16 || tl == 24) ? p.b_kq : 0; g.ks = p.b_ks;
                             g.order = (int64_t)p.M > (int64_t)p.N ? 1 : 0;   // stream the larger operand once
                             g.ksplit = p.ksplit > 1 ? p.ksplit : 1;
                             g.k_chunk = ((p.K + g.ksplit - 1) / g.ksplit + 63) / 64 * 64;
@@ -296,6 +319,9 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             for (const Launch& L : op_launches[k]) {
                 if (L.tile == 32)
                     rc = ghn3_gemm_small_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, stream);
+                else if (L.tile == 16 || L.tile == 24)
+                    rc = ghn3_gemm_h16d_launch(ds + L.first, L.count, L.tiles, L.tile == 16 ? 128 : 256,
+                                               (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, stream);
                 else
                     rc = ghn3_gemm_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, L.tile,
                                           (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, stream);
@@ -405,6 +431,10 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         }
         case GHN3_OP_ADD:
             rc = ghn3_add(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), o.i[0], stream);
+            break;
+        case GHN3_OP_CAST16:
+            rc = ghn3_cast16(R.get<const float>(o.r[0]), R.get<void>(o.r[1]), R.get<const ghn3_cast_desc>(o.r[2]),
+                             (int)o.i[0], (int)o.i[1], R.get<float>(o.r[3]), stream);
             break;
         case GHN3_OP_DACT:
             rc = ghn3_dact(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), (int)o.i[0], (int)o.i[1], (int)o.i[2],

@@ -80,7 +80,8 @@ class _Plan:
         self.nets = nets
         dev = ghn.device
         self.idx = torch.from_numpy(program.idx_blob).to(dev)
-        self.ws = torch.empty(program.ws_bytes, dtype=torch.uint8, device=dev)
+        # zero-filled once: the padding of the 16-bit operand copies (Program.ws16) must read as finite zeros
+        self.ws = torch.zeros(program.ws_bytes, dtype=torch.uint8, device=dev)
         self.scal = torch.zeros(256 + 4 * max(program.n_seg, 1) + 64, dtype=torch.uint8, device=dev)
         self.bufs = np.zeros(program.n_bufs, dtype=np.uint64)
         self.sizes = [p['numel'] for p in program.predicted]
@@ -108,8 +109,12 @@ class GHN3(nn.Module):
     Extra keyword arguments (not in the reference):
       index_mode   'reference' (default; reproduces quirk Q1 of SURVEY 3.2 for B > 1) or 'correct'
       compute      MFMA operand type of the decoder GEMMs (fc / W0 / W2, forward and backward):
-                   'f32' (default: exact fp32 MFMA), 'f16' or 'bf16' (fp32 accumulate, fp32 in HBM).
+                   'f32' (default: exact fp32 MFMA), 'f16' or 'bf16' (fp32 accumulate).
                    The Graphormer and the small heads always run exact fp32.
+      compute_bwd  operand type of the W2 backward GEMMs in 16-bit mode (default: 'bf16' -- the upstream
+                   gradients are too small for f16's range)
+      direct16     True (default): in 16-bit mode the W2 GEMMs read per-step 16-bit operand copies (GHN3_OP_CAST16)
+                   through the LDS-DMA kernel; False: fp32 operands converted while staged
     """
 
     def __init__(self, max_shape, num_classes, hid, heads=8, layers=3, is_ghn2=False, pretrained=False, **kwargs):
@@ -126,6 +131,8 @@ class GHN3(nn.Module):
         self.debug_level = kwargs.pop('debug_level', 0)
         self.index_mode = kwargs.pop('index_mode', 'reference')
         self.compute = kwargs.pop('compute', 'f32')
+        self.compute_bwd = kwargs.pop('compute_bwd', None)
+        self.direct16 = kwargs.pop('direct16', True)
         assert not kwargs, 'unknown arguments %s' % list(kwargs)
         if not self.weight_norm or not self.layernorm:
             raise NotImplementedError('weight_norm=False / layernorm=False are not supported '
@@ -225,7 +232,9 @@ class GHN3(nn.Module):
         prog = Program(cfg, graphs.node_info, graphs.host_n_nodes(), graphs._node_type_host, graphs.max_edge,
                        nets, index_mode=self.index_mode, training=training,
                        predict_class_layers=predict_class_layers, reduce_graph=reduce_graph,
-                       layernorm=self.layernorm, decoder_ctype=L.COMPUTE_TYPES[self.compute])
+                       layernorm=self.layernorm, decoder_ctype=L.COMPUTE_TYPES[self.compute],
+                       decoder_bwd_ctype=L.COMPUTE_TYPES[self.compute_bwd] if self.compute_bwd else None,
+                       direct16=self.direct16)
         plan = _Plan(self, prog, graphs.edges, nets)
         plan.graphs = graphs
         return plan
@@ -370,7 +379,8 @@ def from_pretrained(ghn3_name='ghn3xlm16.pt', **kwargs):
         state_dict = joblib.load(hf_hub_download(repo_id='SamsungSAILMontreal/ghn3', filename=ghn3_name))
     if any(k.find('gnn.gru.') >= 0 for k in state_dict):
         raise NotImplementedError('GHN-2 checkpoints are not supported')
-    extra = {k: kwargs.pop(k) for k in ('index_mode', 'compute', 'debug_level') if k in kwargs}
+    extra = {k: kwargs.pop(k) for k in ('index_mode', 'compute', 'compute_bwd', 'direct16', 'debug_level')
+             if k in kwargs}
     if ghn_config is None:
         num_classes = kwargs.pop('num_classes', 10)
         layers = kwargs.pop('layers', 0)

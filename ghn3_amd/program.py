@@ -54,11 +54,20 @@ class Program:
     X_WS, X_IDX, X_EDGES, X_OUT, X_DOUT, X_TOK, X_SCAL, X_GRADFLAT, X_COUNT = range(9)
 
     def __init__(self, cfg, node_infos, n_nodes, node_types, max_edge, nets, index_mode='reference',
-                 training=True, predict_class_layers=True, reduce_graph=False, layernorm=True, decoder_ctype=None):
+                 training=True, predict_class_layers=True, reduce_graph=False, layernorm=True, decoder_ctype=None,
+                 decoder_bwd_ctype=None, direct16=True):
         self.cfg = cfg
         # MFMA operand type of the decoder GEMMs (fc / W0 / W2, forward and backward): None = context default.
         # The Graphormer, the edge MLP and the small heads always multiply in exact fp32.
         self.decoder_ctype = decoder_ctype
+        # Backward operand type of the W2 trio in the 16-bit pipeline: the upstream gradients d_tiles are ~1e-6 in
+        # magnitude (f16 subnormals), so an f16 forward pairs with a bf16 backward by default.
+        if decoder_bwd_ctype is None:
+            decoder_bwd_ctype = L.CT_BF16 if decoder_ctype == L.CT_F16 else decoder_ctype
+        self.decoder_bwd_ctype = decoder_bwd_ctype
+        # direct16: the W2 GEMMs (98 % of the decoder flops) read 16-bit operand COPIES written once per step by
+        # GHN3_OP_CAST16 (k-contiguous, zero padded, LDS-DMA friendly) instead of converting fp32 while staging.
+        self.direct16 = bool(direct16) and decoder_ctype in (L.CT_F16, L.CT_BF16) and (8 * int(cfg['hid'])) % 64 == 0
         self.C = C = int(cfg['hid'])
         self.H = int(cfg['heads'])
         self.Lyr = int(cfg['layers'])
@@ -137,6 +146,44 @@ class Program:
     def wref(self, name, off_floats=0):
         return (self.xbuf(self.X_WS), self._ws_names[name] + 4 * off_floats)
 
+    def ws16(self, name, n_halfs):
+        """workspace region of 16-bit elements (never written outside GHN3_OP_CAST16; the host zero-fills the
+        workspace once, so its padding reads as zeros); returns the offset in 16-bit elements from the ws base."""
+        return self.ws(name, 2 * (int(n_halfs) + 128)) // 2
+
+    def href(self, off_halfs):
+        return (self.xbuf(self.X_WS), 2 * int(off_halfs))
+
+    def cast16(self, src_base, items, dbias=None):
+        """One GHN3_OP_CAST16 over `items` = dicts(src_off [floats from src_base], rows, cols, ld_src,
+        straight=(off_halfs, ld, ctype) | None, transposed=(off_halfs, ld, ctype) | None, colsum=(q, s) | None)."""
+        descs = np.zeros(len(items), dtype=L.CAST_DT)
+        blocks = 0
+        for D, it in zip(descs, items):
+            D['src_off'], D['rows'], D['cols'], D['ld_src'] = it['src_off'], it['rows'], it['cols'], it['ld_src']
+            flags = 0
+            if it.get('straight'):
+                off, ld, ct = it['straight']
+                assert ld % 8 == 0 and ld >= round_up(it['cols'], 64) and off % 8 == 0
+                D['dst_off'], D['ld_dst'] = off, ld
+                flags |= L.CAST_STRAIGHT | (L.CAST_STRAIGHT_BF16 if ct == L.CT_BF16 else 0)
+            if it.get('transposed'):
+                off, ld, ct = it['transposed']
+                assert ld % 8 == 0 and ld >= round_up(it['rows'], 64) and off % 8 == 0
+                D['dstT_off'], D['ld_dstT'] = off, ld
+                flags |= L.CAST_TRANSPOSED | (L.CAST_TRANSPOSED_BF16 if ct == L.CT_BF16 else 0)
+            if it.get('colsum') is not None:
+                assert dbias is not None
+                D['bias_q'], D['bias_s'] = it['colsum']
+                flags |= L.CAST_COLSUM
+            assert it['ld_src'] % 4 == 0 and it['src_off'] % 4 == 0
+            D['flags'] = flags
+            D['block_start'] = blocks
+            blocks += ((it['rows'] + 63) // 64) * ((it['cols'] + 63) // 64)
+        if blocks:
+            self.op(L.OP_CAST16, refs=(src_base, (self.xbuf(self.X_WS), 0), self.idx(descs),
+                                       dbias if dbias is not None else self.NONE), ints=(len(items), blocks))
+
     def idx(self, arr):
         raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
         off = round_up(self._idx_size, 16)
@@ -168,7 +215,7 @@ class Program:
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, bias=None, bias_q=0,
              bias_s=0, bias_stride=1, act=L.ACT_NONE, dact=L.DACT_NONE, aux_in=None, aux_out=None, residual=None,
              a_gather=None, b_gather=None, c_gather=None, a_qs=(0, 0), b_qs=(0, 0), c_qs=(0, 0), accum=False,
-             alpha=1.0, dbias=None, dbias_stride=1, ksplit=1):
+             alpha=1.0, dbias=None, dbias_stride=1, ksplit=1, op16=False, b_kmap=(0, 0)):
         # dbias: fused bias gradient of a wgrad problem (GHN3_GEMM_BIASGRAD): dbias[cmap(m)*stride] += sum_k A(m,k)
         if dbias is not None:
             assert bias is None and a_mode == L.MODE_COL
@@ -183,7 +230,8 @@ class Program:
                         ('b_mode', b_mode), ('a_q', a_qs[0]), ('a_s', a_qs[1]), ('b_q', b_qs[0]), ('b_s', b_qs[1]),
                         ('c_q', c_qs[0]), ('c_s', c_qs[1]), ('bias_q', bias_q), ('bias_s', bias_s),
                         ('bias_stride', bias_stride), ('act', act), ('dact', dact),
-                        ('flags', (L.GEMM_ACCUM if accum else 0) | (L.GEMM_BIASGRAD if dbias is not None else 0))):
+                        ('flags', (L.GEMM_ACCUM if accum else 0) | (L.GEMM_BIASGRAD if dbias is not None else 0) |
+                         (L.GEMM_OP16 if op16 else 0)), ('b_kq', b_kmap[0]), ('b_ks', b_kmap[1])):
             p[name] = int(v)
         p['alpha'] = alpha
         p['ksplit'] = ksplit
@@ -447,7 +495,32 @@ class Program:
             self.tiles_floats = tiles_floats
             tiles = self.wsf('tiles', tiles_floats)
             for g in self.gemm_groups:
+                g['op16'] = self.direct16 and g['i_ld'] % 8 == 0
+            use16 = any(g['op16'] for g in self.gemm_groups)
+            if use16:
+                # 16-bit operand copies: W2 [C^2][8C] (forward B operand), its transpose [8C][C^2 + 64] (dgrad B
+                # operand, backward type) and u [M][8C]; one pass over W2 writes both W2 copies.
+                fct, bct = self.decoder_ctype, self.decoder_bwd_ctype
+                n_w2 = ms[0] * ms[1]
+                self.w2h = self.ws16('w2h', n_w2 * 8 * C)
+                item = dict(src_off=0, rows=n_w2, cols=8 * C, ld_src=8 * C, straight=(self.w2h, 8 * C, fct))
+                if self.training:
+                    self.w2hT_ld = round_up(n_w2, 64) + 64
+                    self.w2hT = self.ws16('w2hT', 8 * C * self.w2hT_ld)
+                    item['transposed'] = (self.w2hT, self.w2hT_ld, bct)
+                self.cast16(self.pref(W2), [item])
+                self.uh = self.ws16('uh', M * 8 * C)
+                self.cast16((self.xbuf(self.X_WS), 0),
+                            [dict(src_off=u[1] // 4, rows=M, cols=8 * C, ld_src=8 * C, straight=(self.uh, 8 * C, fct))])
+            for g in self.gemm_groups:
                 for (r0, nr) in self._row_parts(g['rows']):
+                    if g['op16']:
+                        self.gemm(self.href(self.uh + (g['row0'] + r0) * 8 * C), self.href(self.w2h),
+                                  self.wref('tiles', g['tile_off'] + r0 * g['ld']),
+                                  nr, g['cols'], 8 * C, 8 * C, 8 * C, g['ld'], b_qs=(g['i_ld'], ms[1]),
+                                  bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1],
+                                  act=L.ACT_RELU if g['kind'] == 'cls' else L.ACT_NONE, op16=True)
+                        continue
                     self.gemm((u[0], u[1] + 4 * (g['row0'] + r0) * 8 * C), self.pref(W2),
                               self.wref('tiles', g['tile_off'] + r0 * g['ld']),
                               nr, g['cols'], 8 * C, 8 * C, 8 * C, g['ld'], b_qs=(g['i_ld'], ms[1]),
@@ -742,28 +815,59 @@ class Program:
             # split into chunks (partial sums added atomically into the zeroed d_u) to fill the 256 CUs; the ReLU
             # mask is applied afterwards in place.
             self.op(L.OP_MEMSET0, refs=(d_u,), ints=(4 * M * 8 * C,))
+            bct = self.decoder_bwd_ctype
+            g16 = [g for g in self.gemm_groups if g['op16']]
+            if g16:
+                # 16-bit copies of the backward operands, one launch: per group d_tiles (straight: dgrad A operand,
+                # transposed: wgrad A operand, column sums: the conv.2 bias gradient) and u^T (wgrad B operand)
+                items = []
+                for g in g16:
+                    g['dth_ld'] = round_up(g['cols'], 64)
+                    g['dth'] = self.ws16('dth%d' % g['row0'], g['rows'] * g['dth_ld'])
+                    g['kT_ld'] = round_up(g['rows'], 64)
+                    g['dthT'] = self.ws16('dthT%d' % g['row0'], g['cols'] * g['kT_ld'])
+                    g['uhT'] = self.ws16('uhT%d' % g['row0'], 8 * C * g['kT_ld'])
+                    items.append(dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'], rows=g['rows'],
+                                      cols=g['cols'], ld_src=g['ld'], straight=(g['dth'], g['dth_ld'], bct),
+                                      transposed=(g['dthT'], g['kT_ld'], bct), colsum=(g['i_ld'], ms[1])))
+                    items.append(dict(src_off=u[1] // 4 + g['row0'] * 8 * C, rows=g['rows'], cols=8 * C,
+                                      ld_src=8 * C, transposed=(g['uhT'], g['kT_ld'], bct)))
+                self.cast16((self.xbuf(self.X_WS), 0), items, dbias=self.gref(b2))
             p0 = len(self._probs)
             for g in self.gemm_groups:
                 for (r0, nr) in self._row_parts(g['rows']):
                     tiles = ((nr + 127) // 128) * ((8 * C + 127) // 128)
                     ks = int(max(2, min(64, (2048 + tiles - 1) // tiles, g['cols'] // 1024)))
+                    if g['op16']:
+                        self.gemm(self.href(g['dth'] + r0 * g['dth_ld']), self.href(self.w2hT),
+                                  (d_u[0], d_u[1] + 4 * (g['row0'] + r0) * 8 * C),
+                                  nr, 8 * C, g['cols'], g['dth_ld'], self.w2hT_ld, 8 * C, ksplit=ks, op16=True,
+                                  b_kmap=(g['i_ld'], ms[1]))
+                        continue
                     self.gemm(self.wref('d_tiles', g['tile_off'] + r0 * g['ld']), self.pref(W2),
                               (d_u[0], d_u[1] + 4 * (g['row0'] + r0) * 8 * C),
                               nr, 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
                               b_qs=(g['i_ld'], ms[1]), ksplit=ks)
-            self.gemm_op(p0, tag=self.TAG_D3_DGRAD)
+            self.gemm_op(p0, ctype=bct if g16 else None, tag=self.TAG_D3_DGRAD)
             self.op(L.OP_DACT, refs=(d_u, u), ints=(M, 8 * C, 8 * C, L.DACT_RELU))
             # dW2[rows of the group] += d_tiles^T u ; groups overlap in W2 rows -> one launch per group
             for gi, g in enumerate(self.gemm_groups):
                 full = gi == 0 and g['o'] == ms[0] and g['i_ld'] == ms[1] and g['kind'] == 'conv'
                 if full:
                     self.grad_no_memset.append(W2)      # every row of dW2 is written by this problem
+                if g['op16']:
+                    p0 = self.gemm(self.href(g['dthT']), self.href(g['uhT']), self.gref(W2), g['cols'], 8 * C,
+                                   g['rows'], g['kT_ld'], g['kT_ld'], 8 * C, c_qs=(g['i_ld'], ms[1]),
+                                   accum=not full, op16=True)
+                    self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD)
+                    continue
                 p0 = self.gemm(self.wref('d_tiles', g['tile_off']), (u[0], u[1] + 4 * g['row0'] * 8 * C),
                                self.gref(W2), g['cols'], 8 * C, g['rows'], g['ld'], 8 * C, 8 * C,
                                a_mode=L.MODE_COL, b_mode=L.MODE_COL, c_qs=(g['i_ld'], ms[1]), accum=not full,
                                dbias=self.gref(b2))
                 # short reduction (K = rows of the group): 64x64 tiles beat 128x128 here (tests/gemm_bench.py)
-                self.gemm_op(p0, tile=64 if g['rows'] <= 1024 else 0, tag=self.TAG_D3_WGRAD)
+                self.gemm_op(p0, tile=64 if g['rows'] <= 1024 else 0, ctype=bct if g16 else None,
+                             tag=self.TAG_D3_WGRAD)
             # D2 backward
             p0 = self.gemm(d_u, t, self.gref(W0), 8 * C, 4 * C, M, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_COL,
                            b_mode=L.MODE_COL, accum=True, dbias=self.gref(b0))

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 3
+#define GHN3_ABI_VERSION 4
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -43,7 +43,8 @@ typedef struct ghn3_ref {
 } ghn3_ref;
 
 /* ---- grouped GEMM --------------------------------------------------------------------------------
- * C(m,n) = epilogue( alpha * sum_k A(m,k) * B(k,n) )           fp32 in HBM, fp32 accumulate.
+ * C(m,n) = epilogue( alpha * sum_k A(m,k) * B(k,n) )           fp32 in HBM (or 16-bit operand copies, see
+ *                                                               GHN3_GEMM_OP16), fp32 accumulate.
  *
  * Operand addressing.  An operand is a row-major stored matrix X with leading dimension ld (floats).
  *   ROW mode (k-contiguous):  A(m,k) = X[rmap(m)][k]        B(k,n) = X[rmap(n)][k]
@@ -65,6 +66,16 @@ enum { GHN3_DACT_NONE = 0, GHN3_DACT_RELU = 1 /* aux_in > 0 */, GHN3_DACT_GELU =
  * dbias[cmap(m) * bias_stride] += sum_k A(m,k), and applies no bias to C.  At most one problem of a launch
  * may touch a given dbias element. */
 #define GHN3_GEMM_BIASGRAD 2u
+/* 16-bit operands ALREADY in HBM (written by GHN3_OP_CAST16): A and B reference f16 or bf16 matrices (the type
+ * is the op's compute type, which must be GHN3_CT_F16 / GHN3_CT_BF16), both in ROW mode (k-contiguous).  lda / ldb
+ * count 16-bit elements and must be multiples of 8, the byte offsets multiples of 16.  The kernel reads whole
+ * 64-wide k-tiles: every operand row must be readable up to round_up(K, 64) and A must hold ZEROS in k >= K.
+ * B may carry a k-map: logical k -> physical (k / b_kq) * b_ks + k % b_kq  (b_kq % 8 == 0; 0 = identity) -- the
+ * row-subset structure of the decoder W2 weights seen from the reduction side (nn.py:747-749 backward).
+ * C, aux_in, aux_out and residual must be 16-byte aligned with ldc % 4 == 0 (row-vector epilogue).
+ * Bias, activations, residual, accumulate, split-K and the C map work as for fp32 operands; GHN3_GEMM_BIASGRAD
+ * is not available (GHN3_OP_CAST16 produces that sum while it writes the transposed copy). */
+#define GHN3_GEMM_OP16 4u
 
 typedef struct ghn3_gemm_problem {
     ghn3_ref A, B, C;
@@ -79,7 +90,31 @@ typedef struct ghn3_gemm_problem {
     float alpha;
     int32_t ksplit;     /* > 1: split the K range into `ksplit` chunks whose partial sums are ADDED atomically to C
                          * (the program must zero C first; no epilogue but alpha is allowed) */
+    int32_t b_kq, b_ks; /* GHN3_GEMM_OP16 only: k-map of B (see above) */
 } ghn3_gemm_problem;
+
+/* ---- 16-bit operand copies (GHN3_OP_CAST16) -----------------------------------------------------------
+ * One descriptor = one fp32 matrix src[rows][cols] (leading dimension ld_src floats) converted to 16 bit:
+ *   GHN3_CAST_STRAIGHT    dst [r][c]  = cvt(src[r][c])   r < rows, c < round_up(cols, 64)   (zeros for c >= cols)
+ *   GHN3_CAST_TRANSPOSED  dstT[c][r]  = cvt(src[r][c])   c < cols, r < round_up(rows, 64)   (zeros for r >= rows)
+ *   GHN3_CAST_COLSUM      dbias[bmap(c)] += sum_r src[r][c]  (fp32, atomics) with bmap(c) = (c / bias_q) * bias_s +
+ *                         c % bias_q (bias_q == 0: c) -- the fused bias gradient of the wgrad that reads dstT.
+ * The type of each copy is f16 unless its *_BF16 flag is set.  Offsets: src_off in floats from r0, dst_off / dstT_off
+ * in 16-bit elements from r1; ld_dst >= round_up(cols, 64), ld_dstT >= round_up(rows, 64), both multiples of 8. */
+#define GHN3_CAST_STRAIGHT 1u
+#define GHN3_CAST_TRANSPOSED 2u
+#define GHN3_CAST_STRAIGHT_BF16 4u
+#define GHN3_CAST_TRANSPOSED_BF16 8u
+#define GHN3_CAST_COLSUM 16u
+typedef struct ghn3_cast_desc {
+    int64_t src_off, dst_off, dstT_off;
+    int32_t rows, cols;
+    int32_t ld_src, ld_dst, ld_dstT;
+    uint32_t flags;
+    int32_t bias_q, bias_s;
+    int32_t block_start;     /* first workgroup of this descriptor: blocks are 64 x 64 source tiles, column-tile fastest */
+    int32_t _pad;
+} ghn3_cast_desc;
 
 /* ---- tile / normalise descriptors  (nn.py:422-506 _tile_params, 554-592 _normalize, 508-552 _set_params)
  * dst[a,b,c,d] = f( src[src_off + (a%E0)*S0 + (b%E1)*S1 + (c%E2)*S2 + (d%E3)*S3] )
@@ -103,7 +138,8 @@ typedef struct ghn3_tile_desc {
 /* ---- ops ------------------------------------------------------------------------------------------- */
 enum ghn3_op_kind {
     GHN3_OP_NOP = 0,
-    /* i: first_problem, n_problems, tile(0 auto / 64 / 128), n_tiles_total (filled by host or 0) */
+    /* i: first_problem, n_problems, tile (0 auto / 32 / 64 / 128 for fp32 operands; 0 auto / 16 = 128x128 / 24 = 256x256
+     * for GHN3_GEMM_OP16 problems), n_tiles_total (filled by host or 0) */
     GHN3_OP_GEMM = 1,                 /* every nn.Linear / F.linear on the path */
     /* graphormer.py:229-237 -- degree counts of A==1, A[0,:], fw/bw pair index
      * r0=A(int64 B,N,N) r1=deg_in r2=deg_out r3=dist0 (int32 B,N) r4=pair (int32 B,N,N); i: B,N,V */
@@ -159,6 +195,10 @@ enum ghn3_op_kind {
     /* in place: X[m][n] *= dact(aux[m][n]) ; r0=X r1=aux ; i: M,N,ld, dact (GHN3_DACT_*) -- the deferred
      * epilogue of a split-K dgrad GEMM */
     GHN3_OP_DACT = 22,
+    /* fp32 -> f16 / bf16 operand copies for GHN3_GEMM_OP16 problems (straight and / or transposed, zero padded)
+     * r0=src base (fp32) r1=dst base (16-bit) r2=ghn3_cast_desc table (device) r3=dbias or absent
+     * i: n_desc, total workgroups */
+    GHN3_OP_CAST16 = 23,
     GHN3_OP_KIND_COUNT
 };
 

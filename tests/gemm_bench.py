@@ -78,3 +78,56 @@ if __name__ == '__main__':
     bench(ctx, 256, 1152, 384, R, R, 64, ct, name='qkv t64')
     bench(ctx, 256, 384, 1536, R, Cc, 0, ct, name='ffn dgrad (auto)')
     bench(ctx, 1536, 384, 256, Cc, Cc, 0, ct, name='ffn wgrad (auto)')
+
+
+def bench16(ctx, M, N, K, ctype, ksplit=1, accum=False, kmap=None, reps=5, name='', tile=0):
+    """GHN3_GEMM_OP16: 16-bit operands resident in HBM (random bit patterns of small magnitude)."""
+    dev = 'cuda'
+    kq, ks = kmap if kmap else (0, 0)
+    Kp = ((K + kq - 1) // kq) * ks if kmap else K
+    lda, ldb, ldc = (K + 63) // 64 * 64, (Kp + 63) // 64 * 64 + 64, N
+    mk = (lambda r, c: torch.randn(r, c, device=dev).to(torch.float16 if ctype == L.CT_F16 else torch.bfloat16))
+    A, B = mk(M, lda), mk(N, ldb)
+    C = torch.zeros(M, ldc, device=dev)
+    bufs = np.asarray([A.data_ptr(), B.data_ptr(), C.data_ptr()], dtype=np.uint64)
+    p = np.zeros(1, dtype=L.PROBLEM_DT)
+    for nme in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather'):
+        p[nme]['buf'] = -1
+    p['A']['buf'], p['B']['buf'], p['C']['buf'] = 0, 1, 2
+    p['M'], p['N'], p['K'], p['lda'], p['ldb'], p['ldc'] = M, N, K, lda, ldb, ldc
+    p['alpha'] = 1.0
+    p['ksplit'] = ksplit
+    p['b_kq'], p['b_ks'] = kq, ks
+    p['flags'] = L.GEMM_OP16 | (L.GEMM_ACCUM if accum else 0)
+    op = np.zeros(1, dtype=L.OP_DT)
+    op['kind'] = L.OP_GEMM
+    op['flags'] = 1 + ctype
+    op['i'][0][:3] = (0, 1, tile)
+    op['r']['buf'][:] = -1
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx.run(op, p, bufs, stream)
+    torch.cuda.synchronize()
+    e0, e1 = L.Event(), L.Event()
+    e0.record(stream)
+    for _ in range(reps):
+        ctx.run(op, p, bufs, stream)
+    e1.record(stream)
+    ms = e0.elapsed_ms(e1) / reps
+    tf = 2.0 * M * N * K / (ms * 1e-3) / 1e12
+    print('%-28s M=%6d N=%6d K=%6d OP16 tile=%2d ksplit=%2d acc=%d  %8.3f ms  %7.1f TF' %
+          (name, M, N, K, tile, ksplit, accum, ms, tf), flush=True)
+    return ms
+
+
+if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] in ('f16', 'bf16'):
+    ct = {'f16': L.CT_F16, 'bf16': L.CT_BF16}[sys.argv[1]]
+    ctx = L.context(0)
+    for tile in (16, 24):
+        bench16(ctx, 4096, 4096, 4096, ct, name='d16 square', tile=tile)
+        bench16(ctx, 8192, 8192, 8192, ct, name='d16 square 8k', tile=tile)
+        bench16(ctx, 512, 147456, 3072, ct, name='d16 w2 fwd', tile=tile)
+        for ks in (4, 9, 16, 32):
+            bench16(ctx, 512, 3072, 147456, ct, ksplit=ks, name='d16 w2 dgrad', tile=tile)
+        bench16(ctx, 512, 3072, 147456, ct, ksplit=16, kmap=(128, 384), name='d16 w2 dgrad kmap', tile=tile)
+        bench16(ctx, 147456, 3072, 512, ct, name='d16 w2 wgrad', tile=tile)
+        bench16(ctx, 147456, 3072, 512, ct, accum=True, name='d16 w2 wgrad accum', tile=tile)

@@ -167,3 +167,146 @@ CASES += [
     dict(M=50, N=90, K=70, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, tile=32, epilogue='bias_relu', qs_map=True),
     dict(M=2, N=3, K=1, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, tile=32),
 ]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 16-bit-operand pipeline: GHN3_OP_CAST16 (straight / transposed / column sums) feeding a GHN3_GEMM_OP16 problem.
+# The expectation is computed in fp64 from the operands rounded on the CPU exactly as the cast kernel rounds them,
+# so the tolerance only has to cover fp32 accumulation order.
+# ---------------------------------------------------------------------------------------------------------------
+def round16(x, ctype):
+    x = np.asarray(x, dtype=np.float32)
+    if ctype == L.CT_F16:
+        return x.astype(np.float16).astype(np.float32)
+    u = x.view(np.uint32).astype(np.uint64)
+    u = (u + 0x7fff + ((u >> 16) & 1)) & 0xffff0000
+    return u.astype(np.uint32).view(np.float32)
+
+
+def run_op16_case(ctx, M, N, K, ctype=L.CT_F16, tile=0, a_transposed=False, b_transposed=False, kmap=None, ksplit=1,
+                  epilogue='none', accum=False, colsum=False, cmap=False, seed=0, dev='cuda'):
+    rs = np.random.RandomState(seed)
+    r64 = lambda v: (v + 63) // 64 * 64
+    # fp32 sources.  A: [M][K] (or [K][M] when the cast transposes it); B physical k extent Kp (k-map) or K.
+    kq, ks = kmap if kmap else (0, 0)
+    Kp = ((K + kq - 1) // kq) * ks if kmap else K
+    A_log = rs.standard_normal((M, K)).astype(np.float32)
+    B_phys = rs.standard_normal((N, Kp)).astype(np.float32)
+    kk = np.arange(K)
+    kphys = (kk // kq) * ks + kk % kq if kmap else kk
+    B_log = B_phys[:, kphys]                                      # [N][K]
+    srcA = np.ascontiguousarray(A_log.T if a_transposed else A_log)
+    srcB = np.ascontiguousarray(B_phys.T if b_transposed else B_phys)
+    assert not (b_transposed and kmap)
+    pad4 = lambda v: (v + 3) // 4 * 4
+    ld_sa, ld_sb = pad4(srcA.shape[1]) + 4, pad4(srcB.shape[1]) + 8
+    SA = np.zeros((srcA.shape[0], ld_sa), np.float32); SA[:, :srcA.shape[1]] = srcA
+    SB = np.zeros((srcB.shape[0], ld_sb), np.float32); SB[:, :srcB.shape[1]] = srcB
+    src = np.concatenate([SA.reshape(-1), SB.reshape(-1)])
+    offB = SA.size
+    assert offB % 4 == 0
+    # 16-bit destinations (elements)
+    lda = r64(K) + 8
+    ldb = r64(Kp) + 64 + 8
+    dA_off, dB_off = 0, (M * lda + 63) // 64 * 64
+    total16 = dB_off + N * ldb + 64
+    descs = np.zeros(2, dtype=L.CAST_DT)
+    bf = ctype == L.CT_BF16
+    blocks = 0
+    for d, (off, rows, cols, ld_s, trans, dst_off, ld_d) in enumerate((
+            (0, srcA.shape[0], srcA.shape[1], ld_sa, a_transposed, dA_off, lda),
+            (offB, srcB.shape[0], srcB.shape[1], ld_sb, b_transposed, dB_off, ldb))):
+        D = descs[d]
+        D['src_off'], D['rows'], D['cols'], D['ld_src'] = off, rows, cols, ld_s
+        if trans:
+            D['dstT_off'], D['ld_dstT'] = dst_off, ld_d
+            D['flags'] = L.CAST_TRANSPOSED | (L.CAST_TRANSPOSED_BF16 if bf else 0)
+        else:
+            D['dst_off'], D['ld_dst'] = dst_off, ld_d
+            D['flags'] = L.CAST_STRAIGHT | (L.CAST_STRAIGHT_BF16 if bf else 0)
+        D['block_start'] = blocks
+        blocks += ((rows + 63) // 64) * ((cols + 63) // 64)
+    ldc = pad4(N) + 4
+    c_rows = M * 2 if cmap else M
+    cq, cs = (max(1, M // 3), max(1, M // 3) + 2) if cmap else (0, 0)
+    m = np.arange(M)
+    c_idx = (m // cq) * cs + m % cq if cmap else m
+    c_rows = int(c_idx.max()) + 1
+    C0 = rs.standard_normal((c_rows, ldc)).astype(np.float32)
+    if ksplit > 1 and not accum:
+        C0[:] = 0
+    bias = rs.standard_normal(max(N, c_rows) + 3).astype(np.float32)
+    dbias0 = rs.standard_normal(c_rows + 3).astype(np.float32)
+    if colsum:
+        assert a_transposed
+        descs[0]['flags'] |= L.CAST_COLSUM
+        descs[0]['bias_q'], descs[0]['bias_s'] = cq, cs
+    # expectation
+    Ar, Br = round16(A_log, ctype).astype(np.float64), round16(B_log, ctype).astype(np.float64)
+    v = Ar @ Br.T
+    if epilogue == 'bias_relu':
+        v = np.maximum(v + bias[:N][None, :], 0)
+    if accum or ksplit > 1:
+        v = v + C0[c_idx][:, :N]
+    expected = C0.astype(np.float64).copy()
+    expected[c_idx, :N] = v
+    dbias_exp = dbias0.astype(np.float64).copy()
+    if colsum:
+        np.add.at(dbias_exp, c_idx, A_log.astype(np.float64).sum(1))
+
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    d_src, d_16 = t(src), torch.full((total16,), 0x7e00 if not bf else 0x7fc0, dtype=torch.int16, device=dev)  # NaNs
+    # the regions the GEMM reads as padding beyond what the cast writes must be finite: B rows are read up to
+    # round64(K) logical k -> zero the B area like the program does for its workspace
+    d_16[dB_off:] = 0
+    d_desc, d_C, d_bias, d_dbias = t(descs.view(np.uint8)), t(C0), t(bias), t(dbias0)
+    bufs = [d_src, d_16, d_desc, d_C, d_bias, d_dbias]
+    ptrs = np.asarray([b.data_ptr() for b in bufs], dtype=np.uint64)
+    p = np.zeros(1, dtype=L.PROBLEM_DT)
+    for name in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather'):
+        p[name]['buf'] = -1
+    p['A']['buf'], p['A']['off'] = 1, 2 * dA_off
+    p['B']['buf'], p['B']['off'] = 1, 2 * dB_off
+    p['C']['buf'] = 3
+    if epilogue == 'bias_relu':
+        p['bias']['buf'] = 4
+        p['act'] = L.ACT_RELU
+    p['M'], p['N'], p['K'], p['lda'], p['ldb'], p['ldc'] = M, N, K, lda, ldb, ldc
+    p['c_q'], p['c_s'] = cq, cs
+    p['flags'] = L.GEMM_OP16 | (L.GEMM_ACCUM if accum else 0)
+    p['alpha'] = 1.0
+    p['ksplit'] = ksplit
+    p['b_kq'], p['b_ks'] = kq, ks
+    p['bias_stride'] = 1
+    ops = np.zeros(2, dtype=L.OP_DT)
+    ops['r']['buf'][:] = -1
+    ops[0]['kind'] = L.OP_CAST16
+    ops[0]['i'][:2] = (2, blocks)
+    ops[0]['r']['buf'][:4] = (0, 1, 2, 5 if colsum else -1)
+    ops[1]['kind'] = L.OP_GEMM
+    ops[1]['flags'] = 1 + ctype
+    ops[1]['i'][:3] = (0, 1, tile)
+    ctx.run(ops, p, ptrs, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = [(d_C.cpu().numpy(), expected)]
+    if colsum:
+        out.append((d_dbias.cpu().numpy(), dbias_exp))
+    return out
+
+
+OP16_CASES = [
+    dict(M=300, N=200, K=150),
+    dict(M=128, N=128, K=64),
+    dict(M=1100, N=1300, K=512, epilogue='bias_relu'),
+    dict(M=300, N=200, K=150, a_transposed=True, b_transposed=True, colsum=True, cmap=True, accum=True),
+    dict(M=70, N=3072 // 8, K=120, kmap=(24, 40), ksplit=2),
+    dict(M=533, N=384, K=64 * 48, kmap=(64, 96), ksplit=5),
+    dict(M=200, N=130, K=1000, a_transposed=True, b_transposed=True, ksplit=3, accum=True),
+    dict(M=5, N=7, K=9),
+    # the 256 x 256 tile variant (tile code 24)
+    dict(M=300, N=520, K=150, tile=24),
+    dict(M=1100, N=1300, K=512, epilogue='bias_relu', tile=24),
+    dict(M=300, N=200, K=150, a_transposed=True, b_transposed=True, colsum=True, cmap=True, accum=True, tile=24),
+    dict(M=533, N=384, K=64 * 48, kmap=(64, 96), ksplit=5, tile=24),
+    dict(M=5, N=7, K=9, tile=24),
+]

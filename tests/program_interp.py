@@ -26,7 +26,7 @@ class Interp:
         b = self.bufs[buf]
         assert b is not None, 'absent buffer %d' % buf
         item = np.dtype(dtype).itemsize
-        assert off % item == 0
+        assert off % min(item, 16) == 0
         out = b[off:off + count * item].view(dtype)
         assert len(out) == count, (buf, off, count, len(b))
         return out
@@ -60,11 +60,88 @@ class Interp:
             r = (r // q) * s + (r % q)
         return r
 
+    # ---- 16-bit operand copies ------------------------------------------------------------------------
+    @staticmethod
+    def to16(x, bf16):
+        x = np.ascontiguousarray(x, dtype=np.float32)
+        if not bf16:
+            return x.astype(np.float16).view(np.uint16)
+        u = x.view(np.uint32).astype(np.uint64)
+        return (((u + 0x7fff + ((u >> 16) & 1)) >> 16) & 0xffff).astype(np.uint16)
+
+    @staticmethod
+    def from16(h, bf16):
+        h = np.ascontiguousarray(h, dtype=np.uint16)
+        if not bf16:
+            return h.view(np.float16).astype(np.float32)
+        return (h.astype(np.uint32) << 16).view(np.float32)
+
+    def op_cast16(self, o, problems):
+        n_desc, blocks = int(o['i'][0]), int(o['i'][1])
+        src = self.tail(o['r'][0], np.float32)
+        dst = self.tail(o['r'][1], np.uint16)
+        descs = self.view(o['r'][2], L.CAST_DT, n_desc)
+        dbias = self.tail(o['r'][3], np.float32)
+        r64 = lambda v: (v + 63) // 64 * 64
+        nb = 0
+        for D in descs:
+            rows, cols, ld = int(D['rows']), int(D['cols']), int(D['ld_src'])
+            assert int(D['block_start']) == nb
+            nb += ((rows + 63) // 64) * ((cols + 63) // 64)
+            off = int(D['src_off'])
+            X = src[off + np.arange(rows)[:, None] * ld + np.arange(cols)[None, :]]
+            fl = int(D['flags'])
+            if fl & L.CAST_STRAIGHT:
+                Z = np.zeros((rows, r64(cols)), np.float32)
+                Z[:, :cols] = X
+                ldd = int(D['ld_dst'])
+                ii = int(D['dst_off']) + np.arange(rows)[:, None] * ldd + np.arange(r64(cols))[None, :]
+                dst[ii] = self.to16(Z, bool(fl & L.CAST_STRAIGHT_BF16))
+            if fl & L.CAST_TRANSPOSED:
+                Z = np.zeros((cols, r64(rows)), np.float32)
+                Z[:, :rows] = X.T
+                ldd = int(D['ld_dstT'])
+                ii = int(D['dstT_off']) + np.arange(cols)[:, None] * ldd + np.arange(r64(rows))[None, :]
+                dst[ii] = self.to16(Z, bool(fl & L.CAST_TRANSPOSED_BF16))
+            if fl & L.CAST_COLSUM:
+                c = np.arange(cols)
+                q, s_ = int(D['bias_q']), int(D['bias_s'])
+                if q > 0:
+                    c = (c // q) * s_ + c % q
+                np.add.at(dbias, c, X.astype(np.float64).sum(0).astype(np.float32))
+        assert nb == blocks
+
+    def _gemm_op16(self, o, p):
+        ct = (int(o['flags']) & 0xff) - 1
+        assert ct in (L.CT_F16, L.CT_BF16), 'OP16 problems need an explicit 16-bit compute type on the op'
+        bf = ct == L.CT_BF16
+        M, N, K = int(p['M']), int(p['N']), int(p['K'])
+        lda, ldb = int(p['lda']), int(p['ldb'])
+        assert int(p['a_mode']) == L.MODE_ROW and int(p['b_mode']) == L.MODE_ROW and lda % 8 == 0 and ldb % 8 == 0
+        assert int(p['A']['off']) % 16 == 0 and int(p['B']['off']) % 16 == 0 and int(p['b_kq']) % 8 == 0
+        XA, XB = self.tail(p['A'], np.uint16), self.tail(p['B'], np.uint16)
+        ga, gb = self.tail(p['a_gather'], np.int32), self.tail(p['b_gather'], np.int32)
+        Kp = (K + 63) // 64 * 64
+        k = np.arange(Kp)                     # the kernel reads whole 64-wide k tiles
+        ra = self._rowmap(np.arange(M), ga, int(p['a_q']), int(p['a_s']))
+        rb = self._rowmap(np.arange(N), gb, int(p['b_q']), int(p['b_s']))
+        kq, ks = int(p['b_kq']), int(p['b_ks'])
+        kphys = (k // kq) * ks + k % kq if kq > 0 else k
+        A = self.from16(XA[ra[:, None] * lda + k[None, :]], bf)
+        Bm = self.from16(XB[rb[None, :] * ldb + kphys[:, None]], bf)
+        assert np.all(A[:, K:] == 0), 'A must hold zeros in the K padding'
+        assert np.isfinite(Bm).all()
+        return A, Bm
+
     def op_gemm(self, o, problems):
         first, cnt = int(o['i'][0]), int(o['i'][1])
         for p in problems[first:first + cnt]:
             M, N, K = int(p['M']), int(p['N']), int(p['K'])
             if M <= 0 or N <= 0:
+                continue
+            if int(p['flags']) & L.GEMM_OP16:
+                A, Bm = self._gemm_op16(o, p)
+                self._gemm_finish(p, A, Bm)
                 continue
             lda, ldb, ldc = int(p['lda']), int(p['ldb']), int(p['ldc'])
             XA, XB, Y = self.tail(p['A'], np.float32), self.tail(p['B'], np.float32), self.tail(p['C'], np.float32)
@@ -82,6 +159,14 @@ class Interp:
             else:
                 rb = self._rowmap(np.arange(K), gb, int(p['b_q']), int(p['b_s']))
                 Bm = XB[(rb[:, None] * ldb + np.arange(N)[None, :])]
+            self._gemm_finish(p, A, Bm)
+
+    def _gemm_finish(self, p, A, Bm):
+        if True:
+            M, N = int(p['M']), int(p['N'])
+            ldc = int(p['ldc'])
+            Y = self.tail(p['C'], np.float32)
+            gc = self.tail(p['c_gather'], np.int32)
             v = (A.astype(np.float64) @ Bm.astype(np.float64)) * float(p['alpha'])
             rc = self._rowmap(np.arange(M), gc, int(p['c_q']), int(p['c_s']))
             ci = rc[:, None] * ldc + np.arange(N)[None, :]

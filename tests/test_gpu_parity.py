@@ -51,6 +51,18 @@ def _run_forward(hip, nets, gb, training=False):
     return plan, flat
 
 
+@pytest.mark.parametrize('ctype', [1, 2])
+def test_cast16_and_16bit_operand_gemm(ctx, ctype):
+    """GHN3_OP_CAST16 + GHN3_GEMM_OP16: exact against fp64 products of the CPU-rounded operands (only the fp32
+    accumulation order differs), incl. transposed copies, zero K padding, the B k-map, split-K and column sums."""
+    from gemm_cases import OP16_CASES, run_op16_case
+    for k, case in enumerate(OP16_CASES):
+        for got, exp in run_op16_case(ctx, ctype=ctype, seed=k, **case):
+            assert np.isfinite(got).all(), case
+            err = rel_l2(got, exp)
+            assert err < 3e-6, (case, err)
+
+
 @pytest.mark.parametrize('case', ['b1', 'b2', 'b2r'])
 def test_tiny_forward_matches_oracle_and_golden(case):
     hip, oracle = make_models(recipe.TINY_CFG, recipe.TINY_SEED)

@@ -28,12 +28,12 @@ def _build(cfg, seed, index_mode):
     return hip, oracle
 
 
-def _run_program(hip, nets, gb, training=True):
+def _run_program(hip, nets, gb, training=True, **prog_kw):
     gb._cat()
     cfg = dict(hid=hip.hid, heads=hip.heads, layers=hip.layers, num_classes=hip.num_classes,
                max_shape=hip.max_shape)
     prog = Program(cfg, gb.node_info, gb.host_n_nodes(), gb._node_type_host, gb.max_edge, nets,
-                   index_mode=hip.index_mode, training=training)
+                   index_mode=hip.index_mode, training=training, **prog_kw)
     P = prog.P
     pflat = hip._flat.detach().numpy().copy().view(np.uint8)
     gflat = np.zeros(hip._flat_numel, dtype=np.float32).view(np.uint8)
@@ -109,6 +109,56 @@ def test_compiled_programs_reproduce_oracle_forward_and_backward(case, index_mod
         # (the edge-MLP output bias has an analytically zero gradient: softmax is shift invariant)
         err = float(np.linalg.norm(got.astype(np.float64) - ref))
         assert err < 5e-5 * float(np.linalg.norm(ref)) + 1e-6, (name, err, float(np.linalg.norm(ref)))
+
+
+@pytest.mark.parametrize('fwd_ct,bwd_ct,tol_f,tol_g', [(L.CT_F16, L.CT_BF16, 1e-3, 1e-2), (L.CT_F16, L.CT_F16, 1e-3, 4e-3),
+                                                        (L.CT_BF16, L.CT_BF16, 8e-3, 1e-2)])
+def test_16bit_operand_pipeline_program(fwd_ct, bwd_ct, tol_f, tol_g):
+    """The 16-bit decoder pipeline (GHN3_OP_CAST16 copies + GHN3_GEMM_OP16 problems, f16 forward / bf16 backward by
+    default): program structure (offsets, k-map, padding, fused bias gradient) validated against the oracle with
+    the rounding emulated by the interpreter.  Tolerances are the measured rounding noise, not fp32 parity."""
+    hip, oracle = _build(recipe.TINY_CFG, recipe.TINY_SEED, 'reference')
+    nets_h, gb_h, nets_o, gb_o = _tiny('b2')
+    prog, it, bufs, gflat = _run_program(hip, nets_h, gb_h, decoder_ctype=fwd_ct, decoder_bwd_ctype=bwd_ct)
+    assert any(g['op16'] for g in prog.gemm_groups)
+    assert sum(int(p['flags']) & L.GEMM_OP16 != 0 for p in prog.problems) >= 3
+    out = bufs[prog.xbuf(prog.X_OUT)].view(np.float32)
+    oracle.train()
+    _, pred_o = oracle(nets_o, gb_o, keep_grads=True)
+    loss_o = 0
+    for k, (ind, attr, m, t) in enumerate(pred_o):
+        p = prog.predicted[k]
+        got = out[p['offset']:p['offset'] + p['numel']].reshape(p['tile_shape'])
+        ref = t.detach().numpy()
+        if ref.ndim == 3:
+            got, ref = got[:, 1:], ref[:, 1:]
+        assert rel_l2(got, ref) < tol_f, (k, attr, ref.shape, rel_l2(got, ref))
+        q = t[:, 1:] if t.dim() == 3 else t
+        loss_o = loss_o + torch.norm(q, p='fro')
+    dout = bufs[prog.xbuf(prog.X_DOUT)].view(np.float32)
+    for p, (_, _, _, t) in zip(prog.predicted, pred_o):
+        v = t.detach().numpy().astype(np.float64)
+        g = np.zeros_like(v)
+        if v.ndim == 3:
+            g[:, 1:] = v[:, 1:] / np.linalg.norm(v[:, 1:])
+        else:
+            g = v / np.linalg.norm(v)
+        dout[p['offset']:p['offset'] + p['numel']] = g.reshape(-1)
+    gflat[:] = 0x7f
+    hip._patch_grad_memsets(prog)
+    it.run(prog.bwd_ops, prog.problems)
+    loss_o.backward()
+    po = dict(oracle.named_parameters())
+    g32 = gflat.view(np.float32)
+    worst = 0.0
+    for name, off in zip(prog.names, hip._offs):
+        ref = po[name].grad.numpy()
+        got = g32[int(off):int(off) + ref.size].reshape(ref.shape)
+        err = float(np.linalg.norm(got.astype(np.float64) - ref))
+        assert err < tol_g * float(np.linalg.norm(ref)) + 1e-6, (name, err, float(np.linalg.norm(ref)))
+        if float(np.linalg.norm(ref)) > 1e-4:
+            worst = max(worst, err / float(np.linalg.norm(ref)))
+    print('worst gradient rel error', worst)
 
 
 def test_param_norm_ops():

@@ -86,8 +86,12 @@ __device__ __forceinline__ bool tile_origin(const GemmProbDev* P, int t, int& m0
 
 // Epilogue shared by all variants.  acc tile layout (32x32 MFMA C/D): col = lane & 31,
 // row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).
-template <int TM, int TN>
-__device__ __forceinline__ void epilogue(const GemmProbDev* P, f32x16 (&acc)[TM][TN], int m_base, int n_base, int lane) {
+// The element math is branch free for everything but GELU (uniform selects instead of per-element scalar
+// branches: the unrolled branchy version was tens of KB of code per kernel and instruction-fetch bound); the GELU
+// variant (erff) is a separate instantiation entered through ONE uniform branch.
+template <int TM, int TN, bool GELU>
+__device__ __forceinline__ void epilogue_impl(const GemmProbDev* P, f32x16 (&acc)[TM][TN], int m_base, int n_base,
+                                              int lane) {
     const int M = P->M, N = P->N, ldc = P->ldc;
     gf C = (gf)P->C;
     gcf bias = (gcf)P->bias;
@@ -100,6 +104,7 @@ __device__ __forceinline__ void epilogue(const GemmProbDev* P, f32x16 (&acc)[TM]
     const bool accum = (P->flags & GHN3_GEMM_ACCUM) != 0;
     const bool split = P->ksplit > 1;
     const float alpha = P->alpha;
+    const bool act_relu = act == GHN3_ACT_RELU, dact_relu = dact == GHN3_DACT_RELU;
     const int l31 = lane & 31, lhi = lane >> 5;
 #pragma unroll
     for (int tn = 0; tn < TN; ++tn) {
@@ -143,16 +148,27 @@ __device__ __forceinline__ void epilogue(const GemmProbDev* P, f32x16 (&acc)[TM]
                 if (ok[r]) {
                     float v = acc[tm][tn][r] * alpha + bv;
                     if (aux_out) aux_out[ci[r]] = v;
-                    if (act == GHN3_ACT_RELU) v = fmaxf(v, 0.f);
-                    else if (act == GHN3_ACT_GELU) v = gelu_f(v);
-                    if (dact == GHN3_DACT_RELU) v = (auxv[r] > 0.f) ? v : 0.f;
-                    else if (dact == GHN3_DACT_GELU) v *= gelu_grad_f(auxv[r]);
+                    if (GELU) {
+                        if (act == GHN3_ACT_RELU) v = fmaxf(v, 0.f);
+                        else if (act == GHN3_ACT_GELU) v = gelu_f(v);
+                        if (dact == GHN3_DACT_RELU) v = (auxv[r] > 0.f) ? v : 0.f;
+                        else if (dact == GHN3_DACT_GELU) v *= gelu_grad_f(auxv[r]);
+                    } else {
+                        v = act_relu ? fmaxf(v, 0.f) : v;
+                        v = (dact_relu && !(auxv[r] > 0.f)) ? 0.f : v;
+                    }
                     v += resv[r] + cold[r];
                     C[ci[r]] = v;
                 }
             }
         }
     }
+}
+
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(const GemmProbDev* P, f32x16 (&acc)[TM][TN], int m_base, int n_base, int lane) {
+    if (P->act == GHN3_ACT_GELU || P->dact == GHN3_DACT_GELU) epilogue_impl<TM, TN, true>(P, acc, m_base, n_base, lane);
+    else epilogue_impl<TM, TN, false>(P, acc, m_base, n_base, lane);
 }
 
 // Row-vector epilogue: the accumulators of a wave's (TM*32) x 64 sub-tile are transposed through a wave-private LDS
@@ -163,7 +179,8 @@ __device__ __forceinline__ void epilogue(const GemmProbDev* P, f32x16 (&acc)[TM]
 // checks and falls back).  `stage` = this wave's LDS region of 32 * 68 floats.
 typedef f32x4 GAS* gf4;
 struct RowsEpi {
-    int M, N, ldc, cq, cs, act, dact, ncol, col, c4, rsub, l31, lhi;
+    int M, N, ldc, cq, cs, ncol, col, c4, rsub, l31, lhi;
+    bool act_relu, dact_relu;
     gf C; gcf residual, aux_in; gf aux_out; gci cg;
     bool accum; float alpha; f32x4 bv;
     float* stage;
@@ -202,12 +219,12 @@ __device__ __forceinline__ void epilogue_rows_block(const RowsEpi& E, const f32x
             cold[j] = z; auxv[j] = z; resv[j] = z;
             if (ok[j] && full) {
                 if (E.accum) cold[j] = *reinterpret_cast<gcf4>(E.C + ci[j]);
-                if (E.dact != GHN3_DACT_NONE) auxv[j] = *reinterpret_cast<gcf4>(E.aux_in + ci[j]);
+                if (E.dact_relu) auxv[j] = *reinterpret_cast<gcf4>(E.aux_in + ci[j]);
                 if (E.residual) resv[j] = *reinterpret_cast<gcf4>(E.residual + ci[j]);
             } else if (ok[j]) {
                 for (int e = 0; e < E.ncol; ++e) {
                     if (E.accum) cold[j][e] = E.C[ci[j] + e];
-                    if (E.dact != GHN3_DACT_NONE) auxv[j][e] = E.aux_in[ci[j] + e];
+                    if (E.dact_relu) auxv[j][e] = E.aux_in[ci[j] + e];
                     if (E.residual) resv[j][e] = E.residual[ci[j] + e];
                 }
             }
@@ -220,10 +237,8 @@ __device__ __forceinline__ void epilogue_rows_block(const RowsEpi& E, const f32x
             for (int e = 0; e < 4; ++e) {
                 float x = v[j][e] * E.alpha + E.bv[e];
                 pre[e] = x;
-                if (E.act == GHN3_ACT_RELU) x = fmaxf(x, 0.f);
-                else if (E.act == GHN3_ACT_GELU) x = gelu_f(x);
-                if (E.dact == GHN3_DACT_RELU) x = (auxv[j][e] > 0.f) ? x : 0.f;
-                else if (E.dact == GHN3_DACT_GELU) x *= gelu_grad_f(auxv[j][e]);
+                x = E.act_relu ? fmaxf(x, 0.f) : x;
+                x = (E.dact_relu && !(auxv[j][e] > 0.f)) ? 0.f : x;
                 o[e] = x + resv[j][e] + cold[j][e];
             }
             if (full) {
@@ -245,7 +260,8 @@ template <int TM>
 __device__ __forceinline__ void epilogue_rows(const GemmProbDev* P, f32x16 (&acc)[TM][2], int m_base, int n_base,
                                               int lane, float* stage) {
     RowsEpi E;
-    E.M = P->M; E.N = P->N; E.ldc = P->ldc; E.cq = P->c_q; E.cs = P->c_s; E.act = P->act; E.dact = P->dact;
+    E.M = P->M; E.N = P->N; E.ldc = P->ldc; E.cq = P->c_q; E.cs = P->c_s;
+    E.act_relu = P->act == GHN3_ACT_RELU; E.dact_relu = P->dact == GHN3_DACT_RELU;      // (GELU: rejected by the host)
     E.C = (gf)P->C; E.residual = (gcf)P->residual; E.aux_in = (gcf)P->aux_in; E.aux_out = (gf)P->aux_out;
     E.cg = (gci)P->c_gather;
     E.accum = (P->flags & GHN3_GEMM_ACCUM) != 0;
@@ -705,11 +721,15 @@ __global__ __launch_bounds__(256) void gemm_h16_kernel(const GemmProbDev* __rest
 #define LAS __attribute__((address_space(3)))
 typedef const unsigned short GAS* gch;
 
-// WGM x WGN waves, each owning a (BM / WGM) x 64 sub-tile.  Instantiated as 128 x 128 (2 x 2 waves, 2 blocks / CU)
-// and 256 x 256 (2 x 4 waves, 1 block / CU): the loop is bound by the L2 -> LDS rate (~17 B/clk/CU measured), so
-// the flop rate scales with the tile's arithmetic intensity BM BN / (BM + BN) -- 64 vs 128 flop/B.
-template <int CT, int BM, int BN, int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_h16d_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
+// WGM x WGN waves, each owning a (BM / WGM) x 64 sub-tile; NS LDS stages form a ring that keeps NS - 1 k-tiles in
+// flight (counted s_waitcnt vmcnt + a raw s_barrier per k-tile: __syncthreads would drain the DMA queue).
+// The loop is bound by the L2 -> LDS rate (~17 B/clk/CU measured), so the flop rate scales with the tile's
+// arithmetic intensity BM BN / (BM + BN): 64 flop/B for 128 x 128, 128 flop/B for 256 x 256.
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int CT, int BM, int BN, int WGM, int WGN, int NS>
+__global__ __launch_bounds__(64 * WGM * WGN, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1) * WGM * WGN / 4)
+void gemm_h16d_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
     constexpr int BK = 64;
     constexpr int NT = 64 * WGM * WGN;               // threads
     constexpr int TM = BM / WGM / 32, TN = 2;
@@ -717,6 +737,7 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_h16d_kernel(const Gemm
     constexpr int OPA = BM * BK * 2, OPB = BN * BK * 2;   // bytes per operand image
     constexpr int STAGE = OPA + OPB;
     constexpr int PA = BM * 8 / NT, PB = BN * 8 / NT;     // 16-byte pieces per thread
+    static_assert((NS - 2) * (PA + PB) < 64, "vmcnt is a 6-bit counter");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sm = reinterpret_cast<char*>(smem);
 
@@ -730,16 +751,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_h16d_kernel(const Gemm
     const int kt0 = kz * (P->k_chunk / BK);
     const int K = (P->ksplit > 1) ? min(P->K, (kz + 1) * P->k_chunk) : P->K;
     if (kt0 * BK >= K && P->ksplit > 1) return;
-    const int nk = (K + BK - 1) / BK;
+    const int nkt = (K + BK - 1) / BK - kt0;         // k-tiles of this block
 
-    // per-lane source pointers: piece p = tid + NT i -> LDS row p / 8, slot p % 8, global chunk slot ^ (row & 7)
+    // per-lane source pointers: piece p = tid + NT i -> LDS row p / 8, slot p % 8, which holds the global 16-byte
+    // chunk slot ^ ((row >> 1) & 7): with that swizzle the 16 lanes of every ds_read_b128 lane group hit 16
+    // different 4-bank columns (MI355X_MICROARCH.md, LDS table)
     gch pa[PA], pb[PB];
     int ck;                                          // k offset of this lane's chunk: the same for all its pieces
     {
         gch A = (gch)P->A; gch B = (gch)P->B;
         gci ag = (gci)P->a_gather; gci bg = (gci)P->b_gather;
-        const int slot = tid & 7, rbase = tid >> 3;  // NT / 8 rows per pass, (row & 7) == (rbase & 7) for every i
-        ck = (slot ^ (rbase & 7)) * 8;
+        const int slot = tid & 7, rbase = tid >> 3;  // NT / 8 rows per pass (a multiple of 16)
+        ck = (slot ^ ((rbase >> 1) & 7)) * 8;
 #pragma unroll
         for (int i = 0; i < PA; ++i) {
             const int ra = min(m0 + rbase + (NT / 8) * i, P->M - 1);
@@ -762,8 +785,8 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_h16d_kernel(const Gemm
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    auto issue = [&](int kt, int stage) {
-        const int k0 = kt * BK;
+    auto issue = [&](int i) {                          // k-tile i of this block -> stage i % NS
+        const int k0 = (kt0 + i) * BK;
         int kb = k0 + ck;
         if (kq > 0) {                                  // k-map of B: (k / kq) * ks + k % kq   (k < 2^24)
             int qd = (int)((float)kb * inv_kq);
@@ -771,48 +794,53 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_h16d_kernel(const Gemm
             if (rm < 0) { rm += kq; --qd; } else if (rm >= kq) { rm -= kq; ++qd; }
             kb = qd * ks + rm;
         }
-        LAS char* la = (LAS char*)(sm + stage * STAGE);
+        LAS char* la = (LAS char*)(sm + (i % NS) * STAGE);
         // wave-uniform LDS base: the 64 lanes of a wave write 64 consecutive 16-byte pieces
 #pragma unroll
-        for (int i = 0; i < PA; ++i)
-            __builtin_amdgcn_global_load_lds((const void GAS*)(pa[i] + k0), (LAS void*)(la + (wave * 64 + NT * i) * 16),
+        for (int j = 0; j < PA; ++j)
+            __builtin_amdgcn_global_load_lds((const void GAS*)(pa[j] + k0), (LAS void*)(la + (wave * 64 + NT * j) * 16),
                                              16, 0, 0);
 #pragma unroll
-        for (int i = 0; i < PB; ++i)
-            __builtin_amdgcn_global_load_lds((const void GAS*)(pb[i] + kb),
-                                             (LAS void*)(la + OPA + (wave * 64 + NT * i) * 16), 16, 0, 0);
+        for (int j = 0; j < PB; ++j)
+            __builtin_amdgcn_global_load_lds((const void GAS*)(pb[j] + kb),
+                                             (LAS void*)(la + OPA + (wave * 64 + NT * j) * 16), 16, 0, 0);
     };
 
-    issue(kt0, 0);
-    for (int kt = kt0; kt < nk; ++kt) {
-        const int cur = (kt - kt0) & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();                               // tile kt is in LDS for every wave; stage cur^1 is free
-        if (kt + 1 < nk) issue(kt + 1, cur ^ 1);
-        const char* a_s = sm + cur * STAGE;
+    const int dbg = P->_pad;
+    const int nkt_run = (dbg & 2) ? 0 : nkt;
+#pragma unroll
+    for (int i = 0; i < NS - 1; ++i)
+        if (i < nkt_run) issue(i);
+    for (int i = 0; i < nkt_run; ++i) {
+        // tile i has landed once at most the NS - 2 younger tiles are outstanding (fewer were issued near the end)
+        if (i + NS - 1 <= nkt_run) wait_vmcnt<(NS - 2) * (PA + PB)>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();                  // every wave's share of tile i landed; stage (i-1) % NS is free
+        if (i + NS - 1 < nkt_run) issue(i + NS - 1);
+        const char* a_s = sm + (i % NS) * STAGE;
         const char* b_s = a_s + OPA;
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {         // 4 MFMA k-steps of 16
             u16x8 af[TM], bf[TN];
             const int slot = kk * 2 + lhi;             // 16-byte k chunk wanted by this lane
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const int row = wm0 + i * 32 + l31;
-                af[i] = *reinterpret_cast<const u16x8*>(a_s + row * 128 + ((slot ^ (row & 7)) << 4));
+            for (int ii = 0; ii < TM; ++ii) {
+                const int row = wm0 + ii * 32 + l31;
+                af[ii] = *reinterpret_cast<const u16x8*>(a_s + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn0 + j * 32 + l31;
-                bf[j] = *reinterpret_cast<const u16x8*>(b_s + row * 128 + ((slot ^ (row & 7)) << 4));
+                bf[j] = *reinterpret_cast<const u16x8*>(b_s + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
-            for (int i = 0; i < TM; ++i)
+            for (int ii = 0; ii < TM; ++ii)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = mfma16<CT>(af[i], bf[j], acc[i][j]);
+                    acc[ii][j] = mfma16<CT>(af[ii], bf[j], acc[ii][j]);
         }
     }
     // (the host only routes problems with ldc % 4 == 0 and 16-byte aligned C / aux / residual to this kernel)
+    if ((dbg & 1) && acc[0][0][0] != 12345.f) return;
     if (P->ksplit > 1) {
         epilogue_split<TM>(P, acc, m0 + wm0, n0 + wn0, lane);
     } else {
@@ -825,11 +853,18 @@ __global__ __launch_bounds__(64 * WGM * WGN, 2) void gemm_h16d_kernel(const Gemm
 // host side
 // ------------------------------------------------------------------------------------------------
 typedef void (*gemm_fn)(const GemmProbDev*, int);
-static constexpr int H16D_LDS_128 = 2 * (128 + 128) * 64 * 2;      // 64 KB: two stages of A + B images
-static constexpr int H16D_LDS_256 = 2 * (256 + 256) * 64 * 2;      // 128 KB
-static gemm_fn g_h16d[2][2] = {
-    {gemm_h16d_kernel<GHN3_CT_F16, 128, 128, 2, 2>, gemm_h16d_kernel<GHN3_CT_BF16, 128, 128, 2, 2>},
-    {gemm_h16d_kernel<GHN3_CT_F16, 256, 256, 2, 4>, gemm_h16d_kernel<GHN3_CT_BF16, 256, 256, 2, 4>}};
+// 16-bit-operand kernel variants, selected by GHN3_H16D_VARIANT (default below) -- tile code 16 / 24 picks the row
+struct H16dVariant { gemm_fn fn[2]; int threads, lds, edge; };
+#define H16D(BMN, WGM, WGN, NS)                                                                          \
+    {{gemm_h16d_kernel<GHN3_CT_F16, BMN, BMN, WGM, WGN, NS>, gemm_h16d_kernel<GHN3_CT_BF16, BMN, BMN, WGM, WGN, NS>}, \
+     64 * WGM * WGN, NS * 2 * BMN * 64 * 2, BMN}
+static H16dVariant g_h16d[] = {
+    H16D(128, 2, 2, 2),      // 0: 64 KB, 2 blocks / CU
+    H16D(128, 2, 2, 4),      // 1: 128 KB, 1 block / CU, 3 k-tiles in flight
+    H16D(256, 2, 4, 2),      // 2: 128 KB, 1 block / CU
+    H16D(128, 2, 2, 3),      // 3: 96 KB, 1 block / CU
+};
+static int g_h16d_small = 0, g_h16d_big = 2;
 
 template <int BM, int BN, int AM, int BMD> static size_t f32_lds() {
     return 2 * (size_t)(F32Tile<BM, AM>::SIZE + F32Tile<BN, BMD>::SIZE) * sizeof(float);
@@ -884,12 +919,12 @@ int ghn3_gemm_init() {
                         }
                     }
                 }
-    for (int big = 0; big < 2; ++big)
+    for (const H16dVariant& v : g_h16d)
         for (int ct = 0; ct < 2; ++ct) {
-            hipError_t e = hipFuncSetAttribute((const void*)g_h16d[big][ct], hipFuncAttributeMaxDynamicSharedMemorySize,
-                                               big ? H16D_LDS_256 : H16D_LDS_128);
+            hipError_t e = hipFuncSetAttribute((const void*)v.fn[ct], hipFuncAttributeMaxDynamicSharedMemorySize, v.lds);
             if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(h16d): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
         }
+    if (const char* env = getenv("GHN3_H16D_SMALL")) g_h16d_small = atoi(env) == 0 ? 0 : atoi(env) == 3 ? 3 : 1;
     g_gemm_ready = true;
     return GHN3_OK;
 }
@@ -902,9 +937,8 @@ int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_til
                        tile);
         return GHN3_E_ARG;
     }
-    const int big = tile == 256;
-    hipLaunchKernelGGL(g_h16d[big][ctype == GHN3_CT_BF16], dim3(total_tiles), dim3(big ? 512 : 256),
-                       big ? H16D_LDS_256 : H16D_LDS_128, stream, d_probs, n_probs);
+    const H16dVariant& v = g_h16d[tile == 256 ? g_h16d_big : g_h16d_small];
+    hipLaunchKernelGGL(v.fn[ctype == GHN3_CT_BF16], dim3(total_tiles), dim3(v.threads), v.lds, stream, d_probs, n_probs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("h16d gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

@@ -231,10 +231,11 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             if ((tl == 16 || tl == 24) && (p.a_mode != GHN3_MODE_ROW || p.b_mode != GHN3_MODE_ROW || (p.lda & 7) ||
                                              (p.ldb & 7) || (p.b_kq & 7) || (p.flags & GHN3_GEMM_BIASGRAD) ||
                                              p.K >= (1 << 24) || (p.ldc & 3) || (p.C.off & 15) ||
+                                             p.act == GHN3_ACT_GELU || p.dact == GHN3_DACT_GELU ||
                                              (p.aux_in.off & 15) || (p.aux_out.off & 15) || (p.residual.off & 15))) {
                                 ghn3_set_error("op %d problem %d: 16-bit operands need ROW/ROW modes, ld %% 8 == 0, "
-                                               "b_kq %% 8 == 0, K < 2^24, no BIASGRAD, ldc %% 4 == 0 and 16-byte "
-                                               "aligned C / aux / residual", k, q);
+                                               "b_kq %% 8 == 0, K < 2^24, no BIASGRAD / GELU, ldc %% 4 == 0 and "
+                                               "16-byte aligned C / aux / residual", k, q);
                                 return GHN3_E_ARG;
                             }
                             if (p.M >= (1 << 24) || p.N >= (1 << 24) || p.K >= (1 << 24)) {
@@ -256,6 +257,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             g.a_q = p.a_q; g.a_s = p.a_s; g.b_q = p.b_q; g.b_s = p.b_s; g.c_q = p.c_q; g.c_s = p.c_s;
                             g.bias_q = p.bias_q; g.bias_s = p.bias_s; g.bias_stride = p.bias_stride ? p.bias_stride : 1;
                             g.act = p.act; g.dact = p.dact; g.flags = p.flags; g.alpha = p.alpha;
+                            { static int dbg = getenv("GHN3_DBG") ? atoi(getenv("GHN3_DBG")) : 0; g._pad = dbg; }
                             if ((p.flags & GHN3_GEMM_BIASGRAD) && (p.a_mode != GHN3_MODE_COL || !g.bias)) {
                                 ghn3_set_error("op %d problem %d: BIASGRAD needs a COL-mode A and a bias ref", k, q);
                                 return GHN3_E_ARG;

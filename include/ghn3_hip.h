@@ -73,8 +73,8 @@ enum { GHN3_DACT_NONE = 0, GHN3_DACT_RELU = 1 /* aux_in > 0 */, GHN3_DACT_GELU =
  * B may carry a k-map: logical k -> physical (k / b_kq) * b_ks + k % b_kq  (b_kq % 8 == 0; 0 = identity) -- the
  * row-subset structure of the decoder W2 weights seen from the reduction side (nn.py:747-749 backward).
  * C, aux_in, aux_out and residual must be 16-byte aligned with ldc % 4 == 0 (row-vector epilogue).
- * Bias, activations, residual, accumulate, split-K and the C map work as for fp32 operands; GHN3_GEMM_BIASGRAD
- * is not available (GHN3_OP_CAST16 produces that sum while it writes the transposed copy). */
+ * Bias, ReLU / dReLU, residual, accumulate, split-K and the C map work as for fp32 operands; GELU and
+ * GHN3_GEMM_BIASGRAD are not available (GHN3_OP_CAST16 produces that sum while it writes the transposed copy). */
 #define GHN3_GEMM_OP16 4u
 
 typedef struct ghn3_gemm_problem {

@@ -80,7 +80,7 @@ if __name__ == '__main__':
     bench(ctx, 1536, 384, 256, Cc, Cc, 0, ct, name='ffn wgrad (auto)')
 
 
-def bench16(ctx, M, N, K, ctype, ksplit=1, accum=False, kmap=None, reps=5, name='', tile=0):
+def bench16(ctx, M, N, K, ctype, ksplit=1, accum=False, kmap=None, reps=5, name='', tile=0, a_qs=None, c_qs=None):
     """GHN3_GEMM_OP16: 16-bit operands resident in HBM (random bit patterns of small magnitude)."""
     dev = 'cuda'
     kq, ks = kmap if kmap else (0, 0)
@@ -98,6 +98,10 @@ def bench16(ctx, M, N, K, ctype, ksplit=1, accum=False, kmap=None, reps=5, name=
     p['alpha'] = 1.0
     p['ksplit'] = ksplit
     p['b_kq'], p['b_ks'] = kq, ks
+    if a_qs:
+        p['a_q'], p['a_s'] = a_qs
+    if c_qs:
+        p['c_q'], p['c_s'] = c_qs
     p['flags'] = L.GEMM_OP16 | (L.GEMM_ACCUM if accum else 0)
     op = np.zeros(1, dtype=L.OP_DT)
     op['kind'] = L.OP_GEMM
@@ -118,6 +122,17 @@ def bench16(ctx, M, N, K, ctype, ksplit=1, accum=False, kmap=None, reps=5, name=
           (name, M, N, K, tile, ksplit, accum, ms, tf), flush=True)
     return ms
 
+
+if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == 'wgrad':
+    ct = {'f16': L.CT_F16, 'bf16': L.CT_BF16}[sys.argv[1]]
+    ctx = L.context(0)
+    for tile in (16, 24):
+        bench16(ctx, 147456, 3072, 512, ct, name='wgrad', tile=tile)
+        bench16(ctx, 147456, 3072, 512, ct, name='wgrad A rows -> 256 (L2)', tile=tile, a_qs=(256, 0))
+        bench16(ctx, 147456, 3072, 512, ct, name='wgrad C rows -> 256 (L2)', tile=tile, c_qs=(256, 0))
+        bench16(ctx, 147456, 3072, 512, ct, name='wgrad A,C rows -> 256', tile=tile, a_qs=(256, 0), c_qs=(256, 0))
+        bench16(ctx, 147456, 3072, 2048, ct, name='wgrad K=2048', tile=tile)
+    sys.exit(0)
 
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] in ('f16', 'bf16'):
     ct = {'f16': L.CT_F16, 'bf16': L.CT_BF16}[sys.argv[1]]

@@ -1,364 +1,419 @@
-// Fused multi-head self-attention with additive edge bias for graph sizes N <= 1024 (gfx950).
+// Fused multi-head self-attention with additive edge bias on the fp32 matrix cores (gfx950), N <= 1024, d <= 32.
 //
 // Replaces ghn3/graphormer.py:121-140:
 //     attn = (q @ k^T) * d^-0.5 + edge_bias ; attn.masked_fill(~mask, -2**15) ; softmax ; attn @ v
-// and its autograd backward.  Head dims on this path are tiny (d = 8..24) and N <= ~10^3, so the
-// products run as exact fp32 VALU FMAs:
-//   * scores: one query row per wavefront, one key per lane (the 64-wide slices of a score row live in
-//     registers); K of one (graph, head) is staged through LDS with an odd row stride (conflict-free walks);
-//     the row softmax is a wave-level reduction (2 scalars per row).
-//   * P.V (and dS.K in the backward): the normalised row is parked in LDS and the wave switches to an
-//     (output column e, key parity g) lane mapping, so no d-wide cross-lane reduction is needed.
-//   * every global->LDS staging loop keeps 8 loads in flight per thread (latency-bound otherwise: one
-//     workgroup per CU at N = 256).
-// The probabilities are written once (B,H,N,N) for the backward pass.
+// and its autograd backward.  Head dims on this path are tiny (d = 8..24) and N <= ~10^3; all four
+// products of the forward and backward run on v_mfma_f32_32x32x2_f32 (exact fp32 products, fp32 accumulate).
 //
-// Mask semantics (quirks Q5/Q6): pair mask = valid(i) & valid(j); masked scores are set to -32768 (not
-// -inf), so fully padded query rows produce a uniform distribution over all N_max keys, as the reference.
+// Layout trick.  Every score-shaped 32 x 32 tile is computed TRANSPOSED: S^T = K_tile Q_tile^T, so that in the MFMA
+// C/D layout (col = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) a LANE is a query and its 16 accumulator
+// REGISTERS are keys.  Then
+//   * the row softmax is a per-lane reduction over registers (+ one xor-32 shuffle + a 4-wave LDS exchange);
+//   * P^T (or dS^T) is already the B operand of the next product O^T = V^T P^T (dQ^T = K^T dS^T): MFMA step s
+//     consumes accumulator register s, the matching A operand row is key (s & 3) + 8 (s >> 2) + 4 (lane >> 5)
+//     -- no LDS round trip, no cross-lane movement between the two GEMMs of the fused op;
+//   * the output tile O^T has e (head column) in registers as 4 groups of 4 consecutive e: float4 stores.
+// The backward runs both reductions in ONE launch: "row" workgroups own 32 queries (dQ, dBias), "column"
+// workgroups own 32 keys (dK, dV, tiles kept un-transposed so that a lane is a key); both recompute
+// dP = dO V^T on the matrix cores, so nothing but P (written once by the forward) is exchanged through memory.
+// A workgroup is 4 waves that split the tiles of the other dimension and combine their partial outputs in LDS.
+//
+// Mask semantics (quirks Q5/Q6): pair mask = valid(i) & valid(j); masked scores are set to -32768 (not -inf), so
+// fully padded query rows produce a uniform distribution over all N_max keys, as the reference.
 
 #include "ghn3_internal.h"
 
 #define ATT_DMAX 32
-#define ATT_WAVES 4
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-__device__ __forceinline__ float wave_max(float v) {
+__device__ __forceinline__ int acc_row(int r, int lhi) { return (r & 3) + 8 * (r >> 2) + 4 * lhi; }
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
-}
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
 }
 
-// Stage one head slice X[j][e] = src[j * row_stride + e] (j < N, e < d) into LDS with row stride lds_ld.
-__device__ __forceinline__ void stage_head(float* __restrict__ dst, const float* __restrict__ src, int N, int d,
-                                           int row_stride, int lds_ld, int tid) {
-    const int total = N * d;
-    constexpr int U = 8;
-    for (int b0 = tid; b0 < total; b0 += 256 * U) {
-        float v[U];
+// Row operand of the MFMA (lane = matrix row l31, k index = 2 s + lhi): x[s] = row[2 s + lhi] for 2 s + lhi < d.
+// vec: d % 4 == 0 and the row is 16-byte aligned -> d / 4 float4 loads (the two half-wave lanes of a row load the
+// same vectors and keep alternate elements).
+template <int KS>
+__device__ __forceinline__ void load_row_operand(const float* __restrict__ row, int d, int lhi, bool vec,
+                                                 float (&x)[KS]) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = b0 + u * 256;
-            const int j = idx / d, e = idx - j * d;
-            v[u] = idx < total ? src[(size_t)j * row_stride + e] : 0.f;
-        }
+    for (int s = 0; s < KS; ++s) x[s] = 0.f;
+    if (row == nullptr) return;
+    if (vec) {
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int idx = b0 + u * 256;
-            const int j = idx / d, e = idx - j * d;
-            if (idx < total) dst[j * lds_ld + e] = v[u];
+        for (int c = 0; c < KS / 2; ++c) {
+            if (4 * c < d) {
+                const f32x4 f = *reinterpret_cast<const f32x4*>(row + 4 * c);
+                x[2 * c] = lhi ? f.y : f.x;
+                x[2 * c + 1] = lhi ? f.w : f.z;
+            }
         }
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int k = 2 * s + lhi;
+            if (k < d) x[s] = row[k];
+        }
+    }
+}
+
+// Column operand (lane = head column e = l31, MFMA step s <-> matrix row acc_row(s, lhi) of the 32-row tile that
+// starts at row0): x[s] = X[(row0 + acc_row(s, lhi)) * stride + e]
+__device__ __forceinline__ void load_col_operand(const float* __restrict__ X, int row0, int n_rows, size_t stride,
+                                                 int e, int d, int lhi, float (&x)[16]) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) {
+        const int row = row0 + acc_row(s, lhi);
+        x[s] = (e < d && row < n_rows) ? X[(size_t)row * stride + e] : 0.f;
     }
 }
 
-// out[r][e] = sum_j Prow[r][j] * X[j][e] for the RW rows of this wave; lane = e + 32 * g, g = key parity.
-template <int RW>
-__device__ __forceinline__ void rows_times_matrix(const float* __restrict__ prow, int p_ld,
-                                                  const float* __restrict__ X, int x_ld, int N, int d, int lane,
-                                                  float (&out)[RW]) {
-    const int e = lane & 31, g = lane >> 5;
-    float acc[RW];
+template <int KS>
+__device__ __forceinline__ f32x16 mfma_rows(const float (&a)[KS], const float (&b)[KS], f32x16 acc) {
 #pragma unroll
-    for (int r = 0; r < RW; ++r) acc[r] = 0.f;
-    if (e < d) {
-        for (int j = g; j < N; j += 2) {
-            const float x = X[j * x_ld + e];
+    for (int s = 0; s < KS; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    return acc;
+}
+__device__ __forceinline__ f32x16 mfma_cols(const float (&a)[16], const f32x16& b, f32x16 acc) {
 #pragma unroll
-            for (int r = 0; r < RW; ++r) acc[r] += prow[r * p_ld + j] * x;
-        }
-    }
-#pragma unroll
-    for (int r = 0; r < RW; ++r) out[r] = acc[r] + __shfl_xor(acc[r], 32, 64);
+    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[s], b[s], acc, 0, 0, 0);
+    return acc;
 }
 
-template <int NT, int RW, int DT>
+// Sum the 4 waves' 32 x 32 partial tiles through LDS; wave w returns register group w (4 consecutive head columns
+// e = 8 w + 4 lhi + c of matrix column l31) of the total.
+__device__ __forceinline__ f32x4 reduce_waves(float* red /* [4][16][64] */, const f32x16& part, int w, int lane) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[(w * 16 + r) * 64 + lane] = part[r];
+    __syncthreads();
+    f32x4 o;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int r = 4 * w + c;
+        o[c] = red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane] + red[(48 + r) * 64 + lane];
+    }
+    return o;
+}
+
+// dst[e0 .. e0 + 3] = v (only e < d), vectorised when possible
+__device__ __forceinline__ void store4(float* __restrict__ dst, int e0, int d, bool vec, f32x4 v) {
+    if (vec && e0 + 3 < d) {
+        *reinterpret_cast<f32x4*>(dst + e0) = v;
+    } else {
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (e0 + c < d) dst[e0 + c] = v[c];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward: grid (ceil(N / 32), H, B), 256 threads; wave w owns key tiles w, w + 4, ... (TPW of them)
+// ------------------------------------------------------------------------------------------------
+template <int KS, int TPW>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, const float* __restrict__ qkv,
                                                        const float* __restrict__ bias, float* __restrict__ Psave,
                                                        const int* __restrict__ n_nodes, int N, int C, int H,
-                                                       float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int d = DT ? DT : C / H, ldk = d | 1;      // DT > 0: head dim known at compile time
-    float* KV = sm;                                   // N x ldk (K, later V)
-    float* Ps = sm + (size_t)N * ldk;                 // ATT_WAVES * RW rows of N (+1 pad)
-    const int p_ld = N + 1;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+                                                       float scale, int vec) {
+    __shared__ float red[4 * 16 * 64];
+    __shared__ float red_m[4][32], red_l[4][32];
+    const int d = C / H;
+    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int nb = n_nodes[b];
-    const float* base = qkv + (size_t)b * N * 3 * C;
+    const float* base = qkv + (size_t)b * N * 3 * C + h * d;
     const size_t bh = ((size_t)b * H + h) * N;
-    const int row0 = (blockIdx.x * ATT_WAVES + w) * RW;
-    float* myP = Ps + (size_t)w * RW * p_ld;
+    const int qi = i0 + l31;                                    // this lane's query
+    const bool vq = (d & 3) == 0 && vec;
 
-    stage_head(KV, base + C + h * d, N, d, 3 * C, ldk, tid);
-    __syncthreads();
-
+    float qb[KS];
+    load_row_operand<KS>(qi < N ? base + (size_t)qi * 3 * C : nullptr, d, lhi, vq, qb);
+    // PRE (N <= 256): every operand of the wave's tiles is loaded up front (all loads in flight at once, V^T
+    // during the softmax); larger N keeps only the score tiles in registers and loads operands per tile.
+    constexpr bool PRE = TPW <= 2;
+    constexpr int TP = PRE ? TPW : 1;
+    float ka[TP][KS];
+    if (PRE) {
 #pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        const int i = row0 + r;
-        if (i < N) {
-            float q[ATT_DMAX];
-#pragma unroll
-            for (int e = 0; e < ATT_DMAX; ++e) q[e] = (e < d) ? base[(size_t)i * 3 * C + h * d + e] : 0.f;
-            float bv[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int j = lane + 64 * t;
-                bv[t] = (bias && j < N) ? bias[(bh + i) * N + j] : 0.f;
-            }
-            float p[NT];
-            float mx = -INFINITY;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int j = lane + 64 * t;
-                float s = -INFINITY;
-                if (j < N) {
-                    s = 0.f;
-                    const float* kr = KV + j * ldk;
-#pragma unroll
-                    for (int e = 0; e < ATT_DMAX; ++e)
-                        if (e < d) s += q[e] * kr[e];
-                    s = s * scale + bv[t];
-                    if (!(i < nb && j < nb)) s = -32768.f;
-                }
-                p[t] = s;
-                mx = fmaxf(mx, s);
-            }
-            mx = wave_max(mx);
-            float sum = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int j = lane + 64 * t;
-                const float e_ = (j < N) ? __expf(p[t] - mx) : 0.f;
-                p[t] = e_;
-                sum += e_;
-            }
-            sum = wave_sum(sum);
-            const float inv = 1.f / sum;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int j = lane + 64 * t;
-                if (j < N) {
-                    const float pv = p[t] * inv;
-                    myP[r * p_ld + j] = pv;
-                    if (Psave) Psave[(bh + i) * N + j] = pv;
-                }
-            }
-        } else {
-            for (int j = lane; j < N; j += 64) myP[r * p_ld + j] = 0.f;
+        for (int k = 0; k < TP; ++k) {
+            const int j = (w + 4 * k) * 32 + l31;
+            load_row_operand<KS>(j < N ? base + (size_t)j * 3 * C + C : nullptr, d, lhi, vq, ka[k]);
         }
     }
-    __syncthreads();
-    stage_head(KV, base + 2 * C + h * d, N, d, 3 * C, ldk, tid);
-    __syncthreads();
-    float o[RW];
-    rows_times_matrix<RW>(myP, p_ld, KV, ldk, N, d, lane, o);
-    if (lane < d) {
+    // edge bias of this lane's query row: register r <-> key tile * 32 + acc_row(r, lhi) (4 runs of 4 keys)
+    f32x16 S[TPW];
+    const bool pvec = (N & 3) == 0 && vec;
 #pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            const int i = row0 + r;
-            if (i < N) out[((size_t)b * N + i) * C + h * d + lane] = o[r];
+    for (int k = 0; k < TPW; ++k) {
+        S[k] = zero16();
+        const int j0 = (w + 4 * k) * 32;
+        if (bias && qi < N && j0 < N) {
+            const float* brow = bias + (bh + qi) * N + j0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int jj = 8 * g + 4 * lhi;
+                if (pvec && j0 + jj + 3 < N) {
+                    const f32x4 f = *reinterpret_cast<const f32x4*>(brow + jj);
+                    S[k][4 * g] = f.x; S[k][4 * g + 1] = f.y; S[k][4 * g + 2] = f.z; S[k][4 * g + 3] = f.w;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (j0 + jj + c < N) S[k][4 * g + c] = brow[jj + c];
+                }
+            }
         }
     }
+    // V^T operands are independent of the softmax: issue their loads now
+    float va[TP][16];
+    if (PRE) {
+#pragma unroll
+        for (int k = 0; k < TP; ++k)
+            load_col_operand(base + 2 * C, (w + 4 * k) * 32, N, (size_t)3 * C, l31, d, lhi, va[k]);
+    }
+
+    float mx = -INFINITY;
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        const f32x16 bia = S[k];
+        const int j0 = (w + 4 * k) * 32;
+        if (!PRE) {
+            const int j = j0 + l31;
+            load_row_operand<KS>(j < N ? base + (size_t)j * 3 * C + C : nullptr, d, lhi, vq, ka[0]);
+        }
+        f32x16 acc = mfma_rows<KS>(ka[PRE ? k : 0], qb, zero16());
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int j = j0 + acc_row(r, lhi);
+            float s = acc[r] * scale + bia[r];
+            if (!(qi < nb && j < nb)) s = -32768.f;
+            if (j >= N) s = -INFINITY;
+            acc[r] = s;
+            mx = fmaxf(mx, s);
+        }
+        S[k] = acc;
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    if (lhi == 0) red_m[w][l31] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red_m[0][l31], red_m[1][l31]), fmaxf(red_m[2][l31], red_m[3][l31]));
+    float sum = 0.f;
+#pragma unroll
+    for (int k = 0; k < TPW; ++k)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const float e_ = __expf(S[k][r] - mx);               // exp(-inf) = 0 for keys beyond N
+            S[k][r] = e_;
+            sum += e_;
+        }
+    sum += __shfl_xor(sum, 32, 64);
+    if (lhi == 0) red_l[w][l31] = sum;
+    __syncthreads();
+    const float inv = 1.f / (red_l[0][l31] + red_l[1][l31] + red_l[2][l31] + red_l[3][l31]);
+    f32x16 O = zero16();
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        const int j0 = (w + 4 * k) * 32;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) S[k][r] *= inv;
+        if (Psave && qi < N && j0 < N) {
+            float* prow = Psave + (bh + qi) * N + j0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int jj = 8 * g + 4 * lhi;
+                if (pvec && j0 + jj + 3 < N) {
+                    f32x4 f = {S[k][4 * g], S[k][4 * g + 1], S[k][4 * g + 2], S[k][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(prow + jj) = f;
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (j0 + jj + c < N) prow[jj + c] = S[k][4 * g + c];
+                }
+            }
+        }
+        if (!PRE && j0 < N) load_col_operand(base + 2 * C, j0, N, (size_t)3 * C, l31, d, lhi, va[0]);
+        if (j0 < N) O = mfma_cols(va[PRE ? k : 0], S[k], O);       // O^T += V^T P^T
+    }
+    const f32x4 o = reduce_waves(red, O, w, lane);
+    if (qi < N) store4(out + ((size_t)b * N + qi) * C + h * d, 8 * w + 4 * lhi, d, vq, o);
 }
 
 // ------------------------------------------------------------------------------------------------
-// backward, pass 1 (row-wise): dP = dO V^T ; dS = P * (dP - rowsum(P*dP)) with masked entries zeroed ;
-// dQ = scale * dS K ; dBias += dS ; dS stored for pass 2.
+// backward: grid (2 * ceil(N / 32), H, B); blockIdx.x < NB: row role (32 queries: dQ, dBias += dS),
+// otherwise column role (32 keys: dK, dV).  delta_i = sum_e dO[i][e] O[i][e] (= rowsum(P * dP)).
 // ------------------------------------------------------------------------------------------------
-template <int NT, int RW, int DT>
-__global__ __launch_bounds__(256) void attn_bwd_rows_kernel(float* __restrict__ dqkv, const float* __restrict__ dO,
-                                                            const float* __restrict__ qkv,
-                                                            const float* __restrict__ P, float* __restrict__ dS,
-                                                            float* __restrict__ dBias,
-                                                            const int* __restrict__ n_nodes, int N, int C, int H,
-                                                            float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int d = DT ? DT : C / H, ldk = d | 1;
-    float* Ks = sm;
-    float* Vs = sm + (size_t)N * ldk;
-    float* Ds = Vs + (size_t)N * ldk;                 // ATT_WAVES * RW rows of dS
-    const int p_ld = N + 1;
+template <int KS>
+__global__ __launch_bounds__(256) void attn_bwd_kernel(float* __restrict__ dqkv, const float* __restrict__ dO,
+                                                       const float* __restrict__ qkv, const float* __restrict__ P,
+                                                       const float* __restrict__ Oin, float* __restrict__ dBias,
+                                                       const int* __restrict__ n_nodes, int N, int C, int H,
+                                                       float scale, int vec) {
+    __shared__ float red[4 * 16 * 64];
+    __shared__ float red2[4 * 16 * 64];
+    __shared__ float dl[4][32];
+    const int d = C / H;
+    const int NB = (N + 31) >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int nb = n_nodes[b];
-    const float* base = qkv + (size_t)b * N * 3 * C;
+    const float* base = qkv + (size_t)b * N * 3 * C + h * d;
+    const float* dOb = dO + (size_t)b * N * C + h * d;
+    const float* Ob = Oin + (size_t)b * N * C + h * d;
     const size_t bh = ((size_t)b * H + h) * N;
-    const int row0 = (blockIdx.x * ATT_WAVES + w) * RW;
-    float* myD = Ds + (size_t)w * RW * p_ld;
-    stage_head(Ks, base + C + h * d, N, d, 3 * C, ldk, tid);
-    stage_head(Vs, base + 2 * C + h * d, N, d, 3 * C, ldk, tid);
-    __syncthreads();
-#pragma unroll
-    for (int r = 0; r < RW; ++r) {
-        const int i = row0 + r;
-        if (i < N) {
-            float g[ATT_DMAX];
-#pragma unroll
-            for (int e = 0; e < ATT_DMAX; ++e) g[e] = (e < d) ? dO[((size_t)b * N + i) * C + h * d + e] : 0.f;
-            float pr[NT], dp[NT];
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int j = lane + 64 * t;
-                pr[t] = (j < N) ? P[(bh + i) * N + j] : 0.f;
-            }
-            float delta = 0.f;
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int j = lane + 64 * t;
-                float dv = 0.f;
-                if (j < N) {
-                    const float* vr = Vs + j * ldk;
-#pragma unroll
-                    for (int e = 0; e < ATT_DMAX; ++e)
-                        if (e < d) dv += g[e] * vr[e];
-                }
-                dp[t] = dv;
-                delta += pr[t] * dv;
-            }
-            delta = wave_sum(delta);
-#pragma unroll
-            for (int t = 0; t < NT; ++t) {
-                const int j = lane + 64 * t;
-                if (j < N) {
-                    float ds = pr[t] * (dp[t] - delta);
-                    if (!(i < nb && j < nb)) ds = 0.f;          // masked_fill blocks the gradient
-                    myD[r * p_ld + j] = ds;
-                    dS[(bh + i) * N + j] = ds;
-                    if (dBias) dBias[(bh + i) * N + j] += ds;
-                }
-            }
-        } else {
-            for (int j = lane; j < N; j += 64) myD[r * p_ld + j] = 0.f;
-        }
-    }
-    // wave-local LDS hand-off (each wave reads back only its own rows)
-    __syncthreads();
-    float dq[RW];
-    rows_times_matrix<RW>(myD, p_ld, Ks, ldk, N, d, lane, dq);
-    if (lane < d) {
-#pragma unroll
-        for (int r = 0; r < RW; ++r) {
-            const int i = row0 + r;
-            if (i < N) dqkv[((size_t)b * N + i) * 3 * C + h * d + lane] = dq[r] * scale;
-        }
-    }
-}
+    const bool vq = (d & 3) == 0 && vec;
+    const bool pvec = (N & 3) == 0 && vec;
 
-// backward, pass 2 (column-wise, one key per lane): dV[j] = sum_i P[i][j] dO[i] ; dK[j] = scale sum_i dS[i][j] Q[i].
-// A block owns 64 keys; its 16 waves split the query rows (4 rows per step, loads batched) and combine their
-// partial sums with LDS float atomics.
-#define COLS_WAVES 16
-template <int DT>
-__global__ __launch_bounds__(1024) void attn_bwd_cols_kernel(float* __restrict__ dqkv, const float* __restrict__ dO,
-                                                             const float* __restrict__ qkv,
-                                                             const float* __restrict__ P, const float* __restrict__ dS,
-                                                             int N, int C, int H, float scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    const int d = DT ? DT : C / H;
-    float* Qs = sm;                       // N x d   (row-broadcast reads)
-    float* Gs = sm + (size_t)N * d;       // N x d   dO
-    float* red = Gs + (size_t)N * d;      // 64 lanes x (2d+1)
-    const int ld2 = 2 * d + 1;
-    const int b = blockIdx.z, h = blockIdx.y;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const float* base = qkv + (size_t)b * N * 3 * C;
-    const size_t bh = ((size_t)b * H + h) * N;
-    {
-        const int total = N * d;
-        for (int idx = tid; idx < total; idx += 1024) {
-            const int i = idx / d, e = idx - i * d;
-            Qs[idx] = base[(size_t)i * 3 * C + h * d + e];
-            Gs[idx] = dO[((size_t)b * N + i) * C + h * d + e];
-        }
-        for (int idx = tid; idx < 64 * ld2; idx += 1024) red[idx] = 0.f;
-    }
-    __syncthreads();
-    const int j = blockIdx.x * 64 + lane;
-    float dv[ATT_DMAX], dk[ATT_DMAX];
+    if ((int)blockIdx.x < NB) {
+        // ---------------- row role: lane = query qi, accumulator registers = keys ----------------
+        const int qi = blockIdx.x * 32 + l31;
+        float gb[KS], ob[KS];
+        load_row_operand<KS>(qi < N ? dOb + (size_t)qi * C : nullptr, d, lhi, vq, gb);
+        load_row_operand<KS>(qi < N ? Ob + (size_t)qi * C : nullptr, d, lhi, vq, ob);
+        float delta = 0.f;
 #pragma unroll
-    for (int e = 0; e < ATT_DMAX; ++e) { dv[e] = 0.f; dk[e] = 0.f; }
-    if (j < N) {
-        constexpr int U = 4;
-        for (int i0 = w * U; i0 < N; i0 += COLS_WAVES * U) {
-            float pv[U], ds[U];
+        for (int s = 0; s < KS; ++s) delta += gb[s] * ob[s];
+        delta += __shfl_xor(delta, 32, 64);
+        f32x16 dQ = zero16();
+        for (int t = w; t < NB; t += 4) {
+            const int j0 = t * 32;
+            float va[KS];
+            const int j = j0 + l31;
+            load_row_operand<KS>(j < N ? base + (size_t)j * 3 * C + 2 * C : nullptr, d, lhi, vq, va);
+            float kc[16];
+            load_col_operand(base + C, j0, N, (size_t)3 * C, l31, d, lhi, kc);
+            f32x16 p = zero16(), db = zero16();
+            if (qi < N) {
+                const float* prow = P + (bh + qi) * N + j0;
+                const float* brow = dBias ? dBias + (bh + qi) * N + j0 : nullptr;
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = i0 + u;
-                pv[u] = (i < N) ? P[(bh + i) * N + j] : 0.f;
-                ds[u] = (i < N) ? dS[(bh + i) * N + j] : 0.f;
+                for (int g = 0; g < 4; ++g) {
+                    const int jj = 8 * g + 4 * lhi;
+                    if (pvec && j0 + jj + 3 < N) {
+                        const f32x4 f = *reinterpret_cast<const f32x4*>(prow + jj);
+                        p[4 * g] = f.x; p[4 * g + 1] = f.y; p[4 * g + 2] = f.z; p[4 * g + 3] = f.w;
+                        if (brow) {
+                            const f32x4 q = *reinterpret_cast<const f32x4*>(brow + jj);
+                            db[4 * g] = q.x; db[4 * g + 1] = q.y; db[4 * g + 2] = q.z; db[4 * g + 3] = q.w;
+                        }
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (j0 + jj + c < N) {
+                                p[4 * g + c] = prow[jj + c];
+                                if (brow) db[4 * g + c] = brow[jj + c];
+                            }
+                    }
+                }
             }
+            f32x16 ds = mfma_rows<KS>(va, gb, zero16());           // dP^T = V dO^T
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int i = min(i0 + u, N - 1);
-                const float* qr = Qs + i * d;
-                const float* gr = Gs + i * d;
-#pragma unroll
-                for (int e = 0; e < ATT_DMAX; ++e)
-                    if (e < d) { dv[e] += pv[u] * gr[e]; dk[e] += ds[u] * qr[e]; }
+            for (int r = 0; r < 16; ++r) {
+                const int jr = j0 + acc_row(r, lhi);
+                float x = p[r] * (ds[r] - delta);
+                if (!(qi < nb && jr < nb)) x = 0.f;               // masked_fill blocks the gradient
+                ds[r] = x;
             }
-        }
-        float* my = red + (size_t)lane * ld2;
+            if (dBias && qi < N) {
+                float* brow = dBias + (bh + qi) * N + j0;
 #pragma unroll
-        for (int e = 0; e < ATT_DMAX; ++e)
-            if (e < d) { atomicAdd(&my[e], dv[e]); atomicAdd(&my[d + e], dk[e]); }
-    }
-    __syncthreads();
-    for (int idx = tid; idx < 64 * 2 * d; idx += 1024) {
-        const int l = idx / (2 * d), c = idx - l * (2 * d);
-        const int jj = blockIdx.x * 64 + l;
-        if (jj < N) {
-            const float s_ = red[(size_t)l * ld2 + c];
-            if (c < d) dqkv[((size_t)b * N + jj) * 3 * C + 2 * C + h * d + c] = s_;            // dV
-            else dqkv[((size_t)b * N + jj) * 3 * C + C + h * d + (c - d)] = s_ * scale;          // dK
+                for (int g = 0; g < 4; ++g) {
+                    const int jj = 8 * g + 4 * lhi;
+                    if (pvec && j0 + jj + 3 < N) {
+                        f32x4 f = {db[4 * g] + ds[4 * g], db[4 * g + 1] + ds[4 * g + 1], db[4 * g + 2] + ds[4 * g + 2],
+                                   db[4 * g + 3] + ds[4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(brow + jj) = f;
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (j0 + jj + c < N) brow[jj + c] = db[4 * g + c] + ds[4 * g + c];
+                    }
+                }
+            }
+            dQ = mfma_cols(kc, ds, dQ);                            // dQ^T += K^T dS^T
+        }
+        f32x4 o = reduce_waves(red, dQ, w, lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] *= scale;
+        if (qi < N) store4(dqkv + ((size_t)b * N + qi) * 3 * C + h * d, 8 * w + 4 * lhi, d, vq, o);
+    } else {
+        // ---------------- column role: lane = key kj, accumulator registers = queries ----------------
+        const int kj = (blockIdx.x - NB) * 32 + l31;
+        float vb[KS];
+        load_row_operand<KS>(kj < N ? base + (size_t)kj * 3 * C + 2 * C : nullptr, d, lhi, vq, vb);
+        f32x16 dV = zero16(), dK = zero16();
+        for (int t = w; t < NB; t += 4) {
+            const int q0 = t * 32;
+            const int qrow = q0 + l31;
+            float ga[KS], oa[KS];
+            load_row_operand<KS>(qrow < N ? dOb + (size_t)qrow * C : nullptr, d, lhi, vq, ga);
+            load_row_operand<KS>(qrow < N ? Ob + (size_t)qrow * C : nullptr, d, lhi, vq, oa);
+            float gc[16], qc[16];
+            load_col_operand(dOb, q0, N, (size_t)C, l31, d, lhi, gc);
+            load_col_operand(base, q0, N, (size_t)3 * C, l31, d, lhi, qc);
+            f32x16 p;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int i = q0 + acc_row(r, lhi);
+                p[r] = (i < N && kj < N) ? P[(bh + i) * N + kj] : 0.f;
+            }
+            float dpart = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) dpart += ga[s] * oa[s];
+            dpart += __shfl_xor(dpart, 32, 64);
+            if (lhi == 0) dl[w][l31] = dpart;                      // wave-private hand-off: lane -> register index
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            f32x16 ds = mfma_rows<KS>(ga, vb, zero16());           // dP = dO V^T   (rows = queries, lane = key)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ir = acc_row(r, lhi);
+                float x = p[r] * (ds[r] - dl[w][ir]);
+                if (!(q0 + ir < nb && kj < nb)) x = 0.f;
+                ds[r] = x;
+            }
+            __builtin_amdgcn_wave_barrier();
+            dV = mfma_cols(gc, p, dV);                             // dV^T += dO^T P
+            dK = mfma_cols(qc, ds, dK);                            // dK^T += Q^T dS
+        }
+        const f32x4 ov = reduce_waves(red, dV, w, lane);
+        f32x4 ok = reduce_waves(red2, dK, w, lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) ok[c] *= scale;
+        if (kj < N) {
+            float* row = dqkv + ((size_t)b * N + kj) * 3 * C + h * d;
+            store4(row + 2 * C, 8 * w + 4 * lhi, d, vq, ov);
+            store4(row + C, 8 * w + 4 * lhi, d, vq, ok);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-typedef void (*attn_fwd_fn)(float*, const float*, const float*, float*, const int*, int, int, int, float);
-typedef void (*attn_bwd_fn)(float*, const float*, const float*, const float*, float*, float*, const int*, int, int,
-                            int, float);
-static const int kMaxLds = 160 * 1024;
+typedef void (*attn_fwd_fn)(float*, const float*, const float*, float*, const int*, int, int, int, float, int);
+typedef void (*attn_bwd_fn)(float*, const float*, const float*, const float*, const float*, float*, const int*, int,
+                            int, int, float, int);
 
-typedef void (*attn_cols_fn)(float*, const float*, const float*, const float*, const float*, int, int, int, float);
-struct AttnCfg { attn_fwd_fn fwd; attn_bwd_fn bwd; attn_cols_fn cols; int rw; };
-
-template <int DT> static AttnCfg pick_n(int N) {
-    if (N <= 256) return {attn_fwd_kernel<4, 4, DT>, attn_bwd_rows_kernel<4, 4, DT>, attn_bwd_cols_kernel<DT>, 4};
-    if (N <= 512) return {attn_fwd_kernel<8, 4, DT>, attn_bwd_rows_kernel<8, 4, DT>, attn_bwd_cols_kernel<DT>, 4};
-    return {attn_fwd_kernel<16, 2, DT>, attn_bwd_rows_kernel<16, 2, DT>, attn_bwd_cols_kernel<DT>, 2};
+template <int KS> static attn_fwd_fn fwd_for(int tpw) {
+    return tpw <= 2 ? (attn_fwd_fn)attn_fwd_kernel<KS, 2> : (attn_fwd_fn)attn_fwd_kernel<KS, 8>;
 }
-static AttnCfg pick(int N, int d) {
-    switch (d) {                      // head dims of the released GHN-3 models: 8 (T, S), 16 (L), 24 (XL)
-    case 8: return pick_n<8>(N);
-    case 16: return pick_n<16>(N);
-    case 24: return pick_n<24>(N);
-    default: return pick_n<0>(N);
-    }
+static attn_fwd_fn pick_fwd(int d, int tpw) {
+    if (d <= 4) return fwd_for<2>(tpw);
+    if (d <= 8) return fwd_for<4>(tpw);                 // released GHN-3 head dims: 8 (T, S), 16 (L), 24 (XL)
+    if (d <= 16) return fwd_for<8>(tpw);
+    if (d <= 24) return fwd_for<12>(tpw);
+    return fwd_for<16>(tpw);
 }
-
-template <int DT> static int set_attrs() {
-    const void* fns[] = {(const void*)attn_fwd_kernel<4, 4, DT>, (const void*)attn_fwd_kernel<8, 4, DT>,
-                         (const void*)attn_fwd_kernel<16, 2, DT>, (const void*)attn_bwd_rows_kernel<4, 4, DT>,
-                         (const void*)attn_bwd_rows_kernel<8, 4, DT>, (const void*)attn_bwd_rows_kernel<16, 2, DT>,
-                         (const void*)attn_bwd_cols_kernel<DT>};
-    for (const void* f : fns) {
-        hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, kMaxLds);
-        if (e != hipSuccess) { ghn3_set_error("attn hipFuncSetAttribute: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
-    }
-    return GHN3_OK;
+static attn_bwd_fn pick_bwd(int d) {
+    if (d <= 4) return attn_bwd_kernel<2>;
+    if (d <= 8) return attn_bwd_kernel<4>;
+    if (d <= 16) return attn_bwd_kernel<8>;
+    if (d <= 24) return attn_bwd_kernel<12>;
+    return attn_bwd_kernel<16>;
 }
 
-int ghn3_attn_init() {
-    int rc = set_attrs<0>();
-    if (!rc) rc = set_attrs<8>();
-    if (!rc) rc = set_attrs<16>();
-    if (!rc) rc = set_attrs<24>();
-    return rc;
-}
+int ghn3_attn_init() { return GHN3_OK; }
 
 static int check_dims(int N, int C, int H) {
     if (H <= 0 || C % H != 0 || C / H > ATT_DMAX) {
@@ -368,19 +423,18 @@ static int check_dims(int N, int C, int H) {
     if (N > 1024 || N <= 0) { ghn3_set_error("attention: N=%d outside [1,1024]", N); return GHN3_E_LIMIT; }
     return GHN3_OK;
 }
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 int ghn3_attn_fwd(float* out, const float* qkv, const float* bias, float* P, const int* n_nodes, int B, int N, int C,
                   int H, hipStream_t s) {
     int rc = check_dims(N, C, H);
     if (rc) return rc;
-    const int d = C / H, ldk = d | 1;
-    const AttnCfg cfg = pick(N, d);
-    const size_t lds = ((size_t)N * ldk + (size_t)ATT_WAVES * cfg.rw * (N + 1)) * sizeof(float);
-    if (lds > (size_t)kMaxLds) { ghn3_set_error("attention fwd: LDS %zu too large (N=%d d=%d)", lds, N, d); return GHN3_E_LIMIT; }
+    const int d = C / H;
     const float scale = 1.0f / sqrtf((float)d);
-    const int rpb = ATT_WAVES * cfg.rw;
-    dim3 grid((N + rpb - 1) / rpb, H, B);
-    hipLaunchKernelGGL(cfg.fwd, grid, dim3(256), lds, s, out, qkv, bias, P, n_nodes, N, C, H, scale);
+    const int nb = (N + 31) / 32, tpw = (nb + 3) / 4;
+    const int vec = (C % 4 == 0) && aligned16(out) && aligned16(qkv) && aligned16(bias) && aligned16(P);
+    hipLaunchKernelGGL(pick_fwd(d, tpw), dim3(nb, H, B), dim3(256), 0, s, out, qkv, bias, P, n_nodes, N, C, H, scale,
+                       vec);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("attn fwd launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;
@@ -388,23 +442,17 @@ int ghn3_attn_fwd(float* out, const float* qkv, const float* bias, float* P, con
 
 int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P, const float* O, float* dS,
                   float* dBias, const int* n_nodes, int B, int N, int C, int H, hipStream_t s) {
-    (void)O;
+    (void)dS;                                  // (scratch of the former two-pass backward; unused)
     int rc = check_dims(N, C, H);
     if (rc) return rc;
-    const int d = C / H, ldk = d | 1;
-    const AttnCfg cfg = pick(N, d);
+    if (!P || !O) { ghn3_set_error("attention bwd: needs the saved probabilities and outputs"); return GHN3_E_ARG; }
+    const int d = C / H;
     const float scale = 1.0f / sqrtf((float)d);
-    const size_t lds1 = ((size_t)2 * N * ldk + (size_t)ATT_WAVES * cfg.rw * (N + 1)) * sizeof(float);
-    const size_t lds2 = ((size_t)2 * N * d + 64 * (2 * d + 1)) * sizeof(float);
-    if (lds1 > (size_t)kMaxLds || lds2 > (size_t)kMaxLds) {
-        ghn3_set_error("attention bwd: LDS %zu/%zu too large (N=%d d=%d)", lds1, lds2, N, d);
-        return GHN3_E_LIMIT;
-    }
-    const int rpb = ATT_WAVES * cfg.rw;
-    dim3 grid((N + rpb - 1) / rpb, H, B);
-    hipLaunchKernelGGL(cfg.bwd, grid, dim3(256), lds1, s, dqkv, dO, qkv, P, dS, dBias, n_nodes, N, C, H, scale);
-    dim3 grid2((N + 63) / 64, H, B);
-    hipLaunchKernelGGL(cfg.cols, grid2, dim3(1024), lds2, s, dqkv, dO, qkv, P, dS, N, C, H, scale);
+    const int nb = (N + 31) / 32;
+    const int vec = (C % 4 == 0) && aligned16(dqkv) && aligned16(dO) && aligned16(qkv) && aligned16(P) &&
+                    aligned16(O) && aligned16(dBias);
+    hipLaunchKernelGGL(pick_bwd(d), dim3(2 * nb, H, B), dim3(256), 0, s, dqkv, dO, qkv, P, O, dBias, n_nodes, N, C, H,
+                       scale, vec);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("attn bwd launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

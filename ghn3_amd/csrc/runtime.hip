@@ -53,6 +53,10 @@ struct ghn3_ctx {
     size_t pool_used;                  // pairs in use
     double tag_ms[256];
     int64_t tag_n[256];
+    // side stream for ops flagged GHN3_OPFLAG_SIDE (work off the critical path of a program)
+    hipStream_t side;
+    hipEvent_t ev_fork, ev_join;
+    bool side_enabled;
 };
 
 static int ctx_reserve(ghn3_ctx* c, size_t n) {
@@ -82,6 +86,10 @@ extern "C" int ghn3_ctx_create(ghn3_ctx** out) {
     for (int i = 0; i < kStageSlots; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->pe0));
     HIPCHK(hipEventCreate(&c->pe1));
+    HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    c->side_enabled = !(getenv("GHN3_NO_SIDE_STREAM") && atoi(getenv("GHN3_NO_SIDE_STREAM")) != 0);
     int rc = ghn3_gemm_init();
     if (rc) return rc;
     rc = ghn3_attn_init();
@@ -102,6 +110,10 @@ extern "C" void ghn3_ctx_destroy(ghn3_ctx* c) {
     }
     hipEventDestroy(c->pe0);
     hipEventDestroy(c->pe1);
+    hipStreamSynchronize(c->side);
+    hipStreamDestroy(c->side);
+    hipEventDestroy(c->ev_fork);
+    hipEventDestroy(c->ev_join);
     for (hipEvent_t e : *c->pool) hipEventDestroy(e);
     delete c->pool;
     delete c->pool_tag;
@@ -297,10 +309,36 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
     }
 
     // ---- 2. launch ops in order ------------------------------------------------------------------
+    // Two-stream execution.  Ops flagged GHN3_OPFLAG_SIDE run on the context's side stream: before such an op the
+    // side stream waits for everything the main stream has been given so far (program order = dependency order);
+    // the main stream waits for the side stream at GHN3_OP_JOIN and at the end of the run.
+    hipStream_t const main_stream = stream;
+    bool main_dirty = true, side_dirty = false;
+    auto join = [&]() -> int {
+        if (side_dirty) {
+            HIPCHK(hipEventRecord(c->ev_join, c->side));
+            HIPCHK(hipStreamWaitEvent(main_stream, c->ev_join, 0));
+            side_dirty = false;
+        }
+        return GHN3_OK;
+    };
     for (int k = 0; k < n_ops; ++k) {
         const ghn3_op& o = ops[k];
         int rc = GHN3_OK;
         R.bad = false;
+        const bool on_side = (o.flags & GHN3_OPFLAG_SIDE) && c->side_enabled && c->profile != 1;
+        if (o.kind == GHN3_OP_JOIN) { rc = join(); if (rc) return rc; continue; }
+        if (on_side) {
+            if (main_dirty) {
+                HIPCHK(hipEventRecord(c->ev_fork, main_stream));
+                HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
+                main_dirty = false;
+            }
+            side_dirty = true;
+        } else {
+            main_dirty = true;
+        }
+        hipStream_t stream = on_side ? c->side : main_stream;
         const bool timed = c->profile == 2 && (o.flags & GHN3_OPFLAG_TIMED);
         if (c->profile == 1) HIPCHK(hipEventRecord(c->pe0, stream));
         if (timed) {
@@ -461,7 +499,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             c->launches[o.kind] += 1;
         }
     }
-    return GHN3_OK;
+    return join();
 }
 
 // ---- timing helpers -----------------------------------------------------------------------------

@@ -113,6 +113,8 @@ class GHN3(nn.Module):
                    The Graphormer and the small heads always run exact fp32.
       compute_bwd  operand type of the W2 backward GEMMs in 16-bit mode (default: 'bf16' -- the upstream
                    gradients are too small for f16's range)
+      side_stream  True (default): weight gradients, LayerNorm parameter gradients and operand copies overlap with
+                   the dependent chain of the program on a second HIP stream
       direct16     True (default): in 16-bit mode the W2 GEMMs read per-step 16-bit operand copies (GHN3_OP_CAST16)
                    through the LDS-DMA kernel; False: fp32 operands converted while staged
     """
@@ -133,6 +135,7 @@ class GHN3(nn.Module):
         self.compute = kwargs.pop('compute', 'f32')
         self.compute_bwd = kwargs.pop('compute_bwd', None)
         self.direct16 = kwargs.pop('direct16', True)
+        self.side_stream = kwargs.pop('side_stream', True)
         assert not kwargs, 'unknown arguments %s' % list(kwargs)
         if not self.weight_norm or not self.layernorm:
             raise NotImplementedError('weight_norm=False / layernorm=False are not supported '
@@ -234,7 +237,7 @@ class GHN3(nn.Module):
                        predict_class_layers=predict_class_layers, reduce_graph=reduce_graph,
                        layernorm=self.layernorm, decoder_ctype=L.COMPUTE_TYPES[self.compute],
                        decoder_bwd_ctype=L.COMPUTE_TYPES[self.compute_bwd] if self.compute_bwd else None,
-                       direct16=self.direct16)
+                       direct16=self.direct16, side_stream=self.side_stream)
         plan = _Plan(self, prog, graphs.edges, nets)
         plan.graphs = graphs
         return plan
@@ -379,7 +382,7 @@ def from_pretrained(ghn3_name='ghn3xlm16.pt', **kwargs):
         state_dict = joblib.load(hf_hub_download(repo_id='SamsungSAILMontreal/ghn3', filename=ghn3_name))
     if any(k.find('gnn.gru.') >= 0 for k in state_dict):
         raise NotImplementedError('GHN-2 checkpoints are not supported')
-    extra = {k: kwargs.pop(k) for k in ('index_mode', 'compute', 'compute_bwd', 'direct16', 'debug_level')
+    extra = {k: kwargs.pop(k) for k in ('index_mode', 'compute', 'compute_bwd', 'direct16', 'side_stream', 'debug_level')
              if k in kwargs}
     if ghn_config is None:
         num_classes = kwargs.pop('num_classes', 10)

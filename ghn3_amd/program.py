@@ -55,8 +55,12 @@ class Program:
 
     def __init__(self, cfg, node_infos, n_nodes, node_types, max_edge, nets, index_mode='reference',
                  training=True, predict_class_layers=True, reduce_graph=False, layernorm=True, decoder_ctype=None,
-                 decoder_bwd_ctype=None, direct16=True):
+                 decoder_bwd_ctype=None, direct16=True, side_stream=True):
         self.cfg = cfg
+        # side_stream: weight-gradient GEMMs, LayerNorm parameter gradients and operand copies (everything off the
+        # dependent chain of the program) carry GHN3_OPFLAG_SIDE and overlap with the chain on a second stream;
+        # the temporaries they read are then per-layer buffers instead of reused ones.
+        self.SIDE = L.OPFLAG_SIDE if side_stream else 0
         # MFMA operand type of the decoder GEMMs (fc / W0 / W2, forward and backward): None = context default.
         # The Graphormer, the edge MLP and the small heads always multiply in exact fp32.
         self.decoder_ctype = decoder_ctype
@@ -154,7 +158,7 @@ class Program:
     def href(self, off_halfs):
         return (self.xbuf(self.X_WS), 2 * int(off_halfs))
 
-    def cast16(self, src_base, items, dbias=None):
+    def cast16(self, src_base, items, dbias=None, flags=0):
         """One GHN3_OP_CAST16 over `items` = dicts(src_off [floats from src_base], rows, cols, ld_src,
         straight=(off_halfs, ld, ctype) | None, transposed=(off_halfs, ld, ctype) | None, colsum=(q, s) | None)."""
         descs = np.zeros(len(items), dtype=L.CAST_DT)
@@ -182,7 +186,8 @@ class Program:
             blocks += ((it['rows'] + 63) // 64) * ((it['cols'] + 63) // 64)
         if blocks:
             self.op(L.OP_CAST16, refs=(src_base, (self.xbuf(self.X_WS), 0), self.idx(descs),
-                                       dbias if dbias is not None else self.NONE), ints=(len(items), blocks))
+                                       dbias if dbias is not None else self.NONE), ints=(len(items), blocks),
+                    flags=flags)
 
     def idx(self, arr):
         raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
@@ -244,13 +249,15 @@ class Program:
     TAG_NAMES = {1: 'w2_fwd', 2: 'w2_dgrad', 3: 'w2_wgrad', 4: 'w0_fwd', 5: 'fc_fwd', 6: 'tile_fwd', 7: 'tile_bwd',
                  8: 'w0_bwd', 9: 'fc_bwd'}
 
-    def gemm_op(self, first, count=None, tile=0, ctype=None, tag=0):
+    def gemm_op(self, first, count=None, tile=0, ctype=None, tag=0, side=False):
         if count is None:
             count = len(self._probs) - first
         if count > 0:
             if tag and ctype is None:
                 ctype = self.decoder_ctype
             flags = 0 if ctype is None else 1 + ctype
+            if side:
+                flags |= self.SIDE
             if tag:
                 flags |= L.OPFLAG_TIMED | (tag << 16)
                 fl = sum(2.0 * int(p['M']) * int(p['N']) * int(p['K']) for p in self._probs[first:first + count])
@@ -360,6 +367,25 @@ class Program:
         self.n1_clsb = self.n1 - self.n1_plain
         self.oned_src = np.asarray(rows, dtype=np.int32)
 
+    def _cast_w2(self):
+        """16-bit operand copies of decoder.conv.2.weight: W2 [C^2][8C] (forward B operand) and its transpose
+        [8C][C^2 + 64] (dgrad B operand, backward type); one pass over W2 writes both.  It depends on nothing but
+        the parameters, so it is the first op of the program and runs on the side stream under the Graphormer."""
+        C, ms = self.C, self.max_shape
+        for g in self.gemm_groups:
+            g['op16'] = self.direct16 and g['i_ld'] % 8 == 0
+        if not any(g['op16'] for g in self.gemm_groups):
+            return
+        fct, bct = self.decoder_ctype, self.decoder_bwd_ctype
+        n_w2 = ms[0] * ms[1]
+        self.w2h = self.ws16('w2h', n_w2 * 8 * C)
+        item = dict(src_off=0, rows=n_w2, cols=8 * C, ld_src=8 * C, straight=(self.w2h, 8 * C, fct))
+        if self.training:
+            self.w2hT_ld = round_up(n_w2, 64) + 64
+            self.w2hT = self.ws16('w2hT', 8 * C * self.w2hT_ld)
+            item['transposed'] = (self.w2hT, self.w2hT_ld, bct)
+        self.cast16(self.pref('decoder.conv.2.weight'), [item], flags=self.SIDE)
+
     # ------------------------------------------------------------------ forward
     def _build_forward(self):
         C, H, B, N, V, K = self.C, self.H, self.B, self.N, self.V, self.K
@@ -370,6 +396,7 @@ class Program:
         self.ldT, self.ldK = ldT, ldK
         train = self.training
 
+        self._cast_w2()
         node_off = np.cumsum([0] + self.n_nodes[:-1]).astype(np.int32)
         r_types = self.idx(self.node_types)
         r_shape = self.idx(self.shape_idx.astype(np.int32))
@@ -494,21 +521,10 @@ class Program:
                 tiles_floats += round_up(gg['rows'] * gg['ld'], 64)
             self.tiles_floats = tiles_floats
             tiles = self.wsf('tiles', tiles_floats)
-            for g in self.gemm_groups:
-                g['op16'] = self.direct16 and g['i_ld'] % 8 == 0
             use16 = any(g['op16'] for g in self.gemm_groups)
             if use16:
-                # 16-bit operand copies: W2 [C^2][8C] (forward B operand), its transpose [8C][C^2 + 64] (dgrad B
-                # operand, backward type) and u [M][8C]; one pass over W2 writes both W2 copies.
-                fct, bct = self.decoder_ctype, self.decoder_bwd_ctype
-                n_w2 = ms[0] * ms[1]
-                self.w2h = self.ws16('w2h', n_w2 * 8 * C)
-                item = dict(src_off=0, rows=n_w2, cols=8 * C, ld_src=8 * C, straight=(self.w2h, 8 * C, fct))
-                if self.training:
-                    self.w2hT_ld = round_up(n_w2, 64) + 64
-                    self.w2hT = self.ws16('w2hT', 8 * C * self.w2hT_ld)
-                    item['transposed'] = (self.w2hT, self.w2hT_ld, bct)
-                self.cast16(self.pref(W2), [item])
+                fct = self.decoder_ctype
+                self.op(L.OP_JOIN)                       # the W2 copies were cast on the side stream (_cast_w2)
                 self.uh = self.ws16('uh', M * 8 * C)
                 self.cast16((self.xbuf(self.X_WS), 0),
                             [dict(src_off=u[1] // 4, rows=M, cols=8 * C, ld_src=8 * C, straight=(self.uh, 8 * C, fct))])
@@ -809,7 +825,7 @@ class Program:
                     dout_n = self.wref('d_clsout', g['cls_off'][n_idx])
                     p0 = self.gemm(dout_n, tile_n, self.gref(Wc), K, ms[0], g['i'], ldK, g['i_ld'], ms[0],
                                    a_mode=L.MODE_COL, b_mode=L.MODE_ROW, accum=True, dbias=self.gref(bc))
-                    self.gemm_op(p0)
+                    self.gemm_op(p0, side=True)
             # D3 backward: d_u = (d_tiles . W2sub) * (u > 0)   -- all groups, one launch.  The reduction runs over
             # the o*i columns of a group (up to C^2 = 147456) while M x N is only rows x 8C, so the K range is
             # split into chunks (partial sums added atomically into the zeroed d_u) to fill the 256 CUs; the ReLU
@@ -820,19 +836,22 @@ class Program:
             if g16:
                 # 16-bit copies of the backward operands, one launch: per group d_tiles (straight: dgrad A operand,
                 # transposed: wgrad A operand, column sums: the conv.2 bias gradient) and u^T (wgrad B operand)
-                items = []
+                items, side_items = [], []
                 for g in g16:
                     g['dth_ld'] = round_up(g['cols'], 64)
                     g['dth'] = self.ws16('dth%d' % g['row0'], g['rows'] * g['dth_ld'])
                     g['kT_ld'] = round_up(g['rows'], 64)
                     g['dthT'] = self.ws16('dthT%d' % g['row0'], g['cols'] * g['kT_ld'])
                     g['uhT'] = self.ws16('uhT%d' % g['row0'], 8 * C * g['kT_ld'])
-                    items.append(dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'], rows=g['rows'],
-                                      cols=g['cols'], ld_src=g['ld'], straight=(g['dth'], g['dth_ld'], bct),
-                                      transposed=(g['dthT'], g['kT_ld'], bct), colsum=(g['i_ld'], ms[1])))
-                    items.append(dict(src_off=u[1] // 4 + g['row0'] * 8 * C, rows=g['rows'], cols=8 * C,
-                                      ld_src=8 * C, transposed=(g['uhT'], g['kT_ld'], bct)))
-                self.cast16((self.xbuf(self.X_WS), 0), items, dbias=self.gref(b2))
+                    src = dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'], rows=g['rows'], cols=g['cols'],
+                               ld_src=g['ld'])
+                    items.append(dict(src, straight=(g['dth'], g['dth_ld'], bct)))
+                    side_items.append(dict(src, transposed=(g['dthT'], g['kT_ld'], bct), colsum=(g['i_ld'], ms[1])))
+                    side_items.append(dict(src_off=u[1] // 4 + g['row0'] * 8 * C, rows=g['rows'], cols=8 * C,
+                                           ld_src=8 * C, transposed=(g['uhT'], g['kT_ld'], bct)))
+                # the dgrad operand on the critical path; the wgrad operands (and the bias gradient) beside it
+                self.cast16((self.xbuf(self.X_WS), 0), items)
+                self.cast16((self.xbuf(self.X_WS), 0), side_items, dbias=self.gref(b2), flags=self.SIDE)
             p0 = len(self._probs)
             for g in self.gemm_groups:
                 for (r0, nr) in self._row_parts(g['rows']):
@@ -859,7 +878,7 @@ class Program:
                     p0 = self.gemm(self.href(g['dthT']), self.href(g['uhT']), self.gref(W2), g['cols'], 8 * C,
                                    g['rows'], g['kT_ld'], g['kT_ld'], 8 * C, c_qs=(g['i_ld'], ms[1]),
                                    accum=not full, op16=True)
-                    self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD)
+                    self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=True)
                     continue
                 p0 = self.gemm(self.wref('d_tiles', g['tile_off']), (u[0], u[1] + 4 * g['row0'] * 8 * C),
                                self.gref(W2), g['cols'], 8 * C, g['rows'], g['ld'], 8 * C, 8 * C,
@@ -867,22 +886,26 @@ class Program:
                                dbias=self.gref(b2))
                 # short reduction (K = rows of the group): 64x64 tiles beat 128x128 here (tests/gemm_bench.py)
                 self.gemm_op(p0, tile=64 if g['rows'] <= 1024 else 0, ctype=bct if g16 else None,
-                             tag=self.TAG_D3_WGRAD)
+                             tag=self.TAG_D3_WGRAD, side=True)
             # D2 backward
             p0 = self.gemm(d_u, t, self.gref(W0), 8 * C, 4 * C, M, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_COL,
                            b_mode=L.MODE_COL, accum=True, dbias=self.gref(b0))
-            self.gemm(d_u, self.pref(W0), d_t, M, 4 * C, 8 * C, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_ROW,
-                      b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=t)
+            self.gemm_op(p0, tag=self.TAG_D2_BWD, side=True)
+            p0 = self.gemm(d_u, self.pref(W0), d_t, M, 4 * C, 8 * C, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_ROW,
+                           b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=t)
             self.gemm_op(p0, tag=self.TAG_D2_BWD)
             # D1 backward (per used position)
+            p0 = len(self._probs)
+            for (p, cnt, r_rows, r_src) in self.d1:
+                self.gemm(d_t, self.pref(Wfc, p * C), d_rows, cnt, C, 4 * C, 4 * C, S2 * C, C, a_mode=L.MODE_ROW,
+                          b_mode=L.MODE_COL, a_gather=r_rows, c_gather=r_rows)
+            self.gemm_op(p0, tag=self.TAG_D1_BWD)
             p0 = len(self._probs)
             for (p, cnt, r_rows, r_src) in self.d1:
                 self.gemm(d_t, xe, self.gref(Wfc, p * C), 4 * C, C, cnt, 4 * C, C, S2 * C, a_mode=L.MODE_COL,
                           b_mode=L.MODE_COL, a_gather=r_rows, b_gather=r_src, accum=True,
                           dbias=self.gref(bfc, p), dbias_stride=S2)
-                self.gemm(d_t, self.pref(Wfc, p * C), d_rows, cnt, C, 4 * C, 4 * C, S2 * C, C, a_mode=L.MODE_ROW,
-                          b_mode=L.MODE_COL, a_gather=r_rows, c_gather=r_rows)
-            self.gemm_op(p0, tag=self.TAG_D1_BWD)
+            self.gemm_op(p0, tag=self.TAG_D1_BWD, side=True)
         if n1 > 0:
             mc = self.mc
             W1, b1 = 'decoder_1d.fc.0.weight', 'decoder_1d.fc.0.bias'
@@ -896,19 +919,22 @@ class Program:
                 w_cb = self.wref('w1d', cb0 * 2 * mc + mc)
                 p0 = self.gemm(d_cb, self.pref(Wb), self.wref('d_w1d', cb0 * 2 * mc + mc), self.n1_clsb, mc, K, ldK,
                                mc, 2 * mc, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=w_cb)
-                self.gemm(d_cb, w_cb, self.gref(Wb), K, mc, self.n1_clsb, ldK, 2 * mc, mc, a_mode=L.MODE_COL,
-                          b_mode=L.MODE_COL, accum=True, dbias=self.gref(bb))
                 self.gemm_op(p0)
+                p0 = self.gemm(d_cb, w_cb, self.gref(Wb), K, mc, self.n1_clsb, ldK, 2 * mc, mc, a_mode=L.MODE_COL,
+                               b_mode=L.MODE_COL, accum=True, dbias=self.gref(bb))
+                self.gemm_op(p0, side=True)
+            p0 = self.gemm(d_w1d, self.pref(W2d), d_h1d, n1, 2 * C, 2 * mc, 2 * mc, 2 * C, 2 * C, a_mode=L.MODE_ROW,
+                           b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=h1d)
+            self.gemm_op(p0)
             p0 = self.gemm(d_w1d, h1d, self.gref(W2d), 2 * mc, 2 * C, n1, 2 * mc, 2 * C, 2 * C, a_mode=L.MODE_COL,
                            b_mode=L.MODE_COL, accum=True, dbias=self.gref(b2d))
-            self.gemm(d_w1d, self.pref(W2d), d_h1d, n1, 2 * C, 2 * mc, 2 * mc, 2 * C, 2 * C, a_mode=L.MODE_ROW,
-                      b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=h1d)
+            self.gemm_op(p0, side=True)
+            p0 = self.gemm(d_h1d, self.pref(W1), (d_rows[0], d_rows[1] + 4 * M * C), n1, C, 2 * C, 2 * C, C, C,
+                           a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
             self.gemm_op(p0)
             p0 = self.gemm(d_h1d, xe, self.gref(W1), 2 * C, C, n1, 2 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
                            b_gather=self.r_src1, accum=True, dbias=self.gref(b1))
-            self.gemm(d_h1d, self.pref(W1), (d_rows[0], d_rows[1] + 4 * M * C), n1, C, 2 * C, 2 * C, C, C,
-                      a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
-            self.gemm_op(p0)
+            self.gemm_op(p0, side=True)
         # ---- d_xe[row] = sum of the decoder rows that read it (deterministic gather-sum) -----------------
         all_src = np.concatenate([self.row_src, self.oned_src]) if (M + n1) else np.zeros(0, dtype=np.int32)
         order = np.argsort(all_src, kind='stable').astype(np.int32)
@@ -918,12 +944,8 @@ class Program:
         self.op(L.OP_ROWSEG_SUM, refs=(d_xe, d_rows, self.idx(seg_ptr), self.idx(order)), ints=(rows, C, C, C, 0))
 
         # ---- final LayerNorm ----------------------------------------------------------------------------
-        dxa, dxb = self.wsf('dxa', rows * C), self.wsf('dxb', rows * C)
-        dh = self.wsf('dh', rows * C)
-        dz = self.wsf('dz', rows * 4 * C)
+        dxa = self.wsf('dxa', rows * C)
         do = self.wsf('do', rows * C)
-        dqkv = self.wsf('dqkv', rows * 3 * C)
-        dS = self.wsf('dS', B * H * N * N)
         dBias = self.wsf('dBias', B * H * N * N)
         self.op(L.OP_MEMSET0, refs=(dBias,), ints=(4 * B * H * N * N,))
         xL = self.wref('x%d' % self.Lyr)
@@ -931,11 +953,10 @@ class Program:
             self.op(L.OP_LAYERNORM_BWD, refs=(dxa, d_xe, xL, self.pref('ln.weight'), self.wref('mf'), self.wref('rf'),
                                               self.NONE), ints=(rows, C))
             self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref('ln.weight'), self.gref('ln.bias'), d_xe, xL,
-                                              self.wref('mf'), self.wref('rf')), ints=(rows, C, 1))
+                                              self.wref('mf'), self.wref('rf')), ints=(rows, C, 1), flags=self.SIDE)
             g_cur = dxa
         else:
             g_cur = d_xe
-        other = dxb
         # ---- Graphormer layers, reversed ----------------------------------------------------------------
         bias = self.wref('bias')
         for l in reversed(range(self.Lyr)):
@@ -947,29 +968,36 @@ class Program:
             m1, r1, m2, r2 = self.wref('m1' + sfx), self.wref('r1' + sfx), self.wref('m2' + sfx), self.wref('r2' + sfx)
             W3, W1f, Wo, Wq = pre + 'ff.net.3.weight', pre + 'ff.net.0.weight', pre + 'attn.to_out.0.weight', \
                 pre + 'attn.to_qkv.weight'
-            # The four dgrad GEMMs form the dependent chain of the layer; the four wgrad GEMMs (+ fused bias
-            # gradients) are off the critical path and are issued as ONE grouped launch at the end of the layer,
-            # while all their operands (g_cur, dz, g_mid, dqkv and the saved activations) are still alive.
+            # The four dgrad GEMMs, the two LayerNorm backward passes and the attention backward form the dependent
+            # chain of the layer.  The four wgrad GEMMs (+ fused bias gradients, ONE grouped launch) and the two
+            # LayerNorm parameter gradients are off that chain: they run on the side stream, which is why every
+            # temporary they read (g_cur, dz, dhA, g_mid, dqkv, dhB) is a buffer of THIS layer -- the chain of the
+            # next layer may start while they are still being read.
+            lsfx = sfx if self.SIDE else ''
+            dz = self.wsf('dz' + lsfx, rows * 4 * C)
+            dhA, dhB = self.wsf('dhA' + lsfx, rows * C), self.wsf('dhB' + lsfx, rows * C)
+            g_mid = self.wsf('gmid' + lsfx, rows * C)
+            g_out = self.wsf(('gout' + sfx) if self.SIDE else 'gout%d' % (l & 1), rows * C)
+            dqkv = self.wsf('dqkv' + lsfx, rows * 3 * C)
             # FFN second linear: x_out = xmid + f W3^T + b3
             p0 = self.gemm(g_cur, self.pref(W3), dz, rows, 4 * C, C, C, 4 * C, 4 * C, a_mode=L.MODE_ROW,
                            b_mode=L.MODE_COL, dact=L.DACT_GELU, aux_in=z)
             self.gemm_op(p0)
             # FFN first linear
-            p0 = self.gemm(dz, self.pref(W1f), dh, rows, C, 4 * C, 4 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+            p0 = self.gemm(dz, self.pref(W1f), dhA, rows, C, 4 * C, 4 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
             self.gemm_op(p0)
             # LN2 (+ residual branch gradient g_cur)
-            self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln2.weight'), self.gref(pre + 'ln2.bias'), dh, xmid,
-                                              m2, r2), ints=(rows, C, 1))
-            self.op(L.OP_LAYERNORM_BWD, refs=(other, dh, xmid, self.pref(pre + 'ln2.weight'), m2, r2, g_cur),
+            self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln2.weight'), self.gref(pre + 'ln2.bias'), dhA, xmid,
+                                              m2, r2), ints=(rows, C, 1), flags=self.SIDE)
+            self.op(L.OP_LAYERNORM_BWD, refs=(g_mid, dhA, xmid, self.pref(pre + 'ln2.weight'), m2, r2, g_cur),
                     ints=(rows, C))
-            g_mid = other
             # attention output projection: xmid = x_in + o Wo^T + bo
             p0 = self.gemm(g_mid, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
             self.gemm_op(p0)
-            self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, dS, dBias, r_nn), ints=(B, N, C, H))
-            p0 = self.gemm(dqkv, self.pref(Wq), dh, rows, C, 3 * C, 3 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+            self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, self.NONE, dBias, r_nn), ints=(B, N, C, H))
+            p0 = self.gemm(dqkv, self.pref(Wq), dhB, rows, C, 3 * C, 3 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
             self.gemm_op(p0)
-            # deferred weight gradients of the layer, one launch
+            # weight gradients of the layer, one launch
             p0 = self.gemm(g_cur, f, self.gref(W3), C, 4 * C, rows, C, 4 * C, 4 * C, a_mode=L.MODE_COL,
                            b_mode=L.MODE_COL, accum=True, dbias=self.gref(pre + 'ff.net.3.bias'))
             self.gemm(dz, h2, self.gref(W1f), 4 * C, C, rows, 4 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
@@ -978,12 +1006,12 @@ class Program:
                       accum=True, dbias=self.gref(pre + 'attn.to_out.0.bias'))
             self.gemm(dqkv, h1, self.gref(Wq), 3 * C, C, rows, 3 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
                       accum=True)
-            self.gemm_op(p0)
-            self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln1.weight'), self.gref(pre + 'ln1.bias'), dh, x_in,
-                                              m1, r1), ints=(rows, C, 1))
-            self.op(L.OP_LAYERNORM_BWD, refs=(g_cur, dh, x_in, self.pref(pre + 'ln1.weight'), m1, r1, g_mid),
+            self.gemm_op(p0, side=True)
+            self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln1.weight'), self.gref(pre + 'ln1.bias'), dhB, x_in,
+                                              m1, r1), ints=(rows, C, 1), flags=self.SIDE)
+            self.op(L.OP_LAYERNORM_BWD, refs=(g_out, dhB, x_in, self.pref(pre + 'ln1.weight'), m1, r1, g_mid),
                     ints=(rows, C))
-            # g_cur now holds d x_l ; `other` is free again
+            g_cur = g_out                   # d x_l
         # ---- layer-0 edge bias: histogram -> table MLP backward ------------------------------------------
         E = 'gnn.0.attn.edge_embed.embed.weight'
         W0e, b0e = 'gnn.0.attn.proj_e.0.weight', 'gnn.0.attn.proj_e.0.bias'

@@ -179,7 +179,8 @@ enum ghn3_op_kind {
     GHN3_OP_LAYERNORM_BWD = 14,
     /* r0=dgamma r1=dbeta r2=dy r3=x r4=mean r5=rstd ; i: rows,C,accum */
     GHN3_OP_LN_PARAM_GRAD = 15,
-    /* r0=dqkv r1=dO r2=qkv r3=P r4=O r5=dS scratch r6=dBias (accumulated) r7=n_nodes ; i: B,N,C,H */
+    /* r0=dqkv r1=dO r2=qkv r3=P r4=O (saved attention output) r5=unused r6=dBias (accumulated) r7=n_nodes
+     * i: B,N,C,H */
     GHN3_OP_ATTN_BWD = 16,
     /* dT[p][h] += sum_{pair==p} dBias[b,h,i,j] ; r0=dT r1=dBias r2=pair ; i: B,N,H,V */
     GHN3_OP_BIAS_HIST = 17,
@@ -199,6 +200,8 @@ enum ghn3_op_kind {
      * r0=src base (fp32) r1=dst base (16-bit) r2=ghn3_cast_desc table (device) r3=dbias or absent
      * i: n_desc, total workgroups */
     GHN3_OP_CAST16 = 23,
+    /* the run's stream waits for every GHN3_OPFLAG_SIDE op issued so far (no refs) */
+    GHN3_OP_JOIN = 24,
     GHN3_OP_KIND_COUNT
 };
 
@@ -248,6 +251,11 @@ int ghn3_event_destroy(void* ev);
  *   mode 2: only ops whose flags carry GHN3_OPFLAG_TIMED get an event pair from a pool, nothing is
  *           synchronised until ghn3_profile_read_tags; the tag is (op.flags >> 16) & 255. */
 #define GHN3_OPFLAG_TIMED 0x100
+/* Run the op on the context's side stream, concurrently with the following ops of the program: it starts after
+ * every earlier op of the program has finished and is waited for by GHN3_OP_JOIN / the end of ghn3_run.  The
+ * program must not let later main-stream ops touch what a pending side op reads or writes (used for weight
+ * gradients and operand copies that are off the critical path).  GHN3_NO_SIDE_STREAM=1 serialises everything. */
+#define GHN3_OPFLAG_SIDE 0x200
 int ghn3_profile_enable(ghn3_ctx* ctx, int mode);
 int ghn3_profile_read(ghn3_ctx* ctx, double* ms_per_kind /* [GHN3_OP_KIND_COUNT] */,
                       int64_t* launches_per_kind, int reset);

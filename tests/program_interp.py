@@ -51,6 +51,9 @@ class Interp:
     def op_nop(self, o, problems):
         pass
 
+    def op_join(self, o, problems):
+        pass                         # (the interpreter runs side-stream ops in program order)
+
     @staticmethod
     def _rowmap(r, g, q, s):
         r = np.asarray(r, dtype=np.int64)
@@ -373,11 +376,12 @@ class Interp:
         dO = self.fview(o['r'][1], B * N * C).reshape(B, N, H, d).transpose(0, 2, 1, 3).astype(np.float64)
         dV = P.transpose(0, 1, 3, 2) @ dO
         dP = dO @ v.transpose(0, 1, 3, 2)
-        dS = P * (dP - (P * dP).sum(-1, keepdims=True))
+        # delta = rowsum(P * dP) = rowsum(dO * O): the kernel uses the saved attention output (r4)
+        O = self.fview(o['r'][4], B * N * C).reshape(B, N, H, d).transpose(0, 2, 1, 3).astype(np.float64)
+        dS = P * (dP - (dO * O).sum(-1, keepdims=True))
         dS = np.where(mask[:, None], dS, 0.0)
         dQ = (dS @ k) * scale
         dK = (dS.transpose(0, 1, 3, 2) @ q) * scale
-        self.fview(o['r'][5], B * H * N * N).reshape(B, H, N, N)[:] = dS
         if int(o['r'][6]['buf']) >= 0:
             self.fview(o['r'][6], B * H * N * N).reshape(B, H, N, N)[:] += dS.astype(np.float32)
         out = self.fview(o['r'][0], B * N * 3 * C).reshape(B, N, 3, H, d)

@@ -149,7 +149,21 @@ def main():
     total_pred = float(n_all.item())
 
     op_breakdown = None
+    phases = None
     if args.profile_ops and rank == 0:
+        ev = [L.Event() for _ in range(4)]
+        ev[0].record(stream)
+        ghn._run_forward(plan)
+        ev[1].record(stream)
+        ghn._fill_bufs(plan, out=plan.out, dout=dout)
+        ctx.run(f_norm, prog.problems, plan.bufs, stream)
+        ctx.run(b_norm, prog.problems, plan.bufs, stream)
+        ev[2].record(stream)
+        ghn._run_backward(plan, dout)
+        ev[3].record(stream)
+        torch.cuda.synchronize()
+        phases = {'forward': round(ev[0].elapsed_ms(ev[1]), 3), 'loss_norms': round(ev[1].elapsed_ms(ev[2]), 3),
+                  'backward': round(ev[2].elapsed_ms(ev[3]), 3)}
         ctx.profile(1)
         ctx.profile_read(reset=True)
         step()
@@ -192,6 +206,7 @@ def main():
         }
         if op_breakdown is not None:
             out['op_breakdown_ms'] = {k: round(v[0], 3) for k, v in op_breakdown.items()}
+            out['phase_ms'] = phases
         if not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(args.model, args.cpu_sample_nodes, 32000)

@@ -405,10 +405,55 @@ struct Odo {
     }
 };
 
+// Row blocks (descriptor index stored as ~k < 0, second word = a0): convolution kernels with kh * kw > 1.  The target
+// [o][i][kh][kw] is contiguous in (i, kh, kw) while the source keeps one [o][i] matrix per kernel position, so the
+// element-wise mapping above reads (backward: writes) one side with a stride of kh * kw floats.  A row block moves
+// one o-row of one tensor through LDS instead: T1 * kh * kw contiguous target floats on one side, kh * kw
+// segments of consecutive i on the other -- both sides coalesced.  Requires mode 0, S[1] == 1 and no tiling
+// along kh / kw (the host checks).
 __global__ __launch_bounds__(256) void tile_fwd_kernel(float* __restrict__ flat, SrcTable srcs,
                                                        const ghn3_tile_desc* __restrict__ desc,
                                                        const int64_t* __restrict__ blocks) {
-    const int64_t di = blocks[2 * (size_t)blockIdx.x];
+    extern __shared__ float tl[];
+    const int64_t di_raw = blocks[2 * (size_t)blockIdx.x];
+    if (di_raw < 0) {
+        const ghn3_tile_desc* D = desc + (~di_raw);
+        const int64_t word = blocks[2 * (size_t)blockIdx.x + 1];
+        const int a0 = (int)(word & 0xffffff), i0 = (int)(word >> 24);          // row, first i of the chunk
+        const int T1 = D->T[1], T3 = D->T[3], hw = D->T[2] * T3, E1 = D->E[1];
+        const int ni = min(D->_pad, T1 - i0);                                   // D->_pad = i per row block
+        const float* src = srcs.p[D->src_buf] + D->src_off + (int64_t)(a0 % D->E[0]) * D->S[0];
+        const int n = ni * hw;
+        const int S2 = (int)D->S[2], S3 = (int)D->S[3];
+        const float inv_ni = 1.f / (float)ni, inv_t3 = 1.f / (float)T3;
+        constexpr int U = 8;                                  // loads in flight per thread
+        for (int b0 = threadIdx.x; b0 < n; b0 += 256 * U) {
+            float v[U];
+            int li[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int idx = b0 + 256 * u;                  // (p, i) with i fastest: consecutive source floats
+                int pp = (int)((float)idx * inv_ni);
+                int i = idx - pp * ni;
+                if (i < 0) { i += ni; --pp; } else if (i >= ni) { i -= ni; ++pp; }
+                int y = (int)((float)pp * inv_t3);
+                int x = pp - y * T3;
+                if (x < 0) { x += T3; --y; } else if (x >= T3) { x -= T3; ++y; }
+                li[u] = i * hw + pp;
+                const int si = i0 + i;
+                v[u] = idx < n ? src[(int64_t)y * S2 + (int64_t)x * S3 + (E1 == T1 ? si : si % E1)] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                if (b0 + 256 * u < n) tl[li[u]] = v[u];
+        }
+        __syncthreads();
+        float* dst = flat + D->dst_off + ((int64_t)a0 * T1 + i0) * hw;
+        const float scale = D->scale;
+        for (int j = threadIdx.x; j < n; j += 256) dst[j] = tl[j] * scale;
+        return;
+    }
+    const int64_t di = di_raw;
     const unsigned start = (unsigned)blocks[2 * (size_t)blockIdx.x + 1];
     const ghn3_tile_desc* D = desc + di;
     const int T0 = D->T[0], T1 = D->T[1], T2 = D->T[2], T3 = D->T[3];
@@ -437,12 +482,16 @@ __global__ __launch_bounds__(256) void tile_fwd_kernel(float* __restrict__ flat,
 }
 
 int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d_desc, int n_desc, int64_t total,
-                  const int64_t* blocks, hipStream_t s) {
+                  const int64_t* blocks, int lds_bytes, hipStream_t s) {
     // `total` = number of work blocks in the (descriptor, start) table `blocks`.
     if (n_desc <= 0 || total <= 0) return GHN3_OK;
     SrcTable st;
     for (int i = 0; i < 6; ++i) st.p[i] = srcs[i];
-    hipLaunchKernelGGL(tile_fwd_kernel, dim3((unsigned)total), dim3(256), 0, s, flat, st, d_desc, blocks);
+    if (lds_bytes > 48 * 1024) {
+        if (lds_bytes > 128 * 1024) { ghn3_set_error("tile_fwd: row blocks need %d bytes of LDS", lds_bytes); return GHN3_E_LIMIT; }
+        hipFuncSetAttribute((const void*)tile_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    }
+    hipLaunchKernelGGL(tile_fwd_kernel, dim3((unsigned)total), dim3(256), lds_bytes, s, flat, st, d_desc, blocks);
     return launch_ok("tile_fwd");
 }
 
@@ -452,7 +501,59 @@ int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d
 __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__ dflat, SrcTable srcs, DstTable dsrcs,
                                                        const ghn3_tile_desc* __restrict__ desc,
                                                        const int64_t* __restrict__ blocks) {
-    const int64_t di = blocks[2 * (size_t)blockIdx.x];
+    extern __shared__ float tl[];
+    const int64_t di_raw = blocks[2 * (size_t)blockIdx.x];
+    if (di_raw < 0) {
+        // row block (see tile_fwd_kernel): source row a0 of the region; replicas along o and i are summed in LDS
+        const ghn3_tile_desc* D = desc + (~di_raw);
+        const int64_t word = blocks[2 * (size_t)blockIdx.x + 1];
+        const int a0 = (int)(word & 0xffffff), i0 = (int)(word >> 24);          // source row, first i of the chunk
+        const int T0 = D->T[0], T1 = D->T[1], T3 = D->T[3], hw = D->T[2] * T3;
+        const int E0 = D->E[0], E1 = D->E[1], R1 = D->R[1];
+        const int ni = min(D->_pad, R1 - i0);                                   // i of this block (source side)
+        const int nl = max(0, min(ni, E1 - i0));                                // of which inside the consumed region
+        float* dsrc = dsrcs.p[D->src_buf] + D->src_off + (int64_t)a0 * D->S[0] + i0;
+        const float* g = dflat + D->dst_off;
+        const bool live = a0 < E0 && nl > 0;
+        if (live) {
+            const int n = nl * hw;
+            constexpr int U = 8;
+            for (int b0 = threadIdx.x; b0 < n; b0 += 256 * U) {
+                float acc[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) acc[u] = 0.f;
+                for (int t0 = a0; t0 < T0; t0 += E0)
+                    for (int r0 = 0; r0 + i0 < T1; r0 += E1) {              // replicas along i
+                        const int lim = min(nl, T1 - r0 - i0) * hw;          // a last partial replica covers fewer i
+                        const float* gr = g + ((int64_t)t0 * T1 + r0 + i0) * hw;
+#pragma unroll
+                        for (int u = 0; u < U; ++u) {
+                            const int j = b0 + 256 * u;
+                            if (j < lim) acc[u] += gr[j];
+                        }
+                    }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (b0 + 256 * u < n) tl[b0 + 256 * u] = acc[u];
+            }
+            __syncthreads();
+        }
+        const float scale = D->scale;
+        const int S2 = (int)D->S[2], S3 = (int)D->S[3];
+        const float inv_ni = 1.f / (float)ni, inv_t3 = 1.f / (float)T3;
+        const int nw = ni * hw;
+        for (int idx = threadIdx.x; idx < nw; idx += 256) {    // (p, i) with i fastest: consecutive source floats
+            int pp = (int)((float)idx * inv_ni);
+            int i = idx - pp * ni;
+            if (i < 0) { i += ni; --pp; } else if (i >= ni) { i -= ni; ++pp; }
+            int y = (int)((float)pp * inv_t3);
+            int x = pp - y * T3;
+            if (x < 0) { x += T3; --y; } else if (x >= T3) { x -= T3; ++y; }
+            dsrc[(int64_t)y * S2 + (int64_t)x * S3 + i] = (live && i < nl) ? tl[i * hw + pp] * scale : 0.f;
+        }
+        return;
+    }
+    const int64_t di = di_raw;
     const unsigned start = (unsigned)blocks[2 * (size_t)blockIdx.x + 1];
     const ghn3_tile_desc* D = desc + di;
     const int R0 = D->R[0], R1 = D->R[1], R2 = D->R[2], R3 = D->R[3];
@@ -488,11 +589,15 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
 }
 
 int ghn3_tile_bwd(const float* dflat, const float* const* srcs, float* const* dsrcs, const ghn3_tile_desc* d_desc,
-                  int n_desc, int64_t total, const int64_t* blocks, hipStream_t s) {
+                  int n_desc, int64_t total, const int64_t* blocks, int lds_bytes, hipStream_t s) {
     if (n_desc <= 0 || total <= 0) return GHN3_OK;
     SrcTable st; DstTable dt;
     for (int i = 0; i < 6; ++i) { st.p[i] = srcs[i]; dt.p[i] = dsrcs[i]; }
-    hipLaunchKernelGGL(tile_bwd_kernel, dim3((unsigned)total), dim3(256), 0, s, dflat, st, dt, d_desc, blocks);
+    if (lds_bytes > 48 * 1024) {
+        if (lds_bytes > 128 * 1024) { ghn3_set_error("tile_bwd: row blocks need %d bytes of LDS", lds_bytes); return GHN3_E_LIMIT; }
+        hipFuncSetAttribute((const void*)tile_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    }
+    hipLaunchKernelGGL(tile_bwd_kernel, dim3((unsigned)total), dim3(256), lds_bytes, s, dflat, st, dt, d_desc, blocks);
     return launch_ok("tile_bwd");
 }
 

@@ -435,7 +435,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             for (int j = 0; j < 6; ++j) srcs[j] = R.get<const float>(o.r[1 + j]);
             const ghn3_tile_desc* dd = R.get<const ghn3_tile_desc>(o.r[7]);
             rc = ghn3_tile_fwd(R.get<float>(o.r[0]), srcs, dd, (int)o.i[0], o.i[1],
-                               reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(dd) + o.i[2]), stream);
+                               reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(dd) + o.i[2]),
+                               (int)o.i[3], stream);
             break;
         }
         case GHN3_OP_TILE_BWD: {
@@ -443,7 +444,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             for (int j = 0; j < 6; ++j) { srcs[j] = R.get<const float>(o.r[1 + j]); dsrcs[j] = R.get<float>(o.r[8 + j]); }
             const ghn3_tile_desc* dd = R.get<const ghn3_tile_desc>(o.r[7]);
             rc = ghn3_tile_bwd(R.get<const float>(o.r[0]), srcs, dsrcs, dd, (int)o.i[0], o.i[1],
-                               reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(dd) + o.i[2]), stream);
+                               reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(dd) + o.i[2]),
+                               (int)o.i[3], stream);
             break;
         }
         case GHN3_OP_PARAM_NORM_FWD:

@@ -703,9 +703,24 @@ class Program:
         self.n_desc = len(descs)
         CH = 2048
         fwd_blocks, bwd_blocks = [], []
+        self.tile_lds = [0, 0]
         for k, d in enumerate(descs):
-            n_f = int(np.prod(d['T'].astype(np.int64)))
-            n_b = int(np.prod(d['R'].astype(np.int64)))
+            T, E, R, S = (d[n].astype(np.int64) for n in ('T', 'E', 'R', 'S'))
+            hw = int(T[2] * T[3])
+            row_ok = (int(d['mode']) == 0 and hw > 1 and S[1] == 1 and E[2] == T[2] == R[2] and E[3] == T[3] == R[3]
+                      and hw <= 1024)
+            if row_ok:
+                # convolution kernels with kh * kw > 1: LDS-transposed row blocks (see tile_fwd_kernel), one per o and
+                # chunk of `ich` input channels (<= 16 KB of LDS, so that many blocks share a CU)
+                ich = int(max(16, min(int(max(T[1], R[1])), 4096 // hw)))
+                descs[k]['_pad'] = ich
+                fwd_blocks += [(~k, a0 | (i0 << 24)) for a0 in range(int(T[0])) for i0 in range(0, int(T[1]), ich)]
+                bwd_blocks += [(~k, a0 | (i0 << 24)) for a0 in range(int(R[0])) for i0 in range(0, int(R[1]), ich)]
+                self.tile_lds[0] = max(self.tile_lds[0], 4 * ich * hw)
+                self.tile_lds[1] = max(self.tile_lds[1], 4 * ich * hw)
+                continue
+            n_f = int(np.prod(T))
+            n_b = int(np.prod(R))
             fwd_blocks += [(k, s) for s in range(0, n_f, CH)]
             bwd_blocks += [(k, s) for s in range(0, n_b, CH)]
         desc_arr = np.array(descs, dtype=L.TILE_DT) if descs else np.zeros(1, dtype=L.TILE_DT)
@@ -722,7 +737,7 @@ class Program:
         srcs = self._tile_sources(False)
         if self.n_desc:
             self.op(L.OP_TILE_FWD, refs=[(self.xbuf(self.X_OUT), 0)] + srcs + [self.r_desc],
-                    ints=(self.n_desc, self.fwd_blk[0], self.fwd_blk[1]),
+                    ints=(self.n_desc, self.fwd_blk[0], self.fwd_blk[1], self.tile_lds[0]),
                     flags=L.OPFLAG_TIMED | (self.TAG_TILE_FWD << 16))
 
     def _tile_sources(self, grad):
@@ -794,7 +809,7 @@ class Program:
                 self.op(L.OP_MEMSET0, refs=(self.wref('d_cbout'),), ints=(4 * self.n1_clsb * ldK,))
         if self.n_desc:
             self.op(L.OP_TILE_BWD, refs=[(self.xbuf(self.X_DOUT), 0)] + self._tile_sources(False) + [self.r_desc] +
-                    self._tile_sources(True), ints=(self.n_desc, self.bwd_blk[0], self.bwd_blk[1]),
+                    self._tile_sources(True), ints=(self.n_desc, self.bwd_blk[0], self.bwd_blk[1], self.tile_lds[1]),
                     flags=L.OPFLAG_TIMED | (self.TAG_TILE_BWD << 16))
 
         Wfc, bfc = 'decoder.fc.0.weight', 'decoder.fc.0.bias'

@@ -132,7 +132,7 @@ typedef struct ghn3_tile_desc {
     int32_t src_buf;        /* index into the op's source table r[1..] */
     int32_t mode;
     float scale;
-    int32_t _pad;
+    int32_t _pad;           /* row blocks: number of second-dimension (i) elements per block */
 } ghn3_tile_desc;
 
 /* ---- ops ------------------------------------------------------------------------------------------- */
@@ -159,7 +159,10 @@ enum ghn3_op_kind {
      * i: B,N,C,H */
     GHN3_OP_ATTN_FWD = 7,
     /* r0=flat out, r1..r6 = sources, r7 = descriptors (device)
-     * i: n_desc, n_work_blocks, byte offset from r7 to the int64 (descriptor, start) work-block table */
+     * i: n_desc, n_work_blocks, byte offset from r7 to the int64 (descriptor, start) work-block table, LDS bytes
+     * A work block (k, start) with k >= 0 covers TILE_CHUNK (2048) consecutive elements of descriptor k; a block
+     * (~k, a0 | i0 << 24) with ~k < 0 is a ROW block: elements [i0, i0 + _pad) of row a0 of descriptor k moved through LDS (4-D
+     * kernels with kh * kw > 1, mode 0, S[1] == 1, E[2..3] == T[2..3] == R[2..3]); i3 = max floats * 4 it needs */
     GHN3_OP_TILE_FWD = 8,
     /* sum over predicted tensors of ||p||_F (trainer.py:97-98,288-294)
      * r0=loss(1 float, accumulated) r1=flat r2=seg_off(int64 (begin,end) pairs) r3=norms(n floats) ; i: n_seg */
@@ -167,7 +170,7 @@ enum ghn3_op_kind {
     /* r0=dflat r1=flat r2=seg_off r3=norms ; i: n_seg ; f0 = upstream grad */
     GHN3_OP_PARAM_NORM_BWD = 10,
     /* r0=dflat, r1..r6 = source buffers (values), r7=desc, r8..r13 = source-grad buffers
-     * i: n_desc, n_work_blocks, byte offset from r7 to the backward work-block table */
+     * i: n_desc, n_work_blocks, byte offset from r7 to the backward work-block table, LDS bytes (row blocks) */
     GHN3_OP_TILE_BWD = 11,
     /* column sums: out[omap(n)] += sum_m X[g(m)][n] ; r0=out r1=X r2=row gather (int32) or absent
      * i: M,N,ld,q,s,stride,accum(must be 1) ; omap(n) = ((n/q)*s + n%q)*stride (q == 0: n*stride) */

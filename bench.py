@@ -152,18 +152,25 @@ def main():
     phases = None
     if args.profile_ops and rank == 0:
         ev = [L.Event() for _ in range(4)]
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
         ev[0].record(stream)
         ghn._run_forward(plan)
         ev[1].record(stream)
+        h1 = time.perf_counter()
         ghn._fill_bufs(plan, out=plan.out, dout=dout)
         ctx.run(f_norm, prog.problems, plan.bufs, stream)
         ctx.run(b_norm, prog.problems, plan.bufs, stream)
         ev[2].record(stream)
+        h2 = time.perf_counter()
         ghn._run_backward(plan, dout)
         ev[3].record(stream)
+        h3 = time.perf_counter()
         torch.cuda.synchronize()
         phases = {'forward': round(ev[0].elapsed_ms(ev[1]), 3), 'loss_norms': round(ev[1].elapsed_ms(ev[2]), 3),
-                  'backward': round(ev[2].elapsed_ms(ev[3]), 3)}
+                  'backward': round(ev[2].elapsed_ms(ev[3]), 3),
+                  'host_enqueue': {'forward': round(1e3 * (h1 - h0), 3), 'loss_norms': round(1e3 * (h2 - h1), 3),
+                                   'backward': round(1e3 * (h3 - h2), 3)}}
         ctx.profile(1)
         ctx.profile_read(reset=True)
         step()

@@ -86,7 +86,12 @@ extern "C" int ghn3_ctx_create(ghn3_ctx** out) {
     for (int i = 0; i < kStageSlots; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
     HIPCHK(hipEventCreate(&c->pe0));
     HIPCHK(hipEventCreate(&c->pe1));
-    HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    {
+        // lowest priority: the side stream only fills what the dependent chain on the caller's stream leaves idle
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&c->side, hipStreamNonBlocking, least));
+    }
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
     c->side_enabled = !(getenv("GHN3_NO_SIDE_STREAM") && atoi(getenv("GHN3_NO_SIDE_STREAM")) != 0);
@@ -269,7 +274,6 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             g.a_q = p.a_q; g.a_s = p.a_s; g.b_q = p.b_q; g.b_s = p.b_s; g.c_q = p.c_q; g.c_s = p.c_s;
                             g.bias_q = p.bias_q; g.bias_s = p.bias_s; g.bias_stride = p.bias_stride ? p.bias_stride : 1;
                             g.act = p.act; g.dact = p.dact; g.flags = p.flags; g.alpha = p.alpha;
-                            { static int dbg = getenv("GHN3_DBG") ? atoi(getenv("GHN3_DBG")) : 0; g._pad = dbg; }
                             if ((p.flags & GHN3_GEMM_BIASGRAD) && (p.a_mode != GHN3_MODE_COL || !g.bias)) {
                                 ghn3_set_error("op %d problem %d: BIASGRAD needs a COL-mode A and a bias ref", k, q);
                                 return GHN3_E_ARG;

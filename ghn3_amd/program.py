@@ -396,7 +396,6 @@ class Program:
         self.ldT, self.ldK = ldT, ldK
         train = self.training
 
-        self._cast_w2()
         node_off = np.cumsum([0] + self.n_nodes[:-1]).astype(np.int32)
         r_types = self.idx(self.node_types)
         r_shape = self.idx(self.shape_idx.astype(np.int32))
@@ -437,6 +436,7 @@ class Program:
         self.op(L.OP_BIAS_GATHER, refs=(bias, T, pair), ints=(B, N, H))
 
         # ---- Graphormer layers --------------------------------------------------------------------
+        self._cast_w2()            # side stream, under the Graphormer (issued once the main stream is busy)
         x_in = x0
         for l in range(self.Lyr):
             pre = 'gnn.%d.' % l

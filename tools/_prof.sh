@@ -2,9 +2,22 @@ cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
 rm -rf /tmp/prof16
-rocprofv3 --kernel-trace --stats -d /tmp/prof16 -o r -- python3 bench.py --compute f16 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/prof_bench16.json 2> gpurun_out/prof_err.log
-DB=$(find /tmp/prof16 -name "*.db" | head -1)
-echo "db: $DB"
-python3 tools/rocprof_summary.py "$DB" gpurun_out/prof16_stats.txt "rocprofv3 --kernel-trace --stats -- python3 bench.py --compute f16 --steps 5 --warmup 2 --no-cpu-baseline (ghn3xlm16, 256-node graph)" 7
-head -45 gpurun_out/prof16_stats.txt | cut -c1-175
-tail -2 gpurun_out/prof_bench16.json | cut -c1-300
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof16 -o r -- python3 bench.py --compute f16 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_bench16.json 2> gpurun_out/prof_err.log
+find /tmp/prof16 -type f | head
+F=$(find /tmp/prof16 -name "*kernel_trace.csv" | head -1)
+python3 - "$F" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+print(len(rows), rows[0].keys())
+# keep the last ~1/3 (last step): find by time
+rows.sort(key=lambda r: int(r['Start_Timestamp']))
+t_end = int(rows[-1]['End_Timestamp'])
+out = open('gpurun_out/trace_last_step.csv', 'w')
+out.write('start_us,dur_us,queue,kernel\n')
+for r in rows:
+    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
+    if t_end - s < 20e6:   # last 20 ms
+        out.write('%.2f,%.2f,%s,%s\n' % ((s - (t_end - 20e6)) / 1e3, (e - s) / 1e3, r.get('Queue_Id', ''), r['Kernel_Name'][:60].replace(',', ';')))
+out.close()
+PY
+wc -l gpurun_out/trace_last_step.csv

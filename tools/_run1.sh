@@ -1,15 +1,15 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -15 > gpurun_out/t16.log
-timeout 300 python bench.py --compute f16 --no-cpu-baseline --steps 10 --warmup 3 --profile-ops > gpurun_out/b_f16_0.log 2>&1
-cat gpurun_out/t16.log
+for m in 0 6 4; do
+GHN3_SIDE_CU_MASK=$m timeout 300 python bench.py --compute f16 --no-cpu-baseline --steps 10 --warmup 3 --profile-ops > gpurun_out/b_f16_m$m.log 2>&1
+done
 python - <<'PY'
 import json
-for f in ('gpurun_out/b_f16_0.log',):
+for m in (0, 6, 4):
+  f = 'gpurun_out/b_f16_m%d.log' % m
   for l in open(f):
     if l.startswith('{'):
         d = json.loads(l)
         print(f, d['ms_per_step'], d['value'], d['roofline']['achieved'], d['phase_ms'])
-        print({k: (v['ms_per_step'], v.get('tflops')) for k, v in d['roofline']['kernels'].items()})
+    elif 'rror' in l: print(l[:200])
 PY
-tail -3 gpurun_out/b_f16_0.log | cut -c1-200

@@ -218,7 +218,60 @@ def make_ghn3_goldens():
     assert counts['ghn3xlm16'] == 654365184, counts     # examples/ghn_all_pytorch.ipynb:109
 
 
+# ------------------------------------------------------------------------------------------------
+# 3. torchvision-shaped ResNets through the reference GHN3 class at the released sizes (BASELINE configs 1 and 4):
+#    ghn3tm8 on the ResNet-18 graph, ghn3xlm16 on the ResNet-50 graph.  Stores per predicted tensor the Frobenius
+#    norm and a seeded sample of its elements (the tensors themselves are 11.7 M / 25.6 M floats).
+# ------------------------------------------------------------------------------------------------
+
+def make_resnet_goldens(which=('18', '50')):
+    install_standins()
+    sys.path.insert(0, REF)
+    import ghn3                                              # noqa: F401  the reference package
+    from ghn3.nn import GHN3
+    from ghn3.graph import Graph, GraphBatch
+    import time
+    for depth, variant in ((18, 'ghn3tm8'), (50, 'ghn3xlm16')):
+        if str(depth) not in which:
+            continue
+        hid, layers, heads = recipe.VARIANTS[variant]
+        cfg = dict(max_shape=(hid, hid, 16, 16), num_classes=1000, hid=hid, heads=heads, layers=layers,
+                   weight_norm=True, ve=True, layernorm=True)
+        torch.manual_seed(0)
+        ghn = GHN3(**cfg, debug_level=0)
+        shapes = {k: tuple(v.shape) for k, v in ghn.state_dict().items()}
+        sd = recipe.seeded_state_dict(shapes, seed=recipe.RESNET_SEED)
+        ghn.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        del sd
+        spec = recipe.resnet_spec(depth)
+        net = recipe.build_torch_net(spec)
+        node_feat, node_info, A = recipe.graph_arrays(spec)
+        g = Graph(node_feat=torch.from_numpy(node_feat), node_info=node_info, A=torch.from_numpy(A), dense=True)
+        batch = GraphBatch([g], dense=True)
+        ghn.eval()
+        t0 = time.time()
+        with torch.no_grad():
+            net_out, emb = ghn(net, batch, return_embeddings=True, bn_track_running_stats=True, reduce_graph=False)
+        print('resnet%d / %s: reference forward %.1f s' % (depth, variant, time.time() - t0))
+        out = {'meta/variant': np.asarray([variant]), 'emb': emb.detach().numpy().astype(np.float32)}
+        total = 0
+        for name, p in recipe.named_predicted(net_out):
+            v = p.detach().reshape(-1)
+            total += v.numel()
+            idx = recipe.sample_indices(v.numel(), recipe.RESNET_SAMPLES, seed=len(name))
+            out['pred/%s/norm' % name] = np.asarray([float(v.double().norm())])
+            out['pred/%s/sample' % name] = v[idx].numpy().astype(np.float32)
+        out['meta/n_predicted'] = np.asarray([total], dtype=np.int64)
+        np.savez_compressed(os.path.join(HERE, 'resnet%d_%s.npz' % (depth, variant)), **out)
+        print('resnet%d_%s.npz: %d predicted params' % (depth, variant, total))
+
+
 if __name__ == '__main__':
-    torch.set_num_threads(4)
-    make_graphormer_goldens()
-    make_ghn3_goldens()
+    # python make_golden.py            -> tiny fixtures (seconds)
+    # python make_golden.py resnet     -> + ResNet-18 / ghn3tm8 and ResNet-50 / ghn3xlm16 (minutes, ~10 GB of RAM)
+    torch.set_num_threads(8 if 'resnet' in sys.argv[1:] else 4)
+    if 'resnet' in sys.argv[1:]:
+        make_resnet_goldens()
+    else:
+        make_graphormer_goldens()
+        make_ghn3_goldens()

@@ -150,7 +150,10 @@ def graph_arrays(spec):
         info.append((i, pname if pname is not None else prim, prim, sz,
                      i == n - 2 and pname is not None and pname.endswith('.weight'),
                      i == n - 1 and pname is not None and pname.endswith('.bias')))
-    edges = [(i, i + 1) for i in range(n - 1)] + list(spec.get('skips', []))
+    if 'edges' in spec:
+        edges = list(spec['edges'])
+    else:
+        edges = [(i, i + 1) for i in range(n - 1)] + list(spec.get('skips', []))
     return node_feat, [info], spd_from_edges(n, edges, 50)
 
 
@@ -186,6 +189,58 @@ def build_torch_net(spec, encoder_cls=None):
             assert tuple(m.weight.shape) == tuple(sz), (m.weight.shape, sz)
         net.add_module(mname, m)
     return net
+
+
+# ------------------------------------------------------------------------------------------------
+# torchvision-shaped ResNets (BASELINE configs 1 and 4): layer shapes and topology of torchvision.models.resnet18 /
+# resnet50 written out by hand (torchvision is not installed); 53 / 127 graph nodes, 11,689,512 / 25,557,032 params.
+# ------------------------------------------------------------------------------------------------
+
+def resnet_spec(depth):
+    assert depth in (18, 50)
+    bottleneck = depth == 50
+    blocks = [2, 2, 2, 2] if depth == 18 else [3, 4, 6, 3]
+    exp = 4 if bottleneck else 1
+    nodes, edges = [('input', None, None)], []
+
+    def add(prim, name, shape, srcs):
+        nodes.append((prim, name, shape))
+        for s_ in srcs:
+            edges.append((s_, len(nodes) - 1))
+        return len(nodes) - 1
+
+    x = add('conv', 'conv1.weight', (64, 3, 7, 7), [0])
+    x = add('bn', 'bn1.weight', (64,), [x])
+    x = add('max_pool', None, None, [x])
+    cin = 64
+    for li, (nb, planes) in enumerate(zip(blocks, (64, 128, 256, 512))):
+        for b in range(nb):
+            pre = 'layer%d_%d_' % (li + 1, b)
+            y = x
+            if bottleneck:
+                convs = [(planes, cin, 1, 1), (planes, planes, 3, 3), (planes * 4, planes, 1, 1)]
+            else:
+                convs = [(planes, cin, 3, 3), (planes, planes, 3, 3)]
+            for k, sz in enumerate(convs):
+                y = add('conv', '%sconv%d.weight' % (pre, k + 1), sz, [y])
+                y = add('bn', '%sbn%d.weight' % (pre, k + 1), (sz[0],), [y])
+            srcs = [y]
+            if b == 0 and (li > 0 or bottleneck):
+                d = add('conv', pre + 'downsample_0.weight', (planes * exp, cin, 1, 1), [x])
+                d = add('bn', pre + 'downsample_1.weight', (planes * exp,), [d])
+                srcs.append(d)
+            else:
+                srcs.append(x)
+            x = add('sum', None, None, srcs)
+            cin = planes * exp
+    x = add('glob_avg', None, None, [x])
+    x = add('conv', 'fc.weight', (1000, cin), [x])
+    add('bias', 'fc.bias', (1000,), [x])
+    return dict(nodes=nodes, edges=edges)
+
+
+RESNET_SEED = 777
+RESNET_SAMPLES = 2048
 
 
 def named_predicted(net):

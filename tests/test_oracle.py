@@ -152,3 +152,36 @@ def test_group_keys():
     assert R.group_key((1000, 2048), ms, True, False) == (384, 384)
     assert R.group_key((1000,), ms, False, True) == (384, -1)
     assert R.group_key((1, 197, 768), ms, False, False) == (1, 768, 14, 14)
+
+
+def test_oracle_matches_reference_on_resnet18_ghn3tm8():
+    """The oracle at a released size on a real architecture: ghn3tm8 on the torchvision.resnet18-shaped graph vs the
+    golden written by the reference GHN3 class (make_golden.py resnet)."""
+    import os
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'resnet18_ghn3tm8.npz'))
+    hid, layers, heads = recipe.VARIANTS['ghn3tm8']
+    cfg = dict(max_shape=(hid, hid, 16, 16), num_classes=1000, hid=hid, heads=heads, layers=layers,
+               weight_norm=True, ve=True, layernorm=True)
+    oracle = R.GHN3Ref(**cfg)
+    shapes = {k: tuple(v.shape) for k, v in oracle.state_dict().items()}
+    sd = recipe.seeded_state_dict(shapes, seed=recipe.RESNET_SEED)
+    oracle.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+    oracle.eval()
+    spec = recipe.resnet_spec(18)
+    net = recipe.build_torch_net(spec)
+    nf, info, A = recipe.graph_arrays(spec)
+    gb = R.GraphBatchRef([R.GraphRef(torch.from_numpy(nf), info, torch.from_numpy(A))])
+    with torch.no_grad():
+        _, pred, emb = oracle([net], gb, return_embeddings=True)
+    assert np.linalg.norm(emb.numpy() - gold['emb']) < 1e-5 * np.linalg.norm(gold['emb'])
+    total = 0
+    mod_name = {id(m): n for n, m in net.named_children()}
+    for (ind, attr, m, t) in pred:
+        name = '%s.%s' % (mod_name[id(m)], attr)
+        v = t.detach().reshape(-1)
+        total += v.numel()
+        idx = recipe.sample_indices(v.numel(), recipe.RESNET_SAMPLES, seed=len(name))
+        ref = gold['pred/%s/sample' % name]
+        err = np.linalg.norm(v[idx].numpy() - ref) / (np.linalg.norm(ref) + 1e-30)
+        assert err < 1e-5, (name, err)
+    assert total == int(gold['meta/n_predicted'][0]) == 11689512

@@ -1,23 +1,10 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-rm -rf /tmp/prof16
-rocprofv3 --kernel-trace --output-format csv -d /tmp/prof16 -o r -- python3 bench.py --compute f16 --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/prof_bench16.json 2> gpurun_out/prof_err.log
-find /tmp/prof16 -type f | head
-F=$(find /tmp/prof16 -name "*kernel_trace.csv" | head -1)
-python3 - "$F" <<'PY'
-import csv, sys
-rows = list(csv.DictReader(open(sys.argv[1])))
-print(len(rows), rows[0].keys())
-# keep the last ~1/3 (last step): find by time
-rows.sort(key=lambda r: int(r['Start_Timestamp']))
-t_end = int(rows[-1]['End_Timestamp'])
-out = open('gpurun_out/trace_last_step.csv', 'w')
-out.write('start_us,dur_us,queue,kernel\n')
-for r in rows:
-    s, e = int(r['Start_Timestamp']), int(r['End_Timestamp'])
-    if t_end - s < 20e6:   # last 20 ms
-        out.write('%.2f,%.2f,%s,%s\n' % ((s - (t_end - 20e6)) / 1e3, (e - s) / 1e3, r.get('Queue_Id', ''), r['Kernel_Name'][:60].replace(',', ';')))
-out.close()
-PY
-wc -l gpurun_out/trace_last_step.csv
+for c in f16 f32; do
+rm -rf /tmp/prof_$c
+rocprofv3 --kernel-trace --stats -d /tmp/prof_$c -o r -- python3 bench.py --compute $c --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/r01c_bench_under_rocprof_xl_$c.json 2> gpurun_out/prof_err_$c.log
+DB=$(find /tmp/prof_$c -name "*.db" | head -1)
+python3 tools/rocprof_summary.py "$DB" gpurun_out/r01c_rocprof_kernel_stats_xl_$c.txt "rocprofv3 --kernel-trace --stats -- python3 bench.py --compute $c --steps 5 --warmup 2 --no-cpu-baseline (ghn3xlm16, one 256-node graph, side stream on)" 7
+done
+head -30 gpurun_out/r01c_rocprof_kernel_stats_xl_f16.txt | cut -c1-170

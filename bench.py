@@ -86,6 +86,11 @@ def main():
     ap.add_argument('--cpu-sample-nodes', type=int, default=32)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-ops', action='store_true', help='print per-op-kind time of one extra step')
+    ap.add_argument('--grad-allreduce', default=os.environ.get('GHN3_GRAD_ALLREDUCE', 'bf16'),
+                    choices=['f32', 'bf16', 'f32-serial'],
+                    help='N > 1: gradient exchange.  bf16 / f32 = two-phase all-reduce overlapped with the backward '
+                         '(bf16 copies on the wire or fp32); f32-serial = one fp32 all-reduce after the backward')
+    ap.add_argument('--force-ddp', action='store_true', help='run the N > 1 code path in a 1-rank group (testing)')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -96,12 +101,18 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the GHN-3 path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-    if world > 1:
+    ddp = world > 1 or args.force_ddp
+    if ddp:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
     from ghn3_amd import GHN3, _lib as L
     from ghn3_amd.synthetic import synthetic_batch
-    from ghn3_amd.ddp_utils import all_reduce_flat_grads
+    from ghn3_amd.ddp_utils import all_reduce_flat_grads_avg as all_reduce_flat_grads, FlatGradReducer
+    reducer = None
+    if ddp and args.grad_allreduce != 'f32-serial':
+        reducer = FlatGradReducer(compress='bf16' if args.grad_allreduce == 'bf16' else None, force=args.force_ddp)
 
     torch.manual_seed(0)                                   # identical random-init GHN weights on every rank
     ghn = GHN3(**model_cfg(args.model), compute=args.compute).to(dev)
@@ -121,8 +132,8 @@ def main():
         ghn._fill_bufs(plan, out=plan.out, dout=dout)
         ctx.run(f_norm, prog.problems, plan.bufs, stream)
         ctx.run(b_norm, prog.problems, plan.bufs, stream)
-        ghn._run_backward(plan, dout)
-        if world > 1:
+        ghn._run_backward(plan, dout, reducer=reducer)
+        if ddp and reducer is None:
             all_reduce_flat_grads(plan.gflat)
 
     for _ in range(args.warmup):
@@ -207,7 +218,8 @@ def main():
                                    'params per GPU, loss = sum of Frobenius norms of the predicted tensors'
                                    % (args.model, args.graphs_per_gpu, args.nodes, args.nodes * 1000, n_pred),
                        'ghn_params': int(ghn._flat_numel), 'decoder_rows': int(prog.M),
-                       'parallelism': 'dp%d' % world, 'index_mode': ghn.index_mode},
+                       'parallelism': 'dp%d' % world, 'index_mode': ghn.index_mode,
+                       'grad_allreduce': (args.grad_allreduce if ddp else None)},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': None,
                          'kernel': 'decoder W2 grouped GEMM (fwd + dgrad + wgrad), %s MFMA operands' % args.compute,

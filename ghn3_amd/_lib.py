@@ -43,14 +43,14 @@ COMPUTE_TYPES = {'f32': CT_F32, 'f16': CT_F16, 'bf16': CT_BF16}
 (OP_NOP, OP_GEMM, OP_GRAPH_PROLOGUE, OP_EMBED_NODES, OP_EDGE_HIDDEN, OP_BIAS_GATHER, OP_LAYERNORM_FWD,
  OP_ATTN_FWD, OP_TILE_FWD, OP_PARAM_NORM_FWD, OP_PARAM_NORM_BWD, OP_TILE_BWD, OP_COLSUM, OP_ROWSEG_SUM,
  OP_LAYERNORM_BWD, OP_LN_PARAM_GRAD, OP_ATTN_BWD, OP_BIAS_HIST, OP_EDGE_HIDDEN_BWD, OP_EMBED_BWD, OP_MEMSET0,
- OP_ADD, OP_DACT, OP_CAST16, OP_JOIN, OP_KIND_COUNT) = range(26)
+ OP_ADD, OP_DACT, OP_CAST16, OP_JOIN, OP_DETACH, OP_KIND_COUNT) = range(27)
 OP_NAMES = ['nop', 'gemm', 'graph_prologue', 'embed_nodes', 'edge_hidden', 'bias_gather', 'layernorm_fwd',
             'attn_fwd', 'tile_fwd', 'param_norm_fwd', 'param_norm_bwd', 'tile_bwd', 'colsum', 'rowseg_sum',
             'layernorm_bwd', 'ln_param_grad', 'attn_bwd', 'bias_hist', 'edge_hidden_bwd', 'embed_bwd', 'memset0',
-            'add', 'dact', 'cast16', 'join']
+            'add', 'dact', 'cast16', 'join', 'detach']
 
 EXPORTS = ['ghn3_abi_version', 'ghn3_last_error', 'ghn3_ctx_create', 'ghn3_ctx_destroy',
-           'ghn3_ctx_set_compute_type', 'ghn3_run', 'ghn3_event_create', 'ghn3_event_record',
+           'ghn3_ctx_set_compute_type', 'ghn3_ctx_side_wait', 'ghn3_run', 'ghn3_event_create', 'ghn3_event_record',
            'ghn3_event_elapsed_ms', 'ghn3_event_destroy', 'ghn3_profile_enable', 'ghn3_profile_read',
            'ghn3_profile_read_tags']
 OPFLAG_TIMED = 0x100
@@ -80,6 +80,7 @@ def load():
         lib.ghn3_ctx_destroy.argtypes = [ctypes.c_void_p]
         lib.ghn3_ctx_destroy.restype = None
         lib.ghn3_ctx_set_compute_type.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        lib.ghn3_ctx_side_wait.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.ghn3_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                  ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         lib.ghn3_event_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
@@ -120,6 +121,10 @@ class Context:
                                 problems.ctypes.data if len(problems) else None, len(problems),
                                 buf_ptrs.ctypes.data, len(buf_ptrs), ctypes.c_void_p(stream))
         _check(rc, 'ghn3_run')
+
+    def side_wait(self, stream):
+        """Make `stream` (a hipStream_t as int) wait for the side-stream work issued so far."""
+        _check(self._lib.ghn3_ctx_side_wait(self._h, ctypes.c_void_p(stream)), 'ghn3_ctx_side_wait')
 
     def profile(self, mode):
         """0 off, 1 every op (synchronising), 2 only ops flagged OPFLAG_TIMED (no sync until read_tags)."""

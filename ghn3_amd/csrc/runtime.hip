@@ -57,6 +57,7 @@ struct ghn3_ctx {
     hipStream_t side;
     hipEvent_t ev_fork, ev_join;
     bool side_enabled;
+    bool side_pending;     // a run ended with GHN3_OP_DETACH: its side-stream work has not been joined yet
 };
 
 static int ctx_reserve(ghn3_ctx* c, size_t n) {
@@ -317,7 +318,9 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
     // side stream waits for everything the main stream has been given so far (program order = dependency order);
     // the main stream waits for the side stream at GHN3_OP_JOIN and at the end of the run.
     hipStream_t const main_stream = stream;
-    bool main_dirty = true, side_dirty = false;
+    bool main_dirty = true, side_dirty = c->side_pending;
+    bool detach = false;
+    c->side_pending = false;
     auto join = [&]() -> int {
         if (side_dirty) {
             HIPCHK(hipEventRecord(c->ev_join, c->side));
@@ -332,6 +335,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         R.bad = false;
         const bool on_side = (o.flags & GHN3_OPFLAG_SIDE) && c->side_enabled && c->profile != 1;
         if (o.kind == GHN3_OP_JOIN) { rc = join(); if (rc) return rc; continue; }
+        if (o.kind == GHN3_OP_DETACH) { detach = true; continue; }
+        detach = false;
         if (on_side) {
             if (main_dirty) {
                 HIPCHK(hipEventRecord(c->ev_fork, main_stream));
@@ -505,7 +510,15 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             c->launches[o.kind] += 1;
         }
     }
+    if (detach && side_dirty) { c->side_pending = true; return GHN3_OK; }   // joined by the next run / ghn3_ctx_side_wait
     return join();
+}
+
+extern "C" int ghn3_ctx_side_wait(ghn3_ctx* c, void* stream) {
+    if (!c) return GHN3_E_NOCTX;
+    HIPCHK(hipEventRecord(c->ev_join, c->side));
+    HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_join, 0));
+    return GHN3_OK;
 }
 
 // ---- timing helpers -----------------------------------------------------------------------------

@@ -278,14 +278,33 @@ class GHN3(nn.Module):
         plan.out = out
         return out
 
-    def _run_backward(self, plan, dout):
+    def decoder_grad_range(self, prog):
+        """[begin, end) of the decoder parameters in the flat gradient buffer (floats)."""
+        lo, hi = prog.decoder_slots
+        return int(self._offs[lo]), int(self._offs[hi]) if hi < len(self._offs) else int(self._flat_numel)
+
+    def _run_backward(self, plan, dout, reducer=None):
+        """reducer (data parallel, ddp_utils.FlatGradReducer): the backward program runs in two parts; the all-reduce
+        of the decoder gradients (93 % of the bytes at ghn3xlm16) starts as soon as the side stream has produced them
+        and overlaps with the Graphormer backward; the remaining gradients are reduced at the end."""
         prog = plan.program
         if len(prog.bwd_ops) == 0:
             raise L.Ghn3Error('this plan was compiled without a backward program (training=False)')
         gflat = torch.empty(self._flat_numel, dtype=torch.float32, device=self.device)
         self._fill_bufs(plan, out=plan.out, dout=dout, gflat=gflat)
         self._patch_grad_memsets(prog)
-        self._ctx().run(prog.bwd_ops, prog.problems, plan.bufs, torch.cuda.current_stream().cuda_stream)
+        stream = torch.cuda.current_stream().cuda_stream
+        if reducer is None:
+            self._ctx().run(prog.bwd_ops, prog.problems, plan.bufs, stream)
+        else:
+            ctx = self._ctx()
+            k = prog.memset_grad_op                      # (the memset placeholders live in the first part)
+            prog.bwd_ops_a[k:k + 2] = prog.bwd_ops[k:k + 2]
+            ctx.run(prog.bwd_ops_a, prog.problems, plan.bufs, stream)
+            lo, hi = self.decoder_grad_range(prog)
+            reducer.start(gflat, lo, hi, wait_for=ctx.side_wait)
+            ctx.run(prog.bwd_ops_b, prog.problems, plan.bufs, stream)
+            reducer.finish(gflat)
         plan.gflat = gflat
         ps = self._slot_params()
         return [gflat[o:o + p.numel()].view(p.shape) for p, o in zip(ps, self._offs)]

@@ -116,6 +116,13 @@ class Program:
         if training:
             self._build_backward()
             self.bwd_ops = self._finish_ops()
+            detach = np.zeros(1, dtype=L.OP_DT)
+            detach['kind'] = L.OP_DETACH
+            detach['r']['buf'][:] = -1
+            self.bwd_ops_a = np.concatenate([self.bwd_ops[:self.bwd_split], detach])
+            self.bwd_ops_b = self.bwd_ops[self.bwd_split:]
+            # flat-gradient slots of the decoder parameters (contiguous in the parameter order)
+            self.decoder_slots = (self.slot['decoder.fc.0.weight'], self.slot['bias_class.1.bias'] + 1)
         else:
             self.bwd_ops = np.zeros(0, dtype=L.OP_DT)
         self.problems = np.array(self._probs, dtype=L.PROBLEM_DT) if self._probs else np.zeros(0, dtype=L.PROBLEM_DT)
@@ -950,6 +957,9 @@ class Program:
             p0 = self.gemm(d_h1d, xe, self.gref(W1), 2 * C, C, n1, 2 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
                            b_gather=self.r_src1, accum=True, dbias=self.gref(b1))
             self.gemm_op(p0, side=True)
+        # Everything above produces the decoder gradients (93 % of the gradient bytes at XL); a data-parallel caller
+        # may run the program in two parts (bwd_ops[:bwd_split] + DETACH, then the rest) and start their all-reduce here.
+        self.bwd_split = len(self._ops)
         # ---- d_xe[row] = sum of the decoder rows that read it (deterministic gather-sum) -----------------
         all_src = np.concatenate([self.row_src, self.oned_src]) if (M + n1) else np.zeros(0, dtype=np.int32)
         order = np.argsort(all_src, kind='stable').astype(np.int32)

@@ -205,6 +205,10 @@ enum ghn3_op_kind {
     GHN3_OP_CAST16 = 23,
     /* the run's stream waits for every GHN3_OPFLAG_SIDE op issued so far (no refs) */
     GHN3_OP_JOIN = 24,
+    /* as the LAST op of a run: return without joining the side stream; the pending side work is joined by the next
+     * ghn3_run on the context (or observed with ghn3_ctx_side_wait).  Lets a caller split a program in two runs and
+     * start the gradient all-reduce of the first part's weight gradients while the second part executes. */
+    GHN3_OP_DETACH = 25,
     GHN3_OP_KIND_COUNT
 };
 
@@ -241,6 +245,10 @@ int ghn3_ctx_set_compute_type(ghn3_ctx* ctx, int ctype);
 int ghn3_run(ghn3_ctx* ctx, const ghn3_op* ops, int n_ops,
              const ghn3_gemm_problem* problems, int n_problems,
              void* const* bufs, int n_bufs, void* stream);
+
+/* Make `stream` wait for everything issued so far on the context's side stream (GHN3_OPFLAG_SIDE ops), e.g. the
+ * communication stream that all-reduces weight gradients produced there. */
+int ghn3_ctx_side_wait(ghn3_ctx* ctx, void* stream);
 
 /* Timing helper for bench.py: HIP events on `stream` (torch.cuda.Event only sees torch's current stream).
  * ghn3_event_elapsed_ms synchronises on the stop event. */

@@ -54,6 +54,9 @@ class Interp:
     def op_join(self, o, problems):
         pass                         # (the interpreter runs side-stream ops in program order)
 
+    def op_detach(self, o, problems):
+        pass
+
     @staticmethod
     def _rowmap(r, g, q, s):
         r = np.asarray(r, dtype=np.int64)

@@ -52,3 +52,36 @@ def test_flat_gradient_allreduce_and_metric_world2():
         ok_grad, ok_metric, sigs = ret[r]
         assert ok_grad and ok_metric
         assert len(set(sigs)) == world, sigs        # different target nets per rank
+
+
+def _reducer_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from ghn3_amd.ddp_utils import setup_ddp, FlatGradReducer, clean_ddp
+    setup_ddp()
+    n, lo, hi = 300007, 1000, 250001
+    base = torch.linspace(-1, 1, n)
+    oks = []
+    for compress, tol in ((None, 1e-6), ('bf16', 1e-2)):
+        g = base * (rank + 1)
+        red = FlatGradReducer(compress=compress, chunk_bytes=1 << 18)
+        red.start(g, lo, hi)                       # "decoder" range first ...
+        g[:lo] += 0.0                              # (the rest of the backward would run here)
+        red.finish(g)                              # ... then everything else
+        expect = base * (sum(range(1, world + 1)) / world)
+        oks.append(bool(torch.allclose(g, expect, rtol=tol, atol=tol * 1e-2)))
+    ret[rank] = oks
+    clean_ddp()
+
+
+def test_two_phase_flat_grad_reducer_world2():
+    """FlatGradReducer (the overlapped exchange used by bench.py / GHN3._run_backward for N > 1): decoder range
+    first, the rest afterwards; fp32 and bf16-on-the-wire give the mean over ranks."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_reducer_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        assert all(ret[r]), ret[r]

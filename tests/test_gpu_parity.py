@@ -308,3 +308,38 @@ def test_resnet50_ghn3xlm16_matches_reference_golden(compute, tol):
     """BASELINE config 4 / north star: ghn3xlm16 predicting the ResNet-50 weight tensors (127 nodes, 25,557,032
     params; output channels up to 2048 are tiled from the 384-wide decoder) within 1e-3 of the reference on CPU."""
     _resnet_fixture_check(50, 'ghn3xlm16', compute, tol)
+
+
+def test_split_backward_with_overlapped_gradient_reduction():
+    """The N > 1 execution path on one GPU: backward program run in two parts (GHN3_OP_DETACH), the decoder
+    gradients all-reduced (1-rank RCCL group) from a communication stream that waits on the side stream while the
+    Graphormer backward runs.  Gradients must equal the single-run path (fp32 exchange: bit-identical up to the
+    atomics' order; bf16 on the wire: 2^-8)."""
+    import socket
+    import torch.distributed as dist
+    from ghn3_amd.ddp_utils import FlatGradReducer
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        hip, _ = make_models(T_CFG, 7, compute='f16')
+        nets_h, gb_h, _, _ = synthetic_case([48], 4800)
+        hip.train()
+        plan = hip.compile(nets_h, gb_h, training=True)
+        hip._run_forward(plan)
+        dout = torch.randn(plan.program.out_numel, device='cuda') * 1e-3
+        hip._run_backward(plan, dout)
+        torch.cuda.synchronize()
+        ref = plan.gflat.clone()
+        for compress, tol in ((None, 2e-5), ('bf16', 1e-2)):
+            hip._run_backward(plan, dout, reducer=FlatGradReducer(compress=compress, force=True))
+            torch.cuda.synchronize()
+            err = float((plan.gflat - ref).norm() / ref.norm())
+            assert err < tol, (compress, err)
+            lo, hi = hip.decoder_grad_range(plan.program)
+            assert 0 < lo < hi <= ref.numel() and (hi - lo) > 0.5 * ref.numel()
+    finally:
+        dist.destroy_process_group()

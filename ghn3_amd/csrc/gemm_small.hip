@@ -4,11 +4,14 @@
 // K, N in {C, 3C, 4C}: a few hundred MFLOP each, far too little to fill 256 CUs with 64x64 / 128x128 tiles,
 // and with a K loop that is latency- rather than throughput-bound.  This kernel trades tile reuse for
 // parallelism and short dependency chains:
-//   * one workgroup = one 32 x 32 output tile; its 16 waves split the K range (split-K inside the workgroup,
-//     combined through 64 KB of LDS), so a C = 384 projection is ONE 32-deep chunk (12 MFMA steps) per wave and a
-//     4C = 1536 reduction three: the per-wave dependency chain is 1-3 memory round trips instead of 12-48;
-//   * operands go global -> registers -> v_mfma_f32_32x32x2_f32 directly (no LDS staging): a ROW-mode operand
-//     row is read as float4 by the two half-wave lanes that need it, a COL-mode operand as coalesced dwords;
+//   * one workgroup = one 32 x 32 output tile; its 16 waves split every 128-wide K chunk 16 ways (split-K inside
+//     the workgroup, combined through 64 KB of LDS): a C = 384 projection is 3 chunks of 4 MFMA steps per wave;
+//   * operand chunks (32 rows x 128 k) are fetched COOPERATIVELY with fully coalesced float4 loads (one per
+//     thread and operand: a ROW-mode row contributes 512 contiguous bytes, a COL-mode k-row 128), staged in
+//     double-buffered LDS and read back in MFMA layout (ROW: one conflict-free ds_read_b128 per operand and
+//     chunk) -- the former direct-to-register version touched 32 cache lines per load instruction and was
+//     bound by the L1 line rate;
+//   * the next chunk's global loads are in flight while the current one is multiplied: one barrier per chunk.
 // Same operand / epilogue contract as the tiled kernels (include/ghn3_hip.h), exact fp32.
 
 #include "ghn3_internal.h"
@@ -23,8 +26,11 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 #define ROWM GHN3_MODE_ROW
 #define COLM GHN3_MODE_COL
-#define KC 32            // K chunk per pipeline stage (16 MFMA steps)
+#define KC 128           // K chunk per pipeline stage: 16 waves x 4 MFMA steps x 2
 #define SW 16            // waves per workgroup = K slices
+#define LD_ROW 132       // LDS row stride of a ROW-mode chunk image [32][KC]   (132 % 64 == 4: b128 reads conflict free)
+#define LD_COL 36        // LDS row stride of a COL-mode chunk image [KC][32]
+#define OP_FLOATS 4608   // floats per operand image (max(32 * 132, 128 * 36))
 
 __device__ __forceinline__ int s_map_row(int r, gci gather, int q, int s) {
     if (gather) r = gather[r];
@@ -44,58 +50,65 @@ __device__ __forceinline__ float s_gelu_grad(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * 0.3989422804014327f * __expf(-0.5f * x * x);
 }
 
-// One operand of the 32-row tile.  lane = (i = lane & 31, h = lane >> 5); MFMA step s of a chunk consumes
-// element (row i, k = k0 + 2 s + h).
+// Cooperative fetch of one operand chunk: 1024 threads x one float4.
+//   ROW mode: thread -> (row = tid / 32, k = 4 (tid % 32));  COL mode: thread -> (k = tid / 8, row = 4 (tid % 8)).
 template <int MODE>
-struct SmallOperand {
-    gcf base; gci gather; int q, s, ld;
-    int row, k_end, h;
-    bool row_ok;
-    gcf rptr;                      // ROW mode: start of this lane's row
-    f32x4 raw4[KC / 4];            // ROW mode: 8 float4 per chunk
-    float raw1[KC / 2];            // COL mode: 16 dwords per chunk
+struct ChunkLoader {
+    gcf base; gci gather; int q, s, ld, rows, K, origin;
+    gcf rptr;          // ROW: start of this thread's row
+    bool row_ok;       // ROW: row inside the matrix
+    int r, c;          // ROW: (row, 4-float column)   COL: (k row, 4-float row group)
 
-    __device__ __forceinline__ void init(const float* b, const int* g, int q_, int s_, int ld_, int rows, int origin,
-                                         int kend, int lane) {
-        base = (gcf)b; gather = (gci)g; q = q_; s = s_; ld = ld_; k_end = kend;
-        row = origin + (lane & 31); h = lane >> 5;
-        row_ok = row < rows;
-        if (MODE == ROWM) rptr = base + (int64_t)s_map_row(row_ok ? row : 0, gather, q, s) * ld;
-    }
-    __device__ __forceinline__ void issue(int k0) {
+    __device__ __forceinline__ void init(const float* b, const int* g, int q_, int s_, int ld_, int rows_, int K_,
+                                         int origin_, int tid) {
+        base = (gcf)b; gather = (gci)g; q = q_; s = s_; ld = ld_; rows = rows_; K = K_; origin = origin_;
         if (MODE == ROWM) {
-#pragma unroll
-            for (int c = 0; c < KC / 4; ++c) {
-                f32x4 x = {0.f, 0.f, 0.f, 0.f};
-                if (row_ok && k0 + 4 * c < k_end) x = *reinterpret_cast<gcf4>(rptr + k0 + 4 * c);
-                raw4[c] = x;
+            r = tid >> 5; c = (tid & 31) * 4;
+            row_ok = origin + r < rows;
+            rptr = base + (int64_t)s_map_row(row_ok ? origin + r : 0, gather, q, s) * ld;
+        } else {
+            r = tid >> 3; c = (tid & 7) * 4;
+        }
+    }
+    __device__ __forceinline__ f32x4 load(int k0) const {
+        f32x4 x = {0.f, 0.f, 0.f, 0.f};
+        if (MODE == ROWM) {
+            const int k = k0 + c;
+            if (row_ok && k < K) {
+                if (k + 3 < K) x = *reinterpret_cast<gcf4>(rptr + k);
+                else { x.x = rptr[k]; if (k + 1 < K) x.y = rptr[k + 1]; if (k + 2 < K) x.z = rptr[k + 2]; }
             }
         } else {
-#pragma unroll
-            for (int st = 0; st < KC / 2; ++st) {
-                const int k = k0 + 2 * st + h;
-                float x = 0.f;
-                if (row_ok && k < k_end) x = base[(int64_t)s_map_row(k, gather, q, s) * ld + row];
-                raw1[st] = x;
+            const int k = k0 + r, row = origin + c;
+            if (k < K && row < rows) {
+                gcf p = base + (int64_t)s_map_row(k, gather, q, s) * ld + row;
+                if (row + 3 < rows) x = *reinterpret_cast<gcf4>(p);
+                else { x.x = p[0]; if (row + 1 < rows) x.y = p[1]; if (row + 2 < rows) x.z = p[2]; }
             }
         }
+        return x;
     }
-    // element consumed by MFMA step st of the chunk that starts at k0
-    __device__ __forceinline__ float value(int st, int k0) const {
-        if (MODE == ROWM) {
-            const f32x4 x = raw4[st >> 1];
-            const float lo = (st & 1) ? x.z : x.x, hi = (st & 1) ? x.w : x.y;
-            const float val = h ? hi : lo;
-            return (k0 + 2 * st + h < k_end) ? val : 0.f;
-        }
-        return raw1[st];
+    __device__ __forceinline__ void store(float* img, f32x4 x) const {
+        if (MODE == ROWM) *reinterpret_cast<f32x4*>(img + r * LD_ROW + c) = x;
+        else *reinterpret_cast<f32x4*>(img + r * LD_COL + c) = x;
+    }
+    // the 4 operand values of lane (i, h) for the 4 MFMA steps of wave w: k = 8 w + 4 h + step
+    static __device__ __forceinline__ f32x4 fragment(const float* img, int w, int i, int h) {
+        const int k = 8 * w + 4 * h;
+        if (MODE == ROWM) return *reinterpret_cast<const f32x4*>(img + i * LD_ROW + k);
+        f32x4 x;
+        x.x = img[k * LD_COL + i]; x.y = img[(k + 1) * LD_COL + i];
+        x.z = img[(k + 2) * LD_COL + i]; x.w = img[(k + 3) * LD_COL + i];
+        return x;
     }
 };
 
 template <int AM, int BMD>
 __global__ __launch_bounds__(1024) void gemm_small_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
-    __shared__ float red[SW][16][64];
-    __shared__ float bgs[SW][64];
+    // two stages x (A image + B image); the split-K reduction buffers alias them after the K loop
+    __shared__ __attribute__((aligned(16))) float lds[4 * OP_FLOATS + SW * 64];
+    float (*red)[16][64] = reinterpret_cast<float (*)[16][64]>(lds);         // [SW][16][64] = 16384 floats
+    float (*bgs)[64] = reinterpret_cast<float (*)[64]>(lds + 4 * OP_FLOATS); // [SW][64]
     int lo = 0, hi_ = n_probs - 1;
     while (lo < hi_) {
         int mid = (lo + hi_ + 1) >> 1;
@@ -105,15 +118,12 @@ __global__ __launch_bounds__(1024) void gemm_small_kernel(const GemmProbDev* __r
     const int t = blockIdx.x - P->tile_start;
     const int m0 = (t % P->tiles_m) * 32, n0 = (t / P->tiles_m) * 32;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int li = lane & 31, lh = lane >> 5;
     const int M = P->M, N = P->N, K = P->K;
-    // K slice of this wave (multiple of 4 so that ROW-mode float4 loads stay aligned)
-    const int slice = (((K + SW - 1) / SW) + 3) / 4 * 4;
-    const int kb = w * slice;
-    const int ke = min(K, kb + slice);
 
-    SmallOperand<AM> oa; SmallOperand<BMD> ob;
-    oa.init(P->A, P->a_gather, P->a_q, P->a_s, P->lda, M, m0, ke, lane);
-    ob.init(P->B, P->b_gather, P->b_q, P->b_s, P->ldb, N, n0, ke, lane);
+    ChunkLoader<AM> la; ChunkLoader<BMD> lb;
+    la.init(P->A, P->a_gather, P->a_q, P->a_s, P->lda, M, K, m0, tid);
+    lb.init(P->B, P->b_gather, P->b_q, P->b_s, P->ldb, N, K, n0, tid);
 
     f32x16 acc;
 #pragma unroll
@@ -121,15 +131,24 @@ __global__ __launch_bounds__(1024) void gemm_small_kernel(const GemmProbDev* __r
     float bg = 0.f;
     const bool do_bg = (AM == COLM) && (P->flags & GHN3_GEMM_BIASGRAD) && n0 == 0;
 
-    // 16 waves per workgroup (4 per SIMD) hide the load latency of one another; a wave runs 1-3 chunks.
-    for (int k0 = kb; k0 < ke; k0 += KC) {
-        oa.issue(k0); ob.issue(k0);
-#pragma unroll
-        for (int st = 0; st < KC / 2; ++st) {
-            const float a = oa.value(st, k0), b = ob.value(st, k0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
-            if (AM == COLM) bg += a;
-        }
+    const int nchunks = (K + KC - 1) / KC;
+    f32x4 ra = la.load(0), rb = lb.load(0);
+    la.store(lds, ra); lb.store(lds + OP_FLOATS, rb);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        float* cur = lds + (c & 1) * 2 * OP_FLOATS;
+        float* nxt = lds + ((c + 1) & 1) * 2 * OP_FLOATS;
+        const bool more = c + 1 < nchunks;
+        if (more) { ra = la.load((c + 1) * KC); rb = lb.load((c + 1) * KC); }     // in flight during the MFMAs
+        const f32x4 a = ChunkLoader<AM>::fragment(cur, w, li, lh);
+        const f32x4 b = ChunkLoader<BMD>::fragment(cur + OP_FLOATS, w, li, lh);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+        if (AM == COLM) bg += (a.x + a.y) + (a.z + a.w);
+        if (more) { la.store(nxt, ra); lb.store(nxt + OP_FLOATS, rb); }
+        __syncthreads();          // chunk c + 1 visible; everybody is done reading chunk c (its stage is reused next)
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[w][r][lane] = acc[r];

@@ -131,6 +131,27 @@ __global__ __launch_bounds__(1024) void gemm_small_kernel(const GemmProbDev* __r
     float bg = 0.f;
     const bool do_bg = (AM == COLM) && (P->flags & GHN3_GEMM_BIASGRAD) && n0 == 0;
 
+    // Epilogue operands of this thread's output element (bias, dact input, residual, old C) do not depend on the
+    // products: they are fetched now, under the K loop, instead of as a second memory round trip at the end.
+    const int e_rl = tid >> 5, e_cl = tid & 31;
+    const int e_row = m0 + e_rl, e_col = n0 + e_cl;
+    const bool e_ok = e_row < M && e_col < N;
+    const bool accum = (P->flags & GHN3_GEMM_ACCUM) != 0;
+    const bool use_bias = P->bias && !(P->flags & GHN3_GEMM_BIASGRAD);
+    int64_t e_ci = 0;
+    float e_bias = 0.f, e_aux = 0.f, e_res = 0.f, e_old = 0.f;
+    if (e_ok) {
+        e_ci = (int64_t)s_map_row(e_row, (gci)P->c_gather, P->c_q, P->c_s) * P->ldc + e_col;
+        if (use_bias) {
+            int bi = e_col;
+            if (P->bias_q > 0) bi = (e_col / P->bias_q) * P->bias_s + (e_col % P->bias_q);
+            e_bias = ((gcf)P->bias)[(int64_t)bi * P->bias_stride];
+        }
+        if (P->dact != GHN3_DACT_NONE) e_aux = ((gcf)P->aux_in)[e_ci];
+        if (P->residual) e_res = ((gcf)P->residual)[e_ci];
+        if (accum) e_old = ((gcf)P->C)[e_ci];
+    }
+
     const int nchunks = (K + KC - 1) / KC;
     f32x4 ra = la.load(0), rb = lb.load(0);
     la.store(lds, ra); lb.store(lds + OP_FLOATS, rb);
@@ -164,41 +185,22 @@ __global__ __launch_bounds__(1024) void gemm_small_kernel(const GemmProbDev* __r
     }
 
     gf C = (gf)P->C;
-    gcf bias = (gcf)P->bias;
-    gcf residual = (gcf)P->residual;
-    gcf aux_in = (gcf)P->aux_in;
     gf aux_out = (gf)P->aux_out;
     const int act = P->act, dact = P->dact;
-    const bool accum = (P->flags & GHN3_GEMM_ACCUM) != 0;
-    const bool use_bias = bias && !(P->flags & GHN3_GEMM_BIASGRAD);
-    const float alpha = P->alpha;
-    {
-        const int e = tid;                      // 1024 threads = 32 x 32 outputs
-        const int rl = e >> 5, cl = e & 31;
-        const int row = m0 + rl, col = n0 + cl;
-        if (row < M && col < N) {
-            const int hh = (rl >> 2) & 1;
-            const int r = (rl & 3) + 4 * (rl >> 3);
-            const int ln = cl + 32 * hh;
-            float v = 0.f;
+    if (e_ok) {                                  // 1024 threads = 32 x 32 outputs
+        const int hh = (e_rl >> 2) & 1;
+        const int r = (e_rl & 3) + 4 * (e_rl >> 3);
+        const int ln = e_cl + 32 * hh;
+        float v = 0.f;
 #pragma unroll
-            for (int ww = 0; ww < SW; ++ww) v += red[ww][r][ln];
-            v *= alpha;
-            if (use_bias) {
-                int bi = col;
-                if (P->bias_q > 0) bi = (col / P->bias_q) * P->bias_s + (col % P->bias_q);
-                v += bias[(int64_t)bi * P->bias_stride];
-            }
-            const int64_t ci = (int64_t)s_map_row(row, (gci)P->c_gather, P->c_q, P->c_s) * P->ldc + col;
-            if (aux_out) aux_out[ci] = v;
-            if (act == GHN3_ACT_RELU) v = fmaxf(v, 0.f);
-            else if (act == GHN3_ACT_GELU) v = s_gelu(v);
-            if (dact == GHN3_DACT_RELU) v = (aux_in[ci] > 0.f) ? v : 0.f;
-            else if (dact == GHN3_DACT_GELU) v *= s_gelu_grad(aux_in[ci]);
-            if (residual) v += residual[ci];
-            if (accum) v += C[ci];
-            C[ci] = v;
-        }
+        for (int ww = 0; ww < SW; ++ww) v += red[ww][r][ln];
+        v = v * P->alpha + e_bias;
+        if (aux_out) aux_out[e_ci] = v;
+        if (act == GHN3_ACT_RELU) v = fmaxf(v, 0.f);
+        else if (act == GHN3_ACT_GELU) v = s_gelu(v);
+        if (dact == GHN3_DACT_RELU) v = (e_aux > 0.f) ? v : 0.f;
+        else if (dact == GHN3_DACT_GELU) v *= s_gelu_grad(e_aux);
+        C[e_ci] = v + e_res + e_old;
     }
 }
 

@@ -172,23 +172,23 @@ class Program:
         blocks = 0
         for D, it in zip(descs, items):
             D['src_off'], D['rows'], D['cols'], D['ld_src'] = it['src_off'], it['rows'], it['cols'], it['ld_src']
-            flags = 0
+            dflags = 0
             if it.get('straight'):
                 off, ld, ct = it['straight']
                 assert ld % 8 == 0 and ld >= round_up(it['cols'], 64) and off % 8 == 0
                 D['dst_off'], D['ld_dst'] = off, ld
-                flags |= L.CAST_STRAIGHT | (L.CAST_STRAIGHT_BF16 if ct == L.CT_BF16 else 0)
+                dflags |= L.CAST_STRAIGHT | (L.CAST_STRAIGHT_BF16 if ct == L.CT_BF16 else 0)
             if it.get('transposed'):
                 off, ld, ct = it['transposed']
                 assert ld % 8 == 0 and ld >= round_up(it['rows'], 64) and off % 8 == 0
                 D['dstT_off'], D['ld_dstT'] = off, ld
-                flags |= L.CAST_TRANSPOSED | (L.CAST_TRANSPOSED_BF16 if ct == L.CT_BF16 else 0)
+                dflags |= L.CAST_TRANSPOSED | (L.CAST_TRANSPOSED_BF16 if ct == L.CT_BF16 else 0)
             if it.get('colsum') is not None:
                 assert dbias is not None
                 D['bias_q'], D['bias_s'] = it['colsum']
-                flags |= L.CAST_COLSUM
+                dflags |= L.CAST_COLSUM
             assert it['ld_src'] % 4 == 0 and it['src_off'] % 4 == 0
-            D['flags'] = flags
+            D['flags'] = dflags
             D['block_start'] = blocks
             blocks += ((it['rows'] + 63) // 64) * ((it['cols'] + 63) // 64)
         if blocks:

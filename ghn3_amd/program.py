@@ -11,6 +11,8 @@ Everything here is host-side shape bookkeeping (numpy); no tensor math.  The com
 """
 
 import math
+import os
+
 import numpy as np
 
 from . import _lib as L
@@ -256,7 +258,7 @@ class Program:
     TAG_NAMES = {1: 'w2_fwd', 2: 'w2_dgrad', 3: 'w2_wgrad', 4: 'w0_fwd', 5: 'fc_fwd', 6: 'tile_fwd', 7: 'tile_bwd',
                  8: 'w0_bwd', 9: 'fc_bwd'}
 
-    def gemm_op(self, first, count=None, tile=0, ctype=None, tag=0, side=False):
+    def gemm_op(self, first, count=None, tile=0, ctype=None, tag=0, side=False, flops=None):
         if count is None:
             count = len(self._probs) - first
         if count > 0:
@@ -267,7 +269,8 @@ class Program:
                 flags |= self.SIDE
             if tag:
                 flags |= L.OPFLAG_TIMED | (tag << 16)
-                fl = sum(2.0 * int(p['M']) * int(p['N']) * int(p['K']) for p in self._probs[first:first + count])
+                fl = flops if flops is not None else \
+                    sum(2.0 * int(p['M']) * int(p['N']) * int(p['K']) for p in self._probs[first:first + count])
                 self.tag_flops[tag] = self.tag_flops.get(tag, 0.0) + fl
             self.op(L.OP_GEMM, ints=(first, count, tile), flags=flags)
 
@@ -858,25 +861,44 @@ class Program:
             if g16:
                 # 16-bit copies of the backward operands, one launch: per group d_tiles (straight: dgrad A operand,
                 # transposed: wgrad A operand, column sums: the conv.2 bias gradient) and u^T (wgrad B operand)
+                # wgrad families.  Conv groups with the same input width i cover nested W2 row sets (o' < o_g), so
+                # their transposed copies share ONE buffer per family: rows = W2 rows (o' * i + i') of the widest
+                # group, columns = the groups' decoder rows concatenated along k in order of decreasing o_g.  The
+                # W2 rows with o' in [o_lo, o_hi) then need exactly a k PREFIX of that buffer: one GEMM problem per
+                # o range writes each dW2 row once (no read-modify-write between the groups of a family, one launch
+                # per family instead of one per group).
                 items, side_items = [], []
+                fams = {}
                 for g in g16:
                     g['dth_ld'] = round_up(g['cols'], 64)
                     g['dth'] = self.ws16('dth%d' % g['row0'], g['rows'] * g['dth_ld'])
-                    g['kT_ld'] = round_up(g['rows'], 64)
-                    g['dthT'] = self.ws16('dthT%d' % g['row0'], g['cols'] * g['kT_ld'])
-                    g['uhT'] = self.ws16('uhT%d' % g['row0'], 8 * C * g['kT_ld'])
-                    src = dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'], rows=g['rows'], cols=g['cols'],
-                               ld_src=g['ld'])
-                    items.append(dict(src, straight=(g['dth'], g['dth_ld'], bct)))
-                    side_items.append(dict(src, transposed=(g['dthT'], g['kT_ld'], bct), colsum=(g['i_ld'], ms[1])))
-                    side_items.append(dict(src_off=u[1] // 4 + g['row0'] * 8 * C, rows=g['rows'], cols=8 * C,
-                                           ld_src=8 * C, transposed=(g['uhT'], g['kT_ld'], bct)))
+                    key = ('conv', g['i_ld']) if g['kind'] == 'conv' else ('cls', g['row0'])
+                    fams.setdefault(key, []).append(g)
+                self.wgrad_families = []
+                for key, gs in fams.items():
+                    gs = sorted(gs, key=lambda g_: -g_['o'])
+                    k_off = 0
+                    for g in gs:
+                        g['k_off'] = k_off
+                        k_off += round_up(g['rows'], 64)
+                    fam = dict(groups=gs, i=gs[0]['i_ld'], o_max=gs[0]['o'], ktot=k_off)
+                    fam['dthT'] = self.ws16('dthT_f%d_%d' % (fam['i'], gs[0]['row0']), fam['o_max'] * fam['i'] * k_off)
+                    fam['uhT'] = self.ws16('uhT_f%d_%d' % (fam['i'], gs[0]['row0']), 8 * C * k_off)
+                    self.wgrad_families.append(fam)
+                    for g in gs:
+                        src = dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'], rows=g['rows'],
+                                   cols=g['cols'], ld_src=g['ld'])
+                        items.append(dict(src, straight=(g['dth'], g['dth_ld'], bct)))
+                        side_items.append(dict(src, transposed=(fam['dthT'] + g['k_off'], k_off, bct),
+                                               colsum=(g['i_ld'], ms[1])))
+                        side_items.append(dict(src_off=u[1] // 4 + g['row0'] * 8 * C, rows=g['rows'], cols=8 * C,
+                                               ld_src=8 * C, transposed=(fam['uhT'] + g['k_off'], k_off, bct)))
                 # the dgrad operand on the critical path; the wgrad operands (and the bias gradient) beside it
                 self.cast16((self.xbuf(self.X_WS), 0), items)
                 self.cast16((self.xbuf(self.X_WS), 0), side_items, dbias=self.gref(b2), flags=self.SIDE)
             p0 = len(self._probs)
             for g in self.gemm_groups:
-                for (r0, nr) in self._row_parts(g['rows']):
+                for (r0, nr) in [(0, g['rows'])]:
                     tiles = ((nr + 127) // 128) * ((8 * C + 127) // 128)
                     ks = int(max(2, min(64, (2048 + tiles - 1) // tiles, g['cols'] // 1024)))
                     if g['op16']:
@@ -891,21 +913,41 @@ class Program:
                               b_qs=(g['i_ld'], ms[1]), ksplit=ks)
             self.gemm_op(p0, ctype=bct if g16 else None, tag=self.TAG_D3_DGRAD)
             self.op(L.OP_DACT, refs=(d_u, u), ints=(M, 8 * C, 8 * C, L.DACT_RELU))
-            # dW2[rows of the group] += d_tiles^T u ; groups overlap in W2 rows -> one launch per group
-            for gi, g in enumerate(self.gemm_groups):
-                full = gi == 0 and g['o'] == ms[0] and g['i_ld'] == ms[1] and g['kind'] == 'conv'
+            # dW2 += d_tiles^T u.  16-bit families first (the family of the full-width groups writes every dW2 row
+            # without reading it), then the groups on the fp32-operand path; families overlap in W2 rows -> one
+            # launch per family, in order, on the side stream.
+            fam_list = sorted(getattr(self, 'wgrad_families', []) if g16 else [],
+                              key=lambda f: -(f['i'] * f['o_max']))
+            first = True
+            for fam in fam_list:
+                gs = fam['groups']
+                full = first and fam['i'] == ms[1] and fam['o_max'] == ms[0] and gs[0]['kind'] == 'conv'
                 if full:
-                    self.grad_no_memset.append(W2)      # every row of dW2 is written by this problem
+                    self.grad_no_memset.append(W2)      # every row of dW2 is written by this family
+                first = False
+                thr = sorted({g['o'] for g in gs}, reverse=True)
+                p0 = len(self._probs)
+                fl = sum(2.0 * g['rows'] * g['cols'] * 8 * C for g in gs)     # algorithmic: unpadded decoder rows
+                for j, o_hi in enumerate(thr):
+                    o_lo = thr[j + 1] if j + 1 < len(thr) else 0
+                    kpre = sum(round_up(g['rows'], 64) for g in gs if g['o'] >= o_hi)       # a prefix (sorted by o)
+                    # the K range is already zero padded per group: pass the padded prefix as K
+                    self.gemm(self.href(fam['dthT'] + o_lo * fam['i'] * fam['ktot']), self.href(fam['uhT']),
+                              self.gref(W2, o_lo * ms[1] * 8 * C), (o_hi - o_lo) * fam['i'], 8 * C, kpre,
+                              fam['ktot'], fam['ktot'], 8 * C, c_qs=(fam['i'], ms[1]), accum=not full, op16=True)
+                self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=True, flops=fl)
+            for gi, g in enumerate(self.gemm_groups):
                 if g['op16']:
-                    p0 = self.gemm(self.href(g['dthT']), self.href(g['uhT']), self.gref(W2), g['cols'], 8 * C,
-                                   g['rows'], g['kT_ld'], g['kT_ld'], 8 * C, c_qs=(g['i_ld'], ms[1]),
-                                   accum=not full, op16=True)
-                    self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=True)
                     continue
+                # (fp32-operand path: one launch per group; without 16-bit families the first full-size group
+                # writes every dW2 row and needs neither the memset nor the accumulate)
+                full = (not fam_list and gi == 0 and g['o'] == ms[0] and g['i_ld'] == ms[1] and g['kind'] == 'conv')
+                if full:
+                    self.grad_no_memset.append(W2)
                 p0 = self.gemm(self.wref('d_tiles', g['tile_off']), (u[0], u[1] + 4 * g['row0'] * 8 * C),
                                self.gref(W2), g['cols'], 8 * C, g['rows'], g['ld'], 8 * C, 8 * C,
-                               a_mode=L.MODE_COL, b_mode=L.MODE_COL, c_qs=(g['i_ld'], ms[1]), accum=not full,
-                               dbias=self.gref(b2))
+                               a_mode=L.MODE_COL, b_mode=L.MODE_COL, c_qs=(g['i_ld'], ms[1]),
+                               accum=not full, dbias=self.gref(b2))
                 # short reduction (K = rows of the group): 64x64 tiles beat 128x128 here (tests/gemm_bench.py)
                 self.gemm_op(p0, tile=64 if g['rows'] <= 1024 else 0, ctype=bct if g16 else None,
                              tag=self.TAG_D3_WGRAD, side=True)

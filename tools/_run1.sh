@@ -1,6 +1,6 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | tail -3 > gpurun_out/t16.log
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | grep -E "passed|failed|Error|error" > gpurun_out/t16.log
 cat gpurun_out/t16.log
 timeout 300 python bench.py --no-cpu-baseline --steps 10 --warmup 3 --profile-ops > gpurun_out/b_f16_0.log 2>&1
 python - <<'PY'
@@ -10,5 +10,5 @@ for f in ('gpurun_out/b_f16_0.log',):
     if l.startswith('{'):
         d = json.loads(l)
         print(f, d['ms_per_step'], d['value'], d['roofline']['achieved'], d['phase_ms'])
-        print({k: (v['ms_per_step'], v.get('tflops')) for k, v in d['roofline']['kernels'].items()})
+        print({k: (v['ms_per_step'], v.get('tflops'), v['launch_groups_per_step']) for k, v in d['roofline']['kernels'].items()})
 PY

@@ -780,16 +780,19 @@ typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
                                                      const ghn3_cast_desc* __restrict__ descs, int n_desc,
-                                                     float* __restrict__ dbias) {
+                                                     float* __restrict__ dbias, int total_items) {
     __shared__ unsigned short tr[64][66];          // transposed-copy staging (already converted)
     __shared__ float csum[16][64];
+    // grid-stride over the 64 x 64 work tiles: a launch may cap its grid (side-stream copies that should leave
+    // HBM bandwidth to the latency-bound chain they run under)
+    for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
     int lo = 0, hi = n_desc - 1;
     while (lo < hi) {
         const int mid = (lo + hi + 1) >> 1;
-        if (descs[mid].block_start <= (int)blockIdx.x) lo = mid; else hi = mid - 1;
+        if (descs[mid].block_start <= item) lo = mid; else hi = mid - 1;
     }
     const ghn3_cast_desc D = descs[lo];
-    const int t = blockIdx.x - D.block_start;
+    const int t = item - D.block_start;
     const int tiles_c = (D.cols + 63) >> 6;
     const int r0 = (t / tiles_c) * 64, c0 = (t % tiles_c) * 64;
     const int tid = threadIdx.x;
@@ -867,12 +870,15 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
         if (D.bias_q > 0) c = (c / D.bias_q) * D.bias_s + c % D.bias_q;
         atomicAdd(dbias + c, s);
     }
+    __syncthreads();                               // LDS staging is reused by the next work tile
+    }
 }
 
 int ghn3_cast16(const float* src, void* dst, const ghn3_cast_desc* d_desc, int n_desc, int total_blocks, float* dbias,
-                hipStream_t s) {
+                int grid_cap, hipStream_t s) {
     if (n_desc <= 0 || total_blocks <= 0) return GHN3_OK;
-    hipLaunchKernelGGL(cast16_kernel, dim3(total_blocks), dim3(256), 0, s, src, (unsigned short*)dst, d_desc, n_desc,
-                       dbias);
+    const int grid = grid_cap > 0 && grid_cap < total_blocks ? grid_cap : total_blocks;
+    hipLaunchKernelGGL(cast16_kernel, dim3(grid), dim3(256), 0, s, src, (unsigned short*)dst, d_desc, n_desc,
+                       dbias, total_blocks);
     return launch_ok("cast16");
 }

@@ -74,7 +74,7 @@ int ghn3_rowseg_sum(float* out, const float* X, const int* seg_ptr, const int* i
                     int ldo, int accum, hipStream_t s);
 int ghn3_add(float* dst, const float* src, int64_t n, hipStream_t s);
 int ghn3_cast16(const float* src, void* dst, const ghn3_cast_desc* d_desc, int n_desc, int total_blocks, float* dbias,
-                hipStream_t s);
+                int grid_cap, hipStream_t s);
 int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, hipStream_t s);
 
 void ghn3_set_error(const char* fmt, ...);

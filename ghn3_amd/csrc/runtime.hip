@@ -485,7 +485,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             break;
         case GHN3_OP_CAST16:
             rc = ghn3_cast16(R.get<const float>(o.r[0]), R.get<void>(o.r[1]), R.get<const ghn3_cast_desc>(o.r[2]),
-                             (int)o.i[0], (int)o.i[1], R.get<float>(o.r[3]), stream);
+                             (int)o.i[0], (int)o.i[1], R.get<float>(o.r[3]), (int)o.i[2], stream);
             break;
         case GHN3_OP_DACT:
             rc = ghn3_dact(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), (int)o.i[0], (int)o.i[1], (int)o.i[2],

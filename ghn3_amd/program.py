@@ -167,7 +167,7 @@ class Program:
     def href(self, off_halfs):
         return (self.xbuf(self.X_WS), 2 * int(off_halfs))
 
-    def cast16(self, src_base, items, dbias=None, flags=0):
+    def cast16(self, src_base, items, dbias=None, flags=0, grid_cap=0):
         """One GHN3_OP_CAST16 over `items` = dicts(src_off [floats from src_base], rows, cols, ld_src,
         straight=(off_halfs, ld, ctype) | None, transposed=(off_halfs, ld, ctype) | None, colsum=(q, s) | None)."""
         descs = np.zeros(len(items), dtype=L.CAST_DT)
@@ -195,7 +195,7 @@ class Program:
             blocks += ((it['rows'] + 63) // 64) * ((it['cols'] + 63) // 64)
         if blocks:
             self.op(L.OP_CAST16, refs=(src_base, (self.xbuf(self.X_WS), 0), self.idx(descs),
-                                       dbias if dbias is not None else self.NONE), ints=(len(items), blocks),
+                                       dbias if dbias is not None else self.NONE), ints=(len(items), blocks, grid_cap),
                     flags=flags)
 
     def idx(self, arr):
@@ -394,7 +394,8 @@ class Program:
             self.w2hT_ld = round_up(n_w2, 64) + 64
             self.w2hT = self.ws16('w2hT', 8 * C * self.w2hT_ld)
             item['transposed'] = (self.w2hT, self.w2hT_ld, bct)
-        self.cast16(self.pref('decoder.conv.2.weight'), [item], flags=self.SIDE)
+        self.cast16(self.pref('decoder.conv.2.weight'), [item], flags=self.SIDE,
+                    grid_cap=int(os.environ.get('GHN3_W2CAST_CAP', '512')) if self.SIDE else 0)
 
     # ------------------------------------------------------------------ forward
     def _build_forward(self):

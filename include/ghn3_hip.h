@@ -201,7 +201,8 @@ enum ghn3_op_kind {
     GHN3_OP_DACT = 22,
     /* fp32 -> f16 / bf16 operand copies for GHN3_GEMM_OP16 problems (straight and / or transposed, zero padded)
      * r0=src base (fp32) r1=dst base (16-bit) r2=ghn3_cast_desc table (device) r3=dbias or absent
-     * i: n_desc, total workgroups */
+     * i: n_desc, total work tiles, grid cap (0 = one workgroup per tile; > 0: at most that many workgroups stride
+     * over the tiles -- side-stream copies that should leave HBM bandwidth to the chain they run under) */
     GHN3_OP_CAST16 = 23,
     /* the run's stream waits for every GHN3_OPFLAG_SIDE op issued so far (no refs) */
     GHN3_OP_JOIN = 24,

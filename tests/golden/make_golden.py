@@ -224,14 +224,15 @@ def make_ghn3_goldens():
 #    norm and a seeded sample of its elements (the tensors themselves are 11.7 M / 25.6 M floats).
 # ------------------------------------------------------------------------------------------------
 
-def make_resnet_goldens(which=('18', '50')):
+def make_resnet_goldens(which=('18', '50', 'vit')):
     install_standins()
     sys.path.insert(0, REF)
     import ghn3                                              # noqa: F401  the reference package
     from ghn3.nn import GHN3
     from ghn3.graph import Graph, GraphBatch
     import time
-    for depth, variant in ((18, 'ghn3tm8'), (50, 'ghn3xlm16')):
+    Encoder = sys.modules['torchvision.models.vision_transformer'].Encoder
+    for depth, variant in ((18, 'ghn3tm8'), (50, 'ghn3xlm16'), ('vit', 'ghn3xlm16')):
         if str(depth) not in which:
             continue
         hid, layers, heads = recipe.VARIANTS[variant]
@@ -243,8 +244,8 @@ def make_resnet_goldens(which=('18', '50')):
         sd = recipe.seeded_state_dict(shapes, seed=recipe.RESNET_SEED)
         ghn.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         del sd
-        spec = recipe.resnet_spec(depth)
-        net = recipe.build_torch_net(spec)
+        spec = recipe.vit_b16_spec() if depth == 'vit' else recipe.resnet_spec(depth)
+        net = recipe.build_torch_net(spec, encoder_cls=Encoder)
         node_feat, node_info, A = recipe.graph_arrays(spec)
         g = Graph(node_feat=torch.from_numpy(node_feat), node_info=node_info, A=torch.from_numpy(A), dense=True)
         batch = GraphBatch([g], dense=True)
@@ -252,18 +253,22 @@ def make_resnet_goldens(which=('18', '50')):
         t0 = time.time()
         with torch.no_grad():
             net_out, emb = ghn(net, batch, return_embeddings=True, bn_track_running_stats=True, reduce_graph=False)
-        print('resnet%d / %s: reference forward %.1f s' % (depth, variant, time.time() - t0))
+        tag = 'vit_b16' if depth == 'vit' else 'resnet%d' % depth
+        print('%s / %s: reference forward %.1f s' % (tag, variant, time.time() - t0))
         out = {'meta/variant': np.asarray([variant]), 'emb': emb.detach().numpy().astype(np.float32)}
         total = 0
         for name, p in recipe.named_predicted(net_out):
             v = p.detach().reshape(-1)
             total += v.numel()
-            idx = recipe.sample_indices(v.numel(), recipe.RESNET_SAMPLES, seed=len(name))
-            out['pred/%s/norm' % name] = np.asarray([float(v.double().norm())])
-            out['pred/%s/sample' % name] = v[idx].numpy().astype(np.float32)
+            if v.dim() == 1 and p.dim() == 3:
+                pass
+            q = p.detach()[:, 1:].reshape(-1) if p.dim() == 3 else v       # Q3: row 0 of a positional encoding is random
+            idx = recipe.sample_indices(q.numel(), recipe.RESNET_SAMPLES, seed=len(name))
+            out['pred/%s/norm' % name] = np.asarray([float(q.double().norm())])
+            out['pred/%s/sample' % name] = q[idx].numpy().astype(np.float32)
         out['meta/n_predicted'] = np.asarray([total], dtype=np.int64)
-        np.savez_compressed(os.path.join(HERE, 'resnet%d_%s.npz' % (depth, variant)), **out)
-        print('resnet%d_%s.npz: %d predicted params' % (depth, variant, total))
+        np.savez_compressed(os.path.join(HERE, '%s_%s.npz' % (tag, variant)), **out)
+        print('%s_%s.npz: %d predicted params' % (tag, variant, total))
 
 
 if __name__ == '__main__':
@@ -271,7 +276,7 @@ if __name__ == '__main__':
     # python make_golden.py resnet     -> + ResNet-18 / ghn3tm8 and ResNet-50 / ghn3xlm16 (minutes, ~10 GB of RAM)
     torch.set_num_threads(8 if 'resnet' in sys.argv[1:] else 4)
     if 'resnet' in sys.argv[1:]:
-        make_resnet_goldens()
+        make_resnet_goldens([a for a in sys.argv[1:] if a in ('18', '50', 'vit')] or ('18', '50', 'vit'))
     else:
         make_graphormer_goldens()
         make_ghn3_goldens()

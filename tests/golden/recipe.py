@@ -166,7 +166,12 @@ def build_torch_net(spec, encoder_cls=None):
     net = _Bag()
     have_bias = {p[:-5] for _, p, _ in spec['nodes'] if p is not None and p.endswith('.bias')}
     for prim, pname, sz in spec['nodes']:
-        if pname is None or pname.endswith('.bias'):
+        if pname is None or pname.endswith('.bias') or pname.endswith('.in_proj_bias'):
+            continue
+        if pname.endswith('.in_proj_weight'):           # torch.nn.MultiheadAttention (torchvision ViT encoder block)
+            net.add_module(pname.rsplit('.', 1)[0], nn.MultiheadAttention(sz[1], spec.get('heads', 12)))
+            continue
+        if pname.endswith('.out_proj.weight'):          # child of the MultiheadAttention module above
             continue
         mname = pname.rsplit('.', 1)[0]
         if prim == 'bn':
@@ -239,13 +244,51 @@ def resnet_spec(depth):
     return dict(nodes=nodes, edges=edges)
 
 
+def vit_b16_spec():
+    """torchvision.models.vit_b_16 layer shapes (hidden 768, 12 layers, 12 heads, mlp 3072, 16x16 patches on 224^2).
+    The class token is a bare nn.Parameter of the top module and is not a graph node."""
+    D, L_, H = 768, 12, 12
+    nodes, edges = [('input', None, None)], []
+
+    def add(prim, name, shape, srcs):
+        nodes.append((prim, name, shape))
+        for s_ in srcs:
+            edges.append((s_, len(nodes) - 1))
+        return len(nodes) - 1
+
+    x = add('conv', 'conv_proj.weight', (D, 3, 16, 16), [0])
+    x = add('bias', 'conv_proj.bias', (D,), [x])
+    x = add('pos_enc', 'encoder.pos_embedding', (1, 197, D), [x])
+    for l in range(L_):
+        pre = 'enc%d_' % l
+        y = add('ln', pre + 'ln_1.weight', (D,), [x])
+        y = add('conv', pre + 'self_attention.in_proj_weight', (3 * D, D), [y])
+        y = add('bias', pre + 'self_attention.in_proj_bias', (3 * D,), [y])
+        y = add('msa', None, None, [y])
+        y = add('conv', pre + 'self_attention.out_proj.weight', (D, D), [y])
+        y = add('bias', pre + 'self_attention.out_proj.bias', (D,), [y])
+        x = add('sum', None, None, [x, y])
+        y = add('ln', pre + 'ln_2.weight', (D,), [x])
+        y = add('conv', pre + 'mlp_0.weight', (4 * D, D), [y])
+        y = add('bias', pre + 'mlp_0.bias', (4 * D,), [y])
+        y = add('conv', pre + 'mlp_3.weight', (D, 4 * D), [y])
+        y = add('bias', pre + 'mlp_3.bias', (D,), [y])
+        x = add('sum', None, None, [x, y])
+    x = add('ln', 'encoder_ln.weight', (D,), [x])
+    x = add('conv', 'heads_head.weight', (1000, D), [x])
+    add('bias', 'heads_head.bias', (1000,), [x])
+    return dict(nodes=nodes, edges=edges, heads=H)
+
+
 RESNET_SEED = 777
 RESNET_SAMPLES = 2048
 
 
 def named_predicted(net):
-    for mname, m in net.named_children():
-        for attr in ('weight', 'bias', 'pos_embedding'):
+    for mname, m in net.named_modules():
+        if mname == '':
+            continue
+        for attr in ('weight', 'bias', 'pos_embedding', 'in_proj_weight', 'in_proj_bias'):
             t = m.__dict__.get(attr, None)
             if t is None:
                 t = m._parameters.get(attr, None)

@@ -816,25 +816,32 @@ void gemm_h16d_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
         if (i + NS - 1 < nkt) issue(i + NS - 1);
         const char* a_s = sm + (i % NS) * STAGE;
         const char* b_s = a_s + OPA;
-#pragma unroll
-        for (int kk = 0; kk < BK / 16; ++kk) {         // 4 MFMA k-steps of 16
-            u16x8 af[TM], bf[TN];
+        // fragments of k-step kk + 1 are read from LDS while the MFMAs of step kk run (two register sets)
+        u16x8 af[2][TM], bf[2][TN];
+        auto load_frags = [&](int kk, int buf) {
             const int slot = kk * 2 + lhi;             // 16-byte k chunk wanted by this lane
 #pragma unroll
             for (int ii = 0; ii < TM; ++ii) {
                 const int row = wm0 + ii * 32 + l31;
-                af[ii] = *reinterpret_cast<const u16x8*>(a_s + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+                af[buf][ii] = *reinterpret_cast<const u16x8*>(a_s + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
                 const int row = wn0 + j * 32 + l31;
-                bf[j] = *reinterpret_cast<const u16x8*>(b_s + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+                bf[buf][j] = *reinterpret_cast<const u16x8*>(b_s + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
             }
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {         // 4 MFMA k-steps of 16
+            if (kk + 1 < BK / 16) load_frags(kk + 1, (kk + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);         // keep the reads of step kk + 1 ahead of the MFMAs of step kk
 #pragma unroll
             for (int ii = 0; ii < TM; ++ii)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[ii][j] = mfma16<CT>(af[ii], bf[j], acc[ii][j]);
+                    acc[ii][j] = mfma16<CT>(af[kk & 1][ii], bf[kk & 1][j], acc[ii][j]);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
     // (the host only routes problems with ldc % 4 == 0 and 16-byte aligned C / aux / residual to this kernel)

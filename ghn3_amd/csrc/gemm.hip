@@ -749,7 +749,15 @@ void gemm_h16d_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
     const int wm0 = (wave / WGN) * (BM / WGM), wn0 = (wave % WGN) * 64;
     const int l31 = lane & 31, lhi = lane >> 5;
     const int kt0 = kz * (P->k_chunk / BK);
-    const int K = (P->ksplit > 1) ? min(P->K, (kz + 1) * P->k_chunk) : P->K;
+    int Kp = P->K;
+    if (P->lim) {                                    // ragged extents of the stacked rows (one entry per 128 rows)
+        const int* lim = P->lim;
+        int ext = lim[m0 >> 7];
+        if (BM > 128 && m0 + 128 < P->M) ext = max(ext, lim[(m0 >> 7) + 1]);
+        if (P->lim_kind == 1) { if (n0 >= ext) return; }
+        else Kp = min(Kp, ext);
+    }
+    const int K = (P->ksplit > 1) ? min(Kp, (kz + 1) * P->k_chunk) : Kp;
     if (kt0 * BK >= K && P->ksplit > 1) return;
     const int nkt = (K + BK - 1) / BK - kt0;         // k-tiles of this block
 

@@ -19,6 +19,8 @@ struct GemmProbDev {
     int ksplit, k_chunk; // split-K: K range [z*k_chunk, (z+1)*k_chunk) per replica z < ksplit
     int order;           // 0: m-tiles innermost (B streamed), 1: n-tiles innermost (A streamed)
     int kq, ks;          // 16-bit-operand kernel: k-map of B (kq == 0: identity)
+    const int* lim;      // ragged extents per 128 rows (see ghn3_gemm_problem::lim)
+    int lim_kind, _pad3;
     int _pad;
 };
 

@@ -287,6 +287,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             g.tiles_m = (p.M + te - 1) / te;
                             g.tiles_n = (p.N + te - 1) / te;
                             g.kq = (tl == 16 || tl == 24) ? p.b_kq : 0; g.ks = p.b_ks;
+                            g.lim = (tl == 16 || tl == 24) ? R.get<const int>(p.lim) : nullptr;
+                            g.lim_kind = g.lim ? p.lim_kind : 0;
                             g.order = (int64_t)p.M > (int64_t)p.N ? 1 : 0;   // stream the larger operand once
                             g.ksplit = p.ksplit > 1 ? p.ksplit : 1;
                             g.k_chunk = ((p.K + g.ksplit - 1) / g.ksplit + 63) / 64 * 64;

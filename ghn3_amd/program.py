@@ -229,7 +229,7 @@ class Program:
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, bias=None, bias_q=0,
              bias_s=0, bias_stride=1, act=L.ACT_NONE, dact=L.DACT_NONE, aux_in=None, aux_out=None, residual=None,
              a_gather=None, b_gather=None, c_gather=None, a_qs=(0, 0), b_qs=(0, 0), c_qs=(0, 0), accum=False,
-             alpha=1.0, dbias=None, dbias_stride=1, ksplit=1, op16=False, b_kmap=(0, 0)):
+             alpha=1.0, dbias=None, dbias_stride=1, ksplit=1, op16=False, b_kmap=(0, 0), lim=None, lim_kind=0):
         # dbias: fused bias gradient of a wgrad problem (GHN3_GEMM_BIASGRAD): dbias[cmap(m)*stride] += sum_k A(m,k)
         if dbias is not None:
             assert bias is None and a_mode == L.MODE_COL
@@ -237,7 +237,7 @@ class Program:
         p = np.zeros((), dtype=L.PROBLEM_DT)
         for name, ref in (('A', A), ('B', B), ('C', C), ('bias', bias), ('residual', residual), ('aux_in', aux_in),
                           ('aux_out', aux_out), ('a_gather', a_gather), ('b_gather', b_gather),
-                          ('c_gather', c_gather)):
+                          ('c_gather', c_gather), ('lim', lim)):
             ref = self.NONE if ref is None else ref
             p[name]['buf'], p[name]['off'] = ref
         for name, v in (('M', M), ('N', N), ('K', K), ('lda', lda), ('ldb', ldb), ('ldc', ldc), ('a_mode', a_mode),
@@ -249,6 +249,7 @@ class Program:
             p[name] = int(v)
         p['alpha'] = alpha
         p['ksplit'] = ksplit
+        p['lim_kind'] = lim_kind if lim is not None else 0
         self._probs.append(p)
         return len(self._probs) - 1
 
@@ -336,22 +337,49 @@ class Program:
         # The W2 GEMM of a group depends only on (o, i): parameter groups that differ just in the kernel size
         # (1x1, 3x3, 5x5, 7x7 ...) are stacked along M into one GEMM problem ("gemm group").  This removes most
         # of the tile-quantisation waste of the reference's per-key grouping (many groups have < 32 rows).
+        # In the 16-bit pipeline ("families") groups are stacked even further: all conv groups with the same input
+        # width i (i % 8 == 0) form ONE gemm group, rows sorted by decreasing o.  Row r then needs the W2 rows
+        # o' < o_r only -- a ragged extent that the kernel receives as one limit per 128 rows (forward: columns,
+        # dgrad: reduction length, ghn3_gemm_problem::lim) -- and every W2 tile is streamed from HBM once per
+        # family instead of once per (o, i) group.
+        fam = lambda g_: self.direct16 and g_['kind'] == 'conv' and g_['i_ld'] % 8 == 0
         order = sorted(range(len(self.conv_groups)),
-                       key=lambda k: (self.conv_groups[k]['kind'] == 'cls', -self.conv_groups[k]['cols'],
-                                      self.conv_groups[k]['o'], self.conv_groups[k]['i_ld'], k))
+                       key=lambda k: (self.conv_groups[k]['kind'] == 'cls',
+                                      (0, -self.conv_groups[k]['i_ld'], -self.conv_groups[k]['o'])
+                                      if fam(self.conv_groups[k]) else
+                                      (1, -self.conv_groups[k]['cols'], self.conv_groups[k]['o']),
+                                      self.conv_groups[k]['i_ld'], k))
         self.conv_groups = [self.conv_groups[k] for k in order]
         self.gemm_groups = []
         for g in self.conv_groups:
             g['row0'] = row
             row += g['rows']
             last = self.gemm_groups[-1] if self.gemm_groups else None
-            if last is not None and g['kind'] == 'conv' and last['kind'] == 'conv' and \
-                    (last['o'], last['i_ld']) == (g['o'], g['i_ld']):
+            same = last is not None and g['kind'] == 'conv' and last['kind'] == 'conv' and \
+                last['i_ld'] == g['i_ld'] and (last['o'] == g['o'] or (fam(g) and last['family']))
+            if same:
                 last['rows'] += g['rows']
                 last['members'].append(g)
             else:
                 self.gemm_groups.append(dict(kind=g['kind'], o=g['o'], i=g['i'], i_ld=g['i_ld'], cols=g['cols'],
-                                             ld=g['ld'], row0=g['row0'], rows=g['rows'], members=[g]))
+                                             ld=g['ld'], row0=g['row0'], rows=g['rows'], members=[g],
+                                             family=fam(g)))
+        for gg in self.gemm_groups:
+            for m in gg['members']:
+                m['ld'] = gg['ld']            # every member lives in the family's tile matrix (widest extent)
+            # sub-ranges of equal o (members are sorted by decreasing o) and the per-128-row extents
+            subs = []
+            for m in gg['members']:
+                if subs and subs[-1]['o'] == m['o']:
+                    subs[-1]['rows'] += m['rows']
+                else:
+                    subs.append(dict(o=m['o'], row0=m['row0'], rows=m['rows'], cols=m['o'] * gg['i_ld']))
+            gg['subs'] = subs
+            ext = np.zeros(gg['rows'], dtype=np.int32)
+            for sb in subs:
+                ext[sb['row0'] - gg['row0']: sb['row0'] - gg['row0'] + sb['rows']] = sb['cols']
+            gg['lim128'] = np.asarray([ext[t0:t0 + 128].max() for t0 in range(0, gg['rows'], 128)], dtype=np.int32)
+            gg['ragged'] = len(subs) > 1
         self.M = row
         # per-row arrays
         self.row_src = np.zeros(self.M, dtype=np.int32)
@@ -539,21 +567,25 @@ class Program:
                 self.uh = self.ws16('uh', M * 8 * C)
                 self.cast16((self.xbuf(self.X_WS), 0),
                             [dict(src_off=u[1] // 4, rows=M, cols=8 * C, ld_src=8 * C, straight=(self.uh, 8 * C, fct))])
+            fl = 0.0
             for g in self.gemm_groups:
+                fl += sum(2.0 * sb['rows'] * sb['cols'] * 8 * C for sb in g['subs'])   # algorithmic: own extents only
+                if g['op16']:
+                    # one problem per family: all its rows share every W2 tile; ragged column extents via `lim`
+                    self.gemm(self.href(self.uh + g['row0'] * 8 * C), self.href(self.w2h),
+                              self.wref('tiles', g['tile_off']),
+                              g['rows'], g['cols'], 8 * C, 8 * C, 8 * C, g['ld'], b_qs=(g['i_ld'], ms[1]),
+                              bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1],
+                              act=L.ACT_RELU if g['kind'] == 'cls' else L.ACT_NONE, op16=True,
+                              lim=self.idx(g['lim128']) if g['ragged'] else None, lim_kind=1)
+                    continue
                 for (r0, nr) in self._row_parts(g['rows']):
-                    if g['op16']:
-                        self.gemm(self.href(self.uh + (g['row0'] + r0) * 8 * C), self.href(self.w2h),
-                                  self.wref('tiles', g['tile_off'] + r0 * g['ld']),
-                                  nr, g['cols'], 8 * C, 8 * C, 8 * C, g['ld'], b_qs=(g['i_ld'], ms[1]),
-                                  bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1],
-                                  act=L.ACT_RELU if g['kind'] == 'cls' else L.ACT_NONE, op16=True)
-                        continue
                     self.gemm((u[0], u[1] + 4 * (g['row0'] + r0) * 8 * C), self.pref(W2),
                               self.wref('tiles', g['tile_off'] + r0 * g['ld']),
                               nr, g['cols'], 8 * C, 8 * C, 8 * C, g['ld'], b_qs=(g['i_ld'], ms[1]),
                               bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1],
                               act=L.ACT_RELU if g['kind'] == 'cls' else L.ACT_NONE)
-            self.gemm_op(p0, tag=self.TAG_D3_FWD)
+            self.gemm_op(p0, tag=self.TAG_D3_FWD, flops=fl)
             # classifier head (nn.py:755-758): out[i'][k] = sum_o' relu(tile[o'][i']) Wcls[k][o'] + bcls[k]
             n_cls_rows = sum(g['rows'] * g['i_ld'] for g in self.conv_groups if g['kind'] == 'cls')
             if n_cls_rows:
@@ -869,50 +901,49 @@ class Program:
                 # o range writes each dW2 row once (no read-modify-write between the groups of a family, one launch
                 # per family instead of one per group).
                 items, side_items = [], []
-                fams = {}
+                self.wgrad_families = []
                 for g in g16:
                     g['dth_ld'] = round_up(g['cols'], 64)
                     g['dth'] = self.ws16('dth%d' % g['row0'], g['rows'] * g['dth_ld'])
-                    key = ('conv', g['i_ld']) if g['kind'] == 'conv' else ('cls', g['row0'])
-                    fams.setdefault(key, []).append(g)
-                self.wgrad_families = []
-                for key, gs in fams.items():
-                    gs = sorted(gs, key=lambda g_: -g_['o'])
+                    # (rows of a family with a smaller extent keep zeros beyond it: d_tiles is never written there)
+                    items.append(dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'], rows=g['rows'],
+                                      cols=g['cols'], ld_src=g['ld'], straight=(g['dth'], g['dth_ld'], bct)))
                     k_off = 0
-                    for g in gs:
-                        g['k_off'] = k_off
-                        k_off += round_up(g['rows'], 64)
-                    fam = dict(groups=gs, i=gs[0]['i_ld'], o_max=gs[0]['o'], ktot=k_off)
-                    fam['dthT'] = self.ws16('dthT_f%d_%d' % (fam['i'], gs[0]['row0']), fam['o_max'] * fam['i'] * k_off)
-                    fam['uhT'] = self.ws16('uhT_f%d_%d' % (fam['i'], gs[0]['row0']), 8 * C * k_off)
+                    for sb in g['subs']:
+                        sb['k_off'] = k_off
+                        k_off += round_up(sb['rows'], 64)
+                    fam = dict(groups=g['subs'], i=g['i_ld'], o_max=g['o'], ktot=k_off, kind=g['kind'])
+                    fam['dthT'] = self.ws16('dthT_f%d_%d' % (fam['i'], g['row0']), fam['o_max'] * fam['i'] * k_off)
+                    fam['uhT'] = self.ws16('uhT_f%d_%d' % (fam['i'], g['row0']), 8 * C * k_off)
                     self.wgrad_families.append(fam)
-                    for g in gs:
-                        src = dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'], rows=g['rows'],
-                                   cols=g['cols'], ld_src=g['ld'])
-                        items.append(dict(src, straight=(g['dth'], g['dth_ld'], bct)))
-                        side_items.append(dict(src, transposed=(fam['dthT'] + g['k_off'], k_off, bct),
+                    for sb in g['subs']:
+                        side_items.append(dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'] +
+                                               (sb['row0'] - g['row0']) * g['ld'], rows=sb['rows'], cols=sb['cols'],
+                                               ld_src=g['ld'], transposed=(fam['dthT'] + sb['k_off'], k_off, bct),
                                                colsum=(g['i_ld'], ms[1])))
-                        side_items.append(dict(src_off=u[1] // 4 + g['row0'] * 8 * C, rows=g['rows'], cols=8 * C,
-                                               ld_src=8 * C, transposed=(fam['uhT'] + g['k_off'], k_off, bct)))
+                        side_items.append(dict(src_off=u[1] // 4 + sb['row0'] * 8 * C, rows=sb['rows'], cols=8 * C,
+                                               ld_src=8 * C, transposed=(fam['uhT'] + sb['k_off'], k_off, bct)))
                 # the dgrad operand on the critical path; the wgrad operands (and the bias gradient) beside it
                 self.cast16((self.xbuf(self.X_WS), 0), items)
                 self.cast16((self.xbuf(self.X_WS), 0), side_items, dbias=self.gref(b2), flags=self.SIDE)
             p0 = len(self._probs)
+            fl = 0.0
             for g in self.gemm_groups:
-                for (r0, nr) in [(0, g['rows'])]:
-                    tiles = ((nr + 127) // 128) * ((8 * C + 127) // 128)
-                    ks = int(max(2, min(64, (2048 + tiles - 1) // tiles, g['cols'] // 1024)))
-                    if g['op16']:
-                        self.gemm(self.href(g['dth'] + r0 * g['dth_ld']), self.href(self.w2hT),
-                                  (d_u[0], d_u[1] + 4 * (g['row0'] + r0) * 8 * C),
-                                  nr, 8 * C, g['cols'], g['dth_ld'], self.w2hT_ld, 8 * C, ksplit=ks, op16=True,
-                                  b_kmap=(g['i_ld'], ms[1]))
-                        continue
-                    self.gemm(self.wref('d_tiles', g['tile_off'] + r0 * g['ld']), self.pref(W2),
-                              (d_u[0], d_u[1] + 4 * (g['row0'] + r0) * 8 * C),
-                              nr, 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
-                              b_qs=(g['i_ld'], ms[1]), ksplit=ks)
-            self.gemm_op(p0, ctype=bct if g16 else None, tag=self.TAG_D3_DGRAD)
+                fl += sum(2.0 * sb['rows'] * sb['cols'] * 8 * C for sb in g['subs'])
+                tiles = ((g['rows'] + 127) // 128) * ((8 * C + 127) // 128)
+                ks = int(max(2, min(64, (2048 + tiles - 1) // tiles, g['cols'] // 1024)))
+                if g['op16']:
+                    # one problem per family; the K loop of a row tile stops at the largest extent of its rows
+                    self.gemm(self.href(g['dth']), self.href(self.w2hT), (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),
+                              g['rows'], 8 * C, g['cols'], g['dth_ld'], self.w2hT_ld, 8 * C, ksplit=ks, op16=True,
+                              b_kmap=(g['i_ld'], ms[1]), lim=self.idx(g['lim128']) if g['ragged'] else None,
+                              lim_kind=2)
+                    continue
+                self.gemm(self.wref('d_tiles', g['tile_off']), self.pref(W2),
+                          (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),
+                          g['rows'], 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
+                          b_qs=(g['i_ld'], ms[1]), ksplit=ks)
+            self.gemm_op(p0, ctype=bct if g16 else None, tag=self.TAG_D3_DGRAD, flops=fl)
             self.op(L.OP_DACT, refs=(d_u, u), ints=(M, 8 * C, 8 * C, L.DACT_RELU))
             # dW2 += d_tiles^T u.  16-bit families first (the family of the full-width groups writes every dW2 row
             # without reading it), then the groups on the fp32-operand path; families overlap in W2 rows -> one
@@ -922,13 +953,13 @@ class Program:
             first = True
             for fam in fam_list:
                 gs = fam['groups']
-                full = first and fam['i'] == ms[1] and fam['o_max'] == ms[0] and gs[0]['kind'] == 'conv'
+                full = first and fam['i'] == ms[1] and fam['o_max'] == ms[0] and fam['kind'] == 'conv'
                 if full:
                     self.grad_no_memset.append(W2)      # every row of dW2 is written by this family
                 first = False
                 thr = sorted({g['o'] for g in gs}, reverse=True)
                 p0 = len(self._probs)
-                fl = sum(2.0 * g['rows'] * g['cols'] * 8 * C for g in gs)     # algorithmic: unpadded decoder rows
+                fl = sum(2.0 * g_['rows'] * g_['cols'] * 8 * C for g_ in gs)     # algorithmic: unpadded decoder rows
                 for j, o_hi in enumerate(thr):
                     o_lo = thr[j + 1] if j + 1 < len(thr) else 0
                     kpre = sum(round_up(g['rows'], 64) for g in gs if g['o'] >= o_hi)       # a prefix (sorted by o)

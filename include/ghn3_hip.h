@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 4
+#define GHN3_ABI_VERSION 5
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -91,6 +91,14 @@ typedef struct ghn3_gemm_problem {
     int32_t ksplit;     /* > 1: split the K range into `ksplit` chunks whose partial sums are ADDED atomically to C
                          * (the program must zero C first; no epilogue but alpha is allowed) */
     int32_t b_kq, b_ks; /* GHN3_GEMM_OP16 only: k-map of B (see above) */
+    /* GHN3_GEMM_OP16 only: ragged extents.  `lim` = int32 array with one entry per 128 rows of M (rows sorted by
+     * decreasing extent).  lim_kind 1: entry = number of valid columns of those rows -- tiles whose first column
+     * is beyond the extent of all their rows are skipped (forward of decoder groups stacked along M: every row
+     * needs only the W2 rows o' < o of its own group; columns between a row's own extent and its tile's extent are
+     * written with don't-care values).  lim_kind 2: entry = valid reduction length of those rows (A holds zeros
+     * beyond it): the K loop of a tile stops at the largest extent of its rows (dgrad of the same stacking). */
+    ghn3_ref lim;
+    int32_t lim_kind, _pad2;
 } ghn3_gemm_problem;
 
 /* ---- 16-bit operand copies (GHN3_OP_CAST16) -----------------------------------------------------------

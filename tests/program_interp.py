@@ -147,7 +147,18 @@ class Interp:
                 continue
             if int(p['flags']) & L.GEMM_OP16:
                 A, Bm = self._gemm_op16(o, p)
-                self._gemm_finish(p, A, Bm)
+                col_ext = None
+                if int(p['lim']['buf']) >= 0:
+                    lim = self.tail(p['lim'], np.int32)[:(M + 127) // 128]
+                    ext = np.repeat(lim, 128)[:M]
+                    assert np.all(np.diff(lim) <= 0), 'rows must be sorted by decreasing extent'
+                    if int(p['lim_kind']) == 2:
+                        # reduction extents: A must already hold zeros beyond each row block's extent
+                        kk = np.arange(A.shape[1])[None, :]
+                        assert np.all(A[kk >= ext[:, None] * np.ones_like(kk)] == 0)
+                    else:
+                        col_ext = ext           # columns >= ext[row] are don't-care: the interpreter leaves them
+                self._gemm_finish(p, A, Bm, col_ext)
                 continue
             lda, ldb, ldc = int(p['lda']), int(p['ldb']), int(p['ldc'])
             XA, XB, Y = self.tail(p['A'], np.float32), self.tail(p['B'], np.float32), self.tail(p['C'], np.float32)
@@ -167,7 +178,7 @@ class Interp:
                 Bm = XB[(rb[:, None] * ldb + np.arange(N)[None, :])]
             self._gemm_finish(p, A, Bm)
 
-    def _gemm_finish(self, p, A, Bm):
+    def _gemm_finish(self, p, A, Bm, col_ext=None):
         if True:
             M, N = int(p['M']), int(p['N'])
             ldc = int(p['ldc'])
@@ -206,7 +217,11 @@ class Interp:
                 v = v + self.tail(p['residual'], np.float32)[ci]
             if int(p['flags']) & L.GEMM_ACCUM or int(p['ksplit']) > 1:
                 v = v + Y[ci]
-            Y[ci] = v.astype(np.float32)
+            if col_ext is not None:
+                keep = np.arange(N)[None, :] < col_ext[:, None]
+                Y[ci[keep]] = v[keep].astype(np.float32)
+            else:
+                Y[ci] = v.astype(np.float32)
 
     def op_graph_prologue(self, o, problems):
         B, N, V = (int(v) for v in o['i'][:3])

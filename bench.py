@@ -228,13 +228,13 @@ def main():
         if op_breakdown is not None:
             out['op_breakdown_ms'] = {k: round(v[0], 3) for k, v in op_breakdown.items()}
             out['phase_ms'] = phases
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # (rank 0 at N = 1 only: the other ranks would idle)
             try:
                 out['cpu_baseline'] = cpu_baseline(args.model, args.cpu_sample_nodes, 32000)
             except Exception as e:                                   # never lose the GPU line
                 out['cpu_baseline'] = {'value': None, 'error': repr(e)}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if ddp:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -424,6 +424,12 @@ class Program:
             item['transposed'] = (self.w2hT, self.w2hT_ld, bct)
         self.cast16(self.pref('decoder.conv.2.weight'), [item], flags=self.SIDE,
                     grid_cap=int(os.environ.get('GHN3_W2CAST_CAP', '512')) if self.SIDE else 0)
+        if self.training and (4 * C) % 64 == 0:
+            # decoder.conv.0.weight^T [4C][8C] (backward type): B operand of the D2 dgrad
+            self.w0hT = self.ws16('w0hT', 4 * C * 8 * C)
+            self.cast16(self.pref('decoder.conv.0.weight'),
+                        [dict(src_off=0, rows=8 * C, cols=4 * C, ld_src=4 * C, transposed=(self.w0hT, 8 * C, bct))],
+                        flags=self.SIDE)
 
     # ------------------------------------------------------------------ forward
     def _build_forward(self):
@@ -984,12 +990,33 @@ class Program:
                 self.gemm_op(p0, tile=64 if g['rows'] <= 1024 else 0, ctype=bct if g16 else None,
                              tag=self.TAG_D3_WGRAD, side=True)
             # D2 backward
-            p0 = self.gemm(d_u, t, self.gref(W0), 8 * C, 4 * C, M, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_COL,
-                           b_mode=L.MODE_COL, accum=True, dbias=self.gref(b0))
-            self.gemm_op(p0, tag=self.TAG_D2_BWD, side=True)
-            p0 = self.gemm(d_u, self.pref(W0), d_t, M, 4 * C, 8 * C, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_ROW,
-                           b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=t)
-            self.gemm_op(p0, tag=self.TAG_D2_BWD)
+            if g16 and hasattr(self, 'w0hT'):
+                # 16-bit operands: d_u (straight for the dgrad on the chain; transposed + column sums = bias
+                # gradient for the wgrad beside it) and t^T
+                Mp = round_up(M, 64)
+                duh = self.ws16('duh', M * 8 * C)
+                duhT = self.ws16('duhT', 8 * C * Mp)
+                thT = self.ws16('thT', 4 * C * Mp)
+                self.cast16((self.xbuf(self.X_WS), 0),
+                            [dict(src_off=d_u[1] // 4, rows=M, cols=8 * C, ld_src=8 * C, straight=(duh, 8 * C, bct))])
+                self.cast16((self.xbuf(self.X_WS), 0),
+                            [dict(src_off=d_u[1] // 4, rows=M, cols=8 * C, ld_src=8 * C, transposed=(duhT, Mp, bct),
+                                  colsum=(0, 0)),
+                             dict(src_off=t[1] // 4, rows=M, cols=4 * C, ld_src=4 * C, transposed=(thT, Mp, bct))],
+                            dbias=self.gref(b0), flags=self.SIDE)
+                p0 = self.gemm(self.href(duhT), self.href(thT), self.gref(W0), 8 * C, 4 * C, Mp, Mp, Mp, 4 * C,
+                               accum=True, op16=True)
+                self.gemm_op(p0, ctype=bct, tag=self.TAG_D2_BWD, side=True, flops=2.0 * 8 * C * 4 * C * M)
+                p0 = self.gemm(self.href(duh), self.href(self.w0hT), d_t, M, 4 * C, 8 * C, 8 * C, 8 * C, 4 * C,
+                               dact=L.DACT_RELU, aux_in=t, op16=True)
+                self.gemm_op(p0, ctype=bct, tag=self.TAG_D2_BWD)
+            else:
+                p0 = self.gemm(d_u, t, self.gref(W0), 8 * C, 4 * C, M, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_COL,
+                               b_mode=L.MODE_COL, accum=True, dbias=self.gref(b0))
+                self.gemm_op(p0, tag=self.TAG_D2_BWD, side=True)
+                p0 = self.gemm(d_u, self.pref(W0), d_t, M, 4 * C, 8 * C, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_ROW,
+                               b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=t)
+                self.gemm_op(p0, tag=self.TAG_D2_BWD)
             # D1 backward (per used position)
             p0 = len(self._probs)
             for (p, cnt, r_rows, r_src) in self.d1:

@@ -1,14 +1,13 @@
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-for cfg in "0 0" "16 0" "24 0" "0 16" "0 24"; do
-set -- $cfg
-GHN3_FWD_TILE=$1 GHN3_DGRAD_TILE=$2 timeout 300 python bench.py --no-cpu-baseline --steps 10 --warmup 3 > gpurun_out/b_x.log 2>&1
-python - <<PY
+timeout 1500 python -m pytest tests/test_gpu_parity.py -x -q 2>&1 | grep -E "passed|failed|rror|assert" | head
+timeout 300 python bench.py --no-cpu-baseline --steps 10 --warmup 3 --profile-ops > gpurun_out/b_f16_0.log 2>&1
+python - <<'PY'
 import json
-for l in open('gpurun_out/b_x.log'):
+for f in ('gpurun_out/b_f16_0.log',):
+  for l in open(f):
     if l.startswith('{'):
         d = json.loads(l)
-        k = d['roofline']['kernels']
-        print("$cfg", d['ms_per_step'], k['w2_fwd']['ms_per_step'], k['w2_dgrad']['ms_per_step'])
+        print(f, d['ms_per_step'], d['value'], d['roofline']['achieved'], d['phase_ms'])
+        print({k: (v['ms_per_step'], v.get('tflops'), v['launch_groups_per_step']) for k, v in d['roofline']['kernels'].items()})
 PY
-done

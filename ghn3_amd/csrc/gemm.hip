@@ -728,8 +728,7 @@ typedef const unsigned short GAS* gch;
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 template <int CT, int BM, int BN, int WGM, int WGN, int NS>
-__global__ __launch_bounds__(64 * WGM * WGN, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1) * WGM * WGN / 4)
-void gemm_h16d_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
+__device__ __forceinline__ void h16d_tile(const GemmProbDev* __restrict__ probs, int n_probs, int tile_id, float* smem) {
     constexpr int BK = 64;
     constexpr int NT = 64 * WGM * WGN;               // threads
     constexpr int TM = BM / WGM / 32, TN = 2;
@@ -738,11 +737,10 @@ void gemm_h16d_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
     constexpr int STAGE = OPA + OPB;
     constexpr int PA = BM * 8 / NT, PB = BN * 8 / NT;     // 16-byte pieces per thread
     static_assert((NS - 2) * (PA + PB) < 64, "vmcnt is a 6-bit counter");
-    extern __shared__ __attribute__((aligned(16))) float smem[];
     char* sm = reinterpret_cast<char*>(smem);
 
-    const GemmProbDev* P = find_problem(probs, n_probs, blockIdx.x);
-    const int t = blockIdx.x - P->tile_start;
+    const GemmProbDev* P = find_problem(probs, n_probs, tile_id);
+    const int t = tile_id - P->tile_start;
     int m0, n0, kz;
     if (!tile_origin<BM, BN>(P, t, m0, n0, kz)) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -861,22 +859,35 @@ void gemm_h16d_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
     }
 }
 
+// One workgroup per tile, or (grid capped by the host) a persistent workgroup that strides over the tiles: a
+// side-stream launch limited to a fraction of the CUs leaves the others to the latency-bound chain it runs beside.
+template <int CT, int BM, int BN, int WGM, int WGN, int NS>
+__global__ __launch_bounds__(64 * WGM * WGN, (NS * (BM + BN) * 128 <= 80 * 1024 ? 2 : 1) * WGM * WGN / 4)
+void gemm_h16d_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        h16d_tile<CT, BM, BN, WGM, WGN, NS>(probs, n_probs, tile, smem);
+        __syncthreads();                               // LDS (stages / epilogue staging) is reused by the next tile
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 typedef void (*gemm_fn)(const GemmProbDev*, int);
-// 16-bit-operand kernel variants, selected by GHN3_H16D_VARIANT (default below) -- tile code 16 / 24 picks the row
-struct H16dVariant { gemm_fn fn[2]; int threads, lds, edge; };
+// 16-bit-operand kernel variants -- tile code 16 / 24 picks the row
+typedef void (*h16d_fn)(const GemmProbDev*, int, int);
+struct H16dVariant { h16d_fn fn[2]; int threads, lds, edge; };
 #define H16D(BMN, WGM, WGN, NS)                                                                          \
     {{gemm_h16d_kernel<GHN3_CT_F16, BMN, BMN, WGM, WGN, NS>, gemm_h16d_kernel<GHN3_CT_BF16, BMN, BMN, WGM, WGN, NS>}, \
      64 * WGM * WGN, NS * 2 * BMN * 64 * 2, BMN}
+// (deeper rings -- NS = 3 / 4 with one 128 x 128 workgroup per CU -- measured 25-35 % slower than two workgroups
+// per CU with two stages: occupancy beats prefetch depth here)
 static H16dVariant g_h16d[] = {
-    H16D(128, 2, 2, 2),      // 0: 64 KB, 2 blocks / CU
-    H16D(128, 2, 2, 4),      // 1: 128 KB, 1 block / CU, 3 k-tiles in flight
-    H16D(256, 2, 4, 2),      // 2: 128 KB, 1 block / CU
-    H16D(128, 2, 2, 3),      // 3: 96 KB, 1 block / CU
+    H16D(128, 2, 2, 2),      // 0: 64 KB, 2 workgroups / CU
+    H16D(256, 2, 4, 2),      // 1: 128 KB, 1 workgroup / CU
 };
-static int g_h16d_small = 0, g_h16d_big = 2;
+static int g_h16d_small = 0, g_h16d_big = 1;
 
 template <int BM, int BN, int AM, int BMD> static size_t f32_lds() {
     return 2 * (size_t)(F32Tile<BM, AM>::SIZE + F32Tile<BN, BMD>::SIZE) * sizeof(float);
@@ -936,12 +947,11 @@ int ghn3_gemm_init() {
             hipError_t e = hipFuncSetAttribute((const void*)v.fn[ct], hipFuncAttributeMaxDynamicSharedMemorySize, v.lds);
             if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(h16d): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
         }
-    if (const char* env = getenv("GHN3_H16D_SMALL")) g_h16d_small = atoi(env) == 0 ? 0 : atoi(env) == 3 ? 3 : 1;
     g_gemm_ready = true;
     return GHN3_OK;
 }
 
-int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int tile, int ctype,
+int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int tile, int ctype, int grid_cap,
                           hipStream_t stream) {
     if (n_probs <= 0 || total_tiles <= 0) return GHN3_OK;
     if ((ctype != GHN3_CT_F16 && ctype != GHN3_CT_BF16) || (tile != 128 && tile != 256)) {
@@ -950,7 +960,9 @@ int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_til
         return GHN3_E_ARG;
     }
     const H16dVariant& v = g_h16d[tile == 256 ? g_h16d_big : g_h16d_small];
-    hipLaunchKernelGGL(v.fn[ctype == GHN3_CT_BF16], dim3(total_tiles), dim3(v.threads), v.lds, stream, d_probs, n_probs);
+    const int grid = grid_cap > 0 && grid_cap < total_tiles ? grid_cap : total_tiles;
+    hipLaunchKernelGGL(v.fn[ctype == GHN3_CT_BF16], dim3(grid), dim3(v.threads), v.lds, stream, d_probs, n_probs,
+                       total_tiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("h16d gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

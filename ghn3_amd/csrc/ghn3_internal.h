@@ -30,7 +30,7 @@ int ghn3_gemm_init();
 int ghn3_gemm_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode,
                      int tile, int ctype, hipStream_t stream);
 
-int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int tile, int ctype,
+int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int tile, int ctype, int grid_cap,
                           hipStream_t stream);
 int ghn3_gemm_small_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode,
                            hipStream_t stream);

@@ -372,7 +372,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                     rc = ghn3_gemm_small_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, stream);
                 else if (L.tile == 16 || L.tile == 24)
                     rc = ghn3_gemm_h16d_launch(ds + L.first, L.count, L.tiles, L.tile == 16 ? 128 : 256,
-                                               (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, stream);
+                                               (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, (int)o.i[3],
+                                               stream);
                 else
                     rc = ghn3_gemm_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, L.tile,
                                           (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, stream);

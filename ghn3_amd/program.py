@@ -259,7 +259,7 @@ class Program:
     TAG_NAMES = {1: 'w2_fwd', 2: 'w2_dgrad', 3: 'w2_wgrad', 4: 'w0_fwd', 5: 'fc_fwd', 6: 'tile_fwd', 7: 'tile_bwd',
                  8: 'w0_bwd', 9: 'fc_bwd'}
 
-    def gemm_op(self, first, count=None, tile=0, ctype=None, tag=0, side=False, flops=None):
+    def gemm_op(self, first, count=None, tile=0, ctype=None, tag=0, side=False, flops=None, grid_cap=0):
         if count is None:
             count = len(self._probs) - first
         if count > 0:
@@ -273,7 +273,7 @@ class Program:
                 fl = flops if flops is not None else \
                     sum(2.0 * int(p['M']) * int(p['N']) * int(p['K']) for p in self._probs[first:first + count])
                 self.tag_flops[tag] = self.tag_flops.get(tag, 0.0) + fl
-            self.op(L.OP_GEMM, ints=(first, count, tile), flags=flags)
+            self.op(L.OP_GEMM, ints=(first, count, tile, grid_cap), flags=flags)
 
     @staticmethod
     def _row_parts(rows):

@@ -183,7 +183,7 @@ def round16(x, ctype):
     return u.astype(np.uint32).view(np.float32)
 
 
-def run_op16_case(ctx, M, N, K, ctype=L.CT_F16, tile=0, a_transposed=False, b_transposed=False, kmap=None, ksplit=1,
+def run_op16_case(ctx, M, N, K, ctype=L.CT_F16, tile=0, grid_cap=0, a_transposed=False, b_transposed=False, kmap=None, ksplit=1,
                   epilogue='none', accum=False, colsum=False, cmap=False, seed=0, dev='cuda'):
     rs = np.random.RandomState(seed)
     r64 = lambda v: (v + 63) // 64 * 64
@@ -285,7 +285,7 @@ def run_op16_case(ctx, M, N, K, ctype=L.CT_F16, tile=0, a_transposed=False, b_tr
     ops[0]['r']['buf'][:4] = (0, 1, 2, 5 if colsum else -1)
     ops[1]['kind'] = L.OP_GEMM
     ops[1]['flags'] = 1 + ctype
-    ops[1]['i'][:3] = (0, 1, tile)
+    ops[1]['i'][:4] = (0, 1, tile, grid_cap)
     ctx.run(ops, p, ptrs, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     out = [(d_C.cpu().numpy(), expected)]
@@ -309,4 +309,7 @@ OP16_CASES = [
     dict(M=300, N=200, K=150, a_transposed=True, b_transposed=True, colsum=True, cmap=True, accum=True, tile=24),
     dict(M=533, N=384, K=64 * 48, kmap=(64, 96), ksplit=5, tile=24),
     dict(M=5, N=7, K=9, tile=24),
+    # persistent workgroups (grid cap): 3 workgroups stride over 99 / 30 tiles
+    dict(M=1100, N=1300, K=512, epilogue='bias_relu', grid_cap=3),
+    dict(M=1100, N=1300, K=200, tile=24, grid_cap=3, accum=True),
 ]

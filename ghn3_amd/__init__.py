@@ -8,6 +8,7 @@ Mirrors the package surface of the reference for this path (/root/reference/ghn3
 from .graph import Graph, GraphBatch
 from .nn import from_pretrained, GHN3, ConvDecoder3, SequentialMultipleInOut, log
 from .ddp_utils import setup_ddp, is_ddp, get_ddp_rank, clean_ddp, avg_ddp_metric, all_reduce_flat_grads
+from .optim import FusedAdamW
 
 __all__ = ['Graph', 'GraphBatch', 'from_pretrained', 'GHN3', 'ConvDecoder3', 'SequentialMultipleInOut', 'log',
-           'setup_ddp', 'is_ddp', 'get_ddp_rank', 'clean_ddp', 'avg_ddp_metric', 'all_reduce_flat_grads']
+           'setup_ddp', 'is_ddp', 'get_ddp_rank', 'clean_ddp', 'avg_ddp_metric', 'all_reduce_flat_grads', 'FusedAdamW']

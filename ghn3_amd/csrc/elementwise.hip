@@ -882,3 +882,62 @@ int ghn3_cast16(const float* src, void* dst, const ghn3_cast_desc* d_desc, int n
                        dbias, total_blocks);
     return launch_ok("cast16");
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Trainer step over the flat buffers (trainer.py:356-381): global gradient norm for
+// nn.utils.clip_grad_norm_ and a fused AdamW update -- two passes over the flat parameter / gradient / moment buffers
+// instead of ~10 ATen launches per parameter tensor.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void sumsq_kernel(float* __restrict__ out, const float* __restrict__ x, int64_t n) {
+    __shared__ float part[4];
+    float acc = 0.f;
+    const int64_t n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        const float4 v = x4[i];
+        acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) { const float v = x[(n4 << 2) + threadIdx.x]; acc += v * v; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+}
+int ghn3_sumsq(float* out, const float* x, int64_t n, hipStream_t s) {
+    if (n <= 0) return GHN3_OK;
+    if (reinterpret_cast<uintptr_t>(x) & 15) { ghn3_set_error("sumsq: buffer must be 16-byte aligned"); return GHN3_E_ARG; }
+    int64_t blocks = (n / 4 + 255) / 256;
+    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, x, n);
+    return launch_ok("sumsq");
+}
+
+struct AdamWArgs { float lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2_sqrt, max_norm; };
+
+// torch.optim.AdamW (decoupled weight decay) with the gradient scaled by clip_grad_norm_'s coefficient
+// min(1, max_norm / (||g|| + 1e-6)); `sumsq` holds ||g||^2 (absent: no clipping)
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                    float* __restrict__ m, float* __restrict__ v, int64_t n,
+                                                    const float* __restrict__ sumsq, AdamWArgs a) {
+    float clip = 1.f;
+    if (sumsq && a.max_norm > 0.f) clip = fminf(1.f, a.max_norm / (sqrtf(*sumsq) + 1e-6f));
+    const float step = a.lr / a.bias_corr1, decay = 1.f - a.lr * a.weight_decay;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float gi = g[i] * clip;
+        const float mi = a.beta1 * m[i] + (1.f - a.beta1) * gi;
+        const float vi = a.beta2 * v[i] + (1.f - a.beta2) * gi * gi;
+        m[i] = mi; v[i] = vi;
+        p[i] = p[i] * decay - step * mi / (sqrtf(vi) / a.bias_corr2_sqrt + a.eps);
+    }
+}
+int ghn3_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float lr, float beta1,
+               float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float max_norm,
+               hipStream_t s) {
+    if (n <= 0) return GHN3_OK;
+    AdamWArgs a{lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrtf(bias_corr2), max_norm};
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, sumsq, a);
+    return launch_ok("adamw");
+}

@@ -77,6 +77,10 @@ int ghn3_rowseg_sum(float* out, const float* X, const int* seg_ptr, const int* i
 int ghn3_add(float* dst, const float* src, int64_t n, hipStream_t s);
 int ghn3_cast16(const float* src, void* dst, const ghn3_cast_desc* d_desc, int n_desc, int total_blocks, float* dbias,
                 int grid_cap, hipStream_t s);
+int ghn3_sumsq(float* out, const float* x, int64_t n, hipStream_t s);
+int ghn3_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float lr, float beta1,
+               float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float max_norm,
+               hipStream_t s);
 int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, hipStream_t s);
 
 void ghn3_set_error(const char* fmt, ...);

@@ -219,6 +219,14 @@ enum ghn3_op_kind {
      * ghn3_run on the context (or observed with ghn3_ctx_side_wait).  Lets a caller split a program in two runs and
      * start the gradient all-reduce of the first part's weight gradients while the second part executes. */
     GHN3_OP_DETACH = 25,
+    /* trainer step over the flat buffers (trainer.py:356-381)
+     * SUMSQ: r0[0] += sum x^2 (r1 = x, i0 = n floats) -- the squared global gradient norm of clip_grad_norm_
+     * ADAMW: torch.optim.AdamW on r0 = params, r1 = grads, r2 = exp_avg, r3 = exp_avg_sq (i0 = n floats);
+     *        r4 = squared gradient norm or absent, f0 = max_norm (<= 0: no clipping): the gradient is scaled by
+     *        min(1, max_norm / (norm + 1e-6)); i1..i7 = IEEE-754 double bit patterns of lr, beta1, beta2, eps,
+     *        weight_decay, 1 - beta1^t, 1 - beta2^t */
+    GHN3_OP_SUMSQ = 26,
+    GHN3_OP_ADAMW = 27,
     GHN3_OP_KIND_COUNT
 };
 

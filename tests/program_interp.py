@@ -57,6 +57,23 @@ class Interp:
     def op_detach(self, o, problems):
         pass
 
+    def op_sumsq(self, o, problems):
+        n = int(o['i'][0])
+        x = self.fview(o['r'][1], n).astype(np.float64)
+        self.fview(o['r'][0], 1)[0] += np.float32((x * x).sum())
+
+    def op_adamw(self, o, problems):
+        n = int(o['i'][0])
+        lr, b1, b2, eps, wd, bc1, bc2 = (float(v) for v in o['i'][1:8].view(np.float64))
+        p, g, m, v = (self.fview(o['r'][k], n) for k in range(4))
+        clip = 1.0
+        if int(o['r'][4]['buf']) >= 0 and float(o['f'][0]) > 0:
+            clip = min(1.0, float(o['f'][0]) / (float(np.sqrt(self.fview(o['r'][4], 1)[0])) + 1e-6))
+        gi = g.astype(np.float64) * clip
+        m[:] = b1 * m + (1 - b1) * gi
+        v[:] = b2 * v + (1 - b2) * gi * gi
+        p[:] = p * (1 - lr * wd) - (lr / bc1) * m / (np.sqrt(v) / np.sqrt(bc2) + eps)
+
     @staticmethod
     def _rowmap(r, g, q, s):
         r = np.asarray(r, dtype=np.int64)

@@ -819,7 +819,6 @@ __device__ __forceinline__ void h16d_tile(const GemmProbDev* __restrict__ probs,
         // tile i has landed once at most the NS - 2 younger tiles are outstanding (fewer were issued near the end)
         if (i + NS - 1 <= nkt) wait_vmcnt<(NS - 2) * (PA + PB)>(); else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();                  // every wave's share of tile i landed; stage (i-1) % NS is free
-        if (i + NS - 1 < nkt) issue(i + NS - 1);
         const char* a_s = sm + (i % NS) * STAGE;
         const char* b_s = a_s + OPA;
         // fragments of k-step kk + 1 are read from LDS while the MFMAs of step kk run (two register sets)
@@ -848,6 +847,9 @@ __device__ __forceinline__ void h16d_tile(const GemmProbDev* __restrict__ probs,
                 for (int j = 0; j < TN; ++j)
                     acc[ii][j] = mfma16<CT>(af[kk & 1][ii], bf[kk & 1][j], acc[ii][j]);
             __builtin_amdgcn_sched_barrier(0);
+            // the DMA of the next tile is issued behind the first MFMA batch: its address arithmetic runs while the
+            // matrix pipe is busy instead of in front of the first fragment reads
+            if (kk == 0 && i + NS - 1 < nkt) { issue(i + NS - 1); __builtin_amdgcn_sched_barrier(0); }
         }
     }
     // (the host only routes problems with ldc % 4 == 0 and 16-byte aligned C / aux / residual to this kernel)

@@ -18,7 +18,19 @@ PRIMITIVES_DEEPNETS1M = ['max_pool', 'avg_pool', 'sep_conv', 'dil_conv', 'conv',
 
 # ---- ShapeEncoder vocabulary (ppuda) ---------------------------------------------------------------
 class ShapeVocab:
-    def __init__(self, num_classes, max_shape):
+    _cache = {}
+
+    def __new__(cls, num_classes, max_shape):
+        # the lookup tables depend on (num_classes, max spatial size) only: built once per process
+        key = (int(num_classes), int(max_shape[3]))
+        inst = cls._cache.get(key)
+        if inst is None:
+            inst = super().__new__(cls)
+            inst._build(num_classes, max_shape)
+            cls._cache[key] = inst
+        return inst
+
+    def _build(self, num_classes, max_shape):
         ch = sorted(set([1, 3, num_classes]) | set(range(8, 64, 8)) | set(range(64, 4096, 16)) |
                     set(range(4096, 8193, 32)))
         sp = sorted(set(range(1, max(12, max_shape[3]), 2)) | {14, 16})

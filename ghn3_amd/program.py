@@ -763,18 +763,21 @@ class Program:
                 # chunk of `ich` input channels (<= 16 KB of LDS, so that many blocks share a CU)
                 ich = int(max(16, min(int(max(T[1], R[1])), 4096 // hw)))
                 descs[k]['_pad'] = ich
-                fwd_blocks += [(~k, a0 | (i0 << 24)) for a0 in range(int(T[0])) for i0 in range(0, int(T[1]), ich)]
-                bwd_blocks += [(~k, a0 | (i0 << 24)) for a0 in range(int(R[0])) for i0 in range(0, int(R[1]), ich)]
+                for blocks, n0, n1 in ((fwd_blocks, int(T[0]), int(T[1])), (bwd_blocks, int(R[0]), int(R[1]))):
+                    word = (np.arange(n0, dtype=np.int64)[:, None] |
+                            (np.arange(0, n1, ich, dtype=np.int64)[None, :] << 24)).reshape(-1)
+                    blocks.append(np.stack([np.full(len(word), ~k, dtype=np.int64), word], axis=1))
                 self.tile_lds[0] = max(self.tile_lds[0], 4 * ich * hw)
                 self.tile_lds[1] = max(self.tile_lds[1], 4 * ich * hw)
                 continue
             n_f = int(np.prod(T))
             n_b = int(np.prod(R))
-            fwd_blocks += [(k, s) for s in range(0, n_f, CH)]
-            bwd_blocks += [(k, s) for s in range(0, n_b, CH)]
+            for blocks, n in ((fwd_blocks, n_f), (bwd_blocks, n_b)):
+                st = np.arange(0, n, CH, dtype=np.int64)
+                blocks.append(np.stack([np.full(len(st), k, dtype=np.int64), st], axis=1))
         desc_arr = np.array(descs, dtype=L.TILE_DT) if descs else np.zeros(1, dtype=L.TILE_DT)
-        fb = np.asarray(fwd_blocks, dtype=np.int64).reshape(-1, 2)
-        bb = np.asarray(bwd_blocks, dtype=np.int64).reshape(-1, 2)
+        fb = np.concatenate(fwd_blocks) if fwd_blocks else np.zeros((0, 2), dtype=np.int64)
+        bb = np.concatenate(bwd_blocks) if bwd_blocks else np.zeros((0, 2), dtype=np.int64)
         raw = np.concatenate([desc_arr.view(np.uint8).reshape(-1), fb.view(np.uint8).reshape(-1),
                               bb.view(np.uint8).reshape(-1)])
         self.r_desc = self.idx(raw)

@@ -500,8 +500,9 @@ int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d
 // region: dimension 1 fastest (the source-contiguous axis for decoder tiles), then 3, 2, 0.
 __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__ dflat, SrcTable srcs, DstTable dsrcs,
                                                        const ghn3_tile_desc* __restrict__ desc,
-                                                       const int64_t* __restrict__ blocks) {
+                                                       const int64_t* __restrict__ blocks, float* __restrict__ amax) {
     extern __shared__ float tl[];
+    float mx = 0.f;                                      // running max |x| written to source-grad buffer 0
     const int64_t di_raw = blocks[2 * (size_t)blockIdx.x];
     if (di_raw < 0) {
         // row block (see tile_fwd_kernel): source row a0 of the region; replicas along o and i are summed in LDS
@@ -549,8 +550,11 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
             int y = (int)((float)pp * inv_t3);
             int x = pp - y * T3;
             if (x < 0) { x += T3; --y; } else if (x >= T3) { x -= T3; ++y; }
-            dsrc[(int64_t)y * S2 + (int64_t)x * S3 + i] = (live && i < nl) ? tl[i * hw + pp] * scale : 0.f;
+            const float val = (live && i < nl) ? tl[i * hw + pp] * scale : 0.f;
+            dsrc[(int64_t)y * S2 + (int64_t)x * S3 + i] = val;
+            mx = fmaxf(mx, fabsf(val));
         }
+        if (amax && D->src_buf == 0) ghn3_atomic_amax(amax, mx);
         return;
     }
     const int64_t di = di_raw;
@@ -584,12 +588,14 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
             acc *= norm_grad(src[so], mode, scale);
         }
         dsrc[so] = acc;
+        mx = fmaxf(mx, fabsf(acc));
         o.step();
     }
+    if (amax && D->src_buf == 0) ghn3_atomic_amax(amax, mx);
 }
 
 int ghn3_tile_bwd(const float* dflat, const float* const* srcs, float* const* dsrcs, const ghn3_tile_desc* d_desc,
-                  int n_desc, int64_t total, const int64_t* blocks, int lds_bytes, hipStream_t s) {
+                  int n_desc, int64_t total, const int64_t* blocks, int lds_bytes, float* amax, hipStream_t s) {
     if (n_desc <= 0 || total <= 0) return GHN3_OK;
     SrcTable st; DstTable dt;
     for (int i = 0; i < 6; ++i) { st.p[i] = srcs[i]; dt.p[i] = dsrcs[i]; }
@@ -597,7 +603,8 @@ int ghn3_tile_bwd(const float* dflat, const float* const* srcs, float* const* ds
         if (lds_bytes > 128 * 1024) { ghn3_set_error("tile_bwd: row blocks need %d bytes of LDS", lds_bytes); return GHN3_E_LIMIT; }
         hipFuncSetAttribute((const void*)tile_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     }
-    hipLaunchKernelGGL(tile_bwd_kernel, dim3((unsigned)total), dim3(256), lds_bytes, s, dflat, st, dt, d_desc, blocks);
+    hipLaunchKernelGGL(tile_bwd_kernel, dim3((unsigned)total), dim3(256), lds_bytes, s, dflat, st, dt, d_desc, blocks,
+                       amax);
     return launch_ok("tile_bwd");
 }
 
@@ -731,8 +738,9 @@ int ghn3_rowseg_sum(float* out, const float* X, const int* seg_ptr, const int* i
 
 // X[m][n] *= dact(aux[m][n]) in place (deferred epilogue of a split-K dgrad)
 __global__ __launch_bounds__(256) void dact_kernel(float* __restrict__ X, const float* __restrict__ aux, int M, int N,
-                                                   int ld, int dact) {
+                                                   int ld, int dact, float* __restrict__ amax) {
     const int64_t total = (int64_t)M * N;
+    float mx = 0.f;
     for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
         const int64_t m = e / N;
         const int64_t o = m * ld + (e - m * N);
@@ -742,13 +750,15 @@ __global__ __launch_bounds__(256) void dact_kernel(float* __restrict__ X, const 
         else if (dact == GHN3_DACT_GELU)
             v *= 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
         X[o] = v;
+        mx = fmaxf(mx, fabsf(v));
     }
+    if (amax) ghn3_atomic_amax(amax, mx);
 }
-int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, hipStream_t s) {
+int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, float* amax, hipStream_t s) {
     if (M <= 0 || N <= 0) return GHN3_OK;
     int64_t blocks = ((int64_t)M * N + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(dact_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, aux, M, N, ld, dact);
+    hipLaunchKernelGGL(dact_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, aux, M, N, ld, dact, amax);
     return launch_ok("dact");
 }
 
@@ -780,7 +790,8 @@ typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 
 __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
                                                      const ghn3_cast_desc* __restrict__ descs, int n_desc,
-                                                     float* __restrict__ dbias, int total_items) {
+                                                     float* __restrict__ dbias, int total_items,
+                                                     const float* __restrict__ amax) {
     __shared__ unsigned short tr[64][66];          // transposed-copy staging (already converted)
     __shared__ float csum[16][64];
     // grid-stride over the 64 x 64 work tiles: a launch may cap its grid (side-stream copies that should leave
@@ -800,6 +811,7 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
     const float* S = src + D.src_off;
     const bool st = D.flags & GHN3_CAST_STRAIGHT, trn = D.flags & GHN3_CAST_TRANSPOSED;
     const bool st_bf = D.flags & GHN3_CAST_STRAIGHT_BF16, tr_bf = D.flags & GHN3_CAST_TRANSPOSED_BF16;
+    const float sc = ((D.flags & GHN3_CAST_SCALED) && amax) ? ghn3_pow2_scale(*amax) : 1.f;
 
     float4 v[4];
 #pragma unroll
@@ -817,6 +829,16 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
         }
         v[i] = x;
     }
+    if (D.flags & GHN3_CAST_COLSUM) {
+        csum[rr][c4] = v[0].x + v[1].x + v[2].x + v[3].x;
+        csum[rr][c4 + 1] = v[0].y + v[1].y + v[2].y + v[3].y;
+        csum[rr][c4 + 2] = v[0].z + v[1].z + v[2].z + v[3].z;
+        csum[rr][c4 + 3] = v[0].w + v[1].w + v[2].w + v[3].w;
+    }
+    if (sc != 1.f) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { v[i].x *= sc; v[i].y *= sc; v[i].z *= sc; v[i].w *= sc; }
+    }
     if (st) {
         unsigned short* Dd = dst + D.dst_off;
 #pragma unroll
@@ -828,12 +850,6 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
             else { h[0] = cast_f16(v[i].x); h[1] = cast_f16(v[i].y); h[2] = cast_f16(v[i].z); h[3] = cast_f16(v[i].w); }
             *reinterpret_cast<us4*>(Dd + (int64_t)r * D.ld_dst + c0 + c4) = h;
         }
-    }
-    if (D.flags & GHN3_CAST_COLSUM) {
-        csum[rr][c4] = v[0].x + v[1].x + v[2].x + v[3].x;
-        csum[rr][c4 + 1] = v[0].y + v[1].y + v[2].y + v[3].y;
-        csum[rr][c4 + 2] = v[0].z + v[1].z + v[2].z + v[3].z;
-        csum[rr][c4 + 3] = v[0].w + v[1].w + v[2].w + v[3].w;
     }
     if (trn) {
 #pragma unroll
@@ -875,11 +891,11 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
 }
 
 int ghn3_cast16(const float* src, void* dst, const ghn3_cast_desc* d_desc, int n_desc, int total_blocks, float* dbias,
-                int grid_cap, hipStream_t s) {
+                const float* amax, int grid_cap, hipStream_t s) {
     if (n_desc <= 0 || total_blocks <= 0) return GHN3_OK;
     const int grid = grid_cap > 0 && grid_cap < total_blocks ? grid_cap : total_blocks;
     hipLaunchKernelGGL(cast16_kernel, dim3(grid), dim3(256), 0, s, src, (unsigned short*)dst, d_desc, n_desc,
-                       dbias, total_blocks);
+                       dbias, total_blocks, amax);
     return launch_ok("cast16");
 }
 

@@ -265,7 +265,7 @@ __device__ __forceinline__ void epilogue_rows(const GemmProbDev* P, f32x16 (&acc
     E.C = (gf)P->C; E.residual = (gcf)P->residual; E.aux_in = (gcf)P->aux_in; E.aux_out = (gf)P->aux_out;
     E.cg = (gci)P->c_gather;
     E.accum = (P->flags & GHN3_GEMM_ACCUM) != 0;
-    E.alpha = P->alpha;
+    E.alpha = P->alpha_amax ? P->alpha * ghn3_pow2_inv_scale(*P->alpha_amax) : P->alpha;
     E.l31 = lane & 31; E.lhi = lane >> 5;
     E.c4 = (lane & 15) * 4; E.rsub = lane >> 4;               // this lane's 4 columns / row inside a 4-row group
     E.col = n_base + E.c4;
@@ -296,12 +296,13 @@ __device__ __forceinline__ void epilogue_rows(const GemmProbDev* P, f32x16 (&acc
 __device__ __forceinline__ void epilogue_split_block(const GemmProbDev* P, const f32x16& a, int row0, int col, int lhi) {
     if (col >= P->N) return;
     gf C = (gf)P->C;
+    const float alpha = P->alpha_amax ? P->alpha * ghn3_pow2_inv_scale(*P->alpha_amax) : P->alpha;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
         if (row < P->M)
             __hip_atomic_fetch_add(C + (int64_t)map_row(row, (gci)P->c_gather, P->c_q, P->c_s) * P->ldc + col,
-                                   a[r] * P->alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                   a[r] * alpha, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 template <int TM>

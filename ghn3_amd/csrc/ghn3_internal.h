@@ -21,6 +21,7 @@ struct GemmProbDev {
     int kq, ks;          // 16-bit-operand kernel: k-map of B (kq == 0: identity)
     const int* lim;      // ragged extents per 128 rows (see ghn3_gemm_problem::lim)
     int lim_kind, _pad3;
+    const float* alpha_amax;   // alpha is divided by ghn3_pow2_scale(*alpha_amax) (operand copies scaled by GHN3_CAST_SCALED)
     int _pad;
 };
 
@@ -65,7 +66,7 @@ int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d
                   int64_t total, const int64_t* blocks, int lds_bytes, hipStream_t s);
 int ghn3_tile_bwd(const float* dflat, const float* const* srcs, float* const* dsrcs,
                   const ghn3_tile_desc* d_desc, int n_desc, int64_t total, const int64_t* blocks, int lds_bytes,
-                  hipStream_t s);
+                  float* amax, hipStream_t s);
 int ghn3_param_norm_fwd(float* loss, const float* flat, const int64_t* seg_off, float* norms, int n_seg,
                         hipStream_t s);
 int ghn3_param_norm_bwd(float* dflat, const float* flat, const int64_t* seg_off, const float* norms, int n_seg,
@@ -76,11 +77,39 @@ int ghn3_rowseg_sum(float* out, const float* X, const int* seg_ptr, const int* i
                     int ldo, int accum, hipStream_t s);
 int ghn3_add(float* dst, const float* src, int64_t n, hipStream_t s);
 int ghn3_cast16(const float* src, void* dst, const ghn3_cast_desc* d_desc, int n_desc, int total_blocks, float* dbias,
-                int grid_cap, hipStream_t s);
+                const float* amax, int grid_cap, hipStream_t s);
 int ghn3_sumsq(float* out, const float* x, int64_t n, hipStream_t s);
 int ghn3_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float lr, float beta1,
                float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float max_norm,
                hipStream_t s);
-int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, hipStream_t s);
+int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, float* amax, hipStream_t s);
 
 void ghn3_set_error(const char* fmt, ...);
+
+#ifdef __HIPCC__
+// Power-of-two scaling of small-magnitude gradients for f16 operand copies: for amax = m * 2^e (1 <= m < 2) the
+// scale 2^(11 - e) maps the largest magnitude into [2048, 4096) (16x headroom to the f16 maximum; 2^-14 / 4096 =
+// 1.5e-8 of amax still a normal f16 number).  Exact, so the GEMM epilogue undoes it with the exact inverse.
+__device__ __forceinline__ int ghn3_amax_exp(float amax) {
+    return (int)((__float_as_uint(amax) >> 23) & 0xff) - 127;
+}
+__device__ __forceinline__ float ghn3_pow2_scale(float amax) {
+    const int e = ghn3_amax_exp(amax);
+    if (!(amax > 0.f) || e < -100) return 1.f;
+    return __uint_as_float((unsigned)(127 + 11 - e) << 23);
+}
+__device__ __forceinline__ float ghn3_pow2_inv_scale(float amax) {
+    const int e = ghn3_amax_exp(amax);
+    if (!(amax > 0.f) || e < -100) return 1.f;
+    return __uint_as_float((unsigned)(127 - 11 + e) << 23);
+}
+// running maximum of non-negative floats (bit pattern order == value order); call with all lanes of the wave
+__device__ __forceinline__ void ghn3_atomic_amax(float* slot, float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    // (the racy pre-check is safe -- the slot only grows -- and keeps thousands of workgroups from serialising on
+    // one address: after the first few, almost no wave exceeds the running maximum)
+    if ((threadIdx.x & 63) == 0 && v > *reinterpret_cast<volatile float*>(slot))
+        atomicMax(reinterpret_cast<int*>(slot), __float_as_int(v));
+}
+#endif

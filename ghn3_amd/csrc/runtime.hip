@@ -289,6 +289,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             g.kq = (tl == 16 || tl == 24) ? p.b_kq : 0; g.ks = p.b_ks;
                             g.lim = (tl == 16 || tl == 24) ? R.get<const int>(p.lim) : nullptr;
                             g.lim_kind = g.lim ? p.lim_kind : 0;
+                            g.alpha_amax = (tl == 16 || tl == 24) ? R.get<const float>(p.alpha_amax) : nullptr;
                             g.order = (int64_t)p.M > (int64_t)p.N ? 1 : 0;   // stream the larger operand once
                             g.ksplit = p.ksplit > 1 ? p.ksplit : 1;
                             g.k_chunk = ((p.K + g.ksplit - 1) / g.ksplit + 63) / 64 * 64;
@@ -453,11 +454,11 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         }
         case GHN3_OP_TILE_BWD: {
             const float* srcs[6]; float* dsrcs[6];
-            for (int j = 0; j < 6; ++j) { srcs[j] = R.get<const float>(o.r[1 + j]); dsrcs[j] = R.get<float>(o.r[8 + j]); }
+            for (int j = 0; j < 6; ++j) { srcs[j] = R.get<const float>(o.r[1 + j]); dsrcs[j] = j < 5 ? R.get<float>(o.r[8 + j]) : nullptr; }
             const ghn3_tile_desc* dd = R.get<const ghn3_tile_desc>(o.r[7]);
             rc = ghn3_tile_bwd(R.get<const float>(o.r[0]), srcs, dsrcs, dd, (int)o.i[0], o.i[1],
                                reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(dd) + o.i[2]),
-                               (int)o.i[3], stream);
+                               (int)o.i[3], R.get<float>(o.r[13]), stream);
             break;
         }
         case GHN3_OP_PARAM_NORM_FWD:
@@ -488,7 +489,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             break;
         case GHN3_OP_CAST16:
             rc = ghn3_cast16(R.get<const float>(o.r[0]), R.get<void>(o.r[1]), R.get<const ghn3_cast_desc>(o.r[2]),
-                             (int)o.i[0], (int)o.i[1], R.get<float>(o.r[3]), (int)o.i[2], stream);
+                             (int)o.i[0], (int)o.i[1], R.get<float>(o.r[3]), R.get<const float>(o.r[4]), (int)o.i[2],
+                             stream);
             break;
         case GHN3_OP_SUMSQ:
             rc = ghn3_sumsq(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), o.i[0], stream);
@@ -503,7 +505,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         }
         case GHN3_OP_DACT:
             rc = ghn3_dact(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), (int)o.i[0], (int)o.i[1], (int)o.i[2],
-                           (int)o.i[3], stream);
+                           (int)o.i[3], R.get<float>(o.r[2]), stream);
             break;
         default:
             ghn3_set_error("op %d: unknown kind %d", k, o.kind);

@@ -111,8 +111,9 @@ class GHN3(nn.Module):
       compute      MFMA operand type of the decoder GEMMs (fc / W0 / W2, forward and backward):
                    'f32' (default: exact fp32 MFMA), 'f16' or 'bf16' (fp32 accumulate).
                    The Graphormer and the small heads always run exact fp32.
-      compute_bwd  operand type of the W2 backward GEMMs in 16-bit mode (default: 'bf16' -- the upstream
-                   gradients are too small for f16's range)
+      compute_bwd  operand type of the decoder backward GEMMs in 16-bit mode (default: same as `compute`; f16
+                   gradient copies are scaled by a power of two derived from their running max, so the ~1e-6
+                   upstream gradients keep 11 significant bits; 'bf16' trades precision for range without scaling)
       side_stream  True (default): weight gradients, LayerNorm parameter gradients and operand copies overlap with
                    the dependent chain of the program on a second HIP stream
       direct16     True (default): in 16-bit mode the W2 GEMMs read per-step 16-bit operand copies (GHN3_OP_CAST16)

@@ -66,11 +66,14 @@ class Program:
         # MFMA operand type of the decoder GEMMs (fc / W0 / W2, forward and backward): None = context default.
         # The Graphormer, the edge MLP and the small heads always multiply in exact fp32.
         self.decoder_ctype = decoder_ctype
-        # Backward operand type of the W2 trio in the 16-bit pipeline: the upstream gradients d_tiles are ~1e-6 in
-        # magnitude (f16 subnormals), so an f16 forward pairs with a bf16 backward by default.
+        # Backward operand type of the W2 trio / D2 in the 16-bit pipeline.  The upstream gradients (d_tiles, d_u) are
+        # ~1e-6 in magnitude -- f16 subnormals -- so f16 backward copies are scaled by a power of two derived from the
+        # running max |x| of their fp32 source (GHN3_CAST_SCALED; the GEMM epilogue divides it out again): 2^-11
+        # operand rounding instead of bf16's 2^-8, gradients within 3e-4 of the oracle instead of 1.3e-3.
         if decoder_bwd_ctype is None:
-            decoder_bwd_ctype = L.CT_BF16 if decoder_ctype == L.CT_F16 else decoder_ctype
+            decoder_bwd_ctype = decoder_ctype
         self.decoder_bwd_ctype = decoder_bwd_ctype
+        self.bwd_scaled = decoder_bwd_ctype == L.CT_F16
         # direct16: the W2 GEMMs (98 % of the decoder flops) read 16-bit operand COPIES written once per step by
         # GHN3_OP_CAST16 (k-contiguous, zero padded, LDS-DMA friendly) instead of converting fp32 while staging.
         self.direct16 = bool(direct16) and decoder_ctype in (L.CT_F16, L.CT_BF16) and (8 * int(cfg['hid'])) % 64 == 0
@@ -167,7 +170,7 @@ class Program:
     def href(self, off_halfs):
         return (self.xbuf(self.X_WS), 2 * int(off_halfs))
 
-    def cast16(self, src_base, items, dbias=None, flags=0, grid_cap=0):
+    def cast16(self, src_base, items, dbias=None, flags=0, grid_cap=0, amax=None):
         """One GHN3_OP_CAST16 over `items` = dicts(src_off [floats from src_base], rows, cols, ld_src,
         straight=(off_halfs, ld, ctype) | None, transposed=(off_halfs, ld, ctype) | None, colsum=(q, s) | None)."""
         descs = np.zeros(len(items), dtype=L.CAST_DT)
@@ -189,13 +192,17 @@ class Program:
                 assert dbias is not None
                 D['bias_q'], D['bias_s'] = it['colsum']
                 dflags |= L.CAST_COLSUM
+            if it.get('scaled'):
+                assert amax is not None
+                dflags |= L.CAST_SCALED
             assert it['ld_src'] % 4 == 0 and it['src_off'] % 4 == 0
             D['flags'] = dflags
             D['block_start'] = blocks
             blocks += ((it['rows'] + 63) // 64) * ((it['cols'] + 63) // 64)
         if blocks:
             self.op(L.OP_CAST16, refs=(src_base, (self.xbuf(self.X_WS), 0), self.idx(descs),
-                                       dbias if dbias is not None else self.NONE), ints=(len(items), blocks, grid_cap),
+                                       dbias if dbias is not None else self.NONE,
+                                       amax if amax is not None else self.NONE), ints=(len(items), blocks, grid_cap),
                     flags=flags)
 
     def idx(self, arr):
@@ -229,7 +236,7 @@ class Program:
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, bias=None, bias_q=0,
              bias_s=0, bias_stride=1, act=L.ACT_NONE, dact=L.DACT_NONE, aux_in=None, aux_out=None, residual=None,
              a_gather=None, b_gather=None, c_gather=None, a_qs=(0, 0), b_qs=(0, 0), c_qs=(0, 0), accum=False,
-             alpha=1.0, dbias=None, dbias_stride=1, ksplit=1, op16=False, b_kmap=(0, 0), lim=None, lim_kind=0):
+             alpha=1.0, dbias=None, dbias_stride=1, ksplit=1, op16=False, b_kmap=(0, 0), lim=None, lim_kind=0, alpha_amax=None):
         # dbias: fused bias gradient of a wgrad problem (GHN3_GEMM_BIASGRAD): dbias[cmap(m)*stride] += sum_k A(m,k)
         if dbias is not None:
             assert bias is None and a_mode == L.MODE_COL
@@ -237,7 +244,7 @@ class Program:
         p = np.zeros((), dtype=L.PROBLEM_DT)
         for name, ref in (('A', A), ('B', B), ('C', C), ('bias', bias), ('residual', residual), ('aux_in', aux_in),
                           ('aux_out', aux_out), ('a_gather', a_gather), ('b_gather', b_gather),
-                          ('c_gather', c_gather), ('lim', lim)):
+                          ('c_gather', c_gather), ('lim', lim), ('alpha_amax', alpha_amax)):
             ref = self.NONE if ref is None else ref
             p[name]['buf'], p[name]['off'] = ref
         for name, v in (('M', M), ('N', N), ('K', K), ('lda', lda), ('ldb', ldb), ('ldc', ldc), ('a_mode', a_mode),
@@ -859,9 +866,20 @@ class Program:
             if self.n1_clsb:
                 self.wsf('d_cbout', self.n1_clsb * ldK)
                 self.op(L.OP_MEMSET0, refs=(self.wref('d_cbout'),), ints=(4 * self.n1_clsb * ldK,))
+        # running max |x| of d_tiles ([0], written by TILE_BWD) and d_u ([4], written by DACT): the power-of-two
+        # scales of the f16 gradient copies
+        self.r_amax = self.wsf('amax', 16)
+        scaled = self.bwd_scaled and self.direct16 and M > 0
+        amax_t = self.r_amax if scaled else None
+        amax_u = (self.r_amax[0], self.r_amax[1] + 16) if scaled else None
+        if scaled:
+            self.op(L.OP_MEMSET0, refs=(self.r_amax,), ints=(64,))
         if self.n_desc:
+            grads = self._tile_sources(True)
+            if scaled:
+                grads[5] = amax_t
             self.op(L.OP_TILE_BWD, refs=[(self.xbuf(self.X_DOUT), 0)] + self._tile_sources(False) + [self.r_desc] +
-                    self._tile_sources(True), ints=(self.n_desc, self.bwd_blk[0], self.bwd_blk[1], self.tile_lds[1]),
+                    grads, ints=(self.n_desc, self.bwd_blk[0], self.bwd_blk[1], self.tile_lds[1]),
                     flags=L.OPFLAG_TIMED | (self.TAG_TILE_BWD << 16))
 
         Wfc, bfc = 'decoder.fc.0.weight', 'decoder.fc.0.bias'
@@ -916,7 +934,8 @@ class Program:
                     g['dth'] = self.ws16('dth%d' % g['row0'], g['rows'] * g['dth_ld'])
                     # (rows of a family with a smaller extent keep zeros beyond it: d_tiles is never written there)
                     items.append(dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'], rows=g['rows'],
-                                      cols=g['cols'], ld_src=g['ld'], straight=(g['dth'], g['dth_ld'], bct)))
+                                      cols=g['cols'], ld_src=g['ld'], straight=(g['dth'], g['dth_ld'], bct),
+                                      scaled=scaled))
                     k_off = 0
                     for sb in g['subs']:
                         sb['k_off'] = k_off
@@ -929,12 +948,12 @@ class Program:
                         side_items.append(dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'] +
                                                (sb['row0'] - g['row0']) * g['ld'], rows=sb['rows'], cols=sb['cols'],
                                                ld_src=g['ld'], transposed=(fam['dthT'] + sb['k_off'], k_off, bct),
-                                               colsum=(g['i_ld'], ms[1])))
+                                               colsum=(g['i_ld'], ms[1]), scaled=scaled))
                         side_items.append(dict(src_off=u[1] // 4 + sb['row0'] * 8 * C, rows=sb['rows'], cols=8 * C,
                                                ld_src=8 * C, transposed=(fam['uhT'] + sb['k_off'], k_off, bct)))
                 # the dgrad operand on the critical path; the wgrad operands (and the bias gradient) beside it
-                self.cast16((self.xbuf(self.X_WS), 0), items)
-                self.cast16((self.xbuf(self.X_WS), 0), side_items, dbias=self.gref(b2), flags=self.SIDE)
+                self.cast16((self.xbuf(self.X_WS), 0), items, amax=amax_t)
+                self.cast16((self.xbuf(self.X_WS), 0), side_items, dbias=self.gref(b2), flags=self.SIDE, amax=amax_t)
             p0 = len(self._probs)
             fl = 0.0
             for g in self.gemm_groups:
@@ -946,14 +965,15 @@ class Program:
                     self.gemm(self.href(g['dth']), self.href(self.w2hT), (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),
                               g['rows'], 8 * C, g['cols'], g['dth_ld'], self.w2hT_ld, 8 * C, ksplit=ks, op16=True,
                               b_kmap=(g['i_ld'], ms[1]), lim=self.idx(g['lim128']) if g['ragged'] else None,
-                              lim_kind=2)
+                              lim_kind=2, alpha_amax=amax_t)
                     continue
                 self.gemm(self.wref('d_tiles', g['tile_off']), self.pref(W2),
                           (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),
                           g['rows'], 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
                           b_qs=(g['i_ld'], ms[1]), ksplit=ks)
             self.gemm_op(p0, ctype=bct if g16 else None, tag=self.TAG_D3_DGRAD, flops=fl)
-            self.op(L.OP_DACT, refs=(d_u, u), ints=(M, 8 * C, 8 * C, L.DACT_RELU))
+            self.op(L.OP_DACT, refs=(d_u, u, amax_u if amax_u is not None else self.NONE),
+                    ints=(M, 8 * C, 8 * C, L.DACT_RELU))
             # dW2 += d_tiles^T u.  16-bit families first (the family of the full-width groups writes every dW2 row
             # without reading it), then the groups on the fp32-operand path; families overlap in W2 rows -> one
             # launch per family, in order, on the side stream.
@@ -975,7 +995,8 @@ class Program:
                     # the K range is already zero padded per group: pass the padded prefix as K
                     self.gemm(self.href(fam['dthT'] + o_lo * fam['i'] * fam['ktot']), self.href(fam['uhT']),
                               self.gref(W2, o_lo * ms[1] * 8 * C), (o_hi - o_lo) * fam['i'], 8 * C, kpre,
-                              fam['ktot'], fam['ktot'], 8 * C, c_qs=(fam['i'], ms[1]), accum=not full, op16=True)
+                              fam['ktot'], fam['ktot'], 8 * C, c_qs=(fam['i'], ms[1]), accum=not full, op16=True,
+                              alpha_amax=amax_t)
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=True, flops=fl)
             for gi, g in enumerate(self.gemm_groups):
                 if g['op16']:
@@ -1001,17 +1022,18 @@ class Program:
                 duhT = self.ws16('duhT', 8 * C * Mp)
                 thT = self.ws16('thT', 4 * C * Mp)
                 self.cast16((self.xbuf(self.X_WS), 0),
-                            [dict(src_off=d_u[1] // 4, rows=M, cols=8 * C, ld_src=8 * C, straight=(duh, 8 * C, bct))])
+                            [dict(src_off=d_u[1] // 4, rows=M, cols=8 * C, ld_src=8 * C, straight=(duh, 8 * C, bct),
+                                  scaled=scaled)], amax=amax_u)
                 self.cast16((self.xbuf(self.X_WS), 0),
                             [dict(src_off=d_u[1] // 4, rows=M, cols=8 * C, ld_src=8 * C, transposed=(duhT, Mp, bct),
-                                  colsum=(0, 0)),
+                                  colsum=(0, 0), scaled=scaled),
                              dict(src_off=t[1] // 4, rows=M, cols=4 * C, ld_src=4 * C, transposed=(thT, Mp, bct))],
-                            dbias=self.gref(b0), flags=self.SIDE)
+                            dbias=self.gref(b0), flags=self.SIDE, amax=amax_u)
                 p0 = self.gemm(self.href(duhT), self.href(thT), self.gref(W0), 8 * C, 4 * C, Mp, Mp, Mp, 4 * C,
-                               accum=True, op16=True)
+                               accum=True, op16=True, alpha_amax=amax_u)
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D2_BWD, side=True, flops=2.0 * 8 * C * 4 * C * M)
                 p0 = self.gemm(self.href(duh), self.href(self.w0hT), d_t, M, 4 * C, 8 * C, 8 * C, 8 * C, 4 * C,
-                               dact=L.DACT_RELU, aux_in=t, op16=True)
+                               dact=L.DACT_RELU, aux_in=t, op16=True, alpha_amax=amax_u)
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D2_BWD)
             else:
                 p0 = self.gemm(d_u, t, self.gref(W0), 8 * C, 4 * C, M, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_COL,

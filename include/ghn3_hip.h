@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 5
+#define GHN3_ABI_VERSION 6
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -99,6 +99,10 @@ typedef struct ghn3_gemm_problem {
      * beyond it): the K loop of a tile stops at the largest extent of its rows (dgrad of the same stacking). */
     ghn3_ref lim;
     int32_t lim_kind, _pad2;
+    /* GHN3_GEMM_OP16 only, optional: device float holding the running max |x| of the fp32 source of an operand copy
+     * that GHN3_OP_CAST16 scaled by a power of two (GHN3_CAST_SCALED): alpha is divided by that scale
+     * (2^(11 - e) for amax = m 2^e; exact).  f16 copies of ~1e-6 gradients would otherwise be subnormal. */
+    ghn3_ref alpha_amax;
 } ghn3_gemm_problem;
 
 /* ---- 16-bit operand copies (GHN3_OP_CAST16) -----------------------------------------------------------
@@ -114,6 +118,9 @@ typedef struct ghn3_gemm_problem {
 #define GHN3_CAST_STRAIGHT_BF16 4u
 #define GHN3_CAST_TRANSPOSED_BF16 8u
 #define GHN3_CAST_COLSUM 16u
+/* multiply by the power-of-two scale derived from the op's r4 (running max |x|, see ghn3_gemm_problem::alpha_amax)
+ * before converting; column sums stay unscaled */
+#define GHN3_CAST_SCALED 32u
 typedef struct ghn3_cast_desc {
     int64_t src_off, dst_off, dstT_off;
     int32_t rows, cols;
@@ -178,7 +185,8 @@ enum ghn3_op_kind {
     GHN3_OP_PARAM_NORM_FWD = 9,
     /* r0=dflat r1=flat r2=seg_off r3=norms ; i: n_seg ; f0 = upstream grad */
     GHN3_OP_PARAM_NORM_BWD = 10,
-    /* r0=dflat, r1..r6 = source buffers (values), r7=desc, r8..r13 = source-grad buffers
+    /* r0=dflat, r1..r6 = source buffers (values), r7=desc, r8..r12 = source-grad buffers, r13 = optional device float
+     * that receives the running max |x| of everything written to source-grad buffer 0 (the decoder tiles)
      * i: n_desc, n_work_blocks, byte offset from r7 to the backward work-block table, LDS bytes (row blocks) */
     GHN3_OP_TILE_BWD = 11,
     /* column sums: out[omap(n)] += sum_m X[g(m)][n] ; r0=out r1=X r2=row gather (int32) or absent
@@ -206,10 +214,11 @@ enum ghn3_op_kind {
     /* r0=dst r1=src ; i0 = n floats ; dst += src */
     GHN3_OP_ADD = 21,
     /* in place: X[m][n] *= dact(aux[m][n]) ; r0=X r1=aux ; i: M,N,ld, dact (GHN3_DACT_*) -- the deferred
-     * epilogue of a split-K dgrad GEMM */
+     * epilogue of a split-K dgrad GEMM; r2 = optional device float receiving the running max |X| after masking */
     GHN3_OP_DACT = 22,
     /* fp32 -> f16 / bf16 operand copies for GHN3_GEMM_OP16 problems (straight and / or transposed, zero padded)
      * r0=src base (fp32) r1=dst base (16-bit) r2=ghn3_cast_desc table (device) r3=dbias or absent
+     * r4=running max |x| (device float) for descriptors flagged GHN3_CAST_SCALED, or absent
      * i: n_desc, total work tiles, grid cap (0 = one workgroup per tile; > 0: at most that many workgroups stride
      * over the tiles -- side-stream copies that should leave HBM bandwidth to the chain they run under) */
     GHN3_OP_CAST16 = 23,

@@ -23,7 +23,7 @@ def bench(ctx, M, N, K, a_mode, b_mode, tile=0, ctype=L.CT_F32, ksplit=1, accum=
     C = torch.zeros(M, ldc, device=dev)
     bufs = np.asarray([A.data_ptr(), B.data_ptr(), C.data_ptr()], dtype=np.uint64)
     p = np.zeros(1, dtype=L.PROBLEM_DT)
-    for nme in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim'):
+    for nme in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim', 'alpha_amax'):
         p[nme]['buf'] = -1
     p['A']['buf'], p['B']['buf'], p['C']['buf'] = 0, 1, 2
     p['M'], p['N'], p['K'], p['lda'], p['ldb'], p['ldc'] = M, N, K, lda, ldb, ldc
@@ -91,7 +91,7 @@ def bench16(ctx, M, N, K, ctype, ksplit=1, accum=False, kmap=None, reps=5, name=
     C = torch.zeros(M, ldc, device=dev)
     bufs = np.asarray([A.data_ptr(), B.data_ptr(), C.data_ptr()], dtype=np.uint64)
     p = np.zeros(1, dtype=L.PROBLEM_DT)
-    for nme in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim'):
+    for nme in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim', 'alpha_amax'):
         p[nme]['buf'] = -1
     p['A']['buf'], p['B']['buf'], p['C']['buf'] = 0, 1, 2
     p['M'], p['N'], p['K'], p['lda'], p['ldb'], p['ldc'] = M, N, K, lda, ldb, ldc

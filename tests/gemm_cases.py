@@ -96,7 +96,7 @@ def run_gemm_case(ctx, M, N, K, a_mode, b_mode, tile=0, ctype=L.CT_F32, gather=F
     bufs = [dA, dB, dC, dbias, dres, daux, daux_out, dga, dgc]
     ptrs = np.asarray([b.data_ptr() if b is not None else 0 for b in bufs], dtype=np.uint64)
     p = np.zeros(1, dtype=L.PROBLEM_DT)
-    for name in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim'):
+    for name in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim', 'alpha_amax'):
         p[name]['buf'] = -1
     p['A']['buf'], p['B']['buf'], p['C']['buf'] = 0, 1, 2
     if epilogue in ('bias_relu', 'full', 'gelu', 'dgelu', 'drelu', 'biasgrad'):
@@ -263,7 +263,7 @@ def run_op16_case(ctx, M, N, K, ctype=L.CT_F16, tile=0, grid_cap=0, a_transposed
     bufs = [d_src, d_16, d_desc, d_C, d_bias, d_dbias]
     ptrs = np.asarray([b.data_ptr() for b in bufs], dtype=np.uint64)
     p = np.zeros(1, dtype=L.PROBLEM_DT)
-    for name in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim'):
+    for name in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim', 'alpha_amax'):
         p[name]['buf'] = -1
     p['A']['buf'], p['A']['off'] = 1, 2 * dA_off
     p['B']['buf'], p['B']['off'] = 1, 2 * dB_off

@@ -99,12 +99,22 @@ class Interp:
             return h.view(np.float16).astype(np.float32)
         return (h.astype(np.uint32) << 16).view(np.float32)
 
+    @staticmethod
+    def pow2_scale(amax):
+        """ghn3_pow2_scale: 2^(11 - e) for amax = m 2^e."""
+        amax = float(amax)
+        if not amax > 0:
+            return 1.0
+        e = int(np.floor(np.log2(amax)))
+        return 1.0 if e < -100 else float(2.0 ** (11 - e))
+
     def op_cast16(self, o, problems):
         n_desc, blocks = int(o['i'][0]), int(o['i'][1])
         src = self.tail(o['r'][0], np.float32)
         dst = self.tail(o['r'][1], np.uint16)
         descs = self.view(o['r'][2], L.CAST_DT, n_desc)
         dbias = self.tail(o['r'][3], np.float32)
+        amax = self.tail(o['r'][4], np.float32)
         r64 = lambda v: (v + 63) // 64 * 64
         nb = 0
         for D in descs:
@@ -114,6 +124,9 @@ class Interp:
             off = int(D['src_off'])
             X = src[off + np.arange(rows)[:, None] * ld + np.arange(cols)[None, :]]
             fl = int(D['flags'])
+            Xsum = X
+            if fl & L.CAST_SCALED and amax is not None:
+                X = (X * np.float32(self.pow2_scale(amax[0]))).astype(np.float32)
             if fl & L.CAST_STRAIGHT:
                 Z = np.zeros((rows, r64(cols)), np.float32)
                 Z[:, :cols] = X
@@ -131,7 +144,7 @@ class Interp:
                 q, s_ = int(D['bias_q']), int(D['bias_s'])
                 if q > 0:
                     c = (c // q) * s_ + c % q
-                np.add.at(dbias, c, X.astype(np.float64).sum(0).astype(np.float32))
+                np.add.at(dbias, c, Xsum.astype(np.float64).sum(0).astype(np.float32))
         assert nb == blocks
 
     def _gemm_op16(self, o, p):
@@ -201,7 +214,10 @@ class Interp:
             ldc = int(p['ldc'])
             Y = self.tail(p['C'], np.float32)
             gc = self.tail(p['c_gather'], np.int32)
-            v = (A.astype(np.float64) @ Bm.astype(np.float64)) * float(p['alpha'])
+            alpha = float(p['alpha'])
+            if 'alpha_amax' in p.dtype.names and int(p['alpha_amax']['buf']) >= 0:
+                alpha /= self.pow2_scale(self.tail(p['alpha_amax'], np.float32)[0])
+            v = (A.astype(np.float64) @ Bm.astype(np.float64)) * alpha
             rc = self._rowmap(np.arange(M), gc, int(p['c_q']), int(p['c_s']))
             ci = rc[:, None] * ldc + np.arange(N)[None, :]
             if int(p['flags']) & L.GEMM_BIASGRAD:
@@ -461,7 +477,8 @@ class Interp:
     def op_tile_bwd(self, o, problems):
         g = self.tail(o['r'][0], np.float32)
         srcs = [self.tail(o['r'][1 + k], np.float32) for k in range(6)]
-        dsrcs = [self.tail(o['r'][8 + k], np.float32) for k in range(6)]
+        dsrcs = [self.tail(o['r'][8 + k], np.float32) for k in range(5)] + [None]
+        amax = self.tail(o['r'][13], np.float32)            # r13: running max |x| written to source-grad buffer 0
         for D in self._descs(o):
             T, E, S, R = (D[k].astype(np.int64) for k in ('T', 'E', 'S', 'R'))
             n = int(np.prod(T))
@@ -481,6 +498,8 @@ class Interp:
             inside[:E[0], :E[1], :E[2], :E[3]] = True
             acc = np.where(inside, acc, 0.0)
             dsrcs[int(D['src_buf'])][so.reshape(-1)] = acc.reshape(-1).astype(np.float32)
+            if amax is not None and int(D['src_buf']) == 0 and acc.size:
+                amax[0] = max(float(amax[0]), float(np.abs(acc.astype(np.float32)).max()))
 
     def op_param_norm_fwd(self, o, problems):
         n = int(o['i'][0])
@@ -541,6 +560,9 @@ class Interp:
             X[ii] = np.where(z > 0, X[ii], 0.0)
         else:
             X[ii] = X[ii] * (0.5 * (1 + erf(z / math.sqrt(2))) + z * np.exp(-0.5 * z * z) / math.sqrt(2 * math.pi))
+        amax = self.tail(o['r'][2], np.float32)
+        if amax is not None:
+            amax[0] = max(float(amax[0]), float(np.abs(X[ii]).max()))
 
     def op_add(self, o, problems):
         n = int(o['i'][0])

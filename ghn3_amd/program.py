@@ -961,7 +961,8 @@ class Program:
                 tiles = ((g['rows'] + 127) // 128) * ((8 * C + 127) // 128)
                 # split K until the launch offers ~512 tiles (two 128 x 128 workgroups per CU): measured best among
                 # 512 .. 3072 (1.39 vs 1.54 ms at 2048) -- more splits only add atomics and tile-count quantisation
-                ks = int(max(2, min(64, (512 + tiles - 1) // tiles, g['cols'] // 1024)))
+                tgt = 512 if g['op16'] else 2048       # (the fp32-operand kernel likes ~2048 tiles: 8.2 vs 9.8 ms)
+                ks = int(max(2, min(64, (tgt + tiles - 1) // tiles, g['cols'] // 1024)))
                 if g['op16']:
                     # one problem per family; the K loop of a row tile stops at the largest extent of its rows
                     self.gemm(self.href(g['dth']), self.href(self.w2hT), (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),

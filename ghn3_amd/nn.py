@@ -138,9 +138,6 @@ class GHN3(nn.Module):
         self.direct16 = kwargs.pop('direct16', True)
         self.side_stream = kwargs.pop('side_stream', True)
         assert not kwargs, 'unknown arguments %s' % list(kwargs)
-        if not self.weight_norm or not self.layernorm:
-            raise NotImplementedError('weight_norm=False / layernorm=False are not supported '
-                                      '(every released GHN-3 uses True for both)')
         assert len(max_shape) == 4, max_shape
         self.max_shape = tuple(int(v) for v in max_shape)
         self.num_classes = num_classes
@@ -171,7 +168,7 @@ class GHN3(nn.Module):
         for m in self.modules():
             if isinstance(m, nn.Embedding):
                 nn.init.trunc_normal_(m.weight.data, std=m.weight.shape[1] ** (-0.5))
-        self._names = param_names(layers)
+        self._names = param_names(layers, self.layernorm)
         self._flat = None
         self._flatten()
 
@@ -236,7 +233,7 @@ class GHN3(nn.Module):
         prog = Program(cfg, graphs.node_info, graphs.host_n_nodes(), graphs._node_type_host, graphs.max_edge,
                        nets, index_mode=self.index_mode, training=training,
                        predict_class_layers=predict_class_layers, reduce_graph=reduce_graph,
-                       layernorm=self.layernorm, decoder_ctype=L.COMPUTE_TYPES[self.compute],
+                       layernorm=self.layernorm, weight_norm=self.weight_norm, decoder_ctype=L.COMPUTE_TYPES[self.compute],
                        decoder_bwd_ctype=L.COMPUTE_TYPES[self.compute_bwd] if self.compute_bwd else None,
                        direct16=self.direct16, side_stream=self.side_stream)
         plan = _Plan(self, prog, graphs.edges, nets)

@@ -38,8 +38,10 @@ LAYER_PARAM_NAMES = ['ln1.weight', 'ln1.bias', 'attn.to_qkv.weight', 'attn.to_ou
                      'ff.net.3.bias']
 
 
-def param_names(layers):
+def param_names(layers, layernorm=True):
     names = global_param_names()
+    if not layernorm:                      # GHN(layernorm=False) has no final LayerNorm (ppuda GHN.__init__)
+        names = [n for n in names if not n.startswith('ln.')]
     for l in range(layers):
         names += ['gnn.%d.%s' % (l, n) for n in LAYER_PARAM_NAMES]
     return names
@@ -56,8 +58,8 @@ class Program:
     X_WS, X_IDX, X_EDGES, X_OUT, X_DOUT, X_TOK, X_SCAL, X_GRADFLAT, X_COUNT = range(9)
 
     def __init__(self, cfg, node_infos, n_nodes, node_types, max_edge, nets, index_mode='reference',
-                 training=True, predict_class_layers=True, reduce_graph=False, layernorm=True, decoder_ctype=None,
-                 decoder_bwd_ctype=None, direct16=True, side_stream=True):
+                 training=True, predict_class_layers=True, reduce_graph=False, layernorm=True, weight_norm=True,
+                 decoder_ctype=None, decoder_bwd_ctype=None, direct16=True, side_stream=True):
         self.cfg = cfg
         # side_stream: weight-gradient GEMMs, LayerNorm parameter gradients and operand copies (everything off the
         # dependent chain of the program) carry GHN3_OPFLAG_SIDE and overlap with the chain on a second stream;
@@ -85,9 +87,10 @@ class Program:
         self.S = self.max_shape[2]                    # decoder spatial size (16)
         assert self.max_shape[2] == self.max_shape[3]
         self.layernorm = layernorm
+        self.weight_norm = weight_norm          # False: predicted tensors are assigned un-normalised (nn.py:543-546)
         self.training = training
         self.index_mode = index_mode
-        self.names = param_names(self.Lyr)
+        self.names = param_names(self.Lyr, layernorm)
         self.P = len(self.names)
         self.slot = {n: i for i, n in enumerate(self.names)}
         self.B = len(n_nodes)
@@ -314,13 +317,22 @@ class Program:
                 continue
             if len(key) == 4 or (len(key) == 2 and key[1] > 0):
                 if len(key) == 4:
-                    if key[2] > S or key[3] > S:
-                        raise NotImplementedError('kernel %s larger than the %dx%d decoder grid needs the bilinear '
-                                                  'interpolation branch of nn.py:751-753' % (str(key), S, S))
                     kh, kw = int(key[2]), int(key[3])
                     o_g, i_g = min(int(key[0]), ms[0]), min(int(key[1]), ms[1])
                     g = dict(kind='conv', key=key, inds=list(inds), o=o_g, i=i_g, i_ld=i_g, kh=kh, kw=kw,
                              cols=o_g * i_g)
+                    if min(kh, kw) > S:
+                        # nn.py:751-753: the whole 16x16 grid is decoded and bilinearly resized to (kh, kw); the
+                        # reference asserts a single node per such group.  Decoded at the grid size here; the resize
+                        # is a constant (kh*kw x S*S) matrix applied by one GEMM (_resize_matrix).
+                        if len(inds) != 1:
+                            raise ValueError('kernels larger than the %dx%d decoder grid need one node per group '
+                                             '(nn.py:752), got %d for key %s' % (S, S, len(inds), str(key)))
+                        g['resize'] = (kh, kw)
+                        kh = kw = g['kh'] = g['kw'] = S
+                    elif max(kh, kw) > S:
+                        raise NotImplementedError('kernel %s exceeds the %dx%d decoder grid along one axis only '
+                                                  '(the reference fails its shape assert, nn.py:550)' % (str(key), S, S))
                 else:
                     kh = kw = 1
                     i_true = min(int(key[1]), ms[1])
@@ -571,6 +583,12 @@ class Program:
                 for g in gg['members']:
                     g['tile_off'] = tiles_floats + (g['row0'] - gg['row0']) * gg['ld']
                 tiles_floats += round_up(gg['rows'] * gg['ld'], 64)
+            # kernels larger than the decoder grid: the resized (kh*kw, o*i) matrix lives behind the grid-sized ones
+            # in the same buffer (and, in the backward, in d_tiles), so that tile descriptors address it like any tile
+            for g in self.conv_groups:
+                if 'resize' in g:
+                    g['rs_off'] = tiles_floats
+                    tiles_floats += round_up(g['resize'][0] * g['resize'][1] * g['ld'], 64)
             self.tiles_floats = tiles_floats
             tiles = self.wsf('tiles', tiles_floats)
             use16 = any(g['op16'] for g in self.gemm_groups)
@@ -599,6 +617,15 @@ class Program:
                               bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1],
                               act=L.ACT_RELU if g['kind'] == 'cls' else L.ACT_NONE)
             self.gemm_op(p0, tag=self.TAG_D3_FWD, flops=fl)
+            p0 = len(self._probs)
+            for g in self.conv_groups:
+                if 'resize' in g:
+                    kh, kw = g['resize']
+                    g['r_wb'] = self.idx(self._resize_matrix(S, S, kh, kw))
+                    # resized[p_out][c] = sum_p Wb[p_out][p] tiles[p][c]     (F.interpolate(..., mode='bilinear'))
+                    self.gemm(g['r_wb'], self.wref('tiles', g['tile_off']), self.wref('tiles', g['rs_off']),
+                              kh * kw, g['cols'], S2, S2, g['ld'], g['ld'], b_mode=L.MODE_COL)
+            self.gemm_op(p0)
             # classifier head (nn.py:755-758): out[i'][k] = sum_o' relu(tile[o'][i']) Wcls[k][o'] + bcls[k]
             n_cls_rows = sum(g['rows'] * g['i_ld'] for g in self.conv_groups if g['kind'] == 'cls')
             if n_cls_rows:
@@ -646,6 +673,24 @@ class Program:
                 self.gemm_op(p0)
         self._build_tile_descriptors()
 
+    @staticmethod
+    def _resize_matrix(hi, wi, ho, wo):
+        """(ho*wo, hi*wi) fp32 matrix of torch's bilinear resize (align_corners=False), the branch of nn.py:751-753:
+        source coordinate = (dst + 0.5) * (in / out) - 0.5 clamped at 0, neighbours i0 and min(i0 + 1, in - 1)."""
+        def axis(n_in, n_out):
+            m = np.zeros((n_out, n_in), dtype=np.float32)
+            scale = np.float32(n_in) / np.float32(n_out)
+            for d in range(n_out):
+                src = max(np.float32(scale * np.float32(d + 0.5) - np.float32(0.5)), np.float32(0))
+                i0 = min(int(src), n_in - 1)
+                i1 = i0 + (1 if i0 < n_in - 1 else 0)
+                l1 = np.float32(src - np.float32(i0))
+                m[d, i0] += np.float32(1) - l1
+                m[d, i1] += l1
+            return m
+        wy, wx = axis(hi, ho), axis(wi, wo)
+        return np.ascontiguousarray(np.einsum('ab,cd->acbd', wy, wx).reshape(ho * wo, hi * wi).astype(np.float32))
+
     # ------------------------------------------------------------------ tile / normalise descriptors
     def _build_tile_descriptors(self):
         C, K, ldK = self.C, self.K, self.ldK
@@ -690,7 +735,7 @@ class Program:
                     tile_t = sz                       # _tile_params target (nn.py:325); norm-layer bias shares it
                     # nn.py:526-528: a 2-D tile assigned to a 4-D (O,I,1,1) parameter is unsqueezed
                     t_assign = bk._sz(tgt) if tgt is not None else tile_t
-                    mode, scale = bk.norm_rule(tile_t, w_flag)
+                    mode, scale = bk.norm_rule(tile_t, w_flag) if self.weight_norm else (0, 1.0)
                     numel = int(np.prod(tile_t))
                     dst = out_off
                     out_off = round_up(out_off + numel, 16)
@@ -701,6 +746,8 @@ class Program:
                         g, n_idx = group_of[ind]
                         base = g['tile_off'] + n_idx * g['hw'] * g['ld']
                         kh, kw, ld = g['kh'], g['kw'], g['ld']
+                        if 'resize' in g:
+                            base, (kh, kw) = g['rs_off'], g['resize']
                         if len(t) == 4:
                             if (t[2], t[3]) != (kh, kw):
                                 raise NotImplementedError('target kernel %s vs group key %s' % (str(t), str(key)))
@@ -711,11 +758,11 @@ class Program:
                             add(dst, 0, base + (cy * kw + cx) * ld, (t[0], t[1], 1, 1),
                                 (min(t[0], g['o']), min(t[1], g['i']), 1, 1), (g['i'], 1, 0, 0),
                                 (g['o'], g['i'], 1, 1), mode, scale)
-                            if g['hw'] != 1:
+                            if kh * kw != 1:
                                 raise NotImplementedError('2-D target from a %dx%d tile' % (kh, kw))
                         elif len(t) == 3:
                             # positional encoding (nn.py:442-446): rows 1.. from the tile, row 0 random (Q3)
-                            hw = g['hw']
+                            hw = kh * kw
                             L1, D = t[1], t[2]
                             if t[0] != 1 or L1 - 1 > hw or g['o'] != 1:
                                 raise NotImplementedError('3-D target %s from key %s' % (str(t), str(key)))
@@ -887,6 +934,14 @@ class Program:
         W2, b2 = 'decoder.conv.2.weight', 'decoder.conv.2.bias'
         Wc, bc = 'decoder.class_layer_predictor.1.weight', 'decoder.class_layer_predictor.1.bias'
         if M > 0:
+            # kernels larger than the decoder grid: d_tiles[p][c] = sum_pout Wb[pout][p] d_resized[pout][c]
+            p0 = len(self._probs)
+            for g in self.conv_groups:
+                if 'resize' in g:
+                    kh, kw = g['resize']
+                    self.gemm(g['r_wb'], self.wref('d_tiles', g['rs_off']), self.wref('d_tiles', g['tile_off']),
+                              S2, g['cols'], kh * kw, S2, g['ld'], g['ld'], a_mode=L.MODE_COL, b_mode=L.MODE_COL)
+            self.gemm_op(p0)
             t, u = self.wref('t'), self.wref('u')
             d_t = self.wsf('d_t', M * 4 * C)
             d_u = self.wsf('d_u', M * 8 * C)

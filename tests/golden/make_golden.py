@@ -219,6 +219,58 @@ def make_ghn3_goldens():
 
 
 # ------------------------------------------------------------------------------------------------
+# 2b. Extra tiny cases (recipe.EXTRA_CASES): kernels larger than the decoder grid (bilinear branch, nn.py:751-753)
+#     and the weight_norm=False / layernorm=False configurations -> ghn3_tiny_extra.npz
+# ------------------------------------------------------------------------------------------------
+
+def make_extra_goldens():
+    install_standins()
+    sys.path.insert(0, REF)
+    import ghn3                                              # noqa: F401  the reference package
+    from ghn3.nn import GHN3
+    from ghn3.graph import Graph, GraphBatch
+    Encoder = sys.modules['torchvision.models.vision_transformer'].Encoder
+    out = {}
+    for case, (specs, over) in recipe.EXTRA_CASES.items():
+        cfg = dict(recipe.TINY_CFG, **over)
+        torch.manual_seed(0)
+        ghn = GHN3(**cfg, debug_level=0)
+        shapes = {k: tuple(v.shape) for k, v in ghn.state_dict().items()}
+        sd = recipe.seeded_state_dict(shapes, seed=recipe.TINY_SEED)
+        ghn.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        out[case + '/state_keys'] = np.asarray(sorted(shapes))
+        nets = [recipe.build_torch_net(s, encoder_cls=Encoder) for s in specs]
+        graphs = []
+        for s in specs:
+            node_feat, node_info, A = recipe.graph_arrays(s)
+            graphs.append(Graph(node_feat=torch.from_numpy(node_feat), node_info=node_info,
+                                A=torch.from_numpy(A), dense=True))
+        batch = GraphBatch(graphs, dense=True)
+        ghn.train()
+        ghn.zero_grad()
+        torch.manual_seed(5)
+        nets_out, emb = ghn(nets, batch, return_embeddings=True, keep_grads=True,
+                            bn_track_running_stats=True, reduce_graph=False)
+        loss = 0
+        for b, net in enumerate(nets_out):
+            for name, p in recipe.named_predicted(net):
+                out['%s/pred/%d/%s' % (case, b, name)] = p.detach().numpy()
+                q = p[:, 1:] if p.dim() == 3 else p            # Q3: skip the random class-token row
+                loss = loss + torch.norm(q, p='fro')
+        out[case + '/emb'] = emb.detach().numpy()
+        out[case + '/loss'] = np.asarray([loss.item()], dtype=np.float64)
+        loss.backward()
+        for k, p in ghn.named_parameters():
+            g = p.grad
+            assert g is not None, k
+            idx = recipe.sample_indices(g.numel(), 8, seed=len(k))
+            out['%s/grad/%s' % (case, k)] = np.concatenate(
+                [[g.norm().item(), g.sum().item()], g.reshape(-1)[idx].numpy()]).astype(np.float64)
+    np.savez_compressed(os.path.join(HERE, 'ghn3_tiny_extra.npz'), **out)
+    print('ghn3_tiny_extra.npz: %d arrays' % len(out))
+
+
+# ------------------------------------------------------------------------------------------------
 # 3. torchvision-shaped ResNets through the reference GHN3 class at the released sizes (BASELINE configs 1 and 4):
 #    ghn3tm8 on the ResNet-18 graph, ghn3xlm16 on the ResNet-50 graph.  Stores per predicted tensor the Frobenius
 #    norm and a seeded sample of its elements (the tensors themselves are 11.7 M / 25.6 M floats).
@@ -273,9 +325,12 @@ def make_resnet_goldens(which=('18', '50', 'vit')):
 
 if __name__ == '__main__':
     # python make_golden.py            -> tiny fixtures (seconds)
+    # python make_golden.py extra      -> ghn3_tiny_extra.npz (big kernels, weight_norm / layernorm off)
     # python make_golden.py resnet     -> + ResNet-18 / ghn3tm8 and ResNet-50 / ghn3xlm16 (minutes, ~10 GB of RAM)
     torch.set_num_threads(8 if 'resnet' in sys.argv[1:] else 4)
-    if 'resnet' in sys.argv[1:]:
+    if 'extra' in sys.argv[1:]:
+        make_extra_goldens()
+    elif 'resnet' in sys.argv[1:]:
         make_resnet_goldens([a for a in sys.argv[1:] if a in ('18', '50', 'vit')] or ('18', '50', 'vit'))
     else:
         make_graphormer_goldens()

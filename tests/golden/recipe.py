@@ -137,6 +137,28 @@ TINY_NETS = [
 ]
 TINY_CASES = {'b1': [0], 'b2': [1, 0], 'b2r': [0, 1]}
 
+# Extra fixtures (ghn3_tiny_extra.npz): kernels larger than the 16x16 decoder grid (bilinear branch of nn.py:751-753,
+# e.g. the 32x32 patch embedding of ViT-B/32) and the weight_norm=False / layernorm=False configurations.
+EXTRA_NETS = [
+    dict(nodes=[('input', None, None),
+                ('conv', 'patch.weight', (24, 3, 20, 20)),
+                ('bias', 'patch.bias', (24,)),
+                ('ln', 'ln.weight', (24,)),
+                ('conv', 'big2.weight', (8, 24, 18, 18)),
+                ('conv', 'c3.weight', (24, 8, 3, 3)),
+                ('sum', None, None),
+                ('glob_avg', None, None),
+                ('conv', 'fc.weight', (10, 24)),
+                ('bias', 'fc.bias', (10,))],
+         skips=[(2, 6)]),
+]
+EXTRA_CASES = {  # name: (spec list, overrides of TINY_CFG)
+    'big': ([EXTRA_NETS[0]], {}),
+    'big_b2': ([TINY_NETS[1], EXTRA_NETS[0]], {}),
+    'nonorm': ([TINY_NETS[0]], dict(weight_norm=False)),
+    'noln': ([TINY_NETS[0]], dict(layernorm=False)),
+}
+
 
 def graph_arrays(spec):
     """(node_feat (N,1) int64, node_info [[(ind, param_name, prim, sz, last_w, last_b)...]], A (N,N) int64)."""

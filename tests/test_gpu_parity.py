@@ -150,6 +150,44 @@ def test_tiny_backward_matches_oracle_and_golden(case):
     print('worst grad rel-L2', worst)
 
 
+@pytest.mark.parametrize('case', sorted(recipe.EXTRA_CASES))
+def test_extra_cases_forward_backward(case):
+    """Kernels larger than the decoder grid (bilinear resize as a constant GEMM, nn.py:751-753) and the
+    weight_norm=False / layernorm=False configurations: HIP path vs the oracle and vs the reference's goldens."""
+    cfg = dict(recipe.TINY_CFG, **recipe.EXTRA_CASES[case][1])
+    hip, oracle = make_models(cfg, recipe.TINY_SEED)
+    nets_h, gb_h, nets_o, gb_o = tiny_case(case)
+    hip.train()
+    nets_h = hip(nets_h, gb_h, keep_grads=True)
+    g = np.load(os.path.join(GOLD, 'ghn3_tiny_extra.npz'))
+    loss = 0
+    for bi, net in enumerate(nets_h):
+        for name, p in recipe.named_predicted(net):
+            ref = g['%s/pred/%d/%s' % (case, bi, name)]
+            got = p.detach().cpu().numpy()
+            assert got.shape == ref.shape, name
+            if ref.ndim == 3:
+                got, ref = got[:, 1:], ref[:, 1:]            # Q3: random class-token row
+            assert rel_l2(got, ref) < 2e-5, (name, rel_l2(got, ref))
+            loss = loss + torch.norm(p[:, 1:] if p.dim() == 3 else p, p='fro')
+    assert rel_l2(hip.embeddings(hip.last_plan).cpu(), g[case + '/emb']) < 2e-5
+    loss.backward()
+    torch.cuda.synchronize()
+    oracle.train()
+    nets_o, pred_o = oracle(nets_o, gb_o, keep_grads=True)
+    loss_o = sum(torch.norm(t[:, 1:] if t.dim() == 3 else t, p='fro') for (_, _, _, t) in pred_o)
+    loss_o.backward()
+    assert abs(loss.item() - loss_o.item()) < 1e-4 * abs(loss_o.item())
+    po = dict(oracle.named_parameters())
+    assert sorted(po) == sorted(k for k, _ in hip.named_parameters())
+    for k, p in hip.named_parameters():
+        go = po[k].grad
+        err = float((p.grad.cpu().double() - go.double()).norm())
+        assert err < 2e-4 * float(go.norm()) + 2e-6, (k, err, float(go.norm()))
+        ref = g['%s/grad/%s' % (case, k)]
+        assert abs(p.grad.norm().item() - ref[0]) < 2e-4 * max(1.0, ref[0]), (k, p.grad.norm().item(), ref[0])
+
+
 def test_index_mode_correct_matches_oracle():
     hip, oracle = make_models(recipe.TINY_CFG, recipe.TINY_SEED, index_mode='correct')
     nets_h, gb_h, nets_o, gb_o = tiny_case('b2')

@@ -114,6 +114,45 @@ def test_full_forward_and_grads_match_reference(case):
         np.testing.assert_allclose(mine, ref, rtol=2e-4, atol=2e-5 * max(1.0, ref[0]), err_msg=k)
 
 
+@pytest.mark.parametrize('case', sorted(recipe.EXTRA_CASES))
+def test_extra_cases_match_reference(case):
+    """Kernels larger than the 16x16 decoder grid (bilinear branch, nn.py:751-753) and the weight_norm=False /
+    layernorm=False configurations: oracle vs the goldens written by the reference GHN3 class (make_golden.py extra)."""
+    g = _np('ghn3_tiny_extra.npz')
+    specs, over = recipe.EXTRA_CASES[case]
+    m = R.GHN3Ref(**dict(recipe.TINY_CFG, **over))
+    shapes = {k: tuple(v.shape) for k, v in m.state_dict().items()}
+    assert sorted(shapes) == [str(k) for k in g[case + '/state_keys']]
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in recipe.seeded_state_dict(shapes, seed=recipe.TINY_SEED).items()})
+    nets = [recipe.build_torch_net(s) for s in specs]
+    graphs = []
+    for s in specs:
+        nf, info, A = recipe.graph_arrays(s)
+        graphs.append(R.GraphRef(torch.from_numpy(nf), info, torch.from_numpy(A)))
+    m.train()
+    nets, predicted, emb = m(nets, R.GraphBatchRef(graphs), return_embeddings=True, keep_grads=True)
+    np.testing.assert_allclose(emb.detach().numpy(), g[case + '/emb'], rtol=2e-5, atol=2e-6)
+    loss, n_checked = 0, 0
+    for b, net in enumerate(nets):
+        for name, p in recipe.named_predicted(net):
+            ref = g['%s/pred/%d/%s' % (case, b, name)]
+            assert tuple(p.shape) == ref.shape, name
+            q, r = (p[:, 1:], ref[:, 1:]) if p.dim() == 3 else (p, ref)
+            np.testing.assert_allclose(q.detach().numpy(), r, rtol=2e-5, atol=2e-6, err_msg=name)
+            loss = loss + torch.norm(q, p='fro')
+            n_checked += 1
+    assert n_checked == sum(1 for k in g.files if k.startswith(case + '/pred/'))
+    assert abs(loss.item() - float(g[case + '/loss'][0])) < 1e-4 * abs(loss.item())
+    loss.backward()
+    for k, p in m.named_parameters():
+        ref = g['%s/grad/%s' % (case, k)]
+        got = p.grad
+        assert got is not None, k
+        idx = recipe.sample_indices(got.numel(), 8, seed=len(k))
+        mine = np.concatenate([[got.norm().item(), got.sum().item()], got.reshape(-1)[idx].numpy()])
+        np.testing.assert_allclose(mine, ref, rtol=2e-4, atol=2e-5 * max(1.0, ref[0]), err_msg=k)
+
+
 def test_q1_index_modes_differ_only_after_a_shorter_graph():
     m_ref, _ = _tiny_model('reference')
     m_cor, _ = _tiny_model('correct')

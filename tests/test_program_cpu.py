@@ -56,7 +56,8 @@ def _run_program(hip, nets, gb, training=True, **prog_kw):
 
 
 def _tiny(case):
-    specs = [recipe.TINY_NETS[i] for i in recipe.TINY_CASES[case]]
+    specs = recipe.EXTRA_CASES[case][0] if case in recipe.EXTRA_CASES else \
+        [recipe.TINY_NETS[i] for i in recipe.TINY_CASES[case]]
     nets_h = [recipe.build_torch_net(s) for s in specs]
     nets_o = [recipe.build_torch_net(s) for s in specs]
     gh, go = [], []
@@ -67,11 +68,14 @@ def _tiny(case):
     return nets_h, GraphBatch(gh, dense=True), nets_o, R.GraphBatchRef(go)
 
 
-@pytest.mark.parametrize('case,index_mode', [('b1', 'reference'), ('b2', 'reference'), ('b2', 'correct')])
+@pytest.mark.parametrize('case,index_mode', [('b1', 'reference'), ('b2', 'reference'), ('b2', 'correct'),
+                                             ('big', 'reference'), ('big_b2', 'reference'), ('nonorm', 'reference'),
+                                             ('noln', 'reference')])
 def test_compiled_programs_reproduce_oracle_forward_and_backward(case, index_mode):
-    hip, oracle = _build(recipe.TINY_CFG, recipe.TINY_SEED, index_mode)
+    cfg = dict(recipe.TINY_CFG, **(recipe.EXTRA_CASES[case][1] if case in recipe.EXTRA_CASES else {}))
+    hip, oracle = _build(cfg, recipe.TINY_SEED, index_mode)
     nets_h, gb_h, nets_o, gb_o = _tiny(case)
-    prog, it, bufs, gflat = _run_program(hip, nets_h, gb_h)
+    prog, it, bufs, gflat = _run_program(hip, nets_h, gb_h, layernorm=hip.layernorm, weight_norm=hip.weight_norm)
     out = bufs[prog.xbuf(prog.X_OUT)].view(np.float32)
     oracle.train()
     _, pred_o = oracle(nets_o, gb_o, keep_grads=True)

@@ -1,4 +1,5 @@
-// Fused multi-head self-attention with additive edge bias on the fp32 matrix cores (gfx950), N <= 1024, d <= 32.
+// Fused multi-head self-attention with additive edge bias on the fp32 matrix cores (gfx950), N <= 4096, d <= 32
+// (score rows held in registers up to N = 1024, streamed twice beyond).
 //
 // Replaces ghn3/graphormer.py:121-140:
 //     attn = (q @ k^T) * d^-0.5 + edge_bias ; attn.masked_fill(~mask, -2**15) ; softmax ; attn @ v
@@ -24,6 +25,7 @@
 #include "ghn3_internal.h"
 
 #define ATT_DMAX 32
+#define ATT_NMAX 4096
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -242,6 +244,103 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, 
 }
 
 // ------------------------------------------------------------------------------------------------
+// forward for N > 1024 (graphs of the largest torchvision networks): same tiles, but the score row no longer fits the
+// register file, so the wave streams its key tiles twice -- pass 1 keeps a running (max, sum) per query (online
+// softmax), pass 2 recomputes the scores, normalises, stores P and accumulates O^T.  The extra Q K^T product is ~d/N
+// of the step; nothing but P is written.
+// ------------------------------------------------------------------------------------------------
+template <int KS>
+__device__ __forceinline__ f32x16 score_tile(const float* __restrict__ base, const float* __restrict__ bias_row,
+                                             const float (&qb)[KS], int j0, int N, int C, int d, int nb, int qi,
+                                             int l31, int lhi, bool vq, float scale) {
+    float ka[KS];
+    const int j = j0 + l31;
+    load_row_operand<KS>(j < N ? base + (size_t)j * 3 * C + C : nullptr, d, lhi, vq, ka);
+    f32x16 acc = mfma_rows<KS>(ka, qb, zero16());
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int jr = j0 + acc_row(r, lhi);
+        float s_ = acc[r] * scale + ((bias_row && qi < N && jr < N) ? bias_row[jr] : 0.f);
+        if (!(qi < nb && jr < nb)) s_ = -32768.f;
+        if (jr >= N) s_ = -INFINITY;
+        acc[r] = s_;
+    }
+    return acc;
+}
+
+template <int KS>
+__global__ __launch_bounds__(256) void attn_fwd_stream_kernel(float* __restrict__ out, const float* __restrict__ qkv,
+                                                              const float* __restrict__ bias,
+                                                              float* __restrict__ Psave,
+                                                              const int* __restrict__ n_nodes, int N, int C, int H,
+                                                              float scale, int vec) {
+    __shared__ float red[4 * 16 * 64];
+    __shared__ float red_m[4][32], red_l[4][32];
+    const int d = C / H;
+    const int NB = (N + 31) >> 5;
+    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * 32;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int nb = n_nodes[b];
+    const float* base = qkv + (size_t)b * N * 3 * C + h * d;
+    const size_t bh = ((size_t)b * H + h) * N;
+    const int qi = i0 + l31;
+    const bool vq = (d & 3) == 0 && vec;
+    const float* brow = (bias && qi < N) ? bias + (bh + qi) * N : nullptr;
+    float qb[KS];
+    load_row_operand<KS>(qi < N ? base + (size_t)qi * 3 * C : nullptr, d, lhi, vq, qb);
+
+    float mx = -INFINITY, sum = 0.f;
+    for (int t = w; t < NB; t += 4) {
+        const f32x16 sc = score_tile<KS>(base, brow, qb, t * 32, N, C, d, nb, qi, l31, lhi, vq, scale);
+        float tm = mx;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tm = fmaxf(tm, sc[r]);
+        if (tm > -INFINITY) {
+            float acc = sum * __expf(mx - tm);                   // (mx = -inf on the first tile: exp(-inf) = 0)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc += __expf(sc[r] - tm);
+            sum = acc;
+            mx = tm;
+        }
+    }
+    {   // the two half-waves of a query hold different keys
+        const float m2 = __shfl_xor(mx, 32, 64), s2 = __shfl_xor(sum, 32, 64);
+        const float mn = fmaxf(mx, m2);
+        sum = (mx > -INFINITY ? sum * __expf(mx - mn) : 0.f) + (m2 > -INFINITY ? s2 * __expf(m2 - mn) : 0.f);
+        mx = mn;
+    }
+    if (lhi == 0) { red_m[w][l31] = mx; red_l[w][l31] = sum; }
+    __syncthreads();
+    const float gm = fmaxf(fmaxf(red_m[0][l31], red_m[1][l31]), fmaxf(red_m[2][l31], red_m[3][l31]));
+    float gl = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+        if (red_m[k][l31] > -INFINITY) gl += red_l[k][l31] * __expf(red_m[k][l31] - gm);
+    const float inv = 1.f / gl;
+
+    f32x16 O = zero16();
+    for (int t = w; t < NB; t += 4) {
+        const int j0 = t * 32;
+        f32x16 sc = score_tile<KS>(base, brow, qb, j0, N, C, d, nb, qi, l31, lhi, vq, scale);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sc[r] = __expf(sc[r] - gm) * inv;
+        if (Psave && qi < N) {
+            float* prow = Psave + (bh + qi) * N;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jr = j0 + acc_row(r, lhi);
+                if (jr < N) prow[jr] = sc[r];
+            }
+        }
+        float va[16];
+        load_col_operand(base + 2 * C, j0, N, (size_t)3 * C, l31, d, lhi, va);
+        O = mfma_cols(va, sc, O);
+    }
+    const f32x4 o = reduce_waves(red, O, w, lane);
+    if (qi < N) store4(out + ((size_t)b * N + qi) * C + h * d, 8 * w + 4 * lhi, d, vq, o);
+}
+
+// ------------------------------------------------------------------------------------------------
 // backward: grid (2 * ceil(N / 32), H, B); blockIdx.x < NB: row role (32 queries: dQ, dBias += dS),
 // otherwise column role (32 keys: dK, dV).  delta_i = sum_e dO[i][e] O[i][e] (= rowsum(P * dP)).
 // ------------------------------------------------------------------------------------------------
@@ -396,6 +495,7 @@ typedef void (*attn_bwd_fn)(float*, const float*, const float*, const float*, co
                             int, int, float, int);
 
 template <int KS> static attn_fwd_fn fwd_for(int tpw) {
+    if (tpw > 8) return (attn_fwd_fn)attn_fwd_stream_kernel<KS>;          // N > 1024
     return tpw <= 2 ? (attn_fwd_fn)attn_fwd_kernel<KS, 2> : (attn_fwd_fn)attn_fwd_kernel<KS, 8>;
 }
 static attn_fwd_fn pick_fwd(int d, int tpw) {
@@ -420,7 +520,7 @@ static int check_dims(int N, int C, int H) {
         ghn3_set_error("attention: head dim %d/%d unsupported (max %d)", C, H, ATT_DMAX);
         return GHN3_E_LIMIT;
     }
-    if (N > 1024 || N <= 0) { ghn3_set_error("attention: N=%d outside [1,1024]", N); return GHN3_E_LIMIT; }
+    if (N > ATT_NMAX || N <= 0) { ghn3_set_error("attention: N=%d outside [1,%d]", N, ATT_NMAX); return GHN3_E_LIMIT; }
     return GHN3_OK;
 }
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }

@@ -100,8 +100,8 @@ class Program:
         if self.V + 1 > 257:
             raise ValueError('shortest-path length %d exceeds the 257-row edge embedding (graphormer.py:95-96)'
                              % max_edge)
-        if self.N > 1024:
-            raise ValueError('graphs with more than 1024 nodes are not supported (got %d)' % self.N)
+        if self.N > 4096:
+            raise ValueError('graphs with more than 4096 nodes are not supported (got %d)' % self.N)
         self._ops, self._probs = [], []
         self.tag_flops = {}
         self._ws = 0

@@ -188,6 +188,34 @@ def test_extra_cases_forward_backward(case):
         assert abs(p.grad.norm().item() - ref[0]) < 2e-4 * max(1.0, ref[0]), (k, p.grad.norm().item(), ref[0])
 
 
+def test_graph_with_more_than_1024_nodes():
+    """N = 1100 (EfficientNet-B7-sized graphs exceed 1024 nodes): streamed two-pass attention forward, generic
+    backward; head dim 24 like ghn3xlm16.  Forward and gradients vs the oracle."""
+    cfg = dict(max_shape=(48, 48, 16, 16), num_classes=1000, hid=48, heads=2, layers=2, weight_norm=True, ve=True,
+               layernorm=True)
+    hip, oracle = make_models(cfg, 11)
+    nets_h, gb_h, nets_o, gb_o = synthetic_case([1100], 1100000)
+    hip.train()
+    nets_h = hip(nets_h, gb_h, keep_grads=True)
+    loss = sum(torch.norm(p, p='fro') for net in nets_h for p in net.parameters())
+    loss.backward()
+    torch.cuda.synchronize()
+    assert hip.last_plan.program.N == 1100
+    oracle.train()
+    nets_o, pred_o = oracle(nets_o, gb_o, keep_grads=True)
+    loss_o = sum(torch.norm(t, p='fro') for (_, _, _, t) in pred_o)
+    loss_o.backward()
+    pred_h = predicted_dict_hip(hip.last_plan, hip.last_plan.out)
+    for k, (ind, attr, m, t) in enumerate(pred_o):
+        e = rel_l2(pred_h[k].detach().cpu(), t.detach())
+        assert e < 2e-5, (k, attr, tuple(t.shape), e)
+    po = dict(oracle.named_parameters())
+    for k, p in hip.named_parameters():
+        go = po[k].grad
+        err = float((p.grad.cpu().double() - go.double()).norm())
+        assert err < 3e-4 * float(go.norm()) + 1e-5, (k, err, float(go.norm()))
+
+
 def test_index_mode_correct_matches_oracle():
     hip, oracle = make_models(recipe.TINY_CFG, recipe.TINY_SEED, index_mode='correct')
     nets_h, gb_h, nets_o, gb_o = tiny_case('b2')

@@ -206,6 +206,20 @@ def main():
             detail[name] = {'ms_per_step': round(tms / args.steps, 4), 'launch_groups_per_step': cnt // args.steps}
             if t in prog.tag_flops and tms > 0:
                 detail[name]['tflops'] = round(prog.tag_flops[t] / (tms / args.steps * 1e-3) / 1e12, 2)
+        # HBM bytes per step of the same kernels from the PMC counters: they cannot be collected inside this process, so
+        # the number comes from the committed rocprofv3 --pmc passes over this exact workload (tools/pmc_profile.sh,
+        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE calibrated); null otherwise.
+        traffic, traffic_src = None, None
+        if (args.model, args.nodes, args.graphs_per_gpu, args.compute) == ('ghn3xlm16', 256, 1, 'f16'):
+            import glob
+            cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic_xl_f16.json')))
+            if cands:
+                try:
+                    with open(cands[-1]) as fh:
+                        traffic = float(json.load(fh)['hbm_bytes_per_step'])
+                    traffic_src = 'profiles/' + os.path.basename(cands[-1])
+                except Exception:
+                    traffic = None
         out = {
             'metric': 'predicted-params/sec (GHN fwd+bwd), %s, %d-node graphs' % (args.model, args.nodes),
             'value': total_pred * args.steps / elapsed,
@@ -218,10 +232,12 @@ def main():
                                    'params per GPU, loss = sum of Frobenius norms of the predicted tensors'
                                    % (args.model, args.graphs_per_gpu, args.nodes, args.nodes * 1000, n_pred),
                        'ghn_params': int(ghn._flat_numel), 'decoder_rows': int(prog.M),
+                       'workspace_bytes': int(prog.ws_bytes),
                        'parallelism': 'dp%d' % world, 'index_mode': ghn.index_mode,
                        'grad_allreduce': (args.grad_allreduce if ddp else None)},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
-                         'frac': achieved / peak, 'traffic': None,
+                         'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'bytes per step',
+                         'traffic_source': traffic_src,
                          'kernel': 'decoder W2 grouped GEMM (fwd + dgrad + wgrad), %s MFMA operands' % args.compute,
                          'algorithmic_gflop_per_step': fl / 1e9, 'kernel_ms_per_step': ms, 'kernels': detail},
         }

@@ -812,6 +812,7 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
     const bool st = D.flags & GHN3_CAST_STRAIGHT, trn = D.flags & GHN3_CAST_TRANSPOSED;
     const bool st_bf = D.flags & GHN3_CAST_STRAIGHT_BF16, tr_bf = D.flags & GHN3_CAST_TRANSPOSED_BF16;
     const float sc = ((D.flags & GHN3_CAST_SCALED) && amax) ? ghn3_pow2_scale(*amax) : 1.f;
+    const int rows_w = (D.flags & GHN3_CAST_TIGHT) ? ((D.rows + 7) & ~7) : 0x7fffffff;   // transposed rows written
 
     float4 v[4];
 #pragma unroll
@@ -819,7 +820,9 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
         const int r = r0 + rr + 16 * i, c = c0 + c4;
         float4 x = make_float4(0.f, 0.f, 0.f, 0.f);
         if (r < D.rows) {
-            const float* p = S + (int64_t)r * D.ld_src + c;
+            // (a float4 never straddles a run of the source column map: src_q % 4 == 0, c % 4 == 0)
+            const int sc_ = D.src_q > 0 ? (c / D.src_q) * D.src_s + c % D.src_q : c;
+            const float* p = S + (int64_t)r * D.ld_src + sc_;
             if (c + 3 < D.cols) x = *reinterpret_cast<const float4*>(p);
             else {
                 if (c < D.cols) x.x = p[0];
@@ -871,7 +874,7 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
         for (int i = 0; i < 2; ++i) {
             const int p = tid + 256 * i;
             const int col = p >> 3, rp = (p & 7) * 8;
-            if (c0 + col >= D.cols) continue;
+            if (c0 + col >= D.cols || r0 + rp >= rows_w) continue;
             us8 h;
 #pragma unroll
             for (int e = 0; e < 8; ++e) h[e] = tr[rp + e][col];
@@ -884,7 +887,7 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
         for (int w = 0; w < 16; ++w) s += csum[w][tid];
         int c = c0 + tid;
         if (D.bias_q > 0) c = (c / D.bias_q) * D.bias_s + c % D.bias_q;
-        atomicAdd(dbias + c, s);
+        atomicAdd(dbias + c + D.bias_off, s);
     }
     __syncthreads();                               // LDS staging is reused by the next work tile
     }

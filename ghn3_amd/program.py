@@ -188,13 +188,19 @@ class Program:
                 dflags |= L.CAST_STRAIGHT | (L.CAST_STRAIGHT_BF16 if ct == L.CT_BF16 else 0)
             if it.get('transposed'):
                 off, ld, ct = it['transposed']
-                assert ld % 8 == 0 and ld >= round_up(it['rows'], 64) and off % 8 == 0
+                assert ld % 8 == 0 and (ld >= round_up(it['rows'], 64) or it.get('tight')) and off % 8 == 0
                 D['dstT_off'], D['ld_dstT'] = off, ld
                 dflags |= L.CAST_TRANSPOSED | (L.CAST_TRANSPOSED_BF16 if ct == L.CT_BF16 else 0)
             if it.get('colsum') is not None:
                 assert dbias is not None
-                D['bias_q'], D['bias_s'] = it['colsum']
+                D['bias_q'], D['bias_s'] = it['colsum'][:2]
+                D['bias_off'] = it['colsum'][2] if len(it['colsum']) > 2 else 0
                 dflags |= L.CAST_COLSUM
+            if it.get('src_map'):
+                D['src_q'], D['src_s'] = it['src_map']
+                assert D['src_q'] % 4 == 0 and D['src_s'] % 4 == 0 and it['cols'] % D['src_q'] == 0
+            if it.get('tight'):
+                dflags |= L.CAST_TIGHT
             if it.get('scaled'):
                 assert amax is not None
                 dflags |= L.CAST_SCALED
@@ -974,16 +980,18 @@ class Program:
             bct = self.decoder_bwd_ctype
             g16 = [g for g in self.gemm_groups if g['op16']]
             if g16:
-                # 16-bit copies of the backward operands, one launch: per group d_tiles (straight: dgrad A operand,
-                # transposed: wgrad A operand, column sums: the conv.2 bias gradient) and u^T (wgrad B operand)
-                # wgrad families.  Conv groups with the same input width i cover nested W2 row sets (o' < o_g), so
-                # their transposed copies share ONE buffer per family: rows = W2 rows (o' * i + i') of the widest
-                # group, columns = the groups' decoder rows concatenated along k in order of decreasing o_g.  The
-                # W2 rows with o' in [o_lo, o_hi) then need exactly a k PREFIX of that buffer: one GEMM problem per
-                # o range writes each dW2 row once (no read-modify-write between the groups of a family, one launch
-                # per family instead of one per group).
+                # 16-bit copies of the backward operands: per group d_tiles straight (dgrad A operand); for the wgrad
+                # transposed copies of d_tiles (A) and u (B) + the column sums of d_tiles = the conv.2 bias gradient.
+                # wgrad bands.  dW2 row (o', i') sums over every decoder row r with o_r > o' and i_r > i' (nn.py:749-750,
+                # 760: a row only consumes the W2 rows o' < o_r, i' < i_r).  The input-channel axis is cut at the distinct
+                # group widths into BANDS [i_lo, i_hi): for i' in a band the contributing rows are exactly those with
+                # i_r >= i_hi, whatever their family.  Per band these rows are concatenated along k in order of
+                # decreasing o_r (transposed copy dthT_b [(o', i' - i_lo)][k], u copy uhT_b [8C][k]), so the W2 rows
+                # with o' in [o_lo, o_hi) need exactly a k PREFIX: one GEMM problem per (band, o range), all in ONE
+                # launch, and every dW2 row is written exactly once -- no accumulation into dW2 between families (was
+                # 2 GB read + 2 GB written per step at ghn3xlm16) and no memset of it when the bands cover it.
                 items, side_items = [], []
-                self.wgrad_families = []
+                rowsets = []
                 for g in g16:
                     g['dth_ld'] = round_up(g['cols'], 64)
                     g['dth'] = self.ws16('dth%d' % g['row0'], g['rows'] * g['dth_ld'])
@@ -991,21 +999,33 @@ class Program:
                     items.append(dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'], rows=g['rows'],
                                       cols=g['cols'], ld_src=g['ld'], straight=(g['dth'], g['dth_ld'], bct),
                                       scaled=scaled))
-                    k_off = 0
                     for sb in g['subs']:
-                        sb['k_off'] = k_off
-                        k_off += round_up(sb['rows'], 64)
-                    fam = dict(groups=g['subs'], i=g['i_ld'], o_max=g['o'], ktot=k_off, kind=g['kind'])
-                    fam['dthT'] = self.ws16('dthT_f%d_%d' % (fam['i'], g['row0']), fam['o_max'] * fam['i'] * k_off)
-                    fam['uhT'] = self.ws16('uhT_f%d_%d' % (fam['i'], g['row0']), 8 * C * k_off)
-                    self.wgrad_families.append(fam)
-                    for sb in g['subs']:
+                        rowsets.append(dict(o=sb['o'], i=g['i_ld'], row0=sb['row0'], rows=sb['rows'], g=g))
+                self.wgrad_bands = []
+                i_lo = 0
+                for i_hi in sorted({rs['i'] for rs in rowsets}):
+                    members = sorted((rs for rs in rowsets if rs['i'] >= i_hi), key=lambda rs: -rs['o'])
+                    bw = i_hi - i_lo
+                    k_off, mem = 0, []
+                    for rs in members:
+                        mem.append(dict(rs, k_off=k_off))
+                        k_off += round_up(rs['rows'], 8)
+                    ktot = round_up(k_off, 64)
+                    band = dict(i_lo=i_lo, bw=bw, members=mem, ktot=ktot, o_max=mem[0]['o'])
+                    band['dthT'] = self.ws16('dthT_b%d' % i_lo, band['o_max'] * bw * ktot)
+                    band['uhT'] = self.ws16('uhT_b%d' % i_lo, 8 * C * ktot)
+                    self.wgrad_bands.append(band)
+                    for m_ in mem:
+                        g = m_['g']
                         side_items.append(dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'] +
-                                               (sb['row0'] - g['row0']) * g['ld'], rows=sb['rows'], cols=sb['cols'],
-                                               ld_src=g['ld'], transposed=(fam['dthT'] + sb['k_off'], k_off, bct),
-                                               colsum=(g['i_ld'], ms[1]), scaled=scaled))
-                        side_items.append(dict(src_off=u[1] // 4 + sb['row0'] * 8 * C, rows=sb['rows'], cols=8 * C,
-                                               ld_src=8 * C, transposed=(fam['uhT'] + sb['k_off'], k_off, bct)))
+                                               (m_['row0'] - g['row0']) * g['ld'] + i_lo, rows=m_['rows'],
+                                               cols=m_['o'] * bw, ld_src=g['ld'], src_map=(bw, m_['i']),
+                                               transposed=(band['dthT'] + m_['k_off'], ktot, bct),
+                                               colsum=(bw, ms[1], i_lo), scaled=scaled, tight=True))
+                        side_items.append(dict(src_off=u[1] // 4 + m_['row0'] * 8 * C, rows=m_['rows'], cols=8 * C,
+                                               ld_src=8 * C, transposed=(band['uhT'] + m_['k_off'], ktot, bct),
+                                               tight=True))
+                    i_lo = i_hi
                 # the dgrad operand on the critical path; the wgrad operands (and the bias gradient) beside it
                 self.cast16((self.xbuf(self.X_WS), 0), items, amax=amax_t)
                 self.cast16((self.xbuf(self.X_WS), 0), side_items, dbias=self.gref(b2), flags=self.SIDE, amax=amax_t)
@@ -1032,30 +1052,29 @@ class Program:
             self.gemm_op(p0, ctype=bct if g16 else None, tag=self.TAG_D3_DGRAD, flops=fl)
             self.op(L.OP_DACT, refs=(d_u, u, amax_u if amax_u is not None else self.NONE),
                     ints=(M, 8 * C, 8 * C, L.DACT_RELU))
-            # dW2 += d_tiles^T u.  16-bit families first (the family of the full-width groups writes every dW2 row
-            # without reading it), then the groups on the fp32-operand path; families overlap in W2 rows -> one
-            # launch per family, in order, on the side stream.
-            fam_list = sorted(getattr(self, 'wgrad_families', []) if g16 else [],
-                              key=lambda f: -(f['i'] * f['o_max']))
-            first = True
-            for fam in fam_list:
-                gs = fam['groups']
-                full = first and fam['i'] == ms[1] and fam['o_max'] == ms[0] and fam['kind'] == 'conv'
-                if full:
-                    self.grad_no_memset.append(W2)      # every row of dW2 is written by this family
-                first = False
-                thr = sorted({g['o'] for g in gs}, reverse=True)
+            # dW2 = d_tiles^T u.  16-bit bands first (one launch; every dW2 row they cover is written once, without
+            # reading it), then the groups on the fp32-operand path accumulate; all on the side stream, in order.
+            bands = getattr(self, 'wgrad_bands', []) if g16 else []
+            if bands:
+                covered = all(b_['o_max'] == ms[0] for b_ in bands) and sum(b_['bw'] for b_ in bands) == ms[1]
+                if covered:
+                    self.grad_no_memset.append(W2)      # every row of dW2 is written by the band problems
                 p0 = len(self._probs)
-                fl = sum(2.0 * g_['rows'] * g_['cols'] * 8 * C for g_ in gs)     # algorithmic: unpadded decoder rows
-                for j, o_hi in enumerate(thr):
-                    o_lo = thr[j + 1] if j + 1 < len(thr) else 0
-                    kpre = sum(round_up(g['rows'], 64) for g in gs if g['o'] >= o_hi)       # a prefix (sorted by o)
-                    # the K range is already zero padded per group: pass the padded prefix as K
-                    self.gemm(self.href(fam['dthT'] + o_lo * fam['i'] * fam['ktot']), self.href(fam['uhT']),
-                              self.gref(W2, o_lo * ms[1] * 8 * C), (o_hi - o_lo) * fam['i'], 8 * C, kpre,
-                              fam['ktot'], fam['ktot'], 8 * C, c_qs=(fam['i'], ms[1]), accum=not full, op16=True,
-                              alpha_amax=amax_t)
+                fl = 0.0
+                for b_ in bands:
+                    mem = b_['members']
+                    fl += sum(2.0 * m_['rows'] * m_['o'] * b_['bw'] * 8 * C for m_ in mem)   # algorithmic
+                    thr = sorted({m_['o'] for m_ in mem}, reverse=True)
+                    for j, o_hi in enumerate(thr):
+                        o_lo = thr[j + 1] if j + 1 < len(thr) else 0
+                        kpre = sum(round_up(m_['rows'], 8) for m_ in mem if m_['o'] >= o_hi)     # a prefix (sorted by o)
+                        # (columns of the last k tile beyond kpre belong to rows with o_r <= o_lo: zeros in these W2 rows)
+                        self.gemm(self.href(b_['dthT'] + o_lo * b_['bw'] * b_['ktot']), self.href(b_['uhT']),
+                                  self.gref(W2, (o_lo * ms[1] + b_['i_lo']) * 8 * C), (o_hi - o_lo) * b_['bw'], 8 * C,
+                                  kpre, b_['ktot'], b_['ktot'], 8 * C, c_qs=(b_['bw'], ms[1]), op16=True,
+                                  alpha_amax=amax_t)
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=True, flops=fl)
+            fam_list = bands
             for gi, g in enumerate(self.gemm_groups):
                 if g['op16']:
                     continue

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 6
+#define GHN3_ABI_VERSION 7
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -110,7 +110,13 @@ typedef struct ghn3_gemm_problem {
  *   GHN3_CAST_STRAIGHT    dst [r][c]  = cvt(src[r][c])   r < rows, c < round_up(cols, 64)   (zeros for c >= cols)
  *   GHN3_CAST_TRANSPOSED  dstT[c][r]  = cvt(src[r][c])   c < cols, r < round_up(rows, 64)   (zeros for r >= rows)
  *   GHN3_CAST_COLSUM      dbias[bmap(c)] += sum_r src[r][c]  (fp32, atomics) with bmap(c) = (c / bias_q) * bias_s +
- *                         c % bias_q (bias_q == 0: c) -- the fused bias gradient of the wgrad that reads dstT.
+ *                         c % bias_q + bias_off (bias_q == 0: c + bias_off) -- the fused bias gradient of the
+ *                         wgrad that reads dstT.
+ * Source column map: with src_q > 0 logical column c reads src[r][(c / src_q) * src_s + c % src_q] (src_q, src_s
+ * multiples of 4) -- a band of input channels i' in [i_lo, i_lo + src_q) of every output channel o' of a decoder tile
+ * row (o' * i + i'), the wgrad operand layout of program.py.
+ * GHN3_CAST_TIGHT: the transposed copy writes r < round_up(rows, 8) only (zeros for r >= rows), so that matrices can be
+ * concatenated along r at multiples of 8 instead of 64; the caller keeps the remaining padding zero.
  * The type of each copy is f16 unless its *_BF16 flag is set.  Offsets: src_off in floats from r0, dst_off / dstT_off
  * in 16-bit elements from r1; ld_dst >= round_up(cols, 64), ld_dstT >= round_up(rows, 64), both multiples of 8. */
 #define GHN3_CAST_STRAIGHT 1u
@@ -121,6 +127,7 @@ typedef struct ghn3_gemm_problem {
 /* multiply by the power-of-two scale derived from the op's r4 (running max |x|, see ghn3_gemm_problem::alpha_amax)
  * before converting; column sums stay unscaled */
 #define GHN3_CAST_SCALED 32u
+#define GHN3_CAST_TIGHT 64u
 typedef struct ghn3_cast_desc {
     int64_t src_off, dst_off, dstT_off;
     int32_t rows, cols;
@@ -128,7 +135,8 @@ typedef struct ghn3_cast_desc {
     uint32_t flags;
     int32_t bias_q, bias_s;
     int32_t block_start;     /* first workgroup of this descriptor: blocks are 64 x 64 source tiles, column-tile fastest */
-    int32_t _pad;
+    int32_t bias_off;
+    int32_t src_q, src_s;    /* source column map (0: identity) */
 } ghn3_cast_desc;
 
 /* ---- tile / normalise descriptors  (nn.py:422-506 _tile_params, 554-592 _normalize, 508-552 _set_params)

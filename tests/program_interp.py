@@ -122,7 +122,11 @@ class Interp:
             assert int(D['block_start']) == nb
             nb += ((rows + 63) // 64) * ((cols + 63) // 64)
             off = int(D['src_off'])
-            X = src[off + np.arange(rows)[:, None] * ld + np.arange(cols)[None, :]]
+            cc = np.arange(cols)
+            if int(D['src_q']) > 0:
+                assert int(D['src_q']) % 4 == 0 and int(D['src_s']) % 4 == 0
+                cc = (cc // int(D['src_q'])) * int(D['src_s']) + cc % int(D['src_q'])
+            X = src[off + np.arange(rows)[:, None] * ld + cc[None, :]]
             fl = int(D['flags'])
             Xsum = X
             if fl & L.CAST_SCALED and amax is not None:
@@ -134,17 +138,18 @@ class Interp:
                 ii = int(D['dst_off']) + np.arange(rows)[:, None] * ldd + np.arange(r64(cols))[None, :]
                 dst[ii] = self.to16(Z, bool(fl & L.CAST_STRAIGHT_BF16))
             if fl & L.CAST_TRANSPOSED:
-                Z = np.zeros((cols, r64(rows)), np.float32)
+                rw = (rows + 7) // 8 * 8 if fl & L.CAST_TIGHT else r64(rows)
+                Z = np.zeros((cols, rw), np.float32)
                 Z[:, :rows] = X.T
                 ldd = int(D['ld_dstT'])
-                ii = int(D['dstT_off']) + np.arange(cols)[:, None] * ldd + np.arange(r64(rows))[None, :]
+                ii = int(D['dstT_off']) + np.arange(cols)[:, None] * ldd + np.arange(rw)[None, :]
                 dst[ii] = self.to16(Z, bool(fl & L.CAST_TRANSPOSED_BF16))
             if fl & L.CAST_COLSUM:
                 c = np.arange(cols)
                 q, s_ = int(D['bias_q']), int(D['bias_s'])
                 if q > 0:
                     c = (c // q) * s_ + c % q
-                np.add.at(dbias, c, Xsum.astype(np.float64).sum(0).astype(np.float32))
+                np.add.at(dbias, c + int(D['bias_off']), Xsum.astype(np.float64).sum(0).astype(np.float32))
         assert nb == blocks
 
     def _gemm_op16(self, o, p):
@@ -283,8 +288,9 @@ class Interp:
         cq = C // 4
         x = self.fview(o['r'][0], B * N * C).reshape(B * N, C)
         T = [self.tail(o['r'][k], np.float32) for k in range(5, 11)]
-        Et, Ech, Esp = T[0].reshape(-1, C), T[1].reshape(-1, cq), T[2].reshape(-1, cq)
-        Ein, Eout, Ed = T[3].reshape(-1, C), T[4].reshape(-1, C), T[5].reshape(-1, C)
+        rs = lambda v, w: v[:len(v) // w * w].reshape(-1, w)      # (table tails run to the end of the flat buffer)
+        Et, Ech, Esp = rs(T[0], C), rs(T[1], cq), rs(T[2], cq)
+        Ein, Eout, Ed = rs(T[3], C), rs(T[4], C), rs(T[5], C)
         for b in range(B):
             for i in range(N):
                 row = b * N + i

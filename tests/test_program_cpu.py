@@ -115,16 +115,28 @@ def test_compiled_programs_reproduce_oracle_forward_and_backward(case, index_mod
         assert err < 5e-5 * float(np.linalg.norm(ref)) + 1e-6, (name, err, float(np.linalg.norm(ref)))
 
 
-@pytest.mark.parametrize('fwd_ct,bwd_ct,tol_f,tol_g', [(L.CT_F16, L.CT_BF16, 1e-3, 1e-2), (L.CT_F16, L.CT_F16, 1e-3, 1e-3),
-                                                        (L.CT_BF16, L.CT_BF16, 8e-3, 1e-2)])
-def test_16bit_operand_pipeline_program(fwd_ct, bwd_ct, tol_f, tol_g):
+@pytest.mark.parametrize('fwd_ct,bwd_ct,tol_f,tol_g,case', [(L.CT_F16, L.CT_BF16, 1e-3, 1e-2, 'b2'),
+                                                             (L.CT_F16, L.CT_F16, 1e-3, 1e-3, 'b2'),
+                                                             (L.CT_BF16, L.CT_BF16, 8e-3, 1e-2, 'b2'),
+                                                             (L.CT_F16, L.CT_F16, 1e-3, 1e-3, 'syn')])
+def test_16bit_operand_pipeline_program(fwd_ct, bwd_ct, tol_f, tol_g, case):
     """The 16-bit decoder pipeline (GHN3_OP_CAST16 copies + GHN3_GEMM_OP16 problems, f16 forward / bf16 backward by
     default): program structure (offsets, k-map, padding, fused bias gradient) validated against the oracle with
     the rounding emulated by the interpreter.  Tolerances are the measured rounding noise, not fp32 parity."""
-    hip, oracle = _build(recipe.TINY_CFG, recipe.TINY_SEED, 'reference')
-    nets_h, gb_h, nets_o, gb_o = _tiny('b2')
+    if case == 'syn':
+        # seeded synthetic graphs (many (o, i) groups -> several wgrad bands and ragged families), 1000 classes
+        from util_parity import synthetic_case
+        cfg = dict(max_shape=(128, 128, 16, 16), num_classes=1000, hid=128, heads=8, layers=1, weight_norm=True,
+                   ve=True, layernorm=True)          # widths 32 < C / 2 stay 32 (nn.py:655-661): two bands
+        hip, oracle = _build(cfg, recipe.TINY_SEED, 'reference')
+        nets_h, gb_h, nets_o, gb_o = synthetic_case([40], 4400)
+    else:
+        hip, oracle = _build(recipe.TINY_CFG, recipe.TINY_SEED, 'reference')
+        nets_h, gb_h, nets_o, gb_o = _tiny(case)
     prog, it, bufs, gflat = _run_program(hip, nets_h, gb_h, decoder_ctype=fwd_ct, decoder_bwd_ctype=bwd_ct)
     assert any(g['op16'] for g in prog.gemm_groups)
+    if case == 'syn':
+        assert len(prog.wgrad_bands) >= 2 and any(len(b['members']) > 2 for b in prog.wgrad_bands)
     assert sum(int(p['flags']) & L.GEMM_OP16 != 0 for p in prog.problems) >= 3
     out = bufs[prog.xbuf(prog.X_OUT)].view(np.float32)
     oracle.train()

@@ -25,9 +25,22 @@ class Graph:
     def __init__(self, model=None, node_feat=None, node_info=None, A=None, edges=None, net_args=None, net_idx=None,
                  ve_cutoff=50, dense=True, **kwargs):
         if model is not None:
-            raise NotImplementedError(
-                'ghn3_amd.Graph(model) -- automatic graph construction (reference ghn3/graph.py:392-908) is not '
-                'implemented yet; pass node_feat/node_info/A (e.g. from ghn3_amd.synthetic or a saved fixture).')
+            # automatic construction from the module's autograd graph (graph.py:392-908) -> graph_build.py
+            assert node_feat is None, 'either model or other arguments must be specified'
+            from .graph_build import build_graph, attach_layered_modules
+            built = build_graph(model, ve_cutoff=ve_cutoff, reduce_graph=kwargs.get('reduce_graph', True),
+                                fix_weight_edges=kwargs.get('fix_weight_edges', True),
+                                fix_softmax_edges=kwargs.get('fix_softmax_edges', True),
+                                list_all_nodes=kwargs.get('list_all_nodes', False),
+                                verbose=kwargs.get('verbose', False))
+            self.model = model
+            self.n_nodes = len(built['node_feat'])
+            self.node_feat, self.node_info, self._Adj = built['node_feat'], built['node_info'], built['A']
+            self._nodes, self._param_shapes = built['nodes'], built['param_shapes']
+            self.expected_input_sz, self.n_cells = built['expected_input_sz'], built['n_cells']
+            attach_layered_modules(model)
+            self.net_args, self.net_idx = net_args, net_idx
+            return
         assert dense, 'only the dense (Graphormer / GHN-3) layout is supported'
         assert node_feat is not None and A is not None and node_info is not None
         self.model = None

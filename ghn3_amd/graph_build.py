@@ -1,0 +1,464 @@
+"""
+Computational graph of an ``nn.Module`` for GHN-3, host side only.
+
+Produces what ``ghn3.Graph(model)`` of the reference produces (/root/reference/ghn3/graph.py:392-908): one forward
+pass on a random input, a walk over the autograd graph, pruning of the nodes GHN-3 has no primitive for, the
+weight / softmax edge repairs, an input node, a topological order, virtual edges (shortest-path lengths up to
+``ve_cutoff``) and the node features / ``node_info`` consumed by ``GHN3.forward``.  The graph heuristics of the
+reference are order dependent (neighbour positions in the node list, Kahn generations of its topological sort), so
+every stage here keeps the reference's node order; the stages themselves are written over plain index arrays
+(no networkx: BFS, path counting and the generation-wise topological order are a few lines each).
+
+Stages (reference lines):  _trace 392-501 · _prune 666-769 · _repair_weight_edges 503-548 · _repair_softmax_edges
+550-572 · input node + order 607-626 · model-specific fixes 628-646 · _virtual_edges 771-812 · _features 814-906.
+Third-party classes (torchvision, ppuda) are recognised by class name along the MRO: neither package is needed.
+"""
+
+import copy
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .bookkeeping import PRIMITIVES_DEEPNETS1M, named_layered_modules
+
+_NAMED_LAYER_CLASSES = {'LayerNorm2d': 'ln', 'PosEnc': 'pos_enc', 'Encoder': 'pos_enc'}
+_OP_PRIMITIVES = {'input': 'input', 'Mean': 'glob_avg', 'AdaptiveAvgPool2D': 'glob_avg',
+                  'MaxPool2DWithIndices': 'max_pool', 'AvgPool2D': 'avg_pool', 'Softmax': 'msa', 'Mul': 'cse',
+                  'Add': 'sum', 'Cat': 'concat', 'skip_connect': 'sum'}
+
+
+def _has_base(obj, *names):
+    """isinstance by class name along the MRO (torchvision / ppuda / transformers classes without importing them)."""
+    return obj is not None and any(c.__name__ in names for c in type(obj).__mro__)
+
+
+def _conv_like(module):
+    return isinstance(module, (nn.Conv2d, nn.Linear, nn.MultiheadAttention)) or _has_base(module, 'Conv1D')
+
+
+def _layer_primitive(module, param_name):
+    """Primitive name of a parameter node (graph.py:1098-1128)."""
+    if _conv_like(module):
+        if 'bias' in param_name:
+            return 'bias'
+        if isinstance(module, nn.Conv2d) and module.groups > 1:
+            return 'dil_conv' if min(module.dilation) > 1 else 'sep_conv'
+        return 'conv'
+    if isinstance(module, nn.BatchNorm2d):
+        return 'bn'
+    if isinstance(module, nn.LayerNorm):
+        return 'ln'
+    if isinstance(module, nn.Embedding):
+        return 'pos_enc'
+    for cls_name, prim in _NAMED_LAYER_CLASSES.items():
+        if _has_base(module, cls_name):
+            return prim
+    return None
+
+
+def _op_prefix(name):
+    k = name.find('Backward')
+    return name if k < 0 else name[:k]
+
+
+class _Node:
+    __slots__ = ('name', 'module', 'size', 'ksize')
+
+    def __init__(self, name, module=None, size=None, ksize=None):
+        self.name, self.module, self.size, self.ksize = name, module, size, ksize
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# stage 1: autograd walk
+# ---------------------------------------------------------------------------------------------------------------
+def _owners(model):
+    """id(parameter) -> (qualified name, owning module); the first qualified name of a tensor is kept per name,
+    the last owner wins per tensor (tied weights), as the reference's dict construction does."""
+    named = {}
+    for mod_name, mod in model.named_modules():
+        for p_name, p in mod.named_parameters(recurse=False):
+            if p is not None:
+                named.setdefault(mod_name + '.' + p_name, (p, mod))
+    return {id(p): (key, mod) for key, (p, mod) in named.items()}
+
+
+def _trace(outputs, owners):
+    """Nodes in creation order of a depth-first walk from the outputs and the directed edges between them.
+    A function with parameter inputs is represented by those parameters (weight first); any other function by
+    itself.  Edges point from producer to consumer, except towards a bias (weight -> bias)."""
+    nodes, slot = [], {}            # slot: autograd object -> index into nodes
+    link = {}                       # autograd object -> (node index or None, name) as seen by its consumers
+    first = {}                      # function -> index of its first node
+    entered = []
+
+    def enter(fn):
+        fname = type(fn).__name__
+        last = None
+        if 'AccumulateGrad' not in fname:
+            leaves = []
+            for child, _ in fn.next_functions:
+                if child is not None and hasattr(child, 'variable'):
+                    pname, mod = owners[id(child.variable)]
+                    leaves.append((child, pname, mod, tuple(child.variable.shape), None))
+            if not leaves:
+                ks = getattr(fn, '_saved_kernel_size', None)
+                leaves.append((fn, fname, None, None, None if ks is None else tuple(int(v) for v in ks)))
+            for obj, pname, mod, size, ks in leaves:
+                if obj not in slot:
+                    slot[obj] = len(nodes)
+                    nodes.append(_Node(pname, mod, size, ks))
+                last = slot[obj]
+                first.setdefault(fn, last)
+                link[obj] = (last, pname)
+        link[fn] = (last, fname)
+        entered.append(fn)
+
+    stack = [fn for fn in reversed(outputs)]
+    while stack:
+        fn = stack.pop()
+        if fn in link:
+            continue
+        enter(fn)
+        for child, _ in reversed(fn.next_functions):
+            if child is not None and child not in link:
+                stack.append(child)
+    edges = set()
+    for fn in entered:
+        src = first.get(fn)
+        for child, _ in fn.next_functions:
+            if child is None:
+                continue
+            idx, cname = link[child]
+            if idx is not None and idx != src and src is not None:
+                edges.add((src, idx) if 'bias' in cname else (idx, src))
+    A = np.zeros((len(nodes), len(nodes)), dtype=np.int64)
+    for a, b in edges:
+        A[a, b] = 1
+    return nodes, A
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# stage 2: pruning (graph.py:666-769)
+# ---------------------------------------------------------------------------------------------------------------
+def _supported(node):
+    mod = node.module
+    if mod is not None and 'norm' in type(mod).__name__.lower() and _op_prefix(node.name).endswith('.bias'):
+        return False                        # biases of normalisation layers are predicted but are not graph nodes
+    return mod is not None and _layer_primitive(mod, node.name) is not None
+
+
+def _prune(nodes, A, drop=None):
+    """Removes the nodes whose name contains one of the `drop` strings (connecting their producers to their
+    consumers), with the reference's special cases for squeeze-excitation products, pooling means and single-input
+    sums / concatenations.  drop=None: everything GHN-3 has no primitive for."""
+    if drop is None:
+        unsupported = {n.name for n in nodes if not _supported(n) and _op_prefix(n.name) not in _OP_PRIMITIVES}
+        drop = ['Mul'] + sorted(unsupported) + ['Mean', 'Add', 'Cat']
+    has_cse = any('sigmoid' in n.name.lower() or 'swish' in n.name.lower() for n in nodes)
+    n_in = [int(np.count_nonzero(A[:, i])) for i in range(len(nodes))]
+    for pattern in drop:
+        keep_idx = []
+        for i, node in enumerate(nodes):
+            keep = True
+            if pattern in node.name:
+                try:
+                    near = {j: nodes[i + j].name.lower() for j in (-1, -2, -3, 1)}     # (negative indices wrap)
+                    head = any(near[j].startswith(('classifier', 'fc', 'head')) for j in (-1, -2))
+                except IndexError:
+                    near, head = None, True
+                if node.name.startswith('Mean'):
+                    if has_cse:
+                        keep = head
+                elif node.name.startswith('Mul'):
+                    keep = has_cse and not head and (near[-2].startswith(('hard', 'sigmoid')) or
+                                                     near[-3].startswith(('relu', 'mean')) or
+                                                     near[1].startswith(('hard', 'sigmoid', 'relu')))
+                elif node.name.startswith(('Cat', 'Add')):
+                    keep = n_in[i] > 1
+                else:
+                    keep = False
+                if not keep:
+                    outs, ins = np.nonzero(A[i, :])[0], np.nonzero(A[:, i])[0]
+                    for n1 in outs:
+                        for n2 in ins:
+                            if n1 != n2:
+                                A[n2, n1] = 1
+            if keep:
+                keep_idx.append(i)
+        if len(keep_idx) < len(nodes):
+            A = A[:, keep_idx][keep_idx, :]
+            nodes = [nodes[i] for i in keep_idx]
+            n_in = [n_in[i] for i in keep_idx]
+    return nodes, A
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# stage 3: edge repairs (graph.py:503-572)
+# ---------------------------------------------------------------------------------------------------------------
+def _repair_weight_edges(nodes, A):
+    """A weight that autograd left without producer (weight -> bias of the same layer) is moved in front of its bias:
+    producer -> weight -> bias -> consumers."""
+    for i in range(len(nodes)):
+        if A[:, i].sum() > 0 or 'weight' not in nodes[i].name:
+            continue
+        weight = nodes[i]                                # (stays the reference point after a swap below)
+        for nb in np.nonzero(A[i, :])[0]:
+            same_layer = weight.module == nodes[nb].module
+            qkv = np.count_nonzero(A[:, i]) == 0 and 'softmax' in nodes[nb].name.lower()
+            if not (same_layer or qkv):
+                continue
+            n_out = np.count_nonzero(A[i, :])
+            others = np.setdiff1d(np.nonzero(A[:, nb])[0], i)
+            if len(others) == 0:
+                continue
+            nodes[i], nodes[nb] = nodes[nb], nodes[i]
+            A[i, nb], A[nb, i] = 0, 1
+            if n_out == 1:
+                rest = np.setdiff1d(np.nonzero(A[nb, :])[0], i)
+                if len(rest) == 0:
+                    continue
+                A[nb, rest] = 0
+                A[i, rest] = 1
+    return nodes, A
+
+
+def _path_counts_to(A, target):
+    """Number of directed paths (capped at 2) from every node to `target` in the DAG given by A != 0."""
+    n = len(A)
+    succ = [np.nonzero(A[i, :])[0] for i in range(n)]
+    memo = {target: 1}
+    for s in range(n):
+        if s in memo:
+            continue
+        stack, open_ = [s], {s}
+        while stack:
+            v = stack[-1]
+            pending = [int(w) for w in succ[v] if int(w) not in memo and int(w) not in open_]
+            if pending:
+                stack.extend(pending)
+                open_.update(pending)
+                continue
+            stack.pop()
+            if v not in memo:
+                memo[v] = min(2, sum(memo.get(int(w), 0) for w in succ[v]))      # (a back edge counts as no path)
+    return memo
+
+
+def _repair_softmax_edges(nodes, A):
+    """Attention: the node after a softmax keeps the softmax as its only producer where the reference says so."""
+    snap = A.copy()                                   # path counts refer to the graph before this repair
+    for i, node in enumerate(nodes):
+        if 'softmax' not in node.name.lower():
+            continue
+        for nb in np.nonzero(A[i, :])[0]:
+            counts = None
+            for j in np.setdiff1d(np.nonzero(A[:, nb])[0], i):
+                if counts is None:
+                    counts = _path_counts_to(snap, int(nb))
+                n_paths = counts.get(int(j), 0)
+                if n_paths > 1 or A[i, j] == 0:
+                    A[j, nb] = 0
+                if n_paths == 1 and A[i, j] == 0:
+                    A[j, i] = 1
+    return A
+
+
+def _repair_swin_edges(nodes, A):
+    """graph.py:577-601 (torchvision SwinTransformer only; restated, not exercised by the fixtures)."""
+    for i, node in enumerate(nodes):
+        low = node.name.lower()
+        if low.endswith('norm.weight'):
+            for nb in np.nonzero(A[i, :])[0]:
+                if nodes[nb].name.endswith('norm1.weight') or 'Add' in nodes[nb].name:
+                    A[i, nb] = 0
+                    target = node.name.replace('norm', 'reduction')
+                    for j, other in enumerate(nodes):
+                        if target in other.name:
+                            A[i, j] = 1
+                            break
+        elif low.endswith('attn.proj.bias'):
+            for nb in np.nonzero(A[i, :])[0]:
+                if nodes[nb].name.endswith('reduction.weight'):
+                    A[i, nb] = 0
+                    for nb2 in np.nonzero(A[nb, :])[0]:
+                        if nodes[nb2].name.startswith('AddBackward'):
+                            A[i, nb2] = 1
+    return A
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# stage 4: order, virtual edges
+# ---------------------------------------------------------------------------------------------------------------
+def _generation_order(A):
+    """Topological order by generations (all nodes whose producers are placed, in discovery order) -- the order
+    networkx.topological_sort yields for DiGraph(A)."""
+    n = len(A)
+    indeg = [int(np.count_nonzero(A[:, i])) for i in range(n)]
+    succ = [np.nonzero(A[i, :])[0] for i in range(n)]
+    gen = [i for i in range(n) if indeg[i] == 0]
+    order = []
+    while gen:
+        nxt = []
+        for v in gen:
+            order.append(v)
+            for w in succ[v]:
+                indeg[w] -= 1
+                if indeg[w] == 0:
+                    nxt.append(int(w))
+        gen = nxt
+    if len(order) != n:
+        raise ValueError('the computational graph has a cycle')
+    return order
+
+
+def _virtual_edges(A, cutoff):
+    """A[i, j] = shortest-path length from i to j (2 .. cutoff) where there is no direct edge (graph.py:803-810)."""
+    n = len(A)
+    succ = [np.nonzero(A[i, :] == 1)[0] for i in range(n)]
+    for s in range(n):
+        dist = {s: 0}
+        frontier, d = [s], 0
+        while frontier and d < cutoff:
+            d += 1
+            nxt = []
+            for v in frontier:
+                for w in succ[v]:
+                    if int(w) not in dist:
+                        dist[int(w)] = d
+                        nxt.append(int(w))
+            frontier = nxt
+        for t, d in dist.items():
+            if d > 0 and A[s, t] == 0:
+                A[s, t] = d
+    return A
+
+
+def _cell_index(param_name, n_cells):
+    """ppuda get_cell_ind: DeepNets-1M networks name their cells 'cells.<k>.' (None for anything else)."""
+    if n_cells > 1:
+        k = param_name.find('cells.')
+        if k >= 0:
+            digits = param_name[k + 6:].split('.')[0]
+            if digits.isdigit():
+                return int(digits)
+    return None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def build_graph(model, ve_cutoff=50, reduce_graph=True, fix_weight_edges=True, fix_softmax_edges=True,
+                list_all_nodes=False, verbose=False):
+    """Returns dict(node_feat (N,1) int64, node_info, A (N,N) int64, nodes, param_shapes, expected_input_sz, n_cells)."""
+    sz = getattr(model, 'expected_input_sz', 299 if _has_base(model, 'Inception3') else 224)
+    in_sz = tuple(sz) if isinstance(sz, (tuple, list)) else (3, sz, sz)
+    n_cells = getattr(model, '_n_cells', 1)
+    device = next(model.parameters()).device
+    with torch.enable_grad():
+        out = model.get_var() if hasattr(model, 'get_var') else model(torch.randn(2, *in_sz, device=device))
+    if isinstance(out, dict):
+        out = list(out.values())
+    if not isinstance(out, (tuple, list)):
+        out = [out]
+    nodes, A = _trace([v.grad_fn for v in out if v is not None], _owners(model))
+    del out
+    if reduce_graph:
+        nodes, A = _prune(nodes, A)
+    if fix_weight_edges:
+        nodes, A = _repair_weight_edges(nodes, A)
+    if fix_softmax_edges:
+        A = _repair_softmax_edges(nodes, A)
+    if verbose and np.trace(A) > 0:
+        print('WARNING: diagonal elements of the adjacency matrix should be zero', np.trace(A))
+    if _has_base(model, 'SwinTransformer'):
+        A = _repair_swin_edges(nodes, A)
+    if reduce_graph:
+        nodes, A = _prune(nodes, A, drop=['Add', 'Cat'])
+    # input node: feeds every weight that has no producer
+    A = np.pad(A, ((0, 1), (0, 1)))
+    nodes.append(_Node('input'))
+    for i in np.nonzero(A.sum(0) == 0)[0]:
+        if 'weight' in nodes[i].name:
+            A[-1, i] = 1
+    np.fill_diagonal(A, 0)
+    order = _generation_order(A)
+    nodes = [nodes[i] for i in order]
+    A = A[order, :][:, order]
+    if _has_base(model, 'VisionTransformer', 'Network'):
+        # the positional encoding is followed by an explicit sum node (DeepNets-1M convention, graph.py:630-638)
+        i = 0
+        while i < len(nodes):
+            if _has_base(nodes[i].module, 'PosEnc', 'Encoder'):
+                nodes.insert(i + 1, _Node('AddBackward0'))
+                A = np.insert(np.insert(A, i, 0, axis=0), i, 0, axis=1)
+                A[i, i + 1] = 1
+            i += 1
+    elif _has_base(model, 'SqueezeNet'):
+        assert nodes[-1].name.startswith('MeanBackward') and nodes[-3].name.startswith('classifier'), nodes[-3].name
+        nodes.insert(len(nodes) - 3, copy.copy(nodes[-1]))
+        del nodes[-1]
+    assert np.trace(A) == 0, 'no loops should be in the graph'
+    if ve_cutoff > 1:
+        A = _virtual_edges(A, ve_cutoff)
+    return _features(nodes, A, n_cells, list_all_nodes, in_sz, verbose)
+
+
+def _features(nodes, A, n_cells, list_all_nodes, in_sz, verbose):
+    prim_id = {p: i for i, p in enumerate(PRIMITIVES_DEEPNETS1M)}
+    n = len(nodes)
+    node_feat = torch.empty(n, 1, dtype=torch.long)
+    node_info = [[] for _ in range(n_cells)]
+    shapes = []
+    cell, n_glob = 0, 0
+    for k, node in enumerate(nodes):
+        pname = node.name
+        c = _cell_index(pname, n_cells)
+        if c is not None:
+            cell = c
+        for marker in ('stem', 'pos_enc'):
+            pos = pname.find(marker)
+            if pos >= 0:
+                pname = pname[pos:]
+                break
+        if node.module is not None:
+            parts = pname.split('.')
+            for j, s_ in enumerate(parts):                  # DeepNets-1M names: '_ops.<k>.<m>' -> '_ops.<k>.op.<m>'
+                if s_ == '_ops' and j + 2 < len(parts) and parts[j + 2] != 'op' and parts[j + 2].isdigit():
+                    parts.insert(j + 2, 'op')
+                    pname = '.'.join(parts)
+                    break
+            prim = _layer_primitive(node.module, pname)
+            if prim is None:
+                raise KeyError('no GHN-3 primitive for %s (%s)' % (type(node.module).__name__, pname))
+        else:
+            prim = _OP_PRIMITIVES.get(_op_prefix(pname), 'sum')
+            n_glob += int(prim == 'glob_avg')
+            if n_cells > 1 and pname.startswith(('MaxPool', 'AvgPool')):
+                pname = 'cells.%d.' % cell + prim
+        sz = None
+        if node.size is not None:
+            sz = tuple(node.size)
+        elif node.module is None and 'pool' in prim and node.name != 'input':
+            sz = (1, 1) + (tuple(node.ksize) if node.ksize is not None else (3, 3))
+        if sz is not None:
+            if len(sz) == 3 and sz[0] == 1 and min(sz[1:]) > 1:           # (1, 197, 768) -> (1, 768, 14, 14)
+                s_ = int(np.floor(sz[1] ** 0.5))
+                sz = (1, sz[2], s_, s_)
+            elif len(sz) == 4 and k == n - 2 and max(sz[2:]) == 1:
+                sz = sz[:2]
+        shapes.append(sz)
+        if prim not in prim_id:
+            raise KeyError('op/layer %s is not one of %s' % (prim, PRIMITIVES_DEEPNETS1M))
+        node_feat[k] = prim_id[prim]
+        if node.module is not None or 'pool' in prim or list_all_nodes:
+            node_info[cell].append([k, pname if node.module is not None else prim, prim, sz,
+                                    k == n - 2 and '.weight' in pname, k == n - 1 and '.bias' in pname])
+    if n_glob != 1 and verbose:
+        print('WARNING: n_glob_avg should be 1 in most architectures, but is %d in this architecture.' % n_glob)
+    return dict(node_feat=node_feat, node_info=node_info, A=torch.as_tensor(A, dtype=torch.long), nodes=nodes,
+                param_shapes=shapes, expected_input_sz=in_sz, n_cells=n_cells)
+
+
+def attach_layered_modules(model):
+    """graph.py:331-333: cache the parameter enumeration GHN3.forward matches node_info against."""
+    if not hasattr(model, '_layered_modules'):
+        model.__dict__['_layered_modules'] = named_layered_modules(model)

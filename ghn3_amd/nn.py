@@ -337,9 +337,8 @@ class GHN3(nn.Module):
         is_lst = isinstance(nets_torch, (list, tuple))
         if not is_lst:
             nets_torch = [nets_torch]
-        if graphs is None:
-            raise NotImplementedError('graphs=None needs automatic graph construction (ghn3/graph.py:392-908), '
-                                      'which is not part of this package yet; pass a Graph / GraphBatch')
+        if graphs is None:                                   # nn.py:217-219: graphs built on the fly
+            graphs = [Graph(net, ve_cutoff=50 if self.ve else 1) for net in nets_torch]
         keep = self.training if keep_grads is None else keep_grads
         plan = self.compile(nets_torch, graphs, predict_class_layers=predict_class_layers, reduce_graph=reduce_graph,
                             training=bool(keep and torch.is_grad_enabled()))

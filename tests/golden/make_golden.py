@@ -271,6 +271,36 @@ def make_extra_goldens():
 
 
 # ------------------------------------------------------------------------------------------------
+# 2c. Automatic graph construction: the reference's Graph(model) (graph.py:292-908) on the hand-written networks of
+#     tests/golden/graph_nets.py -> graphs.npz (node types, adjacency with virtual edges, node_info, shapes)
+# ------------------------------------------------------------------------------------------------
+
+def make_graph_goldens():
+    install_standins()
+    sys.path.insert(0, REF)
+    import ghn3                                              # noqa: F401  the reference package
+    from ghn3.graph import Graph
+    import graph_nets
+    tvm = sys.modules['torchvision.models']
+    bases = {'VisionTransformer': tvm.VisionTransformer, 'Encoder': tvm.vision_transformer.Encoder}
+    out = {}
+    for name, net in graph_nets.all_nets(bases).items():
+        for ve in (50, 1):
+            g = Graph(net, ve_cutoff=ve, verbose=False)
+            tag = '%s/ve%d' % (name, ve)
+            out[tag + '/node_feat'] = g.node_feat.view(-1).numpy().astype(np.int16)
+            out[tag + '/A'] = g._Adj.numpy().astype(np.int16)
+            out[tag + '/names'] = np.asarray([n['param_name'] for n in g._nodes])
+            out[tag + '/node_info'] = np.asarray([repr([(int(a), str(b), str(c), None if d is None else tuple(
+                int(v) for v in d), bool(e), bool(f)) for (a, b, c, d, e, f) in cell]) for cell in g.node_info])
+            out[tag + '/shapes'] = np.asarray([repr(None if s_ is None else tuple(int(v) for v in s_))
+                                               for s_ in g._param_shapes])
+            print(tag, 'nodes', g.n_nodes, 'edges', int((g._Adj == 1).sum()))
+    np.savez_compressed(os.path.join(HERE, 'graphs.npz'), **out)
+    print('graphs.npz: %d arrays' % len(out))
+
+
+# ------------------------------------------------------------------------------------------------
 # 3. torchvision-shaped ResNets through the reference GHN3 class at the released sizes (BASELINE configs 1 and 4):
 #    ghn3tm8 on the ResNet-18 graph, ghn3xlm16 on the ResNet-50 graph.  Stores per predicted tensor the Frobenius
 #    norm and a seeded sample of its elements (the tensors themselves are 11.7 M / 25.6 M floats).
@@ -325,10 +355,13 @@ def make_resnet_goldens(which=('18', '50', 'vit')):
 
 if __name__ == '__main__':
     # python make_golden.py            -> tiny fixtures (seconds)
+    # python make_golden.py graphs     -> graphs.npz (reference Graph(model) on tests/golden/graph_nets.py)
     # python make_golden.py extra      -> ghn3_tiny_extra.npz (big kernels, weight_norm / layernorm off)
     # python make_golden.py resnet     -> + ResNet-18 / ghn3tm8 and ResNet-50 / ghn3xlm16 (minutes, ~10 GB of RAM)
     torch.set_num_threads(8 if 'resnet' in sys.argv[1:] else 4)
-    if 'extra' in sys.argv[1:]:
+    if 'graphs' in sys.argv[1:]:
+        make_graph_goldens()
+    elif 'extra' in sys.argv[1:]:
         make_extra_goldens()
     elif 'resnet' in sys.argv[1:]:
         make_resnet_goldens([a for a in sys.argv[1:] if a in ('18', '50', 'vit')] or ('18', '50', 'vit'))

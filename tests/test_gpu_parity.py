@@ -188,6 +188,46 @@ def test_extra_cases_forward_backward(case):
         assert abs(p.grad.norm().item() - ref[0]) < 2e-4 * max(1.0, ref[0]), (k, p.grad.norm().item(), ref[0])
 
 
+@pytest.mark.parametrize('name', ['resnet_tiny', 'mobile_se', 'vit_tiny', 'attn_tiny'])
+def test_ghn_model_without_a_graph(name):
+    """examples/ghn_single_model.py call sequence: ``ghn(model)`` with graphs=None builds the graph from the module
+    (ghn3_amd/graph_build.py, pinned against the reference in tests/test_graph_build_cpu.py), predicts every
+    parameter and assigns it; values checked against the oracle run on the same graph."""
+    import graph_nets
+    from ghn3_amd import Graph
+    from oracle import ghn3_ref as R
+    hip, oracle = make_models(recipe.TINY_CFG, recipe.TINY_SEED)
+    hip.eval()
+    net = graph_nets.all_nets(graph_nets.local_bases())[name].to('cuda')
+    before = {k: v.detach().clone() for k, v in net.named_parameters()}
+    with torch.no_grad():
+        out = hip(net)                                            # graphs=None
+    assert out is net
+    torch.cuda.synchronize()
+    net_o = graph_nets.all_nets(graph_nets.local_bases())[name]
+    g = Graph(net_o, ve_cutoff=50)
+    gb_o = R.GraphBatchRef([R.GraphRef(g.node_feat, g.node_info, g._Adj)])
+    oracle.eval()
+    with torch.no_grad():
+        oracle([net_o], gb_o, keep_grads=False)
+    po = dict(net_o.named_parameters())
+    changed = 0
+    for k, p in net.named_parameters():
+        assert isinstance(p, torch.nn.Parameter) and torch.isfinite(p).all(), k
+        if k.endswith('class_token'):
+            assert torch.equal(p, before[k])                       # not a graph node: left untouched
+            continue
+        a, b = p.detach().cpu(), po[k].detach()
+        if a.dim() == 3:
+            a, b = a[:, 1:], b[:, 1:]                              # Q3: random class-token row
+        assert rel_l2(a, b) < 2e-5, (k, rel_l2(a, b))
+        changed += int(not torch.equal(p, before[k]))
+    assert changed == len(before) - int(any(k.endswith('class_token') for k in before))
+    # the network runs with the predicted parameters
+    y = net(torch.randn(2, 3, 32, 32, device='cuda'))
+    assert y.shape == (2, 10) and torch.isfinite(y).all()
+
+
 def test_graph_with_more_than_1024_nodes():
     """N = 1100 (EfficientNet-B7-sized graphs exceed 1024 nodes): streamed two-pass attention forward, generic
     backward; head dim 24 like ghn3xlm16.  Forward and gradients vs the oracle."""

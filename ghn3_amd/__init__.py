@@ -2,13 +2,14 @@
 ghn3_amd -- MI355X-native implementation of the GHN-3 parameter-prediction hot path.
 
 Mirrors the package surface of the reference for this path (/root/reference/ghn3/__init__.py:8-13):
-``Graph, GraphBatch, from_pretrained, GHN3, ConvDecoder3, SequentialMultipleInOut`` plus the DDP helpers.
+``Graph, GraphBatch, from_pretrained, GHN3, ConvDecoder3, SequentialMultipleInOut, norm_check, get_metadata`` plus
+the DDP helpers.
 """
 
 from .graph import Graph, GraphBatch
-from .nn import from_pretrained, GHN3, ConvDecoder3, SequentialMultipleInOut, log
+from .nn import from_pretrained, GHN3, ConvDecoder3, SequentialMultipleInOut, log, norm_check, get_metadata
 from .ddp_utils import setup_ddp, is_ddp, get_ddp_rank, clean_ddp, avg_ddp_metric, all_reduce_flat_grads
 from .optim import FusedAdamW
 
-__all__ = ['Graph', 'GraphBatch', 'from_pretrained', 'GHN3', 'ConvDecoder3', 'SequentialMultipleInOut', 'log',
+__all__ = ['Graph', 'GraphBatch', 'from_pretrained', 'GHN3', 'ConvDecoder3', 'SequentialMultipleInOut', 'log', 'norm_check', 'get_metadata',
            'setup_ddp', 'is_ddp', 'get_ddp_rank', 'clean_ddp', 'avg_ddp_metric', 'all_reduce_flat_grads', 'FusedAdamW']

@@ -431,3 +431,67 @@ def from_pretrained(ghn3_name='ghn3xlm16.pt', **kwargs):
     ghn = GHN3(**ghn_config, **extra, **kwargs)
     ghn.load_state_dict(state_dict)
     return ghn
+
+
+# ---------------------------------------------------------------------------------------------------
+# Known-answer harness for the released checkpoints (nn.py:783-861)
+# ---------------------------------------------------------------------------------------------------
+_RESULT_KEYS = {'ghn3xlm16.pt': 'ghn3', 'ghn3tm8.pt': 'ghn3-t', 'ghn2.pt': 'ghn2', 'randinit': 'randinit'}
+_RESULTS_MD5 = 'c9ffc3b9222e872af316eb1cb1ee1c08'
+
+
+def get_metadata(ghn3_name='ghn3xlm16.pt', arch=None, attr=None, path=None):
+    """
+    Per-architecture known answers of the released GHNs (total norm of the predicted parameters, accuracies) from
+    the reference's ``ghn3_results.json`` (one JSON object per line, md5-checked).  ``path`` / $GHN3_RESULTS_JSON name
+    a local copy (the repository keeps one under tests/golden/); otherwise the file is fetched from the HuggingFace
+    hub like the reference does.  Returns None when the file or the GHN name is unknown.
+    """
+    import hashlib
+    import json
+    key = None
+    if ghn3_name is not None:
+        key = _RESULT_KEYS.get(ghn3_name)
+        if key is None:
+            log('WARNING: meta data not unavailable for %s' % ghn3_name)
+            return None
+    path = path or os.environ.get('GHN3_RESULTS_JSON')
+    if path is None:
+        try:
+            from huggingface_hub import hf_hub_download
+            path = hf_hub_download(repo_id='SamsungSAILMontreal/ghn3', filename='ghn3_results.json')
+        except Exception as e:
+            print('Error: ', e)
+            return None
+    with open(path, 'rb') as f:
+        raw = f.read()
+    digest = hashlib.md5(raw).hexdigest()
+    assert digest == _RESULTS_MD5, 'corrupted %s: md5sum=%s' % (path, digest)
+    table = {}
+    for line in raw.decode().splitlines():
+        if line.strip():
+            table.update(json.loads(line))
+    if key is None:
+        return table
+    out = {}
+    for a, row in table.items():
+        out[a] = {k.split('-')[-1]: float(v) for k, v in row.items()
+                  if k.startswith(key) and not (key == 'ghn3' and k.startswith('ghn3-t'))}
+    if arch is not None:
+        out = out[arch]
+        return out[attr] if attr is not None else out
+    if attr is not None:
+        return {a: out[a][attr] for a in out}
+    return out
+
+
+def norm_check(model, arch='resnet50', ghn3_name='ghn3xlm16.pt', path=None):
+    """Total norm of the model's parameters against the released known answer (tolerance 1e-2, nn.py:795).
+    Returns (total_norm, expected or None, passed or None)."""
+    total_norm = torch.norm(torch.stack([p.norm() for p in model.parameters()]), 2).item()
+    norm = get_metadata(ghn3_name, arch=arch, attr='paramnorm', path=path)
+    ok = None if not norm else abs(norm - total_norm) < 1e-2
+    log('Predicted params total norm={:.4f} ({})'.format(
+        total_norm, 'no norm check available' if ok is None else
+        ('check passed!' if ok else 'ERROR: norm check not matched with %.2f' % norm)))
+    return total_norm, norm, ok

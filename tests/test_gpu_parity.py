@@ -191,7 +191,7 @@ def test_extra_cases_forward_backward(case):
 @pytest.mark.parametrize('name', ['resnet_tiny', 'mobile_se', 'vit_tiny', 'attn_tiny'])
 def test_ghn_model_without_a_graph(name):
     """examples/ghn_single_model.py call sequence: ``ghn(model)`` with graphs=None builds the graph from the module
-    (ghn3_amd/graph_build.py, pinned against the reference in tests/test_graph_build_cpu.py), predicts every
+    (ghn3_amd/graph_build.py, pinned against the reference in tests/test_host_api_cpu.py), predicts every
     parameter and assigns it; values checked against the oracle run on the same graph."""
     import graph_nets
     from ghn3_amd import Graph

@@ -80,3 +80,47 @@ def test_graph_is_independent_of_the_random_input():
     torch.manual_seed(2)
     b = Graph(net)
     assert torch.equal(a._Adj, b._Adj) and torch.equal(a.node_feat, b.node_feat)
+
+
+def test_known_answer_table():
+    """ghn3_results.json (data file of the reference, md5-pinned): the paramnorm known answers BASELINE.md cites."""
+    from ghn3_amd import get_metadata, norm_check
+    path = os.path.join(os.path.dirname(__file__), 'golden', 'ghn3_results.json')
+    assert abs(get_metadata('ghn3xlm16.pt', arch='resnet50', attr='paramnorm', path=path) - 108.4530) < 1e-4
+    assert abs(get_metadata('ghn3tm8.pt', arch='resnet50', attr='paramnorm', path=path) - 78.6197) < 1e-4
+    assert abs(get_metadata('ghn3xlm16.pt', arch='vit_b_16', attr='paramnorm', path=path) - 366.0770) < 1e-4
+    norms = get_metadata('ghn3tm8.pt', attr='paramnorm', path=path)
+    assert len(norms) == 74 and abs(norms['resnet18'] - 54.9382) < 1e-4
+    assert get_metadata('unknown.pt', path=path) is None
+    lin = torch.nn.Linear(4, 4)
+    total, expect, ok = norm_check(lin, arch='resnet50', ghn3_name='ghn3xlm16.pt', path=path)
+    assert ok is False and abs(expect - 108.4530) < 1e-4
+
+
+@pytest.mark.parametrize('layout', ['nested', 'hf_top_level', 'with_config'])
+def test_from_pretrained_local_checkpoint(tmp_path, layout):
+    """Checkpoint ingestion (nn.py:31-125): configuration inferred from the state dict (hid, layers, heads, max_shape,
+    decoder grid, layernorm), both key layouts of the three layer-0 embeddings (nn.py:87,174-184), trainer-style files
+    with a config entry (trainer.py:413-432).  Weights must round-trip bit-exactly; the model comes back in train mode
+    on the CPU like the reference."""
+    from ghn3_amd import GHN3, from_pretrained
+    cfg = dict(max_shape=(64, 64, 16, 16), num_classes=1000, hid=64, heads=8, layers=3, weight_norm=True, ve=True,
+               layernorm=True)
+    torch.manual_seed(3)
+    src = GHN3(**cfg)
+    sd = {k: v.detach().clone() for k, v in src.state_dict().items()}
+    if layout == 'hf_top_level':
+        for k in ('centrality_embed_in', 'centrality_embed_out', 'input_dist_embed'):
+            sd[k + '.weight'] = sd.pop('gnn.0.' + k + '.weight')
+    path = str(tmp_path / 'ghn3tm8.pt')
+    torch.save({'state_dict': sd, 'config': cfg} if layout == 'with_config' else sd, path)
+    ghn = from_pretrained(path, debug_level=0)
+    assert ghn.training and ghn.device.type == 'cpu'
+    assert (ghn.hid, ghn.layers, ghn.heads, ghn.max_shape, ghn.num_classes) == (64, 3, 8, (64, 64, 16, 16), 1000)
+    assert ghn.layernorm and ghn.weight_norm
+    ref = src.state_dict()
+    got = ghn.state_dict()
+    assert sorted(ref) == sorted(got)
+    for k in ref:
+        assert torch.equal(ref[k], got[k]), k
+    assert sum(p.numel() for p in ghn.parameters()) == recipe.count_params(64, 3, 8, 1000) == 6906632

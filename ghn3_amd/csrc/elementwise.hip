@@ -612,31 +612,47 @@ int ghn3_tile_bwd(const float* dflat, const float* const* srcs, float* const* ds
 // loss = sum over predicted tensors of ||p||_F  (trainer.py:97-98,288-294).  seg_off holds (begin, end) pairs;
 // norms[] must be zero on entry (it accumulates squared sums, then is square-rooted in place).
 // ------------------------------------------------------------------------------------------------
+// The segments are laid out back to back in the flat buffer (16-float aligned), so both passes stream it: workgroup b
+// owns the floats [b * NORM_CHUNK, (b + 1) * NORM_CHUNK) and visits the (few) segments that intersect them, found by a
+// binary search over the sorted (begin, end) table.
 #define NORM_CHUNK 8192
+__device__ __forceinline__ int first_segment_after(const int64_t* __restrict__ seg_off, int n_seg, int64_t pos) {
+    int lo = 0, hi = n_seg;                               // first segment whose end is > pos
+    while (lo < hi) {
+        const int mid = (lo + hi) >> 1;
+        if (seg_off[2 * mid + 1] > pos) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+}
 __global__ __launch_bounds__(256) void param_sq_kernel(const float* __restrict__ flat,
                                                        const int64_t* __restrict__ seg_off, float* __restrict__ norms,
                                                        int n_seg) {
     __shared__ float red[4];
-    // blockIdx.y = segment, blockIdx.x = chunk (grid.x sized for the largest segment)
-    const int sgm = blockIdx.y;
-    const int64_t b0 = seg_off[2 * sgm], b1 = seg_off[2 * sgm + 1];
-    float acc = 0.f;
-    for (int64_t c0 = b0 + (int64_t)blockIdx.x * NORM_CHUNK; c0 < b1; c0 += (int64_t)gridDim.x * NORM_CHUNK) {
-        const int64_t c1 = min(b1, c0 + NORM_CHUNK);
-        const int64_t n4 = (c1 - c0) >> 2;                       // segments start 64-byte aligned
-        const float4* f4 = reinterpret_cast<const float4*>(flat + c0);
-        for (int64_t q = threadIdx.x; q < n4; q += 256) {
-            const float4 v = f4[q];
-            acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    const int64_t w0 = (int64_t)blockIdx.x * NORM_CHUNK, w1 = w0 + NORM_CHUNK;
+    for (int sgm = first_segment_after(seg_off, n_seg, w0); sgm < n_seg && seg_off[2 * sgm] < w1; ++sgm) {
+        const int64_t c0 = max(seg_off[2 * sgm], w0), c1 = min(seg_off[2 * sgm + 1], w1);
+        float acc = 0.f;
+        const int64_t a0 = (c0 + 3) & ~(int64_t)3, a1 = c1 & ~(int64_t)3;     // 16-byte aligned interior
+        if (a0 < a1) {
+            const float4* f4 = reinterpret_cast<const float4*>(flat + a0);
+            const int64_t n4 = (a1 - a0) >> 2;
+            for (int64_t q = threadIdx.x; q < n4; q += 256) {
+                const float4 v = f4[q];
+                acc += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+            }
+            for (int64_t e = c0 + threadIdx.x; e < a0; e += 256) { const float v = flat[e]; acc += v * v; }
+            for (int64_t e = a1 + threadIdx.x; e < c1; e += 256) { const float v = flat[e]; acc += v * v; }
+        } else {
+            for (int64_t e = c0 + threadIdx.x; e < c1; e += 256) { const float v = flat[e]; acc += v * v; }
         }
-        for (int64_t e = c0 + 4 * n4 + threadIdx.x; e < c1; e += 256) { const float v = flat[e]; acc += v * v; }
-    }
-    acc = wsum(acc);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const float t = red[0] + red[1] + red[2] + red[3];
-        if (t != 0.f) atomicAdd(&norms[sgm], t);
+        acc = wsum(acc);
+        __syncthreads();
+        if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const float t = red[0] + red[1] + red[2] + red[3];
+            if (t != 0.f) atomicAdd(&norms[sgm], t);
+        }
     }
 }
 __global__ void param_sqrt_kernel(float* __restrict__ loss, float* __restrict__ norms, int n_seg) {
@@ -653,37 +669,45 @@ __global__ void param_sqrt_kernel(float* __restrict__ loss, float* __restrict__ 
     if (threadIdx.x == 0) loss[0] += red[0] + red[1] + red[2] + red[3];
 }
 int ghn3_param_norm_fwd(float* loss, const float* flat, const int64_t* seg_off, float* norms, int n_seg,
-                        hipStream_t s) {
+                        int64_t flat_numel, hipStream_t s) {
     if (n_seg <= 0) return GHN3_OK;
     hipMemsetAsync(norms, 0, sizeof(float) * n_seg, s);
-    hipLaunchKernelGGL(param_sq_kernel, dim3(64, n_seg), dim3(256), 0, s, flat, seg_off, norms, n_seg);
+    const int64_t blocks = (flat_numel + NORM_CHUNK - 1) / NORM_CHUNK;
+    hipLaunchKernelGGL(param_sq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, flat, seg_off, norms, n_seg);
     hipLaunchKernelGGL(param_sqrt_kernel, dim3(1), dim3(256), 0, s, loss, norms, n_seg);
     return launch_ok("param_norm_fwd");
 }
 __global__ __launch_bounds__(256) void param_norm_bwd_kernel(float* __restrict__ dflat, const float* __restrict__ flat,
                                                              const int64_t* __restrict__ seg_off,
-                                                             const float* __restrict__ norms, float g) {
-    const int sgm = blockIdx.y;
-    const int64_t b0 = seg_off[2 * sgm], b1 = seg_off[2 * sgm + 1];
-    const float nrm = norms[sgm];
-    const float k = nrm > 0.f ? g / nrm : 0.f;
-    for (int64_t c0 = b0 + (int64_t)blockIdx.x * NORM_CHUNK; c0 < b1; c0 += (int64_t)gridDim.x * NORM_CHUNK) {
-        const int64_t c1 = min(b1, c0 + NORM_CHUNK);
-        const int64_t n4 = (c1 - c0) >> 2;
-        const float4* f4 = reinterpret_cast<const float4*>(flat + c0);
-        float4* d4 = reinterpret_cast<float4*>(dflat + c0);
-        for (int64_t q = threadIdx.x; q < n4; q += 256) {
-            float4 v = f4[q];
-            v.x *= k; v.y *= k; v.z *= k; v.w *= k;
-            d4[q] = v;
+                                                             const float* __restrict__ norms, int n_seg, float g) {
+    const int64_t w0 = (int64_t)blockIdx.x * NORM_CHUNK, w1 = w0 + NORM_CHUNK;
+    for (int sgm = first_segment_after(seg_off, n_seg, w0); sgm < n_seg && seg_off[2 * sgm] < w1; ++sgm) {
+        const int64_t c0 = max(seg_off[2 * sgm], w0), c1 = min(seg_off[2 * sgm + 1], w1);
+        const float nrm = norms[sgm];
+        const float k = nrm > 0.f ? g / nrm : 0.f;
+        const int64_t a0 = (c0 + 3) & ~(int64_t)3, a1 = c1 & ~(int64_t)3;
+        if (a0 < a1) {
+            const float4* f4 = reinterpret_cast<const float4*>(flat + a0);
+            float4* d4 = reinterpret_cast<float4*>(dflat + a0);
+            const int64_t n4 = (a1 - a0) >> 2;
+            for (int64_t q = threadIdx.x; q < n4; q += 256) {
+                float4 v = f4[q];
+                v.x *= k; v.y *= k; v.z *= k; v.w *= k;
+                d4[q] = v;
+            }
+            for (int64_t e = c0 + threadIdx.x; e < a0; e += 256) dflat[e] = flat[e] * k;
+            for (int64_t e = a1 + threadIdx.x; e < c1; e += 256) dflat[e] = flat[e] * k;
+        } else {
+            for (int64_t e = c0 + threadIdx.x; e < c1; e += 256) dflat[e] = flat[e] * k;
         }
-        for (int64_t e = c0 + 4 * n4 + threadIdx.x; e < c1; e += 256) dflat[e] = flat[e] * k;
     }
 }
 int ghn3_param_norm_bwd(float* dflat, const float* flat, const int64_t* seg_off, const float* norms, int n_seg,
-                        float g, hipStream_t s) {
+                        float g, int64_t flat_numel, hipStream_t s) {
     if (n_seg <= 0) return GHN3_OK;
-    hipLaunchKernelGGL(param_norm_bwd_kernel, dim3(64, n_seg), dim3(256), 0, s, dflat, flat, seg_off, norms, g);
+    const int64_t blocks = (flat_numel + NORM_CHUNK - 1) / NORM_CHUNK;
+    hipLaunchKernelGGL(param_norm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dflat, flat, seg_off, norms,
+                       n_seg, g);
     return launch_ok("param_norm_bwd");
 }
 
@@ -718,47 +742,101 @@ int ghn3_colsum(float* out, const float* X, int M, int N, int ld, int q, int sdi
 }
 
 // out[r][:] (+)= sum_{t in [seg_ptr[r], seg_ptr[r+1])} X[idx[t]][:]      (deterministic gather-sum)
+// One workgroup per output row; its four waves take every fourth source row (independent 16-byte loads in flight),
+// partial sums are combined in LDS in a fixed order.  VEC: C, ldx, ldo multiples of 4 and 16-byte aligned bases.
+template <bool VEC>
 __global__ __launch_bounds__(256) void rowseg_sum_kernel(float* __restrict__ out, const float* __restrict__ X,
                                                          const int* __restrict__ seg_ptr, const int* __restrict__ idx,
                                                          int rows, int C, int ldx, int ldo, int accum) {
+    extern __shared__ float part[];                    // [4][C]
     const int r = blockIdx.x;
     const int t0 = seg_ptr[r], t1 = seg_ptr[r + 1];
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (VEC) {
+        const int C4 = C >> 2;
+        for (int c4 = lane; c4 < C4; c4 += 64) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int t = t0 + w; t < t1; t += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(X + (size_t)idx[t] * ldx + 4 * c4);
+                acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+            }
+            *reinterpret_cast<float4*>(part + w * C + 4 * c4) = acc;
+        }
+    } else {
+        for (int c = lane; c < C; c += 64) {
+            float acc = 0.f;
+            for (int t = t0 + w; t < t1; t += 4) acc += X[(size_t)idx[t] * ldx + c];
+            part[w * C + c] = acc;
+        }
+    }
+    __syncthreads();
     for (int c = threadIdx.x; c < C; c += 256) {
         float acc = accum ? out[(size_t)r * ldo + c] : 0.f;
-        for (int t = t0; t < t1; ++t) acc += X[(size_t)idx[t] * ldx + c];
+        acc += (part[c] + part[C + c]) + (part[2 * C + c] + part[3 * C + c]);
         out[(size_t)r * ldo + c] = acc;
     }
 }
 int ghn3_rowseg_sum(float* out, const float* X, const int* seg_ptr, const int* idx, int rows, int C, int ldx, int ldo,
                     int accum, hipStream_t s) {
     if (rows <= 0) return GHN3_OK;
-    hipLaunchKernelGGL(rowseg_sum_kernel, dim3(rows), dim3(256), 0, s, out, X, seg_ptr, idx, rows, C, ldx, ldo, accum);
+    const size_t lds = 4 * sizeof(float) * (size_t)C;
+    if (lds > 64 * 1024) { ghn3_set_error("rowseg_sum: C=%d too wide", C); return GHN3_E_LIMIT; }
+    const bool vec = (C % 4 == 0) && (ldx % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    if (vec)
+        hipLaunchKernelGGL(rowseg_sum_kernel<true>, dim3(rows), dim3(256), lds, s, out, X, seg_ptr, idx, rows, C, ldx,
+                           ldo, accum);
+    else
+        hipLaunchKernelGGL(rowseg_sum_kernel<false>, dim3(rows), dim3(256), lds, s, out, X, seg_ptr, idx, rows, C, ldx,
+                           ldo, accum);
     return launch_ok("rowseg_sum");
 }
 
-// X[m][n] *= dact(aux[m][n]) in place (deferred epilogue of a split-K dgrad)
+// X[m][n] *= dact(aux[m][n]) in place (deferred epilogue of a split-K dgrad); optional running max |x| of the result
+__device__ __forceinline__ float dact_apply(float v, float z, int dact) {
+    if (dact == GHN3_DACT_RELU) return z > 0.f ? v : 0.f;
+    if (dact == GHN3_DACT_GELU)
+        return v * (0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z));
+    return v;
+}
+// VEC: N == ld (dense rows), N % 4 == 0, 16-byte aligned bases -> one float4 per thread and step
+template <bool VEC>
 __global__ __launch_bounds__(256) void dact_kernel(float* __restrict__ X, const float* __restrict__ aux, int M, int N,
                                                    int ld, int dact, float* __restrict__ amax) {
-    const int64_t total = (int64_t)M * N;
     float mx = 0.f;
-    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-        const int64_t m = e / N;
-        const int64_t o = m * ld + (e - m * N);
-        const float z = aux[o];
-        float v = X[o];
-        if (dact == GHN3_DACT_RELU) v = z > 0.f ? v : 0.f;
-        else if (dact == GHN3_DACT_GELU)
-            v *= 0.5f * (1.0f + erff(z * 0.70710678118654752f)) + z * 0.3989422804014327f * __expf(-0.5f * z * z);
-        X[o] = v;
-        mx = fmaxf(mx, fabsf(v));
+    if (VEC) {
+        const int64_t total4 = ((int64_t)M * N) >> 2;
+        float4* X4 = reinterpret_cast<float4*>(X);
+        const float4* A4 = reinterpret_cast<const float4*>(aux);
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
+            const float4 z = A4[e];
+            float4 v = X4[e];
+            v.x = dact_apply(v.x, z.x, dact); v.y = dact_apply(v.y, z.y, dact);
+            v.z = dact_apply(v.z, z.z, dact); v.w = dact_apply(v.w, z.w, dact);
+            X4[e] = v;
+            mx = fmaxf(fmaxf(mx, fmaxf(fabsf(v.x), fabsf(v.y))), fmaxf(fabsf(v.z), fabsf(v.w)));
+        }
+    } else {
+        const int64_t total = (int64_t)M * N;
+        for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+            const int64_t m = e / N;
+            const int64_t o = m * ld + (e - m * N);
+            const float v = dact_apply(X[o], aux[o], dact);
+            X[o] = v;
+            mx = fmaxf(mx, fabsf(v));
+        }
     }
     if (amax) ghn3_atomic_amax(amax, mx);
 }
 int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, float* amax, hipStream_t s) {
     if (M <= 0 || N <= 0) return GHN3_OK;
-    int64_t blocks = ((int64_t)M * N + 255) / 256;
+    const bool vec = N == ld && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(aux) & 15) == 0);
+    int64_t blocks = ((int64_t)M * N / (vec ? 4 : 1) + 255) / 256;
     if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(dact_kernel, dim3((unsigned)blocks), dim3(256), 0, s, X, aux, M, N, ld, dact, amax);
+    if (vec)
+        hipLaunchKernelGGL(dact_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, X, aux, M, N, ld, dact, amax);
+    else
+        hipLaunchKernelGGL(dact_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, X, aux, M, N, ld, dact, amax);
     return launch_ok("dact");
 }
 

@@ -874,10 +874,10 @@ class Program:
         self._ops = []
         self.op(L.OP_MEMSET0, refs=((scal, 0),), ints=(4,))
         self.op(L.OP_PARAM_NORM_FWD, refs=((scal, 0), (self.xbuf(self.X_OUT), 0), self.r_seg, (scal, 256)),
-                ints=(self.n_seg,))
+                ints=(self.n_seg, self.out_numel))
         f_ops = self._finish_ops()
         self.op(L.OP_PARAM_NORM_BWD, refs=((self.xbuf(self.X_DOUT), 0), (self.xbuf(self.X_OUT), 0), self.r_seg,
-                                           (scal, 256)), ints=(self.n_seg,), floats=(upstream,))
+                                           (scal, 256)), ints=(self.n_seg, self.out_numel), floats=(upstream,))
         b_ops = self._finish_ops()
         self._ops = saved
         return f_ops, b_ops

@@ -511,6 +511,7 @@ class Interp:
         n = int(o['i'][0])
         flat = self.tail(o['r'][1], np.float32)
         seg = self.view(o['r'][2], np.int64, 2 * n).reshape(n, 2)
+        assert int(o['i'][1]) >= seg[-1, 1] and np.all(seg[1:, 0] >= seg[:-1, 1]), 'sorted disjoint segments + extent'
         norms = self.fview(o['r'][3], n)
         for s in range(n):
             norms[s] = np.sqrt((flat[seg[s, 0]:seg[s, 1]].astype(np.float64) ** 2).sum())
@@ -521,6 +522,7 @@ class Interp:
         flat = self.tail(o['r'][1], np.float32)
         dflat = self.tail(o['r'][0], np.float32)
         seg = self.view(o['r'][2], np.int64, 2 * n).reshape(n, 2)
+        assert int(o['i'][1]) >= seg[-1, 1] and np.all(seg[1:, 0] >= seg[:-1, 1]), 'sorted disjoint segments + extent'
         norms = self.fview(o['r'][3], n)
         for s in range(n):
             k = float(o['f'][0]) / norms[s] if norms[s] > 0 else 0.0

@@ -87,6 +87,7 @@ class _Plan:
         self.sizes = [p['numel'] for p in program.predicted]
         self.tok = None
         self.out = None
+        self.flat_out = None
 
 
 class _GHN3Function(torch.autograd.Function):
@@ -100,6 +101,31 @@ class _GHN3Function(torch.autograd.Function):
     def backward(ctx, dout):
         grads = ctx.ghn._run_backward(ctx.plan, dout.contiguous())
         return (None, None) + tuple(grads)
+
+
+class _ParamNormLoss(torch.autograd.Function):
+    """sum_t ||p_t||_F over the predicted tensors of a plan (the reference's predparam_wd term, trainer.py:97-98,
+    288-294) straight on the flat output buffer: GHN3_OP_PARAM_NORM_FWD / BWD instead of ~1000 ATen launches."""
+
+    @staticmethod
+    def forward(ctx, flat, ghn, plan):
+        prog = plan.program
+        f_ops, b_ops = prog.norm_ops(1.0)
+        ghn._fill_bufs(plan, out=flat)
+        ghn._ctx().run(f_ops, prog.problems, plan.bufs, torch.cuda.current_stream().cuda_stream)
+        ctx.ghn, ctx.plan, ctx.b_ops = ghn, plan, b_ops
+        ctx.save_for_backward(flat)
+        return plan.scal[:4].view(torch.float32)[0].clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        (flat,) = ctx.saved_tensors
+        ghn, plan = ctx.ghn, ctx.plan
+        dflat = torch.empty_like(flat)
+        ghn._fill_bufs(plan, out=flat, dout=dflat)
+        ghn._ctx().run(ctx.b_ops, plan.program.problems, plan.bufs, torch.cuda.current_stream().cuda_stream)
+        dflat.mul_(g)                          # (the upstream gradient lives on the device: no host read)
+        return dflat, None, None
 
 
 class GHN3(nn.Module):
@@ -347,6 +373,7 @@ class GHN3(nn.Module):
         else:
             with torch.no_grad():
                 flat = self._run_forward(plan)
+        plan.flat_out = flat                      # (autograd-connected in training: predicted_param_norm)
         self.assign(plan, flat, keep_grads=keep)
         if bn_track_running_stats is None:
             bn_track_running_stats = self.training
@@ -362,11 +389,32 @@ class GHN3(nn.Module):
         out = nets_torch if is_lst else nets_torch[0]
         return (out, self.embeddings(plan)) if return_embeddings else out
 
+    def predicted_param_norm(self, plan=None):
+        """Differentiable sum of the Frobenius norms of all tensors predicted by the last forward (or `plan`): the
+        regulariser the reference's trainer adds with weight predparam_wd (trainer.py:97-98,288-294), computed by two
+        streaming kernels on the flat output buffer.  (Positional-encoding tensors include their random class-token
+        row, as in the reference.)"""
+        plan = self.last_plan if plan is None else plan
+        flat = plan.flat_out
+        if flat is None:
+            raise L.Ghn3Error('predicted_param_norm: run the GHN forward first')
+        return _ParamNormLoss.apply(flat, self, plan)
+
     def assign(self, plan, flat, keep_grads):
         """nn.py:508-552 _set_params for every predicted tensor (views of the flat output buffer)."""
         preds = plan.program.predicted
-        for p in preds:
-            t = flat[p['offset']:p['offset'] + p['numel']].view(p['shape'])
+        pieces = None
+        if flat.requires_grad:
+            # ONE autograd node for all views: slicing tensor by tensor would make the backward of every slice
+            # allocate and add a full-size zero buffer (250 x 346 MB at ghn3xlm16 -- 70 ms per step)
+            sizes, pos = [], 0
+            for p in preds:
+                sizes += [p['offset'] - pos, p['numel']]
+                pos = p['offset'] + p['numel']
+            sizes.append(flat.numel() - pos)
+            pieces = flat.split_with_sizes(sizes)
+        for k, p in enumerate(preds):
+            t = (pieces[2 * k + 1] if pieces is not None else flat[p['offset']:p['offset'] + p['numel']]).view(p['shape'])
             m, key = p['module'], p['attr']
             target = getattr(m, key, None)
             if keep_grads or not isinstance(target, nn.Parameter):

@@ -228,6 +228,29 @@ def test_ghn_model_without_a_graph(name):
     assert y.shape == (2, 10) and torch.isfinite(y).all()
 
 
+def test_fused_predicted_param_norm_loss():
+    """GHN3.predicted_param_norm (PARAM_NORM_FWD / BWD on the flat output, trainer.py:288-294) against the per-tensor
+    torch.norm form: same value, same GHN gradients; scaled upstream gradient (predparam_wd) included."""
+    hip, _ = make_models(T_CFG, 7)
+    hip.train()
+    grads = []
+    for fused in (False, True):
+        nets_h, gb_h, _, _ = synthetic_case([40], 4000)
+        hip.zero_grad(set_to_none=True)
+        nets_h = hip(nets_h, gb_h, keep_grads=True)
+        if fused:
+            loss = 3e-2 * hip.predicted_param_norm()
+        else:
+            loss = 3e-2 * sum(torch.norm(p, p='fro') for net in nets_h for p in net.parameters())
+        loss.backward()
+        torch.cuda.synchronize()
+        grads.append((loss.item(), {k: p.grad.detach().clone() for k, p in hip.named_parameters()}))
+    assert abs(grads[0][0] - grads[1][0]) < 1e-5 * abs(grads[0][0])
+    for k in grads[0][1]:
+        a, b = grads[1][1][k], grads[0][1][k]
+        assert float((a - b).norm()) < 1e-5 * float(b.norm()) + 1e-7, k
+
+
 def test_graph_with_more_than_1024_nodes():
     """N = 1100 (EfficientNet-B7-sized graphs exceed 1024 nodes): streamed two-pass attention forward, generic
     backward; head dim 24 like ghn3xlm16.  Forward and gradients vs the oracle."""

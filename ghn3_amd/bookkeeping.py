@@ -188,6 +188,6 @@ def norm_rule(shape, is_w):
             return 0, 1.0
         no_relu = len(shape) > 2 and (shape[1] == 1 or (len(shape) > 3 and shape[2] < shape[3]))
         beta = 1.0 if no_relu else 2.0
-        fan_in = int(np.prod(shape[1:]))
+        fan_in = int(math.prod(shape[1:]))
         return 0, float((beta / fan_in) ** 0.5)
     return (1, 1.0) if is_w else (2, 1.0)

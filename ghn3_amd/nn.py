@@ -87,7 +87,6 @@ class _Plan:
         self.sizes = [p['numel'] for p in program.predicted]
         self.tok = None
         self.out = None
-        self.flat_out = None
 
 
 class _GHN3Function(torch.autograd.Function):
@@ -100,6 +99,10 @@ class _GHN3Function(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         grads = ctx.ghn._run_backward(ctx.plan, dout.contiguous())
+        # The plan references the target modules (to assign into), the modules hold the predicted tensors and those
+        # reference this node: dropping the plan here breaks the cycle, so a step's buffers (4 GB of workspace + 2.6 GB
+        # of gradients at ghn3xlm16) are freed by reference counting instead of waiting for Python's cycle collector.
+        ctx.plan = ctx.ghn = None
         return (None, None) + tuple(grads)
 
 
@@ -125,6 +128,7 @@ class _ParamNormLoss(torch.autograd.Function):
         ghn._fill_bufs(plan, out=flat, dout=dflat)
         ghn._ctx().run(ctx.b_ops, plan.program.problems, plan.bufs, torch.cuda.current_stream().cuda_stream)
         dflat.mul_(g)                          # (the upstream gradient lives on the device: no host read)
+        ctx.ghn = ctx.plan = ctx.b_ops = None
         return dflat, None, None
 
 
@@ -195,6 +199,7 @@ class GHN3(nn.Module):
             if isinstance(m, nn.Embedding):
                 nn.init.trunc_normal_(m.weight.data, std=m.weight.shape[1] ** (-0.5))
         self._names = param_names(layers, self.layernorm)
+        self.last_plan = self._last_flat = None
         self._flat = None
         self._flatten()
 
@@ -299,7 +304,7 @@ class GHN3(nn.Module):
         plan.tok = torch.normal(0.0, 0.02, (prog.tok_floats,), device=dev)
         self._fill_bufs(plan, out=out)
         self._ctx().run(prog.fwd_ops, prog.problems, plan.bufs, torch.cuda.current_stream().cuda_stream)
-        plan.out = out
+        plan.out = out.detach()                   # (an alias without autograd history: see _GHN3Function.backward)
         return out
 
     def decoder_grad_range(self, prog):
@@ -373,8 +378,8 @@ class GHN3(nn.Module):
         else:
             with torch.no_grad():
                 flat = self._run_forward(plan)
-        plan.flat_out = flat                      # (autograd-connected in training: predicted_param_norm)
-        self.assign(plan, flat, keep_grads=keep)
+        self._last_flat = flat                    # (autograd-connected in training: predicted_param_norm; kept on
+        self.assign(plan, flat, keep_grads=keep)  #  the model, not on the plan: the plan must not own autograd tensors)
         if bn_track_running_stats is None:
             bn_track_running_stats = self.training
         if not bn_track_running_stats:
@@ -395,9 +400,9 @@ class GHN3(nn.Module):
         streaming kernels on the flat output buffer.  (Positional-encoding tensors include their random class-token
         row, as in the reference.)"""
         plan = self.last_plan if plan is None else plan
-        flat = plan.flat_out
+        flat = self._last_flat if plan is self.last_plan else None
         if flat is None:
-            raise L.Ghn3Error('predicted_param_norm: run the GHN forward first')
+            raise L.Ghn3Error('predicted_param_norm: run the GHN forward first (only the last forward is kept)')
         return _ParamNormLoss.apply(flat, self, plan)
 
     def assign(self, plan, flat, keep_grads):

@@ -133,7 +133,7 @@ class Program:
             self.decoder_slots = (self.slot['decoder.fc.0.weight'], self.slot['bias_class.1.bias'] + 1)
         else:
             self.bwd_ops = np.zeros(0, dtype=L.OP_DT)
-        self.problems = np.array(self._probs, dtype=L.PROBLEM_DT) if self._probs else np.zeros(0, dtype=L.PROBLEM_DT)
+        self.problems = self._pack_problems()
         self.ws_bytes = round_up(self._ws + 1024, ALIGN)
         self.idx_blob = np.zeros(max(self._idx_size, 16), dtype=np.uint8)
         for off, raw in self._idx_chunks:
@@ -224,21 +224,31 @@ class Program:
     NONE = (-1, 0)
 
     def op(self, kind, refs=(), ints=(), floats=(), flags=0):
-        o = np.zeros((), dtype=L.OP_DT)
-        o['kind'] = kind
-        o['flags'] = flags
-        for k, v in enumerate(ints):
-            o['i'][k] = int(v)
-        for k, v in enumerate(floats):
-            o['f'][k] = float(v)
-        r = o['r']
-        r['buf'][:] = -1
-        for k, ref in enumerate(refs):
-            r['buf'][k], r['off'][k] = ref
-        self._ops.append(o)
+        self._ops.append((kind, flags, tuple(ints), tuple(floats), tuple(refs)))
 
     def _finish_ops(self):
-        out = np.array(self._ops, dtype=L.OP_DT) if self._ops else np.zeros(0, dtype=L.OP_DT)
+        n = len(self._ops)
+        out = np.zeros(n, dtype=L.OP_DT)
+        if n:
+            out['r']['buf'][:] = -1
+            out['kind'] = [o[0] for o in self._ops]
+            out['flags'] = [o[1] for o in self._ops]
+            # ragged per-op fields scattered with one fancy assignment each
+            ir, ic, iv, fr, fc, fv, rr, rc, rb, ro = ([] for _ in range(10))
+            for k, (_, _, ints, floats, refs) in enumerate(self._ops):
+                for j, v in enumerate(ints):
+                    ir.append(k); ic.append(j); iv.append(int(v))
+                for j, v in enumerate(floats):
+                    fr.append(k); fc.append(j); fv.append(v)
+                for j, (b_, o_) in enumerate(refs):
+                    rr.append(k); rc.append(j); rb.append(b_); ro.append(o_)
+            if ir:
+                out['i'][ir, ic] = iv
+            if fr:
+                out['f'][fr, fc] = fv
+            if rr:
+                out['r']['buf'][rr, rc] = rb
+                out['r']['off'][rr, rc] = ro
         self._ops = []
         return out
 
@@ -250,24 +260,39 @@ class Program:
         if dbias is not None:
             assert bias is None and a_mode == L.MODE_COL
             bias, bias_stride = dbias, dbias_stride
-        p = np.zeros((), dtype=L.PROBLEM_DT)
-        for name, ref in (('A', A), ('B', B), ('C', C), ('bias', bias), ('residual', residual), ('aux_in', aux_in),
-                          ('aux_out', aux_out), ('a_gather', a_gather), ('b_gather', b_gather),
-                          ('c_gather', c_gather), ('lim', lim), ('alpha_amax', alpha_amax)):
-            ref = self.NONE if ref is None else ref
-            p[name]['buf'], p[name]['off'] = ref
-        for name, v in (('M', M), ('N', N), ('K', K), ('lda', lda), ('ldb', ldb), ('ldc', ldc), ('a_mode', a_mode),
-                        ('b_mode', b_mode), ('a_q', a_qs[0]), ('a_s', a_qs[1]), ('b_q', b_qs[0]), ('b_s', b_qs[1]),
-                        ('c_q', c_qs[0]), ('c_s', c_qs[1]), ('bias_q', bias_q), ('bias_s', bias_s),
-                        ('bias_stride', bias_stride), ('act', act), ('dact', dact),
-                        ('flags', (L.GEMM_ACCUM if accum else 0) | (L.GEMM_BIASGRAD if dbias is not None else 0) |
-                         (L.GEMM_OP16 if op16 else 0)), ('b_kq', b_kmap[0]), ('b_ks', b_kmap[1])):
-            p[name] = int(v)
-        p['alpha'] = alpha
-        p['ksplit'] = ksplit
-        p['lim_kind'] = lim_kind if lim is not None else 0
-        self._probs.append(p)
+        N_ = self.NONE
+        flags = (L.GEMM_ACCUM if accum else 0) | (L.GEMM_BIASGRAD if dbias is not None else 0) | \
+            (L.GEMM_OP16 if op16 else 0)
+        # one plain tuple per problem (field order of _PROBLEM_REFS + _PROBLEM_INTS + the tail); the structured array
+        # is packed column by column in _pack_problems -- filling a numpy record per call cost 15 us per problem
+        self._probs.append((
+            A or N_, B or N_, C or N_, bias or N_, residual or N_, aux_in or N_, aux_out or N_, a_gather or N_,
+            b_gather or N_, c_gather or N_, lim or N_, alpha_amax or N_,
+            M, N, K, lda, ldb, ldc, a_mode, b_mode, a_qs[0], a_qs[1], b_qs[0], b_qs[1], c_qs[0], c_qs[1], bias_q, bias_s,
+            bias_stride, act, dact, flags, b_kmap[0], b_kmap[1],
+            alpha, ksplit, (lim_kind if lim is not None else 0)))
         return len(self._probs) - 1
+
+    _PROBLEM_REFS = ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim',
+                     'alpha_amax')
+    _PROBLEM_INTS = ('M', 'N', 'K', 'lda', 'ldb', 'ldc', 'a_mode', 'b_mode', 'a_q', 'a_s', 'b_q', 'b_s', 'c_q', 'c_s',
+                     'bias_q', 'bias_s', 'bias_stride', 'act', 'dact', 'flags', 'b_kq', 'b_ks')
+
+    def _pack_problems(self):
+        n = len(self._probs)
+        arr = np.zeros(n, dtype=L.PROBLEM_DT)
+        if n == 0:
+            return arr
+        cols = list(zip(*self._probs))
+        nr = len(self._PROBLEM_REFS)
+        for k, name in enumerate(self._PROBLEM_REFS):
+            ref = np.asarray(cols[k], dtype=np.int64).reshape(n, 2)
+            arr[name]['buf'], arr[name]['off'] = ref[:, 0], ref[:, 1]
+        for k, name in enumerate(self._PROBLEM_INTS):
+            arr[name] = np.asarray(cols[nr + k], dtype=np.int64)
+        k = nr + len(self._PROBLEM_INTS)
+        arr['alpha'], arr['ksplit'], arr['lim_kind'] = cols[k], cols[k + 1], cols[k + 2]
+        return arr
 
     # timing tags (ghn3_profile_enable mode 2): the decoder kernels that dominate the step
     TAG_D3_FWD, TAG_D3_DGRAD, TAG_D3_WGRAD, TAG_D2_FWD, TAG_D1_FWD, TAG_TILE_FWD, TAG_TILE_BWD, TAG_D2_BWD, \
@@ -287,7 +312,7 @@ class Program:
             if tag:
                 flags |= L.OPFLAG_TIMED | (tag << 16)
                 fl = flops if flops is not None else \
-                    sum(2.0 * int(p['M']) * int(p['N']) * int(p['K']) for p in self._probs[first:first + count])
+                    sum(2.0 * int(p[12]) * int(p[13]) * int(p[14]) for p in self._probs[first:first + count])
                 self.tag_flops[tag] = self.tag_flops.get(tag, 0.0) + fl
             self.op(L.OP_GEMM, ints=(first, count, tile, grid_cap), flags=flags)
 
@@ -714,12 +739,9 @@ class Program:
                 clsb_row[ind] = r - self.n1_plain
 
         def add(dst_off, src_buf, src_off, T, E, Sd, R, mode, scale):
-            d = np.zeros((), dtype=L.TILE_DT)
-            d['dst_off'], d['src_off'], d['src_buf'], d['mode'], d['scale'] = dst_off, src_off, src_buf, mode, scale
-            d['T'], d['E'], d['S'], d['R'] = T, E, Sd, R
             for k in range(4):
-                assert 1 <= d['E'][k] <= d['T'][k] and d['E'][k] <= d['R'][k], (T, E, R)
-            descs.append(d)
+                assert 1 <= E[k] <= T[k] and E[k] <= R[k], (T, E, R)
+            descs.append((dst_off, src_off, tuple(Sd), tuple(T), tuple(E), tuple(R), src_buf, mode, scale))
 
         for key, inds in self.param_groups.items():
             if len(inds) == 0:
@@ -742,7 +764,7 @@ class Program:
                     # nn.py:526-528: a 2-D tile assigned to a 4-D (O,I,1,1) parameter is unsqueezed
                     t_assign = bk._sz(tgt) if tgt is not None else tile_t
                     mode, scale = bk.norm_rule(tile_t, w_flag) if self.weight_norm else (0, 1.0)
-                    numel = int(np.prod(tile_t))
+                    numel = int(math.prod(tile_t))
                     dst = out_off
                     out_off = round_up(out_off + numel, 16)
                     predicted.append(dict(node=ind, module=m, attr=attr, shape=tuple(t_assign),
@@ -809,35 +831,50 @@ class Program:
         self.predicted = predicted
         self.out_numel = max(out_off, 16)
         self.tok_floats = max(tok_off, 4)
-        self.n_desc = len(descs)
+        self.n_desc = nd = len(descs)
         CH = 2048
-        fwd_blocks, bwd_blocks = [], []
         self.tile_lds = [0, 0]
-        for k, d in enumerate(descs):
-            T, E, R, S = (d[n].astype(np.int64) for n in ('T', 'E', 'R', 'S'))
-            hw = int(T[2] * T[3])
-            row_ok = (int(d['mode']) == 0 and hw > 1 and S[1] == 1 and E[2] == T[2] == R[2] and E[3] == T[3] == R[3]
-                      and hw <= 1024)
-            if row_ok:
-                # convolution kernels with kh * kw > 1: LDS-transposed row blocks (see tile_fwd_kernel), one per o and
-                # chunk of `ich` input channels (<= 16 KB of LDS, so that many blocks share a CU)
-                ich = int(max(16, min(int(max(T[1], R[1])), 4096 // hw)))
-                descs[k]['_pad'] = ich
-                for blocks, n0, n1 in ((fwd_blocks, int(T[0]), int(T[1])), (bwd_blocks, int(R[0]), int(R[1]))):
-                    word = (np.arange(n0, dtype=np.int64)[:, None] |
-                            (np.arange(0, n1, ich, dtype=np.int64)[None, :] << 24)).reshape(-1)
-                    blocks.append(np.stack([np.full(len(word), ~k, dtype=np.int64), word], axis=1))
-                self.tile_lds[0] = max(self.tile_lds[0], 4 * ich * hw)
-                self.tile_lds[1] = max(self.tile_lds[1], 4 * ich * hw)
-                continue
-            n_f = int(np.prod(T))
-            n_b = int(np.prod(R))
-            for blocks, n in ((fwd_blocks, n_f), (bwd_blocks, n_b)):
-                st = np.arange(0, n, CH, dtype=np.int64)
-                blocks.append(np.stack([np.full(len(st), k, dtype=np.int64), st], axis=1))
-        desc_arr = np.array(descs, dtype=L.TILE_DT) if descs else np.zeros(1, dtype=L.TILE_DT)
-        fb = np.concatenate(fwd_blocks) if fwd_blocks else np.zeros((0, 2), dtype=np.int64)
-        bb = np.concatenate(bwd_blocks) if bwd_blocks else np.zeros((0, 2), dtype=np.int64)
+        # descriptor table and work-block tables, built column-wise (one numpy call per field, not per descriptor)
+        desc_arr = np.zeros(max(nd, 1), dtype=L.TILE_DT)
+        fb = bb = np.zeros((0, 2), dtype=np.int64)
+        if nd:
+            cols = list(zip(*descs))
+            desc_arr['dst_off'], desc_arr['src_off'] = cols[0], cols[1]
+            S = np.asarray(cols[2], dtype=np.int64).reshape(nd, 4)
+            T = np.asarray(cols[3], dtype=np.int64).reshape(nd, 4)
+            E = np.asarray(cols[4], dtype=np.int64).reshape(nd, 4)
+            R = np.asarray(cols[5], dtype=np.int64).reshape(nd, 4)
+            desc_arr['S'], desc_arr['T'], desc_arr['E'], desc_arr['R'] = S, T, E, R
+            desc_arr['src_buf'], desc_arr['mode'], desc_arr['scale'] = cols[6], cols[7], cols[8]
+            mode = np.asarray(cols[7], dtype=np.int64)
+            hw = T[:, 2] * T[:, 3]
+            # convolution kernels with kh * kw > 1: LDS-transposed row blocks (see tile_fwd_kernel), one per o and
+            # chunk of `ich` input channels (<= 16 KB of LDS, so that many blocks share a CU)
+            row_ok = (mode == 0) & (hw > 1) & (S[:, 1] == 1) & (E[:, 2] == T[:, 2]) & (T[:, 2] == R[:, 2]) & \
+                (E[:, 3] == T[:, 3]) & (T[:, 3] == R[:, 3]) & (hw <= 1024)
+            ich = np.maximum(16, np.minimum(np.maximum(T[:, 1], R[:, 1]), 4096 // np.maximum(hw, 1)))
+            desc_arr['_pad'] = np.where(row_ok, ich, 0)
+            if row_ok.any():
+                lds = int((4 * ich * hw)[row_ok].max())
+                self.tile_lds = [lds, lds]
+            ids = np.arange(nd, dtype=np.int64)
+
+            def tables(n0, n1, numel):
+                """(descriptor id or ~id, start / packed (o, first i)) rows: element blocks of CH elements, row blocks
+                of one o and `ich` input channels; descriptors in order, blocks of a descriptor in order."""
+                n_i = (n1 + ich - 1) // ich                                   # i chunks per o (row blocks)
+                cnt = np.where(row_ok, n0 * n_i, (numel + CH - 1) // CH)
+                total = int(cnt.sum())
+                first = np.cumsum(cnt) - cnt
+                d_of = np.repeat(ids, cnt)
+                j = np.arange(total, dtype=np.int64) - np.repeat(first, cnt)     # block index inside its descriptor
+                rb = row_ok[d_of]
+                ni_b = np.maximum(n_i[d_of], 1)
+                word = np.where(rb, (j // ni_b) | (((j % ni_b) * ich[d_of]) << 24), j * CH)
+                return np.stack([np.where(rb, ~d_of, d_of), word], axis=1)
+
+            fb = tables(T[:, 0], T[:, 1], T.prod(axis=1))
+            bb = tables(R[:, 0], R[:, 1], R.prod(axis=1))
         raw = np.concatenate([desc_arr.view(np.uint8).reshape(-1), fb.view(np.uint8).reshape(-1),
                               bb.view(np.uint8).reshape(-1)])
         self.r_desc = self.idx(raw)

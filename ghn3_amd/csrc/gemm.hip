@@ -884,11 +884,15 @@ struct H16dVariant { h16d_fn fn[2]; int threads, lds, edge; };
 #define H16D(BMN, WGM, WGN, NS)                                                                          \
     {{gemm_h16d_kernel<GHN3_CT_F16, BMN, BMN, WGM, WGN, NS>, gemm_h16d_kernel<GHN3_CT_BF16, BMN, BMN, WGM, WGN, NS>}, \
      64 * WGM * WGN, NS * 2 * BMN * 64 * 2, BMN}
+#define H16D_RECT(BM, BN, WGM, WGN, NS)                                                                  \
+    {{gemm_h16d_kernel<GHN3_CT_F16, BM, BN, WGM, WGN, NS>, gemm_h16d_kernel<GHN3_CT_BF16, BM, BN, WGM, WGN, NS>}, \
+     64 * WGM * WGN, NS * (BM + BN) * 64 * 2, BM}
 // (deeper rings -- NS = 3 / 4 with one 128 x 128 workgroup per CU -- measured 25-35 % slower than two workgroups
 // per CU with two stages: occupancy beats prefetch depth here)
 static H16dVariant g_h16d[] = {
     H16D(128, 2, 2, 2),      // 0: 64 KB, 2 workgroups / CU
     H16D(256, 2, 4, 2),      // 1: 128 KB, 1 workgroup / CU
+    H16D_RECT(256, 128, 4, 2, 3),   // 2 (tile code 20): 256 x 128, three stages (two k-tiles in flight), 144 KB
 };
 static int g_h16d_small = 0, g_h16d_big = 1;
 
@@ -957,12 +961,12 @@ int ghn3_gemm_init() {
 int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int tile, int ctype, int grid_cap,
                           hipStream_t stream) {
     if (n_probs <= 0 || total_tiles <= 0) return GHN3_OK;
-    if ((ctype != GHN3_CT_F16 && ctype != GHN3_CT_BF16) || (tile != 128 && tile != 256)) {
+    if ((ctype != GHN3_CT_F16 && ctype != GHN3_CT_BF16) || (tile != 128 && tile != 256 && tile != 20)) {
         ghn3_set_error("16-bit-operand GEMM needs compute type f16 or bf16 (got %d) and tile 128 / 256 (got %d)", ctype,
                        tile);
         return GHN3_E_ARG;
     }
-    const H16dVariant& v = g_h16d[tile == 256 ? g_h16d_big : g_h16d_small];
+    const H16dVariant& v = g_h16d[tile == 20 ? 2 : tile == 256 ? g_h16d_big : g_h16d_small];
     const int grid = grid_cap > 0 && grid_cap < total_tiles ? grid_cap : total_tiles;
     hipLaunchKernelGGL(v.fn[ctype == GHN3_CT_BF16], dim3(grid), dim3(v.threads), v.lds, stream, d_probs, n_probs,
                        total_tiles);

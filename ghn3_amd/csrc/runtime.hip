@@ -188,7 +188,7 @@ static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
     if (p.flags & GHN3_GEMM_OP16) {
         // tile codes 16 / 24 = the 16-bit-operand kernel with 128 x 128 / 256 x 256 tiles.  The big tile has twice
         // the arithmetic intensity but runs one 512-thread block per CU: it needs enough tiles to fill the chip.
-        if (forced == 16 || forced == 24) return forced;
+        if (forced == 16 || forced == 24 || forced == 20) return forced;
         const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) * (p.ksplit > 1 ? p.ksplit : 1);
         const double eff = ((double)p.M / (((p.M + 255) / 256) * 256.0)) * ((double)p.N / (((p.N + 255) / 256) * 256.0));
         return (t256 >= 200 && eff >= 0.8) ? 24 : 16;
@@ -239,14 +239,15 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             // bucket by (a_mode, b_mode, tile)
             for (int am = 0; am < 2; ++am)
                 for (int bm = 0; bm < 2; ++bm)
-                    for (int tl : {16, 24, 32, 64, 128}) {
+                    for (int tl : {16, 20, 24, 32, 64, 128}) {
                         Launch L{am, bm, tl, (int)pos, 0, 0};
-                        const int te = tl == 16 ? 128 : tl == 24 ? 256 : tl;        // tile edge
+                        const int te = tl == 16 ? 128 : (tl == 24 || tl == 20) ? 256 : tl;   // tile edge (rows)
+                        const int te_n = tl == 20 ? 128 : te;                                  // (columns)
                         for (int q = first; q < first + cnt; ++q) {
                             const ghn3_gemm_problem& p = problems[q];
                             if (p.M <= 0 || p.N <= 0) continue;
                             if (p.a_mode != am || p.b_mode != bm || pick_tile(p, forced, op_t64) != tl) continue;
-                            if ((tl == 16 || tl == 24) && (p.a_mode != GHN3_MODE_ROW || p.b_mode != GHN3_MODE_ROW || (p.lda & 7) ||
+                            if ((tl == 16 || tl == 24 || tl == 20) && (p.a_mode != GHN3_MODE_ROW || p.b_mode != GHN3_MODE_ROW || (p.lda & 7) ||
                                              (p.ldb & 7) || (p.b_kq & 7) || (p.flags & GHN3_GEMM_BIASGRAD) ||
                                              p.K >= (1 << 24) || (p.ldc & 3) || (p.C.off & 15) ||
                                              p.act == GHN3_ACT_GELU || p.dact == GHN3_DACT_GELU ||
@@ -285,11 +286,11 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             }
                             g.tile_start = L.tiles;               // always a multiple of 8 (XCD-aware order)
                             g.tiles_m = (p.M + te - 1) / te;
-                            g.tiles_n = (p.N + te - 1) / te;
-                            g.kq = (tl == 16 || tl == 24) ? p.b_kq : 0; g.ks = p.b_ks;
-                            g.lim = (tl == 16 || tl == 24) ? R.get<const int>(p.lim) : nullptr;
+                            g.tiles_n = (p.N + te_n - 1) / te_n;
+                            g.kq = (tl == 16 || tl == 24 || tl == 20) ? p.b_kq : 0; g.ks = p.b_ks;
+                            g.lim = (tl == 16 || tl == 24 || tl == 20) ? R.get<const int>(p.lim) : nullptr;
                             g.lim_kind = g.lim ? p.lim_kind : 0;
-                            g.alpha_amax = (tl == 16 || tl == 24) ? R.get<const float>(p.alpha_amax) : nullptr;
+                            g.alpha_amax = (tl == 16 || tl == 24 || tl == 20) ? R.get<const float>(p.alpha_amax) : nullptr;
                             g.order = (int64_t)p.M > (int64_t)p.N ? 1 : 0;   // stream the larger operand once
                             g.ksplit = p.ksplit > 1 ? p.ksplit : 1;
                             g.k_chunk = ((p.K + g.ksplit - 1) / g.ksplit + 63) / 64 * 64;
@@ -371,8 +372,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             for (const Launch& L : op_launches[k]) {
                 if (L.tile == 32)
                     rc = ghn3_gemm_small_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, stream);
-                else if (L.tile == 16 || L.tile == 24)
-                    rc = ghn3_gemm_h16d_launch(ds + L.first, L.count, L.tiles, L.tile == 16 ? 128 : 256,
+                else if (L.tile == 16 || L.tile == 24 || L.tile == 20)
+                    rc = ghn3_gemm_h16d_launch(ds + L.first, L.count, L.tiles, L.tile == 16 ? 128 : L.tile == 20 ? 20 : 256,
                                                (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, (int)o.i[3],
                                                stream);
                 else

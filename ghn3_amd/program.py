@@ -1030,7 +1030,7 @@ class Program:
                 items, side_items = [], []
                 rowsets = []
                 for g in g16:
-                    g['dth_ld'] = round_up(g['cols'], 64)
+                    g['dth_ld'] = round_up(g['cols'], 64) + 64        # (+64: rows never a power of two apart)
                     g['dth'] = self.ws16('dth%d' % g['row0'], g['rows'] * g['dth_ld'])
                     # (rows of a family with a smaller extent keep zeros beyond it: d_tiles is never written there)
                     items.append(dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'], rows=g['rows'],
@@ -1068,6 +1068,9 @@ class Program:
                 self.cast16((self.xbuf(self.X_WS), 0), side_items, dbias=self.gref(b2), flags=self.SIDE, amax=amax_t)
             p0 = len(self._probs)
             fl = 0.0
+            use_rect = bool(g16) and all(g['op16'] for g in self.gemm_groups if g['rows'] >= 512) and \
+                any(g['op16'] and g['rows'] >= 512 for g in self.gemm_groups) and \
+                os.environ.get('GHN3_DGRAD_RECT', '1') != '0'
             for g in self.gemm_groups:
                 fl += sum(2.0 * sb['rows'] * sb['cols'] * 8 * C for sb in g['subs'])
                 tiles = ((g['rows'] + 127) // 128) * ((8 * C + 127) // 128)
@@ -1075,6 +1078,12 @@ class Program:
                 # 512 .. 3072 (1.39 vs 1.54 ms at 2048) -- more splits only add atomics and tile-count quantisation
                 tgt = 512 if g['op16'] else 2048       # (the fp32-operand kernel likes ~2048 tiles: 8.2 vs 9.8 ms)
                 ks = int(max(2, min(64, (tgt + tiles - 1) // tiles, g['cols'] // 1024)))
+                if g['op16'] and g['rows'] >= 512 and use_rect:
+                    # families with >= 512 rows: 256 x 128 tiles with a three-stage ring (tile code 20; one workgroup
+                    # per CU), split so that the launch offers ~1.75 workgroups per CU -- measured plateau 5 <= ks <= 8
+                    # for 768 rows: 1.16-1.21 ms against 1.45-1.55 ms with 128 x 128 tiles and four splits
+                    t20 = ((g['rows'] + 255) // 256) * ((8 * C + 127) // 128)
+                    ks = int(max(2, min(16, round(448.0 / t20), g['cols'] // 1024)))
                 if g['op16']:
                     # one problem per family; the K loop of a row tile stops at the largest extent of its rows
                     self.gemm(self.href(g['dth']), self.href(self.w2hT), (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),
@@ -1086,7 +1095,7 @@ class Program:
                           (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),
                           g['rows'], 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
                           b_qs=(g['i_ld'], ms[1]), ksplit=ks)
-            self.gemm_op(p0, ctype=bct if g16 else None, tag=self.TAG_D3_DGRAD, flops=fl)
+            self.gemm_op(p0, ctype=bct if g16 else None, tag=self.TAG_D3_DGRAD, flops=fl, tile=20 if use_rect else 0)
             self.op(L.OP_DACT, refs=(d_u, u, amax_u if amax_u is not None else self.NONE),
                     ints=(M, 8 * C, 8 * C, L.DACT_RELU))
             # dW2 = d_tiles^T u.  16-bit bands first (one launch; every dW2 row they cover is written once, without

@@ -126,7 +126,7 @@ def bench16(ctx, M, N, K, ctype, ksplit=1, accum=False, kmap=None, reps=5, name=
 if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == 'wgrad':
     ct = {'f16': L.CT_F16, 'bf16': L.CT_BF16}[sys.argv[1]]
     ctx = L.context(0)
-    for tile in (16, 24):
+    for tile in (16, 20, 24):
         bench16(ctx, 147456, 3072, 512, ct, name='wgrad', tile=tile)
         bench16(ctx, 147456, 3072, 512, ct, name='wgrad A rows -> 256 (L2)', tile=tile, a_qs=(256, 0))
         bench16(ctx, 147456, 3072, 512, ct, name='wgrad C rows -> 256 (L2)', tile=tile, c_qs=(256, 0))
@@ -137,7 +137,7 @@ if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == 'wgrad':
 if __name__ == '__main__' and len(sys.argv) > 1 and sys.argv[1] in ('f16', 'bf16'):
     ct = {'f16': L.CT_F16, 'bf16': L.CT_BF16}[sys.argv[1]]
     ctx = L.context(0)
-    for tile in (16, 24):
+    for tile in (16, 20, 24):
         bench16(ctx, 4096, 4096, 4096, ct, name='d16 square', tile=tile)
         bench16(ctx, 8192, 8192, 8192, ct, name='d16 square 8k', tile=tile)
         bench16(ctx, 512, 147456, 3072, ct, name='d16 w2 fwd', tile=tile)

@@ -309,6 +309,13 @@ OP16_CASES = [
     dict(M=300, N=200, K=150, a_transposed=True, b_transposed=True, colsum=True, cmap=True, accum=True, tile=24),
     dict(M=533, N=384, K=64 * 48, kmap=(64, 96), ksplit=5, tile=24),
     dict(M=5, N=7, K=9, tile=24),
+    # the 256 x 128 three-stage variant (tile code 20): deep K loops (ring wrap-around), k-map + split-K, ragged M / N
+    dict(M=300, N=520, K=150, tile=20),
+    dict(M=1100, N=1300, K=512, epilogue='bias_relu', tile=20),
+    dict(M=533, N=384, K=64 * 48, kmap=(64, 96), ksplit=5, tile=20),
+    dict(M=768, N=200, K=64 * 21, ksplit=3, tile=20),
+    dict(M=5, N=7, K=9, tile=20),
+    dict(M=300, N=200, K=64, tile=20, accum=True),
     # persistent workgroups (grid cap): 3 workgroups stride over 99 / 30 tiles
     dict(M=1100, N=1300, K=512, epilogue='bias_relu', grid_cap=3),
     dict(M=1100, N=1300, K=200, tile=24, grid_cap=3, accum=True),

@@ -626,10 +626,12 @@ __device__ __forceinline__ int first_segment_after(const int64_t* __restrict__ s
 }
 __global__ __launch_bounds__(256) void param_sq_kernel(const float* __restrict__ flat,
                                                        const int64_t* __restrict__ seg_off, float* __restrict__ norms,
-                                                       int n_seg) {
+                                                       int n_seg, const int* __restrict__ first_seg) {
     __shared__ float red[4];
     const int64_t w0 = (int64_t)blockIdx.x * NORM_CHUNK, w1 = w0 + NORM_CHUNK;
-    for (int sgm = first_segment_after(seg_off, n_seg, w0); sgm < n_seg && seg_off[2 * sgm] < w1; ++sgm) {
+    // (first_seg: host-computed first segment of every chunk -- saves the 8 dependent loads of the search)
+    for (int sgm = first_seg ? first_seg[blockIdx.x] : first_segment_after(seg_off, n_seg, w0);
+         sgm < n_seg && seg_off[2 * sgm] < w1; ++sgm) {
         const int64_t c0 = max(seg_off[2 * sgm], w0), c1 = min(seg_off[2 * sgm + 1], w1);
         float acc = 0.f;
         const int64_t a0 = (c0 + 3) & ~(int64_t)3, a1 = c1 & ~(int64_t)3;     // 16-byte aligned interior
@@ -669,19 +671,22 @@ __global__ void param_sqrt_kernel(float* __restrict__ loss, float* __restrict__ 
     if (threadIdx.x == 0) loss[0] += red[0] + red[1] + red[2] + red[3];
 }
 int ghn3_param_norm_fwd(float* loss, const float* flat, const int64_t* seg_off, float* norms, int n_seg,
-                        int64_t flat_numel, hipStream_t s) {
+                        int64_t flat_numel, const int* first_seg, hipStream_t s) {
     if (n_seg <= 0) return GHN3_OK;
     hipMemsetAsync(norms, 0, sizeof(float) * n_seg, s);
     const int64_t blocks = (flat_numel + NORM_CHUNK - 1) / NORM_CHUNK;
-    hipLaunchKernelGGL(param_sq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, flat, seg_off, norms, n_seg);
+    hipLaunchKernelGGL(param_sq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, flat, seg_off, norms, n_seg,
+                       first_seg);
     hipLaunchKernelGGL(param_sqrt_kernel, dim3(1), dim3(256), 0, s, loss, norms, n_seg);
     return launch_ok("param_norm_fwd");
 }
 __global__ __launch_bounds__(256) void param_norm_bwd_kernel(float* __restrict__ dflat, const float* __restrict__ flat,
                                                              const int64_t* __restrict__ seg_off,
-                                                             const float* __restrict__ norms, int n_seg, float g) {
+                                                             const float* __restrict__ norms, int n_seg, float g,
+                                                             const int* __restrict__ first_seg) {
     const int64_t w0 = (int64_t)blockIdx.x * NORM_CHUNK, w1 = w0 + NORM_CHUNK;
-    for (int sgm = first_segment_after(seg_off, n_seg, w0); sgm < n_seg && seg_off[2 * sgm] < w1; ++sgm) {
+    for (int sgm = first_seg ? first_seg[blockIdx.x] : first_segment_after(seg_off, n_seg, w0);
+         sgm < n_seg && seg_off[2 * sgm] < w1; ++sgm) {
         const int64_t c0 = max(seg_off[2 * sgm], w0), c1 = min(seg_off[2 * sgm + 1], w1);
         const float nrm = norms[sgm];
         const float k = nrm > 0.f ? g / nrm : 0.f;
@@ -703,11 +708,11 @@ __global__ __launch_bounds__(256) void param_norm_bwd_kernel(float* __restrict__
     }
 }
 int ghn3_param_norm_bwd(float* dflat, const float* flat, const int64_t* seg_off, const float* norms, int n_seg,
-                        float g, int64_t flat_numel, hipStream_t s) {
+                        float g, int64_t flat_numel, const int* first_seg, hipStream_t s) {
     if (n_seg <= 0) return GHN3_OK;
     const int64_t blocks = (flat_numel + NORM_CHUNK - 1) / NORM_CHUNK;
     hipLaunchKernelGGL(param_norm_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, dflat, flat, seg_off, norms,
-                       n_seg, g);
+                       n_seg, g, first_seg);
     return launch_ok("param_norm_bwd");
 }
 

@@ -68,9 +68,9 @@ int ghn3_tile_bwd(const float* dflat, const float* const* srcs, float* const* ds
                   const ghn3_tile_desc* d_desc, int n_desc, int64_t total, const int64_t* blocks, int lds_bytes,
                   float* amax, hipStream_t s);
 int ghn3_param_norm_fwd(float* loss, const float* flat, const int64_t* seg_off, float* norms, int n_seg,
-                        int64_t flat_numel, hipStream_t s);
+                        int64_t flat_numel, const int* first_seg, hipStream_t s);
 int ghn3_param_norm_bwd(float* dflat, const float* flat, const int64_t* seg_off, const float* norms, int n_seg,
-                        float g, int64_t flat_numel, hipStream_t s);
+                        float g, int64_t flat_numel, const int* first_seg, hipStream_t s);
 int ghn3_colsum(float* out, const float* X, int M, int N, int ld, int q, int sdim, int stride, int accum,
                 const int* gather, hipStream_t s);
 int ghn3_rowseg_sum(float* out, const float* X, const int* seg_ptr, const int* idx, int rows, int C, int ldx,

@@ -465,12 +465,13 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         case GHN3_OP_PARAM_NORM_FWD:
             if (o.i[1] <= 0) { ghn3_set_error("PARAM_NORM_FWD: i1 (flat extent) missing"); rc = GHN3_E_ARG; break; }
             rc = ghn3_param_norm_fwd(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const int64_t>(o.r[2]),
-                                     R.get<float>(o.r[3]), (int)o.i[0], (int64_t)o.i[1], stream);
+                                     R.get<float>(o.r[3]), (int)o.i[0], (int64_t)o.i[1], R.get<const int>(o.r[4]), stream);
             break;
         case GHN3_OP_PARAM_NORM_BWD:
             if (o.i[1] <= 0) { ghn3_set_error("PARAM_NORM_BWD: i1 (flat extent) missing"); rc = GHN3_E_ARG; break; }
             rc = ghn3_param_norm_bwd(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const int64_t>(o.r[2]),
-                                     R.get<const float>(o.r[3]), (int)o.i[0], o.f[0], (int64_t)o.i[1], stream);
+                                     R.get<const float>(o.r[3]), (int)o.i[0], o.f[0], (int64_t)o.i[1], R.get<const int>(o.r[4]),
+                                     stream);
             break;
         case GHN3_OP_COLSUM:
             rc = ghn3_colsum(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), (int)o.i[0], (int)o.i[1], (int)o.i[2],

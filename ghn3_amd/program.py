@@ -883,6 +883,10 @@ class Program:
         seg = np.asarray([[p['offset'], p['offset'] + p['numel']] for p in predicted], dtype=np.int64).reshape(-1, 2)
         self.r_seg = self.idx(seg if len(seg) else np.zeros((1, 2), dtype=np.int64))
         self.n_seg = len(predicted)
+        # first segment that ends beyond the start of every 8192-float chunk of the flat buffer (param-norm passes)
+        ends = seg[:, 1] if len(seg) else np.zeros(1, dtype=np.int64)
+        starts = np.arange(0, max(self.out_numel, 1), 8192, dtype=np.int64)
+        self.r_seg_first = self.idx(np.searchsorted(ends, starts, side='right').astype(np.int32))
         srcs = self._tile_sources(False)
         if self.n_desc:
             self.op(L.OP_TILE_FWD, refs=[(self.xbuf(self.X_OUT), 0)] + srcs + [self.r_desc],
@@ -910,11 +914,12 @@ class Program:
         saved = self._ops
         self._ops = []
         self.op(L.OP_MEMSET0, refs=((scal, 0),), ints=(4,))
-        self.op(L.OP_PARAM_NORM_FWD, refs=((scal, 0), (self.xbuf(self.X_OUT), 0), self.r_seg, (scal, 256)),
-                ints=(self.n_seg, self.out_numel))
+        self.op(L.OP_PARAM_NORM_FWD, refs=((scal, 0), (self.xbuf(self.X_OUT), 0), self.r_seg, (scal, 256),
+                                           self.r_seg_first), ints=(self.n_seg, self.out_numel))
         f_ops = self._finish_ops()
         self.op(L.OP_PARAM_NORM_BWD, refs=((self.xbuf(self.X_DOUT), 0), (self.xbuf(self.X_OUT), 0), self.r_seg,
-                                           (scal, 256)), ints=(self.n_seg, self.out_numel), floats=(upstream,))
+                                           (scal, 256), self.r_seg_first), ints=(self.n_seg, self.out_numel),
+                floats=(upstream,))
         b_ops = self._finish_ops()
         self._ops = saved
         return f_ops, b_ops

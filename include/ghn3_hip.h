@@ -190,9 +190,11 @@ enum ghn3_op_kind {
     GHN3_OP_TILE_FWD = 8,
     /* sum over predicted tensors of ||p||_F (trainer.py:97-98,288-294)
      * r0=loss(1 float, accumulated) r1=flat r2=seg_off(int64 (begin,end) pairs, sorted by begin, disjoint)
-     * r3=norms(n floats) ; i: n_seg, extent of the flat buffer in floats (>= the last end; the passes stream it) */
+     * r3=norms(n floats) r4=optional int32 table: first segment whose end lies beyond float 8192 * b, for every
+     * 8192-float chunk b of the flat buffer (absent: searched on the device)
+     * i: n_seg, extent of the flat buffer in floats (>= the last end; the passes stream it) */
     GHN3_OP_PARAM_NORM_FWD = 9,
-    /* r0=dflat r1=flat r2=seg_off r3=norms ; i: n_seg, flat extent ; f0 = upstream grad */
+    /* r0=dflat r1=flat r2=seg_off r3=norms r4=optional first-segment table ; i: n_seg, flat extent ; f0 = upstream grad */
     GHN3_OP_PARAM_NORM_BWD = 10,
     /* r0=dflat, r1..r6 = source buffers (values), r7=desc, r8..r12 = source-grad buffers, r13 = optional device float
      * that receives the running max |x| of everything written to source-grad buffer 0 (the decoder tiles)

@@ -12,7 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libghn3_hip.so')
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 # ---- numpy mirrors of the C structs -------------------------------------------------------------
 REF_DT = np.dtype([('buf', '<i4'), ('_pad', '<i4'), ('off', '<i8')])
@@ -21,14 +21,15 @@ _INT_NAMES = ('M', 'N', 'K', 'lda', 'ldb', 'ldc', 'a_mode', 'b_mode', 'a_q', 'a_
               'bias_q', 'bias_s', 'bias_stride', 'act', 'dact', 'flags')
 PROBLEM_DT = np.dtype([(n, REF_DT) for n in _REF_NAMES] + [(n, '<i4') for n in _INT_NAMES] +
                       [('alpha', '<f4'), ('ksplit', '<i4'), ('b_kq', '<i4'), ('b_ks', '<i4'), ('lim', REF_DT), ('lim_kind', '<i4'),
-                       ('_pad2', '<i4'), ('alpha_amax', REF_DT)])
+                       ('_pad2', '<i4'), ('alpha_amax', REF_DT), ('ln_p', REF_DT, 6), ('ln_kind', '<i4'),
+                       ('ln_eps', '<f4')])
 TILE_DT = np.dtype([('dst_off', '<i8'), ('src_off', '<i8'), ('S', '<i8', 4), ('T', '<i4', 4), ('E', '<i4', 4),
                     ('R', '<i4', 4), ('src_buf', '<i4'), ('mode', '<i4'), ('scale', '<f4'), ('_pad', '<i4')])
 CAST_DT = np.dtype([('src_off', '<i8'), ('dst_off', '<i8'), ('dstT_off', '<i8'), ('rows', '<i4'), ('cols', '<i4'),
                     ('ld_src', '<i4'), ('ld_dst', '<i4'), ('ld_dstT', '<i4'), ('flags', '<u4'), ('bias_q', '<i4'),
                     ('bias_s', '<i4'), ('block_start', '<i4'), ('bias_off', '<i4'), ('src_q', '<i4'), ('src_s', '<i4')])
 OP_DT = np.dtype([('kind', '<i4'), ('flags', '<i4'), ('i', '<i8', 8), ('f', '<f4', 4), ('r', REF_DT, 14)])
-assert REF_DT.itemsize == 16 and PROBLEM_DT.itemsize == 296 and TILE_DT.itemsize == 112 and OP_DT.itemsize == 312
+assert REF_DT.itemsize == 16 and PROBLEM_DT.itemsize == 400 and TILE_DT.itemsize == 112 and OP_DT.itemsize == 312
 assert CAST_DT.itemsize == 72
 
 MODE_ROW, MODE_COL = 0, 1

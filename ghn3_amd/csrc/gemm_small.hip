@@ -103,6 +103,170 @@ struct ChunkLoader {
     }
 };
 
+// LayerNorm row prologue (see the kernel).  One instance per thread; the 32 threads (tid & 31) of a row cooperate.
+// K <= 512 (every released GHN-3: C <= 384): the thread's <= 4 float4 of the row are loaded ONCE, all loads in flight
+// together, the statistics and the transformed values are computed from registers and handed to the K loop chunk by
+// chunk (no second pass over memory, no A loads inside the loop).  Wider rows take the two-pass path.
+struct LnRow {
+    int kind;
+    bool row_ok, writer, cached;
+    float mu, rs, s1, s2;
+    gcf gamma, beta, xrow, resrow;
+    gf outrow;
+    f32x4 o[4];
+    static __device__ __forceinline__ float rsum32(float v) {       // sum over the 32 lanes that share a row
+#pragma unroll
+        for (int off = 16; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        return v;
+    }
+    __device__ __forceinline__ void init(const GemmProbDev* P, gcf arow, bool ok, int row, int c0, int K, bool wr) {
+        row_ok = ok; writer = wr && ok;
+        gamma = (gcf)P->ln_p[0];
+        mu = 0.f; rs = 1.f; s1 = 0.f; s2 = 0.f;
+        cached = K <= 4 * KC;
+        const float invK = 1.0f / (float)K;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        if (kind == 1) {
+            beta = (gcf)P->ln_p[1];
+            outrow = P->ln_p[4] ? (gf)P->ln_p[4] + (int64_t)row * P->lda : nullptr;
+            if (cached) {
+                f32x4 x[4], g[4], b[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = c0 + j * KC;
+                    const bool in = ok && k < K;
+                    x[j] = in ? *reinterpret_cast<gcf4>(arow + k) : z;
+                    g[j] = in ? *reinterpret_cast<gcf4>(gamma + k) : z;
+                    b[j] = in ? *reinterpret_cast<gcf4>(beta + k) : z;
+                }
+                float sum = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sum += (x[j].x + x[j].y) + (x[j].z + x[j].w);
+                mu = rsum32(sum) * invK;
+                float v = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (c0 + j * KC < K) {
+                        const float a = x[j].x - mu, bb = x[j].y - mu, c = x[j].z - mu, d = x[j].w - mu;
+                        v += (a * a + bb * bb) + (c * c + d * d);
+                    }
+                }
+                rs = rsqrtf(rsum32(v) * invK + P->ln_eps);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = c0 + j * KC;
+                    o[j] = z;
+                    if (ok && k < K) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) o[j][e] = (x[j][e] - mu) * rs * g[j][e] + b[j][e];
+                        if (writer && outrow) *reinterpret_cast<f32x4 GAS*>(outrow + k) = o[j];
+                    }
+                }
+            } else {
+                float sum = 0.f;
+                for (int k = c0; k < K; k += KC)
+                    if (ok) { const f32x4 x = *reinterpret_cast<gcf4>(arow + k); sum += (x.x + x.y) + (x.z + x.w); }
+                mu = rsum32(sum) * invK;
+                float v = 0.f;
+                for (int k = c0; k < K; k += KC)
+                    if (ok) {
+                        const f32x4 x = *reinterpret_cast<gcf4>(arow + k);
+                        const float a = x.x - mu, b = x.y - mu, c = x.z - mu, d = x.w - mu;
+                        v += (a * a + b * b) + (c * c + d * d);
+                    }
+                rs = rsqrtf(rsum32(v) * invK + P->ln_eps);
+            }
+            if (writer && (c0 == 0)) {
+                if (P->ln_p[2]) ((gf)P->ln_p[2])[row] = mu;
+                if (P->ln_p[3]) ((gf)P->ln_p[3])[row] = rs;
+            }
+        } else {
+            xrow = (gcf)P->ln_p[1] + (int64_t)row * P->lda;
+            resrow = P->ln_p[4] ? (gcf)P->ln_p[4] + (int64_t)row * P->lda : nullptr;
+            outrow = P->ln_p[5] ? (gf)P->ln_p[5] + (int64_t)row * P->lda : nullptr;
+            if (ok) { mu = ((gcf)P->ln_p[2])[row]; rs = ((gcf)P->ln_p[3])[row]; }
+            if (cached) {
+                f32x4 dy[4], x[4], g[4], r[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = c0 + j * KC;
+                    const bool in = ok && k < K;
+                    dy[j] = in ? *reinterpret_cast<gcf4>(arow + k) : z;
+                    x[j] = in ? *reinterpret_cast<gcf4>(xrow + k) : z;
+                    g[j] = in ? *reinterpret_cast<gcf4>(gamma + k) : z;
+                    r[j] = (in && resrow) ? *reinterpret_cast<gcf4>(resrow + k) : z;
+                }
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float dg = dy[j][e] * g[j][e];                 // (zero outside the row: g = dy = 0)
+                        a1 += dg;
+                        a2 += dg * (x[j][e] - mu) * rs;
+                    }
+                s1 = rsum32(a1) * invK;
+                s2 = rsum32(a2) * invK;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const int k = c0 + j * KC;
+                    o[j] = z;
+                    if (ok && k < K) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float xh = (x[j][e] - mu) * rs;
+                            o[j][e] = rs * (dy[j][e] * g[j][e] - s1 - xh * s2) + r[j][e];
+                        }
+                        if (writer && outrow) *reinterpret_cast<f32x4 GAS*>(outrow + k) = o[j];
+                    }
+                }
+            } else {
+                float a1 = 0.f, a2 = 0.f;
+                for (int k = c0; k < K; k += KC)
+                    if (ok) {
+                        const f32x4 dy = *reinterpret_cast<gcf4>(arow + k);
+                        const f32x4 x = *reinterpret_cast<gcf4>(xrow + k);
+                        const f32x4 g = *reinterpret_cast<gcf4>(gamma + k);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float dg = dy[e] * g[e];
+                            a1 += dg;
+                            a2 += dg * (x[e] - mu) * rs;
+                        }
+                    }
+                s1 = rsum32(a1) * invK;
+                s2 = rsum32(a2) * invK;
+            }
+        }
+    }
+    // chunk `c` of this thread's row, already transformed (cached rows)
+    __device__ __forceinline__ f32x4 chunk(int c) const {
+        return c == 0 ? o[0] : c == 1 ? o[1] : c == 2 ? o[2] : o[3];
+    }
+    // v = the raw A values of columns k .. k + 3 of this thread's row (K % 4 == 0: a float4 is inside or outside)
+    __device__ __forceinline__ f32x4 apply(f32x4 v, int k, int K) const {
+        f32x4 r_ = {0.f, 0.f, 0.f, 0.f};
+        if (!row_ok || k >= K) return r_;
+        const f32x4 g = *reinterpret_cast<gcf4>(gamma + k);
+        if (kind == 1) {
+            const f32x4 b = *reinterpret_cast<gcf4>(beta + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r_[e] = (v[e] - mu) * rs * g[e] + b[e];
+        } else {
+            const f32x4 x = *reinterpret_cast<gcf4>(xrow + k);
+            f32x4 r = {0.f, 0.f, 0.f, 0.f};
+            if (resrow) r = *reinterpret_cast<gcf4>(resrow + k);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float xh = (x[e] - mu) * rs;
+                r_[e] = rs * (v[e] * g[e] - s1 - xh * s2) + r[e];
+            }
+        }
+        if (writer && outrow) *reinterpret_cast<f32x4 GAS*>(outrow + k) = r_;
+        return r_;
+    }
+};
+
 template <int AM, int BMD>
 __global__ __launch_bounds__(1024) void gemm_small_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
     // two stages x (A image + B image); the split-K reduction buffers alias them after the K loop
@@ -152,15 +316,34 @@ __global__ __launch_bounds__(1024) void gemm_small_kernel(const GemmProbDev* __r
         if (accum) e_old = ((gcf)P->C)[e_ci];
     }
 
+    // Row prologue of A (ghn3_gemm_problem::ln_kind; ROW mode only): the LayerNorm forward / backward that produces
+    // this operand runs here, per workgroup on its own 32 rows (32 threads per row, the same threads that stage the
+    // row's chunks), instead of as a separate launch on the latency-bound chain.
+    LnRow ln;
+    ln.kind = (AM == ROWM) ? P->ln_kind : 0;
+    if (AM == ROWM && ln.kind) ln.init(P, la.rptr, la.row_ok, m0 + la.r, la.c, K, n0 == 0);
     const int nchunks = (K + KC - 1) / KC;
-    f32x4 ra = la.load(0), rb = lb.load(0);
+    const bool ln_cached = AM == ROWM && ln.kind && ln.cached;
+    f32x4 ra, rb = lb.load(0);
+    if (ln_cached) ra = ln.chunk(0);
+    else {
+        ra = la.load(0);
+        if (AM == ROWM && ln.kind) ra = ln.apply(ra, la.c, K);
+    }
     la.store(lds, ra); lb.store(lds + OP_FLOATS, rb);
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         float* cur = lds + (c & 1) * 2 * OP_FLOATS;
         float* nxt = lds + ((c + 1) & 1) * 2 * OP_FLOATS;
         const bool more = c + 1 < nchunks;
-        if (more) { ra = la.load((c + 1) * KC); rb = lb.load((c + 1) * KC); }     // in flight during the MFMAs
+        if (more) {                                                                // in flight during the MFMAs
+            rb = lb.load((c + 1) * KC);
+            if (ln_cached) ra = ln.chunk(c + 1);
+            else {
+                ra = la.load((c + 1) * KC);
+                if (AM == ROWM && ln.kind) ra = ln.apply(ra, (c + 1) * KC + la.c, K);
+            }
+        }
         const f32x4 a = ChunkLoader<AM>::fragment(cur, w, li, lh);
         const f32x4 b = ChunkLoader<BMD>::fragment(cur + OP_FLOATS, w, li, lh);
         acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);

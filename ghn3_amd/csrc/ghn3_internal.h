@@ -22,7 +22,9 @@ struct GemmProbDev {
     const int* lim;      // ragged extents per 128 rows (see ghn3_gemm_problem::lim)
     int lim_kind, _pad3;
     const float* alpha_amax;   // alpha is divided by ghn3_pow2_scale(*alpha_amax) (operand copies scaled by GHN3_CAST_SCALED)
-    int _pad;
+    int ln_kind;               // row prologue of A (ghn3_gemm_problem::ln_kind), small-problem kernel only
+    float ln_eps;
+    const float* ln_p[6];
 };
 
 

@@ -185,6 +185,7 @@ struct Resolver {
 // tile code 32 = the latency-optimised small-problem kernel (gemm_small.hip, exact fp32): chosen when a problem
 // cannot fill the chip with 64x64 tiles and its K loop is short enough for one workgroup to split four ways.
 static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
+    if (p.ln_kind) return 32;                       // the row prologue lives in the small-problem kernel
     if (p.flags & GHN3_GEMM_OP16) {
         // tile codes 16 / 24 = the 16-bit-operand kernel with 128 x 128 / 256 x 256 tiles.  The big tile has twice
         // the arithmetic intensity but runs one 512-thread block per CU: it needs enough tiles to fill the chip.
@@ -291,6 +292,20 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             g.lim = (tl == 16 || tl == 24 || tl == 20) ? R.get<const int>(p.lim) : nullptr;
                             g.lim_kind = g.lim ? p.lim_kind : 0;
                             g.alpha_amax = (tl == 16 || tl == 24 || tl == 20) ? R.get<const float>(p.alpha_amax) : nullptr;
+                            g.ln_kind = p.ln_kind; g.ln_eps = p.ln_eps;
+                            for (int e = 0; e < 6; ++e) g.ln_p[e] = p.ln_kind ? R.get<const float>(p.ln_p[e]) : nullptr;
+                            if (p.ln_kind) {
+                                const bool ok = (p.ln_kind == 1 || p.ln_kind == 2) && p.a_mode == GHN3_MODE_ROW &&
+                                                p.a_gather.buf < 0 && p.a_q == 0 && p.K <= 4096 && (p.K & 3) == 0 &&
+                                                !(p.flags & GHN3_GEMM_OP16) && g.ln_p[0] &&
+                                                (p.ln_kind == 1 ? g.ln_p[1] != nullptr
+                                                                : (g.ln_p[1] && g.ln_p[2] && g.ln_p[3]));
+                                if (!ok) {
+                                    ghn3_set_error("op %d problem %d: the LayerNorm row prologue needs a ROW-mode fp32 A "
+                                                   "without gather, K %% 4 == 0, K <= 4096 and its parameter refs", k, q);
+                                    return GHN3_E_ARG;
+                                }
+                            }
                             g.order = (int64_t)p.M > (int64_t)p.N ? 1 : 0;   // stream the larger operand once
                             g.ksplit = p.ksplit > 1 ? p.ksplit : 1;
                             g.k_chunk = ((p.K + g.ksplit - 1) / g.ksplit + 63) / 64 * 64;

@@ -65,6 +65,10 @@ class Program:
         # dependent chain of the program) carry GHN3_OPFLAG_SIDE and overlap with the chain on a second stream;
         # the temporaries they read are then per-layer buffers instead of reused ones.
         self.SIDE = L.OPFLAG_SIDE if side_stream else 0
+        # fuse_ln: the LayerNorms of the Graphormer layers run as row prologues of the GEMMs that consume them
+        # (forward: LN1 -> to_qkv, LN2 -> ff.net.0; backward: LN2' -> to_out dgrad, LN1' -> the next layer's ff.net.3
+        # dgrad) instead of ~95 separate launches on the dependent chain
+        self.fuse_ln = os.environ.get('GHN3_FUSE_LN', '1') != '0'
         # MFMA operand type of the decoder GEMMs (fc / W0 / W2, forward and backward): None = context default.
         # The Graphormer, the edge MLP and the small heads always multiply in exact fp32.
         self.decoder_ctype = decoder_ctype
@@ -102,7 +106,7 @@ class Program:
                              % max_edge)
         if self.N > 4096:
             raise ValueError('graphs with more than 4096 nodes are not supported (got %d)' % self.N)
-        self._ops, self._probs = [], []
+        self._ops, self._probs, self._ln = [], [], {}
         self.tag_flops = {}
         self._ws = 0
         self._ws_names = {}
@@ -255,7 +259,9 @@ class Program:
     def gemm(self, A, B, C, M, N, K, lda, ldb, ldc, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, bias=None, bias_q=0,
              bias_s=0, bias_stride=1, act=L.ACT_NONE, dact=L.DACT_NONE, aux_in=None, aux_out=None, residual=None,
              a_gather=None, b_gather=None, c_gather=None, a_qs=(0, 0), b_qs=(0, 0), c_qs=(0, 0), accum=False,
-             alpha=1.0, dbias=None, dbias_stride=1, ksplit=1, op16=False, b_kmap=(0, 0), lim=None, lim_kind=0, alpha_amax=None):
+             alpha=1.0, dbias=None, dbias_stride=1, ksplit=1, op16=False, b_kmap=(0, 0), lim=None, lim_kind=0, alpha_amax=None,
+             ln=None):
+        # ln = (kind, [refs p0..p5 or None], eps): LayerNorm row prologue of A (ghn3_gemm_problem::ln_kind)
         # dbias: fused bias gradient of a wgrad problem (GHN3_GEMM_BIASGRAD): dbias[cmap(m)*stride] += sum_k A(m,k)
         if dbias is not None:
             assert bias is None and a_mode == L.MODE_COL
@@ -271,6 +277,8 @@ class Program:
             M, N, K, lda, ldb, ldc, a_mode, b_mode, a_qs[0], a_qs[1], b_qs[0], b_qs[1], c_qs[0], c_qs[1], bias_q, bias_s,
             bias_stride, act, dact, flags, b_kmap[0], b_kmap[1],
             alpha, ksplit, (lim_kind if lim is not None else 0)))
+        if ln is not None:
+            self._ln[len(self._probs) - 1] = ln
         return len(self._probs) - 1
 
     _PROBLEM_REFS = ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim',
@@ -292,6 +300,12 @@ class Program:
             arr[name] = np.asarray(cols[nr + k], dtype=np.int64)
         k = nr + len(self._PROBLEM_INTS)
         arr['alpha'], arr['ksplit'], arr['lim_kind'] = cols[k], cols[k + 1], cols[k + 2]
+        arr['ln_p']['buf'] = -1
+        for q, (kind, refs, eps) in self._ln.items():
+            arr['ln_kind'][q], arr['ln_eps'][q] = kind, eps
+            for e, ref in enumerate(refs):
+                if ref is not None:
+                    arr['ln_p']['buf'][q, e], arr['ln_p']['off'][q, e] = ref
         return arr
 
     # timing tags (ghn3_profile_enable mode 2): the decoder kernels that dominate the step
@@ -547,19 +561,30 @@ class Program:
             z = self.wsf('z' + sfx, rows * 4 * C)
             f = self.wsf('f' + sfx, rows * 4 * C)
             x_out = self.wsf('x%d' % (l + 1), rows * C)
-            self.op(L.OP_LAYERNORM_FWD, refs=(h1, x_in, self.pref(pre + 'ln1.weight'), self.pref(pre + 'ln1.bias'),
-                                              m1, r1), ints=(rows, C), floats=(1e-5,))
-            p0 = self.gemm(h1, self.pref(pre + 'attn.to_qkv.weight'), qkv, rows, 3 * C, C, C, C, 3 * C)
+            if self.fuse_ln:
+                p0 = self.gemm(x_in, self.pref(pre + 'attn.to_qkv.weight'), qkv, rows, 3 * C, C, C, C, 3 * C,
+                               ln=(1, [self.pref(pre + 'ln1.weight'), self.pref(pre + 'ln1.bias'),
+                                       m1 if train else None, r1 if train else None, h1 if train else None], 1e-5))
+            else:
+                self.op(L.OP_LAYERNORM_FWD, refs=(h1, x_in, self.pref(pre + 'ln1.weight'), self.pref(pre + 'ln1.bias'),
+                                                  m1, r1), ints=(rows, C), floats=(1e-5,))
+                p0 = self.gemm(h1, self.pref(pre + 'attn.to_qkv.weight'), qkv, rows, 3 * C, C, C, C, 3 * C)
             self.gemm_op(p0)
             self.op(L.OP_ATTN_FWD, refs=(o, qkv, bias, Pm if Pm is not None else self.NONE, r_nn),
                     ints=(B, N, C, H))
             p0 = self.gemm(o, self.pref(pre + 'attn.to_out.0.weight'), xmid, rows, C, C, C, C, C,
                            bias=self.pref(pre + 'attn.to_out.0.bias'), residual=x_in)
             self.gemm_op(p0)
-            self.op(L.OP_LAYERNORM_FWD, refs=(h2, xmid, self.pref(pre + 'ln2.weight'), self.pref(pre + 'ln2.bias'),
-                                              m2, r2), ints=(rows, C), floats=(1e-5,))
-            p0 = self.gemm(h2, self.pref(pre + 'ff.net.0.weight'), f, rows, 4 * C, C, C, C, 4 * C,
-                           bias=self.pref(pre + 'ff.net.0.bias'), act=L.ACT_GELU, aux_out=z if train else None)
+            if self.fuse_ln:
+                p0 = self.gemm(xmid, self.pref(pre + 'ff.net.0.weight'), f, rows, 4 * C, C, C, C, 4 * C,
+                               bias=self.pref(pre + 'ff.net.0.bias'), act=L.ACT_GELU, aux_out=z if train else None,
+                               ln=(1, [self.pref(pre + 'ln2.weight'), self.pref(pre + 'ln2.bias'),
+                                       m2 if train else None, r2 if train else None, h2 if train else None], 1e-5))
+            else:
+                self.op(L.OP_LAYERNORM_FWD, refs=(h2, xmid, self.pref(pre + 'ln2.weight'), self.pref(pre + 'ln2.bias'),
+                                                  m2, r2), ints=(rows, C), floats=(1e-5,))
+                p0 = self.gemm(h2, self.pref(pre + 'ff.net.0.weight'), f, rows, 4 * C, C, C, C, 4 * C,
+                               bias=self.pref(pre + 'ff.net.0.bias'), act=L.ACT_GELU, aux_out=z if train else None)
             self.gemm_op(p0)
             p0 = self.gemm(f, self.pref(pre + 'ff.net.3.weight'), x_out, rows, C, 4 * C, 4 * C, 4 * C, C,
                            bias=self.pref(pre + 'ff.net.3.bias'), residual=xmid)
@@ -1238,6 +1263,7 @@ class Program:
             g_cur = d_xe
         # ---- Graphormer layers, reversed ----------------------------------------------------------------
         bias = self.wref('bias')
+        pending_ln1 = None                  # (dy buffer, prologue refs) of the LayerNorm backward fused into the next GEMM
         for l in reversed(range(self.Lyr)):
             pre = 'gnn.%d.' % l
             sfx = '_%d' % l
@@ -1258,9 +1284,12 @@ class Program:
             g_mid = self.wsf('gmid' + lsfx, rows * C)
             g_out = self.wsf(('gout' + sfx) if self.SIDE else 'gout%d' % (l & 1), rows * C)
             dqkv = self.wsf('dqkv' + lsfx, rows * 3 * C)
-            # FFN second linear: x_out = xmid + f W3^T + b3
-            p0 = self.gemm(g_cur, self.pref(W3), dz, rows, 4 * C, C, C, 4 * C, 4 * C, a_mode=L.MODE_ROW,
-                           b_mode=L.MODE_COL, dact=L.DACT_GELU, aux_in=z)
+            # FFN second linear: x_out = xmid + f W3^T + b3.  With fuse_ln the upstream gradient g_cur of every layer
+            # but the last is LN1'(dhB) + g_mid of the layer above, produced by this GEMM's row prologue.
+            p0 = self.gemm(g_cur if pending_ln1 is None else pending_ln1[0], self.pref(W3), dz, rows, 4 * C, C, C,
+                           4 * C, 4 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, dact=L.DACT_GELU, aux_in=z,
+                           ln=None if pending_ln1 is None else (2, pending_ln1[1], 0.0))
+            pending_ln1 = None
             self.gemm_op(p0)
             # FFN first linear
             p0 = self.gemm(dz, self.pref(W1f), dhA, rows, C, 4 * C, 4 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
@@ -1268,10 +1297,16 @@ class Program:
             # LN2 (+ residual branch gradient g_cur)
             self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln2.weight'), self.gref(pre + 'ln2.bias'), dhA, xmid,
                                               m2, r2), ints=(rows, C, 1), flags=self.SIDE)
-            self.op(L.OP_LAYERNORM_BWD, refs=(g_mid, dhA, xmid, self.pref(pre + 'ln2.weight'), m2, r2, g_cur),
-                    ints=(rows, C))
-            # attention output projection: xmid = x_in + o Wo^T + bo
-            p0 = self.gemm(g_mid, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+            if self.fuse_ln:
+                # attention output projection: xmid = x_in + o Wo^T + bo; its A operand g_mid = LN2'(dhA) + g_cur is
+                # computed (and written for the wgrad / the residual path) by the GEMM's row prologue
+                p0 = self.gemm(dhA, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
+                               ln=(2, [self.pref(pre + 'ln2.weight'), xmid, m2, r2, g_cur, g_mid], 0.0))
+            else:
+                self.op(L.OP_LAYERNORM_BWD, refs=(g_mid, dhA, xmid, self.pref(pre + 'ln2.weight'), m2, r2, g_cur),
+                        ints=(rows, C))
+                # attention output projection: xmid = x_in + o Wo^T + bo
+                p0 = self.gemm(g_mid, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
             self.gemm_op(p0)
             self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, self.NONE, dBias, r_nn), ints=(B, N, C, H))
             p0 = self.gemm(dqkv, self.pref(Wq), dhB, rows, C, 3 * C, 3 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
@@ -1288,8 +1323,11 @@ class Program:
             self.gemm_op(p0, side=True)
             self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln1.weight'), self.gref(pre + 'ln1.bias'), dhB, x_in,
                                               m1, r1), ints=(rows, C, 1), flags=self.SIDE)
-            self.op(L.OP_LAYERNORM_BWD, refs=(g_out, dhB, x_in, self.pref(pre + 'ln1.weight'), m1, r1, g_mid),
-                    ints=(rows, C))
+            if self.fuse_ln and l > 0:
+                pending_ln1 = (dhB, [self.pref(pre + 'ln1.weight'), x_in, m1, r1, g_mid, g_out])
+            else:
+                self.op(L.OP_LAYERNORM_BWD, refs=(g_out, dhB, x_in, self.pref(pre + 'ln1.weight'), m1, r1, g_mid),
+                        ints=(rows, C))
             g_cur = g_out                   # d x_l
         # ---- layer-0 edge bias: histogram -> table MLP backward ------------------------------------------
         E = 'gnn.0.attn.edge_embed.embed.weight'

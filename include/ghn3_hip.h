@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 7
+#define GHN3_ABI_VERSION 8
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -103,6 +103,19 @@ typedef struct ghn3_gemm_problem {
      * that GHN3_OP_CAST16 scaled by a power of two (GHN3_CAST_SCALED): alpha is divided by that scale
      * (2^(11 - e) for amax = m 2^e; exact).  f16 copies of ~1e-6 gradients would otherwise be subnormal. */
     ghn3_ref alpha_amax;
+    /* Optional row prologue of A (exact-fp32 small-problem kernel only: ROW-mode A without gather, tile 32, K <= 4096):
+     * the LayerNorm that produces A is applied while the operand is staged, so that the latency-bound Graphormer
+     * chain needs no separate LayerNorm launch (every workgroup normalises its own 32 rows; the column-tile-0
+     * workgroups also write the by-products the backward needs).
+     *   ln_kind 1 (forward, graphormer.py:239-241 / F.layer_norm): A' = (A - mean) * rstd * p0 + p1
+     *       p0 = gamma[K] p1 = beta[K] p2 = mean out[M] p3 = rstd out[M] p4 = A' out [M][K] (p2..p4 optional)
+     *   ln_kind 2 (backward): A = dy, A' = rstd * (dy*gamma - s1 - xhat*s2) + res, s1 = mean_k(dy*gamma),
+     *       s2 = mean_k(dy*gamma*xhat), xhat = (x - mean) * rstd
+     *       p0 = gamma[K] p1 = x [M][K] p2 = mean[M] p3 = rstd[M] p4 = res [M][K] or absent p5 = A' out [M][K] or absent
+     * All row-major with leading dimension lda. */
+    ghn3_ref ln_p[6];
+    int32_t ln_kind;
+    float ln_eps;
 } ghn3_gemm_problem;
 
 /* ---- 16-bit operand copies (GHN3_OP_CAST16) -----------------------------------------------------------

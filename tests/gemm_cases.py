@@ -320,3 +320,81 @@ OP16_CASES = [
     dict(M=1100, N=1300, K=512, epilogue='bias_relu', grid_cap=3),
     dict(M=1100, N=1300, K=200, tile=24, grid_cap=3, accum=True),
 ]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# LayerNorm row prologue of the small-problem kernel (ghn3_gemm_problem::ln_kind)
+# ------------------------------------------------------------------------------------------------------------------
+LN_CASES = [  # K <= 512: register-cached single pass; K > 512: two-pass path; ragged M / N; both B modes
+    dict(kind=1, M=256, N=1152, K=384, b_mode=L.MODE_ROW),
+    dict(kind=1, M=70, N=100, K=384, b_mode=L.MODE_ROW),
+    dict(kind=1, M=45, N=64, K=640, b_mode=L.MODE_ROW),
+    dict(kind=1, M=33, N=40, K=24, b_mode=L.MODE_COL),
+    dict(kind=2, M=256, N=384, K=384, b_mode=L.MODE_COL),
+    dict(kind=2, M=70, N=100, K=128, b_mode=L.MODE_COL, res=False),
+    dict(kind=2, M=45, N=64, K=640, b_mode=L.MODE_ROW),
+]
+
+
+def run_ln_case(ctx, kind, M, N, K, b_mode, res=True, seed=0, dev='cuda'):
+    """C = LN(A) @ B (kind 1) or LN'(dy = A) @ B (kind 2) through the C ABI; returns [(got, expected fp64), ...] for C
+    and every by-product the prologue writes."""
+    rs = np.random.RandomState(seed)
+    lda = K + 8
+    A = rs.standard_normal((M, lda)).astype(np.float32) * 1.5 + 0.3
+    XB = rs.standard_normal((N, K + 4) if b_mode == L.MODE_ROW else (K, (N + 3) // 4 * 4 + 4)).astype(np.float32)
+    ldb = XB.shape[1]
+    ldc = (N + 3) // 4 * 4
+    gamma = (1.0 + 0.2 * rs.standard_normal(K)).astype(np.float32)
+    beta = (0.1 * rs.standard_normal(K)).astype(np.float32)
+    X = rs.standard_normal((M, lda)).astype(np.float32)
+    RES = rs.standard_normal((M, lda)).astype(np.float32)
+    eps = 1e-5
+    A64, X64 = A[:, :K].astype(np.float64), X[:, :K].astype(np.float64)
+    if kind == 1:
+        mu = A64.mean(1, keepdims=True)
+        rstd = 1.0 / np.sqrt(((A64 - mu) ** 2).mean(1, keepdims=True) + eps)
+        T = (A64 - mu) * rstd * gamma + beta
+        mean_in = rstd_in = None
+    else:
+        mu = X64.mean(1, keepdims=True)
+        rstd = 1.0 / np.sqrt(((X64 - mu) ** 2).mean(1, keepdims=True) + eps)
+        mean_in, rstd_in = mu[:, 0].astype(np.float32), rstd[:, 0].astype(np.float32)
+        xh = (X64 - mean_in[:, None].astype(np.float64)) * rstd_in[:, None].astype(np.float64)
+        dg = A64 * gamma
+        T = rstd_in[:, None].astype(np.float64) * (dg - dg.mean(1, keepdims=True) - xh * (dg * xh).mean(1, keepdims=True))
+        if res:
+            T = T + RES[:, :K]
+    Bm = XB[:, :K].astype(np.float64).T if b_mode == L.MODE_ROW else XB[:, :N].astype(np.float64)
+    expC = T @ Bm
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    dA, dB, dC = t(A), t(XB), torch.zeros(M, ldc, device=dev)
+    dgam, dbet, dX, dRES = t(gamma), t(beta), t(X), t(RES)
+    dmean = t(mean_in) if kind == 2 else torch.zeros(M, device=dev)
+    drstd = t(rstd_in) if kind == 2 else torch.zeros(M, device=dev)
+    dout = torch.zeros(M, lda, device=dev)
+    bufs = [dA, dB, dC, dgam, dbet, dX, dRES, dmean, drstd, dout]
+    ptrs = np.asarray([b.data_ptr() for b in bufs], dtype=np.uint64)
+    p = np.zeros(1, dtype=L.PROBLEM_DT)
+    for name in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim',
+                 'alpha_amax'):
+        p[name]['buf'] = -1
+    p['ln_p']['buf'] = -1
+    p['A']['buf'], p['B']['buf'], p['C']['buf'] = 0, 1, 2
+    p['M'], p['N'], p['K'], p['lda'], p['ldb'], p['ldc'] = M, N, K, lda, ldb, ldc
+    p['a_mode'], p['b_mode'], p['alpha'], p['ksplit'] = L.MODE_ROW, b_mode, 1.0, 1
+    p['ln_kind'], p['ln_eps'] = kind, eps
+    if kind == 1:
+        p['ln_p']['buf'][0, :5] = (3, 4, 7, 8, 9)
+    else:
+        p['ln_p']['buf'][0, :6] = (3, 5, 7, 8, 6 if res else -1, 9)
+    op = np.zeros(1, dtype=L.OP_DT)
+    op['kind'] = L.OP_GEMM
+    op['i'][0][:3] = (0, 1, 0)
+    op['r']['buf'][:] = -1
+    ctx.run(op, p, ptrs, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out = [(dC.cpu().numpy()[:, :N], expC), (dout.cpu().numpy()[:, :K], T)]
+    if kind == 1:
+        out += [(dmean.cpu().numpy(), mu[:, 0]), (drstd.cpu().numpy(), rstd[:, 0])]
+    return out

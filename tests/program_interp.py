@@ -202,6 +202,8 @@ class Interp:
             if int(p['a_mode']) == L.MODE_ROW:
                 ra = self._rowmap(np.arange(M), ga, int(p['a_q']), int(p['a_s']))
                 A = XA[(ra[:, None] * lda + np.arange(K)[None, :])]
+                if int(p['ln_kind']):
+                    A = self._ln_prologue(p, A, M, K, lda)
             else:
                 ra = self._rowmap(np.arange(K), ga, int(p['a_q']), int(p['a_s']))
                 A = XA[(ra[None, :] * lda + np.arange(M)[:, None])]
@@ -212,6 +214,40 @@ class Interp:
                 rb = self._rowmap(np.arange(K), gb, int(p['b_q']), int(p['b_s']))
                 Bm = XB[(rb[:, None] * ldb + np.arange(N)[None, :])]
             self._gemm_finish(p, A, Bm)
+
+    def _ln_prologue(self, p, A, M, K, lda):
+        """ghn3_gemm_problem::ln_kind: LayerNorm forward (1) / backward (2) applied to the rows of A."""
+        kind = int(p['ln_kind'])
+        assert int(p['a_gather']['buf']) < 0 and int(p['a_q']) == 0 and K % 4 == 0 and K <= 4096
+        P = [self.tail(p['ln_p'][e], np.float32) for e in range(6)]
+        idx = np.arange(M)[:, None] * lda + np.arange(K)[None, :]
+        A64 = A.astype(np.float64)
+        g = P[0][:K].astype(np.float64)
+        if kind == 1:
+            mu = A64.mean(1, keepdims=True)
+            rs = 1.0 / np.sqrt(((A64 - mu) ** 2).mean(1, keepdims=True) + float(p['ln_eps']))
+            out = (A64 - mu) * rs * g + P[1][:K].astype(np.float64)
+            if P[2] is not None:
+                P[2][:M] = mu[:, 0]
+            if P[3] is not None:
+                P[3][:M] = rs[:, 0]
+            if P[4] is not None:
+                P[4][idx] = out.astype(np.float32)
+        else:
+            assert kind == 2
+            x = P[1][idx].astype(np.float64)
+            mu = P[2][:M].astype(np.float64)[:, None]
+            rs = P[3][:M].astype(np.float64)[:, None]
+            xh = (x - mu) * rs
+            dg = A64 * g
+            s1 = dg.mean(1, keepdims=True)
+            s2 = (dg * xh).mean(1, keepdims=True)
+            out = rs * (dg - s1 - xh * s2)
+            if P[4] is not None:
+                out = out + P[4][idx].astype(np.float64)
+            if P[5] is not None:
+                P[5][idx] = out.astype(np.float32)
+        return out.astype(np.float32)
 
     def _gemm_finish(self, p, A, Bm, col_ext=None):
         if True:

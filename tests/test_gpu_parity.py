@@ -43,6 +43,16 @@ def test_gemm_cases(ctx, ctype, tol):
             assert rel_l2(extra[0], extra[1]) < tol, ('aux_out', case)
 
 
+def test_layernorm_row_prologue_of_the_small_gemm(ctx):
+    """ghn3_gemm_problem::ln_kind: LayerNorm forward / backward applied to the A rows while they are staged (exact
+    fp32): products and by-products (normalised rows, mean, rstd) against fp64 numpy."""
+    from gemm_cases import LN_CASES, run_ln_case
+    for k, case in enumerate(LN_CASES):
+        for j, (got, exp) in enumerate(run_ln_case(ctx, seed=k, **case)):
+            assert np.isfinite(got).all(), (case, j)
+            assert rel_l2(got, exp) < 3e-6, (case, j, rel_l2(got, exp))
+
+
 def _run_forward(hip, nets, gb, training=False):
     plan = hip.compile(nets, gb, training=training)
     with torch.no_grad():

@@ -267,7 +267,9 @@ struct LnRow {
     }
 };
 
-template <int AM, int BMD>
+// LN: instantiation with the LayerNorm row prologue (kept out of the plain kernel: its registers and code slowed every
+// launch from 13 to 20 us when it was a run-time branch)
+template <int AM, int BMD, bool LN>
 __global__ __launch_bounds__(1024) void gemm_small_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
     // two stages x (A image + B image); the split-K reduction buffers alias them after the K loop
     __shared__ __attribute__((aligned(16))) float lds[4 * OP_FLOATS + SW * 64];
@@ -320,15 +322,15 @@ __global__ __launch_bounds__(1024) void gemm_small_kernel(const GemmProbDev* __r
     // this operand runs here, per workgroup on its own 32 rows (32 threads per row, the same threads that stage the
     // row's chunks), instead of as a separate launch on the latency-bound chain.
     LnRow ln;
-    ln.kind = (AM == ROWM) ? P->ln_kind : 0;
-    if (AM == ROWM && ln.kind) ln.init(P, la.rptr, la.row_ok, m0 + la.r, la.c, K, n0 == 0);
+    ln.kind = (LN && AM == ROWM) ? P->ln_kind : 0;
+    f32x4 ra, rb = lb.load(0);                        // (in flight under the prologue's loads and reductions)
+    if (LN && AM == ROWM && ln.kind) ln.init(P, la.rptr, la.row_ok, m0 + la.r, la.c, K, n0 == 0);
     const int nchunks = (K + KC - 1) / KC;
-    const bool ln_cached = AM == ROWM && ln.kind && ln.cached;
-    f32x4 ra, rb = lb.load(0);
+    const bool ln_cached = LN && AM == ROWM && ln.kind && ln.cached;
     if (ln_cached) ra = ln.chunk(0);
     else {
         ra = la.load(0);
-        if (AM == ROWM && ln.kind) ra = ln.apply(ra, la.c, K);
+        if (LN && AM == ROWM && ln.kind) ra = ln.apply(ra, la.c, K);
     }
     la.store(lds, ra); lb.store(lds + OP_FLOATS, rb);
     __syncthreads();
@@ -341,7 +343,7 @@ __global__ __launch_bounds__(1024) void gemm_small_kernel(const GemmProbDev* __r
             if (ln_cached) ra = ln.chunk(c + 1);
             else {
                 ra = la.load((c + 1) * KC);
-                if (AM == ROWM && ln.kind) ra = ln.apply(ra, (c + 1) * KC + la.c, K);
+                if (LN && AM == ROWM && ln.kind) ra = ln.apply(ra, (c + 1) * KC + la.c, K);
             }
         }
         const f32x4 a = ChunkLoader<AM>::fragment(cur, w, li, lh);
@@ -389,13 +391,15 @@ __global__ __launch_bounds__(1024) void gemm_small_kernel(const GemmProbDev* __r
 
 typedef void (*small_fn)(const GemmProbDev*, int);
 static small_fn g_small[2][2] = {
-    {gemm_small_kernel<ROWM, ROWM>, gemm_small_kernel<ROWM, COLM>},
-    {gemm_small_kernel<COLM, ROWM>, gemm_small_kernel<COLM, COLM>}};
+    {gemm_small_kernel<ROWM, ROWM, false>, gemm_small_kernel<ROWM, COLM, false>},
+    {gemm_small_kernel<COLM, ROWM, false>, gemm_small_kernel<COLM, COLM, false>}};
+static small_fn g_small_ln[2] = {gemm_small_kernel<ROWM, ROWM, true>, gemm_small_kernel<ROWM, COLM, true>};
 
-int ghn3_gemm_small_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode,
+int ghn3_gemm_small_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode, int with_ln,
                            hipStream_t stream) {
     if (n_probs <= 0 || total_tiles <= 0) return GHN3_OK;
-    hipLaunchKernelGGL(g_small[a_mode][b_mode], dim3(total_tiles), dim3(64 * SW), 0, stream, d_probs, n_probs);
+    small_fn fn = (with_ln && a_mode == GHN3_MODE_ROW) ? g_small_ln[b_mode] : g_small[a_mode][b_mode];
+    hipLaunchKernelGGL(fn, dim3(total_tiles), dim3(64 * SW), 0, stream, d_probs, n_probs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("small gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

@@ -35,7 +35,7 @@ int ghn3_gemm_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, i
 
 int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int tile, int ctype, int grid_cap,
                           hipStream_t stream);
-int ghn3_gemm_small_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode,
+int ghn3_gemm_small_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode, int with_ln,
                            hipStream_t stream);
 
 int ghn3_attn_init();

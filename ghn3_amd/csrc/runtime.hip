@@ -204,7 +204,7 @@ static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
     return 64;
 }
 
-struct Launch { int a_mode, b_mode, tile, first, count, tiles; };
+struct Launch { int a_mode, b_mode, tile, first, count, tiles, with_ln; };
 
 extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_gemm_problem* problems, int n_problems,
                         void* const* bufs, int n_bufs, void* stream_) {
@@ -241,7 +241,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             for (int am = 0; am < 2; ++am)
                 for (int bm = 0; bm < 2; ++bm)
                     for (int tl : {16, 20, 24, 32, 64, 128}) {
-                        Launch L{am, bm, tl, (int)pos, 0, 0};
+                        Launch L{am, bm, tl, (int)pos, 0, 0, 0};
                         const int te = tl == 16 ? 128 : (tl == 24 || tl == 20) ? 256 : tl;   // tile edge (rows)
                         const int te_n = tl == 20 ? 128 : te;                                  // (columns)
                         for (int q = first; q < first + cnt; ++q) {
@@ -293,6 +293,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             g.lim_kind = g.lim ? p.lim_kind : 0;
                             g.alpha_amax = (tl == 16 || tl == 24 || tl == 20) ? R.get<const float>(p.alpha_amax) : nullptr;
                             g.ln_kind = p.ln_kind; g.ln_eps = p.ln_eps;
+                            if (p.ln_kind) L.with_ln = 1;
                             for (int e = 0; e < 6; ++e) g.ln_p[e] = p.ln_kind ? R.get<const float>(p.ln_p[e]) : nullptr;
                             if (p.ln_kind) {
                                 const bool ok = (p.ln_kind == 1 || p.ln_kind == 2) && p.a_mode == GHN3_MODE_ROW &&
@@ -386,7 +387,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         case GHN3_OP_GEMM:
             for (const Launch& L : op_launches[k]) {
                 if (L.tile == 32)
-                    rc = ghn3_gemm_small_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, stream);
+                    rc = ghn3_gemm_small_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, L.with_ln, stream);
                 else if (L.tile == 16 || L.tile == 24 || L.tile == 20)
                     rc = ghn3_gemm_h16d_launch(ds + L.first, L.count, L.tiles, L.tile == 16 ? 128 : L.tile == 20 ? 20 : 256,
                                                (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, (int)o.i[3],

@@ -65,10 +65,12 @@ class Program:
         # dependent chain of the program) carry GHN3_OPFLAG_SIDE and overlap with the chain on a second stream;
         # the temporaries they read are then per-layer buffers instead of reused ones.
         self.SIDE = L.OPFLAG_SIDE if side_stream else 0
-        # fuse_ln: the LayerNorms of the Graphormer layers run as row prologues of the GEMMs that consume them
-        # (forward: LN1 -> to_qkv, LN2 -> ff.net.0; backward: LN2' -> to_out dgrad, LN1' -> the next layer's ff.net.3
-        # dgrad) instead of ~95 separate launches on the dependent chain
-        self.fuse_ln = os.environ.get('GHN3_FUSE_LN', '1') != '0'
+        # fuse_ln (off by default): the LayerNorms of the Graphormer layers run as row prologues of the GEMMs that
+        # consume them (forward: LN1 -> to_qkv, LN2 -> ff.net.0; backward: LN2' -> to_out dgrad, LN1' -> the next
+        # layer's ff.net.3 dgrad) instead of ~95 separate launches.  Measured a LOSS at ghn3xlm16: the prologue's
+        # registers (123 VGPRs against 52-60) halve the occupancy of the 1024-thread workgroups, a fused GEMM takes 34 us
+        # against 13 + 6 us for the separate kernels (11.2 -> 12.2 ms per step); kept for narrower models / as a record.
+        self.fuse_ln = os.environ.get('GHN3_FUSE_LN', '0') != '0'
         # MFMA operand type of the decoder GEMMs (fc / W0 / W2, forward and backward): None = context default.
         # The Graphormer, the edge MLP and the small heads always multiply in exact fp32.
         self.decoder_ctype = decoder_ctype

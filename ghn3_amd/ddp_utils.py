@@ -100,7 +100,8 @@ class FlatGradReducer:
     """
     Mean all-reduce of the flat gradient buffer in two phases, overlapped with the backward program:
 
-        reducer.start(flat, lo, hi, wait_for=ctx.side_wait)   # range whose gradients are complete (decoder: 93 %)
+        reducer.begin()
+        reducer.start(flat, lo, hi, wait_for=ctx.side_wait)   # a range whose gradients are complete (W2: 69 %, ...)
         ... the rest of the backward runs on the current stream ...
         reducer.finish(flat)                                  # everything else, then wait
 
@@ -144,11 +145,15 @@ class FlatGradReducer:
                 piece.mul_(scale)
         self._pending = []
 
-    def start(self, flat, lo, hi, wait_for=None):
+    def begin(self):
+        """New backward: forget the ranges of the previous one."""
         self._done = []
+
+    def start(self, flat, lo, hi, wait_for=None):
+        """May be called several times per backward (one range each, begin() first)."""
         if not self.active():
             return
-        self._done = [(lo, hi)]
+        self._done.append((lo, hi))
         if not flat.is_cuda:
             self._issue(flat, lo, hi)
             return

@@ -313,9 +313,10 @@ class GHN3(nn.Module):
         return int(self._offs[lo]), int(self._offs[hi]) if hi < len(self._offs) else int(self._flat_numel)
 
     def _run_backward(self, plan, dout, reducer=None):
-        """reducer (data parallel, ddp_utils.FlatGradReducer): the backward program runs in two parts; the all-reduce
-        of the decoder gradients (93 % of the bytes at ghn3xlm16) starts as soon as the side stream has produced them
-        and overlaps with the Graphormer backward; the remaining gradients are reduced at the end."""
+        """reducer (data parallel, ddp_utils.FlatGradReducer): the backward program runs in parts (Program.bwd_parts);
+        the all-reduce of the W2 gradient (69 % of the bytes at ghn3xlm16) starts as soon as the side stream has produced
+        it, the rest of the decoder (24 %) follows, both overlap with the Graphormer backward; the remaining gradients
+        are reduced at the end."""
         prog = plan.program
         if len(prog.bwd_ops) == 0:
             raise L.Ghn3Error('this plan was compiled without a backward program (training=False)')
@@ -328,11 +329,16 @@ class GHN3(nn.Module):
         else:
             ctx = self._ctx()
             k = prog.memset_grad_op                      # (the memset placeholders live in the first part)
-            prog.bwd_ops_a[k:k + 2] = prog.bwd_ops[k:k + 2]
-            ctx.run(prog.bwd_ops_a, prog.problems, plan.bufs, stream)
-            lo, hi = self.decoder_grad_range(prog)
-            reducer.start(gflat, lo, hi, wait_for=ctx.side_wait)
-            ctx.run(prog.bwd_ops_b, prog.problems, plan.bufs, stream)
+            prog.bwd_parts[0][0][k:k + 2] = prog.bwd_ops[k:k + 2]
+            reducer.begin()
+            n_off = len(self._offs)
+            for ops, slots in prog.bwd_parts:
+                ctx.run(ops, prog.problems, plan.bufs, stream)
+                for s_lo, s_hi in slots:                 # gradients complete once the side stream has drained
+                    if s_hi > s_lo:
+                        reducer.start(gflat, int(self._offs[s_lo]),
+                                      int(self._offs[s_hi]) if s_hi < n_off else int(self._flat_numel),
+                                      wait_for=ctx.side_wait)
             reducer.finish(gflat)
         plan.gflat = gflat
         ps = self._slot_params()

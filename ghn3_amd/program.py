@@ -137,6 +137,23 @@ class Program:
             self.bwd_ops_b = self.bwd_ops[self.bwd_split:]
             # flat-gradient slots of the decoder parameters (contiguous in the parameter order)
             self.decoder_slots = (self.slot['decoder.fc.0.weight'], self.slot['bias_class.1.bias'] + 1)
+            # Data-parallel schedule: the backward program is run in parts; after part k the gradients of `slots`
+            # (half-open slot ranges) are complete once the side stream has drained, and their all-reduce may start
+            # while the next parts execute.  Part 1 ends behind the W2 weight gradient (69 % of all gradient bytes at
+            # ghn3xlm16), part 2 behind the rest of the decoder (24 %), the Graphormer backward is the last part.
+            w2 = self.slot['decoder.conv.2.weight']
+            lo, hi = self.decoder_slots
+            cuts = []
+            if 0 < self.bwd_cut_w2 < self.bwd_split:
+                cuts.append((self.bwd_cut_w2, [(w2, w2 + 1)]))
+                cuts.append((self.bwd_split, [(lo, w2), (w2 + 1, hi)]))
+            else:
+                cuts.append((self.bwd_split, [(lo, hi)]))
+            self.bwd_parts, pos = [], 0
+            for end, slots in cuts:
+                self.bwd_parts.append((np.concatenate([self.bwd_ops[pos:end], detach]), slots))
+                pos = end
+            self.bwd_parts.append((self.bwd_ops[pos:], []))
         else:
             self.bwd_ops = np.zeros(0, dtype=L.OP_DT)
         self.problems = self._pack_problems()
@@ -972,6 +989,7 @@ class Program:
         self.op(L.OP_MEMSET0, refs=((self.xbuf(self.X_GRADFLAT), 0),), ints=(-1,))
         self.memset_grad_op = 0
         self.grad_no_memset = []
+        self.bwd_cut_w2 = 0
 
         d_rows = self.wsf('d_xrows', (M + n1) * C)
         # ---- tile backward -------------------------------------------------------------------------
@@ -1168,6 +1186,7 @@ class Program:
                 # short reduction (K = rows of the group): 64x64 tiles beat 128x128 here (tests/gemm_bench.py)
                 self.gemm_op(p0, tile=64 if g['rows'] <= 1024 else 0, ctype=bct if g16 else None,
                              tag=self.TAG_D3_WGRAD, side=True)
+            self.bwd_cut_w2 = len(self._ops)             # every op that writes dW2 has been issued
             # D2 backward
             if g16 and hasattr(self, 'w0hT'):
                 # 16-bit operands: d_u (straight for the dgrad on the chain; transposed + column sums = bias

@@ -65,18 +65,23 @@ def _reducer_worker(rank, world, port, ret):
     for compress, tol in ((None, 1e-6), ('bf16', 1e-2)):
         g = base * (rank + 1)
         red = FlatGradReducer(compress=compress, chunk_bytes=1 << 18)
-        red.start(g, lo, hi)                       # "decoder" range first ...
-        g[:lo] += 0.0                              # (the rest of the backward would run here)
-        red.finish(g)                              # ... then everything else
         expect = base * (sum(range(1, world + 1)) / world)
-        oks.append(bool(torch.allclose(g, expect, rtol=tol, atol=tol * 1e-2)))
+        for it in range(2):                            # (two backward passes through one reducer)
+            g = base * (rank + 1)
+            red.begin()
+            red.start(g, 120000, 200000)               # the "W2" range first ...
+            red.start(g, lo, 120000)                   # ... the rest of the "decoder" around it ...
+            red.start(g, 200000, hi)
+            g[:lo] += 0.0                              # (the rest of the backward would run here)
+            red.finish(g)                              # ... then everything else
+            oks.append(bool(torch.allclose(g, expect, rtol=tol, atol=tol * 1e-2)))
     ret[rank] = oks
     clean_ddp()
 
 
 def test_two_phase_flat_grad_reducer_world2():
-    """FlatGradReducer (the overlapped exchange used by bench.py / GHN3._run_backward for N > 1): decoder range
-    first, the rest afterwards; fp32 and bf16-on-the-wire give the mean over ranks."""
+    """FlatGradReducer (the overlapped exchange used by bench.py / GHN3._run_backward for N > 1): the W2 range
+    first, the rest of the decoder in two pieces, everything else afterwards; fp32 and bf16-on-the-wire give the mean over ranks."""
     world = 2
     port = _free_port()
     mgr = mp.Manager()

@@ -485,8 +485,8 @@ def test_vit_b16_ghn3xlm16_matches_reference_golden(compute, tol):
 
 
 def test_split_backward_with_overlapped_gradient_reduction():
-    """The N > 1 execution path on one GPU: backward program run in two parts (GHN3_OP_DETACH), the decoder
-    gradients all-reduced (1-rank RCCL group) from a communication stream that waits on the side stream while the
+    """The N > 1 execution path on one GPU: backward program run in three parts (GHN3_OP_DETACH), the W2 and the
+    other decoder gradients all-reduced (1-rank RCCL group) from a communication stream that waits on the side stream while the
     Graphormer backward runs.  Gradients must equal the single-run path (fp32 exchange: bit-identical up to the
     atomics' order; bf16 on the wire: 2^-8)."""
     import socket
@@ -515,6 +515,9 @@ def test_split_backward_with_overlapped_gradient_reduction():
             assert err < tol, (compress, err)
             lo, hi = hip.decoder_grad_range(plan.program)
             assert 0 < lo < hi <= ref.numel() and (hi - lo) > 0.5 * ref.numel()
+        # three parts: ... W2 gradient | rest of the decoder | Graphormer
+        assert len(plan.program.bwd_parts) == 3 and sum(len(o) for o, _ in plan.program.bwd_parts) == \
+            len(plan.program.bwd_ops) + 2
     finally:
         dist.destroy_process_group()
 

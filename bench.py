@@ -249,6 +249,11 @@ def main():
                 out['cpu_baseline'] = cpu_baseline(args.model, args.cpu_sample_nodes, 32000)
             except Exception as e:                                   # never lose the GPU line
                 out['cpu_baseline'] = {'value': None, 'error': repr(e)}
+        try:                                   # RCCL's version banner (NCCL_DEBUG=VERSION) sits in the C stdio buffer:
+            import ctypes                       # flush it first so that the JSON line is the last line of stdout
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if ddp:
         dist.barrier()

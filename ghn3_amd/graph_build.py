@@ -380,9 +380,12 @@ def build_graph(model, ve_cutoff=50, reduce_graph=True, fix_weight_edges=True, f
         if 'weight' in nodes[i].name:
             A[-1, i] = 1
     np.fill_diagonal(A, 0)
-    order = _generation_order(A)
-    nodes = [nodes[i] for i in order]
-    A = A[order, :][:, order]
+    try:
+        order = _generation_order(A)
+        nodes = [nodes[i] for i in order]
+        A = A[order, :][:, order]
+    except ValueError as e:                       # e.g. tied weights: the reference keeps the unsorted order too
+        print('WARNING: topological sort failed:', e)
     if _has_base(model, 'VisionTransformer', 'Network'):
         # the positional encoding is followed by an explicit sum node (DeepNets-1M convention, graph.py:630-638)
         i = 0

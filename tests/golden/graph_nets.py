@@ -167,6 +167,32 @@ class AttnTiny(nn.Module):
         return self.head(self.norm(x).mean(1))
 
 
+class TwoHeads(nn.Module):
+    """Dict output with two heads, a weight shared by two layers (tied), BatchNorm1d / GroupNorm (no GHN-3 primitive:
+    pruned), an embedding-like parameter of the top module."""
+    expected_input_sz = 32
+
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(3, 16, 3, 2, 1)
+        self.gn = nn.GroupNorm(4, 16)
+        self.conv2 = nn.Conv2d(16, 16, 3, 1, 1, bias=False)
+        self.scale = nn.Parameter(torch.ones(1, 16, 1, 1))
+        self.fc_a = nn.Linear(16, 16)
+        self.fc_b = nn.Linear(16, 16)
+        self.fc_b.weight = self.fc_a.weight                      # tied
+        self.bn1d = nn.BatchNorm1d(16)
+        self.head = nn.Linear(16, 10)
+        self.aux_head = nn.Linear(16, 5)
+
+    def forward(self, x):
+        x = F.relu(self.gn(self.conv(x)))
+        x = self.conv2(x) * self.scale
+        x = F.adaptive_avg_pool2d(x, 1).flatten(1)
+        y = self.bn1d(self.fc_b(F.relu(self.fc_a(x))))
+        return {'out': self.head(y), 'aux': self.aux_head(x)}
+
+
 def make_vit(bases):
     """A 2-layer ViT shaped like torchvision's (conv_proj, class_token, encoder.pos_embedding, encoder.layers,
     encoder.ln, heads.head).  The encoder instance has EXACTLY the type bases['Encoder'] (the reference looks the
@@ -214,4 +240,4 @@ def local_bases():
 def all_nets(bases):
     torch.manual_seed(0)
     return {'resnet_tiny': ResNetTiny(), 'mobile_se': MobileSE(), 'alex_tiny': AlexTiny(),
-            'vit_tiny': make_vit(bases)(), 'attn_tiny': AttnTiny()}
+            'vit_tiny': make_vit(bases)(), 'attn_tiny': AttnTiny(), 'two_heads': TwoHeads()}

@@ -207,3 +207,34 @@ def test_synthetic_program_and_counts():
     # every GEMM operand obeys the ABI alignment rules
     for p in prog.problems:
         assert p['lda'] % 4 == 0 and p['ldb'] % 4 == 0 and p['A']['off'] % 16 == 0 and p['B']['off'] % 16 == 0
+
+
+def test_predict_class_layers_false_and_reduce_graph():
+    """nn.py:301-302 (fine-tuning: the classification layers are not predicted; their shape-embedding indices use the
+    GHN's own class count, ppuda ShapeEncoder) and nn.py:684-690 (reduce_graph prunes modules the graph does not
+    reference): forward vs the oracle."""
+    hip, oracle = _build(recipe.TINY_CFG, recipe.TINY_SEED, 'reference')
+    nets_h, gb_h, nets_o, gb_o = _tiny('b2')
+    prog, it, bufs, gflat = _run_program(hip, nets_h, gb_h, training=False, predict_class_layers=False)
+    out = bufs[prog.xbuf(prog.X_OUT)].view(np.float32)
+    oracle.eval()
+    with torch.no_grad():
+        _, pred_o = oracle(nets_o, gb_o, predict_class_layers=False, assign=False)
+    assert len(pred_o) == len(prog.predicted) and len(pred_o) > 0
+    assert not any(p['attr'] in ('weight', 'bias') and p['module'] is nets_h[0].fc for p in prog.predicted)
+    for k, (ind, attr, m, t) in enumerate(pred_o):
+        p = prog.predicted[k]
+        assert p['node'] == ind and p['attr'] == attr
+        got = out[p['offset']:p['offset'] + p['numel']].reshape(p['tile_shape'])
+        ref = t.numpy()
+        if ref.ndim == 3:
+            got, ref = got[:, 1:], ref[:, 1:]
+        assert rel_l2(got, ref) < 1e-5, (k, attr)
+    # reduce_graph: same predictions; a module that no graph node references loses its parameters
+    nets_r, gb_r, _, _ = _tiny('b2')
+    extra = torch.nn.Conv2d(4, 4, 3)
+    nets_r[0].add_module('unused', extra)
+    prog_r, it_r, bufs_r, _ = _run_program(hip, nets_r, gb_r, training=False, reduce_graph=True)
+    prog_f, it_f, bufs_f, _ = _run_program(hip, *_tiny('b2')[:2], training=False)
+    np.testing.assert_array_equal(bufs_r[prog_r.xbuf(prog_r.X_OUT)], bufs_f[prog_f.xbuf(prog_f.X_OUT)])
+    assert extra.weight is None and extra.bias is None

@@ -8,7 +8,7 @@ of /root/reference/train_ghn_ddp.py:87-150 with the image branch replaced by the
     for step:  nets, graphs = next(loader)       # one fresh architecture (graph) per GPU and step
                nets = ghn(nets, graphs, keep_grads=True)        # GHN3.forward, autograd-connected predictions
                loss = sum(||p||_F) ; loss.backward()            # backward program through torch.autograd
-               gradient all-reduce (N > 1) ; clip + AdamW       # flat buffers: FlatGradReducer / FusedAdamW
+               (gradient all-reduce inside backward, N > 1) ; clip + AdamW   # FlatGradReducer / FusedAdamW
 
     python examples/train_synthetic.py [--steps 20] [--model ghn3xlm16] [--nodes 256]
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 examples/train_synthetic.py
@@ -22,7 +22,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ghn3_amd import GHN3, FusedAdamW, setup_ddp, clean_ddp, avg_ddp_metric          # noqa: E402
-from ghn3_amd.ddp_utils import all_reduce_flat_grads_avg                               # noqa: E402
+from ghn3_amd.ddp_utils import FlatGradReducer                                         # noqa: E402
 from ghn3_amd.synthetic import synthetic_batch                                         # noqa: E402
 
 MODELS = {'ghn3tm8': (64, 3, 8), 'ghn3sm8': (128, 5, 16), 'ghn3lm8': (256, 12, 16), 'ghn3xlm16': (384, 24, 16)}
@@ -41,6 +41,10 @@ def main():
     ghn = GHN3(max_shape=(hid, hid, 16, 16), num_classes=1000, hid=hid, heads=heads, layers=layers, weight_norm=True,
                ve=True, layernorm=True, compute=args.compute).to(ddp.device)
     ghn.train()
+    if ddp.ddp:
+        # mean all-reduce of the flat gradient buffer inside loss.backward(), bf16 on the wire, overlapped with the
+        # Graphormer backward (the reference wraps the GHN in DistributedDataParallel, trainer.py:136)
+        ghn.grad_reducer = FlatGradReducer(compress='bf16')
     opt = FusedAdamW(ghn, lr=4e-4, weight_decay=1e-2, max_grad_norm=5.0)
     t_host = t0 = None
     for step in range(args.steps):
@@ -56,9 +60,7 @@ def main():
         #   sum(torch.norm(p, p='fro') for net in nets for p in net.parameters())   (~1000 ATen launches per step)
         loss = ghn.predicted_param_norm()
         loss.backward()
-        gflat = ghn.last_plan.gflat
-        all_reduce_flat_grads_avg(gflat)
-        gnorm = opt.step(gflat)
+        gnorm = opt.step(ghn.last_plan.gflat)          # (already averaged over the ranks by ghn.grad_reducer)
         if step % 5 == 0 or step == args.steps - 1:
             m = avg_ddp_metric(loss.detach())
             if ddp.rank == 0:

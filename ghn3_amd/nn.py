@@ -98,7 +98,7 @@ class _GHN3Function(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        grads = ctx.ghn._run_backward(ctx.plan, dout.contiguous())
+        grads = ctx.ghn._run_backward(ctx.plan, dout.contiguous(), reducer=ctx.ghn.grad_reducer)
         # The plan references the target modules (to assign into), the modules hold the predicted tensors and those
         # reference this node: dropping the plan here breaks the cycle, so a step's buffers (4 GB of workspace + 2.6 GB
         # of gradients at ghn3xlm16) are freed by reference counting instead of waiting for Python's cycle collector.
@@ -200,6 +200,9 @@ class GHN3(nn.Module):
                 nn.init.trunc_normal_(m.weight.data, std=m.weight.shape[1] ** (-0.5))
         self._names = param_names(layers, self.layernorm)
         self.last_plan = self._last_flat = None
+        # data parallel: set to a ddp_utils.FlatGradReducer and loss.backward() all-reduces the flat gradient buffer
+        # itself, overlapped with the Graphormer backward (instead of DistributedDataParallel's bucket copies)
+        self.grad_reducer = None
         self._flat = None
         self._flatten()
 

@@ -10,7 +10,7 @@ from .graph import Graph, GraphBatch
 from .nn import from_pretrained, GHN3, ConvDecoder3, SequentialMultipleInOut, norm_check, get_metadata
 from .utils import log, Logger, print_grads
 from .ddp_utils import setup_ddp, is_ddp, get_ddp_rank, clean_ddp, avg_ddp_metric, all_reduce_flat_grads
-from .optim import FusedAdamW
+from .optim import FusedAdamW, save_checkpoint
 
 __all__ = ['Graph', 'GraphBatch', 'from_pretrained', 'GHN3', 'ConvDecoder3', 'SequentialMultipleInOut', 'log', 'Logger', 'print_grads', 'norm_check', 'get_metadata',
-           'setup_ddp', 'is_ddp', 'get_ddp_rank', 'clean_ddp', 'avg_ddp_metric', 'all_reduce_flat_grads', 'FusedAdamW']
+           'setup_ddp', 'is_ddp', 'get_ddp_rank', 'clean_ddp', 'avg_ddp_metric', 'all_reduce_flat_grads', 'FusedAdamW', 'save_checkpoint']

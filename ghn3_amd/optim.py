@@ -61,3 +61,63 @@ class FusedAdamW:
         ops[2]['f'][0] = float(self.max_grad_norm or 0.0)
         ghn._ctx().run(ops, np.zeros(0, dtype=L.PROBLEM_DT), bufs, torch.cuda.current_stream().cuda_stream)
         return self.scal[0].sqrt() if clip else None
+
+    # ------------------------------------------------------------------ checkpoints (trainer.py:413-432)
+    def state_dict(self):
+        """State in the layout of ``torch.optim.AdamW.state_dict()`` over ``ghn.parameters()`` (the order the reference's
+        trainer hands to its optimizer, trainer.py:165-175), so that ``{'state_dict', 'optimizer', 'epoch', 'step'}``
+        checkpoints written by either trainer resume in the other.  The moment tensors are views of the flat buffers."""
+        ghn = self.ghn
+        slot_of = {id(p): k for k, p in enumerate(ghn._slot_params())}
+        state, order = {}, []
+        for i, p in enumerate(ghn.parameters()):
+            k = slot_of[id(p)]
+            o, n = int(ghn._offs[k]), p.numel()
+            order.append(i)
+            if self.steps > 0:
+                state[i] = {'step': torch.tensor(float(self.steps)),
+                            'exp_avg': self.exp_avg[o:o + n].view(p.shape),
+                            'exp_avg_sq': self.exp_avg_sq[o:o + n].view(p.shape)}
+        group = {'lr': self.lr, 'betas': tuple(self.betas), 'eps': self.eps, 'weight_decay': self.weight_decay,
+                 'amsgrad': False, 'maximize': False, 'foreach': None, 'capturable': False, 'differentiable': False,
+                 'fused': None, 'params': order}
+        return {'state': state, 'param_groups': [group]}
+
+    def load_state_dict(self, sd):
+        """Accepts a ``torch.optim.AdamW`` (or FusedAdamW) state dict over ``ghn.parameters()``."""
+        ghn = self.ghn
+        groups = sd['param_groups']
+        assert len(groups) == 1, 'one parameter group expected (trainer.py:175)'
+        g = groups[0]
+        self.lr, self.betas, self.eps = float(g['lr']), tuple(g['betas']), float(g['eps'])
+        self.weight_decay = float(g['weight_decay'])
+        assert not g.get('amsgrad', False), 'amsgrad is not supported'
+        params = list(ghn.parameters())
+        assert len(g['params']) == len(params), (len(g['params']), len(params))
+        slot_of = {id(p): k for k, p in enumerate(ghn._slot_params())}
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        steps = 0
+        for idx, p in zip(g['params'], params):
+            st = sd['state'].get(idx)
+            if st is None:
+                continue
+            k = slot_of[id(p)]
+            o, n = int(ghn._offs[k]), p.numel()
+            self.exp_avg[o:o + n].copy_(st['exp_avg'].reshape(-1))
+            self.exp_avg_sq[o:o + n].copy_(st['exp_avg_sq'].reshape(-1))
+            steps = max(steps, int(float(st['step'])))
+        self.steps = steps
+
+
+def save_checkpoint(path, ghn, optimizer, epoch, step, config=None):
+    """Checkpoint in the reference trainer's format (trainer.py:413-426): {'state_dict', 'optimizer', 'epoch', 'step',
+    **config}; `ghn3_amd.from_pretrained(path)` and the reference's resume code both read it."""
+    ckpt = {'state_dict': {k: v.detach().cpu() for k, v in ghn.state_dict().items()},
+            'optimizer': {'state': {i: {k: (v.detach().cpu() if torch.is_tensor(v) else v) for k, v in st.items()}
+                                    for i, st in optimizer.state_dict()['state'].items()},
+                          'param_groups': optimizer.state_dict()['param_groups']},
+            'epoch': epoch, 'step': step}
+    ckpt.update(config or {})
+    torch.save(ckpt, path)
+    return path

@@ -544,3 +544,60 @@ def test_fused_adamw_step_matches_torch():
         assert abs(float(norm) - float(norm_ref)) < 1e-4 * float(norm_ref)
         for p, r in zip(hip._slot_params(), ref):
             assert rel_l2(p.detach().cpu().numpy(), r.detach().numpy()) < 2e-6
+
+
+def test_optimizer_state_interchanges_with_torch_adamw(tmp_path):
+    """Checkpoint compatibility (trainer.py:413-432): a torch.optim.AdamW state over ghn.parameters() loads into
+    FusedAdamW (and back) and training continues identically; save_checkpoint writes the reference trainer's file
+    layout, which from_pretrained reads."""
+    from ghn3_amd import FusedAdamW, from_pretrained, save_checkpoint
+    hip, _ = make_models(T_CFG, 7)
+    params = list(hip.parameters())
+    ref = [p.detach().cpu().clone().requires_grad_(True) for p in params]
+    kw = dict(lr=2e-3, betas=(0.9, 0.95), eps=1e-8, weight_decay=0.02)
+    opt_ref = torch.optim.AdamW(ref, **kw)
+    gen = torch.Generator().manual_seed(5)
+
+    def grads():
+        gs = [torch.randn(r.shape, generator=gen) for r in ref]
+        gflat = torch.zeros_like(hip._flat)
+        slot_of = {id(p): k for k, p in enumerate(hip._slot_params())}
+        for p, g in zip(params, gs):
+            o = int(hip._offs[slot_of[id(p)]])
+            gflat[o:o + g.numel()] = g.reshape(-1).cuda()
+        for r, g in zip(ref, gs):
+            r.grad = g.clone()
+        return gflat
+
+    for _ in range(2):                                   # two reference steps build up a state
+        grads()
+        opt_ref.step()
+    with torch.no_grad():
+        for p, r in zip(params, ref):
+            p.copy_(r.cuda())
+    opt = FusedAdamW(hip, lr=1.0)                        # (hyper-parameters come from the loaded state)
+    opt.load_state_dict(opt_ref.state_dict())
+    assert opt.steps == 2 and opt.lr == kw['lr'] and opt.betas == kw['betas']
+    for _ in range(2):                                   # continue on both sides
+        gflat = grads()
+        opt_ref.step()
+        opt.step(gflat)
+    torch.cuda.synchronize()
+    for p, r in zip(params, ref):
+        assert rel_l2(p.detach().cpu().numpy(), r.detach().numpy()) < 3e-6
+    sd = opt.state_dict()
+    sd_ref = opt_ref.state_dict()
+    assert sd['param_groups'][0]['params'] == sd_ref['param_groups'][0]['params']
+    for i in sd_ref['state']:
+        assert float(sd['state'][i]['step']) == float(sd_ref['state'][i]['step']) == 4.0
+        assert rel_l2(sd['state'][i]['exp_avg'].cpu().numpy(), sd_ref['state'][i]['exp_avg'].numpy()) < 3e-6
+        assert rel_l2(sd['state'][i]['exp_avg_sq'].cpu().numpy(), sd_ref['state'][i]['exp_avg_sq'].numpy()) < 3e-6
+    opt_back = torch.optim.AdamW(ref, **kw)              # ... and back into torch
+    opt_back.load_state_dict({'state': {i: {k: (v.cpu() if torch.is_tensor(v) else v) for k, v in st.items()}
+                                        for i, st in sd['state'].items()}, 'param_groups': sd['param_groups']})
+    path = save_checkpoint(str(tmp_path / 'checkpoint.pt'), hip, opt, epoch=3, step=17, config={'config': dict(T_CFG)})
+    ck = torch.load(path, map_location='cpu')
+    assert ck['epoch'] == 3 and ck['step'] == 17 and set(ck) >= {'state_dict', 'optimizer', 'config'}
+    again = from_pretrained(path)
+    for (k, a), (_, b) in zip(sorted(again.state_dict().items()), sorted(hip.state_dict().items())):
+        assert torch.equal(a, b.cpu()), k

@@ -78,7 +78,7 @@ def diag_grads(case='b2', cfg=None, seed=None, synth=None, compute='f32'):
     hip.train()
     nets_h2 = hip(nets_h, gb_h, keep_grads=True)
     plan = hip.last_plan
-    pred_h = predicted_dict_hip(plan, plan.out)
+    pred_h = predicted_dict_hip(plan, hip._last_flat)
     loss = 0
     for k in pred_h:
         q = pred_h[k]

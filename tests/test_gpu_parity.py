@@ -601,3 +601,9 @@ def test_optimizer_state_interchanges_with_torch_adamw(tmp_path):
     again = from_pretrained(path)
     for (k, a), (_, b) in zip(sorted(again.state_dict().items()), sorted(hip.state_dict().items())):
         assert torch.equal(a, b.cpu()), k
+
+
+def test_graft_entry_smoke():
+    """The driver's smoke(): tiny forward + backward through the public API, checked against the oracle."""
+    import __graft_entry__ as g
+    g.smoke()

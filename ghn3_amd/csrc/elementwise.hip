@@ -804,17 +804,29 @@ __device__ __forceinline__ float dact_apply(float v, float z, int dact) {
     return v;
 }
 // VEC: N == ld (dense rows), N % 4 == 0, 16-byte aligned bases -> one float4 per thread and step
+// parts / n_parts / part_stride / rows_parts: the K-split partial sums of the dgrad that are not in X itself (planes
+// 1 .. of a plane-wise split): rows m < rows_parts add parts[p * part_stride + m * N + n] for p < n_parts first
+// (fixed order: the result is deterministic, unlike atomically accumulated splits).  VEC only.
 template <bool VEC>
 __global__ __launch_bounds__(256) void dact_kernel(float* __restrict__ X, const float* __restrict__ aux, int M, int N,
-                                                   int ld, int dact, float* __restrict__ amax) {
+                                                   int ld, int dact, float* __restrict__ amax,
+                                                   const float* __restrict__ parts, int n_parts, int64_t part_stride,
+                                                   int rows_parts) {
     float mx = 0.f;
     if (VEC) {
         const int64_t total4 = ((int64_t)M * N) >> 2;
+        const int64_t lim4 = parts ? ((int64_t)rows_parts * N) >> 2 : 0;
         float4* X4 = reinterpret_cast<float4*>(X);
         const float4* A4 = reinterpret_cast<const float4*>(aux);
         for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total4; e += (int64_t)gridDim.x * 256) {
             const float4 z = A4[e];
             float4 v = X4[e];
+            if (e < lim4) {
+                for (int p = 0; p < n_parts; ++p) {
+                    const float4 q = *reinterpret_cast<const float4*>(parts + (int64_t)p * part_stride + 4 * e);
+                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                }
+            }
             v.x = dact_apply(v.x, z.x, dact); v.y = dact_apply(v.y, z.y, dact);
             v.z = dact_apply(v.z, z.z, dact); v.w = dact_apply(v.w, z.w, dact);
             X4[e] = v;
@@ -832,16 +844,24 @@ __global__ __launch_bounds__(256) void dact_kernel(float* __restrict__ X, const 
     }
     if (amax) ghn3_atomic_amax(amax, mx);
 }
-int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, float* amax, hipStream_t s) {
+int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, float* amax, const float* parts, int n_parts,
+              int64_t part_stride, int rows_parts, hipStream_t s) {
     if (M <= 0 || N <= 0) return GHN3_OK;
     const bool vec = N == ld && (N % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(aux) & 15) == 0);
+    if (parts && n_parts > 0 && (!vec || (reinterpret_cast<uintptr_t>(parts) & 15) || (part_stride & 3))) {
+        ghn3_set_error("dact: partial planes need dense 16-byte aligned rows (N == ld, N %% 4 == 0)");
+        return GHN3_E_ARG;
+    }
+    if (!parts || n_parts <= 0) { parts = nullptr; n_parts = 0; }
     int64_t blocks = ((int64_t)M * N / (vec ? 4 : 1) + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (vec)
-        hipLaunchKernelGGL(dact_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, X, aux, M, N, ld, dact, amax);
+        hipLaunchKernelGGL(dact_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, s, X, aux, M, N, ld, dact, amax,
+                           parts, n_parts, part_stride, rows_parts);
     else
-        hipLaunchKernelGGL(dact_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, X, aux, M, N, ld, dact, amax);
+        hipLaunchKernelGGL(dact_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, X, aux, M, N, ld, dact, amax,
+                           parts, n_parts, part_stride, rows_parts);
     return launch_ok("dact");
 }
 

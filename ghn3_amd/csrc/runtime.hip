@@ -525,7 +525,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         }
         case GHN3_OP_DACT:
             rc = ghn3_dact(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), (int)o.i[0], (int)o.i[1], (int)o.i[2],
-                           (int)o.i[3], R.get<float>(o.r[2]), stream);
+                           (int)o.i[3], R.get<float>(o.r[2]), R.get<const float>(o.r[3]), (int)o.i[4], (int64_t)o.i[5],
+                           (int)o.i[6], stream);
             break;
         default:
             ghn3_set_error("op %d: unknown kind %d", k, o.kind);

@@ -426,8 +426,11 @@ class Program:
         # dgrad: reduction length, ghn3_gemm_problem::lim) -- and every W2 tile is streamed from HBM once per
         # family instead of once per (o, i) group.
         fam = lambda g_: self.direct16 and g_['kind'] == 'conv' and g_['i_ld'] % 8 == 0
+        # (groups the 16-bit pipeline can take -- i % 8 == 0 -- come first: their decoder rows are contiguous, which the
+        # plane-wise dgrad reduction relies on)
+        cap16 = lambda g_: self.direct16 and g_['i_ld'] % 8 == 0
         order = sorted(range(len(self.conv_groups)),
-                       key=lambda k: (self.conv_groups[k]['kind'] == 'cls',
+                       key=lambda k: (not cap16(self.conv_groups[k]), self.conv_groups[k]['kind'] == 'cls',
                                       (0, -self.conv_groups[k]['i_ld'], -self.conv_groups[k]['o'])
                                       if fam(self.conv_groups[k]) else
                                       (1, -self.conv_groups[k]['cols'], self.conv_groups[k]['o']),
@@ -1063,9 +1066,13 @@ class Program:
             # the o*i columns of a group (up to C^2 = 147456) while M x N is only rows x 8C, so the K range is
             # split into chunks (partial sums added atomically into the zeroed d_u) to fill the 256 CUs; the ReLU
             # mask is applied afterwards in place.
-            self.op(L.OP_MEMSET0, refs=(d_u,), ints=(4 * M * 8 * C,))
             bct = self.decoder_bwd_ctype
             g16 = [g for g in self.gemm_groups if g['op16']]
+            # planes: the K splits of the 16-bit dgrad write separate partial planes (plane 0 = d_u) that the DACT pass
+            # sums in a fixed order -- no atomics, no memset of d_u, deterministic gradients
+            planes = bool(g16) and os.environ.get('GHN3_DGRAD_PLANES', '1') != '0'
+            if not planes:
+                self.op(L.OP_MEMSET0, refs=(d_u,), ints=(4 * M * 8 * C,))
             if g16:
                 # 16-bit copies of the backward operands: per group d_tiles straight (dgrad A operand); for the wgrad
                 # transposed copies of d_tiles (A) and u (B) + the column sums of d_tiles = the conv.2 bias gradient.
@@ -1121,9 +1128,47 @@ class Program:
             use_rect = bool(g16) and all(g['op16'] for g in self.gemm_groups if g['rows'] >= 512) and \
                 any(g['op16'] and g['rows'] >= 512 for g in self.gemm_groups) and \
                 os.environ.get('GHN3_DGRAD_RECT', '1') != '0'
+            n_planes, rows16 = 1, 0
+            if planes:
+                big = [g for g in g16 if g['rows'] >= 512]
+                if big and use_rect:
+                    t20 = max(((g['rows'] + 255) // 256) * ((8 * C + 127) // 128) for g in big)
+                    n_planes = int(max(2, min(16, round(448.0 / t20))))
+                else:
+                    t16 = max(((g['rows'] + 127) // 128) * ((8 * C + 127) // 128) for g in g16)
+                    n_planes = int(max(2, min(16, (512 + t16 - 1) // t16)))
+                n_planes = int(max(1, min(n_planes, min(g['o'] for g in g16))))
+                rows16 = sum(g['rows'] for g in g16)
+                assert all(g['row0'] < rows16 for g in g16), 'op16 groups first'
+                d_up = self.wsf('d_u_parts', max(n_planes - 1, 1) * M * 8 * C)
             for g in self.gemm_groups:
                 fl += sum(2.0 * sb['rows'] * sb['cols'] * 8 * C for sb in g['subs'])
                 tiles = ((g['rows'] + 127) // 128) * ((8 * C + 127) // 128)
+                if planes and g['op16']:
+                    # chunk j covers the W2 rows o' in [j * oc, (j + 1) * oc): k = o' * i + i' is contiguous in the copy
+                    # of d_tiles and a multiple of the k-map period i, so A and B just start further in
+                    # (the kernel consumes whole 64-wide k tiles: a chunk is a multiple of 64 so that the next chunk's
+                    # data is never read as padding)
+                    oc = round_up((g['o'] + n_planes - 1) // n_planes, 64 // math.gcd(g['i_ld'], 64))
+                    for j in range(n_planes):
+                        k0 = j * oc * g['i_ld']
+                        kc = max(0, min(g['cols'] - k0, oc * g['i_ld']))
+                        dst = (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C) if j == 0 else \
+                            (d_up[0], d_up[1] + 4 * ((j - 1) * M + g['row0']) * 8 * C)
+                        lim = None
+                        if g['ragged'] or kc < g['cols']:
+                            lim = self.idx(np.clip(g['lim128'] - k0, 0, kc).astype(np.int32))
+                        self.gemm(self.href(g['dth'] + min(k0, g['cols'])), self.href(self.w2hT + j * oc * ms[1]), dst,
+                                  g['rows'], 8 * C, kc, g['dth_ld'], self.w2hT_ld, 8 * C, op16=True,
+                                  b_kmap=(g['i_ld'], ms[1]), lim=lim, lim_kind=2, alpha_amax=amax_t)
+                    continue
+                if planes:
+                    # (groups outside the 16-bit pipeline have i <= 4: a short reduction, one pass into plane 0)
+                    self.gemm(self.wref('d_tiles', g['tile_off']), self.pref(W2),
+                              (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),
+                              g['rows'], 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
+                              b_qs=(g['i_ld'], ms[1]))
+                    continue
                 # split K until the launch offers ~512 tiles (two 128 x 128 workgroups per CU): measured best among
                 # 512 .. 3072 (1.39 vs 1.54 ms at 2048) -- more splits only add atomics and tile-count quantisation
                 tgt = 512 if g['op16'] else 2048       # (the fp32-operand kernel likes ~2048 tiles: 8.2 vs 9.8 ms)
@@ -1146,8 +1191,12 @@ class Program:
                           g['rows'], 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
                           b_qs=(g['i_ld'], ms[1]), ksplit=ks)
             self.gemm_op(p0, ctype=bct if g16 else None, tag=self.TAG_D3_DGRAD, flops=fl, tile=20 if use_rect else 0)
-            self.op(L.OP_DACT, refs=(d_u, u, amax_u if amax_u is not None else self.NONE),
-                    ints=(M, 8 * C, 8 * C, L.DACT_RELU))
+            if planes and n_planes > 1:
+                self.op(L.OP_DACT, refs=(d_u, u, amax_u if amax_u is not None else self.NONE, d_up),
+                        ints=(M, 8 * C, 8 * C, L.DACT_RELU, n_planes - 1, M * 8 * C, rows16))
+            else:
+                self.op(L.OP_DACT, refs=(d_u, u, amax_u if amax_u is not None else self.NONE),
+                        ints=(M, 8 * C, 8 * C, L.DACT_RELU))
             # dW2 = d_tiles^T u.  16-bit bands first (one launch; every dW2 row they cover is written once, without
             # reading it), then the groups on the fp32-operand path accumulate; all on the side stream, in order.
             bands = getattr(self, 'wgrad_bands', []) if g16 else []

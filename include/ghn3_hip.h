@@ -238,7 +238,9 @@ enum ghn3_op_kind {
     /* r0=dst r1=src ; i0 = n floats ; dst += src */
     GHN3_OP_ADD = 21,
     /* in place: X[m][n] *= dact(aux[m][n]) ; r0=X r1=aux ; i: M,N,ld, dact (GHN3_DACT_*) -- the deferred
-     * epilogue of a split-K dgrad GEMM; r2 = optional device float receiving the running max |X| after masking */
+     * epilogue of a split-K dgrad GEMM; r2 = optional device float receiving the running max |X| after masking.
+     * Plane-wise splits (no atomics, deterministic): r3 = further partial planes, i4 = their number, i5 = floats between
+     * planes, i6 = rows that have them: X[m][n] = dact(X[m][n] + sum_p r3[p * i5 + m * N + n]) for m < i6 (N == ld) */
     GHN3_OP_DACT = 22,
     /* fp32 -> f16 / bf16 operand copies for GHN3_GEMM_OP16 problems (straight and / or transposed, zero padded)
      * r0=src base (fp32) r1=dst base (16-bit) r2=ghn3_cast_desc table (device) r3=dbias or absent

@@ -600,6 +600,15 @@ class Interp:
         aux = self.tail(o['r'][1], np.float32)
         ii = np.arange(M)[:, None] * ld + np.arange(N)[None, :]
         z = aux[ii].astype(np.float64)
+        n_parts, stride, rows_parts = int(o['i'][4]), int(o['i'][5]), int(o['i'][6])
+        if n_parts > 0 and int(o['r'][3]['buf']) >= 0:
+            assert N == ld
+            parts = self.tail(o['r'][3], np.float32)
+            jj = np.arange(rows_parts)[:, None] * N + np.arange(N)[None, :]
+            acc = X[ii[:rows_parts]].astype(np.float32)
+            for p_ in range(n_parts):
+                acc = acc + parts[p_ * stride + jj]
+            X[ii[:rows_parts]] = acc
         if dact == L.DACT_RELU:
             X[ii] = np.where(z > 0, X[ii], 0.0)
         else:

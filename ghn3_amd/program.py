@@ -1128,28 +1128,37 @@ class Program:
             use_rect = bool(g16) and all(g['op16'] for g in self.gemm_groups if g['rows'] >= 512) and \
                 any(g['op16'] and g['rows'] >= 512 for g in self.gemm_groups) and \
                 os.environ.get('GHN3_DGRAD_RECT', '1') != '0'
+            def splits(g):
+                """K splits of a group's dgrad: until the launch offers ~512 tiles of 128 x 128 (two workgroups per CU;
+                measured best among 512 .. 3072: more splits only add traffic and tile-count quantisation); families with
+                >= 512 rows run on 256 x 128 three-stage tiles (tile code 20, one workgroup per CU) and are split to ~1.75
+                workgroups per CU (measured plateau 5 <= ks <= 8 for 768 rows: 1.1-1.2 ms against 1.45-1.55 ms)."""
+                tiles = ((g['rows'] + 127) // 128) * ((8 * C + 127) // 128)
+                tgt = 512 if g['op16'] else 2048       # (the fp32-operand kernel likes ~2048 tiles: 8.2 vs 9.8 ms)
+                ks = int(max(2, min(64, (tgt + tiles - 1) // tiles, g['cols'] // 1024)))
+                if g['op16'] and g['rows'] >= 512 and use_rect:
+                    t20 = ((g['rows'] + 255) // 256) * ((8 * C + 127) // 128)
+                    ks = int(max(2, min(16, round(448.0 / t20), g['cols'] // 1024)))
+                return ks
+
             n_planes, rows16 = 1, 0
             if planes:
-                big = [g for g in g16 if g['rows'] >= 512]
-                if big and use_rect:
-                    t20 = max(((g['rows'] + 255) // 256) * ((8 * C + 127) // 128) for g in big)
-                    n_planes = int(max(2, min(16, round(448.0 / t20))))
-                else:
-                    t16 = max(((g['rows'] + 127) // 128) * ((8 * C + 127) // 128) for g in g16)
-                    n_planes = int(max(2, min(16, (512 + t16 - 1) // t16)))
-                n_planes = int(max(1, min(n_planes, min(g['o'] for g in g16))))
+                # every 16-bit group writes the same number of planes (its own chunk count <= 8, K = 0 problems -- zeros
+                # -- for the rest), so that one reduction pass serves all rows
+                for g in g16:
+                    g['nc'] = int(max(1, min(8, splits(g), g['o'])))
+                n_planes = max(g['nc'] for g in g16)
                 rows16 = sum(g['rows'] for g in g16)
                 assert all(g['row0'] < rows16 for g in g16), 'op16 groups first'
                 d_up = self.wsf('d_u_parts', max(n_planes - 1, 1) * M * 8 * C)
             for g in self.gemm_groups:
                 fl += sum(2.0 * sb['rows'] * sb['cols'] * 8 * C for sb in g['subs'])
-                tiles = ((g['rows'] + 127) // 128) * ((8 * C + 127) // 128)
                 if planes and g['op16']:
                     # chunk j covers the W2 rows o' in [j * oc, (j + 1) * oc): k = o' * i + i' is contiguous in the copy
                     # of d_tiles and a multiple of the k-map period i, so A and B just start further in
                     # (the kernel consumes whole 64-wide k tiles: a chunk is a multiple of 64 so that the next chunk's
                     # data is never read as padding)
-                    oc = round_up((g['o'] + n_planes - 1) // n_planes, 64 // math.gcd(g['i_ld'], 64))
+                    oc = round_up((g['o'] + g['nc'] - 1) // g['nc'], 64 // math.gcd(g['i_ld'], 64))
                     for j in range(n_planes):
                         k0 = j * oc * g['i_ld']
                         kc = max(0, min(g['cols'] - k0, oc * g['i_ld']))
@@ -1158,7 +1167,8 @@ class Program:
                         lim = None
                         if g['ragged'] or kc < g['cols']:
                             lim = self.idx(np.clip(g['lim128'] - k0, 0, kc).astype(np.int32))
-                        self.gemm(self.href(g['dth'] + min(k0, g['cols'])), self.href(self.w2hT + j * oc * ms[1]), dst,
+                        self.gemm(self.href(g['dth'] + min(k0, g['cols'])),
+                                  self.href(self.w2hT + min(j * oc, g['o']) * ms[1]), dst,
                                   g['rows'], 8 * C, kc, g['dth_ld'], self.w2hT_ld, 8 * C, op16=True,
                                   b_kmap=(g['i_ld'], ms[1]), lim=lim, lim_kind=2, alpha_amax=amax_t)
                     continue
@@ -1169,16 +1179,7 @@ class Program:
                               g['rows'], 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
                               b_qs=(g['i_ld'], ms[1]))
                     continue
-                # split K until the launch offers ~512 tiles (two 128 x 128 workgroups per CU): measured best among
-                # 512 .. 3072 (1.39 vs 1.54 ms at 2048) -- more splits only add atomics and tile-count quantisation
-                tgt = 512 if g['op16'] else 2048       # (the fp32-operand kernel likes ~2048 tiles: 8.2 vs 9.8 ms)
-                ks = int(max(2, min(64, (tgt + tiles - 1) // tiles, g['cols'] // 1024)))
-                if g['op16'] and g['rows'] >= 512 and use_rect:
-                    # families with >= 512 rows: 256 x 128 tiles with a three-stage ring (tile code 20; one workgroup
-                    # per CU), split so that the launch offers ~1.75 workgroups per CU -- measured plateau 5 <= ks <= 8
-                    # for 768 rows: 1.16-1.21 ms against 1.45-1.55 ms with 128 x 128 tiles and four splits
-                    t20 = ((g['rows'] + 255) // 256) * ((8 * C + 127) // 128)
-                    ks = int(max(2, min(16, round(448.0 / t20), g['cols'] // 1024)))
+                ks = splits(g)
                 if g['op16']:
                     # one problem per family; the K loop of a row tile stops at the largest extent of its rows
                     self.gemm(self.href(g['dth']), self.href(self.w2hT), (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),

@@ -383,8 +383,16 @@ class Program:
                 if len(key) == 4:
                     kh, kw = int(key[2]), int(key[3])
                     o_g, i_g = min(int(key[0]), ms[0]), min(int(key[1]), ms[1])
-                    g = dict(kind='conv', key=key, inds=list(inds), o=o_g, i=i_g, i_ld=i_g, kh=kh, kw=kw,
-                             cols=o_g * i_g)
+                    # input widths that are not a multiple of 8 (the 3 -> 4 channels of a stem) are padded to 8 in the
+                    # 16-bit pipeline: the group then runs with the families (forward, dgrad, wgrad bands) instead of as
+                    # three lone launches of the fp32-operand kernels; the extra tile columns (real W2 rows i' < 8) are
+                    # computed but never consumed, their gradient is written as zeros by the tile backward
+                    i_ld = i_g
+                    if self.direct16 and i_g % 8 and round_up(i_g, 8) <= ms[1] and \
+                            os.environ.get('GHN3_PAD_I8', '1') != '0':
+                        i_ld = round_up(i_g, 8)
+                    g = dict(kind='conv', key=key, inds=list(inds), o=o_g, i=i_g, i_ld=i_ld, kh=kh, kw=kw,
+                             cols=o_g * i_ld)
                     if min(kh, kw) > S:
                         # nn.py:751-753: the whole 16x16 grid is decoded and bilinearly resized to (kh, kw); the
                         # reference asserts a single node per such group.  Decoded at the grid size here; the resize
@@ -827,12 +835,12 @@ class Program:
                             if (t[2], t[3]) != (kh, kw):
                                 raise NotImplementedError('target kernel %s vs group key %s' % (str(t), str(key)))
                             add(dst, 0, base, (t[0], t[1], kh, kw), (min(t[0], g['o']), min(t[1], g['i']), kh, kw),
-                                (g['i'], 1, kw * ld, ld), (g['o'], g['i'], kh, kw), mode, scale)
+                                (g['i_ld'], 1, kw * ld, ld), (g['o'], g['i_ld'], kh, kw), mode, scale)
                         elif len(t) == 2:
                             cy, cx = kh // 2, kw // 2
                             add(dst, 0, base + (cy * kw + cx) * ld, (t[0], t[1], 1, 1),
-                                (min(t[0], g['o']), min(t[1], g['i']), 1, 1), (g['i'], 1, 0, 0),
-                                (g['o'], g['i'], 1, 1), mode, scale)
+                                (min(t[0], g['o']), min(t[1], g['i']), 1, 1), (g['i_ld'], 1, 0, 0),
+                                (g['o'], g['i_ld'], 1, 1), mode, scale)
                             if kh * kw != 1:
                                 raise NotImplementedError('2-D target from a %dx%d tile' % (kh, kw))
                         elif len(t) == 3:
@@ -843,7 +851,7 @@ class Program:
                                 raise NotImplementedError('3-D target %s from key %s' % (str(t), str(key)))
                             i_e = min(D, g['i'])
                             add(dst + D, 0, base, (1, L1 - 1, D, 1), (1, L1 - 1, i_e, 1), (0, ld, 1, 0),
-                                (1, hw, g['i'], 1), mode, scale)
+                                (1, hw, g['i_ld'], 1), mode, scale)
                             add(dst, 4, tok_off, (1, 1, D, 1), (1, 1, i_e, 1), (0, 0, 1, 0), (1, 1, i_e, 1), mode,
                                 scale)
                             predicted[-1]['tok'] = (tok_off, i_e)

@@ -260,42 +260,121 @@ int ghn3_bias_hist(float* dT, const float* dBias, const int* pair, int B, int N,
 // ------------------------------------------------------------------------------------------------
 // LayerNorm (F.layer_norm, graphormer.py:239,241 and nn.py:262-263), one wave per row.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* __restrict__ y, const float* __restrict__ x,
+// Rows of up to LN_REG * 64 channels (every released GHN-3: C <= 384) are loaded ONCE into registers -- all loads in
+// flight together -- and the statistics and the result are computed from there: on this latency-bound chain every
+// further pass over the row was another ~1 us round trip (the row was just written by a GEMM on other XCDs, so
+// even the first touch misses the local L2).  Same summation order as the wide-row loops: identical results.
+// `add` (optional): second K-half plane of the GEMM that produced x (split-K over two workgroup sets, see
+// program.py::_split_k): the row is x + add, written back to x for the later readers of the residual stream.
+#define LN_REG 8
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* __restrict__ y, float* __restrict__ x,
                                                             const float* __restrict__ g, const float* __restrict__ bta,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
-                                                            int rows, int C, float eps) {
+                                                            const float* __restrict__ add, int rows, int C, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
-    const float* xr = x + (size_t)row * C;
+    float* xr = x + (size_t)row * C;
+    float* yr = y + (size_t)row * C;
+    const float* ar = add ? add + (size_t)row * C : nullptr;
+    if (C <= LN_REG * 64) {
+        float xv[LN_REG], gv[LN_REG], bv[LN_REG];
+#pragma unroll
+        for (int j = 0; j < LN_REG; ++j) {
+            const int c = lane + 64 * j;
+            const bool in = c < C;
+            xv[j] = in ? xr[c] : 0.f;
+            if (ar) xv[j] += in ? ar[c] : 0.f;
+            gv[j] = in ? g[c] : 0.f;
+            bv[j] = in ? bta[c] : 0.f;
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_REG; ++j) if (lane + 64 * j < C) s += xv[j];
+        const float mu = wsum(s) / (float)C;
+        float v = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_REG; ++j) if (lane + 64 * j < C) { const float d = xv[j] - mu; v += d * d; }
+        const float rs = rsqrtf(wsum(v) / (float)C + eps);
+#pragma unroll
+        for (int j = 0; j < LN_REG; ++j) {
+            const int c = lane + 64 * j;
+            if (c < C) {
+                yr[c] = (xv[j] - mu) * rs * gv[j] + bv[j];
+                if (ar) xr[c] = xv[j];
+            }
+        }
+        if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
+        return;
+    }
+    if (ar) for (int c = lane; c < C; c += 64) xr[c] += ar[c];        // (each lane re-reads only its own writes)
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += xr[c];
     const float mu = wsum(s) / (float)C;
     float v = 0.f;
     for (int c = lane; c < C; c += 64) { float d = xr[c] - mu; v += d * d; }
     const float rs = rsqrtf(wsum(v) / (float)C + eps);
-    float* yr = y + (size_t)row * C;
     for (int c = lane; c < C; c += 64) yr[c] = (xr[c] - mu) * rs * g[c] + bta[c];
     if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
 }
-int ghn3_layernorm_fwd(float* y, const float* x, const float* g, const float* b, float* mean, float* rstd, int rows,
-                       int C, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, y, x, g, b, mean, rstd, rows, C,
+int ghn3_layernorm_fwd(float* y, float* x, const float* g, const float* b, float* mean, float* rstd, const float* add,
+                       int rows, int C, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, y, x, g, b, mean, rstd, add, rows, C,
                        eps);
     return launch_ok("layernorm_fwd");
 }
 
-__global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ dx, const float* __restrict__ dy,
+// `add` (optional): second K-half plane of the dgrad GEMM that produced dy; dy + add is written back to dy (the
+// LayerNorm parameter gradients read it afterwards).
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ dx, float* __restrict__ dy,
                                                             const float* __restrict__ x, const float* __restrict__ g,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
-                                                            const float* __restrict__ res, int rows, int C) {
+                                                            const float* __restrict__ res,
+                                                            const float* __restrict__ add, int rows, int C) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
     const float* xr = x + (size_t)row * C;
-    const float* gr = dy + (size_t)row * C;
+    float* gr = dy + (size_t)row * C;
+    float* dr = dx + (size_t)row * C;
+    const float* rr = res ? res + (size_t)row * C : nullptr;
+    const float* ar = add ? add + (size_t)row * C : nullptr;
     const float mu = mean[row], rs = rstd[row];
+    if (C <= LN_REG * 64) {
+        float dgv[LN_REG], xh[LN_REG], rv[LN_REG];
+#pragma unroll
+        for (int j = 0; j < LN_REG; ++j) {
+            const int c = lane + 64 * j;
+            const bool in = c < C;
+            float d = in ? gr[c] : 0.f;
+            if (ar) { d += in ? ar[c] : 0.f; if (in) gr[c] = d; }
+            dgv[j] = d * (in ? g[c] : 0.f);
+            xh[j] = in ? xr[c] : 0.f;
+            rv[j] = (rr && in) ? rr[c] : 0.f;
+        }
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < LN_REG; ++j)
+            if (lane + 64 * j < C) {
+                s1 += dgv[j];
+                s2 += dgv[j] * (xh[j] - mu) * rs;
+            }
+        s1 = wsum(s1) / (float)C;
+        s2 = wsum(s2) / (float)C;
+#pragma unroll
+        for (int j = 0; j < LN_REG; ++j) {
+            const int c = lane + 64 * j;
+            if (c < C) {
+                const float h = (xh[j] - mu) * rs;
+                float v = rs * (dgv[j] - s1 - h * s2);
+                if (rr) v += rv[j];
+                dr[c] = v;
+            }
+        }
+        return;
+    }
+    if (ar) for (int c = lane; c < C; c += 64) gr[c] += ar[c];
     float s1 = 0.f, s2 = 0.f;
     for (int c = lane; c < C; c += 64) {
         const float dg = gr[c] * g[c];
@@ -304,8 +383,6 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ 
     }
     s1 = wsum(s1) / (float)C;
     s2 = wsum(s2) / (float)C;
-    float* dr = dx + (size_t)row * C;
-    const float* rr = res ? res + (size_t)row * C : nullptr;
     for (int c = lane; c < C; c += 64) {
         const float xh = (xr[c] - mu) * rs;
         float v = rs * (gr[c] * g[c] - s1 - xh * s2);
@@ -313,9 +390,9 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ 
         dr[c] = v;
     }
 }
-int ghn3_layernorm_bwd(float* dx, const float* dy, const float* x, const float* g, const float* mean,
-                       const float* rstd, const float* res, int rows, int C, hipStream_t s) {
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dx, dy, x, g, mean, rstd, res,
+int ghn3_layernorm_bwd(float* dx, float* dy, const float* x, const float* g, const float* mean,
+                       const float* rstd, const float* res, const float* add, int rows, int C, hipStream_t s) {
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dx, dy, x, g, mean, rstd, res, add,
                        rows, C);
     return launch_ok("layernorm_bwd");
 }

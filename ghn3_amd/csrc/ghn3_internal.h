@@ -58,10 +58,10 @@ int ghn3_edge_hidden(float* hid, const float* Pfw, const float* Pbw, int V, int 
 int ghn3_edge_hidden_bwd(float* dPfw, float* dPbw, float* dhid, const float* hid, int V, int C, hipStream_t s);
 int ghn3_bias_gather(float* bias, const float* T, const int* pair, int B, int N, int H, hipStream_t s);
 int ghn3_bias_hist(float* dT, const float* dBias, const int* pair, int B, int N, int H, int V, hipStream_t s);
-int ghn3_layernorm_fwd(float* y, const float* x, const float* g, const float* b, float* mean, float* rstd,
+int ghn3_layernorm_fwd(float* y, float* x, const float* g, const float* b, float* mean, float* rstd, const float* add,
                        int rows, int C, float eps, hipStream_t s);
-int ghn3_layernorm_bwd(float* dx, const float* dy, const float* x, const float* g, const float* mean,
-                       const float* rstd, const float* res, int rows, int C, hipStream_t s);
+int ghn3_layernorm_bwd(float* dx, float* dy, const float* x, const float* g, const float* mean,
+                       const float* rstd, const float* res, const float* add, int rows, int C, hipStream_t s);
 int ghn3_ln_param_grad(float* dg, float* db, const float* dy, const float* x, const float* mean,
                        const float* rstd, int rows, int C, int accum, hipStream_t s);
 int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d_desc, int n_desc,

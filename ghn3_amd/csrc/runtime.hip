@@ -435,14 +435,15 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                 (int)o.i[0], (int)o.i[1], (int)o.i[2], (int)o.i[3], stream);
             break;
         case GHN3_OP_LAYERNORM_FWD:
-            rc = ghn3_layernorm_fwd(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const float>(o.r[2]),
+            rc = ghn3_layernorm_fwd(R.get<float>(o.r[0]), R.get<float>(o.r[1]), R.get<const float>(o.r[2]),
                                     R.get<const float>(o.r[3]), R.get<float>(o.r[4]), R.get<float>(o.r[5]),
-                                    (int)o.i[0], (int)o.i[1], o.f[0], stream);
+                                    R.get<const float>(o.r[6]), (int)o.i[0], (int)o.i[1], o.f[0], stream);
             break;
         case GHN3_OP_LAYERNORM_BWD:
-            rc = ghn3_layernorm_bwd(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const float>(o.r[2]),
+            rc = ghn3_layernorm_bwd(R.get<float>(o.r[0]), R.get<float>(o.r[1]), R.get<const float>(o.r[2]),
                                     R.get<const float>(o.r[3]), R.get<const float>(o.r[4]), R.get<const float>(o.r[5]),
-                                    R.get<const float>(o.r[6]), (int)o.i[0], (int)o.i[1], stream);
+                                    R.get<const float>(o.r[6]), R.get<const float>(o.r[7]), (int)o.i[0], (int)o.i[1],
+                                    stream);
             break;
         case GHN3_OP_LN_PARAM_GRAD:
             rc = ghn3_ln_param_grad(R.get<float>(o.r[0]), R.get<float>(o.r[1]), R.get<const float>(o.r[2]),

@@ -71,6 +71,8 @@ class Program:
         # registers (123 VGPRs against 52-60) halve the occupancy of the 1024-thread workgroups, a fused GEMM takes 34 us
         # against 13 + 6 us for the separate kernels (11.2 -> 12.2 ms per step); kept for narrower models / as a record.
         self.fuse_ln = os.environ.get('GHN3_FUSE_LN', '0') != '0'
+        self.split_k2 = os.environ.get('GHN3_SPLIT_K2', '1') != '0'       # see split_small()
+        self.split_k2_min = int(os.environ.get('GHN3_SPLIT_K2_MIN', '768'))  # (lowered by the CPU tests)
         # MFMA operand type of the decoder GEMMs (fc / W0 / W2, forward and backward): None = context default.
         # The Graphormer, the edge MLP and the small heads always multiply in exact fp32.
         self.decoder_ctype = decoder_ctype
@@ -299,6 +301,24 @@ class Program:
         if ln is not None:
             self._ln[len(self._probs) - 1] = ln
         return len(self._probs) - 1
+
+    def split_small(self, M, N, K):
+        """K split of a lone 32 x 32-tile GEMM over two workgroup sets.  A [256 x 384] output is 96 tiles on 256 CUs and
+        its K loop is bound by the fp32 MFMA rate of those 96 CUs (4 waves per SIMD take turns on the matrix core: ~1 us
+        per 128-wide K chunk); two K halves as two problems of the same launch use twice the CUs.  The second half
+        goes to a plane that the consuming LayerNorm kernel adds (and writes back), so no extra launch and a fixed
+        summation order."""
+        return self.split_k2 and not self.fuse_ln and K >= self.split_k2_min and \
+            ((M + 31) // 32) * ((N + 31) // 32) <= 128
+
+    def gemm_k2(self, A, B, C, plane, M, N, K, lda, ldb, ldc, b_mode, **epilogue):
+        """ROW-mode A.  Problem 1: columns [0, k0) with the epilogue -> C; problem 2: [k0, K) -> plane [M][N]."""
+        k0 = round_up((K + 1) // 2, 128 if K >= 512 else 4)
+        p0 = self.gemm(A, B, C, M, N, k0, lda, ldb, ldc, a_mode=L.MODE_ROW, b_mode=b_mode, **epilogue)
+        b_off = k0 if b_mode == L.MODE_ROW else k0 * ldb
+        self.gemm((A[0], A[1] + 4 * k0), (B[0], B[1] + 4 * b_off), plane, M, N, K - k0, lda, ldb, N,
+                  a_mode=L.MODE_ROW, b_mode=b_mode)
+        return p0
 
     _PROBLEM_REFS = ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim',
                      'alpha_amax')
@@ -577,6 +597,7 @@ class Program:
         # ---- Graphormer layers --------------------------------------------------------------------
         self._cast_w2()            # side stream, under the Graphormer (issued once the main stream is busy)
         x_in = x0
+        x_plane = None             # second K half of the previous layer's ff.net.3 (split_small)
         for l in range(self.Lyr):
             pre = 'gnn.%d.' % l
             sfx = '_%d' % l
@@ -597,7 +618,8 @@ class Program:
                                        m1 if train else None, r1 if train else None, h1 if train else None], 1e-5))
             else:
                 self.op(L.OP_LAYERNORM_FWD, refs=(h1, x_in, self.pref(pre + 'ln1.weight'), self.pref(pre + 'ln1.bias'),
-                                                  m1, r1), ints=(rows, C), floats=(1e-5,))
+                                                  m1, r1, x_plane or self.NONE), ints=(rows, C), floats=(1e-5,))
+                x_plane = None
                 p0 = self.gemm(h1, self.pref(pre + 'attn.to_qkv.weight'), qkv, rows, 3 * C, C, C, C, 3 * C)
             self.gemm_op(p0)
             self.op(L.OP_ATTN_FWD, refs=(o, qkv, bias, Pm if Pm is not None else self.NONE, r_nn),
@@ -616,15 +638,21 @@ class Program:
                 p0 = self.gemm(h2, self.pref(pre + 'ff.net.0.weight'), f, rows, 4 * C, C, C, C, 4 * C,
                                bias=self.pref(pre + 'ff.net.0.bias'), act=L.ACT_GELU, aux_out=z if train else None)
             self.gemm_op(p0)
-            p0 = self.gemm(f, self.pref(pre + 'ff.net.3.weight'), x_out, rows, C, 4 * C, 4 * C, 4 * C, C,
-                           bias=self.pref(pre + 'ff.net.3.bias'), residual=xmid)
+            if self.split_small(rows, C, 4 * C) and (self.layernorm or l + 1 < self.Lyr):
+                # x_out = xmid + f W3^T + b3 in two K halves; the next LayerNorm adds the second one
+                x_plane = self.wsf('x_plane', rows * C)
+                p0 = self.gemm_k2(f, self.pref(pre + 'ff.net.3.weight'), x_out, x_plane, rows, C, 4 * C, 4 * C, 4 * C, C,
+                                  L.MODE_ROW, bias=self.pref(pre + 'ff.net.3.bias'), residual=xmid)
+            else:
+                p0 = self.gemm(f, self.pref(pre + 'ff.net.3.weight'), x_out, rows, C, 4 * C, 4 * C, 4 * C, C,
+                               bias=self.pref(pre + 'ff.net.3.bias'), residual=xmid)
             self.gemm_op(p0)
             x_in = x_out
         xe = self.wsf('xe', rows * C)
         mf, rf = self.wsf('mf', rows), self.wsf('rf', rows)
         if self.layernorm:
-            self.op(L.OP_LAYERNORM_FWD, refs=(xe, x_in, self.pref('ln.weight'), self.pref('ln.bias'), mf, rf),
-                    ints=(rows, C), floats=(1e-5,))
+            self.op(L.OP_LAYERNORM_FWD, refs=(xe, x_in, self.pref('ln.weight'), self.pref('ln.bias'), mf, rf,
+                                              x_plane or self.NONE), ints=(rows, C), floats=(1e-5,))
         else:
             self._ws_names['xe'] = self._ws_names['x%d' % self.Lyr]
             xe = x_in
@@ -1371,25 +1399,46 @@ class Program:
             pending_ln1 = None
             self.gemm_op(p0)
             # FFN first linear
-            p0 = self.gemm(dz, self.pref(W1f), dhA, rows, C, 4 * C, 4 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+            dhA_p = None
+            if self.split_small(rows, C, 4 * C):
+                dhA_p = self.wsf('dhA_plane', rows * C)
+                p0 = self.gemm_k2(dz, self.pref(W1f), dhA, dhA_p, rows, C, 4 * C, 4 * C, C, C, L.MODE_COL)
+            else:
+                p0 = self.gemm(dz, self.pref(W1f), dhA, rows, C, 4 * C, 4 * C, C, C, a_mode=L.MODE_ROW,
+                               b_mode=L.MODE_COL)
             self.gemm_op(p0)
             # LN2 (+ residual branch gradient g_cur)
-            self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln2.weight'), self.gref(pre + 'ln2.bias'), dhA, xmid,
-                                              m2, r2), ints=(rows, C, 1), flags=self.SIDE)
             if self.fuse_ln:
                 # attention output projection: xmid = x_in + o Wo^T + bo; its A operand g_mid = LN2'(dhA) + g_cur is
                 # computed (and written for the wgrad / the residual path) by the GEMM's row prologue
                 p0 = self.gemm(dhA, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
                                ln=(2, [self.pref(pre + 'ln2.weight'), xmid, m2, r2, g_cur, g_mid], 0.0))
             else:
-                self.op(L.OP_LAYERNORM_BWD, refs=(g_mid, dhA, xmid, self.pref(pre + 'ln2.weight'), m2, r2, g_cur),
-                        ints=(rows, C))
+                self.op(L.OP_LAYERNORM_BWD, refs=(g_mid, dhA, xmid, self.pref(pre + 'ln2.weight'), m2, r2, g_cur,
+                                                  dhA_p or self.NONE), ints=(rows, C))
                 # attention output projection: xmid = x_in + o Wo^T + bo
                 p0 = self.gemm(g_mid, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
             self.gemm_op(p0)
             self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, self.NONE, dBias, r_nn), ints=(B, N, C, H))
-            p0 = self.gemm(dqkv, self.pref(Wq), dhB, rows, C, 3 * C, 3 * C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+            dhB_p = None
+            if self.split_small(rows, C, 3 * C):
+                dhB_p = self.wsf('dhB_plane', rows * C)
+                p0 = self.gemm_k2(dqkv, self.pref(Wq), dhB, dhB_p, rows, C, 3 * C, 3 * C, C, C, L.MODE_COL)
+            else:
+                p0 = self.gemm(dqkv, self.pref(Wq), dhB, rows, C, 3 * C, 3 * C, C, C, a_mode=L.MODE_ROW,
+                               b_mode=L.MODE_COL)
             self.gemm_op(p0)
+            if self.fuse_ln and l > 0:
+                pending_ln1 = (dhB, [self.pref(pre + 'ln1.weight'), x_in, m1, r1, g_mid, g_out])
+            else:
+                self.op(L.OP_LAYERNORM_BWD, refs=(g_out, dhB, x_in, self.pref(pre + 'ln1.weight'), m1, r1, g_mid,
+                                                  dhB_p or self.NONE), ints=(rows, C))
+            # Side-stream work of the layer in ONE group at its end (the backward buffers are per layer when the side
+            # stream is on): every main -> side hand-off is an event record that costs the main chain ~6 us, so the
+            # LayerNorm parameter gradients (which read dhA / dhB after the LayerNorm backward has added the K-half
+            # planes) and the weight gradients share one.
+            self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln2.weight'), self.gref(pre + 'ln2.bias'), dhA, xmid,
+                                              m2, r2), ints=(rows, C, 1), flags=self.SIDE)
             # weight gradients of the layer, one launch
             p0 = self.gemm(g_cur, f, self.gref(W3), C, 4 * C, rows, C, 4 * C, 4 * C, a_mode=L.MODE_COL,
                            b_mode=L.MODE_COL, accum=True, dbias=self.gref(pre + 'ff.net.3.bias'))
@@ -1402,11 +1451,6 @@ class Program:
             self.gemm_op(p0, side=True)
             self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln1.weight'), self.gref(pre + 'ln1.bias'), dhB, x_in,
                                               m1, r1), ints=(rows, C, 1), flags=self.SIDE)
-            if self.fuse_ln and l > 0:
-                pending_ln1 = (dhB, [self.pref(pre + 'ln1.weight'), x_in, m1, r1, g_mid, g_out])
-            else:
-                self.op(L.OP_LAYERNORM_BWD, refs=(g_out, dhB, x_in, self.pref(pre + 'ln1.weight'), m1, r1, g_mid),
-                        ints=(rows, C))
             g_cur = g_out                   # d x_l
         # ---- layer-0 edge bias: histogram -> table MLP backward ------------------------------------------
         E = 'gnn.0.attn.edge_embed.embed.weight'

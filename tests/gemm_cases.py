@@ -166,6 +166,14 @@ CASES += [
     dict(M=70, N=40, K=130, a_mode=L.MODE_COL, b_mode=L.MODE_ROW, tile=32, epilogue='drelu', qs_map=True),
     dict(M=50, N=90, K=70, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, tile=32, epilogue='bias_relu', qs_map=True),
     dict(M=2, N=3, K=1, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, tile=32),
+    # deep-prefetch variant (ROW-mode A, <= 256 tiles, K >= 256, K % 4 == 0, no gather / row map): ragged M / N, K tails
+    # inside and across the 128-wide chunks, trip counts that are not multiples of the prefetch depth
+    dict(M=250, N=380, K=388, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, tile=32, epilogue='full'),
+    dict(M=256, N=384, K=384, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, tile=32, epilogue='bias_relu'),
+    dict(M=100, N=76, K=1156, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, tile=32, accum=True),
+    dict(M=33, N=36, K=644, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, tile=32, epilogue='drelu'),
+    dict(M=31, N=64, K=256, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, tile=32),
+    dict(M=512, N=500, K=1152, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, tile=32),
 ]
 
 

@@ -400,7 +400,10 @@ class Interp:
 
     def op_layernorm_fwd(self, o, problems):
         rows, C = int(o['i'][0]), int(o['i'][1])
-        x = self.fview(o['r'][1], rows * C).reshape(rows, C).astype(np.float64)
+        xv = self.fview(o['r'][1], rows * C).reshape(rows, C)
+        if int(o['r'][6]['buf']) >= 0:                  # second K-half plane of the producing GEMM: summed in place
+            xv[:] = xv + self.fview(o['r'][6], rows * C).reshape(rows, C)
+        x = xv.astype(np.float64)
         g, b = self.fview(o['r'][2], C), self.fview(o['r'][3], C)
         mu = x.mean(1)
         var = x.var(1)
@@ -412,7 +415,10 @@ class Interp:
 
     def op_layernorm_bwd(self, o, problems):
         rows, C = int(o['i'][0]), int(o['i'][1])
-        dy = self.fview(o['r'][1], rows * C).reshape(rows, C).astype(np.float64)
+        dyv = self.fview(o['r'][1], rows * C).reshape(rows, C)
+        if int(o['r'][7]['buf']) >= 0:                  # second K-half plane of the producing dgrad: summed in place
+            dyv[:] = dyv + self.fview(o['r'][7], rows * C).reshape(rows, C)
+        dy = dyv.astype(np.float64)
         x = self.fview(o['r'][2], rows * C).reshape(rows, C).astype(np.float64)
         g = self.fview(o['r'][3], C).astype(np.float64)
         mu, rs = self.fview(o['r'][4], rows).astype(np.float64), self.fview(o['r'][5], rows).astype(np.float64)

@@ -354,7 +354,9 @@ def test_graph_with_more_than_1024_nodes():
     for k, p in hip.named_parameters():
         go = po[k].grad
         err = float((p.grad.cpu().double() - go.double()).norm())
-        assert err < 3e-4 * float(go.norm()) + 1e-5, (k, err, float(go.norm()))
+        # (gnn.0.attn.proj_e.2.bias has an analytically zero gradient -- softmax is shift invariant -- so both sides hold
+        # rounding noise of ~1e-5 there: absolute floor)
+        assert err < 3e-4 * float(go.norm()) + 5e-5, (k, err, float(go.norm()))
 
 
 def test_index_mode_correct_matches_oracle():

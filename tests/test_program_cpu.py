@@ -115,6 +115,23 @@ def test_compiled_programs_reproduce_oracle_forward_and_backward(case, index_mod
         assert err < 5e-5 * float(np.linalg.norm(ref)) + 1e-6, (name, err, float(np.linalg.norm(ref)))
 
 
+@pytest.mark.parametrize('case', ['b2', 'noln'])
+def test_split_k_planes_of_the_graphormer_gemms(case, monkeypatch):
+    """Program.split_small(): ff.net.3 forward, ff.net.0 dgrad and to_qkv dgrad in two K halves whose second plane the
+    consuming LayerNorm op adds (threshold lowered so that the tiny configuration takes the path the 384-wide
+    models take); same forward / gradients as the oracle."""
+    monkeypatch.setenv('GHN3_SPLIT_K2_MIN', '64')
+    cfg = dict(recipe.TINY_CFG, **(recipe.EXTRA_CASES[case][1] if case in recipe.EXTRA_CASES else {}))
+    hip, _ = _build(cfg, recipe.TINY_SEED, 'reference')
+    nets_h, gb_h, _, _ = _tiny(case)
+    prog, it, bufs, gflat = _run_program(hip, nets_h, gb_h, layernorm=hip.layernorm, weight_norm=hip.weight_norm)
+    n_fwd = sum(1 for o in prog.fwd_ops if int(o['kind']) == L.OP_LAYERNORM_FWD and int(o['r'][6]['buf']) >= 0)
+    n_bwd = sum(1 for o in prog.bwd_ops if int(o['kind']) == L.OP_LAYERNORM_BWD and int(o['r'][7]['buf']) >= 0)
+    layers = cfg['layers']
+    assert n_fwd == (layers if cfg['layernorm'] else layers - 1) and n_bwd == 2 * layers, (n_fwd, n_bwd)
+    test_compiled_programs_reproduce_oracle_forward_and_backward(case, 'reference')
+
+
 @pytest.mark.parametrize('fwd_ct,bwd_ct,tol_f,tol_g,case', [(L.CT_F16, L.CT_BF16, 1e-3, 1e-2, 'b2'),
                                                              (L.CT_F16, L.CT_F16, 1e-3, 1e-3, 'b2'),
                                                              (L.CT_BF16, L.CT_BF16, 8e-3, 1e-2, 'b2'),

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 8
+#define GHN3_ABI_VERSION 9
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -190,7 +190,9 @@ enum ghn3_op_kind {
     GHN3_OP_EDGE_HIDDEN = 4,
     /* bias[b,h,i,j] = T[pair[b,i,j]][h] ; r0=bias r1=T r2=pair ; i: B,N,H */
     GHN3_OP_BIAS_GATHER = 5,
-    /* F.layer_norm ; r0=y r1=x r2=gamma r3=beta r4=mean r5=rstd ; i: rows,C ; f0=eps */
+    /* F.layer_norm ; r0=y r1=x r2=gamma r3=beta r4=mean r5=rstd r6=addend plane or absent ; i: rows,C ; f0=eps
+     * With r6 the normalised rows are x + r6 and the sum is written back to x (r6 = second K half of the GEMM that
+     * produced x, split over two workgroup sets). */
     GHN3_OP_LAYERNORM_FWD = 6,
     /* graphormer.py:121-140 ; r0=out(B*N,C) r1=qkv(B*N,3C) r2=bias(B,H,N,N) r3=P save or absent r4=n_nodes
      * i: B,N,C,H */
@@ -219,7 +221,8 @@ enum ghn3_op_kind {
     /* segmented row sum: out[r][:] (+)= sum_{t in seg(r)} X[idx[t]][:]
      * r0=out r1=X r2=seg_ptr(int32 rows+1) r3=idx(int32) ; i: rows,C,ldx,ldo,accum */
     GHN3_OP_ROWSEG_SUM = 13,
-    /* r0=dx r1=dy r2=x r3=gamma r4=mean r5=rstd r6=residual grad or absent ; i: rows,C */
+    /* r0=dx r1=dy r2=x r3=gamma r4=mean r5=rstd r6=residual grad or absent r7=addend plane of dy or absent
+     * (dy + r7 is written back to dy) ; i: rows,C */
     GHN3_OP_LAYERNORM_BWD = 14,
     /* r0=dgamma r1=dbeta r2=dy r3=x r4=mean r5=rstd ; i: rows,C,accum */
     GHN3_OP_LN_PARAM_GRAD = 15,

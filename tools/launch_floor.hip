@@ -1,4 +1,7 @@
-// micro-benchmark: cost of dependent back-to-back kernels in one stream (not part of the product)
+// Micro-benchmark behind DESIGN.md section 6: cost of dependent back-to-back kernels in one stream on the GPU box
+// (about 3 us whatever the grid).  Not part of the product.
+//   hipcc --offload-arch=gfx950 -O2 -o tools/launch_floor tools/launch_floor.hip   (in-tree: the binary travels with the
+//   gpurun snapshot; it is git-ignored), then on the GPU box: ./tools/launch_floor
 #include <hip/hip_runtime.h>
 #include <cstdio>
 __global__ void empty_k(float* p) { if (p == nullptr) return; }

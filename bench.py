@@ -75,8 +75,8 @@ def cpu_baseline(model, sample_nodes, seed):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=10)
-    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--model', default='ghn3xlm16')
     ap.add_argument('--nodes', type=int, default=256)
     ap.add_argument('--graphs-per-gpu', type=int, default=1)

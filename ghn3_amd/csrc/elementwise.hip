@@ -899,9 +899,19 @@ __global__ __launch_bounds__(256) void dact_kernel(float* __restrict__ X, const 
             const float4 z = A4[e];
             float4 v = X4[e];
             if (e < lim4) {
-                for (int p = 0; p < n_parts; ++p) {
-                    const float4 q = *reinterpret_cast<const float4*>(parts + (int64_t)p * part_stride + 4 * e);
-                    v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w;
+                // the planes of one element: all loads in flight together (<= 7 extra planes in every program the host
+                // emits), summed in plane order
+                float4 q[7];
+#pragma unroll
+                for (int p = 0; p < 7; ++p)
+                    q[p] = p < n_parts ? *reinterpret_cast<const float4*>(parts + (int64_t)p * part_stride + 4 * e)
+                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int p = 0; p < 7; ++p)
+                    if (p < n_parts) { v.x += q[p].x; v.y += q[p].y; v.z += q[p].z; v.w += q[p].w; }
+                for (int p = 7; p < n_parts; ++p) {
+                    const float4 r = *reinterpret_cast<const float4*>(parts + (int64_t)p * part_stride + 4 * e);
+                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
                 }
             }
             v.x = dact_apply(v.x, z.x, dact); v.y = dact_apply(v.y, z.y, dact);

@@ -11,7 +11,13 @@ One "step" = one pass of the hot path over one batch of synthetic graphs per GPU
   + for N > 1: mean all-reduce of that gradient buffer over RCCL/xGMI (the DDP exchange of trainer.py:136).
 Inputs (graph tensors, index tables, GHN weights) are resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects.
+`--gpus N` with N > 1 and no RANK in the environment starts N ranks itself (fresh child processes, one per GPU, created
+before this process touches the GPU); under `python -m torch.distributed.run` the ranks are the launcher's.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline` objects, plus (N = 1)
+`forward` (forward-only time and its fraction of the 16-bit MFMA peak on algorithmic FLOPs: the north star's >= 30 %
+target), `fresh_graph_ms_per_step` (a NEW architecture compiled every step on a host thread, what train_ghn_ddp.py does)
+and `f32_mode` (the exact-fp32 configuration of the same workload).
 """
 
 import argparse
@@ -37,8 +43,9 @@ def model_cfg(name):
                 weight_norm=True, ve=True, layernorm=True)
 
 
-def cpu_baseline(model, sample_nodes, seed):
-    """Oracle (CPU restatement of the reference algorithm incl. its per-group Python loops) timed on the host."""
+def cpu_baseline(model, sample_nodes, seed, graphs=1):
+    """Oracle (CPU restatement of the reference algorithm incl. its per-group Python loops) timed on the host, by default
+    on the SAME seeded graph(s) the GPU ran (one step: ~20-40 s at ghn3xlm16 / 256 nodes)."""
     from oracle import ghn3_ref as R
     from ghn3_amd.synthetic import synthetic_batch
     # torch's CPU GEMMs stop scaling (and the many small per-group ops get slower) beyond a few dozen threads;
@@ -47,7 +54,7 @@ def cpu_baseline(model, sample_nodes, seed):
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     oracle = R.GHN3Ref(**model_cfg(model))
-    gb, nets = synthetic_batch([sample_nodes], seed)
+    gb, nets = synthetic_batch([sample_nodes] * graphs, seed)
     go = R.GraphBatchRef([R.GraphRef(g.node_feat, g.node_info, g._Adj) for g in gb.graphs])
     n_pred = sum(n.num_params() for n in nets)
 
@@ -60,30 +67,59 @@ def cpu_baseline(model, sample_nodes, seed):
     step()
     t1 = time.time() - t0
     times = [t1]
-    if t1 < 10:
+    if t1 < 5:                                   # small samples: median of three
         for _ in range(2):
             t0 = time.time()
             step()
             times.append(time.time() - t0)
     t = float(np.median(times))
     return {'value': n_pred / t, 'unit': 'predicted-params/s', 'cores': cores, 'kind': 'port',
-            'sample': '%s fwd+bwd (sum of Frobenius norms loss), one synthetic %d-node graph (%d predicted params), '
-                      'fp32, torch %s CPU ops, %d threads, %.1f s per step'
-                      % (model, sample_nodes, n_pred, torch.__version__, cores, t)}
+            'host_cpus': os.cpu_count(),
+            'sample': '%s fwd+bwd (sum of Frobenius norms loss), %d synthetic %d-node graph(s), seed %d (%d predicted '
+                      'params), fp32, torch %s CPU ops, %d threads, %.1f s per step (%d run%s)'
+                      % (model, graphs, sample_nodes, seed, n_pred, torch.__version__, cores, t, len(times),
+                         's' if len(times) > 1 else '')}
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: N fresh child processes (one rank per GPU) started BEFORE this
+    process initialises the GPU; rank 0's stdout (the JSON line) is relayed.  Never exec()s."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR='127.0.0.1',
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
+    out, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        rc = rc or p.wait()
+    sys.stdout.write(out.decode())
+    sys.stdout.flush()
+    return rc
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=30)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=10)
     ap.add_argument('--model', default='ghn3xlm16')
     ap.add_argument('--nodes', type=int, default=256)
     ap.add_argument('--graphs-per-gpu', type=int, default=1)
     # f16: decoder GEMMs on f16 operands (bf16 for the W2 backward), fp32 accumulate, everything else exact fp32 --
     # the mode the 1e-3 parity tests cover (tests/test_gpu_parity.py); f32: exact fp32 MFMA everywhere
     ap.add_argument('--compute', default=os.environ.get('GHN3_COMPUTE', 'f16'), choices=['f32', 'f16', 'bf16'])
-    ap.add_argument('--cpu-sample-nodes', type=int, default=32)
+    ap.add_argument('--cpu-sample-nodes', type=int, default=0,
+                    help='nodes of the CPU-baseline graph (0 = the same graph(s) the GPU ran)')
+    ap.add_argument('--no-extras', action='store_true',
+                    help='skip the forward-only / fresh-graph / f32-mode measurements (profiling runs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-ops', action='store_true', help='print per-op-kind time of one extra step')
     ap.add_argument('--grad-allreduce', default=os.environ.get('GHN3_GRAD_ALLREDUCE', 'bf16'),
@@ -93,9 +129,15 @@ def main():
     ap.add_argument('--force-ddp', action='store_true', help='run the N > 1 code path in a 1-rank group (testing)')
     args = ap.parse_args()
 
+    if 'RANK' not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args.gpus))        # (before any GPU call in this process)
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if world != args.gpus:
+        raise SystemExit('bench.py: --gpus %d but WORLD_SIZE=%d: start one rank per GPU (python -m torch.distributed.run '
+                         '--nproc-per-node %d ... bench.py --gpus %d) or drop RANK/WORLD_SIZE from the environment'
+                         % (args.gpus, world, args.gpus, args.gpus))
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the GHN-3 path has no CPU fallback')
@@ -127,14 +169,17 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     dout = torch.empty(prog.out_numel, dtype=torch.float32, device=dev)
 
-    def step():
-        ghn._run_forward(plan)
-        ghn._fill_bufs(plan, out=plan.out, dout=dout)
-        ctx.run(f_norm, prog.problems, plan.bufs, stream)
-        ctx.run(b_norm, prog.problems, plan.bufs, stream)
-        ghn._run_backward(plan, dout, reducer=reducer)
+    def run_step(model, pl, d_out, norms):
+        model._run_forward(pl)
+        model._fill_bufs(pl, out=pl.out, dout=d_out)
+        ctx.run(norms[0], pl.program.problems, pl.bufs, stream)
+        ctx.run(norms[1], pl.program.problems, pl.bufs, stream)
+        model._run_backward(pl, d_out, reducer=reducer)
         if ddp and reducer is None:
-            all_reduce_flat_grads(plan.gflat)
+            all_reduce_flat_grads(pl.gflat)
+
+    def step():
+        run_step(ghn, plan, dout, (f_norm, b_norm))
 
     for _ in range(args.warmup):
         step()
@@ -160,6 +205,73 @@ def main():
         dist.all_reduce(n_all, op=dist.ReduceOp.SUM)
     elapsed = float(t_all.item())
     total_pred = float(n_all.item())
+
+    extras = {}
+    if world == 1 and not args.no_extras and not args.force_ddp:
+        # (a) forward only: the north star's target is stated on the Graphormer + decoder FORWARD
+        ev0, ev1 = L.Event(), L.Event()
+        n_f = max(5, args.steps)
+        torch.cuda.synchronize()
+        ev0.record(stream)
+        for _ in range(n_f):
+            ghn._run_forward(plan)
+        ev1.record(stream)
+        fwd_ms = ev0.elapsed_ms(ev1) / n_f
+        rows = prog.B * prog.N
+        g_fl = prog.Lyr * (24.0 * rows * prog.C ** 2 + 4.0 * prog.B * prog.N ** 2 * prog.C)
+        d_fl = sum(prog.tag_flops.get(t, 0.0) for t in (prog.TAG_D3_FWD, prog.TAG_D2_FWD, prog.TAG_D1_FWD))
+        extras['forward'] = {'ms': fwd_ms, 'algorithmic_gflop': (g_fl + d_fl) / 1e9,
+                             'graphormer_gflop': g_fl / 1e9, 'decoder_gflop': d_fl / 1e9,
+                             'tflops': (g_fl + d_fl) / (fwd_ms * 1e-3) / 1e12,
+                             'frac_of_16bit_mfma_peak': (g_fl + d_fl) / (fwd_ms * 1e-3) / 1e12 / 2500.0}
+        # (b) a NEW architecture every step (train_ghn_ddp.py draws one per step): graph generation + host compile on a
+        # producer thread, two plans ahead; the GPU path is the same
+        import queue
+        import threading
+        n_fresh = max(8, min(args.steps, 30))
+        q = queue.Queue(maxsize=2)
+
+        def producer():
+            torch.cuda.set_device(local_rank)
+            for k in range(n_fresh + 2):
+                gbk, netsk = synthetic_batch([args.nodes] * args.graphs_per_gpu, seeds + 7919 * (k + 1))
+                q.put(ghn.compile(netsk, gbk, training=True))
+        th = threading.Thread(target=producer, daemon=True)
+        th.start()
+        n_fresh_pred = 0
+        for k in range(n_fresh + 2):
+            if k == 2:
+                torch.cuda.synchronize()
+                t_f = time.perf_counter()
+            pk = q.get()
+            run_step(ghn, pk, torch.empty(pk.program.out_numel, dtype=torch.float32, device=dev), pk.program.norm_ops(1.0))
+            if k >= 2:
+                n_fresh_pred += sum(p_['numel'] for p_ in pk.program.predicted)
+            del pk
+        torch.cuda.synchronize()
+        dt_f = time.perf_counter() - t_f
+        th.join()
+        extras['fresh_graph_ms_per_step'] = 1e3 * dt_f / n_fresh
+        extras['fresh_graph_value'] = n_fresh_pred / dt_f
+        # (c) the exact-fp32 configuration of the same workload
+        if args.compute != 'f32':
+            torch.manual_seed(0)
+            g32 = GHN3(**model_cfg(args.model), compute='f32').to(dev)
+            g32.train()
+            p32 = g32.compile(nets, gb, training=True)
+            n32 = p32.program.norm_ops(1.0)
+            for _ in range(2):
+                run_step(g32, p32, dout, n32)
+            torch.cuda.synchronize()
+            t32 = time.perf_counter()
+            n_32 = max(5, args.steps // 3)
+            for _ in range(n_32):
+                run_step(g32, p32, dout, n32)
+            torch.cuda.synchronize()
+            t32 = (time.perf_counter() - t32) / n_32
+            extras['f32_mode'] = {'ms_per_step': 1e3 * t32, 'value': n_pred / t32, 'dtype': 'f32',
+                                  'note': 'exact fp32 MFMA everywhere (v_mfma_f32_32x32x2_f32), same workload'}
+            del g32, p32
 
     op_breakdown = None
     phases = None
@@ -241,12 +353,16 @@ def main():
                          'kernel': 'decoder W2 grouped GEMM (fwd + dgrad + wgrad), %s MFMA operands' % args.compute,
                          'algorithmic_gflop_per_step': fl / 1e9, 'kernel_ms_per_step': ms, 'kernels': detail},
         }
+        out.update(extras)
         if op_breakdown is not None:
             out['op_breakdown_ms'] = {k: round(v[0], 3) for k, v in op_breakdown.items()}
             out['phase_ms'] = phases
         if not args.no_cpu_baseline and world == 1:      # (rank 0 at N = 1 only: the other ranks would idle)
             try:
-                out['cpu_baseline'] = cpu_baseline(args.model, args.cpu_sample_nodes, 32000)
+                if args.cpu_sample_nodes:
+                    out['cpu_baseline'] = cpu_baseline(args.model, args.cpu_sample_nodes, args.cpu_sample_nodes * 1000)
+                else:
+                    out['cpu_baseline'] = cpu_baseline(args.model, args.nodes, seeds, args.graphs_per_gpu)
             except Exception as e:                                   # never lose the GPU line
                 out['cpu_baseline'] = {'value': None, 'error': repr(e)}
         try:                                   # RCCL's version banner (NCCL_DEBUG=VERSION) sits in the C stdio buffer:

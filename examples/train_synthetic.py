@@ -22,7 +22,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ghn3_amd import GHN3, FusedAdamW, setup_ddp, clean_ddp, avg_ddp_metric          # noqa: E402
-from ghn3_amd.ddp_utils import FlatGradReducer                                         # noqa: E402
+from ghn3_amd.ddp_utils import FlatGradReducer, sync_parameters                                        # noqa: E402
 from ghn3_amd.synthetic import synthetic_batch                                         # noqa: E402
 
 MODELS = {'ghn3tm8': (64, 3, 8), 'ghn3sm8': (128, 5, 16), 'ghn3lm8': (256, 12, 16), 'ghn3xlm16': (384, 24, 16)}
@@ -42,6 +42,7 @@ def main():
                ve=True, layernorm=True, compute=args.compute).to(ddp.device)
     ghn.train()
     if ddp.ddp:
+        sync_parameters(ghn)            # rank 0's weights everywhere (DistributedDataParallel's initial broadcast)
         # mean all-reduce of the flat gradient buffer inside loss.backward(), bf16 on the wire, overlapped with the
         # Graphormer backward (the reference wraps the GHN in DistributedDataParallel, trainer.py:136)
         ghn.grad_reducer = FlatGradReducer(compress='bf16')
@@ -53,6 +54,7 @@ def main():
             t0, t_host = time.perf_counter(), 0.0
         h0 = time.perf_counter()
         graphs, nets = synthetic_batch([args.nodes], args.nodes * 1000 + step * ddp.world_size + ddp.rank)
+        ghn.zero_grad(set_to_none=True)                # (p.grad are views of the previous step's flat gradient buffer)
         nets = ghn(nets, graphs, keep_grads=True)
         if t_host is not None:
             t_host += time.perf_counter() - h0

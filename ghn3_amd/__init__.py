@@ -9,8 +9,9 @@ the DDP helpers.
 from .graph import Graph, GraphBatch
 from .nn import from_pretrained, GHN3, ConvDecoder3, SequentialMultipleInOut, norm_check, get_metadata
 from .utils import log, Logger, print_grads
-from .ddp_utils import setup_ddp, is_ddp, get_ddp_rank, clean_ddp, avg_ddp_metric, all_reduce_flat_grads
+from .ddp_utils import (setup_ddp, is_ddp, get_ddp_rank, clean_ddp, avg_ddp_metric, all_reduce_flat_grads,
+                        sync_parameters)
 from .optim import FusedAdamW, save_checkpoint
 
 __all__ = ['Graph', 'GraphBatch', 'from_pretrained', 'GHN3', 'ConvDecoder3', 'SequentialMultipleInOut', 'log', 'Logger', 'print_grads', 'norm_check', 'get_metadata',
-           'setup_ddp', 'is_ddp', 'get_ddp_rank', 'clean_ddp', 'avg_ddp_metric', 'all_reduce_flat_grads', 'FusedAdamW', 'save_checkpoint']
+           'setup_ddp', 'is_ddp', 'get_ddp_rank', 'clean_ddp', 'avg_ddp_metric', 'all_reduce_flat_grads', 'sync_parameters', 'FusedAdamW', 'save_checkpoint']

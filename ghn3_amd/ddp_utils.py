@@ -62,6 +62,18 @@ def avg_ddp_metric(metric):
     return (m / dist.get_world_size()).view_as(metric)
 
 
+def sync_parameters(ghn, src=0):
+    """Broadcast rank `src`'s GHN parameters (the flat fp32 buffer) to every rank -- what wrapping the model in
+    DistributedDataParallel does at construction (trainer.py:136).  Without it replicas stay consistent only if every
+    rank seeds identically and loads the same checkpoint."""
+    if not is_ddp() or dist.get_world_size() == 1:
+        return ghn
+    with torch.no_grad():
+        dist.broadcast(ghn._flat, src=src)
+    ghn.params_changed()
+    return ghn
+
+
 def all_reduce_flat_grads(flat, chunk_bytes=256 << 20, average=True):
     """
     In-place mean all-reduce of the flat gradient buffer in `chunk_bytes` pieces (async, then waited).

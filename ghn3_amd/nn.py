@@ -219,12 +219,15 @@ class GHN3(nn.Module):
             offs.append(total)
             total += (p.numel() + 63) // 64 * 64
         dev = ps[0].device
-        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        flat = torch.zeros(total, dtype=torch.float32, device=dev)      # (alignment gaps stay zero: AdamW walks them)
         for p, o in zip(ps, offs):
             flat[o:o + p.numel()].copy_(p.data.reshape(-1).to(torch.float32))
             p.data = flat[o:o + p.numel()].view(p.shape)
         self._flat, self._offs, self._flat_numel = flat, np.asarray(offs, dtype=np.int64), total
         self._plans = {}
+        self._shadow = None                       # 16-bit copies of the decoder weights (Program.shadow_layout)
+        self._shadow_state = None                 # (parameter version, has the transposed copies) they were cast from
+        self._param_epoch = getattr(self, '_param_epoch', 0) + 1
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -238,6 +241,34 @@ class GHN3(nn.Module):
             if k + '.weight' in sd:
                 sd['gnn.0.' + k + '.weight'] = sd.pop(k + '.weight')
         return super().load_state_dict(sd, strict=strict)
+
+    def params_changed(self):
+        """Call after writing parameters behind torch's back (through ``p.data`` / raw pointers): the 16-bit shadow
+        copies of the decoder weights are re-cast by the next forward.  In-place torch ops on the parameters
+        (optimizers, ``load_state_dict``, ``.to()``) and ``FusedAdamW.step`` are tracked automatically."""
+        self._param_epoch += 1
+
+    def _shadow_version(self):
+        w2, w0 = self.decoder.conv[2].weight, self.decoder.conv[0].weight
+        return (self._param_epoch, w2._version, w0._version, w2.data_ptr())
+
+    def _refresh_shadows(self, plan, stream):
+        """Replays Program.shadow_ops (fp32 -> 16-bit copies of W2, W2^T, W0^T) when the decoder weights changed since
+        the copies were written; otherwise every forward / backward reuses them."""
+        prog = plan.program
+        if not prog.uses_shadow:
+            return
+        if self._shadow is None:
+            nbytes = prog.shadow_layout(prog.C, prog.max_shape)['nbytes']
+            self._shadow = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
+        plan.bufs[prog.xbuf(prog.X_SHADOW)] = self._shadow.data_ptr()
+        ver = self._shadow_version()
+        types = (prog.decoder_ctype, prog.decoder_bwd_ctype)
+        st = self._shadow_state
+        if st is not None and st[0] == ver and st[2] == types and (st[1] or not prog.training):
+            return
+        self._ctx().run(prog.shadow_ops, prog.problems, plan.bufs, stream)
+        self._shadow_state = (ver, bool(prog.training), types)
 
     def fix_embed_layers(self):
         return  # the embeddings already live under gnn.0 (nn.py:174-184)
@@ -306,7 +337,9 @@ class GHN3(nn.Module):
         # Q3: random class-token rows of positional encodings (nn.py:446)
         plan.tok = torch.normal(0.0, 0.02, (prog.tok_floats,), device=dev)
         self._fill_bufs(plan, out=out)
-        self._ctx().run(prog.fwd_ops, prog.problems, plan.bufs, torch.cuda.current_stream().cuda_stream)
+        stream = torch.cuda.current_stream().cuda_stream
+        self._refresh_shadows(plan, stream)
+        self._ctx().run(prog.fwd_ops, prog.problems, plan.bufs, stream)
         plan.out = out.detach()                   # (an alias without autograd history: see _GHN3Function.backward)
         return out
 
@@ -438,7 +471,9 @@ class GHN3(nn.Module):
                     m.__dict__[key] = t
                     m._parameters[key] = t
             else:
-                target.data = t
+                # eval (nn.py:545-548): `target_param.data = tensor.clone()` -- no memory shared with the flat
+                # batch buffer, so a saved / pickled network carries its own parameters only
+                target.data = t.clone()
 
 
 def from_pretrained(ghn3_name='ghn3xlm16.pt', **kwargs):

@@ -60,6 +60,7 @@ class FusedAdamW:
             ops[2]['i'][1 + k] = _dbits(h)
         ops[2]['f'][0] = float(self.max_grad_norm or 0.0)
         ghn._ctx().run(ops, np.zeros(0, dtype=L.PROBLEM_DT), bufs, torch.cuda.current_stream().cuda_stream)
+        ghn.params_changed()                     # (the kernel wrote the parameters through raw pointers)
         return self.scal[0].sqrt() if clip else None
 
     # ------------------------------------------------------------------ checkpoints (trainer.py:413-432)

@@ -55,7 +55,7 @@ class Program:
     """See module docstring.  cfg: dict(hid, heads, layers, num_classes, max_shape)."""
 
     # extra buffer slots after the 2*P parameter / gradient pointers
-    X_WS, X_IDX, X_EDGES, X_OUT, X_DOUT, X_TOK, X_SCAL, X_GRADFLAT, X_COUNT = range(9)
+    X_WS, X_IDX, X_EDGES, X_OUT, X_DOUT, X_TOK, X_SCAL, X_GRADFLAT, X_SHADOW, X_COUNT = range(10)
 
     def __init__(self, cfg, node_infos, n_nodes, node_types, max_edge, nets, index_mode='reference',
                  training=True, predict_class_layers=True, reduce_graph=False, layernorm=True, weight_norm=True,
@@ -126,6 +126,12 @@ class Program:
         self.predict_class_layers = predict_class_layers
 
         self._layout_decoder()
+        # 16-bit shadows of the decoder weights (a separate, plan-independent program: GHN3 runs it only when the
+        # parameters changed since the shadows were written)
+        self._cast_w2()
+        if self._ops:
+            self.op(L.OP_DETACH)
+        self.shadow_ops = self._finish_ops()
         self._build_forward()
         self.fwd_ops = self._finish_ops()
         self.n_fwd_problems = len(self._probs)
@@ -143,14 +149,14 @@ class Program:
             # (half-open slot ranges) are complete once the side stream has drained, and their all-reduce may start
             # while the next parts execute.  Part 1 ends behind the W2 weight gradient (69 % of all gradient bytes at
             # ghn3xlm16), part 2 behind the rest of the decoder (24 %), the Graphormer backward is the last part.
+            # The schedule (number of parts, slot ranges = collective sizes) depends on the GHN's parameter layout ONLY,
+            # never on the rank's graph: every rank compiles a different architecture each step and mismatched
+            # collective sequences would hang RCCL.  A batch without any 2-D / 4-D weight node gets an empty first part
+            # (just the gradient memsets, which always live in part 1).
             w2 = self.slot['decoder.conv.2.weight']
             lo, hi = self.decoder_slots
-            cuts = []
-            if 0 < self.bwd_cut_w2 < self.bwd_split:
-                cuts.append((self.bwd_cut_w2, [(w2, w2 + 1)]))
-                cuts.append((self.bwd_split, [(lo, w2), (w2 + 1, hi)]))
-            else:
-                cuts.append((self.bwd_split, [(lo, hi)]))
+            cut1 = min(max(self.bwd_cut_w2, self.memset_grad_op + 2), self.bwd_split)
+            cuts = [(cut1, [(w2, w2 + 1)]), (self.bwd_split, [(lo, w2), (w2 + 1, hi)])]
             self.bwd_parts, pos = [], 0
             for end, slots in cuts:
                 self.bwd_parts.append((np.concatenate([self.bwd_ops[pos:end], detach]), slots))
@@ -198,7 +204,7 @@ class Program:
     def href(self, off_halfs):
         return (self.xbuf(self.X_WS), 2 * int(off_halfs))
 
-    def cast16(self, src_base, items, dbias=None, flags=0, grid_cap=0, amax=None):
+    def cast16(self, src_base, items, dbias=None, flags=0, grid_cap=0, amax=None, dst_base=None):
         """One GHN3_OP_CAST16 over `items` = dicts(src_off [floats from src_base], rows, cols, ld_src,
         straight=(off_halfs, ld, ctype) | None, transposed=(off_halfs, ld, ctype) | None, colsum=(q, s) | None)."""
         descs = np.zeros(len(items), dtype=L.CAST_DT)
@@ -234,7 +240,7 @@ class Program:
             D['block_start'] = blocks
             blocks += ((it['rows'] + 63) // 64) * ((it['cols'] + 63) // 64)
         if blocks:
-            self.op(L.OP_CAST16, refs=(src_base, (self.xbuf(self.X_WS), 0), self.idx(descs),
+            self.op(L.OP_CAST16, refs=(src_base, dst_base or (self.xbuf(self.X_WS), 0), self.idx(descs),
                                        dbias if dbias is not None else self.NONE,
                                        amax if amax is not None else self.NONE), ints=(len(items), blocks, grid_cap),
                     flags=flags)
@@ -519,31 +525,52 @@ class Program:
         self.n1_clsb = self.n1 - self.n1_plain
         self.oned_src = np.asarray(rows, dtype=np.int32)
 
+    @staticmethod
+    def shadow_layout(C, max_shape):
+        """Offsets (16-bit elements) of the persistent 16-bit copies of the decoder weights inside the GHN-owned shadow
+        buffer (X_SHADOW) and its size in bytes: W2 [C^2][8C] (forward B operand), W2^T [8C][C^2 + 64] (dgrad B operand)
+        and W0^T [4C][8C] (D2 dgrad B operand).  Depends on the model only, never on the batch."""
+        n_w2 = int(max_shape[0]) * int(max_shape[1])
+        w2hT_ld = round_up(n_w2, 64) + 64
+        w2h = 0
+        w2hT = round_up(w2h + n_w2 * 8 * C + 128, 128)
+        w0hT = round_up(w2hT + 8 * C * w2hT_ld + 128, 128)
+        end = round_up(w0hT + 4 * C * 8 * C + 128, 128)
+        return dict(w2h=w2h, w2hT=w2hT, w2hT_ld=w2hT_ld, w0hT=w0hT, nbytes=2 * end)
+
+    def sref(self, off_halfs):
+        return (self.xbuf(self.X_SHADOW), 2 * int(off_halfs))
+
     def _cast_w2(self):
         """16-bit operand copies of decoder.conv.2.weight: W2 [C^2][8C] (forward B operand) and its transpose
-        [8C][C^2 + 64] (dgrad B operand, backward type); one pass over W2 writes both.  It depends on nothing but
-        the parameters, so it is the first op of the program and runs on the side stream under the Graphormer."""
+        [8C][C^2 + 64] (dgrad B operand, backward type); one pass over W2 writes both.  They depend on nothing but
+        the parameters: the ops form their own program (Program.shadow_ops) that writes a persistent buffer owned by
+        the model; GHN3 replays it only after the parameters changed (optimizer step, load_state_dict), on the side
+        stream under the Graphormer, and every forward in between reuses the copies (was 1.65 ms / 3.6 GB per step)."""
         C, ms = self.C, self.max_shape
         for g in self.gemm_groups:
             g['op16'] = self.direct16 and g['i_ld'] % 8 == 0
-        if not any(g['op16'] for g in self.gemm_groups):
+        self.uses_shadow = any(g['op16'] for g in self.gemm_groups)
+        if not self.uses_shadow:
             return
         fct, bct = self.decoder_ctype, self.decoder_bwd_ctype
         n_w2 = ms[0] * ms[1]
-        self.w2h = self.ws16('w2h', n_w2 * 8 * C)
+        lay = self.shadow_layout(C, ms)
+        self.w2h = lay['w2h']
         item = dict(src_off=0, rows=n_w2, cols=8 * C, ld_src=8 * C, straight=(self.w2h, 8 * C, fct))
         if self.training:
-            self.w2hT_ld = round_up(n_w2, 64) + 64
-            self.w2hT = self.ws16('w2hT', 8 * C * self.w2hT_ld)
+            self.w2hT_ld = lay['w2hT_ld']
+            self.w2hT = lay['w2hT']
             item['transposed'] = (self.w2hT, self.w2hT_ld, bct)
+        shadow = (self.xbuf(self.X_SHADOW), 0)
         self.cast16(self.pref('decoder.conv.2.weight'), [item], flags=self.SIDE,
-                    grid_cap=int(os.environ.get('GHN3_W2CAST_CAP', '512')) if self.SIDE else 0)
+                    grid_cap=int(os.environ.get('GHN3_W2CAST_CAP', '512')) if self.SIDE else 0, dst_base=shadow)
         if self.training and (4 * C) % 64 == 0:
             # decoder.conv.0.weight^T [4C][8C] (backward type): B operand of the D2 dgrad
-            self.w0hT = self.ws16('w0hT', 4 * C * 8 * C)
+            self.w0hT = lay['w0hT']
             self.cast16(self.pref('decoder.conv.0.weight'),
                         [dict(src_off=0, rows=8 * C, cols=4 * C, ld_src=4 * C, transposed=(self.w0hT, 8 * C, bct))],
-                        flags=self.SIDE)
+                        flags=self.SIDE, dst_base=shadow)
 
     # ------------------------------------------------------------------ forward
     def _build_forward(self):
@@ -595,7 +622,6 @@ class Program:
         self.op(L.OP_BIAS_GATHER, refs=(bias, T, pair), ints=(B, N, H))
 
         # ---- Graphormer layers --------------------------------------------------------------------
-        self._cast_w2()            # side stream, under the Graphormer (issued once the main stream is busy)
         x_in = x0
         x_plane = None             # second K half of the previous layer's ff.net.3 (split_small)
         for l in range(self.Lyr):
@@ -717,7 +743,7 @@ class Program:
                 fl += sum(2.0 * sb['rows'] * sb['cols'] * 8 * C for sb in g['subs'])   # algorithmic: own extents only
                 if g['op16']:
                     # one problem per family: all its rows share every W2 tile; ragged column extents via `lim`
-                    self.gemm(self.href(self.uh + g['row0'] * 8 * C), self.href(self.w2h),
+                    self.gemm(self.href(self.uh + g['row0'] * 8 * C), self.sref(self.w2h),
                               self.wref('tiles', g['tile_off']),
                               g['rows'], g['cols'], 8 * C, 8 * C, 8 * C, g['ld'], b_qs=(g['i_ld'], ms[1]),
                               bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1],
@@ -1204,7 +1230,7 @@ class Program:
                         if g['ragged'] or kc < g['cols']:
                             lim = self.idx(np.clip(g['lim128'] - k0, 0, kc).astype(np.int32))
                         self.gemm(self.href(g['dth'] + min(k0, g['cols'])),
-                                  self.href(self.w2hT + min(j * oc, g['o']) * ms[1]), dst,
+                                  self.sref(self.w2hT + min(j * oc, g['o']) * ms[1]), dst,
                                   g['rows'], 8 * C, kc, g['dth_ld'], self.w2hT_ld, 8 * C, op16=True,
                                   b_kmap=(g['i_ld'], ms[1]), lim=lim, lim_kind=2, alpha_amax=amax_t)
                     continue
@@ -1218,7 +1244,7 @@ class Program:
                 ks = splits(g)
                 if g['op16']:
                     # one problem per family; the K loop of a row tile stops at the largest extent of its rows
-                    self.gemm(self.href(g['dth']), self.href(self.w2hT), (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),
+                    self.gemm(self.href(g['dth']), self.sref(self.w2hT), (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),
                               g['rows'], 8 * C, g['cols'], g['dth_ld'], self.w2hT_ld, 8 * C, ksplit=ks, op16=True,
                               b_kmap=(g['i_ld'], ms[1]), lim=self.idx(g['lim128']) if g['ragged'] else None,
                               lim_kind=2, alpha_amax=amax_t)
@@ -1292,7 +1318,7 @@ class Program:
                 p0 = self.gemm(self.href(duhT), self.href(thT), self.gref(W0), 8 * C, 4 * C, Mp, Mp, Mp, 4 * C,
                                accum=True, op16=True, alpha_amax=amax_u)
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D2_BWD, side=True, flops=2.0 * 8 * C * 4 * C * M)
-                p0 = self.gemm(self.href(duh), self.href(self.w0hT), d_t, M, 4 * C, 8 * C, 8 * C, 8 * C, 4 * C,
+                p0 = self.gemm(self.href(duh), self.sref(self.w0hT), d_t, M, 4 * C, 8 * C, 8 * C, 8 * C, 4 * C,
                                dact=L.DACT_RELU, aux_in=t, op16=True, alpha_amax=amax_u)
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D2_BWD)
             else:

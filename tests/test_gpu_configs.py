@@ -1,0 +1,231 @@
+"""
+GPU parity tests at the widths BASELINE.json's configurations actually run (`pytest -m gpu`, MI355X box):
+
+  * ghn3xlm16 (C=384, L=24, H=16, head dim 24) in the benchmarked f16 mode: forward AND backward against the CPU
+    oracle on synthetic graphs the oracle finishes in seconds -- B=1 and a ragged B=2 batch (quirk Q1 of the
+    reference's dense/sparse indexing, config 5: two graphs per GPU);
+  * ghn3lm8 (C=256, L=12, H=16, head dim 16), config 3;
+  * ghn3tm8 at 128 nodes (config 2) in f32 / f16 / bf16 operand modes;
+  * the exact bench workload (ghn3xlm16, one 256-node graph, f16): size-independent properties -- finite gradients,
+    bit-identical results of repeated runs, f16-mode flat gradient within 1e-3 of the exact-fp32 mode per parameter;
+  * the integer prologue (degrees, input distance, fw/bw pair ids): bit-exact (north star: "bit-exact for node-index
+    gathers").
+
+Tolerance: north star 1e-3 relative (per-tensor relative L2), gradients of parameters whose gradient is analytically
+zero (softmax shift invariance) get an absolute floor.
+"""
+
+import numpy as np
+import pytest
+import torch
+
+from util_parity import rel_l2, make_models, synthetic_case, predicted_dict_hip
+
+pytestmark = pytest.mark.gpu
+
+CFGS = {
+    'ghn3tm8': dict(max_shape=(64, 64, 16, 16), num_classes=1000, hid=64, heads=8, layers=3),
+    'ghn3lm8': dict(max_shape=(256, 256, 16, 16), num_classes=1000, hid=256, heads=16, layers=12),
+    'ghn3xlm16': dict(max_shape=(384, 384, 16, 16), num_classes=1000, hid=384, heads=16, layers=24),
+}
+
+
+def _cfg(name):
+    return dict(CFGS[name], weight_norm=True, ve=True, layernorm=True)
+
+
+def _fwd_bwd_vs_oracle(name, nodes, seed, compute, tol_f, tol_g):
+    hip, oracle = make_models(_cfg(name), 7, compute=compute)
+    nets_h, gb_h, nets_o, gb_o = synthetic_case(nodes, seed)
+    hip.train()
+    nets_h = hip(nets_h, gb_h, keep_grads=True)
+    loss = hip.predicted_param_norm()
+    loss.backward()
+    torch.cuda.synchronize()
+    oracle.train()
+    nets_o, pred_o = oracle(nets_o, gb_o, keep_grads=True)
+    loss_o = sum(torch.norm(t, p='fro') for (_, _, _, t) in pred_o)
+    loss_o.backward()
+    assert abs(loss.item() - loss_o.item()) < 1e-4 * abs(loss_o.item()), (loss.item(), loss_o.item())
+    pred_h = predicted_dict_hip(hip.last_plan, hip.last_plan.out)
+    assert len(pred_h) == len(pred_o)
+    worst_f = 0.0
+    for k, (ind, attr, m, t) in enumerate(pred_o):
+        e = rel_l2(pred_h[k].detach().cpu(), t.detach())
+        worst_f = max(worst_f, e)
+        assert e < tol_f, (k, attr, tuple(t.shape), e)
+    po = dict(oracle.named_parameters())
+    worst_g = 0.0
+    for k, p in hip.named_parameters():
+        go = po[k].grad
+        assert p.grad is not None and torch.isfinite(p.grad).all(), k
+        err = float((p.grad.cpu().double() - go.double()).norm())
+        worst_g = max(worst_g, err / (float(go.norm()) + 1e-4))
+        assert err < tol_g * float(go.norm()) + 1e-5, (k, err, float(go.norm()))
+    print('%s %s nodes=%s: worst forward rel-L2 %.2e, worst gradient rel-L2 %.2e' % (name, compute, nodes, worst_f,
+                                                                                    worst_g))
+
+
+@pytest.mark.parametrize('nodes,seed', [([40], 40000), ([28, 36], 36000)])
+def test_ghn3xlm16_f16_forward_backward_vs_oracle(nodes, seed):
+    """The benchmarked model and mode (ghn3xlm16, f16 decoder operands with power-of-two scaled gradient copies, 256 x 128
+    partial-plane dgrad, band wgrad): per-parameter gradients and every predicted tensor against the oracle.  B = 2 with
+    different node counts exercises quirk Q1 at XL width (config 5: two graphs per GPU)."""
+    _fwd_bwd_vs_oracle('ghn3xlm16', nodes, seed, 'f16', 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize('nodes,seed', [([48], 48000), ([25, 40], 41000)])
+def test_ghn3lm8_f16_forward_backward_vs_oracle(nodes, seed):
+    """Config 3's model: ghn3lm8 (C = 256, 12 layers, 16 heads of 16) forward + backward vs the oracle."""
+    _fwd_bwd_vs_oracle('ghn3lm8', nodes, seed, 'f16', 1e-3, 1e-3)
+
+
+@pytest.mark.parametrize('compute,tol_f,tol_g', [('f32', 2e-5, 3e-4), ('f16', 1e-3, 1e-3), ('bf16', 8e-3, 1.5e-2)])
+def test_ghn3tm8_128_nodes_forward_backward_vs_oracle(compute, tol_f, tol_g):
+    """Config 2: ghn3tm8 forward + backward on a synthetic 128-node graph.  bf16 operands are the throughput option of
+    that config: their error (2^-8 operand rounding through three chained GEMMs) is stated here, not hidden -- they do
+    not meet the 1e-3 gate, the f16 mode (same MFMA rate) does."""
+    _fwd_bwd_vs_oracle('ghn3tm8', [128], 128000, compute, tol_f, tol_g)
+
+
+def test_integer_prologue_is_bit_exact():
+    """graphormer.py:229-237: degrees of A == 1, A[0, :] and the (fw, bw) pair index -- integer work, bit-exact."""
+    hip, _ = make_models(_cfg('ghn3tm8'), 7)
+    nets_h, gb_h, _, gb_o = synthetic_case([70, 33], 7000)
+    plan = hip.compile(nets_h, gb_h, training=False)
+    with torch.no_grad():
+        hip._run_forward(plan)
+    torch.cuda.synchronize()
+    prog = plan.program
+    B, N, V = prog.B, prog.N, prog.V
+    A = gb_o.edges                                                     # (B, N, N) int64, zero padded
+    assert tuple(A.shape) == (B, N, N)
+
+    def ws_int(name, count):
+        off = prog._ws_names[name]
+        return plan.ws[off:off + 4 * count].view(torch.int32).cpu().numpy()
+    deg_in = torch.clip((A == 1).long().sum(1), 0, 100).numpy().astype(np.int32)
+    deg_out = torch.clip((A == 1).long().sum(2), 0, 100).numpy().astype(np.int32)
+    dist0 = torch.clip(A[:, 0, :], 0, 1000).numpy().astype(np.int32)
+    pair = (A * V + A.permute(0, 2, 1)).numpy().astype(np.int32)
+    np.testing.assert_array_equal(ws_int('deg_in', B * N).reshape(B, N), deg_in)
+    np.testing.assert_array_equal(ws_int('deg_out', B * N).reshape(B, N), deg_out)
+    np.testing.assert_array_equal(ws_int('dist0', B * N).reshape(B, N), dist0)
+    np.testing.assert_array_equal(ws_int('pair', B * N * N).reshape(B, N, N), pair)
+
+
+def _bench_step(hip, plan, dout):
+    from ghn3_amd import _lib as L
+    prog = plan.program
+    f_norm, b_norm = prog.norm_ops(1.0)
+    ctx = L.context(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    hip._run_forward(plan)
+    hip._fill_bufs(plan, out=plan.out, dout=dout)
+    ctx.run(f_norm, prog.problems, plan.bufs, stream)
+    ctx.run(b_norm, prog.problems, plan.bufs, stream)
+    hip._run_backward(plan, dout)
+    torch.cuda.synchronize()
+    return plan.out.clone(), plan.gflat.clone(), float(plan.scal[:4].view(torch.float32)[0])
+
+
+def test_bench_workload_properties_at_full_size():
+    """bench.py's default workload (ghn3xlm16, one seeded 256-node synthetic graph, f16 mode, loss = sum of Frobenius
+    norms): properties that hold without the oracle at full size."""
+    from ghn3_amd import GHN3
+    from ghn3_amd.synthetic import synthetic_batch
+    res = {}
+    for compute in ('f16', 'f32'):
+        torch.manual_seed(0)
+        hip = GHN3(**_cfg('ghn3xlm16'), compute=compute).to('cuda')
+        hip.train()
+        gb, nets = synthetic_batch([256], 256000)
+        plan = hip.compile(nets, gb, training=True)
+        dout = torch.empty(plan.program.out_numel, dtype=torch.float32, device='cuda')
+        runs = [_bench_step(hip, plan, dout) for _ in range(2 if compute == 'f16' else 1)]
+        res[compute] = (hip, plan, runs)
+        n_pred = sum(p['numel'] for p in plan.program.predicted)
+        assert n_pred == nets[0].num_params()
+    hip, plan, runs = res['f16']
+    out, gflat, loss = runs[0]
+    preds = plan.program.predicted
+    # (1) every predicted element and every gradient is finite
+    for p in preds:
+        assert torch.isfinite(out[p['offset']:p['offset'] + p['numel']]).all()
+    assert torch.isfinite(gflat).all() and np.isfinite(loss)
+    # (2) determinism: a second run of the same plan gives the same bits (forward, loss, flat gradient)
+    out2, gflat2, loss2 = runs[1]
+    for p in preds:
+        assert torch.equal(out[p['offset']:p['offset'] + p['numel']], out2[p['offset']:p['offset'] + p['numel']])
+    assert loss == loss2
+    assert torch.equal(gflat, gflat2), 'flat gradient differs between two runs: %d of %d floats' % (
+        int((gflat != gflat2).sum()), gflat.numel())
+    # (3) f16 operand mode against the exact-fp32 mode: per predicted tensor and per parameter gradient within 1e-3
+    hip32, plan32, runs32 = res['f32']
+    out32, g32, loss32 = runs32[0]
+    assert abs(loss - loss32) < 1e-4 * abs(loss32)
+    worst = 0.0
+    for p in preds:
+        a = out[p['offset']:p['offset'] + p['numel']]
+        b = out32[p['offset']:p['offset'] + p['numel']]
+        e = float((a - b).norm() / b.norm())
+        worst = max(worst, e)
+        assert e < 1e-3, (p['attr'], p['shape'], e)
+    worst_g = 0.0
+    for name, off in zip(plan.program.names, hip._offs):
+        n = dict(hip.named_parameters())[name].numel()
+        a, b = gflat[int(off):int(off) + n], g32[int(off):int(off) + n]
+        err, ref = float((a - b).norm()), float(b.norm())
+        worst_g = max(worst_g, err / (ref + 1e-4))
+        assert err < 1e-3 * ref + 1e-5, (name, err, ref)
+    print('bench workload f16 vs f32 mode: worst forward %.2e, worst gradient %.2e' % (worst, worst_g))
+
+
+def test_shadow_copies_follow_the_parameters():
+    """The 16-bit copies of the decoder weights persist across forwards (Program.shadow_ops runs only when the weights
+    changed): a forward after an optimizer step / an in-place parameter update must see the new weights, a forward
+    without one must not re-cast."""
+    from ghn3_amd import FusedAdamW
+    hip, _ = make_models(_cfg('ghn3tm8'), 7, compute='f16')
+    hip.train()
+    nets_h, gb_h, _, _ = synthetic_case([48], 4800)
+    plan = hip.compile(nets_h, gb_h, training=True)
+    a = hip._run_forward(plan).clone()
+    state = hip._shadow_state
+    b = hip._run_forward(plan).clone()
+    assert hip._shadow_state is state                      # no re-cast
+    for p in plan.program.predicted:
+        assert torch.equal(a[p['offset']:p['offset'] + p['numel']], b[p['offset']:p['offset'] + p['numel']])
+    # in-place torch update of the W2 weights -> tracked through the tensor version
+    with torch.no_grad():
+        hip.decoder.conv[2].weight.mul_(1.5)
+    c = hip._run_forward(plan).clone()
+    assert hip._shadow_state is not state
+    ref = GHN3_like(hip, 'f16')
+    d = ref._run_forward(ref.compile(nets_h, gb_h, training=True))
+    torch.cuda.synchronize()
+    for p in plan.program.predicted:
+        assert torch.equal(c[p['offset']:p['offset'] + p['numel']], d[p['offset']:p['offset'] + p['numel']])
+    # fused optimizer step (raw-pointer writes) -> tracked through params_changed()
+    opt = FusedAdamW(hip, lr=1e-2)
+    dout = torch.randn(plan.program.out_numel, device='cuda') * 1e-3
+    hip._run_backward(plan, dout)
+    state = hip._shadow_state
+    opt.step(plan.gflat)
+    e = hip._run_forward(plan).clone()
+    assert hip._shadow_state is not state
+    ref = GHN3_like(hip, 'f16')
+    f = ref._run_forward(ref.compile(nets_h, gb_h, training=True))
+    torch.cuda.synchronize()
+    for p in plan.program.predicted:
+        assert torch.equal(e[p['offset']:p['offset'] + p['numel']], f[p['offset']:p['offset'] + p['numel']])
+
+
+def GHN3_like(hip, compute):
+    """A fresh model (fresh shadows) with the same weights."""
+    from ghn3_amd import GHN3
+    cfg = dict(max_shape=hip.max_shape, num_classes=hip.num_classes, hid=hip.hid, heads=hip.heads, layers=hip.layers,
+               weight_norm=hip.weight_norm, ve=hip.ve, layernorm=hip.layernorm)
+    m = GHN3(**cfg, compute=compute)
+    m.load_state_dict({k: v.detach().cpu().clone() for k, v in hip.state_dict().items()})
+    return m.to('cuda').train()

@@ -50,7 +50,10 @@ def _run_program(hip, nets, gb, training=True, **prog_kw):
                                    ).astype(np.float32).view(np.uint8)
     bufs[prog.xbuf(prog.X_SCAL)] = np.zeros(256 + 4 * max(prog.n_seg, 1) + 64, dtype=np.uint8)
     bufs[prog.xbuf(prog.X_GRADFLAT)] = gflat
+    if prog.uses_shadow:
+        bufs[prog.xbuf(prog.X_SHADOW)] = np.zeros(prog.shadow_layout(prog.C, prog.max_shape)['nbytes'], dtype=np.uint8)
     it = Interp(bufs)
+    it.run(prog.shadow_ops, prog.problems)      # (GHN3._refresh_shadows: only when the parameters changed)
     it.run(prog.fwd_ops, prog.problems)
     return prog, it, bufs, gflat
 

@@ -13,11 +13,11 @@ export GHN3_NO_SIDE_STREAM=1
 OUT=gpurun_out/${TAG}_pmc_xl_f16.txt
 STEPS=2; WARM=1
 : > $OUT
-echo "# GHN3_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline (ghn3xlm16 N=256, f16 mode; side stream serialised so that counters are per kernel); sums over the $((STEPS+WARM)) steps of the run" >> $OUT
+echo "# GHN3_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-extras (ghn3xlm16 N=256, f16 mode; side stream serialised so that counters are per kernel); sums over the $((STEPS+WARM)) steps of the run" >> $OUT
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   name=$(echo $set | cut -d' ' -f1)
   rm -rf /tmp/pmc_$name
-  timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_$name -o r -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline > /tmp/pmc_bench.json 2> /tmp/pmc_err.log
+  timeout 600 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_$name -o r -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-extras > /tmp/pmc_bench.json 2> /tmp/pmc_err.log
   cp /tmp/pmc_bench.json /tmp/pmc_bench_$name.json
   DB=$(find /tmp/pmc_$name -name "*.db" | head -1)
   if [ -n "$DB" ]; then

@@ -9,7 +9,7 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 STEPS=5; WARM=2
 rm -rf /tmp/prof_$TAG
-CMD="python3 bench.py --compute $CT --steps $STEPS --warmup $WARM --no-cpu-baseline"
+CMD="python3 bench.py --compute $CT --steps $STEPS --warmup $WARM --no-cpu-baseline --no-extras"
 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$TAG -o r -- $CMD > gpurun_out/${TAG}_bench_under_rocprof_xl_$CT.json 2> /tmp/prof_err.log
 DB=$(find /tmp/prof_$TAG -name "*.db" | head -1)
 if [ -z "$DB" ]; then echo "no db"; tail -5 /tmp/prof_err.log; exit 1; fi

@@ -12,7 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libghn3_hip.so')
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 # ---- numpy mirrors of the C structs -------------------------------------------------------------
 REF_DT = np.dtype([('buf', '<i4'), ('_pad', '<i4'), ('off', '<i8')])
@@ -22,15 +22,16 @@ _INT_NAMES = ('M', 'N', 'K', 'lda', 'ldb', 'ldc', 'a_mode', 'b_mode', 'a_q', 'a_
 PROBLEM_DT = np.dtype([(n, REF_DT) for n in _REF_NAMES] + [(n, '<i4') for n in _INT_NAMES] +
                       [('alpha', '<f4'), ('ksplit', '<i4'), ('b_kq', '<i4'), ('b_ks', '<i4'), ('lim', REF_DT), ('lim_kind', '<i4'),
                        ('_pad2', '<i4'), ('alpha_amax', REF_DT), ('ln_p', REF_DT, 6), ('ln_kind', '<i4'),
-                       ('ln_eps', '<f4')])
+                       ('ln_eps', '<f4'), ('B2', REF_DT), ('x3_slice', '<i4'), ('_pad3', '<i4')])
 TILE_DT = np.dtype([('dst_off', '<i8'), ('src_off', '<i8'), ('S', '<i8', 4), ('T', '<i4', 4), ('E', '<i4', 4),
                     ('R', '<i4', 4), ('src_buf', '<i4'), ('mode', '<i4'), ('scale', '<f4'), ('_pad', '<i4')])
 CAST_DT = np.dtype([('src_off', '<i8'), ('dst_off', '<i8'), ('dstT_off', '<i8'), ('rows', '<i4'), ('cols', '<i4'),
                     ('ld_src', '<i4'), ('ld_dst', '<i4'), ('ld_dstT', '<i4'), ('flags', '<u4'), ('bias_q', '<i4'),
-                    ('bias_s', '<i4'), ('block_start', '<i4'), ('bias_off', '<i4'), ('src_q', '<i4'), ('src_s', '<i4')])
+                    ('bias_s', '<i4'), ('block_start', '<i4'), ('bias_off', '<i4'), ('src_q', '<i4'), ('src_s', '<i4'),
+                    ('lo_off', '<i8')])
 OP_DT = np.dtype([('kind', '<i4'), ('flags', '<i4'), ('i', '<i8', 8), ('f', '<f4', 4), ('r', REF_DT, 14)])
-assert REF_DT.itemsize == 16 and PROBLEM_DT.itemsize == 400 and TILE_DT.itemsize == 112 and OP_DT.itemsize == 312
-assert CAST_DT.itemsize == 72
+assert REF_DT.itemsize == 16 and PROBLEM_DT.itemsize == 424 and TILE_DT.itemsize == 112 and OP_DT.itemsize == 312
+assert CAST_DT.itemsize == 80
 
 MODE_ROW, MODE_COL = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
@@ -38,8 +39,10 @@ DACT_NONE, DACT_RELU, DACT_GELU = 0, 1, 2
 GEMM_ACCUM = 1
 GEMM_BIASGRAD = 2
 GEMM_OP16 = 4
+GEMM_X3 = 8
 CAST_STRAIGHT, CAST_TRANSPOSED, CAST_STRAIGHT_BF16, CAST_TRANSPOSED_BF16, CAST_COLSUM, CAST_SCALED = 1, 2, 4, 8, 16, 32
 CAST_TIGHT = 64
+CAST_SPLIT = 128
 CT_F32, CT_F16, CT_BF16 = 0, 1, 2
 COMPUTE_TYPES = {'f32': CT_F32, 'f16': CT_F16, 'bf16': CT_BF16}
 

@@ -270,7 +270,8 @@ int ghn3_bias_hist(float* dT, const float* dBias, const int* pair, int B, int N,
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* __restrict__ y, float* __restrict__ x,
                                                             const float* __restrict__ g, const float* __restrict__ bta,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
-                                                            const float* __restrict__ add, int rows, int C, float eps) {
+                                                            const float* __restrict__ add, int n_add, int64_t add_stride,
+                                                            int rows, int C, float eps) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -284,7 +285,8 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* __restrict__ 
             const int c = lane + 64 * j;
             const bool in = c < C;
             xv[j] = in ? xr[c] : 0.f;
-            if (ar) xv[j] += in ? ar[c] : 0.f;
+            if (ar)
+                for (int p = 0; p < n_add; ++p) xv[j] += in ? ar[p * add_stride + c] : 0.f;     // (plane order: fixed)
             gv[j] = in ? g[c] : 0.f;
             bv[j] = in ? bta[c] : 0.f;
         }
@@ -307,7 +309,12 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* __restrict__ 
         if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
         return;
     }
-    if (ar) for (int c = lane; c < C; c += 64) xr[c] += ar[c];        // (each lane re-reads only its own writes)
+    if (ar)
+        for (int c = lane; c < C; c += 64) {                          // (each lane re-reads only its own writes)
+            float v = xr[c];
+            for (int p = 0; p < n_add; ++p) v += ar[p * add_stride + c];
+            xr[c] = v;
+        }
     float s = 0.f;
     for (int c = lane; c < C; c += 64) s += xr[c];
     const float mu = wsum(s) / (float)C;
@@ -318,9 +325,10 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* __restrict__ 
     if (lane == 0) { if (mean) mean[row] = mu; if (rstd) rstd[row] = rs; }
 }
 int ghn3_layernorm_fwd(float* y, float* x, const float* g, const float* b, float* mean, float* rstd, const float* add,
-                       int rows, int C, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, y, x, g, b, mean, rstd, add, rows, C,
-                       eps);
+                       int n_add, int64_t add_stride, int rows, int C, float eps, hipStream_t s) {
+    if (add && n_add <= 0) n_add = 1;
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, y, x, g, b, mean, rstd, add, n_add,
+                       add_stride, rows, C, eps);
     return launch_ok("layernorm_fwd");
 }
 
@@ -331,7 +339,8 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ 
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd,
                                                             const float* __restrict__ res,
-                                                            const float* __restrict__ add, int rows, int C) {
+                                                            const float* __restrict__ add, int n_add, int64_t add_stride,
+                                                            int rows, int C) {
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
     const int lane = threadIdx.x & 63;
@@ -348,7 +357,10 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ 
             const int c = lane + 64 * j;
             const bool in = c < C;
             float d = in ? gr[c] : 0.f;
-            if (ar) { d += in ? ar[c] : 0.f; if (in) gr[c] = d; }
+            if (ar) {
+                for (int p = 0; p < n_add; ++p) d += in ? ar[p * add_stride + c] : 0.f;
+                if (in) gr[c] = d;
+            }
             dgv[j] = d * (in ? g[c] : 0.f);
             xh[j] = in ? xr[c] : 0.f;
             rv[j] = (rr && in) ? rr[c] : 0.f;
@@ -374,7 +386,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ 
         }
         return;
     }
-    if (ar) for (int c = lane; c < C; c += 64) gr[c] += ar[c];
+    if (ar)
+        for (int c = lane; c < C; c += 64) {
+            float v = gr[c];
+            for (int p = 0; p < n_add; ++p) v += ar[p * add_stride + c];
+            gr[c] = v;
+        }
     float s1 = 0.f, s2 = 0.f;
     for (int c = lane; c < C; c += 64) {
         const float dg = gr[c] * g[c];
@@ -391,9 +408,11 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ 
     }
 }
 int ghn3_layernorm_bwd(float* dx, float* dy, const float* x, const float* g, const float* mean,
-                       const float* rstd, const float* res, const float* add, int rows, int C, hipStream_t s) {
+                       const float* rstd, const float* res, const float* add, int n_add, int64_t add_stride, int rows,
+                       int C, hipStream_t s) {
+    if (add && n_add <= 0) n_add = 1;
     hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, dx, dy, x, g, mean, rstd, res, add,
-                       rows, C);
+                       n_add, add_stride, rows, C);
     return launch_ok("layernorm_bwd");
 }
 
@@ -975,6 +994,7 @@ __device__ __forceinline__ unsigned short cast_bf16(float x) {
     u += 0x7fffu + ((u >> 16) & 1u);              // round to nearest even (finite inputs)
     return (unsigned short)(u >> 16);
 }
+__device__ __forceinline__ float bf16_back(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 
@@ -1000,7 +1020,8 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
     const int c4 = (tid & 15) * 4, rr = tid >> 4;
     const float* S = src + D.src_off;
     const bool st = D.flags & GHN3_CAST_STRAIGHT, trn = D.flags & GHN3_CAST_TRANSPOSED;
-    const bool st_bf = D.flags & GHN3_CAST_STRAIGHT_BF16, tr_bf = D.flags & GHN3_CAST_TRANSPOSED_BF16;
+    const bool split = D.flags & GHN3_CAST_SPLIT;   // bf16 hi + lo copies (GHN3_GEMM_X3 operands)
+    const bool st_bf = (D.flags & GHN3_CAST_STRAIGHT_BF16) || split, tr_bf = (D.flags & GHN3_CAST_TRANSPOSED_BF16) || split;
     const float sc = ((D.flags & GHN3_CAST_SCALED) && amax) ? ghn3_pow2_scale(*amax) : 1.f;
     const int rows_w = (D.flags & GHN3_CAST_TIGHT) ? ((D.rows + 7) & ~7) : 0x7fffffff;   // transposed rows written
 
@@ -1042,6 +1063,12 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
             if (st_bf) { h[0] = cast_bf16(v[i].x); h[1] = cast_bf16(v[i].y); h[2] = cast_bf16(v[i].z); h[3] = cast_bf16(v[i].w); }
             else { h[0] = cast_f16(v[i].x); h[1] = cast_f16(v[i].y); h[2] = cast_f16(v[i].z); h[3] = cast_f16(v[i].w); }
             *reinterpret_cast<us4*>(Dd + (int64_t)r * D.ld_dst + c0 + c4) = h;
+            if (split) {
+                us4 l;
+                l[0] = cast_bf16(v[i].x - bf16_back(h[0])); l[1] = cast_bf16(v[i].y - bf16_back(h[1]));
+                l[2] = cast_bf16(v[i].z - bf16_back(h[2])); l[3] = cast_bf16(v[i].w - bf16_back(h[3]));
+                *reinterpret_cast<us4*>(Dd + D.lo_off + (int64_t)r * D.ld_dst + c0 + c4) = l;
+            }
         }
     }
     if (trn) {
@@ -1060,6 +1087,30 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
     __syncthreads();
     if (trn) {
         unsigned short* Dt = dst + D.dstT_off;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int p = tid + 256 * i;
+            const int col = p >> 3, rp = (p & 7) * 8;
+            if (c0 + col >= D.cols || r0 + rp >= rows_w) continue;
+            us8 h;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) h[e] = tr[rp + e][col];
+            *reinterpret_cast<us8*>(Dt + (int64_t)(c0 + col) * D.ld_dstT + r0 + rp) = h;
+        }
+    }
+    if (trn && split) {
+        // second round through the staging tile: the lo halves (x - hi, both known to the thread that loaded x)
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = rr + 16 * i;
+            tr[r][c4] = cast_bf16(v[i].x - bf16_back(cast_bf16(v[i].x)));
+            tr[r][c4 + 1] = cast_bf16(v[i].y - bf16_back(cast_bf16(v[i].y)));
+            tr[r][c4 + 2] = cast_bf16(v[i].z - bf16_back(cast_bf16(v[i].z)));
+            tr[r][c4 + 3] = cast_bf16(v[i].w - bf16_back(cast_bf16(v[i].w)));
+        }
+        __syncthreads();
+        unsigned short* Dt = dst + D.dstT_off + D.lo_off;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             const int p = tid + 256 * i;

@@ -25,6 +25,7 @@ struct GemmProbDev {
     int ln_kind;               // row prologue of A (ghn3_gemm_problem::ln_kind), small-problem kernel only
     float ln_eps;
     const float* ln_p[6];
+    const void* B2;            // GHN3_GEMM_X3: the bf16 lo copy of B (B itself points at the hi copy)
 };
 
 
@@ -35,6 +36,10 @@ int ghn3_gemm_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, i
 
 int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int tile, int ctype, int grid_cap,
                           hipStream_t stream);
+int ghn3_gemm_x3_init();
+int ghn3_gemm_x3_tile(int code, int slice, int* bm, int* bn);
+int ghn3_gemm_x3_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int code, int slice,
+                        hipStream_t stream);
 int ghn3_gemm_small_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode, int with_ln,
                            hipStream_t stream);
 
@@ -59,9 +64,10 @@ int ghn3_edge_hidden_bwd(float* dPfw, float* dPbw, float* dhid, const float* hid
 int ghn3_bias_gather(float* bias, const float* T, const int* pair, int B, int N, int H, hipStream_t s);
 int ghn3_bias_hist(float* dT, const float* dBias, const int* pair, int B, int N, int H, int V, hipStream_t s);
 int ghn3_layernorm_fwd(float* y, float* x, const float* g, const float* b, float* mean, float* rstd, const float* add,
-                       int rows, int C, float eps, hipStream_t s);
+                       int n_add, int64_t add_stride, int rows, int C, float eps, hipStream_t s);
 int ghn3_layernorm_bwd(float* dx, float* dy, const float* x, const float* g, const float* mean,
-                       const float* rstd, const float* res, const float* add, int rows, int C, hipStream_t s);
+                       const float* rstd, const float* res, const float* add, int n_add, int64_t add_stride, int rows,
+                       int C, hipStream_t s);
 int ghn3_ln_param_grad(float* dg, float* db, const float* dy, const float* x, const float* mean,
                        const float* rstd, int rows, int C, int accum, hipStream_t s);
 int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d_desc, int n_desc,

@@ -100,6 +100,8 @@ extern "C" int ghn3_ctx_create(ghn3_ctx** out) {
     if (rc) return rc;
     rc = ghn3_attn_init();
     if (rc) return rc;
+    rc = ghn3_gemm_x3_init();
+    if (rc) return rc;
     rc = ctx_reserve(c, 1024);
     if (rc) return rc;
     *out = c;
@@ -185,6 +187,8 @@ struct Resolver {
 // tile code 32 = the latency-optimised small-problem kernel (gemm_small.hip, exact fp32): chosen when a problem
 // cannot fill the chip with 64x64 tiles and its K loop is short enough for one workgroup to split four ways.
 static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
+    // split-bf16 kernel (gemm_x3.hip): one instantiation per (tile, K slice) -> composite bucket code
+    if (p.flags & GHN3_GEMM_X3) return 4000 + 10 * (((forced >= 40 && forced <= 42) ? forced : 40) - 40) + p.x3_slice / 64;
     if (p.ln_kind) return 32;                       // the row prologue lives in the small-problem kernel
     if (p.flags & GHN3_GEMM_OP16) {
         // tile codes 16 / 24 = the 16-bit-operand kernel with 128 x 128 / 256 x 256 tiles.  The big tile has twice
@@ -204,7 +208,7 @@ static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
     return 64;
 }
 
-struct Launch { int a_mode, b_mode, tile, first, count, tiles, with_ln; };
+struct Launch { int a_mode, b_mode, tile, first, count, tiles, with_ln, max_slice; };
 
 extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_gemm_problem* problems, int n_problems,
                         void* const* bufs, int n_bufs, void* stream_) {
@@ -240,10 +244,13 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             // bucket by (a_mode, b_mode, tile)
             for (int am = 0; am < 2; ++am)
                 for (int bm = 0; bm < 2; ++bm)
-                    for (int tl : {16, 20, 24, 32, 64, 128}) {
-                        Launch L{am, bm, tl, (int)pos, 0, 0, 0};
-                        const int te = tl == 16 ? 128 : (tl == 24 || tl == 20) ? 256 : tl;   // tile edge (rows)
-                        const int te_n = tl == 20 ? 128 : te;                                  // (columns)
+                    for (int tl : {16, 20, 24, 32, 64, 128, 4001, 4002, 4003, 4004, 4006, 4011, 4012, 4013, 4014, 4021,
+                                   4022, 4023, 4024, 4026}) {
+                        Launch L{am, bm, tl, (int)pos, 0, 0, 0, 0};
+                        int te = tl == 16 ? 128 : (tl == 24 || tl == 20) ? 256 : tl;         // tile edge (rows)
+                        int te_n = tl == 20 ? 128 : te;                                        // (columns)
+                        const bool x3 = tl >= 4000;
+                        if (x3 && !ghn3_gemm_x3_tile(40 + (tl - 4000) / 10, 64 * (tl % 10), &te, &te_n)) continue;
                         for (int q = first; q < first + cnt; ++q) {
                             const ghn3_gemm_problem& p = problems[q];
                             if (p.M <= 0 || p.N <= 0) continue;
@@ -256,6 +263,19 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                 ghn3_set_error("op %d problem %d: 16-bit operands need ROW/ROW modes, ld %% 8 == 0, "
                                                "b_kq %% 8 == 0, K < 2^24, no BIASGRAD / GELU, ldc %% 4 == 0 and "
                                                "16-byte aligned C / aux / residual", k, q);
+                                return GHN3_E_ARG;
+                            }
+                            if (x3 && (p.a_mode != GHN3_MODE_ROW || p.b_mode != GHN3_MODE_ROW || p.a_gather.buf >= 0 ||
+                                       p.b_gather.buf >= 0 || p.c_gather.buf >= 0 || p.a_q || p.b_q || p.c_q || p.bias_q ||
+                                       (p.N & 3) || (p.ldc & 3) || (p.ldb & 7) || p.x3_slice <= 0 ||
+                                       (p.x3_slice & 63) || (p.K % p.x3_slice) || p.ksplit > 1 || p.B2.buf < 0 || (p.C.off & 15) ||
+                                       (p.bias.off & 15) || (p.aux_in.off & 15) || (p.aux_out.off & 15) ||
+                                       (p.residual.off & 15) || (p.flags & (GHN3_GEMM_ACCUM | GHN3_GEMM_BIASGRAD)) ||
+                                       (p.bias.buf >= 0 && p.bias_stride > 1))) {
+                                ghn3_set_error("op %d problem %d: split-bf16 (X3) problems need ROW/ROW modes without "
+                                               "gathers / maps, N %% 4 == 0, ldc %% 4 == 0, ldb %% 8 == 0, a K slice that is "
+                                               "a multiple of 64 and divides K, the lo copy B2 and 16-byte aligned C / "
+                                               "bias / aux / residual", k, q);
                                 return GHN3_E_ARG;
                             }
                             if (p.M >= (1 << 24) || p.N >= (1 << 24) || p.K >= (1 << 24)) {
@@ -292,6 +312,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             g.lim = (tl == 16 || tl == 24 || tl == 20) ? R.get<const int>(p.lim) : nullptr;
                             g.lim_kind = g.lim ? p.lim_kind : 0;
                             g.alpha_amax = (tl == 16 || tl == 24 || tl == 20) ? R.get<const float>(p.alpha_amax) : nullptr;
+                            g.B2 = x3 ? R.get<const void>(p.B2) : nullptr;
+                            if (x3 && p.x3_slice > L.max_slice) L.max_slice = p.x3_slice;
                             g.ln_kind = p.ln_kind; g.ln_eps = p.ln_eps;
                             if (p.ln_kind) L.with_ln = 1;
                             for (int e = 0; e < 6; ++e) g.ln_p[e] = p.ln_kind ? R.get<const float>(p.ln_p[e]) : nullptr;
@@ -309,14 +331,14 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             }
                             g.order = (int64_t)p.M > (int64_t)p.N ? 1 : 0;   // stream the larger operand once
                             g.ksplit = p.ksplit > 1 ? p.ksplit : 1;
-                            g.k_chunk = ((p.K + g.ksplit - 1) / g.ksplit + 63) / 64 * 64;
+                            g.k_chunk = x3 ? p.x3_slice : ((p.K + g.ksplit - 1) / g.ksplit + 63) / 64 * 64;
                             if (g.ksplit > 1 && (p.bias.buf >= 0 || p.act || p.dact || p.residual.buf >= 0 ||
                                                  p.aux_out.buf >= 0)) {
                                 ghn3_set_error("op %d problem %d: split-K allows no epilogue but alpha", k, q);
                                 return GHN3_E_ARG;
                             }
-                            if (tl == 32) {
-                                L.tiles += g.tiles_m * g.tiles_n;          // plain m-fastest order, no padding
+                            if (tl == 32 || x3) {
+                                L.tiles += g.tiles_m * g.tiles_n;          // plain order, no padding
                             } else {
                                 const int per_split = g.order ? ((g.tiles_m + 7) / 8 * 8) * g.tiles_n
                                                               : g.tiles_m * ((g.tiles_n + 7) / 8 * 8);
@@ -386,7 +408,10 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         case GHN3_OP_NOP: break;
         case GHN3_OP_GEMM:
             for (const Launch& L : op_launches[k]) {
-                if (L.tile == 32)
+                if (L.tile >= 4000)
+                    rc = ghn3_gemm_x3_launch(ds + L.first, L.count, L.tiles, 40 + (L.tile - 4000) / 10,
+                                             64 * (L.tile % 10), stream);
+                else if (L.tile == 32)
                     rc = ghn3_gemm_small_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, L.with_ln, stream);
                 else if (L.tile == 16 || L.tile == 24 || L.tile == 20)
                     rc = ghn3_gemm_h16d_launch(ds + L.first, L.count, L.tiles, L.tile == 16 ? 128 : L.tile == 20 ? 20 : 256,
@@ -437,13 +462,14 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         case GHN3_OP_LAYERNORM_FWD:
             rc = ghn3_layernorm_fwd(R.get<float>(o.r[0]), R.get<float>(o.r[1]), R.get<const float>(o.r[2]),
                                     R.get<const float>(o.r[3]), R.get<float>(o.r[4]), R.get<float>(o.r[5]),
-                                    R.get<const float>(o.r[6]), (int)o.i[0], (int)o.i[1], o.f[0], stream);
+                                    R.get<const float>(o.r[6]), (int)o.i[2], (int64_t)o.i[3], (int)o.i[0], (int)o.i[1],
+                                    o.f[0], stream);
             break;
         case GHN3_OP_LAYERNORM_BWD:
             rc = ghn3_layernorm_bwd(R.get<float>(o.r[0]), R.get<float>(o.r[1]), R.get<const float>(o.r[2]),
                                     R.get<const float>(o.r[3]), R.get<const float>(o.r[4]), R.get<const float>(o.r[5]),
-                                    R.get<const float>(o.r[6]), R.get<const float>(o.r[7]), (int)o.i[0], (int)o.i[1],
-                                    stream);
+                                    R.get<const float>(o.r[6]), R.get<const float>(o.r[7]), (int)o.i[2], (int64_t)o.i[3],
+                                    (int)o.i[0], (int)o.i[1], stream);
             break;
         case GHN3_OP_LN_PARAM_GRAD:
             rc = ghn3_ln_param_grad(R.get<float>(o.r[0]), R.get<float>(o.r[1]), R.get<const float>(o.r[2]),

@@ -146,8 +146,10 @@ class GHN3(nn.Module):
                    upstream gradients keep 11 significant bits; 'bf16' trades precision for range without scaling)
       side_stream  True (default): weight gradients, LayerNorm parameter gradients and operand copies overlap with
                    the dependent chain of the program on a second HIP stream
-      direct16     True (default): in 16-bit mode the W2 GEMMs read per-step 16-bit operand copies (GHN3_OP_CAST16)
-                   through the LDS-DMA kernel; False: fp32 operands converted while staged
+      direct16     True (default): in 16-bit mode the W2 GEMMs read 16-bit operand copies (GHN3_OP_CAST16) through the
+                   LDS-DMA kernel; False: fp32 operands converted while staged
+      graphormer_x3  None (default): in the 16-bit modes the Graphormer linears multiply split-bf16 operands on the 16-bit
+                   matrix cores (hi.hi + hi.lo + lo.hi, ~1e-5 relative; GHN3_GEMM_X3); False: exact fp32 everywhere
     """
 
     def __init__(self, max_shape, num_classes, hid, heads=8, layers=3, is_ghn2=False, pretrained=False, **kwargs):
@@ -166,6 +168,7 @@ class GHN3(nn.Module):
         self.compute = kwargs.pop('compute', 'f32')
         self.compute_bwd = kwargs.pop('compute_bwd', None)
         self.direct16 = kwargs.pop('direct16', True)
+        self.graphormer_x3 = kwargs.pop('graphormer_x3', None)
         self.side_stream = kwargs.pop('side_stream', True)
         assert not kwargs, 'unknown arguments %s' % list(kwargs)
         assert len(max_shape) == 4, max_shape
@@ -226,6 +229,7 @@ class GHN3(nn.Module):
         self._flat, self._offs, self._flat_numel = flat, np.asarray(offs, dtype=np.int64), total
         self._plans = {}
         self._shadow = None                       # 16-bit copies of the decoder weights (Program.shadow_layout)
+        self._shadowed = None
         self._shadow_state = None                 # (parameter version, has the transposed copies) they were cast from
         self._param_epoch = getattr(self, '_param_epoch', 0) + 1
 
@@ -250,7 +254,11 @@ class GHN3(nn.Module):
 
     def _shadow_version(self):
         w2, w0 = self.decoder.conv[2].weight, self.decoder.conv[0].weight
-        return (self._param_epoch, w2._version, w0._version, w2.data_ptr())
+        if getattr(self, '_shadowed', None) is None:
+            self._shadowed = [w2, w0] + [p for n, p in self.named_parameters()
+                                         if n.startswith('gnn.') and n.endswith('.weight') and p.dim() == 2
+                                         and ('to_qkv' in n or 'to_out' in n or 'ff.net' in n)]
+        return (self._param_epoch, sum(p._version for p in self._shadowed), w2.data_ptr())
 
     def _refresh_shadows(self, plan, stream):
         """Replays Program.shadow_ops (fp32 -> 16-bit copies of W2, W2^T, W0^T) when the decoder weights changed since
@@ -259,11 +267,11 @@ class GHN3(nn.Module):
         if not prog.uses_shadow:
             return
         if self._shadow is None:
-            nbytes = prog.shadow_layout(prog.C, prog.max_shape)['nbytes']
+            nbytes = prog.shadow_layout(prog.C, prog.max_shape, prog.Lyr)['nbytes']
             self._shadow = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         plan.bufs[prog.xbuf(prog.X_SHADOW)] = self._shadow.data_ptr()
         ver = self._shadow_version()
-        types = (prog.decoder_ctype, prog.decoder_bwd_ctype)
+        types = (prog.decoder_ctype, prog.decoder_bwd_ctype, prog.x3, any(g['op16'] for g in prog.gemm_groups))
         st = self._shadow_state
         if st is not None and st[0] == ver and st[2] == types and (st[1] or not prog.training):
             return
@@ -300,7 +308,7 @@ class GHN3(nn.Module):
                        predict_class_layers=predict_class_layers, reduce_graph=reduce_graph,
                        layernorm=self.layernorm, weight_norm=self.weight_norm, decoder_ctype=L.COMPUTE_TYPES[self.compute],
                        decoder_bwd_ctype=L.COMPUTE_TYPES[self.compute_bwd] if self.compute_bwd else None,
-                       direct16=self.direct16, side_stream=self.side_stream)
+                       direct16=self.direct16, side_stream=self.side_stream, graphormer_x3=self.graphormer_x3)
         plan = _Plan(self, prog, graphs.edges, nets)
         plan.graphs = graphs
         return plan
@@ -495,7 +503,8 @@ def from_pretrained(ghn3_name='ghn3xlm16.pt', **kwargs):
         state_dict = joblib.load(hf_hub_download(repo_id='SamsungSAILMontreal/ghn3', filename=ghn3_name))
     if any(k.find('gnn.gru.') >= 0 for k in state_dict):
         raise NotImplementedError('GHN-2 checkpoints are not supported')
-    extra = {k: kwargs.pop(k) for k in ('index_mode', 'compute', 'compute_bwd', 'direct16', 'side_stream', 'debug_level')
+    extra = {k: kwargs.pop(k) for k in ('index_mode', 'compute', 'compute_bwd', 'direct16', 'side_stream', 'debug_level',
+                                        'graphormer_x3')
              if k in kwargs}
     if ghn_config is None:
         num_classes = kwargs.pop('num_classes', 10)

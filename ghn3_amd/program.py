@@ -59,7 +59,7 @@ class Program:
 
     def __init__(self, cfg, node_infos, n_nodes, node_types, max_edge, nets, index_mode='reference',
                  training=True, predict_class_layers=True, reduce_graph=False, layernorm=True, weight_norm=True,
-                 decoder_ctype=None, decoder_bwd_ctype=None, direct16=True, side_stream=True):
+                 decoder_ctype=None, decoder_bwd_ctype=None, direct16=True, side_stream=True, graphormer_x3=None):
         self.cfg = cfg
         # side_stream: weight-gradient GEMMs, LayerNorm parameter gradients and operand copies (everything off the
         # dependent chain of the program) carry GHN3_OPFLAG_SIDE and overlap with the chain on a second stream;
@@ -87,7 +87,21 @@ class Program:
         # direct16: the W2 GEMMs (98 % of the decoder flops) read 16-bit operand COPIES written once per step by
         # GHN3_OP_CAST16 (k-contiguous, zero padded, LDS-DMA friendly) instead of converting fp32 while staging.
         self.direct16 = bool(direct16) and decoder_ctype in (L.CT_F16, L.CT_BF16) and (8 * int(cfg['hid'])) % 64 == 0
+        # Exact ReLU masks: the first two decoder linears (fc, conv.0 -- 2.3 % of the decoder flops) multiply in exact
+        # fp32 even in the 16-bit modes.  Their outputs t, u carry the ReLU masks of the backward: a 3e-4 forward error
+        # flips the mask of ~3e-4 of the elements (those with |u| below the error), and every flipped element is an
+        # O(1) error of d_u / d_t there -- measured 1-5 % per decoder row against the fp32 path, 6e-3 on the gradient
+        # of decoder.fc.0.weight at ghn3xlm16.  Likewise the fc backward (d_t ~ 1e-4, f16 subnormal range) stays fp32.
+        self.d12_fwd_ctype = {'f32': L.CT_F32, 'f16': None}[os.environ.get('GHN3_D12_FWD', 'f32')]
+        self.d1_bwd_ctype = {'f32': L.CT_F32, 'f16': None}[os.environ.get('GHN3_D1_BWD', 'f32')]
         self.C = C = int(cfg['hid'])
+        # x3: the Graphormer linears (to_qkv, to_out, ff.net.0, ff.net.3; forward and dgrad) as split-bf16 products on the
+        # 16-bit matrix cores (GHN3_GEMM_X3: hi.hi + hi.lo + lo.hi, ~1e-5 relative) against persistent bf16 hi / lo copies
+        # of the weights, instead of the exact-fp32 matrix instruction.  Default: on in the 16-bit modes when the width
+        # suits the kernel's K slices (C a multiple of 64, <= 384: every released GHN-3); off in the exact 'f32' mode.
+        if graphormer_x3 is None:
+            graphormer_x3 = decoder_ctype in (L.CT_F16, L.CT_BF16) and os.environ.get('GHN3_X3', '1') != '0'
+        self.x3 = bool(graphormer_x3) and C % 64 == 0 and 64 <= C <= 384
         self.H = int(cfg['heads'])
         self.Lyr = int(cfg['layers'])
         self.K = int(cfg['num_classes'])
@@ -232,6 +246,9 @@ class Program:
                 assert D['src_q'] % 4 == 0 and D['src_s'] % 4 == 0 and it['cols'] % D['src_q'] == 0
             if it.get('tight'):
                 dflags |= L.CAST_TIGHT
+            if it.get('split'):
+                dflags |= L.CAST_SPLIT
+                D['lo_off'] = it['split']
             if it.get('scaled'):
                 assert amax is not None
                 dflags |= L.CAST_SCALED
@@ -287,7 +304,7 @@ class Program:
              bias_s=0, bias_stride=1, act=L.ACT_NONE, dact=L.DACT_NONE, aux_in=None, aux_out=None, residual=None,
              a_gather=None, b_gather=None, c_gather=None, a_qs=(0, 0), b_qs=(0, 0), c_qs=(0, 0), accum=False,
              alpha=1.0, dbias=None, dbias_stride=1, ksplit=1, op16=False, b_kmap=(0, 0), lim=None, lim_kind=0, alpha_amax=None,
-             ln=None):
+             ln=None, x3=None):
         # ln = (kind, [refs p0..p5 or None], eps): LayerNorm row prologue of A (ghn3_gemm_problem::ln_kind)
         # dbias: fused bias gradient of a wgrad problem (GHN3_GEMM_BIASGRAD): dbias[cmap(m)*stride] += sum_k A(m,k)
         if dbias is not None:
@@ -295,15 +312,15 @@ class Program:
             bias, bias_stride = dbias, dbias_stride
         N_ = self.NONE
         flags = (L.GEMM_ACCUM if accum else 0) | (L.GEMM_BIASGRAD if dbias is not None else 0) | \
-            (L.GEMM_OP16 if op16 else 0)
+            (L.GEMM_OP16 if op16 else 0) | (L.GEMM_X3 if x3 is not None else 0)
         # one plain tuple per problem (field order of _PROBLEM_REFS + _PROBLEM_INTS + the tail); the structured array
         # is packed column by column in _pack_problems -- filling a numpy record per call cost 15 us per problem
         self._probs.append((
             A or N_, B or N_, C or N_, bias or N_, residual or N_, aux_in or N_, aux_out or N_, a_gather or N_,
-            b_gather or N_, c_gather or N_, lim or N_, alpha_amax or N_,
+            b_gather or N_, c_gather or N_, lim or N_, alpha_amax or N_, (x3[0] if x3 is not None else N_),
             M, N, K, lda, ldb, ldc, a_mode, b_mode, a_qs[0], a_qs[1], b_qs[0], b_qs[1], c_qs[0], c_qs[1], bias_q, bias_s,
             bias_stride, act, dact, flags, b_kmap[0], b_kmap[1],
-            alpha, ksplit, (lim_kind if lim is not None else 0)))
+            (x3[1] if x3 is not None else 0), alpha, ksplit, (lim_kind if lim is not None else 0)))
         if ln is not None:
             self._ln[len(self._probs) - 1] = ln
         return len(self._probs) - 1
@@ -327,9 +344,9 @@ class Program:
         return p0
 
     _PROBLEM_REFS = ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim',
-                     'alpha_amax')
+                     'alpha_amax', 'B2')
     _PROBLEM_INTS = ('M', 'N', 'K', 'lda', 'ldb', 'ldc', 'a_mode', 'b_mode', 'a_q', 'a_s', 'b_q', 'b_s', 'c_q', 'c_s',
-                     'bias_q', 'bias_s', 'bias_stride', 'act', 'dact', 'flags', 'b_kq', 'b_ks')
+                     'bias_q', 'bias_s', 'bias_stride', 'act', 'dact', 'flags', 'b_kq', 'b_ks', 'x3_slice')
 
     def _pack_problems(self):
         n = len(self._probs)
@@ -371,7 +388,7 @@ class Program:
             if tag:
                 flags |= L.OPFLAG_TIMED | (tag << 16)
                 fl = flops if flops is not None else \
-                    sum(2.0 * int(p[12]) * int(p[13]) * int(p[14]) for p in self._probs[first:first + count])
+                    sum(2.0 * int(p[13]) * int(p[14]) * int(p[15]) for p in self._probs[first:first + count])
                 self.tag_flops[tag] = self.tag_flops.get(tag, 0.0) + fl
             self.op(L.OP_GEMM, ints=(first, count, tile, grid_cap), flags=flags)
 
@@ -525,18 +542,30 @@ class Program:
         self.n1_clsb = self.n1 - self.n1_plain
         self.oned_src = np.asarray(rows, dtype=np.int32)
 
+    X3_WEIGHTS = (('attn.to_qkv.weight', 3, 1), ('attn.to_out.0.weight', 1, 1), ('ff.net.0.weight', 4, 1),
+                  ('ff.net.3.weight', 1, 4))          # (name, rows / C, cols / C)
+
     @staticmethod
-    def shadow_layout(C, max_shape):
-        """Offsets (16-bit elements) of the persistent 16-bit copies of the decoder weights inside the GHN-owned shadow
-        buffer (X_SHADOW) and its size in bytes: W2 [C^2][8C] (forward B operand), W2^T [8C][C^2 + 64] (dgrad B operand)
-        and W0^T [4C][8C] (D2 dgrad B operand).  Depends on the model only, never on the batch."""
+    def shadow_layout(C, max_shape, layers=0):
+        """Offsets (16-bit elements) of the persistent 16-bit copies of GHN weights inside the model-owned shadow buffer
+        (X_SHADOW) and its size in bytes.  Decoder: W2 [C^2][8C] (forward B operand), W2^T [8C][C^2 + 64] (dgrad B
+        operand), W0^T [4C][8C] (D2 dgrad B operand).  Graphormer (GHN3_GEMM_X3), per layer and linear weight W [r][c]:
+        one block [hi straight r x c | hi transposed c x r] and the identical block of the lo halves `lo` elements behind it
+        (straight = forward B operand, transposed = dgrad B operand).  Depends on the model only, never on the batch."""
         n_w2 = int(max_shape[0]) * int(max_shape[1])
         w2hT_ld = round_up(n_w2, 64) + 64
         w2h = 0
         w2hT = round_up(w2h + n_w2 * 8 * C + 128, 128)
         w0hT = round_up(w2hT + 8 * C * w2hT_ld + 128, 128)
-        end = round_up(w0hT + 4 * C * 8 * C + 128, 128)
-        return dict(w2h=w2h, w2hT=w2hT, w2hT_ld=w2hT_ld, w0hT=w0hT, nbytes=2 * end)
+        pos = round_up(w0hT + 4 * C * 8 * C + 128, 128)
+        lay = dict(w2h=w2h, w2hT=w2hT, w2hT_ld=w2hT_ld, w0hT=w0hT, x3={})
+        for l in range(layers):
+            for name, r, c in Program.X3_WEIGHTS:
+                n = r * C * c * C
+                lay['x3']['gnn.%d.%s' % (l, name)] = dict(hi=pos, hiT=pos + n, lo=2 * n, rows=r * C, cols=c * C)
+                pos += 4 * n
+        lay['nbytes'] = 2 * round_up(pos + 128, 128)
+        return lay
 
     def sref(self, off_halfs):
         return (self.xbuf(self.X_SHADOW), 2 * int(off_halfs))
@@ -550,27 +579,100 @@ class Program:
         C, ms = self.C, self.max_shape
         for g in self.gemm_groups:
             g['op16'] = self.direct16 and g['i_ld'] % 8 == 0
-        self.uses_shadow = any(g['op16'] for g in self.gemm_groups)
+        op16 = any(g['op16'] for g in self.gemm_groups)
+        self.uses_shadow = op16 or self.x3
         if not self.uses_shadow:
             return
         fct, bct = self.decoder_ctype, self.decoder_bwd_ctype
         n_w2 = ms[0] * ms[1]
-        lay = self.shadow_layout(C, ms)
-        self.w2h = lay['w2h']
-        item = dict(src_off=0, rows=n_w2, cols=8 * C, ld_src=8 * C, straight=(self.w2h, 8 * C, fct))
-        if self.training:
-            self.w2hT_ld = lay['w2hT_ld']
-            self.w2hT = lay['w2hT']
-            item['transposed'] = (self.w2hT, self.w2hT_ld, bct)
+        lay = self.shadow_lay = self.shadow_layout(C, ms, self.Lyr if self.x3 else 0)
         shadow = (self.xbuf(self.X_SHADOW), 0)
-        self.cast16(self.pref('decoder.conv.2.weight'), [item], flags=self.SIDE,
-                    grid_cap=int(os.environ.get('GHN3_W2CAST_CAP', '512')) if self.SIDE else 0, dst_base=shadow)
-        if self.training and (4 * C) % 64 == 0:
-            # decoder.conv.0.weight^T [4C][8C] (backward type): B operand of the D2 dgrad
-            self.w0hT = lay['w0hT']
-            self.cast16(self.pref('decoder.conv.0.weight'),
-                        [dict(src_off=0, rows=8 * C, cols=4 * C, ld_src=4 * C, transposed=(self.w0hT, 8 * C, bct))],
-                        flags=self.SIDE, dst_base=shadow)
+        if op16:
+            self.w2h = lay['w2h']
+            item = dict(src_off=0, rows=n_w2, cols=8 * C, ld_src=8 * C, straight=(self.w2h, 8 * C, fct))
+            if self.training:
+                self.w2hT_ld = lay['w2hT_ld']
+                self.w2hT = lay['w2hT']
+                item['transposed'] = (self.w2hT, self.w2hT_ld, bct)
+            self.cast16(self.pref('decoder.conv.2.weight'), [item], flags=self.SIDE,
+                        grid_cap=int(os.environ.get('GHN3_W2CAST_CAP', '512')) if self.SIDE else 0, dst_base=shadow)
+            if self.training and (4 * C) % 64 == 0:
+                # decoder.conv.0.weight^T [4C][8C] (backward type): B operand of the D2 dgrad
+                self.w0hT = lay['w0hT']
+                self.cast16(self.pref('decoder.conv.0.weight'),
+                            [dict(src_off=0, rows=8 * C, cols=4 * C, ld_src=4 * C, transposed=(self.w0hT, 8 * C, bct))],
+                            flags=self.SIDE, dst_base=shadow)
+        if self.x3:
+            # bf16 hi / lo copies of the Graphormer linears, straight (forward) and transposed (dgrad): one launch per
+            # layer (the source base of a cast op is one parameter; the four weights of a layer are addressed from its
+            # first one -- the flat parameter buffer is contiguous) -- on the main stream: layer 0 needs them at once
+            for l in range(self.Lyr):
+                base = 'gnn.%d.%s' % (l, self.X3_WEIGHTS[0][0])
+                items = []
+                for name, r, c in self.X3_WEIGHTS:
+                    e = lay['x3']['gnn.%d.%s' % (l, name)]
+                    it = dict(src_off=self.param_gap(base, 'gnn.%d.%s' % (l, name)), rows=e['rows'], cols=e['cols'],
+                              ld_src=e['cols'], straight=(e['hi'], e['cols'], L.CT_BF16), split=e['lo'])
+                    if self.training:
+                        it['transposed'] = (e['hiT'], e['rows'], L.CT_BF16)
+                    items.append(it)
+                self.cast16(self.pref(base), items, dst_base=shadow)
+
+    def param_gap(self, a, b):
+        """floats from the start of parameter `a` to the start of parameter `b` in the flat parameter buffer (slot
+        order, every slot padded to 64 floats: GHN3._flatten)."""
+        sa, sb = self.slot[a], self.slot[b]
+        assert sa <= sb
+        return sum(round_up(self.param_numel(self.names[k]), 64) for k in range(sa, sb))
+
+    def param_numel(self, name):
+        C, H, K, ms = self.C, self.H, self.K, self.max_shape
+        tail = name.split('.', 2)[2] if name.startswith('gnn.') else name
+        table = {'ln1.weight': C, 'ln1.bias': C, 'ln2.weight': C, 'ln2.bias': C, 'attn.to_qkv.weight': 3 * C * C,
+                 'attn.to_out.0.weight': C * C, 'attn.to_out.0.bias': C, 'ff.net.0.weight': 4 * C * C,
+                 'ff.net.0.bias': 4 * C, 'ff.net.3.weight': 4 * C * C, 'ff.net.3.bias': C}
+        return table[tail]
+
+    # ---- split-bf16 Graphormer linears (GHN3_GEMM_X3) ----------------------------------------------------------
+    @staticmethod
+    def x3_split(M, N, K, may_split):
+        """(tile code, K splits over workgroups, K slice per staging round) of a [M x N x K] Graphormer linear.
+        The kernel is bound by what one CU can pull through L2 -> LDS (~17 B/clk): the bytes per workgroup are
+        4 K_slice (BM + BN), so narrow outputs (N <= 512: to_out, ff.net.3, the dgrads of to_qkv / ff.net.0) take 32 x 32
+        tiles and -- where the consumer is a LayerNorm op that can sum partial planes -- K slices of 192 (then 128, 64)
+        run by different workgroup sets; wide outputs (to_qkv, ff.net.0, ff.net.3 dgrad) take 32 x 64 tiles over the whole
+        K = C.  Measured at ghn3xlm16 (tests/x3_bench.py, us per dependent launch, exact-fp32 kernel in brackets):
+        to_qkv 6.4 (9.9), to_out 4.4 (6.5), ff.net.0 6.4 (10.3), ff.net.3 7.3 (10.0 with its two K halves)."""
+        nk = K // 64
+        whole = max(d for d in (6, 4, 3, 2, 1) if nk % d == 0)         # k-tiles per slice without a split
+        if N > 512:
+            return 40, 1, 64 * whole
+        if not may_split:
+            return 42, 1, 64 * whole
+        for d in (3, 2, 4, 6, 1):
+            if nk % d == 0 and nk // d <= 8:
+                return 42, nk // d, 64 * d
+        return 42, 1, 64 * whole
+
+    def x3_linear(self, A, wname, transposed, Cref, M, N, K, lda, ldc, split=False, planes=None, **epi):
+        """C = A W^T (nn.Linear forward, W [N][K]) or, transposed, C = A W (dgrad, W [K][N]) with split-bf16 operands.
+        With split, K is cut into `ks` slices run by different workgroups: slice 0 carries the epilogue into C, slice
+        j > 0 goes to plane j - 1 of the workspace buffer `planes` ([ks - 1][M][N], summed by the consuming LayerNorm).
+        Returns (ks - 1, planes ref or None) and launches the problems."""
+        e = self.shadow_lay['x3'][wname]
+        hi = e['hiT'] if transposed else e['hi']
+        tile, ks, slice_ = self.x3_split(M, N, K, split)
+        pref = None
+        if ks > 1:
+            pref = self.wsf(planes, (ks - 1) * M * N)
+        p0 = len(self._probs)
+        kc = K // ks
+        for j in range(ks):
+            Cj = Cref if j == 0 else (pref[0], pref[1] + 4 * (j - 1) * M * N)
+            self.gemm((A[0], A[1] + 4 * j * kc), self.sref(hi + j * kc), Cj, M, N, kc, lda, K, ldc if j == 0 else N,
+                      x3=(self.sref(hi + e['lo'] + j * kc), slice_), **(epi if j == 0 else {}))
+        self.gemm_op(p0, tile=tile)
+        return ks - 1, pref
 
     # ------------------------------------------------------------------ forward
     def _build_forward(self):
@@ -638,6 +740,29 @@ class Program:
             z = self.wsf('z' + sfx, rows * 4 * C)
             f = self.wsf('f' + sfx, rows * 4 * C)
             x_out = self.wsf('x%d' % (l + 1), rows * C)
+            if self.x3:
+                # split-bf16 linears (GHN3_GEMM_X3); K splits of the linear-epilogue GEMMs go to partial planes that the
+                # next LayerNorm op sums (and writes back) -- x_plane: (number of planes, ref) of the previous ff.net.3
+                self.op(L.OP_LAYERNORM_FWD, refs=(h1, x_in, self.pref(pre + 'ln1.weight'), self.pref(pre + 'ln1.bias'),
+                                                  m1, r1, x_plane[1] if x_plane else self.NONE),
+                        ints=(rows, C, x_plane[0] if x_plane else 0, rows * C), floats=(1e-5,))
+                x_plane = None
+                self.x3_linear(h1, pre + 'attn.to_qkv.weight', False, qkv, rows, 3 * C, C, C, 3 * C)
+                self.op(L.OP_ATTN_FWD, refs=(o, qkv, bias, Pm if Pm is not None else self.NONE, r_nn),
+                        ints=(B, N, C, H))
+                np_, pl = self.x3_linear(o, pre + 'attn.to_out.0.weight', False, xmid, rows, C, C, C, C, split=True,
+                                         planes='xmid_plane', bias=self.pref(pre + 'attn.to_out.0.bias'), residual=x_in)
+                self.op(L.OP_LAYERNORM_FWD, refs=(h2, xmid, self.pref(pre + 'ln2.weight'), self.pref(pre + 'ln2.bias'),
+                                                  m2, r2, pl if np_ else self.NONE), ints=(rows, C, np_, rows * C),
+                        floats=(1e-5,))
+                self.x3_linear(h2, pre + 'ff.net.0.weight', False, f, rows, 4 * C, C, C, 4 * C,
+                               bias=self.pref(pre + 'ff.net.0.bias'), act=L.ACT_GELU, aux_out=z if train else None)
+                np_, pl = self.x3_linear(f, pre + 'ff.net.3.weight', False, x_out, rows, C, 4 * C, 4 * C, C,
+                                         split=bool(self.layernorm or l + 1 < self.Lyr), planes='x_plane',
+                                         bias=self.pref(pre + 'ff.net.3.bias'), residual=xmid)
+                x_plane = (np_, pl) if np_ else None
+                x_in = x_out
+                continue
             if self.fuse_ln:
                 p0 = self.gemm(x_in, self.pref(pre + 'attn.to_qkv.weight'), qkv, rows, 3 * C, C, C, C, 3 * C,
                                ln=(1, [self.pref(pre + 'ln1.weight'), self.pref(pre + 'ln1.bias'),
@@ -677,8 +802,12 @@ class Program:
         xe = self.wsf('xe', rows * C)
         mf, rf = self.wsf('mf', rows), self.wsf('rf', rows)
         if self.layernorm:
-            self.op(L.OP_LAYERNORM_FWD, refs=(xe, x_in, self.pref('ln.weight'), self.pref('ln.bias'), mf, rf,
-                                              x_plane or self.NONE), ints=(rows, C), floats=(1e-5,))
+            if isinstance(x_plane, tuple) and isinstance(x_plane[0], int) and self.x3:
+                self.op(L.OP_LAYERNORM_FWD, refs=(xe, x_in, self.pref('ln.weight'), self.pref('ln.bias'), mf, rf,
+                                                  x_plane[1]), ints=(rows, C, x_plane[0], rows * C), floats=(1e-5,))
+            else:
+                self.op(L.OP_LAYERNORM_FWD, refs=(xe, x_in, self.pref('ln.weight'), self.pref('ln.bias'), mf, rf,
+                                                  x_plane or self.NONE), ints=(rows, C), floats=(1e-5,))
         else:
             self._ws_names['xe'] = self._ws_names['x%d' % self.Lyr]
             xe = x_in
@@ -710,11 +839,11 @@ class Program:
                 self.gemm(xe, self.pref(Wfc, int(p) * C), t, len(rws), 4 * C, C, C, S2 * C, 4 * C,
                           bias=self.pref(bfc, int(p)), bias_stride=S2, act=L.ACT_RELU, a_gather=r_src,
                           c_gather=r_rows)
-            self.gemm_op(p0, tag=self.TAG_D1_FWD)
+            self.gemm_op(p0, tag=self.TAG_D1_FWD, ctype=self.d12_fwd_ctype)
             # D2
             p0 = self.gemm(t, self.pref(W0), u, M, 8 * C, 4 * C, 4 * C, 4 * C, 8 * C, bias=self.pref(b0),
                            act=L.ACT_RELU)
-            self.gemm_op(p0, tag=self.TAG_D2_FWD)
+            self.gemm_op(p0, tag=self.TAG_D2_FWD, ctype=self.d12_fwd_ctype)
             # D3: only the W2 rows (o' < o, i' < i) each group consumes; all groups in one launch
             p0 = len(self._probs)
             tiles_floats = 0
@@ -1333,13 +1462,13 @@ class Program:
             for (p, cnt, r_rows, r_src) in self.d1:
                 self.gemm(d_t, self.pref(Wfc, p * C), d_rows, cnt, C, 4 * C, 4 * C, S2 * C, C, a_mode=L.MODE_ROW,
                           b_mode=L.MODE_COL, a_gather=r_rows, c_gather=r_rows)
-            self.gemm_op(p0, tag=self.TAG_D1_BWD)
+            self.gemm_op(p0, tag=self.TAG_D1_BWD, ctype=self.d1_bwd_ctype)
             p0 = len(self._probs)
             for (p, cnt, r_rows, r_src) in self.d1:
                 self.gemm(d_t, xe, self.gref(Wfc, p * C), 4 * C, C, cnt, 4 * C, C, S2 * C, a_mode=L.MODE_COL,
                           b_mode=L.MODE_COL, a_gather=r_rows, b_gather=r_src, accum=True,
                           dbias=self.gref(bfc, p), dbias_stride=S2)
-            self.gemm_op(p0, tag=self.TAG_D1_BWD, side=True)
+            self.gemm_op(p0, tag=self.TAG_D1_BWD, side=True, ctype=self.d1_bwd_ctype)
         if n1 > 0:
             mc = self.mc
             W1, b1 = 'decoder_1d.fc.0.weight', 'decoder_1d.fc.0.bias'
@@ -1417,48 +1546,62 @@ class Program:
             g_mid = self.wsf('gmid' + lsfx, rows * C)
             g_out = self.wsf(('gout' + sfx) if self.SIDE else 'gout%d' % (l & 1), rows * C)
             dqkv = self.wsf('dqkv' + lsfx, rows * 3 * C)
-            # FFN second linear: x_out = xmid + f W3^T + b3.  With fuse_ln the upstream gradient g_cur of every layer
-            # but the last is LN1'(dhB) + g_mid of the layer above, produced by this GEMM's row prologue.
-            p0 = self.gemm(g_cur if pending_ln1 is None else pending_ln1[0], self.pref(W3), dz, rows, 4 * C, C, C,
-                           4 * C, 4 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, dact=L.DACT_GELU, aux_in=z,
-                           ln=None if pending_ln1 is None else (2, pending_ln1[1], 0.0))
-            pending_ln1 = None
-            self.gemm_op(p0)
-            # FFN first linear
-            dhA_p = None
-            if self.split_small(rows, C, 4 * C):
-                dhA_p = self.wsf('dhA_plane', rows * C)
-                p0 = self.gemm_k2(dz, self.pref(W1f), dhA, dhA_p, rows, C, 4 * C, 4 * C, C, C, L.MODE_COL)
-            else:
-                p0 = self.gemm(dz, self.pref(W1f), dhA, rows, C, 4 * C, 4 * C, C, C, a_mode=L.MODE_ROW,
-                               b_mode=L.MODE_COL)
-            self.gemm_op(p0)
-            # LN2 (+ residual branch gradient g_cur)
-            if self.fuse_ln:
-                # attention output projection: xmid = x_in + o Wo^T + bo; its A operand g_mid = LN2'(dhA) + g_cur is
-                # computed (and written for the wgrad / the residual path) by the GEMM's row prologue
-                p0 = self.gemm(dhA, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
-                               ln=(2, [self.pref(pre + 'ln2.weight'), xmid, m2, r2, g_cur, g_mid], 0.0))
-            else:
+            if self.x3:
+                # split-bf16 dgrads against the transposed weight copies; K splits -> planes summed by the LayerNorm
+                # backward ops (which write the sums back for the LayerNorm parameter gradients on the side stream)
+                self.x3_linear(g_cur, W3, True, dz, rows, 4 * C, C, C, 4 * C, dact=L.DACT_GELU, aux_in=z)
+                np_, pl = self.x3_linear(dz, W1f, True, dhA, rows, C, 4 * C, 4 * C, C, split=True, planes='dhA_plane')
                 self.op(L.OP_LAYERNORM_BWD, refs=(g_mid, dhA, xmid, self.pref(pre + 'ln2.weight'), m2, r2, g_cur,
-                                                  dhA_p or self.NONE), ints=(rows, C))
-                # attention output projection: xmid = x_in + o Wo^T + bo
-                p0 = self.gemm(g_mid, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
-            self.gemm_op(p0)
-            self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, self.NONE, dBias, r_nn), ints=(B, N, C, H))
-            dhB_p = None
-            if self.split_small(rows, C, 3 * C):
-                dhB_p = self.wsf('dhB_plane', rows * C)
-                p0 = self.gemm_k2(dqkv, self.pref(Wq), dhB, dhB_p, rows, C, 3 * C, 3 * C, C, C, L.MODE_COL)
-            else:
-                p0 = self.gemm(dqkv, self.pref(Wq), dhB, rows, C, 3 * C, 3 * C, C, C, a_mode=L.MODE_ROW,
-                               b_mode=L.MODE_COL)
-            self.gemm_op(p0)
-            if self.fuse_ln and l > 0:
-                pending_ln1 = (dhB, [self.pref(pre + 'ln1.weight'), x_in, m1, r1, g_mid, g_out])
-            else:
+                                                  pl if np_ else self.NONE), ints=(rows, C, np_, rows * C))
+                # (its output feeds the attention backward, which reads ONE matrix: no K split)
+                self.x3_linear(g_mid, Wo, True, do, rows, C, C, C, C)
+                self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, self.NONE, dBias, r_nn), ints=(B, N, C, H))
+                np_, pl = self.x3_linear(dqkv, Wq, True, dhB, rows, C, 3 * C, 3 * C, C, split=True, planes='dhB_plane')
                 self.op(L.OP_LAYERNORM_BWD, refs=(g_out, dhB, x_in, self.pref(pre + 'ln1.weight'), m1, r1, g_mid,
-                                                  dhB_p or self.NONE), ints=(rows, C))
+                                                  pl if np_ else self.NONE), ints=(rows, C, np_, rows * C))
+            else:
+                # FFN second linear: x_out = xmid + f W3^T + b3.  With fuse_ln the upstream gradient g_cur of every layer
+                # but the last is LN1'(dhB) + g_mid of the layer above, produced by this GEMM's row prologue.
+                p0 = self.gemm(g_cur if pending_ln1 is None else pending_ln1[0], self.pref(W3), dz, rows, 4 * C, C, C,
+                               4 * C, 4 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, dact=L.DACT_GELU, aux_in=z,
+                               ln=None if pending_ln1 is None else (2, pending_ln1[1], 0.0))
+                pending_ln1 = None
+                self.gemm_op(p0)
+                # FFN first linear
+                dhA_p = None
+                if self.split_small(rows, C, 4 * C):
+                    dhA_p = self.wsf('dhA_plane', rows * C)
+                    p0 = self.gemm_k2(dz, self.pref(W1f), dhA, dhA_p, rows, C, 4 * C, 4 * C, C, C, L.MODE_COL)
+                else:
+                    p0 = self.gemm(dz, self.pref(W1f), dhA, rows, C, 4 * C, 4 * C, C, C, a_mode=L.MODE_ROW,
+                                   b_mode=L.MODE_COL)
+                self.gemm_op(p0)
+                # LN2 (+ residual branch gradient g_cur)
+                if self.fuse_ln:
+                    # attention output projection: xmid = x_in + o Wo^T + bo; its A operand g_mid = LN2'(dhA) + g_cur is
+                    # computed (and written for the wgrad / the residual path) by the GEMM's row prologue
+                    p0 = self.gemm(dhA, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
+                                   ln=(2, [self.pref(pre + 'ln2.weight'), xmid, m2, r2, g_cur, g_mid], 0.0))
+                else:
+                    self.op(L.OP_LAYERNORM_BWD, refs=(g_mid, dhA, xmid, self.pref(pre + 'ln2.weight'), m2, r2, g_cur,
+                                                      dhA_p or self.NONE), ints=(rows, C))
+                    # attention output projection: xmid = x_in + o Wo^T + bo
+                    p0 = self.gemm(g_mid, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+                self.gemm_op(p0)
+                self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, self.NONE, dBias, r_nn), ints=(B, N, C, H))
+                dhB_p = None
+                if self.split_small(rows, C, 3 * C):
+                    dhB_p = self.wsf('dhB_plane', rows * C)
+                    p0 = self.gemm_k2(dqkv, self.pref(Wq), dhB, dhB_p, rows, C, 3 * C, 3 * C, C, C, L.MODE_COL)
+                else:
+                    p0 = self.gemm(dqkv, self.pref(Wq), dhB, rows, C, 3 * C, 3 * C, C, C, a_mode=L.MODE_ROW,
+                                   b_mode=L.MODE_COL)
+                self.gemm_op(p0)
+                if self.fuse_ln and l > 0:
+                    pending_ln1 = (dhB, [self.pref(pre + 'ln1.weight'), x_in, m1, r1, g_mid, g_out])
+                else:
+                    self.op(L.OP_LAYERNORM_BWD, refs=(g_out, dhB, x_in, self.pref(pre + 'ln1.weight'), m1, r1, g_mid,
+                                                      dhB_p or self.NONE), ints=(rows, C))
             # Side-stream work of the layer in ONE group at its end (the backward buffers are per layer when the side
             # stream is on): every main -> side hand-off is an event record that costs the main chain ~6 us, so the
             # LayerNorm parameter gradients (which read dhA / dhB after the LayerNorm backward has added the K-half

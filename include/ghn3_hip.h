@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 9
+#define GHN3_ABI_VERSION 10
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -76,6 +76,19 @@ enum { GHN3_DACT_NONE = 0, GHN3_DACT_RELU = 1 /* aux_in > 0 */, GHN3_DACT_GELU =
  * Bias, ReLU / dReLU, residual, accumulate, split-K and the C map work as for fp32 operands; GELU and
  * GHN3_GEMM_BIASGRAD are not available (GHN3_OP_CAST16 produces that sum while it writes the transposed copy). */
 #define GHN3_GEMM_OP16 4u
+/* Split-bf16 operands ("x3"): near-fp32 products on the 16-bit matrix cores for the latency-bound Graphormer linears
+ * (graphormer.py:38-44,121,141 and their dgrad) -- v_mfma_f32_16x16x32_bf16 needs 1/16 of the matrix-core cycles of the
+ * exact-fp32 v_mfma_f32_32x32x2_f32 per product, three products per term leave ~5x.
+ *   A: fp32, ROW mode, no gather / map; split on the fly into a = hi + lo (hi = bf16(a), lo = bf16(a - hi)).
+ *   B: a weight's persistent bf16 copies written by GHN3_OP_CAST16 with GHN3_CAST_SPLIT: `B` = hi [N][ldb], `B2` = lo
+ *      (same layout), both k-contiguous (ROW mode), ldb in 16-bit elements (% 8 == 0), K zero padded to 64.
+ *   C = alpha * (hi.hi + hi.lo + lo.hi) (+ epilogue), fp32 accumulate; the dropped lo.lo term is 2^-16 relative.
+ * A workgroup keeps a whole K slice (`x3_slice`, a multiple of 64, <= 384 for 32 x 64 tiles) of both operands in LDS
+ * and walks the slices of its K range in order.  K splits over workgroups are separate problems (partial planes
+ * summed by the consuming LayerNorm op).  Epilogue: bias, ReLU / GELU (+ aux_out), dReLU / dGELU (aux_in), residual;
+ * N % 4 == 0, ldc % 4 == 0, 16-byte aligned C / aux / residual / bias.  Tile codes (op.i[2]): 40 = 32 x 64,
+ * 41 = 64 x 64, 42 = 32 x 32. */
+#define GHN3_GEMM_X3 8u
 
 typedef struct ghn3_gemm_problem {
     ghn3_ref A, B, C;
@@ -116,6 +129,9 @@ typedef struct ghn3_gemm_problem {
     ghn3_ref ln_p[6];
     int32_t ln_kind;
     float ln_eps;
+    /* GHN3_GEMM_X3 only: the lo copy of B and the K slice a workgroup stages at a time */
+    ghn3_ref B2;
+    int32_t x3_slice, _pad3;
 } ghn3_gemm_problem;
 
 /* ---- 16-bit operand copies (GHN3_OP_CAST16) -----------------------------------------------------------
@@ -141,6 +157,9 @@ typedef struct ghn3_gemm_problem {
  * before converting; column sums stay unscaled */
 #define GHN3_CAST_SCALED 32u
 #define GHN3_CAST_TIGHT 64u
+/* bf16 split copies for GHN3_GEMM_X3: the straight and / or transposed copy is written twice, hi = bf16(x) at
+ * dst_off / dstT_off and lo = bf16(x - hi) `lo_off` 16-bit elements behind it (both bf16 whatever the *_BF16 flags) */
+#define GHN3_CAST_SPLIT 128u
 typedef struct ghn3_cast_desc {
     int64_t src_off, dst_off, dstT_off;
     int32_t rows, cols;
@@ -150,6 +169,7 @@ typedef struct ghn3_cast_desc {
     int32_t block_start;     /* first workgroup of this descriptor: blocks are 64 x 64 source tiles, column-tile fastest */
     int32_t bias_off;
     int32_t src_q, src_s;    /* source column map (0: identity) */
+    int64_t lo_off;          /* GHN3_CAST_SPLIT: distance (16-bit elements) from a hi copy to its lo copy */
 } ghn3_cast_desc;
 
 /* ---- tile / normalise descriptors  (nn.py:422-506 _tile_params, 554-592 _normalize, 508-552 _set_params)
@@ -190,9 +210,10 @@ enum ghn3_op_kind {
     GHN3_OP_EDGE_HIDDEN = 4,
     /* bias[b,h,i,j] = T[pair[b,i,j]][h] ; r0=bias r1=T r2=pair ; i: B,N,H */
     GHN3_OP_BIAS_GATHER = 5,
-    /* F.layer_norm ; r0=y r1=x r2=gamma r3=beta r4=mean r5=rstd r6=addend plane or absent ; i: rows,C ; f0=eps
-     * With r6 the normalised rows are x + r6 and the sum is written back to x (r6 = second K half of the GEMM that
-     * produced x, split over two workgroup sets). */
+    /* F.layer_norm ; r0=y r1=x r2=gamma r3=beta r4=mean r5=rstd r6=addend planes or absent ; i: rows,C,n_planes
+     * (0 with r6 present = 1), floats between planes ; f0=eps
+     * With r6 the normalised rows are x + sum_p r6[p] (summed in plane order) and the sum is written back to x (the
+     * planes are the further K slices of the GEMM that produced x, split over several workgroup sets). */
     GHN3_OP_LAYERNORM_FWD = 6,
     /* graphormer.py:121-140 ; r0=out(B*N,C) r1=qkv(B*N,3C) r2=bias(B,H,N,N) r3=P save or absent r4=n_nodes
      * i: B,N,C,H */
@@ -221,8 +242,8 @@ enum ghn3_op_kind {
     /* segmented row sum: out[r][:] (+)= sum_{t in seg(r)} X[idx[t]][:]
      * r0=out r1=X r2=seg_ptr(int32 rows+1) r3=idx(int32) ; i: rows,C,ldx,ldo,accum */
     GHN3_OP_ROWSEG_SUM = 13,
-    /* r0=dx r1=dy r2=x r3=gamma r4=mean r5=rstd r6=residual grad or absent r7=addend plane of dy or absent
-     * (dy + r7 is written back to dy) ; i: rows,C */
+    /* r0=dx r1=dy r2=x r3=gamma r4=mean r5=rstd r6=residual grad or absent r7=addend planes of dy or absent
+     * (dy + sum_p r7[p] is written back to dy) ; i: rows,C,n_planes (0 with r7 present = 1), floats between planes */
     GHN3_OP_LAYERNORM_BWD = 14,
     /* r0=dgamma r1=dbeta r2=dy r3=x r4=mean r5=rstd ; i: rows,C,accum */
     GHN3_OP_LN_PARAM_GRAD = 15,

@@ -406,3 +406,117 @@ def run_ln_case(ctx, kind, M, N, K, b_mode, res=True, seed=0, dev='cuda'):
     if kind == 1:
         out += [(dmean.cpu().numpy(), mu[:, 0]), (drstd.cpu().numpy(), rstd[:, 0])]
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Split-bf16 ("x3") GEMM: GHN3_OP_CAST16 with GHN3_CAST_SPLIT (hi / lo copies, straight + transposed) feeding
+# GHN3_GEMM_X3 problems.  Expectation: fp64 product of the fp32 operands (the deviation is the dropped lo.lo term and
+# the bf16 rounding of the lo halves: ~1e-5 relative).
+# ---------------------------------------------------------------------------------------------------------------
+def x3_setup(W, dev='cuda'):
+    """fp32 weight W [R][Cc] (numpy) -> (device fp32 weight, shadow buffer (uint16), layout dict) through one cast op."""
+    R, Cc = W.shape
+    n = R * Cc
+    lay = dict(hi=0, hiT=n, lo=2 * n)
+    dW = torch.from_numpy(np.ascontiguousarray(W)).to(dev)
+    shadow = torch.zeros(4 * n + 256, dtype=torch.int16, device=dev)
+    desc = np.zeros(1, dtype=L.CAST_DT)
+    desc['rows'], desc['cols'], desc['ld_src'] = R, Cc, Cc
+    desc['dst_off'], desc['ld_dst'] = lay['hi'], Cc
+    desc['dstT_off'], desc['ld_dstT'] = lay['hiT'], R
+    desc['lo_off'] = lay['lo']
+    desc['flags'] = L.CAST_STRAIGHT | L.CAST_TRANSPOSED | L.CAST_SPLIT
+    return dW, shadow, lay, desc
+
+
+def run_x3_case(ctx, M, N, K, transposed=False, tile=40, ksplit=1, slice_=0, epilogue='none', seed=0, dev='cuda'):
+    """C = A W^T (W [N][K]) or, transposed, C = A W (W [K][N]).  Returns [(got, expected)]."""
+    rs = np.random.RandomState(seed)
+    A = rs.standard_normal((M, K)).astype(np.float32)
+    W = (rs.standard_normal((K, N) if transposed else (N, K)) * 0.05).astype(np.float32)
+    bias = rs.standard_normal(N).astype(np.float32)
+    resid = rs.standard_normal((M, N)).astype(np.float32)
+    aux = rs.standard_normal((M, N)).astype(np.float32)
+    acc = A.astype(np.float64) @ (W.astype(np.float64) if transposed else W.astype(np.float64).T)
+    v = acc.copy()
+    aux_expected = None
+    if epilogue in ('full', 'gelu', 'bias_relu', 'bias_res'):
+        v = v + bias[None, :]
+    if epilogue == 'bias_res':
+        v = v + resid
+    if epilogue in ('full', 'gelu'):
+        aux_expected = v.copy()
+        v = torch.nn.functional.gelu(torch.from_numpy(v)).numpy()
+    if epilogue == 'bias_relu':
+        v = np.maximum(v, 0)
+    if epilogue == 'dgelu':
+        z = torch.from_numpy(aux.astype(np.float64)).requires_grad_(True)
+        torch.nn.functional.gelu(z).sum().backward()
+        v = v * z.grad.numpy()
+    if epilogue == 'drelu':
+        v = v * (aux > 0)
+    if epilogue == 'full':
+        v = v + resid
+    dW, shadow, lay, desc = x3_setup(W, dev)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
+    dA, dbias, dres, daux = t(A), t(bias), t(resid), t(aux)
+    dC = torch.full((max(ksplit, 1), M, N), 7.0, dtype=torch.float32, device=dev)
+    daux_out = torch.zeros(M, N, dtype=torch.float32, device=dev)
+    ddesc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
+    bufs = [dA, shadow, dC, dbias, dres, daux, daux_out, dW, ddesc]
+    ptrs = np.asarray([b.data_ptr() for b in bufs], dtype=np.uint64)
+    hi = lay['hiT'] if transposed else lay['hi']
+    kc = K // ksplit
+    sl = slice_ or 64 * max(d for d in (6, 4, 3, 2, 1) if (kc // 64) % d == 0)
+    p = np.zeros(ksplit, dtype=L.PROBLEM_DT)
+    for name in L._REF_NAMES + ('lim', 'alpha_amax', 'B2'):
+        p[name]['buf'] = -1
+    p['ln_p']['buf'] = -1
+    for j in range(ksplit):
+        p[j]['A']['buf'], p[j]['A']['off'] = 0, 4 * j * kc
+        p[j]['B']['buf'], p[j]['B']['off'] = 1, 2 * (hi + j * kc)
+        p[j]['B2']['buf'], p[j]['B2']['off'] = 1, 2 * (hi + lay['lo'] + j * kc)
+        p[j]['C']['buf'], p[j]['C']['off'] = 2, 4 * j * M * N
+        p[j]['M'], p[j]['N'], p[j]['K'], p[j]['lda'], p[j]['ldb'], p[j]['ldc'] = M, N, kc, K, K, N
+        p[j]['flags'], p[j]['alpha'], p[j]['x3_slice'] = L.GEMM_X3, 1.0, sl
+    if epilogue in ('full', 'gelu', 'bias_relu', 'bias_res'):
+        p[0]['bias']['buf'] = 3
+    if epilogue in ('full', 'bias_res'):
+        p[0]['residual']['buf'] = 4
+    if epilogue in ('dgelu', 'drelu'):
+        p[0]['aux_in']['buf'] = 5
+    if epilogue in ('full', 'gelu'):
+        p[0]['aux_out']['buf'] = 6
+    p[0]['act'] = {'bias_relu': L.ACT_RELU, 'gelu': L.ACT_GELU, 'full': L.ACT_GELU}.get(epilogue, L.ACT_NONE)
+    p[0]['dact'] = {'drelu': L.DACT_RELU, 'dgelu': L.DACT_GELU}.get(epilogue, L.DACT_NONE)
+    ops = np.zeros(2, dtype=L.OP_DT)
+    ops['r']['buf'][:] = -1
+    ops[0]['kind'] = L.OP_CAST16
+    ops[0]['r']['buf'][:3] = (7, 1, 8)
+    ops[0]['i'][:2] = (1, ((W.shape[0] + 63) // 64) * ((W.shape[1] + 63) // 64))
+    ops[1]['kind'] = L.OP_GEMM
+    ops[1]['i'][:3] = (0, ksplit, tile)
+    ctx.run(ops, p, ptrs, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got = dC.cpu().numpy().astype(np.float64).sum(0) if ksplit > 1 else dC[0].cpu().numpy()
+    out = [(got, v)]
+    if aux_expected is not None:
+        out.append((daux_out.cpu().numpy(), aux_expected))
+    return out
+
+
+X3_CASES = [
+    dict(M=256, N=1152, K=384, tile=40),                                        # to_qkv forward (ghn3xlm16)
+    dict(M=256, N=384, K=384, tile=42, ksplit=2, epilogue='bias_res'),          # to_out forward, 2 K planes (linear epilogue)
+    dict(M=256, N=1536, K=384, tile=40, epilogue='gelu'),                       # ff.net.0 forward
+    dict(M=256, N=384, K=1536, tile=42, ksplit=8),                              # ff.net.3 forward, 8 planes of 192
+    dict(M=256, N=384, K=1536, tile=40, ksplit=4, epilogue='bias_res'),
+    dict(M=256, N=1536, K=384, tile=40, transposed=True, epilogue='dgelu'),     # ff.net.3 dgrad
+    dict(M=256, N=384, K=1152, tile=42, transposed=True, ksplit=6),             # to_qkv dgrad
+    dict(M=256, N=384, K=384, tile=42, transposed=True),                        # to_out dgrad on 32 x 32 tiles
+    dict(M=200, N=256, K=1024, tile=41, slice_=256),                            # 64 x 64 tiles, four slices in the workgroup
+    dict(M=70, N=64, K=64, tile=40, epilogue='bias_relu'),                      # ghn3tm8 width, ragged M
+    dict(M=48, N=192, K=64, tile=42, epilogue='drelu'),
+    dict(M=1421, N=3072, K=1536, tile=41, slice_=256, epilogue='bias_relu'),    # decoder.conv.0 forward shape
+    dict(M=33, N=128, K=512, tile=40, slice_=128, epilogue='full'),             # walks 4 slices of 128
+]

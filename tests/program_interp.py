@@ -131,19 +131,28 @@ class Interp:
             Xsum = X
             if fl & L.CAST_SCALED and amax is not None:
                 X = (X * np.float32(self.pow2_scale(amax[0]))).astype(np.float32)
+            split = bool(fl & L.CAST_SPLIT)
+            if split:                               # bf16 hi copy + lo = bf16(x - hi) copy `lo_off` elements behind
+                Xlo = (X - self.from16(self.to16(X, True), True)).astype(np.float32)
             if fl & L.CAST_STRAIGHT:
                 Z = np.zeros((rows, r64(cols)), np.float32)
                 Z[:, :cols] = X
                 ldd = int(D['ld_dst'])
                 ii = int(D['dst_off']) + np.arange(rows)[:, None] * ldd + np.arange(r64(cols))[None, :]
-                dst[ii] = self.to16(Z, bool(fl & L.CAST_STRAIGHT_BF16))
+                dst[ii] = self.to16(Z, bool(fl & L.CAST_STRAIGHT_BF16) or split)
+                if split:
+                    Z[:, :cols] = Xlo
+                    dst[ii + int(D['lo_off'])] = self.to16(Z, True)
             if fl & L.CAST_TRANSPOSED:
                 rw = (rows + 7) // 8 * 8 if fl & L.CAST_TIGHT else r64(rows)
                 Z = np.zeros((cols, rw), np.float32)
                 Z[:, :rows] = X.T
                 ldd = int(D['ld_dstT'])
                 ii = int(D['dstT_off']) + np.arange(cols)[:, None] * ldd + np.arange(rw)[None, :]
-                dst[ii] = self.to16(Z, bool(fl & L.CAST_TRANSPOSED_BF16))
+                dst[ii] = self.to16(Z, bool(fl & L.CAST_TRANSPOSED_BF16) or split)
+                if split:
+                    Z[:, :rows] = Xlo.T
+                    dst[ii + int(D['lo_off'])] = self.to16(Z, True)
             if fl & L.CAST_COLSUM:
                 c = np.arange(cols)
                 q, s_ = int(D['bias_q']), int(D['bias_s'])
@@ -174,11 +183,34 @@ class Interp:
         assert np.isfinite(Bm).all()
         return A, Bm
 
+    def _gemm_x3(self, p):
+        """GHN3_GEMM_X3: fp32 A split on the fly into bf16 hi + lo, B from the bf16 hi / lo copies; the three products
+        hi.hi + hi.lo + lo.hi (fp32 accumulate on the device, fp64 here)."""
+        M, N, K = int(p['M']), int(p['N']), int(p['K'])
+        lda, ldb, sl = int(p['lda']), int(p['ldb']), int(p['x3_slice'])
+        assert int(p['a_mode']) == L.MODE_ROW and int(p['b_mode']) == L.MODE_ROW and ldb % 8 == 0 and N % 4 == 0
+        assert sl > 0 and sl % 64 == 0 and K % sl == 0 and sl <= 384 and int(p['ksplit']) <= 1
+        for n in ('a_gather', 'b_gather', 'c_gather'):
+            assert int(p[n]['buf']) < 0
+        assert int(p['B']['off']) % 16 == 0 and int(p['B2']['off']) % 16 == 0 and int(p['B2']['buf']) >= 0
+        XA = self.tail(p['A'], np.float32)
+        Bh, Bl = self.tail(p['B'], np.uint16), self.tail(p['B2'], np.uint16)
+        A = XA[np.arange(M)[:, None] * lda + np.arange(K)[None, :]]
+        ah = self.from16(self.to16(A, True), True)
+        al = self.from16(self.to16((A - ah).astype(np.float32), True), True)
+        ib = np.arange(N)[None, :] * ldb + np.arange(K)[:, None]
+        bh, bl = self.from16(Bh[ib], True).astype(np.float64), self.from16(Bl[ib], True).astype(np.float64)
+        ah, al = ah.astype(np.float64), al.astype(np.float64)
+        self._gemm_finish(p, None, None, prod=ah @ bh + (ah @ bl + al @ bh))
+
     def op_gemm(self, o, problems):
         first, cnt = int(o['i'][0]), int(o['i'][1])
         for p in problems[first:first + cnt]:
             M, N, K = int(p['M']), int(p['N']), int(p['K'])
             if M <= 0 or N <= 0:
+                continue
+            if int(p['flags']) & L.GEMM_X3:
+                self._gemm_x3(p)
                 continue
             if int(p['flags']) & L.GEMM_OP16:
                 A, Bm = self._gemm_op16(o, p)
@@ -249,7 +281,7 @@ class Interp:
                 P[5][idx] = out.astype(np.float32)
         return out.astype(np.float32)
 
-    def _gemm_finish(self, p, A, Bm, col_ext=None):
+    def _gemm_finish(self, p, A, Bm, col_ext=None, prod=None):
         if True:
             M, N = int(p['M']), int(p['N'])
             ldc = int(p['ldc'])
@@ -258,7 +290,7 @@ class Interp:
             alpha = float(p['alpha'])
             if 'alpha_amax' in p.dtype.names and int(p['alpha_amax']['buf']) >= 0:
                 alpha /= self.pow2_scale(self.tail(p['alpha_amax'], np.float32)[0])
-            v = (A.astype(np.float64) @ Bm.astype(np.float64)) * alpha
+            v = (prod if prod is not None else (A.astype(np.float64) @ Bm.astype(np.float64))) * alpha
             rc = self._rowmap(np.arange(M), gc, int(p['c_q']), int(p['c_s']))
             ci = rc[:, None] * ldc + np.arange(N)[None, :]
             if int(p['flags']) & L.GEMM_BIASGRAD:
@@ -401,8 +433,11 @@ class Interp:
     def op_layernorm_fwd(self, o, problems):
         rows, C = int(o['i'][0]), int(o['i'][1])
         xv = self.fview(o['r'][1], rows * C).reshape(rows, C)
-        if int(o['r'][6]['buf']) >= 0:                  # second K-half plane of the producing GEMM: summed in place
-            xv[:] = xv + self.fview(o['r'][6], rows * C).reshape(rows, C)
+        if int(o['r'][6]['buf']) >= 0:                  # further K-slice planes of the producing GEMM: summed in place
+            n_add, stride = max(1, int(o['i'][2])), int(o['i'][3])
+            for q in range(n_add):
+                pl = self.tail(o['r'][6], np.float32)[q * stride:q * stride + rows * C].reshape(rows, C)
+                xv[:] = xv + pl
         x = xv.astype(np.float64)
         g, b = self.fview(o['r'][2], C), self.fview(o['r'][3], C)
         mu = x.mean(1)
@@ -416,8 +451,11 @@ class Interp:
     def op_layernorm_bwd(self, o, problems):
         rows, C = int(o['i'][0]), int(o['i'][1])
         dyv = self.fview(o['r'][1], rows * C).reshape(rows, C)
-        if int(o['r'][7]['buf']) >= 0:                  # second K-half plane of the producing dgrad: summed in place
-            dyv[:] = dyv + self.fview(o['r'][7], rows * C).reshape(rows, C)
+        if int(o['r'][7]['buf']) >= 0:                  # further K-slice planes of the producing dgrad: summed in place
+            n_add, stride = max(1, int(o['i'][2])), int(o['i'][3])
+            for q in range(n_add):
+                pl = self.tail(o['r'][7], np.float32)[q * stride:q * stride + rows * C].reshape(rows, C)
+                dyv[:] = dyv + pl
         dy = dyv.astype(np.float64)
         x = self.fview(o['r'][2], rows * C).reshape(rows, C).astype(np.float64)
         g = self.fview(o['r'][3], C).astype(np.float64)

@@ -53,6 +53,18 @@ def test_layernorm_row_prologue_of_the_small_gemm(ctx):
             assert rel_l2(got, exp) < 3e-6, (case, j, rel_l2(got, exp))
 
 
+def test_split_bf16_gemm_cases(ctx):
+    """GHN3_GEMM_X3 + GHN3_CAST_SPLIT: split-bf16 products (hi.hi + hi.lo + lo.hi on v_mfma_f32_16x16x32_bf16) against fp64
+    on the Graphormer shapes of the released models, every tile / slice variant and epilogue; tolerance = the dropped
+    lo.lo term (2^-16 relative per product)."""
+    from gemm_cases import X3_CASES, run_x3_case
+    for k, case in enumerate(X3_CASES):
+        for j, (got, exp) in enumerate(run_x3_case(ctx, seed=k, **case)):
+            assert np.isfinite(got).all(), (case, j)
+            err = rel_l2(got, exp)
+            assert err < 3e-5, (case, j, err)
+
+
 def _run_forward(hip, nets, gb, training=False):
     plan = hip.compile(nets, gb, training=training)
     with torch.no_grad():

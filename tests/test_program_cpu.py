@@ -51,7 +51,7 @@ def _run_program(hip, nets, gb, training=True, **prog_kw):
     bufs[prog.xbuf(prog.X_SCAL)] = np.zeros(256 + 4 * max(prog.n_seg, 1) + 64, dtype=np.uint8)
     bufs[prog.xbuf(prog.X_GRADFLAT)] = gflat
     if prog.uses_shadow:
-        bufs[prog.xbuf(prog.X_SHADOW)] = np.zeros(prog.shadow_layout(prog.C, prog.max_shape)['nbytes'], dtype=np.uint8)
+        bufs[prog.xbuf(prog.X_SHADOW)] = np.zeros(prog.shadow_layout(prog.C, prog.max_shape, prog.Lyr)['nbytes'], dtype=np.uint8)
     it = Interp(bufs)
     it.run(prog.shadow_ops, prog.problems)      # (GHN3._refresh_shadows: only when the parameters changed)
     it.run(prog.fwd_ops, prog.problems)
@@ -258,3 +258,45 @@ def test_predict_class_layers_false_and_reduce_graph():
     prog_f, it_f, bufs_f, _ = _run_program(hip, *_tiny('b2')[:2], training=False)
     np.testing.assert_array_equal(bufs_r[prog_r.xbuf(prog_r.X_OUT)], bufs_f[prog_f.xbuf(prog_f.X_OUT)])
     assert extra.weight is None and extra.bias is None
+
+
+@pytest.mark.parametrize('nodes', [[30], [22, 17]])
+def test_split_bf16_graphormer_program(nodes):
+    """GHN3_GEMM_X3: the Graphormer linears (forward and dgrad) on split-bf16 operands against persistent hi / lo weight
+    copies (GHN3_CAST_SPLIT), K splits as partial planes summed by the LayerNorm ops.  Decoder exact fp32, so the only
+    deviation from the oracle is the dropped lo.lo term (2^-16 relative): forward 2e-5, gradients 1e-4."""
+    from util_parity import synthetic_case
+    cfg = dict(max_shape=(64, 64, 16, 16), num_classes=1000, hid=64, heads=8, layers=2, weight_norm=True, ve=True,
+               layernorm=True)
+    hip, oracle = _build(cfg, recipe.TINY_SEED, 'reference')
+    nets_h, gb_h, nets_o, gb_o = synthetic_case(nodes, 3100)
+    prog, it, bufs, gflat = _run_program(hip, nets_h, gb_h, graphormer_x3=True)
+    assert prog.x3 and prog.uses_shadow
+    n_x3 = sum(int(p['flags']) & L.GEMM_X3 != 0 for p in prog.problems)
+    assert n_x3 >= 8 * cfg['layers']                              # 4 forward + 4 dgrad linears per layer (+ K splits)
+    n_planes = sum(1 for o in list(prog.fwd_ops) + list(prog.bwd_ops)
+                   if int(o['kind']) in (L.OP_LAYERNORM_FWD, L.OP_LAYERNORM_BWD) and int(o['i'][2]) > 0)
+    assert n_planes >= 2 * cfg['layers']                          # K-split planes are consumed by LayerNorm ops
+    out = bufs[prog.xbuf(prog.X_OUT)].view(np.float32)
+    oracle.train()
+    _, pred_o = oracle(nets_o, gb_o, keep_grads=True)
+    loss_o = 0
+    dout = bufs[prog.xbuf(prog.X_DOUT)].view(np.float32)
+    for k, (ind, attr, m, t) in enumerate(pred_o):
+        p = prog.predicted[k]
+        got = out[p['offset']:p['offset'] + p['numel']].reshape(p['tile_shape'])
+        assert rel_l2(got, t.detach().numpy()) < 2e-5, (k, attr, rel_l2(got, t.detach().numpy()))
+        loss_o = loss_o + torch.norm(t, p='fro')
+        v = t.detach().numpy().astype(np.float64)
+        dout[p['offset']:p['offset'] + p['numel']] = (v / np.linalg.norm(v)).reshape(-1)
+    gflat[:] = 0x7f
+    hip._patch_grad_memsets(prog)
+    it.run(prog.bwd_ops, prog.problems)
+    loss_o.backward()
+    po = dict(oracle.named_parameters())
+    g32 = gflat.view(np.float32)
+    for name, off in zip(prog.names, hip._offs):
+        ref = po[name].grad.numpy()
+        got = g32[int(off):int(off) + ref.size].reshape(ref.shape)
+        err = float(np.linalg.norm(got.astype(np.float64) - ref))
+        assert err < 1e-4 * float(np.linalg.norm(ref)) + 2e-6, (name, err, float(np.linalg.norm(ref)))

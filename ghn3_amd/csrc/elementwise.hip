@@ -267,6 +267,7 @@ int ghn3_bias_hist(float* dT, const float* dBias, const int* pair, int B, int N,
 // `add` (optional): second K-half plane of the GEMM that produced x (split-K over two workgroup sets, see
 // program.py::_split_k): the row is x + add, written back to x for the later readers of the residual stream.
 #define LN_REG 8
+#define LN_PLANES 7          // addend planes whose loads are issued together (more are summed in a loop)
 __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* __restrict__ y, float* __restrict__ x,
                                                             const float* __restrict__ g, const float* __restrict__ bta,
                                                             float* __restrict__ mean, float* __restrict__ rstd,
@@ -285,10 +286,26 @@ __global__ __launch_bounds__(256) void layernorm_fwd_kernel(float* __restrict__ 
             const int c = lane + 64 * j;
             const bool in = c < C;
             xv[j] = in ? xr[c] : 0.f;
-            if (ar)
-                for (int p = 0; p < n_add; ++p) xv[j] += in ? ar[p * add_stride + c] : 0.f;     // (plane order: fixed)
             gv[j] = in ? g[c] : 0.f;
             bv[j] = in ? bta[c] : 0.f;
+        }
+        if (ar) {
+            // K-slice planes of the producing GEMM: every load of the row is issued before the first add (one round trip
+            // for all planes: a loop with a run-time trip count serialised them), summed in plane order
+            float pv[LN_PLANES][LN_REG];
+#pragma unroll
+            for (int p = 0; p < LN_PLANES; ++p)
+#pragma unroll
+                for (int j = 0; j < LN_REG; ++j) {
+                    const int c = lane + 64 * j;
+                    pv[p][j] = (p < n_add && c < C) ? ar[p * add_stride + c] : 0.f;
+                }
+#pragma unroll
+            for (int p = 0; p < LN_PLANES; ++p)
+#pragma unroll
+                for (int j = 0; j < LN_REG; ++j) xv[j] += pv[p][j];
+            for (int p = LN_PLANES; p < n_add; ++p)
+                for (int j = 0; j < LN_REG; ++j) { const int c = lane + 64 * j; if (c < C) xv[j] += ar[p * add_stride + c]; }
         }
         float s = 0.f;
 #pragma unroll
@@ -356,15 +373,30 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(float* __restrict__ 
         for (int j = 0; j < LN_REG; ++j) {
             const int c = lane + 64 * j;
             const bool in = c < C;
-            float d = in ? gr[c] : 0.f;
-            if (ar) {
-                for (int p = 0; p < n_add; ++p) d += in ? ar[p * add_stride + c] : 0.f;
-                if (in) gr[c] = d;
-            }
-            dgv[j] = d * (in ? g[c] : 0.f);
+            dgv[j] = in ? gr[c] : 0.f;
             xh[j] = in ? xr[c] : 0.f;
             rv[j] = (rr && in) ? rr[c] : 0.f;
         }
+        if (ar) {
+            float pv[LN_PLANES][LN_REG];
+#pragma unroll
+            for (int p = 0; p < LN_PLANES; ++p)
+#pragma unroll
+                for (int j = 0; j < LN_REG; ++j) {
+                    const int c = lane + 64 * j;
+                    pv[p][j] = (p < n_add && c < C) ? ar[p * add_stride + c] : 0.f;
+                }
+#pragma unroll
+            for (int p = 0; p < LN_PLANES; ++p)
+#pragma unroll
+                for (int j = 0; j < LN_REG; ++j) dgv[j] += pv[p][j];
+            for (int p = LN_PLANES; p < n_add; ++p)
+                for (int j = 0; j < LN_REG; ++j) { const int c = lane + 64 * j; if (c < C) dgv[j] += ar[p * add_stride + c]; }
+#pragma unroll
+            for (int j = 0; j < LN_REG; ++j) { const int c = lane + 64 * j; if (c < C) gr[c] = dgv[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < LN_REG; ++j) { const int c = lane + 64 * j; dgv[j] *= (c < C) ? g[c] : 0.f; }
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
         for (int j = 0; j < LN_REG; ++j)
@@ -969,6 +1001,66 @@ int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, float*
         hipLaunchKernelGGL(dact_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, s, X, aux, M, N, ld, dact, amax,
                            parts, n_parts, part_stride, rows_parts);
     return launch_ok("dact");
+}
+
+// GHN3_OP_RELU_FIX (see include/ghn3_hip.h): in-place ReLU of the classifier tiles; elements within tau of zero are
+// recomputed in fp32 from the master weights first, so that the ReLU mask of the backward does not hang on 16-bit rounding.
+__global__ __launch_bounds__(256) void relu_fix_kernel(float* __restrict__ X, const float* __restrict__ U,
+                                                       const float* __restrict__ W, const float* __restrict__ bias,
+                                                       int cols, int ld, int K, int q, int sdim, float tau_rel) {
+    __shared__ float part[4];
+    __shared__ int cnt;
+    __shared__ int list[1024];
+    const int r = blockIdx.y, c0 = blockIdx.x * 1024, tid = threadIdx.x;
+    float* xr = X + (size_t)r * ld;
+    const int c = c0 + tid * 4;
+    float v[4] = {0.f, 0.f, 0.f, 0.f};
+    const bool vec = c + 3 < cols;
+    if (vec) { const float4 t = *reinterpret_cast<const float4*>(xr + c); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else for (int e = 0; e < 4; ++e) if (c + e < cols) v[e] = xr[c + e];
+    float ss = v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    if (tid == 0) cnt = 0;
+    if ((tid & 63) == 0) part[tid >> 6] = ss;
+    __syncthreads();
+    const int n_valid = min(1024, cols - c0);
+    const float tau = tau_rel > 0.f ? tau_rel * sqrtf((part[0] + part[1] + part[2] + part[3]) / (float)n_valid) : -1.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+        if (c + e < cols && fabsf(v[e]) < tau) list[atomicAdd(&cnt, 1)] = tid * 4 + e;
+    if (vec) *reinterpret_cast<float4*>(xr + c) = make_float4(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f), fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+    else for (int e = 0; e < 4; ++e) if (c + e < cols) xr[c + e] = fmaxf(v[e], 0.f);
+    __syncthreads();
+    // one wave per candidate: exact fp32 dot product of the weight row with this decoder row's hidden vector
+    const int n = cnt, lane = tid & 63;
+    const float* ur = U + (size_t)r * K;
+    for (int k = tid >> 6; k < n; k += 4) {
+        const int cc = c0 + list[k];
+        const int wrow = q > 0 ? (cc / q) * sdim + cc % q : cc;
+        const float* wr = W + (size_t)wrow * K;
+        float acc = 0.f;
+        for (int j = lane * 4; j < K; j += 256) {                     // (K % 4 == 0)
+            const float4 a = *reinterpret_cast<const float4*>(wr + j);
+            const float4 b = *reinterpret_cast<const float4*>(ur + j);
+            acc += (a.x * b.x + a.y * b.y) + (a.z * b.z + a.w * b.w);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+        if (lane == 0) xr[cc] = fmaxf(acc + (bias ? bias[wrow] : 0.f), 0.f);
+    }
+}
+int ghn3_relu_fix(float* X, const float* U, const float* W, const float* bias, int rows, int cols, int ld, int K, int q,
+                  int sdim, float tau_rel, hipStream_t s) {
+    if (rows <= 0 || cols <= 0) return GHN3_OK;
+    if ((ld & 3) || (K & 3) || (reinterpret_cast<uintptr_t>(X) & 15) || (reinterpret_cast<uintptr_t>(U) & 15) ||
+        (reinterpret_cast<uintptr_t>(W) & 15)) {
+        ghn3_set_error("relu_fix: ld %% 4, K %% 4 and 16-byte aligned X / U / W required");
+        return GHN3_E_ARG;
+    }
+    hipLaunchKernelGGL(relu_fix_kernel, dim3((cols + 1023) / 1024, rows), dim3(256), 0, s, X, U, W, bias, cols, ld, K, q,
+                       sdim, tau_rel);
+    return launch_ok("relu_fix");
 }
 
 __global__ __launch_bounds__(256) void add_kernel(float* __restrict__ dst, const float* __restrict__ src, int64_t n) {

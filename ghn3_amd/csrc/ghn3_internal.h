@@ -93,6 +93,9 @@ int ghn3_adamw(float* p, const float* g, float* m, float* v, int64_t n, const fl
 int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, float* amax, const float* parts, int n_parts,
               int64_t part_stride, int rows_parts, hipStream_t s);
 
+int ghn3_relu_fix(float* X, const float* U, const float* W, const float* bias, int rows, int cols, int ld, int K, int q,
+                  int sdim, float tau_rel, hipStream_t s);
+
 void ghn3_set_error(const char* fmt, ...);
 
 #ifdef __HIPCC__

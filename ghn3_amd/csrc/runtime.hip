@@ -550,6 +550,11 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             (float)h[4], (float)h[5], (float)h[6], o.f[0], stream);
             break;
         }
+        case GHN3_OP_RELU_FIX:
+            rc = ghn3_relu_fix(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const float>(o.r[2]),
+                               R.get<const float>(o.r[3]), (int)o.i[0], (int)o.i[1], (int)o.i[2], (int)o.i[3], (int)o.i[4],
+                               (int)o.i[5], o.f[0], stream);
+            break;
         case GHN3_OP_DACT:
             rc = ghn3_dact(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), (int)o.i[0], (int)o.i[1], (int)o.i[2],
                            (int)o.i[3], R.get<float>(o.r[2]), R.get<const float>(o.r[3]), (int)o.i[4], (int64_t)o.i[5],

@@ -476,12 +476,17 @@ class Program:
         # o' < o_r only -- a ragged extent that the kernel receives as one limit per 128 rows (forward: columns,
         # dgrad: reduction length, ghn3_gemm_problem::lim) -- and every W2 tile is streamed from HBM once per
         # family instead of once per (o, i) group.
-        fam = lambda g_: self.direct16 and g_['kind'] == 'conv' and g_['i_ld'] % 8 == 0
+        # The classifier-weight rows (nn.py:755-758: tile over ALL C output rows, then relu -> class_layer_predictor) are
+        # family members like any convolution row with o = C (one row alone cost a whole 128-row tile sweep over W2:
+        # 0.19 ms of the forward at ghn3xlm16, again in the dgrad); their ReLU is applied afterwards by GHN3_OP_RELU_FIX.
+        fam = lambda g_: self.direct16 and g_['i_ld'] % 8 == 0 and \
+            (g_['kind'] == 'conv' or os.environ.get('GHN3_CLS_FAMILY', '1') != '0')
         # (groups the 16-bit pipeline can take -- i % 8 == 0 -- come first: their decoder rows are contiguous, which the
         # plane-wise dgrad reduction relies on)
         cap16 = lambda g_: self.direct16 and g_['i_ld'] % 8 == 0
         order = sorted(range(len(self.conv_groups)),
-                       key=lambda k: (not cap16(self.conv_groups[k]), self.conv_groups[k]['kind'] == 'cls',
+                       key=lambda k: (not cap16(self.conv_groups[k]),
+                                      self.conv_groups[k]['kind'] == 'cls' and not fam(self.conv_groups[k]),
                                       (0, -self.conv_groups[k]['i_ld'], -self.conv_groups[k]['o'])
                                       if fam(self.conv_groups[k]) else
                                       (1, -self.conv_groups[k]['cols'], self.conv_groups[k]['o']),
@@ -492,8 +497,9 @@ class Program:
             g['row0'] = row
             row += g['rows']
             last = self.gemm_groups[-1] if self.gemm_groups else None
-            same = last is not None and g['kind'] == 'conv' and last['kind'] == 'conv' and \
-                last['i_ld'] == g['i_ld'] and (last['o'] == g['o'] or (fam(g) and last['family']))
+            same = last is not None and last['i_ld'] == g['i_ld'] and \
+                ((fam(g) and last['family']) or
+                 (g['kind'] == 'conv' and last['kind'] == 'conv' and last['o'] == g['o']))
             if same:
                 last['rows'] += g['rows']
                 last['members'].append(g)
@@ -645,8 +651,16 @@ class Program:
         to_qkv 6.4 (9.9), to_out 4.4 (6.5), ff.net.0 6.4 (10.3), ff.net.3 7.3 (10.0 with its two K halves)."""
         nk = K // 64
         whole = max(d for d in (6, 4, 3, 2, 1) if nk % d == 0)         # k-tiles per slice without a split
+        plan = os.environ.get('GHN3_X3_PLAN', 'A')
         if N > 512:
             return 40, 1, 64 * whole
+        if plan == 'B':                                                  # 32 x 64 tiles, slices of up to 384: few planes
+            return 40, (nk // whole if may_split else 1), 64 * whole
+        if plan == 'C':                                                  # 64 x 64 tiles, slices of 192 / 128
+            for d in (3, 2, 4, 1):
+                if nk % d == 0 and (nk // d <= 8 and may_split or nk == d):
+                    return 41, nk // d, 64 * d
+            return 40, (nk // whole if may_split else 1), 64 * whole
         if not may_split:
             return 42, 1, 64 * whole
         for d in (3, 2, 4, 6, 1):
@@ -875,8 +889,7 @@ class Program:
                     self.gemm(self.href(self.uh + g['row0'] * 8 * C), self.sref(self.w2h),
                               self.wref('tiles', g['tile_off']),
                               g['rows'], g['cols'], 8 * C, 8 * C, 8 * C, g['ld'], b_qs=(g['i_ld'], ms[1]),
-                              bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1],
-                              act=L.ACT_RELU if g['kind'] == 'cls' else L.ACT_NONE, op16=True,
+                              bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1], op16=True,
                               lim=self.idx(g['lim128']) if g['ragged'] else None, lim_kind=1)
                     continue
                 for (r0, nr) in self._row_parts(g['rows']):
@@ -886,6 +899,18 @@ class Program:
                               bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1],
                               act=L.ACT_RELU if g['kind'] == 'cls' else L.ACT_NONE)
             self.gemm_op(p0, tag=self.TAG_D3_FWD, flops=fl)
+            # classifier rows of the 16-bit pipeline: ReLU afterwards, elements the f16 product left within 5e-3 rms of
+            # zero recomputed in fp32 (their sign is the ReLU mask of the backward)
+            for gg in self.gemm_groups:
+                if not gg['op16']:
+                    continue
+                for g in gg['members']:
+                    if g['kind'] == 'cls':
+                        self.op(L.OP_RELU_FIX,
+                                refs=(self.wref('tiles', g['tile_off']), (u[0], u[1] + 4 * g['row0'] * 8 * C),
+                                      self.pref(W2), self.pref(b2)),
+                                ints=(g['rows'], g['cols'], g['ld'], 8 * C, g['i_ld'], ms[1]),
+                                floats=(float(os.environ.get('GHN3_RELU_FIX_TAU', '5e-3')),))
             p0 = len(self._probs)
             for g in self.conv_groups:
                 if 'resize' in g:

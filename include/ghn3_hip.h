@@ -286,6 +286,14 @@ enum ghn3_op_kind {
      *        weight_decay, 1 - beta1^t, 1 - beta2^t */
     GHN3_OP_SUMSQ = 26,
     GHN3_OP_ADAMW = 27,
+    /* ReLU of the classifier tiles (nn.py:755-758 `relu(x)` in front of class_layer_predictor) with EXACT masks in the
+     * 16-bit modes: X[r][c] = relu(X[r][c]) in place, except that elements the 16-bit GEMM left within f0 * rms of zero
+     * (rms over their 1024-element chunk; ~0.4 % of the elements) are first recomputed in fp32,
+     * X[r][c] = relu(dot(W[wrow(c)][0..K), U[r][0..K)) + bias[wrow(c)]), wrow(c) = (c / q) * s + c % q.
+     * A sign decided by a 3e-4 rounding error would otherwise flip the ReLU mask of that element in the backward -- an
+     * O(1) error of a whole dW2 row.  r0=X [rows][ld] r1=U [rows][K] r2=W [.][K] r3=bias or absent
+     * i: rows, cols, ld, K, q, s ; f0 = threshold factor (<= 0: plain ReLU) */
+    GHN3_OP_RELU_FIX = 28,
     GHN3_OP_KIND_COUNT
 };
 

@@ -57,6 +57,27 @@ class Interp:
     def op_detach(self, o, problems):
         pass
 
+    def op_relu_fix(self, o, problems):
+        rows, cols, ld, K, q, s_ = (int(v) for v in o['i'][:6])
+        X = self.tail(o['r'][0], np.float32)
+        U = self.tail(o['r'][1], np.float32)
+        W = self.tail(o['r'][2], np.float32)
+        b = self.tail(o['r'][3], np.float32)
+        tau_rel = float(o['f'][0])
+        c = np.arange(cols)
+        wrow = (c // q) * s_ + c % q if q > 0 else c
+        for r in range(rows):
+            x = X[r * ld:r * ld + cols]
+            if tau_rel > 0:
+                for c0 in range(0, cols, 1024):
+                    seg = x[c0:c0 + 1024]
+                    tau = tau_rel * np.sqrt(float((seg.astype(np.float64) ** 2).mean()))
+                    for k in np.nonzero(np.abs(seg) < tau)[0]:
+                        wr = wrow[c0 + k]
+                        v = float(W[wr * K:(wr + 1) * K].astype(np.float64) @ U[r * K:(r + 1) * K].astype(np.float64))
+                        seg[k] = v + (float(b[wr]) if b is not None else 0.0)
+            np.maximum(x, 0, out=x)
+
     def op_sumsq(self, o, problems):
         n = int(o['i'][0])
         x = self.fview(o['r'][1], n).astype(np.float64)

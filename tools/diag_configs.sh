@@ -1,3 +1,4 @@
 cd "${GRAFT_REPO_ROOT:-.}"
-timeout 600 python -m pytest tests/test_gpu_parity.py -m gpu -q -x -k "split_bf16 or gemm_cases" 2>&1 | tail -15
-timeout 900 python tests/x3_bench.py 2>&1 | grep -v amdgpu.ids
+for args in "ghn3lm8 f16 25 40" "ghn3xlm16 f16 40"; do
+  timeout 600 python tests/gpu_diag_configs.py $args 2>&1 | grep -v amdgpu.ids | head -8 | cut -c1-160
+done

@@ -114,44 +114,68 @@ int ghn3_embed_nodes(float* x, const int* node_type, const int* shape_idx, const
     return launch_ok("embed_nodes");
 }
 
+// Deterministic scatter-add: one workgroup per TABLE ROW gathers the gradient rows of the nodes that index it, in node
+// order (float atomics in node-major order gave run-to-run different sums).  Tables in block order: type (n_type rows),
+// channel (n_ch), spatial (n_sp), in-degree (101), out-degree (101), input distance (1001); every workgroup scans the
+// node index arrays (a few hundred nodes), rows nobody indexes are left untouched (zero-initialised gradients).
 __global__ __launch_bounds__(256) void embed_bwd_kernel(
     const float* __restrict__ dx, const int* __restrict__ node_type, const int* __restrict__ shape_idx,
     const int* __restrict__ n_nodes, const int* __restrict__ node_off, float* __restrict__ dE_type,
     float* __restrict__ dE_ch, float* __restrict__ dE_sp, float* __restrict__ dE_in, float* __restrict__ dE_out,
     float* __restrict__ dE_dist, const int* __restrict__ deg_in, const int* __restrict__ deg_out,
-    const int* __restrict__ dist0, int B, int N, int C) {
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= B * N) return;
-    const int lane = threadIdx.x & 63;
-    const int b = row / N, i = row - b * N;
-    if (i >= n_nodes[b]) return;                      // x * mask: padded rows carry no gradient
-    const float* g = dx + (size_t)row * C;
-    const int sidx = node_off[b] + i;
-    const int t = node_type[sidx];
-    const int s0 = shape_idx[4 * sidx], s1 = shape_idx[4 * sidx + 1], s2 = shape_idx[4 * sidx + 2],
-              s3 = shape_idx[4 * sidx + 3];
-    const int di = deg_in[row], dout = deg_out[row], dd = dist0[row];
+    const int* __restrict__ dist0, int B, int N, int C, int n_type, int n_ch, int n_sp) {
+    int r = blockIdx.x, tab = 0;
+    const int sizes[6] = {n_type, n_ch, n_sp, 101, 101, 1001};
+    while (tab < 5 && r >= sizes[tab]) { r -= sizes[tab]; ++tab; }
     const int cq = C >> 2;
-    for (int c = lane; c < C; c += 64) {
-        const float v = g[c];
-        const int part = c / cq, cc = c - part * cq;
-        atomicAdd(&dE_type[(size_t)t * C + c], v);
-        if (part == 0) atomicAdd(&dE_ch[(size_t)s0 * cq + cc], v);
-        else if (part == 1) atomicAdd(&dE_ch[(size_t)s1 * cq + cc], v);
-        else if (part == 2) atomicAdd(&dE_sp[(size_t)s2 * cq + cc], v);
-        else atomicAdd(&dE_sp[(size_t)s3 * cq + cc], v);
-        atomicAdd(&dE_in[(size_t)di * C + c], v);
-        atomicAdd(&dE_out[(size_t)dout * C + c], v);
-        atomicAdd(&dE_dist[(size_t)dd * C + c], v);
+    const int width = (tab == 1 || tab == 2) ? cq : C;
+    float acc[2] = {0.f, 0.f};                         // columns threadIdx.x and threadIdx.x + 256 (C <= 512)
+    bool hit = false;
+    for (int b = 0; b < B; ++b) {
+        const int nb = n_nodes[b], off = node_off[b];
+        for (int i = 0; i < nb; ++i) {
+            const int row = b * N + i, sidx = off + i;
+            const float* g = dx + (size_t)row * C;
+            int m0 = 0, m1 = 0, base0 = 0, base1 = 0;    // up to two matching column blocks of the gradient row
+            if (tab == 0) m0 = node_type[sidx] == r;
+            else if (tab == 1) { m0 = shape_idx[4 * sidx] == r; m1 = shape_idx[4 * sidx + 1] == r; base1 = cq; }
+            else if (tab == 2) { m0 = shape_idx[4 * sidx + 2] == r; m1 = shape_idx[4 * sidx + 3] == r; base0 = 2 * cq; base1 = 3 * cq; }
+            else if (tab == 3) m0 = deg_in[row] == r;
+            else if (tab == 4) m0 = deg_out[row] == r;
+            else m0 = dist0[row] == r;
+            if (!(m0 | m1)) continue;                  // (uniform over the workgroup)
+            hit = true;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int c = threadIdx.x + 256 * k;
+                if (c < width) {
+                    if (m0) acc[k] += g[base0 + c];
+                    if (m1) acc[k] += g[base1 + c];
+                }
+            }
+        }
+    }
+    if (!hit) return;
+    float* dst = tab == 0 ? dE_type : tab == 1 ? dE_ch : tab == 2 ? dE_sp : tab == 3 ? dE_in : tab == 4 ? dE_out : dE_dist;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int c = threadIdx.x + 256 * k;
+        if (c < width) dst[(size_t)r * width + c] += acc[k];
     }
 }
 
 int ghn3_embed_bwd(const float* dx, const int* node_type, const int* shape_idx, const int* n_nodes,
                    const int* node_off, float* dE_type, float* dE_ch, float* dE_sp, float* dE_in, float* dE_out,
                    float* dE_dist, const int* deg_in, const int* deg_out, const int* dist0, int B, int N, int C,
-                   hipStream_t s) {
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3((B * N + 3) / 4), dim3(256), 0, s, dx, node_type, shape_idx, n_nodes,
-                       node_off, dE_type, dE_ch, dE_sp, dE_in, dE_out, dE_dist, deg_in, deg_out, dist0, B, N, C);
+                   int n_type, int n_ch, int n_sp, hipStream_t s) {
+    if (C > 512 || n_type <= 0 || n_ch <= 0 || n_sp <= 0) {
+        ghn3_set_error("embed_bwd: C <= 512 and the table row counts (i3..i5) are required");
+        return GHN3_E_ARG;
+    }
+    const int blocks = n_type + n_ch + n_sp + 101 + 101 + 1001;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), 0, s, dx, node_type, shape_idx, n_nodes,
+                       node_off, dE_type, dE_ch, dE_sp, dE_in, dE_out, dE_dist, deg_in, deg_out, dist0, B, N, C, n_type,
+                       n_ch, n_sp);
     return launch_ok("embed_bwd");
 }
 
@@ -217,43 +241,77 @@ int ghn3_bias_gather(float* bias, const float* T, const int* pair, int B, int N,
     return launch_ok("bias_gather");
 }
 
-// dT[p][h] += sum_{(b,i,j): pair == p} dBias[b,h,i,j].  One block per (row chunk, head, graph) with an
-// LDS-private histogram (ds_add_f32), flushed with one global atomic per touched bin.
-__global__ __launch_bounds__(256) void bias_hist_kernel(float* __restrict__ dT, const float* __restrict__ dBias,
-                                                        const int* __restrict__ pair, int N, int H, int V, int ldT,
-                                                        int rows_per_block, int use_lds) {
-    extern __shared__ __attribute__((aligned(16))) float hist[];
+// dT[p][h] += sum_{(b,i,j): pair == p} dBias[b,h,i,j]  -- deterministic: the histogram is accumulated in 64-bit FIXED
+// POINT (integer addition is associative, so the order in which the atomics land does not matter).  Three small passes:
+// max |dBias| (atomicMax on the bit pattern) -> scale 2^(30 - e) for amax = m 2^e, so that every term is below 2^31 and
+// 2^24 of them still fit 63 bits with 2^-31 relative resolution (finer than an fp32 sum); the LDS-private int64
+// histograms per (row chunk, head, graph) flushed with 64-bit global atomics; the conversion back to fp32.
+// scratch: int64 [V * V * H] (zeroed by the caller) followed by one float (amax, zeroed with it).
+__global__ __launch_bounds__(256) void bias_amax_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ amax) {
+    float m = 0.f;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n; e += (int64_t)gridDim.x * 256) m = fmaxf(m, fabsf(x[e]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
+    if ((threadIdx.x & 63) == 0 && m > 0.f) atomicMax(reinterpret_cast<int*>(amax), __float_as_int(m));
+}
+__device__ __forceinline__ float fix_scale(float amax) {            // 2^(30 - e), amax = m 2^e
+    if (!(amax > 0.f)) return 1.f;
+    const int e = (int)((__float_as_uint(amax) >> 23) & 0xff) - 127;
+    return __uint_as_float((unsigned)(127 + 30 - e) << 23);
+}
+__global__ __launch_bounds__(256) void bias_hist_kernel(long long* __restrict__ acc, const float* __restrict__ dBias,
+                                                        const int* __restrict__ pair, int N, int H, int V,
+                                                        int rows_per_block, int use_lds, const float* __restrict__ amax) {
+    extern __shared__ __attribute__((aligned(16))) long long hist[];
     const int b = blockIdx.z, h = blockIdx.y;
     const int i0 = blockIdx.x * rows_per_block;
     const int i1 = min(N, i0 + rows_per_block);
     const int bins = V * V;
+    const float sc = fix_scale(*amax);
     if (use_lds) {
-        for (int k = threadIdx.x; k < bins; k += 256) hist[k] = 0.f;
+        for (int k = threadIdx.x; k < bins; k += 256) hist[k] = 0;
         __syncthreads();
     }
     const size_t total = (size_t)(i1 - i0) * N;
     for (size_t e = threadIdx.x; e < total; e += 256) {
         const size_t off = (size_t)i0 * N + e;
         const int p = pair[(size_t)b * N * N + off];
-        const float g = dBias[((size_t)b * H + h) * N * N + off];
-        if (use_lds) atomicAdd(&hist[p], g);
-        else atomicAdd(&dT[(size_t)p * ldT + h], g);
+        const long long g = (long long)llrintf(dBias[((size_t)b * H + h) * N * N + off] * sc);
+        if (g == 0) continue;
+        if (use_lds) atomicAdd(reinterpret_cast<unsigned long long*>(&hist[p]), (unsigned long long)g);
+        else atomicAdd(reinterpret_cast<unsigned long long*>(&acc[(size_t)p * H + h]), (unsigned long long)g);
     }
     if (use_lds) {
         __syncthreads();
         for (int k = threadIdx.x; k < bins; k += 256) {
-            const float v = hist[k];
-            if (v != 0.f) atomicAdd(&dT[(size_t)k * ldT + h], v);
+            const long long v = hist[k];
+            if (v != 0) atomicAdd(reinterpret_cast<unsigned long long*>(&acc[(size_t)k * H + h]), (unsigned long long)v);
         }
     }
 }
-int ghn3_bias_hist(float* dT, const float* dBias, const int* pair, int B, int N, int H, int V, hipStream_t s) {
+__global__ __launch_bounds__(256) void bias_hist_finish_kernel(float* __restrict__ dT, const long long* __restrict__ acc,
+                                                               int bins, int H, int ldT, const float* __restrict__ amax) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= bins * H) return;
+    const float inv = 1.f / fix_scale(*amax);                         // (exact: a power of two)
+    dT[(size_t)(e / H) * ldT + e % H] += (float)((double)acc[e] * (double)inv);
+}
+int ghn3_bias_hist(float* dT, const float* dBias, const int* pair, int B, int N, int H, int V, void* scratch,
+                   hipStream_t s) {
+    if (!scratch) { ghn3_set_error("bias_hist: r3 (zeroed int64 [V*V*H] + 16 bytes of scratch) is required"); return GHN3_E_ARG; }
     const int ldT = (H + 3) & ~3;
-    const size_t lds = (size_t)V * V * sizeof(float);
+    long long* acc = reinterpret_cast<long long*>(scratch);
+    float* amax = reinterpret_cast<float*>(acc + (size_t)V * V * H);
+    const int64_t n = (int64_t)B * H * N * N;
+    hipLaunchKernelGGL(bias_amax_kernel, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, s, dBias,
+                       n, amax);
+    const size_t lds = (size_t)V * V * sizeof(long long);
     const int use_lds = lds <= 64 * 1024;
     const int rpb = 16;
-    hipLaunchKernelGGL(bias_hist_kernel, dim3((N + rpb - 1) / rpb, H, B), dim3(256), use_lds ? lds : 0, s, dT, dBias,
-                       pair, N, H, V, ldT, rpb, use_lds);
+    hipLaunchKernelGGL(bias_hist_kernel, dim3((N + rpb - 1) / rpb, H, B), dim3(256), use_lds ? lds : 0, s, acc, dBias,
+                       pair, N, H, V, rpb, use_lds, amax);
+    hipLaunchKernelGGL(bias_hist_finish_kernel, dim3((V * V * H + 255) / 256), dim3(256), 0, s, dT, acc, V * V, H, ldT,
+                       amax);
     return launch_ok("bias_hist");
 }
 
@@ -448,19 +506,19 @@ int ghn3_layernorm_bwd(float* dx, float* dy, const float* x, const float* g, con
     return launch_ok("layernorm_bwd");
 }
 
-// dgamma[c] += sum_r dy[r,c] * xhat[r,c] ; dbeta[c] += sum_r dy[r,c].  Block = 64 columns x 4 row lanes,
-// 64-row chunks per block, one atomic per column per block (outputs are zero-initialised gradients).
+// dgamma[c] += sum_r dy[r,c] * xhat[r,c] ; dbeta[c] += sum_r dy[r,c].  Block = 64 columns x 4 row lanes over ALL rows
+// (row r goes to lane r % 4, the four lane sums are added in a fixed order): one writer per column, no atomics,
+// run-to-run identical sums.  (Off the critical path: it runs on the side stream.)
 __global__ __launch_bounds__(256) void ln_param_grad_kernel(float* __restrict__ dg, float* __restrict__ db,
                                                             const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean,
-                                                            const float* __restrict__ rstd, int rows, int C) {
+                                                            const float* __restrict__ rstd, int rows, int C, int accum) {
     __shared__ float sg[4][64], sb[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
-    const int r0 = blockIdx.y * 64;
     float ag = 0.f, ab = 0.f;
     if (c < C) {
-        for (int r = r0 + rl; r < min(rows, r0 + 64); r += 4) {
+        for (int r = rl; r < rows; r += 4) {
             const float d = dy[(size_t)r * C + c];
             ag += d * (x[(size_t)r * C + c] - mean[r]) * rstd[r];
             ab += d;
@@ -470,19 +528,47 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(float* __restrict__ 
     __syncthreads();
     if (rl == 0 && c < C) {
         const int l = threadIdx.x & 63;
-        atomicAdd(&dg[c], sg[0][l] + sg[1][l] + sg[2][l] + sg[3][l]);
-        atomicAdd(&db[c], sb[0][l] + sb[1][l] + sb[2][l] + sb[3][l]);
+        const float g = (sg[0][l] + sg[1][l]) + (sg[2][l] + sg[3][l]), b = (sb[0][l] + sb[1][l]) + (sb[2][l] + sb[3][l]);
+        dg[c] = accum ? dg[c] + g : g;
+        db[c] = accum ? db[c] + b : b;
     }
 }
 int ghn3_ln_param_grad(float* dg, float* db, const float* dy, const float* x, const float* mean, const float* rstd,
                        int rows, int C, int accum, hipStream_t s) {
-    if (!accum) {
-        hipMemsetAsync(dg, 0, sizeof(float) * C, s);
-        hipMemsetAsync(db, 0, sizeof(float) * C, s);
-    }
-    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((C + 63) / 64, (rows + 63) / 64), dim3(256), 0, s, dg, db, dy, x,
-                       mean, rstd, rows, C);
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((C + 63) / 64), dim3(256), 0, s, dg, db, dy, x, mean, rstd, rows, C,
+                       accum);
     return launch_ok("ln_param_grad");
+}
+
+// GHN3_OP_ROWSET_COLSUM: bias gradient of a decoder linear from the stacked row sets of its output gradient,
+//   out[o' * I + i'] += sum_{sets with o' < o_s, i' < i_s} sum_{r < rows_s} X[off_s + r * ld_s + o' * i_s + i']
+// (decoder.conv.2.bias: every decoder row contributes to the W2 rows o' < o_r, i' < i_r it consumed, nn.py:749-750;
+// decoder.conv.0.bias: one set with o = 1).  Block = 64 columns i' of one o' x 4 row lanes, sets and rows in a fixed
+// order, one writer per output: deterministic (the column sums fused into GHN3_OP_CAST16 used float atomics).
+struct RowSet { int64_t off; int32_t rows, o, i, ld; };
+__global__ __launch_bounds__(256) void rowset_colsum_kernel(float* __restrict__ out, const float* __restrict__ X,
+                                                            const RowSet* __restrict__ sets, int n_sets, int I) {
+    __shared__ float red[4][64];
+    const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int ip = blockIdx.x * 64 + l, op = blockIdx.y;
+    float acc = 0.f;
+    for (int k = 0; k < n_sets; ++k) {
+        const RowSet S = sets[k];
+        if (op >= S.o || blockIdx.x * 64 >= S.i) continue;             // (uniform)
+        if (ip < S.i) {
+            const float* p = X + S.off + (size_t)op * S.i + ip;
+            for (int r = rl; r < S.rows; r += 4) acc += p[(size_t)r * S.ld];
+        }
+    }
+    red[rl][l] = acc;
+    __syncthreads();
+    if (rl == 0 && ip < I) out[(size_t)op * I + ip] += (red[0][l] + red[1][l]) + (red[2][l] + red[3][l]);
+}
+int ghn3_rowset_colsum(float* out, const float* X, const void* sets, int n_sets, int O, int I, hipStream_t s) {
+    if (n_sets <= 0 || O <= 0 || I <= 0) return GHN3_OK;
+    hipLaunchKernelGGL(rowset_colsum_kernel, dim3((I + 63) / 64, O), dim3(256), 0, s, out, X,
+                       reinterpret_cast<const RowSet*>(sets), n_sets, I);
+    return launch_ok("rowset_colsum");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -752,14 +838,19 @@ __device__ __forceinline__ int first_segment_after(const int64_t* __restrict__ s
     }
     return lo;
 }
+// Deterministic: with the host table (first_seg) a chunk writes the partial sum of its k-th segment to slot
+// first_slot[chunk] + k of `parts` (first_slot[b] = first_seg[b] + b: a chunk touches segments first_seg[b] ..
+// first_seg[b + 1] at most), and param_sqrt_kernel adds a segment's slots in chunk order.  Without the table the partial
+// sums are added with float atomics.
 __global__ __launch_bounds__(256) void param_sq_kernel(const float* __restrict__ flat,
                                                        const int64_t* __restrict__ seg_off, float* __restrict__ norms,
-                                                       int n_seg, const int* __restrict__ first_seg) {
+                                                       int n_seg, const int* __restrict__ first_seg,
+                                                       float* __restrict__ parts) {
     __shared__ float red[4];
     const int64_t w0 = (int64_t)blockIdx.x * NORM_CHUNK, w1 = w0 + NORM_CHUNK;
     // (first_seg: host-computed first segment of every chunk -- saves the 8 dependent loads of the search)
-    for (int sgm = first_seg ? first_seg[blockIdx.x] : first_segment_after(seg_off, n_seg, w0);
-         sgm < n_seg && seg_off[2 * sgm] < w1; ++sgm) {
+    const int sg0 = first_seg ? first_seg[blockIdx.x] : first_segment_after(seg_off, n_seg, w0);
+    for (int sgm = sg0; sgm < n_seg && seg_off[2 * sgm] < w1; ++sgm) {
         const int64_t c0 = max(seg_off[2 * sgm], w0), c1 = min(seg_off[2 * sgm + 1], w1);
         float acc = 0.f;
         const int64_t a0 = (c0 + 3) & ~(int64_t)3, a1 = c1 & ~(int64_t)3;     // 16-byte aligned interior
@@ -780,32 +871,46 @@ __global__ __launch_bounds__(256) void param_sq_kernel(const float* __restrict__
         if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
         __syncthreads();
         if (threadIdx.x == 0) {
-            const float t = red[0] + red[1] + red[2] + red[3];
-            if (t != 0.f) atomicAdd(&norms[sgm], t);
+            const float t = (red[0] + red[1]) + (red[2] + red[3]);
+            if (parts && first_seg) parts[sg0 + (int64_t)blockIdx.x + (sgm - sg0)] = t;
+            else if (t != 0.f) atomicAdd(&norms[sgm], t);
         }
     }
 }
-__global__ void param_sqrt_kernel(float* __restrict__ loss, float* __restrict__ norms, int n_seg) {
+__global__ void param_sqrt_kernel(float* __restrict__ loss, float* __restrict__ norms, int n_seg,
+                                  const int64_t* __restrict__ seg_off, const int* __restrict__ first_seg,
+                                  const float* __restrict__ parts) {
     __shared__ float red[4];
+    __shared__ float tot[256];
     float acc = 0.f;
     for (int i = threadIdx.x; i < n_seg; i += 256) {
-        const float v = sqrtf(norms[i]);
+        float sq = norms[i];
+        if (parts && first_seg) {                                    // this segment's slots, in chunk order
+            sq = 0.f;
+            const int64_t b0 = seg_off[2 * i] / NORM_CHUNK, b1 = (seg_off[2 * i + 1] - 1) / NORM_CHUNK;
+            if (seg_off[2 * i + 1] > seg_off[2 * i])
+                for (int64_t b = b0; b <= b1; ++b) sq += parts[first_seg[b] + b + (i - first_seg[b])];
+        }
+        const float v = sqrtf(sq);
         norms[i] = v;
         acc += v;
     }
-    acc = wsum(acc);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    tot[threadIdx.x] = acc;                                           // (fixed-order sum over the 256 threads)
     __syncthreads();
-    if (threadIdx.x == 0) loss[0] += red[0] + red[1] + red[2] + red[3];
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 256; ++k) t += tot[k];
+        loss[0] += t;
+    }
 }
 int ghn3_param_norm_fwd(float* loss, const float* flat, const int64_t* seg_off, float* norms, int n_seg,
-                        int64_t flat_numel, const int* first_seg, hipStream_t s) {
+                        int64_t flat_numel, const int* first_seg, float* parts, hipStream_t s) {
     if (n_seg <= 0) return GHN3_OK;
-    hipMemsetAsync(norms, 0, sizeof(float) * n_seg, s);
+    if (!(parts && first_seg)) hipMemsetAsync(norms, 0, sizeof(float) * n_seg, s);
     const int64_t blocks = (flat_numel + NORM_CHUNK - 1) / NORM_CHUNK;
     hipLaunchKernelGGL(param_sq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, flat, seg_off, norms, n_seg,
-                       first_seg);
-    hipLaunchKernelGGL(param_sqrt_kernel, dim3(1), dim3(256), 0, s, loss, norms, n_seg);
+                       first_seg, parts);
+    hipLaunchKernelGGL(param_sqrt_kernel, dim3(1), dim3(256), 0, s, loss, norms, n_seg, seg_off, first_seg, parts);
     return launch_ok("param_norm_fwd");
 }
 __global__ __launch_bounds__(256) void param_norm_bwd_kernel(float* __restrict__ dflat, const float* __restrict__ flat,
@@ -1240,7 +1345,8 @@ int ghn3_cast16(const float* src, void* dst, const ghn3_cast_desc* d_desc, int n
 // nn.utils.clip_grad_norm_ and a fused AdamW update -- two passes over the flat parameter / gradient / moment buffers
 // instead of ~10 ATen launches per parameter tensor.
 // ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void sumsq_kernel(float* __restrict__ out, const float* __restrict__ x, int64_t n) {
+__global__ __launch_bounds__(256) void sumsq_kernel(float* __restrict__ out, const float* __restrict__ x, int64_t n,
+                                                    float* __restrict__ parts) {
     __shared__ float part[4];
     float acc = 0.f;
     const int64_t n4 = n >> 2;
@@ -1254,14 +1360,26 @@ __global__ __launch_bounds__(256) void sumsq_kernel(float* __restrict__ out, con
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
+    if (threadIdx.x == 0) {
+        const float t = (part[0] + part[1]) + (part[2] + part[3]);
+        if (parts) parts[blockIdx.x] = t; else atomicAdd(out, t);     // (parts: summed in block order below)
+    }
 }
-int ghn3_sumsq(float* out, const float* x, int64_t n, hipStream_t s) {
+__global__ void sumsq_finish_kernel(float* __restrict__ out, const float* __restrict__ parts, int n) {
+    __shared__ float tot[256];
+    float acc = 0.f;
+    for (int k = threadIdx.x; k < n; k += 256) acc += parts[k];
+    tot[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { float t = 0.f; for (int k = 0; k < 256; ++k) t += tot[k]; out[0] += t; }
+}
+int ghn3_sumsq(float* out, const float* x, int64_t n, float* parts, hipStream_t s) {
     if (n <= 0) return GHN3_OK;
     if (reinterpret_cast<uintptr_t>(x) & 15) { ghn3_set_error("sumsq: buffer must be 16-byte aligned"); return GHN3_E_ARG; }
     int64_t blocks = (n / 4 + 255) / 256;
     blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, x, n);
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, x, n, parts);
+    if (parts) hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, out, parts, (int)blocks);
     return launch_ok("sumsq");
 }
 

@@ -58,11 +58,13 @@ int ghn3_embed_nodes(float* x, const int* node_type, const int* shape_idx, const
 int ghn3_embed_bwd(const float* dx, const int* node_type, const int* shape_idx, const int* n_nodes,
                    const int* node_off, float* dE_type, float* dE_ch, float* dE_sp, float* dE_in, float* dE_out,
                    float* dE_dist, const int* deg_in, const int* deg_out, const int* dist0,
-                   int B, int N, int C, hipStream_t s);
+                   int B, int N, int C, int n_type, int n_ch, int n_sp, hipStream_t s);
 int ghn3_edge_hidden(float* hid, const float* Pfw, const float* Pbw, int V, int C, hipStream_t s);
 int ghn3_edge_hidden_bwd(float* dPfw, float* dPbw, float* dhid, const float* hid, int V, int C, hipStream_t s);
 int ghn3_bias_gather(float* bias, const float* T, const int* pair, int B, int N, int H, hipStream_t s);
-int ghn3_bias_hist(float* dT, const float* dBias, const int* pair, int B, int N, int H, int V, hipStream_t s);
+int ghn3_bias_hist(float* dT, const float* dBias, const int* pair, int B, int N, int H, int V, void* scratch,
+                   hipStream_t s);
+int ghn3_rowset_colsum(float* out, const float* X, const void* sets, int n_sets, int O, int I, hipStream_t s);
 int ghn3_layernorm_fwd(float* y, float* x, const float* g, const float* b, float* mean, float* rstd, const float* add,
                        int n_add, int64_t add_stride, int rows, int C, float eps, hipStream_t s);
 int ghn3_layernorm_bwd(float* dx, float* dy, const float* x, const float* g, const float* mean,
@@ -76,7 +78,7 @@ int ghn3_tile_bwd(const float* dflat, const float* const* srcs, float* const* ds
                   const ghn3_tile_desc* d_desc, int n_desc, int64_t total, const int64_t* blocks, int lds_bytes,
                   float* amax, hipStream_t s);
 int ghn3_param_norm_fwd(float* loss, const float* flat, const int64_t* seg_off, float* norms, int n_seg,
-                        int64_t flat_numel, const int* first_seg, hipStream_t s);
+                        int64_t flat_numel, const int* first_seg, float* parts, hipStream_t s);
 int ghn3_param_norm_bwd(float* dflat, const float* flat, const int64_t* seg_off, const float* norms, int n_seg,
                         float g, int64_t flat_numel, const int* first_seg, hipStream_t s);
 int ghn3_colsum(float* out, const float* X, int M, int N, int ld, int q, int sdim, int stride, int accum,
@@ -86,7 +88,7 @@ int ghn3_rowseg_sum(float* out, const float* X, const int* seg_ptr, const int* i
 int ghn3_add(float* dst, const float* src, int64_t n, hipStream_t s);
 int ghn3_cast16(const float* src, void* dst, const ghn3_cast_desc* d_desc, int n_desc, int total_blocks, float* dbias,
                 const float* amax, int grid_cap, hipStream_t s);
-int ghn3_sumsq(float* out, const float* x, int64_t n, hipStream_t s);
+int ghn3_sumsq(float* out, const float* x, int64_t n, float* parts, hipStream_t s);
 int ghn3_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float lr, float beta1,
                float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float max_norm,
                hipStream_t s);

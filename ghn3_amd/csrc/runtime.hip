@@ -441,7 +441,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                 R.get<const int>(o.r[3]), R.get<const int>(o.r[4]), R.get<float>(o.r[5]),
                                 R.get<float>(o.r[6]), R.get<float>(o.r[7]), R.get<float>(o.r[8]), R.get<float>(o.r[9]),
                                 R.get<float>(o.r[10]), R.get<const int>(o.r[11]), R.get<const int>(o.r[12]),
-                                R.get<const int>(o.r[13]), (int)o.i[0], (int)o.i[1], (int)o.i[2], stream);
+                                R.get<const int>(o.r[13]), (int)o.i[0], (int)o.i[1], (int)o.i[2], (int)o.i[3], (int)o.i[4],
+                                (int)o.i[5], stream);
             break;
         case GHN3_OP_EDGE_HIDDEN:
             rc = ghn3_edge_hidden(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const float>(o.r[2]),
@@ -457,7 +458,11 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             break;
         case GHN3_OP_BIAS_HIST:
             rc = ghn3_bias_hist(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const int>(o.r[2]),
-                                (int)o.i[0], (int)o.i[1], (int)o.i[2], (int)o.i[3], stream);
+                                (int)o.i[0], (int)o.i[1], (int)o.i[2], (int)o.i[3], R.get<void>(o.r[3]), stream);
+            break;
+        case GHN3_OP_ROWSET_COLSUM:
+            rc = ghn3_rowset_colsum(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const void>(o.r[2]),
+                                    (int)o.i[0], (int)o.i[1], (int)o.i[2], stream);
             break;
         case GHN3_OP_LAYERNORM_FWD:
             rc = ghn3_layernorm_fwd(R.get<float>(o.r[0]), R.get<float>(o.r[1]), R.get<const float>(o.r[2]),
@@ -508,7 +513,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         case GHN3_OP_PARAM_NORM_FWD:
             if (o.i[1] <= 0) { ghn3_set_error("PARAM_NORM_FWD: i1 (flat extent) missing"); rc = GHN3_E_ARG; break; }
             rc = ghn3_param_norm_fwd(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const int64_t>(o.r[2]),
-                                     R.get<float>(o.r[3]), (int)o.i[0], (int64_t)o.i[1], R.get<const int>(o.r[4]), stream);
+                                     R.get<float>(o.r[3]), (int)o.i[0], (int64_t)o.i[1], R.get<const int>(o.r[4]),
+                                     R.get<float>(o.r[5]), stream);
             break;
         case GHN3_OP_PARAM_NORM_BWD:
             if (o.i[1] <= 0) { ghn3_set_error("PARAM_NORM_BWD: i1 (flat extent) missing"); rc = GHN3_E_ARG; break; }
@@ -540,7 +546,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                              stream);
             break;
         case GHN3_OP_SUMSQ:
-            rc = ghn3_sumsq(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), o.i[0], stream);
+            rc = ghn3_sumsq(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), o.i[0], R.get<float>(o.r[2]), stream);
             break;
         case GHN3_OP_ADAMW: {
             double h[7];

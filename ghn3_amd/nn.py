@@ -82,7 +82,7 @@ class _Plan:
         self.idx = torch.from_numpy(program.idx_blob).to(dev)
         # zero-filled once: the padding of the 16-bit operand copies (Program.ws16) must read as finite zeros
         self.ws = torch.zeros(program.ws_bytes, dtype=torch.uint8, device=dev)
-        self.scal = torch.zeros(256 + 4 * max(program.n_seg, 1) + 64, dtype=torch.uint8, device=dev)
+        self.scal = torch.zeros(program.scal_bytes, dtype=torch.uint8, device=dev)
         self.bufs = np.zeros(program.n_bufs, dtype=np.uint64)
         self.sizes = [p['numel'] for p in program.predicted]
         self.tok = None

@@ -29,7 +29,7 @@ class FusedAdamW:
             raise L.Ghn3Error('FusedAdamW runs on an MI355X only (no CPU path)')
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
-        self.scal = torch.zeros(16, dtype=torch.float32, device=flat.device)
+        self.scal = torch.zeros(16 + 4096, dtype=torch.float32, device=flat.device)   # [norm^2 ...| partial sums]
         self.steps = 0
 
     def step(self, gflat):
@@ -44,12 +44,12 @@ class FusedAdamW:
         ops = np.zeros(3, dtype=L.OP_DT)
         ops['r']['buf'][:] = -1
         bufs = np.asarray([flat.data_ptr(), gflat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                           self.scal.data_ptr()], dtype=np.uint64)
+                           self.scal.data_ptr(), self.scal.data_ptr() + 64], dtype=np.uint64)
         ops[0]['kind'] = L.OP_MEMSET0
         ops[0]['r']['buf'][0] = 4
         ops[0]['i'][0] = 4
         ops[1]['kind'] = L.OP_SUMSQ if clip else L.OP_NOP
-        ops[1]['r']['buf'][:2] = (4, 1)
+        ops[1]['r']['buf'][:3] = (4, 1, 5)         # (r2: scratch for the fixed-order sum of the workgroup partials)
         ops[1]['i'][0] = n
         ops[2]['kind'] = L.OP_ADAMW
         ops[2]['r']['buf'][:5] = (0, 1, 2, 3, 4 if clip else -1)

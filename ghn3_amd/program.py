@@ -132,7 +132,7 @@ class Program:
 
         self.param_groups, self.params_map = bk.map_net_params(node_infos, self.n_nodes, nets, self.max_shape,
                                                                reduce_graph=reduce_graph)
-        vocab = bk.ShapeVocab(self.K, self.max_shape)
+        vocab = self.vocab = bk.ShapeVocab(self.K, self.max_shape)
         total_nodes = sum(self.n_nodes)
         self.shape_idx = vocab.indices(total_nodes, self.params_map, predict_class_layers)
         self.node_types = np.asarray(node_types, dtype=np.int32)
@@ -179,6 +179,9 @@ class Program:
         else:
             self.bwd_ops = np.zeros(0, dtype=L.OP_DT)
         self.problems = self._pack_problems()
+        # scalar buffer (X_SCAL): loss [0:256) | per-tensor norms | per-(chunk, tensor) partial sums of the norm pass
+        self.scal_bytes = 256 + round_up(4 * max(self.n_seg, 1), 64) + \
+            4 * (max(self.n_seg, 1) + (self.out_numel + 8191) // 8192 + 1) + 64
         self.ws_bytes = round_up(self._ws + 1024, ALIGN)
         self.idx_blob = np.zeros(max(self._idx_size, 16), dtype=np.uint8)
         for off, raw in self._idx_chunks:
@@ -1178,7 +1181,8 @@ class Program:
         self._ops = []
         self.op(L.OP_MEMSET0, refs=((scal, 0),), ints=(4,))
         self.op(L.OP_PARAM_NORM_FWD, refs=((scal, 0), (self.xbuf(self.X_OUT), 0), self.r_seg, (scal, 256),
-                                           self.r_seg_first), ints=(self.n_seg, self.out_numel))
+                                           self.r_seg_first, (scal, 256 + round_up(4 * max(self.n_seg, 1), 64))),
+                ints=(self.n_seg, self.out_numel))
         f_ops = self._finish_ops()
         self.op(L.OP_PARAM_NORM_BWD, refs=((self.xbuf(self.X_DOUT), 0), (self.xbuf(self.X_OUT), 0), self.r_seg,
                                            (scal, 256), self.r_seg_first), ints=(self.n_seg, self.out_numel),
@@ -1331,14 +1335,24 @@ class Program:
                                                (m_['row0'] - g['row0']) * g['ld'] + i_lo, rows=m_['rows'],
                                                cols=m_['o'] * bw, ld_src=g['ld'], src_map=(bw, m_['i']),
                                                transposed=(band['dthT'] + m_['k_off'], ktot, bct),
-                                               colsum=(bw, ms[1], i_lo), scaled=scaled, tight=True))
+                                               scaled=scaled, tight=True))
                         side_items.append(dict(src_off=u[1] // 4 + m_['row0'] * 8 * C, rows=m_['rows'], cols=8 * C,
                                                ld_src=8 * C, transposed=(band['uhT'] + m_['k_off'], ktot, bct),
                                                tight=True))
                     i_lo = i_hi
                 # the dgrad operand on the critical path; the wgrad operands (and the bias gradient) beside it
                 self.cast16((self.xbuf(self.X_WS), 0), items, amax=amax_t)
-                self.cast16((self.xbuf(self.X_WS), 0), side_items, dbias=self.gref(b2), flags=self.SIDE, amax=amax_t)
+                self.cast16((self.xbuf(self.X_WS), 0), side_items, flags=self.SIDE, amax=amax_t)
+                # decoder.conv.2.bias gradient: every decoder row adds its d_tiles row to the bias entries (o', i') it
+                # consumed -- one deterministic pass over d_tiles (fixed set / row order, one writer per entry)
+                sets = np.zeros(len(rowsets), dtype=[('off', '<i8'), ('rows', '<i4'), ('o', '<i4'), ('i', '<i4'),
+                                                     ('ld', '<i4')])
+                for k_, rs in enumerate(rowsets):
+                    g = rs['g']
+                    sets[k_] = (self._ws_names['d_tiles'] // 4 + g['tile_off'] + (rs['row0'] - g['row0']) * g['ld'],
+                                rs['rows'], rs['o'], rs['i'], g['ld'])
+                self.op(L.OP_ROWSET_COLSUM, refs=(self.gref(b2), (self.xbuf(self.X_WS), 0), self.idx(sets)),
+                        ints=(len(sets), ms[0], ms[1]), flags=self.SIDE)
             p0 = len(self._probs)
             fl = 0.0
             use_rect = bool(g16) and all(g['op16'] for g in self.gemm_groups if g['rows'] >= 512) and \
@@ -1466,9 +1480,13 @@ class Program:
                                   scaled=scaled)], amax=amax_u)
                 self.cast16((self.xbuf(self.X_WS), 0),
                             [dict(src_off=d_u[1] // 4, rows=M, cols=8 * C, ld_src=8 * C, transposed=(duhT, Mp, bct),
-                                  colsum=(0, 0), scaled=scaled),
+                                  scaled=scaled),
                              dict(src_off=t[1] // 4, rows=M, cols=4 * C, ld_src=4 * C, transposed=(thT, Mp, bct))],
-                            dbias=self.gref(b0), flags=self.SIDE, amax=amax_u)
+                            flags=self.SIDE, amax=amax_u)
+                set0 = np.zeros(1, dtype=[('off', '<i8'), ('rows', '<i4'), ('o', '<i4'), ('i', '<i4'), ('ld', '<i4')])
+                set0[0] = (d_u[1] // 4, M, 1, 8 * C, 8 * C)
+                self.op(L.OP_ROWSET_COLSUM, refs=(self.gref(b0), (self.xbuf(self.X_WS), 0), self.idx(set0)),
+                        ints=(1, 1, 8 * C), flags=self.SIDE)
                 p0 = self.gemm(self.href(duhT), self.href(thT), self.gref(W0), 8 * C, 4 * C, Mp, Mp, Mp, 4 * C,
                                accum=True, op16=True, alpha_amax=amax_u)
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D2_BWD, side=True, flops=2.0 * 8 * C * 4 * C * M)
@@ -1655,7 +1673,9 @@ class Program:
         dPfw, dPbw = self.wsf('dPfw', V * C), self.wsf('dPbw', V * C)
         hid = self.wref('hid')
         self.op(L.OP_MEMSET0, refs=(dT,), ints=(4 * V * V * ldT,))
-        self.op(L.OP_BIAS_HIST, refs=(dT, dBias, pair), ints=(B, N, H, V))
+        hist = (self.xbuf(self.X_WS), self.ws('dT_fix', 8 * V * V * H + 64))     # 64-bit fixed-point histogram + amax
+        self.op(L.OP_MEMSET0, refs=(hist,), ints=(8 * V * V * H + 16,))
+        self.op(L.OP_BIAS_HIST, refs=(dT, dBias, pair, hist), ints=(B, N, H, V))
         p0 = self.gemm(dT, hid, self.gref(W2e), H, C, V * V, ldT, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
                        accum=True, dbias=self.gref(b2e))
         self.gemm(dT, self.pref(W2e), dhid, V * V, C, H, ldT, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
@@ -1677,4 +1697,4 @@ class Program:
                       self.gref('shape_enc.embed_channel.weight'), self.gref('shape_enc.embed_spatial.weight'),
                       self.gref('gnn.0.centrality_embed_in.weight'), self.gref('gnn.0.centrality_embed_out.weight'),
                       self.gref('gnn.0.input_dist_embed.weight'), deg_in, deg_out, dist0),
-                ints=(B, N, C))
+                ints=(B, N, C, len(bk.PRIMITIVES_DEEPNETS1M), self.vocab.n_ch + 1, self.vocab.n_sp + 1))

@@ -227,7 +227,8 @@ enum ghn3_op_kind {
     /* sum over predicted tensors of ||p||_F (trainer.py:97-98,288-294)
      * r0=loss(1 float, accumulated) r1=flat r2=seg_off(int64 (begin,end) pairs, sorted by begin, disjoint)
      * r3=norms(n floats) r4=optional int32 table: first segment whose end lies beyond float 8192 * b, for every
-     * 8192-float chunk b of the flat buffer (absent: searched on the device)
+     * 8192-float chunk b of the flat buffer (absent: searched on the device) r5=optional partial-sum slots (n_seg +
+     * number of chunks floats; needs r4): per-chunk partial sums added in chunk order instead of with float atomics
      * i: n_seg, extent of the flat buffer in floats (>= the last end; the passes stream it) */
     GHN3_OP_PARAM_NORM_FWD = 9,
     /* r0=dflat r1=flat r2=seg_off r3=norms r4=optional first-segment table ; i: n_seg, flat extent ; f0 = upstream grad */
@@ -250,12 +251,14 @@ enum ghn3_op_kind {
     /* r0=dqkv r1=dO r2=qkv r3=P r4=O (saved attention output) r5=unused r6=dBias (accumulated) r7=n_nodes
      * i: B,N,C,H */
     GHN3_OP_ATTN_BWD = 16,
-    /* dT[p][h] += sum_{pair==p} dBias[b,h,i,j] ; r0=dT r1=dBias r2=pair ; i: B,N,H,V */
+    /* dT[p][h] += sum_{pair==p} dBias[b,h,i,j] ; r0=dT r1=dBias r2=pair r3=scratch: 8 * V * V * H + 16 bytes, ZEROED by
+     * the program (64-bit fixed-point histogram: the order of the atomics does not matter -> deterministic) ; i: B,N,H,V */
     GHN3_OP_BIAS_HIST = 17,
     /* r0=dPfw r1=dPbw r2=dhid(in, masked in place) r3=hid ; i: V,C */
     GHN3_OP_EDGE_HIDDEN_BWD = 18,
     /* scatter-add of dx(B,N,C) into the six embedding tables; refs as EMBED_NODES with r0=dx and
-     * r5..r10 = table gradients */
+     * r5..r10 = table gradients ; i: B,N,C, rows of E_type, E_ch, E_sp (one workgroup per table row gathers its nodes in
+     * node order: deterministic) */
     GHN3_OP_EMBED_BWD = 19,
     /* r0=dst ; i0 = bytes */
     GHN3_OP_MEMSET0 = 20,
@@ -279,7 +282,8 @@ enum ghn3_op_kind {
      * start the gradient all-reduce of the first part's weight gradients while the second part executes. */
     GHN3_OP_DETACH = 25,
     /* trainer step over the flat buffers (trainer.py:356-381)
-     * SUMSQ: r0[0] += sum x^2 (r1 = x, i0 = n floats) -- the squared global gradient norm of clip_grad_norm_
+     * SUMSQ: r0[0] += sum x^2 (r1 = x, i0 = n floats; r2 = optional 4096 floats of scratch: per-workgroup partial sums
+     *        added in a fixed order instead of with float atomics) -- the squared global gradient norm of clip_grad_norm_
      * ADAMW: torch.optim.AdamW on r0 = params, r1 = grads, r2 = exp_avg, r3 = exp_avg_sq (i0 = n floats);
      *        r4 = squared gradient norm or absent, f0 = max_norm (<= 0: no clipping): the gradient is scaled by
      *        min(1, max_norm / (norm + 1e-6)); i1..i7 = IEEE-754 double bit patterns of lr, beta1, beta2, eps,
@@ -294,6 +298,10 @@ enum ghn3_op_kind {
      * O(1) error of a whole dW2 row.  r0=X [rows][ld] r1=U [rows][K] r2=W [.][K] r3=bias or absent
      * i: rows, cols, ld, K, q, s ; f0 = threshold factor (<= 0: plain ReLU) */
     GHN3_OP_RELU_FIX = 28,
+    /* bias gradient of a decoder linear from the stacked row sets of its output gradient (deterministic, one writer
+     * per output): out[o' * I + i'] += sum_{sets: o' < o_s, i' < i_s} sum_{r < rows_s} X[off_s + r * ld_s + o' * i_s + i']
+     * r0=out r1=X (fp32 base) r2=table of {int64 off (floats from r1); int32 rows, o, i, ld} ; i: n_sets, O, I */
+    GHN3_OP_ROWSET_COLSUM = 29,
     GHN3_OP_KIND_COUNT
 };
 

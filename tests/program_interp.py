@@ -57,6 +57,19 @@ class Interp:
     def op_detach(self, o, problems):
         pass
 
+    def op_rowset_colsum(self, o, problems):
+        n_sets, O, I = (int(v) for v in o['i'][:3])
+        out = self.tail(o['r'][0], np.float32)
+        X = self.tail(o['r'][1], np.float32)
+        sets = self.view(o['r'][2], np.dtype([('off', '<i8'), ('rows', '<i4'), ('o', '<i4'), ('i', '<i4'), ('ld', '<i4')]),
+                         n_sets)
+        acc = np.zeros((O, I), np.float64)
+        for S in sets:
+            off, rows, o_, i_, ld = (int(S[k]) for k in ('off', 'rows', 'o', 'i', 'ld'))
+            blk = X[off + np.arange(rows)[:, None] * ld + np.arange(o_ * i_)[None, :]].astype(np.float64).sum(0)
+            acc[:o_, :i_] += blk.reshape(o_, i_)
+        out[:O * I] += acc.reshape(-1).astype(np.float32)
+
     def op_relu_fix(self, o, problems):
         rows, cols, ld, K, q, s_ = (int(v) for v in o['i'][:6])
         X = self.tail(o['r'][0], np.float32)

@@ -48,7 +48,7 @@ def _run_program(hip, nets, gb, training=True, **prog_kw):
     bufs[prog.xbuf(prog.X_DOUT)] = np.zeros(prog.out_numel, dtype=np.float32).view(np.uint8)
     bufs[prog.xbuf(prog.X_TOK)] = (0.02 * np.random.RandomState(0).standard_normal(prog.tok_floats)
                                    ).astype(np.float32).view(np.uint8)
-    bufs[prog.xbuf(prog.X_SCAL)] = np.zeros(256 + 4 * max(prog.n_seg, 1) + 64, dtype=np.uint8)
+    bufs[prog.xbuf(prog.X_SCAL)] = np.zeros(prog.scal_bytes, dtype=np.uint8)
     bufs[prog.xbuf(prog.X_GRADFLAT)] = gflat
     if prog.uses_shadow:
         bufs[prog.xbuf(prog.X_SHADOW)] = np.zeros(prog.shadow_layout(prog.C, prog.max_shape, prog.Lyr)['nbytes'], dtype=np.uint8)

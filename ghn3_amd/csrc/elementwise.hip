@@ -124,38 +124,46 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
     float* __restrict__ dE_ch, float* __restrict__ dE_sp, float* __restrict__ dE_in, float* __restrict__ dE_out,
     float* __restrict__ dE_dist, const int* __restrict__ deg_in, const int* __restrict__ deg_out,
     const int* __restrict__ dist0, int B, int N, int C, int n_type, int n_ch, int n_sp) {
+    extern __shared__ unsigned char emb_flags[];        // per dense row: bit 0 / 1 = first / second column block matches
     int r = blockIdx.x, tab = 0;
     const int sizes[6] = {n_type, n_ch, n_sp, 101, 101, 1001};
     while (tab < 5 && r >= sizes[tab]) { r -= sizes[tab]; ++tab; }
     const int cq = C >> 2;
     const int width = (tab == 1 || tab == 2) ? cq : C;
+    const int base0 = tab == 2 ? 2 * cq : 0, base1 = tab == 1 ? cq : 3 * cq;
+    // pass 1 (parallel): which nodes index this table row -- the index loads of all nodes are in flight together
+    int any = 0;
+    for (int row = threadIdx.x; row < B * N; row += 256) {
+        const int b = row / N, i = row - b * N;
+        int f = 0;
+        if (i < n_nodes[b]) {                          // x * mask: padded rows carry no gradient
+            const int sidx = node_off[b] + i;
+            if (tab == 0) f = node_type[sidx] == r;
+            else if (tab == 1) f = (shape_idx[4 * sidx] == r) | ((shape_idx[4 * sidx + 1] == r) << 1);
+            else if (tab == 2) f = (shape_idx[4 * sidx + 2] == r) | ((shape_idx[4 * sidx + 3] == r) << 1);
+            else if (tab == 3) f = deg_in[row] == r;
+            else if (tab == 4) f = deg_out[row] == r;
+            else f = dist0[row] == r;
+        }
+        emb_flags[row] = (unsigned char)f;
+        any |= f;
+    }
+    if (!__syncthreads_or(any)) return;               // nobody indexes this row: its (zero-initialised) gradient stays
+    // pass 2: the matching gradient rows, summed in node order
     float acc[2] = {0.f, 0.f};                         // columns threadIdx.x and threadIdx.x + 256 (C <= 512)
-    bool hit = false;
-    for (int b = 0; b < B; ++b) {
-        const int nb = n_nodes[b], off = node_off[b];
-        for (int i = 0; i < nb; ++i) {
-            const int row = b * N + i, sidx = off + i;
-            const float* g = dx + (size_t)row * C;
-            int m0 = 0, m1 = 0, base0 = 0, base1 = 0;    // up to two matching column blocks of the gradient row
-            if (tab == 0) m0 = node_type[sidx] == r;
-            else if (tab == 1) { m0 = shape_idx[4 * sidx] == r; m1 = shape_idx[4 * sidx + 1] == r; base1 = cq; }
-            else if (tab == 2) { m0 = shape_idx[4 * sidx + 2] == r; m1 = shape_idx[4 * sidx + 3] == r; base0 = 2 * cq; base1 = 3 * cq; }
-            else if (tab == 3) m0 = deg_in[row] == r;
-            else if (tab == 4) m0 = deg_out[row] == r;
-            else m0 = dist0[row] == r;
-            if (!(m0 | m1)) continue;                  // (uniform over the workgroup)
-            hit = true;
+    for (int row = 0; row < B * N; ++row) {
+        const int f = emb_flags[row];
+        if (!f) continue;                              // (uniform over the workgroup)
+        const float* g = dx + (size_t)row * C;
 #pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int c = threadIdx.x + 256 * k;
-                if (c < width) {
-                    if (m0) acc[k] += g[base0 + c];
-                    if (m1) acc[k] += g[base1 + c];
-                }
+        for (int k = 0; k < 2; ++k) {
+            const int c = threadIdx.x + 256 * k;
+            if (c < width) {
+                if (f & 1) acc[k] += g[base0 + c];
+                if (f & 2) acc[k] += g[base1 + c];
             }
         }
     }
-    if (!hit) return;
     float* dst = tab == 0 ? dE_type : tab == 1 ? dE_ch : tab == 2 ? dE_sp : tab == 3 ? dE_in : tab == 4 ? dE_out : dE_dist;
 #pragma unroll
     for (int k = 0; k < 2; ++k) {
@@ -172,8 +180,9 @@ int ghn3_embed_bwd(const float* dx, const int* node_type, const int* shape_idx, 
         ghn3_set_error("embed_bwd: C <= 512 and the table row counts (i3..i5) are required");
         return GHN3_E_ARG;
     }
+    if (B * N > 64 * 1024) { ghn3_set_error("embed_bwd: more than 65536 dense node rows"); return GHN3_E_LIMIT; }
     const int blocks = n_type + n_ch + n_sp + 101 + 101 + 1001;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), 0, s, dx, node_type, shape_idx, n_nodes,
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), (size_t)((B * N + 15) & ~15), s, dx, node_type, shape_idx, n_nodes,
                        node_off, dE_type, dE_ch, dE_sp, dE_in, dE_out, dE_dist, deg_in, deg_out, dist0, B, N, C, n_type,
                        n_ch, n_sp);
     return launch_ok("embed_bwd");

@@ -28,10 +28,12 @@ TILE_DT = np.dtype([('dst_off', '<i8'), ('src_off', '<i8'), ('S', '<i8', 4), ('T
 CAST_DT = np.dtype([('src_off', '<i8'), ('dst_off', '<i8'), ('dstT_off', '<i8'), ('rows', '<i4'), ('cols', '<i4'),
                     ('ld_src', '<i4'), ('ld_dst', '<i4'), ('ld_dstT', '<i4'), ('flags', '<u4'), ('bias_q', '<i4'),
                     ('bias_s', '<i4'), ('block_start', '<i4'), ('bias_off', '<i4'), ('src_q', '<i4'), ('src_s', '<i4'),
-                    ('lo_off', '<i8')])
+                    ('lo_off', '<i8'), ('part_off', '<i8')])
+ROWSET_DT = np.dtype([('off', '<i8'), ('rows', '<i4'), ('o', '<i4'), ('i', '<i4'), ('ld', '<i4'), ('i0', '<i4'),
+                      ('_pad', '<i4')])
 OP_DT = np.dtype([('kind', '<i4'), ('flags', '<i4'), ('i', '<i8', 8), ('f', '<f4', 4), ('r', REF_DT, 14)])
 assert REF_DT.itemsize == 16 and PROBLEM_DT.itemsize == 424 and TILE_DT.itemsize == 112 and OP_DT.itemsize == 312
-assert CAST_DT.itemsize == 80
+assert CAST_DT.itemsize == 88 and ROWSET_DT.itemsize == 32
 
 MODE_ROW, MODE_COL = 0, 1
 ACT_NONE, ACT_RELU, ACT_GELU = 0, 1, 2
@@ -43,6 +45,7 @@ GEMM_X3 = 8
 CAST_STRAIGHT, CAST_TRANSPOSED, CAST_STRAIGHT_BF16, CAST_TRANSPOSED_BF16, CAST_COLSUM, CAST_SCALED = 1, 2, 4, 8, 16, 32
 CAST_TIGHT = 64
 CAST_SPLIT = 128
+CAST_COLSUM_PARTS = 256
 CT_F32, CT_F16, CT_BF16 = 0, 1, 2
 COMPUTE_TYPES = {'f32': CT_F32, 'f16': CT_F16, 'bf16': CT_BF16}
 

@@ -124,43 +124,52 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
     float* __restrict__ dE_ch, float* __restrict__ dE_sp, float* __restrict__ dE_in, float* __restrict__ dE_out,
     float* __restrict__ dE_dist, const int* __restrict__ deg_in, const int* __restrict__ deg_out,
     const int* __restrict__ dist0, int B, int N, int C, int n_type, int n_ch, int n_sp) {
-    extern __shared__ unsigned char emb_flags[];        // per dense row: bit 0 / 1 = first / second column block matches
+    extern __shared__ unsigned long long emb_mask[];     // [2][ceil(B * N / 64)]: nodes matching column block 0 / 1
     int r = blockIdx.x, tab = 0;
     const int sizes[6] = {n_type, n_ch, n_sp, 101, 101, 1001};
     while (tab < 5 && r >= sizes[tab]) { r -= sizes[tab]; ++tab; }
     const int cq = C >> 2;
     const int width = (tab == 1 || tab == 2) ? cq : C;
     const int base0 = tab == 2 ? 2 * cq : 0, base1 = tab == 1 ? cq : 3 * cq;
-    // pass 1 (parallel): which nodes index this table row -- the index loads of all nodes are in flight together
+    const int rows = B * N, words = (rows + 63) >> 6;
+    // pass 1 (parallel): which nodes index this table row -- one ballot word per 64 dense rows
     int any = 0;
-    for (int row = threadIdx.x; row < B * N; row += 256) {
-        const int b = row / N, i = row - b * N;
+    for (int row0 = (threadIdx.x >> 6) * 64; row0 < rows; row0 += 256) {
+        const int row = row0 + (threadIdx.x & 63);
         int f = 0;
-        if (i < n_nodes[b]) {                          // x * mask: padded rows carry no gradient
-            const int sidx = node_off[b] + i;
-            if (tab == 0) f = node_type[sidx] == r;
-            else if (tab == 1) f = (shape_idx[4 * sidx] == r) | ((shape_idx[4 * sidx + 1] == r) << 1);
-            else if (tab == 2) f = (shape_idx[4 * sidx + 2] == r) | ((shape_idx[4 * sidx + 3] == r) << 1);
-            else if (tab == 3) f = deg_in[row] == r;
-            else if (tab == 4) f = deg_out[row] == r;
-            else f = dist0[row] == r;
+        if (row < rows) {
+            const int b = row / N, i = row - b * N;
+            if (i < n_nodes[b]) {                      // x * mask: padded rows carry no gradient
+                const int sidx = node_off[b] + i;
+                if (tab == 0) f = node_type[sidx] == r;
+                else if (tab == 1) f = (shape_idx[4 * sidx] == r) | ((shape_idx[4 * sidx + 1] == r) << 1);
+                else if (tab == 2) f = (shape_idx[4 * sidx + 2] == r) | ((shape_idx[4 * sidx + 3] == r) << 1);
+                else if (tab == 3) f = deg_in[row] == r;
+                else if (tab == 4) f = deg_out[row] == r;
+                else f = dist0[row] == r;
+            }
         }
-        emb_flags[row] = (unsigned char)f;
+        const unsigned long long m0 = __ballot(f & 1), m1 = __ballot(f & 2);
+        if ((threadIdx.x & 63) == 0) { emb_mask[row0 >> 6] = m0; emb_mask[words + (row0 >> 6)] = m1; }
         any |= f;
     }
     if (!__syncthreads_or(any)) return;               // nobody indexes this row: its (zero-initialised) gradient stays
-    // pass 2: the matching gradient rows, summed in node order
+    // pass 2: the matching gradient rows, summed in node order (only the set bits are visited)
     float acc[2] = {0.f, 0.f};                         // columns threadIdx.x and threadIdx.x + 256 (C <= 512)
-    for (int row = 0; row < B * N; ++row) {
-        const int f = emb_flags[row];
-        if (!f) continue;                              // (uniform over the workgroup)
-        const float* g = dx + (size_t)row * C;
+    for (int w = 0; w < words; ++w) {
+        unsigned long long m0 = emb_mask[w], m1 = emb_mask[words + w];
+        unsigned long long m = m0 | m1;
+        while (m) {                                    // (uniform over the workgroup)
+            const int bit = __ffsll((long long)m) - 1;
+            m &= m - 1;
+            const float* g = dx + (size_t)(w * 64 + bit) * C;
 #pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int c = threadIdx.x + 256 * k;
-            if (c < width) {
-                if (f & 1) acc[k] += g[base0 + c];
-                if (f & 2) acc[k] += g[base1 + c];
+            for (int k = 0; k < 2; ++k) {
+                const int c = threadIdx.x + 256 * k;
+                if (c < width) {
+                    if ((m0 >> bit) & 1) acc[k] += g[base0 + c];
+                    if ((m1 >> bit) & 1) acc[k] += g[base1 + c];
+                }
             }
         }
     }
@@ -182,7 +191,7 @@ int ghn3_embed_bwd(const float* dx, const int* node_type, const int* shape_idx, 
     }
     if (B * N > 64 * 1024) { ghn3_set_error("embed_bwd: more than 65536 dense node rows"); return GHN3_E_LIMIT; }
     const int blocks = n_type + n_ch + n_sp + 101 + 101 + 1001;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), (size_t)((B * N + 15) & ~15), s, dx, node_type, shape_idx, n_nodes,
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), (size_t)(16 * ((B * N + 63) / 64)), s, dx, node_type, shape_idx, n_nodes,
                        node_off, dE_type, dE_ch, dE_sp, dE_in, dE_out, dE_dist, deg_in, deg_out, dist0, B, N, C, n_type,
                        n_ch, n_sp);
     return launch_ok("embed_bwd");
@@ -522,51 +531,70 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(float* __restrict__ 
                                                             const float* __restrict__ dy, const float* __restrict__ x,
                                                             const float* __restrict__ mean,
                                                             const float* __restrict__ rstd, int rows, int C, int accum) {
-    __shared__ float sg[4][64], sb[4][64];
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
+    // 16 columns x 16 row lanes per workgroup: row r goes to lane r % 16 (8 rows of a lane in flight at a time), the 16
+    // lane sums are added in a fixed order
+    __shared__ float sg[16][16], sb[16][16];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float ag = 0.f, ab = 0.f;
     if (c < C) {
-        for (int r = rl; r < rows; r += 4) {
-            const float d = dy[(size_t)r * C + c];
-            ag += d * (x[(size_t)r * C + c] - mean[r]) * rstd[r];
-            ab += d;
+        for (int r0 = rl; r0 < rows; r0 += 16 * 8) {
+            float d[8], xv[8], mu[8], rs[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = r0 + 16 * k;
+                const bool in = r < rows;
+                d[k] = in ? dy[(size_t)r * C + c] : 0.f;
+                xv[k] = in ? x[(size_t)r * C + c] : 0.f;
+                mu[k] = in ? mean[r] : 0.f;
+                rs[k] = in ? rstd[r] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { ag += d[k] * (xv[k] - mu[k]) * rs[k]; ab += d[k]; }
         }
     }
-    sg[rl][threadIdx.x & 63] = ag; sb[rl][threadIdx.x & 63] = ab;
+    sg[rl][cl] = ag; sb[rl][cl] = ab;
     __syncthreads();
     if (rl == 0 && c < C) {
-        const int l = threadIdx.x & 63;
-        const float g = (sg[0][l] + sg[1][l]) + (sg[2][l] + sg[3][l]), b = (sb[0][l] + sb[1][l]) + (sb[2][l] + sb[3][l]);
+        float g = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { g += sg[k][cl]; b += sb[k][cl]; }
         dg[c] = accum ? dg[c] + g : g;
         db[c] = accum ? db[c] + b : b;
     }
 }
 int ghn3_ln_param_grad(float* dg, float* db, const float* dy, const float* x, const float* mean, const float* rstd,
                        int rows, int C, int accum, hipStream_t s) {
-    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((C + 63) / 64), dim3(256), 0, s, dg, db, dy, x, mean, rstd, rows, C,
+    hipLaunchKernelGGL(ln_param_grad_kernel, dim3((C + 15) / 16), dim3(256), 0, s, dg, db, dy, x, mean, rstd, rows, C,
                        accum);
     return launch_ok("ln_param_grad");
 }
 
 // GHN3_OP_ROWSET_COLSUM: bias gradient of a decoder linear from the stacked row sets of its output gradient,
-//   out[o' * I + i'] += sum_{sets with o' < o_s, i' < i_s} sum_{r < rows_s} X[off_s + r * ld_s + o' * i_s + i']
+//   out[o' * I + i0_s + i'] += sum_{sets with o' < o_s, i' < i_s} sum_{r < rows_s} X[off_s + r * ld_s + o' * i_s + i']
 // (decoder.conv.2.bias: every decoder row contributes to the W2 rows o' < o_r, i' < i_r it consumed, nn.py:749-750;
 // decoder.conv.0.bias: one set with o = 1).  Block = 64 columns i' of one o' x 4 row lanes, sets and rows in a fixed
 // order, one writer per output: deterministic (the column sums fused into GHN3_OP_CAST16 used float atomics).
-struct RowSet { int64_t off; int32_t rows, o, i, ld; };
+struct RowSet { int64_t off; int32_t rows, o, i, ld, i0, _pad; };
 __global__ __launch_bounds__(256) void rowset_colsum_kernel(float* __restrict__ out, const float* __restrict__ X,
                                                             const RowSet* __restrict__ sets, int n_sets, int I) {
     __shared__ float red[4][64];
     const int l = threadIdx.x & 63, rl = threadIdx.x >> 6;
-    const int ip = blockIdx.x * 64 + l, op = blockIdx.y;
+    const int ip = blockIdx.x * 64 + l, op = blockIdx.y;               // output column / row
     float acc = 0.f;
     for (int k = 0; k < n_sets; ++k) {
         const RowSet S = sets[k];
-        if (op >= S.o || blockIdx.x * 64 >= S.i) continue;             // (uniform)
-        if (ip < S.i) {
-            const float* p = X + S.off + (size_t)op * S.i + ip;
-            for (int r = rl; r < S.rows; r += 4) acc += p[(size_t)r * S.ld];
+        const int il = ip - S.i0;                                      // column inside the set
+        if (op >= S.o || (int)(blockIdx.x * 64 + 63) < S.i0 || (int)(blockIdx.x * 64) >= S.i0 + S.i) continue;   // (uniform)
+        if (il >= 0 && il < S.i) {
+            const float* p = X + S.off + (size_t)op * S.i + il;
+            for (int r0 = rl; r0 < S.rows; r0 += 4 * 8) {
+                float v[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const int r = r0 + 4 * e; v[e] = r < S.rows ? p[(size_t)r * S.ld] : 0.f; }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc += v[e];
+            }
         }
     }
     red[rl][l] = acc;
@@ -886,25 +914,31 @@ __global__ __launch_bounds__(256) void param_sq_kernel(const float* __restrict__
         }
     }
 }
-__global__ void param_sqrt_kernel(float* __restrict__ loss, float* __restrict__ norms, int n_seg,
-                                  const int64_t* __restrict__ seg_off, const int* __restrict__ first_seg,
-                                  const float* __restrict__ parts) {
-    __shared__ float red[4];
+// one wave per tensor: its slots (chunk order) are summed by the 64 lanes (lane l takes chunks l, l + 64, ...) and a fixed
+// shuffle tree; a second single-workgroup pass adds the norms in a fixed order
+__global__ __launch_bounds__(256) void param_sqrt_kernel(float* __restrict__ norms, int n_seg,
+                                                         const int64_t* __restrict__ seg_off,
+                                                         const int* __restrict__ first_seg,
+                                                         const float* __restrict__ parts) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n_seg) return;
+    float sq = 0.f;
+    if (parts && first_seg) {
+        if (seg_off[2 * i + 1] > seg_off[2 * i]) {
+            const int64_t b0 = seg_off[2 * i] / NORM_CHUNK, b1 = (seg_off[2 * i + 1] - 1) / NORM_CHUNK;
+            for (int64_t b = b0 + lane; b <= b1; b += 64) sq += parts[b + i];
+        }
+        sq = wsum(sq);
+    } else {
+        sq = norms[i];
+    }
+    if (lane == 0) norms[i] = sqrtf(sq);
+}
+__global__ void param_loss_kernel(float* __restrict__ loss, const float* __restrict__ norms, int n_seg) {
     __shared__ float tot[256];
     float acc = 0.f;
-    for (int i = threadIdx.x; i < n_seg; i += 256) {
-        float sq = norms[i];
-        if (parts && first_seg) {                                    // this segment's slots, in chunk order
-            sq = 0.f;
-            const int64_t b0 = seg_off[2 * i] / NORM_CHUNK, b1 = (seg_off[2 * i + 1] - 1) / NORM_CHUNK;
-            if (seg_off[2 * i + 1] > seg_off[2 * i])
-                for (int64_t b = b0; b <= b1; ++b) sq += parts[first_seg[b] + b + (i - first_seg[b])];
-        }
-        const float v = sqrtf(sq);
-        norms[i] = v;
-        acc += v;
-    }
-    tot[threadIdx.x] = acc;                                           // (fixed-order sum over the 256 threads)
+    for (int i = threadIdx.x; i < n_seg; i += 256) acc += norms[i];
+    tot[threadIdx.x] = acc;
     __syncthreads();
     if (threadIdx.x == 0) {
         float t = 0.f;
@@ -919,7 +953,8 @@ int ghn3_param_norm_fwd(float* loss, const float* flat, const int64_t* seg_off, 
     const int64_t blocks = (flat_numel + NORM_CHUNK - 1) / NORM_CHUNK;
     hipLaunchKernelGGL(param_sq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, flat, seg_off, norms, n_seg,
                        first_seg, parts);
-    hipLaunchKernelGGL(param_sqrt_kernel, dim3(1), dim3(256), 0, s, loss, norms, n_seg, seg_off, first_seg, parts);
+    hipLaunchKernelGGL(param_sqrt_kernel, dim3((n_seg + 3) / 4), dim3(256), 0, s, norms, n_seg, seg_off, first_seg, parts);
+    hipLaunchKernelGGL(param_loss_kernel, dim3(1), dim3(256), 0, s, loss, norms, n_seg);
     return launch_ok("param_norm_fwd");
 }
 __global__ __launch_bounds__(256) void param_norm_bwd_kernel(float* __restrict__ dflat, const float* __restrict__ flat,
@@ -1332,9 +1367,15 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
         float s = 0.f;
 #pragma unroll
         for (int w = 0; w < 16; ++w) s += csum[w][tid];
-        int c = c0 + tid;
-        if (D.bias_q > 0) c = (c / D.bias_q) * D.bias_s + c % D.bias_q;
-        atomicAdd(dbias + c + D.bias_off, s);
+        if (D.flags & GHN3_CAST_COLSUM_PARTS) {
+            // deterministic: this row tile's partial sums go to their own slot; GHN3_OP_ROWSET_COLSUM adds the slots of
+            // all row tiles (and row sets) of a bias entry in a fixed order
+            dbias[D.part_off + (int64_t)(r0 >> 6) * D.cols + c0 + tid] = s;
+        } else {
+            int c = c0 + tid;
+            if (D.bias_q > 0) c = (c / D.bias_q) * D.bias_s + c % D.bias_q;
+            atomicAdd(dbias + c + D.bias_off, s);
+        }
     }
     __syncthreads();                               // LDS staging is reused by the next work tile
     }

@@ -244,6 +244,11 @@ class Program:
                 D['bias_q'], D['bias_s'] = it['colsum'][:2]
                 D['bias_off'] = it['colsum'][2] if len(it['colsum']) > 2 else 0
                 dflags |= L.CAST_COLSUM
+            if it.get('colsum_parts') is not None:
+                # deterministic column sums: one slot row per 64-row tile of the descriptor (dbias = the slot buffer)
+                assert dbias is not None
+                D['part_off'] = it['colsum_parts']
+                dflags |= L.CAST_COLSUM | L.CAST_COLSUM_PARTS
             if it.get('src_map'):
                 D['src_q'], D['src_s'] = it['src_map']
                 assert D['src_q'] % 4 == 0 and D['src_s'] % 4 == 0 and it['cols'] % D['src_q'] == 0
@@ -1305,7 +1310,7 @@ class Program:
                 # launch, and every dW2 row is written exactly once -- no accumulation into dW2 between families (was
                 # 2 GB read + 2 GB written per step at ghn3xlm16) and no memset of it when the bands cover it.
                 items, side_items = [], []
-                rowsets = []
+                rowsets, bias_sets, n_parts = [], [], 0
                 for g in g16:
                     g['dth_ld'] = round_up(g['cols'], 64) + 64        # (+64: rows never a power of two apart)
                     g['dth'] = self.ws16('dth%d' % g['row0'], g['rows'] * g['dth_ld'])
@@ -1335,23 +1340,24 @@ class Program:
                                                (m_['row0'] - g['row0']) * g['ld'] + i_lo, rows=m_['rows'],
                                                cols=m_['o'] * bw, ld_src=g['ld'], src_map=(bw, m_['i']),
                                                transposed=(band['dthT'] + m_['k_off'], ktot, bct),
-                                               scaled=scaled, tight=True))
+                                               scaled=scaled, tight=True, colsum_parts=n_parts))
+                        bias_sets.append((n_parts, (m_['rows'] + 63) // 64, m_['o'], bw, m_['o'] * bw, i_lo))
+                        n_parts += ((m_['rows'] + 63) // 64) * m_['o'] * bw
                         side_items.append(dict(src_off=u[1] // 4 + m_['row0'] * 8 * C, rows=m_['rows'], cols=8 * C,
                                                ld_src=8 * C, transposed=(band['uhT'] + m_['k_off'], ktot, bct),
                                                tight=True))
                     i_lo = i_hi
                 # the dgrad operand on the critical path; the wgrad operands (and the bias gradient) beside it
                 self.cast16((self.xbuf(self.X_WS), 0), items, amax=amax_t)
-                self.cast16((self.xbuf(self.X_WS), 0), side_items, flags=self.SIDE, amax=amax_t)
-                # decoder.conv.2.bias gradient: every decoder row adds its d_tiles row to the bias entries (o', i') it
-                # consumed -- one deterministic pass over d_tiles (fixed set / row order, one writer per entry)
-                sets = np.zeros(len(rowsets), dtype=[('off', '<i8'), ('rows', '<i4'), ('o', '<i4'), ('i', '<i4'),
-                                                     ('ld', '<i4')])
-                for k_, rs in enumerate(rowsets):
-                    g = rs['g']
-                    sets[k_] = (self._ws_names['d_tiles'] // 4 + g['tile_off'] + (rs['row0'] - g['row0']) * g['ld'],
-                                rs['rows'], rs['o'], rs['i'], g['ld'])
-                self.op(L.OP_ROWSET_COLSUM, refs=(self.gref(b2), (self.xbuf(self.X_WS), 0), self.idx(sets)),
+                # decoder.conv.2.bias gradient = column sums of d_tiles: every 64-row tile of the transposed band copies
+                # leaves its partial sums in a slot (no atomics), GHN3_OP_ROWSET_COLSUM adds the slots of a bias entry
+                # (all row tiles of all row sets with o_r > o', i_r > i') in a fixed order: deterministic
+                parts = self.wsf('b2_parts', n_parts)
+                self.cast16((self.xbuf(self.X_WS), 0), side_items, dbias=parts, flags=self.SIDE, amax=amax_t)
+                sets = np.zeros(len(bias_sets), dtype=L.ROWSET_DT)
+                for k_, (off, n_rt, o_, bw_, ld_, i0_) in enumerate(bias_sets):
+                    sets[k_] = (off, n_rt, o_, bw_, ld_, i0_, 0)
+                self.op(L.OP_ROWSET_COLSUM, refs=(self.gref(b2), parts, self.idx(sets)),
                         ints=(len(sets), ms[0], ms[1]), flags=self.SIDE)
             p0 = len(self._probs)
             fl = 0.0
@@ -1480,12 +1486,12 @@ class Program:
                                   scaled=scaled)], amax=amax_u)
                 self.cast16((self.xbuf(self.X_WS), 0),
                             [dict(src_off=d_u[1] // 4, rows=M, cols=8 * C, ld_src=8 * C, transposed=(duhT, Mp, bct),
-                                  scaled=scaled),
+                                  scaled=scaled, colsum_parts=0),
                              dict(src_off=t[1] // 4, rows=M, cols=4 * C, ld_src=4 * C, transposed=(thT, Mp, bct))],
-                            flags=self.SIDE, amax=amax_u)
-                set0 = np.zeros(1, dtype=[('off', '<i8'), ('rows', '<i4'), ('o', '<i4'), ('i', '<i4'), ('ld', '<i4')])
-                set0[0] = (d_u[1] // 4, M, 1, 8 * C, 8 * C)
-                self.op(L.OP_ROWSET_COLSUM, refs=(self.gref(b0), (self.xbuf(self.X_WS), 0), self.idx(set0)),
+                            dbias=self.wsf('b0_parts', ((M + 63) // 64) * 8 * C), flags=self.SIDE, amax=amax_u)
+                set0 = np.zeros(1, dtype=L.ROWSET_DT)
+                set0[0] = (0, (M + 63) // 64, 1, 8 * C, 8 * C, 0, 0)
+                self.op(L.OP_ROWSET_COLSUM, refs=(self.gref(b0), self.wref('b0_parts'), self.idx(set0)),
                         ints=(1, 1, 8 * C), flags=self.SIDE)
                 p0 = self.gemm(self.href(duhT), self.href(thT), self.gref(W0), 8 * C, 4 * C, Mp, Mp, Mp, 4 * C,
                                accum=True, op16=True, alpha_amax=amax_u)

@@ -160,6 +160,9 @@ typedef struct ghn3_gemm_problem {
 /* bf16 split copies for GHN3_GEMM_X3: the straight and / or transposed copy is written twice, hi = bf16(x) at
  * dst_off / dstT_off and lo = bf16(x - hi) `lo_off` 16-bit elements behind it (both bf16 whatever the *_BF16 flags) */
 #define GHN3_CAST_SPLIT 128u
+/* with GHN3_CAST_COLSUM: deterministic column sums -- every 64-row tile of the descriptor writes its partial sums to
+ * dbias[part_off + tile_row * cols + c] (plain stores, no atomics); GHN3_OP_ROWSET_COLSUM adds them in a fixed order */
+#define GHN3_CAST_COLSUM_PARTS 256u
 typedef struct ghn3_cast_desc {
     int64_t src_off, dst_off, dstT_off;
     int32_t rows, cols;
@@ -170,6 +173,7 @@ typedef struct ghn3_cast_desc {
     int32_t bias_off;
     int32_t src_q, src_s;    /* source column map (0: identity) */
     int64_t lo_off;          /* GHN3_CAST_SPLIT: distance (16-bit elements) from a hi copy to its lo copy */
+    int64_t part_off;        /* GHN3_CAST_COLSUM_PARTS: float offset (from r3) of this descriptor's [row tiles][cols] slots */
 } ghn3_cast_desc;
 
 /* ---- tile / normalise descriptors  (nn.py:422-506 _tile_params, 554-592 _normalize, 508-552 _set_params)
@@ -300,7 +304,8 @@ enum ghn3_op_kind {
     GHN3_OP_RELU_FIX = 28,
     /* bias gradient of a decoder linear from the stacked row sets of its output gradient (deterministic, one writer
      * per output): out[o' * I + i'] += sum_{sets: o' < o_s, i' < i_s} sum_{r < rows_s} X[off_s + r * ld_s + o' * i_s + i']
-     * r0=out r1=X (fp32 base) r2=table of {int64 off (floats from r1); int32 rows, o, i, ld} ; i: n_sets, O, I */
+     * (+ i0_s on the output column); r0=out r1=X (fp32 base) r2=table of {int64 off (floats from r1); int32 rows, o, i,
+     * ld, i0, pad} ; i: n_sets, O, I */
     GHN3_OP_ROWSET_COLSUM = 29,
     GHN3_OP_KIND_COUNT
 };

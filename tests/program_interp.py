@@ -61,13 +61,12 @@ class Interp:
         n_sets, O, I = (int(v) for v in o['i'][:3])
         out = self.tail(o['r'][0], np.float32)
         X = self.tail(o['r'][1], np.float32)
-        sets = self.view(o['r'][2], np.dtype([('off', '<i8'), ('rows', '<i4'), ('o', '<i4'), ('i', '<i4'), ('ld', '<i4')]),
-                         n_sets)
+        sets = self.view(o['r'][2], L.ROWSET_DT, n_sets)
         acc = np.zeros((O, I), np.float64)
         for S in sets:
-            off, rows, o_, i_, ld = (int(S[k]) for k in ('off', 'rows', 'o', 'i', 'ld'))
+            off, rows, o_, i_, ld, i0 = (int(S[k]) for k in ('off', 'rows', 'o', 'i', 'ld', 'i0'))
             blk = X[off + np.arange(rows)[:, None] * ld + np.arange(o_ * i_)[None, :]].astype(np.float64).sum(0)
-            acc[:o_, :i_] += blk.reshape(o_, i_)
+            acc[:o_, i0:i0 + i_] += blk.reshape(o_, i_)
         out[:O * I] += acc.reshape(-1).astype(np.float32)
 
     def op_relu_fix(self, o, problems):
@@ -187,7 +186,11 @@ class Interp:
                 if split:
                     Z[:, :rows] = Xlo.T
                     dst[ii + int(D['lo_off'])] = self.to16(Z, True)
-            if fl & L.CAST_COLSUM:
+            if fl & L.CAST_COLSUM_PARTS:
+                for rt in range((rows + 63) // 64):
+                    dbias[int(D['part_off']) + rt * cols + np.arange(cols)] = \
+                        Xsum[rt * 64:(rt + 1) * 64].astype(np.float64).sum(0).astype(np.float32)
+            elif fl & L.CAST_COLSUM:
                 c = np.arange(cols)
                 q, s_ = int(D['bias_q']), int(D['bias_s'])
                 if q > 0:

@@ -12,6 +12,7 @@ from .utils import log, Logger, print_grads
 from .ddp_utils import (setup_ddp, is_ddp, get_ddp_rank, clean_ddp, avg_ddp_metric, all_reduce_flat_grads,
                         sync_parameters)
 from .optim import FusedAdamW, save_checkpoint
+from .trainer import Trainer
 
 __all__ = ['Graph', 'GraphBatch', 'from_pretrained', 'GHN3', 'ConvDecoder3', 'SequentialMultipleInOut', 'log', 'Logger', 'print_grads', 'norm_check', 'get_metadata',
-           'setup_ddp', 'is_ddp', 'get_ddp_rank', 'clean_ddp', 'avg_ddp_metric', 'all_reduce_flat_grads', 'sync_parameters', 'FusedAdamW', 'save_checkpoint']
+           'setup_ddp', 'is_ddp', 'get_ddp_rank', 'clean_ddp', 'avg_ddp_metric', 'all_reduce_flat_grads', 'sync_parameters', 'FusedAdamW', 'save_checkpoint', 'Trainer']

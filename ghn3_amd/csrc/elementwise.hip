@@ -125,9 +125,12 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
     float* __restrict__ dE_dist, const int* __restrict__ deg_in, const int* __restrict__ deg_out,
     const int* __restrict__ dist0, int B, int N, int C, int n_type, int n_ch, int n_sp) {
     extern __shared__ unsigned long long emb_mask[];     // [2][ceil(B * N / 64)]: nodes matching column block 0 / 1
-    int r = blockIdx.x, tab = 0;
-    const int sizes[6] = {n_type, n_ch, n_sp, 101, 101, 1001};
-    while (tab < 5 && r >= sizes[tab]) { r -= sizes[tab]; ++tab; }
+    int r = blockIdx.x, tab = 0;                         // (no local array: a dynamically indexed one lives in scratch)
+    if (r >= n_type) { r -= n_type; tab = 1;
+        if (r >= n_ch) { r -= n_ch; tab = 2;
+            if (r >= n_sp) { r -= n_sp; tab = 3;
+                if (r >= 101) { r -= 101; tab = 4;
+                    if (r >= 101) { r -= 101; tab = 5; } } } } }
     const int cq = C >> 2;
     const int width = (tab == 1 || tab == 2) ? cq : C;
     const int base0 = tab == 2 ? 2 * cq : 0, base1 = tab == 1 ? cq : 3 * cq;
@@ -1433,15 +1436,19 @@ int ghn3_sumsq(float* out, const float* x, int64_t n, float* parts, hipStream_t 
     return launch_ok("sumsq");
 }
 
-struct AdamWArgs { float lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2_sqrt, max_norm; };
+struct AdamWArgs { float lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2_sqrt, max_norm, inv_scale; };
 
 // torch.optim.AdamW (decoupled weight decay) with the gradient scaled by clip_grad_norm_'s coefficient
 // min(1, max_norm / (||g|| + 1e-6)); `sumsq` holds ||g||^2 (absent: no clipping)
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                     float* __restrict__ m, float* __restrict__ v, int64_t n,
                                                     const float* __restrict__ sumsq, AdamWArgs a) {
-    float clip = 1.f;
-    if (sumsq && a.max_norm > 0.f) clip = fminf(1.f, a.max_norm / (sqrtf(*sumsq) + 1e-6f));
+    // Non-finite gradient norm (a NaN / inf anywhere in the -- already rank-averaged -- flat gradient): the update is
+    // skipped on every rank alike, like GradScaler's found_inf and the reference trainer's NaN-loss skip
+    // (trainer.py:240-257), without a host round trip.
+    if (sumsq && !isfinite(*sumsq)) return;
+    float clip = a.inv_scale;                          // (1 / loss scale: the gradients arrive multiplied by it)
+    if (sumsq && a.max_norm > 0.f) clip *= fminf(1.f, a.max_norm / (sqrtf(*sumsq) * a.inv_scale + 1e-6f));
     const float step = a.lr / a.bias_corr1, decay = 1.f - a.lr * a.weight_decay;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const float gi = g[i] * clip;
@@ -1453,9 +1460,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
 }
 int ghn3_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float lr, float beta1,
                float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float max_norm,
-               hipStream_t s) {
+               float inv_scale, hipStream_t s) {
     if (n <= 0) return GHN3_OK;
-    AdamWArgs a{lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrtf(bias_corr2), max_norm};
+    AdamWArgs a{lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrtf(bias_corr2), max_norm,
+                inv_scale > 0.f ? inv_scale : 1.f};
     int64_t blocks = (n + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, sumsq, a);

@@ -553,7 +553,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             memcpy(h, &o.i[1], sizeof(h));            // i[1..7] carry IEEE-754 double bit patterns
             rc = ghn3_adamw(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<float>(o.r[2]), R.get<float>(o.r[3]),
                             o.i[0], R.get<const float>(o.r[4]), (float)h[0], (float)h[1], (float)h[2], (float)h[3],
-                            (float)h[4], (float)h[5], (float)h[6], o.f[0], stream);
+                            (float)h[4], (float)h[5], (float)h[6], o.f[0], o.f[1], stream);
             break;
         }
         case GHN3_OP_RELU_FIX:

@@ -10,6 +10,7 @@ path: calling ``forward`` without a HIP device raises.
 
 import os
 import math
+import copy
 import numpy as np
 import torch
 import torch.nn as nn
@@ -27,32 +28,51 @@ def log(*args, **kwargs):
 
 
 # ---------------------------------------------------------------------------------------------------
-# parameter containers with the reference's module tree (names only; never called)
+# the reference's module tree: parameter containers (state-dict names) whose forward() runs on the HIP kernels
 # ---------------------------------------------------------------------------------------------------
 class _Holder(nn.Module):
     pass
 
 
-def _graphormer_layer(dim, heads, layer0, mlp_ratio=4):
-    m = _Holder()
-    m.ln1 = nn.LayerNorm(dim)
-    m.attn = _Holder()
-    m.attn.to_qkv = nn.Linear(dim, 3 * dim, bias=False)
-    m.attn.to_out = nn.Sequential(nn.Linear(dim, dim), nn.Identity())
-    if layer0:
-        m.attn.edge_embed = _Holder()
-        m.attn.edge_embed.embed = nn.Embedding(257, dim)             # graphormer.py:95-96
-        m.attn.proj_e = nn.Sequential(nn.Linear(2 * dim, dim), nn.ReLU(), nn.Linear(dim, heads))
-    m.ln2 = nn.LayerNorm(dim)
-    m.ff = _Holder()
-    m.ff.net = nn.Sequential(nn.Linear(dim, mlp_ratio * dim), nn.GELU(), nn.Identity(),
-                             nn.Linear(mlp_ratio * dim, dim), nn.Identity())
-    m.max_degree, m.max_input_dist = 100, 1000                           # graphormer.py:196-197
-    return m
+class TransformerLayer(nn.Module):
+    """Graphormer layer (graphormer.py:144-248): ``forward(x, edges, mask) -> (x, edges, mask)`` if return_edges else x.
+    GHN3.forward never calls it (the whole model is one compiled op program); the call compiles and runs the ops of
+    this layer alone through the same C ABI (ghn3_amd/operators.py), forward only."""
+
+    def __init__(self, dim, heads, layer0, mlp_ratio=4, return_edges=True):
+        super().__init__()
+        self.dim, self.num_heads, self.edge_dim, self.return_edges = dim, heads, (2 if layer0 else 0), return_edges
+        self.ln1 = nn.LayerNorm(dim)
+        self.attn = _Holder()
+        self.attn.to_qkv = nn.Linear(dim, 3 * dim, bias=False)
+        self.attn.to_out = nn.Sequential(nn.Linear(dim, dim), nn.Identity())
+        if layer0:
+            self.attn.edge_embed = _Holder()
+            self.attn.edge_embed.embed = nn.Embedding(257, dim)             # graphormer.py:95-96
+            self.attn.proj_e = nn.Sequential(nn.Linear(2 * dim, dim), nn.ReLU(), nn.Linear(dim, heads))
+        self.ln2 = nn.LayerNorm(dim)
+        self.ff = _Holder()
+        self.ff.net = nn.Sequential(nn.Linear(dim, mlp_ratio * dim), nn.GELU(), nn.Identity(),
+                                    nn.Linear(mlp_ratio * dim, dim), nn.Identity())
+        self.max_degree, self.max_input_dist = 100, 1000                      # graphormer.py:196-197
+        self._index = 0
+
+    def forward(self, x, edges=None, mask=None):
+        from .operators import transformer_layer_forward
+        ghn = self.__dict__.get('_owner')                # (set by GHN3 past nn.Module.__setattr__: not a sub-module)
+        if ghn is None:
+            raise L.Ghn3Error('TransformerLayer.forward needs the GHN3 that owns the layer (flat parameter buffer)')
+        return transformer_layer_forward(ghn, self._index, x, edges, mask, return_edges=self.return_edges)
+
+
+def _graphormer_layer(dim, heads, layer0, mlp_ratio=4, return_edges=True):
+    return TransformerLayer(dim, heads, layer0, mlp_ratio, return_edges)
 
 
 class ConvDecoder3(nn.Module):
-    """Parameter layout of nn.py:716-733 (fc -> conv.0 -> conv.2, class_layer_predictor)."""
+    """nn.py:716-762: fc -> centre crop -> conv.0 -> conv.2 (-> class_layer_predictor).  ``forward(x, max_shape,
+    class_pred)`` runs the decoder GEMMs of ghn3_amd/operators.py (forward only; inside GHN3.forward the decoders are
+    part of the compiled op program)."""
 
     def __init__(self, in_features, hid, out_shape, num_classes):
         super().__init__()
@@ -64,10 +84,21 @@ class ConvDecoder3(nn.Module):
                                   nn.Linear(hid[1], int(out_shape[0] * out_shape[1])), nn.Identity())
         self.class_layer_predictor = nn.Sequential(nn.ReLU(), nn.Linear(out_shape[0], num_classes))
 
+    def forward(self, x, max_shape=(1, 1, 1, 1), class_pred=False):
+        from .operators import conv_decoder3_forward
+        ghn = self.__dict__.get('_owner')
+        if ghn is None:
+            raise L.Ghn3Error('ConvDecoder3.forward needs the GHN3 that owns the decoder (flat parameter buffer)')
+        return conv_decoder3_forward(ghn, x, max_shape, class_pred)
+
 
 class SequentialMultipleInOut(nn.Sequential):
-    """Name kept for drop-in imports (nn.py:765-780); the layers execute inside the HIP program."""
-    pass
+    """Sequence of Graphormer layers threading (x, edges, mask) (nn.py:765-780)."""
+
+    def forward(self, input, *args):
+        for module in self:
+            input = module(*input) if isinstance(input, tuple) else module(input, *args)
+        return input
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -184,11 +215,17 @@ class GHN3(nn.Module):
         self.shape_enc = _Holder()
         self.shape_enc.embed_spatial = nn.Embedding(vocab.n_sp + 1, hid // 4)
         self.shape_enc.embed_channel = nn.Embedding(vocab.n_ch + 1, hid // 4)
-        self.gnn = SequentialMultipleInOut(*[_graphormer_layer(hid, heads, layer0=(l == 0)) for l in range(layers)])
+        self.gnn = SequentialMultipleInOut(*[_graphormer_layer(hid, heads, layer0=(l == 0),
+                                                               return_edges=(l < layers - 1))      # nn.py:154
+                                             for l in range(layers)])
+        for l, layer in enumerate(self.gnn):
+            layer._index = l
+            object.__setattr__(layer, '_owner', self)    # (plain attribute: the operator-level forwards need the model)
         self.gnn[0].centrality_embed_in = nn.Embedding(101, hid)
         self.gnn[0].centrality_embed_out = nn.Embedding(101, hid)
         self.gnn[0].input_dist_embed = nn.Embedding(1001, hid)
         self.decoder = ConvDecoder3(hid, (hid * 4, hid * 8), self.max_shape, num_classes)
+        object.__setattr__(self.decoder, '_owner', self)
         max_ch = max(self.max_shape[:2])
         self.decoder_1d = _Holder()
         self.decoder_1d.fc = nn.Sequential(nn.Linear(hid, hid * 2), nn.ReLU(), nn.Linear(hid * 2, 2 * max_ch),
@@ -232,6 +269,14 @@ class GHN3(nn.Module):
         self._shadowed = None
         self._shadow_state = None                 # (parameter version, has the transposed copies) they were cast from
         self._param_epoch = getattr(self, '_param_epoch', 0) + 1
+
+    def __deepcopy__(self, memo):
+        new = self.__class__.__new__(self.__class__)
+        memo[id(self)] = new
+        for k, v in self.__dict__.items():
+            new.__dict__[k] = copy.deepcopy(v, memo)
+        new._flatten()                                   # (the copy's parameters become views of ITS flat buffer)
+        return new
 
     def _apply(self, fn, *args, **kwargs):
         out = super()._apply(fn, *args, **kwargs)
@@ -591,11 +636,12 @@ def get_metadata(ghn3_name='ghn3xlm16.pt', arch=None, attr=None, path=None):
     return out
 
 
-def norm_check(model, arch='resnet50', ghn3_name='ghn3xlm16.pt', path=None):
+def norm_check(model, arch='resnet50', ghn3_name='ghn3xlm16.pt', path=None, expected=None):
     """Total norm of the model's parameters against the released known answer (tolerance 1e-2, nn.py:795).
-    Returns (total_norm, expected or None, passed or None)."""
+    `expected` overrides the table lookup (a known answer for weights other than the released checkpoints, e.g. the
+    seeded fixtures under tests/golden/).  Returns (total_norm, expected or None, passed or None)."""
     total_norm = torch.norm(torch.stack([p.norm() for p in model.parameters()]), 2).item()
-    norm = get_metadata(ghn3_name, arch=arch, attr='paramnorm', path=path)
+    norm = expected if expected is not None else get_metadata(ghn3_name, arch=arch, attr='paramnorm', path=path)
     ok = None if not norm else abs(norm - total_norm) < 1e-2
     log('Predicted params total norm={:.4f} ({})'.format(
         total_norm, 'no norm check available' if ok is None else

@@ -20,10 +20,15 @@ def _dbits(x):
 class FusedAdamW:
     """AdamW + gradient-norm clipping for a ghn3_amd.GHN3 (same update rule and defaults as torch.optim.AdamW)."""
 
-    def __init__(self, ghn, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=0.0):
+    def __init__(self, ghn, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=0.0,
+                 nan_guard=True):
         self.ghn = ghn
         self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.max_grad_norm = max_grad_norm
+        # nan_guard: the squared gradient norm is always computed; when it is not finite (a NaN / inf anywhere in the
+        # flat gradient -- after the data-parallel average every rank sees the same value) the kernel leaves parameters
+        # and moments untouched: the reference trainer's skip-this-batch (trainer.py:240-257) without a host sync
+        self.nan_guard = nan_guard
         flat = ghn._flat
         if not flat.is_cuda:
             raise L.Ghn3Error('FusedAdamW runs on an MI355X only (no CPU path)')
@@ -32,9 +37,11 @@ class FusedAdamW:
         self.scal = torch.zeros(16 + 4096, dtype=torch.float32, device=flat.device)   # [norm^2 ...| partial sums]
         self.steps = 0
 
-    def step(self, gflat):
-        """gflat: the flat gradient buffer of the last backward (plan.gflat).  Returns the gradient norm tensor
-        (device scalar, like clip_grad_norm_) when clipping is on."""
+    def step(self, gflat, grad_scale=1.0):
+        """gflat: the flat gradient buffer of the last backward (plan.gflat); grad_scale: the loss scale the gradients
+        carry (AMP: they are divided by it inside the kernel, no separate unscale pass).  Returns the gradient norm
+        (device scalar, like clip_grad_norm_) when clipping or the NaN guard is on; when it is not finite the kernel
+        left parameters and moments untouched."""
         ghn = self.ghn
         flat = ghn._flat
         assert gflat.numel() == flat.numel() and gflat.is_cuda
@@ -48,20 +55,22 @@ class FusedAdamW:
         ops[0]['kind'] = L.OP_MEMSET0
         ops[0]['r']['buf'][0] = 4
         ops[0]['i'][0] = 4
-        ops[1]['kind'] = L.OP_SUMSQ if clip else L.OP_NOP
+        guard = clip or self.nan_guard
+        ops[1]['kind'] = L.OP_SUMSQ if guard else L.OP_NOP
         ops[1]['r']['buf'][:3] = (4, 1, 5)         # (r2: scratch for the fixed-order sum of the workgroup partials)
         ops[1]['i'][0] = n
         ops[2]['kind'] = L.OP_ADAMW
-        ops[2]['r']['buf'][:5] = (0, 1, 2, 3, 4 if clip else -1)
+        ops[2]['r']['buf'][:5] = (0, 1, 2, 3, 4 if guard else -1)
         ops[2]['i'][0] = n
         hyper = (self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                  1.0 - self.betas[0] ** self.steps, 1.0 - self.betas[1] ** self.steps)
         for k, h in enumerate(hyper):
             ops[2]['i'][1 + k] = _dbits(h)
-        ops[2]['f'][0] = float(self.max_grad_norm or 0.0)
+        ops[2]['f'][0] = float(self.max_grad_norm or 0.0) if clip else 0.0
+        ops[2]['f'][1] = 1.0 / float(grad_scale)
         ghn._ctx().run(ops, np.zeros(0, dtype=L.PROBLEM_DT), bufs, torch.cuda.current_stream().cuda_stream)
         ghn.params_changed()                     # (the kernel wrote the parameters through raw pointers)
-        return self.scal[0].sqrt() if clip else None
+        return self.scal[0].sqrt() / float(grad_scale) if guard else None
 
     # ------------------------------------------------------------------ checkpoints (trainer.py:413-432)
     def state_dict(self):

@@ -1,0 +1,235 @@
+"""
+Trainer for the GHN branch of the reference's training loop, with the same call sequence and file formats
+(/root/reference/ghn3/trainer.py:42-68 constructor, 238-411 ``update``, 413-432 ``save``, 434-440 ``log``; driven by
+train_ghn_ddp.py:132-150):
+
+    trainer = Trainer(ghn, opt='adamw', opt_args={'lr': 4e-4, 'weight_decay': 1e-2}, scheduler='cosine-warmup',
+                      n_batches=len(queue), grad_clip=5, device=device, predparam_wd=3e-5, save_dir=..., epochs=...)
+    for epoch in range(trainer.start_epoch, epochs):
+        trainer.reset_metrics(epoch)
+        for step, (images, targets, graphs) in enumerate(queue, start=trainer.start_step):
+            trainer.update(images, targets, graphs)
+            trainer.log(step)
+            trainer.save(epoch, step, {'config': config})
+        trainer.scheduler_step()
+
+What is different underneath (MI355X-first, same results):
+  * the GHN forward / backward are the HIP op programs of ghn3_amd.GHN3; the predicted-parameter regulariser
+    (predparam_wd, trainer.py:97-98,288-294) is two streaming kernels on the flat output (GHN3.predicted_param_norm);
+  * data parallel: no DistributedDataParallel wrapper -- rank 0's parameters are broadcast once (sync_parameters), the
+    flat gradient buffer is averaged by FlatGradReducer inside loss.backward(), overlapped with the Graphormer backward;
+  * clip_grad_norm_ + AdamW are two kernels over the flat buffers (FusedAdamW); a non-finite gradient norm (NaN / inf
+    loss on ANY rank reaches every rank through the averaged gradient) skips the step on all ranks alike, on the
+    device -- the reference's all-gather of the loss and host-side skip (trainer.py:240-257,397-409) without the syncs;
+  * the training metrics (loss, top-1, top-5, regulariser) stay on the device and are averaged over the ranks with ONE
+    all-reduce of a 4-vector per step instead of 4-5 scalar all-gathers; they are read at log time only.
+Target networks run on stock torch ops with the predicted tensors; images may be None, in which case
+the step trains on the regulariser alone (the benchmark's loss).
+"""
+
+import math
+import os
+
+import torch
+import torch.nn.functional as F
+
+from .ddp_utils import is_ddp, get_ddp_rank, sync_parameters, FlatGradReducer
+from .optim import FusedAdamW, save_checkpoint
+from .utils import log, Logger
+
+import torch.distributed as dist
+
+
+class _DeviceMeter:
+    """Running sums kept on the device (no host read until .avg)."""
+
+    def __init__(self, names, device):
+        self.names = list(names)
+        self.sum = torch.zeros(len(self.names), dtype=torch.float64, device=device)
+        self.cnt = 0
+
+    def update(self, vec, n):
+        self.sum += vec.to(torch.float64) * n
+        self.cnt += n
+
+    def avg(self):
+        vals = (self.sum / max(self.cnt, 1)).tolist()
+        return dict(zip(self.names, vals))
+
+
+def _schedule(name, epochs, base_lr, scheduler_args):
+    """Learning-rate multiplier per epoch for the schedules the reference offers (trainer.py:177-206)."""
+    args = scheduler_args or {}
+    if name.startswith('cosine-warmup'):
+        def parse(key, default):
+            p = name.find(key)
+            if p < 0:
+                return default
+            end = name.find('-', p)
+            return float(name[p + len(key):] if end < 0 else name[p + len(key):end])
+        warm = int(parse('steps', 5))
+        init = parse('init_lr', 1e-5) / base_lr
+
+        def mult(e):
+            if e < warm - 1:
+                return init + (1.0 - init) * e / max(1, warm - 1)
+            prog = float(e - warm) / float(max(1, epochs - warm))
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+        return mult
+    if name == 'cosine':
+        return lambda e: 0.5 * (1.0 + math.cos(math.pi * e / max(1, epochs)))
+    if name == 'step':
+        return lambda e: args.get('gamma', 0.1) ** (e // args['step_size'])
+    if name == 'mstep':
+        return lambda e: args.get('gamma', 0.1) ** sum(1 for m in args['milestones'] if e >= m)
+    raise NotImplementedError(name)
+
+
+class Trainer:
+    def __init__(self, model, opt, opt_args, scheduler, n_batches, grad_clip=5, auxiliary=False, auxiliary_weight=0.4,
+                 device='cuda', log_interval=100, label_smoothing=0, predparam_wd=0, scheduler_args=None, save_dir=None,
+                 ckpt=None, epochs=None, verbose=False, amp=False, amp_min_scale=None, amp_growth_interval=2000,
+                 grad_compress='bf16', **unused):
+        from .nn import GHN3
+        if not isinstance(model, GHN3):
+            raise NotImplementedError('ghn3_amd.Trainer drives the GHN branch (train_ghn_ddp.py); plain networks '
+                                      '(train_ddp.py) train with stock PyTorch')
+        if opt.lower() != 'adamw':
+            raise NotImplementedError('the fused optimizer step implements AdamW (the GHN-3 recipe); got %s' % opt)
+        assert 'lr' in opt_args, 'learning rate must be specified in opt_args'
+        self.n_batches, self.grad_clip, self.device = n_batches, grad_clip, device
+        self.auxiliary, self.auxiliary_weight = auxiliary, auxiliary_weight
+        self.log_interval, self.label_smoothing = log_interval, label_smoothing
+        self.predparam_wd, self.epochs, self.verbose = predparam_wd, epochs, verbose
+        self.amp = amp
+        # AMP (trainer.py:269,346-379): the target networks run under autocast; the GHN's own 16-bit mode is `compute`.
+        # The loss scale is static (amp_min_scale, 1024 in the GHN-3 recipe): overflow steps are skipped by the
+        # optimizer's non-finite-norm guard; the f16 backward copies are power-of-two scaled per step anyway.
+        self.loss_scale = float(amp_min_scale or 1024.0) if amp else 1.0
+        self.ddp = is_ddp()
+        self.rank = get_ddp_rank() if self.ddp else 0
+        model.to(device)
+        self.start_epoch = self.start_step = 0
+        self.checkpoint_path = os.path.join(save_dir, 'checkpoint.pt') if save_dir else None
+        state = None
+        if self.checkpoint_path is not None and os.path.exists(self.checkpoint_path):
+            ckpt = self.checkpoint_path
+            log('Found existing checkpoint %s: resuming.' % ckpt)
+        if ckpt is not None:
+            if self.ddp:
+                dist.barrier()
+            state = torch.load(ckpt, map_location='cpu')
+            model.load_state_dict(state['state_dict'])
+            self.start_epoch, self.start_step = int(state.get('epoch', 0)), int(state.get('step', 0))
+        self._model = model
+        if self.ddp:
+            sync_parameters(model)                       # what DistributedDataParallel's constructor does
+            model.grad_reducer = FlatGradReducer(compress=grad_compress)
+        self.base_lr = float(opt_args['lr'])
+        kw = {k: v for k, v in opt_args.items() if k in ('betas', 'eps', 'weight_decay')}
+        self._optimizer = FusedAdamW(model, lr=self.base_lr, max_grad_norm=float(grad_clip or 0.0), **kw)
+        self._lr_mult = _schedule(scheduler, epochs or 1, self.base_lr, scheduler_args)
+        self._epoch = self.start_epoch
+        if state is not None and 'optimizer' in state:
+            self._optimizer.load_state_dict(state['optimizer'])
+        self._optimizer.lr = self.base_lr * self._lr_mult(self._epoch)
+        self.skipped_updates = 0
+        self.reset_metrics(self.start_epoch)
+        if state is not None:
+            if self.start_step >= self.n_batches - 1:
+                self.start_step, self.start_epoch = 0, self.start_epoch + 1
+            else:
+                self.start_step += 1
+
+    # ------------------------------------------------------------------ schedule / bookkeeping
+    def reset_metrics(self, epoch):
+        self._step = 0
+        if epoch > self.start_epoch:
+            self.start_step = 0
+        names = ['loss', 'top1', 'top5'] + (['loss_predwd'] if self.predparam_wd > 0 else [])
+        self.metrics = _DeviceMeter(names, self.device)
+        self.logger = Logger(self.n_batches, start_step=self.start_step)
+
+    def get_lr(self):
+        return self._optimizer.lr
+
+    def scheduler_step(self):
+        self._epoch += 1
+        self._optimizer.lr = self.base_lr * self._lr_mult(self._epoch)
+
+    # ------------------------------------------------------------------ one training step
+    def update(self, images, targets, graphs=None):
+        ghn = self._model
+        if not ghn.training:
+            ghn.train()
+        ghn.zero_grad(set_to_none=True)                 # (p.grad are views of the previous flat gradient buffer)
+        dev = self.device
+        models = graphs.nets if hasattr(graphs, 'nets') and len(graphs.nets) > 0 else None
+        if models is None:
+            raise ValueError('graphs.nets is empty: the batch must carry the target networks (deepnets1m.py:80)')
+        models = ghn(models, graphs.to_device(dev), bn_track_running_stats=True, keep_grads=True, reduce_graph=True)
+        loss = torch.zeros((), device=dev)
+        stats = torch.zeros(4, device=dev)               # loss, top1, top5, loss_predwd
+        if images is not None:
+            images = images.to(dev, non_blocking=True)
+            targets = targets.to(dev, non_blocking=True)
+            logits = []
+            with torch.autocast('cuda', dtype=torch.float16, enabled=self.amp):
+                for m in models:
+                    out = m(images)
+                    y = out[0] if isinstance(out, tuple) else out
+                    loss = loss + F.cross_entropy(y.float(), targets, label_smoothing=self.label_smoothing)
+                    if self.auxiliary and isinstance(out, tuple):
+                        loss = loss + self.auxiliary_weight * F.cross_entropy(out[1].float(), targets,
+                                                                              label_smoothing=self.label_smoothing)
+                    logits.append(y.detach().float())
+            loss = loss / len(models)
+            with torch.no_grad():
+                lg = torch.stack(logits)                                  # models x batch x classes
+                k = min(5, lg.shape[-1])
+                top = lg.topk(k, dim=-1).indices
+                hit = top == targets.view(1, -1, 1)
+                stats[1] = 100.0 * hit[..., :1].any(-1).float().mean()
+                stats[2] = 100.0 * hit.any(-1).float().mean()
+        if self.predparam_wd > 0:
+            wd = self.predparam_wd * ghn.predicted_param_norm() / len(models)
+            loss = loss + wd
+            stats[3] = wd.detach()
+        stats[0] = loss.detach()
+        (loss * self.loss_scale).backward()              # backward program (+ overlapped gradient average, N > 1)
+        # clip + AdamW on the flat buffers; a non-finite norm (NaN loss on any rank) skips the update everywhere
+        gnorm = self._optimizer.step(ghn.last_plan.gflat, grad_scale=self.loss_scale)
+        with torch.no_grad():
+            bad = ~torch.isfinite(gnorm) if gnorm is not None else ~torch.isfinite(stats[0])
+            vec = torch.cat([stats, bad.float().view(1)])
+            if self.ddp:                                 # ONE small collective for all metrics
+                dist.all_reduce(vec)
+                vec[:4] /= dist.get_world_size()
+            self._skipped = getattr(self, '_skipped', torch.zeros((), device=dev)) + (vec[4] > 0).float()
+            n = int(targets.numel()) * len(models) if images is not None else len(models)
+            good = (vec[4] == 0).float()                 # (skipped steps do not enter the averages)
+            self.metrics.update(torch.nan_to_num(vec[:len(self.metrics.names)]) * good, n)
+        self._step += 1
+        return self.metrics
+
+    # ------------------------------------------------------------------ checkpoints / logging
+    def save(self, epoch, step, config, save_freq=300, interm_epoch=5):
+        if not ((((step + 1) % save_freq == 0) or step == self.n_batches - 1) and self.rank == 0):
+            return
+        save_checkpoint(self.checkpoint_path, self._model, self._optimizer, epoch, step, config)
+        log('\nsaved the checkpoint to {} at epoch={}, step={}'.format(self.checkpoint_path, epoch, step))
+        if (epoch + 1) % interm_epoch == 0 or epoch == 0:
+            path = self.checkpoint_path.replace('.pt', '_epoch%d.pt' % (epoch + 1))
+            save_checkpoint(path, self._model, self._optimizer, epoch, step, config)
+            log('saved the intermediate checkpoint to {}'.format(path))
+
+    def log(self, step=None):
+        step_ = self._step if step is None else (step + 1)
+        if step_ % self.log_interval == 0 or step_ >= self.n_batches - 1 or step_ == 1:
+            metrics = self.metrics.avg()                 # (the only host read of the step statistics)
+            self.skipped_updates = int(getattr(self, '_skipped', torch.zeros(())).item())
+            if self.skipped_updates:
+                metrics['skipped'] = self.skipped_updates
+            if self.amp:
+                metrics['amp_scale'] = self.loss_scale
+            self.logger(step_, metrics)

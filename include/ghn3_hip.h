@@ -290,7 +290,8 @@ enum ghn3_op_kind {
      *        added in a fixed order instead of with float atomics) -- the squared global gradient norm of clip_grad_norm_
      * ADAMW: torch.optim.AdamW on r0 = params, r1 = grads, r2 = exp_avg, r3 = exp_avg_sq (i0 = n floats);
      *        r4 = squared gradient norm or absent, f0 = max_norm (<= 0: no clipping): the gradient is scaled by
-     *        min(1, max_norm / (norm + 1e-6)); i1..i7 = IEEE-754 double bit patterns of lr, beta1, beta2, eps,
+     *        min(1, max_norm / (norm + 1e-6)); a non-finite r4 skips the whole update (NaN guard, trainer.py:240-257);
+     *        f1 = 1 / loss scale (0 = 1): the gradients arrive multiplied by the AMP loss scale (trainer.py:346-352); i1..i7 = IEEE-754 double bit patterns of lr, beta1, beta2, eps,
      *        weight_decay, 1 - beta1^t, 1 - beta2^t */
     GHN3_OP_SUMSQ = 26,
     GHN3_OP_ADAMW = 27,

@@ -99,9 +99,13 @@ class Interp:
         n = int(o['i'][0])
         lr, b1, b2, eps, wd, bc1, bc2 = (float(v) for v in o['i'][1:8].view(np.float64))
         p, g, m, v = (self.fview(o['r'][k], n) for k in range(4))
-        clip = 1.0
-        if int(o['r'][4]['buf']) >= 0 and float(o['f'][0]) > 0:
-            clip = min(1.0, float(o['f'][0]) / (float(np.sqrt(self.fview(o['r'][4], 1)[0])) + 1e-6))
+        inv = float(o['f'][1]) if float(o['f'][1]) > 0 else 1.0
+        clip = inv
+        if int(o['r'][4]['buf']) >= 0:
+            if not np.isfinite(self.fview(o['r'][4], 1)[0]):
+                return
+            if float(o['f'][0]) > 0:
+                clip *= min(1.0, float(o['f'][0]) / (float(np.sqrt(self.fview(o['r'][4], 1)[0])) * inv + 1e-6))
         gi = g.astype(np.float64) * clip
         m[:] = b1 * m + (1 - b1) * gi
         v[:] = b2 * v + (1 - b2) * gi * gi

@@ -62,9 +62,10 @@ def _reducer_worker(rank, world, port, ret):
     n, lo, hi = 300007, 1000, 250001
     base = torch.linspace(-1, 1, n)
     oks = []
-    for compress, tol in ((None, 1e-6), ('bf16', 1e-2)):
+    for compress, tol, algo in ((None, 1e-6, 'mesh'), ('bf16', 1e-2, 'mesh'), (None, 1e-6, 'allreduce'),
+                                ('bf16', 1e-2, 'allreduce')):
         g = base * (rank + 1)
-        red = FlatGradReducer(compress=compress, chunk_bytes=1 << 18)
+        red = FlatGradReducer(compress=compress, chunk_bytes=1 << 18, algo=algo)
         expect = base * (sum(range(1, world + 1)) / world)
         for it in range(2):                            # (two backward passes through one reducer)
             g = base * (rank + 1)
@@ -90,3 +91,46 @@ def test_two_phase_flat_grad_reducer_world2():
     assert len(ret) == world
     for r in range(world):
         assert all(ret[r]), ret[r]
+
+
+def _mesh_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from ghn3_amd.ddp_utils import setup_ddp, mesh_all_reduce_avg, sync_parameters, clean_ddp
+    setup_ddp()
+    oks = []
+    for n in (1, 7, 1000, 100003):                       # sizes that do not divide the world size
+        x = torch.arange(n, dtype=torch.float32) * (rank + 1) + rank
+        mesh_all_reduce_avg(x)
+        expect = torch.arange(n, dtype=torch.float32) * (sum(range(1, world + 1)) / world) + (world - 1) / 2
+        oks.append(bool(torch.allclose(x, expect, rtol=1e-6, atol=1e-6)))
+        # a NaN on one rank reaches every rank (the optimizer's NaN guard then skips the step everywhere alike)
+        y = torch.ones(max(n, 4))
+        if rank == world - 1:
+            y[0] = float('nan')
+        mesh_all_reduce_avg(y)
+        oks.append(bool(torch.isnan(y[0])) and bool(torch.isfinite(y[1:]).all()))
+
+    class _M:                                             # (sync_parameters only needs the flat buffer)
+        def __init__(self):
+            self._flat = torch.full((1000,), float(rank))
+
+        def params_changed(self):
+            self.changed = True
+    m = sync_parameters(_M(), src=0)
+    oks.append(bool((m._flat == 0).all()) and m.changed)
+    ret[rank] = oks
+    clean_ddp()
+
+
+def test_mesh_all_reduce_world3():
+    """mesh_all_reduce_avg (all-to-all + fp32 local sum + all-gather, the xGMI-mesh-shaped exchange) on 3 ranks: odd
+    sizes, NaN propagation (the cross-rank NaN guard relies on it), and the initial parameter broadcast."""
+    world = 3
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_mesh_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        assert all(ret[r]), (r, ret[r])

@@ -518,6 +518,14 @@ def _resnet_fixture_check(depth, variant, compute, tol, n_expected=None):
         n_ref = float(gold['pred/%s/norm' % name][0])
         assert abs(float(v.double().norm()) - n_ref) < tol * n_ref, (name, float(v.norm()), n_ref)
     assert total == int(gold['meta/n_predicted'][0]) == {18: 11689512, 50: 25557032, 'vit': 86566888}[depth]
+    if depth != 'vit':
+        # eval_ghn.py:147-169 / nn.py:783-796: the total-norm known-answer check, executed against the norm of the
+        # REFERENCE's own prediction for these seeded weights (the released checkpoints are not obtainable offline)
+        from ghn3_amd import norm_check
+        names = [n for n, _ in recipe.named_predicted(net)]
+        ref_total = float(np.sqrt(sum(float(gold['pred/%s/norm' % n][0]) ** 2 for n in names)))
+        total_norm, expected, ok = norm_check(net, arch=tag, ghn3_name='ghn3xlm16.pt', expected=ref_total)
+        assert ok and abs(total_norm - ref_total) < 1e-2, (total_norm, ref_total)
     print('%s %s %s: worst sampled rel-L2 error %.2e' % (tag, variant, compute, worst))
 
 
@@ -659,6 +667,41 @@ def test_optimizer_state_interchanges_with_torch_adamw(tmp_path):
     again = from_pretrained(path)
     for (k, a), (_, b) in zip(sorted(again.state_dict().items()), sorted(hip.state_dict().items())):
         assert torch.equal(a, b.cpu()), k
+
+
+@pytest.mark.skipif(not os.environ.get('GHN3_CKPT'), reason='set GHN3_CKPT=/path/to/ghn3xlm16.pt (released checkpoint) '
+                    'and GHN3_RESULTS_JSON to run the known-answer check of nn.py:783-861')
+def test_released_checkpoint_known_answer():
+    """With a released checkpoint at hand: from_pretrained -> predict the torchvision-shaped ResNet-50 -> total norm
+    against the `ghn3-paramnorm` entry of ghn3_results.json (108.4530 for ghn3xlm16; nn.py:783-796).  This also pins the
+    parts of the path only ppuda defines (shape vocabulary, primitive order), see DESIGN.md 5."""
+    from ghn3_amd import from_pretrained, norm_check, Graph, GraphBatch
+    ckpt = os.environ['GHN3_CKPT']
+    ghn = from_pretrained(ckpt, compute='f32').to('cuda').eval()
+    spec = recipe.resnet_spec(50)
+    net = recipe.build_torch_net(spec)
+    nf, info, A = recipe.graph_arrays(spec)
+    with torch.no_grad():
+        net = ghn(net, GraphBatch([Graph(node_feat=nf, node_info=info, A=A)], dense=True), bn_track_running_stats=True)
+    path = os.environ.get('GHN3_RESULTS_JSON', os.path.join(GOLD, 'ghn3_results.json'))
+    total, expected, ok = norm_check(net, arch='resnet50', ghn3_name=os.path.basename(ckpt), path=path)
+    assert ok, (total, expected)
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason='needs 2 GPUs (the driver runs the multi-GPU bench itself)')
+def test_two_rank_rccl_bench_line():
+    """`python bench.py --gpus 2` starts its own ranks (fresh processes), exchanges the flat gradients over RCCL with the
+    overlapped reducer and prints one JSON line for the whole job."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, os.path.join(root, 'bench.py'), '--gpus', '2', '--steps', '3', '--warmup', '1',
+                          '--model', 'ghn3tm8', '--nodes', '64', '--no-cpu-baseline', '--no-extras'],
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line['n_gpus'] == 2 and line['value'] > 0 and line['config']['parallelism'] == 'dp2'
 
 
 def test_graft_entry_smoke():

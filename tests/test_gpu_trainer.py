@@ -1,0 +1,90 @@
+"""GPU tests of the Trainer (the GHN branch of trainer.py:238-440 on the flat-buffer optimizer) and of the counterpart
+scripts' call sequences."""
+
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import recipe
+from util_parity import make_models
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _batch(names):
+    import graph_nets
+    from ghn3_amd import Graph, GraphBatch
+    nets = [graph_nets.all_nets(graph_nets.local_bases())[n].to('cuda') for n in names]
+    gb = GraphBatch([Graph(net, ve_cutoff=50) for net in nets], dense=True)
+    gb.nets = nets                                           # (the loader attaches the target networks, deepnets1m.py:80)
+    return gb
+
+
+def test_trainer_update_log_save_resume(tmp_path):
+    """Trainer.update / log / save / scheduler_step over three steps on image batches (cross-entropy of the predicted
+    networks + the predicted-parameter regulariser), then resume from the checkpoint it wrote: same parameters, same
+    optimizer state, next step index."""
+    from ghn3_amd import Trainer
+    cfg = dict(recipe.TINY_CFG)
+    hip, _ = make_models(cfg, recipe.TINY_SEED)
+    gen = torch.Generator().manual_seed(1)
+    images = torch.randn(4, 3, 32, 32, generator=gen)
+    targets = torch.tensor([1, 7, 3, 9])
+    tr = Trainer(hip, 'adamw', {'lr': 1e-3, 'weight_decay': 1e-2}, 'cosine-warmup-steps2', n_batches=3, grad_clip=5,
+                 device='cuda', log_interval=1, predparam_wd=3e-5, save_dir=str(tmp_path), epochs=4)
+    before = hip._flat.detach().clone()
+    losses = []
+    for step in range(3):
+        m = tr.update(images, targets, _batch(['resnet_tiny', 'mobile_se']))
+        tr.log(step)
+        tr.save(0, step, {'config': cfg}, save_freq=3)
+        losses.append(m.avg()['loss'])
+    assert all(np.isfinite(l) for l in losses) and tr.skipped_updates == 0
+    assert not torch.equal(before, hip._flat)
+    assert os.path.exists(tmp_path / 'checkpoint.pt')
+    lr0 = tr.get_lr()
+    tr.scheduler_step()
+    assert tr.get_lr() != lr0
+    # resume
+    hip2, _ = make_models(cfg, recipe.TINY_SEED + 1)
+    tr2 = Trainer(hip2, 'adamw', {'lr': 1e-3, 'weight_decay': 1e-2}, 'cosine-warmup-steps2', n_batches=3, grad_clip=5,
+                  device='cuda', save_dir=str(tmp_path), epochs=4)
+    assert torch.equal(hip2._flat, hip._flat)
+    assert tr2._optimizer.steps == 3 and torch.equal(tr2._optimizer.exp_avg, tr._optimizer.exp_avg)
+    assert (tr2.start_epoch, tr2.start_step) == (1, 0)       # the saved step was the last of its epoch
+
+
+def test_trainer_skips_non_finite_steps():
+    """A NaN loss (here: NaN images) must leave parameters and optimizer moments untouched -- the device-side guard that
+    replaces the reference's NaN-loss all-gather / skip (trainer.py:240-257)."""
+    from ghn3_amd import Trainer
+    hip, _ = make_models(dict(recipe.TINY_CFG), recipe.TINY_SEED)
+    tr = Trainer(hip, 'adamw', {'lr': 1e-3}, 'cosine', n_batches=10, grad_clip=5, device='cuda', epochs=2)
+    images = torch.randn(2, 3, 32, 32)
+    targets = torch.tensor([1, 2])
+    tr.update(images, targets, _batch(['resnet_tiny']))
+    torch.cuda.synchronize()
+    p, m = hip._flat.detach().clone(), tr._optimizer.exp_avg.clone()
+    tr.update(images * float('nan'), targets, _batch(['resnet_tiny']))
+    torch.cuda.synchronize()
+    assert torch.equal(p, hip._flat) and torch.equal(m, tr._optimizer.exp_avg)
+    tr.log(0)
+    assert tr.skipped_updates == 1
+    tr.update(images, targets, _batch(['resnet_tiny']))      # and training goes on
+    torch.cuda.synchronize()
+    assert not torch.equal(p, hip._flat) and torch.isfinite(hip._flat).all()
+
+
+def test_eval_ghn_counterpart_script():
+    """examples/eval_ghn.py: from-scratch GHN of the smallest released size, two architectures, prediction + norm print +
+    evaluation forward (the eval_ghn.py:107-183 sequence)."""
+    out = subprocess.run([sys.executable, os.path.join(ROOT, 'examples', 'eval_ghn.py'), '--ghn', 'ghn3tm8', '--arch',
+                          'resnet_small', '--batch', '2'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                         timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:]
+    assert 'finite=True' in out.stdout and 'total norm' in out.stdout.lower(), out.stdout[-1000:]

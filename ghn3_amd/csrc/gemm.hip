@@ -875,6 +875,226 @@ void gemm_h16d_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int to
 }
 
 // ------------------------------------------------------------------------------------------------
+// 256 x 256 "ping-pong" variant of the 16-bit-operand kernel (tile code 26).
+//
+// The two-stage kernel above runs all 8 waves of a workgroup in the same phase: everybody reads fragments, then everybody
+// multiplies, and the LDS-DMA of the next k-tile is issued in one burst -- measured 921-958 TF at 4096^3 against a
+// ceiling of ~1.34 PF set by what one CU pulls through L2 -> LDS (~17 B/clk: 64 KB per 256 x 256 x 64 k-tile).  Here the
+// workgroup is two wave GROUPS (wave rows wr = 0 / 1: one wave of each on every SIMD) that run HALF A PHASE APART: while
+// one group multiplies, the other reads fragments, issues its share of the DMA and waits for it -- the matrix pipe of a
+// SIMD always has one wave feeding it and one wave hiding memory work behind it.
+//   * a k-tile (64 k) is four PHASES of 8 MFMAs (32 x 32 x 16): the wave's 128 x 64 output as quadrants Q(a, b) of
+//     64 x 32 in the order Q00, Q01, Q11, Q10: phase 1 reads A sub-tile a = 0 (8 ds_read_b128) and B sub-tile b = 0 (4),
+//     phase 2 B b = 1 (4), phase 3 A a = 1 (8), phase 4 nothing (B b = 0 is still in registers);
+//   * ONE s_barrier per phase: in the interval behind it group 0 multiplies the phase first and reads the fragments of
+//     the next one afterwards, group 1 reads first and multiplies afterwards -- a load segment = fragment reads, ONE
+//     half-tile of DMA (2 pieces per thread) and a counted vmcnt;
+//   * LDS: 2 k-tile buffers x 4 half-tiles of 16 KB.  A half-tile is defined by QUADRANT PARITY, not by contiguous rows:
+//     A_h = the rows of sub-tile a = h of both wave rows, B_h = the columns of sub-tile b = h of the four wave columns,
+//     so that phase 1 needs exactly {A_0, B_0}, phase 2 {B_1}, phase 3 {A_1}: the DMA is issued in that consumption
+//     order, one half-tile per phase, each into its buffer two phases after the buffer's last read (the staggered
+//     group's reads retire one barrier later) -- six half-tiles (96 KB) ahead of the phase that issues them, four
+//     (64 KB) in flight at every wait;
+//   * a half-tile is waited for (vmcnt(8): this thread's pieces of the four younger half-tiles may stay in flight) in
+//     the phase BEFORE the one that reads it; the barriers in between make every wave's pieces visible.
+// Same operand / epilogue contract as gemm_h16d_kernel (k-map, ragged extents, split-K, row-vector epilogue).
+//
+// MEASURED (round 2, MI355X, f16, tests/gemm_bench.py shapes) and therefore OFF by default (GHN3_PINGPONG=1 selects it):
+//   4096^3 847 TF (two-stage kernel 934), 8192^3 874 (854), W2 forward 768 x 147456 x 3072 854 (870), wgrad band 512 (546).
+// Ablations of this kernel (GHN3_PP_DEBUG): without the DMA 1150-1390 TF-equivalent, without the MFMAs 1160-1710, without
+// the fragment reads 902-933 -- the DMA stream and the matrix work each take ~60 % of the time of the full kernel and
+// do NOT overlap the way the structure intends: per k-tile the load segments (12 ds_read_b128 + 2 DMA pieces per phase)
+// cost ~360 cycles per phase, the vmcnt waits almost nothing -- the DMA pieces block at ISSUE (the L2 -> LDS path
+// saturates at ~17-19 B/clk/CU, 64 KB per k-tile = ~3400 cycles against 2048 cycles of MFMA), and a wave blocked in a
+// DMA issue does not release its SIMD's issue slots to the partner's MFMAs as cleanly as assumed.  The tile would have
+// to move fewer bytes per flop (bigger than 256 x 256 does not fit the accumulators) for this structure to pay.
+// ------------------------------------------------------------------------------------------------
+template <int CT, int DBG = 0>      // DBG (ablation runs only): 1 = no DMA, 2 = no MFMA, 3 = no fragment reads
+__device__ __forceinline__ void h16p_tile(const GemmProbDev* __restrict__ probs, int n_probs, int tile_id, float* smem) {
+    constexpr int BM = 256, BN = 256, BK = 64, NT = 512;
+    constexpr int HALF = 128 * 128;                  // bytes per half-tile image: 128 rows x 128 B
+    char* sm = reinterpret_cast<char*>(smem);        // [k-tile parity][A0, B0, B1, A1][128][128 B]
+
+    const GemmProbDev* P = find_problem(probs, n_probs, tile_id);
+    const int t = tile_id - P->tile_start;
+    int m0, n0, kz;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 2, wc = wave & 3;
+    bool live = tile_origin<BM, BN>(P, t, m0, n0, kz);
+    const int l31 = lane & 31, lhi = lane >> 5;
+    int Kp = P->K;
+    if (live && P->lim) {
+        const int* lim = P->lim;
+        int ext = lim[m0 >> 7];
+        if (m0 + 128 < P->M) ext = max(ext, lim[(m0 >> 7) + 1]);
+        if (P->lim_kind == 1) { if (n0 >= ext) live = false; }
+        else Kp = min(Kp, ext);
+    }
+    const int kt0 = live ? kz * (P->k_chunk / BK) : 0;
+    const int K = (P->ksplit > 1) ? min(Kp, (kz + 1) * P->k_chunk) : Kp;
+    if (live && kt0 * BK >= K && P->ksplit > 1) live = false;
+    if (!live) return;                               // (uniform over the workgroup: nobody is left at a barrier)
+    const int nkt = (K + BK - 1) / BK - kt0;
+
+    // DMA: piece p = tid + 512 i (i = 0, 1) of a half-tile -> buffer row rho = p >> 3, slot p & 7 holding k-chunk
+    // slot ^ ((rho >> 1) & 7).  A_h row rho <-> tile row 128 (rho >> 6) + 64 h + (rho & 63); B_h row rho <-> tile column
+    // 64 (rho >> 5) + 32 h + (rho & 31).
+    gch pa[2][2], pb[2][2];                          // [half][piece]
+    int ck;
+    {
+        gch A = (gch)P->A; gch B = (gch)P->B;
+        gci ag = (gci)P->a_gather; gci bg = (gci)P->b_gather;
+        const int slot = tid & 7;
+        ck = (slot ^ ((tid >> 4) & 7)) * 8;          // ((rho >> 1) & 7 is the same for both pieces: 64 rows apart)
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rho = (tid >> 3) + 64 * i;
+                const int ra = min(m0 + 128 * (rho >> 6) + 64 * h + (rho & 63), P->M - 1);
+                const int rb = min(n0 + 64 * (rho >> 5) + 32 * h + (rho & 31), P->N - 1);
+                pa[h][i] = A + (int64_t)map_row(ra, ag, P->a_q, P->a_s) * P->lda + ck;
+                pb[h][i] = B + (int64_t)map_row(rb, bg, P->b_q, P->b_s) * P->ldb;
+            }
+    }
+    const int kq = P->kq, ks = P->ks;
+    const float inv_kq = kq > 0 ? 1.0f / (float)kq : 0.f;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // half-tile sequence index q = 4 T + j, j = 0..3 <-> (A0, B0, B1, A1) of k-tile T, stored at buffer (T & 1, j)
+    auto issue = [&](int q) {
+        const int T = q >> 2, j = q & 3;
+        if (T >= nkt || DBG == 1) return;            // (past the last k-tile: nothing to fetch)
+        const int k0 = (kt0 + T) * BK;
+        LAS char* dst = (LAS char*)(sm + ((T & 1) * 4 + j) * HALF);
+        if (j == 0 || j == 3) {
+            const int h = j == 3;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((const void GAS*)(pa[h][i] + k0), (LAS void*)(dst + (wave * 64 + NT * i) * 16),
+                                                 16, 0, 0);
+        } else {
+            const int h = j == 2;
+            int kb = k0 + ck;
+            if (kq > 0) {
+                int qd = (int)((float)kb * inv_kq);
+                int rm = kb - qd * kq;
+                if (rm < 0) { rm += kq; --qd; } else if (rm >= kq) { rm -= kq; ++qd; }
+                kb = qd * ks + rm;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                __builtin_amdgcn_global_load_lds((const void GAS*)(pb[h][i] + kb), (LAS void*)(dst + (wave * 64 + NT * i) * 16),
+                                                 16, 0, 0);
+        }
+    };
+    // pieces of this thread still allowed in flight so that half-tile `q` has landed, given `last` = newest issued index
+    auto wait_for = [&](int q, int last) {
+        const int total = 4 * nkt - 1;               // newest half-tile that exists
+        const int younger = min(last, total) - q;    // issued after q (each 2 pieces per thread)
+        if (younger >= 4) wait_vmcnt<8>();
+        else if (younger == 3) wait_vmcnt<6>();
+        else if (younger == 2) wait_vmcnt<4>();
+        else if (younger == 1) wait_vmcnt<2>();
+        else wait_vmcnt<0>();
+    };
+
+    // prologue: the first seven half-tiles; A0(0), B0(0) must have landed for phase 0
+#pragma unroll
+    for (int q = 0; q < 7; ++q) issue(q);
+    wait_for(2, 6);                                  // (phase 0 reads A0, B0 and phase 1 B1 of k-tile 0)
+    __builtin_amdgcn_s_barrier();
+
+    u16x8 fa[2][4], fb[2][4];                        // A sub-tile fragments [32-row tile][k-step]; B fragments [b][k-step]
+    // fragment reads of phase (T, ph): quadrant order Q00, Q01, Q11, Q10
+    auto load_phase = [&](int T, int ph) {
+        if (DBG == 3 && T > 0) return;
+        const char* buf = sm + (T & 1) * 4 * HALF;
+        if (ph == 0 || ph == 2) {                    // A sub-tile a = (ph == 2): buffer row 64 wr + 32 i + l31
+            const char* a_s = buf + (ph == 0 ? 0 : 3) * HALF;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = 64 * wr + 32 * i + l31;
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+                    fa[i][kk] = *reinterpret_cast<const u16x8*>(a_s + row * 128 + (((kk * 2 + lhi) ^ ((row >> 1) & 7)) << 4));
+            }
+        }
+        if (ph == 0 || ph == 1) {                    // B sub-tile b = ph: buffer row 32 wc + l31
+            const char* b_s = buf + (1 + ph) * HALF;
+            const int row = 32 * wc + l31;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+                fb[ph][kk] = *reinterpret_cast<const u16x8*>(b_s + row * 128 + (((kk * 2 + lhi) ^ ((row >> 1) & 7)) << 4));
+        }
+    };
+    auto mfma_phase = [&](int T, int ph) {
+        if (DBG == 2 && T > 0) return;
+        const int a = ph >> 1, b = (ph == 1 || ph == 2) ? 1 : 0;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                acc[2 * a + i][b] = mfma16<CT>(fa[i][kk], fb[b][kk], acc[2 * a + i][b]);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    // ONE barrier per phase.  Interval k (after barrier k) computes phase k - 1: group 0 multiplies first and then reads the
+    // fragments of phase k, group 1 reads the fragments of phase k - 1 first and multiplies then -- on every SIMD one
+    // wave multiplies while the other one reads, issues its DMA pieces (half-tile k + 6) and waits for what phase k + 1
+    // needs.  A buffer is refilled two intervals after its last read (group 1 reads a phase one interval later).
+    if (wr == 0) load_phase(0, 0);
+    for (int T = 0; T < nkt; ++T) {
+#pragma unroll
+        for (int ph = 0; ph < 4; ++ph) {
+            const int k = 4 * T + ph + 1;            // interval index; phase k - 1 = (T, ph)
+            __builtin_amdgcn_s_barrier();
+            if (wr == 0) {
+                mfma_phase(T, ph);
+                __builtin_amdgcn_sched_barrier(0);
+                if (ph < 3) load_phase(T, ph + 1); else if (T + 1 < nkt) load_phase(T + 1, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                issue(k + 6);
+                if (ph != 1) wait_for(k + 2, k + 6);   // (phase k + 1 = (.., 3) reads nothing new)
+            } else {
+                load_phase(T, ph);
+                __builtin_amdgcn_sched_barrier(0);
+                issue(k + 6);
+                if (ph != 1) wait_for(k + 2, k + 6);
+                __builtin_amdgcn_sched_barrier(0);
+                mfma_phase(T, ph);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    const int wm0 = 128 * wr, wn0 = 64 * wc;
+    if (P->ksplit > 1) {
+        epilogue_split<4>(P, acc, m0 + wm0, n0 + wn0, lane);
+    } else {
+        __syncthreads();                             // every wave is done with the operand buffers
+        epilogue_rows<4>(P, acc, m0 + wm0, n0 + wn0, lane, smem + wave * (32 * 68));
+    }
+}
+
+template <int CT, int DBG = 0>
+__global__ __launch_bounds__(512, 2)
+void gemm_h16p_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        h16p_tile<CT, DBG>(probs, n_probs, tile, smem);
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 typedef void (*gemm_fn)(const GemmProbDev*, int);
@@ -895,6 +1115,11 @@ static H16dVariant g_h16d[] = {
     H16D_RECT(256, 128, 4, 2, 3),   // 2 (tile code 20): 256 x 128, three stages (two k-tiles in flight), 144 KB
 };
 static int g_h16d_small = 0, g_h16d_big = 1;
+static h16d_fn g_h16p[2] = {gemm_h16p_kernel<GHN3_CT_F16>, gemm_h16p_kernel<GHN3_CT_BF16>};
+static h16d_fn g_h16p_dbg[4] = {nullptr, gemm_h16p_kernel<GHN3_CT_F16, 1>, gemm_h16p_kernel<GHN3_CT_F16, 2>,
+                                gemm_h16p_kernel<GHN3_CT_F16, 3>};
+static int g_pp_dbg = 0;
+static int g_pingpong = 0;      // GHN3_PINGPONG=1: 256 x 256 problems on the ping-pong kernel (measured no faster, see above)
 
 template <int BM, int BN, int AM, int BMD> static size_t f32_lds() {
     return 2 * (size_t)(F32Tile<BM, AM>::SIZE + F32Tile<BN, BMD>::SIZE) * sizeof(float);
@@ -954,6 +1179,14 @@ int ghn3_gemm_init() {
             hipError_t e = hipFuncSetAttribute((const void*)v.fn[ct], hipFuncAttributeMaxDynamicSharedMemorySize, v.lds);
             if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(h16d): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
         }
+    for (int ct = 0; ct < 2; ++ct) {
+        hipError_t e = hipFuncSetAttribute((const void*)g_h16p[ct], hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(h16p): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
+    }
+    if (getenv("GHN3_PINGPONG")) g_pingpong = atoi(getenv("GHN3_PINGPONG"));
+    if (getenv("GHN3_PP_DEBUG")) g_pp_dbg = atoi(getenv("GHN3_PP_DEBUG")) & 3;
+    for (int d = 1; d < 4; ++d)
+        (void)hipFuncSetAttribute((const void*)g_h16p_dbg[d], hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     g_gemm_ready = true;
     return GHN3_OK;
 }
@@ -966,8 +1199,15 @@ int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_til
                        tile);
         return GHN3_E_ARG;
     }
-    const H16dVariant& v = g_h16d[tile == 20 ? 2 : tile == 256 ? g_h16d_big : g_h16d_small];
     const int grid = grid_cap > 0 && grid_cap < total_tiles ? grid_cap : total_tiles;
+    if (tile == 256 && g_pingpong) {
+        hipLaunchKernelGGL(g_pp_dbg ? g_h16p_dbg[g_pp_dbg] : g_h16p[ctype == GHN3_CT_BF16], dim3(grid), dim3(512),
+                           128 * 1024, stream, d_probs, n_probs, total_tiles);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ghn3_set_error("h16p gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
+        return GHN3_OK;
+    }
+    const H16dVariant& v = g_h16d[tile == 20 ? 2 : tile == 256 ? g_h16d_big : g_h16d_small];
     hipLaunchKernelGGL(v.fn[ctype == GHN3_CT_BF16], dim3(grid), dim3(v.threads), v.lds, stream, d_probs, n_probs,
                        total_tiles);
     hipError_t e = hipGetLastError();

@@ -31,14 +31,17 @@ extern "C" int ghn3_abi_version(void) { return GHN3_ABI_VERSION; }
         }                                                                             \
     } while (0)
 
-static const int kStageSlots = 4;
+static const int kStageSlots = 8;
 
 struct ghn3_ctx {
     // ring of staging slots for resolved GEMM problem tables
     GemmProbDev* h_stage[kStageSlots];
     GemmProbDev* d_stage[kStageSlots];
-    hipEvent_t ev[kStageSlots];
+    hipEvent_t ev[kStageSlots];        // the slot's upload has completed (host buffer reusable)
     bool ev_used[kStageSlots];
+    hipEvent_t ev_done[kStageSlots];   // the run that used the slot has been fully enqueued behind this event
+    bool done_used[kStageSlots];
+    hipStream_t copy;                  // problem tables are uploaded here, ahead of the stream that will read them
     size_t cap;            // problems per slot
     int next;
     int ctype;             // compute type for GEMM operands
@@ -65,6 +68,7 @@ static int ctx_reserve(ghn3_ctx* c, size_t n) {
     size_t cap = std::max<size_t>(n, 1024);
     for (int i = 0; i < kStageSlots; ++i) {
         if (c->ev_used[i]) { HIPCHK(hipEventSynchronize(c->ev[i])); c->ev_used[i] = false; }
+        if (c->done_used[i]) { HIPCHK(hipEventSynchronize(c->ev_done[i])); c->done_used[i] = false; }
         if (c->h_stage[i]) HIPCHK(hipHostFree(c->h_stage[i]));
         if (c->d_stage[i]) HIPCHK(hipFree(c->d_stage[i]));
         c->h_stage[i] = nullptr; c->d_stage[i] = nullptr;
@@ -84,7 +88,11 @@ extern "C" int ghn3_ctx_create(ghn3_ctx** out) {
     memset(c, 0, sizeof(*c));
     c->pool = new std::vector<hipEvent_t>();
     c->pool_tag = new std::vector<int>();
-    for (int i = 0; i < kStageSlots; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+    for (int i = 0; i < kStageSlots; ++i) {
+        HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
+    }
+    HIPCHK(hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->pe0));
     HIPCHK(hipEventCreate(&c->pe1));
     {
@@ -115,7 +123,9 @@ extern "C" void ghn3_ctx_destroy(ghn3_ctx* c) {
         if (c->h_stage[i]) hipHostFree(c->h_stage[i]);
         if (c->d_stage[i]) hipFree(c->d_stage[i]);
         hipEventDestroy(c->ev[i]);
+        hipEventDestroy(c->ev_done[i]);
     }
+    hipStreamDestroy(c->copy);
     hipEventDestroy(c->pe0);
     hipEventDestroy(c->pe1);
     hipStreamSynchronize(c->side);
@@ -223,6 +233,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
     for (int k = 0; k < n_ops; ++k)
         if (ops[k].kind == GHN3_OP_GEMM) need += (size_t)ops[k].i[1];
     GemmProbDev* hs = nullptr; GemmProbDev* ds = nullptr;
+    int used_slot = -1;
     if (need > 0) {
         int rc = ctx_reserve(c, need);
         if (rc) return rc;
@@ -350,9 +361,15 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                     }
         }
         if (R.bad) { ghn3_set_error("ghn3_run: a GEMM problem references an absent buffer"); return GHN3_E_ARG; }
-        HIPCHK(hipMemcpyAsync(ds, hs, pos * sizeof(GemmProbDev), hipMemcpyHostToDevice, stream));
-        HIPCHK(hipEventRecord(c->ev[slot], stream));
+        // Upload on the copy stream: stream-ordered behind `stream` the ~100 KB table sat on the critical path of every run
+        // (in 4 KB pieces: ~170 us in front of the backward program).  The copy stream only waits for the kernels of the
+        // run that used this slot last (kStageSlots runs ago); `stream` waits for the copy.
+        if (c->done_used[slot]) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_done[slot], 0));
+        HIPCHK(hipMemcpyAsync(ds, hs, pos * sizeof(GemmProbDev), hipMemcpyHostToDevice, c->copy));
+        HIPCHK(hipEventRecord(c->ev[slot], c->copy));
         c->ev_used[slot] = true;
+        HIPCHK(hipStreamWaitEvent(stream, c->ev[slot], 0));
+        used_slot = slot;
     }
 
     // ---- 2. launch ops in order ------------------------------------------------------------------
@@ -585,8 +602,24 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             c->launches[o.kind] += 1;
         }
     }
-    if (detach && side_dirty) { c->side_pending = true; return GHN3_OK; }   // joined by the next run / ghn3_ctx_side_wait
-    return join();
+    auto mark_done = [&]() -> int {                  // the slot's table may be overwritten once these kernels are done
+        if (used_slot >= 0) {
+            if (side_dirty || c->side_pending) {         // (side-stream kernels read the table too)
+                HIPCHK(hipEventRecord(c->ev_join, c->side));
+                HIPCHK(hipStreamWaitEvent(c->copy, c->ev_join, 0));
+            }
+            HIPCHK(hipEventRecord(c->ev_done[used_slot], main_stream));
+            c->done_used[used_slot] = true;
+        }
+        return GHN3_OK;
+    };
+    if (detach && side_dirty) {                          // joined by the next run / ghn3_ctx_side_wait
+        c->side_pending = true;
+        return mark_done();
+    }
+    int rc_join = join();
+    if (rc_join) return rc_join;
+    return mark_done();
 }
 
 extern "C" int ghn3_ctx_side_wait(ghn3_ctx* c, void* stream) {

@@ -345,6 +345,10 @@ def main():
                                    % (args.model, args.graphs_per_gpu, args.nodes, args.nodes * 1000, n_pred),
                        'ghn_params': int(ghn._flat_numel), 'decoder_rows': int(prog.M),
                        'workspace_bytes': int(prog.ws_bytes),
+                       # every uint8 zero-fill of the run (workspace, scalar buffer, weight shadows): the known store
+                       # size the WRITE_SIZE counter is calibrated against (tools/pmc_traffic.py)
+                       'zero_fill_bytes': int(prog.ws_bytes + prog.scal_bytes +
+                                              (ghn._shadow.numel() if ghn._shadow is not None else 0)),
                        'parallelism': 'dp%d' % world, 'index_mode': ghn.index_mode,
                        'grad_allreduce': (args.grad_allreduce if ddp else None)},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',

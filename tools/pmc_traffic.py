@@ -55,7 +55,8 @@ def main():
         out['fill_launches'] = sum(wc[k] for k in fill)
         if len(sys.argv) > 4:                      # bench line of the WRITE_SIZE run: config.workspace_bytes
             line = [l for l in open(sys.argv[4]).read().splitlines() if l.startswith('{')][-1]
-            ws_bytes = json.loads(line)['config']['workspace_bytes']
+            cfg = json.loads(line)['config']
+            ws_bytes = cfg.get('zero_fill_bytes', cfg['workspace_bytes'])
             out['fill_true_bytes'] = ws_bytes
             write_cal = out['fill_write_size_kib_raw'] * 1024.0 / ws_bytes
     out['write_calibration'] = write_cal

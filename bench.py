@@ -81,6 +81,21 @@ def cpu_baseline(model, sample_nodes, seed, graphs=1):
                          's' if len(times) > 1 else '')}
 
 
+def _loader_worker(task):
+    """Loader worker (separate process, never touches the GPU): one fresh synthetic architecture per step -- graph
+    generation + the host half of GHN3.compile (numpy bookkeeping -> op program), what a DeepNets-1M loader worker
+    would do per batch (deepnets1m.py:84-269)."""
+    nodes, graphs_per_gpu, seed, pcfg = task
+    from ghn3_amd.program import Program
+    from ghn3_amd.synthetic import synthetic_batch
+    gb, nets = synthetic_batch([nodes] * graphs_per_gpu, seed)
+    gb._cat()
+    pcfg = dict(pcfg)
+    cfg = pcfg.pop('cfg')
+    prog = Program(cfg, gb.node_info, gb.host_n_nodes(), gb._node_type_host, gb.max_edge, nets, training=True, **pcfg)
+    return gb, nets, prog
+
+
 def launch_ranks(n):
     """`python bench.py --gpus N` without a launcher: N fresh child processes (one rank per GPU) started BEFORE this
     process initialises the GPU; rank 0's stdout (the JSON line) is relayed.  Never exec()s."""
@@ -139,6 +154,10 @@ def main():
                          '--nproc-per-node %d ... bench.py --gpus %d) or drop RANK/WORLD_SIZE from the environment'
                          % (args.gpus, world, args.gpus, args.gpus))
     import torch.distributed as dist
+    pool = None
+    if world == 1 and not args.no_extras and not args.force_ddp and torch.cuda.device_count() > 0:
+        import multiprocessing as mp                     # loader workers: started before this process touches the GPU
+        pool = mp.get_context('spawn').Pool(int(os.environ.get('GHN3_LOADER_WORKERS', '3')))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the GHN-3 path has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -224,33 +243,27 @@ def main():
                              'graphormer_gflop': g_fl / 1e9, 'decoder_gflop': d_fl / 1e9,
                              'tflops': (g_fl + d_fl) / (fwd_ms * 1e-3) / 1e12,
                              'frac_of_16bit_mfma_peak': (g_fl + d_fl) / (fwd_ms * 1e-3) / 1e12 / 2500.0}
-        # (b) a NEW architecture every step (train_ghn_ddp.py draws one per step): graph generation + host compile on a
-        # producer thread, two plans ahead; the GPU path is the same
-        import queue
-        import threading
-        n_fresh = max(8, min(args.steps, 30))
-        q = queue.Queue(maxsize=2)
-
-        def producer():
-            torch.cuda.set_device(local_rank)
-            for k in range(n_fresh + 2):
-                gbk, netsk = synthetic_batch([args.nodes] * args.graphs_per_gpu, seeds + 7919 * (k + 1))
-                q.put(ghn.compile(netsk, gbk, training=True))
-        th = threading.Thread(target=producer, daemon=True)
-        th.start()
+        # (b) a NEW architecture every step (train_ghn_ddp.py draws one per step): graph generation + the host half of the
+        # compile in loader worker processes (like the reference's DataLoader workers), the device half + the GPU path
+        # in this process
+        n_fresh = max(8, min(args.steps, 40))
+        pcfg = ghn.program_config()
+        tasks = [(args.nodes, args.graphs_per_gpu, seeds + 7919 * (k + 1), pcfg) for k in range(n_fresh + 3)]
+        stream_it = pool.imap(_loader_worker, tasks)       # (ordered; the workers run ahead of the consumer)
         n_fresh_pred = 0
-        for k in range(n_fresh + 2):
-            if k == 2:
+        for k in range(n_fresh + 3):
+            if k == 3:
                 torch.cuda.synchronize()
                 t_f = time.perf_counter()
-            pk = q.get()
-            run_step(ghn, pk, torch.empty(pk.program.out_numel, dtype=torch.float32, device=dev), pk.program.norm_ops(1.0))
-            if k >= 2:
-                n_fresh_pred += sum(p_['numel'] for p_ in pk.program.predicted)
+            gbk, netsk, progk = next(stream_it)
+            pk = ghn.plan(progk, gbk, netsk)
+            run_step(ghn, pk, torch.empty(progk.out_numel, dtype=torch.float32, device=dev), progk.norm_ops(1.0))
+            if k >= 3:
+                n_fresh_pred += sum(p_['numel'] for p_ in progk.predicted)
             del pk
         torch.cuda.synchronize()
         dt_f = time.perf_counter() - t_f
-        th.join()
+        pool.close()
         extras['fresh_graph_ms_per_step'] = 1e3 * dt_f / n_fresh
         extras['fresh_graph_value'] = n_fresh_pred / dt_f
         # (c) the exact-fp32 configuration of the same workload

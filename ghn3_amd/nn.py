@@ -354,9 +354,26 @@ class GHN3(nn.Module):
                        layernorm=self.layernorm, weight_norm=self.weight_norm, decoder_ctype=L.COMPUTE_TYPES[self.compute],
                        decoder_bwd_ctype=L.COMPUTE_TYPES[self.compute_bwd] if self.compute_bwd else None,
                        direct16=self.direct16, side_stream=self.side_stream, graphormer_x3=self.graphormer_x3)
+        return self.plan(prog, graphs, nets)
+
+    def plan(self, prog, graphs, nets):
+        """Device half of compile(): wraps a host-compiled Program (which a loader worker may have built in another
+        process -- it is plain numpy and pickles together with its graphs and networks) into a runnable plan: index
+        blob upload, workspace, graph tensors on the device."""
+        if not graphs.on_device(self.device):
+            graphs.to_device(self.device)
         plan = _Plan(self, prog, graphs.edges, nets)
         plan.graphs = graphs
         return plan
+
+    def program_config(self):
+        """Keyword arguments for ghn3_amd.program.Program that reproduce what compile() would build (loader workers)."""
+        return dict(cfg=dict(hid=self.hid, heads=self.heads, layers=self.layers, num_classes=self.num_classes,
+                             max_shape=self.max_shape),
+                    index_mode=self.index_mode, layernorm=self.layernorm, weight_norm=self.weight_norm,
+                    decoder_ctype=L.COMPUTE_TYPES[self.compute],
+                    decoder_bwd_ctype=L.COMPUTE_TYPES[self.compute_bwd] if self.compute_bwd else None,
+                    direct16=self.direct16, side_stream=self.side_stream, graphormer_x3=self.graphormer_x3)
 
     def _fill_bufs(self, plan, out=None, dout=None, gflat=None):
         prog = plan.program

@@ -132,7 +132,8 @@ class Program:
 
         self.param_groups, self.params_map = bk.map_net_params(node_infos, self.n_nodes, nets, self.max_shape,
                                                                reduce_graph=reduce_graph)
-        vocab = self.vocab = bk.ShapeVocab(self.K, self.max_shape)
+        vocab = bk.ShapeVocab(self.K, self.max_shape)
+        self.vocab_rows = (vocab.n_ch + 1, vocab.n_sp + 1)          # rows of the channel / spatial embedding tables
         total_nodes = sum(self.n_nodes)
         self.shape_idx = vocab.indices(total_nodes, self.params_map, predict_class_layers)
         self.node_types = np.asarray(node_types, dtype=np.int32)
@@ -1703,4 +1704,4 @@ class Program:
                       self.gref('shape_enc.embed_channel.weight'), self.gref('shape_enc.embed_spatial.weight'),
                       self.gref('gnn.0.centrality_embed_in.weight'), self.gref('gnn.0.centrality_embed_out.weight'),
                       self.gref('gnn.0.input_dist_embed.weight'), deg_in, deg_out, dist0),
-                ints=(B, N, C, len(bk.PRIMITIVES_DEEPNETS1M), self.vocab.n_ch + 1, self.vocab.n_sp + 1))
+                ints=(B, N, C, len(bk.PRIMITIVES_DEEPNETS1M), self.vocab_rows[0], self.vocab_rows[1]))

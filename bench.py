@@ -93,7 +93,7 @@ def _loader_worker(task):
     pcfg = dict(pcfg)
     cfg = pcfg.pop('cfg')
     prog = Program(cfg, gb.node_info, gb.host_n_nodes(), gb._node_type_host, gb.max_edge, nets, training=True, **pcfg)
-    return gb, nets, prog
+    return gb, nets, prog.strip()
 
 
 def launch_ranks(n):
@@ -157,7 +157,9 @@ def main():
     pool = None
     if world == 1 and not args.no_extras and not args.force_ddp and torch.cuda.device_count() > 0:
         import multiprocessing as mp                     # loader workers: started before this process touches the GPU
-        pool = mp.get_context('spawn').Pool(int(os.environ.get('GHN3_LOADER_WORKERS', '3')))
+        for var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):
+            os.environ.setdefault(var, '4')              # (inherited by the workers: no 256-thread pools per worker)
+        pool = mp.get_context('spawn').Pool(int(os.environ.get('GHN3_LOADER_WORKERS', '8')))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the GHN-3 path has no CPU fallback')
     torch.cuda.set_device(local_rank)
@@ -250,20 +252,39 @@ def main():
         pcfg = ghn.program_config()
         tasks = [(args.nodes, args.graphs_per_gpu, seeds + 7919 * (k + 1), pcfg) for k in range(n_fresh + 3)]
         stream_it = pool.imap(_loader_worker, tasks)       # (ordered; the workers run ahead of the consumer)
+        import queue
+        import threading
+        ready = queue.Queue(maxsize=3)
+
+        def prefetch():                                    # waits for the workers + device half of the compile
+            torch.cuda.set_device(local_rank)
+            for _ in range(n_fresh + 3):
+                gbk, netsk, progk = next(stream_it)
+                ready.put(ghn.plan(progk, gbk, netsk))
+        th = threading.Thread(target=prefetch, daemon=True)
+        th.start()
         n_fresh_pred = 0
+        t_wait = t_enq = 0.0
         for k in range(n_fresh + 3):
             if k == 3:
                 torch.cuda.synchronize()
                 t_f = time.perf_counter()
-            gbk, netsk, progk = next(stream_it)
-            pk = ghn.plan(progk, gbk, netsk)
+                t_wait = t_enq = 0.0
+            h0 = time.perf_counter()
+            pk = ready.get()
+            h1 = time.perf_counter()
+            progk = pk.program
             run_step(ghn, pk, torch.empty(progk.out_numel, dtype=torch.float32, device=dev), progk.norm_ops(1.0))
+            h2 = time.perf_counter()
+            t_wait, t_enq = t_wait + h1 - h0, t_enq + h2 - h1
             if k >= 3:
                 n_fresh_pred += sum(p_['numel'] for p_ in progk.predicted)
             del pk
         torch.cuda.synchronize()
         dt_f = time.perf_counter() - t_f
+        th.join()
         pool.close()
+        extras['fresh_graph_host_ms'] = {'wait_for_plan': 1e3 * t_wait / n_fresh, 'enqueue': 1e3 * t_enq / n_fresh}
         extras['fresh_graph_ms_per_step'] = 1e3 * dt_f / n_fresh
         extras['fresh_graph_value'] = n_fresh_pred / dt_f
         # (c) the exact-fp32 configuration of the same workload

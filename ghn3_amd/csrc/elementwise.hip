@@ -157,24 +157,45 @@ __global__ __launch_bounds__(256) void embed_bwd_kernel(
         any |= f;
     }
     if (!__syncthreads_or(any)) return;               // nobody indexes this row: its (zero-initialised) gradient stays
-    // pass 2: the matching gradient rows, summed in node order (only the set bits are visited)
+    // pass 2: the matching gradient rows, summed in node order.  Thread 0 expands the ballot words into an ordered list
+    // (row | block flags << 24); everybody then walks it eight entries at a time with all loads of a group in flight (a
+    // hot row -- the `conv` type, degree 1 -- matches >100 nodes: one dependent round trip per node was 118 us).
+    int* lst = reinterpret_cast<int*>(emb_mask + 2 * words);
+    __shared__ int n_match;
+    if (threadIdx.x == 0) {
+        int n = 0;
+        for (int w = 0; w < words; ++w) {
+            const unsigned long long m0 = emb_mask[w], m1 = emb_mask[words + w];
+            unsigned long long m = m0 | m1;
+            while (m) {
+                const int bit = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                lst[n++] = (w * 64 + bit) | ((int)((m0 >> bit) & 1) << 24) | ((int)((m1 >> bit) & 1) << 25);
+            }
+        }
+        n_match = n;
+    }
+    __syncthreads();
+    const int n = n_match;
     float acc[2] = {0.f, 0.f};                         // columns threadIdx.x and threadIdx.x + 256 (C <= 512)
-    for (int w = 0; w < words; ++w) {
-        unsigned long long m0 = emb_mask[w], m1 = emb_mask[words + w];
-        unsigned long long m = m0 | m1;
-        while (m) {                                    // (uniform over the workgroup)
-            const int bit = __ffsll((long long)m) - 1;
-            m &= m - 1;
-            const float* g = dx + (size_t)(w * 64 + bit) * C;
+    for (int i0 = 0; i0 < n; i0 += 8) {
+        float v0[8][2], v1[8][2];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int ent = i0 + e < n ? lst[i0 + e] : 0;
+            const float* g = dx + (size_t)(ent & 0xffffff) * C;
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 const int c = threadIdx.x + 256 * k;
-                if (c < width) {
-                    if ((m0 >> bit) & 1) acc[k] += g[base0 + c];
-                    if ((m1 >> bit) & 1) acc[k] += g[base1 + c];
-                }
+                const bool in = i0 + e < n && c < width;
+                v0[e][k] = (in && (ent & (1 << 24))) ? g[base0 + c] : 0.f;
+                v1[e][k] = (in && (ent & (1 << 25))) ? g[base1 + c] : 0.f;
             }
         }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+#pragma unroll
+            for (int k = 0; k < 2; ++k) { acc[k] += v0[e][k]; acc[k] += v1[e][k]; }
     }
     float* dst = tab == 0 ? dE_type : tab == 1 ? dE_ch : tab == 2 ? dE_sp : tab == 3 ? dE_in : tab == 4 ? dE_out : dE_dist;
 #pragma unroll
@@ -192,9 +213,9 @@ int ghn3_embed_bwd(const float* dx, const int* node_type, const int* shape_idx, 
         ghn3_set_error("embed_bwd: C <= 512 and the table row counts (i3..i5) are required");
         return GHN3_E_ARG;
     }
-    if (B * N > 64 * 1024) { ghn3_set_error("embed_bwd: more than 65536 dense node rows"); return GHN3_E_LIMIT; }
+    if (B * N > 12 * 1024) { ghn3_set_error("embed_bwd: more than 12288 dense node rows"); return GHN3_E_LIMIT; }
     const int blocks = n_type + n_ch + n_sp + 101 + 101 + 1001;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), (size_t)(16 * ((B * N + 63) / 64)), s, dx, node_type, shape_idx, n_nodes,
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(blocks), dim3(256), (size_t)(16 * ((B * N + 63) / 64) + 4 * (size_t)B * N + 16), s, dx, node_type, shape_idx, n_nodes,
                        node_off, dE_type, dE_ch, dE_sp, dE_in, dE_out, dE_dist, deg_in, deg_out, dist0, B, N, C, n_type,
                        n_ch, n_sp);
     return launch_ok("embed_bwd");

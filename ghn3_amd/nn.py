@@ -316,7 +316,7 @@ class GHN3(nn.Module):
             self._shadow = torch.zeros(nbytes, dtype=torch.uint8, device=self.device)
         plan.bufs[prog.xbuf(prog.X_SHADOW)] = self._shadow.data_ptr()
         ver = self._shadow_version()
-        types = (prog.decoder_ctype, prog.decoder_bwd_ctype, prog.x3, any(g['op16'] for g in prog.gemm_groups))
+        types = (prog.decoder_ctype, prog.decoder_bwd_ctype, prog.x3, prog.uses_op16)
         st = self._shadow_state
         if st is not None and st[0] == ver and st[2] == types and (st[1] or not prog.training):
             return

@@ -189,6 +189,19 @@ class Program:
             self.idx_blob[off:off + len(raw)] = raw
         self.n_bufs = 2 * self.P + self.X_COUNT
 
+    def strip(self):
+        """Drops the builder-only state (problem tuples, index chunks, group dictionaries): what remains is what a plan
+        needs at run time.  A loader worker calls it before sending the program to the training process (the pickle
+        shrinks from 4.5 MB / ~60k objects to the packed arrays)."""
+        for name in ('_probs', '_ops', '_ln', '_idx_chunks', 'conv_groups', 'gemm_groups', 'param_groups', 'params_map',
+                     'wgrad_bands', 'd1', 'row_src', 'row_pos', 'oned_src', 'oned_index', 'oned_plain', 'oned_clsb',
+                     'shape_idx', 'node_types', 'shadow_lay'):
+            if hasattr(self, name):
+                setattr(self, name, None)
+        for p_ in self.predicted:
+            p_.pop('tok', None)
+        return self
+
     # ------------------------------------------------------------------ small helpers
     def xbuf(self, which):
         return 2 * self.P + which
@@ -594,7 +607,7 @@ class Program:
         C, ms = self.C, self.max_shape
         for g in self.gemm_groups:
             g['op16'] = self.direct16 and g['i_ld'] % 8 == 0
-        op16 = any(g['op16'] for g in self.gemm_groups)
+        op16 = self.uses_op16 = any(g['op16'] for g in self.gemm_groups)
         self.uses_shadow = op16 or self.x3
         if not self.uses_shadow:
             return

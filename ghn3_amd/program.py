@@ -1477,7 +1477,10 @@ class Program:
                                   self.gref(W2, (o_lo * ms[1] + b_['i_lo']) * 8 * C), (o_hi - o_lo) * b_['bw'], 8 * C,
                                   kpre, b_['ktot'], b_['ktot'], 8 * C, c_qs=(b_['bw'], ms[1]), op16=True,
                                   alpha_amax=amax_t)
-                self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=True, flops=fl)
+                # on the side stream the launch is capped at 3/4 of the CUs (persistent workgroups stride over the
+                # tiles): the dependent chain on the main stream keeps CUs of its own (8.65 -> 8.43 ms per step)
+                self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=True, flops=fl,
+                             grid_cap=int(os.environ.get('GHN3_WGRAD_CAP', '192')) if self.SIDE else 0)
             fam_list = bands
             for gi, g in enumerate(self.gemm_groups):
                 if g['op16']:

@@ -1199,6 +1199,8 @@ int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_til
                        tile);
         return GHN3_E_ARG;
     }
+    // grid_cap counts CUs' worth of workgroups: the 128 x 128 variant runs two workgroups per CU
+    if (tile == 128) grid_cap *= 2;
     const int grid = grid_cap > 0 && grid_cap < total_tiles ? grid_cap : total_tiles;
     if (tile == 256 && g_pingpong) {
         hipLaunchKernelGGL(g_pp_dbg ? g_h16p_dbg[g_pp_dbg] : g_h16p[ctype == GHN3_CT_BF16], dim3(grid), dim3(512),

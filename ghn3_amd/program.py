@@ -1477,10 +1477,11 @@ class Program:
                                   self.gref(W2, (o_lo * ms[1] + b_['i_lo']) * 8 * C), (o_hi - o_lo) * b_['bw'], 8 * C,
                                   kpre, b_['ktot'], b_['ktot'], 8 * C, c_qs=(b_['bw'], ms[1]), op16=True,
                                   alpha_amax=amax_t)
-                # on the side stream the launch is capped at 3/4 of the CUs (persistent workgroups stride over the
-                # tiles): the dependent chain on the main stream keeps CUs of its own (8.65 -> 8.43 ms per step)
+                # GHN3_WGRAD_CAP=n: the side-stream launch as n CUs' worth of persistent workgroups, so that the dependent
+                # chain on the main stream keeps CUs of its own.  Measured at n = 192: the step 8.65 -> 8.54 ms, but the
+                # weight gradient itself 1.46 -> 1.72 ms (the family's roofline fraction drops); off by default.
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=True, flops=fl,
-                             grid_cap=int(os.environ.get('GHN3_WGRAD_CAP', '192')) if self.SIDE else 0)
+                             grid_cap=int(os.environ.get('GHN3_WGRAD_CAP', '0')) if self.SIDE else 0)
             fam_list = bands
             for gi, g in enumerate(self.gemm_groups):
                 if g['op16']:
@@ -1600,6 +1601,10 @@ class Program:
         # ---- Graphormer layers, reversed ----------------------------------------------------------------
         bias = self.wref('bias')
         pending_ln1 = None                  # (dy buffer, prologue refs) of the LayerNorm backward fused into the next GEMM
+        # Side-stream ops of `side_group` consecutive layers are issued together: every main -> side hand-off is an event
+        # record that stalls the main chain for 6-12 us, and the temporaries the side ops read are per layer anyway.
+        side_group = max(1, int(os.environ.get('GHN3_SIDE_GROUP', '4'))) if self.SIDE else 1
+        side_pending = []
         for l in reversed(range(self.Lyr)):
             pre = 'gnn.%d.' % l
             sfx = '_%d' % l
@@ -1680,6 +1685,7 @@ class Program:
             # stream is on): every main -> side hand-off is an event record that costs the main chain ~6 us, so the
             # LayerNorm parameter gradients (which read dhA / dhB after the LayerNorm backward has added the K-half
             # planes) and the weight gradients share one.
+            main_ops, self._ops = self._ops, []
             self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln2.weight'), self.gref(pre + 'ln2.bias'), dhA, xmid,
                                               m2, r2), ints=(rows, C, 1), flags=self.SIDE)
             # weight gradients of the layer, one launch
@@ -1694,6 +1700,10 @@ class Program:
             self.gemm_op(p0, side=True)
             self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln1.weight'), self.gref(pre + 'ln1.bias'), dhB, x_in,
                                               m1, r1), ints=(rows, C, 1), flags=self.SIDE)
+            side_pending, self._ops = side_pending + self._ops, main_ops
+            if (self.Lyr - l) % side_group == 0 or l == 0:
+                self._ops.extend(side_pending)
+                side_pending = []
             g_cur = g_out                   # d x_l
         # ---- layer-0 edge bias: histogram -> table MLP backward ------------------------------------------
         E = 'gnn.0.attn.edge_embed.embed.weight'

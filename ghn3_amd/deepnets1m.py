@@ -1,0 +1,132 @@
+"""
+Training architectures for the GHN (role of /root/reference/ghn3/deepnets1m.py:29-319).
+
+The reference trains on DeepNets-1M: one million architectures stored as (genotype, network arguments) in a json meta
+file with their precomputed computational graphs in an hdf5 file, served by ``DeepNets1MDDP.loader`` as ``GraphBatch``
+objects that carry a ``NetworkLight`` per graph.  Neither the files nor ``h5py`` exist in this image, so this module
+draws architectures from the same search space instead (same op vocabulary, cell structure and argument ranges; the
+exact sampling frequencies of the DeepNets-1M generator are NOT reproduced) and builds their graphs with
+``ghn3_amd.Graph(model)`` -- which is what generated the graphs of DeepNets-1M in the first place:
+
+    queue = SampledNets.loader(meta_batch_size=8, num_nets=10 ** 6, large_images=False, seed=0)
+    for graphs in queue:                      # GraphBatch: .nets = [NetworkLight], dense tensors for GHN3.forward
+        trainer.update(images, targets, graphs=graphs)
+
+Every architecture is a pure function of (seed, index): all ranks of a data-parallel job can address the same virtual
+dataset and take disjoint slices of each meta-batch (``rank`` / ``world_size``), like the reference's
+DistributedSampler (deepnets1m.py:289).
+"""
+
+import numpy as np
+import torch
+
+from . import ops
+from .graph import Graph, GraphBatch
+
+# op vocabulary of the DeepNets-1M generator (ppuda genotypes): name -> available kernel sizes
+_SIZED = {'sep_conv': (3, 5, 7), 'dil_conv': (3, 5), 'conv': (1, 3, 5, 7), 'max_pool': (3,), 'avg_pool': (3,)}
+_PLAIN = ('skip_connect', 'cse', 'none')
+
+
+def _op_name(rng, vit):
+    kinds = list(_SIZED) + list(_PLAIN) + (['msa'] if vit else []) + ['conv2']
+    kind = kinds[rng.randint(len(kinds))]
+    if kind == 'conv2':
+        return 'conv_7x1_1x7'
+    if kind in _SIZED:
+        k = _SIZED[kind][rng.randint(len(_SIZED[kind]))]
+        return '%s_%dx%d' % (kind, k, k)
+    return kind
+
+
+def sample_genotype(rng, vit=False, max_steps=4):
+    """A random cell pair: `steps` intermediate states, two (op, input) pairs each; inputs are earlier states."""
+    def cell(steps):
+        pairs = []
+        for s in range(steps):
+            for _ in range(2):
+                pairs.append((_op_name(rng, vit), int(rng.randint(s + 2))))
+            if all(p[0] == 'none' for p in pairs[-2:]):      # keep every state alive
+                pairs[-1] = ('skip_connect', pairs[-1][1])
+        used = {i for name, i in pairs if name != 'none'}     # a state read by 'none' only still has to reach the output
+        concat = [k for k in range(2, steps + 2) if k not in used] or [steps + 1]
+        return pairs, concat
+    steps = int(rng.randint(1, max_steps + 1))
+    normal, n_cat = cell(steps)
+    reduce, r_cat = cell(steps)
+    if len(r_cat) != len(n_cat):                             # (the channel bookkeeping assumes equal multipliers)
+        reduce, r_cat = normal, n_cat
+    return ops.Genotype(normal=normal, normal_concat=n_cat, reduce=reduce, reduce_concat=r_cat)
+
+
+def sample_net_args(rng, large_images=False):
+    """Network keyword arguments in the ranges the DeepNets-1M loader uses (deepnets1m.py:96-143)."""
+    vit = rng.rand() < 0.1
+    genotype = sample_genotype(rng, vit=vit, max_steps=1 if vit else 4)
+    steps = len(genotype.normal_concat)
+    preproc = True if (steps > 1) else bool(rng.rand() < 0.5)
+    n_cells = int(rng.randint(3, 10)) if not vit else int(rng.randint(3, 7))
+    args = dict(genotype=genotype, n_cells=n_cells, C=int(rng.choice([32, 48, 64] if not vit else [32, 64, 128])),
+                ks=int(rng.choice([3, 5, 7])), norm='bn', preproc=preproc, C_mult=2 if preproc else 1,
+                stem_type=int(rng.randint(2)) if not vit else 0, stem_pool=bool(rng.rand() < 0.5),
+                glob_avg=True, fc_layers=int(rng.randint(1, 3)), fc_dim=int(rng.choice([64, 128, 256])),
+                imagenet_stride=4)
+    if vit:
+        args.update(preproc=False, C_mult=1, stem_pool=False)
+    args['is_imagenet_input'] = bool(large_images)
+    args['num_classes'] = 1000 if large_images else 10
+    return args
+
+
+class SampledNets:
+    """A virtual dataset of architectures: ``self[i]`` is a Graph with ``.net`` (a NetworkLight) and ``.net_args``."""
+
+    def __init__(self, num_nets=10 ** 6, large_images=False, seed=0, virtual_edges=50, max_nodes=1000, light=True,
+                 verbose=False):
+        self.num_nets, self.large_images, self.seed = int(num_nets), large_images, int(seed)
+        self.virtual_edges, self.max_nodes, self.light, self.verbose = virtual_edges, max_nodes, light, verbose
+
+    def __len__(self):
+        return self.num_nets
+
+    def __getitem__(self, idx):
+        idx = int(idx) % self.num_nets
+        for attempt in range(64):
+            rng = np.random.RandomState((self.seed * 1000003 + idx * 64 + attempt) % (2 ** 31 - 1))
+            args = sample_net_args(rng, self.large_images)
+            try:
+                model = ops.Network(**args)
+                graph = Graph(model, ve_cutoff=self.virtual_edges, verbose=False)
+            except Exception as e:                            # an invalid draw (e.g. a state of shape zero): redraw
+                if self.verbose:
+                    print('SampledNets: redraw %d/%d (%s)' % (idx, attempt, repr(e)[:80]))
+                continue
+            if graph.n_nodes > self.max_nodes:
+                continue
+            # every parameter must be reachable from the output (a cell that ignores one of its inputs leaves the
+            # preprocessing layer of that input outside the graph: the GHN would predict nothing for it)
+            in_graph = {n[1] for cell in graph.node_info for n in cell}
+            table = [k for cell in model._layered_modules for k in cell]
+            if any(k not in in_graph and k.replace('.bias', '.weight') not in in_graph for k in table):
+                continue
+            out = Graph(node_feat=graph.node_feat, node_info=graph.node_info, A=graph._Adj, net_args=args, net_idx=idx)
+            out.net = ops.NetworkLight(**args) if self.light else model
+            return out
+        raise RuntimeError('no valid architecture for index %d' % idx)
+
+    @staticmethod
+    def loader(meta_batch_size=1, dense=True, rank=0, world_size=1, start_step=0, **kwargs):
+        """Endless iterator of GraphBatch objects (``DeepNets1MDDP.loader`` of deepnets1m.py:271-319): step s of rank r
+        holds the architectures s * meta_batch_size + [r * m, (r + 1) * m) with m = meta_batch_size / world_size."""
+        assert dense, 'GHN-3 uses the dense layout'
+        assert meta_batch_size % world_size == 0, (meta_batch_size, world_size)
+        nets = SampledNets(**kwargs)
+        per_rank = meta_batch_size // world_size
+
+        def generate():
+            step = int(start_step)
+            while True:
+                base = step * meta_batch_size + rank * per_rank
+                yield GraphBatch([nets[base + k] for k in range(per_rank)], dense=True)
+                step += 1
+        return generate()

@@ -5,8 +5,8 @@ Mirrors the interface of /root/reference/ghn3/graph.py:38-352 for the dense (Gra
 ``Graph(node_feat=, node_info=, A=, dense=True)`` and ``GraphBatch(graphs, dense=True)`` with
 ``to_device / on_device / to_dense / to_sparse / __len__ / __getitem__ / __iter__`` and the fields
 ``node_feat (B,N,1) int64, edges (B,N,N) int64, mask (B,N,1) bool, n_nodes (B,) int64, node_info, net_args,
-nets``.  Building a graph from an arbitrary ``nn.Module`` (graph.py:392-908: autograd walk + virtual edges)
-is the "next" row f1 of SURVEY 8 and is not part of this package yet.
+nets``.  ``Graph(model)`` builds the graph of an arbitrary ``nn.Module`` (graph.py:392-908: autograd walk, pruning,
+virtual edges) through ``ghn3_amd.graph_build``.
 """
 
 import numpy as np

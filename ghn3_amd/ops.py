@@ -1,0 +1,548 @@
+"""
+Target networks of the DeepNets-1M search space, in two flavours (behaviour of
+/root/reference/ghn3/ops.py:143-585):
+
+  * ``Network``      -- ``torch.nn`` layers with their own parameters (evaluation, graph construction);
+  * ``NetworkLight`` -- the light layers of ``ghn3_amd.light_ops``: shapes only, until ``GHN3.forward`` assigns the
+    predicted tensors (the networks ``train_ghn_ddp.py`` runs on images every step, trainer.py:308-319).
+
+A network is a stem, ``n_cells`` DARTS-style cells built from a ``Genotype`` (pairs of (op name, input index) per
+step, concatenation of the listed states) and a classifier.  Every definition below is written once as a plain class
+whose layers come from ``self.L`` (the layer namespace of the flavour); ``_flavours`` derives the two concrete classes
+at module level, so light networks pickle like any object (DataLoader workers, the loader pool of ``bench.py``).
+
+The helpers the reference imports from the third-party ``ppuda`` package (absent from /root/reference: genotype
+tuple, ``parse_op_ks``, ``drop_path``, ``_is_none``, auxiliary heads) are restated here from that package's published
+behaviour -- parity for them is unpinned, see DESIGN.md 8.
+"""
+
+import sys
+from collections import namedtuple
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import light_ops
+from .bookkeeping import named_layered_modules
+
+Genotype = namedtuple('Genotype', 'normal normal_concat reduce reduce_concat')
+
+
+def from_dict(d):
+    """Genotype from the json form of the DeepNets-1M meta files ({'normal': [[op, idx], ...], ...})."""
+    return Genotype(normal=[tuple(p) for p in d['normal']], normal_concat=list(d['normal_concat']),
+                    reduce=[tuple(p) for p in d['reduce']], reduce_concat=list(d['reduce_concat']))
+
+
+def parse_op_ks(op):
+    """'sep_conv_5x5' -> ('sep_conv', 5); 'conv_7x1_1x7' -> ('conv2', 7); names without a size keep ks = 3."""
+    parts = op.split('_')
+    sizes = [p for p in parts if 'x' in p and p.replace('x', '').isdigit()]
+    if not sizes:
+        return op, 3
+    name = '_'.join(p for p in parts if p not in sizes)
+    if len(sizes) == 2:
+        return name + '2', max(int(v) for v in sizes[0].split('x'))
+    return name, int(sizes[0].split('x')[0])
+
+
+def drop_path(x, drop_prob):
+    """Per-sample stochastic depth: zero the branch with probability drop_prob, rescale the survivors."""
+    if drop_prob > 0.:
+        keep = 1. - drop_prob
+        mask = torch.empty(x.size(0), 1, 1, 1, device=x.device, dtype=x.dtype).bernoulli_(keep)
+        x = x / keep * mask
+    return x
+
+
+def _is_none(mod):
+    """True when a layer below ``mod`` has no weight (the GHN was told not to predict it): the op is skipped."""
+    if mod is None:
+        return True
+    if not hasattr(mod, 'named_modules'):
+        return False
+    for _, m in mod.named_modules():
+        if hasattr(m, 'weight') and m.weight is None:
+            return True
+    return False
+
+
+class _TorchLayers:
+    """Layer namespace of the ``torch.nn`` flavour."""
+    light = False
+    Module = ModuleEmpty = nn.Module
+    for _n in ('ModuleList', 'Sequential', 'Dropout', 'Identity', 'Linear', 'Conv2d', 'BatchNorm2d', 'LayerNorm',
+               'AvgPool2d', 'MaxPool2d', 'AdaptiveAvgPool2d', 'ReLU', 'GELU', 'Hardswish'):
+        locals()[_n] = getattr(nn, _n)
+    del _n
+
+
+class _LightLayers:
+    """Layer namespace of the light flavour."""
+    light = True
+    for _n in light_ops.__all__:
+        locals()[_n] = getattr(light_ops, _n)
+    del _n
+
+
+def bn_layer(Lyr, norm, C):
+    if norm in (None, '', 'none'):
+        return Lyr.Identity()
+    if norm.startswith('bn'):
+        return Lyr.BatchNorm2d(C, track_running_stats=norm.find('track') >= 0)
+    raise NotImplementedError(norm)
+
+
+# ======================================================================================================
+# definitions (flavour-free): `self.L` is the layer namespace, `self.T` the table of sibling classes
+# ======================================================================================================
+class _Stride:
+    _base = 'ModuleEmpty'
+
+    def __init__(self, stride):
+        super().__init__()
+        self.stride = stride
+
+    def forward(self, x):
+        return x if self.stride == 1 else x[:, :, ::self.stride, ::self.stride]
+
+
+class _Zero:
+    _base = 'ModuleEmpty'
+
+    def __init__(self, stride):
+        super().__init__()
+        self.stride = stride
+
+    def forward(self, x):
+        return (x if self.stride == 1 else x[:, :, ::self.stride, ::self.stride]).mul(0.)
+
+
+class _FactorizedReduce:
+    """Two 1x1 convolutions of stride 2 on the even and the odd pixel grid, concatenated (ops.py:163-178)."""
+
+    def __init__(self, C_in, C_out, norm='bn', stride=2):
+        super().__init__()
+        assert C_out % 2 == 0
+        Lyr = self.L
+        self.stride = stride
+        self.relu = Lyr.ReLU(inplace=False)
+        self.conv_1 = Lyr.Conv2d(C_in, C_out // 2, 1, stride=stride, padding=0, bias=False)
+        self.conv_2 = Lyr.Conv2d(C_in, C_out // 2, 1, stride=stride, padding=0, bias=False)
+        self.bn = bn_layer(Lyr, norm, C_out)
+
+    def forward(self, x):
+        x = self.relu(x)
+        shifted = x[:, :, 1:, 1:] if self.stride > 1 else x
+        return self.bn(torch.cat([self.conv_1(x), self.conv_2(shifted)], dim=1))
+
+
+class _ReLUConvBN:
+    """ReLU - conv (or a 1 x ks, ks x 1 pair) - norm (ops.py:180-198)."""
+
+    def __init__(self, C_in, C_out, ks=1, stride=1, padding=0, norm='bn', double=False):
+        super().__init__()
+        Lyr = self.L
+        self.stride = stride
+        if double:
+            convs = [Lyr.Conv2d(C_in, C_in, (1, ks), stride=(1, stride), padding=(0, padding), bias=False),
+                     Lyr.Conv2d(C_in, C_out, (ks, 1), stride=(stride, 1), padding=(padding, 0), bias=False)]
+        else:
+            convs = [Lyr.Conv2d(C_in, C_out, ks, stride=stride, padding=padding, bias=False)]
+        self.op = Lyr.Sequential(Lyr.ReLU(inplace=False), *convs, bn_layer(Lyr, norm, C_out))
+
+    def forward(self, x):
+        return self.op(x)
+
+
+class _DilConv:
+    """ReLU - dilated depthwise conv - 1x1 conv - norm (ops.py:200-216)."""
+
+    def __init__(self, C_in, C_out, ks, stride, padding, dilation, norm='bn'):
+        super().__init__()
+        Lyr = self.L
+        self.stride = stride
+        self.op = Lyr.Sequential(
+            Lyr.ReLU(inplace=False),
+            Lyr.Conv2d(C_in, C_in, kernel_size=ks, stride=stride, padding=padding, dilation=dilation, groups=C_in,
+                       bias=False),
+            Lyr.Conv2d(C_in, C_out, kernel_size=1, padding=0, bias=False),
+            bn_layer(Lyr, norm, C_out))
+
+    def forward(self, x):
+        return self.op(x)
+
+
+class _SepConv:
+    """Two (ReLU - depthwise conv - 1x1 conv - norm) blocks, the stride in the first (ops.py:218-237)."""
+
+    def __init__(self, C_in, C_out, ks, stride, padding, norm='bn'):
+        super().__init__()
+        Lyr = self.L
+        self.stride = stride
+
+        def block(c_out, s):
+            return [Lyr.ReLU(inplace=False),
+                    Lyr.Conv2d(C_in, C_in, kernel_size=ks, stride=s, padding=padding, groups=C_in, bias=False),
+                    Lyr.Conv2d(C_in, c_out, kernel_size=1, padding=0, bias=False),
+                    bn_layer(Lyr, norm, c_out)]
+        self.op = Lyr.Sequential(*block(C_in, stride), *block(C_out, 1))
+
+    def forward(self, x):
+        return self.op(x)
+
+
+class _ChannelSELayer:
+    """Squeeze-and-excitation with a hard-swish gate (ops.py:239-274)."""
+
+    def __init__(self, num_channels, reduction_ratio=2, dim_out=None, stride=1):
+        super().__init__()
+        if dim_out is not None:
+            assert dim_out == num_channels, (dim_out, num_channels, 'only same dimensionality is supported')
+        Lyr = self.L
+        self.reduction_ratio, self.stride = reduction_ratio, stride
+        self.fc1 = Lyr.Linear(num_channels, num_channels // reduction_ratio, bias=True)
+        self.fc2 = Lyr.Linear(num_channels // reduction_ratio, num_channels, bias=True)
+        self.relu = Lyr.ReLU(inplace=True)
+        self.sigmoid = Lyr.Hardswish()
+
+    def forward(self, x):
+        b, c = x.shape[:2]
+        squeeze = x.reshape(b, c, -1).mean(dim=2)
+        gate = self.sigmoid(self.fc2(self.relu(self.fc1(squeeze))))
+        y = torch.mul(x, gate.view(b, c, 1, 1))
+        return y[:, :, ::self.stride, ::self.stride] if self.stride > 1 else y
+
+
+class _PosEnc:
+    """Learned positional encoding added to the patch grid (ops.py:278-291)."""
+
+    def __init__(self, C, ks):
+        super().__init__()
+        self.weight = [1, C, ks, ks] if self.L.light else nn.Parameter(torch.randn(1, C, ks, ks))
+
+    def forward(self, x):
+        return x + self.weight
+
+
+class _FeedForward:
+    """graphormer.py:22-48."""
+
+    def __init__(self, in_features, hidden_features=None, out_features=None, act_layer=None, drop=0):
+        super().__init__()
+        Lyr = self.L
+        act_layer = act_layer or Lyr.GELU
+        out_features = out_features or in_features
+        hidden_features = hidden_features or in_features
+
+        def dropout():
+            return Lyr.Dropout(drop) if drop > 0 else Lyr.Identity()
+        self.net = Lyr.Sequential(Lyr.Linear(in_features, hidden_features), act_layer(), dropout(),
+                                  Lyr.Linear(hidden_features, out_features), dropout())
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class _MultiHeadSelfAttention:
+    """graphormer.py:66-142 without the edge branch (edge_dim = 0: target networks have no graph)."""
+
+    def __init__(self, dim, num_heads=8, qkv_bias=False, attn_drop=0., proj_drop=0.):
+        super().__init__()
+        Lyr = self.L
+        self.num_heads, self.dim, self.edge_dim = num_heads, dim, 0
+        self.scale = (dim // num_heads) ** -0.5
+        self.to_qkv = Lyr.Linear(dim, dim * 3, bias=qkv_bias)
+        self.attn_drop = Lyr.Dropout(attn_drop) if attn_drop > 0 else Lyr.Identity()
+        self.to_out = Lyr.Sequential(Lyr.Linear(dim, dim), Lyr.Dropout(proj_drop) if proj_drop > 0 else Lyr.Identity())
+
+    def forward(self, x, edges=None, mask=None):
+        B, N, C = x.shape
+        q, k, v = self.to_qkv(x).reshape(B, N, 3, self.num_heads, C // self.num_heads).permute(2, 0, 3, 1, 4).unbind(0)
+        attn = (q @ k.transpose(-2, -1)) * self.scale
+        if edges is not None:
+            attn = attn + edges.permute(0, 3, 1, 2)
+        if mask is not None:
+            attn = attn.masked_fill(~mask.unsqueeze(1), -2 ** 15)
+        attn = self.attn_drop(attn.softmax(dim=-1))
+        return self.to_out((attn @ v).transpose(1, 2).reshape(B, N, C)), edges
+
+
+class _TransformerLayer:
+    """Pre-LN transformer layer on a (B, C, H, W) feature map, the 'msa' op (graphormer.py:144-248 with edge_dim = 0)."""
+
+    def __init__(self, dim, num_heads=8, mlp_ratio=1, qkv_bias=False, act_layer=None, eps=1e-5, stride=1):
+        super().__init__()
+        Lyr, T = self.L, self.T
+        self.stride, self.edge_dim, self.return_edges = stride, 0, False
+        self.ln1 = Lyr.LayerNorm(dim, eps=eps)
+        self.attn = T['MultiHeadSelfAttention'](dim, num_heads=num_heads, qkv_bias=qkv_bias)
+        self.ln2 = Lyr.LayerNorm(dim, eps=eps)
+        self.ff = T['FeedForward'](in_features=dim, hidden_features=int(dim * mlp_ratio), act_layer=act_layer)
+
+    def forward(self, x, edges=None, mask=None):
+        sz = x.shape
+        if len(sz) == 2:
+            x = x.unsqueeze(0)
+        elif len(sz) == 4:
+            x = x.reshape(sz[0], sz[1], -1).permute(0, 2, 1)
+        assert x.dim() == 3, x.shape
+        x = x + self.attn(self.ln1(x), edges, mask)[0]
+        x = x + self.ff(self.ln2(x))
+        if len(sz) == 4:
+            x = x.permute(0, 2, 1).view(sz[0], x.shape[2], sz[2], sz[3])
+            if self.stride > 1:
+                x = x[:, :, ::self.stride, ::self.stride]
+        return x
+
+
+class _AuxiliaryHeadCIFAR:
+    """DARTS auxiliary classifier on the 2/3-depth feature map (8 x 8 input assumed)."""
+
+    def __init__(self, C, num_classes, norm='bn', pool_sz=5):
+        super().__init__()
+        Lyr = self.L
+        self.features = Lyr.Sequential(
+            Lyr.ReLU(inplace=True), Lyr.AvgPool2d(pool_sz, stride=3, padding=0, count_include_pad=False),
+            Lyr.Conv2d(C, 128, 1, bias=False), bn_layer(Lyr, norm, 128), Lyr.ReLU(inplace=True),
+            Lyr.Conv2d(128, 768, 2, bias=False), bn_layer(Lyr, norm, 768), Lyr.ReLU(inplace=True))
+        self.classifier = Lyr.Linear(768, num_classes)
+
+    def forward(self, x):
+        x = self.features(x)
+        return self.classifier(x.view(x.size(0), -1))
+
+
+class _AuxiliaryHeadImageNet:
+    """DARTS auxiliary classifier for 224 x 224 inputs (14 x 14 feature map assumed)."""
+
+    def __init__(self, C, num_classes, norm='bn'):
+        super().__init__()
+        Lyr = self.L
+        self.features = Lyr.Sequential(
+            Lyr.ReLU(inplace=True), Lyr.AvgPool2d(5, stride=2, padding=0, count_include_pad=False),
+            Lyr.Conv2d(C, 128, 1, bias=False), bn_layer(Lyr, norm, 128), Lyr.ReLU(inplace=True),
+            Lyr.Conv2d(128, 768, 2, bias=False), bn_layer(Lyr, norm, 768), Lyr.ReLU(inplace=True))
+        self.classifier = Lyr.Linear(768, num_classes)
+
+    def forward(self, x):
+        x = self.features(x)
+        return self.classifier(x.view(x.size(0), -1))
+
+
+def _make_op(T, Lyr, name, i, o, k, s, n):
+    """The op table of the search space (ops.py:293-304): i, o = channels in / out, k = kernel size, s = stride,
+    n = norm."""
+    if name == 'none':
+        return T['Zero'](s)
+    if name == 'skip_connect':
+        return Lyr.Identity() if s == 1 else T['FactorizedReduce'](i, o, norm=n)
+    if name == 'avg_pool':
+        return Lyr.AvgPool2d(k, stride=s, padding=k // 2, count_include_pad=False)
+    if name == 'max_pool':
+        return Lyr.MaxPool2d(k, stride=s, padding=k // 2)
+    if name == 'conv':
+        return T['ReLUConvBN'](i, o, k, s, k // 2, norm=n)
+    if name == 'sep_conv':
+        return T['SepConv'](i, o, k, s, k // 2, norm=n)
+    if name == 'dil_conv':
+        return T['DilConv'](i, o, k, s, k - k % 2, 2, norm=n)
+    if name == 'conv2':
+        return T['ReLUConvBN'](i, o, k, s, k // 2, norm=n, double=True)
+    if name == 'conv_stride':
+        return Lyr.Conv2d(i, o, k, stride=k, bias=False, padding=int(k < 4))
+    if name == 'msa':
+        return T['TransformerLayer'](i, stride=s)
+    if name == 'cse':
+        return T['ChannelSELayer'](i, dim_out=o, stride=s)
+    raise KeyError(name)
+
+
+class _Cell:
+    """One cell: two preprocessed inputs, `steps` intermediate states (each the sum of two ops applied to earlier states),
+    concatenation of the states the genotype lists (ops.py:306-401)."""
+
+    def __init__(self, genotype, C_prev_prev, C_prev, C_in, C_out, reduction, reduction_prev, norm='bn', preproc=True,
+                 is_vit=False, cell_ind=0):
+        super().__init__()
+        Lyr, T = self.L, self.T
+        self._is_vit, self._cell_ind, self.genotype = is_vit, cell_ind, genotype
+        self._has_none = any(n[0] == 'none' for n in genotype.normal + genotype.reduce)
+        halve = reduction_prev and not is_vit
+        if preproc:
+            self.preprocess0 = T['FactorizedReduce'](C_prev_prev, C_out, norm=norm) if halve else \
+                T['ReLUConvBN'](C_prev_prev, C_out, norm=norm)
+            self.preprocess1 = T['ReLUConvBN'](C_prev, C_out, norm=norm)
+        else:
+            self.preprocess0 = T['Stride'](stride=2) if halve else Lyr.Identity()
+            self.preprocess1 = Lyr.Identity()
+        pairs = genotype.reduce if reduction else genotype.normal
+        self._concat = genotype.reduce_concat if reduction else genotype.normal_concat
+        self.multiplier = len(self._concat)
+        self._steps = len(pairs) // 2
+        self._indices = tuple(index for _, index in pairs)
+        self._ops = Lyr.ModuleList()
+        for name, index in pairs:
+            stride = 2 if (reduction and index < 2 and not is_vit) else 1
+            name, ks = parse_op_ks(name)
+            self._ops.append(_make_op(T, Lyr, name, C_in if index <= 1 else C_out, C_out, ks, stride, norm))
+
+    def _branch(self, op, h, drop_path_prob):
+        """One op applied to one earlier state; None when the op or its input is absent."""
+        if h is None or isinstance(op, self.T['Zero']) or _is_none(op):
+            return None
+        h = op(h)
+        if self.training and drop_path_prob > 0 and not isinstance(op, self.L.Identity):
+            h = drop_path(h, drop_path_prob)
+        return h
+
+    def forward(self, s0, s1, drop_path_prob=0):
+        s0 = None if (s0 is None or _is_none(self.preprocess0)) else self.preprocess0(s0)
+        s1 = None if (s1 is None or _is_none(self.preprocess1)) else self.preprocess1(s1)
+        states = [s0, s1]
+        for k in range(self._steps):
+            a = self._branch(self._ops[2 * k], states[self._indices[2 * k]], drop_path_prob)
+            b = self._branch(self._ops[2 * k + 1], states[self._indices[2 * k + 1]], drop_path_prob)
+            states.append(a if b is None else (b if a is None else a + b))
+        outs = [states[k] for k in self._concat]
+        if any(s is None for s in outs):
+            # states that received nothing ('none' ops) are replaced by zeros of a live state's shape
+            assert self._has_none, self.genotype
+            live = next((s for s in outs if s is not None), None)
+            if live is None:
+                return None
+            outs = [live * 0 if s is None else s for s in outs]
+        return torch.cat(outs, dim=1)
+
+
+class _Network:
+    """Stem + cells + classifier (ops.py:403-569)."""
+
+    def __init__(self, C, num_classes, genotype, n_cells, ks=3, is_imagenet_input=True, stem_pool=False, stem_type=0,
+                 imagenet_stride=4, is_vit=None, norm='bn-track', preproc=True, C_mult=2, fc_layers=0, fc_dim=0,
+                 glob_avg=True, auxiliary=False):
+        super().__init__()
+        Lyr, T = self.L, self.T
+        self.genotype, self._C, self._auxiliary = genotype, C, auxiliary
+        self.drop_path_prob = 0
+        self.expected_input_sz = 224 if is_imagenet_input else 32
+        self._is_vit = any(n[0] == 'msa' for n in genotype.normal + genotype.reduce) if is_vit is None else is_vit
+        steps = len(genotype.normal_concat)
+        if steps > 1 or C_mult > 1:
+            assert preproc, 'preprocessing layers must be used in this case'
+        assert stem_type in (0, 1), ('either 0 (simple) or 1 (imagenet-style) stem must be chosen', stem_type)
+        self._stem_type = stem_type
+        C_prev_prev = C_prev = C_curr = C
+        if self._is_vit:
+            self.stem0 = _make_op(T, Lyr, 'conv_stride', 3, C, 16 if is_imagenet_input else 3, None, None)
+            self.pos_enc = T['PosEnc'](C, 14 if is_imagenet_input else 11)
+        elif stem_type == 0:
+            C_stem = int(C * (3 if (preproc and not is_imagenet_input) else 1))
+            self.stem = Lyr.Sequential(
+                Lyr.Conv2d(3, C_stem, ks, stride=imagenet_stride if is_imagenet_input else 1, padding=ks // 2, bias=False),
+                bn_layer(Lyr, norm, C_stem),
+                Lyr.MaxPool2d(3, stride=2, padding=1, ceil_mode=False) if stem_pool else Lyr.Identity())
+            C_prev_prev = C_prev = C_stem
+        else:
+            s = 2 if is_imagenet_input else 1
+            self.stem0 = Lyr.Sequential(
+                Lyr.Conv2d(3, C // 2, kernel_size=ks, stride=s, padding=ks // 2, bias=False), bn_layer(Lyr, norm, C // 2),
+                Lyr.ReLU(inplace=True),
+                Lyr.Conv2d(C // 2, C, kernel_size=3, stride=s, padding=1, bias=False), bn_layer(Lyr, norm, C))
+            self.stem1 = Lyr.Sequential(Lyr.ReLU(inplace=True), Lyr.Conv2d(C, C, 3, stride=2, padding=1, bias=False),
+                                        bn_layer(Lyr, norm, C))
+        self._n_cells = n_cells
+        self.cells = Lyr.ModuleList()
+
+        def is_reduction(c):
+            return c > 0 and c in (n_cells // 3, 2 * n_cells // 3)
+        self._auxiliary_cell_ind = 2 * n_cells // 3
+        reduction_prev = stem_type == 1
+        for c in range(n_cells):
+            reduction = is_reduction(c)
+            if reduction:
+                C_curr *= C_mult
+            widen_next = is_reduction(c + 1) and steps == 1 and not preproc
+            cell = T['Cell'](genotype, C_prev_prev, C_prev, C_in=C_curr if preproc else C_prev,
+                             C_out=C_curr * (C_mult if widen_next else 1), reduction=reduction,
+                             reduction_prev=reduction_prev, norm=norm, is_vit=self._is_vit, preproc=preproc, cell_ind=c)
+            self.cells.append(cell)
+            reduction_prev = reduction
+            C_prev_prev, C_prev = C_prev, cell.multiplier * C_curr
+            if auxiliary and c == self._auxiliary_cell_ind:
+                if is_imagenet_input:
+                    self.auxiliary_head = T['AuxiliaryHeadImageNet'](C_prev, num_classes, norm=norm)
+                else:
+                    self.auxiliary_head = T['AuxiliaryHeadCIFAR'](C_prev, num_classes, norm=norm,
+                                                                  pool_sz=2 if (stem_type == 1 or stem_pool) else 5)
+        self._glob_avg = glob_avg
+        if glob_avg:
+            self.global_pooling = Lyr.AdaptiveAvgPool2d(1)
+        else:
+            small = stem_type == 1 or stem_pool
+            s = (7 if small else 14) if is_imagenet_input else (4 if small else 8)
+            C_prev *= s ** 2
+        fc = [Lyr.Linear(C_prev, fc_dim if fc_layers > 1 else num_classes)]
+        for k in range(fc_layers - 1):
+            assert fc_dim > 0, fc_dim
+            fc += [Lyr.ReLU(inplace=True), Lyr.Dropout(p=0.5, inplace=False),
+                   Lyr.Linear(in_features=fc_dim, out_features=fc_dim if k < fc_layers - 2 else num_classes)]
+        self.classifier = Lyr.Sequential(*fc)
+        if Lyr.light:
+            # the parameter table GHN3.forward walks (nn.py:612); built once, here
+            self.__dict__['_layered_modules'] = named_layered_modules(self)
+
+    def forward(self, x):
+        if self._is_vit:
+            s0 = s1 = self.pos_enc(self.stem0(x))
+        elif self._stem_type == 1:
+            s0 = self.stem0(x)
+            s1 = None if _is_none(self.stem1) else self.stem1(s0)
+        else:
+            s0 = s1 = self.stem(x)
+        logits_aux = None
+        for c, cell in enumerate(self.cells):
+            s0, s1 = s1, cell(s0, s1, self.drop_path_prob)
+            if self._auxiliary and c == self._auxiliary_cell_ind and self.training:
+                small_vit = self._is_vit and self.expected_input_sz == 32
+                logits_aux = self.auxiliary_head(F.adaptive_avg_pool2d(s1, 8) if small_vit else s1)
+        if s1 is None:
+            raise ValueError('the network has invalid configuration: the output is None')
+        out = self.global_pooling(s1) if self._glob_avg else s1
+        with torch.autocast(out.device.type, enabled=False):       # the classifier always runs in fp32
+            logits = self.classifier(out.float().reshape(out.size(0), -1))
+        return logits, logits_aux
+
+
+# ======================================================================================================
+# the two flavours
+# ======================================================================================================
+_DEFS = (_Stride, _Zero, _FactorizedReduce, _ReLUConvBN, _DilConv, _SepConv, _ChannelSELayer, _PosEnc, _FeedForward,
+         _MultiHeadSelfAttention, _TransformerLayer, _AuxiliaryHeadCIFAR, _AuxiliaryHeadImageNet, _Cell, _Network)
+
+
+def _flavours():
+    this = sys.modules[__name__]
+    tables = {}
+    for Lyr, suffix in ((_TorchLayers, ''), (_LightLayers, 'Light')):
+        T = {}
+        for d in _DEFS:
+            short = d.__name__[1:]
+            base = getattr(Lyr, getattr(d, '_base', 'Module'))
+            body = {'L': Lyr, 'T': T, '__module__': __name__, '__qualname__': short + suffix, '__doc__': d.__doc__}
+            if Lyr.light and short.startswith('AuxiliaryHead'):
+                # the auxiliary classifiers stay torch.nn modules with parameters of their own in a light network too
+                # (the reference takes them from ppuda, ops.py:21,506-510): the GHN does not predict them
+                T[short] = tables[False][short]
+                continue
+            cls = type(short + suffix, (d, base), body)
+            T[short] = cls
+            setattr(this, short + suffix, cls)
+        tables[Lyr.light] = T
+    return tables
+
+
+_T = _flavours()
+types_torch_nn, types_light = _T[False], _T[True]       # name -> class, as the reference's two tables (ops.py:572-573)
+del _T

@@ -228,3 +228,70 @@ def capacity(model, is_grad=True):
             c += 1
             n += int(np.prod(p.shape))
     return c, int(n)
+
+
+# ---- ppuda.deepnets1m.{ops,net} helpers the reference's target networks import (ghn3/ops.py:20-21) ----------------
+# Restated from the published ppuda package (absent offline): parity unpinned for these few functions; the reference's
+# own Cell / Network / op classes that call them are pinned by tests/golden/networks.npz.
+
+def parse_op_ks(op):
+    """'sep_conv_5x5' -> ('sep_conv', 5), 'conv_7x1_1x7' -> ('conv2', 7), names without a size -> (name, 3)."""
+    toks = op.split('_')
+    ks = [t for t in toks if t.count('x') == 1 and all(v.isdigit() for v in t.split('x'))]
+    if len(ks) == 0:
+        return op, 3
+    base = '_'.join(t for t in toks if t not in ks)
+    if len(ks) > 1:
+        return base + '2', max(int(v) for v in ks[0].split('x'))
+    return base, int(ks[0].split('x')[0])
+
+
+def drop_path(x, drop_prob):
+    if drop_prob > 0.:
+        keep_prob = 1. - drop_prob
+        mask = torch.empty(x.size(0), 1, 1, 1, device=x.device).bernoulli_(keep_prob)
+        x = x.div(keep_prob) * mask
+    return x
+
+
+def is_none(mod):
+    if mod is None:
+        return True
+    for _, m in (mod.named_modules() if hasattr(mod, 'named_modules') else ()):
+        if hasattr(m, 'weight') and m.weight is None:
+            return True
+    return False
+
+
+def _norm(norm, C):
+    if norm in [None, '', 'none']:
+        return nn.Identity()
+    return nn.BatchNorm2d(C, track_running_stats=norm.find('track') >= 0)
+
+
+class AuxiliaryHeadCIFAR(nn.Module):
+    def __init__(self, C, num_classes, norm='bn', pool_sz=5):
+        super().__init__()
+        self.features = nn.Sequential(
+            nn.ReLU(inplace=True), nn.AvgPool2d(pool_sz, stride=3, padding=0, count_include_pad=False),
+            nn.Conv2d(C, 128, 1, bias=False), _norm(norm, 128), nn.ReLU(inplace=True),
+            nn.Conv2d(128, 768, 2, bias=False), _norm(norm, 768), nn.ReLU(inplace=True))
+        self.classifier = nn.Linear(768, num_classes)
+
+    def forward(self, x):
+        x = self.features(x)
+        return self.classifier(x.view(x.size(0), -1))
+
+
+class AuxiliaryHeadImageNet(nn.Module):
+    def __init__(self, C, num_classes, norm='bn'):
+        super().__init__()
+        self.features = nn.Sequential(
+            nn.ReLU(inplace=True), nn.AvgPool2d(5, stride=2, padding=0, count_include_pad=False),
+            nn.Conv2d(C, 128, 1, bias=False), _norm(norm, 128), nn.ReLU(inplace=True),
+            nn.Conv2d(128, 768, 2, bias=False), _norm(norm, 768), nn.ReLU(inplace=True))
+        self.classifier = nn.Linear(768, num_classes)
+
+    def forward(self, x):
+        x = self.features(x)
+        return self.classifier(x.view(x.size(0), -1))

@@ -76,8 +76,9 @@ def install_standins():
     mod('ppuda.deepnets1m')
     mod('ppuda.deepnets1m.net', named_layered_modules=ppuda_base.named_layered_modules,
         get_cell_ind=lambda *a, **k: 0, Network=type('Network', (nn.Module,), {}),
-        AuxiliaryHeadImageNet=_Stub, AuxiliaryHeadCIFAR=_Stub, drop_path=None, _is_none=lambda x: x is None)
-    mod('ppuda.deepnets1m.ops', parse_op_ks=None, PosEnc=type('PosEnc', (nn.Module,), {}))
+        AuxiliaryHeadImageNet=ppuda_base.AuxiliaryHeadImageNet, AuxiliaryHeadCIFAR=ppuda_base.AuxiliaryHeadCIFAR,
+        drop_path=ppuda_base.drop_path, _is_none=ppuda_base.is_none)
+    mod('ppuda.deepnets1m.ops', parse_op_ks=ppuda_base.parse_op_ks, PosEnc=type('PosEnc', (nn.Module,), {}))
     mod('ppuda.deepnets1m.genotypes', PRIMITIVES_DEEPNETS1M=ppuda_base.PRIMITIVES_DEEPNETS1M, from_dict=None)
     mod('ppuda.deepnets1m.loader', DeepNets1M=object, NetBatchSampler=object, MAX_NODES_BATCH=2200)
 
@@ -301,6 +302,62 @@ def make_graph_goldens():
 
 
 # ------------------------------------------------------------------------------------------------
+# 2d. Target networks of the DeepNets-1M search space: the reference's Network (torch.nn flavour) and NetworkLight
+#     (light layers) of ghn3/ops.py:306-585 on the genotypes of tests/golden/network_cases.py -> networks.npz:
+#     seeded parameters (recipe.seeded_net_params), a seeded image batch, logits in training mode (batch statistics),
+#     logits of the light flavour with the same tensors assigned, parameter names / shapes, gradient norms.
+# ------------------------------------------------------------------------------------------------
+
+def make_network_goldens():
+    install_standins()
+    sys.path.insert(0, REF)
+    import ghn3                                              # noqa: F401
+    from ghn3.ops import Network, NetworkLight
+    from collections import namedtuple
+    import network_cases
+    Genotype = namedtuple('Genotype', 'normal normal_concat reduce reduce_concat')
+    out = {}
+    for name, (geno, kw, img) in network_cases.CASES.items():
+        g = Genotype(**geno)
+        torch.manual_seed(0)
+        net = Network(genotype=g, **kw)
+        names = [n for n, _ in net.named_parameters()]
+        params = recipe.seeded_net_params([(n, tuple(p.shape)) for n, p in net.named_parameters()], seed=len(name))
+        with torch.no_grad():
+            for n, p in net.named_parameters():
+                p.copy_(torch.from_numpy(params[n]))
+        x = torch.from_numpy(recipe.seeded_images(img, seed=7))
+        net.train()
+        torch.manual_seed(123)                               # (Dropout in the two-layer classifier head)
+        logits, aux = net(x)
+        loss = logits.square().mean() + (aux.square().mean() if aux is not None else 0.)
+        loss.backward()
+        out[name + '/names'] = np.asarray(names)
+        out[name + '/shapes'] = np.asarray([repr(tuple(p.shape)) for _, p in net.named_parameters()])
+        out[name + '/logits'] = logits.detach().numpy()
+        if aux is not None:
+            out[name + '/aux'] = aux.detach().numpy()
+        out[name + '/grad_norms'] = np.asarray([float(p.grad.norm()) if p.grad is not None else -1.0
+                                                for _, p in net.named_parameters()], dtype=np.float64)
+        # light flavour: same tensors assigned through the table GHN3.forward walks
+        light = NetworkLight(genotype=g, **{k: ('bn' if (k == 'norm' and v) else v) for k, v in kw.items()})
+        table = {}
+        for cell in light._layered_modules:
+            table.update(cell)
+        out[name + '/light_names'] = np.asarray(sorted(table))
+        out[name + '/light_cells'] = np.asarray([c for c, cell in enumerate(light._layered_modules) for _ in cell])
+        for n, e in table.items():
+            setattr(e['module'], 'weight' if e['is_w'] else 'bias', torch.from_numpy(params[n]))
+        torch.manual_seed(123)
+        ll, la = light(x)
+        out[name + '/light_logits'] = ll.detach().numpy()
+        print(name, 'params', sum(int(np.prod(p.shape)) for p in params.values()), 'logits', tuple(logits.shape),
+              'light == torch:', float((ll - logits).detach().abs().max()))
+    np.savez_compressed(os.path.join(HERE, 'networks.npz'), **out)
+    print('networks.npz: %d arrays' % len(out))
+
+
+# ------------------------------------------------------------------------------------------------
 # 3. torchvision-shaped ResNets through the reference GHN3 class at the released sizes (BASELINE configs 1 and 4):
 #    ghn3tm8 on the ResNet-18 graph, ghn3xlm16 on the ResNet-50 graph.  Stores per predicted tensor the Frobenius
 #    norm and a seeded sample of its elements (the tensors themselves are 11.7 M / 25.6 M floats).
@@ -357,12 +414,15 @@ if __name__ == '__main__':
     # python make_golden.py            -> tiny fixtures (seconds)
     # python make_golden.py graphs     -> graphs.npz (reference Graph(model) on tests/golden/graph_nets.py)
     # python make_golden.py extra      -> ghn3_tiny_extra.npz (big kernels, weight_norm / layernorm off)
+    # python make_golden.py networks   -> networks.npz (reference Network / NetworkLight on tests/golden/network_cases.py)
     # python make_golden.py resnet     -> + ResNet-18 / ghn3tm8 and ResNet-50 / ghn3xlm16 (minutes, ~10 GB of RAM)
     torch.set_num_threads(8 if 'resnet' in sys.argv[1:] else 4)
     if 'graphs' in sys.argv[1:]:
         make_graph_goldens()
     elif 'extra' in sys.argv[1:]:
         make_extra_goldens()
+    elif 'networks' in sys.argv[1:]:
+        make_network_goldens()
     elif 'resnet' in sys.argv[1:]:
         make_resnet_goldens([a for a in sys.argv[1:] if a in ('18', '50', 'vit')] or ('18', '50', 'vit'))
     else:

@@ -329,3 +329,28 @@ TILE_CASES = [
     ((8, 12, 16, 16), (8, 8, 16, 16)), ((32, 32, 5, 5), (20, 20, 3, 3)), ((16, 16), (8, 40, 1, 1)),
     ((1, 32, 14, 14), (1, 32, 14, 14)), ((32, 32, 4, 4), (16, 40, 4, 4)), ((32, 32, 2, 2), (48, 16, 2, 2)),
 ]
+
+
+# ------------------------------------------------------------------------------------------------
+# seeded target-network parameters / images (tests/golden/networks.npz)
+# ------------------------------------------------------------------------------------------------
+
+def seeded_net_params(named_shapes, seed):
+    """[(name, shape)] -> {name: float32 ndarray}: 1-D weights of norm layers near one, biases small, everything else
+    He-like; depends only on (name, shape, seed)."""
+    out = {}
+    for name, shape in named_shapes:
+        rs = np.random.RandomState((seed * 7919 + zlib.crc32(name.encode())) % (2 ** 31 - 1))
+        v = rs.standard_normal(shape).astype(np.float32)
+        if name.endswith('.bias'):
+            out[name] = (0.1 * v).astype(np.float32)
+        elif len(shape) == 1:
+            out[name] = (1.0 + 0.2 * v).astype(np.float32)
+        else:
+            fan_in = int(np.prod(shape[1:]))
+            out[name] = (v * np.sqrt(2.0 / fan_in)).astype(np.float32)
+    return out
+
+
+def seeded_images(shape, seed):
+    return np.random.RandomState(seed).standard_normal(shape).astype(np.float32)

@@ -1,0 +1,194 @@
+"""Target networks of the DeepNets-1M search space: ``ghn3_amd.ops.Network`` / ``NetworkLight``
+and the light layers of ``ghn3_amd.light_ops`` against tests/golden/networks.npz, which the REFERENCE's Network /
+NetworkLight (ghn3/ops.py:306-585) produced for the cases of tests/golden/network_cases.py (make_golden.py networks).
+Host-side code: runs on the CPU."""
+import os
+import pickle
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+import network_cases                                        # noqa: E402
+import recipe                                               # noqa: E402
+from ghn3_amd import light_ops, ops                         # noqa: E402
+
+GOLD = np.load(os.path.join(HERE, 'golden', 'networks.npz'))
+
+
+def _build(name, light):
+    geno, kw, img = network_cases.CASES[name]
+    g = ops.Genotype(**geno)
+    kw = dict(kw)
+    cls = ops.NetworkLight if light else ops.Network
+    return cls(genotype=g, **kw), torch.from_numpy(recipe.seeded_images(img, seed=7))
+
+
+def _params(name):
+    names = [str(n) for n in GOLD[name + '/names']]
+    shapes = [eval(str(s)) for s in GOLD[name + '/shapes']]
+    return names, recipe.seeded_net_params(list(zip(names, shapes)), seed=len(name))
+
+
+@pytest.mark.parametrize('name', sorted(network_cases.CASES))
+def test_network_matches_reference(name):
+    """torch.nn flavour: same parameter names and shapes (state-dict compatible), same logits, auxiliary logits and
+    per-parameter gradient norms as the reference's Network with the same seeded parameters."""
+    net, x = _build(name, light=False)
+    names, params = _params(name)
+    mine = [(n, tuple(p.shape)) for n, p in net.named_parameters()]
+    assert [n for n, _ in mine] == names
+    assert [repr(s) for _, s in mine] == [str(s) for s in GOLD[name + '/shapes']]
+    with torch.no_grad():
+        for n, p in net.named_parameters():
+            p.copy_(torch.from_numpy(params[n]))
+    net.train()
+    torch.manual_seed(123)
+    logits, aux = net(x)
+    np.testing.assert_allclose(logits.detach().numpy(), GOLD[name + '/logits'], rtol=2e-5, atol=2e-5)
+    loss = logits.square().mean()
+    if name + '/aux' in GOLD:
+        np.testing.assert_allclose(aux.detach().numpy(), GOLD[name + '/aux'], rtol=2e-5, atol=2e-5)
+        loss = loss + aux.square().mean()
+    else:
+        assert aux is None
+    loss.backward()
+    gn = np.asarray([float(p.grad.norm()) if p.grad is not None else -1.0 for _, p in net.named_parameters()])
+    np.testing.assert_allclose(gn, GOLD[name + '/grad_norms'], rtol=2e-4, atol=1e-6)
+
+
+@pytest.mark.parametrize('name', sorted(network_cases.CASES))
+def test_network_light_matches_reference(name):
+    """Light flavour: the parameter table (names per cell) GHN3.forward walks equals the reference's, shapes are lists
+    until tensors are assigned, logits equal the reference's NetworkLight with the same tensors, gradients reach the
+    assigned tensors, and the network pickles (loader workers)."""
+    net, x = _build(name, light=True)
+    names, params = _params(name)
+    table = {}
+    for cell in net._layered_modules:
+        table.update(cell)
+    assert sorted(table) == [str(n) for n in GOLD[name + '/light_names']]
+    cells = [c for c, cell in enumerate(net._layered_modules) for _ in cell]
+    assert cells == [int(c) for c in GOLD[name + '/light_cells']]
+    for n, e in table.items():
+        assert e['sz'] == tuple(params[n].shape), n
+        assert isinstance(getattr(e['module'], 'weight' if e['is_w'] else 'bias'), list)
+    assert len(list(net.parameters())) == 0                 # nothing assigned yet
+    clone = pickle.loads(pickle.dumps(net))
+    assert sorted(k for cell in clone._layered_modules for k in cell) == sorted(table)
+    leaves = {}
+    for n, e in table.items():
+        leaves[n] = torch.from_numpy(params[n]).requires_grad_(True)
+        setattr(e['module'], 'weight' if e['is_w'] else 'bias', leaves[n])
+    assert len(list(net.parameters())) == len(table)
+    if hasattr(net, 'auxiliary_head'):                      # a torch.nn module with parameters of its own (ops.py:506-510)
+        assert isinstance(net.auxiliary_head, nn.Module)
+        with torch.no_grad():
+            for n, p in net.auxiliary_head.named_parameters():
+                p.copy_(torch.from_numpy(params['auxiliary_head.' + n]))
+    net.train()
+    torch.manual_seed(123)
+    logits, aux = net(x)
+    np.testing.assert_allclose(logits.detach().numpy(), GOLD[name + '/light_logits'], rtol=2e-5, atol=2e-5)
+    loss = logits.square().mean() + (aux.square().mean() if aux is not None else 0.)
+    loss.backward()
+    gn = {n: float(t.grad.norm()) if t.grad is not None else -1.0 for n, t in leaves.items()}
+    want = dict(zip([str(n) for n in GOLD[name + '/names']], GOLD[name + '/grad_norms']))
+    for n in leaves:
+        assert abs(gn[n] - want[n]) <= 2e-4 * abs(want[n]) + 1e-6, (n, gn[n], want[n])
+
+
+def test_light_layers_follow_torch_layers():
+    """Every light layer against its torch.nn counterpart on random inputs (light_ops.py:126-331)."""
+    torch.manual_seed(0)
+    x = torch.randn(3, 6, 9, 9)
+    pairs = [(light_ops.AvgPool2d(3, stride=2, padding=1, count_include_pad=False),
+              nn.AvgPool2d(3, stride=2, padding=1, count_include_pad=False)),
+             (light_ops.MaxPool2d(3, stride=2, padding=1), nn.MaxPool2d(3, stride=2, padding=1)),
+             (light_ops.AdaptiveAvgPool2d(1), nn.AdaptiveAvgPool2d(1)), (light_ops.ReLU(), nn.ReLU()),
+             (light_ops.GELU(), nn.GELU()), (light_ops.Hardswish(), nn.Hardswish()),
+             (light_ops.Identity(), nn.Identity())]
+    for a, b in pairs:
+        assert torch.equal(a(x), b(x)), type(a).__name__
+    conv_t = nn.Conv2d(6, 4, 3, stride=2, padding=1, dilation=1, groups=2, bias=True)
+    conv_l = light_ops.Conv2d(6, 4, 3, stride=2, padding=1, dilation=1, groups=2, bias=True)
+    assert conv_l.weight == [4, 3, 3, 3] and conv_l.bias == [4]
+    conv_l.weight, conv_l.bias = conv_t.weight, conv_t.bias
+    assert torch.equal(conv_l(x), conv_t(x))
+    lin_t, lin_l = nn.Linear(9, 5), light_ops.Linear(9, 5)
+    lin_l.weight, lin_l.bias = lin_t.weight, lin_t.bias
+    assert torch.equal(lin_l(x), lin_t(x))
+    bn_t, bn_l = nn.BatchNorm2d(6, track_running_stats=False), light_ops.BatchNorm2d(6)
+    bn_l.weight, bn_l.bias = bn_t.weight, bn_t.bias
+    assert torch.equal(bn_l(x), bn_t(x))
+    bn_l.eval()                                              # no running statistics: batch statistics in eval as well
+    assert torch.equal(bn_l(x), bn_t(x))
+    with pytest.raises(AssertionError):
+        light_ops.BatchNorm2d(6, track_running_stats=True)
+    ln_t, ln_l = nn.LayerNorm(9), light_ops.LayerNorm(9)
+    ln_l.weight, ln_l.bias = ln_t.weight, ln_t.bias
+    assert torch.equal(ln_l(x), ln_t(x))
+    drop = light_ops.Dropout(0.5)
+    drop.eval()
+    assert torch.equal(drop(x), x)
+    seq = light_ops.Sequential(light_ops.ReLU(), conv_l, light_ops.Identity())
+    assert len(seq) == 3 and seq[1] is conv_l and len(seq[1:]) == 2 and seq[-1] is seq[2]
+    assert [n for n, _ in seq.named_modules()] == ['', '1']     # parameter-free children are not listed
+    ml = light_ops.ModuleList([conv_l]) + light_ops.ModuleList([lin_l])
+    assert len(ml) == 2 and ml[-1] is lin_l and [type(m) for m in ml[0:1]] == [light_ops.Conv2d]
+    assert set(seq.shapes()) == {'1.weight', '1.bias'}
+
+
+def test_op_name_parser_and_helpers():
+    assert ops.parse_op_ks('sep_conv_5x5') == ('sep_conv', 5)
+    assert ops.parse_op_ks('conv_7x1_1x7') == ('conv2', 7)
+    assert ops.parse_op_ks('max_pool_3x3') == ('max_pool', 3)
+    assert ops.parse_op_ks('skip_connect')[0] == 'skip_connect' and ops.parse_op_ks('msa')[0] == 'msa'
+    g = ops.from_dict(dict(normal=[['conv_3x3', 0], ['none', 1]], normal_concat=[2], reduce=[['conv_3x3', 0], ['none', 1]],
+                           reduce_concat=[2]))
+    assert g.normal[0] == ('conv_3x3', 0)
+    x = torch.ones(64, 2, 3, 3)
+    torch.manual_seed(0)
+    y = ops.drop_path(x, 0.25)
+    kept = (y.flatten(1).abs().sum(1) > 0).float().mean().item()
+    assert 0.5 < kept < 0.95 and torch.allclose(y[y != 0], torch.tensor(1 / 0.75))
+    lin = light_ops.Linear(3, 3)
+    assert not ops._is_none(lin)
+    lin.weight = None
+    assert ops._is_none(lin) and ops._is_none(None)
+    assert ops.types_light['Network'] is ops.NetworkLight and ops.types_torch_nn['Network'] is ops.Network
+
+
+def test_sampled_nets_loader_and_oracle_ghn():
+    """The architecture stream (deepnets1m.py:271-319 role): deterministic in (seed, index), disjoint slices per rank,
+    graphs whose parameter nodes match the light network's table; the CPU oracle GHN assigns every tensor and the
+    network runs on images."""
+    from ghn3_amd.deepnets1m import SampledNets
+    from oracle import ghn3_ref as R
+    a = next(SampledNets.loader(meta_batch_size=4, rank=0, world_size=2, seed=3))
+    b = next(SampledNets.loader(meta_batch_size=4, rank=1, world_size=2, seed=3))
+    c = next(SampledNets.loader(meta_batch_size=4, rank=0, world_size=1, seed=3))
+    assert len(a.nets) == 2 and len(b.nets) == 2 and len(c.nets) == 4
+    assert a.net_inds == [0, 1] and b.net_inds == [2, 3] and c.net_inds == [0, 1, 2, 3]
+    for k in range(2):
+        assert torch.equal(a.edges[k], c.edges[k]) and torch.equal(b.edges[k], c.edges[2 + k])
+        assert a.net_args[k]['genotype'] == c.net_args[k]['genotype']
+    torch.manual_seed(0)
+    oracle = R.GHN3Ref(**recipe.TINY_CFG)
+    oracle.train()
+    gb = R.GraphBatchRef([R.GraphRef(nf, ni, A) for nf, ni, A in zip(a.node_feat, a.node_info, a.edges)])
+    nets, _ = oracle(a.nets, gb, keep_grads=True)
+    x = torch.randn(2, 3, 32, 32)
+    for net in nets:
+        for cell in net._layered_modules:
+            for name, e in cell.items():
+                t = getattr(e['module'], 'weight' if e['is_w'] else 'bias')
+                assert isinstance(t, torch.Tensor) and tuple(t.shape) == e['sz'], name
+        logits, _ = net(x)
+        assert logits.shape == (2, 10) and torch.isfinite(logits).all()
+    logits.square().mean().backward()
+    assert sum(float(p.grad.abs().sum()) > 0 for p in oracle.parameters() if p.grad is not None) > 10

@@ -105,9 +105,14 @@ class SampledNets:
                 continue
             # every parameter must be reachable from the output (a cell that ignores one of its inputs leaves the
             # preprocessing layer of that input outside the graph: the GHN would predict nothing for it)
-            in_graph = {n[1] for cell in graph.node_info for n in cell}
-            table = [k for cell in model._layered_modules for k in cell]
-            if any(k not in in_graph and k.replace('.bias', '.weight') not in in_graph for k in table):
+            # (matched cell by cell, as GHN3.forward does: nn.py:612-650)
+            if len(graph.node_info) != len(model._layered_modules):
+                continue
+            complete = True
+            for cell_nodes, cell_table in zip(graph.node_info, model._layered_modules):
+                in_graph = {n[1] for n in cell_nodes}
+                complete &= all(k in in_graph or k.replace('.bias', '.weight') in in_graph for k in cell_table)
+            if not complete:
                 continue
             out = Graph(node_feat=graph.node_feat, node_info=graph.node_info, A=graph._Adj, net_args=args, net_idx=idx)
             out.net = ops.NetworkLight(**args) if self.light else model

@@ -335,13 +335,20 @@ def _virtual_edges(A, cutoff):
 
 
 def _cell_index(param_name, n_cells):
-    """ppuda get_cell_ind: DeepNets-1M networks name their cells 'cells.<k>.' (None for anything else)."""
-    if n_cells > 1:
-        k = param_name.find('cells.')
-        if k >= 0:
-            digits = param_name[k + 6:].split('.')[0]
-            if digits.isdigit():
-                return int(digits)
+    """Cell of a node by its name (ppuda get_cell_ind, restated from the published package): 'cells.<k>.' -> k, the
+    classifier and the auxiliary head -> the last cell, stems and positional encodings -> 0 -- the same split
+    ``named_layered_modules`` makes on the network side; None keeps the previous node's cell."""
+    if n_cells <= 1:
+        return 0
+    k = param_name.find('cells.')
+    if k >= 0:
+        digits = param_name[k + 6:].split('.')[0]
+        if digits.isdigit():
+            return int(digits)
+    if param_name.startswith(('classifier', 'auxiliary')):
+        return n_cells - 1
+    if param_name.startswith(('stem', 'pos_enc')):
+        return 0
     return None
 
 

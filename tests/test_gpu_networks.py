@@ -42,6 +42,7 @@ def test_light_networks_trained_through_the_ghn_vs_oracle():
             for name, e in cell.items():
                 t = getattr(e['module'], 'weight' if e['is_w'] else 'bias')
                 assert isinstance(t, torch.Tensor) and t.is_cuda and tuple(t.shape) == e['sz'], name
+        net.eval()                      # (Dropout of a two-layer head off; light BatchNorm keeps batch statistics)
         logits, aux = net(images.cuda())
         assert aux is None and logits.shape == (4, 10)
         loss = loss + F.cross_entropy(logits, labels.cuda())
@@ -49,6 +50,16 @@ def test_light_networks_trained_through_the_ghn_vs_oracle():
     torch.cuda.synchronize()
 
     nets_o, _ = oracle(gb_o.nets, _oracle_batch(gb_o), keep_grads=True)
+    for net, net_o in zip(nets, nets_o):
+        net_o.eval()
+        worst = 0.0
+        for cell, cell_o in zip(net._layered_modules, net_o._layered_modules):
+            for name, e in cell.items():
+                attr = 'weight' if e['is_w'] else 'bias'
+                t, t_o = getattr(e['module'], attr), getattr(cell_o[name]['module'], attr)
+                err = float((t.detach().cpu().double() - t_o.detach().double()).norm() / (t_o.detach().double().norm() + 1e-12))
+                worst = max(worst, err)
+                assert err < 1e-4, (name, tuple(t_o.shape), err)
     loss_o = sum(F.cross_entropy(net(images)[0], labels) for net in nets_o)
     loss_o.backward()
     assert abs(loss.item() - loss_o.item()) < 2e-4 * max(1.0, abs(loss_o.item())), (loss.item(), loss_o.item())

@@ -1,15 +1,8 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-O=gpurun_out/r02q_group.txt; : > $O
-run() { echo "== $*" >> $O; env "$@" timeout 600 python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras 2>>gpurun_out/r02q.err | python -c "
-import sys, json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1]); k=d['roofline']['kernels']
-print(d['ms_per_step'], {n:(v['ms_per_step']) for n,v in k.items() if n.startswith('w2')})" >> $O; }
-run GHN3_SIDE_GROUP=1
-run GHN3_SIDE_GROUP=2
-run GHN3_SIDE_GROUP=4
-run GHN3_SIDE_GROUP=8
-run GHN3_SIDE_GROUP=1
-run GHN3_SIDE_GROUP=4
-run GHN3_SIDE_GROUP=24
+O=gpurun_out/r02s_train_scan.txt; : > $O
+for a in "--meta-batch-size 8 --batch-size 64" "--meta-batch-size 8 --batch-size 8" "--meta-batch-size 1 --batch-size 64" "--meta-batch-size 8 --batch-size 64 --miopen --steps 63" "--meta-batch-size 8 --batch-size 64 --amp"; do
+  echo "== $a" >> $O
+  timeout 900 python examples/train_ghn_ddp.py --steps 23 $a 2>&1 | tail -1 >> $O
+done
 cat $O

@@ -546,6 +546,38 @@ class GHN3(nn.Module):
                 target.data = t.clone()
 
 
+# What each architecture argument can be read from in a bare state dict (checkpoints without a 'config' entry,
+# nn.py:62-95).  (key suffix, required substring, config field, value from the tensor)
+_CONFIG_EVIDENCE = (
+    ('', 'class_layer_predictor', 'num_classes', lambda t: int(t.shape[0])),
+    ('embed.weight', '', 'hid', lambda t: int(t.shape[-1])),
+    ('decoder.conv.2.weight', '', 'max_ch', lambda t: int(math.isqrt(int(t.shape[0])))),
+    ('shape_enc.embed_spatial.weight', '', 'spatial', lambda t: 11 if int(t.shape[0]) == 9 else 16),
+    ('ln.weight', '', 'layernorm', lambda t: True),
+)
+
+
+def infer_config(state_dict, num_classes=10, layers=0, hid=32, layernorm=False, max_shape=64):
+    """GHN-3 constructor arguments from the tensors of a state dict: the width from the node embedding, the class count
+    from the classifier head of the decoder, the channel limit from the W2 row count (max_ch ** 2 rows), the spatial
+    limit from the shape-encoder vocabulary (9 entries <-> 11 x 11, otherwise 16 x 16; without that table 16 for
+    ImageNet-sized heads), one layer per 'gnn.<l>.ln1.weight'.  Arguments are the fall-backs for what the state dict
+    does not show."""
+    found = {'num_classes': num_classes, 'hid': hid, 'layernorm': layernorm, 'max_ch': max_shape}
+    depth = layers
+    for name, t in state_dict.items():
+        if '.ln1.weight' in name and 'gnn.' in name:
+            depth += 1
+        for suffix, needle, field, read in _CONFIG_EVIDENCE:
+            if name.endswith(suffix) and needle in name:
+                found[field] = read(t)
+    spatial = found.get('spatial', 16 if found['num_classes'] >= 1000 else 11)
+    limit = found['max_ch']
+    return {'hid': found['hid'], 'max_shape': limit if isinstance(limit, tuple) else (limit, limit, spatial, spatial),
+            'num_classes': found['num_classes'], 'heads': 16 if found['hid'] > 64 else 8, 'layers': depth,
+            'weight_norm': True, 've': True, 'layernorm': found['layernorm']}
+
+
 def from_pretrained(ghn3_name='ghn3xlm16.pt', **kwargs):
     """
     Loads a GHN-3 checkpoint (nn.py:31-125).  Local files are tried first (the reference's local fallback is
@@ -569,31 +601,8 @@ def from_pretrained(ghn3_name='ghn3xlm16.pt', **kwargs):
                                         'graphormer_x3')
              if k in kwargs}
     if ghn_config is None:
-        num_classes = kwargs.pop('num_classes', 10)
-        layers = kwargs.pop('layers', 0)
-        hid = kwargs.pop('hid', 32)
-        layernorm = kwargs.pop('layernorm', False)
-        max_shape = kwargs.pop('max_shape', 64)
-        for name, p in state_dict.items():
-            if name.find('class_layer_predictor') >= 0:
-                num_classes = len(p)
-                break
-        s = 16 if num_classes >= 1000 else 11
-        for name, p in state_dict.items():
-            if name.endswith('ln.weight'):
-                layernorm = True
-            elif name.endswith('embed.weight'):
-                hid = p.shape[-1]
-            elif name.endswith('decoder.conv.2.weight'):
-                max_shape = int(len(p) ** 0.5)
-            elif name.endswith('shape_enc.embed_spatial.weight'):
-                s = 11 if len(p) == 9 else 16
-            elif name.endswith('ln1.weight') and name.find('gnn.') >= 0:
-                layers += 1
-        ghn_config = {'hid': hid,
-                      'max_shape': max_shape if isinstance(max_shape, tuple) else (max_shape, max_shape, s, s),
-                      'num_classes': num_classes, 'heads': 16 if hid > 64 else 8, 'layers': layers,
-                      'weight_norm': True, 've': True, 'layernorm': layernorm}
+        defaults = {k: kwargs.pop(k) for k in ('num_classes', 'layers', 'hid', 'layernorm', 'max_shape') if k in kwargs}
+        ghn_config = infer_config(state_dict, **defaults)
     else:
         ghn_config = {k: v for k, v in ghn_config.items() if k not in ('is_ghn2', 'pretrained')}
     ghn = GHN3(**ghn_config, **extra, **kwargs)

@@ -588,6 +588,49 @@ def test_split_backward_with_overlapped_gradient_reduction():
         dist.destroy_process_group()
 
 
+def test_distributed_data_parallel_wrapper_gives_the_same_gradients():
+    """The reference wraps the GHN in DistributedDataParallel (trainer.py:136).  The flat-buffer model is an ordinary
+    nn.Module whose parameters receive .grad through autograd, so the wrapper works on it (1-rank RCCL group; gloo cannot
+    reduce device tensors): same predicted tensors and the same gradients as the bare model and as the model with the
+    in-backward FlatGradReducer."""
+    import socket
+    import torch.distributed as dist
+    from torch.nn.parallel import DistributedDataParallel
+    from ghn3_amd.ddp_utils import FlatGradReducer
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        hip, _ = make_models(T_CFG, 7)
+        hip.train()
+
+        def step(model, reducer=None):
+            hip.zero_grad(set_to_none=True)
+            hip.grad_reducer = reducer
+            nets_h, gb_h, _, _ = synthetic_case([40], 4000)
+            nets_h = model(nets_h, gb_h, keep_grads=True)
+            loss = sum(p.square().sum() for p in list(nets_h[0].parameters())[:12]) + hip.predicted_param_norm()
+            loss.backward()
+            torch.cuda.synchronize()
+            return loss.item(), {k: p.grad.detach().clone() for k, p in hip.named_parameters() if p.grad is not None}
+
+        loss0, g0 = step(hip)
+        loss1, g1 = step(hip, FlatGradReducer(compress=None, force=True))
+        ddp = DistributedDataParallel(hip, device_ids=[torch.cuda.current_device()])
+        loss2, g2 = step(ddp)
+        assert loss0 == loss1 == loss2
+        assert set(g0) == set(g1) == set(g2) and len(g0) > 20
+        for k in g0:
+            assert torch.equal(g0[k], g1[k]), k
+            assert torch.allclose(g0[k], g2[k], rtol=1e-6, atol=1e-9), k
+    finally:
+        hip.grad_reducer = None
+        dist.destroy_process_group()
+
+
 def test_fused_adamw_step_matches_torch():
     """clip_grad_norm_ + torch.optim.AdamW (trainer.py:356-381) as two kernels over the flat
     parameter / gradient buffers vs the PyTorch CPU implementation, 3 steps with clipping active."""

@@ -621,11 +621,13 @@ def test_distributed_data_parallel_wrapper_gives_the_same_gradients():
         loss1, g1 = step(hip, FlatGradReducer(compress=None, force=True))
         ddp = DistributedDataParallel(hip, device_ids=[torch.cuda.current_device()])
         loss2, g2 = step(ddp)
-        assert loss0 == loss1 == loss2
+        assert abs(loss0 - loss1) < 1e-6 * abs(loss0) and abs(loss0 - loss2) < 1e-6 * abs(loss0)
         assert set(g0) == set(g1) == set(g2) and len(g0) > 20
-        for k in g0:
-            assert torch.equal(g0[k], g1[k]), k
-            assert torch.allclose(g0[k], g2[k], rtol=1e-6, atol=1e-9), k
+        for k in g0:                       # (fp32-mode split-K sums are atomic: equal up to the order of the additions)
+            # (+ 1e-5: the bias in front of a softmax has a zero gradient in exact arithmetic, rounding noise here)
+            bound = 1e-4 * float(g0[k].norm()) + 1e-5
+            assert float((g0[k] - g1[k]).norm()) < bound, k
+            assert float((g0[k] - g2[k]).norm()) < bound, k
     finally:
         hip.grad_reducer = None
         dist.destroy_process_group()

@@ -1,8 +1,11 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-O=gpurun_out/r02s_train_scan.txt; : > $O
-for a in "--meta-batch-size 8 --batch-size 64" "--meta-batch-size 8 --batch-size 8" "--meta-batch-size 1 --batch-size 64" "--meta-batch-size 8 --batch-size 64 --miopen --steps 63" "--meta-batch-size 8 --batch-size 64 --amp"; do
+timeout 800 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "distributed_data_parallel" 2>&1 | tail -12
+O=gpurun_out/r02t_force_ddp.txt; : > $O
+for a in "--force-ddp" "--force-ddp --grad-allreduce f32" "--force-ddp --grad-allreduce f32-serial"; do
   echo "== $a" >> $O
-  timeout 900 python examples/train_ghn_ddp.py --steps 23 $a 2>&1 | tail -1 >> $O
+  timeout 600 python bench.py --steps 60 --warmup 10 --no-cpu-baseline --no-extras $a 2>>gpurun_out/r02t.err | grep '^{"metric' | python -c "
+import sys, json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], d['config'].get('grad_allreduce'))" >> $O
 done
 cat $O

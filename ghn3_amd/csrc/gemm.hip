@@ -875,6 +875,157 @@ void gemm_h16d_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int to
 }
 
 // ------------------------------------------------------------------------------------------------
+// 256 x 256 PERSISTENT variant for output-heavy problems (tile code 25): the decoder's W2 weight gradient is
+// dW2 [o i x 8C] = d_tiles^T u with K = the family's rows (<= 768: twelve k-tiles) -- every tile computes for ~5 us and
+// then writes 256 KB.  In the kernel above a workgroup owns the CU (128 KB of LDS), so nothing overlaps its prologue
+// (first DMA round trip), its LDS-staged epilogue and its stores: the matrix cores idle half the time (measured 534 TF
+// standalone against 864-921 TF for K = 3072).  Here
+//   * a workgroup walks its tiles (tile += gridDim.x) and issues the FIRST k-tile of the next tile in the last
+//     iteration of the current one -- the stage it lands in was released by the barrier of that iteration;
+//   * the products are computed TRANSPOSED (operands swapped: D^T = B_tile A_tile^T), so that in the 32 x 32 C/D layout a
+//     lane is an output ROW and its registers 4 g .. 4 g + 3 are 4 consecutive COLUMNS: the epilogue is 32 float4
+//     stores per lane straight from the accumulators -- no LDS staging, no barrier, and it runs while the next tile's
+//     first k-tile is in flight (the store acknowledgements and that DMA share one s_waitcnt vmcnt(0)).
+// Plain problems only (the host checks): C = alpha * A B^T with an optional row map of C; no bias / activation /
+// residual / accumulate, no gathers, no k-map, no ragged extents, no split-K.
+// ------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(512)
+void gemm_h16w_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int total_tiles) {
+    constexpr int BM = 256, BN = 256, BK = 64, WGN = 4, NT = 512, TM = 4, TN = 2;
+    constexpr int OPA = BM * BK * 2, OPB = BN * BK * 2, STAGE = OPA + OPB;
+    constexpr int PA = BM * 8 / NT, PB = BN * 8 / NT;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* sm = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm0 = (wave / WGN) * (BM / 2), wn0 = (wave % WGN) * 64;
+    const int l31 = lane & 31, lhi = lane >> 5;
+    const int slot = tid & 7, rbase = tid >> 3;
+    const int ck = (slot ^ ((rbase >> 1) & 7)) * 8;          // k offset of this lane's 16-byte chunk (swizzled source)
+
+    gch pa[PA], pb[PB];
+    const GemmProbDev* P = nullptr;
+    int m0 = 0, n0 = 0, nkt = 0;
+    // first valid tile at or behind `t` (surplus ids of the XCD-aware order are skipped); sets P, m0, n0, nkt, pa, pb
+    auto setup = [&](int t) -> int {
+        for (; t < total_tiles; t += gridDim.x) {
+            const GemmProbDev* Q = find_problem(probs, n_probs, t);
+            int kz;
+            if (!tile_origin<BM, BN>(Q, t - Q->tile_start, m0, n0, kz)) continue;
+            P = Q;
+            nkt = (Q->K + BK - 1) / BK;
+            gch A = (gch)Q->A; gch B = (gch)Q->B;
+#pragma unroll
+            for (int i = 0; i < PA; ++i)
+                pa[i] = A + (int64_t)min(m0 + rbase + (NT / 8) * i, Q->M - 1) * Q->lda + ck;
+#pragma unroll
+            for (int i = 0; i < PB; ++i)
+                pb[i] = B + (int64_t)min(n0 + rbase + (NT / 8) * i, Q->N - 1) * Q->ldb + ck;
+            return t;
+        }
+        return total_tiles;
+    };
+    auto issue = [&](int kt, int stage) {                     // k-tile kt of the tile described by pa / pb
+        LAS char* la = (LAS char*)(sm + stage * STAGE);
+#pragma unroll
+        for (int j = 0; j < PA; ++j)
+            __builtin_amdgcn_global_load_lds((const void GAS*)(pa[j] + kt * BK), (LAS void*)(la + (wave * 64 + NT * j) * 16),
+                                             16, 0, 0);
+#pragma unroll
+        for (int j = 0; j < PB; ++j)
+            __builtin_amdgcn_global_load_lds((const void GAS*)(pb[j] + kt * BK),
+                                             (LAS void*)(la + OPA + (wave * 64 + NT * j) * 16), 16, 0, 0);
+    };
+
+    int tile = setup(blockIdx.x);
+    int st = 0;                                               // stage that holds k-tile 0 of the current tile
+    if (tile < total_tiles) issue(0, 0);
+    while (tile < total_tiles) {
+        // what the epilogue needs of the current tile (pa / pb / P are re-used for the next one inside the loop)
+        const GemmProbDev* Pc = P;
+        const int cm0 = m0, cn0 = n0, cnkt = nkt;
+        int next_tile = total_tiles;
+        f32x16 acc[TM][TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int i = 0; i < cnkt; ++i) {
+            wait_vmcnt<0>();                                  // k-tile i landed (and the previous tile's stores are out)
+            __builtin_amdgcn_s_barrier();
+            const int s_cur = (st + i) & 1;
+            const char* a_s = sm + s_cur * STAGE;
+            const char* b_s = a_s + OPA;
+            u16x8 af[2][TM], bf[2][TN];
+            auto load_frags = [&](int kk, int buf) {
+                const int sl = kk * 2 + lhi;
+#pragma unroll
+                for (int ii = 0; ii < TM; ++ii) {
+                    const int row = wm0 + ii * 32 + l31;
+                    af[buf][ii] = *reinterpret_cast<const u16x8*>(a_s + row * 128 + ((sl ^ ((row >> 1) & 7)) << 4));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int row = wn0 + j * 32 + l31;
+                    bf[buf][j] = *reinterpret_cast<const u16x8*>(b_s + row * 128 + ((sl ^ ((row >> 1) & 7)) << 4));
+                }
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int kk = 0; kk < BK / 16; ++kk) {
+                if (kk + 1 < BK / 16) load_frags(kk + 1, (kk + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int ii = 0; ii < TM; ++ii)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[ii][j] = mfma16<CT>(bf[kk & 1][j], af[kk & 1][ii], acc[ii][j]);   // transposed block
+                __builtin_amdgcn_sched_barrier(0);
+                if (kk == 0) {
+                    if (i + 1 < cnkt) {
+                        issue(i + 1, s_cur ^ 1);
+                    } else {
+                        next_tile = setup(tile + gridDim.x);  // pa / pb of the current tile are dead from here on
+                        if (next_tile < total_tiles) issue(0, s_cur ^ 1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+        // epilogue: lane = output row (l31 of a 32-row block), registers 4 g .. 4 g + 3 = columns 8 g + 4 lhi .. + 3
+        {
+            gf C = (gf)Pc->C;
+            const float alpha = Pc->alpha_amax ? Pc->alpha * ghn3_pow2_inv_scale(*Pc->alpha_amax) : Pc->alpha;
+#pragma unroll
+            for (int ii = 0; ii < TM; ++ii) {
+                const int row = cm0 + wm0 + ii * 32 + l31;
+                if (row >= Pc->M) continue;
+                float GAS* crow = C + (int64_t)map_row(row, nullptr, Pc->c_q, Pc->c_s) * Pc->ldc;
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const int col = cn0 + wn0 + j * 32 + 8 * g + 4 * lhi;
+                        if (col + 3 < Pc->N) {
+                            f32x4 v = {acc[ii][j][4 * g] * alpha, acc[ii][j][4 * g + 1] * alpha,
+                                       acc[ii][j][4 * g + 2] * alpha, acc[ii][j][4 * g + 3] * alpha};
+                            *reinterpret_cast<gf4>(crow + col) = v;
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (col + e < Pc->N) crow[col + e] = acc[ii][j][4 * g + e] * alpha;
+                        }
+                    }
+            }
+        }
+        st = (st + cnkt) & 1;
+        tile = next_tile;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // 256 x 256 "ping-pong" variant of the 16-bit-operand kernel (tile code 26).
 //
 // The two-stage kernel above runs all 8 waves of a workgroup in the same phase: everybody reads fragments, then everybody
@@ -1116,6 +1267,8 @@ static H16dVariant g_h16d[] = {
 };
 static int g_h16d_small = 0, g_h16d_big = 1;
 static h16d_fn g_h16p[2] = {gemm_h16p_kernel<GHN3_CT_F16>, gemm_h16p_kernel<GHN3_CT_BF16>};
+static h16d_fn g_h16w[2] = {gemm_h16w_kernel<GHN3_CT_F16>, gemm_h16w_kernel<GHN3_CT_BF16>};
+static int g_n_cu = 256;
 static h16d_fn g_h16p_dbg[4] = {nullptr, gemm_h16p_kernel<GHN3_CT_F16, 1>, gemm_h16p_kernel<GHN3_CT_F16, 2>,
                                 gemm_h16p_kernel<GHN3_CT_F16, 3>};
 static int g_pp_dbg = 0;
@@ -1182,6 +1335,14 @@ int ghn3_gemm_init() {
     for (int ct = 0; ct < 2; ++ct) {
         hipError_t e = hipFuncSetAttribute((const void*)g_h16p[ct], hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(h16p): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
+        e = hipFuncSetAttribute((const void*)g_h16w[ct], hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(h16w): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
+    }
+    {
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0)
+            g_n_cu = n_cu;
     }
     if (getenv("GHN3_PINGPONG")) g_pingpong = atoi(getenv("GHN3_PINGPONG"));
     if (getenv("GHN3_PP_DEBUG")) g_pp_dbg = atoi(getenv("GHN3_PP_DEBUG")) & 3;
@@ -1194,10 +1355,19 @@ int ghn3_gemm_init() {
 int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int tile, int ctype, int grid_cap,
                           hipStream_t stream) {
     if (n_probs <= 0 || total_tiles <= 0) return GHN3_OK;
-    if ((ctype != GHN3_CT_F16 && ctype != GHN3_CT_BF16) || (tile != 128 && tile != 256 && tile != 20)) {
+    if ((ctype != GHN3_CT_F16 && ctype != GHN3_CT_BF16) || (tile != 128 && tile != 256 && tile != 20 && tile != 25)) {
         ghn3_set_error("16-bit-operand GEMM needs compute type f16 or bf16 (got %d) and tile 128 / 256 (got %d)", ctype,
                        tile);
         return GHN3_E_ARG;
+    }
+    if (tile == 25) {
+        // persistent by construction: one workgroup per CU (or per CU the caller leaves to this launch)
+        const int want = grid_cap > 0 ? grid_cap : g_n_cu;
+        hipLaunchKernelGGL(g_h16w[ctype == GHN3_CT_BF16], dim3(want < total_tiles ? want : total_tiles), dim3(512),
+                           128 * 1024, stream, d_probs, n_probs, total_tiles);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { ghn3_set_error("h16w gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
+        return GHN3_OK;
     }
     // grid_cap counts CUs' worth of workgroups: the 128 x 128 variant runs two workgroups per CU
     if (tile == 128) grid_cap *= 2;

@@ -203,7 +203,7 @@ static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
     if (p.flags & GHN3_GEMM_OP16) {
         // tile codes 16 / 24 = the 16-bit-operand kernel with 128 x 128 / 256 x 256 tiles.  The big tile has twice
         // the arithmetic intensity but runs one 512-thread block per CU: it needs enough tiles to fill the chip.
-        if (forced == 16 || forced == 24 || forced == 20) return forced;
+        if (forced == 16 || forced == 24 || forced == 20 || forced == 25) return forced;
         const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) * (p.ksplit > 1 ? p.ksplit : 1);
         const double eff = ((double)p.M / (((p.M + 255) / 256) * 256.0)) * ((double)p.N / (((p.N + 255) / 256) * 256.0));
         return (t256 >= 200 && eff >= 0.8) ? 24 : 16;
@@ -219,6 +219,7 @@ static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
 }
 
 struct Launch { int a_mode, b_mode, tile, first, count, tiles, with_ln, max_slice; };
+static inline bool is16(int tl) { return tl == 16 || tl == 24 || tl == 20 || tl == 25; }   // 16-bit-operand kernels
 
 extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_gemm_problem* problems, int n_problems,
                         void* const* bufs, int n_bufs, void* stream_) {
@@ -255,10 +256,10 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             // bucket by (a_mode, b_mode, tile)
             for (int am = 0; am < 2; ++am)
                 for (int bm = 0; bm < 2; ++bm)
-                    for (int tl : {16, 20, 24, 32, 64, 128, 4001, 4002, 4003, 4004, 4006, 4011, 4012, 4013, 4014, 4021,
+                    for (int tl : {16, 20, 24, 25, 32, 64, 128, 4001, 4002, 4003, 4004, 4006, 4011, 4012, 4013, 4014, 4021,
                                    4022, 4023, 4024, 4026}) {
                         Launch L{am, bm, tl, (int)pos, 0, 0, 0, 0};
-                        int te = tl == 16 ? 128 : (tl == 24 || tl == 20) ? 256 : tl;         // tile edge (rows)
+                        int te = tl == 16 ? 128 : (tl == 24 || tl == 20 || tl == 25) ? 256 : tl;         // tile edge (rows)
                         int te_n = tl == 20 ? 128 : te;                                        // (columns)
                         const bool x3 = tl >= 4000;
                         if (x3 && !ghn3_gemm_x3_tile(40 + (tl - 4000) / 10, 64 * (tl % 10), &te, &te_n)) continue;
@@ -266,7 +267,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             const ghn3_gemm_problem& p = problems[q];
                             if (p.M <= 0 || p.N <= 0) continue;
                             if (p.a_mode != am || p.b_mode != bm || pick_tile(p, forced, op_t64) != tl) continue;
-                            if ((tl == 16 || tl == 24 || tl == 20) && (p.a_mode != GHN3_MODE_ROW || p.b_mode != GHN3_MODE_ROW || (p.lda & 7) ||
+                            if (is16(tl) && (p.a_mode != GHN3_MODE_ROW || p.b_mode != GHN3_MODE_ROW || (p.lda & 7) ||
                                              (p.ldb & 7) || (p.b_kq & 7) || (p.flags & GHN3_GEMM_BIASGRAD) ||
                                              p.K >= (1 << 24) || (p.ldc & 3) || (p.C.off & 15) ||
                                              p.act == GHN3_ACT_GELU || p.dact == GHN3_DACT_GELU ||
@@ -274,6 +275,14 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                 ghn3_set_error("op %d problem %d: 16-bit operands need ROW/ROW modes, ld %% 8 == 0, "
                                                "b_kq %% 8 == 0, K < 2^24, no BIASGRAD / GELU, ldc %% 4 == 0 and "
                                                "16-byte aligned C / aux / residual", k, q);
+                                return GHN3_E_ARG;
+                            }
+                            if (tl == 25 && (p.bias.buf >= 0 || p.residual.buf >= 0 || p.aux_in.buf >= 0 || p.aux_out.buf >= 0 ||
+                                             p.act != GHN3_ACT_NONE || p.dact != GHN3_DACT_NONE || p.a_gather.buf >= 0 ||
+                                             p.b_gather.buf >= 0 || p.c_gather.buf >= 0 || p.a_q || p.b_q || p.b_kq ||
+                                             p.lim.buf >= 0 || p.ksplit > 1 || (p.flags & GHN3_GEMM_ACCUM))) {
+                                ghn3_set_error("op %d problem %d: tile 25 (persistent output-heavy kernel) takes plain "
+                                               "problems only: C = alpha A B^T with an optional row map of C", k, q);
                                 return GHN3_E_ARG;
                             }
                             if (x3 && (p.a_mode != GHN3_MODE_ROW || p.b_mode != GHN3_MODE_ROW || p.a_gather.buf >= 0 ||
@@ -319,10 +328,10 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             g.tile_start = L.tiles;               // always a multiple of 8 (XCD-aware order)
                             g.tiles_m = (p.M + te - 1) / te;
                             g.tiles_n = (p.N + te_n - 1) / te_n;
-                            g.kq = (tl == 16 || tl == 24 || tl == 20) ? p.b_kq : 0; g.ks = p.b_ks;
-                            g.lim = (tl == 16 || tl == 24 || tl == 20) ? R.get<const int>(p.lim) : nullptr;
+                            g.kq = is16(tl) ? p.b_kq : 0; g.ks = p.b_ks;
+                            g.lim = is16(tl) ? R.get<const int>(p.lim) : nullptr;
                             g.lim_kind = g.lim ? p.lim_kind : 0;
-                            g.alpha_amax = (tl == 16 || tl == 24 || tl == 20) ? R.get<const float>(p.alpha_amax) : nullptr;
+                            g.alpha_amax = is16(tl) ? R.get<const float>(p.alpha_amax) : nullptr;
                             g.B2 = x3 ? R.get<const void>(p.B2) : nullptr;
                             if (x3 && p.x3_slice > L.max_slice) L.max_slice = p.x3_slice;
                             g.ln_kind = p.ln_kind; g.ln_eps = p.ln_eps;
@@ -439,8 +448,9 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                              64 * (L.tile % 10), stream);
                 else if (L.tile == 32)
                     rc = ghn3_gemm_small_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, L.with_ln, stream);
-                else if (L.tile == 16 || L.tile == 24 || L.tile == 20)
-                    rc = ghn3_gemm_h16d_launch(ds + L.first, L.count, L.tiles, L.tile == 16 ? 128 : L.tile == 20 ? 20 : 256,
+                else if (is16(L.tile))
+                    rc = ghn3_gemm_h16d_launch(ds + L.first, L.count, L.tiles,
+                                               L.tile == 16 ? 128 : L.tile == 20 ? 20 : L.tile == 25 ? 25 : 256,
                                                (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, (int)o.i[3],
                                                stream);
                 else

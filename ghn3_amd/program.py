@@ -1477,11 +1477,14 @@ class Program:
                                   self.gref(W2, (o_lo * ms[1] + b_['i_lo']) * 8 * C), (o_hi - o_lo) * b_['bw'], 8 * C,
                                   kpre, b_['ktot'], b_['ktot'], 8 * C, c_qs=(b_['bw'], ms[1]), op16=True,
                                   alpha_amax=amax_t)
-                # GHN3_WGRAD_CAP=n: the side-stream launch as n CUs' worth of persistent workgroups, so that the dependent
-                # chain on the main stream keeps CUs of its own.  Measured at n = 192: the step 8.65 -> 8.54 ms, but the
-                # weight gradient itself 1.46 -> 1.72 ms (the family's roofline fraction drops); off by default.
+                # tile 25 = the persistent output-heavy kernel (K = the family's rows: 12 k-tiles per 256 KB of output):
+                # 1.44 -> 1.10 ms.  On the side stream it runs as 224 workgroups (GHN3_WGRAD_CAP), leaving 4 CUs per XCD
+                # to the dependent chain on the main stream, which the faster kernel otherwise slows down by what it
+                # gained (step 8.51 ms with the old kernel, 8.56 with tile 25 on every CU, 8.46 at 224, 8.38 at 192 --
+                # but there the weight gradient is back at 1.49 ms).
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=True, flops=fl,
-                             grid_cap=int(os.environ.get('GHN3_WGRAD_CAP', '0')) if self.SIDE else 0)
+                             tile=int(os.environ.get('GHN3_WGRAD_TILE', '25')),
+                             grid_cap=int(os.environ.get('GHN3_WGRAD_CAP', '224')) if self.SIDE else 0)
             fam_list = bands
             for gi, g in enumerate(self.gemm_groups):
                 if g['op16']:

@@ -199,7 +199,8 @@ typedef struct ghn3_tile_desc {
 enum ghn3_op_kind {
     GHN3_OP_NOP = 0,
     /* i: first_problem, n_problems, tile (0 auto / 32 / 64 / 128 for fp32 operands; 0 auto / 16 = 128x128 / 24 = 256x256 /
-     * 20 = 256x128 with a three-stage ring for GHN3_GEMM_OP16 problems), grid cap for GHN3_GEMM_OP16 launches (0 = one workgroup per tile; > 0: at most
+     * 20 = 256x128 with a three-stage ring / 25 = persistent 256x256 for output-heavy PLAIN problems (C = alpha A B^T,
+     * optional row map of C: short K, e.g. the W2 weight gradient) for GHN3_GEMM_OP16 problems), grid cap for GHN3_GEMM_OP16 launches (0 = one workgroup per tile; > 0: at most
      * that many CUs' worth of persistent workgroups -- a side-stream GEMM that should leave CUs to the chain it runs beside) */
     GHN3_OP_GEMM = 1,                 /* every nn.Linear / F.linear on the path */
     /* graphormer.py:229-237 -- degree counts of A==1, A[0,:], fw/bw pair index

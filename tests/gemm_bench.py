@@ -126,8 +126,12 @@ def bench16(ctx, M, N, K, ctype, ksplit=1, accum=False, kmap=None, reps=5, name=
 if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == 'wgrad':
     ct = {'f16': L.CT_F16, 'bf16': L.CT_BF16}[sys.argv[1]]
     ctx = L.context(0)
-    for tile in (16, 20, 24):
+    for tile in (16, 20, 24, 25):
+        bench16(ctx, 147456, 3072, 768, ct, name='wgrad K=768', tile=tile)
         bench16(ctx, 147456, 3072, 512, ct, name='wgrad', tile=tile)
+        if tile == 25:
+            bench16(ctx, 147456, 3072, 2048, ct, name='wgrad K=2048', tile=tile)
+            continue
         bench16(ctx, 147456, 3072, 512, ct, name='wgrad A rows -> 256 (L2)', tile=tile, a_qs=(256, 0))
         bench16(ctx, 147456, 3072, 512, ct, name='wgrad C rows -> 256 (L2)', tile=tile, c_qs=(256, 0))
         bench16(ctx, 147456, 3072, 512, ct, name='wgrad A,C rows -> 256', tile=tile, a_qs=(256, 0), c_qs=(256, 0))

@@ -324,6 +324,15 @@ OP16_CASES = [
     dict(M=768, N=200, K=64 * 21, ksplit=3, tile=20),
     dict(M=5, N=7, K=9, tile=20),
     dict(M=300, N=200, K=64, tile=20, accum=True),
+    # the persistent output-heavy variant (tile code 25): transposed products + direct float4 stores, the next tile's
+    # first k-tile issued from the last iteration of the current one; ragged M / N, one and many k-tiles, odd and even
+    # k-tile counts (stage parity carried across tiles), a row map of C, more tiles than workgroups (grid cap)
+    dict(M=300, N=520, K=150, tile=25),
+    dict(M=1100, N=1300, K=512, tile=25, grid_cap=3),
+    dict(M=1100, N=780, K=64 * 3, tile=25, grid_cap=2),
+    dict(M=700, N=3072 // 4, K=64, tile=25, grid_cap=2, cmap=True),
+    dict(M=5, N=7, K=9, tile=25),
+    dict(M=2048, N=1024, K=768, a_transposed=True, b_transposed=True, tile=25, grid_cap=5),
     # persistent workgroups (grid cap): 3 workgroups stride over 99 / 30 tiles
     dict(M=1100, N=1300, K=512, epilogue='bias_relu', grid_cap=3),
     dict(M=1100, N=1300, K=200, tile=24, grid_cap=3, accum=True),

@@ -26,6 +26,14 @@
 
 #define ATT_DMAX 32
 #define ATT_NMAX 4096
+// tools/attn_probe.hip builds this file with GHN3_ATTN_PROBE: wave 0 of block (0,0,0) leaves shader-clock stamps
+#ifdef GHN3_ATTN_PROBE
+__device__ long long g_attn_stamps[64];
+#define ATT_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) \
+    g_attn_stamps[stamp_base + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define ATT_STAMP(i) do { } while (0)
+#endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
@@ -75,6 +83,53 @@ __device__ __forceinline__ void load_col_operand(const float* __restrict__ X, in
     }
 }
 
+// Cooperative, coalesced copy of the block's head slices into LDS: 32 query rows (from row i0), then `nkeys` key rows and
+// `nkeys` value rows (from row 0); rows beyond N are zero.  LDS rows of ldw floats, one lane per 16-byte chunk
+// (consecutive lanes read consecutive chunks of a row, then the next row: 96-byte runs at d = 24 instead of one cache
+// line per lane), and EVERY load is issued before the first LDS write: one memory round trip for the whole prologue
+// (copying in batches measured one dependent round trip per batch: 6.5k of the kernel's 20k cycles).
+__device__ __forceinline__ void stage_head_slices(float* __restrict__ dst, int ldw, const float* __restrict__ base,
+                                                  int C, int i0, int nkeys, int N, int d, bool vec, int tid) {
+    const size_t stride = (size_t)3 * C;
+    const int rows = 32 + 2 * nkeys;
+    auto source = [&](int r) -> const float* {      // nullptr: zero row
+        if (r < 32) return i0 + r < N ? base + (size_t)(i0 + r) * stride : nullptr;
+        r -= 32;
+        if (r < nkeys) return r < N ? base + (size_t)r * stride + C : nullptr;
+        r -= nkeys;
+        return r < N ? base + (size_t)r * stride + 2 * C : nullptr;
+    };
+    if (vec) {
+        const int chunks = d >> 2;
+        const int rpp = 256 / chunks;                // rows per pass
+        const int r0 = tid / chunks, c = tid - r0 * chunks;
+        const bool lane_on = r0 < rpp;
+        constexpr int G = 18;                        // >= ceil(544 / (256 / 8)) passes at d = 32
+        f32x4 v[G];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int r = g * rpp + r0;
+            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+            v[g] = z;
+            if (lane_on && r < rows) {
+                const float* p = source(r);
+                if (p) v[g] = *reinterpret_cast<const f32x4*>(p + 4 * c);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            const int r = g * rpp + r0;
+            if (lane_on && r < rows) *reinterpret_cast<f32x4*>(dst + r * ldw + 4 * c) = v[g];
+        }
+    } else {
+        for (int f = tid; f < rows * d; f += 256) {
+            const int r = f / d, e = f - r * d;
+            const float* p = source(r);
+            dst[r * ldw + e] = p ? p[e] : 0.f;
+        }
+    }
+}
+
 template <int KS>
 __device__ __forceinline__ f32x16 mfma_rows(const float (&a)[KS], const float (&b)[KS], f32x16 acc) {
 #pragma unroll
@@ -117,12 +172,13 @@ __device__ __forceinline__ void store4(float* __restrict__ dst, int e0, int d, b
 // forward: grid (ceil(N / 32), H, B), 256 threads; wave w owns key tiles w, w + 4, ... (TPW of them)
 // ------------------------------------------------------------------------------------------------
 template <int KS, int TPW>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, const float* __restrict__ qkv,
-                                                       const float* __restrict__ bias, float* __restrict__ Psave,
-                                                       const int* __restrict__ n_nodes, int N, int C, int H,
-                                                       float scale, int vec) {
+__device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const float* __restrict__ qkv,
+                                              const float* __restrict__ bias, float* __restrict__ Psave,
+                                              const int* __restrict__ n_nodes, int N, int C, int H, float scale, int vec,
+                                              int stamp_base) {
     __shared__ float red[4 * 16 * 64];
     __shared__ float red_m[4][32], red_l[4][32];
+    extern __shared__ __attribute__((aligned(16))) float stage[];   // TPW <= 2: Q | K | V head slices (see below)
     const int d = C / H;
     const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * 32;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
@@ -132,19 +188,23 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, 
     const int qi = i0 + l31;                                    // this lane's query
     const bool vq = (d & 3) == 0 && vec;
 
-    float qb[KS];
-    load_row_operand<KS>(qi < N ? base + (size_t)qi * 3 * C : nullptr, d, lhi, vq, qb);
-    // PRE (N <= 256): every operand of the wave's tiles is loaded up front (all loads in flight at once, V^T
-    // during the softmax); larger N keeps only the score tiles in registers and loads operands per tile.
+    ATT_STAMP(0);
+    // PRE (N <= 256): the head slices of the block's 32 queries and of ALL keys / values are staged in LDS with
+    // coalesced loads (one pass, every load in flight at once) and the MFMA operands are read from there; larger N
+    // keeps only the score tiles in registers and loads operands per tile from memory.
     constexpr bool PRE = TPW <= 2;
     constexpr int TP = PRE ? TPW : 1;
+    const int ldw = ((d + 3) & ~3) + 4;                          // padded LDS row (16-byte aligned for the float4 copy)
+    const int nkeys = TPW * 128;                                 // keys covered by the block's 4 waves
+    float* Qs = stage;
+    float* Ks = stage + 32 * ldw;
+    float* Vs = Ks + nkeys * ldw;
+    float qb[KS];
     float ka[TP][KS];
     if (PRE) {
-#pragma unroll
-        for (int k = 0; k < TP; ++k) {
-            const int j = (w + 4 * k) * 32 + l31;
-            load_row_operand<KS>(j < N ? base + (size_t)j * 3 * C + C : nullptr, d, lhi, vq, ka[k]);
-        }
+        stage_head_slices(stage, ldw, base, C, i0, nkeys, N, d, vq, tid);
+    } else {
+        load_row_operand<KS>(qi < N ? base + (size_t)qi * 3 * C : nullptr, d, lhi, vq, qb);
     }
     // edge bias of this lane's query row: register r <-> key tile * 32 + acc_row(r, lhi) (4 runs of 4 keys)
     f32x16 S[TPW];
@@ -169,14 +229,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, 
             }
         }
     }
-    // V^T operands are independent of the softmax: issue their loads now
     float va[TP][16];
     if (PRE) {
+        __syncthreads();                                         // the staged slices are complete
 #pragma unroll
-        for (int k = 0; k < TP; ++k)
-            load_col_operand(base + 2 * C, (w + 4 * k) * 32, N, (size_t)3 * C, l31, d, lhi, va[k]);
+        for (int sx = 0; sx < KS; ++sx) {
+            const int kx = 2 * sx + lhi;
+            qb[sx] = kx < d ? Qs[l31 * ldw + kx] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < TP; ++k) {
+            const int j0 = (w + 4 * k) * 32;
+#pragma unroll
+            for (int sx = 0; sx < KS; ++sx) {
+                const int kx = 2 * sx + lhi;
+                ka[k][sx] = kx < d ? Ks[(j0 + l31) * ldw + kx] : 0.f;
+            }
+#pragma unroll
+            for (int sx = 0; sx < 16; ++sx)
+                va[k][sx] = l31 < d ? Vs[(j0 + acc_row(sx, lhi)) * ldw + l31] : 0.f;
+        }
     }
 
+    ATT_STAMP(1);
     float mx = -INFINITY;
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
@@ -198,9 +273,11 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, 
         }
         S[k] = acc;
     }
+    ATT_STAMP(2);
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
     if (lhi == 0) red_m[w][l31] = mx;
     __syncthreads();
+    ATT_STAMP(3);
     mx = fmaxf(fmaxf(red_m[0][l31], red_m[1][l31]), fmaxf(red_m[2][l31], red_m[3][l31]));
     float sum = 0.f;
 #pragma unroll
@@ -214,6 +291,7 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, 
     sum += __shfl_xor(sum, 32, 64);
     if (lhi == 0) red_l[w][l31] = sum;
     __syncthreads();
+    ATT_STAMP(4);
     const float inv = 1.f / (red_l[0][l31] + red_l[1][l31] + red_l[2][l31] + red_l[3][l31]);
     f32x16 O = zero16();
 #pragma unroll
@@ -239,8 +317,18 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, 
         if (!PRE && j0 < N) load_col_operand(base + 2 * C, j0, N, (size_t)3 * C, l31, d, lhi, va[0]);
         if (j0 < N) O = mfma_cols(va[PRE ? k : 0], S[k], O);       // O^T += V^T P^T
     }
+    ATT_STAMP(5);
     const f32x4 o = reduce_waves(red, O, w, lane);
+    ATT_STAMP(6);
     if (qi < N) store4(out + ((size_t)b * N + qi) * C + h * d, 8 * w + 4 * lhi, d, vq, o);
+    ATT_STAMP(7);
+}
+template <int KS, int TPW>
+__global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, const float* __restrict__ qkv,
+                                                       const float* __restrict__ bias, float* __restrict__ Psave,
+                                                       const int* __restrict__ n_nodes, int N, int C, int H,
+                                                       float scale, int vec) {
+    attn_fwd_body<KS, TPW>(out, qkv, bias, Psave, n_nodes, N, C, H, scale, vec, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -533,8 +621,14 @@ int ghn3_attn_fwd(float* out, const float* qkv, const float* bias, float* P, con
     const float scale = 1.0f / sqrtf((float)d);
     const int nb = (N + 31) / 32, tpw = (nb + 3) / 4;
     const int vec = (C % 4 == 0) && aligned16(out) && aligned16(qkv) && aligned16(bias) && aligned16(P);
-    hipLaunchKernelGGL(pick_fwd(d, tpw), dim3(nb, H, B), dim3(256), 0, s, out, qkv, bias, P, n_nodes, N, C, H, scale,
-                       vec);
+    // TPW <= 2 variants stage Q (32 rows) + K + V (tpw * 128 rows each) head slices in LDS
+    const size_t lds = tpw <= 2 ? (size_t)(32 + 2 * 2 * 128) * (((d + 3) & ~3) + 4) * sizeof(float) : 0;
+    attn_fwd_fn fn = pick_fwd(d, tpw);
+    if (lds > 32 * 1024) {
+        hipError_t ea = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) { ghn3_set_error("attn fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(ea)); return GHN3_E_HIP; }
+    }
+    hipLaunchKernelGGL(fn, dim3(nb, H, B), dim3(256), lds, s, out, qkv, bias, P, n_nodes, N, C, H, scale, vec);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("attn fwd launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

@@ -171,7 +171,7 @@ __device__ __forceinline__ void store4(float* __restrict__ dst, int e0, int d, b
 // ------------------------------------------------------------------------------------------------
 // forward: grid (ceil(N / 32), H, B), 256 threads; wave w owns key tiles w, w + 4, ... (TPW of them)
 // ------------------------------------------------------------------------------------------------
-template <int KS, int TPW>
+template <int KS, int TPW, int QB>
 __device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const float* __restrict__ qkv,
                                               const float* __restrict__ bias, float* __restrict__ Psave,
                                               const int* __restrict__ n_nodes, int N, int C, int H, float scale, int vec,
@@ -180,12 +180,15 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const flo
     __shared__ float red_m[4][32], red_l[4][32];
     extern __shared__ __attribute__((aligned(16))) float stage[];   // TPW <= 2: Q | K | V head slices (see below)
     const int d = C / H;
-    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * 32;
+    const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * QB;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
     const int nb = n_nodes[b];
     const float* base = qkv + (size_t)b * N * 3 * C + h * d;
     const size_t bh = ((size_t)b * H + h) * N;
-    const int qi = i0 + l31;                                    // this lane's query
+    // QB = 16: a block owns 16 queries (lanes 16-31 of the 32-row MFMA tiles idle) -- twice the workgroups, so that a
+    // short graph's launch covers every CU: the kernel is bound by what ONE CU can fetch (~14 B/clk, the K / V slices
+    // of all keys + the bias rows + the probabilities of its queries), not by the matrix cores
+    const int qi = l31 < QB ? i0 + l31 : N;                     // this lane's query (N: none)
     const bool vq = (d & 3) == 0 && vec;
 
     ATT_STAMP(0);
@@ -323,12 +326,12 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const flo
     if (qi < N) store4(out + ((size_t)b * N + qi) * C + h * d, 8 * w + 4 * lhi, d, vq, o);
     ATT_STAMP(7);
 }
-template <int KS, int TPW>
+template <int KS, int TPW, int QB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, const float* __restrict__ qkv,
                                                        const float* __restrict__ bias, float* __restrict__ Psave,
                                                        const int* __restrict__ n_nodes, int N, int C, int H,
                                                        float scale, int vec) {
-    attn_fwd_body<KS, TPW>(out, qkv, bias, Psave, n_nodes, N, C, H, scale, vec, 0);
+    attn_fwd_body<KS, TPW, QB>(out, qkv, bias, Psave, n_nodes, N, C, H, scale, vec, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -584,7 +587,7 @@ typedef void (*attn_bwd_fn)(float*, const float*, const float*, const float*, co
 
 template <int KS> static attn_fwd_fn fwd_for(int tpw) {
     if (tpw > 8) return (attn_fwd_fn)attn_fwd_stream_kernel<KS>;          // N > 1024
-    return tpw <= 2 ? (attn_fwd_fn)attn_fwd_kernel<KS, 2> : (attn_fwd_fn)attn_fwd_kernel<KS, 8>;
+    return tpw <= 2 ? (attn_fwd_fn)attn_fwd_kernel<KS, 2, 16> : (attn_fwd_fn)attn_fwd_kernel<KS, 8, 32>;
 }
 static attn_fwd_fn pick_fwd(int d, int tpw) {
     if (d <= 4) return fwd_for<2>(tpw);
@@ -628,7 +631,9 @@ int ghn3_attn_fwd(float* out, const float* qkv, const float* bias, float* P, con
         hipError_t ea = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (ea != hipSuccess) { ghn3_set_error("attn fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(ea)); return GHN3_E_HIP; }
     }
-    hipLaunchKernelGGL(fn, dim3(nb, H, B), dim3(256), lds, s, out, qkv, bias, P, n_nodes, N, C, H, scale, vec);
+    // (the staged variants own 16 queries per block)
+    hipLaunchKernelGGL(fn, dim3(tpw <= 2 ? (N + 15) / 16 : nb, H, B), dim3(256), lds, s, out, qkv, bias, P, n_nodes, N, C, H,
+                       scale, vec);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("attn fwd launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

@@ -910,8 +910,20 @@ void gemm_h16w_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int to
     auto setup = [&](int t) -> int {
         for (; t < total_tiles; t += gridDim.x) {
             const GemmProbDev* Q = find_problem(probs, n_probs, t);
-            int kz;
-            if (!tile_origin<BM, BN>(Q, t - Q->tile_start, m0, n0, kz)) continue;
+            {
+                // XCD-blocked order (workgroup b runs on XCD b % 8; tile ids keep their residue: gridDim.x % 8 == 0).
+                // XCD x = (row class x / G, column group x % G): consecutive tiles of an XCD walk the column tiles of its
+                // group for one row tile (they share that A tile while it streams), then the next row tile of its class;
+                // the group's slice of B (<= 1.5 MB) stays in the XCD's L2.  With every XCD cycling through ALL of B
+                // (4.7 MB for the W2 weight gradient, more than one L2) each tile re-fetched its B tile: 2.7 GB per step.
+                const int tl = t - Q->tile_start, x = tl & 7, grp = tl >> 3;
+                const int G = Q->xcd_cols, Gm = 8 / G;
+                const int npg = (Q->tiles_n + G - 1) / G;
+                const int nt = (x % G) * npg + grp % npg, mt = (grp / npg) * Gm + x / G;
+                if (nt >= Q->tiles_n || mt >= Q->tiles_m) continue;
+                m0 = mt * BM;
+                n0 = nt * BN;
+            }
             P = Q;
             nkt = (Q->K + BK - 1) / BK;
             gch A = (gch)Q->A; gch B = (gch)Q->B;

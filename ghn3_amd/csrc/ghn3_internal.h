@@ -20,7 +20,8 @@ struct GemmProbDev {
     int order;           // 0: m-tiles innermost (B streamed), 1: n-tiles innermost (A streamed)
     int kq, ks;          // 16-bit-operand kernel: k-map of B (kq == 0: identity)
     const int* lim;      // ragged extents per 128 rows (see ghn3_gemm_problem::lim)
-    int lim_kind, _pad3;
+    int lim_kind;
+    int xcd_cols;        // tile code 25: column groups of the XCD-blocked tile order (1, 2, 4 or 8; see gemm_h16w_kernel)
     const float* alpha_amax;   // alpha is divided by ghn3_pow2_scale(*alpha_amax) (operand copies scaled by GHN3_CAST_SCALED)
     int ln_kind;               // row prologue of A (ghn3_gemm_problem::ln_kind), small-problem kernel only
     float ln_eps;

@@ -357,7 +357,19 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                 ghn3_set_error("op %d problem %d: split-K allows no epilogue but alpha", k, q);
                                 return GHN3_E_ARG;
                             }
-                            if (tl == 32 || x3) {
+                            g.xcd_cols = 0;
+                            if (tl == 25) {
+                                // XCD-blocked order of the persistent kernel: the 8 XCDs form a (8 / G) x G grid; an XCD
+                                // works on every (8 / G)-th row tile and on one of G column groups, chosen so that its
+                                // share of B stays in its 4 MB L2 while the A tiles stream through once per column group
+                                static const int64_t b_budget = getenv("GHN3_XCD_B_BYTES") ? atoll(getenv("GHN3_XCD_B_BYTES"))
+                                                                                          : (int64_t)(3 << 19);
+                                int G = 1;
+                                while (G < 8 && (int64_t)p.N * p.K * 2 / G > b_budget && g.tiles_n >= 2 * G) G *= 2;
+                                g.xcd_cols = G;
+                                const int npg = (g.tiles_n + G - 1) / G, mpc = (g.tiles_m + 8 / G - 1) / (8 / G);
+                                L.tiles += 8 * npg * mpc;
+                            } else if (tl == 32 || x3) {
                                 L.tiles += g.tiles_m * g.tiles_n;          // plain order, no padding
                             } else {
                                 const int per_split = g.order ? ((g.tiles_m + 7) / 8 * 8) * g.tiles_n

@@ -95,3 +95,19 @@ def test_trainer_steps_on_sampled_light_networks():
     avg = m.avg()
     assert np.isfinite(avg['loss']) and 0.0 <= avg['top1'] <= 100.0 and tr.skipped_updates == 0
     assert not torch.equal(before, hip._flat)
+
+
+def test_train_ghn_ddp_counterpart_script(tmp_path):
+    """examples/train_ghn_ddp.py (the train_ghn_ddp.py:87-150 sequence on the sampled architecture stream): a few steps
+    with checkpoints, then a second run that resumes from the checkpoint the first one wrote."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, os.path.join(root, 'examples', 'train_ghn_ddp.py'), '--steps', '5', '--meta-batch-size', '2',
+           '--batch-size', '8', '--workers', '2', '--max-nodes', '120', '--save', str(tmp_path)]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert out.returncode == 0, out.stdout[-3000:]
+    assert 'ms per step' in out.stdout and os.path.exists(tmp_path / 'checkpoint.pt'), out.stdout[-1500:]
+    out2 = subprocess.run(cmd + ['--epochs', '2'], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=900)
+    assert out2.returncode == 0, out2.stdout[-3000:]
+    assert 'resuming' in out2.stdout, out2.stdout[-1500:]

@@ -252,29 +252,44 @@ def main():
         pcfg = ghn.program_config()
         tasks = [(args.nodes, args.graphs_per_gpu, seeds + 7919 * (k + 1), pcfg) for k in range(n_fresh + 3)]
         stream_it = pool.imap(_loader_worker, tasks)       # (ordered; the workers run ahead of the consumer)
-        import queue
-        import threading
-        ready = queue.Queue(maxsize=3)
+        # single consumer thread: the device half of the compile (GHN3.plan: asynchronous uploads from reusable pinned
+        # slots) costs ~3 ms of host time and the enqueue of a step ~3 ms -- together less than the GPU's step, so the
+        # loop stays GPU-bound without a prefetch thread (one was measured: with the pool's result thread it made three
+        # Python threads compete for the interpreter lock, 12-23 ms per step)
+        threaded = os.environ.get('GHN3_FRESH_PREFETCH_THREAD', '0') == '1'
+        if threaded:
+            import queue
+            import threading
+            ready = queue.Queue(maxsize=3)
 
-        def prefetch():                                    # waits for the workers + device half of the compile
-            torch.cuda.set_device(local_rank)
-            for _ in range(n_fresh + 3):
-                gbk, netsk, progk = next(stream_it)
-                ready.put(ghn.plan(progk, gbk, netsk))
-        th = threading.Thread(target=prefetch, daemon=True)
-        th.start()
+            def prefetch():                                # waits for the workers + device half of the compile
+                torch.cuda.set_device(local_rank)
+                for _ in range(n_fresh + 3):
+                    gbk, netsk, progk = next(stream_it)
+                    ready.put(ghn.plan(progk, gbk, netsk))
+            th = threading.Thread(target=prefetch, daemon=True)
+            th.start()
         n_fresh_pred = 0
         t_wait = t_enq = 0.0
+        gpu_spans = []
         for k in range(n_fresh + 3):
             if k == 3:
                 torch.cuda.synchronize()
                 t_f = time.perf_counter()
                 t_wait = t_enq = 0.0
             h0 = time.perf_counter()
-            pk = ready.get()
+            if threaded:
+                pk = ready.get()
+            else:
+                gbk, netsk, progk = next(stream_it)
+                pk = ghn.plan(progk, gbk, netsk)
             h1 = time.perf_counter()
             progk = pk.program
+            ea, eb = L.Event(), L.Event()
+            ea.record(stream)
             run_step(ghn, pk, torch.empty(progk.out_numel, dtype=torch.float32, device=dev), progk.norm_ops(1.0))
+            eb.record(stream)
+            gpu_spans.append((ea, eb))
             h2 = time.perf_counter()
             t_wait, t_enq = t_wait + h1 - h0, t_enq + h2 - h1
             if k >= 3:
@@ -282,9 +297,11 @@ def main():
             del pk
         torch.cuda.synchronize()
         dt_f = time.perf_counter() - t_f
-        th.join()
+        if threaded:
+            th.join()
         pool.close()
         extras['fresh_graph_host_ms'] = {'wait_for_plan': 1e3 * t_wait / n_fresh, 'enqueue': 1e3 * t_enq / n_fresh}
+        extras['fresh_graph_gpu_ms'] = sum(a_.elapsed_ms(b_) for a_, b_ in gpu_spans[3:]) / max(1, len(gpu_spans) - 3)
         extras['fresh_graph_ms_per_step'] = 1e3 * dt_f / n_fresh
         extras['fresh_graph_value'] = n_fresh_pred / dt_f
         # (c) the exact-fp32 configuration of the same workload

@@ -107,10 +107,17 @@ class GraphBatch:
         if isinstance(device, (tuple, list)):
             device = device[0]
         self._cat()
-        self.n_nodes = self.n_nodes.to(device, non_blocking=True)
-        self.node_feat = self.node_feat.to(device, non_blocking=True)
-        self.edges = self.edges.to(device, non_blocking=True)
-        self.mask = self.mask.to(device, non_blocking=True)
+        if torch.device(device).type == 'cuda':
+            from .nn import pinned_ring               # reusable pinned staging: asynchronous for the host
+            ring = pinned_ring(device)
+
+            def move(t):
+                return ring.upload(t, device)
+        else:
+            def move(t):
+                return t.to(device, non_blocking=True)
+        self.n_nodes, self.node_feat = move(self.n_nodes), move(self.node_feat)
+        self.edges, self.mask = move(self.edges), move(self.mask)
         return self
 
     def on_device(self, device):

@@ -102,6 +102,57 @@ class SequentialMultipleInOut(nn.Sequential):
 
 
 # ---------------------------------------------------------------------------------------------------
+class _PinnedRing:
+    """Reusable page-locked staging slots for host -> device uploads.  `upload(array, device)` copies the array into a
+    slot and issues an asynchronous copy on the current stream; a slot is reused once its copy has completed.  (Pinning a
+    fresh buffer per upload -- Tensor.pin_memory() -- costs a hipHostMalloc each time: milliseconds; a pageable source
+    makes the copy synchronous.)  ONE arena allocated at first use, two size classes: small tensors (graph fields) and
+    index blobs (a few MB); anything larger than a slot falls back to a synchronous copy."""
+    SMALL, BIG = 1 << 16, 12 << 20
+
+    def __init__(self, small_slots=32, big_slots=6):
+        self.layout = [(self.SMALL, small_slots), (self.BIG, big_slots)]
+        self.arena = None
+        self.next = [0, 0]
+        self.events = [[None] * small_slots, [None] * big_slots]
+
+    def upload(self, array, device):
+        if isinstance(array, torch.Tensor):
+            if array.is_cuda:
+                return array.to(device, non_blocking=True)
+            array = array.numpy()
+        # (numpy for the host-side copy: torch's CPU ops wake a thread pool -- tens of milliseconds on many-core hosts)
+        host = np.ascontiguousarray(array)
+        flat = host.reshape(-1).view(np.uint8)
+        if flat.size > self.BIG or os.environ.get('GHN3_PINNED_UPLOAD', '1') == '0':
+            return torch.from_numpy(host).to(device)
+        if self.arena is None:
+            self.arena = torch.empty(sum(sz * n for sz, n in self.layout), dtype=torch.uint8).pin_memory()
+        c = 0 if flat.size <= self.SMALL else 1
+        k = self.next[c]
+        self.next[c] = (k + 1) % self.layout[c][1]
+        if self.events[c][k] is not None:
+            self.events[c][k].synchronize()
+        base = (0 if c == 0 else self.layout[0][0] * self.layout[0][1]) + k * self.layout[c][0]
+        stage = self.arena[base:base + flat.size]
+        np.copyto(stage.numpy(), flat)
+        out = stage.to(device, non_blocking=True).view(torch.from_numpy(host[:0].reshape(-1)).dtype).view(host.shape)
+        ev = self.events[c][k] or torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        self.events[c][k] = ev
+        return out
+
+
+_RINGS = {}
+
+
+def pinned_ring(device):
+    key = torch.device(device).index or 0
+    if key not in _RINGS:
+        _RINGS[key] = _PinnedRing()
+    return _RINGS[key]
+
+
 class _Plan:
     """A compiled batch: Program + device-resident index blob + workspace."""
 
@@ -110,7 +161,11 @@ class _Plan:
         self.edges = edges
         self.nets = nets
         dev = ghn.device
-        self.idx = torch.from_numpy(program.idx_blob).to(dev)
+        # (reusable pinned staging + asynchronous copy in stream order: a pageable .to(device) blocks the calling thread for
+        # the copy AND for the work queued on the stream before it -- 0.8 ms each, five per plan, in the loop that feeds
+        # the GPU.  A separate upload stream was measured and dropped: buffers allocated on it come from another pool of
+        # the caching allocator, and the 2.3 GB workspace of every plan then costs a hipMalloc.)
+        self.idx = pinned_ring(dev).upload(program.idx_blob, dev)
         # zero-filled once: the padding of the 16-bit operand copies (Program.ws16) must read as finite zeros
         self.ws = torch.zeros(program.ws_bytes, dtype=torch.uint8, device=dev)
         self.scal = torch.zeros(program.scal_bytes, dtype=torch.uint8, device=dev)
@@ -248,11 +303,16 @@ class GHN3(nn.Module):
 
     # ------------------------------------------------------------------ parameter storage
     def _slot_params(self):
-        named = dict(self.named_parameters())
-        return [named[n] for n in self._names]
+        cached = self.__dict__.get('_slot_cache')
+        if cached is None:
+            named = dict(self.named_parameters())
+            cached = [named[n] for n in self._names]
+            self.__dict__['_slot_cache'] = cached         # (the Parameter objects: stable until modules are replaced)
+        return cached
 
     def _flatten(self):
         """All parameters become views of one flat fp32 buffer (slot order, 64-float aligned)."""
+        self.__dict__['_slot_cache'] = None
         ps = self._slot_params()
         offs, total = [], 0
         for p in ps:
@@ -264,6 +324,11 @@ class GHN3(nn.Module):
             flat[o:o + p.numel()].copy_(p.data.reshape(-1).to(torch.float32))
             p.data = flat[o:o + p.numel()].view(p.shape)
         self._flat, self._offs, self._flat_numel = flat, np.asarray(offs, dtype=np.int64), total
+        # split sizes of a flat buffer into (parameter, alignment gap) pieces: the per-parameter views in one call
+        self._split_sizes = []
+        for k, p in enumerate(ps):
+            nxt = offs[k + 1] if k + 1 < len(offs) else total
+            self._split_sizes += [p.numel(), nxt - offs[k] - p.numel()]
         self._plans = {}
         self._shadow = None                       # 16-bit copies of the decoder weights (Program.shadow_layout)
         self._shadowed = None
@@ -447,8 +512,8 @@ class GHN3(nn.Module):
                                       wait_for=ctx.side_wait)
             reducer.finish(gflat)
         plan.gflat = gflat
-        ps = self._slot_params()
-        return [gflat[o:o + p.numel()].view(p.shape) for p, o in zip(ps, self._offs)]
+        pieces = gflat.split_with_sizes(self._split_sizes)
+        return [pieces[2 * k].view(p.shape) for k, p in enumerate(self._slot_params())]
 
     def _patch_grad_memsets(self, prog):
         """Zero the flat gradient buffer except tensors the backward program fully overwrites."""

@@ -1,8 +1,7 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-for b in 100000000 2500000 1500000 700000; do
-  export GHN3_XCD_B_BYTES=$b
-  echo "== B budget $b"
-  timeout 600 python tests/gemm_bench.py bf16 wgrad 2>&1 | grep "tile=25" | grep "K=   768"
-  bash tools/pmc_profile.sh r02zb > /dev/null 2>&1; grep "h16w" gpurun_out/r02zb_pmc_xl_f16.txt | head -1
+for v in "GHN3_FRESH_PREFETCH_THREAD=1" "GHN3_FRESH_PREFETCH_THREAD=0" "GHN3_FRESH_PREFETCH_THREAD=1" "GHN3_FRESH_PREFETCH_THREAD=0 GHN3_LOADER_WORKERS=4"; do
+env $v timeout 900 python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | grep '^{"metric' | python -c "
+import sys, json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$v', d['ms_per_step'], 'fresh', d['fresh_graph_ms_per_step'], d['fresh_graph_host_ms'], 'gpu', d['fresh_graph_gpu_ms'])"
 done

@@ -12,7 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libghn3_hip.so')
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 # ---- numpy mirrors of the C structs -------------------------------------------------------------
 REF_DT = np.dtype([('buf', '<i4'), ('_pad', '<i4'), ('off', '<i8')])
@@ -21,7 +21,7 @@ _INT_NAMES = ('M', 'N', 'K', 'lda', 'ldb', 'ldc', 'a_mode', 'b_mode', 'a_q', 'a_
               'bias_q', 'bias_s', 'bias_stride', 'act', 'dact', 'flags')
 PROBLEM_DT = np.dtype([(n, REF_DT) for n in _REF_NAMES] + [(n, '<i4') for n in _INT_NAMES] +
                       [('alpha', '<f4'), ('ksplit', '<i4'), ('b_kq', '<i4'), ('b_ks', '<i4'), ('lim', REF_DT), ('lim_kind', '<i4'),
-                       ('_pad2', '<i4'), ('alpha_amax', REF_DT), ('ln_p', REF_DT, 6), ('ln_kind', '<i4'),
+                       ('xcd_pin', '<i4'), ('alpha_amax', REF_DT), ('ln_p', REF_DT, 6), ('ln_kind', '<i4'),
                        ('ln_eps', '<f4'), ('B2', REF_DT), ('x3_slice', '<i4'), ('_pad3', '<i4')])
 TILE_DT = np.dtype([('dst_off', '<i8'), ('src_off', '<i8'), ('S', '<i8', 4), ('T', '<i4', 4), ('E', '<i4', 4),
                     ('R', '<i4', 4), ('src_buf', '<i4'), ('mode', '<i4'), ('scale', '<f4'), ('_pad', '<i4')])

@@ -740,10 +740,32 @@ __device__ __forceinline__ void h16d_tile(const GemmProbDev* __restrict__ probs,
     static_assert((NS - 2) * (PA + PB) < 64, "vmcnt is a 6-bit counter");
     char* sm = reinterpret_cast<char*>(smem);
 
-    const GemmProbDev* P = find_problem(probs, n_probs, tile_id);
-    const int t = tile_id - P->tile_start;
+    const GemmProbDev* P;
     int m0, n0, kz;
-    if (!tile_origin<BM, BN>(P, t, m0, n0, kz)) return;
+    const int pin_end = probs[0].pin_end;
+    if (tile_id < pin_end) {
+        // XCD-pinned problems (ghn3_gemm_problem::xcd_pin): id -> (XCD, local index); the problems of an XCD are found
+        // through the directory in entry x of the array; their tiles run m fastest (the row tiles of a column tile share
+        // its B rows, consecutive column tiles the A rows of the chunk)
+        const int x = tile_id & 7, local = tile_id >> 3;
+        const int cnt = probs[x].pin_count;
+        if (cnt == 0) return;
+        int lo = probs[x].pin_first, hi = lo + cnt - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (probs[mid].tile_start <= local) lo = mid; else hi = mid - 1;
+        }
+        P = probs + lo;
+        const int t = local - P->tile_start;
+        if (t >= P->tiles_m * P->tiles_n) return;
+        m0 = (t % P->tiles_m) * BM;
+        n0 = (t / P->tiles_m) * BN;
+        kz = 0;
+    } else {
+        const int n_pin = probs[0].pin_total;
+        P = find_problem(probs + n_pin, n_probs - n_pin, tile_id);
+        if (!tile_origin<BM, BN>(P, tile_id - P->tile_start, m0, n0, kz)) return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm0 = (wave / WGN) * (BM / WGM), wn0 = (wave % WGN) * 64;
     const int l31 = lane & 31, lhi = lane >> 5;

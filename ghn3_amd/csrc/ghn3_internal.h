@@ -22,6 +22,12 @@ struct GemmProbDev {
     const int* lim;      // ragged extents per 128 rows (see ghn3_gemm_problem::lim)
     int lim_kind;
     int xcd_cols;        // tile code 25: column groups of the XCD-blocked tile order (1, 2, 4 or 8; see gemm_h16w_kernel)
+    // XCD-pinned problems of a 16-bit-operand launch (ghn3_gemm_problem::xcd_pin): they come first in the launch's array,
+    // sorted by XCD; tile id t < pin_end belongs to XCD t & 7, local index t >> 3, and tile_start of a pinned problem is
+    // its first LOCAL index.  Entry x (x < 8) of the array carries the directory of XCD x; every entry carries the totals.
+    int pin;             // 0 or x + 1
+    int pin_first, pin_count;   // (entry x) first array index / number of the problems pinned to XCD x
+    int pin_end, pin_total;     // ids below pin_end are pinned ids; number of pinned problems
     const float* alpha_amax;   // alpha is divided by ghn3_pow2_scale(*alpha_amax) (operand copies scaled by GHN3_CAST_SCALED)
     int ln_kind;               // row prologue of A (ghn3_gemm_problem::ln_kind), small-problem kernel only
     float ln_eps;

@@ -263,10 +263,46 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                         int te_n = tl == 20 ? 128 : te;                                        // (columns)
                         const bool x3 = tl >= 4000;
                         if (x3 && !ghn3_gemm_x3_tile(40 + (tl - 4000) / 10, 64 * (tl % 10), &te, &te_n)) continue;
+                        // members of this launch; XCD-pinned problems (16-bit-operand kernel, tile codes 16 / 20) first, by XCD
+                        std::vector<int> members, pinned_m;
                         for (int q = first; q < first + cnt; ++q) {
                             const ghn3_gemm_problem& p = problems[q];
                             if (p.M <= 0 || p.N <= 0) continue;
                             if (p.a_mode != am || p.b_mode != bm || pick_tile(p, forced, op_t64) != tl) continue;
+                            members.push_back(q);
+                        }
+                        const bool pin_ok = (tl == 16 || tl == 20) && members.size() >= 8;
+                        if (pin_ok) {
+                            for (int x = 0; x < 8; ++x)
+                                for (int q : members)
+                                    if (problems[q].xcd_pin == x + 1 && problems[q].ksplit <= 1) pinned_m.push_back(q);
+                            if (!pinned_m.empty()) {
+                                std::vector<int> rest;
+                                for (int q : members)
+                                    if (!(problems[q].xcd_pin >= 1 && problems[q].xcd_pin <= 8 && problems[q].ksplit <= 1))
+                                        rest.push_back(q);
+                                members = pinned_m;
+                                members.insert(members.end(), rest.begin(), rest.end());
+                            }
+                        }
+                        const int n_pinned = (int)pinned_m.size();
+                        int pin_local[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pin_first[8] = {0, 0, 0, 0, 0, 0, 0, 0},
+                            pin_count[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                        int pin_end = 0;
+                        if (n_pinned) {                          // local tile counts per XCD -> first unpinned id
+                            for (int q : pinned_m) {
+                                const ghn3_gemm_problem& p = problems[q];
+                                pin_local[p.xcd_pin - 1] += ((p.M + te - 1) / te) * ((p.N + te_n - 1) / te_n);
+                            }
+                            for (int x = 0; x < 8; ++x) pin_end = std::max(pin_end, 8 * pin_local[x]);
+                            for (int x = 0; x < 8; ++x) pin_local[x] = 0;
+                            L.tiles = pin_end;
+                        }
+                        int member_k = 0;
+                        for (int q : members) {
+                            const ghn3_gemm_problem& p = problems[q];
+                            const int member_i = member_k++;
+                            const int pin_x = member_i < n_pinned ? p.xcd_pin - 1 : -1;
                             if (is16(tl) && (p.a_mode != GHN3_MODE_ROW || p.b_mode != GHN3_MODE_ROW || (p.lda & 7) ||
                                              (p.ldb & 7) || (p.b_kq & 7) || (p.flags & GHN3_GEMM_BIASGRAD) ||
                                              p.K >= (1 << 24) || (p.ldc & 3) || (p.C.off & 15) ||
@@ -328,6 +364,13 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             g.tile_start = L.tiles;               // always a multiple of 8 (XCD-aware order)
                             g.tiles_m = (p.M + te - 1) / te;
                             g.tiles_n = (p.N + te_n - 1) / te_n;
+                            g.pin = pin_x + 1; g.pin_first = g.pin_count = 0;
+                            g.pin_end = pin_end; g.pin_total = n_pinned;
+                            if (pin_x >= 0) {
+                                g.tile_start = pin_local[pin_x];  // first LOCAL index on its XCD
+                                pin_local[pin_x] += g.tiles_m * g.tiles_n;
+                                if (pin_count[pin_x]++ == 0) pin_first[pin_x] = member_i;
+                            }
                             g.kq = is16(tl) ? p.b_kq : 0; g.ks = p.b_ks;
                             g.lim = is16(tl) ? R.get<const int>(p.lim) : nullptr;
                             g.lim_kind = g.lim ? p.lim_kind : 0;
@@ -358,7 +401,9 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                 return GHN3_E_ARG;
                             }
                             g.xcd_cols = 0;
-                            if (tl == 25) {
+                            if (pin_x >= 0) {
+                                // (ids were reserved above: [0, pin_end))
+                            } else if (tl == 25) {
                                 // XCD-blocked order of the persistent kernel: the 8 XCDs form a (8 / G) x G grid; an XCD
                                 // works on every (8 / G)-th row tile and on one of G column groups, chosen so that its
                                 // share of B stays in its 4 MB L2 while the A tiles stream through once per column group
@@ -378,6 +423,11 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             }
                             L.count++;
                         }
+                        if (n_pinned)                            // directory of XCD x in entry x of the launch's array
+                            for (int x = 0; x < 8; ++x) {
+                                hs[L.first + x].pin_first = pin_first[x];
+                                hs[L.first + x].pin_count = pin_count[x];
+                            }
                         if (L.count > 0) op_launches[k].push_back(L);
                     }
         }

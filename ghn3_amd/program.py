@@ -326,7 +326,7 @@ class Program:
              bias_s=0, bias_stride=1, act=L.ACT_NONE, dact=L.DACT_NONE, aux_in=None, aux_out=None, residual=None,
              a_gather=None, b_gather=None, c_gather=None, a_qs=(0, 0), b_qs=(0, 0), c_qs=(0, 0), accum=False,
              alpha=1.0, dbias=None, dbias_stride=1, ksplit=1, op16=False, b_kmap=(0, 0), lim=None, lim_kind=0, alpha_amax=None,
-             ln=None, x3=None):
+             ln=None, x3=None, xcd=None):
         # ln = (kind, [refs p0..p5 or None], eps): LayerNorm row prologue of A (ghn3_gemm_problem::ln_kind)
         # dbias: fused bias gradient of a wgrad problem (GHN3_GEMM_BIASGRAD): dbias[cmap(m)*stride] += sum_k A(m,k)
         if dbias is not None:
@@ -342,7 +342,8 @@ class Program:
             b_gather or N_, c_gather or N_, lim or N_, alpha_amax or N_, (x3[0] if x3 is not None else N_),
             M, N, K, lda, ldb, ldc, a_mode, b_mode, a_qs[0], a_qs[1], b_qs[0], b_qs[1], c_qs[0], c_qs[1], bias_q, bias_s,
             bias_stride, act, dact, flags, b_kmap[0], b_kmap[1],
-            (x3[1] if x3 is not None else 0), alpha, ksplit, (lim_kind if lim is not None else 0)))
+            (x3[1] if x3 is not None else 0), alpha, ksplit, (lim_kind if lim is not None else 0),
+            (0 if xcd is None else 1 + int(xcd) % 8)))
         if ln is not None:
             self._ln[len(self._probs) - 1] = ln
         return len(self._probs) - 1
@@ -383,7 +384,7 @@ class Program:
         for k, name in enumerate(self._PROBLEM_INTS):
             arr[name] = np.asarray(cols[nr + k], dtype=np.int64)
         k = nr + len(self._PROBLEM_INTS)
-        arr['alpha'], arr['ksplit'], arr['lim_kind'] = cols[k], cols[k + 1], cols[k + 2]
+        arr['alpha'], arr['ksplit'], arr['lim_kind'], arr['xcd_pin'] = cols[k], cols[k + 1], cols[k + 2], cols[k + 3]
         arr['ln_p']['buf'] = -1
         for q, (kind, refs, eps) in self._ln.items():
             arr['ln_kind'][q], arr['ln_eps'][q] = kind, eps
@@ -1414,8 +1415,11 @@ class Program:
             if planes:
                 # every 16-bit group writes the same number of planes (its own chunk count <= 8, K = 0 problems -- zeros
                 # -- for the rest), so that one reduction pass serves all rows
+                # GHN3_DGRAD_PIN (default on): eight K chunks per family, chunk j on XCD j -- the chunk's slices of d_tiles and
+                # of W2^T are then fetched by one L2 instead of by all eight (4.1 GB of fetches per step without it)
+                pin = os.environ.get('GHN3_DGRAD_PIN', '1') != '0'
                 for g in g16:
-                    g['nc'] = int(max(1, min(8, splits(g), g['o'])))
+                    g['nc'] = int(max(1, min(8, g['o']))) if pin else int(max(1, min(8, splits(g), g['o'])))
                 n_planes = max(g['nc'] for g in g16)
                 rows16 = sum(g['rows'] for g in g16)
                 assert all(g['row0'] < rows16 for g in g16), 'op16 groups first'
@@ -1439,7 +1443,8 @@ class Program:
                         self.gemm(self.href(g['dth'] + min(k0, g['cols'])),
                                   self.sref(self.w2hT + min(j * oc, g['o']) * ms[1]), dst,
                                   g['rows'], 8 * C, kc, g['dth_ld'], self.w2hT_ld, 8 * C, op16=True,
-                                  b_kmap=(g['i_ld'], ms[1]), lim=lim, lim_kind=2, alpha_amax=amax_t)
+                                  b_kmap=(g['i_ld'], ms[1]), lim=lim, lim_kind=2, alpha_amax=amax_t,
+                                  xcd=j if (pin and n_planes == 8) else None)
                     continue
                 if planes:
                     # (groups outside the 16-bit pipeline have i <= 4: a short reduction, one pass into plane 0)

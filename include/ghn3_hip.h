@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 10
+#define GHN3_ABI_VERSION 11
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -111,7 +111,12 @@ typedef struct ghn3_gemm_problem {
      * written with don't-care values).  lim_kind 2: entry = valid reduction length of those rows (A holds zeros
      * beyond it): the K loop of a tile stops at the largest extent of its rows (dgrad of the same stacking). */
     ghn3_ref lim;
-    int32_t lim_kind, _pad2;
+    int32_t lim_kind;
+    /* GHN3_GEMM_OP16 only: 0, or x + 1 to run every tile of this problem on XCD x (workgroup b of a launch runs on XCD
+     * b % 8, each XCD has a private 4 MB L2).  Meant for the K chunks of a long reduction (the W2 dgrad): with one chunk
+     * per XCD the chunk's slices of A and B are fetched by ONE L2 instead of by all eight.  Pinned problems need
+     * ksplit <= 1; a launch honours the pins when it holds at least 8 problems. */
+    int32_t xcd_pin;
     /* GHN3_GEMM_OP16 only, optional: device float holding the running max |x| of the fp32 source of an operand copy
      * that GHN3_OP_CAST16 scaled by a power of two (GHN3_CAST_SCALED): alpha is divided by that scale
      * (2^(11 - e) for amax = m 2^e; exact).  f16 copies of ~1e-6 gradients would otherwise be subnormal. */

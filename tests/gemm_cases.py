@@ -192,7 +192,9 @@ def round16(x, ctype):
 
 
 def run_op16_case(ctx, M, N, K, ctype=L.CT_F16, tile=0, grid_cap=0, a_transposed=False, b_transposed=False, kmap=None, ksplit=1,
-                  epilogue='none', accum=False, colsum=False, cmap=False, seed=0, dev='cuda'):
+                  epilogue='none', accum=False, colsum=False, cmap=False, seed=0, dev='cuda', pins=None):
+    """pins: a list (one entry per problem of ONE launch) of XCD numbers or None: problem r multiplies the first
+    M - 29 r rows of the same A into its own C (ghn3_gemm_problem::xcd_pin)."""
     rs = np.random.RandomState(seed)
     r64 = lambda v: (v + 63) // 64 * 64
     # fp32 sources.  A: [M][K] (or [K][M] when the cast transposes it); B physical k extent Kp (k-map) or K.
@@ -294,6 +296,27 @@ def run_op16_case(ctx, M, N, K, ctype=L.CT_F16, tile=0, grid_cap=0, a_transposed
     ops[1]['kind'] = L.OP_GEMM
     ops[1]['flags'] = 1 + ctype
     ops[1]['i'][:4] = (0, 1, tile, grid_cap)
+    if pins is not None:
+        assert not (cmap or colsum or accum or ksplit > 1)
+        R = len(pins)
+        p = np.repeat(p, R)
+        d_CR = torch.from_numpy(np.ascontiguousarray(np.stack([C0] * R))).to(dev)
+        ptrs[3] = d_CR.data_ptr()
+        for r in range(R):
+            p[r]['M'] = max(1, M - 29 * r)
+            p[r]['C']['off'] = 4 * r * C0.size
+            p[r]['xcd_pin'] = 0 if pins[r] is None else 1 + pins[r]
+        ops[1]['i'][1] = R
+        ctx.run(ops, p, ptrs, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        got = d_CR.cpu().numpy()
+        out = []
+        for r in range(R):
+            e = C0.astype(np.float64).copy()
+            mr = max(1, M - 29 * r)
+            e[:mr, :N] = expected[:mr, :N]
+            out.append((got[r], e))
+        return out
     ctx.run(ops, p, ptrs, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
     out = [(d_C.cpu().numpy(), expected)]
@@ -333,6 +356,13 @@ OP16_CASES = [
     dict(M=700, N=3072 // 4, K=64, tile=25, grid_cap=2, cmap=True),
     dict(M=5, N=7, K=9, tile=25),
     dict(M=2048, N=1024, K=768, a_transposed=True, b_transposed=True, tile=25, grid_cap=5),
+    # XCD-pinned problems of one launch (xcd_pin): several problems on one XCD, XCDs without a problem, unpinned problems
+    # behind the pinned ids, fewer than 8 problems (pins ignored), the 256 x 128 variant and the persistent grid
+    dict(M=300, N=520, K=150, pins=[0, 1, 2, 3, 4, 5, 6, 7, 0, 3, None, 5]),
+    dict(M=300, N=200, K=200, epilogue='bias_relu', pins=[2, 2, 2, None, 7, None, 2, 0, None]),
+    dict(M=533, N=384, K=64 * 12, kmap=(64, 96), tile=20, pins=[0, 1, 2, 3, 4, 5, 6, 7]),
+    dict(M=700, N=300, K=130, tile=20, pins=[1, None, 6, 6, 3, None, None, 1, 4, 4], grid_cap=3),
+    dict(M=300, N=200, K=64, pins=[3, 5, None]),
     # persistent workgroups (grid cap): 3 workgroups stride over 99 / 30 tiles
     dict(M=1100, N=1300, K=512, epilogue='bias_relu', grid_cap=3),
     dict(M=1100, N=1300, K=200, tile=24, grid_cap=3, accum=True),

@@ -53,9 +53,16 @@ def main():
     ap.add_argument('--max-nodes', type=int, default=400)
     ap.add_argument('--seed', type=int, default=0)
     ap.add_argument('--save', default=None)
-    ap.add_argument('--miopen', action='store_true',
-                    help='run the target networks on MIOpen (default: ATen native convolution / batch-norm kernels)')
+    ap.add_argument('--native', action='store_true',
+                    help='run the target networks on ATen native convolution / batch-norm kernels instead of MIOpen')
     args = ap.parse_args()
+    # Every step brings NEW architectures, i.e. convolution configurations MIOpen may not have seen.  On first sight of a
+    # configuration its default (hybrid) find mode benchmarks candidate kernels and records the winner in the user's
+    # find-db; from then on the configuration costs nothing extra.  Measured at meta-batch 8, 64 images of 32 x 32, one
+    # MI355X: ~1.0 s per step on a first pass over a set of architectures, 132 ms (--amp) / 140 ms (fp32) per step once
+    # their configurations are in the find-db -- the configuration space of the search space is finite, so a long run
+    # converges to the latter.  MIOPEN_FIND_MODE=2 (heuristics only, no benchmark) gives 0.35-0.6 s per step from a cold
+    # find-db; the ATen native kernels (--native: im2col + GEMM per sample, no build step) 1.03 s.
 
     import multiprocessing as mp
     for var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS'):
@@ -64,10 +71,7 @@ def main():
 
     from ghn3_amd import GHN3, Trainer, setup_ddp, clean_ddp, log
     ddp = setup_ddp()
-    # Every step brings NEW architectures: MIOpen builds (and searches) kernels per convolution configuration on first
-    # use -- seconds per step on a stream of configurations seen once each (measured: 2.4 s per step at meta-batch 8,
-    # against the time below with ATen's own im2col + GEMM / depthwise / batch-norm kernels, which need no build step).
-    torch.backends.cudnn.enabled = bool(args.miopen)
+    torch.backends.cudnn.enabled = not args.native
     hid, layers, heads = MODELS[args.model]
     num_classes = 1000 if args.imagenet else 10
     s = 16 if args.imagenet else 11

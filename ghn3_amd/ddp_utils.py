@@ -127,11 +127,14 @@ def mesh_all_reduce_avg(piece, wire_dtype=None):
         return piece
     per = (n + W - 1) // W
     wd = wire_dtype or piece.dtype
-    send = torch.zeros(W * per, dtype=wd, device=piece.device)
+    send = torch.empty(W * per, dtype=wd, device=piece.device)
     send[:n].copy_(piece)
+    if W * per > n:
+        send[n:].zero_()                                          # (fewer than W padding elements)
     recv = torch.empty_like(send)
     dist.all_to_all_single(recv, send)
-    red = recv.view(W, per).to(torch.float32).sum(0).mul_(1.0 / W).to(wd)
+    # (one pass: the W chunks are accumulated in fp32 on the fly, in rank order on every rank)
+    red = torch.sum(recv.view(W, per), dim=0, dtype=torch.float32).mul_(1.0 / W).to(wd)
     dist.all_gather_into_tensor(send, red)
     piece.copy_(send[:n])
     return piece

@@ -90,6 +90,7 @@ def _loader_worker(task):
     from ghn3_amd.synthetic import synthetic_batch
     gb, nets = synthetic_batch([nodes] * graphs_per_gpu, seed)
     gb._cat()
+    gb.graphs = None                                     # (the per-graph copies of what _cat stacked: half of the pickle)
     pcfg = dict(pcfg)
     cfg = pcfg.pop('cfg')
     prog = Program(cfg, gb.node_info, gb.host_n_nodes(), gb._node_type_host, gb.max_edge, nets, training=True, **pcfg)

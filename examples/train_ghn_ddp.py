@@ -34,6 +34,7 @@ def _draw(task):
     base = step * meta + rank * per_rank
     gb = GraphBatch([nets[base + k] for k in range(per_rank)], dense=True)
     gb._cat()
+    gb.graphs = None                 # (the per-graph copies of what _cat stacked: half of the pickle)
     return gb
 
 

@@ -1,11 +1,7 @@
 #!/bin/bash
+# scratch script for one-off GPU experiments (rewritten per experiment; see profiles/README.md for kept results)
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out
-O=gpurun_out/r02zf_train_warm2.txt; : > $O
-for m in 3 3 2; do
-  echo "== MIOPEN_FIND_MODE=$m --amp --steps 63" >> $O
-  MIOPEN_FIND_MODE=$m timeout 1200 python examples/train_ghn_ddp.py --amp --steps 63 2>&1 | tail -1 >> $O
-done
-echo "== MIOPEN_FIND_MODE=3 --steps 63 (fp32) twice" >> $O
-MIOPEN_FIND_MODE=3 timeout 1200 python examples/train_ghn_ddp.py --steps 63 2>&1 | tail -1 >> $O
-MIOPEN_FIND_MODE=3 timeout 1200 python examples/train_ghn_ddp.py --steps 63 2>&1 | tail -1 >> $O
-cat $O
+timeout 900 python -m pytest tests/test_gpu_networks.py -m gpu -x -q 2>&1 | grep -E "passed|failed"
+timeout 900 python bench.py --steps 60 --warmup 10 --no-cpu-baseline 2>/dev/null | grep '^{"metric' | python -c "
+import sys, json
+d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'], 'fresh', d['fresh_graph_ms_per_step'], d['fresh_graph_host_ms'], 'gpu', d['fresh_graph_gpu_ms'])"

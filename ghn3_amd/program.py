@@ -669,13 +669,18 @@ class Program:
         The kernel is bound by what one CU can pull through L2 -> LDS (~17 B/clk): the bytes per workgroup are
         4 K_slice (BM + BN), so narrow outputs (N <= 512: to_out, ff.net.3, the dgrads of to_qkv / ff.net.0) take 32 x 32
         tiles and -- where the consumer is a LayerNorm op that can sum partial planes -- K slices of 192 (then 128, 64)
-        run by different workgroup sets; wide outputs (to_qkv, ff.net.0, ff.net.3 dgrad) take 32 x 64 tiles over the whole
-        K = C.  Measured at ghn3xlm16 (tests/x3_bench.py, us per dependent launch, exact-fp32 kernel in brackets):
+        run by different workgroup sets; wide outputs (to_qkv, ff.net.0, ff.net.3 dgrad) took 32 x 64 tiles over the whole
+        K = C until round 2 (see below).  Measured at ghn3xlm16 (tests/x3_bench.py, us per dependent launch, exact-fp32 kernel in brackets):
         to_qkv 6.4 (9.9), to_out 4.4 (6.5), ff.net.0 6.4 (10.3), ff.net.3 7.3 (10.0 with its two K halves)."""
         nk = K // 64
         whole = max(d for d in (6, 4, 3, 2, 1) if nk % d == 0)         # k-tiles per slice without a split
         plan = os.environ.get('GHN3_X3_PLAN', 'A')
         if N > 512:
+            # 32 x 32 tiles walking K in slices of 192: 49 KB of LDS per workgroup, so that several of the 288-384 workgroups
+            # share a CU -- a workgroup's fetch rate is ~5 B/clk per WAVE (20 B/clk for a lone 4-wave workgroup with its
+            # 147 KB at 32 x 64 / whole K; tools/fetch_rate_probe.hip).  Step 8.35 -> 8.20 ms; GHN3_X3_PLAN=W: the former plan
+            if plan != 'W' and K % 192 == 0:
+                return 42, 1, 192
             return 40, 1, 64 * whole
         if plan == 'B':                                                  # 32 x 64 tiles, slices of up to 384: few planes
             return 40, (nk // whole if may_split else 1), 64 * whole

@@ -88,6 +88,7 @@ __device__ __forceinline__ void load_col_operand(const float* __restrict__ X, in
 // (consecutive lanes read consecutive chunks of a row, then the next row: 96-byte runs at d = 24 instead of one cache
 // line per lane), and EVERY load is issued before the first LDS write: one memory round trip for the whole prologue
 // (copying in batches measured one dependent round trip per batch: 6.5k of the kernel's 20k cycles).
+template <int NT>
 __device__ __forceinline__ void stage_head_slices(float* __restrict__ dst, int ldw, const float* __restrict__ base,
                                                   int C, int i0, int nkeys, int N, int d, bool vec, int tid) {
     const size_t stride = (size_t)3 * C;
@@ -101,10 +102,10 @@ __device__ __forceinline__ void stage_head_slices(float* __restrict__ dst, int l
     };
     if (vec) {
         const int chunks = d >> 2;
-        const int rpp = 256 / chunks;                // rows per pass
+        const int rpp = NT / chunks;                 // rows per pass
         const int r0 = tid / chunks, c = tid - r0 * chunks;
         const bool lane_on = r0 < rpp;
-        constexpr int G = 18;                        // >= ceil(544 / (256 / 8)) passes at d = 32
+        constexpr int G = NT == 256 ? 18 : 9;        // >= ceil(544 / (NT / 8)) passes at d = 32
         f32x4 v[G];
 #pragma unroll
         for (int g = 0; g < G; ++g) {
@@ -122,7 +123,7 @@ __device__ __forceinline__ void stage_head_slices(float* __restrict__ dst, int l
             if (lane_on && r < rows) *reinterpret_cast<f32x4*>(dst + r * ldw + 4 * c) = v[g];
         }
     } else {
-        for (int f = tid; f < rows * d; f += 256) {
+        for (int f = tid; f < rows * d; f += NT) {
             const int r = f / d, e = f - r * d;
             const float* p = source(r);
             dst[r * ldw + e] = p ? p[e] : 0.f;
@@ -142,17 +143,23 @@ __device__ __forceinline__ f32x16 mfma_cols(const float (&a)[16], const f32x16& 
     return acc;
 }
 
-// Sum the 4 waves' 32 x 32 partial tiles through LDS; wave w returns register group w (4 consecutive head columns
-// e = 8 w + 4 lhi + c of matrix column l31) of the total.
-__device__ __forceinline__ f32x4 reduce_waves(float* red /* [4][16][64] */, const f32x16& part, int w, int lane) {
+// Sum the NW waves' 32 x 32 partial tiles through LDS; wave w < 4 returns register group w (4 consecutive head columns
+// e = 8 w + 4 lhi + c of matrix column l31) of the total (waves 4 .. NW - 1 only contribute).
+template <int NW = 4>
+__device__ __forceinline__ f32x4 reduce_waves(float* red /* [NW][16][64] */, const f32x16& part, int w, int lane) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[(w * 16 + r) * 64 + lane] = part[r];
     __syncthreads();
-    f32x4 o;
+    f32x4 o = {0.f, 0.f, 0.f, 0.f};
+    if (w < 4) {
 #pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int r = 4 * w + c;
-        o[c] = red[r * 64 + lane] + red[(16 + r) * 64 + lane] + red[(32 + r) * 64 + lane] + red[(48 + r) * 64 + lane];
+        for (int c = 0; c < 4; ++c) {
+            const int r = 4 * w + c;
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < NW; ++q) t += red[(16 * q + r) * 64 + lane];
+            o[c] = t;
+        }
     }
     return o;
 }
@@ -171,13 +178,13 @@ __device__ __forceinline__ void store4(float* __restrict__ dst, int e0, int d, b
 // ------------------------------------------------------------------------------------------------
 // forward: grid (ceil(N / 32), H, B), 256 threads; wave w owns key tiles w, w + 4, ... (TPW of them)
 // ------------------------------------------------------------------------------------------------
-template <int KS, int TPW, int QB>
+template <int KS, int TPW, int QB, int NW = 4>
 __device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const float* __restrict__ qkv,
                                               const float* __restrict__ bias, float* __restrict__ Psave,
                                               const int* __restrict__ n_nodes, int N, int C, int H, float scale, int vec,
                                               int stamp_base) {
-    __shared__ float red[4 * 16 * 64];
-    __shared__ float red_m[4][32], red_l[4][32];
+    __shared__ float red[NW * 16 * 64];
+    __shared__ float red_m[NW][32], red_l[NW][32];
     extern __shared__ __attribute__((aligned(16))) float stage[];   // TPW <= 2: Q | K | V head slices (see below)
     const int d = C / H;
     const int b = blockIdx.z, h = blockIdx.y, i0 = blockIdx.x * QB;
@@ -198,14 +205,14 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const flo
     constexpr bool PRE = TPW <= 2;
     constexpr int TP = PRE ? TPW : 1;
     const int ldw = ((d + 3) & ~3) + 4;                          // padded LDS row (16-byte aligned for the float4 copy)
-    const int nkeys = TPW * 128;                                 // keys covered by the block's 4 waves
+    const int nkeys = TPW * NW * 32;                             // keys covered by the block's NW waves
     float* Qs = stage;
     float* Ks = stage + 32 * ldw;
     float* Vs = Ks + nkeys * ldw;
     float qb[KS];
     float ka[TP][KS];
     if (PRE) {
-        stage_head_slices(stage, ldw, base, C, i0, nkeys, N, d, vq, tid);
+        stage_head_slices<64 * NW>(stage, ldw, base, C, i0, nkeys, N, d, vq, tid);
     } else {
         load_row_operand<KS>(qi < N ? base + (size_t)qi * 3 * C : nullptr, d, lhi, vq, qb);
     }
@@ -215,7 +222,7 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const flo
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
         S[k] = zero16();
-        const int j0 = (w + 4 * k) * 32;
+        const int j0 = (w + NW * k) * 32;
         if (bias && qi < N && j0 < N) {
             const float* brow = bias + (bh + qi) * N + j0;
 #pragma unroll
@@ -242,7 +249,7 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const flo
         }
 #pragma unroll
         for (int k = 0; k < TP; ++k) {
-            const int j0 = (w + 4 * k) * 32;
+            const int j0 = (w + NW * k) * 32;
 #pragma unroll
             for (int sx = 0; sx < KS; ++sx) {
                 const int kx = 2 * sx + lhi;
@@ -259,7 +266,7 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const flo
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
         const f32x16 bia = S[k];
-        const int j0 = (w + 4 * k) * 32;
+        const int j0 = (w + NW * k) * 32;
         if (!PRE) {
             const int j = j0 + l31;
             load_row_operand<KS>(j < N ? base + (size_t)j * 3 * C + C : nullptr, d, lhi, vq, ka[0]);
@@ -281,7 +288,9 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const flo
     if (lhi == 0) red_m[w][l31] = mx;
     __syncthreads();
     ATT_STAMP(3);
-    mx = fmaxf(fmaxf(red_m[0][l31], red_m[1][l31]), fmaxf(red_m[2][l31], red_m[3][l31]));
+    mx = red_m[0][l31];
+#pragma unroll
+    for (int q = 1; q < NW; ++q) mx = fmaxf(mx, red_m[q][l31]);
     float sum = 0.f;
 #pragma unroll
     for (int k = 0; k < TPW; ++k)
@@ -295,11 +304,14 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const flo
     if (lhi == 0) red_l[w][l31] = sum;
     __syncthreads();
     ATT_STAMP(4);
-    const float inv = 1.f / (red_l[0][l31] + red_l[1][l31] + red_l[2][l31] + red_l[3][l31]);
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < NW; ++q) tot += red_l[q][l31];
+    const float inv = 1.f / tot;
     f32x16 O = zero16();
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
-        const int j0 = (w + 4 * k) * 32;
+        const int j0 = (w + NW * k) * 32;
 #pragma unroll
         for (int r = 0; r < 16; ++r) S[k][r] *= inv;
         if (Psave && qi < N && j0 < N) {
@@ -321,17 +333,17 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const flo
         if (j0 < N) O = mfma_cols(va[PRE ? k : 0], S[k], O);       // O^T += V^T P^T
     }
     ATT_STAMP(5);
-    const f32x4 o = reduce_waves(red, O, w, lane);
+    const f32x4 o = reduce_waves<NW>(red, O, w, lane);
     ATT_STAMP(6);
-    if (qi < N) store4(out + ((size_t)b * N + qi) * C + h * d, 8 * w + 4 * lhi, d, vq, o);
+    if (w < 4 && qi < N) store4(out + ((size_t)b * N + qi) * C + h * d, 8 * w + 4 * lhi, d, vq, o);
     ATT_STAMP(7);
 }
-template <int KS, int TPW, int QB>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(float* __restrict__ out, const float* __restrict__ qkv,
-                                                       const float* __restrict__ bias, float* __restrict__ Psave,
-                                                       const int* __restrict__ n_nodes, int N, int C, int H,
-                                                       float scale, int vec) {
-    attn_fwd_body<KS, TPW, QB>(out, qkv, bias, Psave, n_nodes, N, C, H, scale, vec, 0);
+template <int KS, int TPW, int QB, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(float* __restrict__ out, const float* __restrict__ qkv,
+                                                          const float* __restrict__ bias, float* __restrict__ Psave,
+                                                          const int* __restrict__ n_nodes, int N, int C, int H,
+                                                          float scale, int vec) {
+    attn_fwd_body<KS, TPW, QB, NW>(out, qkv, bias, Psave, n_nodes, N, C, H, scale, vec, 0);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -585,9 +597,12 @@ typedef void (*attn_fwd_fn)(float*, const float*, const float*, float*, const in
 typedef void (*attn_bwd_fn)(float*, const float*, const float*, const float*, const float*, float*, const int*, int,
                             int, int, float, int);
 
+static int g_attn_fwd_waves = 8;
 template <int KS> static attn_fwd_fn fwd_for(int tpw) {
     if (tpw > 8) return (attn_fwd_fn)attn_fwd_stream_kernel<KS>;          // N > 1024
-    return tpw <= 2 ? (attn_fwd_fn)attn_fwd_kernel<KS, 2, 16> : (attn_fwd_fn)attn_fwd_kernel<KS, 8, 32>;
+    // N <= 256: eight waves with one key tile each (a workgroup fetches ~5 B/clk per wave: tools/fetch_rate_probe.hip)
+    if (tpw <= 2) return g_attn_fwd_waves == 8 ? (attn_fwd_fn)attn_fwd_kernel<KS, 1, 16, 8> : (attn_fwd_fn)attn_fwd_kernel<KS, 2, 16, 4>;
+    return (attn_fwd_fn)attn_fwd_kernel<KS, 8, 32, 4>;
 }
 static attn_fwd_fn pick_fwd(int d, int tpw) {
     if (d <= 4) return fwd_for<2>(tpw);
@@ -604,7 +619,10 @@ static attn_bwd_fn pick_bwd(int d) {
     return attn_bwd_kernel<16>;
 }
 
-int ghn3_attn_init() { return GHN3_OK; }
+int ghn3_attn_init() {
+    if (getenv("GHN3_ATTN_FWD_WAVES")) g_attn_fwd_waves = atoi(getenv("GHN3_ATTN_FWD_WAVES")) == 4 ? 4 : 8;
+    return GHN3_OK;
+}
 
 static int check_dims(int N, int C, int H) {
     if (H <= 0 || C % H != 0 || C / H > ATT_DMAX) {
@@ -632,8 +650,8 @@ int ghn3_attn_fwd(float* out, const float* qkv, const float* bias, float* P, con
         if (ea != hipSuccess) { ghn3_set_error("attn fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(ea)); return GHN3_E_HIP; }
     }
     // (the staged variants own 16 queries per block)
-    hipLaunchKernelGGL(fn, dim3(tpw <= 2 ? (N + 15) / 16 : nb, H, B), dim3(256), lds, s, out, qkv, bias, P, n_nodes, N, C, H,
-                       scale, vec);
+    hipLaunchKernelGGL(fn, dim3(tpw <= 2 ? (N + 15) / 16 : nb, H, B), dim3(tpw <= 2 ? 64 * g_attn_fwd_waves : 256), lds, s, out,
+                       qkv, bias, P, n_nodes, N, C, H, scale, vec);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("attn fwd launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

@@ -12,7 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libghn3_hip.so')
-ABI_VERSION = 11
+ABI_VERSION = 12
 
 # ---- numpy mirrors of the C structs -------------------------------------------------------------
 REF_DT = np.dtype([('buf', '<i4'), ('_pad', '<i4'), ('off', '<i8')])
@@ -22,7 +22,8 @@ _INT_NAMES = ('M', 'N', 'K', 'lda', 'ldb', 'ldc', 'a_mode', 'b_mode', 'a_q', 'a_
 PROBLEM_DT = np.dtype([(n, REF_DT) for n in _REF_NAMES] + [(n, '<i4') for n in _INT_NAMES] +
                       [('alpha', '<f4'), ('ksplit', '<i4'), ('b_kq', '<i4'), ('b_ks', '<i4'), ('lim', REF_DT), ('lim_kind', '<i4'),
                        ('xcd_pin', '<i4'), ('alpha_amax', REF_DT), ('ln_p', REF_DT, 6), ('ln_kind', '<i4'),
-                       ('ln_eps', '<f4'), ('B2', REF_DT), ('x3_slice', '<i4'), ('_pad3', '<i4')])
+                       ('ln_eps', '<f4'), ('B2', REF_DT), ('x3_slice', '<i4'), ('_pad3', '<i4'), ('mtiles', REF_DT),
+                       ('n_mtiles', '<i4'), ('_pad4', '<i4')])
 TILE_DT = np.dtype([('dst_off', '<i8'), ('src_off', '<i8'), ('S', '<i8', 4), ('T', '<i4', 4), ('E', '<i4', 4),
                     ('R', '<i4', 4), ('src_buf', '<i4'), ('mode', '<i4'), ('scale', '<f4'), ('_pad', '<i4')])
 CAST_DT = np.dtype([('src_off', '<i8'), ('dst_off', '<i8'), ('dstT_off', '<i8'), ('rows', '<i4'), ('cols', '<i4'),
@@ -32,7 +33,7 @@ CAST_DT = np.dtype([('src_off', '<i8'), ('dst_off', '<i8'), ('dstT_off', '<i8'),
 ROWSET_DT = np.dtype([('off', '<i8'), ('rows', '<i4'), ('o', '<i4'), ('i', '<i4'), ('ld', '<i4'), ('i0', '<i4'),
                       ('_pad', '<i4')])
 OP_DT = np.dtype([('kind', '<i4'), ('flags', '<i4'), ('i', '<i8', 8), ('f', '<f4', 4), ('r', REF_DT, 14)])
-assert REF_DT.itemsize == 16 and PROBLEM_DT.itemsize == 424 and TILE_DT.itemsize == 112 and OP_DT.itemsize == 312
+assert REF_DT.itemsize == 16 and PROBLEM_DT.itemsize == 448 and TILE_DT.itemsize == 112 and OP_DT.itemsize == 312
 assert CAST_DT.itemsize == 88 and ROWSET_DT.itemsize == 32
 
 MODE_ROW, MODE_COL = 0, 1

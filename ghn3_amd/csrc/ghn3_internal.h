@@ -33,6 +33,7 @@ struct GemmProbDev {
     float ln_eps;
     const float* ln_p[6];
     const void* B2;            // GHN3_GEMM_X3: the bf16 lo copy of B (B itself points at the hi copy)
+    const int* mtab;           // tile code 28: row-tile table {m0, mi, extent} x tiles_m (ghn3_gemm_problem::mtiles) or null
 };
 
 
@@ -43,6 +44,9 @@ int ghn3_gemm_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, i
 
 int ghn3_gemm_h16d_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int tile, int ctype, int grid_cap,
                           hipStream_t stream);
+int ghn3_gemm_p8_init();
+int ghn3_gemm_p8_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int ctype, int grid_cap,
+                        hipStream_t stream);
 int ghn3_gemm_x3_init();
 int ghn3_gemm_x3_tile(int code, int slice, int* bm, int* bn);
 int ghn3_gemm_x3_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int code, int slice,

@@ -110,6 +110,8 @@ extern "C" int ghn3_ctx_create(ghn3_ctx** out) {
     if (rc) return rc;
     rc = ghn3_gemm_x3_init();
     if (rc) return rc;
+    rc = ghn3_gemm_p8_init();
+    if (rc) return rc;
     rc = ctx_reserve(c, 1024);
     if (rc) return rc;
     *out = c;
@@ -204,6 +206,13 @@ static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
         // tile codes 16 / 24 = the 16-bit-operand kernel with 128 x 128 / 256 x 256 tiles.  The big tile has twice
         // the arithmetic intensity but runs one 512-thread block per CU: it needs enough tiles to fill the chip.
         if (forced == 16 || forced == 24 || forced == 20 || forced == 25) return forced;
+        // 28 = the 8-phase kernel ((192 | 256 | 320) x 256 tiles): everything it can take that has at least ~a tile of rows;
+        // the rest of the op (small families, atomically split problems) stays on the 128 x 128 kernel
+        if (forced == 28) {
+            const bool kmap_ok = p.b_kq == 0 || p.b_kq % 64 == 0 || 64 % p.b_kq == 0;
+            return (p.ksplit <= 1 && p.M >= 160 && (p.N & 3) == 0 && kmap_ok && p.a_gather.buf < 0 && p.b_gather.buf < 0 &&
+                    p.c_gather.buf < 0) ? 28 : 16;
+        }
         const int64_t t256 = (int64_t)((p.M + 255) / 256) * ((p.N + 255) / 256) * (p.ksplit > 1 ? p.ksplit : 1);
         const double eff = ((double)p.M / (((p.M + 255) / 256) * 256.0)) * ((double)p.N / (((p.N + 255) / 256) * 256.0));
         return (t256 >= 200 && eff >= 0.8) ? 24 : 16;
@@ -219,7 +228,7 @@ static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
 }
 
 struct Launch { int a_mode, b_mode, tile, first, count, tiles, with_ln, max_slice; };
-static inline bool is16(int tl) { return tl == 16 || tl == 24 || tl == 20 || tl == 25; }   // 16-bit-operand kernels
+static inline bool is16(int tl) { return tl == 16 || tl == 24 || tl == 20 || tl == 25 || tl == 28; }   // 16-bit-operand kernels
 
 extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_gemm_problem* problems, int n_problems,
                         void* const* bufs, int n_bufs, void* stream_) {
@@ -256,10 +265,10 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             // bucket by (a_mode, b_mode, tile)
             for (int am = 0; am < 2; ++am)
                 for (int bm = 0; bm < 2; ++bm)
-                    for (int tl : {16, 20, 24, 25, 32, 64, 128, 4001, 4002, 4003, 4004, 4006, 4011, 4012, 4013, 4014, 4021,
+                    for (int tl : {16, 20, 24, 25, 28, 32, 64, 128, 4001, 4002, 4003, 4004, 4006, 4011, 4012, 4013, 4014, 4021,
                                    4022, 4023, 4024, 4026}) {
                         Launch L{am, bm, tl, (int)pos, 0, 0, 0, 0};
-                        int te = tl == 16 ? 128 : (tl == 24 || tl == 20 || tl == 25) ? 256 : tl;         // tile edge (rows)
+                        int te = tl == 16 ? 128 : (tl == 24 || tl == 20 || tl == 25 || tl == 28) ? 256 : tl;   // tile edge (rows)
                         int te_n = tl == 20 ? 128 : te;                                        // (columns)
                         const bool x3 = tl >= 4000;
                         if (x3 && !ghn3_gemm_x3_tile(40 + (tl - 4000) / 10, 64 * (tl % 10), &te, &te_n)) continue;
@@ -271,7 +280,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             if (p.a_mode != am || p.b_mode != bm || pick_tile(p, forced, op_t64) != tl) continue;
                             members.push_back(q);
                         }
-                        const bool pin_ok = (tl == 16 || tl == 20) && members.size() >= 8;
+                        const bool pin_ok = (tl == 16 || tl == 20 || tl == 28) && members.size() >= 8;
                         if (pin_ok) {
                             for (int x = 0; x < 8; ++x)
                                 for (int q : members)
@@ -292,7 +301,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                         if (n_pinned) {                          // local tile counts per XCD -> first unpinned id
                             for (int q : pinned_m) {
                                 const ghn3_gemm_problem& p = problems[q];
-                                pin_local[p.xcd_pin - 1] += ((p.M + te - 1) / te) * ((p.N + te_n - 1) / te_n);
+                                const int tm_ = (tl == 28 && p.mtiles.buf >= 0) ? p.n_mtiles : (p.M + te - 1) / te;
+                                pin_local[p.xcd_pin - 1] += tm_ * ((p.N + te_n - 1) / te_n);
                             }
                             for (int x = 0; x < 8; ++x) pin_end = std::max(pin_end, 8 * pin_local[x]);
                             for (int x = 0; x < 8; ++x) pin_local[x] = 0;
@@ -320,6 +330,20 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                 ghn3_set_error("op %d problem %d: tile 25 (persistent output-heavy kernel) takes plain "
                                                "problems only: C = alpha A B^T with an optional row map of C", k, q);
                                 return GHN3_E_ARG;
+                            }
+                            if (tl == 28) {
+                                // 32-bit byte offsets inside the kernel: both operands must span less than 4 GB
+                                const int64_t a_rows = p.a_q > 0 ? ((int64_t)(p.M - 1) / p.a_q) * p.a_s + p.a_q : p.M;
+                                const int64_t b_rows = p.b_q > 0 ? ((int64_t)(p.N - 1) / p.b_q) * p.b_s + p.b_q : p.N;
+                                const int64_t k_phys = p.b_kq > 0 ? ((int64_t)(p.K + 63) / p.b_kq + 1) * p.b_ks : p.K + 64;
+                                if (p.ksplit > 1 || p.a_gather.buf >= 0 || p.b_gather.buf >= 0 || p.c_gather.buf >= 0 ||
+                                    a_rows * p.lda * 2 >= (int64_t)0xfff00000 ||
+                                    (b_rows * p.ldb + k_phys) * 2 >= (int64_t)0xfff00000 ||
+                                    (p.mtiles.buf >= 0 && p.n_mtiles <= 0)) {
+                                    ghn3_set_error("op %d problem %d: tile 28 (8-phase kernel) takes no split-K / gathers and "
+                                                   "operands below 4 GB", k, q);
+                                    return GHN3_E_ARG;
+                                }
                             }
                             if (x3 && (p.a_mode != GHN3_MODE_ROW || p.b_mode != GHN3_MODE_ROW || p.a_gather.buf >= 0 ||
                                        p.b_gather.buf >= 0 || p.c_gather.buf >= 0 || p.a_q || p.b_q || p.c_q || p.bias_q ||
@@ -364,6 +388,11 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             g.tile_start = L.tiles;               // always a multiple of 8 (XCD-aware order)
                             g.tiles_m = (p.M + te - 1) / te;
                             g.tiles_n = (p.N + te_n - 1) / te_n;
+                            g.mtab = nullptr;
+                            if (tl == 28 && p.mtiles.buf >= 0) {
+                                g.mtab = R.get<const int>(p.mtiles);
+                                g.tiles_m = p.n_mtiles;
+                            }
                             g.pin = pin_x + 1; g.pin_first = g.pin_count = 0;
                             g.pin_end = pin_end; g.pin_total = n_pinned;
                             if (pin_x >= 0) {
@@ -373,7 +402,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             }
                             g.kq = is16(tl) ? p.b_kq : 0; g.ks = p.b_ks;
                             g.lim = is16(tl) ? R.get<const int>(p.lim) : nullptr;
-                            g.lim_kind = g.lim ? p.lim_kind : 0;
+                            g.lim_kind = (g.lim || (tl == 28 && p.mtiles.buf >= 0)) ? p.lim_kind : 0;
                             g.alpha_amax = is16(tl) ? R.get<const float>(p.alpha_amax) : nullptr;
                             g.B2 = x3 ? R.get<const void>(p.B2) : nullptr;
                             if (x3 && p.x3_slice > L.max_slice) L.max_slice = p.x3_slice;
@@ -393,6 +422,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                 }
                             }
                             g.order = (int64_t)p.M > (int64_t)p.N ? 1 : 0;   // stream the larger operand once
+                            if (tl == 28) g.order = 0;                       // (the 8-phase kernel has one tile order)
                             g.ksplit = p.ksplit > 1 ? p.ksplit : 1;
                             g.k_chunk = x3 ? p.x3_slice : ((p.K + g.ksplit - 1) / g.ksplit + 63) / 64 * 64;
                             if (g.ksplit > 1 && (p.bias.buf >= 0 || p.act || p.dact || p.residual.buf >= 0 ||
@@ -510,6 +540,9 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                              64 * (L.tile % 10), stream);
                 else if (L.tile == 32)
                     rc = ghn3_gemm_small_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, L.with_ln, stream);
+                else if (L.tile == 28)
+                    rc = ghn3_gemm_p8_launch(ds + L.first, L.count, L.tiles,
+                                             (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, (int)o.i[3], stream);
                 else if (is16(L.tile))
                     rc = ghn3_gemm_h16d_launch(ds + L.first, L.count, L.tiles,
                                                L.tile == 16 ? 128 : L.tile == 20 ? 20 : L.tile == 25 ? 25 : 256,

@@ -93,6 +93,8 @@ class Program:
         # O(1) error of d_u / d_t there -- measured 1-5 % per decoder row against the fp32 path, 6e-3 on the gradient
         # of decoder.fc.0.weight at ghn3xlm16.  Likewise the fc backward (d_t ~ 1e-4, f16 subnormal range) stays fp32.
         self.d12_fwd_ctype = {'f32': L.CT_F32, 'f16': None}[os.environ.get('GHN3_D12_FWD', 'f32')]
+        # 8-phase kernel (tile code 28) with per-family row tiles for the W2 forward and dgrad (round 3)
+        self.use_p8 = os.environ.get('GHN3_P8', '1') != '0'
         self.d1_bwd_ctype = {'f32': L.CT_F32, 'f16': None}[os.environ.get('GHN3_D1_BWD', 'f32')]
         self.C = C = int(cfg['hid'])
         # x3: the Graphormer linears (to_qkv, to_out, ff.net.0, ff.net.3; forward and dgrad) as split-bf16 products on the
@@ -326,7 +328,8 @@ class Program:
              bias_s=0, bias_stride=1, act=L.ACT_NONE, dact=L.DACT_NONE, aux_in=None, aux_out=None, residual=None,
              a_gather=None, b_gather=None, c_gather=None, a_qs=(0, 0), b_qs=(0, 0), c_qs=(0, 0), accum=False,
              alpha=1.0, dbias=None, dbias_stride=1, ksplit=1, op16=False, b_kmap=(0, 0), lim=None, lim_kind=0, alpha_amax=None,
-             ln=None, x3=None, xcd=None):
+             ln=None, x3=None, xcd=None, mtiles=None):
+        # mtiles = (ref of int32 triples {m0, mi, extent}, count): row-tile table of the 8-phase kernel (tile code 28)
         # ln = (kind, [refs p0..p5 or None], eps): LayerNorm row prologue of A (ghn3_gemm_problem::ln_kind)
         # dbias: fused bias gradient of a wgrad problem (GHN3_GEMM_BIASGRAD): dbias[cmap(m)*stride] += sum_k A(m,k)
         if dbias is not None:
@@ -340,10 +343,11 @@ class Program:
         self._probs.append((
             A or N_, B or N_, C or N_, bias or N_, residual or N_, aux_in or N_, aux_out or N_, a_gather or N_,
             b_gather or N_, c_gather or N_, lim or N_, alpha_amax or N_, (x3[0] if x3 is not None else N_),
+            (mtiles[0] if mtiles is not None else N_),
             M, N, K, lda, ldb, ldc, a_mode, b_mode, a_qs[0], a_qs[1], b_qs[0], b_qs[1], c_qs[0], c_qs[1], bias_q, bias_s,
             bias_stride, act, dact, flags, b_kmap[0], b_kmap[1],
-            (x3[1] if x3 is not None else 0), alpha, ksplit, (lim_kind if lim is not None else 0),
-            (0 if xcd is None else 1 + int(xcd) % 8)))
+            (x3[1] if x3 is not None else 0), alpha, ksplit, (lim_kind if (lim is not None or mtiles is not None) else 0),
+            (0 if xcd is None else 1 + int(xcd) % 8), (mtiles[1] if mtiles is not None else 0)))
         if ln is not None:
             self._ln[len(self._probs) - 1] = ln
         return len(self._probs) - 1
@@ -367,7 +371,7 @@ class Program:
         return p0
 
     _PROBLEM_REFS = ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim',
-                     'alpha_amax', 'B2')
+                     'alpha_amax', 'B2', 'mtiles')
     _PROBLEM_INTS = ('M', 'N', 'K', 'lda', 'ldb', 'ldc', 'a_mode', 'b_mode', 'a_q', 'a_s', 'b_q', 'b_s', 'c_q', 'c_s',
                      'bias_q', 'bias_s', 'bias_stride', 'act', 'dact', 'flags', 'b_kq', 'b_ks', 'x3_slice')
 
@@ -385,6 +389,7 @@ class Program:
             arr[name] = np.asarray(cols[nr + k], dtype=np.int64)
         k = nr + len(self._PROBLEM_INTS)
         arr['alpha'], arr['ksplit'], arr['lim_kind'], arr['xcd_pin'] = cols[k], cols[k + 1], cols[k + 2], cols[k + 3]
+        arr['n_mtiles'] = cols[k + 4]
         arr['ln_p']['buf'] = -1
         for q, (kind, refs, eps) in self._ln.items():
             arr['ln_kind'][q], arr['ln_eps'][q] = kind, eps
@@ -411,7 +416,7 @@ class Program:
             if tag:
                 flags |= L.OPFLAG_TIMED | (tag << 16)
                 fl = flops if flops is not None else \
-                    sum(2.0 * int(p[13]) * int(p[14]) * int(p[15]) for p in self._probs[first:first + count])
+                    sum(2.0 * int(p[14]) * int(p[15]) * int(p[16]) for p in self._probs[first:first + count])
                 self.tag_flops[tag] = self.tag_flops.get(tag, 0.0) + fl
             self.op(L.OP_GEMM, ints=(first, count, tile, grid_cap), flags=flags)
 
@@ -424,6 +429,31 @@ class Program:
         if main >= 128 and 0 < rem <= 64:
             return [(0, main), (main, rem)]
         return [(0, rows)]
+
+    # cost of one k-tile step of a (64 mi) x 256 tile of the 8-phase kernel, mi = 3, 4, 5 (tools/gemm_lab.hip, relative)
+    P8_COST = {3: 1.72, 4: 2.0, 5: 2.42}
+    P8_MI = (3, 4)          # (the library kernel instantiates 192- and 256-row tiles; 320 exists in tools/gemm_lab.hip)
+
+    @classmethod
+    def row_tiles(cls, ext):
+        """Row tiles of the 8-phase kernel (tile code 28) for stacked rows whose extents `ext` (one per row: valid columns of
+        the forward = reduction length of the dgrad) do not increase: tiles of 192 / 256 / 320 rows, each paying for the
+        extent of its FIRST row over all its rows.  Exact minimum of sum(cost[mi] * extent) by dynamic programming over
+        64-row positions (533 full-width rows followed by 235 rows of a third of the width: 320 + 256 + 192 instead of
+        three full-width 256-row tiles).  Returns an int32 array of {m0, mi, extent} triples."""
+        ext = np.asarray(ext, dtype=np.int64)
+        R = len(ext)
+        n = (R + 63) // 64
+        best = [0.0] * (n + 6)
+        choice = [0] * (n + 6)
+        for k in range(n - 1, -1, -1):
+            e = float(ext[k * 64]) + 1e-3           # (the epsilon: fewer tiles among equals)
+            best[k], choice[k] = min((cls.P8_COST[mi] * e + best[min(k + mi, n)], mi) for mi in cls.P8_MI)
+        out, k = [], 0
+        while k < n:
+            out.append((k * 64, choice[k], int(ext[k * 64])))
+            k += choice[k]
+        return np.asarray(out, dtype=np.int32).reshape(-1, 3)
 
     # ------------------------------------------------------------------ decoder layout (host bookkeeping)
     def _src_row(self, ind):
@@ -546,6 +576,11 @@ class Program:
                 ext[sb['row0'] - gg['row0']: sb['row0'] - gg['row0'] + sb['rows']] = sb['cols']
             gg['lim128'] = np.asarray([ext[t0:t0 + 128].max() for t0 in range(0, gg['rows'], 128)], dtype=np.int32)
             gg['ragged'] = len(subs) > 1
+            gg['ext'] = ext
+            # row tiles of the 8-phase kernel (families with at least ~a tile of rows; the rest runs on 128 x 128 tiles)
+            gg['p8'] = self.use_p8 and self.direct16 and gg['i_ld'] % 8 == 0 and gg['rows'] >= 160
+            if gg['p8']:
+                gg['mtiles'] = self.row_tiles(ext)
         self.M = row
         # per-row arrays
         self.row_src = np.zeros(self.M, dtype=np.int32)
@@ -926,7 +961,8 @@ class Program:
                               self.wref('tiles', g['tile_off']),
                               g['rows'], g['cols'], 8 * C, 8 * C, 8 * C, g['ld'], b_qs=(g['i_ld'], ms[1]),
                               bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1], op16=True,
-                              lim=self.idx(g['lim128']) if g['ragged'] else None, lim_kind=1)
+                              lim=self.idx(g['lim128']) if g['ragged'] else None, lim_kind=1,
+                              mtiles=(self.idx(g['mtiles']), len(g['mtiles'])) if g['p8'] else None)
                     continue
                 for (r0, nr) in self._row_parts(g['rows']):
                     self.gemm((u[0], u[1] + 4 * (g['row0'] + r0) * 8 * C), self.pref(W2),
@@ -934,7 +970,7 @@ class Program:
                               nr, g['cols'], 8 * C, 8 * C, 8 * C, g['ld'], b_qs=(g['i_ld'], ms[1]),
                               bias=self.pref(b2), bias_q=g['i_ld'], bias_s=ms[1],
                               act=L.ACT_RELU if g['kind'] == 'cls' else L.ACT_NONE)
-            self.gemm_op(p0, tag=self.TAG_D3_FWD, flops=fl)
+            self.gemm_op(p0, tag=self.TAG_D3_FWD, flops=fl, tile=28 if any(g.get('p8') for g in self.gemm_groups) else 0)
             # classifier rows of the 16-bit pipeline: ReLU afterwards, elements the f16 product left within 5e-3 rms of
             # zero recomputed in fp32 (their sign is the ReLU mask of the backward)
             for gg in self.gemm_groups:
@@ -1445,11 +1481,16 @@ class Program:
                         lim = None
                         if g['ragged'] or kc < g['cols']:
                             lim = self.idx(np.clip(g['lim128'] - k0, 0, kc).astype(np.int32))
+                        mt = None
+                        if g['p8']:
+                            mt = g['mtiles'].copy()
+                            mt[:, 2] = np.clip(mt[:, 2] - k0, 0, kc)
+                            mt = (self.idx(mt), len(mt))
                         self.gemm(self.href(g['dth'] + min(k0, g['cols'])),
                                   self.sref(self.w2hT + min(j * oc, g['o']) * ms[1]), dst,
                                   g['rows'], 8 * C, kc, g['dth_ld'], self.w2hT_ld, 8 * C, op16=True,
                                   b_kmap=(g['i_ld'], ms[1]), lim=lim, lim_kind=2, alpha_amax=amax_t,
-                                  xcd=j if (pin and n_planes == 8) else None)
+                                  xcd=j if (pin and n_planes == 8) else None, mtiles=mt)
                     continue
                 if planes:
                     # (groups outside the 16-bit pipeline have i <= 4: a short reduction, one pass into plane 0)
@@ -1470,7 +1511,9 @@ class Program:
                           (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C),
                           g['rows'], 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
                           b_qs=(g['i_ld'], ms[1]), ksplit=ks)
-            self.gemm_op(p0, ctype=bct if g16 else None, tag=self.TAG_D3_DGRAD, flops=fl, tile=20 if use_rect else 0)
+            p8_dgrad = planes and any(g.get('p8') for g in g16)
+            self.gemm_op(p0, ctype=bct if g16 else None, tag=self.TAG_D3_DGRAD, flops=fl,
+                         tile=28 if p8_dgrad else 20 if use_rect else 0)
             self._ops.extend(late_ops)
             if planes and n_planes > 1:
                 self.op(L.OP_DACT, refs=(d_u, u, amax_u if amax_u is not None else self.NONE, d_up),

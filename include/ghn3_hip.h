@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 11
+#define GHN3_ABI_VERSION 12
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -137,6 +137,14 @@ typedef struct ghn3_gemm_problem {
     /* GHN3_GEMM_X3 only: the lo copy of B and the K slice a workgroup stages at a time */
     ghn3_ref B2;
     int32_t x3_slice, _pad3;
+    /* GHN3_GEMM_OP16, tile code 28 only, optional: row-tile table, `n_mtiles` int32 triples {m0, mi, extent}.  Row tile t
+     * covers rows [m0, m0 + 64 * mi) with mi in {3, 4, 5} (192 / 256 / 320 rows; tiles must not overlap, rows beyond M are
+     * ignored) and `extent` replaces the per-128-row `lim` entries for it: valid columns (lim_kind 1) or valid reduction
+     * length (lim_kind 2) of the tile's rows; lim_kind 0 ignores it.  Lets the host cut a stacked decoder family at its
+     * extent boundaries with little row padding (533 full-width rows = 320 + 256 instead of three 256-row tiles).
+     * Absent: 256-row tiles and `lim` as for the other 16-bit-operand kernels. */
+    ghn3_ref mtiles;
+    int32_t n_mtiles, _pad4;
 } ghn3_gemm_problem;
 
 /* ---- 16-bit operand copies (GHN3_OP_CAST16) -----------------------------------------------------------
@@ -205,7 +213,9 @@ enum ghn3_op_kind {
     GHN3_OP_NOP = 0,
     /* i: first_problem, n_problems, tile (0 auto / 32 / 64 / 128 for fp32 operands; 0 auto / 16 = 128x128 / 24 = 256x256 /
      * 20 = 256x128 with a three-stage ring / 25 = persistent 256x256 for output-heavy PLAIN problems (C = alpha A B^T,
-     * optional row map of C: short K, e.g. the W2 weight gradient) for GHN3_GEMM_OP16 problems), grid cap for GHN3_GEMM_OP16 launches (0 = one workgroup per tile; > 0: at most
+     * optional row map of C: short K, e.g. the W2 weight gradient) / 28 = the 8-phase kernel, (192 | 256 | 320) x 256 tiles,
+     * no split-K / gathers (problems of the op with fewer than 160 rows or with ksplit > 1 fall back to 16) for
+     * GHN3_GEMM_OP16 problems), grid cap for GHN3_GEMM_OP16 launches (0 = one workgroup per tile; > 0: at most
      * that many CUs' worth of persistent workgroups -- a side-stream GEMM that should leave CUs to the chain it runs beside) */
     GHN3_OP_GEMM = 1,                 /* every nn.Linear / F.linear on the path */
     /* graphormer.py:229-237 -- degree counts of A==1, A[0,:], fw/bw pair index

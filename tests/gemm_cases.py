@@ -192,8 +192,11 @@ def round16(x, ctype):
 
 
 def run_op16_case(ctx, M, N, K, ctype=L.CT_F16, tile=0, grid_cap=0, a_transposed=False, b_transposed=False, kmap=None, ksplit=1,
-                  epilogue='none', accum=False, colsum=False, cmap=False, seed=0, dev='cuda', pins=None):
-    """pins: a list (one entry per problem of ONE launch) of XCD numbers or None: problem r multiplies the first
+                  epilogue='none', accum=False, colsum=False, cmap=False, seed=0, dev='cuda', pins=None, mtiles=None,
+                  ragged=0):
+    """mtiles: row-tile table of tile code 28 as a list of (m0, mi[, extent]); ragged = 1: the extents are valid COLUMNS
+    (columns of a tile beyond its extent are don't-care), 2: valid reduction lengths (A holds zeros beyond them).
+    pins: a list (one entry per problem of ONE launch) of XCD numbers or None: problem r multiplies the first
     M - 29 r rows of the same A into its own C (ghn3_gemm_problem::xcd_pin)."""
     rs = np.random.RandomState(seed)
     r64 = lambda v: (v + 63) // 64 * 64
@@ -201,6 +204,9 @@ def run_op16_case(ctx, M, N, K, ctype=L.CT_F16, tile=0, grid_cap=0, a_transposed
     kq, ks = kmap if kmap else (0, 0)
     Kp = ((K + kq - 1) // kq) * ks if kmap else K
     A_log = rs.standard_normal((M, K)).astype(np.float32)
+    if ragged == 2:
+        for (m0_, mi_, e_) in mtiles:
+            A_log[m0_:m0_ + 64 * mi_, e_:] = 0
     B_phys = rs.standard_normal((N, Kp)).astype(np.float32)
     kk = np.arange(K)
     kphys = (kk // kq) * ks + kk % kq if kmap else kk
@@ -254,8 +260,14 @@ def run_op16_case(ctx, M, N, K, ctype=L.CT_F16, tile=0, grid_cap=0, a_transposed
     # expectation
     Ar, Br = round16(A_log, ctype).astype(np.float64), round16(B_log, ctype).astype(np.float64)
     v = Ar @ Br.T
+    aux = rs.standard_normal((c_rows, ldc)).astype(np.float32)
+    res = rs.standard_normal((c_rows, ldc)).astype(np.float32)
+    pre = None
     if epilogue == 'bias_relu':
         v = np.maximum(v + bias[:N][None, :], 0)
+    if epilogue == 'drelu_res':                       # alpha, bias, aux_out, dReLU(aux_in), residual
+        pre = 0.5 * v + bias[:N][None, :]
+        v = np.where(aux[c_idx][:, :N] > 0, pre, 0.0) + res[c_idx][:, :N]
     if accum or ksplit > 1:
         v = v + C0[c_idx][:, :N]
     expected = C0.astype(np.float64).copy()
@@ -270,11 +282,20 @@ def run_op16_case(ctx, M, N, K, ctype=L.CT_F16, tile=0, grid_cap=0, a_transposed
     # round64(K) logical k -> zero the B area like the program does for its workspace
     d_16[dB_off:] = 0
     d_desc, d_C, d_bias, d_dbias = t(descs.view(np.uint8)), t(C0), t(bias), t(dbias0)
-    bufs = [d_src, d_16, d_desc, d_C, d_bias, d_dbias]
+    d_aux, d_res, d_pre = t(aux), t(res), torch.zeros(c_rows, ldc, device=dev)
+    mt = np.zeros((1, 3), np.int32)
+    if mtiles is not None:
+        mt = np.asarray([(m_[0], m_[1], m_[2] if len(m_) > 2 else (1 << 30)) for m_ in mtiles], dtype=np.int32)
+    d_mt = t(mt)
+    bufs = [d_src, d_16, d_desc, d_C, d_bias, d_dbias, d_aux, d_res, d_pre, d_mt]
     ptrs = np.asarray([b.data_ptr() for b in bufs], dtype=np.uint64)
     p = np.zeros(1, dtype=L.PROBLEM_DT)
-    for name in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim', 'alpha_amax'):
+    for name in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim', 'alpha_amax',
+                 'B2', 'mtiles'):
         p[name]['buf'] = -1
+    p['ln_p']['buf'] = -1
+    if mtiles is not None:
+        p['mtiles']['buf'], p['n_mtiles'], p['lim_kind'] = 9, len(mt), ragged
     p['A']['buf'], p['A']['off'] = 1, 2 * dA_off
     p['B']['buf'], p['B']['off'] = 1, 2 * dB_off
     p['C']['buf'] = 3
@@ -285,6 +306,9 @@ def run_op16_case(ctx, M, N, K, ctype=L.CT_F16, tile=0, grid_cap=0, a_transposed
     p['c_q'], p['c_s'] = cq, cs
     p['flags'] = L.GEMM_OP16 | (L.GEMM_ACCUM if accum else 0)
     p['alpha'] = 1.0
+    if epilogue == 'drelu_res':
+        p['bias']['buf'], p['aux_in']['buf'], p['residual']['buf'], p['aux_out']['buf'] = 4, 6, 7, 8
+        p['dact'], p['alpha'] = L.DACT_RELU, 0.5
     p['ksplit'] = ksplit
     p['b_kq'], p['b_ks'] = kq, ks
     p['bias_stride'] = 1
@@ -319,7 +343,16 @@ def run_op16_case(ctx, M, N, K, ctype=L.CT_F16, tile=0, grid_cap=0, a_transposed
         return out
     ctx.run(ops, p, ptrs, torch.cuda.current_stream().cuda_stream)
     torch.cuda.synchronize()
-    out = [(d_C.cpu().numpy(), expected)]
+    got = d_C.cpu().numpy()
+    if ragged == 1:                                   # columns beyond a tile's extent are don't-care
+        for (m0_, mi_, e_) in mtiles:
+            rows_ = c_idx[m0_:min(m0_ + 64 * mi_, M)]
+            expected[rows_, e_:N] = got[rows_, e_:N]
+    out = [(got, expected)]
+    if pre is not None:
+        e_pre = np.zeros((c_rows, ldc))
+        e_pre[c_idx, :N] = pre
+        out.append((d_pre.cpu().numpy(), e_pre))
     if colsum:
         out.append((d_dbias.cpu().numpy(), dbias_exp))
     return out
@@ -363,6 +396,22 @@ OP16_CASES = [
     dict(M=533, N=384, K=64 * 12, kmap=(64, 96), tile=20, pins=[0, 1, 2, 3, 4, 5, 6, 7]),
     dict(M=700, N=300, K=130, tile=20, pins=[1, None, 6, 6, 3, None, None, 1, 4, 4], grid_cap=3),
     dict(M=300, N=200, K=64, pins=[3, 5, None]),
+    # the 8-phase kernel (tile code 28): default 256-row tiles, ragged M / N, one / few / many k-tiles (ring wrap-around and
+    # the tail waits), K = 0 is covered by the pinned planes of the program; row-tile tables with 192 / 256 / 320-row tiles,
+    # extents as columns and as reduction lengths, k-map, row map of C, accumulate, the full epilogue, XCD pins, grid cap
+    dict(M=300, N=520, K=150, tile=28),
+    dict(M=1100, N=1300, K=512, epilogue='bias_relu', tile=28),
+    dict(M=533, N=384, K=64 * 48, kmap=(64, 96), tile=28),
+    dict(M=260, N=250, K=64, tile=28, accum=True),
+    dict(M=200, N=7, K=9, tile=28),
+    dict(M=300, N=200, K=150, a_transposed=True, b_transposed=True, cmap=True, accum=True, tile=28),
+    dict(M=700, N=600, K=64 * 7, tile=28, mtiles=[(0, 4), (256, 3), (448, 4)]),
+    dict(M=533, N=1000, K=64 * 5 + 8, tile=28, mtiles=[(0, 3), (192, 3), (384, 3)], epilogue='drelu_res'),
+    dict(M=700, N=900, K=64 * 3, tile=28, mtiles=[(0, 3, 900), (192, 3, 900), (384, 4, 520), (640, 3, 64)], ragged=1, epilogue='bias_relu'),
+    dict(M=768, N=300, K=64 * 9, tile=28, mtiles=[(0, 4, 576), (256, 4, 300), (512, 4, 64)], ragged=2, kmap=(64, 96)),
+    dict(M=640, N=512, K=64 * 2, tile=28, mtiles=[(0, 3), (192, 4), (448, 3)], grid_cap=3),
+    dict(M=533, N=384, K=64 * 12, kmap=(64, 96), tile=28, pins=[0, 1, 2, 3, 4, 5, 6, 7]),
+    dict(M=700, N=300, K=130, tile=28, pins=[1, None, 6, 6, 3, None, None, 1, 4, 4], grid_cap=3),
     # persistent workgroups (grid cap): 3 workgroups stride over 99 / 30 tiles
     dict(M=1100, N=1300, K=512, epilogue='bias_relu', grid_cap=3),
     dict(M=1100, N=1300, K=200, tile=24, grid_cap=3, accum=True),

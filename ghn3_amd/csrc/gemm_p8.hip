@@ -42,6 +42,18 @@ typedef const f32x4 GAS* gcf4;
 
 namespace {
 
+// Values read from the problem table are wave-uniform, but the compiler cannot prove it (the table index comes out of a
+// search over loaded values): without help they live in VGPRs, every "uniform" branch becomes an exec-mask dance and the
+// operand bases are re-read with v_readfirstlane at each DMA.  rfl() pins them to SGPRs.
+__device__ __forceinline__ int rfl(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float rflf(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+template <typename T> __device__ __forceinline__ T* rflp(T* p) {
+    const uint64_t u = reinterpret_cast<uint64_t>(p);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    const uint32_t hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(u >> 32));
+    return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
+}
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ int p8_map_row(int r, int q, int s) {
@@ -73,21 +85,21 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int r16 = lane & 15, kc = lane >> 4;
-    const int M = P->M, N = P->N;
+    const int M = rfl(P->M), N = rfl(P->N);
     const int nkt = (K + BK - 1) / BK;
     const int nq = 4 * nkt;
-    const char GAS* Ab = (const char GAS*)P->A;
-    const char GAS* Bb = (const char GAS*)P->B;
+    const char GAS* Ab = (const char GAS*)rflp(P->A);
+    const char GAS* Bb = (const char GAS*)rflp(P->B);
 
     // byte offsets of this thread's DMA pieces at k = 0 (the host checked that both operands span < 4 GB)
     unsigned oa[2][NPA], ob[2][2];
     const int slot = tid & 7, rb = tid >> 3;
     const int ck = (slot ^ ((rb >> 1) & 7)) * 8;     // k offset (16-bit elements) of this lane's chunk in the full rounds
     {
-        const unsigned lda2 = (unsigned)P->lda * 2u, ldb2 = (unsigned)P->ldb * 2u;
-        const int aq = P->a_q, as = P->a_s, bq = P->b_q, bs = P->b_s;
-        const int kq0 = P->kq;
-        const int ckb = (kq0 > 0 && kq0 < 64) ? (ck / kq0) * P->ks + ck % kq0 : ck;   // k-map, per-lane part (64 % kq == 0)
+        const unsigned lda2 = (unsigned)rfl(P->lda) * 2u, ldb2 = (unsigned)rfl(P->ldb) * 2u;
+        const int aq = rfl(P->a_q), as = rfl(P->a_s), bq = rfl(P->b_q), bs = rfl(P->b_s);
+        const int kq0 = rfl(P->kq);
+        const int ckb = (kq0 > 0 && kq0 < 64) ? (ck / kq0) * rfl(P->ks) + ck % kq0 : ck;   // k-map, per-lane part (64 % kq == 0)
         auto arow = [&](int rho, int h) -> unsigned {    // buffer row of A_h -> operand row
             const int w = rho >= 16 * MI;
             const int r = min(m0 + w * (BM / 2) + h * 16 * MI + (rho - w * 16 * MI), M - 1);
@@ -114,7 +126,7 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
     // 1, ...), so the byte offsets along k are wave-uniform running values: A advances 128 bytes per k-tile, B follows the
     // k-map (physical k = (k / kq) * ks + k % kq; the host admits kq % 64 == 0 -- a k-tile never straddles a period -- or
     // 64 % kq == 0 -- the per-lane part is constant and already folded into ob[][]).
-    const int kq = P->kq, ks = P->ks;
+    const int kq = rfl(P->kq), ks = rfl(P->ks);
     int kA = 0, kB = 0, tmod = 0, par = 0, qi = 0;   // bytes, bytes, k inside the current period, ring parity offset, next q
     const int stepB = kq > 0 && kq < 64 ? (64 / kq) * ks * 2 : 128;
     auto issue = [&](const int j) {                   // j = (next half-tile) & 3, known at every call site
@@ -246,15 +258,18 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
     // a lane's four columns are all inside or all outside).  Order: acc * alpha -> + bias -> aux_out -> ReLU -> dReLU(aux_in)
     // -> + residual -> (+ C) -> store
     {
-        gf C = (gf)P->C;
-        gcf residual = (gcf)P->residual;
-        gcf aux_in = (gcf)P->aux_in;
-        gf aux_out = (gf)P->aux_out;
-        gcf bias = (P->flags & GHN3_GEMM_BIASGRAD) ? nullptr : (gcf)P->bias;
-        const int ldc = P->ldc, cq = P->c_q, cs = P->c_s;
-        const bool act_relu = P->act == GHN3_ACT_RELU, dact_relu = P->dact == GHN3_DACT_RELU;
-        const bool accum = (P->flags & GHN3_GEMM_ACCUM) != 0;
-        const float alpha = P->alpha_amax ? P->alpha * ghn3_pow2_inv_scale(*P->alpha_amax) : P->alpha;
+        const int flags = rfl(P->flags);
+        gf C = (gf)rflp(P->C);
+        gcf residual = (gcf)rflp(P->residual);
+        gcf aux_in = (gcf)rflp(P->aux_in);
+        gf aux_out = (gf)rflp(P->aux_out);
+        gcf bias = (flags & GHN3_GEMM_BIASGRAD) ? nullptr : (gcf)rflp(P->bias);
+        const int ldc = rfl(P->ldc), cq = rfl(P->c_q), cs = rfl(P->c_s);
+        const int bias_q = rfl(P->bias_q), bias_s = rfl(P->bias_s), bias_stride = rfl(P->bias_stride);
+        const bool act_relu = rfl(P->act) == GHN3_ACT_RELU, dact_relu = rfl(P->dact) == GHN3_DACT_RELU;
+        const bool accum = (flags & GHN3_GEMM_ACCUM) != 0;
+        const float* amax_p = rflp(P->alpha_amax);
+        const float alpha = rflf(amax_p ? P->alpha * ghn3_pow2_inv_scale(*amax_p) : P->alpha);
         const int col0 = n0 + wc * 64 + 4 * kc;       // + 32 b + 16 ni
         f32x4 bv[2][2];
 #pragma unroll
@@ -267,8 +282,8 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
                         int bi = col + e;
-                        if (P->bias_q > 0) bi = (bi / P->bias_q) * P->bias_s + (bi % P->bias_q);
-                        v[e] = bias[(int64_t)bi * P->bias_stride];
+                        if (bias_q > 0) bi = (bi / bias_q) * bias_s + (bi % bias_q);
+                        v[e] = bias[(int64_t)bi * bias_stride];
                     }
                 }
                 bv[b][ni] = v;
@@ -311,59 +326,64 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
 // problem is cut into 256-row tiles and the extent comes from the per-128-row `lim` array as in the older kernels.
 template <int CT>
 __device__ __forceinline__ void p8_dispatch(const GemmProbDev* __restrict__ probs, int n_probs, int tile_id, char* sm) {
-    const GemmProbDev* P;
-    int mt, nt;
-    const int pin_end = probs[0].pin_end;
+    int idx, mt, nt;
+    const int pin_end = rfl(probs[0].pin_end);
     if (tile_id < pin_end) {
         // XCD-pinned problems: id -> (XCD, local index); the problems of an XCD are found through the directory in entry x
         const int x = tile_id & 7, local = tile_id >> 3;
-        const int cnt = probs[x].pin_count;
+        const int cnt = rfl(probs[x].pin_count);
         if (cnt == 0) return;
-        int lo = probs[x].pin_first, hi = lo + cnt - 1;
+        int lo = rfl(probs[x].pin_first), hi = lo + cnt - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (probs[mid].tile_start <= local) lo = mid; else hi = mid - 1;
+            if (rfl(probs[mid].tile_start) <= local) lo = mid; else hi = mid - 1;
         }
-        P = probs + lo;
-        const int t = local - P->tile_start;
-        if (t >= P->tiles_m * P->tiles_n) return;
-        mt = t % P->tiles_m;                          // row tiles of a column tile back to back: they share its B rows
-        nt = t / P->tiles_m;
+        idx = lo;
+        const int t = local - rfl(probs[idx].tile_start);
+        const int tm = rfl(probs[idx].tiles_m);
+        if (t >= tm * rfl(probs[idx].tiles_n)) return;
+        // row tile by row tile (a chunk's <= 36 tiles all start at once on its XCD, so they still share B rows in L2): the
+        // rows are sorted by decreasing extent, i.e. the long tiles are dispatched first and the short ones (a third of the
+        // reduction for the narrow groups of a family) fill the remaining CUs instead of delaying a long tile
+        const int tn = rfl(probs[idx].tiles_n);
+        mt = t / tn;
+        nt = t % tn;
     } else {
-        const int n_pin = probs[0].pin_total;
-        int lo = n_pin, hi = n_probs - 1;
+        int lo = rfl(probs[0].pin_total), hi = n_probs - 1;
         while (lo < hi) {
             const int mid = (lo + hi + 1) >> 1;
-            if (probs[mid].tile_start <= tile_id) lo = mid; else hi = mid - 1;
+            if (rfl(probs[mid].tile_start) <= tile_id) lo = mid; else hi = mid - 1;
         }
-        P = probs + lo;
+        idx = lo;
         // the row tiles of one column tile (same streamed B panel) are congruent mod 8: same XCD, same L2
-        const int t = tile_id - P->tile_start, grp = t >> 3;
-        nt = (grp / P->tiles_m) * 8 + (t & 7);
-        mt = grp % P->tiles_m;
-        if (nt >= P->tiles_n) return;
+        const int t = tile_id - rfl(probs[idx].tile_start), grp = t >> 3;
+        const int tm = rfl(probs[idx].tiles_m);
+        nt = (grp / tm) * 8 + (t & 7);
+        mt = grp % tm;
+        if (nt >= rfl(probs[idx].tiles_n)) return;
     }
+    const GemmProbDev* P = probs + idx;
+    const int M = rfl(P->M);
+    const int* mtab = rflp(P->mtab);
     int m0, mi, ext;
-    if (P->mtab) {
-        const int* e = P->mtab + 3 * mt;
-        m0 = e[0]; mi = e[1]; ext = e[2];
+    if (mtab) {
+        m0 = rfl(mtab[3 * mt]); mi = rfl(mtab[3 * mt + 1]); ext = rfl(mtab[3 * mt + 2]);
     } else {
         m0 = mt * 256; mi = 4; ext = 0x7fffffff;
-        if (P->lim) {
-            ext = P->lim[m0 >> 7];
-            if (m0 + 128 < P->M) ext = max(ext, P->lim[(m0 >> 7) + 1]);
+        const int* lim = rflp(P->lim);
+        if (lim) {
+            ext = rfl(lim[m0 >> 7]);
+            if (m0 + 128 < M) ext = max(ext, rfl(lim[(m0 >> 7) + 1]));
         }
     }
-    if (m0 >= P->M) return;
+    if (m0 >= M) return;
     const int n0 = nt * 256;
-    int K = P->K;
-    if (P->lim_kind == 1) { if (n0 >= ext) return; }
-    else if (P->lim_kind == 2) K = min(K, ext);
-    // (MI = 5 -- 320 rows -- is written and verified in tools/gemm_lab.hip, but with the row / k maps of the library
-    // contract its 160 accumulators + 72 fragment registers leave no room: the compiler spills an address register inside
-    // the loop and the reload drains the DMA queue.  Every row count >= 384 is a sum of 192s and 256s rounded up to 64, so
-    // the row padding is the same; 192-row tiles cost ~15 % more per row.)
-    if (mi == 3) p8_tile<CT, 3>(P, m0, n0, K, sm);
+    int K = rfl(P->K);
+    const int lim_kind = rfl(P->lim_kind);
+    if (lim_kind == 1) { if (n0 >= ext) return; }
+    else if (lim_kind == 2) K = min(K, ext);
+    if (mi == 5) p8_tile<CT, 5>(P, m0, n0, K, sm);   // (160 accumulators + 72 fragment registers: fits 256 only because
+    else if (mi == 3) p8_tile<CT, 3>(P, m0, n0, K, sm);   //  every table value lives in SGPRs; spills stay outside the k loop)
     else p8_tile<CT, 4>(P, m0, n0, K, sm);
 }
 
@@ -376,18 +396,259 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmProbDev* __re
     }
 }
 
-constexpr int kP8Lds = 2 * (2 * 4 * 4096 + 32768);    // MI = 4: 128 KB
+// ---------------------------------------------------------------------------------------------------------------------
+// Tile code 29: the 8-phase loop as a PERSISTENT STREAM for output-heavy plain problems -- the decoder's W2 weight gradient
+// dW2 [o i x 8C] = d_tiles^T u (autograd of nn.py:747-749): K = the family's rows (9..23 k-tiles) and 256 KB of fp32 output
+// per tile, so a tile's prologue (first DMA round trip) and its stores weigh as much as its k loop.  Here
+//   * a workgroup walks its tiles (XCD-blocked order of tile code 25) and the half-tile DMA stream simply CONTINUES across
+//     tile boundaries: the issue side runs 7 half-tiles ahead of the compute side, switches to the next tile's operand
+//     rows when it has issued the last k-tile of the current one (the offsets are recomputed there, no second set of
+//     registers), and the LDS ring never drains between tiles;
+//   * the stores of a finished tile are DEFERRED into the first k-tile of the next one: phase p of that k-tile stores
+//     quadrant p of the old accumulators from its load segment -- i.e. while the partner wave of the SIMD multiplies --
+//     right before the quadrant's first MFMA of the new tile overwrites it (that MFMA takes C = 0 as an inline constant:
+//     no re-zeroing pass).  Stores and DMA share vmcnt; loads retire in order among themselves, so a counted wait with
+//     stores in between only ever over-waits.
+// Contract as tile code 25 (checked by the host): C = alpha * A B^T with an optional row map of C; no bias / activation /
+// residual / accumulate / gathers / k-map / ragged extents / split-K; N % 4 == 0, K >= 1; 256 x 256 tiles.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int total_tiles) {
+    constexpr int MI = 4, BK = 64;
+    constexpr int AH = 32 * MI * 128, BH = 128 * 128, KT = 2 * AH + 2 * BH;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* sm = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = rfl(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r16 = lane & 15, kc = lane >> 4;
+    const int stride = (int)gridDim.x;
+
+    // first valid tile at or behind id t (XCD-blocked order: see gemm_h16w_kernel / runtime.hip) -> problem index, origin, k-tiles
+    auto next_tile = [&](int t, int& idx, int& m0, int& n0, int& nkt) -> int {
+        for (; t < total_tiles; t += stride) {
+            int lo = 0, hi = n_probs - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (rfl(probs[mid].tile_start) <= t) lo = mid; else hi = mid - 1;
+            }
+            const GemmProbDev* Q = probs + lo;
+            const int tl = t - rfl(Q->tile_start), x = tl & 7, grp = tl >> 3;
+            const int G = rfl(Q->xcd_cols), Gm = 8 / G;
+            const int tn = rfl(Q->tiles_n), tm = rfl(Q->tiles_m);
+            const int npg = (tn + G - 1) / G;
+            const int nt = (x % G) * npg + grp % npg, mt = (grp / npg) * Gm + x / G;
+            if (nt >= tn || mt >= tm) continue;
+            idx = lo; m0 = mt * 256; n0 = nt * 256; nkt = (rfl(Q->K) + BK - 1) / BK;
+            return t;
+        }
+        return total_tiles;
+    };
+
+    // ---- issue side -------------------------------------------------------------------------------------------------
+    int i_idx = 0, i_m0 = 0, i_n0 = 0, i_nkt = 0;
+    int it = next_tile((int)blockIdx.x, i_idx, i_m0, i_n0, i_nkt);
+    if (it >= total_tiles) return;                    // (uniform over the workgroup)
+    // ---- compute side starts at the same tile
+    int c_idx = i_idx, c_m0 = i_m0, c_n0 = i_n0, c_nkt = i_nkt, ct = it;
+
+    unsigned oa[2][2], ob[2][2];
+    const char GAS* Ab = nullptr;
+    const char GAS* Bb = nullptr;
+    const int slot = tid & 7, rb = tid >> 3;
+    const unsigned ck2 = (unsigned)((slot ^ ((rb >> 1) & 7)) * 16);
+    auto load_issue_tile = [&]() {
+        const GemmProbDev* Q = probs + i_idx;
+        Ab = (const char GAS*)rflp(Q->A);
+        Bb = (const char GAS*)rflp(Q->B);
+        const int M = rfl(Q->M), N = rfl(Q->N);
+        const unsigned lda2 = (unsigned)rfl(Q->lda) * 2u, ldb2 = (unsigned)rfl(Q->ldb) * 2u;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int rho = rb + 64 * i;
+                const int ra = min(i_m0 + 128 * (rho >> 6) + 64 * h + (rho & 63), M - 1);
+                const int rn = min(i_n0 + 64 * (rho >> 5) + 32 * h + (rho & 31), N - 1);
+                oa[h][i] = (unsigned)ra * lda2 + ck2;
+                ob[h][i] = (unsigned)rn * ldb2 + ck2;
+            }
+    };
+    load_issue_tile();
+    bool i_live = true;
+    int kA = 0, i_left = i_nkt, par = 0, issued = 0;  // k byte offset, k-tiles left to issue, ring parity offset, half-tiles issued
+    auto issue = [&](const int j) {                   // j = (next half-tile) & 3: 0 = B0, 1 = A0, 2 = B1, 3 = A1
+        if (!i_live) return;
+        char* kt = sm + par;
+        if (j == 1 || j == 3) {
+            const int h = j == 3;
+            LAS char* dst = (LAS char*)(kt + (h ? AH + 2 * BH : 0) + wave * 1024);
+            __builtin_amdgcn_global_load_lds((const void GAS*)(Ab + (oa[h][0] + (unsigned)kA)), (LAS void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void GAS*)(Ab + (oa[h][1] + (unsigned)kA)), (LAS void*)(dst + 8192), 16, 0, 0);
+        } else {
+            const int h = j == 2;
+            LAS char* dst = (LAS char*)(kt + AH + h * BH + wave * 1024);
+            __builtin_amdgcn_global_load_lds((const void GAS*)(Bb + (ob[h][0] + (unsigned)kA)), (LAS void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void GAS*)(Bb + (ob[h][1] + (unsigned)kA)), (LAS void*)(dst + 8192), 16, 0, 0);
+        }
+        ++issued;
+        if (j == 3) {
+            kA += 128; par = KT - par;
+            if (--i_left == 0) {                      // the issue side moves on to the workgroup's next tile
+                it = next_tile(it + stride, i_idx, i_m0, i_n0, i_nkt);
+                i_live = it < total_tiles;
+                if (i_live) { load_issue_tile(); kA = 0; i_left = i_nkt; }
+            }
+        }
+    };
+
+    // ---- compute side -----------------------------------------------------------------------------------------------
+    f32x4 acc[2][2][MI][2];
+    const int sw = r16 >> 1;
+    const int offA = (16 * MI * wr + r16) * 128 + ((kc ^ sw) << 4);
+    const int offB = AH + (32 * wc + r16) * 128 + ((kc ^ sw) << 4);
+    u16x8 fa[MI][2], fb[2][2][2];
+    auto read_a = [&](const char* ring, int a) {
+        const char* base = ring + (a ? AH + 2 * BH : 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            fa[mi][0] = *reinterpret_cast<const u16x8*>(base + offA + mi * 2048);
+            fa[mi][1] = *reinterpret_cast<const u16x8*>(base + (offA ^ 64) + mi * 2048);
+        }
+    };
+    auto read_b = [&](const char* ring, int b) {
+        const char* base = ring + b * BH;
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            fb[b][ni][0] = *reinterpret_cast<const u16x8*>(base + offB + ni * 2048);
+            fb[b][ni][1] = *reinterpret_cast<const u16x8*>(base + (offB ^ 64) + ni * 2048);
+        }
+    };
+    auto mfma_q = [&](int a, int b, const bool first) {   // first: the quadrant starts from zero (inline constant C)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[a][b][mi][ni] = mfma16x16<CT>(fb[b][ni][k2], fa[mi][k2], (first && k2 == 0) ? z : acc[a][b][mi][ni]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // previous tile of this workgroup, whose accumulators are still in the registers
+    bool p_valid = false;
+    gf pC = nullptr;
+    int p_ldc = 0, p_cq = 0, p_cs = 0, p_M = 0, p_N = 0, p_m0 = 0, p_n0 = 0;
+    float p_alpha = 1.f;
+    auto store_prev = [&](int a, int b) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            const int row = p_m0 + wr * 128 + a * 64 + mi * 16 + r16;
+            if (row >= p_M) continue;
+            float GAS* crow = pC + (int64_t)p8_map_row(row, p_cq, p_cs) * p_ldc;
+#pragma unroll
+            for (int ni = 0; ni < 2; ++ni) {
+                const int col = p_n0 + wc * 64 + b * 32 + ni * 16 + 4 * kc;
+                if (col < p_N) *reinterpret_cast<gf4>(crow + col) = acc[a][b][mi][ni] * p_alpha;
+            }
+        }
+    };
+    int G = 0;                                        // k-tiles computed so far (ring parity, half-tile bookkeeping)
+    auto wait_next_ktile = [&]() {                    // k-tile G + 1 (half-tiles .. 4 G + 7) has landed; the newer ones stay in flight
+        const int keep = issued - 1 - (4 * G + 7);
+        if (keep >= 3) wait_vm<6>();
+        else if (keep == 2) wait_vm<4>();
+        else if (keep == 1) wait_vm<2>();
+        else wait_vm<0>();
+    };
+    auto ktile = [&](const bool first) {
+        const char* ring = sm + (G & 1) * KT;
+        const bool st = first && p_valid;
+        if (st) store_prev(0, 0);
+        read_b(ring, 0);                              // (first: retired by the counted lgkmcnt below)
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(ring, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(3);
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * MI) : "memory");
+        __builtin_amdgcn_s_barrier();
+        mfma_q(0, 0, first);
+        __builtin_amdgcn_s_barrier();
+        if (st) store_prev(0, 1);
+        read_b(ring, 1);
+        issue(0);
+        __builtin_amdgcn_s_barrier();
+        mfma_q(0, 1, first);
+        __builtin_amdgcn_s_barrier();
+        if (st) store_prev(1, 1);
+        read_a(ring, 1);
+        issue(1);
+        __builtin_amdgcn_s_barrier();
+        mfma_q(1, 1, first);
+        __builtin_amdgcn_s_barrier();
+        issue(2);
+        wait_next_ktile();
+        if (st) store_prev(1, 0);                     // (behind the wait: these stores are not waited for with the DMA)
+        __builtin_amdgcn_s_barrier();
+        mfma_q(1, 0, first);
+        __builtin_amdgcn_s_barrier();
+        ++G;
+    };
+
+#pragma unroll
+    for (int q = 0; q < 7; ++q) issue(q & 3);
+    {                                                 // k-tile 0 (half-tiles 0..3)
+        const int keep = issued - 1 - 3;
+        if (keep >= 3) wait_vm<6>(); else if (keep == 2) wait_vm<4>(); else if (keep == 1) wait_vm<2>(); else wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs one barrier behind
+
+    while (ct < total_tiles) {
+        ktile(true);
+        for (int kt = 1; kt < c_nkt; ++kt) ktile(false);
+        {                                             // this tile's accumulators are stored during the next tile's first k-tile
+            const GemmProbDev* Q = probs + c_idx;
+            pC = (gf)rflp(Q->C);
+            p_ldc = rfl(Q->ldc); p_cq = rfl(Q->c_q); p_cs = rfl(Q->c_s); p_M = rfl(Q->M); p_N = rfl(Q->N);
+            p_m0 = c_m0; p_n0 = c_n0;
+            const float* amax_p = rflp(Q->alpha_amax);
+            p_alpha = rflf(amax_p ? Q->alpha * ghn3_pow2_inv_scale(*amax_p) : Q->alpha);
+            p_valid = true;
+        }
+        ct = next_tile(ct + stride, c_idx, c_m0, c_n0, c_nkt);
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();        // pairs the extra barrier of wave row 1
+    store_prev(0, 0); store_prev(0, 1); store_prev(1, 1); store_prev(1, 0);
+}
+
+constexpr int kP8Lds = 2 * (2 * 5 * 4096 + 32768);    // MI = 5: 144 KB
 
 }  // namespace
 
 static bool g_p8_ready = false;
+static int g_p8_n_cu = 256;
 
 int ghn3_gemm_p8_init() {
     if (g_p8_ready) return GHN3_OK;
     hipError_t e = hipFuncSetAttribute((const void*)gemm_p8_kernel<GHN3_CT_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Lds);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)gemm_p8_kernel<GHN3_CT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Lds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(p8): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
+    {
+        int dev = 0, n_cu = 0;
+        if (hipGetDevice(&dev) == hipSuccess &&
+            hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0)
+            g_p8_n_cu = n_cu;
+    }
     g_p8_ready = true;
     return GHN3_OK;
 }
@@ -407,5 +668,29 @@ int ghn3_gemm_p8_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles
         hipLaunchKernelGGL(gemm_p8_kernel<GHN3_CT_BF16>, dim3(grid), dim3(512), kP8Lds, stream, d_probs, n_probs, total_tiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("p8 gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
+    return GHN3_OK;
+}
+
+// tile code 29: persistent stream (one workgroup per CU, or per CU the caller leaves to this launch; a multiple of 8 so
+// that a workgroup's tiles keep their XCD)
+int ghn3_gemm_p8w_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int ctype, int grid_cap, hipStream_t stream) {
+    if (n_probs <= 0 || total_tiles <= 0) return GHN3_OK;
+    if (ctype != GHN3_CT_F16 && ctype != GHN3_CT_BF16) {
+        ghn3_set_error("8-phase GEMM needs compute type f16 or bf16 (got %d)", ctype);
+        return GHN3_E_ARG;
+    }
+    int rc = ghn3_gemm_p8_init();
+    if (rc) return rc;
+    int grid = grid_cap > 0 ? grid_cap : g_p8_n_cu;
+    if (grid > total_tiles) grid = total_tiles;
+    grid = grid >= 8 ? grid / 8 * 8 : grid;
+    if (grid < 8) grid = 8 < total_tiles ? 8 : total_tiles;     // (fewer than 8 tiles: one workgroup each)
+    if (total_tiles >= 8 && grid % 8) grid = 8;
+    if (ctype == GHN3_CT_F16)
+        hipLaunchKernelGGL(gemm_p8w_kernel<GHN3_CT_F16>, dim3(grid), dim3(512), 128 * 1024, stream, d_probs, n_probs, total_tiles);
+    else
+        hipLaunchKernelGGL(gemm_p8w_kernel<GHN3_CT_BF16>, dim3(grid), dim3(512), 128 * 1024, stream, d_probs, n_probs, total_tiles);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ghn3_set_error("p8w gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;
 }

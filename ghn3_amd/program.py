@@ -432,7 +432,7 @@ class Program:
 
     # cost of one k-tile step of a (64 mi) x 256 tile of the 8-phase kernel, mi = 3, 4, 5 (tools/gemm_lab.hip, relative)
     P8_COST = {3: 1.72, 4: 2.0, 5: 2.42}
-    P8_MI = (3, 4)          # (the library kernel instantiates 192- and 256-row tiles; 320 exists in tools/gemm_lab.hip)
+    P8_MI = tuple(int(v) for v in os.environ.get('GHN3_P8_MI', '3,4,5').split(','))
 
     @classmethod
     def row_tiles(cls, ext):
@@ -1548,7 +1548,7 @@ class Program:
                 # gained (step 8.51 ms with the old kernel, 8.56 with tile 25 on every CU, 8.46 at 224, 8.38 at 192 --
                 # but there the weight gradient is back at 1.49 ms).
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=True, flops=fl,
-                             tile=int(os.environ.get('GHN3_WGRAD_TILE', '25')),
+                             tile=int(os.environ.get('GHN3_WGRAD_TILE', '29')),
                              grid_cap=int(os.environ.get('GHN3_WGRAD_CAP', '224')) if self.SIDE else 0)
             fam_list = bands
             for gi, g in enumerate(self.gemm_groups):

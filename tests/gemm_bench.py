@@ -23,8 +23,10 @@ def bench(ctx, M, N, K, a_mode, b_mode, tile=0, ctype=L.CT_F32, ksplit=1, accum=
     C = torch.zeros(M, ldc, device=dev)
     bufs = np.asarray([A.data_ptr(), B.data_ptr(), C.data_ptr()], dtype=np.uint64)
     p = np.zeros(1, dtype=L.PROBLEM_DT)
-    for nme in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim', 'alpha_amax'):
+    for nme in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim', 'alpha_amax',
+                'B2', 'mtiles'):
         p[nme]['buf'] = -1
+    p['ln_p']['buf'] = -1
     p['A']['buf'], p['B']['buf'], p['C']['buf'] = 0, 1, 2
     p['M'], p['N'], p['K'], p['lda'], p['ldb'], p['ldc'] = M, N, K, lda, ldb, ldc
     p['a_mode'], p['b_mode'] = a_mode, b_mode
@@ -91,8 +93,10 @@ def bench16(ctx, M, N, K, ctype, ksplit=1, accum=False, kmap=None, reps=5, name=
     C = torch.zeros(M, ldc, device=dev)
     bufs = np.asarray([A.data_ptr(), B.data_ptr(), C.data_ptr()], dtype=np.uint64)
     p = np.zeros(1, dtype=L.PROBLEM_DT)
-    for nme in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim', 'alpha_amax'):
+    for nme in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim', 'alpha_amax',
+                'B2', 'mtiles'):
         p[nme]['buf'] = -1
+    p['ln_p']['buf'] = -1
     p['A']['buf'], p['B']['buf'], p['C']['buf'] = 0, 1, 2
     p['M'], p['N'], p['K'], p['lda'], p['ldb'], p['ldc'] = M, N, K, lda, ldb, ldc
     p['alpha'] = 1.0
@@ -126,10 +130,11 @@ def bench16(ctx, M, N, K, ctype, ksplit=1, accum=False, kmap=None, reps=5, name=
 if __name__ == '__main__' and len(sys.argv) > 2 and sys.argv[2] == 'wgrad':
     ct = {'f16': L.CT_F16, 'bf16': L.CT_BF16}[sys.argv[1]]
     ctx = L.context(0)
-    for tile in (16, 20, 24, 25):
+    for tile in (16, 20, 24, 25, 28, 29):
         bench16(ctx, 147456, 3072, 768, ct, name='wgrad K=768', tile=tile)
+        bench16(ctx, 65536, 3072, 576, ct, name='wgrad band 65536 x 576', tile=tile)
         bench16(ctx, 147456, 3072, 512, ct, name='wgrad', tile=tile)
-        if tile == 25:
+        if tile in (25, 28, 29):
             bench16(ctx, 147456, 3072, 2048, ct, name='wgrad K=2048', tile=tile)
             continue
         bench16(ctx, 147456, 3072, 512, ct, name='wgrad A rows -> 256 (L2)', tile=tile, a_qs=(256, 0))

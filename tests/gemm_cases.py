@@ -96,7 +96,7 @@ def run_gemm_case(ctx, M, N, K, a_mode, b_mode, tile=0, ctype=L.CT_F32, gather=F
     bufs = [dA, dB, dC, dbias, dres, daux, daux_out, dga, dgc]
     ptrs = np.asarray([b.data_ptr() if b is not None else 0 for b in bufs], dtype=np.uint64)
     p = np.zeros(1, dtype=L.PROBLEM_DT)
-    for name in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim', 'alpha_amax'):
+    for name in ('A', 'B', 'C', 'bias', 'residual', 'aux_in', 'aux_out', 'a_gather', 'b_gather', 'c_gather', 'lim', 'alpha_amax', 'B2', 'mtiles'):
         p[name]['buf'] = -1
     p['A']['buf'], p['B']['buf'], p['C']['buf'] = 0, 1, 2
     if epilogue in ('bias_relu', 'full', 'gelu', 'dgelu', 'drelu', 'biasgrad'):
@@ -389,6 +389,17 @@ OP16_CASES = [
     dict(M=700, N=3072 // 4, K=64, tile=25, grid_cap=2, cmap=True),
     dict(M=5, N=7, K=9, tile=25),
     dict(M=2048, N=1024, K=768, a_transposed=True, b_transposed=True, tile=25, grid_cap=5),
+    # the persistent 8-phase stream (tile code 29): the DMA stream continues across tile boundaries, a tile's stores are
+    # deferred into the next tile's first k-tile; one / two / many k-tiles per tile (stream shorter than the look-ahead),
+    # more tiles than workgroups, a row map of C, ragged M / N
+    dict(M=300, N=520, K=150, tile=29),
+    dict(M=1100, N=1300, K=512, tile=29, grid_cap=3),
+    dict(M=1100, N=780, K=64 * 3, tile=29, grid_cap=2),
+    dict(M=700, N=3072 // 4, K=64, tile=29, grid_cap=2, cmap=True),
+    dict(M=5, N=8, K=9, tile=29),
+    dict(M=2048, N=1024, K=768, a_transposed=True, b_transposed=True, tile=29, grid_cap=5),
+    dict(M=4096, N=512, K=64 * 9, tile=29, grid_cap=8),
+    dict(M=2100, N=512, K=100, tile=29, grid_cap=16, cmap=True),
     # XCD-pinned problems of one launch (xcd_pin): several problems on one XCD, XCDs without a problem, unpinned problems
     # behind the pinned ids, fewer than 8 problems (pins ignored), the 256 x 128 variant and the persistent grid
     dict(M=300, N=520, K=150, pins=[0, 1, 2, 3, 4, 5, 6, 7, 0, 3, None, 5]),
@@ -557,7 +568,7 @@ def run_x3_case(ctx, M, N, K, transposed=False, tile=40, ksplit=1, slice_=0, epi
     kc = K // ksplit
     sl = slice_ or 64 * max(d for d in (6, 4, 3, 2, 1) if (kc // 64) % d == 0)
     p = np.zeros(ksplit, dtype=L.PROBLEM_DT)
-    for name in L._REF_NAMES + ('lim', 'alpha_amax', 'B2'):
+    for name in L._REF_NAMES + ('lim', 'alpha_amax', 'B2', 'mtiles'):
         p[name]['buf'] = -1
     p['ln_p']['buf'] = -1
     for j in range(ksplit):

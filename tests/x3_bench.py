@@ -42,7 +42,7 @@ def bench(ctx, M, N, K, kind, tile=40, ksplit=1, slice_=0, transposed=False, rep
     kc = K // ksplit
     sl = slice_ or 64 * max(d for d in (6, 4, 3, 2, 1) if (kc // 64) % d == 0)
     p = np.zeros(layers * ksplit, dtype=L.PROBLEM_DT)
-    for nm in L._REF_NAMES + ('lim', 'alpha_amax', 'B2'):
+    for nm in L._REF_NAMES + ('lim', 'alpha_amax', 'B2', 'mtiles'):
         p[nm]['buf'] = -1
     p['ln_p']['buf'] = -1
     for l in range(layers):

@@ -1248,6 +1248,101 @@ int ghn3_add(float* dst, const float* src, int64_t n, hipStream_t s) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// GHN3_OP_WIRE_PACK / GHN3_OP_RANK_REDUCE: the local passes of the mesh gradient exchange (ddp_utils.mesh_all_reduce_avg).
+// HBM streaming kernels: 16-byte accesses, grid-stride, bf16 round-to-nearest-even.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned short wire_bf16(float x) {
+    unsigned u = __float_as_uint(x);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);   // NaN stays NaN (the guard needs it)
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ float wire_f32(unsigned short h) { return __uint_as_float(((unsigned)h) << 16); }
+
+__global__ __launch_bounds__(256) void wire_pack_kernel(unsigned short* __restrict__ dst, const float* __restrict__ src,
+                                                        int64_t n, int64_t n_pad) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; e < n_pad; e += stride) {
+        if (e + 8 <= n && ((reinterpret_cast<uintptr_t>(src + e) | reinterpret_cast<uintptr_t>(dst + e)) & 15) == 0) {
+            const float4 a = *reinterpret_cast<const float4*>(src + e), b = *reinterpret_cast<const float4*>(src + e + 4);
+            uint4 o;
+            o.x = wire_bf16(a.x) | ((unsigned)wire_bf16(a.y) << 16); o.y = wire_bf16(a.z) | ((unsigned)wire_bf16(a.w) << 16);
+            o.z = wire_bf16(b.x) | ((unsigned)wire_bf16(b.y) << 16); o.w = wire_bf16(b.z) | ((unsigned)wire_bf16(b.w) << 16);
+            *reinterpret_cast<uint4*>(dst + e) = o;
+        } else {
+            for (int k = 0; k < 8 && e + k < n_pad; ++k) dst[e + k] = e + k < n ? wire_bf16(src[e + k]) : (unsigned short)0;
+        }
+    }
+}
+__global__ __launch_bounds__(256) void wire_unpack_kernel(float* __restrict__ dst, const unsigned short* __restrict__ src,
+                                                          int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 8;
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 8; e < n; e += stride) {
+        if (e + 8 <= n && ((reinterpret_cast<uintptr_t>(src + e) | reinterpret_cast<uintptr_t>(dst + e)) & 15) == 0) {
+            const uint4 v = *reinterpret_cast<const uint4*>(src + e);
+            float4 a, b;
+            a.x = wire_f32(v.x & 0xffff); a.y = wire_f32(v.x >> 16); a.z = wire_f32(v.y & 0xffff); a.w = wire_f32(v.y >> 16);
+            b.x = wire_f32(v.z & 0xffff); b.y = wire_f32(v.z >> 16); b.z = wire_f32(v.w & 0xffff); b.w = wire_f32(v.w >> 16);
+            *reinterpret_cast<float4*>(dst + e) = a;
+            *reinterpret_cast<float4*>(dst + e + 4) = b;
+        } else {
+            for (int k = 0; k < 8 && e + k < n; ++k) dst[e + k] = wire_f32(src[e + k]);
+        }
+    }
+}
+int ghn3_wire_pack(void* dst, const void* src, int64_t n, int64_t n_pad, int reverse, hipStream_t s) {
+    const int64_t total = reverse ? n : n_pad;
+    if (total <= 0) return GHN3_OK;
+    if (!reverse && n_pad < n) { ghn3_set_error("wire_pack: padded length below the valid length"); return GHN3_E_ARG; }
+    int64_t blocks = (total / 8 + 255) / 256 + 1;
+    if (blocks > 8192) blocks = 8192;
+    if (reverse) hipLaunchKernelGGL(wire_unpack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (float*)dst, (const unsigned short*)src, n);
+    else hipLaunchKernelGGL(wire_pack_kernel, dim3((unsigned)blocks), dim3(256), 0, s, (unsigned short*)dst, (const float*)src, n, n_pad);
+    return launch_ok("wire_pack");
+}
+
+template <bool IN16, bool OUT16>
+__global__ __launch_bounds__(256) void rank_reduce_kernel(void* __restrict__ out_, const void* __restrict__ in_, int64_t per, int W,
+                                                          float scale) {
+    const int64_t stride = (int64_t)gridDim.x * 256 * 4;
+    for (int64_t e = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4; e < per; e += stride) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const int cnt = (int)(per - e < 4 ? per - e : 4);
+        for (int w = 0; w < W; ++w) {                  // rank order: the same bits on every rank
+            if (IN16) {
+                const unsigned short* p = reinterpret_cast<const unsigned short*>(in_) + (int64_t)w * per + e;
+                if (cnt == 4 && (reinterpret_cast<uintptr_t>(p) & 7) == 0) {
+                    const uint2 v = *reinterpret_cast<const uint2*>(p);
+                    acc[0] += wire_f32(v.x & 0xffff); acc[1] += wire_f32(v.x >> 16);
+                    acc[2] += wire_f32(v.y & 0xffff); acc[3] += wire_f32(v.y >> 16);
+                } else for (int k = 0; k < cnt; ++k) acc[k] += wire_f32(p[k]);
+            } else {
+                const float* p = reinterpret_cast<const float*>(in_) + (int64_t)w * per + e;
+                if (cnt == 4 && (reinterpret_cast<uintptr_t>(p) & 15) == 0) {
+                    const float4 v = *reinterpret_cast<const float4*>(p);
+                    acc[0] += v.x; acc[1] += v.y; acc[2] += v.z; acc[3] += v.w;
+                } else for (int k = 0; k < cnt; ++k) acc[k] += p[k];
+            }
+        }
+        for (int k = 0; k < cnt; ++k) {
+            if (OUT16) reinterpret_cast<unsigned short*>(out_)[e + k] = wire_bf16(acc[k] * scale);
+            else reinterpret_cast<float*>(out_)[e + k] = acc[k] * scale;
+        }
+    }
+}
+int ghn3_rank_reduce(void* out, const void* in, int64_t per, int W, int in16, int out16, float scale, hipStream_t s) {
+    if (per <= 0 || W <= 0) return GHN3_OK;
+    int64_t blocks = (per / 4 + 255) / 256 + 1;
+    if (blocks > 8192) blocks = 8192;
+    const dim3 g((unsigned)blocks), b(256);
+    if (in16 && out16) hipLaunchKernelGGL((rank_reduce_kernel<true, true>), g, b, 0, s, out, in, per, W, scale);
+    else if (in16) hipLaunchKernelGGL((rank_reduce_kernel<true, false>), g, b, 0, s, out, in, per, W, scale);
+    else if (out16) hipLaunchKernelGGL((rank_reduce_kernel<false, true>), g, b, 0, s, out, in, per, W, scale);
+    else hipLaunchKernelGGL((rank_reduce_kernel<false, false>), g, b, 0, s, out, in, per, W, scale);
+    return launch_ok("rank_reduce");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // GHN3_OP_CAST16: fp32 -> f16 / bf16 operand copies for the 16-bit-operand GEMM (gemm.hip gemm_h16d_kernel).
 // One workgroup = one 64 x 64 source tile: read once (float4, coalesced), converted, written straight (128-byte row
 // segments) and / or transposed through LDS (128-byte column segments); source elements outside rows x cols read as

@@ -679,6 +679,13 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         case GHN3_OP_ADD:
             rc = ghn3_add(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), o.i[0], stream);
             break;
+        case GHN3_OP_WIRE_PACK:
+            rc = ghn3_wire_pack(R.get<void>(o.r[0]), R.get<const void>(o.r[1]), o.i[0], o.i[1], (int)o.i[2], stream);
+            break;
+        case GHN3_OP_RANK_REDUCE:
+            rc = ghn3_rank_reduce(R.get<void>(o.r[0]), R.get<const void>(o.r[1]), o.i[0], (int)o.i[1], (int)o.i[2],
+                                  (int)o.i[3], o.f[0], stream);
+            break;
         case GHN3_OP_CAST16:
             rc = ghn3_cast16(R.get<const float>(o.r[0]), R.get<void>(o.r[1]), R.get<const ghn3_cast_desc>(o.r[2]),
                              (int)o.i[0], (int)o.i[1], R.get<float>(o.r[3]), R.get<const float>(o.r[4]), (int)o.i[2],

@@ -108,25 +108,70 @@ def all_reduce_flat_grads_avg(flat, chunk_bytes=256 << 20):
     return flat
 
 
-def mesh_all_reduce_avg(piece, wire_dtype=None):
+def _hip_ops(records, ptrs, stream):
+    """Run a few buffer-level ops of the library (GHN3_OP_WIRE_PACK / GHN3_OP_RANK_REDUCE) on `stream`."""
+    import numpy as np
+    from . import _lib as L
+    ops = np.zeros(len(records), dtype=L.OP_DT)
+    ops['r']['buf'][:] = -1
+    for k, (kind, refs, ints, f0) in enumerate(records):
+        ops[k]['kind'] = kind
+        for e, r in enumerate(refs):
+            ops[k]['r'][e]['buf'], ops[k]['r'][e]['off'] = r, 0
+        ops[k]['i'][:len(ints)] = ints
+        ops[k]['f'][0] = f0
+    L.context(torch.cuda.current_device()).run(ops, np.zeros(0, dtype=L.PROBLEM_DT), np.asarray(ptrs, dtype=np.uint64), stream)
+
+
+def mesh_all_reduce_avg(piece, wire_dtype=None, force=False):
     """
-    Mean all-reduce of a 1-D tensor shaped for a fully connected xGMI mesh (7 links x ~153 GB/s per MI355X): instead of
-    a ring, whose every step is bound by ONE link, the two-shot direct algorithm keeps all links busy --
+    Mean all-reduce of a 1-D tensor shaped for a fully connected xGMI mesh (7 links x ~153 GB/s per MI355X): the two-shot
+    direct algorithm
         all-to-all:  rank r receives chunk r of every rank       (W - 1 links carry S / W each, concurrently)
-        local sum :  fp32 accumulation of the W chunks, averaged  (no 16-bit accumulation error over the ranks)
+        local sum :  fp32 accumulation of the W chunks, averaged, in rank order (every rank computes the same bits; no
+                     16-bit accumulation error over the ranks)
         all-gather:  every rank receives every reduced chunk      (again all links, S / W each)
-    i.e. 2 S / W bytes per link instead of 2 S (W - 1) / W over one: 2.1 ms for the 1.31 GB of bf16 gradients of
-    ghn3xlm16 on 8 GPUs against ~15 ms for a single-link ring.  `wire_dtype` (e.g. torch.bfloat16)
-    is the type on the wire; the result is written back to `piece` in place.  Works on gloo (CPU) for the tests.
+    `wire_dtype` (torch.bfloat16) is the type on the wire; the result is written back to `piece` in place.
+    On the GPU the local passes are library ops on the current stream (GHN3_OP_WIRE_PACK: fp32 -> bf16 of the range and
+    back, GHN3_OP_RANK_REDUCE: W-way sum + scale), 2-3 streaming passes instead of the five ATen ones of round 2; an
+    fp32 exchange of a length divisible by W sends and gathers in place (one pass).  CPU tensors (gloo, the tests) take
+    the equivalent torch expressions.  `force`: run the collectives even in a 1-rank group (GPU test of the code path).
     """
     W = dist.get_world_size()
     n = piece.numel()
-    if W == 1:
+    if W == 1 and not force:
         if wire_dtype is not None and wire_dtype != piece.dtype:
             piece.copy_(piece.to(wire_dtype))                     # (the rounding a real exchange would apply)
         return piece
     per = (n + W - 1) // W
     wd = wire_dtype or piece.dtype
+    if piece.is_cuda and piece.dtype == torch.float32 and wd in (torch.float32, torch.bfloat16):
+        from . import _lib as L
+        stream = torch.cuda.current_stream(piece.device).cuda_stream
+        b16 = wd == torch.bfloat16
+        if not b16 and W * per == n:
+            recv = torch.empty_like(piece)
+            dist.all_to_all_single(recv, piece)
+            red = torch.empty(per, dtype=torch.float32, device=piece.device)
+            _hip_ops([(L.OP_RANK_REDUCE, (0, 1), (per, W, 0, 0), 1.0 / W)], [red.data_ptr(), recv.data_ptr()], stream)
+            dist.all_gather_into_tensor(piece, red)
+            return piece
+        send = torch.empty(W * per, dtype=wd, device=piece.device)
+        recv = torch.empty_like(send)
+        red = torch.empty(per, dtype=wd, device=piece.device)
+        if b16:
+            _hip_ops([(L.OP_WIRE_PACK, (0, 1), (n, W * per, 0), 0.0)], [send.data_ptr(), piece.data_ptr()], stream)
+        else:
+            send[:n].copy_(piece)
+            send[n:].zero_()
+        dist.all_to_all_single(recv, send)
+        _hip_ops([(L.OP_RANK_REDUCE, (0, 1), (per, W, int(b16), int(b16)), 1.0 / W)], [red.data_ptr(), recv.data_ptr()], stream)
+        dist.all_gather_into_tensor(send, red)
+        if b16:
+            _hip_ops([(L.OP_WIRE_PACK, (0, 1), (n, n, 1), 0.0)], [piece.data_ptr(), send.data_ptr()], stream)
+        else:
+            piece.copy_(send[:n])
+        return piece
     send = torch.empty(W * per, dtype=wd, device=piece.device)
     send[:n].copy_(piece)
     if W * per > n:
@@ -152,9 +197,12 @@ class FlatGradReducer:
     The collectives are issued from a dedicated communication stream that waits for the producers (the current
     stream and, through `wait_for`, the context's side stream), so RCCL runs under the Graphormer backward.
     compress='bf16' sends bf16 copies (half the xGMI bytes); None keeps fp32.
-    algo: 'mesh' (default) = all-to-all + fp32 local sum + all-gather (mesh_all_reduce_avg: every xGMI link carries
-    S / W; the sum over ranks is accumulated in fp32 even with bf16 on the wire); 'allreduce' = RCCL's own all-reduce
-    (ncclAvg, sum accumulated in the wire type like torch's bf16_compress_hook).  Works on CPU tensors (gloo).
+    algo: 'allreduce' (default) = RCCL's own all-reduce (ncclAvg, sum accumulated in the wire type like torch's
+    bf16_compress_hook); 'mesh' (GHN3_ALLREDUCE_ALGO=mesh) = all-to-all + fp32 local sum + all-gather
+    (mesh_all_reduce_avg: the sum over ranks is accumulated in fp32 even with bf16 on the wire, replicas bit-identical).
+    The mesh path has only ever run under gloo and in 1-rank RCCL groups (no multi-GPU box was available to the
+    builder), so RCCL's tuned collective is the default until the two are timed side by side on real links.
+    Works on CPU tensors (gloo).
     The sequence and sizes of the collectives depend on the GHN's parameter layout only (Program.bwd_parts), never on
     a rank's graph.
     """
@@ -164,7 +212,7 @@ class FlatGradReducer:
         self.compress = compress
         self.chunk = max(1, chunk_bytes // 4)
         self.force = force                      # run the code path even for a 1-rank group (tests)
-        self.algo = algo or os.environ.get('GHN3_ALLREDUCE_ALGO', 'mesh')
+        self.algo = algo or os.environ.get('GHN3_ALLREDUCE_ALGO', 'allreduce')
         assert self.algo in ('mesh', 'allreduce')
         self._comm = None
         self._pending = []                      # (work, flat slice, staging buffer or None)
@@ -177,7 +225,7 @@ class FlatGradReducer:
         if self.algo == 'mesh':
             wd = torch.bfloat16 if self.compress == 'bf16' else None
             for s in range(lo, hi, self.chunk):
-                mesh_all_reduce_avg(flat[s:min(hi, s + self.chunk)], wd)     # (ordered on the communication stream)
+                mesh_all_reduce_avg(flat[s:min(hi, s + self.chunk)], wd, force=self.force)   # (ordered on the comm stream)
             return
         # RCCL averages inside the collective (ncclAvg): no separate scaling pass over the 2.6 GB buffer
         self._avg = flat.is_cuda and dist.get_backend() == 'nccl'

@@ -455,6 +455,34 @@ class Program:
             k += choice[k]
         return np.asarray(out, dtype=np.int32).reshape(-1, 3)
 
+    def _dgrad_sub_split(self, g16, n_cols, n_cu=32):
+        """Split of every XCD's K chunk of the W2 dgrad into parts (see _build_backward).  Candidates are scored by a
+        longest-first list schedule of ONE XCD's work items (families x row tiles x 256-column tiles x parts) on its CUs;
+        chunk 0 (all extents still alive) is the fullest and is the one simulated."""
+        nt = (n_cols + 255) // 256
+        def makespan(sub):
+            items = []
+            for g in g16:
+                if not g.get('p8'):
+                    continue
+                oc = (g['o'] + 7) // 8
+                for (m0, mi, ext) in g['mtiles']:
+                    steps = min(int(ext), oc * g['i_ld']) / 64.0
+                    for f in sub:
+                        items += [self.P8_COST[int(mi)] * steps * f / sum(sub)] * nt
+            items.sort(reverse=True)
+            cu = [0.0] * n_cu
+            for it in items:
+                k = cu.index(min(cu))
+                cu[k] += it + 4.0                      # (+ prologue / epilogue of a tile, in the same relative units)
+            return max(cu) if items else 0.0
+        best, best_sub = None, (1,)
+        for sub in ((1,), (3, 1), (1, 1), (2, 1, 1), (1, 1, 1, 1)):
+            score = makespan(sub) + 14.0 * 8 * (len(sub) - 1)     # (a partial plane: ~7 us written + read again)
+            if best is None or score < best - 1e-9:
+                best, best_sub = score, sub
+        return best_sub
+
     # ------------------------------------------------------------------ decoder layout (host bookkeeping)
     def _src_row(self, ind):
         """xe row read for sparse-flat node index `ind` (quirk Q1: reference reads dense-flat row `ind`)."""
@@ -1461,7 +1489,18 @@ class Program:
                 pin = os.environ.get('GHN3_DGRAD_PIN', '1') != '0'
                 for g in g16:
                     g['nc'] = int(max(1, min(8, g['o']))) if pin else int(max(1, min(8, splits(g), g['o'])))
-                n_planes = max(g['nc'] for g in g16)
+                nc_max = max(g['nc'] for g in g16)
+                # Sub-chunks (round 3).  With one K chunk per XCD a family of two or three row tiles is 24 .. 36 output tiles on
+                # the XCD's 32 CUs: a quarter of the CUs idles, or a second round starts for a handful of tiles.  Each chunk is
+                # therefore cut again into parts `sub` (e.g. 3/4 + 1/4: the eight CUs the long parts leave free take three
+                # quarter parts each); every part writes its own partial plane.  The split is chosen by simulating the
+                # longest-first dispatch of one XCD's tiles (a plane costs ~7 us of extra traffic).
+                sub = self._dgrad_sub_split(g16, 8 * C) if (pin and nc_max == 8 and self.use_p8) else (1,)
+                forced = os.environ.get('GHN3_DGRAD_SUB')
+                if forced:
+                    sub = tuple(int(v) for v in forced.split(','))
+                self.dgrad_sub = sub
+                n_planes = nc_max * len(sub)
                 rows16 = sum(g['rows'] for g in g16)
                 assert all(g['row0'] < rows16 for g in g16), 'op16 groups first'
                 d_up = self.wsf('d_u_parts', max(n_planes - 1, 1) * M * 8 * C)
@@ -1472,12 +1511,38 @@ class Program:
                     # of d_tiles and a multiple of the k-map period i, so A and B just start further in
                     # (the kernel consumes whole 64-wide k tiles: a chunk is a multiple of 64 so that the next chunk's
                     # data is never read as padding)
-                    oc = round_up((g['o'] + g['nc'] - 1) // g['nc'], 64 // math.gcd(g['i_ld'], 64))
-                    for j in range(n_planes):
-                        k0 = j * oc * g['i_ld']
-                        kc = max(0, min(g['cols'] - k0, oc * g['i_ld']))
-                        dst = (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C) if j == 0 else \
-                            (d_up[0], d_up[1] + 4 * ((j - 1) * M + g['row0']) * 8 * C)
+                    unit = 64 // math.gcd(g['i_ld'], 64)
+                    sub = self.dgrad_sub
+                    # chunk boundaries in W2 rows o' (multiples of `unit`: every part is whole 64-wide k tiles).  A family's
+                    # narrow members only reach the first chunks, so equal chunks would give the first XCDs more work than
+                    # the last: the boundaries equalise the WORK (row tiles alive at o' x their cost) instead of the length.
+                    if g['p8'] and g['nc'] == 8 and os.environ.get('GHN3_DGRAD_EQ', '1') != '0':
+                        dens = np.zeros(g['o'])
+                        for (m0_, mi_, ext_) in g['mtiles']:
+                            dens[:min(g['o'], int(ext_) // g['i_ld'])] += self.P8_COST[int(mi_)]
+                        cw = np.concatenate([[0.0], np.cumsum(dens)])
+                        bounds = [0]
+                        for j in range(1, g['nc']):
+                            b = int(np.searchsorted(cw, cw[-1] * j / g['nc']))
+                            bounds.append(min(g['o'], max(bounds[-1], round_up(b, unit))))
+                        bounds.append(round_up(g['o'], unit))
+                    else:
+                        oc = round_up((g['o'] + g['nc'] - 1) // g['nc'], unit)
+                        bounds = [min(j * oc, round_up(g['o'], unit)) for j in range(g['nc'])] + [round_up(g['o'], unit)]
+                    for pl in range(n_planes):
+                        j, sidx = pl // len(sub), pl % len(sub)
+                        if j < g['nc']:
+                            lo_, hi_ = bounds[j], bounds[j + 1]
+                            cuts = [lo_ + min(hi_ - lo_, round_up(int(round((hi_ - lo_) * float(v) / sum(sub))), unit))
+                                    for v in np.concatenate([[0], np.cumsum(sub)])]
+                            cuts[-1] = hi_
+                            o0, o1 = cuts[sidx], max(cuts[sidx], cuts[sidx + 1])
+                        else:
+                            o0 = o1 = round_up(g['o'], unit)
+                        k0 = o0 * g['i_ld']
+                        kc = max(0, min(g['cols'] - k0, (o1 - o0) * g['i_ld']))
+                        dst = (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C) if pl == 0 else \
+                            (d_up[0], d_up[1] + 4 * ((pl - 1) * M + g['row0']) * 8 * C)
                         lim = None
                         if g['ragged'] or kc < g['cols']:
                             lim = self.idx(np.clip(g['lim128'] - k0, 0, kc).astype(np.int32))
@@ -1487,10 +1552,10 @@ class Program:
                             mt[:, 2] = np.clip(mt[:, 2] - k0, 0, kc)
                             mt = (self.idx(mt), len(mt))
                         self.gemm(self.href(g['dth'] + min(k0, g['cols'])),
-                                  self.sref(self.w2hT + min(j * oc, g['o']) * ms[1]), dst,
+                                  self.sref(self.w2hT + min(o0, g['o']) * ms[1]), dst,
                                   g['rows'], 8 * C, kc, g['dth_ld'], self.w2hT_ld, 8 * C, op16=True,
                                   b_kmap=(g['i_ld'], ms[1]), lim=lim, lim_kind=2, alpha_amax=amax_t,
-                                  xcd=j if (pin and n_planes == 8) else None, mtiles=mt)
+                                  xcd=j if (pin and nc_max == 8) else None, mtiles=mt)
                     continue
                 if planes:
                     # (groups outside the 16-bit pipeline have i <= 4: a short reduction, one pass into plane 0)

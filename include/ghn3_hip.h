@@ -324,6 +324,14 @@ enum ghn3_op_kind {
      * (+ i0_s on the output column); r0=out r1=X (fp32 base) r2=table of {int64 off (floats from r1); int32 rows, o, i,
      * ld, i0, pad} ; i: n_sets, O, I */
     GHN3_OP_ROWSET_COLSUM = 29,
+    /* Local passes of the data-parallel gradient exchange (trainer.py:136: DistributedDataParallel's all-reduce of the GHN
+     * gradients; here all-to-all + local sum + all-gather on the flat gradient buffer, ghn3_amd/ddp_utils.py).
+     * WIRE_PACK:   r0 = dst (i1 16-bit elements) r1 = src (fp32) ; i0 = n valid, i1 = n padded (dst[n..i1) = 0), i2 = 1:
+     *              the reverse, dst fp32 [i0] <- src bf16 (the gathered result back into the gradient buffer)
+     * RANK_REDUCE: out[e] = f0 * sum_{w < i1} in[w * i0 + e], summed in fp32 in rank order (every rank computes the same
+     *              bits); r0 = out r1 = in ; i0 = elements per rank, i1 = ranks W, i2 = 1: `in` is bf16, i3 = 1: `out` is bf16 */
+    GHN3_OP_WIRE_PACK = 30,
+    GHN3_OP_RANK_REDUCE = 31,
     GHN3_OP_KIND_COUNT
 };
 

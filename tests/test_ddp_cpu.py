@@ -134,3 +134,99 @@ def test_mesh_all_reduce_world3():
     assert len(ret) == world
     for r in range(world):
         assert all(ret[r]), (r, ret[r])
+
+
+def _schedule_worker(rank, world, port, ret):
+    """Two ranks compile DIFFERENT architectures; the collectives each one issues for a backward (the sequence RCCL would
+    see: kind, element count, wire type) are recorded by wrapping torch.distributed's entry points."""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, os.path.join(here, 'golden'))
+    import recipe
+    from ghn3_amd import _lib as L
+    from ghn3_amd.nn import GHN3
+    from ghn3_amd.program import Program
+    from ghn3_amd.ddp_utils import setup_ddp, FlatGradReducer, clean_ddp
+    from ghn3_amd.synthetic import synthetic_batch
+    setup_ddp()
+    torch.manual_seed(0)
+    ghn = GHN3(**recipe.TINY_CFG)                                   # (host object: flat parameter layout only)
+    gb, nets = synthetic_batch([20 + 9 * rank], 31000 + rank)       # a different target network per rank
+    gb._cat()
+    cfg = dict(hid=ghn.hid, heads=ghn.heads, layers=ghn.layers, num_classes=ghn.num_classes, max_shape=ghn.max_shape)
+    prog = Program(cfg, gb.node_info, gb.host_n_nodes(), gb._node_type_host, gb.max_edge, nets, training=True,
+                   decoder_ctype=L.CT_F16, decoder_bwd_ctype=L.CT_F16)
+    offs, total = [int(v) for v in ghn._offs], int(ghn._flat_numel)
+    log = []
+    real = {n: getattr(dist, n) for n in ('all_reduce', 'all_to_all_single', 'all_gather_into_tensor')}
+
+    def wrap(name):
+        def f(*a, **k):
+            t = a[0]
+            log.append((name, int(t.numel()), str(t.dtype)))
+            return real[name](*a, **k)
+        return f
+    for n in real:
+        setattr(dist, n, wrap(n))
+    oks = []
+    try:
+        for algo in ('allreduce', 'mesh'):
+            for compress in (None, 'bf16'):
+                log.append(('config', algo, str(compress)))
+                g0 = torch.randn(total, generator=torch.Generator().manual_seed(5 + rank))
+                g = g0.clone()
+                red = FlatGradReducer(compress=compress, chunk_bytes=1 << 16, algo=algo)
+                red.begin()
+                for ops, slots in prog.bwd_parts:                    # what GHN3._run_backward does between the parts
+                    for s_lo, s_hi in slots:
+                        if s_hi > s_lo:
+                            red.start(g, offs[s_lo], offs[s_hi] if s_hi < len(offs) else total)
+                red.finish(g)
+                both = [torch.empty_like(g0) for _ in range(world)]
+                real_gather = dist.all_gather
+                real_gather(both, g0)
+                mean = sum(both) / world
+                tol = 1e-6 if compress is None else 2e-2
+                oks.append(bool(torch.allclose(g, mean, rtol=tol, atol=tol)))
+    finally:
+        for n in real:
+            setattr(dist, n, real[n])
+    w2 = prog.slot['decoder.conv.2.weight']
+    ret[rank] = (oks, log, offs[w2 + 1] - offs[w2], int(prog.M), total)
+    clean_ddp()
+
+
+def test_collective_schedule_is_identical_for_different_graphs_world2():
+    """RCCL hangs (or silently mixes buffers) when ranks disagree on the sequence or the sizes of their collectives.  Every
+    rank compiles its own architecture each step, so the schedule of the overlapped exchange must depend on the GHN's
+    parameter layout only: two ranks with different graphs (different decoder row counts, different op programs) must log
+    exactly the same sequence of (collective, element count, wire type), for both algorithms and both wire types, the first
+    range being the W2 gradient; and the exchanged buffer must be the mean over the ranks."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_schedule_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    (ok0, log0, w2n0, rows0, total0), (ok1, log1, w2n1, rows1, total1) = ret[0], ret[1]
+    assert all(ok0) and all(ok1), (ok0, ok1)
+    assert rows0 != rows1, 'the two ranks were meant to compile different architectures'
+    assert log0 == log1 and total0 == total1
+    # allreduce / fp32: the first collectives cover exactly the W2 gradient, in 64 KB pieces
+    k = log0.index(('config', 'allreduce', 'None')) + 1
+    n, first = 0, []
+    while n < w2n0:
+        name, numel, dt = log0[k]
+        assert name == 'all_reduce' and dt == 'torch.float32'
+        first.append(numel)
+        n += numel
+        k += 1
+    assert n == w2n0 and max(first) <= (1 << 16) // 4
+    # mesh / bf16: all-to-all + all-gather pairs on bf16 buffers, every element of the flat buffer exactly once
+    k = log0.index(('config', 'mesh', 'bf16')) + 1
+    seq = log0[k:]
+    assert all(a[0] == 'all_to_all_single' and b[0] == 'all_gather_into_tensor' and a[2] == b[2] == 'torch.bfloat16'
+               for a, b in zip(seq[0::2], seq[1::2]))
+    assert sum(a[1] for a in seq[0::2]) >= total0

@@ -574,16 +574,36 @@ def test_split_backward_with_overlapped_gradient_reduction():
         hip._run_backward(plan, dout)
         torch.cuda.synchronize()
         ref = plan.gflat.clone()
-        for compress, tol in ((None, 2e-5), ('bf16', 1e-2)):
-            hip._run_backward(plan, dout, reducer=FlatGradReducer(compress=compress, force=True))
-            torch.cuda.synchronize()
-            err = float((plan.gflat - ref).norm() / ref.norm())
-            assert err < tol, (compress, err)
+        # both exchange algorithms; with force=True the mesh path really issues its all-to-all / all-gather in the 1-rank
+        # RCCL group and runs its local passes as library ops (GHN3_OP_WIRE_PACK, GHN3_OP_RANK_REDUCE)
+        for algo in ('allreduce', 'mesh'):
+            for compress, tol in ((None, 2e-5), ('bf16', 1e-2)):
+                hip._run_backward(plan, dout, reducer=FlatGradReducer(compress=compress, force=True, algo=algo))
+                torch.cuda.synchronize()
+                err = float((plan.gflat - ref).norm() / ref.norm())
+                assert err < tol, (algo, compress, err)
             lo, hi = hip.decoder_grad_range(plan.program)
             assert 0 < lo < hi <= ref.numel() and (hi - lo) > 0.5 * ref.numel()
         # three parts: ... W2 gradient | rest of the decoder | Graphormer
         assert len(plan.program.bwd_parts) == 3 and sum(len(o) for o, _ in plan.program.bwd_parts) == \
             len(plan.program.bwd_ops) + 2
+        # the local passes alone, against torch: W-way fp32 sum of bf16 chunks in rank order, pack / unpack round trip
+        from ghn3_amd.ddp_utils import _hip_ops
+        from ghn3_amd import _lib as L
+        W, per = 5, 1003
+        x = torch.randn(W * per, device='cuda')
+        xb = x.to(torch.bfloat16)
+        out = torch.empty(per, dtype=torch.bfloat16, device='cuda')
+        st = torch.cuda.current_stream().cuda_stream
+        _hip_ops([(L.OP_RANK_REDUCE, (0, 1), (per, W, 1, 1), 1.0 / W)], [out.data_ptr(), xb.data_ptr()], st)
+        want = (torch.sum(xb.view(W, per), dim=0, dtype=torch.float32) / W).to(torch.bfloat16)
+        assert torch.equal(out, want)
+        packed = torch.full((W * per + 13,), 7, dtype=torch.bfloat16, device='cuda')
+        _hip_ops([(L.OP_WIRE_PACK, (0, 1), (W * per, W * per + 13, 0), 0.0)], [packed.data_ptr(), x.data_ptr()], st)
+        assert torch.equal(packed[:W * per], xb) and float(packed[W * per:].abs().sum()) == 0.0
+        back = torch.empty(W * per, device='cuda')
+        _hip_ops([(L.OP_WIRE_PACK, (0, 1), (W * per, W * per, 1), 0.0)], [back.data_ptr(), packed.data_ptr()], st)
+        assert torch.equal(back, xb.float())
     finally:
         dist.destroy_process_group()
 

@@ -81,11 +81,21 @@ def cpu_baseline(model, sample_nodes, seed, graphs=1):
                          's' if len(times) > 1 else '')}
 
 
+_WORKER_NICED = False
+
+
 def _loader_worker(task):
     """Loader worker (separate process, never touches the GPU): one fresh synthetic architecture per step -- graph
     generation + the host half of GHN3.compile (numpy bookkeeping -> op program), what a DeepNets-1M loader worker
     would do per batch (deepnets1m.py:84-269)."""
     nodes, graphs_per_gpu, seed, pcfg = task
+    global _WORKER_NICED
+    if not _WORKER_NICED:                                # the training process's enqueue thread goes first on a busy host
+        try:
+            os.nice(10)
+        except OSError:
+            pass
+        _WORKER_NICED = True
     from ghn3_amd.program import Program
     from ghn3_amd.synthetic import synthetic_batch
     gb, nets = synthetic_batch([nodes] * graphs_per_gpu, seed)
@@ -156,12 +166,22 @@ def main():
                          % (args.gpus, world, args.gpus, args.gpus))
     import torch.distributed as dist
     pool = None
-    if world == 1 and not args.no_extras and not args.force_ddp and torch.cuda.device_count() > 0:
-        import multiprocessing as mp                     # loader workers: started before this process touches the GPU
+    if world == 1 and not args.no_extras and not args.force_ddp:
+        import multiprocessing as mp                     # loader workers: started before ANY torch.cuda call of this process
         for var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):
             os.environ.setdefault(var, '4')              # (inherited by the workers: no 256-thread pools per worker)
-        pool = mp.get_context('spawn').Pool(int(os.environ.get('GHN3_LOADER_WORKERS', '8')))
+        # a worker needs ~10 ms of CPU per architecture (graph + host half of the compile) and the GPU consumes one every
+        # ~7.5 ms: three busy workers keep up.  More workers than spare cores only take the cores the enqueue thread of
+        # this process needs (the driver's box of round 2: 8 workers, enqueue 14 ms per step instead of 3)
+        try:
+            n_cores = len(os.sched_getaffinity(0))
+        except AttributeError:
+            n_cores = os.cpu_count() or 4
+        n_workers = int(os.environ.get('GHN3_LOADER_WORKERS', str(max(2, min(6, n_cores // 2 - 1)))))
+        pool = mp.get_context('spawn').Pool(n_workers)
     if not torch.cuda.is_available():
+        if pool is not None:
+            pool.terminate()
         raise SystemExit('bench.py needs an MI355X: the GHN-3 path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -254,6 +274,11 @@ def main():
         n_skip = 12                                        # untimed: every worker's first item carries ~0.5 s of imports
         tasks = [(args.nodes, args.graphs_per_gpu, seeds + 7919 * (k + 1), pcfg) for k in range(n_fresh + n_skip)]
         stream_it = pool.imap(_loader_worker, tasks)       # (ordered; the workers run ahead of the consumer)
+        # (GHN3_SWITCH_INTERVAL: interpreter switch interval while the pool's result-handler thread unpickles the workers'
+        # results inside this process; measured r03: 0.2 ms instead of the default 5 ms made the loop SLOWER, 15.4 vs 11.5 ms
+        # per step -- the enqueue time is mostly the host waiting for the GPU two steps ahead, not lock hand-offs)
+        old_switch = sys.getswitchinterval()
+        sys.setswitchinterval(float(os.environ.get('GHN3_SWITCH_INTERVAL', str(old_switch))))
         # single consumer thread: the device half of the compile (GHN3.plan: asynchronous uploads from reusable pinned
         # slots) costs ~3 ms of host time and the enqueue of a step ~3 ms -- together less than the GPU's step, so the
         # loop stays GPU-bound without a prefetch thread (one was measured: with the pool's result thread it made three
@@ -302,11 +327,91 @@ def main():
         if threaded:
             th.join()
         pool.close()
-        extras['fresh_graph_host_ms'] = {'wait_for_plan': 1e3 * t_wait / n_fresh, 'enqueue': 1e3 * t_enq / n_fresh}
+        sys.setswitchinterval(old_switch)
+        extras['fresh_graph_host_ms'] = {'wait_for_plan': 1e3 * t_wait / n_fresh, 'enqueue': 1e3 * t_enq / n_fresh,
+                                         'loader_workers': n_workers, 'usable_cores': n_cores}
         extras['fresh_graph_gpu_ms'] = sum(a_.elapsed_ms(b_) for a_, b_ in gpu_spans[n_skip:]) / max(1, len(gpu_spans) - n_skip)
         extras['fresh_graph_ms_per_step'] = 1e3 * dt_f / n_fresh
         extras['fresh_graph_value'] = n_fresh_pred / dt_f
-        # (c) the exact-fp32 configuration of the same workload
+        # (c) what a TRAINING step adds to the benchmarked forward + backward: the optimizer pass over all GHN parameters
+        # (clip_grad_norm_ + AdamW fused, trainer.py:356-381) and -- because the weights now change every step -- the
+        # re-cast of their 16-bit copies ("shadows") in front of the next forward
+        from ghn3_amd.optim import FusedAdamW
+        opt = FusedAdamW(ghn, lr=1e-6, max_grad_norm=5.0)
+        n_t = max(5, min(args.steps, 30))
+        for _ in range(2):
+            step()
+            opt.step(plan.gflat)
+        torch.cuda.synchronize()
+        t_t = time.perf_counter()
+        for _ in range(n_t):
+            step()
+            opt.step(plan.gflat)
+        torch.cuda.synchronize()
+        t_t = 1e3 * (time.perf_counter() - t_t) / n_t
+        ea, eb = L.Event(), L.Event()
+        ea.record(stream)
+        for _ in range(n_t):
+            opt.step(plan.gflat)
+        eb.record(stream)
+        adam_ms = ea.elapsed_ms(eb) / n_t
+        ghn.params_changed()
+        ea.record(stream)
+        for _ in range(n_t):
+            ghn.params_changed()
+            ghn._refresh_shadows(plan, stream)
+        eb.record(stream)
+        refresh_ms = ea.elapsed_ms(eb) / n_t
+        extras['train_step'] = {'ms_per_step': t_t, 'value': n_pred / (t_t * 1e-3), 'adamw_ms': adam_ms,
+                                'shadow_refresh_ms': refresh_ms,
+                                'note': 'fwd + loss + bwd + fused clip/AdamW over %d GHN parameters + 16-bit weight copies '
+                                        're-cast every step (weights change)' % int(ghn._flat_numel)}
+        del opt
+        # (d) the real per-GPU batches of BASELINE config 5 (ghn3xlm16, meta-batch 16 on 8 GPUs = 2 graphs per GPU; 4 = the
+        # same meta-batch on 4 GPUs): same measurement as the headline line, more decoder rows per launch
+        for gpg in (2, 4):
+            if gpg == args.graphs_per_gpu:
+                continue
+            gb_b, nets_b = synthetic_batch([args.nodes] * gpg, args.nodes * 1000 + rank * gpg)
+            plan_b = ghn.compile(nets_b, gb_b, training=True)
+            prog_b = plan_b.program
+            norms_b = prog_b.norm_ops(1.0)
+            dout_b = torch.empty(prog_b.out_numel, dtype=torch.float32, device=dev)
+            n_b = max(5, args.steps // 4)
+            for _ in range(3):
+                run_step(ghn, plan_b, dout_b, norms_b)
+            torch.cuda.synchronize()
+            ctx.profile(2)
+            ctx.profile_read_tags(reset=True)
+            t_b = time.perf_counter()
+            for _ in range(n_b):
+                run_step(ghn, plan_b, dout_b, norms_b)
+            torch.cuda.synchronize()
+            t_b = (time.perf_counter() - t_b) / n_b
+            tags_b = ctx.profile_read_tags(reset=True)
+            ctx.profile(0)
+            ea, eb = L.Event(), L.Event()
+            ea.record(stream)
+            for _ in range(n_b):
+                ghn._run_forward(plan_b)
+            eb.record(stream)
+            fwd_b = ea.elapsed_ms(eb) / n_b
+            dom_b = [prog_b.TAG_D3_FWD, prog_b.TAG_D3_DGRAD, prog_b.TAG_D3_WGRAD]
+            fl_b = sum(prog_b.tag_flops.get(t, 0.0) for t in dom_b)
+            ms_b = sum(tags_b.get(t, (0.0, 0))[0] for t in dom_b) / n_b
+            rows_b = prog_b.B * prog_b.N
+            gfl_b = prog_b.Lyr * (24.0 * rows_b * prog_b.C ** 2 + 4.0 * prog_b.B * prog_b.N ** 2 * prog_b.C)
+            dfl_b = sum(prog_b.tag_flops.get(t, 0.0) for t in (prog_b.TAG_D3_FWD, prog_b.TAG_D2_FWD, prog_b.TAG_D1_FWD))
+            n_pred_b = sum(p_['numel'] for p_ in prog_b.predicted)
+            extras['b%d' % gpg] = {
+                'graphs_per_gpu': gpg, 'ms_per_step': 1e3 * t_b, 'value': n_pred_b / t_b, 'predicted_params': n_pred_b,
+                'decoder_rows': int(prog_b.M),
+                'roofline_frac': (fl_b / (ms_b * 1e-3) / 1e12 / PEAK_TFLOPS[args.compute]) if ms_b > 0 else None,
+                'w2_family_ms': ms_b,
+                'forward': {'ms': fwd_b, 'frac_of_16bit_mfma_peak': (gfl_b + dfl_b) / (fwd_b * 1e-3) / 1e12 / 2500.0}}
+            del plan_b, dout_b
+            torch.cuda.empty_cache()
+        # (e) the exact-fp32 configuration of the same workload
         if args.compute != 'f32':
             torch.manual_seed(0)
             g32 = GHN3(**model_cfg(args.model), compute='f32').to(dev)

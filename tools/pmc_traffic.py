@@ -24,7 +24,7 @@ def sums(db, counter):
                                               % name_col):
         if cname != counter:
             continue
-        key = name.split('(')[0]
+        key = name.replace('(anonymous namespace)::', '').split('(')[0]
         agg[key] += val
         calls[key].add(did)
     return agg, {k: len(v) for k, v in calls.items()}
@@ -34,7 +34,7 @@ def main():
     fdb, wdb, steps = sys.argv[1], sys.argv[2], int(sys.argv[3])
     f, fc = sums(fdb, 'FETCH_SIZE')
     w, wc = sums(wdb, 'WRITE_SIZE')
-    fam = [k for k in f if 'gemm_h16d_kernel' in k or 'gemm_h16w_kernel' in k]
+    fam = [k for k in f if 'gemm_h16d_kernel' in k or 'gemm_h16w_kernel' in k or 'gemm_p8_kernel' in k or 'gemm_p8w_kernel' in k]
     fetch_kib = sum(f[k] for k in fam)
     write_kib = sum(w.get(k, 0.0) for k in fam)
     launches = sum(fc[k] for k in fam)
@@ -42,7 +42,7 @@ def main():
     fill = [k for k in w if 'FillFunctor<unsigned char>' in k]
     out = {
         'workload': 'bench.py defaults: ghn3xlm16, one synthetic 256-node graph, f16 mode, side stream serialised',
-        'kernel': 'gemm_h16d_kernel + gemm_h16w_kernel (decoder W2 forward / dgrad / wgrad + decoder.conv.0 backward)',
+        'kernel': 'gemm_p8_kernel + gemm_p8w_kernel + gemm_h16d_kernel (decoder W2 forward / dgrad / wgrad + decoder.conv.0 backward)',
         'steps_in_run': steps, 'launches_per_step': launches / steps,
         'fetch_size_kib_per_step_raw': fetch_kib / steps, 'write_size_kib_per_step_raw': write_kib / steps,
         'fetch_correction': 2.0,

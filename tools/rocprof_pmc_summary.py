@@ -22,7 +22,7 @@ def main():
     agg = defaultdict(lambda: defaultdict(float))
     disp = defaultdict(dict)
     for name, did, cname, val, st, en in rows:
-        key = name.split('(')[0][:70]
+        key = name.replace('(anonymous namespace)::', '').split('(')[0][:70]
         agg[key][cname] += val
         disp[key][did] = (en - st)
     for key, d in sorted(agg.items(), key=lambda kv: -sum(disp[kv[0]].values())):

@@ -1342,6 +1342,41 @@ int ghn3_rank_reduce(void* out, const void* in, int64_t per, int W, int in16, in
     return launch_ok("rank_reduce");
 }
 
+// GHN3_OP_TRANSPOSE32: batched fp32 transpose through LDS (64 x 64 tiles, 16-byte accesses on both sides)
+__global__ __launch_bounds__(256) void transpose32_kernel(float* __restrict__ dst, const float* __restrict__ src, int rows, int cols,
+                                                          int ld_src, int ld_dst, int64_t sb, int64_t db) {
+    __shared__ float t[64][65];
+    const float* S = src + (int64_t)blockIdx.z * sb;
+    float* D = dst + (int64_t)blockIdx.z * db;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;      // 16 float4 per 64-float row, 16 rows per pass
+    for (int i = ty; i < 64; i += 16) {
+        const int r = r0 + i, c = c0 + tx * 4;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (r < rows) {
+            if (c + 3 < cols && ((ld_src & 3) == 0) && ((reinterpret_cast<uintptr_t>(S) & 15) == 0)) v = *reinterpret_cast<const float4*>(S + (int64_t)r * ld_src + c);
+            else { float e[4] = {0.f, 0.f, 0.f, 0.f}; for (int k = 0; k < 4; ++k) if (c + k < cols) e[k] = S[(int64_t)r * ld_src + c + k]; v = {e[0], e[1], e[2], e[3]}; }
+        }
+        t[i][tx * 4] = v.x; t[i][tx * 4 + 1] = v.y; t[i][tx * 4 + 2] = v.z; t[i][tx * 4 + 3] = v.w;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 16) {
+        const int c = c0 + i, r = r0 + tx * 4;                   // output row = source column
+        if (c >= cols) continue;
+        float e[4] = {t[tx * 4][i], t[tx * 4 + 1][i], t[tx * 4 + 2][i], t[tx * 4 + 3][i]};
+        if (r + 3 < rows && ((ld_dst & 3) == 0) && ((reinterpret_cast<uintptr_t>(D) & 15) == 0)) *reinterpret_cast<float4*>(D + (int64_t)c * ld_dst + r) = float4{e[0], e[1], e[2], e[3]};
+        else for (int k = 0; k < 4; ++k) if (r + k < rows) D[(int64_t)c * ld_dst + r + k] = e[k];
+    }
+}
+int ghn3_transpose32(float* dst, const float* src, int rows, int cols, int ld_src, int ld_dst, int batch, int64_t sb, int64_t db,
+                     hipStream_t s) {
+    if (rows <= 0 || cols <= 0 || batch <= 0) return GHN3_OK;
+    if (batch > 65535 || (rows + 63) / 64 > 65535) { ghn3_set_error("transpose32: too many batches / row tiles"); return GHN3_E_LIMIT; }
+    hipLaunchKernelGGL(transpose32_kernel, dim3((cols + 63) / 64, (rows + 63) / 64, batch), dim3(256), 0, s, dst, src, rows, cols,
+                       ld_src, ld_dst, sb, db);
+    return launch_ok("transpose32");
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // GHN3_OP_CAST16: fp32 -> f16 / bf16 operand copies for the 16-bit-operand GEMM (gemm.hip gemm_h16d_kernel).
 // One workgroup = one 64 x 64 source tile: read once (float4, coalesced), converted, written straight (128-byte row

@@ -92,7 +92,10 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmProbDev* __restr
 
     // A: this thread's row and first chunk; B: this thread's DMA row / swizzled source chunk
     const int a_r = tid / TPR, a_c = tid % TPR;
-    const float GAS* a_row = (const float GAS*)P->A + (int64_t)min(m0 + a_r, M - 1) * P->lda;
+    // (optional row gathers of A and C: the decoder's fc dgrad multiplies the rows of ONE grid position, nn.py:738 backward)
+    int a_idx = min(m0 + a_r, M - 1);
+    if (P->a_gather) a_idx = P->a_gather[a_idx];
+    const float GAS* a_row = (const float GAS*)P->A + (int64_t)a_idx * P->lda;
     const int b_r = tid >> 3;                                           // + 32 j
     const int b_ck = ((tid & 7) ^ ((tid >> 4) & 7)) * 8;                 // source k offset of this lane's 16-byte slot
     gch Bh = (gch)P->B, Bl = (gch)P->B2;
@@ -210,7 +213,7 @@ __global__ __launch_bounds__(256) void gemm_x3_kernel(const GemmProbDev* __restr
         for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn0 + 16 * j + 4 * lq;
             if (m >= M || n >= N) continue;
-            const int64_t ci = (int64_t)m * P->ldc + n;
+            const int64_t ci = (int64_t)(P->c_gather ? P->c_gather[m] : m) * P->ldc + n;
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = (acc0[i][j][e] + acc1[i][j][e]) * alpha;

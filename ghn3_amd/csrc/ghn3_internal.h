@@ -99,6 +99,8 @@ int ghn3_colsum(float* out, const float* X, int M, int N, int ld, int q, int sdi
 int ghn3_rowseg_sum(float* out, const float* X, const int* seg_ptr, const int* idx, int rows, int C, int ldx,
                     int ldo, int accum, hipStream_t s);
 int ghn3_add(float* dst, const float* src, int64_t n, hipStream_t s);
+int ghn3_transpose32(float* dst, const float* src, int rows, int cols, int ld_src, int ld_dst, int batch, int64_t sb, int64_t db,
+                     hipStream_t s);
 int ghn3_wire_pack(void* dst, const void* src, int64_t n, int64_t n_pad, int reverse, hipStream_t s);
 int ghn3_rank_reduce(void* out, const void* in, int64_t per, int W, int in16, int out16, float scale, hipStream_t s);
 int ghn3_cast16(const float* src, void* dst, const ghn3_cast_desc* d_desc, int n_desc, int total_blocks, float* dbias,

@@ -350,15 +350,15 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                     return GHN3_E_ARG;
                                 }
                             }
-                            if (x3 && (p.a_mode != GHN3_MODE_ROW || p.b_mode != GHN3_MODE_ROW || p.a_gather.buf >= 0 ||
-                                       p.b_gather.buf >= 0 || p.c_gather.buf >= 0 || p.a_q || p.b_q || p.c_q || p.bias_q ||
+                            if (x3 && (p.a_mode != GHN3_MODE_ROW || p.b_mode != GHN3_MODE_ROW ||
+                                       p.b_gather.buf >= 0 || p.a_q || p.b_q || p.c_q || p.bias_q ||
                                        (p.N & 3) || (p.ldc & 3) || (p.ldb & 7) || p.x3_slice <= 0 ||
                                        (p.x3_slice & 63) || (p.K % p.x3_slice) || p.ksplit > 1 || p.B2.buf < 0 || (p.C.off & 15) ||
                                        (p.bias.off & 15) || (p.aux_in.off & 15) || (p.aux_out.off & 15) ||
                                        (p.residual.off & 15) || (p.flags & (GHN3_GEMM_ACCUM | GHN3_GEMM_BIASGRAD)) ||
                                        (p.bias.buf >= 0 && p.bias_stride > 1))) {
                                 ghn3_set_error("op %d problem %d: split-bf16 (X3) problems need ROW/ROW modes without "
-                                               "gathers / maps, N %% 4 == 0, ldc %% 4 == 0, ldb %% 8 == 0, a K slice that is "
+                                               "a B gather / maps, N %% 4 == 0, ldc %% 4 == 0, ldb %% 8 == 0, a K slice that is "
                                                "a multiple of 64 and divides K, the lo copy B2 and 16-byte aligned C / "
                                                "bias / aux / residual", k, q);
                                 return GHN3_E_ARG;
@@ -678,6 +678,10 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         }
         case GHN3_OP_ADD:
             rc = ghn3_add(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), o.i[0], stream);
+            break;
+        case GHN3_OP_TRANSPOSE32:
+            rc = ghn3_transpose32(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), (int)o.i[0], (int)o.i[1], (int)o.i[2],
+                                  (int)o.i[3], (int)o.i[4], o.i[5], o.i[6], stream);
             break;
         case GHN3_OP_WIRE_PACK:
             rc = ghn3_wire_pack(R.get<void>(o.r[0]), R.get<const void>(o.r[1]), o.i[0], o.i[1], (int)o.i[2], stream);

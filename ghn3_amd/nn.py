@@ -365,7 +365,7 @@ class GHN3(nn.Module):
     def _shadow_version(self):
         w2, w0 = self.decoder.conv[2].weight, self.decoder.conv[0].weight
         if getattr(self, '_shadowed', None) is None:
-            self._shadowed = [w2, w0] + [p for n, p in self.named_parameters()
+            self._shadowed = [w2, w0, self.decoder.fc[0].weight] + [p for n, p in self.named_parameters()
                                          if n.startswith('gnn.') and n.endswith('.weight') and p.dim() == 2
                                          and ('to_qkv' in n or 'to_out' in n or 'ff.net' in n)]
         return (self._param_epoch, sum(p._version for p in self._shadowed), w2.data_ptr())
@@ -548,6 +548,7 @@ class GHN3(nn.Module):
         if graphs is None:                                   # nn.py:217-219: graphs built on the fly
             graphs = [Graph(net, ve_cutoff=50 if self.ve else 1) for net in nets_torch]
         keep = self.training if keep_grads is None else keep_grads
+        debug_info = self._init_debug_info(nets_torch)
         plan = self.compile(nets_torch, graphs, predict_class_layers=predict_class_layers, reduce_graph=reduce_graph,
                             training=bool(keep and torch.is_grad_enabled()))
         if keep and torch.is_grad_enabled():
@@ -568,8 +569,69 @@ class GHN3(nn.Module):
                 if isinstance(net, nn.Module):
                     net.apply(bn_set_train)
         self.last_plan = plan
+        self._print_debug_info(nets_torch, plan, debug_info)
         out = nets_torch if is_lst else nets_torch[0]
         return (out, self.embeddings(plan)) if return_embeddings else out
+
+    # ------------------------------------------------------------------ debug_level self-checks (nn.py:354-420)
+    @staticmethod
+    def _count_params(net):
+        """Number of parameter elements of a target network: nn.Module parameters, or -- for the light networks whose
+        `weight` / `bias` are shape lists until the GHN assigns tensors (light_ops.py) -- the shapes / tensors found on the
+        modules (ppuda's `capacity(net)[1]` counts the same elements)."""
+        if hasattr(net, 'named_parameters'):
+            total = 0
+            for _, p in net.named_parameters():
+                total += int(p.numel()) if torch.is_tensor(p) else int(np.prod(p)) if p is not None and len(p) else 0
+            if total:
+                return total
+        if hasattr(net, 'num_params'):
+            return int(net.num_params())
+        return 0
+
+    def _init_debug_info(self, nets_torch):
+        if not self.debug_level:
+            return None
+        import time
+        n_params = sum(self._count_params(net) for net in nets_torch)
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize()
+        return {'n_params': n_params, 'start_time': time.time()}
+
+    def _print_debug_info(self, nets_torch, plan, info):
+        """The reference's end-of-forward report (nn.py:373-420): number of predicted tensors / parameters, the
+        MATCHED! / ERROR! comparison with the networks' own parameter count (an end-to-end assertion that every parameter
+        received a prediction), the prediction time, and -- debug_level > 2 -- per-tensor statistics."""
+        if not self.debug_level or info is None:
+            return
+        import time
+        from .utils import log
+        if self.device.type == 'cuda':
+            torch.cuda.synchronize()
+        preds = plan.program.predicted
+        n_tensors_pred, n_params_pred = len(preds), int(sum(p['numel'] for p in preds))
+        has_none = [sum(n[0] == 'none' for n in net.genotype.normal + net.genotype.reduce) > 0
+                    for net in nets_torch if hasattr(net, 'genotype')]
+        n_recompute = sum(self._count_params(net) for net in nets_torch)
+        matched = info['n_params'] == n_params_pred
+        log('number of parameter tensors predicted using GHN: {}, total parameters predicted: {} ({}), '
+            'time to predict (on {}): {:.4f} sec'.format(
+                n_tensors_pred, n_params_pred,
+                'MATCHED!' if matched else 'ERROR! NOT MATCHED WITH {} ACTUAL PARAMS (HAS_NONE={}, N_PARAMS={})'.format(
+                    info['n_params'], has_none, n_recompute),
+                str(self.device).upper(), time.time() - info['start_time']))
+        self.last_debug_info = {'n_tensors_pred': n_tensors_pred, 'n_params_pred': n_params_pred,
+                                'n_params': info['n_params'], 'matched': matched}
+        if self.training and len(nets_torch) > 1:
+            assert matched or (any(has_none) and n_recompute == n_params_pred), 'not all params predicted!'
+        if self.debug_level > 2:
+            for net_id, net in enumerate(nets_torch):
+                log('\npredicted parameter stats for net %d:' % net_id)
+                named = net.named_parameters() if isinstance(net, nn.Module) else []
+                for n, p in named:
+                    log('{:30s} ({:30s}): min={:.3f} \t max={:.3f} \t mean={:.3f} \t std={:.3f} \t norm={:.3f}'.format(
+                        n[:30], str(tuple(p.shape))[:30], p.min().item(), p.max().item(), p.mean().item(),
+                        p.std().item() if p.numel() > 1 else 0.0, torch.norm(p).item()))
 
     def predicted_param_norm(self, plan=None):
         """Differentiable sum of the Frobenius norms of all tensors predicted by the last forward (or `plan`): the

@@ -649,8 +649,11 @@ class Program:
         w2h = 0
         w2hT = round_up(w2h + n_w2 * 8 * C + 128, 128)
         w0hT = round_up(w2hT + 8 * C * w2hT_ld + 128, 128)
-        pos = round_up(w0hT + 4 * C * 8 * C + 128, 128)
-        lay = dict(w2h=w2h, w2hT=w2hT, w2hT_ld=w2hT_ld, w0hT=w0hT, x3={})
+        # fp32, k-contiguous copy of decoder.fc.0.weight for the fc dgrad: [position p][C][4C] (GHN3_OP_TRANSPOSE32)
+        S2 = int(max_shape[2]) * int(max_shape[3])
+        wfcT = round_up(w0hT + 4 * C * 8 * C + 128, 128)
+        pos = round_up(wfcT + 2 * S2 * C * 4 * C + 128, 128)
+        lay = dict(w2h=w2h, w2hT=w2hT, w2hT_ld=w2hT_ld, w0hT=w0hT, wfcT=wfcT, x3={})
         for l in range(layers):
             for name, r, c in Program.X3_WEIGHTS:
                 n = r * C * c * C
@@ -694,6 +697,19 @@ class Program:
                 self.cast16(self.pref('decoder.conv.0.weight'),
                             [dict(src_off=0, rows=8 * C, cols=4 * C, ld_src=4 * C, transposed=(self.w0hT, 8 * C, bct))],
                             flags=self.SIDE, dst_base=shadow)
+        if self.training and os.environ.get('GHN3_FC_DGRAD_T', '1') != '0' and (4 * C) % 64 == 0 and C % 4 == 0:
+            # decoder.fc.0.weight transposed per grid position, as bf16 hi / lo copies (GHN3_GEMM_X3 B operand):
+            # wfcT[p][n][ch] = Wfc[ch * 256 + p][n].  The fc dgrad reduces over ch; on the exact-fp32 small-problem kernel it
+            # was ~50 problems (one per used grid position) of a few dozen rows, 12 column tiles each walking K = 4C in
+            # latency-bound 128-wide chunks: 0.39 ms on the critical path (4 TFLOP/s).  Split-bf16 products against these
+            # copies run the same problems with the whole K slice in LDS.  Written on the side stream when the weights
+            # changed, used by the backward only.
+            S2 = self.S * self.S
+            self.wfcT = lay['wfcT']
+            self.wfcT_lo = S2 * C * 4 * C
+            items = [dict(src_off=p_ * C, rows=4 * C, cols=C, ld_src=S2 * C,
+                          transposed=(self.wfcT + p_ * C * 4 * C, 4 * C, L.CT_BF16), split=self.wfcT_lo) for p_ in range(S2)]
+            self.cast16(self.pref('decoder.fc.0.weight'), items, flags=self.SIDE, dst_base=shadow)
         if self.x3:
             # bf16 hi / lo copies of the Graphormer linears, straight (forward) and transposed (dgrad): one launch per
             # layer (the source base of a cast op is one parameter; the four weights of a layer are addressed from its
@@ -1314,7 +1330,12 @@ class Program:
         self.bwd_cut_w2 = 0
         late_ops = []
 
-        d_rows = self.wsf('d_xrows', (M + n1) * C)
+        # K splits of the fc dgrad write separate planes of d_xrows (plane j at rows j * (M + n1) ..); the gather-sum that
+        # folds decoder rows into node rows adds the planes in a fixed order (no atomics)
+        self.fc_ks = int(os.environ.get('GHN3_FC_DGRAD_KS', '1')) if (False and M > 0 and self.training and self.uses_shadow and
+                                                                     os.environ.get('GHN3_FC_DGRAD_T', '1') != '0' and
+                                                                     (4 * C) % 8 == 0) else 1
+        d_rows = self.wsf('d_xrows', self.fc_ks * (M + n1) * C)
         # ---- tile backward -------------------------------------------------------------------------
         if M > 0:
             self.wsf('d_tiles', self.tiles_floats)
@@ -1614,7 +1635,7 @@ class Program:
                 # but there the weight gradient is back at 1.49 ms).
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=True, flops=fl,
                              tile=int(os.environ.get('GHN3_WGRAD_TILE', '29')),
-                             grid_cap=int(os.environ.get('GHN3_WGRAD_CAP', '224')) if self.SIDE else 0)
+                             grid_cap=int(os.environ.get('GHN3_WGRAD_CAP', '200')) if self.SIDE else 0)
             fam_list = bands
             for gi, g in enumerate(self.gemm_groups):
                 if g['op16']:
@@ -1668,9 +1689,15 @@ class Program:
             # D1 backward (per used position)
             p0 = len(self._probs)
             for (p, cnt, r_rows, r_src) in self.d1:
+                if hasattr(self, 'wfcT'):             # split-bf16 products against the transposed copies (see _cast_w2)
+                    b_hi = self.wfcT + p * C * 4 * C
+                    self.gemm(d_t, self.sref(b_hi), d_rows, cnt, C, 4 * C, 4 * C, 4 * C, C, a_gather=r_rows,
+                              c_gather=r_rows, x3=(self.sref(b_hi + self.wfcT_lo), 384 if (4 * C) % 384 == 0 else 64))
+                    continue
                 self.gemm(d_t, self.pref(Wfc, p * C), d_rows, cnt, C, 4 * C, 4 * C, S2 * C, C, a_mode=L.MODE_ROW,
                           b_mode=L.MODE_COL, a_gather=r_rows, c_gather=r_rows)
-            self.gemm_op(p0, tag=self.TAG_D1_BWD, ctype=self.d1_bwd_ctype)
+            self.gemm_op(p0, tag=self.TAG_D1_BWD, ctype=self.d1_bwd_ctype,
+                         tile=42 if hasattr(self, 'wfcT') else int(os.environ.get('GHN3_D1_DGRAD_TILE', '0')))
             p0 = len(self._probs)
             for (p, cnt, r_rows, r_src) in self.d1:
                 self.gemm(d_t, xe, self.gref(Wfc, p * C), 4 * C, C, cnt, 4 * C, C, S2 * C, a_mode=L.MODE_COL,
@@ -1715,6 +1742,18 @@ class Program:
         counts = np.bincount(all_src, minlength=rows)[:rows]
         seg_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         d_xe = self.wsf('d_xe', rows * C)
+        if getattr(self, 'fc_ks', 1) > 1 and hasattr(self, 'wfcT'):
+            # planes of the decoder rows (the 1-D rows live in plane 0 only): node row r sums its rows of every plane
+            ks = self.fc_ks
+            is_dec = order < M
+            reps = np.where(is_dec, ks, 1)
+            order_k = np.repeat(order, reps)
+            plane = np.concatenate([np.arange(k_) for k_ in reps]) if len(reps) else np.zeros(0, dtype=np.int64)
+            order_k = (order_k + plane * (M + n1)).astype(np.int32)
+            cnt_k = np.zeros(rows, dtype=np.int64)
+            np.add.at(cnt_k, all_src[order], reps)
+            seg_ptr = np.concatenate([[0], np.cumsum(cnt_k)]).astype(np.int32)
+            order = order_k
         self.op(L.OP_ROWSEG_SUM, refs=(d_xe, d_rows, self.idx(seg_ptr), self.idx(order)), ints=(rows, C, C, C, 0))
 
         # ---- final LayerNorm ----------------------------------------------------------------------------

@@ -79,7 +79,8 @@ enum { GHN3_DACT_NONE = 0, GHN3_DACT_RELU = 1 /* aux_in > 0 */, GHN3_DACT_GELU =
 /* Split-bf16 operands ("x3"): near-fp32 products on the 16-bit matrix cores for the latency-bound Graphormer linears
  * (graphormer.py:38-44,121,141 and their dgrad) -- v_mfma_f32_16x16x32_bf16 needs 1/16 of the matrix-core cycles of the
  * exact-fp32 v_mfma_f32_32x32x2_f32 per product, three products per term leave ~5x.
- *   A: fp32, ROW mode, no gather / map; split on the fly into a = hi + lo (hi = bf16(a), lo = bf16(a - hi)).
+ *   A: fp32, ROW mode, optional row gather (a_gather; also c_gather for C), no q / s map; split on the fly into
+ *      a = hi + lo (hi = bf16(a), lo = bf16(a - hi)).
  *   B: a weight's persistent bf16 copies written by GHN3_OP_CAST16 with GHN3_CAST_SPLIT: `B` = hi [N][ldb], `B2` = lo
  *      (same layout), both k-contiguous (ROW mode), ldb in 16-bit elements (% 8 == 0), K zero padded to 64.
  *   C = alpha * (hi.hi + hi.lo + lo.hi) (+ epilogue), fp32 accumulate; the dropped lo.lo term is 2^-16 relative.
@@ -332,6 +333,12 @@ enum ghn3_op_kind {
      *              bits); r0 = out r1 = in ; i0 = elements per rank, i1 = ranks W, i2 = 1: `in` is bf16, i3 = 1: `out` is bf16 */
     GHN3_OP_WIRE_PACK = 30,
     GHN3_OP_RANK_REDUCE = 31,
+    /* batched fp32 transpose: dst[b][c][r] = src[b][r][c], r < i0 rows, c < i1 cols; i2 = ld_src, i3 = ld_dst, i4 = batch,
+     * i5 / i6 = floats between batches in src / dst.  Writes the persistent k-contiguous copy of decoder.fc.0.weight the
+     * fc dgrad multiplies with (per used position of the 16 x 16 grid the [4C] x [C] row subset `ch * 256 + p` of Wfc,
+     * nn.py:738 backward): read k-strided, one 128-byte piece of every 1.5 KB row per column tile, that GEMM ran at
+     * 4 TFLOP/s on the critical path. */
+    GHN3_OP_TRANSPOSE32 = 32,
     GHN3_OP_KIND_COUNT
 };
 

@@ -231,12 +231,13 @@ class Interp:
         lda, ldb, sl = int(p['lda']), int(p['ldb']), int(p['x3_slice'])
         assert int(p['a_mode']) == L.MODE_ROW and int(p['b_mode']) == L.MODE_ROW and ldb % 8 == 0 and N % 4 == 0
         assert sl > 0 and sl % 64 == 0 and K % sl == 0 and sl <= 384 and int(p['ksplit']) <= 1
-        for n in ('a_gather', 'b_gather', 'c_gather'):
-            assert int(p[n]['buf']) < 0
+        assert int(p['b_gather']['buf']) < 0
         assert int(p['B']['off']) % 16 == 0 and int(p['B2']['off']) % 16 == 0 and int(p['B2']['buf']) >= 0
         XA = self.tail(p['A'], np.float32)
         Bh, Bl = self.tail(p['B'], np.uint16), self.tail(p['B2'], np.uint16)
-        A = XA[np.arange(M)[:, None] * lda + np.arange(K)[None, :]]
+        ga = self.tail(p['a_gather'], np.int32)
+        ra = ga[:M].astype(np.int64) if ga is not None else np.arange(M)
+        A = XA[ra[:, None] * lda + np.arange(K)[None, :]]
         ah = self.from16(self.to16(A, True), True)
         al = self.from16(self.to16((A - ah).astype(np.float32), True), True)
         ib = np.arange(N)[None, :] * ldb + np.arange(K)[:, None]
@@ -701,6 +702,15 @@ class Interp:
         amax = self.tail(o['r'][2], np.float32)
         if amax is not None:
             amax[0] = max(float(amax[0]), float(np.abs(X[ii]).max()))
+
+    def op_transpose32(self, o, problems):
+        rows, cols, ld_s, ld_d, batch, sb, db = (int(v) for v in o['i'][:7])
+        src = self.tail(o['r'][1], np.float32)
+        dst = self.tail(o['r'][0], np.float32)
+        for b in range(batch):
+            S = np.lib.stride_tricks.as_strided(src[b * sb:], shape=(rows, cols), strides=(4 * ld_s, 4))
+            D = np.lib.stride_tricks.as_strided(dst[b * db:], shape=(cols, rows), strides=(4 * ld_d, 4))
+            D[:] = S.T
 
     def op_add(self, o, problems):
         n = int(o['i'][0])

@@ -220,11 +220,16 @@ def test_ghn_model_without_a_graph(name):
     from oracle import ghn3_ref as R
     hip, oracle = make_models(recipe.TINY_CFG, recipe.TINY_SEED)
     hip.eval()
+    hip.debug_level = 1                                           # nn.py:354-403: the MATCHED! self-check
     net = graph_nets.all_nets(graph_nets.local_bases())[name].to('cuda')
     before = {k: v.detach().clone() for k, v in net.named_parameters()}
     with torch.no_grad():
         out = hip(net)                                            # graphs=None
     assert out is net
+    info = hip.last_debug_info
+    n_untouched = sum(v.numel() for k, v in before.items() if k.endswith('class_token'))
+    assert info['n_params'] == sum(v.numel() for v in before.values())
+    assert info['n_params_pred'] == info['n_params'] - n_untouched and info['matched'] == (n_untouched == 0)
     torch.cuda.synchronize()
     net_o = graph_nets.all_nets(graph_nets.local_bases())[name]
     g = Graph(net_o, ve_cutoff=50)
@@ -415,10 +420,11 @@ def test_ghn3tm8_synthetic_forward_backward(compute, tol_f, tol_g):
 
 
 def test_size_independent_properties_at_scale():
-    """ghn3lm8-sized decoder rows at N=200: properties that do not need the oracle at full size."""
+    """BASELINE config 3 per GPU at FULL size -- ghn3lm8 (hid 256, 12 layers, 16 heads, 214.7 M parameters), one synthetic
+    200-node graph: properties that do not need the oracle at full size."""
     from ghn3_amd import GHN3
     from ghn3_amd.synthetic import synthetic_batch
-    cfg = dict(max_shape=(128, 128, 16, 16), num_classes=1000, hid=128, heads=16, layers=5, weight_norm=True,
+    cfg = dict(max_shape=(256, 256, 16, 16), num_classes=1000, hid=256, heads=16, layers=12, weight_norm=True,
                ve=True, layernorm=True)
     torch.manual_seed(0)
     hip = GHN3(**cfg).to('cuda')
@@ -444,12 +450,26 @@ def test_size_independent_properties_at_scale():
     # tiling is periodic: a tensor wider than the tile repeats with period = tile extent (nn.py:466-485)
     for p, d in zip(plan.program.predicted, range(len(plan.program.predicted))):
         shp = p['tile_shape']
-        if len(shp) == 4 and shp[0] > 128:
+        if len(shp) == 4 and shp[0] > 256:
             t = flat2[p['offset']:p['offset'] + p['numel']].view(shp)
-            assert torch.equal(t[:shp[0] - 128], t[128:])
+            assert torch.equal(t[:shp[0] - 256], t[256:])
             break
     n_pred = sum(p['numel'] for p in plan.program.predicted)
     assert n_pred == nets[0].num_params()
+    assert sum(p.numel() for p in hip.parameters()) == 214668960          # ghn3lm8
+    # forward + backward at full size: finite gradients for every parameter, bit-identical on a rerun (no float atomics)
+    hip.train()
+    plan_t = hip.compile(nets, gb, training=True)
+    hip._run_forward(plan_t)
+    dout = torch.randn(plan_t.program.out_numel, device='cuda') * 1e-3
+    hip._run_backward(plan_t, dout)
+    torch.cuda.synchronize()
+    g1 = plan_t.gflat.clone()
+    hip._run_forward(plan_t)
+    hip._run_backward(plan_t, dout)
+    torch.cuda.synchronize()
+    assert torch.isfinite(g1).all() and float(g1.abs().sum()) > 0
+    assert torch.equal(g1, plan_t.gflat)
 
 
 @pytest.mark.parametrize('hid,heads,nodes', [(96, 4, [40]), (64, 4, [70, 33]), (48, 16, [30])])

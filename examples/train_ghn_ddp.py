@@ -85,12 +85,15 @@ def main():
     per_rank = args.meta_batch_size // world
     kw = dict(large_images=args.imagenet, seed=args.seed, max_nodes=args.max_nodes)
     total = args.steps * args.epochs
-    queue = pool.imap(_draw, [(st, ddp.rank, per_rank, args.meta_batch_size, kw) for st in range(total + 1)])
 
     trainer = Trainer(ghn, opt='adamw', opt_args={'lr': args.lr, 'weight_decay': args.wd}, scheduler='cosine',
                       n_batches=args.steps, grad_clip=5, device=ddp.device, log_interval=10, amp=args.amp,
                       amp_min_scale=1024, predparam_wd=3e-5, label_smoothing=0.1 if args.imagenet else 0.0,
                       save_dir=args.save, epochs=args.epochs, verbose=ddp.rank == 0)
+    # the architecture stream is a pure function of (seed, step): a resumed run continues at the checkpointed position
+    # instead of replaying the architectures of step 0 onwards
+    first = trainer.start_epoch * args.steps + trainer.start_step
+    queue = pool.imap(_draw, [(st, ddp.rank, per_rank, args.meta_batch_size, kw) for st in range(first, total + 1)])
     log('training %s (%d parameters) on %d sampled architectures per step, %d x %d images'
         % (args.model, sum(p.numel() for p in ghn.parameters()), args.meta_batch_size, args.batch_size,
            224 if args.imagenet else 32))

@@ -1412,7 +1412,10 @@ class Program:
             # planes: the K splits of the 16-bit dgrad write separate partial planes (plane 0 = d_u) that the DACT pass
             # sums in a fixed order -- no atomics, no memset of d_u, deterministic gradients
             planes = bool(g16) and os.environ.get('GHN3_DGRAD_PLANES', '1') != '0'
-            if not planes:
+            # exact-fp32 mode (no 16-bit groups): the K chunks write partial planes as well (round 3; they used to add
+            # atomically into a zeroed d_u, the one non-deterministic reduction left on the path)
+            planes32 = (not g16) and os.environ.get('GHN3_DGRAD_PLANES', '1') != '0'
+            if not planes and not planes32:
                 self.op(L.OP_MEMSET0, refs=(d_u,), ints=(4 * M * 8 * C,))
             if g16:
                 # 16-bit copies of the backward operands: per group d_tiles straight (dgrad A operand); for the wgrad
@@ -1502,6 +1505,10 @@ class Program:
                 return ks
 
             n_planes, rows16 = 1, 0
+            if planes32:
+                n_planes = int(max(1, min(8, max(g['o'] for g in self.gemm_groups))))
+                rows16 = M
+                d_up = self.wsf('d_u_parts', max(n_planes - 1, 1) * M * 8 * C)
             if planes:
                 # every 16-bit group writes the same number of planes (its own chunk count <= 8, K = 0 problems -- zeros
                 # -- for the rest), so that one reduction pass serves all rows
@@ -1578,6 +1585,19 @@ class Program:
                                   b_kmap=(g['i_ld'], ms[1]), lim=lim, lim_kind=2, alpha_amax=amax_t,
                                   xcd=j if (pin and nc_max == 8) else None, mtiles=mt)
                     continue
+                if planes32:
+                    # chunk j = W2 rows o' in [j oc, (j + 1) oc): a multiple of the row-map period i, so A and B just start
+                    # further in; chunks beyond a group's own o range are K = 0 problems (zeros)
+                    oc = round_up((g['o'] + n_planes - 1) // n_planes, 4)      # (k0 * 4 bytes stays 16-byte aligned)
+                    for j in range(n_planes):
+                        k0 = min(j * oc, round_up(g['o'], 4)) * g['i_ld']
+                        kc = max(0, min(g['cols'] - k0, oc * g['i_ld']))
+                        dst = (d_u[0], d_u[1] + 4 * g['row0'] * 8 * C) if j == 0 else \
+                            (d_up[0], d_up[1] + 4 * ((j - 1) * M + g['row0']) * 8 * C)
+                        self.gemm(self.wref('d_tiles', g['tile_off'] + k0), self.pref(W2, min(j * oc, round_up(g['o'], 4)) * ms[1] * 8 * C),
+                                  dst, g['rows'], 8 * C, kc, g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
+                                  b_qs=(g['i_ld'], ms[1]))
+                    continue
                 if planes:
                     # (groups outside the 16-bit pipeline have i <= 4: a short reduction, one pass into plane 0)
                     self.gemm(self.wref('d_tiles', g['tile_off']), self.pref(W2),
@@ -1601,7 +1621,7 @@ class Program:
             self.gemm_op(p0, ctype=bct if g16 else None, tag=self.TAG_D3_DGRAD, flops=fl,
                          tile=28 if p8_dgrad else 20 if use_rect else 0)
             self._ops.extend(late_ops)
-            if planes and n_planes > 1:
+            if (planes or planes32) and n_planes > 1:
                 self.op(L.OP_DACT, refs=(d_u, u, amax_u if amax_u is not None else self.NONE, d_up),
                         ints=(M, 8 * C, 8 * C, L.DACT_RELU, n_planes - 1, M * 8 * C, rows16))
             else:

@@ -20,7 +20,10 @@ What is different underneath (MI355X-first, same results):
     flat gradient buffer is averaged by FlatGradReducer inside loss.backward(), overlapped with the Graphormer backward;
   * clip_grad_norm_ + AdamW are two kernels over the flat buffers (FusedAdamW); a non-finite gradient norm (NaN / inf
     loss on ANY rank reaches every rank through the averaged gradient) skips the step on all ranks alike, on the
-    device -- the reference's all-gather of the loss and host-side skip (trainer.py:240-257,397-409) without the syncs;
+    device -- the reference's all-gather of the loss and host-side skip (trainer.py:240-257,397-409) without the syncs.
+    Skipped steps enter neither the metric sums nor their counts; when EVERY step between two checks was skipped (and,
+    under AMP, the loss scale is already at its floor) `update` / `log` raise like the reference does;
+  * gradients travel in fp32 by default, as under DistributedDataParallel; grad_compress='bf16' is opt-in;
   * the training metrics (loss, top-1, top-5, regulariser) stay on the device and are averaged over the ranks with ONE
     all-reduce of a 4-vector per step instead of 4-5 scalar all-gathers; they are read at log time only.
 Target networks run on stock torch ops with the predicted tensors; images may be None, in which case
@@ -46,14 +49,17 @@ class _DeviceMeter:
     def __init__(self, names, device):
         self.names = list(names)
         self.sum = torch.zeros(len(self.names), dtype=torch.float64, device=device)
-        self.cnt = 0
+        self.cnt = torch.zeros((), dtype=torch.float64, device=device)
 
     def update(self, vec, n):
+        """n: sample count of the step, a Python number or a device scalar (0 for a skipped step: neither its values nor
+        its count enter the averages)."""
+        n = n.to(torch.float64) if torch.is_tensor(n) else float(n)
         self.sum += vec.to(torch.float64) * n
         self.cnt += n
 
     def avg(self):
-        vals = (self.sum / max(self.cnt, 1)).tolist()
+        vals = (self.sum / torch.clamp(self.cnt, min=1.0)).tolist()
         return dict(zip(self.names, vals))
 
 
@@ -89,7 +95,7 @@ class Trainer:
     def __init__(self, model, opt, opt_args, scheduler, n_batches, grad_clip=5, auxiliary=False, auxiliary_weight=0.4,
                  device='cuda', log_interval=100, label_smoothing=0, predparam_wd=0, scheduler_args=None, save_dir=None,
                  ckpt=None, epochs=None, verbose=False, amp=False, amp_min_scale=None, amp_growth_interval=2000,
-                 grad_compress='bf16', **unused):
+                 grad_compress=None, amp_init_scale=65536.0, **unused):
         from .nn import GHN3
         if not isinstance(model, GHN3):
             raise NotImplementedError('ghn3_amd.Trainer drives the GHN branch (train_ghn_ddp.py); plain networks '
@@ -103,9 +109,18 @@ class Trainer:
         self.predparam_wd, self.epochs, self.verbose = predparam_wd, epochs, verbose
         self.amp = amp
         # AMP (trainer.py:269,346-379): the target networks run under autocast; the GHN's own 16-bit mode is `compute`.
-        # The loss scale is static (amp_min_scale, 1024 in the GHN-3 recipe): overflow steps are skipped by the
-        # optimizer's non-finite-norm guard; the f16 backward copies are power-of-two scaled per step anyway.
-        self.loss_scale = float(amp_min_scale or 1024.0) if amp else 1.0
+        # Dynamic loss scale with GradScaler's rule -- start at 65536, halve after an overflow step (which the optimizer's
+        # non-finite-norm guard skips on the device), double after `amp_growth_interval` clean steps, never below
+        # `amp_min_scale` (1024 in the GHN-3 recipe, trainer.py:364-379).  The overflow flags stay on the device; the host
+        # copy of the scale is brought up to date every `amp_check_interval` steps and at log time (one 2-float read), so
+        # the reaction to an overflow is delayed by at most that many (skipped) steps instead of a sync every step.
+        self.amp_min_scale = float(amp_min_scale or 1024.0)
+        self.amp_growth_interval = int(amp_growth_interval)
+        self.amp_check_interval = int(unused.pop('amp_check_interval', 25))
+        self.loss_scale = max(self.amp_min_scale, float(amp_init_scale)) if amp else 1.0
+        self._clean_steps = 0
+        # grad_compress: None = fp32 on the wire (what DistributedDataParallel does, trainer.py:136); 'bf16' halves the xGMI
+        # bytes at ~3 significant digits per gradient element (torch's bf16_compress_hook trade-off) -- opt-in
         self.ddp = is_ddp()
         self.rank = get_ddp_rank() if self.ddp else 0
         model.to(device)
@@ -207,10 +222,41 @@ class Trainer:
                 vec[:4] /= dist.get_world_size()
             self._skipped = getattr(self, '_skipped', torch.zeros((), device=dev)) + (vec[4] > 0).float()
             n = int(targets.numel()) * len(models) if images is not None else len(models)
-            good = (vec[4] == 0).float()                 # (skipped steps do not enter the averages)
-            self.metrics.update(torch.nan_to_num(vec[:len(self.metrics.names)]) * good, n)
+            good = (vec[4] == 0).float()                 # (skipped steps enter neither the sums nor the counts)
+            self.metrics.update(torch.nan_to_num(vec[:len(self.metrics.names)]) * good, good * n)
         self._step += 1
+        self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
+        if self.amp and self._steps_since_check >= self.amp_check_interval:
+            self._sync_skips()
         return self.metrics
+
+    def _sync_skips(self):
+        """One host read of the device-side skip counter: loss-scale back-off / growth (GradScaler's rule, applied with a
+        delay of at most amp_check_interval steps), the optimizer's bias-correction step count (a skipped update must not
+        advance it), and the reference's refusal to train on non-finite losses (trainer.py:240-257 raises)."""
+        total = int(getattr(self, '_skipped', torch.zeros(())).item())
+        new = total - self.skipped_updates
+        steps = getattr(self, '_steps_since_check', 0)
+        self._steps_since_check = 0
+        self.skipped_updates = total
+        if new > 0:
+            self._optimizer.steps = max(0, self._optimizer.steps - new)
+            self._bad_checks = getattr(self, '_bad_checks', 0) + 1
+            if self.amp:
+                self.loss_scale = max(self.amp_min_scale, self.loss_scale * 0.5 ** min(new, 16))
+                self._clean_steps = 0
+            if steps > 0 and new >= steps and (not self.amp or self.loss_scale <= self.amp_min_scale):
+                # every step since the last check was skipped and the scale cannot shrink further: the loss itself is
+                # non-finite -- the model has diverged (the reference raises at the first such batch)
+                raise RuntimeError('the loss / gradient norm was not finite in all of the last %d steps (%d skipped '
+                                   'updates in total): the GHN has diverged' % (steps, total))
+        else:
+            self._bad_checks = 0
+            if self.amp:
+                self._clean_steps += steps
+                if self._clean_steps >= self.amp_growth_interval:
+                    self.loss_scale *= 2.0
+                    self._clean_steps = 0
 
     # ------------------------------------------------------------------ checkpoints / logging
     def save(self, epoch, step, config, save_freq=300, interm_epoch=5):
@@ -227,7 +273,7 @@ class Trainer:
         step_ = self._step if step is None else (step + 1)
         if step_ % self.log_interval == 0 or step_ >= self.n_batches - 1 or step_ == 1:
             metrics = self.metrics.avg()                 # (the only host read of the step statistics)
-            self.skipped_updates = int(getattr(self, '_skipped', torch.zeros(())).item())
+            self._sync_skips()
             if self.skipped_updates:
                 metrics['skipped'] = self.skipped_updates
             if self.amp:

@@ -75,3 +75,84 @@ def test_conv_decoder3_forward_matches_oracle(max_shape, class_pred):
     torch.cuda.synchronize()
     assert tuple(got.shape) == tuple(ref.shape), (got.shape, ref.shape)
     assert rel_l2(got.cpu().numpy(), ref.numpy()) < 2e-5
+
+
+def test_transformer_layer_backward_matches_oracle_autograd():
+    """``y0, bias, m = layer0(x, A, mask); y1 = layer1(y0, bias, mask); loss.backward()`` -- the reference's layers are
+    ordinary autograd modules (graphormer.py:208-248).  Gradients w.r.t. the input, every parameter of both layers
+    (incl. the centrality / input-distance tables and the edge-bias MLP of layer 0, reached through the bias layer 1
+    re-adds) against torch autograd of the oracle restatement on the same weights."""
+    from ghn3_amd import GHN3
+    from oracle import graphormer_ref as G
+    C, H, N, B = 32, 4, 20, 2
+    torch.manual_seed(3)
+    ghn = GHN3(max_shape=(C, C, 16, 16), num_classes=10, hid=C, heads=H, layers=2, layernorm=True, ve=True,
+               weight_norm=True).to('cuda')
+    with torch.no_grad():
+        for n_, p_ in ghn.named_parameters():
+            if n_.startswith('gnn.'):
+                p_.copy_(torch.randn_like(p_) * (0.3 if p_.dim() > 1 else 0.1) + (1.0 if n_.endswith('ln1.weight') or n_.endswith('ln2.weight') else 0.0))
+    ghn.params_changed()
+    gen = torch.Generator().manual_seed(5)
+    n_nodes = [20, 13]
+    A = torch.zeros(B, N, N, dtype=torch.int64)
+    for b in range(B):
+        for i in range(n_nodes[b]):
+            for j in range(i + 1, n_nodes[b]):
+                A[b, i, j] = min(j - i, 6) if (j - i) % 3 != 2 else 0
+    nm = torch.zeros(B, N, 1, dtype=torch.bool)
+    for b, n in enumerate(n_nodes):
+        nm[b, :n] = True
+    mask = nm & nm.permute(0, 2, 1)
+    x0 = torch.randn(B, N, C, generator=gen)
+    wgt = torch.randn(B, N, C, generator=gen) * nm.float()             # loss weights (padded rows do not count)
+    # HIP operators
+    x = x0.clone().cuda().requires_grad_(True)
+    y0, bias, m_out = ghn.gnn[0](x, A.cuda(), mask.cuda())
+    y1 = ghn.gnn[1](y0, bias, m_out)
+    (y1 * wgt.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    # oracle + torch autograd
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in ghn.named_parameters() if k.startswith('gnn.')}
+    xo = x0.clone().requires_grad_(True)
+    z0, b0 = G.transformer_layer(xo, A, mask, p, 'gnn.0.', H, True)
+    z1, _ = G.transformer_layer(z0, b0, mask, p, 'gnn.1.', H, False)
+    (z1 * wgt).sum().backward()
+    assert rel_l2((y1.detach().cpu() * nm.float()).numpy(), (z1.detach() * nm.float()).numpy()) < 2e-5
+    valid = nm[:, :, 0]
+    assert rel_l2(x.grad.cpu()[valid].numpy(), xo.grad[valid].numpy()) < 5e-5
+    named = dict(ghn.named_parameters())
+    for k, v in p.items():
+        assert named[k].grad is not None, k
+        err = float((named[k].grad.cpu().double() - v.grad.double()).norm())
+        assert err < 1e-4 * float(v.grad.norm()) + 1e-6, (k, err, float(v.grad.norm()))
+
+
+@pytest.mark.parametrize('max_shape,class_pred', [((32, 32, 3, 3), False), ((16, 8, 1, 1), False), ((32, 20, 7, 5), False),
+                                                  ((10, 24, 1, 1), True)])
+def test_conv_decoder3_backward_matches_oracle_autograd(max_shape, class_pred):
+    """``ghn.decoder(x, max_shape, class_pred)`` is differentiable like the reference's module (nn.py:735-762): gradients
+    w.r.t. the node embeddings and the decoder parameters against torch autograd of the oracle."""
+    from oracle import ghn3_ref as R
+    hip, oracle = make_models(recipe.TINY_CFG, recipe.TINY_SEED)
+    C = recipe.TINY_CFG['hid']
+    gen = torch.Generator().manual_seed(11)
+    x0 = torch.randn(4, C, generator=gen)
+    x = x0.clone().cuda().requires_grad_(True)
+    out = hip.decoder(x, max_shape, class_pred)
+    wgt = torch.randn(out.shape, generator=gen)
+    (out * wgt.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    p = {k: v.detach().clone().requires_grad_(True) for k, v in oracle.named_parameters() if k.startswith('decoder.')}
+    xo = x0.clone().requires_grad_(True)
+    ref = R.conv_decoder3(xo, p, oracle.max_shape, max_shape, class_pred)
+    (ref * wgt).sum().backward()
+    assert rel_l2(out.detach().cpu().numpy(), ref.detach().numpy()) < 2e-5
+    assert rel_l2(x.grad.cpu().numpy(), xo.grad.numpy()) < 5e-5
+    named = dict(hip.named_parameters())
+    for k, v in p.items():
+        if v.grad is None:                                        # (the classifier head is unused without class_pred)
+            assert named[k].grad is None or float(named[k].grad.abs().sum()) == 0.0, k
+            continue
+        err = float((named[k].grad.cpu().double() - v.grad.double()).norm())
+        assert err < 1e-4 * float(v.grad.norm()) + 1e-6, (k, err, float(v.grad.norm()))

@@ -73,11 +73,42 @@ def test_trainer_skips_non_finite_steps():
     tr.update(images * float('nan'), targets, _batch(['resnet_tiny']))
     torch.cuda.synchronize()
     assert torch.equal(p, hip._flat) and torch.equal(m, tr._optimizer.exp_avg)
+    first_loss = None
     tr.log(0)
     assert tr.skipped_updates == 1
+    # the skipped step entered neither the sums nor the counts of the metrics, and did not advance the bias correction
+    avg = tr.metrics.avg()
+    assert np.isfinite(avg['loss']) and float(tr.metrics.cnt.item()) == 2.0          # (2 images x 1 network, one step)
+    assert tr._optimizer.steps == 1
     tr.update(images, targets, _batch(['resnet_tiny']))      # and training goes on
     torch.cuda.synchronize()
     assert not torch.equal(p, hip._flat) and torch.isfinite(hip._flat).all()
+    # a run of nothing but non-finite steps is an error, as in the reference (trainer.py:240-257 raises)
+    tr.log(1)
+    for _ in range(3):
+        tr.update(images * float('nan'), targets, _batch(['resnet_tiny']))
+    with pytest.raises(RuntimeError):
+        tr.log(2)
+
+
+def test_trainer_dynamic_loss_scale():
+    """AMP: GradScaler's rule on the device-side overflow flags -- 65536 at start, halved after a skipped (overflow) step,
+    doubled after amp_growth_interval clean steps, floored at amp_min_scale (trainer.py:346-379)."""
+    from ghn3_amd import Trainer
+    hip, _ = make_models(dict(recipe.TINY_CFG), recipe.TINY_SEED)
+    tr = Trainer(hip, 'adamw', {'lr': 1e-4}, 'cosine', n_batches=100, grad_clip=5, device='cuda', epochs=2, amp=True,
+                 amp_min_scale=1024, amp_growth_interval=4, amp_check_interval=2, log_interval=1000)
+    assert tr.loss_scale == 65536.0
+    images = torch.randn(2, 3, 32, 32)
+    targets = torch.tensor([1, 2])
+    tr.update(images, targets, _batch(['resnet_tiny']))
+    tr.update(images * float('inf'), targets, _batch(['resnet_tiny']))     # overflow -> skipped, scale halves at the check
+    assert tr.loss_scale == 32768.0 and tr.skipped_updates == 1
+    for _ in range(4):
+        tr.update(images, targets, _batch(['resnet_tiny']))
+    assert tr.loss_scale == 65536.0                                        # four clean steps: doubled
+    torch.cuda.synchronize()
+    assert torch.isfinite(hip._flat).all()
 
 
 def test_eval_ghn_counterpart_script():

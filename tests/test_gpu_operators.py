@@ -125,7 +125,10 @@ def test_transformer_layer_backward_matches_oracle_autograd():
     for k, v in p.items():
         assert named[k].grad is not None, k
         err = float((named[k].grad.cpu().double() - v.grad.double()).norm())
-        assert err < 1e-4 * float(v.grad.norm()) + 1e-6, (k, err, float(v.grad.norm()))
+        # (a constant added to every score of a softmax row changes nothing: the exact gradient of the last edge-MLP bias
+        # is zero, both sides hold rounding noise of the ~1e-1-sized terms that cancel)
+        atol = 1e-4 if k.endswith('proj_e.2.bias') else 1e-6
+        assert err < 1e-4 * float(v.grad.norm()) + atol, (k, err, float(v.grad.norm()))
 
 
 @pytest.mark.parametrize('max_shape,class_pred', [((32, 32, 3, 3), False), ((16, 8, 1, 1), False), ((32, 20, 7, 5), False),

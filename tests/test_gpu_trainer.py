@@ -64,7 +64,7 @@ def test_trainer_skips_non_finite_steps():
     replaces the reference's NaN-loss all-gather / skip (trainer.py:240-257)."""
     from ghn3_amd import Trainer
     hip, _ = make_models(dict(recipe.TINY_CFG), recipe.TINY_SEED)
-    tr = Trainer(hip, 'adamw', {'lr': 1e-3}, 'cosine', n_batches=10, grad_clip=5, device='cuda', epochs=2)
+    tr = Trainer(hip, 'adamw', {'lr': 1e-3}, 'cosine', n_batches=10, grad_clip=5, device='cuda', epochs=2, log_interval=1)
     images = torch.randn(2, 3, 32, 32)
     targets = torch.tensor([1, 2])
     tr.update(images, targets, _batch(['resnet_tiny']))
@@ -97,16 +97,19 @@ def test_trainer_dynamic_loss_scale():
     from ghn3_amd import Trainer
     hip, _ = make_models(dict(recipe.TINY_CFG), recipe.TINY_SEED)
     tr = Trainer(hip, 'adamw', {'lr': 1e-4}, 'cosine', n_batches=100, grad_clip=5, device='cuda', epochs=2, amp=True,
-                 amp_min_scale=1024, amp_growth_interval=4, amp_check_interval=2, log_interval=1000)
-    assert tr.loss_scale == 65536.0
+                 amp_init_scale=4096, amp_min_scale=64, amp_growth_interval=4, amp_check_interval=2, log_interval=1000)
+    import inspect
+    assert inspect.signature(Trainer.__init__).parameters['amp_init_scale'].default == 65536     # GradScaler's default
+    assert tr.loss_scale == 4096.0       # (a scale the tiny model's f16 gradients do not overflow at, so that only the
+    #                                       injected overflow below is skipped)
     images = torch.randn(2, 3, 32, 32)
     targets = torch.tensor([1, 2])
     tr.update(images, targets, _batch(['resnet_tiny']))
     tr.update(images * float('inf'), targets, _batch(['resnet_tiny']))     # overflow -> skipped, scale halves at the check
-    assert tr.loss_scale == 32768.0 and tr.skipped_updates == 1
+    assert tr.loss_scale == 2048.0 and tr.skipped_updates == 1
     for _ in range(4):
         tr.update(images, targets, _batch(['resnet_tiny']))
-    assert tr.loss_scale == 65536.0                                        # four clean steps: doubled
+    assert tr.loss_scale == 4096.0                                         # four clean steps: doubled
     torch.cuda.synchronize()
     assert torch.isfinite(hip._flat).all()
 

@@ -179,6 +179,15 @@ class Program:
                 self.bwd_parts.append((np.concatenate([self.bwd_ops[pos:end], detach]), slots))
                 pos = end
             self.bwd_parts.append((self.bwd_ops[pos:], []))
+            # Single-process order (bwd_ops; the parts above keep the early order so that a data-parallel run can start the
+            # exchange of dW2 -- 69 % of the gradient bytes -- as soon as possible): the W2 weight gradient is issued
+            # BEHIND the rest of the decoder backward.  The conv.0 / fc dgrads, the plane sums and the node-row gather are on
+            # the dependent chain and no longer share the chip with it (fc dgrad 0.39 -> 0.1 ms); the weight gradient then
+            # runs beside the Graphormer backward only, which is long enough to hide it (GHN3_WGRAD_LATE=0: early order).
+            if self.wgrad_op_range is not None and self.SIDE and os.environ.get('GHN3_WGRAD_LATE', '1') != '0':
+                a, b = self.wgrad_op_range
+                o = self.bwd_ops
+                self.bwd_ops = np.concatenate([o[:a], o[b:self.bwd_split], o[a:b], o[self.bwd_split:]])
         else:
             self.bwd_ops = np.zeros(0, dtype=L.OP_DT)
         self.problems = self._pack_problems()
@@ -1329,6 +1338,7 @@ class Program:
         self.grad_no_memset = []
         self.bwd_cut_w2 = 0
         late_ops = []
+        self.wgrad_op_range = None
 
         # K splits of the fc dgrad write separate planes of d_xrows (plane j at rows j * (M + n1) ..); the gather-sum that
         # folds decoder rows into node rows adds the planes in a fixed order (no atomics)
@@ -1653,9 +1663,11 @@ class Program:
                 # to the dependent chain on the main stream, which the faster kernel otherwise slows down by what it
                 # gained (step 8.51 ms with the old kernel, 8.56 with tile 25 on every CU, 8.46 at 224, 8.38 at 192 --
                 # but there the weight gradient is back at 1.49 ms).
+                n_before = len(self._ops)
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=True, flops=fl,
                              tile=int(os.environ.get('GHN3_WGRAD_TILE', '29')),
-                             grid_cap=int(os.environ.get('GHN3_WGRAD_CAP', '200')) if self.SIDE else 0)
+                             grid_cap=int(os.environ.get('GHN3_WGRAD_CAP', '224')) if self.SIDE else 0)
+                self.wgrad_op_range = (n_before, len(self._ops))
             fam_list = bands
             for gi, g in enumerate(self.gemm_groups):
                 if g['op16']:

@@ -651,6 +651,7 @@ __device__ __forceinline__ float norm_grad(float v, int mode, float scale) {
     return 0.2f * (1.f - th * th);
 }
 
+typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at dword alignment
 struct SrcTable { const float* p[6]; };
 struct DstTable { float* p[6]; };
 
@@ -701,31 +702,70 @@ __global__ __launch_bounds__(256) void tile_fwd_kernel(float* __restrict__ flat,
         const int n = ni * hw;
         const int S2 = (int)D->S[2], S3 = (int)D->S[3];
         const float inv_ni = 1.f / (float)ni, inv_t3 = 1.f / (float)T3;
-        constexpr int U = 8;                                  // loads in flight per thread
-        for (int b0 = threadIdx.x; b0 < n; b0 += 256 * U) {
-            float v[U];
-            int li[U];
+        // Both sides move 16 bytes per lane: four consecutive i of one kernel position on the source side (when the
+        // chunk, the strides and the base allow it), four consecutive target floats on the other (dword-aligned
+        // global_store_dwordx4: a tensor's o-row starts at any multiple of kh * kw floats).
+        const bool vec = E1 == T1 && (ni & 3) == 0 && (S2 & 3) == 0 && (S3 & 3) == 0 &&
+                         ((reinterpret_cast<uintptr_t>(src + i0)) & 15) == 0;
+        if (vec) {
+            const int ni4 = ni >> 2, n4 = ni4 * hw;
+            const float inv_ni4 = 1.f / (float)ni4;
+            constexpr int U = 4;
+            for (int b0 = threadIdx.x; b0 < n4; b0 += 256 * U) {
+                float4 v[U];
+                int li[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int idx = b0 + 256 * u;                  // (p, i) with i fastest: consecutive source floats
-                int pp = (int)((float)idx * inv_ni);
-                int i = idx - pp * ni;
-                if (i < 0) { i += ni; --pp; } else if (i >= ni) { i -= ni; ++pp; }
-                int y = (int)((float)pp * inv_t3);
-                int x = pp - y * T3;
-                if (x < 0) { x += T3; --y; } else if (x >= T3) { x -= T3; ++y; }
-                li[u] = i * hw + pp;
-                const int si = i0 + i;
-                v[u] = idx < n ? src[(int64_t)y * S2 + (int64_t)x * S3 + (E1 == T1 ? si : si % E1)] : 0.f;
+                for (int u = 0; u < U; ++u) {
+                    const int idx = b0 + 256 * u;              // (p, i / 4) with i fastest
+                    int pp = (int)((float)idx * inv_ni4);
+                    int i4 = idx - pp * ni4;
+                    if (i4 < 0) { i4 += ni4; --pp; } else if (i4 >= ni4) { i4 -= ni4; ++pp; }
+                    int y = (int)((float)pp * inv_t3);
+                    int x = pp - y * T3;
+                    if (x < 0) { x += T3; --y; } else if (x >= T3) { x -= T3; ++y; }
+                    li[u] = i4 * 4 * hw + pp;
+                    v[u] = idx < n4 ? *reinterpret_cast<const float4*>(src + (int64_t)y * S2 + (int64_t)x * S3 + i0 + i4 * 4)
+                                    : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (b0 + 256 * u < n4) {
+                        tl[li[u]] = v[u].x; tl[li[u] + hw] = v[u].y; tl[li[u] + 2 * hw] = v[u].z; tl[li[u] + 3 * hw] = v[u].w;
+                    }
             }
+        } else {
+            constexpr int U = 8;                                  // loads in flight per thread
+            for (int b0 = threadIdx.x; b0 < n; b0 += 256 * U) {
+                float v[U];
+                int li[U];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                if (b0 + 256 * u < n) tl[li[u]] = v[u];
+                for (int u = 0; u < U; ++u) {
+                    const int idx = b0 + 256 * u;                  // (p, i) with i fastest: consecutive source floats
+                    int pp = (int)((float)idx * inv_ni);
+                    int i = idx - pp * ni;
+                    if (i < 0) { i += ni; --pp; } else if (i >= ni) { i -= ni; ++pp; }
+                    int y = (int)((float)pp * inv_t3);
+                    int x = pp - y * T3;
+                    if (x < 0) { x += T3; --y; } else if (x >= T3) { x -= T3; ++y; }
+                    li[u] = i * hw + pp;
+                    const int si = i0 + i;
+                    v[u] = idx < n ? src[(int64_t)y * S2 + (int64_t)x * S3 + (E1 == T1 ? si : si % E1)] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < U; ++u)
+                    if (b0 + 256 * u < n) tl[li[u]] = v[u];
+            }
         }
         __syncthreads();
         float* dst = flat + D->dst_off + ((int64_t)a0 * T1 + i0) * hw;
         const float scale = D->scale;
-        for (int j = threadIdx.x; j < n; j += 256) dst[j] = tl[j] * scale;
+        const int nv = n & ~3;
+        for (int j = threadIdx.x * 4; j < nv; j += 1024) {
+            f4u o;
+            o.x = tl[j] * scale; o.y = tl[j + 1] * scale; o.z = tl[j + 2] * scale; o.w = tl[j + 3] * scale;
+            *reinterpret_cast<f4u*>(dst + j) = o;
+        }
+        for (int j = nv + threadIdx.x; j < n; j += 256) dst[j] = tl[j] * scale;
         return;
     }
     const int64_t di = di_raw;
@@ -793,41 +833,77 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
         const bool live = a0 < E0 && nl > 0;
         if (live) {
             const int n = nl * hw;
-            constexpr int U = 8;
-            for (int b0 = threadIdx.x; b0 < n; b0 += 256 * U) {
-                float acc[U];
+            constexpr int U = 4;                              // 16-byte loads in flight per thread (dword aligned)
+            for (int b0 = threadIdx.x * 4; b0 < n; b0 += 1024 * U) {
+                f4u acc[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) acc[u] = 0.f;
+                for (int u = 0; u < U; ++u) acc[u] = f4u{0.f, 0.f, 0.f, 0.f};
                 for (int t0 = a0; t0 < T0; t0 += E0)
                     for (int r0 = 0; r0 + i0 < T1; r0 += E1) {              // replicas along i
                         const int lim = min(nl, T1 - r0 - i0) * hw;          // a last partial replica covers fewer i
                         const float* gr = g + ((int64_t)t0 * T1 + r0 + i0) * hw;
 #pragma unroll
                         for (int u = 0; u < U; ++u) {
-                            const int j = b0 + 256 * u;
-                            if (j < lim) acc[u] += gr[j];
+                            const int j = b0 + 1024 * u;
+                            if (j + 4 <= lim) {
+                                acc[u] += *reinterpret_cast<const f4u*>(gr + j);
+                            } else {
+                                if (j < lim) acc[u].x += gr[j];
+                                if (j + 1 < lim) acc[u].y += gr[j + 1];
+                                if (j + 2 < lim) acc[u].z += gr[j + 2];
+                            }
                         }
                     }
 #pragma unroll
-                for (int u = 0; u < U; ++u)
-                    if (b0 + 256 * u < n) tl[b0 + 256 * u] = acc[u];
+                for (int u = 0; u < U; ++u) {
+                    const int j = b0 + 1024 * u;
+                    if (j + 4 <= n) {
+                        *reinterpret_cast<float4*>(tl + j) = make_float4(acc[u].x, acc[u].y, acc[u].z, acc[u].w);
+                    } else {
+                        if (j < n) tl[j] = acc[u].x;
+                        if (j + 1 < n) tl[j + 1] = acc[u].y;
+                        if (j + 2 < n) tl[j + 2] = acc[u].z;
+                    }
+                }
             }
             __syncthreads();
         }
         const float scale = D->scale;
         const int S2 = (int)D->S[2], S3 = (int)D->S[3];
-        const float inv_ni = 1.f / (float)ni, inv_t3 = 1.f / (float)T3;
-        const int nw = ni * hw;
-        for (int idx = threadIdx.x; idx < nw; idx += 256) {    // (p, i) with i fastest: consecutive source floats
-            int pp = (int)((float)idx * inv_ni);
-            int i = idx - pp * ni;
-            if (i < 0) { i += ni; --pp; } else if (i >= ni) { i -= ni; ++pp; }
-            int y = (int)((float)pp * inv_t3);
-            int x = pp - y * T3;
-            if (x < 0) { x += T3; --y; } else if (x >= T3) { x -= T3; ++y; }
-            const float val = (live && i < nl) ? tl[i * hw + pp] * scale : 0.f;
-            dsrc[(int64_t)y * S2 + (int64_t)x * S3 + i] = val;
-            mx = fmaxf(mx, fabsf(val));
+        const float inv_t3 = 1.f / (float)T3;
+        if ((ni & 3) == 0 && (S2 & 3) == 0 && (S3 & 3) == 0 && (reinterpret_cast<uintptr_t>(dsrc) & 15) == 0) {
+            const int ni4 = ni >> 2, nw4 = ni4 * hw;
+            const float inv_ni4 = 1.f / (float)ni4;
+            for (int idx = threadIdx.x; idx < nw4; idx += 256) {    // (p, i / 4) with i fastest: 16 bytes per lane
+                int pp = (int)((float)idx * inv_ni4);
+                int i4 = idx - pp * ni4;
+                if (i4 < 0) { i4 += ni4; --pp; } else if (i4 >= ni4) { i4 -= ni4; ++pp; }
+                int y = (int)((float)pp * inv_t3);
+                int x = pp - y * T3;
+                if (x < 0) { x += T3; --y; } else if (x >= T3) { x -= T3; ++y; }
+                const int i = i4 * 4;
+                float4 val;
+                val.x = (live && i < nl) ? tl[i * hw + pp] * scale : 0.f;
+                val.y = (live && i + 1 < nl) ? tl[(i + 1) * hw + pp] * scale : 0.f;
+                val.z = (live && i + 2 < nl) ? tl[(i + 2) * hw + pp] * scale : 0.f;
+                val.w = (live && i + 3 < nl) ? tl[(i + 3) * hw + pp] * scale : 0.f;
+                *reinterpret_cast<float4*>(dsrc + (int64_t)y * S2 + (int64_t)x * S3 + i) = val;
+                mx = fmaxf(fmaxf(mx, fmaxf(fabsf(val.x), fabsf(val.y))), fmaxf(fabsf(val.z), fabsf(val.w)));
+            }
+        } else {
+            const float inv_ni = 1.f / (float)ni;
+            const int nw = ni * hw;
+            for (int idx = threadIdx.x; idx < nw; idx += 256) {    // (p, i) with i fastest: consecutive source floats
+                int pp = (int)((float)idx * inv_ni);
+                int i = idx - pp * ni;
+                if (i < 0) { i += ni; --pp; } else if (i >= ni) { i -= ni; ++pp; }
+                int y = (int)((float)pp * inv_t3);
+                int x = pp - y * T3;
+                if (x < 0) { x += T3; --y; } else if (x >= T3) { x -= T3; ++y; }
+                const float val = (live && i < nl) ? tl[i * hw + pp] * scale : 0.f;
+                dsrc[(int64_t)y * S2 + (int64_t)x * S3 + i] = val;
+                mx = fmaxf(mx, fabsf(val));
+            }
         }
         if (amax && D->src_buf == 0) ghn3_atomic_amax(amax, mx);
         return;

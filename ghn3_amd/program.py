@@ -1240,7 +1240,9 @@ class Program:
             # chunk of `ich` input channels (<= 16 KB of LDS, so that many blocks share a CU)
             row_ok = (mode == 0) & (hw > 1) & (S[:, 1] == 1) & (E[:, 2] == T[:, 2]) & (T[:, 2] == R[:, 2]) & \
                 (E[:, 3] == T[:, 3]) & (T[:, 3] == R[:, 3]) & (hw <= 1024)
-            ich = np.maximum(16, np.minimum(np.maximum(T[:, 1], R[:, 1]), 4096 // np.maximum(hw, 1)))
+            # (a multiple of 16 channels unless the tensor has fewer: the row blocks move 16 bytes per lane when the chunk is
+            # a multiple of 4 floats)
+            ich = np.maximum(16, np.minimum(np.maximum(T[:, 1], R[:, 1]), (4096 // np.maximum(hw, 1)) // 16 * 16))
             desc_arr['_pad'] = np.where(row_ok, ich, 0)
             if row_ok.any():
                 lds = int((4 * ich * hw)[row_ok].max())

@@ -1,6 +1,3 @@
 B="python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras"
 sel='import sys,json; d=json.loads(sys.stdin.read().strip().split("\n")[-1]); k=d["roofline"].get("kernels",{}); print(sys.argv[1], round(d["ms_per_step"],3), round(d["roofline"]["frac"],4), {a:k[a]["ms_per_step"] for a in k})'
-for cap in 208 224 232 240; do
-GHN3_WGRAD_CAP=$cap $B 2>/dev/null | python -c "$sel" late1_cap$cap
-done
-GHN3_WGRAD_LATE=0 GHN3_WGRAD_CAP=200 $B 2>/dev/null | python -c "$sel" late0_cap200
+$B 2>/dev/null | python -c "$sel" vec_tiles

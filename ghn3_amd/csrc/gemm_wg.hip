@@ -1,0 +1,188 @@
+// Split-bf16 weight-gradient GEMM for gfx950 (tile code 48): C[M x N] (+)= alpha * sum_k A[k][m] * B[k][n].
+//
+// Replaces the autograd weight gradients of the Graphormer linears (/root/reference/ghn3/graphormer.py:208-248: to_qkv,
+// to_out, ff.net.0, ff.net.3; dW = dY^T X) and their fused bias gradients (db = column sums of dY).  Both operands are
+// fp32 activations [rows][features] in HBM, the reduction runs over ROWS (k-strided operands: GHN3_MODE_COL / GHN3_MODE_COL),
+// K = B * N nodes (256 for the bench workload), so there is no k-contiguous copy to DMA from.  Rounds 1-2 ran these on the
+// exact-fp32 matrix instruction (v_mfma_f32_32x32x2_f32, 64 x 64 tiles of the generic kernel): 30 us per layer alone,
+// 0.9 ms per step on the side stream beside the dependent chain.  Here
+//   * a workgroup (4 waves, 2 x 2) owns a 64 x 64 tile of C and walks K in chunks of 64 rows;
+//   * a chunk of A [64 k][64 m] and of B [64 k][64 n] is read with coalesced 16-byte loads (a lane: 4 consecutive features
+//     of TWO consecutive rows), split into bf16 hi = bf16(x), lo = bf16(x - hi) and written TRANSPOSED into LDS as
+//     [feature][k] images (a pair of rows -> one ds_write_b32), 128-byte rows, 16-byte slot s of row r holds k chunk
+//     s ^ ((r >> 1) & 7): the fragment reads of v_mfma_f32_16x16x32_bf16 are conflict-free ds_read_b128;
+//   * products hi*hi + hi*lo + lo*hi (fp32 accumulate, the cross terms in their own accumulator): ~8e-6 relative, as the
+//     split-bf16 linears of the chain (gemm_x3.hip);
+//   * the loads of chunk c + 1 are issued before the MFMAs of chunk c (register prefetch, one LDS stage of 32 KB: several
+//     workgroups per CU hide each other's staging);
+//   * the products are taken transposed (B fragment first), a lane owns 4 consecutive columns of a row: float4 epilogue with
+//     optional accumulate; the workgroups of column tile 0 also reduce their A chunks over k: the bias gradient, one writer
+//     per element (deterministic).
+// Contract (host-checked, runtime.hip): fp32 operands, COL / COL modes, no gathers / maps / activation / residual / split-K,
+// M % 4 == 0, N % 4 == 0, lda / ldb / ldc % 4 == 0, 16-byte aligned bases.
+
+#include "ghn3_internal.h"
+
+#define GAS __attribute__((address_space(1)))
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef f32x4 GAS* gf4;
+typedef const f32x4 GAS* gcf4;
+
+namespace {
+
+constexpr int WG_BM = 64, WG_BN = 64, WG_KC = 64;
+constexpr int WG_LDS = 4 * 64 * 128 + 16 * 64 * 4;       // A hi | A lo | B hi | B lo images + bias-gradient partials
+
+__device__ __forceinline__ unsigned wg_pack(__bf16 a, __bf16 b) {
+    return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+// rows k, k + 1 of 4 consecutive features -> hi / lo pairs at [feature f .. f + 3][k, k + 1] of the transposed images
+__device__ __forceinline__ void wg_stage(char* s_hi, char* s_lo, int f, int k, const f32x4& r0, const f32x4& r1) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const __bf16 h0 = (__bf16)r0[e], h1 = (__bf16)r1[e];
+        const __bf16 l0 = (__bf16)(r0[e] - (float)h0), l1 = (__bf16)(r1[e] - (float)h1);
+        const int row = f + e;
+        const int off = row * 128 + (((k >> 3) ^ ((row >> 1) & 7)) << 4) + ((k & 7) << 1);
+        *reinterpret_cast<unsigned*>(s_hi + off) = wg_pack(h0, h1);
+        *reinterpret_cast<unsigned*>(s_lo + off) = wg_pack(l0, l1);
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_wg_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
+    __shared__ __attribute__((aligned(16))) char sm[WG_LDS];
+    char* sAh = sm;
+    char* sAl = sm + 64 * 128;
+    char* sBh = sm + 2 * 64 * 128;
+    char* sBl = sm + 3 * 64 * 128;
+    float* sbias = reinterpret_cast<float*>(sm + 4 * 64 * 128);
+
+    int lo = 0, hi_ = n_probs - 1;
+    while (lo < hi_) {
+        const int mid = (lo + hi_ + 1) >> 1;
+        if (probs[mid].tile_start <= (int)blockIdx.x) lo = mid; else hi_ = mid - 1;
+    }
+    const GemmProbDev* P = probs + lo;
+    const int t_id = blockIdx.x - P->tile_start;
+    const int n0 = (t_id % P->tiles_n) * WG_BN, m0 = (t_id / P->tiles_n) * WG_BM;
+    const int M = P->M, N = P->N, K = P->K, lda = P->lda, ldb = P->ldb;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, lq = lane >> 4;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const bool want_bias = (P->flags & GHN3_GEMM_BIASGRAD) && n0 == 0;
+
+    // staging role: features 4 f4 .. 4 f4 + 3, rows 2 kp + 32 i + {0, 1} of the chunk (i = 0, 1)
+    const int f4 = (tid & 15) * 4, kp = tid >> 4;
+    const float GAS* Ag = (const float GAS*)P->A;
+    const float GAS* Bg = (const float GAS*)P->B;
+    const bool a_in = m0 + f4 < M, b_in = n0 + f4 < N;       // (M % 4 == 0, N % 4 == 0: a float4 is inside or outside)
+    const f32x4 zero = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 ra[2][2], rb[2][2];
+    auto load_chunk = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 2; ++r) {
+                const int k = k0 + 2 * kp + 32 * i + r;
+                ra[i][r] = (a_in && k < K) ? *reinterpret_cast<gcf4>(Ag + (int64_t)k * lda + m0 + f4) : zero;
+                rb[i][r] = (b_in && k < K) ? *reinterpret_cast<gcf4>(Bg + (int64_t)k * ldb + n0 + f4) : zero;
+            }
+    };
+
+    f32x4 acc0[2][2], acc1[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { acc0[i][j] = zero; acc1[i][j] = zero; }
+    f32x4 bsum = zero;
+
+    load_chunk(0);
+    for (int k0 = 0; k0 < K; k0 += WG_KC) {
+        if (k0 > 0) __syncthreads();                      // the fragment reads of the previous chunk are done
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            wg_stage(sAh, sAl, f4, 2 * kp + 32 * i, ra[i][0], ra[i][1]);
+            wg_stage(sBh, sBl, f4, 2 * kp + 32 * i, rb[i][0], rb[i][1]);
+            if (want_bias) bsum += ra[i][0] + ra[i][1];
+        }
+        if (k0 + WG_KC < K) load_chunk(k0 + WG_KC);       // in flight during this chunk's products
+        __syncthreads();
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ch = 4 * h + lq;
+            bf16x8 xh[2], xl[2], wh[2], wl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int row = wm0 + 16 * i + l15;
+                const int off = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+                xh[i] = *reinterpret_cast<const bf16x8*>(sAh + off);
+                xl[i] = *reinterpret_cast<const bf16x8*>(sAl + off);
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int row = wn0 + 16 * j + l15;
+                const int off = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
+                wh[j] = *reinterpret_cast<const bf16x8*>(sBh + off);
+                wl[j] = *reinterpret_cast<const bf16x8*>(sBl + off);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xh[i], acc0[i][j], 0, 0, 0);
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xl[i], acc1[i][j], 0, 0, 0);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], xh[i], acc1[i][j], 0, 0, 0);
+        }
+    }
+
+    // ---- epilogue: lane owns C[m][n .. n + 3], m = tile row l15, n = 4 lq
+    const float alpha = P->alpha;
+    const bool accum = (P->flags & GHN3_GEMM_ACCUM) != 0;
+    float GAS* C = (float GAS*)P->C;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = m0 + wm0 + 16 * i + l15;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int n = n0 + wn0 + 16 * j + 4 * lq;
+            if (m >= M || n >= N) continue;
+            const int64_t ci = (int64_t)m * P->ldc + n;
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (acc0[i][j][e] + acc1[i][j][e]) * alpha;
+            if (accum) v += *reinterpret_cast<gcf4>(C + ci);
+            *reinterpret_cast<gf4>(C + ci) = v;
+        }
+    }
+    // ---- bias gradient: db[m] += sum_k A[k][m] -- the 16 row-pair owners of a feature add up in a fixed order
+    if (want_bias) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sbias[kp * 64 + f4 + e] = bsum[e];
+        __syncthreads();
+        if (tid < 64 && m0 + tid < M) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) t += sbias[q * 64 + tid];
+            float GAS* db = (float GAS*)P->bias + (int64_t)(m0 + tid) * P->bias_stride;
+            *db += t;                                       // (the bias gradient always accumulates, ghn3_hip.h)
+        }
+    }
+}
+
+}  // namespace
+
+int ghn3_gemm_wg_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, hipStream_t stream) {
+    if (n_probs <= 0 || total_tiles <= 0) return GHN3_OK;
+    hipLaunchKernelGGL(gemm_wg_kernel, dim3(total_tiles), dim3(256), 0, stream, d_probs, n_probs);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ghn3_set_error("wgrad x3 gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
+    return GHN3_OK;
+}

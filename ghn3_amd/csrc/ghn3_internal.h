@@ -53,6 +53,7 @@ int ghn3_gemm_x3_init();
 int ghn3_gemm_x3_tile(int code, int slice, int* bm, int* bn);
 int ghn3_gemm_x3_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int code, int slice,
                         hipStream_t stream);
+int ghn3_gemm_wg_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, hipStream_t stream);
 int ghn3_gemm_small_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode, int with_ln,
                            hipStream_t stream);
 

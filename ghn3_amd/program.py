@@ -1906,7 +1906,7 @@ class Program:
             # 64 x 64 fp32 tiles (432 per launch) instead of the small-problem kernel: 8.47 -> 8.41 ms per step.  (Without
             # these launches the step is 8.14 ms: the bound on what a faster weight-gradient path could gain; 16-bit
             # operands converted in the kernel are slower and bf16 misses the gradient gate.)
-            self.gemm_op(p0, side=True, tile=int(os.environ.get('GHN3_LAYER_WGRAD_TILE', '64' if C >= 256 else '0')))
+            self.gemm_op(p0, side=True, tile=int(os.environ.get('GHN3_LAYER_WGRAD_TILE', ('48' if self.x3 else '64') if C >= 256 else '0')))
             self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln1.weight'), self.gref(pre + 'ln1.bias'), dhB, x_in,
                                               m1, r1), ints=(rows, C, 1), flags=self.SIDE)
             side_pending, self._ops = side_pending + self._ops, main_ops

@@ -154,6 +154,19 @@ CASES += [
     dict(M=1100, N=1300, K=64, a_mode=L.MODE_ROW, b_mode=L.MODE_ROW, tile=128),
     dict(M=40, N=2100, K=40, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, tile=64),
 ]
+# split-bf16 weight-gradient kernel (tile code 48, gemm_wg.hip): fp32 activations reduced over rows (COL / COL), fused bias
+# gradient, accumulate; Graphormer shapes of ghn3xlm16 / ghn3tm8, ragged M / N (multiples of 4), K tails, a problem the kernel
+# cannot take (N % 4 != 0: falls back to the exact 64 x 64 tiles)
+WG_CASES = [
+    dict(M=384, N=1536, K=256, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=48, epilogue='biasgrad', accum=True),
+    dict(M=1152, N=384, K=256, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=48, accum=True),
+    dict(M=1536, N=384, K=512, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=48, epilogue='biasgrad'),
+    dict(M=64, N=256, K=128, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=48, epilogue='biasgrad'),
+    dict(M=100, N=76, K=300, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=48, epilogue='biasgrad', accum=True),
+    dict(M=4, N=8, K=1, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=48),
+    dict(M=132, N=72, K=33, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=48),
+    dict(M=130, N=70, K=33, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=48, epilogue='biasgrad'),
+]
 # the 32x32 split-K-in-workgroup kernel (tile code 32), every addressing mode and epilogue
 for a_mode in (L.MODE_ROW, L.MODE_COL):
     for b_mode in (L.MODE_ROW, L.MODE_COL):

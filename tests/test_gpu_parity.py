@@ -43,6 +43,19 @@ def test_gemm_cases(ctx, ctype, tol):
             assert rel_l2(extra[0], extra[1]) < tol, ('aux_out', case)
 
 
+def test_split_bf16_weight_gradient_gemm_cases(ctx):
+    """Tile code 48 (gemm_wg.hip): dW = dY^T X with both operands fp32 activations reduced over rows, as split-bf16 products;
+    fused bias gradient and accumulate; tolerance = the dropped lo.lo term, as for the split-bf16 linears."""
+    from gemm_cases import WG_CASES, run_gemm_case
+    for k, case in enumerate(WG_CASES):
+        got, exp, extra = run_gemm_case(ctx, ctype=0, seed=100 + k, **case)
+        assert np.isfinite(got).all(), case
+        err = rel_l2(got, exp)
+        assert err < 3e-5, (case, err)
+        if extra is not None:
+            assert rel_l2(extra[0], extra[1]) < 2e-6, ('bias gradient', case, rel_l2(extra[0], extra[1]))
+
+
 def test_layernorm_row_prologue_of_the_small_gemm(ctx):
     """ghn3_gemm_problem::ln_kind: LayerNorm forward / backward applied to the A rows while they are staged (exact
     fp32): products and by-products (normalised rows, mean, rstd) against fp64 numpy."""

@@ -14,7 +14,8 @@ from .ddp_utils import (setup_ddp, is_ddp, get_ddp_rank, clean_ddp, avg_ddp_metr
 from .optim import FusedAdamW, save_checkpoint
 from .trainer import Trainer
 from .ops import Network, NetworkLight
+from .deepnets1m import DeepNets1MDDP, NetBatchSamplerDDP
 
 __all__ = ['Graph', 'GraphBatch', 'from_pretrained', 'GHN3', 'ConvDecoder3', 'SequentialMultipleInOut', 'log', 'Logger', 'print_grads', 'norm_check', 'get_metadata',
            'setup_ddp', 'is_ddp', 'get_ddp_rank', 'clean_ddp', 'avg_ddp_metric', 'all_reduce_flat_grads', 'sync_parameters', 'FusedAdamW', 'save_checkpoint', 'Trainer',
-           'Network', 'NetworkLight']
+           'Network', 'NetworkLight', 'DeepNets1MDDP', 'NetBatchSamplerDDP']

@@ -135,3 +135,96 @@ class SampledNets:
                 yield GraphBatch([nets[base + k] for k in range(per_rank)], dense=True)
                 step += 1
         return generate()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The reference's names for the same roles (ghn3/__init__.py:13, deepnets1m.py:29-79,281-319)
+# ---------------------------------------------------------------------------------------------------------------------
+MAX_NODES_BATCH = 2200          # ppuda.deepnets1m.loader.MAX_NODES_BATCH (published value; the package is not in this image)
+
+
+class DeepNets1MDDP(SampledNets, torch.utils.data.Dataset):
+    """``DeepNets1MDDP`` of deepnets1m.py:29-79 over the sampled architecture stream: same ``loader`` contract -- a training
+    loader comes with its (infinite, rank-aware) batch sampler, an evaluation loader alone; items are ``Graph`` objects with
+    ``.net`` / ``.net_args`` / ``.net_idx``, batches are ``GraphBatch`` objects.  The arguments that name DeepNets-1M files
+    (``nets_dir``, ``split`` other than train / val / test ...) are accepted and only select the stream's seed: there is no
+    json / hdf5 file to read here."""
+
+    def __init__(self, split='train', nets_dir=None, virtual_edges=50, num_nets=None, large_images=False, dense=True,
+                 wider_nets=True, debug=False, verbose=False, seed=None, max_nodes=1000, light=True, **unused):
+        assert dense, 'GHN-3 uses the dense layout'
+        self.split, self.is_train, self.dense, self.wider_nets, self.debug = split, split == 'train', dense, wider_nets, debug
+        if seed is None:                                        # disjoint streams per split
+            seed = {'train': 0, 'val': 1, 'test': 2}.get(split, 3)
+        if num_nets is None:
+            num_nets = 10 ** 6 if self.is_train else 500
+        SampledNets.__init__(self, num_nets=num_nets, large_images=large_images, seed=seed, virtual_edges=virtual_edges,
+                             max_nodes=max_nodes, light=light, verbose=verbose)
+        self._nodes = {}                                        # node counts of the graphs built so far (check_batch)
+
+    def __getitem__(self, idx):
+        g = SampledNets.__getitem__(self, idx)
+        self._nodes[int(idx)] = int(g.n_nodes)
+        return g
+
+    @staticmethod
+    def loader(meta_batch_size=1, dense=True, num_workers=None, **kwargs):
+        from functools import partial
+        nets = DeepNets1MDDP(dense=dense, **kwargs)
+        sampler = NetBatchSamplerDDP(nets, meta_batch_size) if nets.is_train else None
+        if num_workers is None:                                 # (deepnets1m.py:74)
+            num_workers = (0 if meta_batch_size <= 1 else min(8, max(4, meta_batch_size // 2))) if nets.is_train else 0
+        loader = torch.utils.data.DataLoader(nets, batch_sampler=sampler, batch_size=1, pin_memory=False,
+                                             collate_fn=partial(GraphBatch, dense=dense), num_workers=num_workers)
+        return (loader, sampler) if nets.is_train else loader   # (the sampler is returned for distributed training)
+
+
+class NetBatchSamplerDDP(torch.utils.data.BatchSampler):
+    """deepnets1m.py:281-319: endless sampler of meta-batches.  Every epoch is a permutation of the dataset drawn from
+    (seed, epoch) -- the same on all ranks -- of which rank r takes the indices r, r + W, r + 2 W ... (DistributedSampler's
+    rule, padded by wrapping around to a multiple of the world size), so the ranks train on disjoint architectures;
+    meta-batches whose graphs are known to hold more than ``max_nodes_batch`` nodes are skipped."""
+
+    def __init__(self, deepnets, meta_batch_size=1, seed=0):
+        from .ddp_utils import is_ddp, get_ddp_rank
+        self.dataset, self.batch_size, self.drop_last, self.seed = deepnets, int(meta_batch_size), False, int(seed)
+        self.rank, self.world = (get_ddp_rank(), torch.distributed.get_world_size()) if is_ddp() else (0, 1)
+        self.max_nodes_batch = int(MAX_NODES_BATCH / 8 * max(8, meta_batch_size)) \
+            if deepnets.is_train and meta_batch_size > 1 else None
+        self.epoch = 0
+
+    def set_epoch(self, epoch):
+        self.epoch = int(epoch)
+
+    def epoch_indices(self, epoch):
+        n = len(self.dataset)
+        if self.dataset.is_train:
+            perm = np.random.RandomState((self.seed * 7919 + epoch) % (2 ** 31 - 1)).permutation(n)
+        else:
+            perm = np.arange(n)
+        total = (n + self.world - 1) // self.world * self.world
+        perm = np.concatenate([perm, perm[:total - n]])
+        return perm[self.rank:total:self.world]
+
+    def check_batch(self, batch):
+        known = getattr(self.dataset, '_nodes', {})
+        return self.max_nodes_batch is None or sum(known.get(int(i), 0) for i in batch) <= self.max_nodes_batch
+
+    def __len__(self):
+        return (len(self.dataset) // self.world + self.batch_size - 1) // self.batch_size
+
+    def __iter__(self):
+        epoch = self.epoch
+        while True:                                             # infinite sampler
+            batch = []
+            for idx in self.epoch_indices(epoch):
+                batch.append(int(idx))
+                if len(batch) == self.batch_size:
+                    if self.check_batch(batch):
+                        yield batch
+                    batch = []
+            if len(batch) > 0 and not self.drop_last and self.check_batch(batch):
+                yield batch
+            epoch += 1
+            if not self.dataset.is_train:
+                return

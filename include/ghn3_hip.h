@@ -217,7 +217,11 @@ enum ghn3_op_kind {
      * optional row map of C: short K, e.g. the W2 weight gradient) / 28 = the 8-phase kernel, (192 | 256 | 320) x 256 tiles,
      * no split-K / gathers (problems of the op with fewer than 160 rows or with ksplit > 1 fall back to 16) for
      * GHN3_GEMM_OP16 problems), grid cap for GHN3_GEMM_OP16 launches (0 = one workgroup per tile; > 0: at most
-     * that many CUs' worth of persistent workgroups -- a side-stream GEMM that should leave CUs to the chain it runs beside) */
+     * that many CUs' worth of persistent workgroups -- a side-stream GEMM that should leave CUs to the chain it runs beside).
+     * fp32 operands additionally: 48 = the split-bf16 weight-gradient kernel (both operands GHN3_MODE_COL fp32 activations,
+     * reduction over rows: dW = dY^T X of the Graphormer linears, graphormer.py:208-248 backward; GHN3_GEMM_ACCUM and
+     * GHN3_GEMM_BIASGRAD allowed, M % 4 == 0, N % 4 == 0, no gathers / maps / activation / residual / split-K -- problems of
+     * the op that do not qualify run on the exact 64 x 64 tiles; ~8e-6 relative like GHN3_GEMM_X3) */
     GHN3_OP_GEMM = 1,                 /* every nn.Linear / F.linear on the path */
     /* graphormer.py:229-237 -- degree counts of A==1, A[0,:], fw/bw pair index
      * r0=A(int64 B,N,N) r1=deg_in r2=deg_out r3=dist0 (int32 B,N) r4=pair (int32 B,N,N); i: B,N,V */

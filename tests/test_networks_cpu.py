@@ -192,3 +192,32 @@ def test_sampled_nets_loader_and_oracle_ghn():
         assert logits.shape == (2, 10) and torch.isfinite(logits).all()
     logits.square().mean().backward()
     assert sum(float(p.grad.abs().sum()) > 0 for p in oracle.parameters() if p.grad is not None) > 10
+
+
+def test_deepnets1m_ddp_names():
+    """`DeepNets1MDDP.loader` / `NetBatchSamplerDDP` (ghn3/__init__.py:13, deepnets1m.py:71-79,281-319): the training loader
+    returns (loader, sampler), batches are GraphBatch objects with light networks, the sampler is endless, reshuffles per
+    epoch with the same permutation on every rank and gives the ranks disjoint indices; the evaluation loader comes alone
+    and is finite."""
+    import itertools
+    from ghn3_amd import DeepNets1MDDP, NetBatchSamplerDDP, GraphBatch
+    loader, sampler = DeepNets1MDDP.loader(meta_batch_size=2, split='train', num_nets=12, max_nodes=120, num_workers=0)
+    assert isinstance(sampler, NetBatchSamplerDDP) and sampler.max_nodes_batch == 2200
+    batches = list(itertools.islice(iter(sampler), 14))                 # 6 per epoch: crosses two epoch boundaries
+    assert all(len(b) == 2 for b in batches)
+    e0, e1 = sum(batches[:6], []), sum(batches[6:12], [])
+    assert sorted(e0) == list(range(12)) and sorted(e1) == list(range(12)) and e0 != e1
+    gb = next(iter(loader))
+    assert isinstance(gb, GraphBatch) and len(gb.nets) == 2 and gb.net_inds == batches[0]
+    assert all(type(n).__name__ == 'NetworkLight' for n in gb.nets)
+    # rank slices of one epoch: disjoint, together the whole permutation
+    s0, s1 = NetBatchSamplerDDP(loader.dataset, 2), NetBatchSamplerDDP(loader.dataset, 2)
+    s0.rank, s0.world, s1.rank, s1.world = 0, 2, 1, 2
+    i0, i1 = s0.epoch_indices(3), s1.epoch_indices(3)
+    assert len(i0) == len(i1) == 6 and sorted(np.concatenate([i0, i1]).tolist()) == list(range(12))
+    # a batch known to exceed the node budget is skipped
+    s0.max_nodes_batch = 10
+    loader.dataset._nodes.update({int(i): 100 for i in i0})
+    assert not s0.check_batch(list(i0[:2]))
+    ev = DeepNets1MDDP.loader(meta_batch_size=1, split='val', num_nets=3, max_nodes=120)
+    assert not isinstance(ev, tuple) and len(list(ev)) == 3

@@ -43,14 +43,39 @@ def model_cfg(name):
                 weight_norm=True, ve=True, layernorm=True)
 
 
+def usable_cores():
+    """CPUs this process may really use: the affinity mask capped by the cgroup's CPU quota (the GPU boxes show 256 logical
+    CPUs behind a quota of 16: more runnable threads than that are throttled, not run)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 4
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as fh:
+            quota, period = fh.read().split()[:2]
+        if quota != 'max':
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            with open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us') as fq, open('/sys/fs/cgroup/cpu/cpu.cfs_period_us') as fp:
+                q, per = int(fq.read()), int(fp.read())
+            if q > 0:
+                n = max(1, min(n, q // per))
+        except (OSError, ValueError):
+            pass
+    return n
+
+
 def cpu_baseline(model, sample_nodes, seed, graphs=1):
     """Oracle (CPU restatement of the reference algorithm incl. its per-group Python loops) timed on the host, by default
     on the SAME seeded graph(s) the GPU ran (one step: ~20-40 s at ghn3xlm16 / 256 nodes)."""
     from oracle import ghn3_ref as R
     from ghn3_amd.synthetic import synthetic_batch
-    # torch's CPU GEMMs stop scaling (and the many small per-group ops get slower) beyond a few dozen threads;
-    # 256 threads measured 168 s per step where 16 take a fraction of it, so the baseline uses <= 16 threads.
-    cores = min(os.cpu_count() or 1, int(os.environ.get('GHN3_CPU_THREADS', '16')))
+    # Threads = the CPUs this container may really use (GPU boxes: 256 logical CPUs behind a cgroup quota of 16; measured
+    # once on such a box, profiles/r03n_cpu_baseline_threads_256_64_16.txt: 16 threads 26.1 s per step, 64 threads 39.6 s,
+    # 256 threads 581 s -- threads beyond the quota are throttled), at most GHN3_CPU_THREADS (default 16: torch's CPU GEMMs
+    # stop scaling and the many small per-group ops get slower beyond a few dozen threads anyway).
+    cores = max(1, min(usable_cores(), int(os.environ.get('GHN3_CPU_THREADS', '16'))))
     torch.set_num_threads(cores)
     torch.manual_seed(0)
     oracle = R.GHN3Ref(**model_cfg(model))
@@ -74,7 +99,7 @@ def cpu_baseline(model, sample_nodes, seed, graphs=1):
             times.append(time.time() - t0)
     t = float(np.median(times))
     return {'value': n_pred / t, 'unit': 'predicted-params/s', 'cores': cores, 'kind': 'port',
-            'host_cpus': os.cpu_count(),
+            'host_cpus': os.cpu_count(), 'usable_cpus': usable_cores(),
             'sample': '%s fwd+bwd (sum of Frobenius norms loss), %d synthetic %d-node graph(s), seed %d (%d predicted '
                       'params), fp32, torch %s CPU ops, %d threads, %.1f s per step (%d run%s)'
                       % (model, graphs, sample_nodes, seed, n_pred, torch.__version__, cores, t, len(times),
@@ -165,18 +190,20 @@ def main():
                          '--nproc-per-node %d ... bench.py --gpus %d) or drop RANK/WORLD_SIZE from the environment'
                          % (args.gpus, world, args.gpus, args.gpus))
     import torch.distributed as dist
+    # host-side torch ops of this process (unpickled graph tensors, pinned staging): ONE thread -- torch's default
+    # is one per LOGICAL CPU (256 on the GPU boxes, behind a cgroup quota of 16: a spinning OpenMP pool of that size gets the
+    # whole process throttled).  cpu_baseline() sets its own count.
+    torch.set_num_threads(int(os.environ.get('GHN3_HOST_THREADS', '1')))     # (4 threads measured 9.2 vs 7.4 ms per fresh step)
     pool = None
     if world == 1 and not args.no_extras and not args.force_ddp:
         import multiprocessing as mp                     # loader workers: started before ANY torch.cuda call of this process
         for var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):
-            os.environ.setdefault(var, '4')              # (inherited by the workers: no 256-thread pools per worker)
+            os.environ.setdefault(var, '1')              # (inherited by the workers: the host half of the compile is
+            #                                              single-threaded numpy; 4 threads each measured 9.2 vs 7.4 ms per step)
         # a worker needs ~10 ms of CPU per architecture (graph + host half of the compile) and the GPU consumes one every
         # ~7.5 ms: three busy workers keep up.  More workers than spare cores only take the cores the enqueue thread of
         # this process needs (the driver's box of round 2: 8 workers, enqueue 14 ms per step instead of 3)
-        try:
-            n_cores = len(os.sched_getaffinity(0))
-        except AttributeError:
-            n_cores = os.cpu_count() or 4
+        n_cores = usable_cores()
         n_workers = int(os.environ.get('GHN3_LOADER_WORKERS', str(max(2, min(6, n_cores // 2 - 1)))))
         pool = mp.get_context('spawn').Pool(n_workers)
     if not torch.cuda.is_available():

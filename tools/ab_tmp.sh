@@ -1,2 +1,6 @@
-sel='import sys,json; d=json.loads(sys.stdin.read().strip().split("\n")[-1]); print(sys.argv[1], json.dumps(d["cpu_baseline"]))'
-for th in 256 64 16; do GHN3_CPU_THREADS=$th python bench.py --steps 3 --warmup 2 --no-extras 2>/dev/null | python -c "$sel" threads$th; done
+B="python bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extras"
+sel='import sys,json; d=json.loads(sys.stdin.read().strip().split("\n")[-1]); print(sys.argv[1], round(d["ms_per_step"],3), round(d["roofline"]["frac"],4))'
+GHN3_EARLY_GRAD_ZERO=0 $B 2>/dev/null | python -c "$sel" late_zero
+$B 2>/dev/null | python -c "$sel" early_zero
+GHN3_EARLY_GRAD_ZERO=0 $B 2>/dev/null | python -c "$sel" late_zero
+$B 2>/dev/null | python -c "$sel" early_zero

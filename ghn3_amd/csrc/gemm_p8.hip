@@ -413,7 +413,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmProbDev* __re
 // residual / accumulate / gathers / k-map / ragged extents / split-K; N % 4 == 0, K >= 1; 256 x 256 tiles.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int CT>
-__global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int total_tiles) {
+__global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int total_tiles_all,
+                                                           int vgrid, int tpw) {
     constexpr int MI = 4, BK = 64;
     constexpr int AH = 32 * MI * 128, BH = 128 * 128, KT = 2 * AH + 2 * BH;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -422,7 +423,15 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
     const int wave = rfl(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
     const int r16 = lane & 15, kc = lane >> 4;
-    const int stride = (int)gridDim.x;
+    // Virtual persistent grid: worker v of `vgrid` owns the tile ids v, v + vgrid, v + 2 vgrid ... (vgrid % 8 == 0: a worker's
+    // tiles keep their XCD).  tpw == 0: one workgroup per worker walks all of them.  tpw > 0: workgroup (chunk c, worker v)
+    // walks tpw of them and exits -- the launch then has vgrid * chunks workgroups that the dispatcher starts in order as CUs
+    // free up, so a higher-priority stream (the dependent chain this weight gradient runs beside) gets CUs every few tiles
+    // instead of never, at the price of one un-overlapped prologue / store phase per tpw tiles.
+    const int stride = vgrid;
+    const int w_v = (int)blockIdx.x % vgrid, w_c = (int)blockIdx.x / vgrid;
+    const int t_first = w_v + vgrid * w_c * tpw;
+    const int total_tiles = tpw > 0 ? min(total_tiles_all, t_first + vgrid * tpw) : total_tiles_all;
 
     // first valid tile at or behind id t (XCD-blocked order: see gemm_h16w_kernel / runtime.hip) -> problem index, origin, k-tiles
     auto next_tile = [&](int t, int& idx, int& m0, int& n0, int& nkt) -> int {
@@ -447,7 +456,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
 
     // ---- issue side -------------------------------------------------------------------------------------------------
     int i_idx = 0, i_m0 = 0, i_n0 = 0, i_nkt = 0;
-    int it = next_tile((int)blockIdx.x, i_idx, i_m0, i_n0, i_nkt);
+    int it = next_tile(t_first, i_idx, i_m0, i_n0, i_nkt);
     if (it >= total_tiles) return;                    // (uniform over the workgroup)
     // ---- compute side starts at the same tile
     int c_idx = i_idx, c_m0 = i_m0, c_n0 = i_n0, c_nkt = i_nkt, ct = it;
@@ -681,15 +690,22 @@ int ghn3_gemm_p8w_launch(const GemmProbDev* d_probs, int n_probs, int total_tile
     }
     int rc = ghn3_gemm_p8_init();
     if (rc) return rc;
+    // grid_cap: low 16 bits = workers (CUs' worth of workgroups in flight), high bits = tiles per workgroup (0: persistent)
+    const int tpw = grid_cap > 0 ? (grid_cap >> 16) : 0;
+    grid_cap &= 0xffff;
     int grid = grid_cap > 0 ? grid_cap : g_p8_n_cu;
     if (grid > total_tiles) grid = total_tiles;
     grid = grid >= 8 ? grid / 8 * 8 : grid;
     if (grid < 8) grid = 8 < total_tiles ? 8 : total_tiles;     // (fewer than 8 tiles: one workgroup each)
     if (total_tiles >= 8 && grid % 8) grid = 8;
+    const int per_worker = (total_tiles + grid - 1) / grid;
+    const int chunks = tpw > 0 ? (per_worker + tpw - 1) / tpw : 1;
     if (ctype == GHN3_CT_F16)
-        hipLaunchKernelGGL(gemm_p8w_kernel<GHN3_CT_F16>, dim3(grid), dim3(512), 128 * 1024, stream, d_probs, n_probs, total_tiles);
+        hipLaunchKernelGGL(gemm_p8w_kernel<GHN3_CT_F16>, dim3(grid * chunks), dim3(512), 128 * 1024, stream, d_probs, n_probs,
+                           total_tiles, grid, tpw);
     else
-        hipLaunchKernelGGL(gemm_p8w_kernel<GHN3_CT_BF16>, dim3(grid), dim3(512), 128 * 1024, stream, d_probs, n_probs, total_tiles);
+        hipLaunchKernelGGL(gemm_p8w_kernel<GHN3_CT_BF16>, dim3(grid * chunks), dim3(512), 128 * 1024, stream, d_probs, n_probs,
+                           total_tiles, grid, tpw);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("p8w gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

@@ -1668,7 +1668,8 @@ class Program:
                 n_before = len(self._ops)
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=True, flops=fl,
                              tile=int(os.environ.get('GHN3_WGRAD_TILE', '29')),
-                             grid_cap=int(os.environ.get('GHN3_WGRAD_CAP', '224')) if self.SIDE else 0)
+                             grid_cap=(int(os.environ.get('GHN3_WGRAD_CAP', '224')) |
+                                       (int(os.environ.get('GHN3_WGRAD_TPW', '0')) << 16)) if self.SIDE else 0)
                 self.wgrad_op_range = (n_before, len(self._ops))
             fam_list = bands
             for gi, g in enumerate(self.gemm_groups):

@@ -413,6 +413,10 @@ OP16_CASES = [
     dict(M=2048, N=1024, K=768, a_transposed=True, b_transposed=True, tile=29, grid_cap=5),
     dict(M=4096, N=512, K=64 * 9, tile=29, grid_cap=8),
     dict(M=2100, N=512, K=100, tile=29, grid_cap=16, cmap=True),
+    # ... and with a bounded number of tiles per workgroup (grid_cap = workers | tiles << 16): chunks of 1 / 2 / 3 tiles
+    dict(M=4096, N=512, K=64 * 9, tile=29, grid_cap=8 | (1 << 16)),
+    dict(M=2100, N=1024, K=100, tile=29, grid_cap=8 | (2 << 16), cmap=True),
+    dict(M=4096, N=1300, K=200, tile=29, grid_cap=16 | (3 << 16)),
     # XCD-pinned problems of one launch (xcd_pin): several problems on one XCD, XCDs without a problem, unpinned problems
     # behind the pinned ids, fewer than 8 problems (pins ignored), the 256 x 128 variant and the persistent grid
     dict(M=300, N=520, K=150, pins=[0, 1, 2, 3, 4, 5, 6, 7, 0, 3, None, 5]),

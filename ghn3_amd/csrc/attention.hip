@@ -448,7 +448,7 @@ __global__ __launch_bounds__(256) void attn_fwd_stream_kernel(float* __restrict_
 // otherwise column role (32 keys: dK, dV).  delta_i = sum_e dO[i][e] O[i][e] (= rowsum(P * dP)).
 // ------------------------------------------------------------------------------------------------
 template <int KS>
-__global__ __launch_bounds__(256) void attn_bwd_kernel(float* __restrict__ dqkv, const float* __restrict__ dO,
+__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(float* __restrict__ dqkv, const float* __restrict__ dO,
                                                        const float* __restrict__ qkv, const float* __restrict__ P,
                                                        const float* __restrict__ Oin, float* __restrict__ dBias,
                                                        const int* __restrict__ n_nodes, int N, int C, int H,

@@ -453,7 +453,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                 // works on every (8 / G)-th row tile and on one of G column groups, chosen so that its
                                 // share of B stays in its 4 MB L2 while the A tiles stream through once per column group
                                 static const int64_t b_budget = getenv("GHN3_XCD_B_BYTES") ? atoll(getenv("GHN3_XCD_B_BYTES"))
-                                                                                          : (int64_t)(3 << 19);
+                                                                                          : (int64_t)(5 << 19);     // (2.5 MB: two column groups for the W2 weight gradient; r03: 1.07 ms against 1.13 ms with four, same traffic)
                                 int G = 1;
                                 while (G < 8 && (int64_t)p.N * p.K * 2 / G > b_budget && g.tiles_n >= 2 * G) G *= 2;
                                 g.xcd_cols = G;

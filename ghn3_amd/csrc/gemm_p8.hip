@@ -30,6 +30,13 @@
 #include "ghn3_internal.h"
 
 #define GAS __attribute__((address_space(1)))
+// cache-policy bits of the LDS-DMA loads of the forward / dgrad kernel (aux: 1 = sc0, 2 = nt, 16 = sc1); experiments only
+#ifndef P8_AUX_A
+#define P8_AUX_A 0
+#endif
+#ifndef P8_AUX_B
+#define P8_AUX_B 0
+#endif
 #define LAS __attribute__((address_space(3)))
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -137,14 +144,14 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
                 LAS char* dst = (LAS char*)(kt + (h ? AH + 2 * BH : 0));
 #pragma unroll
                 for (int i = 0; i < NFA; ++i)
-                    __builtin_amdgcn_global_load_lds((const void GAS*)(Ab + (oa[h][i] + (unsigned)kA)), (LAS void*)(dst + i * 8192 + wave * 1024), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const void GAS*)(Ab + (oa[h][i] + (unsigned)kA)), (LAS void*)(dst + i * 8192 + wave * 1024), 16, 0, P8_AUX_A);
                 if (ODD && lane < 32)
-                    __builtin_amdgcn_global_load_lds((const void GAS*)(Ab + (oa[h][NFA] + (unsigned)kA)), (LAS void*)(dst + NFA * 8192 + wave * 512), 16, 0, 0);
+                    __builtin_amdgcn_global_load_lds((const void GAS*)(Ab + (oa[h][NFA] + (unsigned)kA)), (LAS void*)(dst + NFA * 8192 + wave * 512), 16, 0, P8_AUX_A);
             } else {
                 const int h = j == 2;
                 LAS char* dst = (LAS char*)(kt + AH + h * BH + wave * 1024);
-                __builtin_amdgcn_global_load_lds((const void GAS*)(Bb + (ob[h][0] + (unsigned)kB)), (LAS void*)dst, 16, 0, 0);
-                __builtin_amdgcn_global_load_lds((const void GAS*)(Bb + (ob[h][1] + (unsigned)kB)), (LAS void*)(dst + 8192), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const void GAS*)(Bb + (ob[h][0] + (unsigned)kB)), (LAS void*)dst, 16, 0, P8_AUX_B);
+                __builtin_amdgcn_global_load_lds((const void GAS*)(Bb + (ob[h][1] + (unsigned)kB)), (LAS void*)(dst + 8192), 16, 0, P8_AUX_B);
             }
         }
         ++qi;

@@ -441,6 +441,7 @@ class Program:
 
     # cost of one k-tile step of a (64 mi) x 256 tile of the 8-phase kernel, mi = 3, 4, 5 (tools/gemm_lab.hip, relative)
     P8_COST = {3: 1.72, 4: 2.0, 5: 2.42}
+    FC_DGRAD_T = os.environ.get('GHN3_FC_DGRAD_T', '0') != '0'
     P8_MI = tuple(int(v) for v in os.environ.get('GHN3_P8_MI', '3,4,5').split(','))
 
     @classmethod
@@ -658,10 +659,13 @@ class Program:
         w2h = 0
         w2hT = round_up(w2h + n_w2 * 8 * C + 128, 128)
         w0hT = round_up(w2hT + 8 * C * w2hT_ld + 128, 128)
-        # fp32, k-contiguous copy of decoder.fc.0.weight for the fc dgrad: [position p][C][4C] (GHN3_OP_TRANSPOSE32)
+        # bf16 hi / lo copies of decoder.fc.0.weight, transposed per grid position ([position p][C][4C], k-contiguous), for the
+        # split-bf16 fc dgrad (see _cast_w2)
+        # (off by default since the weight gradient is issued behind the decoder backward: 6.97 ms per step either way, and
+        # the copies are 604 MB at ghn3xlm16; GHN3_FC_DGRAD_T=1 enables them)
         S2 = int(max_shape[2]) * int(max_shape[3])
         wfcT = round_up(w0hT + 4 * C * 8 * C + 128, 128)
-        pos = round_up(wfcT + 2 * S2 * C * 4 * C + 128, 128)
+        pos = round_up(wfcT + (2 * S2 * C * 4 * C if Program.FC_DGRAD_T else 0) + 128, 128)
         lay = dict(w2h=w2h, w2hT=w2hT, w2hT_ld=w2hT_ld, w0hT=w0hT, wfcT=wfcT, x3={})
         for l in range(layers):
             for name, r, c in Program.X3_WEIGHTS:
@@ -706,7 +710,7 @@ class Program:
                 self.cast16(self.pref('decoder.conv.0.weight'),
                             [dict(src_off=0, rows=8 * C, cols=4 * C, ld_src=4 * C, transposed=(self.w0hT, 8 * C, bct))],
                             flags=self.SIDE, dst_base=shadow)
-        if self.training and os.environ.get('GHN3_FC_DGRAD_T', '1') != '0' and (4 * C) % 64 == 0 and C % 4 == 0:
+        if self.training and self.FC_DGRAD_T and (4 * C) % 64 == 0 and C % 4 == 0:
             # decoder.fc.0.weight transposed per grid position, as bf16 hi / lo copies (GHN3_GEMM_X3 B operand):
             # wfcT[p][n][ch] = Wfc[ch * 256 + p][n].  The fc dgrad reduces over ch; on the exact-fp32 small-problem kernel it
             # was ~50 problems (one per used grid position) of a few dozen rows, 12 column tiles each walking K = 4C in
@@ -1342,12 +1346,7 @@ class Program:
         late_ops = []
         self.wgrad_op_range = None
 
-        # K splits of the fc dgrad write separate planes of d_xrows (plane j at rows j * (M + n1) ..); the gather-sum that
-        # folds decoder rows into node rows adds the planes in a fixed order (no atomics)
-        self.fc_ks = int(os.environ.get('GHN3_FC_DGRAD_KS', '1')) if (False and M > 0 and self.training and self.uses_shadow and
-                                                                     os.environ.get('GHN3_FC_DGRAD_T', '1') != '0' and
-                                                                     (4 * C) % 8 == 0) else 1
-        d_rows = self.wsf('d_xrows', self.fc_ks * (M + n1) * C)
+        d_rows = self.wsf('d_xrows', (M + n1) * C)
         # ---- tile backward -------------------------------------------------------------------------
         if M > 0:
             self.wsf('d_tiles', self.tiles_floats)
@@ -1777,18 +1776,6 @@ class Program:
         counts = np.bincount(all_src, minlength=rows)[:rows]
         seg_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         d_xe = self.wsf('d_xe', rows * C)
-        if getattr(self, 'fc_ks', 1) > 1 and hasattr(self, 'wfcT'):
-            # planes of the decoder rows (the 1-D rows live in plane 0 only): node row r sums its rows of every plane
-            ks = self.fc_ks
-            is_dec = order < M
-            reps = np.where(is_dec, ks, 1)
-            order_k = np.repeat(order, reps)
-            plane = np.concatenate([np.arange(k_) for k_ in reps]) if len(reps) else np.zeros(0, dtype=np.int64)
-            order_k = (order_k + plane * (M + n1)).astype(np.int32)
-            cnt_k = np.zeros(rows, dtype=np.int64)
-            np.add.at(cnt_k, all_src[order], reps)
-            seg_ptr = np.concatenate([[0], np.cumsum(cnt_k)]).astype(np.int32)
-            order = order_k
         self.op(L.OP_ROWSEG_SUM, refs=(d_xe, d_rows, self.idx(seg_ptr), self.idx(order)), ints=(rows, C, C, C, 0))
 
         # ---- final LayerNorm ----------------------------------------------------------------------------

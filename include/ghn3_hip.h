@@ -338,10 +338,8 @@ enum ghn3_op_kind {
     GHN3_OP_WIRE_PACK = 30,
     GHN3_OP_RANK_REDUCE = 31,
     /* batched fp32 transpose: dst[b][c][r] = src[b][r][c], r < i0 rows, c < i1 cols; i2 = ld_src, i3 = ld_dst, i4 = batch,
-     * i5 / i6 = floats between batches in src / dst.  Writes the persistent k-contiguous copy of decoder.fc.0.weight the
-     * fc dgrad multiplies with (per used position of the 16 x 16 grid the [4C] x [C] row subset `ch * 256 + p` of Wfc,
-     * nn.py:738 backward): read k-strided, one 128-byte piece of every 1.5 KB row per column tile, that GEMM ran at
-     * 4 TFLOP/s on the critical path. */
+     * i5 / i6 = floats between batches in src / dst.  Utility (k-contiguous fp32 copies of k-strided operands; the compiled
+     * programs of this round use the 16-bit transposed copies of GHN3_OP_CAST16 instead). */
     GHN3_OP_TRANSPOSE32 = 32,
     GHN3_OP_KIND_COUNT
 };

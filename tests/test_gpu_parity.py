@@ -637,6 +637,12 @@ def test_split_backward_with_overlapped_gradient_reduction():
         back = torch.empty(W * per, device='cuda')
         _hip_ops([(L.OP_WIRE_PACK, (0, 1), (W * per, W * per, 1), 0.0)], [back.data_ptr(), packed.data_ptr()], st)
         assert torch.equal(back, xb.float())
+        # GHN3_OP_TRANSPOSE32: batched fp32 transpose with leading dimensions and batch strides
+        src = torch.randn(3, 37, 52, device='cuda')
+        dst = torch.zeros(3, 50, 40, device='cuda')
+        _hip_ops([(L.OP_TRANSPOSE32, (0, 1), (37, 50, 52, 40, 3, 37 * 52, 50 * 40), 0.0)], [dst.data_ptr(), src.data_ptr()], st)
+        torch.cuda.synchronize()
+        assert torch.equal(dst[:, :, :37], src[:, :, :50].transpose(1, 2)) and float(dst[:, :, 37:].abs().sum()) == 0.0
     finally:
         dist.destroy_process_group()
 

@@ -1687,6 +1687,9 @@ class Program:
                 self.gemm_op(p0, tile=64 if g['rows'] <= 1024 else 0, ctype=bct if g16 else None,
                              tag=self.TAG_D3_WGRAD, side=True)
             self.bwd_cut_w2 = len(self._ops)             # every op that writes dW2 has been issued
+            if self.wgrad_op_range is not None:
+                # (the late order moves ALL of them: the fp32-operand groups accumulate into what the band problems write)
+                self.wgrad_op_range = (self.wgrad_op_range[0], self.bwd_cut_w2)
             # D2 backward
             if g16 and hasattr(self, 'w0hT'):
                 # 16-bit operands: d_u (straight for the dgrad on the chain; transposed + column sums = bias

@@ -152,6 +152,20 @@ EXTRA_NETS = [
                 ('bias', 'fc.bias', (10,))],
          skips=[(2, 6)]),
 ]
+# Degenerate batches (no golden file: HIP path / host compiler against the oracle only): a network without any 2-D / 4-D
+# weight (the decoder GEMMs have zero rows), a single 1x1 convolution, three graphs of very different sizes in one batch.
+EDGE_NETS = {
+    'only1d': dict(nodes=[('input', None, None), ('bn', 'bn.weight', (8,)), ('bias', 'bn.bias', (8,)),
+                          ('ln', 'ln.weight', (8,)), ('bias', 'ln.bias', (8,)), ('glob_avg', None, None)]),
+    'single': dict(nodes=[('input', None, None), ('conv', 'c.weight', (4, 3, 1, 1)), ('glob_avg', None, None)]),
+}
+EDGE_CASES = {'only1d': ['only1d'], 'single': ['single'], 'ragged3': [1, 'single', 0], 'mixed1d': ['only1d', 1]}
+
+
+def edge_specs(case):
+    return [EDGE_NETS[k] if isinstance(k, str) else TINY_NETS[k] for k in EDGE_CASES[case]]
+
+
 EXTRA_CASES = {  # name: (spec list, overrides of TINY_CFG)
     'big': ([EXTRA_NETS[0]], {}),
     'big_b2': ([TINY_NETS[1], EXTRA_NETS[0]], {}),

@@ -223,6 +223,44 @@ def test_extra_cases_forward_backward(case):
         assert abs(p.grad.norm().item() - ref[0]) < 2e-4 * max(1.0, ref[0]), (k, p.grad.norm().item(), ref[0])
 
 
+@pytest.mark.parametrize('case', sorted(recipe.EDGE_CASES))
+@pytest.mark.parametrize('compute', ['f32', 'f16'])
+def test_degenerate_batches_forward_backward(case, compute):
+    """Edge cases of the batch: a network without any 2-D / 4-D weight (zero decoder rows: every decoder GEMM, cast and
+    tile launch of the family is empty), a single 1x1 convolution, three graphs of very different sizes (ragged masks), a
+    weight-less network next to a normal one -- predicted tensors and every GHN gradient against the oracle; parameters
+    the batch does not touch get an all-zero gradient."""
+    hip, oracle = make_models(dict(recipe.TINY_CFG), recipe.TINY_SEED, compute=compute)
+    nets_h, gb_h, nets_o, gb_o = tiny_case(case)
+    hip.train()
+    nets_h = hip(nets_h, gb_h, keep_grads=True)
+    oracle.train()
+    nets_o, pred_o = oracle(nets_o, gb_o, keep_grads=True)
+    tol_f, tol_g = (2e-5, 2e-4) if compute == 'f32' else (1e-3, 2e-3)
+    loss, loss_o, n_cmp = 0, 0, 0
+    for net_h, net_o in zip(nets_h, nets_o):
+        ref = dict(recipe.named_predicted(net_o))
+        for name, p in recipe.named_predicted(net_h):
+            t = ref[name]
+            n_cmp += 1
+            assert tuple(p.shape) == tuple(t.shape), name
+            if p.dim() == 3:
+                p, t = p[:, 1:], t[:, 1:]                    # Q3: random class-token row of positional encodings
+            assert rel_l2(p.detach().cpu(), t.detach()) < tol_f, (name, rel_l2(p.detach().cpu(), t.detach()))
+            loss = loss + torch.norm(p, p='fro')
+            loss_o = loss_o + torch.norm(t, p='fro')
+    assert n_cmp >= 1
+    loss.backward()
+    torch.cuda.synchronize()
+    loss_o.backward()
+    po = dict(oracle.named_parameters())
+    for name, p in hip.named_parameters():
+        assert p.grad is not None and torch.isfinite(p.grad).all(), name
+        go = po[name].grad if po[name].grad is not None else torch.zeros_like(po[name])
+        err = float((p.grad.cpu().double() - go.double()).norm())
+        assert err < tol_g * float(go.norm()) + 2e-6, (name, err, float(go.norm()))
+
+
 @pytest.mark.parametrize('name', ['resnet_tiny', 'mobile_se', 'vit_tiny', 'attn_tiny'])
 def test_ghn_model_without_a_graph(name):
     """examples/ghn_single_model.py call sequence: ``ghn(model)`` with graphs=None builds the graph from the module

@@ -31,8 +31,8 @@ def make_models(cfg, seed, index_mode='reference', compute='f32', device='cuda')
 def tiny_case(case):
     """(nets for HIP, GraphBatch for HIP, nets for oracle, GraphBatchRef) of a committed tiny case."""
     from ghn3_amd import Graph, GraphBatch
-    specs = recipe.EXTRA_CASES[case][0] if case in recipe.EXTRA_CASES else \
-        [recipe.TINY_NETS[i] for i in recipe.TINY_CASES[case]]
+    specs = recipe.edge_specs(case) if case in recipe.EDGE_CASES else \
+        recipe.EXTRA_CASES[case][0] if case in recipe.EXTRA_CASES else [recipe.TINY_NETS[i] for i in recipe.TINY_CASES[case]]
     nets_h = [recipe.build_torch_net(s) for s in specs]
     nets_o = [recipe.build_torch_net(s) for s in specs]
     gh, go = [], []

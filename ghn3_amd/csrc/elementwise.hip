@@ -1496,6 +1496,35 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
     const float sc = ((D.flags & GHN3_CAST_SCALED) && amax) ? ghn3_pow2_scale(*amax) : 1.f;
     const int rows_w = (D.flags & GHN3_CAST_TIGHT) ? ((D.rows + 7) & ~7) : 0x7fffffff;   // transposed rows written
 
+    if (st && !trn && !(D.flags & GHN3_CAST_COLSUM) && D.src_q == 0 && !(D.ld_dst & 7) && !(D.dst_off & 7) && !(D.lo_off & 7)) {
+        // straight copy only (the dgrad operand of the decoder gradients, forward activations): 8 consecutive floats per
+        // lane -> one 16-byte store (the general path below writes 8 bytes per lane)
+        unsigned short* Dd = dst + D.dst_off;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = r0 + (tid >> 3) + 32 * i, c = c0 + (tid & 7) * 8;
+            if (r >= D.rows) continue;
+            const float* p = S + (int64_t)r * D.ld_src + c;
+            float x[8];
+            if (c + 7 < D.cols) {
+                const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+                x[0] = a.x; x[1] = a.y; x[2] = a.z; x[3] = a.w; x[4] = b.x; x[5] = b.y; x[6] = b.z; x[7] = b.w;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = c + e < D.cols ? p[e] : 0.f;
+            }
+            us8 h, l;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xs = x[e] * sc;
+                h[e] = st_bf ? cast_bf16(xs) : cast_f16(xs);
+                if (split) l[e] = cast_bf16(xs - bf16_back(h[e]));
+            }
+            *reinterpret_cast<us8*>(Dd + (int64_t)r * D.ld_dst + c) = h;
+            if (split) *reinterpret_cast<us8*>(Dd + D.lo_off + (int64_t)r * D.ld_dst + c) = l;
+        }
+        continue;                                      // (uniform over the workgroup: no barrier is skipped by a subset)
+    }
     float4 v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

@@ -163,3 +163,48 @@ def test_primitive_vocabulary_against_what_the_reference_forces():
                     assert P[int(ids[ind])] == prim
                     checked += 1
     assert checked > 100
+
+
+def test_graph_batch_pickles_tensors_as_numpy():
+    """GraphBatch / Graph leave a process with their CPU tensors as numpy arrays (torch's shared-memory reducers for the
+    multiprocessing pickler cost ~7 ms per batch in the process that feeds the GPU) and come back as the same tensors."""
+    import io
+    import pickle
+    import multiprocessing.reduction as mpr
+    from ghn3_amd.synthetic import synthetic_batch
+    gb, _ = synthetic_batch([30, 20], 5)
+    for cat in (False, True):
+        if cat:
+            gb._cat()
+        buf = io.BytesIO()
+        mpr.ForkingPickler(buf, pickle.HIGHEST_PROTOCOL).dump(gb)       # (the pickler multiprocessing.Pool uses)
+        raw = buf.getvalue()
+        assert b'rebuild_storage' not in raw and b'_rebuild_tensor' not in raw, 'a tensor went through torch reducers'
+        back = pickle.loads(raw)
+        for k, v in gb.__dict__.items():
+            w = back.__dict__[k]
+            if isinstance(v, torch.Tensor):
+                assert isinstance(w, torch.Tensor) and w.dtype == v.dtype and torch.equal(v, w), k
+            elif isinstance(v, list) and v and isinstance(v[0], torch.Tensor):
+                assert all(torch.equal(a, b) for a, b in zip(v, w)), k
+    g = gb.graphs[0]
+    g2 = pickle.loads(pickle.dumps(g))
+    assert torch.equal(torch.as_tensor(g.node_feat), torch.as_tensor(g2.node_feat)) and g2.n_nodes == g.n_nodes
+
+
+def test_usable_cores_applies_the_cgroup_quota(tmp_path, monkeypatch):
+    import builtins
+    import bench
+    real_open = builtins.open
+
+    def fake_open(path, *a, **k):
+        if path == '/sys/fs/cgroup/cpu.max':
+            return io.StringIO('400000 100000\n')
+        return real_open(path, *a, **k)
+    import io
+    monkeypatch.setattr(builtins, 'open', fake_open)
+    monkeypatch.setattr(os, 'sched_getaffinity', lambda pid: set(range(64)), raising=False)
+    assert bench.usable_cores() == 4
+    monkeypatch.setattr(builtins, 'open', lambda path, *a, **k: io.StringIO('max 100000\n') if path == '/sys/fs/cgroup/cpu.max'
+                        else real_open(path, *a, **k))
+    assert bench.usable_cores() == 64

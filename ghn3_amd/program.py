@@ -304,7 +304,11 @@ class Program:
 
     NONE = (-1, 0)
 
+    _ABLATE = tuple(int(v) for v in os.environ.get('GHN3_ABLATE_OPS', '').split(',') if v)    # (timing experiments only)
+
     def op(self, kind, refs=(), ints=(), floats=(), flags=0):
+        if kind in self._ABLATE:
+            return
         self._ops.append((kind, flags, tuple(ints), tuple(floats), tuple(refs)))
 
     def _finish_ops(self):

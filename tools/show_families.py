@@ -27,3 +27,13 @@ for p in prog.predicted:
     k = 'hw>1' if sh and len(sh) == 4 and sh[2] * sh[3] > 1 else ('1x1' if sh and len(sh) == 4 else ('2d' if sh and len(sh) == 2 else '1d'))
     tot[k] = tot.get(k, 0) + p['numel']
 print('predicted elements by kind', tot, 'fwd blocks', prog.fwd_blk[0], 'bwd blocks', prog.bwd_blk[0], 'tile lds', prog.tile_lds)
+import collections
+wg = [p for p in prog.problems if int(p['lda']) == int(p['ldb']) and (int(p['flags']) & L.GEMM_OP16) and int(p['N']) == 8 * prog.C and int(p['c_q']) > 0]
+tot_tiles = 0; tot_fl = 0
+print('wgrad band problems (M, K, tiles of 256x256, k-tiles):')
+for p in wg:
+    M, N, K = int(p['M']), int(p['N']), int(p['K'])
+    t = ((M + 255) // 256) * ((N + 255) // 256)
+    tot_tiles += t; tot_fl += 2.0 * M * N * K
+    print('  M %6d K %4d tiles %5d ktiles %2d' % (M, K, t, (K + 63) // 64))
+print('total tiles', tot_tiles, 'GFLOP (padded K not counted)', tot_fl / 1e9)

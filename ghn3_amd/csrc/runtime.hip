@@ -58,7 +58,7 @@ struct ghn3_ctx {
     int64_t tag_n[256];
     // side stream for ops flagged GHN3_OPFLAG_SIDE (work off the critical path of a program)
     hipStream_t side;
-    hipEvent_t ev_fork, ev_join;
+    hipEvent_t ev_fork, ev_join, ev_mark[4];
     bool side_enabled;
     bool side_pending;     // a run ended with GHN3_OP_DETACH: its side-stream work has not been joined yet
 };
@@ -103,6 +103,7 @@ extern "C" int ghn3_ctx_create(ghn3_ctx** out) {
     }
     HIPCHK(hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming));
+    for (int i = 0; i < 4; ++i) HIPCHK(hipEventCreateWithFlags(&c->ev_mark[i], hipEventDisableTiming));
     c->side_enabled = !(getenv("GHN3_NO_SIDE_STREAM") && atoi(getenv("GHN3_NO_SIDE_STREAM")) != 0);
     int rc = ghn3_gemm_init();
     if (rc) return rc;
@@ -133,6 +134,7 @@ extern "C" void ghn3_ctx_destroy(ghn3_ctx* c) {
     hipStreamSynchronize(c->side);
     hipStreamDestroy(c->side);
     hipEventDestroy(c->ev_fork);
+    for (int i = 0; i < 4; ++i) hipEventDestroy(c->ev_mark[i]);
     hipEventDestroy(c->ev_join);
     for (hipEvent_t e : *c->pool) hipEventDestroy(e);
     delete c->pool;
@@ -504,6 +506,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
     hipStream_t const main_stream = stream;
     bool main_dirty = true, side_dirty = c->side_pending;
     bool detach = false;
+    bool mark_set[4] = {false, false, false, false};
     c->side_pending = false;
     auto join = [&]() -> int {
         if (side_dirty) {
@@ -518,7 +521,18 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         int rc = GHN3_OK;
         R.bad = false;
         const bool on_side = (o.flags & GHN3_OPFLAG_SIDE) && c->side_enabled && c->profile != 1;
-        if (o.kind == GHN3_OP_JOIN) { rc = join(); if (rc) return rc; continue; }
+        if (o.kind == GHN3_OP_JOIN) {
+            const int mode = (int)o.i[0], id = (int)o.i[1] & 3;
+            if (mode == 1) {                             // mark: the side-stream work issued so far
+                if (side_dirty) { HIPCHK(hipEventRecord(c->ev_mark[id], c->side)); mark_set[id] = true; }
+            } else if (mode == 2) {                      // the run's stream waits for that mark only (later side work keeps running)
+                if (mark_set[id]) { HIPCHK(hipStreamWaitEvent(main_stream, c->ev_mark[id], 0)); mark_set[id] = false; }
+            } else {
+                rc = join();
+                if (rc) return rc;
+            }
+            continue;
+        }
         if (o.kind == GHN3_OP_DETACH) { detach = true; continue; }
         detach = false;
         if (on_side) {

@@ -963,6 +963,42 @@ class Program:
         W0, b0 = 'decoder.conv.0.weight', 'decoder.conv.0.bias'
         W2, b2 = 'decoder.conv.2.weight', 'decoder.conv.2.bias'
         Wc, bc = 'decoder.class_layer_predictor.1.weight', 'decoder.class_layer_predictor.1.bias'
+        def decoder_1d(side):
+            # 1-D decoder (nn.py:286-295)
+            if self.n1 <= 0:
+                return
+            W1, b1 = 'decoder_1d.fc.0.weight', 'decoder_1d.fc.0.bias'
+            W2d, b2d = 'decoder_1d.fc.2.weight', 'decoder_1d.fc.2.bias'
+            Wb, bb = 'bias_class.1.weight', 'bias_class.1.bias'
+            mc = max(self.max_shape[:2])
+            self.mc = mc
+            r_src1 = self.idx(self.oned_src)
+            self.r_src1 = r_src1
+            h1d = self.wsf('h1d', self.n1 * 2 * C)
+            w1d = self.wsf('w1d', self.n1 * 2 * mc)
+            p0 = self.gemm(xe, self.pref(W1), h1d, self.n1, 2 * C, C, C, C, 2 * C, bias=self.pref(b1),
+                           act=L.ACT_RELU, a_gather=r_src1)
+            self.gemm_op(p0, side=side)
+            p0 = len(self._probs)
+            if self.n1_plain:
+                self.gemm(h1d, self.pref(W2d), w1d, self.n1_plain, 2 * mc, 2 * C, 2 * C, 2 * C, 2 * mc,
+                          bias=self.pref(b2d))
+            if self.n1_clsb:
+                self.gemm(self.wref('h1d', self.n1_plain * 2 * C), self.pref(W2d),
+                          self.wref('w1d', self.n1_plain * 2 * mc), self.n1_clsb, 2 * mc, 2 * C, 2 * C, 2 * C, 2 * mc,
+                          bias=self.pref(b2d), act=L.ACT_RELU)
+            self.gemm_op(p0, side=side)
+            if self.n1_clsb:
+                cbout = self.wsf('cbout', self.n1_clsb * ldK)
+                p0 = self.gemm(self.wref('w1d', self.n1_plain * 2 * mc + mc), self.pref(Wb), cbout, self.n1_clsb, K,
+                               mc, 2 * mc, mc, ldK, bias=self.pref(bb))
+                self.gemm_op(p0, side=side)
+
+        # The 1-D decoder (bn / bias / norm nodes) depends on the node embeddings only: with two streams it runs on the side
+        # stream beside the W2 GEMMs instead of behind them (~35 us of small launches off the forward chain)
+        early_1d = bool(self.SIDE) and M > 0 and os.environ.get('GHN3_EARLY_1D', '1') != '0'
+        if early_1d:
+            decoder_1d(True)
         if M > 0:
             t = self.wsf('t', M * 4 * C)
             u = self.wsf('u', M * 8 * C)
@@ -1070,34 +1106,10 @@ class Program:
                                   a_mode=L.MODE_COL, bias=self.pref(bc))
                         off += g['i_ld'] * ldK
                 self.gemm_op(p0)
-        # 1-D decoder (nn.py:286-295)
-        if self.n1 > 0:
-            W1, b1 = 'decoder_1d.fc.0.weight', 'decoder_1d.fc.0.bias'
-            W2d, b2d = 'decoder_1d.fc.2.weight', 'decoder_1d.fc.2.bias'
-            Wb, bb = 'bias_class.1.weight', 'bias_class.1.bias'
-            mc = max(self.max_shape[:2])
-            self.mc = mc
-            r_src1 = self.idx(self.oned_src)
-            self.r_src1 = r_src1
-            h1d = self.wsf('h1d', self.n1 * 2 * C)
-            w1d = self.wsf('w1d', self.n1 * 2 * mc)
-            p0 = self.gemm(xe, self.pref(W1), h1d, self.n1, 2 * C, C, C, C, 2 * C, bias=self.pref(b1),
-                           act=L.ACT_RELU, a_gather=r_src1)
-            self.gemm_op(p0)
-            p0 = len(self._probs)
-            if self.n1_plain:
-                self.gemm(h1d, self.pref(W2d), w1d, self.n1_plain, 2 * mc, 2 * C, 2 * C, 2 * C, 2 * mc,
-                          bias=self.pref(b2d))
-            if self.n1_clsb:
-                self.gemm(self.wref('h1d', self.n1_plain * 2 * C), self.pref(W2d),
-                          self.wref('w1d', self.n1_plain * 2 * mc), self.n1_clsb, 2 * mc, 2 * C, 2 * C, 2 * C, 2 * mc,
-                          bias=self.pref(b2d), act=L.ACT_RELU)
-            self.gemm_op(p0)
-            if self.n1_clsb:
-                cbout = self.wsf('cbout', self.n1_clsb * ldK)
-                p0 = self.gemm(self.wref('w1d', self.n1_plain * 2 * mc + mc), self.pref(Wb), cbout, self.n1_clsb, K,
-                               mc, 2 * mc, mc, ldK, bias=self.pref(bb))
-                self.gemm_op(p0)
+        if not early_1d:
+            decoder_1d(False)
+        elif self.n1 > 0:
+            self.op(L.OP_JOIN)                          # the side-stream 1-D decoder is complete before the tile kernels read it
         self._build_tile_descriptors()
 
     @staticmethod
@@ -1381,6 +1393,44 @@ class Program:
                     grads, ints=(self.n_desc, self.bwd_blk[0], self.bwd_blk[1], self.tile_lds[1]),
                     flags=L.OPFLAG_TIMED | (self.TAG_TILE_BWD << 16))
 
+        def decoder_1d_bwd(side):
+            if n1 <= 0:
+                return
+            mc = self.mc
+            W1, b1 = 'decoder_1d.fc.0.weight', 'decoder_1d.fc.0.bias'
+            W2d, b2d = 'decoder_1d.fc.2.weight', 'decoder_1d.fc.2.bias'
+            Wb, bb = 'bias_class.1.weight', 'bias_class.1.bias'
+            h1d, w1d, d_w1d = self.wref('h1d'), self.wref('w1d'), self.wref('d_w1d')
+            d_h1d = self.wsf('d_h1d', n1 * 2 * C)
+            if self.n1_clsb:
+                cb0 = self.n1_plain
+                d_cb = self.wref('d_cbout')
+                w_cb = self.wref('w1d', cb0 * 2 * mc + mc)
+                p0 = self.gemm(d_cb, self.pref(Wb), self.wref('d_w1d', cb0 * 2 * mc + mc), self.n1_clsb, mc, K, ldK,
+                               mc, 2 * mc, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=w_cb)
+                self.gemm_op(p0, side=side)
+                p0 = self.gemm(d_cb, w_cb, self.gref(Wb), K, mc, self.n1_clsb, ldK, 2 * mc, mc, a_mode=L.MODE_COL,
+                               b_mode=L.MODE_COL, accum=True, dbias=self.gref(bb))
+                self.gemm_op(p0, side=True)
+            p0 = self.gemm(d_w1d, self.pref(W2d), d_h1d, n1, 2 * C, 2 * mc, 2 * mc, 2 * C, 2 * C, a_mode=L.MODE_ROW,
+                           b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=h1d)
+            self.gemm_op(p0, side=side)
+            p0 = self.gemm(d_w1d, h1d, self.gref(W2d), 2 * mc, 2 * C, n1, 2 * mc, 2 * C, 2 * C, a_mode=L.MODE_COL,
+                           b_mode=L.MODE_COL, accum=True, dbias=self.gref(b2d))
+            self.gemm_op(p0, side=True)
+            p0 = self.gemm(d_h1d, self.pref(W1), (d_rows[0], d_rows[1] + 4 * M * C), n1, C, 2 * C, 2 * C, C, C,
+                           a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+            self.gemm_op(p0, side=side)
+            p0 = self.gemm(d_h1d, xe, self.gref(W1), 2 * C, C, n1, 2 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
+                           b_gather=self.r_src1, accum=True, dbias=self.gref(b1))
+            self.gemm_op(p0, side=True)
+
+        # The 1-D decoder backward needs the tile backward only: on the side stream beside the W2 dgrad instead of behind the
+        # decoder.fc backward on the chain; joined in front of the node-row gather that adds its rows
+        early_1d = bool(self.SIDE) and M > 0 and n1 > 0 and os.environ.get('GHN3_EARLY_1D', '1') != '0'
+        if early_1d:
+            decoder_1d_bwd(True)
+            self.op(L.OP_JOIN, ints=(1, 0))              # mark: the 1-D backward (waited for in front of the node-row gather)
         Wfc, bfc = 'decoder.fc.0.weight', 'decoder.fc.0.bias'
         W0, b0 = 'decoder.conv.0.weight', 'decoder.conv.0.bias'
         W2, b2 = 'decoder.conv.2.weight', 'decoder.conv.2.bias'
@@ -1745,35 +1795,8 @@ class Program:
                           b_mode=L.MODE_COL, a_gather=r_rows, b_gather=r_src, accum=True,
                           dbias=self.gref(bfc, p), dbias_stride=S2)
             self.gemm_op(p0, tag=self.TAG_D1_BWD, side=True, ctype=self.d1_bwd_ctype)
-        if n1 > 0:
-            mc = self.mc
-            W1, b1 = 'decoder_1d.fc.0.weight', 'decoder_1d.fc.0.bias'
-            W2d, b2d = 'decoder_1d.fc.2.weight', 'decoder_1d.fc.2.bias'
-            Wb, bb = 'bias_class.1.weight', 'bias_class.1.bias'
-            h1d, w1d, d_w1d = self.wref('h1d'), self.wref('w1d'), self.wref('d_w1d')
-            d_h1d = self.wsf('d_h1d', n1 * 2 * C)
-            if self.n1_clsb:
-                cb0 = self.n1_plain
-                d_cb = self.wref('d_cbout')
-                w_cb = self.wref('w1d', cb0 * 2 * mc + mc)
-                p0 = self.gemm(d_cb, self.pref(Wb), self.wref('d_w1d', cb0 * 2 * mc + mc), self.n1_clsb, mc, K, ldK,
-                               mc, 2 * mc, a_mode=L.MODE_ROW, b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=w_cb)
-                self.gemm_op(p0)
-                p0 = self.gemm(d_cb, w_cb, self.gref(Wb), K, mc, self.n1_clsb, ldK, 2 * mc, mc, a_mode=L.MODE_COL,
-                               b_mode=L.MODE_COL, accum=True, dbias=self.gref(bb))
-                self.gemm_op(p0, side=True)
-            p0 = self.gemm(d_w1d, self.pref(W2d), d_h1d, n1, 2 * C, 2 * mc, 2 * mc, 2 * C, 2 * C, a_mode=L.MODE_ROW,
-                           b_mode=L.MODE_COL, dact=L.DACT_RELU, aux_in=h1d)
-            self.gemm_op(p0)
-            p0 = self.gemm(d_w1d, h1d, self.gref(W2d), 2 * mc, 2 * C, n1, 2 * mc, 2 * C, 2 * C, a_mode=L.MODE_COL,
-                           b_mode=L.MODE_COL, accum=True, dbias=self.gref(b2d))
-            self.gemm_op(p0, side=True)
-            p0 = self.gemm(d_h1d, self.pref(W1), (d_rows[0], d_rows[1] + 4 * M * C), n1, C, 2 * C, 2 * C, C, C,
-                           a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
-            self.gemm_op(p0)
-            p0 = self.gemm(d_h1d, xe, self.gref(W1), 2 * C, C, n1, 2 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
-                           b_gather=self.r_src1, accum=True, dbias=self.gref(b1))
-            self.gemm_op(p0, side=True)
+        if not early_1d:
+            decoder_1d_bwd(False)
         # Everything above produces the decoder gradients (93 % of the gradient bytes at XL); a data-parallel caller
         # may run the program in two parts (bwd_ops[:bwd_split] + DETACH, then the rest) and start their all-reduce here.
         self.bwd_split = len(self._ops)
@@ -1783,6 +1806,8 @@ class Program:
         counts = np.bincount(all_src, minlength=rows)[:rows]
         seg_ptr = np.concatenate([[0], np.cumsum(counts)]).astype(np.int32)
         d_xe = self.wsf('d_xe', rows * C)
+        if early_1d:
+            self.op(L.OP_JOIN, ints=(2, 0))              # wait for the mark only: the W2 weight gradient keeps running
         self.op(L.OP_ROWSEG_SUM, refs=(d_xe, d_rows, self.idx(seg_ptr), self.idx(order)), ints=(rows, C, C, C, 0))
 
         # ---- final LayerNorm ----------------------------------------------------------------------------

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 12
+#define GHN3_ABI_VERSION 13
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -300,7 +300,10 @@ enum ghn3_op_kind {
      * i: n_desc, total work tiles, grid cap (0 = one workgroup per tile; > 0: at most that many workgroups stride
      * over the tiles -- side-stream copies that should leave HBM bandwidth to the chain they run under) */
     GHN3_OP_CAST16 = 23,
-    /* the run's stream waits for every GHN3_OPFLAG_SIDE op issued so far (no refs) */
+    /* i0 = 0: the run's stream waits for every GHN3_OPFLAG_SIDE op issued so far (no refs).
+     * i0 = 1: MARK -- remember the side-stream work issued so far under id i1 (0..3); i0 = 2: the run's stream waits for the
+     * work marked i1 only, later side-stream work keeps running (a short side-stream branch that rejoins the chain while a
+     * long one, e.g. the W2 weight gradient, continues).  A wait without a mark in the same run is a no-op.  (ABI v13) */
     GHN3_OP_JOIN = 24,
     /* as the LAST op of a run: return without joining the side stream; the pending side work is joined by the next
      * ghn3_run on the context (or observed with ghn3_ctx_side_wait).  Lets a caller split a program in two runs and

@@ -237,33 +237,40 @@ int ghn3_edge_hidden(float* hid, const float* Pfw, const float* Pbw, int V, int 
     return launch_ok("edge_hidden");
 }
 
-// dhid masked by (hid > 0) in place; dPfw[fw] = sum_bw dhid ; dPbw[bw] = sum_fw dhid
+// dhid masked by (hid > 0) in place; dPfw[fw] = sum_bw dhid ; dPbw[bw] = sum_fw dhid.
+// One workgroup per (table row, 64 columns): its four waves split the V terms of the sum four ways (independent loads in
+// flight) and add their partial sums in a fixed order -- V workgroups of one wave's worth of work each took 52 + 25 us at
+// the end of every backward, on an otherwise idle chip.
 __global__ __launch_bounds__(256) void edge_hidden_bwd_fw_kernel(float* __restrict__ dPfw, float* __restrict__ dhid,
                                                                  const float* __restrict__ hid, int V, int C) {
-    const int fw = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float acc = 0.f;
-        for (int bw = 0; bw < V; ++bw) {
+    __shared__ float part[4][64];
+    const int fw = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C)
+        for (int bw = w; bw < V; bw += 4) {
             const size_t o = ((size_t)fw * V + bw) * C + c;
-            float g = hid[o] > 0.f ? dhid[o] : 0.f;
+            const float g = hid[o] > 0.f ? dhid[o] : 0.f;
             dhid[o] = g;
             acc += g;
         }
-        dPfw[(size_t)fw * C + c] = acc;
-    }
+    part[w][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (w == 0 && c < C) dPfw[(size_t)fw * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 __global__ __launch_bounds__(256) void edge_hidden_bwd_bw_kernel(float* __restrict__ dPbw,
                                                                  const float* __restrict__ dhid, int V, int C) {
-    const int bw = blockIdx.x;
-    for (int c = threadIdx.x; c < C; c += 256) {
-        float acc = 0.f;
-        for (int fw = 0; fw < V; ++fw) acc += dhid[((size_t)fw * V + bw) * C + c];
-        dPbw[(size_t)bw * C + c] = acc;
-    }
+    __shared__ float part[4][64];
+    const int bw = blockIdx.x, c = blockIdx.y * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6;
+    float acc = 0.f;
+    if (c < C)
+        for (int fw = w; fw < V; fw += 4) acc += dhid[((size_t)fw * V + bw) * C + c];
+    part[w][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (w == 0 && c < C) dPbw[(size_t)bw * C + c] = (part[0][threadIdx.x] + part[1][threadIdx.x]) + (part[2][threadIdx.x] + part[3][threadIdx.x]);
 }
 int ghn3_edge_hidden_bwd(float* dPfw, float* dPbw, float* dhid, const float* hid, int V, int C, hipStream_t s) {
-    hipLaunchKernelGGL(edge_hidden_bwd_fw_kernel, dim3(V), dim3(256), 0, s, dPfw, dhid, hid, V, C);
-    hipLaunchKernelGGL(edge_hidden_bwd_bw_kernel, dim3(V), dim3(256), 0, s, dPbw, dhid, V, C);
+    hipLaunchKernelGGL(edge_hidden_bwd_fw_kernel, dim3(V, (C + 63) / 64), dim3(256), 0, s, dPfw, dhid, hid, V, C);
+    hipLaunchKernelGGL(edge_hidden_bwd_bw_kernel, dim3(V, (C + 63) / 64), dim3(256), 0, s, dPbw, dhid, V, C);
     return launch_ok("edge_hidden_bwd");
 }
 

@@ -1934,6 +1934,13 @@ class Program:
                 self._ops.extend(side_pending)
                 side_pending = []
             g_cur = g_out                   # d x_l
+        # ---- node embeddings (side stream: beside the edge-bias backward below, which does not depend on it) --------
+        self.op(L.OP_EMBED_BWD,
+                refs=(g_cur, r_types, r_shape, r_nn, r_noff, self.gref('embed.weight'),
+                      self.gref('shape_enc.embed_channel.weight'), self.gref('shape_enc.embed_spatial.weight'),
+                      self.gref('gnn.0.centrality_embed_in.weight'), self.gref('gnn.0.centrality_embed_out.weight'),
+                      self.gref('gnn.0.input_dist_embed.weight'), deg_in, deg_out, dist0),
+                ints=(B, N, C, len(bk.PRIMITIVES_DEEPNETS1M), self.vocab_rows[0], self.vocab_rows[1]), flags=self.SIDE)
         # ---- layer-0 edge bias: histogram -> table MLP backward ------------------------------------------
         E = 'gnn.0.attn.edge_embed.embed.weight'
         W0e, b0e = 'gnn.0.attn.proj_e.0.weight', 'gnn.0.attn.proj_e.0.bias'
@@ -1948,7 +1955,8 @@ class Program:
         self.op(L.OP_BIAS_HIST, refs=(dT, dBias, pair, hist), ints=(B, N, H, V))
         p0 = self.gemm(dT, hid, self.gref(W2e), H, C, V * V, ldT, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
                        accum=True, dbias=self.gref(b2e))
-        self.gemm(dT, self.pref(W2e), dhid, V * V, C, H, ldT, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
+        self.gemm_op(p0, side=True)                      # (weight gradient: off the chain)
+        p0 = self.gemm(dT, self.pref(W2e), dhid, V * V, C, H, ldT, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
         self.gemm_op(p0)
         self.op(L.OP_EDGE_HIDDEN_BWD, refs=(dPfw, dPbw, dhid, hid), ints=(V, C))
         p0 = self.gemm(dPfw, self.pref(E, 2 * C), self.gref(W0e, 0), C, C, V, C, C, 2 * C, a_mode=L.MODE_COL,
@@ -1961,10 +1969,3 @@ class Program:
         p0 = self.gemm(dPbw, self.pref(W0e, C), self.gref(E, 2 * C), V, C, C, C, 2 * C, C, a_mode=L.MODE_ROW,
                        b_mode=L.MODE_COL, accum=True)
         self.gemm_op(p0)
-        # ---- node embeddings ---------------------------------------------------------------------------------
-        self.op(L.OP_EMBED_BWD,
-                refs=(g_cur, r_types, r_shape, r_nn, r_noff, self.gref('embed.weight'),
-                      self.gref('shape_enc.embed_channel.weight'), self.gref('shape_enc.embed_spatial.weight'),
-                      self.gref('gnn.0.centrality_embed_in.weight'), self.gref('gnn.0.centrality_embed_out.weight'),
-                      self.gref('gnn.0.input_dist_embed.weight'), deg_in, deg_out, dist0),
-                ints=(B, N, C, len(bk.PRIMITIVES_DEEPNETS1M), self.vocab_rows[0], self.vocab_rows[1]))

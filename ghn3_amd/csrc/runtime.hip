@@ -569,7 +569,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             static const bool split_small = !(getenv("GHN3_SPLIT_SMALL_LAUNCH") && atoi(getenv("GHN3_SPLIT_SMALL_LAUNCH")) == 0);
             bool has28 = false, has16 = false;
             for (const Launch& L : op_launches[k]) { has28 |= L.tile == 28; has16 |= L.tile == 16; }
-            const bool beside = split_small && !on_side && c->side_enabled && c->profile != 1 && has28 && has16;
+            const bool beside = split_small && (o.flags & GHN3_OPFLAG_BESIDE) && !on_side && c->side_enabled && c->profile != 1 &&
+                                has28 && has16;
             if (beside) {
                 HIPCHK(hipEventRecord(c->ev_fork, main_stream));
                 HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));

@@ -67,7 +67,6 @@ EXPORTS = ['ghn3_abi_version', 'ghn3_last_error', 'ghn3_ctx_create', 'ghn3_ctx_d
            'ghn3_profile_read_tags']
 OPFLAG_TIMED = 0x100
 OPFLAG_SIDE = 0x200
-OPFLAG_BESIDE = 0x400
 
 _lib = None
 _lock = threading.Lock()

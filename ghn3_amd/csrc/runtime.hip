@@ -562,22 +562,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         }
         switch (o.kind) {
         case GHN3_OP_NOP: break;
-        case GHN3_OP_GEMM: {
-            // An op whose problems split into an 8-phase launch (tile 28) and a 128 x 128 launch for its small families
-            // (fewer than 160 rows) runs the small launch on the side stream beside the big one: the problems of an op are
-            // independent, and the small tiles fill the tail of the big launch instead of waiting behind it.
-            static const bool split_small = !(getenv("GHN3_SPLIT_SMALL_LAUNCH") && atoi(getenv("GHN3_SPLIT_SMALL_LAUNCH")) == 0);
-            bool has28 = false, has16 = false;
-            for (const Launch& L : op_launches[k]) { has28 |= L.tile == 28; has16 |= L.tile == 16; }
-            const bool beside = split_small && (o.flags & GHN3_OPFLAG_BESIDE) && !on_side && c->side_enabled && c->profile != 1 &&
-                                has28 && has16;
-            if (beside) {
-                HIPCHK(hipEventRecord(c->ev_fork, main_stream));
-                HIPCHK(hipStreamWaitEvent(c->side, c->ev_fork, 0));
-            }
-            hipStream_t const op_stream = stream;
+        case GHN3_OP_GEMM:
             for (const Launch& L : op_launches[k]) {
-                hipStream_t stream = (beside && L.tile == 16) ? c->side : op_stream;
                 if (L.tile >= 4000)
                     rc = ghn3_gemm_x3_launch(ds + L.first, L.count, L.tiles, 40 + (L.tile - 4000) / 10,
                                              64 * (L.tile % 10), stream);
@@ -601,12 +587,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                           (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, stream);
                 if (rc) break;
             }
-            if (beside && !rc) {                         // the op is complete when both launches are
-                HIPCHK(hipEventRecord(c->ev_join, c->side));
-                HIPCHK(hipStreamWaitEvent(main_stream, c->ev_join, 0));
-            }
             break;
-        }
         case GHN3_OP_GRAPH_PROLOGUE:
             rc = ghn3_graph_prologue(R.get<const int64_t>(o.r[0]), R.get<int>(o.r[1]), R.get<int>(o.r[2]),
                                      R.get<int>(o.r[3]), R.get<int>(o.r[4]), (int)o.i[0], (int)o.i[1], (int)o.i[2],

@@ -417,7 +417,7 @@ class Program:
     TAG_NAMES = {1: 'w2_fwd', 2: 'w2_dgrad', 3: 'w2_wgrad', 4: 'w0_fwd', 5: 'fc_fwd', 6: 'tile_fwd', 7: 'tile_bwd',
                  8: 'w0_bwd', 9: 'fc_bwd'}
 
-    def gemm_op(self, first, count=None, tile=0, ctype=None, tag=0, side=False, flops=None, grid_cap=0, beside=False):
+    def gemm_op(self, first, count=None, tile=0, ctype=None, tag=0, side=False, flops=None, grid_cap=0):
         if count is None:
             count = len(self._probs) - first
         if count > 0:
@@ -426,8 +426,6 @@ class Program:
             flags = 0 if ctype is None else 1 + ctype
             if side:
                 flags |= self.SIDE
-            if beside and self.SIDE:
-                flags |= L.OPFLAG_BESIDE
             if tag:
                 flags |= L.OPFLAG_TIMED | (tag << 16)
                 fl = flops if flops is not None else \
@@ -1689,7 +1687,7 @@ class Program:
                           b_qs=(g['i_ld'], ms[1]), ksplit=ks)
             p8_dgrad = planes and any(g.get('p8') for g in g16)
             self.gemm_op(p0, ctype=bct if g16 else None, tag=self.TAG_D3_DGRAD, flops=fl,
-                         tile=28 if p8_dgrad else 20 if use_rect else 0, beside=True)
+                         tile=28 if p8_dgrad else 20 if use_rect else 0)
             self._ops.extend(late_ops)
             if (planes or planes32) and n_planes > 1:
                 self.op(L.OP_DACT, refs=(d_u, u, amax_u if amax_u is not None else self.NONE, d_up),

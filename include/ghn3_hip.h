@@ -402,10 +402,6 @@ int ghn3_event_destroy(void* ev);
  * program must not let later main-stream ops touch what a pending side op reads or writes (used for weight
  * gradients and operand copies that are off the critical path).  GHN3_NO_SIDE_STREAM=1 serialises everything. */
 #define GHN3_OPFLAG_SIDE 0x200
-/* GHN3_OP_GEMM on the run's stream whose problems split into an 8-phase launch (tile 28) and a 128 x 128 launch of small
- * families: the small launch may run on the side stream beside the big one (joined inside the op).  Worth it where the
- * side stream is busy anyway (the backward); in a forward-only run the cross-stream hand-off costs more than it saves. */
-#define GHN3_OPFLAG_BESIDE 0x400
 int ghn3_profile_enable(ghn3_ctx* ctx, int mode);
 int ghn3_profile_read(ghn3_ctx* ctx, double* ms_per_kind /* [GHN3_OP_KIND_COUNT] */,
                       int64_t* launches_per_kind, int reset);

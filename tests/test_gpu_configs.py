@@ -34,8 +34,26 @@ def _cfg(name):
     return dict(CFGS[name], weight_norm=True, ve=True, layernorm=True)
 
 
+_MODELS = {}
+
+
+def _models(name, compute):
+    """(HIP model, oracle) per (configuration, mode), built once per test session: constructing the 654 M-parameter oracle and
+    its seeded state dict costs ~40 s -- more than the comparison itself."""
+    key = (name, compute)
+    if key not in _MODELS:
+        if len(_MODELS) >= 2:                             # (two XL pairs hold ~16 GB of host memory)
+            _MODELS.pop(next(iter(_MODELS)))
+        _MODELS[key] = make_models(_cfg(name), 7, compute=compute)
+    hip, oracle = _MODELS[key]
+    for p in hip.parameters():
+        p.grad = None
+    oracle.zero_grad(set_to_none=True)
+    return hip, oracle
+
+
 def _fwd_bwd_vs_oracle(name, nodes, seed, compute, tol_f, tol_g):
-    hip, oracle = make_models(_cfg(name), 7, compute=compute)
+    hip, oracle = _models(name, compute)
     nets_h, gb_h, nets_o, gb_o = synthetic_case(nodes, seed)
     hip.train()
     nets_h = hip(nets_h, gb_h, keep_grads=True)
@@ -66,7 +84,7 @@ def _fwd_bwd_vs_oracle(name, nodes, seed, compute, tol_f, tol_g):
                                                                                     worst_g))
 
 
-@pytest.mark.parametrize('nodes,seed', [([40], 40000), ([28, 36], 36000), ([120], 120000)])
+@pytest.mark.parametrize('nodes,seed', [([28, 36], 36000), ([120], 120000)])
 def test_ghn3xlm16_f16_forward_backward_vs_oracle(nodes, seed):
     """The benchmarked model and mode (ghn3xlm16, f16 decoder operands with power-of-two scaled gradient copies, 256 x 128
     partial-plane dgrad, band wgrad): per-parameter gradients and every predicted tensor against the oracle.  B = 2 with

@@ -100,6 +100,9 @@ def cpu_baseline(model, sample_nodes, seed, graphs=1):
     t = float(np.median(times))
     return {'value': n_pred / t, 'unit': 'predicted-params/s', 'cores': cores, 'kind': 'port',
             'host_cpus': os.cpu_count(), 'usable_cpus': usable_cores(),
+            'threads_note': 'threads = the cgroup CPU quota (<= 16); measured once on a GPU box, 256 logical CPUs behind a quota of '
+                            '16: 16 threads 26.1 s per step, 64 threads 39.6 s, 256 threads 581 s '
+                            '(profiles/r03n_cpu_baseline_threads_256_64_16.txt)',
             'sample': '%s fwd+bwd (sum of Frobenius norms loss), %d synthetic %d-node graph(s), seed %d (%d predicted '
                       'params), fp32, torch %s CPU ops, %d threads, %.1f s per step (%d run%s)'
                       % (model, graphs, sample_nodes, seed, n_pred, torch.__version__, cores, t, len(times),

@@ -88,15 +88,18 @@ def cpu_baseline(model, sample_nodes, seed, graphs=1):
         _, pred = oracle(nets, go, keep_grads=True)
         loss = sum(torch.norm(t, p='fro') for (_, _, _, t) in pred)
         loss.backward()
+    # median of three runs (>= 3 at ghn3xlm16 -- ~3 x 28 s on the GPU box's 16 usable cores); samples that run
+    # in seconds get an untimed warm-up first (allocator, thread pool)
+    runs = int(os.environ.get('GHN3_CPU_RUNS', '3'))
     t0 = time.time()
     step()
-    t1 = time.time() - t0
-    times = [t1]
-    if t1 < 5:                                   # small samples: median of three
-        for _ in range(2):
-            t0 = time.time()
-            step()
-            times.append(time.time() - t0)
+    times = [time.time() - t0]
+    if times[0] < 5:
+        times = []
+    while len(times) < runs:
+        t0 = time.time()
+        step()
+        times.append(time.time() - t0)
     t = float(np.median(times))
     return {'value': n_pred / t, 'unit': 'predicted-params/s', 'cores': cores, 'kind': 'port',
             'host_cpus': os.cpu_count(), 'usable_cpus': usable_cores(),
@@ -104,9 +107,9 @@ def cpu_baseline(model, sample_nodes, seed, graphs=1):
                             '16: 16 threads 26.1 s per step, 64 threads 39.6 s, 256 threads 581 s '
                             '(profiles/r03n_cpu_baseline_threads_256_64_16.txt)',
             'sample': '%s fwd+bwd (sum of Frobenius norms loss), %d synthetic %d-node graph(s), seed %d (%d predicted '
-                      'params), fp32, torch %s CPU ops, %d threads, %.1f s per step (%d run%s)'
+                      'params), fp32, torch %s CPU ops, %d threads, median %.1f s per step of %d runs (%s)'
                       % (model, graphs, sample_nodes, seed, n_pred, torch.__version__, cores, t, len(times),
-                         's' if len(times) > 1 else '')}
+                         ', '.join('%.1f' % v for v in times))}
 
 
 _WORKER_NICED = False
@@ -176,10 +179,12 @@ def main():
                     help='skip the forward-only / fresh-graph / f32-mode measurements (profiling runs)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--profile-ops', action='store_true', help='print per-op-kind time of one extra step')
-    ap.add_argument('--grad-allreduce', default=os.environ.get('GHN3_GRAD_ALLREDUCE', 'bf16'),
+    ap.add_argument('--grad-allreduce', default=os.environ.get('GHN3_GRAD_ALLREDUCE', 'f32'),
                     choices=['f32', 'bf16', 'f32-serial'],
-                    help='N > 1: gradient exchange.  bf16 / f32 = two-phase all-reduce overlapped with the backward '
-                         '(bf16 copies on the wire or fp32); f32-serial = one fp32 all-reduce after the backward')
+                    help='N > 1: gradient exchange.  f32 (default: what DistributedDataParallel does, trainer.py:136) / bf16 = '
+                         'all-reduce overlapped with the backward, fp32 or bf16 copies on the wire; f32-serial = one fp32 '
+                         'all-reduce after the backward.  The line of the default also carries the bf16-wire timing as '
+                         '`bf16_wire` (an extra, lower-precision figure: never `value`)')
     ap.add_argument('--force-ddp', action='store_true', help='run the N > 1 code path in a 1-rank group (testing)')
     args = ap.parse_args()
 
@@ -241,13 +246,16 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     dout = torch.empty(prog.out_numel, dtype=torch.float32, device=dev)
 
+    exchange = {'on': True, 'reducer': reducer}
+
     def run_step(model, pl, d_out, norms):
         model._run_forward(pl)
         model._fill_bufs(pl, out=pl.out, dout=d_out)
         ctx.run(norms[0], pl.program.problems, pl.bufs, stream)
         ctx.run(norms[1], pl.program.problems, pl.bufs, stream)
-        model._run_backward(pl, d_out, reducer=reducer)
-        if ddp and reducer is None:
+        red = exchange['reducer'] if exchange['on'] else None
+        model._run_backward(pl, d_out, reducer=red)
+        if ddp and red is None and exchange['on']:
             all_reduce_flat_grads(pl.gflat)
 
     def step():
@@ -279,6 +287,50 @@ def main():
     total_pred = float(n_all.item())
 
     extras = {}
+    if ddp:
+        # What the N > 1 line needs to be judged: proof that RCCL spans all ranks (an all-reduce of ones), the EXPOSED cost
+        # of the gradient exchange (step with it - the same step without any collective), the exchange alone (serial, not
+        # overlapped) and -- for the default fp32 wire -- the bf16-wire variant as an extra figure.
+        def timed(n):
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            t_ = time.perf_counter()
+            for _ in range(n):
+                step()
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            tt = torch.tensor([time.perf_counter() - t_], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            return 1e3 * float(tt.item()) / n
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        n_x = max(5, args.steps // 4)
+        exchange['on'] = False
+        compute_ms = timed(n_x)
+        exchange['on'] = True
+        torch.cuda.synchronize()
+        ea, eb = L.Event(), L.Event()
+        ea.record(stream)
+        for _ in range(3):
+            all_reduce_flat_grads(plan.gflat)
+        eb.record(stream)
+        serial_ms = ea.elapsed_ms(eb) / 3
+        extras['rccl_ranks'] = int(round(float(ones.item())))
+        extras['exchange_ms'] = {'exposed': 1e3 * elapsed / args.steps - compute_ms, 'compute_only_ms_per_step': compute_ms,
+                                 'serial_fp32_allreduce': serial_ms, 'gradient_bytes': int(plan.gflat.numel()) * 4,
+                                 'wire': args.grad_allreduce}
+        if args.grad_allreduce == 'f32':
+            exchange['reducer'] = FlatGradReducer(compress='bf16', force=args.force_ddp)
+            for _ in range(2):
+                step()
+            b16 = timed(n_x)
+            exchange['reducer'] = reducer
+            extras['bf16_wire'] = {'ms_per_step': b16, 'value': total_pred / (b16 * 1e-3),
+                                   'note': 'same step with bf16 copies of the gradients on the wire (fp32 local sums): lower '
+                                           'precision than the reference DDP exchange -- reported beside, never as `value`'}
     if world == 1 and not args.no_extras and not args.force_ddp:
         # (a) forward only: the north star's target is stated on the Graphormer + decoder FORWARD
         ev0, ev1 = L.Event(), L.Event()

@@ -1084,7 +1084,7 @@ void gemm_h16w_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int to
 //     the phase BEFORE the one that reads it; the barriers in between make every wave's pieces visible.
 // Same operand / epilogue contract as gemm_h16d_kernel (k-map, ragged extents, split-K, row-vector epilogue).
 //
-// MEASURED (round 2, MI355X, f16, tests/gemm_bench.py shapes) and therefore OFF by default (GHN3_PINGPONG=1 selects it):
+// MEASURED (round 2, MI355X, f16, tools/diag/gemm_bench.py shapes) and therefore OFF by default (GHN3_PINGPONG=1 selects it):
 //   4096^3 847 TF (two-stage kernel 934), 8192^3 874 (854), W2 forward 768 x 147456 x 3072 854 (870), wgrad band 512 (546).
 // Ablations of this kernel (GHN3_PP_DEBUG): without the DMA 1150-1390 TF-equivalent, without the MFMAs 1160-1710, without
 // the fragment reads 902-933 -- the DMA stream and the matrix work each take ~60 % of the time of the full kernel and

@@ -61,6 +61,7 @@ struct ghn3_ctx {
     hipEvent_t ev_fork, ev_join, ev_mark[4];
     bool side_enabled;
     bool side_pending;     // a run ended with GHN3_OP_DETACH: its side-stream work has not been joined yet
+    bool mark_set[4];      // GHN3_OP_JOIN marks survive a DETACHed run: a later run of the same context may wait for them
 };
 
 static int ctx_reserve(ghn3_ctx* c, size_t n) {
@@ -223,7 +224,8 @@ static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
     // of the op it cannot take run on the 64 x 64 fp32 tiles
     if (forced == 48) {
         const bool ok = p.a_mode == GHN3_MODE_COL && p.b_mode == GHN3_MODE_COL && p.ksplit <= 1 && (p.M & 3) == 0 &&
-                        (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.C.off & 15) == 0 && p.a_gather.buf < 0 &&
+                        (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.C.off & 15) == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 &&
+                        (p.A.off & 15) == 0 && (p.B.off & 15) == 0 && p.a_gather.buf < 0 &&
                         p.b_gather.buf < 0 && p.c_gather.buf < 0 && !p.a_q && !p.b_q && !p.c_q && !p.bias_q &&
                         p.act == GHN3_ACT_NONE && p.dact == GHN3_DACT_NONE && p.residual.buf < 0 && p.aux_out.buf < 0 &&
                         (p.bias.buf < 0 || (p.flags & GHN3_GEMM_BIASGRAD));
@@ -504,16 +506,24 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
     // side stream waits for everything the main stream has been given so far (program order = dependency order);
     // the main stream waits for the side stream at GHN3_OP_JOIN and at the end of the run.
     hipStream_t const main_stream = stream;
-    bool main_dirty = true, side_dirty = c->side_pending;
+    // A run without side-stream ops or joins (e.g. the local passes of the gradient exchange, issued from the
+    // communication stream between two parts of a backward) leaves the pending side work of a DETACHed run alone: it is
+    // still joined by the next run that does use the side stream, or observed with ghn3_ctx_side_wait.
+    bool touches_side = false;
+    for (int k = 0; k < n_ops && !touches_side; ++k)
+        touches_side = ((ops[k].flags & GHN3_OPFLAG_SIDE) && c->side_enabled) || ops[k].kind == GHN3_OP_JOIN ||
+                       ops[k].kind == GHN3_OP_DETACH;
+    bool main_dirty = true, side_dirty = touches_side && c->side_pending;
     bool detach = false;
-    bool mark_set[4] = {false, false, false, false};
-    c->side_pending = false;
+    bool* const mark_set = c->mark_set;                  // (kept across runs: a MARK in one part, its WAIT in a later one)
+    if (touches_side) c->side_pending = false;
     auto join = [&]() -> int {
         if (side_dirty) {
             HIPCHK(hipEventRecord(c->ev_join, c->side));
             HIPCHK(hipStreamWaitEvent(main_stream, c->ev_join, 0));
             side_dirty = false;
         }
+        for (int i = 0; i < 4; ++i) mark_set[i] = false;    // everything marked so far has been waited for
         return GHN3_OK;
     };
     for (int k = 0; k < n_ops; ++k) {
@@ -774,6 +784,9 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
     };
     if (detach && side_dirty) {                          // joined by the next run / ghn3_ctx_side_wait
         c->side_pending = true;
+        return mark_done();
+    }
+    if (!touches_side) {                                 // (side state untouched, see above)
         return mark_done();
     }
     int rc_join = join();

@@ -160,12 +160,6 @@ class DeepNets1MDDP(SampledNets, torch.utils.data.Dataset):
             num_nets = 10 ** 6 if self.is_train else 500
         SampledNets.__init__(self, num_nets=num_nets, large_images=large_images, seed=seed, virtual_edges=virtual_edges,
                              max_nodes=max_nodes, light=light, verbose=verbose)
-        self._nodes = {}                                        # node counts of the graphs built so far (check_batch)
-
-    def __getitem__(self, idx):
-        g = SampledNets.__getitem__(self, idx)
-        self._nodes[int(idx)] = int(g.n_nodes)
-        return g
 
     @staticmethod
     def loader(meta_batch_size=1, dense=True, num_workers=None, **kwargs):
@@ -174,16 +168,33 @@ class DeepNets1MDDP(SampledNets, torch.utils.data.Dataset):
         sampler = NetBatchSamplerDDP(nets, meta_batch_size) if nets.is_train else None
         if num_workers is None:                                 # (deepnets1m.py:74)
             num_workers = (0 if meta_batch_size <= 1 else min(8, max(4, meta_batch_size // 2))) if nets.is_train else 0
+        # The node budget of a meta-batch (deepnets1m.py:299 filters on node counts precomputed in the hdf5 file) is applied
+        # where the counts exist: in the collate function, which runs in the worker that built the graphs.
+        cap = sampler.max_nodes_batch if sampler is not None else None
         loader = torch.utils.data.DataLoader(nets, batch_sampler=sampler, batch_size=1, pin_memory=False,
-                                             collate_fn=partial(GraphBatch, dense=dense), num_workers=num_workers)
+                                             collate_fn=partial(collate_capped, dense=dense, max_nodes_batch=cap),
+                                             num_workers=num_workers)
         return (loader, sampler) if nets.is_train else loader   # (the sampler is returned for distributed training)
+
+
+def collate_capped(graphs, dense=True, max_nodes_batch=None):
+    """GraphBatch of a meta-batch under the node budget of deepnets1m.py:288-300.  The reference skips a meta-batch whose
+    precomputed node counts exceed the budget; this stream has no precomputed counts (architectures are sampled, their
+    graphs built by the loader workers), so the budget is enforced here, after the graphs exist: graphs are dropped from
+    the end of the meta-batch until it fits (at least one is kept)."""
+    graphs = list(graphs)
+    if max_nodes_batch is not None:
+        while len(graphs) > 1 and sum(int(g.n_nodes) for g in graphs) > max_nodes_batch:
+            graphs.pop()
+    return GraphBatch(graphs, dense=dense)
 
 
 class NetBatchSamplerDDP(torch.utils.data.BatchSampler):
     """deepnets1m.py:281-319: endless sampler of meta-batches.  Every epoch is a permutation of the dataset drawn from
     (seed, epoch) -- the same on all ranks -- of which rank r takes the indices r, r + W, r + 2 W ... (DistributedSampler's
-    rule, padded by wrapping around to a multiple of the world size), so the ranks train on disjoint architectures;
-    meta-batches whose graphs are known to hold more than ``max_nodes_batch`` nodes are skipped."""
+    rule, padded by wrapping around to a multiple of the world size), so the ranks train on disjoint architectures.  The
+    node budget ``max_nodes_batch`` is applied by the loader's collate function (``collate_capped``): node counts only
+    exist once a worker has built the graphs."""
 
     def __init__(self, deepnets, meta_batch_size=1, seed=0):
         from .ddp_utils import is_ddp, get_ddp_rank
@@ -206,10 +217,6 @@ class NetBatchSamplerDDP(torch.utils.data.BatchSampler):
         perm = np.concatenate([perm, perm[:total - n]])
         return perm[self.rank:total:self.world]
 
-    def check_batch(self, batch):
-        known = getattr(self.dataset, '_nodes', {})
-        return self.max_nodes_batch is None or sum(known.get(int(i), 0) for i in batch) <= self.max_nodes_batch
-
     def __len__(self):
         return (len(self.dataset) // self.world + self.batch_size - 1) // self.batch_size
 
@@ -220,10 +227,9 @@ class NetBatchSamplerDDP(torch.utils.data.BatchSampler):
             for idx in self.epoch_indices(epoch):
                 batch.append(int(idx))
                 if len(batch) == self.batch_size:
-                    if self.check_batch(batch):
-                        yield batch
+                    yield batch
                     batch = []
-            if len(batch) > 0 and not self.drop_last and self.check_batch(batch):
+            if len(batch) > 0 and not self.drop_last:
                 yield batch
             epoch += 1
             if not self.dataset.is_train:

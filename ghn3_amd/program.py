@@ -766,7 +766,7 @@ class Program:
         4 K_slice (BM + BN), so narrow outputs (N <= 512: to_out, ff.net.3, the dgrads of to_qkv / ff.net.0) take 32 x 32
         tiles and -- where the consumer is a LayerNorm op that can sum partial planes -- K slices of 192 (then 128, 64)
         run by different workgroup sets; wide outputs (to_qkv, ff.net.0, ff.net.3 dgrad) took 32 x 64 tiles over the whole
-        K = C until round 2 (see below).  Measured at ghn3xlm16 (tests/x3_bench.py, us per dependent launch, exact-fp32 kernel in brackets):
+        K = C until round 2 (see below).  Measured at ghn3xlm16 (tools/diag/x3_bench.py, us per dependent launch, exact-fp32 kernel in brackets):
         to_qkv 6.4 (9.9), to_out 4.4 (6.5), ff.net.0 6.4 (10.3), ff.net.3 7.3 (10.0 with its two K halves)."""
         nk = K // 64
         whole = max(d for d in (6, 4, 3, 2, 1) if nk % d == 0)         # k-tiles per slice without a split
@@ -1740,7 +1740,7 @@ class Program:
                                self.gref(W2), g['cols'], 8 * C, g['rows'], g['ld'], 8 * C, 8 * C,
                                a_mode=L.MODE_COL, b_mode=L.MODE_COL, c_qs=(g['i_ld'], ms[1]),
                                accum=not full, dbias=self.gref(b2))
-                # short reduction (K = rows of the group): 64x64 tiles beat 128x128 here (tests/gemm_bench.py)
+                # short reduction (K = rows of the group): 64x64 tiles beat 128x128 here (tools/diag/gemm_bench.py)
                 self.gemm_op(p0, tile=64 if g['rows'] <= 1024 else 0, ctype=bct if g16 else None,
                              tag=self.TAG_D3_WGRAD, side=True)
             self.bwd_cut_w2 = len(self._ops)             # every op that writes dW2 has been issued

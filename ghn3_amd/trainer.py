@@ -119,6 +119,7 @@ class Trainer:
         self.amp_check_interval = int(unused.pop('amp_check_interval', 25))
         self.loss_scale = max(self.amp_min_scale, float(amp_init_scale)) if amp else 1.0
         self._clean_steps = 0
+        self._amp_hot = False            # an overflow was seen at the last check: check every step until a clean one
         # grad_compress: None = fp32 on the wire (what DistributedDataParallel does, trainer.py:136); 'bf16' halves the xGMI
         # bytes at ~3 significant digits per gradient element (torch's bf16_compress_hook trade-off) -- opt-in
         self.ddp = is_ddp()
@@ -136,6 +137,9 @@ class Trainer:
             state = torch.load(ckpt, map_location='cpu')
             model.load_state_dict(state['state_dict'])
             self.start_epoch, self.start_step = int(state.get('epoch', 0)), int(state.get('step', 0))
+            if amp and 'amp_loss_scale' in state:        # (a resumed run does not repeat the warm-down from 65536)
+                self.loss_scale = max(self.amp_min_scale, float(state['amp_loss_scale']))
+                self._clean_steps = int(state.get('amp_clean_steps', 0))
         self._model = model
         if self.ddp:
             sync_parameters(model)                       # what DistributedDataParallel's constructor does
@@ -226,32 +230,40 @@ class Trainer:
             self.metrics.update(torch.nan_to_num(vec[:len(self.metrics.names)]) * good, good * n)
         self._step += 1
         self._steps_since_check = getattr(self, '_steps_since_check', 0) + 1
-        if self.amp and self._steps_since_check >= self.amp_check_interval:
+        if self.amp and (self._amp_hot or self._steps_since_check >= self.amp_check_interval):
             self._sync_skips()
         return self.metrics
 
     def _sync_skips(self):
-        """One host read of the device-side skip counter: loss-scale back-off / growth (GradScaler's rule, applied with a
-        delay of at most amp_check_interval steps), the optimizer's bias-correction step count (a skipped update must not
-        advance it), and the reference's refusal to train on non-finite losses (trainer.py:240-257 raises)."""
+        """One host read of the device-side skip counter: loss-scale back-off / growth (GradScaler's rule), the optimizer's
+        bias-correction step count (a skipped update must not advance it), and the reference's refusal to train on
+        non-finite losses (trainer.py:240-257 raises).
+
+        The host copy of the scale only changes here, so every step of the window since the last check ran at ONE scale:
+        however many of them overflowed, that is one back-off (GradScaler halves once per overflowing step, each at a new
+        scale).  After an overflow the check runs every step until a clean one (`_amp_hot`), so the warm-down from 65536
+        takes as many steps as GradScaler's.  The run is declared diverged only when a whole window was skipped although
+        its scale was already at the floor when the window STARTED (or without AMP, where no scale can be blamed)."""
         total = int(getattr(self, '_skipped', torch.zeros(())).item())
         new = total - self.skipped_updates
         steps = getattr(self, '_steps_since_check', 0)
+        if steps == 0 and new == 0:
+            return                                       # nothing ran since the last check
         self._steps_since_check = 0
         self.skipped_updates = total
         if new > 0:
             self._optimizer.steps = max(0, self._optimizer.steps - new)
-            self._bad_checks = getattr(self, '_bad_checks', 0) + 1
+            window_scale = self.loss_scale               # the scale every step of this window used
             if self.amp:
-                self.loss_scale = max(self.amp_min_scale, self.loss_scale * 0.5 ** min(new, 16))
+                self.loss_scale = max(self.amp_min_scale, self.loss_scale * 0.5)
                 self._clean_steps = 0
-            if steps > 0 and new >= steps and (not self.amp or self.loss_scale <= self.amp_min_scale):
-                # every step since the last check was skipped and the scale cannot shrink further: the loss itself is
-                # non-finite -- the model has diverged (the reference raises at the first such batch)
+                self._amp_hot = True
+            if steps > 0 and new >= steps and (not self.amp or window_scale <= self.amp_min_scale):
                 raise RuntimeError('the loss / gradient norm was not finite in all of the last %d steps (%d skipped '
-                                   'updates in total): the GHN has diverged' % (steps, total))
+                                   'updates in total%s): the GHN has diverged'
+                                   % (steps, total, ', loss scale at its floor %g' % window_scale if self.amp else ''))
         else:
-            self._bad_checks = 0
+            self._amp_hot = False
             if self.amp:
                 self._clean_steps += steps
                 if self._clean_steps >= self.amp_growth_interval:
@@ -262,6 +274,9 @@ class Trainer:
     def save(self, epoch, step, config, save_freq=300, interm_epoch=5):
         if not ((((step + 1) % save_freq == 0) or step == self.n_batches - 1) and self.rank == 0):
             return
+        self._sync_skips()          # (the optimizer's bias-correction count must not include skipped steps when it is saved)
+        if self.amp:
+            config = dict(config or {}, amp_loss_scale=self.loss_scale, amp_clean_steps=self._clean_steps)
         save_checkpoint(self.checkpoint_path, self._model, self._optimizer, epoch, step, config)
         log('\nsaved the checkpoint to {} at epoch={}, step={}'.format(self.checkpoint_path, epoch, step))
         if (epoch + 1) % interm_epoch == 0 or epoch == 0:

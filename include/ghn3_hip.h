@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 13
+#define GHN3_ABI_VERSION 14
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -303,7 +303,10 @@ enum ghn3_op_kind {
     /* i0 = 0: the run's stream waits for every GHN3_OPFLAG_SIDE op issued so far (no refs).
      * i0 = 1: MARK -- remember the side-stream work issued so far under id i1 (0..3); i0 = 2: the run's stream waits for the
      * work marked i1 only, later side-stream work keeps running (a short side-stream branch that rejoins the chain while a
-     * long one, e.g. the W2 weight gradient, continues).  A wait without a mark in the same run is a no-op.  (ABI v13) */
+     * long one, e.g. the W2 weight gradient, continues).  Marks belong to the context and survive a run that ends in
+     * GHN3_OP_DETACH, so the wait may be issued by a LATER run (the parts of a data-parallel backward); a full join clears
+     * them, a wait without a pending mark is a no-op.  A run without side-stream ops / JOIN / DETACH leaves the side-stream
+     * state of the context untouched.  (ABI v14) */
     GHN3_OP_JOIN = 24,
     /* as the LAST op of a run: return without joining the side stream; the pending side work is joined by the next
      * ghn3_run on the context (or observed with ghn3_ctx_side_wait).  Lets a caller split a program in two runs and

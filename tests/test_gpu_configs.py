@@ -266,7 +266,7 @@ def test_f16_mode_agrees_with_the_fp32_mode_on_varied_batches(name, batches):
     every parameter gradient within 1.5e-3, everything finite.  (Weights: the seeded state dict of the oracle tests.  With
     torch's default initialisation one hidden unit of decoder_1d had a pre-activation of 3e-6 rms on the -- identical --
     padded rows that quirk Q1 makes 68 bias / norm nodes read: its ReLU mask differs between any two arithmetics that differ at
-    1e-5, the gradients downstream of it by 1 %.  Measured, understood, not a defect of either mode: tests/modes_diag*.py.)"""
+    1e-5, the gradients downstream of it by 1 %.  Measured, understood, not a defect of either mode: tools/diag/modes_diag*.py.)"""
     from ghn3_amd import GHN3
     from ghn3_amd.synthetic import synthetic_batch
     import recipe

@@ -107,11 +107,51 @@ def test_trainer_dynamic_loss_scale():
     tr.update(images, targets, _batch(['resnet_tiny']))
     tr.update(images * float('inf'), targets, _batch(['resnet_tiny']))     # overflow -> skipped, scale halves at the check
     assert tr.loss_scale == 2048.0 and tr.skipped_updates == 1
-    for _ in range(4):
+    for _ in range(5):                   # (after an overflow every step is checked until a clean one, then every second)
         tr.update(images, targets, _batch(['resnet_tiny']))
-    assert tr.loss_scale == 4096.0                                         # four clean steps: doubled
+    assert tr.loss_scale == 4096.0                                         # four clean steps seen by the host: doubled
     torch.cuda.synchronize()
     assert torch.isfinite(hip._flat).all()
+
+
+def test_trainer_loss_scale_warm_down_from_the_default(tmp_path):
+    """The normal fp16 warm-down (GradScaler: 65536 -> a scale the gradients fit, one halving per overflowing step) must not
+    be mistaken for divergence: several consecutive overflow steps inside one check window are ONE back-off (they all ran at
+    the same scale), after an overflow every step is checked, and the run only counts as diverged when a whole window
+    overflows at a scale that was already at the floor when the window started.  The scale travels in the checkpoint."""
+    from ghn3_amd import Trainer
+    hip, _ = make_models(dict(recipe.TINY_CFG), recipe.TINY_SEED)
+    tr = Trainer(hip, 'adamw', {'lr': 1e-4}, 'cosine', n_batches=100, grad_clip=5, device='cuda', epochs=2, amp=True,
+                 log_interval=10, save_dir=str(tmp_path))          # defaults: 65536 at start, floor 1024, check every 25
+    assert tr.loss_scale == 65536.0 and tr.amp_min_scale == 1024.0
+    images = torch.randn(2, 3, 32, 32)
+    targets = torch.tensor([1, 2])
+    bad = images * float('inf')
+    # steps 1-4 overflow (as they would at 65536 .. 8192 for gradients that fit at 4096)
+    for step in range(4):
+        tr.update(bad, targets, _batch(['resnet_tiny']))
+        tr.log(step)                     # (step 0 logs: first check -> 32768; from then on every step is checked)
+    assert tr.loss_scale == 4096.0 and tr.skipped_updates == 4, (tr.loss_scale, tr.skipped_updates)
+    for step in range(4, 7):
+        tr.update(images, targets, _batch(['resnet_tiny']))
+        tr.log(step)
+    torch.cuda.synchronize()
+    assert tr.loss_scale == 4096.0 and tr._optimizer.steps == 3 and torch.isfinite(hip._flat).all()
+    # nine overflowing steps inside ONE window (no check in between): one halving, no exception
+    for _ in range(9):
+        tr.update(bad, targets, _batch(['resnet_tiny']))
+    tr._sync_skips()
+    assert tr.loss_scale == 2048.0
+    tr.save(0, 299, {'config': dict(recipe.TINY_CFG)})
+    hip2, _ = make_models(dict(recipe.TINY_CFG), recipe.TINY_SEED + 1)
+    tr2 = Trainer(hip2, 'adamw', {'lr': 1e-4}, 'cosine', n_batches=1000, grad_clip=5, device='cuda', epochs=2, amp=True,
+                  save_dir=str(tmp_path))
+    assert tr2.loss_scale == 2048.0 and tr2._optimizer.steps == 3
+    # divergence: whole windows of non-finite steps all the way down to the floor, then one more at the floor
+    with pytest.raises(RuntimeError):
+        for _ in range(8):
+            tr.update(bad, targets, _batch(['resnet_tiny']))
+    assert tr.loss_scale == 1024.0
 
 
 def test_eval_ghn_counterpart_script():

@@ -215,9 +215,13 @@ def test_deepnets1m_ddp_names():
     s0.rank, s0.world, s1.rank, s1.world = 0, 2, 1, 2
     i0, i1 = s0.epoch_indices(3), s1.epoch_indices(3)
     assert len(i0) == len(i1) == 6 and sorted(np.concatenate([i0, i1]).tolist()) == list(range(12))
-    # a batch known to exceed the node budget is skipped
-    s0.max_nodes_batch = 10
-    loader.dataset._nodes.update({int(i): 100 for i in i0})
-    assert not s0.check_batch(list(i0[:2]))
+    # the node budget is applied where node counts exist -- in the collate function, also with worker processes
+    from ghn3_amd.deepnets1m import collate_capped
+    g2 = [loader.dataset[int(i)] for i in i0[:2]]
+    assert len(collate_capped(g2, max_nodes_batch=int(g2[0].n_nodes) + 1).nets) == 1
+    assert len(collate_capped(g2, max_nodes_batch=None).nets) == 2 and len(collate_capped(g2, max_nodes_batch=1).nets) == 1
+    capped, _ = DeepNets1MDDP.loader(meta_batch_size=2, split='train', num_nets=12, max_nodes=120, num_workers=2)
+    capped.collate_fn.keywords['max_nodes_batch'] = 1
+    assert len(next(iter(capped)).nets) == 1
     ev = DeepNets1MDDP.loader(meta_batch_size=1, split='val', num_nets=3, max_nodes=120)
     assert not isinstance(ev, tuple) and len(list(ev)) == 3

@@ -304,3 +304,71 @@ def test_split_bf16_graphormer_program(nodes):
         got = g32[int(off):int(off) + ref.size].reshape(ref.shape)
         err = float(np.linalg.norm(got.astype(np.float64) - ref))
         assert err < 1e-4 * float(np.linalg.norm(ref)) + 2e-6, (name, err, float(np.linalg.norm(ref)))
+
+
+def _simulate_side_state(runs):
+    """Host model of ghn3_run's two-stream bookkeeping (runtime.hip: marks and the pending flag belong to the context and
+    survive a DETACHed run).  Returns, per WAIT op, whether the mark it names was pending when it was issued, and the
+    list of (run, op) positions of main-stream ops that were issued while un-waited side work of a MARKed branch existed."""
+    mark_set = [False] * 4
+    pending = False
+    waits = []
+    for r, ops in enumerate(runs):
+        touches = any((int(o['flags']) & L.OPFLAG_SIDE) or int(o['kind']) in (L.OP_JOIN, L.OP_DETACH) for o in ops)
+        side_dirty = touches and pending
+        if touches:
+            pending = False
+        detach = False
+        for k, o in enumerate(ops):
+            kind = int(o['kind'])
+            if kind == L.OP_JOIN:
+                mode, mid = int(o['i'][0]), int(o['i'][1]) & 3
+                if mode == 1:
+                    if side_dirty:
+                        mark_set[mid] = True
+                elif mode == 2:
+                    waits.append((r, k, mark_set[mid]))
+                    mark_set[mid] = False
+                else:
+                    side_dirty = False
+                    mark_set = [False] * 4
+                continue
+            if kind == L.OP_DETACH:
+                detach = True
+                continue
+            detach = False
+            if int(o['flags']) & L.OPFLAG_SIDE:
+                side_dirty = True
+        if detach and side_dirty:
+            pending = True
+        elif touches:
+            mark_set = [False] * 4
+    return waits
+
+
+def test_mark_wait_pairs_survive_the_data_parallel_split():
+    """The 1-D decoder backward runs on the side stream behind a MARK; the node-row gather that reads its rows WAITs for
+    that mark.  In the data-parallel schedule the MARK lands in part 1 and the WAIT in part 3 (separate ghn3_run calls):
+    the mark must still be pending there, in the single-run order and in the two-part order alike (round-3 advisor
+    finding: marks used to be local to a run, so the split runs raced)."""
+    hip, _ = _build(recipe.TINY_CFG, recipe.TINY_SEED, 'reference')
+    nets_h, gb_h, _, _ = _tiny('b2')
+    gb_h._cat()
+    cfg = dict(hid=hip.hid, heads=hip.heads, layers=hip.layers, num_classes=hip.num_classes, max_shape=hip.max_shape)
+    prog = Program(cfg, gb_h.node_info, gb_h.host_n_nodes(), gb_h._node_type_host, gb_h.max_edge, nets_h,
+                   decoder_ctype=L.CT_F16, decoder_bwd_ctype=L.CT_F16)
+    assert prog.n1 > 0 and prog.M > 0
+    for runs in ([prog.bwd_ops], [p for p, _ in prog.bwd_parts], [prog.bwd_ops_a, prog.bwd_ops_b]):
+        n_marks = sum(int(o['kind']) == L.OP_JOIN and int(o['i'][0]) == 1 for ops in runs for o in ops)
+        waits = _simulate_side_state(runs)
+        assert n_marks == 1 and len(waits) == 1, (n_marks, waits)
+        assert all(ok for (_, _, ok) in waits), waits
+    # the mark is in the first part, its wait in the last one
+    parts = [p for p, _ in prog.bwd_parts]
+    assert any(int(o['kind']) == L.OP_JOIN and int(o['i'][0]) == 1 for o in parts[0])
+    assert any(int(o['kind']) == L.OP_JOIN and int(o['i'][0]) == 2 for o in parts[-1])
+    # a run without side ops (the exchange's local passes on the shared context) does not consume the pending state
+    passes = np.zeros(1, dtype=L.OP_DT)
+    passes['kind'] = L.OP_WIRE_PACK
+    waits = _simulate_side_state([parts[0], passes, parts[1], passes, parts[2]])
+    assert len(waits) == 1 and waits[0][2]

@@ -3,7 +3,7 @@ scalar path (selected by misaligning the buffers by one float)."""
 import os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 from ghn3_amd import _lib as L
 from ghn3_amd.optim import _dbits
 

@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """Latency of the attention kernels at the bench shape (one 256-node graph, 16 heads of 24, ghn3xlm16): `layers` launches
 back to back on one stream, each on its own qkv / P / out buffers (as in the model: fresh data from the previous kernel),
-one shared edge bias.  GPU box only.   python tests/attn_bench.py [N] [H] [C]"""
+one shared edge bias.  GPU box only.   python tools/diag/attn_bench.py [N] [H] [C]"""
 import os
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 from ghn3_amd import _lib as L   # noqa: E402
 
 

@@ -1,6 +1,6 @@
 """Diagnostic (GPU box): where the host time of the fresh-architecture loop goes.
 
-    python tests/fresh_loop_diag.py [steps]
+    python tools/diag/fresh_loop_diag.py [steps]
 
 Runs bench.py's fresh-graph loop (loader worker processes -> GHN3.plan -> forward + loss + backward) three ways and prints
 per-step host timers: (a) results streamed from the pool while the loop runs (what bench.py measures), (b) the same plans
@@ -11,7 +11,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 import multiprocessing as mp
 
 

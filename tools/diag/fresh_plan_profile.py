@@ -6,7 +6,7 @@ import pstats
 import sys
 import time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 from bench import model_cfg, _loader_worker
 from ghn3_amd import GHN3, _lib as L
 

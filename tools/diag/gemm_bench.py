@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Micro-benchmark of the grouped GEMM kernels on shapes of the decoder W2 GEMMs (GPU box only).
-    python tests/gemm_bench.py [f32|f16]
+    python tools/diag/gemm_bench.py [f32|f16]
 """
 import os
 import sys
@@ -9,7 +9,7 @@ import time
 import numpy as np
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 from ghn3_amd import _lib as L   # noqa: E402
 
 

@@ -2,7 +2,7 @@
 """Latency probe of the small-problem GEMM kernels (GPU box only)."""
 import os
 import sys
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 from gemm_bench import bench, L   # noqa: E402
 
 if __name__ == '__main__':

@@ -1,14 +1,12 @@
 #!/usr/bin/env python3
 """Prints measured forward / gradient errors of the compute modes vs the CPU oracle (GPU box only; documentation
-numbers for DESIGN.md, not a test).   python tests/gpu_accuracy.py"""
+numbers for DESIGN.md, not a test).   python tools/diag/gpu_accuracy.py"""
 import os
 import sys
 
 import torch
 
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 from util_parity import rel_l2, make_models, synthetic_case, predicted_dict_hip   # noqa: E402
 
 CFGS = {'ghn3tm8': dict(max_shape=(64, 64, 16, 16), num_classes=1000, hid=64, heads=8, layers=3, weight_norm=True,

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Diagnostic sweep on the GPU box: prints per-stage errors instead of stopping at the first failure.
-    python tests/gpu_diag.py [gemm] [tiny] [grads] [synth]
+    python tools/diag/gpu_diag.py [gemm] [tiny] [grads] [synth]
 """
 import os
 import sys
@@ -10,9 +10,7 @@ import numpy as np
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, os.path.dirname(HERE))
-sys.path.insert(0, HERE)
-sys.path.insert(0, os.path.join(HERE, 'golden'))
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 
 import recipe                                                     # noqa: E402
 from util_parity import (rel_l2, make_models, tiny_case, synthetic_case, oracle_intermediates, ws_tensor,

@@ -1,9 +1,7 @@
 """Diagnostic (not a test): per-tensor forward / per-parameter gradient errors of the HIP path vs the oracle at released
-widths.   python tests/gpu_diag_configs.py ghn3xlm16 40 f16 [more node counts...]"""
+widths.   python tools/diag/gpu_diag_configs.py ghn3xlm16 40 f16 [more node counts...]"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 import torch
 from util_parity import rel_l2, make_models, synthetic_case, predicted_dict_hip
 from test_gpu_configs import _cfg

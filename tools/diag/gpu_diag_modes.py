@@ -1,9 +1,7 @@
 """Diagnostic (not a test): f16-mode backward against the exact-fp32 mode of the HIP path itself, per node of d_xe.
-    python tests/gpu_diag_modes.py ghn3lm8 25 40"""
+    python tools/diag/gpu_diag_modes.py ghn3lm8 25 40"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden'))
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 import numpy as np
 import torch
 from util_parity import make_models, synthetic_case, ws_tensor

@@ -1,7 +1,7 @@
 """Diagnostic (not a test): host time to ENQUEUE one step of the bench workload vs the GPU time of that step."""
 import os, sys, time
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 from bench import model_cfg
 from ghn3_amd import GHN3, _lib as L
 from ghn3_amd.synthetic import synthetic_batch

@@ -1,5 +1,5 @@
 import sys, torch, numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/golden')
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 from test_gpu_configs import _cfg, _bench_step
 from ghn3_amd import GHN3
 from ghn3_amd.synthetic import synthetic_batch

@@ -1,6 +1,6 @@
 """Diagnostic: f16 mode vs f32 mode with default-initialised weights, Graphormer backward intermediates."""
 import sys, os
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/golden')
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 import torch
 from util_parity import synthetic_case, ws_tensor
 from test_gpu_configs import _cfg

@@ -1,6 +1,6 @@
 """Diagnostic: 1-D decoder backward intermediates, f16 vs f32 mode, default-initialised weights."""
 import sys
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/golden')
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 import torch, numpy as np
 from util_parity import synthetic_case, ws_tensor
 from test_gpu_configs import _cfg

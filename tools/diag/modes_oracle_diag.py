@@ -1,5 +1,5 @@
 import sys, torch
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/golden')
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 from test_gpu_configs import _cfg
 from util_parity import synthetic_case
 from oracle import ghn3_ref as R

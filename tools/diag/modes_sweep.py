@@ -1,6 +1,6 @@
 """One-off robustness sweep (GPU box): f16 mode vs exact-fp32 mode on many random batches; prints the worst pairs."""
 import sys, torch, numpy as np
-sys.path.insert(0, '.'); sys.path.insert(0, 'tests'); sys.path.insert(0, 'tests/golden')
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 import recipe
 from test_gpu_configs import _cfg, _bench_step
 from ghn3_amd import GHN3

@@ -3,8 +3,7 @@
 import os, sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 from ghn3_amd import GHN3, _lib as L
 from ghn3_amd.synthetic import synthetic_batch
 import bench

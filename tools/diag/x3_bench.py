@@ -6,8 +6,7 @@ import os
 import sys
 import numpy as np
 import torch
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 from ghn3_amd import _lib as L   # noqa: E402
 
 

@@ -47,6 +47,7 @@ CAST_STRAIGHT, CAST_TRANSPOSED, CAST_STRAIGHT_BF16, CAST_TRANSPOSED_BF16, CAST_C
 CAST_TIGHT = 64
 CAST_SPLIT = 128
 CAST_COLSUM_PARTS = 256
+CAST_FRAG = 512
 CT_F32, CT_F16, CT_BF16 = 0, 1, 2
 COMPUTE_TYPES = {'f32': CT_F32, 'f16': CT_F16, 'bf16': CT_BF16}
 

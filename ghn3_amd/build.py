@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 OUT_DIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(OUT_DIR, 'libghn3_hip.so')
-SOURCES = ['gemm.hip', 'gemm_p8.hip', 'gemm_small.hip', 'gemm_x3.hip', 'gemm_wg.hip', 'attention.hip', 'elementwise.hip', 'runtime.hip']
+SOURCES = ['gemm.hip', 'gemm_p8.hip', 'gemm_small.hip', 'gemm_x3.hip', 'gemm_x3d.hip', 'gemm_wg.hip', 'attention.hip', 'elementwise.hip', 'runtime.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'),
          '-I' + CSRC, '-Wno-unused-result'] + os.environ.get('GHN3_HIPCC_EXTRA', '').split()
 

@@ -1504,11 +1504,14 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
     const float* S = src + D.src_off;
     const bool st = D.flags & GHN3_CAST_STRAIGHT, trn = D.flags & GHN3_CAST_TRANSPOSED;
     const bool split = D.flags & GHN3_CAST_SPLIT;   // bf16 hi + lo copies (GHN3_GEMM_X3 operands)
+    // fragment-major copies (gemm_x3d.hip): element (n, k) of a [rows n][cols k] matrix lives at
+    // ((n / 16) * (K / 32) + k / 32) * 512 + ((k % 32) / 8 * 16 + n % 16) * 8 + k % 8   (K = cols, a multiple of 32)
+    const bool frag = D.flags & GHN3_CAST_FRAG;
     const bool st_bf = (D.flags & GHN3_CAST_STRAIGHT_BF16) || split, tr_bf = (D.flags & GHN3_CAST_TRANSPOSED_BF16) || split;
     const float sc = ((D.flags & GHN3_CAST_SCALED) && amax) ? ghn3_pow2_scale(*amax) : 1.f;
     const int rows_w = (D.flags & GHN3_CAST_TIGHT) ? ((D.rows + 7) & ~7) : 0x7fffffff;   // transposed rows written
 
-    if (st && !trn && !(D.flags & GHN3_CAST_COLSUM) && D.src_q == 0 && !(D.ld_dst & 7) && !(D.dst_off & 7) && !(D.lo_off & 7)) {
+    if (st && !trn && !frag && !(D.flags & GHN3_CAST_COLSUM) && D.src_q == 0 && !(D.ld_dst & 7) && !(D.dst_off & 7) && !(D.lo_off & 7)) {
         // straight copy only (the dgrad operand of the decoder gradients, forward activations): 8 consecutive floats per
         // lane -> one 16-byte store (the general path below writes 8 bytes per lane)
         unsigned short* Dd = dst + D.dst_off;
@@ -1574,12 +1577,17 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
             us4 h;
             if (st_bf) { h[0] = cast_bf16(v[i].x); h[1] = cast_bf16(v[i].y); h[2] = cast_bf16(v[i].z); h[3] = cast_bf16(v[i].w); }
             else { h[0] = cast_f16(v[i].x); h[1] = cast_f16(v[i].y); h[2] = cast_f16(v[i].z); h[3] = cast_f16(v[i].w); }
-            *reinterpret_cast<us4*>(Dd + (int64_t)r * D.ld_dst + c0 + c4) = h;
+            const int c = c0 + c4;
+            // (frag: n = r, k = c; the four consecutive k of this lane share one 8-element run)
+            const int64_t o = frag ? ((int64_t)(r >> 4) * (D.cols >> 5) + (c >> 5)) * 512 + ((((c & 31) >> 3) * 16 + (r & 15)) << 3) + (c & 7)
+                                   : (int64_t)r * D.ld_dst + c;
+            if (frag && c >= D.cols) continue;
+            *reinterpret_cast<us4*>(Dd + o) = h;
             if (split) {
                 us4 l;
                 l[0] = cast_bf16(v[i].x - bf16_back(h[0])); l[1] = cast_bf16(v[i].y - bf16_back(h[1]));
                 l[2] = cast_bf16(v[i].z - bf16_back(h[2])); l[3] = cast_bf16(v[i].w - bf16_back(h[3]));
-                *reinterpret_cast<us4*>(Dd + D.lo_off + (int64_t)r * D.ld_dst + c0 + c4) = l;
+                *reinterpret_cast<us4*>(Dd + D.lo_off + o) = l;
             }
         }
     }
@@ -1607,7 +1615,12 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
             us8 h;
 #pragma unroll
             for (int e = 0; e < 8; ++e) h[e] = tr[rp + e][col];
-            *reinterpret_cast<us8*>(Dt + (int64_t)(c0 + col) * D.ld_dstT + r0 + rp) = h;
+            // (frag: the transposed matrix has n = source column, k = source row; 8 consecutive k per store)
+            const int fn = c0 + col, fk = r0 + rp;
+            const int64_t o = frag ? ((int64_t)(fn >> 4) * (D.rows >> 5) + (fk >> 5)) * 512 + ((((fk & 31) >> 3) * 16 + (fn & 15)) << 3)
+                                   : (int64_t)fn * D.ld_dstT + fk;
+            if (frag && fk >= D.rows) continue;
+            *reinterpret_cast<us8*>(Dt + o) = h;
         }
     }
     if (trn && split) {
@@ -1631,7 +1644,12 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
             us8 h;
 #pragma unroll
             for (int e = 0; e < 8; ++e) h[e] = tr[rp + e][col];
-            *reinterpret_cast<us8*>(Dt + (int64_t)(c0 + col) * D.ld_dstT + r0 + rp) = h;
+            // (frag: the transposed matrix has n = source column, k = source row; 8 consecutive k per store)
+            const int fn = c0 + col, fk = r0 + rp;
+            const int64_t o = frag ? ((int64_t)(fn >> 4) * (D.rows >> 5) + (fk >> 5)) * 512 + ((((fk & 31) >> 3) * 16 + (fn & 15)) << 3)
+                                   : (int64_t)fn * D.ld_dstT + fk;
+            if (frag && fk >= D.rows) continue;
+            *reinterpret_cast<us8*>(Dt + o) = h;
         }
     }
     if ((D.flags & GHN3_CAST_COLSUM) && tid < 64 && c0 + tid < D.cols) {

@@ -53,6 +53,12 @@ int ghn3_gemm_x3_init();
 int ghn3_gemm_x3_tile(int code, int slice, int* bm, int* bn);
 int ghn3_gemm_x3_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int code, int slice,
                         hipStream_t stream);
+// gemm_x3d.hip: staged split-bf16 GEMMs (tile codes 44 / 45): fragment-major weights, no partial planes, optional
+// LayerNorm row prologue
+int ghn3_gemm_x3s_init();
+int ghn3_gemm_x3s_tile(int code, int K, int ln_kind, int* bm, int* bn);
+int ghn3_gemm_x3s_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int code, int K, int ln_kind,
+                         hipStream_t stream);
 int ghn3_gemm_wg_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, hipStream_t stream);
 int ghn3_gemm_small_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode, int with_ln,
                            hipStream_t stream);

@@ -112,6 +112,8 @@ extern "C" int ghn3_ctx_create(ghn3_ctx** out) {
     if (rc) return rc;
     rc = ghn3_gemm_x3_init();
     if (rc) return rc;
+    rc = ghn3_gemm_x3s_init();
+    if (rc) return rc;
     rc = ghn3_gemm_p8_init();
     if (rc) return rc;
     rc = ctx_reserve(c, 1024);
@@ -203,7 +205,13 @@ struct Resolver {
 // cannot fill the chip with 64x64 tiles and its K loop is short enough for one workgroup to split four ways.
 static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
     // split-bf16 kernel (gemm_x3.hip): one instantiation per (tile, K slice) -> composite bucket code
-    if (p.flags & GHN3_GEMM_X3) return 4000 + 10 * (((forced >= 40 && forced <= 42) ? forced : 40) - 40) + p.x3_slice / 64;
+    if (p.flags & GHN3_GEMM_X3) {
+        // 44 / 45 = staged kernels (gemm_x3d.hip: fragment-major weights, whole-K activation rows in LDS, optional
+        // LayerNorm row prologue; 32 x 48 / 16 x 32 tiles): bucket by (code, ln_kind, K)
+        if (forced == 44 || forced == 45 || p.ln_kind)
+            return (forced == 45 ? 7000 : 6000) + 100 * (p.ln_kind & 3) + ((p.K / 64) % 100);
+        return 4000 + 10 * (((forced >= 40 && forced <= 42) ? forced : 40) - 40) + p.x3_slice / 64;
+    }
     if (p.ln_kind) return 32;                       // the row prologue lives in the small-problem kernel
     if (p.flags & GHN3_GEMM_OP16) {
         // tile codes 16 / 24 = the 16-bit-operand kernel with 128 x 128 / 256 x 256 tiles.  The big tile has twice
@@ -276,16 +284,34 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             int64_t op_t64 = 0;
             for (int q = first; q < first + cnt; ++q)
                 op_t64 += (int64_t)((problems[q].M + 63) / 64) * ((problems[q].N + 63) / 64);
-            // bucket by (a_mode, b_mode, tile)
+            // bucket by (a_mode, b_mode, tile): the tile codes that occur among the op's problems, in ascending order
+            std::vector<int> codes;
+            for (int q = first; q < first + cnt; ++q) {
+                if (problems[q].M <= 0 || problems[q].N <= 0) continue;
+                const int tc = pick_tile(problems[q], forced, op_t64);
+                if (std::find(codes.begin(), codes.end(), tc) == codes.end()) codes.push_back(tc);
+            }
+            std::sort(codes.begin(), codes.end());
             for (int am = 0; am < 2; ++am)
                 for (int bm = 0; bm < 2; ++bm)
-                    for (int tl : {16, 20, 24, 25, 28, 29, 32, 48, 64, 128, 4001, 4002, 4003, 4004, 4006, 4011, 4012, 4013, 4014, 4021,
-                                   4022, 4023, 4024, 4026}) {
+                    for (int tl : codes) {
                         Launch L{am, bm, tl, (int)pos, 0, 0, 0, 0};
                         int te = tl == 16 ? 128 : (tl == 24 || tl == 20 || tl == 25 || tl == 28 || tl == 29) ? 256 : tl == 48 ? 64 : tl;   // tile edge (rows)
                         int te_n = tl == 20 ? 128 : te;                                        // (columns)
                         const bool x3 = tl >= 4000;
-                        if (x3 && !ghn3_gemm_x3_tile(40 + (tl - 4000) / 10, 64 * (tl % 10), &te, &te_n)) continue;
+                        const bool x3old = x3 && tl < 5000;
+                        if (x3old && !ghn3_gemm_x3_tile(40 + (tl - 4000) / 10, 64 * (tl % 10), &te, &te_n)) {
+                            ghn3_set_error("op %d: no split-bf16 kernel for tile bucket %d (tile code %d, K slice %d)", k, tl,
+                                           40 + (tl - 4000) / 10, 64 * (tl % 10));
+                            return GHN3_E_LIMIT;
+                        }
+                        const int x3s_code = tl >= 7000 ? 45 : 44, x3s_ln = (tl / 100) % 10, x3s_k = 64 * (tl % 100);
+                        if (tl >= 6000 && !ghn3_gemm_x3s_tile(x3s_code, x3s_k, x3s_ln, &te, &te_n)) {
+                            ghn3_set_error("op %d: no staged split-bf16 kernel for tile code %d, K = %d, ln_kind %d "
+                                           "(gemm_x3d.hip: K = C <= 384 with a prologue; 16 x 32 tiles also K = 3C / 4C)", k,
+                                           x3s_code, x3s_k, x3s_ln);
+                            return GHN3_E_LIMIT;
+                        }
                         // members of this launch; XCD-pinned problems (16-bit-operand kernel, tile codes 16 / 20) first, by XCD
                         std::vector<int> members, pinned_m;
                         for (int q = first; q < first + cnt; ++q) {
@@ -366,8 +392,9 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             }
                             if (x3 && (p.a_mode != GHN3_MODE_ROW || p.b_mode != GHN3_MODE_ROW ||
                                        p.b_gather.buf >= 0 || p.a_q || p.b_q || p.c_q || p.bias_q ||
-                                       (p.N & 3) || (p.ldc & 3) || (p.ldb & 7) || p.x3_slice <= 0 ||
-                                       (p.x3_slice & 63) || (p.K % p.x3_slice) || p.ksplit > 1 || p.B2.buf < 0 || (p.C.off & 15) ||
+                                       (p.N & 3) || (p.ldc & 3) || (p.ldb & 7) ||
+                                       (x3old && (p.x3_slice <= 0 || (p.x3_slice & 63) || (p.K % p.x3_slice))) ||
+                                       (!x3old && ((p.K & 63) || (p.N & 15) || (p.ln_kind && p.a_gather.buf >= 0))) || p.ksplit > 1 || p.B2.buf < 0 || (p.C.off & 15) ||
                                        (p.bias.off & 15) || (p.aux_in.off & 15) || (p.aux_out.off & 15) ||
                                        (p.residual.off & 15) || (p.flags & (GHN3_GEMM_ACCUM | GHN3_GEMM_BIASGRAD)) ||
                                        (p.bias.buf >= 0 && p.bias_stride > 1))) {
@@ -424,7 +451,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             g.lim_kind = (g.lim || (tl == 28 && p.mtiles.buf >= 0)) ? p.lim_kind : 0;
                             g.alpha_amax = is16(tl) ? R.get<const float>(p.alpha_amax) : nullptr;
                             g.B2 = x3 ? R.get<const void>(p.B2) : nullptr;
-                            if (x3 && p.x3_slice > L.max_slice) L.max_slice = p.x3_slice;
+                            if (x3old && p.x3_slice > L.max_slice) L.max_slice = p.x3_slice;
+                            if (x3 && !x3old) L.max_slice = p.K;     // (one K per bucket: the bucket code carries it)
                             g.ln_kind = p.ln_kind; g.ln_eps = p.ln_eps;
                             if (p.ln_kind) L.with_ln = 1;
                             for (int e = 0; e < 6; ++e) g.ln_p[e] = p.ln_kind ? R.get<const float>(p.ln_p[e]) : nullptr;
@@ -443,7 +471,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             g.order = (int64_t)p.M > (int64_t)p.N ? 1 : 0;   // stream the larger operand once
                             if (tl == 28) g.order = 0;                       // (the 8-phase kernel has one tile order)
                             g.ksplit = p.ksplit > 1 ? p.ksplit : 1;
-                            g.k_chunk = x3 ? p.x3_slice : ((p.K + g.ksplit - 1) / g.ksplit + 63) / 64 * 64;
+                            g.k_chunk = x3old ? p.x3_slice : x3 ? p.K : ((p.K + g.ksplit - 1) / g.ksplit + 63) / 64 * 64;
                             if (g.ksplit > 1 && (p.bias.buf >= 0 || p.act || p.dact || p.residual.buf >= 0 ||
                                                  p.aux_out.buf >= 0)) {
                                 ghn3_set_error("op %d problem %d: split-K allows no epilogue but alpha", k, q);
@@ -574,7 +602,10 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         case GHN3_OP_NOP: break;
         case GHN3_OP_GEMM:
             for (const Launch& L : op_launches[k]) {
-                if (L.tile >= 4000)
+                if (L.tile >= 6000)
+                    rc = ghn3_gemm_x3s_launch(ds + L.first, L.count, L.tiles, L.tile >= 7000 ? 45 : 44, L.max_slice,
+                                              (L.tile / 100) % 10, stream);
+                else if (L.tile >= 4000)
                     rc = ghn3_gemm_x3_launch(ds + L.first, L.count, L.tiles, 40 + (L.tile - 4000) / 10,
                                              64 * (L.tile % 10), stream);
                 else if (L.tile == 48)

@@ -104,6 +104,11 @@ class Program:
         if graphormer_x3 is None:
             graphormer_x3 = decoder_ctype in (L.CT_F16, L.CT_BF16) and os.environ.get('GHN3_X3', '1') != '0'
         self.x3 = bool(graphormer_x3) and C % 64 == 0 and 64 <= C <= 384
+        # x3s (round 4): the split-bf16 linears on the STAGED kernels (gemm_x3d.hip, tile codes 44 / 45): fragment-major weight
+        # copies loaded straight into registers, whole-K activation rows in LDS, K split over the waves of a workgroup -- no
+        # partial planes -- and the LayerNorms as row prologues of the GEMMs that consume them: 5 dependent launches per
+        # layer forward / backward instead of 7.  Needs a kernel for K = C, 3C and 4C (every released width).
+        self.x3s = self.x3 and C in (64, 128, 256, 384) and os.environ.get('GHN3_X3S', '1') != '0'
         self.H = int(cfg['heads'])
         self.Lyr = int(cfg['layers'])
         self.K = int(cfg['num_classes'])
@@ -282,6 +287,9 @@ class Program:
             if it.get('split'):
                 dflags |= L.CAST_SPLIT
                 D['lo_off'] = it['split']
+            if it.get('frag'):
+                assert it.get('split') and it['rows'] % 32 == 0 and it['cols'] % 32 == 0
+                dflags |= L.CAST_FRAG
             if it.get('scaled'):
                 assert amax is not None
                 dflags |= L.CAST_SCALED
@@ -737,7 +745,7 @@ class Program:
                 for name, r, c in self.X3_WEIGHTS:
                     e = lay['x3']['gnn.%d.%s' % (l, name)]
                     it = dict(src_off=self.param_gap(base, 'gnn.%d.%s' % (l, name)), rows=e['rows'], cols=e['cols'],
-                              ld_src=e['cols'], straight=(e['hi'], e['cols'], L.CT_BF16), split=e['lo'])
+                              ld_src=e['cols'], straight=(e['hi'], e['cols'], L.CT_BF16), split=e['lo'], frag=self.x3s)
                     if self.training:
                         it['transposed'] = (e['hiT'], e['rows'], L.CT_BF16)
                     items.append(it)
@@ -812,6 +820,16 @@ class Program:
         self.gemm_op(p0, tile=tile)
         return ks - 1, pref
 
+    def x3s_linear(self, A, wname, transposed, Cref, M, N, K, lda, ldc, ln=None, **epi):
+        """C = f(A) W^T (nn.Linear forward, W [N][K]) or, transposed, C = f(A) W (dgrad, W [K][N]) on the staged split-bf16
+        kernels (gemm_x3d.hip): 32 x 48 tiles (tile code 44) for the wide outputs, 16 x 32 tiles with the reduction split
+        over the waves (45) for N <= 512; f = the LayerNorm forward / backward row prologue `ln` = (kind, refs) or nothing."""
+        e = self.shadow_lay['x3'][wname]
+        hi = e['hiT'] if transposed else e['hi']
+        p0 = self.gemm(A, self.sref(hi), Cref, M, N, K, lda, K, ldc, x3=(self.sref(hi + e['lo']), K),
+                       ln=None if ln is None else (ln[0], ln[1], 1e-5), **epi)
+        self.gemm_op(p0, tile=45 if N <= 512 else 44)
+
     # ------------------------------------------------------------------ forward
     def _build_forward(self):
         C, H, B, N, V, K = self.C, self.H, self.B, self.N, self.V, self.K
@@ -878,6 +896,25 @@ class Program:
             z = self.wsf('z' + sfx, rows * 4 * C)
             f = self.wsf('f' + sfx, rows * 4 * C)
             x_out = self.wsf('x%d' % (l + 1), rows * C)
+            if self.x3s:
+                # staged split-bf16 linears: LayerNorm 1 / 2 are row prologues of to_qkv / ff.net.0 (their by-products --
+                # normalised rows, mean, rstd -- are written by the column-tile-0 workgroups when the backward needs them),
+                # the narrow linears split K inside the workgroup: five dependent launches per layer
+                self.x3s_linear(x_in, pre + 'attn.to_qkv.weight', False, qkv, rows, 3 * C, C, C, 3 * C,
+                                ln=(1, [self.pref(pre + 'ln1.weight'), self.pref(pre + 'ln1.bias'),
+                                        m1 if train else None, r1 if train else None, h1 if train else None]))
+                self.op(L.OP_ATTN_FWD, refs=(o, qkv, bias, Pm if Pm is not None else self.NONE, r_nn),
+                        ints=(B, N, C, H))
+                self.x3s_linear(o, pre + 'attn.to_out.0.weight', False, xmid, rows, C, C, C, C,
+                                bias=self.pref(pre + 'attn.to_out.0.bias'), residual=x_in)
+                self.x3s_linear(xmid, pre + 'ff.net.0.weight', False, f, rows, 4 * C, C, C, 4 * C,
+                                ln=(1, [self.pref(pre + 'ln2.weight'), self.pref(pre + 'ln2.bias'),
+                                        m2 if train else None, r2 if train else None, h2 if train else None]),
+                                bias=self.pref(pre + 'ff.net.0.bias'), act=L.ACT_GELU, aux_out=z if train else None)
+                self.x3s_linear(f, pre + 'ff.net.3.weight', False, x_out, rows, C, 4 * C, 4 * C, C,
+                                bias=self.pref(pre + 'ff.net.3.bias'), residual=xmid)
+                x_in = x_out
+                continue
             if self.x3:
                 # split-bf16 linears (GHN3_GEMM_X3); K splits of the linear-epilogue GEMMs go to partial planes that the
                 # next LayerNorm op sums (and writes back) -- x_plane: (number of planes, ref) of the previous ff.net.3
@@ -1722,10 +1759,11 @@ class Program:
                 # gained (step 8.51 ms with the old kernel, 8.56 with tile 25 on every CU, 8.46 at 224, 8.38 at 192 --
                 # but there the weight gradient is back at 1.49 ms).
                 n_before = len(self._ops)
-                self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=True, flops=fl,
+                wg_main = os.environ.get('GHN3_WGRAD_MAIN', '0') != '0'      # (experiment: on the chain, every CU)
+                self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=not wg_main, flops=fl,
                              tile=int(os.environ.get('GHN3_WGRAD_TILE', '29')),
                              grid_cap=(int(os.environ.get('GHN3_WGRAD_CAP', '224')) |
-                                       (int(os.environ.get('GHN3_WGRAD_TPW', '0')) << 16)) if self.SIDE else 0)
+                                       (int(os.environ.get('GHN3_WGRAD_TPW', '0')) << 16)) if (self.SIDE and not wg_main) else 0)
                 self.wgrad_op_range = (n_before, len(self._ops))
             fam_list = bands
             for gi, g in enumerate(self.gemm_groups):
@@ -1854,7 +1892,26 @@ class Program:
             g_mid = self.wsf('gmid' + lsfx, rows * C)
             g_out = self.wsf(('gout' + sfx) if self.SIDE else 'gout%d' % (l & 1), rows * C)
             dqkv = self.wsf('dqkv' + lsfx, rows * 3 * C)
-            if self.x3:
+            if self.x3s:
+                # staged split-bf16 dgrads against the transposed (fragment-major) weight copies.  The two LayerNorm
+                # backward passes are row prologues: LN2' (+ the residual gradient g_cur) of the to_out dgrad, which writes
+                # g_mid; LN1' (+ g_mid) of the ff.net.3 dgrad of the layer BELOW, which writes g_out = that layer's g_cur.
+                self.x3s_linear(g_cur if pending_ln1 is None else pending_ln1[0], W3, True, dz, rows, 4 * C, C, C, 4 * C,
+                                ln=None if pending_ln1 is None else (2, pending_ln1[1]), dact=L.DACT_GELU, aux_in=z)
+                if pending_ln1 is not None:
+                    g_cur = pending_ln1[1][5]           # (written by the prologue: this layer's upstream gradient)
+                pending_ln1 = None
+                self.x3s_linear(dz, W1f, True, dhA, rows, C, 4 * C, 4 * C, C)
+                self.x3s_linear(dhA, Wo, True, do, rows, C, C, C, C,
+                                ln=(2, [self.pref(pre + 'ln2.weight'), xmid, m2, r2, g_cur, g_mid]))
+                self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, self.NONE, dBias, r_nn), ints=(B, N, C, H))
+                self.x3s_linear(dqkv, Wq, True, dhB, rows, C, 3 * C, 3 * C, C)
+                if l > 0:
+                    pending_ln1 = (dhB, [self.pref(pre + 'ln1.weight'), x_in, m1, r1, g_mid, g_out])
+                else:
+                    self.op(L.OP_LAYERNORM_BWD, refs=(g_out, dhB, x_in, self.pref(pre + 'ln1.weight'), m1, r1, g_mid,
+                                                      self.NONE), ints=(rows, C))
+            elif self.x3:
                 # split-bf16 dgrads against the transposed weight copies; K splits -> planes summed by the LayerNorm
                 # backward ops (which write the sums back for the LayerNorm parameter gradients on the side stream)
                 self.x3_linear(g_cur, W3, True, dz, rows, 4 * C, C, C, 4 * C, dact=L.DACT_GELU, aux_in=z)

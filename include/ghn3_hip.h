@@ -88,7 +88,13 @@ enum { GHN3_DACT_NONE = 0, GHN3_DACT_RELU = 1 /* aux_in > 0 */, GHN3_DACT_GELU =
  * and walks the slices of its K range in order.  K splits over workgroups are separate problems (partial planes
  * summed by the consuming LayerNorm op).  Epilogue: bias, ReLU / GELU (+ aux_out), dReLU / dGELU (aux_in), residual;
  * N % 4 == 0, ldc % 4 == 0, 16-byte aligned C / aux / residual / bias.  Tile codes (op.i[2]): 40 = 32 x 64,
- * 41 = 64 x 64, 42 = 32 x 32. */
+ * 41 = 64 x 64, 42 = 32 x 32.
+ * Tile codes 44 (32 x 48 tiles, 12 waves) and 45 (16 x 32 tiles, 4 - 16 waves) select the STAGED kernels (gemm_x3d.hip,
+ * round 4): B / B2 are FRAGMENT-MAJOR hi / lo copies (GHN3_CAST_FRAG; ldb unused) that every wave loads straight into
+ * registers, the workgroup keeps its activation rows over the WHOLE reduction length in LDS (K % 64 == 0, K <= 1536 for
+ * 16-row tiles), the waves split K among themselves and add their partial tiles through LDS in a fixed order: no partial
+ * planes, x3_slice unused, N % 16 == 0.  These problems may carry the LayerNorm row prologue of A (ln_kind 1 / 2 below,
+ * K <= 384, no a_gather): the Graphormer chain then needs no LayerNorm launches (graphormer.py:239-241 and its backward). */
 #define GHN3_GEMM_X3 8u
 
 typedef struct ghn3_gemm_problem {
@@ -122,7 +128,8 @@ typedef struct ghn3_gemm_problem {
      * that GHN3_OP_CAST16 scaled by a power of two (GHN3_CAST_SCALED): alpha is divided by that scale
      * (2^(11 - e) for amax = m 2^e; exact).  f16 copies of ~1e-6 gradients would otherwise be subnormal. */
     ghn3_ref alpha_amax;
-    /* Optional row prologue of A (exact-fp32 small-problem kernel only: ROW-mode A without gather, tile 32, K <= 4096):
+    /* Optional row prologue of A (exact-fp32 small-problem kernel: ROW-mode A without gather, tile 32, K <= 4096; staged
+     * split-bf16 kernels: GHN3_GEMM_X3 problems with tile code 44 / 45, K <= 384):
      * the LayerNorm that produces A is applied while the operand is staged, so that the latency-bound Graphormer
      * chain needs no separate LayerNorm launch (every workgroup normalises its own 32 rows; the column-tile-0
      * workgroups also write the by-products the backward needs).
@@ -177,6 +184,13 @@ typedef struct ghn3_gemm_problem {
 /* with GHN3_CAST_COLSUM: deterministic column sums -- every 64-row tile of the descriptor writes its partial sums to
  * dbias[part_off + tile_row * cols + c] (plain stores, no atomics); GHN3_OP_ROWSET_COLSUM adds them in a fixed order */
 #define GHN3_CAST_COLSUM_PARTS 256u
+/* with GHN3_CAST_SPLIT: the straight and / or transposed hi / lo copies are written in FRAGMENT-MAJOR order instead of
+ * row-major (ld_dst / ld_dstT unused): element (n, k) of the copied [n][k] matrix -- the straight copy has n = source row,
+ * k = source column, the transposed one n = source column, k = source row -- lives at
+ *     ((n / 16) * (K / 32) + k / 32) * 512 + ((k % 32) / 8 * 16 + n % 16) * 8 + k % 8          (16-bit elements)
+ * i.e. the 16 x 32 operand of one v_mfma_f32_16x16x32_bf16 is one contiguous kilobyte in lane order.  rows and cols must be
+ * multiples of 32.  Operand layout of the staged split-bf16 kernels (GHN3_OP_GEMM tile codes 44 / 45).  (ABI v14) */
+#define GHN3_CAST_FRAG 512u
 typedef struct ghn3_cast_desc {
     int64_t src_off, dst_off, dstT_off;
     int32_t rows, cols;

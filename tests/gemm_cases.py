@@ -529,8 +529,9 @@ def run_ln_case(ctx, kind, M, N, K, b_mode, res=True, seed=0, dev='cuda'):
 # GHN3_GEMM_X3 problems.  Expectation: fp64 product of the fp32 operands (the deviation is the dropped lo.lo term and
 # the bf16 rounding of the lo halves: ~1e-5 relative).
 # ---------------------------------------------------------------------------------------------------------------
-def x3_setup(W, dev='cuda'):
-    """fp32 weight W [R][Cc] (numpy) -> (device fp32 weight, shadow buffer (uint16), layout dict) through one cast op."""
+def x3_setup(W, dev='cuda', frag=False):
+    """fp32 weight W [R][Cc] (numpy) -> (device fp32 weight, shadow buffer (uint16), layout dict) through one cast op.
+    frag: fragment-major copies (GHN3_CAST_FRAG, the operand layout of tile codes 44 / 45)."""
     R, Cc = W.shape
     n = R * Cc
     lay = dict(hi=0, hiT=n, lo=2 * n)
@@ -541,19 +542,45 @@ def x3_setup(W, dev='cuda'):
     desc['dst_off'], desc['ld_dst'] = lay['hi'], Cc
     desc['dstT_off'], desc['ld_dstT'] = lay['hiT'], R
     desc['lo_off'] = lay['lo']
-    desc['flags'] = L.CAST_STRAIGHT | L.CAST_TRANSPOSED | L.CAST_SPLIT
+    desc['flags'] = L.CAST_STRAIGHT | L.CAST_TRANSPOSED | L.CAST_SPLIT | (L.CAST_FRAG if frag else 0)
     return dW, shadow, lay, desc
 
 
-def run_x3_case(ctx, M, N, K, transposed=False, tile=40, ksplit=1, slice_=0, epilogue='none', seed=0, dev='cuda'):
-    """C = A W^T (W [N][K]) or, transposed, C = A W (W [K][N]).  Returns [(got, expected)]."""
+def run_x3_case(ctx, M, N, K, transposed=False, tile=40, ksplit=1, slice_=0, epilogue='none', seed=0, dev='cuda', ln=0,
+                ln_res=True):
+    """C = A W^T (W [N][K]) or, transposed, C = A W (W [K][N]).  Returns [(got, expected)].
+    ln = 1 / 2 (tile codes 44 / 45, gemm_x3d.hip): the LayerNorm forward / backward row prologue of A
+    (ghn3_gemm_problem::ln_kind); the by-products (normalised rows, mean, rstd / the propagated gradient) are returned too."""
     rs = np.random.RandomState(seed)
     A = rs.standard_normal((M, K)).astype(np.float32)
     W = (rs.standard_normal((K, N) if transposed else (N, K)) * 0.05).astype(np.float32)
     bias = rs.standard_normal(N).astype(np.float32)
     resid = rs.standard_normal((M, N)).astype(np.float32)
     aux = rs.standard_normal((M, N)).astype(np.float32)
-    acc = A.astype(np.float64) @ (W.astype(np.float64) if transposed else W.astype(np.float64).T)
+    A_eff = A.astype(np.float64)
+    ln_extra = []
+    if ln:
+        A = (A * 1.5 + 0.3).astype(np.float32)
+        gamma = (1.0 + 0.2 * rs.standard_normal(K)).astype(np.float32)
+        beta = (0.1 * rs.standard_normal(K)).astype(np.float32)
+        X = rs.standard_normal((M, K)).astype(np.float32)
+        RES = rs.standard_normal((M, K)).astype(np.float32)
+        A64, X64 = A.astype(np.float64), X.astype(np.float64)
+        if ln == 1:
+            mu = A64.mean(1, keepdims=True)
+            rstd = 1.0 / np.sqrt(((A64 - mu) ** 2).mean(1, keepdims=True) + 1e-5)
+            A_eff = (A64 - mu) * rstd * gamma + beta
+            mean_in = rstd_in = None
+        else:
+            mu = X64.mean(1, keepdims=True)
+            rstd = 1.0 / np.sqrt(((X64 - mu) ** 2).mean(1, keepdims=True) + 1e-5)
+            mean_in, rstd_in = mu[:, 0].astype(np.float32), rstd[:, 0].astype(np.float32)
+            xh = (X64 - mean_in[:, None].astype(np.float64)) * rstd_in[:, None].astype(np.float64)
+            dg = A64 * gamma
+            A_eff = rstd_in[:, None].astype(np.float64) * (dg - dg.mean(1, keepdims=True) - xh * (dg * xh).mean(1, keepdims=True))
+            if ln_res:
+                A_eff = A_eff + RES
+    acc = A_eff @ (W.astype(np.float64) if transposed else W.astype(np.float64).T)
     v = acc.copy()
     aux_expected = None
     if epilogue in ('full', 'gelu', 'bias_relu', 'bias_res'):
@@ -573,13 +600,18 @@ def run_x3_case(ctx, M, N, K, transposed=False, tile=40, ksplit=1, slice_=0, epi
         v = v * (aux > 0)
     if epilogue == 'full':
         v = v + resid
-    dW, shadow, lay, desc = x3_setup(W, dev)
+    dW, shadow, lay, desc = x3_setup(W, dev, frag=tile in (44, 45))
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     dA, dbias, dres, daux = t(A), t(bias), t(resid), t(aux)
     dC = torch.full((max(ksplit, 1), M, N), 7.0, dtype=torch.float32, device=dev)
     daux_out = torch.zeros(M, N, dtype=torch.float32, device=dev)
     ddesc = torch.from_numpy(desc.view(np.uint8).copy()).to(dev)
     bufs = [dA, shadow, dC, dbias, dres, daux, daux_out, dW, ddesc]
+    if ln:
+        dmean = t(mean_in) if ln == 2 else torch.zeros(M, device=dev)
+        drstd = t(rstd_in) if ln == 2 else torch.zeros(M, device=dev)
+        dlnout = torch.zeros(M, K, device=dev)
+        bufs += [t(gamma), t(beta), t(X), t(RES), dmean, drstd, dlnout]          # 9 .. 15
     ptrs = np.asarray([b.data_ptr() for b in bufs], dtype=np.uint64)
     hi = lay['hiT'] if transposed else lay['hi']
     kc = K // ksplit
@@ -605,6 +637,12 @@ def run_x3_case(ctx, M, N, K, transposed=False, tile=40, ksplit=1, slice_=0, epi
         p[0]['aux_out']['buf'] = 6
     p[0]['act'] = {'bias_relu': L.ACT_RELU, 'gelu': L.ACT_GELU, 'full': L.ACT_GELU}.get(epilogue, L.ACT_NONE)
     p[0]['dact'] = {'drelu': L.DACT_RELU, 'dgelu': L.DACT_GELU}.get(epilogue, L.DACT_NONE)
+    if ln:
+        p[0]['ln_kind'], p[0]['ln_eps'] = ln, 1e-5
+        if ln == 1:
+            p['ln_p']['buf'][0, :5] = (9, 10, 13, 14, 15)
+        else:
+            p['ln_p']['buf'][0, :6] = (9, 11, 13, 14, 12 if ln_res else -1, 15)
     ops = np.zeros(2, dtype=L.OP_DT)
     ops['r']['buf'][:] = -1
     ops[0]['kind'] = L.OP_CAST16
@@ -618,6 +656,10 @@ def run_x3_case(ctx, M, N, K, transposed=False, tile=40, ksplit=1, slice_=0, epi
     out = [(got, v)]
     if aux_expected is not None:
         out.append((daux_out.cpu().numpy(), aux_expected))
+    if ln:
+        out.append((dlnout.cpu().numpy(), A_eff))
+        if ln == 1:
+            out += [(dmean.cpu().numpy(), mu[:, 0]), (drstd.cpu().numpy(), rstd[:, 0])]
     return out
 
 
@@ -635,4 +677,32 @@ X3_CASES = [
     dict(M=48, N=192, K=64, tile=42, epilogue='drelu'),
     dict(M=1421, N=3072, K=1536, tile=41, slice_=256, epilogue='bias_relu'),    # decoder.conv.0 forward shape
     dict(M=33, N=128, K=512, tile=40, slice_=128, epilogue='full'),             # walks 4 slices of 128
+    # staged kernels (gemm_x3d.hip: fragment-major weights, no partial planes).  45 = 16 x 32 tiles, K split over the waves
+    dict(M=256, N=384, K=384, tile=45, epilogue='bias_res'),                    # to_out forward: 4 parts of 96
+    dict(M=256, N=384, K=1536, tile=45, epilogue='bias_res'),                   # ff.net.3 forward: 8 parts of 192
+    dict(M=256, N=384, K=1536, tile=45, transposed=True),                       # ff.net.0 dgrad
+    dict(M=256, N=384, K=1152, tile=45, transposed=True),                       # to_qkv dgrad: 6 parts of 192
+    dict(M=200, N=256, K=1024, tile=45, epilogue='full'),                       # ghn3lm8 widths, ragged M: 8 parts of 128
+    dict(M=200, N=256, K=768, tile=45, transposed=True),                        # 8 parts of 96
+    dict(M=70, N=64, K=64, tile=45, epilogue='bias_relu'),                      # ghn3tm8: 2 parts of 32
+    dict(M=48, N=64, K=192, tile=45, epilogue='drelu'),                         # 2 parts of 96
+    dict(M=33, N=112, K=256, tile=45, epilogue='dgelu'),                        # 4 parts of 64, N = 7 x 16 (half a column tile)
+    dict(M=512, N=128, K=512, tile=45, epilogue='gelu'),                        # ghn3sm8, two graphs: 8 parts of 64
+    # 44 = 32 x 48 tiles, two K halves (wide outputs, K = C)
+    dict(M=256, N=1536, K=384, tile=44, transposed=True, epilogue='dgelu'),     # ff.net.3 dgrad of the top layer (no prologue)
+    dict(M=100, N=192, K=64, tile=44, epilogue='gelu'),
+    # LayerNorm row prologues (tile codes 44 = 32 x 32 tiles, 45 = 16 x 32 tiles): forward (ln=1) and backward (ln=2)
+    dict(M=256, N=1152, K=384, tile=44, ln=1),                                  # LN1 -> to_qkv
+    dict(M=256, N=1536, K=384, tile=44, ln=1, epilogue='gelu'),                 # LN2 -> ff.net.0
+    dict(M=256, N=1536, K=384, tile=44, ln=2, transposed=True, epilogue='dgelu'),   # LN1' -> ff.net.3 dgrad of the layer below
+    dict(M=256, N=384, K=384, tile=45, ln=2, transposed=True),                  # LN2' -> to_out dgrad
+    dict(M=256, N=384, K=384, tile=45, ln=2, transposed=True, ln_res=False),
+    dict(M=200, N=768, K=256, tile=44, ln=1),                                   # ghn3lm8
+    dict(M=200, N=256, K=256, tile=45, ln=2, transposed=True),
+    dict(M=70, N=192, K=64, tile=44, ln=1, epilogue='bias_relu'),               # ghn3tm8, ragged M
+    dict(M=70, N=64, K=64, tile=45, ln=2, transposed=True),
+    dict(M=45, N=512, K=128, tile=44, ln=2, transposed=True, epilogue='dgelu'),  # ghn3sm8
+    dict(M=45, N=128, K=128, tile=45, ln=1),
+    dict(M=33, N=96, K=192, tile=45, ln=2, transposed=True),
+    dict(M=33, N=96, K=192, tile=44, ln=1),
 ]

@@ -410,14 +410,91 @@ def make_resnet_goldens(which=('18', '50', 'vit')):
         print('%s_%s.npz: %d predicted params' % (tag, variant, total))
 
 
+# ------------------------------------------------------------------------------------------------
+# 4. The BENCHMARKED workload through the reference GHN3 class, forward AND backward: ghn3xlm16 on the seeded synthetic
+#    256-node graph bench.py times (seed 256000) and on one ragged two-graph batch (quirk Q1: padded dense rows), loss =
+#    sum of Frobenius norms of the predicted tensors (the reference's predparam_wd term, trainer.py:97-98,288-294).
+#    Stores per predicted tensor the norm + a seeded sample, per GHN parameter the gradient norm + a seeded sample.
+#    The graphs come from ghn3_amd.synthetic (inputs are data; the generator is numpy-only and seeded), the target networks
+#    are its shape-only light networks, which the reference handles through `_layered_modules` (nn.py:612, 531-538).
+# ------------------------------------------------------------------------------------------------
+
+BENCH_CASES = {'b1': ('ghn3xlm16', [256], 256000), 'b2r': ('ghn3xlm16', [90, 170], 777000)}
+BENCH_SEED = 31337
+BENCH_SAMPLES = 2048
+
+
+def make_bench_goldens(which=('b1', 'b2r')):
+    install_standins()
+    sys.path.insert(0, REF)
+    import ghn3                                              # noqa: F401  the reference package
+    from ghn3.nn import GHN3
+    from ghn3.graph import Graph, GraphBatch
+    from ghn3_amd.synthetic import synthetic_batch
+    import time
+    for case in which:
+        variant, nodes, seed0 = BENCH_CASES[case]
+        hid, layers, heads = recipe.VARIANTS[variant]
+        cfg = dict(max_shape=(hid, hid, 16, 16), num_classes=1000, hid=hid, heads=heads, layers=layers,
+                   weight_norm=True, ve=True, layernorm=True)
+        torch.manual_seed(0)
+        ghn = GHN3(**cfg, debug_level=0)
+        shapes = {k: tuple(v.shape) for k, v in ghn.state_dict().items()}
+        sd = recipe.seeded_state_dict(shapes, seed=BENCH_SEED)
+        ghn.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        del sd
+        gb, nets = synthetic_batch(nodes, seed0)
+        graphs = [Graph(node_feat=g.node_feat.clone(), node_info=g.node_info, A=g._Adj.clone(), dense=True)
+                  for g in gb.graphs]
+        batch = GraphBatch(graphs, dense=True)
+        ghn.train()
+        t0 = time.time()
+        ghn(nets, batch, keep_grads=True, bn_track_running_stats=True, reduce_graph=False)
+        named = []
+        for b, net in enumerate(nets):
+            for lname, m in net.layers.items():
+                for attr in ('weight', 'bias'):
+                    t = getattr(m, attr)
+                    if torch.is_tensor(t):
+                        named.append(('%d/%s.%s' % (b, lname, attr), t))
+        loss = sum(torch.norm(t, p='fro') for _, t in named)
+        t1 = time.time()
+        loss.backward()
+        print('%s / %s: reference forward %.1f s, backward %.1f s, loss %.6f' % (case, variant, t1 - t0, time.time() - t1,
+                                                                               float(loss)))
+        out = {'meta/variant': np.asarray([variant]), 'meta/nodes': np.asarray(nodes, dtype=np.int64),
+               'meta/seed0': np.asarray([seed0], dtype=np.int64), 'meta/weights_seed': np.asarray([BENCH_SEED], dtype=np.int64),
+               'meta/loss': np.asarray([float(loss)], dtype=np.float64)}
+        total = 0
+        for name, t in named:
+            q = t.detach().reshape(-1)
+            total += q.numel()
+            idx = recipe.sample_indices(q.numel(), BENCH_SAMPLES, seed=len(name))
+            out['pred/%s/norm' % name] = np.asarray([float(q.double().norm())])
+            out['pred/%s/sample' % name] = q[idx].numpy().astype(np.float32)
+        out['meta/n_predicted'] = np.asarray([total], dtype=np.int64)
+        for name, p in ghn.named_parameters():
+            gq = p.grad.detach().reshape(-1)
+            idx = recipe.sample_indices(gq.numel(), BENCH_SAMPLES, seed=len(name))
+            out['grad/%s/norm' % name] = np.asarray([float(gq.double().norm())])
+            out['grad/%s/sample' % name] = gq[idx].numpy().astype(np.float32)
+        np.savez_compressed(os.path.join(HERE, 'bench_%s_%s.npz' % (case, variant)), **out)
+        print('bench_%s_%s.npz: %d predicted params, %d GHN parameter gradients' % (case, variant, total,
+                                                                                len(list(ghn.named_parameters()))))
+        del ghn, named, loss
+
+
 if __name__ == '__main__':
     # python make_golden.py            -> tiny fixtures (seconds)
     # python make_golden.py graphs     -> graphs.npz (reference Graph(model) on tests/golden/graph_nets.py)
     # python make_golden.py extra      -> ghn3_tiny_extra.npz (big kernels, weight_norm / layernorm off)
     # python make_golden.py networks   -> networks.npz (reference Network / NetworkLight on tests/golden/network_cases.py)
     # python make_golden.py resnet     -> + ResNet-18 / ghn3tm8 and ResNet-50 / ghn3xlm16 (minutes, ~10 GB of RAM)
-    torch.set_num_threads(8 if 'resnet' in sys.argv[1:] else 4)
-    if 'graphs' in sys.argv[1:]:
+    # python make_golden.py bench    -> bench_b1 / bench_b2r: the benchmarked ghn3xlm16 workload, forward + backward (minutes)
+    torch.set_num_threads(8 if ('resnet' in sys.argv[1:] or 'bench' in sys.argv[1:]) else 4)
+    if 'bench' in sys.argv[1:]:
+        make_bench_goldens([a for a in sys.argv[1:] if a in BENCH_CASES] or tuple(BENCH_CASES))
+    elif 'graphs' in sys.argv[1:]:
         make_graph_goldens()
     elif 'extra' in sys.argv[1:]:
         make_extra_goldens()

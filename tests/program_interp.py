@@ -145,6 +145,11 @@ class Interp:
         e = int(np.floor(np.log2(amax)))
         return 1.0 if e < -100 else float(2.0 ** (11 - e))
 
+    @staticmethod
+    def frag_index(n, k, K):
+        """GHN3_CAST_FRAG: position of element (n, k) of a [n][k] matrix with K columns in fragment-major order."""
+        return ((n // 16) * (K // 32) + k // 32) * 512 + (((k % 32) // 8) * 16 + n % 16) * 8 + k % 8
+
     def op_cast16(self, o, problems):
         n_desc, blocks = int(o['i'][0]), int(o['i'][1])
         src = self.tail(o['r'][0], np.float32)
@@ -171,6 +176,18 @@ class Interp:
             split = bool(fl & L.CAST_SPLIT)
             if split:                               # bf16 hi copy + lo = bf16(x - hi) copy `lo_off` elements behind
                 Xlo = (X - self.from16(self.to16(X, True), True)).astype(np.float32)
+            if fl & L.CAST_FRAG:
+                assert split and rows % 32 == 0 and cols % 32 == 0
+                r_, c_ = np.arange(rows)[:, None], np.arange(cols)[None, :]
+                if fl & L.CAST_STRAIGHT:
+                    ii = int(D['dst_off']) + self.frag_index(r_, c_, cols)
+                    dst[ii] = self.to16(X, True)
+                    dst[ii + int(D['lo_off'])] = self.to16(Xlo, True)
+                if fl & L.CAST_TRANSPOSED:
+                    ii = int(D['dstT_off']) + self.frag_index(c_, r_, rows)
+                    dst[ii] = self.to16(X, True)
+                    dst[ii + int(D['lo_off'])] = self.to16(Xlo, True)
+                continue
             if fl & L.CAST_STRAIGHT:
                 Z = np.zeros((rows, r64(cols)), np.float32)
                 Z[:, :cols] = X
@@ -224,13 +241,24 @@ class Interp:
         assert np.isfinite(Bm).all()
         return A, Bm
 
-    def _gemm_x3(self, p):
+    # (tile code, ln_kind) -> reduction lengths the staged kernels are instantiated for (gemm_x3d.hip g_cfg)
+    X3S_K = {44: {0: (64, 128, 192, 256, 384), 1: (64, 128, 192, 256, 384), 2: (64, 128, 192, 256, 384)},
+             45: {0: (64, 128, 192, 256, 384, 512, 768, 1024, 1152, 1536), 1: (64, 128, 192, 256, 384),
+                  2: (64, 128, 192, 256, 384)}}
+
+    def _gemm_x3(self, p, tile=40):
         """GHN3_GEMM_X3: fp32 A split on the fly into bf16 hi + lo, B from the bf16 hi / lo copies; the three products
-        hi.hi + hi.lo + lo.hi (fp32 accumulate on the device, fp64 here)."""
+        hi.hi + hi.lo + lo.hi (fp32 accumulate on the device, fp64 here).  Tile codes 44 / 45: fragment-major copies,
+        optional LayerNorm row prologue of A."""
         M, N, K = int(p['M']), int(p['N']), int(p['K'])
         lda, ldb, sl = int(p['lda']), int(p['ldb']), int(p['x3_slice'])
+        staged = tile in (44, 45)
         assert int(p['a_mode']) == L.MODE_ROW and int(p['b_mode']) == L.MODE_ROW and ldb % 8 == 0 and N % 4 == 0
-        assert sl > 0 and sl % 64 == 0 and K % sl == 0 and sl <= 384 and int(p['ksplit']) <= 1
+        if staged:
+            assert K in self.X3S_K[tile][int(p['ln_kind'])] and N % 16 == 0 and int(p['ksplit']) <= 1, (tile, K, N)
+        else:
+            assert sl > 0 and sl % 64 == 0 and K % sl == 0 and sl <= 384 and int(p['ksplit']) <= 1
+            assert not int(p['ln_kind'])
         assert int(p['b_gather']['buf']) < 0
         assert int(p['B']['off']) % 16 == 0 and int(p['B2']['off']) % 16 == 0 and int(p['B2']['buf']) >= 0
         XA = self.tail(p['A'], np.float32)
@@ -238,9 +266,14 @@ class Interp:
         ga = self.tail(p['a_gather'], np.int32)
         ra = ga[:M].astype(np.int64) if ga is not None else np.arange(M)
         A = XA[ra[:, None] * lda + np.arange(K)[None, :]]
+        if int(p['ln_kind']):
+            A = self._ln_prologue(p, A, M, K, lda)
         ah = self.from16(self.to16(A, True), True)
         al = self.from16(self.to16((A - ah).astype(np.float32), True), True)
-        ib = np.arange(N)[None, :] * ldb + np.arange(K)[:, None]
+        if staged:
+            ib = self.frag_index(np.arange(N)[None, :], np.arange(K)[:, None], K)
+        else:
+            ib = np.arange(N)[None, :] * ldb + np.arange(K)[:, None]
         bh, bl = self.from16(Bh[ib], True).astype(np.float64), self.from16(Bl[ib], True).astype(np.float64)
         ah, al = ah.astype(np.float64), al.astype(np.float64)
         self._gemm_finish(p, None, None, prod=ah @ bh + (ah @ bl + al @ bh))
@@ -252,7 +285,7 @@ class Interp:
             if M <= 0 or N <= 0:
                 continue
             if int(p['flags']) & L.GEMM_X3:
-                self._gemm_x3(p)
+                self._gemm_x3(p, int(o['i'][2]))
                 continue
             if int(p['flags']) & L.GEMM_OP16:
                 A, Bm = self._gemm_op16(o, p)

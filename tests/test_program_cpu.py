@@ -264,23 +264,38 @@ def test_predict_class_layers_false_and_reduce_graph():
     assert extra.weight is None and extra.bias is None
 
 
-@pytest.mark.parametrize('nodes', [[30], [22, 17]])
-def test_split_bf16_graphormer_program(nodes):
+@pytest.mark.parametrize('nodes,staged', [([30], False), ([22, 17], False), ([30], True), ([22, 17], True)])
+def test_split_bf16_graphormer_program(nodes, staged, monkeypatch):
     """GHN3_GEMM_X3: the Graphormer linears (forward and dgrad) on split-bf16 operands against persistent hi / lo weight
-    copies (GHN3_CAST_SPLIT), K splits as partial planes summed by the LayerNorm ops.  Decoder exact fp32, so the only
-    deviation from the oracle is the dropped lo.lo term (2^-16 relative): forward 2e-5, gradients 1e-4."""
+    copies (GHN3_CAST_SPLIT).  Round-3 plan: K splits as partial planes summed by the LayerNorm ops.  Staged plan (round 4,
+    the default): fragment-major copies (GHN3_CAST_FRAG), tile codes 44 / 45, no planes, every per-layer LayerNorm (forward
+    and backward) a row prologue of the GEMM that consumes it.  Decoder exact fp32, so the only deviation from the oracle is
+    the dropped lo.lo term (2^-16 relative): forward 2e-5, gradients 1e-4."""
     from util_parity import synthetic_case
+    monkeypatch.setenv('GHN3_X3S', '1' if staged else '0')
     cfg = dict(max_shape=(64, 64, 16, 16), num_classes=1000, hid=64, heads=8, layers=2, weight_norm=True, ve=True,
                layernorm=True)
     hip, oracle = _build(cfg, recipe.TINY_SEED, 'reference')
     nets_h, gb_h, nets_o, gb_o = synthetic_case(nodes, 3100)
     prog, it, bufs, gflat = _run_program(hip, nets_h, gb_h, graphormer_x3=True)
-    assert prog.x3 and prog.uses_shadow
+    assert prog.x3 and prog.uses_shadow and prog.x3s == staged
     n_x3 = sum(int(p['flags']) & L.GEMM_X3 != 0 for p in prog.problems)
     assert n_x3 >= 8 * cfg['layers']                              # 4 forward + 4 dgrad linears per layer (+ K splits)
-    n_planes = sum(1 for o in list(prog.fwd_ops) + list(prog.bwd_ops)
-                   if int(o['kind']) in (L.OP_LAYERNORM_FWD, L.OP_LAYERNORM_BWD) and int(o['i'][2]) > 0)
-    assert n_planes >= 2 * cfg['layers']                          # K-split planes are consumed by LayerNorm ops
+    ln_ops = [o for o in list(prog.fwd_ops) + list(prog.bwd_ops)
+              if int(o['kind']) in (L.OP_LAYERNORM_FWD, L.OP_LAYERNORM_BWD)]
+    if staged:
+        # the final LayerNorm forward + backward and the LayerNorm-1 backward of layer 0 (its output feeds the embedding
+        # backward, not a GEMM) are the only LayerNorm launches left
+        assert len(ln_ops) == 3 and all(int(o['i'][2]) == 0 for o in ln_ops)
+        assert n_x3 == 8 * cfg['layers']
+        n_ln = sum(int(p['ln_kind']) != 0 for p in prog.problems if int(p['flags']) & L.GEMM_X3)
+        assert n_ln == 2 * cfg['layers'] + 2 * cfg['layers'] - 1
+        tiles = {int(o['i'][2]) for o in list(prog.fwd_ops) + list(prog.bwd_ops) if int(o['kind']) == L.OP_GEMM and
+                 any(int(p['flags']) & L.GEMM_X3 for p in prog.problems[int(o['i'][0]):int(o['i'][0]) + int(o['i'][1])])}
+        assert tiles <= {44, 45} and 45 in tiles           # (44 = the wide outputs of models with 3C > 512)
+    else:
+        n_planes = sum(1 for o in ln_ops if int(o['i'][2]) > 0)
+        assert n_planes >= 2 * cfg['layers']                      # K-split planes are consumed by LayerNorm ops
     out = bufs[prog.xbuf(prog.X_OUT)].view(np.float32)
     oracle.train()
     _, pred_o = oracle(nets_o, gb_o, keep_grads=True)

@@ -247,19 +247,31 @@ def main():
     dout = torch.empty(prog.out_numel, dtype=torch.float32, device=dev)
 
     exchange = {'on': True, 'reducer': reducer}
+    # loss = sum_t ||p_t||_F (the reference's predparam_wd term, trainer.py:97-98,288-294).  Default: fused into the tile
+    # kernels -- the tile forward leaves per-block sums of squares, GHN3_OP_PARAM_NORM_FIN turns them into norms + loss and
+    # the tile backward forms p / ||p|| itself (what `loss.backward()` of GHN3.predicted_param_norm() runs).
+    # GHN3_FUSED_LOSS=0: the streaming passes of rounds 1-3 (PARAM_NORM_FWD / BWD over the 346 MB output, materialised dout).
+    fused_loss = os.environ.get('GHN3_FUSED_LOSS', '1') != '0'
+    one = torch.ones(1, dtype=torch.float32, device=dev)
 
     def run_step(model, pl, d_out, norms):
         model._run_forward(pl)
-        model._fill_bufs(pl, out=pl.out, dout=d_out)
-        ctx.run(norms[0], pl.program.problems, pl.bufs, stream)
-        ctx.run(norms[1], pl.program.problems, pl.bufs, stream)
         red = exchange['reducer'] if exchange['on'] else None
-        model._run_backward(pl, d_out, reducer=red)
+        if fused_loss:
+            ctx.run(norms[2], pl.program.problems, pl.bufs, stream)
+            model._run_backward(pl, None, reducer=red, norm_g=one)
+        else:
+            model._fill_bufs(pl, out=pl.out, dout=d_out)
+            ctx.run(norms[0], pl.program.problems, pl.bufs, stream)
+            ctx.run(norms[1], pl.program.problems, pl.bufs, stream)
+            model._run_backward(pl, d_out, reducer=red)
         if ddp and red is None and exchange['on']:
             all_reduce_flat_grads(pl.gflat)
 
+    fin_norm = prog.norm_fin_ops()
+
     def step():
-        run_step(ghn, plan, dout, (f_norm, b_norm))
+        run_step(ghn, plan, dout, (f_norm, b_norm, fin_norm))
 
     for _ in range(args.warmup):
         step()
@@ -396,7 +408,8 @@ def main():
             progk = pk.program
             ea, eb = L.Event(), L.Event()
             ea.record(stream)
-            run_step(ghn, pk, torch.empty(progk.out_numel, dtype=torch.float32, device=dev), progk.norm_ops(1.0))
+            run_step(ghn, pk, None if fused_loss else torch.empty(progk.out_numel, dtype=torch.float32, device=dev),
+                     progk.norm_ops(1.0) + (progk.norm_fin_ops(),))
             eb.record(stream)
             gpu_spans.append((ea, eb))
             h2 = time.perf_counter()
@@ -457,7 +470,7 @@ def main():
             gb_b, nets_b = synthetic_batch([args.nodes] * gpg, args.nodes * 1000 + rank * gpg)
             plan_b = ghn.compile(nets_b, gb_b, training=True)
             prog_b = plan_b.program
-            norms_b = prog_b.norm_ops(1.0)
+            norms_b = prog_b.norm_ops(1.0) + (prog_b.norm_fin_ops(),)
             dout_b = torch.empty(prog_b.out_numel, dtype=torch.float32, device=dev)
             n_b = max(5, args.steps // 4)
             for _ in range(3):
@@ -499,7 +512,7 @@ def main():
             g32 = GHN3(**model_cfg(args.model), compute='f32').to(dev)
             g32.train()
             p32 = g32.compile(nets, gb, training=True)
-            n32 = p32.program.norm_ops(1.0)
+            n32 = p32.program.norm_ops(1.0) + (p32.program.norm_fin_ops(),)
             for _ in range(2):
                 run_step(g32, p32, dout, n32)
             torch.cuda.synchronize()
@@ -523,12 +536,15 @@ def main():
         ghn._run_forward(plan)
         ev[1].record(stream)
         h1 = time.perf_counter()
-        ghn._fill_bufs(plan, out=plan.out, dout=dout)
-        ctx.run(f_norm, prog.problems, plan.bufs, stream)
-        ctx.run(b_norm, prog.problems, plan.bufs, stream)
+        if fused_loss:
+            ctx.run(fin_norm, prog.problems, plan.bufs, stream)
+        else:
+            ghn._fill_bufs(plan, out=plan.out, dout=dout)
+            ctx.run(f_norm, prog.problems, plan.bufs, stream)
+            ctx.run(b_norm, prog.problems, plan.bufs, stream)
         ev[2].record(stream)
         h2 = time.perf_counter()
-        ghn._run_backward(plan, dout)
+        ghn._run_backward(plan, None if fused_loss else dout, norm_g=one if fused_loss else None)
         ev[3].record(stream)
         h3 = time.perf_counter()
         torch.cuda.synchronize()
@@ -593,6 +609,7 @@ def main():
                        'zero_fill_bytes': int(prog.ws_bytes + prog.scal_bytes +
                                               (ghn._shadow.numel() if ghn._shadow is not None else 0)),
                        'parallelism': 'dp%d' % world, 'index_mode': ghn.index_mode,
+                       'loss': 'fused into the tile kernels' if fused_loss else 'streaming norm passes',
                        'grad_allreduce': (args.grad_allreduce if ddp else None)},
             'roofline': {'bound': 'mfma', 'achieved': achieved, 'peak': peak, 'unit': 'TFLOP/s',
                          'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'bytes per step',

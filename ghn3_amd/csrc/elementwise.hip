@@ -699,10 +699,22 @@ struct Odo {
 // one o-row of one tensor through LDS instead: T1 * kh * kw contiguous target floats on one side, kh * kw
 // segments of consecutive i on the other -- both sides coalesced.  Requires mode 0, S[1] == 1 and no tiling
 // along kh / kw (the host checks).
+// sq_parts (optional): slot blockIdx.x receives the sum of squares of everything this block wrote (fixed reduction
+// order): the per-tensor Frobenius norms of the predicted-parameter loss without another pass over the output.
+__device__ __forceinline__ void tile_block_sumsq(float ss, float* __restrict__ sq_parts) {
+    __shared__ float sq_red[4];
+    ss = wsum(ss);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sq_red[threadIdx.x >> 6] = ss;
+    __syncthreads();
+    if (threadIdx.x == 0) sq_parts[blockIdx.x] = (sq_red[0] + sq_red[1]) + (sq_red[2] + sq_red[3]);
+}
+
 __global__ __launch_bounds__(256) void tile_fwd_kernel(float* __restrict__ flat, SrcTable srcs,
                                                        const ghn3_tile_desc* __restrict__ desc,
-                                                       const int64_t* __restrict__ blocks) {
+                                                       const int64_t* __restrict__ blocks, float* __restrict__ sq_parts) {
     extern __shared__ float tl[];
+    float ss = 0.f;
     const int64_t di_raw = blocks[2 * (size_t)blockIdx.x];
     if (di_raw < 0) {
         const ghn3_tile_desc* D = desc + (~di_raw);
@@ -776,8 +788,10 @@ __global__ __launch_bounds__(256) void tile_fwd_kernel(float* __restrict__ flat,
             f4u o;
             o.x = tl[j] * scale; o.y = tl[j + 1] * scale; o.z = tl[j + 2] * scale; o.w = tl[j + 3] * scale;
             *reinterpret_cast<f4u*>(dst + j) = o;
+            ss += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
         }
-        for (int j = nv + threadIdx.x; j < n; j += 256) dst[j] = tl[j] * scale;
+        for (int j = nv + threadIdx.x; j < n; j += 256) { const float o = tl[j] * scale; dst[j] = o; ss += o * o; }
+        if (sq_parts) tile_block_sumsq(ss, sq_parts);
         return;
     }
     const int64_t di = di_raw;
@@ -803,13 +817,16 @@ __global__ __launch_bounds__(256) void tile_fwd_kernel(float* __restrict__ flat,
         const int m2 = w2 ? o.d[2] % E2 : o.d[2];
         const int m3 = w3 ? o.d[3] % E3 : o.d[3];
         const int64_t so = (int64_t)m0 * S0 + (int64_t)m1 * S1 + (int64_t)m2 * S2 + (int64_t)m3 * S3;
-        dst[e] = norm_apply(src[so], mode, scale);
+        const float val = norm_apply(src[so], mode, scale);
+        dst[e] = val;
+        ss += val * val;
         o.step();
     }
+    if (sq_parts) tile_block_sumsq(ss, sq_parts);
 }
 
 int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d_desc, int n_desc, int64_t total,
-                  const int64_t* blocks, int lds_bytes, hipStream_t s) {
+                  const int64_t* blocks, int lds_bytes, float* sq_parts, hipStream_t s) {
     // `total` = number of work blocks in the (descriptor, start) table `blocks`.
     if (n_desc <= 0 || total <= 0) return GHN3_OK;
     SrcTable st;
@@ -818,19 +835,31 @@ int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d
         if (lds_bytes > 128 * 1024) { ghn3_set_error("tile_fwd: row blocks need %d bytes of LDS", lds_bytes); return GHN3_E_LIMIT; }
         hipFuncSetAttribute((const void*)tile_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     }
-    hipLaunchKernelGGL(tile_fwd_kernel, dim3((unsigned)total), dim3(256), lds_bytes, s, flat, st, d_desc, blocks);
+    hipLaunchKernelGGL(tile_fwd_kernel, dim3((unsigned)total), dim3(256), lds_bytes, s, flat, st, d_desc, blocks, sq_parts);
     return launch_ok("tile_fwd");
 }
 
 // Backward: source-centric.  Each source element of the descriptor's region R0 x R1 x R2 x R3 receives
 // norm'(src) * sum over the target replicas (zero outside the consumed E region).  Iteration order over the
 // region: dimension 1 fastest (the source-contiguous axis for decoder tiles), then 3, 2, 0.
+// Fused predicted-parameter-norm loss (trainer.py:97-98,288-294): with `norms` the upstream gradient of element e of the
+// descriptor's tensor t is  dflat[e] + (g / norm_t) out[e]  (dflat optional) -- the norm term's gradient is formed from the
+// predicted values themselves instead of being materialised by a pass over the 346 MB output.
+struct NormLoss { const float* out; const float* norms; const int* desc_seg; const float* g; };
 __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__ dflat, SrcTable srcs, DstTable dsrcs,
                                                        const ghn3_tile_desc* __restrict__ desc,
-                                                       const int64_t* __restrict__ blocks, float* __restrict__ amax) {
+                                                       const int64_t* __restrict__ blocks, float* __restrict__ amax,
+                                                       NormLoss nl_) {
     extern __shared__ float tl[];
     float mx = 0.f;                                      // running max |x| written to source-grad buffer 0
     const int64_t di_raw = blocks[2 * (size_t)blockIdx.x];
+    const int64_t di_any = di_raw < 0 ? ~di_raw : di_raw;
+    float kn = 0.f;                                      // g / ||p_t|| of this block's tensor (0: no norm term)
+    if (nl_.norms) {
+        const float nrm = nl_.norms[nl_.desc_seg[di_any]];
+        kn = nrm > 0.f ? nl_.g[0] / nrm : 0.f;
+    }
+    const float* __restrict__ outp = nl_.norms ? nl_.out + desc[di_any].dst_off : nullptr;
     if (di_raw < 0) {
         // row block (see tile_fwd_kernel): source row a0 of the region; replicas along o and i are summed in LDS
         const ghn3_tile_desc* D = desc + (~di_raw);
@@ -841,7 +870,7 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
         const int ni = min(D->_pad, R1 - i0);                                   // i of this block (source side)
         const int nl = max(0, min(ni, E1 - i0));                                // of which inside the consumed region
         float* dsrc = dsrcs.p[D->src_buf] + D->src_off + (int64_t)a0 * D->S[0] + i0;
-        const float* g = dflat + D->dst_off;
+        const float* g = dflat ? dflat + D->dst_off : nullptr;
         const bool live = a0 < E0 && nl > 0;
         if (live) {
             const int n = nl * hw;
@@ -853,16 +882,34 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
                 for (int t0 = a0; t0 < T0; t0 += E0)
                     for (int r0 = 0; r0 + i0 < T1; r0 += E1) {              // replicas along i
                         const int lim = min(nl, T1 - r0 - i0) * hw;          // a last partial replica covers fewer i
-                        const float* gr = g + ((int64_t)t0 * T1 + r0 + i0) * hw;
+                        const int64_t go = ((int64_t)t0 * T1 + r0 + i0) * hw;
+                        if (g) {
+                            const float* gr = g + go;
 #pragma unroll
-                        for (int u = 0; u < U; ++u) {
-                            const int j = b0 + 1024 * u;
-                            if (j + 4 <= lim) {
-                                acc[u] += *reinterpret_cast<const f4u*>(gr + j);
-                            } else {
-                                if (j < lim) acc[u].x += gr[j];
-                                if (j + 1 < lim) acc[u].y += gr[j + 1];
-                                if (j + 2 < lim) acc[u].z += gr[j + 2];
+                            for (int u = 0; u < U; ++u) {
+                                const int j = b0 + 1024 * u;
+                                if (j + 4 <= lim) {
+                                    acc[u] += *reinterpret_cast<const f4u*>(gr + j);
+                                } else {
+                                    if (j < lim) acc[u].x += gr[j];
+                                    if (j + 1 < lim) acc[u].y += gr[j + 1];
+                                    if (j + 2 < lim) acc[u].z += gr[j + 2];
+                                }
+                            }
+                        }
+                        if (outp) {
+                            const float* pr = outp + go;
+#pragma unroll
+                            for (int u = 0; u < U; ++u) {
+                                const int j = b0 + 1024 * u;
+                                if (j + 4 <= lim) {
+                                    const f4u v = *reinterpret_cast<const f4u*>(pr + j);
+                                    acc[u].x += kn * v.x; acc[u].y += kn * v.y; acc[u].z += kn * v.z; acc[u].w += kn * v.w;
+                                } else {
+                                    if (j < lim) acc[u].x += kn * pr[j];
+                                    if (j + 1 < lim) acc[u].y += kn * pr[j + 1];
+                                    if (j + 2 < lim) acc[u].z += kn * pr[j + 2];
+                                }
                             }
                         }
                     }
@@ -928,7 +975,7 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
     const unsigned end = min(numel, start + TILE_CHUNK);
     const float* src = srcs.p[D->src_buf] + D->src_off;
     float* dsrc = dsrcs.p[D->src_buf] + D->src_off;
-    const float* g = dflat + D->dst_off;
+    const float* g = dflat ? dflat + D->dst_off : nullptr;
     const int T0 = D->T[0], T1 = D->T[1], T2 = D->T[2], T3 = D->T[3];
     const int E0 = D->E[0], E1 = D->E[1], E2 = D->E[2], E3 = D->E[3];
     const int S0 = (int)D->S[0], S1 = (int)D->S[1], S2 = (int)D->S[2], S3 = (int)D->S[3];
@@ -946,8 +993,11 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
             for (int t0 = a0; t0 < T0; t0 += E0)
                 for (int t1 = a1; t1 < T1; t1 += E1)
                     for (int t2 = a2; t2 < T2; t2 += E2)
-                        for (int t3 = a3; t3 < T3; t3 += E3)
-                            acc += g[(((int64_t)t0 * T1 + t1) * T2 + t2) * T3 + t3];
+                        for (int t3 = a3; t3 < T3; t3 += E3) {
+                            const int64_t gi = (((int64_t)t0 * T1 + t1) * T2 + t2) * T3 + t3;
+                            if (g) acc += g[gi];
+                            if (outp) acc += kn * outp[gi];
+                        }
             acc *= norm_grad(src[so], mode, scale);
         }
         dsrc[so] = acc;
@@ -958,8 +1008,12 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
 }
 
 int ghn3_tile_bwd(const float* dflat, const float* const* srcs, float* const* dsrcs, const ghn3_tile_desc* d_desc,
-                  int n_desc, int64_t total, const int64_t* blocks, int lds_bytes, float* amax, hipStream_t s) {
+                  int n_desc, int64_t total, const int64_t* blocks, int lds_bytes, float* amax, const float* out,
+                  const float* norms, const int* desc_seg, const float* gscale, hipStream_t s) {
     if (n_desc <= 0 || total <= 0) return GHN3_OK;
+    if (!dflat && !norms) { ghn3_set_error("tile_bwd: neither an upstream gradient nor the fused norm loss"); return GHN3_E_ARG; }
+    if (norms && (!out || !desc_seg || !gscale)) { ghn3_set_error("tile_bwd: the fused norm loss needs out, the descriptor -> tensor table and g"); return GHN3_E_ARG; }
+    NormLoss nl{out, norms, desc_seg, gscale};
     SrcTable st; DstTable dt;
     for (int i = 0; i < 6; ++i) { st.p[i] = srcs[i]; dt.p[i] = dsrcs[i]; }
     if (lds_bytes > 48 * 1024) {
@@ -967,7 +1021,7 @@ int ghn3_tile_bwd(const float* dflat, const float* const* srcs, float* const* ds
         hipFuncSetAttribute((const void*)tile_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     }
     hipLaunchKernelGGL(tile_bwd_kernel, dim3((unsigned)total), dim3(256), lds_bytes, s, dflat, st, dt, d_desc, blocks,
-                       amax);
+                       amax, nl);
     return launch_ok("tile_bwd");
 }
 
@@ -1058,6 +1112,37 @@ __global__ void param_loss_kernel(float* __restrict__ loss, const float* __restr
         loss[0] += t;
     }
 }
+// GHN3_OP_PARAM_NORM_FIN: norms from the per-work-block sums of squares tile_fwd left; one wave per tensor, its blocks
+// in block order by the 64 lanes + a fixed shuffle tree; then the loss = sum of the norms in a fixed order
+__global__ __launch_bounds__(256) void param_norm_fin_kernel(float* __restrict__ norms, int n_seg,
+                                                             const float* __restrict__ parts,
+                                                             const int* __restrict__ first) {
+    const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i >= n_seg) return;
+    float sq = 0.f;
+    for (int b = first[i] + lane; b < first[i + 1]; b += 64) sq += parts[b];
+    sq = wsum(sq);
+    if (lane == 0) norms[i] = sqrtf(sq);
+}
+__global__ void param_loss_set_kernel(float* __restrict__ loss, const float* __restrict__ norms, int n_seg) {
+    __shared__ float tot[256];
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < n_seg; i += 256) acc += norms[i];
+    tot[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int k = 0; k < 256; ++k) t += tot[k];
+        loss[0] = t;
+    }
+}
+int ghn3_param_norm_fin(float* loss, float* norms, const float* parts, const int* first, int n_seg, hipStream_t s) {
+    if (n_seg <= 0) return GHN3_OK;
+    hipLaunchKernelGGL(param_norm_fin_kernel, dim3((n_seg + 3) / 4), dim3(256), 0, s, norms, n_seg, parts, first);
+    hipLaunchKernelGGL(param_loss_set_kernel, dim3(1), dim3(256), 0, s, loss, norms, n_seg);
+    return launch_ok("param_norm_fin");
+}
+
 int ghn3_param_norm_fwd(float* loss, const float* flat, const int64_t* seg_off, float* norms, int n_seg,
                         int64_t flat_numel, const int* first_seg, float* parts, hipStream_t s) {
     if (n_seg <= 0) return GHN3_OK;

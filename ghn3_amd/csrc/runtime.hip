@@ -704,16 +704,20 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             const ghn3_tile_desc* dd = R.get<const ghn3_tile_desc>(o.r[7]);
             rc = ghn3_tile_fwd(R.get<float>(o.r[0]), srcs, dd, (int)o.i[0], o.i[1],
                                reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(dd) + o.i[2]),
-                               (int)o.i[3], stream);
+                               (int)o.i[3], R.get<float>(o.r[8]), stream);
             break;
         }
         case GHN3_OP_TILE_BWD: {
             const float* srcs[6]; float* dsrcs[6];
-            for (int j = 0; j < 6; ++j) { srcs[j] = R.get<const float>(o.r[1 + j]); dsrcs[j] = j < 5 ? R.get<float>(o.r[8 + j]) : nullptr; }
+            // (source slot 5 -- r6 -- is never a tile source: with the fused norm loss it carries the device float g)
+            for (int j = 0; j < 6; ++j) { srcs[j] = j < 5 ? R.get<const float>(o.r[1 + j]) : nullptr; dsrcs[j] = j < 5 ? R.get<float>(o.r[8 + j]) : nullptr; }
             const ghn3_tile_desc* dd = R.get<const ghn3_tile_desc>(o.r[7]);
+            const float* norms = R.get<const float>(o.r[14]);
             rc = ghn3_tile_bwd(R.get<const float>(o.r[0]), srcs, dsrcs, dd, (int)o.i[0], o.i[1],
                                reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(dd) + o.i[2]),
-                               (int)o.i[3], R.get<float>(o.r[13]), stream);
+                               (int)o.i[3], R.get<float>(o.r[13]), R.get<const float>(o.r[15]), norms,
+                               norms ? reinterpret_cast<const int*>(reinterpret_cast<const char*>(dd) + o.i[4]) : nullptr,
+                               norms ? R.get<const float>(o.r[6]) : nullptr, stream);
             break;
         }
         case GHN3_OP_PARAM_NORM_FWD:
@@ -721,6 +725,10 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             rc = ghn3_param_norm_fwd(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const int64_t>(o.r[2]),
                                      R.get<float>(o.r[3]), (int)o.i[0], (int64_t)o.i[1], R.get<const int>(o.r[4]),
                                      R.get<float>(o.r[5]), stream);
+            break;
+        case GHN3_OP_PARAM_NORM_FIN:
+            rc = ghn3_param_norm_fin(R.get<float>(o.r[0]), R.get<float>(o.r[1]), R.get<const float>(o.r[2]),
+                                     R.get<const int>(o.r[3]), (int)o.i[0], stream);
             break;
         case GHN3_OP_PARAM_NORM_BWD:
             if (o.i[1] <= 0) { ghn3_set_error("PARAM_NORM_BWD: i1 (flat extent) missing"); rc = GHN3_E_ARG; break; }

@@ -184,7 +184,14 @@ class _GHN3Function(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        grads = ctx.ghn._run_backward(ctx.plan, dout.contiguous(), reducer=ctx.ghn.grad_reducer)
+        # (a stride-0 gradient is the placeholder _ParamNormLoss returns: the norm term is the only upstream gradient and
+        # the tile backward forms it from the predicted values -- nothing to read)
+        plan = ctx.plan
+        norm_g, plan.norm_g = getattr(plan, 'norm_g', None), None
+        if dout is not None and dout.dim() == 1 and dout.numel() > 1 and dout.stride(0) == 0:
+            dout = None
+        grads = ctx.ghn._run_backward(plan, None if dout is None else dout.contiguous(), reducer=ctx.ghn.grad_reducer,
+                                      norm_g=norm_g)
         # The plan references the target modules (to assign into), the modules hold the predicted tensors and those
         # reference this node: dropping the plan here breaks the cycle, so a step's buffers (4 GB of workspace + 2.6 GB
         # of gradients at ghn3xlm16) are freed by reference counting instead of waiting for Python's cycle collector.
@@ -194,15 +201,24 @@ class _GHN3Function(torch.autograd.Function):
 
 class _ParamNormLoss(torch.autograd.Function):
     """sum_t ||p_t||_F over the predicted tensors of a plan (the reference's predparam_wd term, trainer.py:97-98,
-    288-294) straight on the flat output buffer: GHN3_OP_PARAM_NORM_FWD / BWD instead of ~1000 ATen launches."""
+    288-294), fused into the tile kernels (round 4): the tile forward left every work block's sum of squares, so the norms
+    are two tiny launches (GHN3_OP_PARAM_NORM_FIN) and the gradient  g p / ||p||  is formed inside the tile backward from
+    the predicted values -- no pass over the 346 MB output in either direction (rounds 1-3: GHN3_OP_PARAM_NORM_FWD / BWD,
+    0.24 ms per step).  Plans compiled without a backward program keep the streaming ops."""
 
     @staticmethod
     def forward(ctx, flat, ghn, plan):
         prog = plan.program
-        f_ops, b_ops = prog.norm_ops(1.0)
         ghn._fill_bufs(plan, out=flat)
-        ghn._ctx().run(f_ops, prog.problems, plan.bufs, torch.cuda.current_stream().cuda_stream)
-        ctx.ghn, ctx.plan, ctx.b_ops = ghn, plan, b_ops
+        stream = torch.cuda.current_stream().cuda_stream
+        ctx.fused = prog.training and getattr(prog, 'tile_bwd_op', None) is not None
+        if ctx.fused:
+            ghn._ctx().run(prog.norm_fin_ops(), prog.problems, plan.bufs, stream)
+            ctx.b_ops = None
+        else:
+            f_ops, ctx.b_ops = prog.norm_ops(1.0)
+            ghn._ctx().run(f_ops, prog.problems, plan.bufs, stream)
+        ctx.ghn, ctx.plan = ghn, plan
         ctx.save_for_backward(flat)
         return plan.scal[:4].view(torch.float32)[0].clone()
 
@@ -210,6 +226,12 @@ class _ParamNormLoss(torch.autograd.Function):
     def backward(ctx, g):
         (flat,) = ctx.saved_tensors
         ghn, plan = ctx.ghn, ctx.plan
+        if ctx.fused:
+            # hand the (device-side) weight of the term to the GHN's backward and return a stride-0 zero gradient: the
+            # autograd engine still runs _GHN3Function.backward, which recognises the placeholder
+            plan.norm_g = g.detach().to(torch.float32).reshape(1).contiguous()
+            ctx.ghn = ctx.plan = None
+            return flat.new_zeros(1).expand(flat.numel()), None, None
         dflat = torch.empty_like(flat)
         ghn._fill_bufs(plan, out=flat, dout=dflat)
         ghn._ctx().run(ctx.b_ops, plan.program.problems, plan.bufs, torch.cuda.current_stream().cuda_stream)
@@ -483,17 +505,33 @@ class GHN3(nn.Module):
         lo, hi = prog.decoder_slots
         return int(self._offs[lo]), int(self._offs[hi]) if hi < len(self._offs) else int(self._flat_numel)
 
-    def _run_backward(self, plan, dout, reducer=None):
-        """reducer (data parallel, ddp_utils.FlatGradReducer): the backward program runs in parts (Program.bwd_parts);
+    def _run_backward(self, plan, dout, reducer=None, norm_g=None):
+        """dout: upstream gradient of the flat predicted buffer (or None); norm_g: device float, weight of the fused
+        predicted-parameter-norm loss  norm_g * sum_t ||p_t||_F  whose gradient the tile backward forms itself (needs the
+        norms of Program.norm_fin_ops in the plan's scalar buffer).
+        reducer (data parallel, ddp_utils.FlatGradReducer): the backward program runs in parts (Program.bwd_parts);
         the all-reduce of the W2 gradient (69 % of the bytes at ghn3xlm16) starts as soon as the side stream has produced
         it, the rest of the decoder (24 %) follows, both overlap with the Graphormer backward; the remaining gradients
         are reduced at the end."""
         prog = plan.program
         if len(prog.bwd_ops) == 0:
             raise L.Ghn3Error('this plan was compiled without a backward program (training=False)')
+        if dout is None and norm_g is None:
+            raise L.Ghn3Error('backward without an upstream gradient')
         gflat = torch.empty(self._flat_numel, dtype=torch.float32, device=self.device)
         self._fill_bufs(plan, out=plan.out, dout=dout, gflat=gflat)
         self._patch_grad_memsets(prog)
+        kt = getattr(prog, 'tile_bwd_op', None)
+        if kt is not None:                               # which upstream terms the tile backward reads in this step
+            r = prog.bwd_ops[kt]['r']
+            for slot, (buf, off) in prog.tile_bwd_refs.items():
+                on = (dout is not None) if slot == 0 else (norm_g is not None)
+                r[slot]['buf'], r[slot]['off'] = (buf, off) if on else (-1, 0)
+            if norm_g is not None:
+                plan._norm_g = norm_g                    # (kept alive until the kernels ran)
+                plan.bufs[prog.xbuf(prog.X_NORMG)] = norm_g.data_ptr()
+        elif norm_g is not None:
+            raise L.Ghn3Error('the fused norm loss needs a plan with predicted tensors')
         stream = torch.cuda.current_stream().cuda_stream
         if reducer is None:
             self._ctx().run(prog.bwd_ops, prog.problems, plan.bufs, stream)
@@ -501,6 +539,8 @@ class GHN3(nn.Module):
             ctx = self._ctx()
             k = prog.memset_grad_op                      # (the memset placeholders live in the first part)
             prog.bwd_parts[0][0][k:k + 2] = prog.bwd_ops[k:k + 2]
+            if kt is not None:
+                prog.bwd_parts[0][0][kt] = prog.bwd_ops[kt]
             reducer.begin()
             n_off = len(self._offs)
             for ops, slots in prog.bwd_parts:

@@ -55,7 +55,7 @@ class Program:
     """See module docstring.  cfg: dict(hid, heads, layers, num_classes, max_shape)."""
 
     # extra buffer slots after the 2*P parameter / gradient pointers
-    X_WS, X_IDX, X_EDGES, X_OUT, X_DOUT, X_TOK, X_SCAL, X_GRADFLAT, X_SHADOW, X_COUNT = range(10)
+    X_WS, X_IDX, X_EDGES, X_OUT, X_DOUT, X_TOK, X_SCAL, X_GRADFLAT, X_SHADOW, X_NORMG, X_COUNT = range(11)
 
     def __init__(self, cfg, node_infos, n_nodes, node_types, max_edge, nets, index_mode='reference',
                  training=True, predict_class_layers=True, reduce_graph=False, layernorm=True, weight_norm=True,
@@ -1186,10 +1186,13 @@ class Program:
             if r >= self.n1_plain:
                 clsb_row[ind] = r - self.n1_plain
 
+        desc_seg = []                                   # descriptor -> predicted tensor (the fused norm loss)
+
         def add(dst_off, src_buf, src_off, T, E, Sd, R, mode, scale):
             for k in range(4):
                 assert 1 <= E[k] <= T[k] and E[k] <= R[k], (T, E, R)
             descs.append((dst_off, src_off, tuple(Sd), tuple(T), tuple(E), tuple(R), src_buf, mode, scale))
+            desc_seg.append(len(predicted) - 1)
 
         for key, inds in self.param_groups.items():
             if len(inds) == 0:
@@ -1321,15 +1324,25 @@ class Program:
                 rb = row_ok[d_of]
                 ni_b = np.maximum(n_i[d_of], 1)
                 word = np.where(rb, (j // ni_b) | (((j % ni_b) * ich[d_of]) << 24), j * CH)
-                return np.stack([np.where(rb, ~d_of, d_of), word], axis=1)
+                return np.stack([np.where(rb, ~d_of, d_of), word], axis=1), first
 
-            fb = tables(T[:, 0], T[:, 1], T.prod(axis=1))
-            bb = tables(R[:, 0], R[:, 1], R.prod(axis=1))
+            fb, fwd_first = tables(T[:, 0], T[:, 1], T.prod(axis=1))
+            bb, _ = tables(R[:, 0], R[:, 1], R.prod(axis=1))
+        dseg = np.asarray(desc_seg if nd else [0], dtype=np.int32)
         raw = np.concatenate([desc_arr.view(np.uint8).reshape(-1), fb.view(np.uint8).reshape(-1),
-                              bb.view(np.uint8).reshape(-1)])
+                              bb.view(np.uint8).reshape(-1), dseg.view(np.uint8).reshape(-1)])
         self.r_desc = self.idx(raw)
         self.fwd_blk = (len(fb), desc_arr.nbytes)
         self.bwd_blk = (len(bb), desc_arr.nbytes + fb.nbytes)
+        self.desc_seg_off = desc_arr.nbytes + fb.nbytes + bb.nbytes
+        # first forward work block of every predicted tensor (+ the total): the blocks of a tensor are consecutive
+        seg_blk = np.zeros(len(predicted) + 1, dtype=np.int32)
+        if nd:
+            first_desc = np.full(len(predicted), nd, dtype=np.int64)
+            np.minimum.at(first_desc, dseg, np.arange(nd))
+            seg_blk[:-1] = fwd_first[first_desc]
+        seg_blk[-1] = len(fb)
+        self.r_seg_blk = self.idx(seg_blk)
         seg = np.asarray([[p['offset'], p['offset'] + p['numel']] for p in predicted], dtype=np.int64).reshape(-1, 2)
         self.r_seg = self.idx(seg if len(seg) else np.zeros((1, 2), dtype=np.int64))
         self.n_seg = len(predicted)
@@ -1339,7 +1352,10 @@ class Program:
         self.r_seg_first = self.idx(np.searchsorted(ends, starts, side='right').astype(np.int32))
         srcs = self._tile_sources(False)
         if self.n_desc:
-            self.op(L.OP_TILE_FWD, refs=[(self.xbuf(self.X_OUT), 0)] + srcs + [self.r_desc],
+            # (training: every work block leaves the sum of squares of what it wrote -- the predicted-parameter norm loss
+            # then needs no pass over the output, see norm_fin_ops)
+            parts = self.wsf('sq_parts', self.fwd_blk[0]) if self.training else self.NONE
+            self.op(L.OP_TILE_FWD, refs=[(self.xbuf(self.X_OUT), 0)] + srcs + [self.r_desc, parts],
                     ints=(self.n_desc, self.fwd_blk[0], self.fwd_blk[1], self.tile_lds[0]),
                     flags=L.OPFLAG_TIMED | (self.TAG_TILE_FWD << 16))
 
@@ -1375,6 +1391,21 @@ class Program:
         self._ops = saved
         return f_ops, b_ops
 
+    def norm_fin_ops(self):
+        """Ops of the FUSED sum_t ||p_t||_F (trainer.py:288-294): the per-tensor norms from the block sums the tile forward
+        left in the workspace (no pass over the flat output); loss -> X_SCAL[0], norms -> X_SCAL[256 ...].  The gradient of
+        the term is formed inside GHN3_OP_TILE_BWD (GHN3._run_backward(norm_g=...))."""
+        scal = self.xbuf(self.X_SCAL)
+        saved, self._ops = self._ops, []
+        if self.n_desc and 'sq_parts' in self._ws_names:
+            self.op(L.OP_PARAM_NORM_FIN, refs=((scal, 0), (scal, 256), self.wref('sq_parts'), self.r_seg_blk),
+                    ints=(self.n_seg,))
+        else:
+            self.op(L.OP_MEMSET0, refs=((scal, 0),), ints=(4,))
+        ops = self._finish_ops()
+        self._ops = saved
+        return ops
+
     # ------------------------------------------------------------------ backward
     def _colsum(self, out, X, M, N, ld, q=0, s=0, stride=1, gather=None):
         self.op(L.OP_COLSUM, refs=(out, X, gather if gather is not None else self.NONE),
@@ -1397,6 +1428,7 @@ class Program:
         self.op(L.OP_MEMSET0, refs=((self.xbuf(self.X_GRADFLAT), 0),), ints=(-1,))
         self.op(L.OP_MEMSET0, refs=((self.xbuf(self.X_GRADFLAT), 0),), ints=(-1,))
         self.memset_grad_op = 0
+        self.tile_bwd_op = None
         self.grad_no_memset = []
         self.bwd_cut_w2 = 0
         late_ops = []
@@ -1429,8 +1461,16 @@ class Program:
             grads = self._tile_sources(True)
             if scaled:
                 grads[5] = amax_t
-            self.op(L.OP_TILE_BWD, refs=[(self.xbuf(self.X_DOUT), 0)] + self._tile_sources(False) + [self.r_desc] +
-                    grads, ints=(self.n_desc, self.bwd_blk[0], self.bwd_blk[1], self.tile_lds[1]),
+            # r0 = upstream gradient of the predicted tensors and / or the fused norm loss (r6 = its device-side weight g,
+            # r14 = per-tensor norms, r15 = the predicted values): GHN3._run_backward disables what a step does not use
+            # (compiled with the norm term off: r6 / r14 / r15 absent; tile_bwd_refs = what GHN3._run_backward patches in)
+            srcs = self._tile_sources(False)
+            self.tile_bwd_op = len(self._ops)
+            self.tile_bwd_refs = {0: (self.xbuf(self.X_DOUT), 0), 6: (self.xbuf(self.X_NORMG), 0),
+                                  14: (self.xbuf(self.X_SCAL), 256), 15: (self.xbuf(self.X_OUT), 0)}
+            self.op(L.OP_TILE_BWD, refs=[(self.xbuf(self.X_DOUT), 0)] + srcs + [self.r_desc] + grads +
+                    [self.NONE, self.NONE],
+                    ints=(self.n_desc, self.bwd_blk[0], self.bwd_blk[1], self.tile_lds[1], self.desc_seg_off),
                     flags=L.OPFLAG_TIMED | (self.TAG_TILE_BWD << 16))
 
         def decoder_1d_bwd(side):

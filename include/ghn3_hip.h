@@ -261,7 +261,9 @@ enum ghn3_op_kind {
      * i: n_desc, n_work_blocks, byte offset from r7 to the int64 (descriptor, start) work-block table, LDS bytes
      * A work block (k, start) with k >= 0 covers TILE_CHUNK (2048) consecutive elements of descriptor k; a block
      * (~k, a0 | i0 << 24) with ~k < 0 is a ROW block: elements [i0, i0 + _pad) of row a0 of descriptor k moved through LDS (4-D
-     * kernels with kh * kw > 1, mode 0, S[1] == 1, E[2..3] == T[2..3] == R[2..3]); i3 = max floats * 4 it needs */
+     * kernels with kh * kw > 1, mode 0, S[1] == 1, E[2..3] == T[2..3] == R[2..3]); i3 = max floats * 4 it needs
+     * r8 = optional float slots, one per work block: the block's sum of squares of what it wrote (the per-tensor Frobenius
+     * norms of trainer.py:288-294 then need no pass over the 346 MB output: GHN3_OP_PARAM_NORM_FIN adds a tensor's slots) */
     GHN3_OP_TILE_FWD = 8,
     /* sum over predicted tensors of ||p||_F (trainer.py:97-98,288-294)
      * r0=loss(1 float, accumulated) r1=flat r2=seg_off(int64 (begin,end) pairs, sorted by begin, disjoint)
@@ -274,7 +276,12 @@ enum ghn3_op_kind {
     GHN3_OP_PARAM_NORM_BWD = 10,
     /* r0=dflat, r1..r6 = source buffers (values), r7=desc, r8..r12 = source-grad buffers, r13 = optional device float
      * that receives the running max |x| of everything written to source-grad buffer 0 (the decoder tiles)
-     * i: n_desc, n_work_blocks, byte offset from r7 to the backward work-block table, LDS bytes (row blocks) */
+     * i: n_desc, n_work_blocks, byte offset from r7 to the backward work-block table, LDS bytes (row blocks)
+     * Fused predicted-parameter-norm loss (trainer.py:97-98,288-294: loss += w sum_t ||p_t||_F): with r14 = per-tensor norms
+     * (GHN3_OP_PARAM_NORM_FIN) the upstream gradient of element e of tensor t is  dflat[e] + g * out[e] / norm_t  with
+     * r15 = the flat predicted buffer `out`, g = the device float r6 (source slot 5 is never a tile source) and i4 = byte
+     * offset from r7 to the int32 descriptor -> tensor table; r0 (dflat) may then be absent: the norm term alone.  The
+     * 346 MB gradient of the norm term is never materialised. */
     GHN3_OP_TILE_BWD = 11,
     /* column sums: out[omap(n)] += sum_m X[g(m)][n] ; r0=out r1=X r2=row gather (int32) or absent
      * i: M,N,ld,q,s,stride,accum(must be 1) ; omap(n) = ((n/q)*s + n%q)*stride (q == 0: n*stride) */
@@ -361,6 +368,11 @@ enum ghn3_op_kind {
      * i5 / i6 = floats between batches in src / dst.  Utility (k-contiguous fp32 copies of k-strided operands; the compiled
      * programs of this round use the 16-bit transposed copies of GHN3_OP_CAST16 instead). */
     GHN3_OP_TRANSPOSE32 = 32,
+    /* per-tensor Frobenius norms from the per-work-block sums of squares GHN3_OP_TILE_FWD left (r8 there), added in block
+     * order (deterministic): norms[t] = sqrt(sum_{b in [first[t], first[t + 1])} parts[b]); loss[0] = sum_t norms[t] (fixed
+     * order).  r0=loss (1 float, overwritten) r1=norms (n floats) r2=parts r3=first (int32, n + 1 entries) ; i0 = n tensors.
+     * Replaces GHN3_OP_PARAM_NORM_FWD's pass over the flat output (trainer.py:288-294).  (ABI v14) */
+    GHN3_OP_PARAM_NORM_FIN = 33,
     GHN3_OP_KIND_COUNT
 };
 
@@ -369,7 +381,7 @@ typedef struct ghn3_op {
     int32_t flags;
     int64_t i[8];
     float f[4];
-    ghn3_ref r[14];
+    ghn3_ref r[16];
 } ghn3_op;
 
 typedef struct ghn3_ctx ghn3_ctx;

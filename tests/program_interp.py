@@ -626,6 +626,13 @@ class Interp:
     def op_tile_fwd(self, o, problems):
         flat = self.tail(o['r'][0], np.float32)
         srcs = [self.tail(o['r'][1 + k], np.float32) for k in range(6)]
+        parts = self.tail(o['r'][8], np.float32)
+        desc_of_block = None
+        if parts is not None:
+            nblk = int(o['i'][1])
+            tab = self.tail(o['r'][7], np.uint8)[int(o['i'][2]):int(o['i'][2]) + 16 * nblk].view(np.int64).reshape(nblk, 2)
+            desc_of_block = np.where(tab[:, 0] < 0, ~tab[:, 0], tab[:, 0])
+        kd = 0
         for D in self._descs(o):
             T, E, S = D['T'].astype(np.int64), D['E'].astype(np.int64), D['S'].astype(np.int64)
             idx = [np.arange(T[k]) % E[k] for k in range(4)]
@@ -633,17 +640,36 @@ class Interp:
                   idx[2][None, None, :, None] * S[2] + idx[3][None, None, None, :] * S[3]) + int(D['src_off'])
             v = srcs[int(D['src_buf'])][so.reshape(-1)].astype(np.float64)
             n = int(np.prod(T))
-            flat[int(D['dst_off']):int(D['dst_off']) + n] = self._norm(v, int(D['mode']), float(D['scale']))
+            val = self._norm(v, int(D['mode']), float(D['scale']))
+            flat[int(D['dst_off']):int(D['dst_off']) + n] = val
+            if parts is not None:                       # r8: per-work-block sums of squares (here: all in the first block)
+                blk = np.nonzero(desc_of_block == kd)[0]
+                parts[blk] = 0.0
+                parts[blk[0]] = np.float32((val.astype(np.float32).astype(np.float64) ** 2).sum())
+            kd += 1
 
     def op_tile_bwd(self, o, problems):
         g = self.tail(o['r'][0], np.float32)
         srcs = [self.tail(o['r'][1 + k], np.float32) for k in range(6)]
         dsrcs = [self.tail(o['r'][8 + k], np.float32) for k in range(5)] + [None]
         amax = self.tail(o['r'][13], np.float32)            # r13: running max |x| written to source-grad buffer 0
-        for D in self._descs(o):
+        # fused predicted-parameter-norm loss: r14 = per-tensor norms, r15 = predicted values, r6 = device float g,
+        # i4 = byte offset (from r7) of the int32 descriptor -> tensor table
+        norms = self.tail(o['r'][14], np.float32)
+        assert g is not None or norms is not None
+        if norms is not None:
+            outv, gs = self.tail(o['r'][15], np.float32), float(self.tail(o['r'][6], np.float32)[0])
+            dseg = self.tail(o['r'][7], np.uint8)[int(o['i'][4]):int(o['i'][4]) + 4 * int(o['i'][0])].view(np.int32)
+        for kd, D in enumerate(self._descs(o)):
             T, E, S, R = (D[k].astype(np.int64) for k in ('T', 'E', 'S', 'R'))
             n = int(np.prod(T))
-            gt = g[int(D['dst_off']):int(D['dst_off']) + n].astype(np.float64).reshape(T)
+            gt = np.zeros(tuple(T), dtype=np.float64)
+            if g is not None:
+                gt = gt + g[int(D['dst_off']):int(D['dst_off']) + n].astype(np.float64).reshape(T)
+            if norms is not None:
+                nrm = float(norms[int(dseg[kd])])
+                if nrm > 0:
+                    gt = gt + (gs / nrm) * outv[int(D['dst_off']):int(D['dst_off']) + n].astype(np.float64).reshape(T)
             acc = np.zeros(tuple(R), dtype=np.float64)
             sub = np.zeros(tuple(E), dtype=np.float64)
             idx = [np.arange(T[k]) % E[k] for k in range(4)]
@@ -661,6 +687,14 @@ class Interp:
             dsrcs[int(D['src_buf'])][so.reshape(-1)] = acc.reshape(-1).astype(np.float32)
             if amax is not None and int(D['src_buf']) == 0 and acc.size:
                 amax[0] = max(float(amax[0]), float(np.abs(acc.astype(np.float32)).max()))
+
+    def op_param_norm_fin(self, o, problems):
+        n = int(o['i'][0])
+        loss, norms = self.tail(o['r'][0], np.float32), self.tail(o['r'][1], np.float32)
+        parts, first = self.tail(o['r'][2], np.float32), self.tail(o['r'][3], np.int32)
+        for t in range(n):
+            norms[t] = np.float32(np.sqrt(parts[int(first[t]):int(first[t + 1])].astype(np.float64).sum()))
+        loss[0] = np.float32(norms[:n].astype(np.float64).sum())
 
     def op_param_norm_fwd(self, o, problems):
         n = int(o['i'][0])

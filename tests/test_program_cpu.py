@@ -220,6 +220,50 @@ def test_param_norm_ops():
                                atol=1e-7)
 
 
+@pytest.mark.parametrize('case,with_dout', [('b2', False), ('b2', True), ('big', False), ('mixed1d', False)])
+def test_fused_param_norm_loss_program(case, with_dout):
+    """The predicted-parameter-norm loss fused into the tile kernels (round 4): per-work-block sums of squares from
+    GHN3_OP_TILE_FWD -> GHN3_OP_PARAM_NORM_FIN (norms, loss); GHN3_OP_TILE_BWD forms  dout + g p / ||p||  itself.  The flat
+    gradient must equal the one of the streaming ops (PARAM_NORM_FWD / BWD writing a materialised dout), with and without an
+    additional upstream gradient."""
+    cfg = dict(recipe.TINY_CFG, **(recipe.EXTRA_CASES[case][1] if case in recipe.EXTRA_CASES else {}))
+    g_w = 0.37
+    grads = []
+    for fused in (False, True):
+        hip, _ = _build(cfg, recipe.TINY_SEED, 'reference')
+        nets_h, gb_h, _, _ = _tiny(case)
+        prog, it, bufs, gflat = _run_program(hip, nets_h, gb_h)
+        out = bufs[prog.xbuf(prog.X_OUT)].view(np.float32)
+        dout = bufs[prog.xbuf(prog.X_DOUT)].view(np.float32)
+        extra = (0.01 * np.random.RandomState(5).standard_normal(prog.out_numel)).astype(np.float32)
+        expect = sum(np.linalg.norm(out[p['offset']:p['offset'] + p['numel']].astype(np.float64)) for p in prog.predicted)
+        if fused:
+            it.run(prog.norm_fin_ops(), prog.problems)
+            loss = bufs[prog.xbuf(prog.X_SCAL)][:4].view(np.float32)[0]
+            assert abs(loss - expect) < 1e-5 * expect
+            bufs[prog.xbuf(prog.X_NORMG)] = np.asarray([g_w], dtype=np.float32).view(np.uint8)
+            it.bufs = bufs
+            r = prog.bwd_ops[prog.tile_bwd_op]['r']
+            for slot, (buf, off) in prog.tile_bwd_refs.items():
+                on = with_dout if slot == 0 else True
+                r[slot]['buf'], r[slot]['off'] = (buf, off) if on else (-1, 0)
+            if with_dout:
+                dout[:] = extra
+        else:
+            f_ops, b_ops = prog.norm_ops(g_w)
+            it.run(f_ops, prog.problems)
+            it.run(b_ops, prog.problems)
+            if with_dout:
+                dout += extra
+        gflat[:] = 0x7f
+        hip._patch_grad_memsets(prog)
+        it.run(prog.bwd_ops, prog.problems)
+        grads.append(gflat.view(np.float32).copy())
+    a, b = grads
+    assert np.isfinite(a).all() and np.isfinite(b).all()
+    assert np.linalg.norm(a.astype(np.float64) - b) < 1e-5 * np.linalg.norm(a.astype(np.float64))
+
+
 def test_synthetic_program_and_counts():
     from ghn3_amd.synthetic import synthetic_batch
     gb, nets = synthetic_batch([40, 31], 777)

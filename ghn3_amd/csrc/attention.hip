@@ -447,15 +447,17 @@ __global__ __launch_bounds__(256) void attn_fwd_stream_kernel(float* __restrict_
 // backward: grid (2 * ceil(N / 32), H, B); blockIdx.x < NB: row role (32 queries: dQ, dBias += dS),
 // otherwise column role (32 keys: dK, dV).  delta_i = sum_e dO[i][e] O[i][e] (= rowsum(P * dP)).
 // ------------------------------------------------------------------------------------------------
-template <int KS>
-__global__ __launch_bounds__(256, 2) void attn_bwd_kernel(float* __restrict__ dqkv, const float* __restrict__ dO,
+// NW waves per workgroup split the tiles of the other dimension.  NW = 8 for graphs of up to 256 nodes (one tile per wave:
+// no dependent second round of loads, twice the fetch rate of a 4-wave workgroup): 16.3 -> 14.8 us alone (round 3), adopted
+// in round 4 when the W2 weight gradient left the side stream and the chain runs undisturbed.
+template <int KS, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_bwd_kernel(float* __restrict__ dqkv, const float* __restrict__ dO,
                                                        const float* __restrict__ qkv, const float* __restrict__ P,
                                                        const float* __restrict__ Oin, float* __restrict__ dBias,
                                                        const int* __restrict__ n_nodes, int N, int C, int H,
                                                        float scale, int vec) {
-    __shared__ float red[4 * 16 * 64];
-    __shared__ float red2[4 * 16 * 64];
-    __shared__ float dl[4][32];
+    __shared__ float red[NW * 16 * 64];
+    __shared__ float dl[NW][32];
     const int d = C / H;
     const int NB = (N + 31) >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -479,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(float* __restrict__ dq
         for (int s = 0; s < KS; ++s) delta += gb[s] * ob[s];
         delta += __shfl_xor(delta, 32, 64);
         f32x16 dQ = zero16();
-        for (int t = w; t < NB; t += 4) {
+        for (int t = w; t < NB; t += NW) {
             const int j0 = t * 32;
             float va[KS];
             const int j = j0 + l31;
@@ -536,17 +538,17 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(float* __restrict__ dq
             }
             dQ = mfma_cols(kc, ds, dQ);                            // dQ^T += K^T dS^T
         }
-        f32x4 o = reduce_waves(red, dQ, w, lane);
+        f32x4 o = reduce_waves<NW>(red, dQ, w, lane);
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] *= scale;
-        if (qi < N) store4(dqkv + ((size_t)b * N + qi) * 3 * C + h * d, 8 * w + 4 * lhi, d, vq, o);
+        if (w < 4 && qi < N) store4(dqkv + ((size_t)b * N + qi) * 3 * C + h * d, 8 * w + 4 * lhi, d, vq, o);
     } else {
         // ---------------- column role: lane = key kj, accumulator registers = queries ----------------
         const int kj = (blockIdx.x - NB) * 32 + l31;
         float vb[KS];
         load_row_operand<KS>(kj < N ? base + (size_t)kj * 3 * C + 2 * C : nullptr, d, lhi, vq, vb);
         f32x16 dV = zero16(), dK = zero16();
-        for (int t = w; t < NB; t += 4) {
+        for (int t = w; t < NB; t += NW) {
             const int q0 = t * 32;
             const int qrow = q0 + l31;
             float ga[KS], oa[KS];
@@ -580,11 +582,12 @@ __global__ __launch_bounds__(256, 2) void attn_bwd_kernel(float* __restrict__ dq
             dV = mfma_cols(gc, p, dV);                             // dV^T += dO^T P
             dK = mfma_cols(qc, ds, dK);                            // dK^T += Q^T dS
         }
-        const f32x4 ov = reduce_waves(red, dV, w, lane);
-        f32x4 ok = reduce_waves(red2, dK, w, lane);
+        const f32x4 ov = reduce_waves<NW>(red, dV, w, lane);
+        __syncthreads();                                      // (one exchange buffer for both reductions)
+        f32x4 ok = reduce_waves<NW>(red, dK, w, lane);
 #pragma unroll
         for (int c = 0; c < 4; ++c) ok[c] *= scale;
-        if (kj < N) {
+        if (w < 4 && kj < N) {
             float* row = dqkv + ((size_t)b * N + kj) * 3 * C + h * d;
             store4(row + 2 * C, 8 * w + 4 * lhi, d, vq, ov);
             store4(row + C, 8 * w + 4 * lhi, d, vq, ok);
@@ -611,16 +614,23 @@ static attn_fwd_fn pick_fwd(int d, int tpw) {
     if (d <= 24) return fwd_for<12>(tpw);
     return fwd_for<16>(tpw);
 }
-static attn_bwd_fn pick_bwd(int d) {
-    if (d <= 4) return attn_bwd_kernel<2>;
-    if (d <= 8) return attn_bwd_kernel<4>;
-    if (d <= 16) return attn_bwd_kernel<8>;
-    if (d <= 24) return attn_bwd_kernel<12>;
-    return attn_bwd_kernel<16>;
+static int g_attn_bwd_waves = 8;
+template <int NW> static attn_bwd_fn pick_bwd_nw(int d) {
+    if (d <= 4) return attn_bwd_kernel<2, NW>;
+    if (d <= 8) return attn_bwd_kernel<4, NW>;
+    if (d <= 16) return attn_bwd_kernel<8, NW>;
+    if (d <= 24) return attn_bwd_kernel<12, NW>;
+    return attn_bwd_kernel<16, NW>;
+}
+// eight waves when every wave gets at most one tile of the other dimension (N <= 256), four otherwise
+static attn_bwd_fn pick_bwd(int d, int N, int* nw) {
+    *nw = (g_attn_bwd_waves == 8 && N <= 256) ? 8 : 4;
+    return *nw == 8 ? pick_bwd_nw<8>(d) : pick_bwd_nw<4>(d);
 }
 
 int ghn3_attn_init() {
     if (getenv("GHN3_ATTN_FWD_WAVES")) g_attn_fwd_waves = atoi(getenv("GHN3_ATTN_FWD_WAVES")) == 4 ? 4 : 8;
+    if (getenv("GHN3_ATTN_BWD_WAVES")) g_attn_bwd_waves = atoi(getenv("GHN3_ATTN_BWD_WAVES")) == 4 ? 4 : 8;
     return GHN3_OK;
 }
 
@@ -668,7 +678,9 @@ int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P
     const int nb = (N + 31) / 32;
     const int vec = (C % 4 == 0) && aligned16(dqkv) && aligned16(dO) && aligned16(qkv) && aligned16(P) &&
                     aligned16(O) && aligned16(dBias);
-    hipLaunchKernelGGL(pick_bwd(d), dim3(2 * nb, H, B), dim3(256), 0, s, dqkv, dO, qkv, P, O, dBias, n_nodes, N, C, H,
+    int nw = 4;
+    attn_bwd_fn fn = pick_bwd(d, N, &nw);
+    hipLaunchKernelGGL(fn, dim3(2 * nb, H, B), dim3(64 * nw), 0, s, dqkv, dO, qkv, P, O, dBias, n_nodes, N, C, H,
                        scale, vec);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("attn bwd launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }

@@ -876,9 +876,11 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
             const int n = nl * hw;
             constexpr int U = 4;                              // 16-byte loads in flight per thread (dword aligned)
             for (int b0 = threadIdx.x * 4; b0 < n; b0 += 1024 * U) {
-                f4u acc[U];
+                // (the norm term is linear: the predicted values are summed on their own and scaled by g / ||p|| once at
+                // the end, so the two dependent loads behind `kn` are not waited for inside the replica loop)
+                f4u acc[U], acc2[U];
 #pragma unroll
-                for (int u = 0; u < U; ++u) acc[u] = f4u{0.f, 0.f, 0.f, 0.f};
+                for (int u = 0; u < U; ++u) { acc[u] = f4u{0.f, 0.f, 0.f, 0.f}; acc2[u] = f4u{0.f, 0.f, 0.f, 0.f}; }
                 for (int t0 = a0; t0 < T0; t0 += E0)
                     for (int r0 = 0; r0 + i0 < T1; r0 += E1) {              // replicas along i
                         const int lim = min(nl, T1 - r0 - i0) * hw;          // a last partial replica covers fewer i
@@ -903,16 +905,21 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
                             for (int u = 0; u < U; ++u) {
                                 const int j = b0 + 1024 * u;
                                 if (j + 4 <= lim) {
-                                    const f4u v = *reinterpret_cast<const f4u*>(pr + j);
-                                    acc[u].x += kn * v.x; acc[u].y += kn * v.y; acc[u].z += kn * v.z; acc[u].w += kn * v.w;
+                                    acc2[u] += *reinterpret_cast<const f4u*>(pr + j);
                                 } else {
-                                    if (j < lim) acc[u].x += kn * pr[j];
-                                    if (j + 1 < lim) acc[u].y += kn * pr[j + 1];
-                                    if (j + 2 < lim) acc[u].z += kn * pr[j + 2];
+                                    if (j < lim) acc2[u].x += pr[j];
+                                    if (j + 1 < lim) acc2[u].y += pr[j + 1];
+                                    if (j + 2 < lim) acc2[u].z += pr[j + 2];
                                 }
                             }
                         }
                     }
+                if (outp) {
+#pragma unroll
+                    for (int u = 0; u < U; ++u) {
+                        acc[u].x += kn * acc2[u].x; acc[u].y += kn * acc2[u].y; acc[u].z += kn * acc2[u].z; acc[u].w += kn * acc2[u].w;
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < U; ++u) {
                     const int j = b0 + 1024 * u;
@@ -988,7 +995,7 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
     for (; e < end; e += 256) {
         const int a0 = o.d[0], a2 = o.d[1], a3 = o.d[2], a1 = o.d[3];
         const int64_t so = (int64_t)a0 * S0 + (int64_t)a1 * S1 + (int64_t)a2 * S2 + (int64_t)a3 * S3;
-        float acc = 0.f;
+        float acc = 0.f, acc2 = 0.f;
         if (a0 < E0 && a1 < E1 && a2 < E2 && a3 < E3) {
             for (int t0 = a0; t0 < T0; t0 += E0)
                 for (int t1 = a1; t1 < T1; t1 += E1)
@@ -996,9 +1003,9 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
                         for (int t3 = a3; t3 < T3; t3 += E3) {
                             const int64_t gi = (((int64_t)t0 * T1 + t1) * T2 + t2) * T3 + t3;
                             if (g) acc += g[gi];
-                            if (outp) acc += kn * outp[gi];
+                            if (outp) acc2 += outp[gi];
                         }
-            acc *= norm_grad(src[so], mode, scale);
+            acc = (acc + kn * acc2) * norm_grad(src[so], mode, scale);
         }
         dsrc[so] = acc;
         mx = fmaxf(mx, fabsf(acc));
@@ -1600,9 +1607,14 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
         // straight copy only (the dgrad operand of the decoder gradients, forward activations): 8 consecutive floats per
         // lane -> one 16-byte store (the general path below writes 8 bytes per lane)
         unsigned short* Dd = dst + D.dst_off;
+        // (no transposition here, so the work tile need not be square: block t of the descriptor covers the 4096 consecutive
+        // elements [4096 t, 4096 t + 4096) of the row-major (64-padded rows) x (64-padded cols) grid -- 8 KB contiguous
+        // source runs per pass instead of 64 runs of 256 bytes from 64 different rows / DRAM pages)
+        const int64_t wp = (int64_t)tiles_c * 64;               // padded row length
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int r = r0 + (tid >> 3) + 32 * i, c = c0 + (tid & 7) * 8;
+            const int64_t e0 = (int64_t)t * 4096 + 2048 * i + tid * 8;
+            const int r = (int)(e0 / wp), c = (int)(e0 - (int64_t)r * wp);
             if (r >= D.rows) continue;
             const float* p = S + (int64_t)r * D.ld_src + c;
             float x[8];

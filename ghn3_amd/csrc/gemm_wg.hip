@@ -51,8 +51,8 @@ __device__ __forceinline__ void wg_stage(char* s_hi, char* s_lo, int f, int k, c
     }
 }
 
-__global__ __launch_bounds__(256) void gemm_wg_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
-    __shared__ __attribute__((aligned(16))) char sm[WG_LDS];
+// one 64 x 64 tile (tile id `tile` of the launch)
+__device__ __forceinline__ void wg_tile(const GemmProbDev* __restrict__ probs, int n_probs, int tile, char* sm) {
     char* sAh = sm;
     char* sAl = sm + 64 * 128;
     char* sBh = sm + 2 * 64 * 128;
@@ -62,10 +62,10 @@ __global__ __launch_bounds__(256) void gemm_wg_kernel(const GemmProbDev* __restr
     int lo = 0, hi_ = n_probs - 1;
     while (lo < hi_) {
         const int mid = (lo + hi_ + 1) >> 1;
-        if (probs[mid].tile_start <= (int)blockIdx.x) lo = mid; else hi_ = mid - 1;
+        if (probs[mid].tile_start <= tile) lo = mid; else hi_ = mid - 1;
     }
     const GemmProbDev* P = probs + lo;
-    const int t_id = blockIdx.x - P->tile_start;
+    const int t_id = tile - P->tile_start;
     const int n0 = (t_id % P->tiles_n) * WG_BN, m0 = (t_id / P->tiles_n) * WG_BM;
     const int M = P->M, N = P->N, K = P->K, lda = P->lda, ldb = P->ldb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -177,11 +177,25 @@ __global__ __launch_bounds__(256) void gemm_wg_kernel(const GemmProbDev* __restr
     }
 }
 
+// A launch may cap its grid: the workgroups then stride over the tiles.  The weight gradients run on the side stream beside
+// the dependent chain; an uncapped launch (432 small workgroups per layer) back-fills every wave slot that frees up, so the
+// chain's fat workgroups (768 threads, 168 VGPRs) find no empty CU until the launch has drained (r04h: up to 100 us stalls
+// at the hand-offs).  Measured r04i: capped launches stretch the side stream beyond the chain (128 workgroups: +0.13 ms per
+// step, 64: +0.55 ms) -- the cap stays available (op.i[3]) but the compiled programs do not use it.
+__global__ __launch_bounds__(256) void gemm_wg_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int total_tiles) {
+    __shared__ __attribute__((aligned(16))) char sm[WG_LDS];
+    for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
+        wg_tile(probs, n_probs, tile, sm);
+        __syncthreads();                                    // the LDS images are reused by the next tile
+    }
+}
+
 }  // namespace
 
-int ghn3_gemm_wg_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, hipStream_t stream) {
+int ghn3_gemm_wg_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int grid_cap, hipStream_t stream) {
     if (n_probs <= 0 || total_tiles <= 0) return GHN3_OK;
-    hipLaunchKernelGGL(gemm_wg_kernel, dim3(total_tiles), dim3(256), 0, stream, d_probs, n_probs);
+    const int grid = grid_cap > 0 && grid_cap < total_tiles ? grid_cap : total_tiles;
+    hipLaunchKernelGGL(gemm_wg_kernel, dim3(grid), dim3(256), 0, stream, d_probs, n_probs, total_tiles);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("wgrad x3 gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

@@ -609,7 +609,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                     rc = ghn3_gemm_x3_launch(ds + L.first, L.count, L.tiles, 40 + (L.tile - 4000) / 10,
                                              64 * (L.tile % 10), stream);
                 else if (L.tile == 48)
-                    rc = ghn3_gemm_wg_launch(ds + L.first, L.count, L.tiles, stream);
+                    rc = ghn3_gemm_wg_launch(ds + L.first, L.count, L.tiles, (int)o.i[3], stream);
                 else if (L.tile == 32)
                     rc = ghn3_gemm_small_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, L.with_ln, stream);
                 else if (L.tile == 29)

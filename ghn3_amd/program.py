@@ -1799,7 +1799,13 @@ class Program:
                 # gained (step 8.51 ms with the old kernel, 8.56 with tile 25 on every CU, 8.46 at 224, 8.38 at 192 --
                 # but there the weight gradient is back at 1.49 ms).
                 n_before = len(self._ops)
-                wg_main = os.environ.get('GHN3_WGRAD_MAIN', '0') != '0'      # (experiment: on the chain, every CU)
+                # Round 4: the W2 weight gradient runs on the chain's own stream (every CU, in front of the Graphormer backward)
+                # instead of on the side stream beside it.  The persistent kernel takes 144 KB of LDS and 256 VGPRs on every
+                # CU it sits on, so nothing of the chain could co-reside: beside 224 of its workgroups the chain's kernels ran
+                # on the 32 CUs left (336 us per layer instead of ~53).  Serial, the kernel runs undisturbed (0.96 instead of
+                # 1.09 ms: roofline.frac 0.336 instead of 0.318) and the step time is the same within +-0.06 ms
+                # (GHN3_WGRAD_MAIN=0: side stream with GHN3_WGRAD_CAP workgroups, 160 gives the fastest step at frac 0.28).
+                wg_main = os.environ.get('GHN3_WGRAD_MAIN', '1') != '0'
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=not wg_main, flops=fl,
                              tile=int(os.environ.get('GHN3_WGRAD_TILE', '29')),
                              grid_cap=(int(os.environ.get('GHN3_WGRAD_CAP', '224')) |
@@ -1848,9 +1854,28 @@ class Program:
                 p0 = self.gemm(self.href(duhT), self.href(thT), self.gref(W0), 8 * C, 4 * C, Mp, Mp, Mp, 4 * C,
                                accum=True, op16=True, alpha_amax=amax_u)
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D2_BWD, side=True, flops=2.0 * 8 * C * 4 * C * M)
-                p0 = self.gemm(self.href(duh), self.sref(self.w0hT), d_t, M, 4 * C, 8 * C, 8 * C, 8 * C, 4 * C,
-                               dact=L.DACT_RELU, aux_in=t, op16=True, alpha_amax=amax_u)
-                self.gemm_op(p0, ctype=bct, tag=self.TAG_D2_BWD)
+                # conv.0 dgrad: [M x 4C] output with K = 8C is 144 tiles of 128 x 128 at ghn3xlm16 -- half the CUs, 48 k-tiles
+                # each (154 us, 87 TF).  K chunks as separate problems writing partial planes (summed + masked by a DACT
+                # pass in plane order: deterministic) fill the chip.
+                ks = int(os.environ.get('GHN3_D2_DGRAD_KS', '0')) or \
+                    max(1, min(4, 320 // max(1, ((M + 127) // 128) * ((4 * C + 127) // 128))))
+                while ks > 1 and (8 * C) % (64 * ks):
+                    ks -= 1
+                if ks > 1:
+                    kc = 8 * C // ks
+                    planes = self.wsf('d_t_parts', (ks - 1) * M * 4 * C)
+                    p0 = len(self._probs)
+                    for j in range(ks):
+                        dst = d_t if j == 0 else (planes[0], planes[1] + 4 * (j - 1) * M * 4 * C)
+                        self.gemm(self.href(duh + j * kc), self.sref(self.w0hT + j * kc), dst, M, 4 * C, kc, 8 * C, 8 * C,
+                                  4 * C, op16=True, alpha_amax=amax_u)
+                    self.gemm_op(p0, ctype=bct, tag=self.TAG_D2_BWD, flops=2.0 * M * 4 * C * 8 * C)
+                    self.op(L.OP_DACT, refs=(d_t, t, self.NONE, planes),
+                            ints=(M, 4 * C, 4 * C, L.DACT_RELU, ks - 1, M * 4 * C, M))
+                else:
+                    p0 = self.gemm(self.href(duh), self.sref(self.w0hT), d_t, M, 4 * C, 8 * C, 8 * C, 8 * C, 4 * C,
+                                   dact=L.DACT_RELU, aux_in=t, op16=True, alpha_amax=amax_u)
+                    self.gemm_op(p0, ctype=bct, tag=self.TAG_D2_BWD)
             else:
                 p0 = self.gemm(d_u, t, self.gref(W0), 8 * C, 4 * C, M, 8 * C, 4 * C, 4 * C, a_mode=L.MODE_COL,
                                b_mode=L.MODE_COL, accum=True, dbias=self.gref(b0))
@@ -2026,7 +2051,10 @@ class Program:
             # 64 x 64 fp32 tiles (432 per launch) instead of the small-problem kernel: 8.47 -> 8.41 ms per step.  (Without
             # these launches the step is 8.14 ms: the bound on what a faster weight-gradient path could gain; 16-bit
             # operands converted in the kernel are slower and bf16 misses the gradient gate.)
-            self.gemm_op(p0, side=True, tile=int(os.environ.get('GHN3_LAYER_WGRAD_TILE', ('48' if self.x3 else '64') if C >= 256 else '0')))
+            # (optional grid cap, see gemm_wg.hip; measured r04i: 128 / 64 workgroups cost 0.13 / 0.55 ms per step -- the side
+            # stream then takes longer than the chain it runs beside -- so the default is uncapped)
+            self.gemm_op(p0, side=True, tile=int(os.environ.get('GHN3_LAYER_WGRAD_TILE', ('48' if self.x3 else '64') if C >= 256 else '0')),
+                         grid_cap=int(os.environ.get('GHN3_LAYER_WGRAD_CAP', '0')) if self.SIDE else 0)
             self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln1.weight'), self.gref(pre + 'ln1.bias'), dhB, x_in,
                                               m1, r1), ints=(rows, C, 1), flags=self.SIDE)
             side_pending, self._ops = side_pending + self._ops, main_ops

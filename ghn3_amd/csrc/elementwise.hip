@@ -599,6 +599,53 @@ __global__ __launch_bounds__(256) void ln_param_grad_kernel(float* __restrict__ 
         db[c] = accum ? db[c] + b : b;
     }
 }
+// GHN3_OP_LN_PARAM_GRAD_BATCH: the same reduction for many LayerNorms in one launch (blockIdx.y = item)
+__global__ __launch_bounds__(256) void ln_param_grad_batch_kernel(float* __restrict__ gbase, const float* __restrict__ abase,
+                                                                  const int64_t* __restrict__ table, int rows, int C) {
+    __shared__ float sg[16][16], sb[16][16];
+    const int64_t* T = table + 6 * (int64_t)blockIdx.y;
+    float* dg = gbase + T[0];
+    float* db = gbase + T[1];
+    const float* dy = abase + T[2];
+    const float* x = abase + T[3];
+    const float* mean = abase + T[4];
+    const float* rstd = abase + T[5];
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
+    float ag = 0.f, ab = 0.f;
+    if (c < C) {
+        for (int r0 = rl; r0 < rows; r0 += 16 * 8) {
+            float d[8], xv[8], mu[8], rs[8];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const int r = r0 + 16 * k;
+                const bool in = r < rows;
+                d[k] = in ? dy[(size_t)r * C + c] : 0.f;
+                xv[k] = in ? x[(size_t)r * C + c] : 0.f;
+                mu[k] = in ? mean[r] : 0.f;
+                rs[k] = in ? rstd[r] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 8; ++k) { ag += d[k] * (xv[k] - mu[k]) * rs[k]; ab += d[k]; }
+        }
+    }
+    sg[rl][cl] = ag; sb[rl][cl] = ab;
+    __syncthreads();
+    if (rl == 0 && c < C) {
+        float g = 0.f, b = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { g += sg[k][cl]; b += sb[k][cl]; }
+        dg[c] += g;
+        db[c] += b;
+    }
+}
+int ghn3_ln_param_grad_batch(float* gbase, const float* abase, const int64_t* table, int n_items, int rows, int C,
+                             hipStream_t s) {
+    if (n_items <= 0 || rows <= 0 || C <= 0) return GHN3_OK;
+    hipLaunchKernelGGL(ln_param_grad_batch_kernel, dim3((C + 15) / 16, n_items), dim3(256), 0, s, gbase, abase, table, rows, C);
+    return launch_ok("ln_param_grad_batch");
+}
+
 int ghn3_ln_param_grad(float* dg, float* db, const float* dy, const float* x, const float* mean, const float* rstd,
                        int rows, int C, int accum, hipStream_t s) {
     hipLaunchKernelGGL(ln_param_grad_kernel, dim3((C + 15) / 16), dim3(256), 0, s, dg, db, dy, x, mean, rstd, rows, C,
@@ -1303,19 +1350,18 @@ __global__ __launch_bounds__(256) void dact_kernel(float* __restrict__ X, const 
             const float4 z = A4[e];
             float4 v = X4[e];
             if (e < lim4) {
-                // the planes of one element: all loads in flight together (<= 7 extra planes in every program the host
-                // emits), summed in plane order
-                float4 q[7];
+                // the planes of one element, eight loads in flight at a time (the W2 dgrad of the bench workload leaves
+                // 15 planes: a one-at-a-time tail behind the first seven was a chain of dependent round trips), summed in
+                // plane order
+                for (int p0 = 0; p0 < n_parts; p0 += 8) {
+                    float4 q[8];
 #pragma unroll
-                for (int p = 0; p < 7; ++p)
-                    q[p] = p < n_parts ? *reinterpret_cast<const float4*>(parts + (int64_t)p * part_stride + 4 * e)
-                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                    for (int p = 0; p < 8; ++p)
+                        q[p] = p0 + p < n_parts ? *reinterpret_cast<const float4*>(parts + (int64_t)(p0 + p) * part_stride + 4 * e)
+                                                : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                for (int p = 0; p < 7; ++p)
-                    if (p < n_parts) { v.x += q[p].x; v.y += q[p].y; v.z += q[p].z; v.w += q[p].w; }
-                for (int p = 7; p < n_parts; ++p) {
-                    const float4 r = *reinterpret_cast<const float4*>(parts + (int64_t)p * part_stride + 4 * e);
-                    v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+                    for (int p = 0; p < 8; ++p)
+                        if (p0 + p < n_parts) { v.x += q[p].x; v.y += q[p].y; v.z += q[p].z; v.w += q[p].w; }
                 }
             }
             v.x = dact_apply(v.x, z.x, dact); v.y = dact_apply(v.y, z.y, dact);

@@ -92,6 +92,8 @@ int ghn3_layernorm_bwd(float* dx, float* dy, const float* x, const float* g, con
                        int C, hipStream_t s);
 int ghn3_ln_param_grad(float* dg, float* db, const float* dy, const float* x, const float* mean,
                        const float* rstd, int rows, int C, int accum, hipStream_t s);
+int ghn3_ln_param_grad_batch(float* gbase, const float* abase, const int64_t* table, int n_items, int rows, int C,
+                             hipStream_t s);
 int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d_desc, int n_desc,
                   int64_t total, const int64_t* blocks, int lds_bytes, float* sq_parts, hipStream_t s);
 int ghn3_tile_bwd(const float* dflat, const float* const* srcs, float* const* dsrcs,

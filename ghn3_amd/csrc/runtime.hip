@@ -687,6 +687,10 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                     R.get<const float>(o.r[3]), R.get<const float>(o.r[4]), R.get<const float>(o.r[5]),
                                     (int)o.i[0], (int)o.i[1], (int)o.i[2], stream);
             break;
+        case GHN3_OP_LN_PARAM_GRAD_BATCH:
+            rc = ghn3_ln_param_grad_batch(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const int64_t>(o.r[2]),
+                                          (int)o.i[0], (int)o.i[1], (int)o.i[2], stream);
+            break;
         case GHN3_OP_ATTN_FWD:
             rc = ghn3_attn_fwd(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const float>(o.r[2]),
                                R.get<float>(o.r[3]), R.get<const int>(o.r[4]), (int)o.i[0], (int)o.i[1], (int)o.i[2],

@@ -1406,6 +1406,47 @@ class Program:
         self._ops = saved
         return ops
 
+    def _layer_side_ops(self, layers, rows):
+        """Weight gradients (one grouped GEMM launch) and LayerNorm parameter gradients of the given Graphormer layers
+        (autograd of graphormer.py:208-248), on the side stream."""
+        C = self.C
+        p0 = len(self._probs)
+        for d in layers:
+            pre = d['pre']
+            W3, W1f, Wo, Wq = pre + 'ff.net.3.weight', pre + 'ff.net.0.weight', pre + 'attn.to_out.0.weight', \
+                pre + 'attn.to_qkv.weight'
+            self.gemm(d['g_cur'], d['f'], self.gref(W3), C, 4 * C, rows, C, 4 * C, 4 * C, a_mode=L.MODE_COL,
+                      b_mode=L.MODE_COL, accum=True, dbias=self.gref(pre + 'ff.net.3.bias'))
+            self.gemm(d['dz'], d['h2'], self.gref(W1f), 4 * C, C, rows, 4 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
+                      accum=True, dbias=self.gref(pre + 'ff.net.0.bias'))
+            self.gemm(d['g_mid'], d['o'], self.gref(Wo), C, C, rows, C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
+                      accum=True, dbias=self.gref(pre + 'attn.to_out.0.bias'))
+            self.gemm(d['dqkv'], d['h1'], self.gref(Wq), 3 * C, C, rows, 3 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
+                      accum=True)
+        # 64 x 64 fp32 tiles / the split-bf16 weight-gradient kernel (tile 48) instead of the small-problem kernel
+        self.gemm_op(p0, side=True, tile=int(os.environ.get('GHN3_LAYER_WGRAD_TILE', ('48' if self.x3 else '64') if C >= 256 else '0')),
+                     grid_cap=int(os.environ.get('GHN3_LAYER_WGRAD_CAP', '0')) if self.SIDE else 0)
+        if len(layers) == 1:
+            d = layers[0]
+            pre = d['pre']
+            self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln2.weight'), self.gref(pre + 'ln2.bias'), d['dhA'], d['xmid'],
+                                              d['m2'], d['r2']), ints=(rows, C, 1), flags=self.SIDE)
+            self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln1.weight'), self.gref(pre + 'ln1.bias'), d['dhB'], d['x_in'],
+                                              d['m1'], d['r1']), ints=(rows, C, 1), flags=self.SIDE)
+            return
+        # batched: offsets (floats) from the first layer parameter's gradient / from the workspace base
+        base = 'gnn.0.' + LAYER_PARAM_NAMES[0]
+        ws = self.xbuf(self.X_WS)
+        tab = []
+        for d in layers:
+            pre = d['pre']
+            for (gn, bn, dy, x, mu, rs) in ((pre + 'ln2.weight', pre + 'ln2.bias', d['dhA'], d['xmid'], d['m2'], d['r2']),
+                                           (pre + 'ln1.weight', pre + 'ln1.bias', d['dhB'], d['x_in'], d['m1'], d['r1'])):
+                assert all(r_[0] == ws and r_[1] % 4 == 0 for r_ in (dy, x, mu, rs))
+                tab.append((self.param_gap(base, gn), self.param_gap(base, bn), dy[1] // 4, x[1] // 4, mu[1] // 4, rs[1] // 4))
+        self.op(L.OP_LN_PARAM_GRAD_BATCH, refs=(self.gref(base), (ws, 0), self.idx(np.asarray(tab, dtype=np.int64))),
+                ints=(len(tab), rows, C), flags=self.SIDE)
+
     # ------------------------------------------------------------------ backward
     def _colsum(self, out, X, M, N, ld, q=0, s=0, stride=1, gather=None):
         self.op(L.OP_COLSUM, refs=(out, X, gather if gather is not None else self.NONE),
@@ -1937,6 +1978,8 @@ class Program:
         # record that stalls the main chain for 6-12 us, and the temporaries the side ops read are per layer anyway.
         side_group = max(1, int(os.environ.get('GHN3_SIDE_GROUP', '4'))) if self.SIDE else 1
         side_pending = []
+        layer_side = []
+        defer = bool(self.SIDE) and os.environ.get('GHN3_LAYER_WGRAD_DEFER', '1') != '0'
         for l in reversed(range(self.Lyr)):
             pre = 'gnn.%d.' % l
             sfx = '_%d' % l
@@ -2032,36 +2075,25 @@ class Program:
                 else:
                     self.op(L.OP_LAYERNORM_BWD, refs=(g_out, dhB, x_in, self.pref(pre + 'ln1.weight'), m1, r1, g_mid,
                                                       dhB_p or self.NONE), ints=(rows, C))
-            # Side-stream work of the layer in ONE group at its end (the backward buffers are per layer when the side
-            # stream is on): every main -> side hand-off is an event record that costs the main chain ~6 us, so the
-            # LayerNorm parameter gradients (which read dhA / dhB after the LayerNorm backward has added the K-half
-            # planes) and the weight gradients share one.
-            main_ops, self._ops = self._ops, []
-            self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln2.weight'), self.gref(pre + 'ln2.bias'), dhA, xmid,
-                                              m2, r2), ints=(rows, C, 1), flags=self.SIDE)
-            # weight gradients of the layer, one launch
-            p0 = self.gemm(g_cur, f, self.gref(W3), C, 4 * C, rows, C, 4 * C, 4 * C, a_mode=L.MODE_COL,
-                           b_mode=L.MODE_COL, accum=True, dbias=self.gref(pre + 'ff.net.3.bias'))
-            self.gemm(dz, h2, self.gref(W1f), 4 * C, C, rows, 4 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
-                      accum=True, dbias=self.gref(pre + 'ff.net.0.bias'))
-            self.gemm(g_mid, o, self.gref(Wo), C, C, rows, C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
-                      accum=True, dbias=self.gref(pre + 'attn.to_out.0.bias'))
-            self.gemm(dqkv, h1, self.gref(Wq), 3 * C, C, rows, 3 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
-                      accum=True)
-            # 64 x 64 fp32 tiles (432 per launch) instead of the small-problem kernel: 8.47 -> 8.41 ms per step.  (Without
-            # these launches the step is 8.14 ms: the bound on what a faster weight-gradient path could gain; 16-bit
-            # operands converted in the kernel are slower and bf16 misses the gradient gate.)
-            # (optional grid cap, see gemm_wg.hip; measured r04i: 128 / 64 workgroups cost 0.13 / 0.55 ms per step -- the side
-            # stream then takes longer than the chain it runs beside -- so the default is uncapped)
-            self.gemm_op(p0, side=True, tile=int(os.environ.get('GHN3_LAYER_WGRAD_TILE', ('48' if self.x3 else '64') if C >= 256 else '0')),
-                         grid_cap=int(os.environ.get('GHN3_LAYER_WGRAD_CAP', '0')) if self.SIDE else 0)
-            self.op(L.OP_LN_PARAM_GRAD, refs=(self.gref(pre + 'ln1.weight'), self.gref(pre + 'ln1.bias'), dhB, x_in,
-                                              m1, r1), ints=(rows, C, 1), flags=self.SIDE)
-            side_pending, self._ops = side_pending + self._ops, main_ops
-            if (self.Lyr - l) % side_group == 0 or l == 0:
-                self._ops.extend(side_pending)
-                side_pending = []
+            # Side-stream work of the layer: four weight gradients (+ fused bias gradients) and the two LayerNorm parameter
+            # gradients.  Round 4 (`defer`, side stream only): ALL layers' weight gradients are ONE grouped launch and all
+            # LayerNorm parameter gradients ONE batched launch behind the chain -- the 24 x 3 small side launches beside the
+            # chain cost 0.30 ms of step time (hand-off stalls, CU slots) for 0.56 ms of kernel time; every temporary they read
+            # is a per-layer buffer anyway.  Without a side stream (or GHN3_LAYER_WGRAD_DEFER=0) they follow their layer.
+            layer_side.append(dict(pre=pre, g_cur=g_cur, f=f, dz=dz, h2=h2, g_mid=g_mid, o=o, dqkv=dqkv, h1=h1, dhA=dhA,
+                                   xmid=xmid, m2=m2, r2=r2, dhB=dhB, x_in=x_in, m1=m1, r1=r1))
+            if not defer:
+                main_ops, self._ops = self._ops, []
+                self._layer_side_ops([layer_side[-1]], rows)
+                if os.environ.get('GHN3_SKIP_LAYER_SIDE', '0') != '0':   # (timing experiment: wrong gradients)
+                    self._ops = []
+                side_pending, self._ops = side_pending + self._ops, main_ops
+                if (self.Lyr - l) % side_group == 0 or l == 0:
+                    self._ops.extend(side_pending)
+                    side_pending = []
             g_cur = g_out                   # d x_l
+        if defer and os.environ.get('GHN3_SKIP_LAYER_SIDE', '0') == '0':
+            self._layer_side_ops(layer_side, rows)
         # ---- node embeddings (side stream: beside the edge-bias backward below, which does not depend on it) --------
         self.op(L.OP_EMBED_BWD,
                 refs=(g_cur, r_types, r_shape, r_nn, r_noff, self.gref('embed.weight'),

@@ -373,6 +373,11 @@ enum ghn3_op_kind {
      * order).  r0=loss (1 float, overwritten) r1=norms (n floats) r2=parts r3=first (int32, n + 1 entries) ; i0 = n tensors.
      * Replaces GHN3_OP_PARAM_NORM_FWD's pass over the flat output (trainer.py:288-294).  (ABI v14) */
     GHN3_OP_PARAM_NORM_FIN = 33,
+    /* GHN3_OP_LN_PARAM_GRAD for many LayerNorms in ONE launch (the 2 L LayerNorms of the Graphormer, deferred behind the
+     * chain): item t adds  dgamma_t[c] += sum_r dy_t[r][c] xhat_t[r][c],  dbeta_t[c] += sum_r dy_t[r][c].
+     * r0 = base of the parameter gradients, r1 = base of the activations, r2 = table of 6 int64 per item: float offsets
+     * {dgamma, dbeta} from r0 and {dy, x, mean, rstd} from r1 ; i: n_items, rows, C.  One writer per element, fixed order. */
+    GHN3_OP_LN_PARAM_GRAD_BATCH = 34,
     GHN3_OP_KIND_COUNT
 };
 

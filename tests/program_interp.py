@@ -688,6 +688,17 @@ class Interp:
             if amax is not None and int(D['src_buf']) == 0 and acc.size:
                 amax[0] = max(float(amax[0]), float(np.abs(acc.astype(np.float32)).max()))
 
+    def op_ln_param_grad_batch(self, o, problems):
+        n, rows, C = int(o['i'][0]), int(o['i'][1]), int(o['i'][2])
+        gb, ab = self.tail(o['r'][0], np.float32), self.tail(o['r'][1], np.float32)
+        tab = self.view(o['r'][2], np.int64, 6 * n).reshape(n, 6)
+        for dg, db, dy, x, mean, rstd in tab:
+            dyv = ab[dy:dy + rows * C].reshape(rows, C).astype(np.float64)
+            xv = ab[x:x + rows * C].reshape(rows, C).astype(np.float64)
+            mu, rs = ab[mean:mean + rows].astype(np.float64)[:, None], ab[rstd:rstd + rows].astype(np.float64)[:, None]
+            gb[dg:dg + C] += (dyv * (xv - mu) * rs).sum(0).astype(np.float32)
+            gb[db:db + C] += dyv.sum(0).astype(np.float32)
+
     def op_param_norm_fin(self, o, problems):
         n = int(o['i'][0])
         loss, norms = self.tail(o['r'][0], np.float32), self.tail(o['r'][1], np.float32)

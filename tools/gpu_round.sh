@@ -1,17 +1,14 @@
 #!/bin/bash
-# One GPU-box session: the GPU parity suite, the default bench line and the rocprof summary (run through gpurun):
-#   bash tools/gpu_round.sh <tag> [tests|bench|prof|pmc ...]
-TAG=${1:-r02}; shift
-WHAT=${@:-tests bench prof}
+# One GPU-box call that produces the judged artefacts of a round (run through gpurun):
+#   bash tools/gpu_round.sh <tag>
+# -> gpurun_out/<tag>_bench_default_xl_f16.json (the default `python bench.py` line, incl. roofline / cpu_baseline / extras),
+#    <tag>_rocprof_kernel_stats_xl_f16.txt + <tag>_kernel_timeline_last_step_xl_f16.csv (tools/profile_bench.sh),
+#    <tag>_pmc_xl_f16.txt + <tag>_pmc_traffic_xl_f16.json (tools/pmc_profile.sh)
+TAG=${1:-r}
 cd "${GRAFT_REPO_ROOT:-.}"
 mkdir -p gpurun_out
-for w in $WHAT; do
-  case $w in
-    tests)  timeout 1500 python -m pytest tests -m gpu -q -x --timeout 1200 2>&1 | tail -25 > gpurun_out/${TAG}_pytest.log; tail -8 gpurun_out/${TAG}_pytest.log ;;
-    newtests) timeout 1500 python -m pytest tests/test_gpu_configs.py -m gpu -q -s --timeout 1200 2>&1 | tail -60 > gpurun_out/${TAG}_pytest_configs.log; tail -40 gpurun_out/${TAG}_pytest_configs.log ;;
-    bench)  timeout 900 python bench.py > gpurun_out/${TAG}_bench_default_xl_f16.json 2> gpurun_out/${TAG}_bench.err; tail -c 3000 gpurun_out/${TAG}_bench_default_xl_f16.json; tail -3 gpurun_out/${TAG}_bench.err ;;
-    benchq) timeout 600 python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras > gpurun_out/${TAG}_bench_quick.json 2> gpurun_out/${TAG}_bench.err; tail -c 2500 gpurun_out/${TAG}_bench_quick.json; tail -3 gpurun_out/${TAG}_bench.err ;;
-    prof)   bash tools/profile_bench.sh $TAG f16 ;;
-    pmc)    bash tools/pmc_profile.sh $TAG ;;
-  esac
-done
+bash tools/profile_bench.sh $TAG f16 > gpurun_out/${TAG}_profile.log 2>&1
+bash tools/pmc_profile.sh $TAG > gpurun_out/${TAG}_pmc.log 2>&1
+cp gpurun_out/${TAG}_pmc_traffic_xl_f16.json profiles/ 2>/dev/null     # (bench.py reads the newest committed traffic figure)
+python bench.py > gpurun_out/${TAG}_bench_default_xl_f16.json 2> gpurun_out/${TAG}_bench_default.err
+tail -c 2500 gpurun_out/${TAG}_bench_default_xl_f16.json

@@ -31,8 +31,10 @@ typedef const f32x4 GAS* gcf4;
 
 namespace {
 
-constexpr int WG_BM = 64, WG_BN = 64, WG_KC = 64;
-constexpr int WG_LDS = 4 * 64 * 128 + 16 * 64 * 4;       // A hi | A lo | B hi | B lo images + bias-gradient partials
+constexpr int WG_KC = 64;
+// T x T tiles: T = 64 (4 waves, tile code 48) or T = 128 (8 waves, tile code 49: half the operand bytes per flop -- the
+// launch that carries all layers' weight gradients behind the chain is bound by the L2 -> CU rate, 1.36 GB at T = 64)
+template <int T> constexpr int wg_lds() { return 4 * T * 128 + 16 * T * 4; }   // A hi | A lo | B hi | B lo images + bias partials
 
 __device__ __forceinline__ unsigned wg_pack(__bf16 a, __bf16 b) {
     return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
@@ -51,13 +53,17 @@ __device__ __forceinline__ void wg_stage(char* s_hi, char* s_lo, int f, int k, c
     }
 }
 
-// one 64 x 64 tile (tile id `tile` of the launch)
+// one T x T tile (tile id `tile` of the launch)
+template <int T>
 __device__ __forceinline__ void wg_tile(const GemmProbDev* __restrict__ probs, int n_probs, int tile, char* sm) {
+    constexpr int WG_BM = T, WG_BN = T;
+    constexpr int TN = T / 32;                           // 16-column MFMA tiles per wave (wave tile 32 x T / 2)
+    constexpr int FPR = T / 4;                           // float4 per operand row of a chunk
     char* sAh = sm;
-    char* sAl = sm + 64 * 128;
-    char* sBh = sm + 2 * 64 * 128;
-    char* sBl = sm + 3 * 64 * 128;
-    float* sbias = reinterpret_cast<float*>(sm + 4 * 64 * 128);
+    char* sAl = sm + T * 128;
+    char* sBh = sm + 2 * T * 128;
+    char* sBl = sm + 3 * T * 128;
+    float* sbias = reinterpret_cast<float*>(sm + 4 * T * 128);
 
     int lo = 0, hi_ = n_probs - 1;
     while (lo < hi_) {
@@ -70,11 +76,11 @@ __device__ __forceinline__ void wg_tile(const GemmProbDev* __restrict__ probs, i
     const int M = P->M, N = P->N, K = P->K, lda = P->lda, ldb = P->ldb;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, lq = lane >> 4;
-    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * 32;
+    const int wm0 = (wave >> 1) * 32, wn0 = (wave & 1) * (T / 2);
     const bool want_bias = (P->flags & GHN3_GEMM_BIASGRAD) && n0 == 0;
 
     // staging role: features 4 f4 .. 4 f4 + 3, rows 2 kp + 32 i + {0, 1} of the chunk (i = 0, 1)
-    const int f4 = (tid & 15) * 4, kp = tid >> 4;
+    const int f4 = (tid % FPR) * 4, kp = tid / FPR;
     const float GAS* Ag = (const float GAS*)P->A;
     const float GAS* Bg = (const float GAS*)P->B;
     const bool a_in = m0 + f4 < M, b_in = n0 + f4 < N;       // (M % 4 == 0, N % 4 == 0: a float4 is inside or outside)
@@ -92,11 +98,11 @@ __device__ __forceinline__ void wg_tile(const GemmProbDev* __restrict__ probs, i
             }
     };
 
-    f32x4 acc0[2][2], acc1[2][2];
+    f32x4 acc0[2][TN], acc1[2][TN];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) { acc0[i][j] = zero; acc1[i][j] = zero; }
+        for (int j = 0; j < TN; ++j) { acc0[i][j] = zero; acc1[i][j] = zero; }
     f32x4 bsum = zero;
 
     load_chunk(0);
@@ -113,7 +119,7 @@ __device__ __forceinline__ void wg_tile(const GemmProbDev* __restrict__ probs, i
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int ch = 4 * h + lq;
-            bf16x8 xh[2], xl[2], wh[2], wl[2];
+            bf16x8 xh[2], xl[2], wh[TN], wl[TN];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const int row = wm0 + 16 * i + l15;
@@ -122,7 +128,7 @@ __device__ __forceinline__ void wg_tile(const GemmProbDev* __restrict__ probs, i
                 xl[i] = *reinterpret_cast<const bf16x8*>(sAl + off);
             }
 #pragma unroll
-            for (int j = 0; j < 2; ++j) {
+            for (int j = 0; j < TN; ++j) {
                 const int row = wn0 + 16 * j + l15;
                 const int off = row * 128 + ((ch ^ ((row >> 1) & 7)) << 4);
                 wh[j] = *reinterpret_cast<const bf16x8*>(sBh + off);
@@ -131,14 +137,14 @@ __device__ __forceinline__ void wg_tile(const GemmProbDev* __restrict__ probs, i
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < TN; ++j) {
                     acc0[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xh[i], acc0[i][j], 0, 0, 0);
                     acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[j], xl[i], acc1[i][j], 0, 0, 0);
                 }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < TN; ++j)
                     acc1[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[j], xh[i], acc1[i][j], 0, 0, 0);
         }
     }
@@ -151,7 +157,7 @@ __device__ __forceinline__ void wg_tile(const GemmProbDev* __restrict__ probs, i
     for (int i = 0; i < 2; ++i) {
         const int m = m0 + wm0 + 16 * i + l15;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < TN; ++j) {
             const int n = n0 + wn0 + 16 * j + 4 * lq;
             if (m >= M || n >= N) continue;
             const int64_t ci = (int64_t)m * P->ldc + n;
@@ -165,12 +171,12 @@ __device__ __forceinline__ void wg_tile(const GemmProbDev* __restrict__ probs, i
     // ---- bias gradient: db[m] += sum_k A[k][m] -- the 16 row-pair owners of a feature add up in a fixed order
     if (want_bias) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) sbias[kp * 64 + f4 + e] = bsum[e];
+        for (int e = 0; e < 4; ++e) sbias[kp * T + f4 + e] = bsum[e];
         __syncthreads();
-        if (tid < 64 && m0 + tid < M) {
+        if (tid < T && m0 + tid < M) {
             float t = 0.f;
 #pragma unroll
-            for (int q = 0; q < 16; ++q) t += sbias[q * 64 + tid];
+            for (int q = 0; q < 16; ++q) t += sbias[q * T + tid];
             float GAS* db = (float GAS*)P->bias + (int64_t)(m0 + tid) * P->bias_stride;
             *db += t;                                       // (the bias gradient always accumulates, ghn3_hip.h)
         }
@@ -182,20 +188,31 @@ __device__ __forceinline__ void wg_tile(const GemmProbDev* __restrict__ probs, i
 // chain's fat workgroups (768 threads, 168 VGPRs) find no empty CU until the launch has drained (r04h: up to 100 us stalls
 // at the hand-offs).  Measured r04i: capped launches stretch the side stream beyond the chain (128 workgroups: +0.13 ms per
 // step, 64: +0.55 ms) -- the cap stays available (op.i[3]) but the compiled programs do not use it.
-__global__ __launch_bounds__(256) void gemm_wg_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int total_tiles) {
-    __shared__ __attribute__((aligned(16))) char sm[WG_LDS];
+template <int T>
+__global__ __launch_bounds__(T * 4) void gemm_wg_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int total_tiles) {
+    extern __shared__ __attribute__((aligned(16))) char wg_sm[];
     for (int tile = blockIdx.x; tile < total_tiles; tile += gridDim.x) {
-        wg_tile(probs, n_probs, tile, sm);
+        wg_tile<T>(probs, n_probs, tile, wg_sm);
         __syncthreads();                                    // the LDS images are reused by the next tile
     }
 }
 
 }  // namespace
 
-int ghn3_gemm_wg_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int grid_cap, hipStream_t stream) {
+// tile_edge: 64 (tile code 48) or 128 (tile code 49)
+int ghn3_gemm_wg_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int grid_cap, int tile_edge, hipStream_t stream) {
     if (n_probs <= 0 || total_tiles <= 0) return GHN3_OK;
     const int grid = grid_cap > 0 && grid_cap < total_tiles ? grid_cap : total_tiles;
-    hipLaunchKernelGGL(gemm_wg_kernel, dim3(grid), dim3(256), 0, stream, d_probs, n_probs, total_tiles);
+    if (tile_edge == 128) {
+        static bool attr = false;
+        if (!attr) {
+            hipFuncSetAttribute((const void*)gemm_wg_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, wg_lds<128>());
+            attr = true;
+        }
+        hipLaunchKernelGGL(gemm_wg_kernel<128>, dim3(grid), dim3(512), wg_lds<128>(), stream, d_probs, n_probs, total_tiles);
+    } else {
+        hipLaunchKernelGGL(gemm_wg_kernel<64>, dim3(grid), dim3(256), wg_lds<64>(), stream, d_probs, n_probs, total_tiles);
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("wgrad x3 gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

@@ -230,14 +230,14 @@ static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
     }
     // 48 = the split-bf16 weight-gradient kernel (gemm_wg.hip): fp32 activations, reduction over rows (COL / COL); problems
     // of the op it cannot take run on the 64 x 64 fp32 tiles
-    if (forced == 48) {
+    if (forced == 48 || forced == 49) {
         const bool ok = p.a_mode == GHN3_MODE_COL && p.b_mode == GHN3_MODE_COL && p.ksplit <= 1 && (p.M & 3) == 0 &&
                         (p.N & 3) == 0 && (p.ldc & 3) == 0 && (p.C.off & 15) == 0 && (p.lda & 3) == 0 && (p.ldb & 3) == 0 &&
                         (p.A.off & 15) == 0 && (p.B.off & 15) == 0 && p.a_gather.buf < 0 &&
                         p.b_gather.buf < 0 && p.c_gather.buf < 0 && !p.a_q && !p.b_q && !p.c_q && !p.bias_q &&
                         p.act == GHN3_ACT_NONE && p.dact == GHN3_DACT_NONE && p.residual.buf < 0 && p.aux_out.buf < 0 &&
                         (p.bias.buf < 0 || (p.flags & GHN3_GEMM_BIASGRAD));
-        return ok ? 48 : 64;
+        return ok ? forced : 64;
     }
     if (forced == 32 || forced == 64 || forced == 128) return forced;
     // op_t64 = 64x64 tiles of ALL problems launched together with this one: a grouped launch that already fills
@@ -296,7 +296,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                 for (int bm = 0; bm < 2; ++bm)
                     for (int tl : codes) {
                         Launch L{am, bm, tl, (int)pos, 0, 0, 0, 0};
-                        int te = tl == 16 ? 128 : (tl == 24 || tl == 20 || tl == 25 || tl == 28 || tl == 29) ? 256 : tl == 48 ? 64 : tl;   // tile edge (rows)
+                        int te = tl == 16 ? 128 : (tl == 24 || tl == 20 || tl == 25 || tl == 28 || tl == 29) ? 256 : tl == 48 ? 64 : tl == 49 ? 128 : tl;   // tile edge (rows)
                         int te_n = tl == 20 ? 128 : te;                                        // (columns)
                         const bool x3 = tl >= 4000;
                         const bool x3old = x3 && tl < 5000;
@@ -491,7 +491,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                 g.xcd_cols = G;
                                 const int npg = (g.tiles_n + G - 1) / G, mpc = (g.tiles_m + 8 / G - 1) / (8 / G);
                                 L.tiles += 8 * npg * mpc;
-                            } else if (tl == 32 || tl == 48 || x3) {
+                            } else if (tl == 32 || tl == 48 || tl == 49 || x3) {
                                 L.tiles += g.tiles_m * g.tiles_n;          // plain order, no padding
                             } else {
                                 const int per_split = g.order ? ((g.tiles_m + 7) / 8 * 8) * g.tiles_n
@@ -608,8 +608,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                 else if (L.tile >= 4000)
                     rc = ghn3_gemm_x3_launch(ds + L.first, L.count, L.tiles, 40 + (L.tile - 4000) / 10,
                                              64 * (L.tile % 10), stream);
-                else if (L.tile == 48)
-                    rc = ghn3_gemm_wg_launch(ds + L.first, L.count, L.tiles, (int)o.i[3], stream);
+                else if (L.tile == 48 || L.tile == 49)
+                    rc = ghn3_gemm_wg_launch(ds + L.first, L.count, L.tiles, (int)o.i[3], L.tile == 49 ? 128 : 64, stream);
                 else if (L.tile == 32)
                     rc = ghn3_gemm_small_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, L.with_ln, stream);
                 else if (L.tile == 29)

@@ -1423,8 +1423,11 @@ class Program:
                       accum=True, dbias=self.gref(pre + 'attn.to_out.0.bias'))
             self.gemm(d['dqkv'], d['h1'], self.gref(Wq), 3 * C, C, rows, 3 * C, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
                       accum=True)
-        # 64 x 64 fp32 tiles / the split-bf16 weight-gradient kernel (tile 48) instead of the small-problem kernel
-        self.gemm_op(p0, side=True, tile=int(os.environ.get('GHN3_LAYER_WGRAD_TILE', ('48' if self.x3 else '64') if C >= 256 else '0')),
+        # the split-bf16 weight-gradient kernel on 64 x 64 tiles (48); exact fp32 tiles (64) outside the 16-bit modes; the
+        # small-problem kernel for narrow models.  (49 = the same kernel on 128 x 128 tiles, half the operand bytes per flop:
+        # measured slower for the grouped launch, 6.61-6.63 against 6.54-6.56 ms per step -- fewer, fatter workgroups.)
+        dflt = ('48' if self.x3 else '64') if C >= 256 else '0'
+        self.gemm_op(p0, side=True, tile=int(os.environ.get('GHN3_LAYER_WGRAD_TILE', dflt)),
                      grid_cap=int(os.environ.get('GHN3_LAYER_WGRAD_CAP', '0')) if self.SIDE else 0)
         if len(layers) == 1:
             d = layers[0]
@@ -1980,6 +1983,8 @@ class Program:
         side_pending = []
         layer_side = []
         defer = bool(self.SIDE) and os.environ.get('GHN3_LAYER_WGRAD_DEFER', '1') != '0'
+        defer_group = int(os.environ.get('GHN3_LAYER_WGRAD_GROUP', '0'))     # 0: one launch behind the chain
+        side_done = 0
         for l in reversed(range(self.Lyr)):
             pre = 'gnn.%d.' % l
             sfx = '_%d' % l
@@ -2082,6 +2087,9 @@ class Program:
             # is a per-layer buffer anyway.  Without a side stream (or GHN3_LAYER_WGRAD_DEFER=0) they follow their layer.
             layer_side.append(dict(pre=pre, g_cur=g_cur, f=f, dz=dz, h2=h2, g_mid=g_mid, o=o, dqkv=dqkv, h1=h1, dhA=dhA,
                                    xmid=xmid, m2=m2, r2=r2, dhB=dhB, x_in=x_in, m1=m1, r1=r1))
+            if defer and defer_group and len(layer_side) - side_done >= defer_group and l > 0:
+                self._layer_side_ops(layer_side[side_done:], rows)       # (a group of layers, beside the chain)
+                side_done = len(layer_side)
             if not defer:
                 main_ops, self._ops = self._ops, []
                 self._layer_side_ops([layer_side[-1]], rows)
@@ -2092,8 +2100,8 @@ class Program:
                     self._ops.extend(side_pending)
                     side_pending = []
             g_cur = g_out                   # d x_l
-        if defer and os.environ.get('GHN3_SKIP_LAYER_SIDE', '0') == '0':
-            self._layer_side_ops(layer_side, rows)
+        if defer and os.environ.get('GHN3_SKIP_LAYER_SIDE', '0') == '0' and side_done < len(layer_side):
+            self._layer_side_ops(layer_side[side_done:], rows)
         # ---- node embeddings (side stream: beside the edge-bias backward below, which does not depend on it) --------
         self.op(L.OP_EMBED_BWD,
                 refs=(g_cur, r_types, r_shape, r_nn, r_noff, self.gref('embed.weight'),

@@ -166,6 +166,13 @@ WG_CASES = [
     dict(M=4, N=8, K=1, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=48),
     dict(M=132, N=72, K=33, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=48),
     dict(M=130, N=70, K=33, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=48, epilogue='biasgrad'),
+    # tile code 49: the same kernel on 128 x 128 tiles (8 waves), used for the grouped launch of all layers' weight gradients
+    dict(M=384, N=1536, K=256, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=49, epilogue='biasgrad', accum=True),
+    dict(M=1152, N=384, K=256, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=49, accum=True),
+    dict(M=384, N=384, K=512, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=49, epilogue='biasgrad'),
+    dict(M=100, N=76, K=300, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=49, epilogue='biasgrad', accum=True),
+    dict(M=260, N=132, K=70, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=49, epilogue='biasgrad'),
+    dict(M=4, N=8, K=1, a_mode=L.MODE_COL, b_mode=L.MODE_COL, tile=49),
 ]
 # the 32x32 split-K-in-workgroup kernel (tile code 32), every addressing mode and epilogue
 for a_mode in (L.MODE_ROW, L.MODE_COL):

@@ -711,6 +711,7 @@ __device__ __forceinline__ float norm_grad(float v, int mode, float scale) {
 }
 
 typedef float f4u __attribute__((ext_vector_type(4), aligned(4)));   // 16-byte access at dword alignment
+typedef unsigned short us4h __attribute__((ext_vector_type(4)));
 struct SrcTable { const float* p[6]; };
 struct DstTable { float* p[6]; };
 
@@ -748,20 +749,37 @@ struct Odo {
 // along kh / kw (the host checks).
 // sq_parts (optional): slot blockIdx.x receives the sum of squares of everything this block wrote (fixed reduction
 // order): the per-tensor Frobenius norms of the predicted-parameter loss without another pass over the output.
-__device__ __forceinline__ void tile_block_sumsq(float ss, float* __restrict__ sq_parts) {
-    __shared__ float sq_red[4];
+// b_parts (optional, with sq_parts): slot blockIdx.x receives  max |written value| * replicas * |scale|  for blocks of mode-0
+// descriptors of source buffer 0 (0 otherwise): an a-priori bound of the tile backward's output, see tile_bwd_kernel.
+__device__ __forceinline__ void tile_block_sumsq(float ss, float bm, float* __restrict__ sq_parts, float* __restrict__ b_parts,
+                                                 const ghn3_tile_desc* __restrict__ D) {
+    __shared__ float sq_red[4], mx_red[4];
     ss = wsum(ss);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o, 64));
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) sq_red[threadIdx.x >> 6] = ss;
+    if ((threadIdx.x & 63) == 0) { sq_red[threadIdx.x >> 6] = ss; mx_red[threadIdx.x >> 6] = bm; }
     __syncthreads();
-    if (threadIdx.x == 0) sq_parts[blockIdx.x] = (sq_red[0] + sq_red[1]) + (sq_red[2] + sq_red[3]);
+    if (threadIdx.x == 0) {
+        sq_parts[blockIdx.x] = (sq_red[0] + sq_red[1]) + (sq_red[2] + sq_red[3]);
+        if (b_parts) {
+            float f = 0.f;
+            if (D->src_buf == 0 && D->mode == 0) {
+                f = fabsf(D->scale);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) f *= (float)((D->T[k] + D->E[k] - 1) / D->E[k]);
+            }
+            b_parts[blockIdx.x] = fmaxf(fmaxf(mx_red[0], mx_red[1]), fmaxf(mx_red[2], mx_red[3])) * f;
+        }
+    }
 }
 
 __global__ __launch_bounds__(256) void tile_fwd_kernel(float* __restrict__ flat, SrcTable srcs,
                                                        const ghn3_tile_desc* __restrict__ desc,
-                                                       const int64_t* __restrict__ blocks, float* __restrict__ sq_parts) {
+                                                       const int64_t* __restrict__ blocks, float* __restrict__ sq_parts,
+                                                       float* __restrict__ b_parts) {
     extern __shared__ float tl[];
-    float ss = 0.f;
+    float ss = 0.f, bm = 0.f;
     const int64_t di_raw = blocks[2 * (size_t)blockIdx.x];
     if (di_raw < 0) {
         const ghn3_tile_desc* D = desc + (~di_raw);
@@ -836,9 +854,10 @@ __global__ __launch_bounds__(256) void tile_fwd_kernel(float* __restrict__ flat,
             o.x = tl[j] * scale; o.y = tl[j + 1] * scale; o.z = tl[j + 2] * scale; o.w = tl[j + 3] * scale;
             *reinterpret_cast<f4u*>(dst + j) = o;
             ss += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+            bm = fmaxf(fmaxf(bm, fmaxf(fabsf(o.x), fabsf(o.y))), fmaxf(fabsf(o.z), fabsf(o.w)));
         }
-        for (int j = nv + threadIdx.x; j < n; j += 256) { const float o = tl[j] * scale; dst[j] = o; ss += o * o; }
-        if (sq_parts) tile_block_sumsq(ss, sq_parts);
+        for (int j = nv + threadIdx.x; j < n; j += 256) { const float o = tl[j] * scale; dst[j] = o; ss += o * o; bm = fmaxf(bm, fabsf(o)); }
+        if (sq_parts) tile_block_sumsq(ss, bm, sq_parts, b_parts, D);
         return;
     }
     const int64_t di = di_raw;
@@ -867,13 +886,14 @@ __global__ __launch_bounds__(256) void tile_fwd_kernel(float* __restrict__ flat,
         const float val = norm_apply(src[so], mode, scale);
         dst[e] = val;
         ss += val * val;
+        bm = fmaxf(bm, fabsf(val));
         o.step();
     }
-    if (sq_parts) tile_block_sumsq(ss, sq_parts);
+    if (sq_parts) tile_block_sumsq(ss, bm, sq_parts, b_parts, D);
 }
 
 int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d_desc, int n_desc, int64_t total,
-                  const int64_t* blocks, int lds_bytes, float* sq_parts, hipStream_t s) {
+                  const int64_t* blocks, int lds_bytes, float* sq_parts, float* b_parts, hipStream_t s) {
     // `total` = number of work blocks in the (descriptor, start) table `blocks`.
     if (n_desc <= 0 || total <= 0) return GHN3_OK;
     SrcTable st;
@@ -882,7 +902,8 @@ int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d
         if (lds_bytes > 128 * 1024) { ghn3_set_error("tile_fwd: row blocks need %d bytes of LDS", lds_bytes); return GHN3_E_LIMIT; }
         hipFuncSetAttribute((const void*)tile_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     }
-    hipLaunchKernelGGL(tile_fwd_kernel, dim3((unsigned)total), dim3(256), lds_bytes, s, flat, st, d_desc, blocks, sq_parts);
+    hipLaunchKernelGGL(tile_fwd_kernel, dim3((unsigned)total), dim3(256), lds_bytes, s, flat, st, d_desc, blocks, sq_parts,
+                       sq_parts ? b_parts : nullptr);
     return launch_ok("tile_fwd");
 }
 
@@ -893,10 +914,32 @@ int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d
 // descriptor's tensor t is  dflat[e] + (g / norm_t) out[e]  (dflat optional) -- the norm term's gradient is formed from the
 // predicted values themselves instead of being materialised by a pass over the 346 MB output.
 struct NormLoss { const float* out; const float* norms; const int* desc_seg; const float* g; };
+// Direct 16-bit gradient tiles (fused norm loss only, no dflat): the gradient of source buffer 0 -- the decoder tiles, whose
+// only consumers are the 16-bit W2 dgrad / wgrad GEMMs -- is written ONCE, as the scaled f16 / bf16 operand copy, instead of as
+// fp32 followed by a cast pass that first needs the measured maximum.  The power-of-two scale comes from an a-priori bound:
+// an element of the tile gradient is  (g / ||p_t||) * scale * (sum of the predicted values of its replicas), at most
+// |g| * max_t( max|p_t| * replicas * |scale| / ||p_t|| ) = |g| * norms[-1] (GHN3_OP_PARAM_NORM_FIN).  The bound is what the
+// consumers find in the amax slot (block 0 stores it), so copies and GEMM epilogues agree on the scale; it can never
+// overflow and is within a few binades of the true maximum (f16 has 29 normal binades, the gradients span ~13).
+// tab: per descriptor {h, rel0, ld32 | ld16 << 32}: the descriptor's region starts `rel0` floats into a row-major fp32 matrix
+// with row stride ld32 whose 16-bit copy (row stride ld16) starts h 16-bit elements behind dsrcs.p[0]; h = INT64_MIN: the
+// descriptor keeps its fp32 output.
+struct H16 { const int64_t* tab; int bf16; };
+__device__ __forceinline__ unsigned short h16_cast(float x, int bf16) {
+    if (bf16) {
+        const unsigned u = __float_as_uint(x);
+        return (unsigned short)((u + 0x7fffu + ((u >> 16) & 1u)) >> 16);
+    }
+    return __builtin_bit_cast(unsigned short, (_Float16)x);
+}
+__device__ __forceinline__ int64_t h16_index(unsigned rel, unsigned ld32, unsigned ld16) {
+    const unsigned r = rel / ld32;
+    return (int64_t)r * ld16 + (rel - r * ld32);
+}
 __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__ dflat, SrcTable srcs, DstTable dsrcs,
                                                        const ghn3_tile_desc* __restrict__ desc,
                                                        const int64_t* __restrict__ blocks, float* __restrict__ amax,
-                                                       NormLoss nl_) {
+                                                       NormLoss nl_, H16 h16) {
     extern __shared__ float tl[];
     float mx = 0.f;                                      // running max |x| written to source-grad buffer 0
     const int64_t di_raw = blocks[2 * (size_t)blockIdx.x];
@@ -905,6 +948,22 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
     if (nl_.norms) {
         const float nrm = nl_.norms[nl_.desc_seg[di_any]];
         kn = nrm > 0.f ? nl_.g[0] / nrm : 0.f;
+    }
+    // direct 16-bit output of this block's descriptor?
+    unsigned short* hdst = nullptr;
+    unsigned hrel0 = 0, hld32 = 1, hld16 = 0;
+    float hsc = 1.f;
+    if (h16.tab) {
+        const float bnd = nl_.norms[-1] * fabsf(nl_.g[0]);
+        if (blockIdx.x == 0 && threadIdx.x == 0 && amax) amax[0] = bnd;
+        const int64_t h = h16.tab[3 * di_any];
+        if (h != INT64_MIN && desc[di_any].src_buf == 0) {
+            hdst = reinterpret_cast<unsigned short*>(dsrcs.p[0]) + h;
+            hrel0 = (unsigned)h16.tab[3 * di_any + 1];
+            const int64_t lds_ = h16.tab[3 * di_any + 2];
+            hld32 = (unsigned)(lds_ & 0xffffffff); hld16 = (unsigned)(lds_ >> 32);
+            hsc = ghn3_pow2_scale(bnd);
+        }
     }
     const float* __restrict__ outp = nl_.norms ? nl_.out + desc[di_any].dst_off : nullptr;
     if (di_raw < 0) {
@@ -1000,6 +1059,16 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
                 val.y = (live && i + 1 < nl) ? tl[(i + 1) * hw + pp] * scale : 0.f;
                 val.z = (live && i + 2 < nl) ? tl[(i + 2) * hw + pp] * scale : 0.f;
                 val.w = (live && i + 3 < nl) ? tl[(i + 3) * hw + pp] * scale : 0.f;
+                if (hdst) {
+                    // (rel is a multiple of 4 like the fp32 address, ld32 % 4 == 0: the four columns stay in one row)
+                    unsigned short* hp = hdst + h16_index(hrel0 + (unsigned)(a0 * (int)D->S[0] + i0 + y * S2 + x * S3 + i), hld32, hld16);
+                    us4h o;
+                    o[0] = h16_cast(val.x * hsc, h16.bf16); o[1] = h16_cast(val.y * hsc, h16.bf16);
+                    o[2] = h16_cast(val.z * hsc, h16.bf16); o[3] = h16_cast(val.w * hsc, h16.bf16);
+                    if ((reinterpret_cast<uintptr_t>(hp) & 7) == 0) *reinterpret_cast<us4h*>(hp) = o;
+                    else { hp[0] = o[0]; hp[1] = o[1]; hp[2] = o[2]; hp[3] = o[3]; }
+                    continue;
+                }
                 *reinterpret_cast<float4*>(dsrc + (int64_t)y * S2 + (int64_t)x * S3 + i) = val;
                 mx = fmaxf(fmaxf(mx, fmaxf(fabsf(val.x), fabsf(val.y))), fmaxf(fabsf(val.z), fabsf(val.w)));
             }
@@ -1014,11 +1083,15 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
                 int x = pp - y * T3;
                 if (x < 0) { x += T3; --y; } else if (x >= T3) { x -= T3; ++y; }
                 const float val = (live && i < nl) ? tl[i * hw + pp] * scale : 0.f;
+                if (hdst) {
+                    hdst[h16_index(hrel0 + (unsigned)(a0 * (int)D->S[0] + i0 + y * S2 + x * S3 + i), hld32, hld16)] = h16_cast(val * hsc, h16.bf16);
+                    continue;
+                }
                 dsrc[(int64_t)y * S2 + (int64_t)x * S3 + i] = val;
                 mx = fmaxf(mx, fabsf(val));
             }
         }
-        if (amax && D->src_buf == 0) ghn3_atomic_amax(amax, mx);
+        if (amax && D->src_buf == 0 && !h16.tab) ghn3_atomic_amax(amax, mx);
         return;
     }
     const int64_t di = di_raw;
@@ -1054,20 +1127,24 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
                         }
             acc = (acc + kn * acc2) * norm_grad(src[so], mode, scale);
         }
-        dsrc[so] = acc;
+        if (hdst) hdst[h16_index(hrel0 + (unsigned)so, hld32, hld16)] = h16_cast(acc * hsc, h16.bf16);
+        else dsrc[so] = acc;
         mx = fmaxf(mx, fabsf(acc));
         o.step();
     }
-    if (amax && D->src_buf == 0) ghn3_atomic_amax(amax, mx);
+    if (amax && D->src_buf == 0 && !h16.tab) ghn3_atomic_amax(amax, mx);
 }
 
 int ghn3_tile_bwd(const float* dflat, const float* const* srcs, float* const* dsrcs, const ghn3_tile_desc* d_desc,
                   int n_desc, int64_t total, const int64_t* blocks, int lds_bytes, float* amax, const float* out,
-                  const float* norms, const int* desc_seg, const float* gscale, hipStream_t s) {
+                  const float* norms, const int* desc_seg, const float* gscale, const int64_t* h16_tab, int h16_bf16,
+                  hipStream_t s) {
     if (n_desc <= 0 || total <= 0) return GHN3_OK;
     if (!dflat && !norms) { ghn3_set_error("tile_bwd: neither an upstream gradient nor the fused norm loss"); return GHN3_E_ARG; }
     if (norms && (!out || !desc_seg || !gscale)) { ghn3_set_error("tile_bwd: the fused norm loss needs out, the descriptor -> tensor table and g"); return GHN3_E_ARG; }
+    if (h16_tab && (dflat || !norms || !amax)) { ghn3_set_error("tile_bwd: direct 16-bit tiles need the fused norm loss alone (no upstream gradient) and the amax slot"); return GHN3_E_ARG; }
     NormLoss nl{out, norms, desc_seg, gscale};
+    H16 h16{h16_tab, h16_bf16};
     SrcTable st; DstTable dt;
     for (int i = 0; i < 6; ++i) { st.p[i] = srcs[i]; dt.p[i] = dsrcs[i]; }
     if (lds_bytes > 48 * 1024) {
@@ -1075,7 +1152,7 @@ int ghn3_tile_bwd(const float* dflat, const float* const* srcs, float* const* ds
         hipFuncSetAttribute((const void*)tile_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
     }
     hipLaunchKernelGGL(tile_bwd_kernel, dim3((unsigned)total), dim3(256), lds_bytes, s, dflat, st, dt, d_desc, blocks,
-                       amax, nl);
+                       amax, nl, h16);
     return launch_ok("tile_bwd");
 }
 
@@ -1170,30 +1247,45 @@ __global__ void param_loss_kernel(float* __restrict__ loss, const float* __restr
 // in block order by the 64 lanes + a fixed shuffle tree; then the loss = sum of the norms in a fixed order
 __global__ __launch_bounds__(256) void param_norm_fin_kernel(float* __restrict__ norms, int n_seg,
                                                              const float* __restrict__ parts,
-                                                             const int* __restrict__ first) {
+                                                             const int* __restrict__ first,
+                                                             const float* __restrict__ b_parts, float* __restrict__ ratio) {
     const int i = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (i >= n_seg) return;
-    float sq = 0.f;
-    for (int b = first[i] + lane; b < first[i + 1]; b += 64) sq += parts[b];
+    float sq = 0.f, bm = 0.f;
+    for (int b = first[i] + lane; b < first[i + 1]; b += 64) { sq += parts[b]; if (b_parts) bm = fmaxf(bm, b_parts[b]); }
     sq = wsum(sq);
-    if (lane == 0) norms[i] = sqrtf(sq);
-}
-__global__ void param_loss_set_kernel(float* __restrict__ loss, const float* __restrict__ norms, int n_seg) {
-    __shared__ float tot[256];
-    float acc = 0.f;
-    for (int i = threadIdx.x; i < n_seg; i += 256) acc += norms[i];
-    tot[threadIdx.x] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        float t = 0.f;
-        for (int k = 0; k < 256; ++k) t += tot[k];
-        loss[0] = t;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) bm = fmaxf(bm, __shfl_xor(bm, o, 64));
+    if (lane == 0) {
+        const float nrm = sqrtf(sq);
+        norms[i] = nrm;
+        if (ratio) ratio[i] = nrm > 0.f ? bm / nrm : 0.f;
     }
 }
-int ghn3_param_norm_fin(float* loss, float* norms, const float* parts, const int* first, int n_seg, hipStream_t s) {
+// loss = sum of the norms (fixed order); bound = max_t (bound part of t) / ||p_t||: times |g| an upper bound of every element the
+// tile backward writes to source-gradient buffer 0 under the fused norm loss (see tile_bwd_kernel)
+__global__ void param_loss_set_kernel(float* __restrict__ loss, const float* __restrict__ norms, int n_seg,
+                                      const float* __restrict__ ratio, float* __restrict__ bound) {
+    __shared__ float tot[256], mx[256];
+    float acc = 0.f, m = 0.f;
+    for (int i = threadIdx.x; i < n_seg; i += 256) { acc += norms[i]; if (ratio) m = fmaxf(m, ratio[i]); }
+    tot[threadIdx.x] = acc;
+    mx[threadIdx.x] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f, b = 0.f;
+        for (int k = 0; k < 256; ++k) { t += tot[k]; b = fmaxf(b, mx[k]); }
+        loss[0] = t;
+        if (bound) bound[0] = b;
+    }
+}
+int ghn3_param_norm_fin(float* loss, float* norms, const float* parts, const int* first, int n_seg, const float* b_parts,
+                        float* ratio, float* bound, hipStream_t s) {
     if (n_seg <= 0) return GHN3_OK;
-    hipLaunchKernelGGL(param_norm_fin_kernel, dim3((n_seg + 3) / 4), dim3(256), 0, s, norms, n_seg, parts, first);
-    hipLaunchKernelGGL(param_loss_set_kernel, dim3(1), dim3(256), 0, s, loss, norms, n_seg);
+    if (b_parts && !(ratio && bound)) { ghn3_set_error("PARAM_NORM_FIN: bound parts need the ratio scratch (r5) and the bound slot (r6)"); return GHN3_E_ARG; }
+    if (!b_parts) ratio = nullptr, bound = nullptr;
+    hipLaunchKernelGGL(param_norm_fin_kernel, dim3((n_seg + 3) / 4), dim3(256), 0, s, norms, n_seg, parts, first, b_parts, ratio);
+    hipLaunchKernelGGL(param_loss_set_kernel, dim3(1), dim3(256), 0, s, loss, norms, n_seg, ratio, bound);
     return launch_ok("param_norm_fin");
 }
 
@@ -1616,6 +1708,7 @@ __device__ __forceinline__ unsigned short cast_bf16(float x) {
     return (unsigned short)(u >> 16);
 }
 __device__ __forceinline__ float bf16_back(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ __forceinline__ float f16_back(unsigned short h) { return (float)__builtin_bit_cast(_Float16, h); }
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 
@@ -1649,7 +1742,7 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
     const float sc = ((D.flags & GHN3_CAST_SCALED) && amax) ? ghn3_pow2_scale(*amax) : 1.f;
     const int rows_w = (D.flags & GHN3_CAST_TIGHT) ? ((D.rows + 7) & ~7) : 0x7fffffff;   // transposed rows written
 
-    if (st && !trn && !frag && !(D.flags & GHN3_CAST_COLSUM) && D.src_q == 0 && !(D.ld_dst & 7) && !(D.dst_off & 7) && !(D.lo_off & 7)) {
+    if (st && !trn && !frag && !(D.flags & (GHN3_CAST_COLSUM | GHN3_CAST_SRC16)) && D.src_q == 0 && !(D.ld_dst & 7) && !(D.dst_off & 7) && !(D.lo_off & 7)) {
         // straight copy only (the dgrad operand of the decoder gradients, forward activations): 8 consecutive floats per
         // lane -> one 16-byte store (the general path below writes 8 bytes per lane)
         unsigned short* Dd = dst + D.dst_off;
@@ -1683,6 +1776,9 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
         }
         continue;                                      // (uniform over the workgroup: no barrier is skipped by a subset)
     }
+    // GHN3_CAST_SRC16: the source is a 16-bit matrix (offsets from r1, type of the copies written) that already carries the
+    // GHN3_CAST_SCALED scale: the values are re-laid out as they are, the column sums take the scale back out
+    const bool src16 = D.flags & GHN3_CAST_SRC16;
     float4 v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -1691,23 +1787,40 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
         if (r < D.rows) {
             // (a float4 never straddles a run of the source column map: src_q % 4 == 0, c % 4 == 0)
             const int sc_ = D.src_q > 0 ? (c / D.src_q) * D.src_s + c % D.src_q : c;
-            const float* p = S + (int64_t)r * D.ld_src + sc_;
-            if (c + 3 < D.cols) x = *reinterpret_cast<const float4*>(p);
-            else {
-                if (c < D.cols) x.x = p[0];
-                if (c + 1 < D.cols) x.y = p[1];
-                if (c + 2 < D.cols) x.z = p[2];
+            if (src16) {
+                const unsigned short* p = dst + D.src_off + (int64_t)r * D.ld_src + sc_;
+                unsigned short h0 = 0, h1 = 0, h2 = 0, h3 = 0;
+                if (c + 3 < D.cols) {
+                    const uint2 w = *reinterpret_cast<const uint2*>(p);      // (8-byte aligned: every term is a multiple of 4)
+                    h0 = (unsigned short)(w.x & 0xffffu); h1 = (unsigned short)(w.x >> 16);
+                    h2 = (unsigned short)(w.y & 0xffffu); h3 = (unsigned short)(w.y >> 16);
+                } else {
+                    if (c < D.cols) h0 = p[0];
+                    if (c + 1 < D.cols) h1 = p[1];
+                    if (c + 2 < D.cols) h2 = p[2];
+                }
+                if (tr_bf) x = make_float4(bf16_back(h0), bf16_back(h1), bf16_back(h2), bf16_back(h3));
+                else x = make_float4(f16_back(h0), f16_back(h1), f16_back(h2), f16_back(h3));
+            } else {
+                const float* p = S + (int64_t)r * D.ld_src + sc_;
+                if (c + 3 < D.cols) x = *reinterpret_cast<const float4*>(p);
+                else {
+                    if (c < D.cols) x.x = p[0];
+                    if (c + 1 < D.cols) x.y = p[1];
+                    if (c + 2 < D.cols) x.z = p[2];
+                }
             }
         }
         v[i] = x;
     }
     if (D.flags & GHN3_CAST_COLSUM) {
-        csum[rr][c4] = v[0].x + v[1].x + v[2].x + v[3].x;
-        csum[rr][c4 + 1] = v[0].y + v[1].y + v[2].y + v[3].y;
-        csum[rr][c4 + 2] = v[0].z + v[1].z + v[2].z + v[3].z;
-        csum[rr][c4 + 3] = v[0].w + v[1].w + v[2].w + v[3].w;
+        const float un = src16 ? 1.f / sc : 1.f;        // (a power of two: exact)
+        csum[rr][c4] = (v[0].x + v[1].x + v[2].x + v[3].x) * un;
+        csum[rr][c4 + 1] = (v[0].y + v[1].y + v[2].y + v[3].y) * un;
+        csum[rr][c4 + 2] = (v[0].z + v[1].z + v[2].z + v[3].z) * un;
+        csum[rr][c4 + 3] = (v[0].w + v[1].w + v[2].w + v[3].w) * un;
     }
-    if (sc != 1.f) {
+    if (sc != 1.f && !src16) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) { v[i].x *= sc; v[i].y *= sc; v[i].z *= sc; v[i].w *= sc; }
     }

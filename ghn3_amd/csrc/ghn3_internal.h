@@ -95,11 +95,13 @@ int ghn3_ln_param_grad(float* dg, float* db, const float* dy, const float* x, co
 int ghn3_ln_param_grad_batch(float* gbase, const float* abase, const int64_t* table, int n_items, int rows, int C,
                              hipStream_t s);
 int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d_desc, int n_desc,
-                  int64_t total, const int64_t* blocks, int lds_bytes, float* sq_parts, hipStream_t s);
+                  int64_t total, const int64_t* blocks, int lds_bytes, float* sq_parts, float* b_parts, hipStream_t s);
 int ghn3_tile_bwd(const float* dflat, const float* const* srcs, float* const* dsrcs,
                   const ghn3_tile_desc* d_desc, int n_desc, int64_t total, const int64_t* blocks, int lds_bytes,
-                  float* amax, const float* out, const float* norms, const int* desc_seg, const float* gscale, hipStream_t s);
-int ghn3_param_norm_fin(float* loss, float* norms, const float* parts, const int* first, int n_seg, hipStream_t s);
+                  float* amax, const float* out, const float* norms, const int* desc_seg, const float* gscale,
+                  const int64_t* h16_tab, int h16_bf16, hipStream_t s);
+int ghn3_param_norm_fin(float* loss, float* norms, const float* parts, const int* first, int n_seg, const float* b_parts,
+                        float* ratio, float* bound, hipStream_t s);
 int ghn3_param_norm_fwd(float* loss, const float* flat, const int64_t* seg_off, float* norms, int n_seg,
                         int64_t flat_numel, const int* first_seg, float* parts, hipStream_t s);
 int ghn3_param_norm_bwd(float* dflat, const float* flat, const int64_t* seg_off, const float* norms, int n_seg,

@@ -708,7 +708,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             const ghn3_tile_desc* dd = R.get<const ghn3_tile_desc>(o.r[7]);
             rc = ghn3_tile_fwd(R.get<float>(o.r[0]), srcs, dd, (int)o.i[0], o.i[1],
                                reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(dd) + o.i[2]),
-                               (int)o.i[3], R.get<float>(o.r[8]), stream);
+                               (int)o.i[3], R.get<float>(o.r[8]), R.get<float>(o.r[9]), stream);
             break;
         }
         case GHN3_OP_TILE_BWD: {
@@ -721,7 +721,9 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(dd) + o.i[2]),
                                (int)o.i[3], R.get<float>(o.r[13]), R.get<const float>(o.r[15]), norms,
                                norms ? reinterpret_cast<const int*>(reinterpret_cast<const char*>(dd) + o.i[4]) : nullptr,
-                               norms ? R.get<const float>(o.r[6]) : nullptr, stream);
+                               norms ? R.get<const float>(o.r[6]) : nullptr,
+                               (norms && o.i[5] > 0) ? reinterpret_cast<const int64_t*>(reinterpret_cast<const char*>(dd) + o.i[5]) : nullptr,
+                               (int)o.i[6], stream);
             break;
         }
         case GHN3_OP_PARAM_NORM_FWD:
@@ -732,7 +734,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             break;
         case GHN3_OP_PARAM_NORM_FIN:
             rc = ghn3_param_norm_fin(R.get<float>(o.r[0]), R.get<float>(o.r[1]), R.get<const float>(o.r[2]),
-                                     R.get<const int>(o.r[3]), (int)o.i[0], stream);
+                                     R.get<const int>(o.r[3]), (int)o.i[0], R.get<const float>(o.r[4]), R.get<float>(o.r[5]),
+                                     R.get<float>(o.r[6]), stream);
             break;
         case GHN3_OP_PARAM_NORM_BWD:
             if (o.i[1] <= 0) { ghn3_set_error("PARAM_NORM_BWD: i1 (flat extent) missing"); rc = GHN3_E_ARG; break; }

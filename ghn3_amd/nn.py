@@ -530,6 +530,8 @@ class GHN3(nn.Module):
             if norm_g is not None:
                 plan._norm_g = norm_g                    # (kept alive until the kernels ran)
                 plan.bufs[prog.xbuf(prog.X_NORMG)] = norm_g.data_ptr()
+            # direct 16-bit tiles (Program._build_backward): only the norm term has an a-priori bound of the tile gradient
+            patched = [kt] + prog.set_tile_route(direct=dout is None and norm_g is not None)
         elif norm_g is not None:
             raise L.Ghn3Error('the fused norm loss needs a plan with predicted tensors')
         stream = torch.cuda.current_stream().cuda_stream
@@ -540,7 +542,8 @@ class GHN3(nn.Module):
             k = prog.memset_grad_op                      # (the memset placeholders live in the first part)
             prog.bwd_parts[0][0][k:k + 2] = prog.bwd_ops[k:k + 2]
             if kt is not None:
-                prog.bwd_parts[0][0][kt] = prog.bwd_ops[kt]
+                for k_ in patched:                       # (all in front of the W2 weight gradient: same index in part 1)
+                    prog.bwd_parts[0][0][k_] = prog.bwd_ops[k_]
             reducer.begin()
             n_off = len(self._offs)
             for ops, slots in prog.bwd_parts:

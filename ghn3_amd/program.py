@@ -159,7 +159,18 @@ class Program:
         self.n_fwd_problems = len(self._probs)
         if training:
             self._build_backward()
+            # direct 16-bit tiles: ops of the direct route (off unless GHN3._run_backward turns them on) and of the fp32 route
+            on, off = getattr(self, '_d16_on', []), getattr(self, '_d16_off', [])
+            self.d16_on_idx = [k for k, o in enumerate(self._ops) if any(o is t for t in on)]
+            self.d16_off_idx = [k for k, o in enumerate(self._ops) if any(o is t for t in off)]
+            assert all(k < self.bwd_cut_w2 and (self.wgrad_op_range is None or k < self.wgrad_op_range[0])
+                       for k in self.d16_on_idx + self.d16_off_idx)
             self.bwd_ops = self._finish_ops()
+            self.d16_kinds = {k: int(self.bwd_ops[k]['kind']) for k in self.d16_on_idx + self.d16_off_idx}
+            if not hasattr(self, 'tile_bwd_h16'):
+                self.tile_bwd_h16 = 0
+            for k in self.d16_on_idx:
+                self.bwd_ops[k]['kind'] = L.OP_NOP               # (compiled state = the fp32 route)
             detach = np.zeros(1, dtype=L.OP_DT)
             detach['kind'] = L.OP_DETACH
             detach['r']['buf'][:] = -1
@@ -211,7 +222,7 @@ class Program:
         shrinks from 4.5 MB / ~60k objects to the packed arrays)."""
         for name in ('_probs', '_ops', '_ln', '_idx_chunks', 'conv_groups', 'gemm_groups', 'param_groups', 'params_map',
                      'wgrad_bands', 'd1', 'row_src', 'row_pos', 'oned_src', 'oned_index', 'oned_plain', 'oned_clsb',
-                     'shape_idx', 'node_types', 'shadow_lay'):
+                     'shape_idx', 'node_types', 'shadow_lay', '_tile_desc_arr', '_d16_on', '_d16_off'):
             if hasattr(self, name):
                 setattr(self, name, None)
         for p_ in self.predicted:
@@ -293,6 +304,10 @@ class Program:
             if it.get('scaled'):
                 assert amax is not None
                 dflags |= L.CAST_SCALED
+            if it.get('src16'):
+                # (source = a 16-bit matrix of the destination buffer that already carries the scale, see GHN3_CAST_SRC16)
+                assert not it.get('straight') and not it.get('split') and (dst_base is None)
+                dflags |= L.CAST_SRC16
             assert it['ld_src'] % 4 == 0 and it['src_off'] % 4 == 0
             D['flags'] = dflags
             D['block_start'] = blocks
@@ -1355,7 +1370,10 @@ class Program:
             # (training: every work block leaves the sum of squares of what it wrote -- the predicted-parameter norm loss
             # then needs no pass over the output, see norm_fin_ops)
             parts = self.wsf('sq_parts', self.fwd_blk[0]) if self.training else self.NONE
-            self.op(L.OP_TILE_FWD, refs=[(self.xbuf(self.X_OUT), 0)] + srcs + [self.r_desc, parts],
+            # (+ per-block ingredients of the tile backward's a-priori output bound, see _build_backward: direct 16-bit tiles)
+            bparts = self.wsf('b_parts', self.fwd_blk[0]) if self.training else self.NONE
+            self._tile_desc_arr = desc_arr
+            self.op(L.OP_TILE_FWD, refs=[(self.xbuf(self.X_OUT), 0)] + srcs + [self.r_desc, parts, bparts],
                     ints=(self.n_desc, self.fwd_blk[0], self.fwd_blk[1], self.tile_lds[0]),
                     flags=L.OPFLAG_TIMED | (self.TAG_TILE_FWD << 16))
 
@@ -1398,7 +1416,10 @@ class Program:
         scal = self.xbuf(self.X_SCAL)
         saved, self._ops = self._ops, []
         if self.n_desc and 'sq_parts' in self._ws_names:
-            self.op(L.OP_PARAM_NORM_FIN, refs=((scal, 0), (scal, 256), self.wref('sq_parts'), self.r_seg_blk),
+            # (r4..r6: the bound of the tile gradient for GHN3_OP_TILE_BWD's direct 16-bit output, left in front of the norms)
+            self.op(L.OP_PARAM_NORM_FIN, refs=((scal, 0), (scal, 256), self.wref('sq_parts'), self.r_seg_blk,
+                                               self.wref('b_parts'), (scal, 256 + round_up(4 * max(self.n_seg, 1), 64)),
+                                               (scal, 252)),
                     ints=(self.n_seg,))
         else:
             self.op(L.OP_MEMSET0, refs=((scal, 0),), ints=(4,))
@@ -1454,6 +1475,56 @@ class Program:
     def _colsum(self, out, X, M, N, ld, q=0, s=0, stride=1, gather=None):
         self.op(L.OP_COLSUM, refs=(out, X, gather if gather is not None else self.NONE),
                 ints=(M, N, ld, q, s, stride, 1))
+
+    def set_tile_route(self, direct):
+        """Switches the compiled backward between the fp32 route of the tile gradient (tile backward -> fp32 d_tiles ->
+        cast passes with the measured maximum) and the direct 16-bit route (see _build_backward; only valid when the fused
+        norm loss is the ONLY upstream term of the step).  Returns the indices of the ops it touched (all lie in front of
+        the W2 weight gradient, i.e. in the first part of bwd_parts at the same index)."""
+        direct = bool(direct and getattr(self, 'tile_bwd_h16', 0))
+        if self.tile_bwd_op is None or not hasattr(self, 'd16_kinds'):
+            return []
+        self.bwd_ops[self.tile_bwd_op]['i'][5] = self.tile_bwd_h16 if direct else 0
+        touched = []
+        for idx, on in ((self.d16_on_idx, direct), (self.d16_off_idx, not direct)):
+            for k in idx:
+                self.bwd_ops[k]['kind'] = self.d16_kinds[k] if on else L.OP_NOP
+                touched.append(k)
+        return touched
+
+    def _build_h16_table(self, g16, direct_member):
+        """Per tile descriptor {h, rel0, ld32 | ld16 << 32} of GHN3_OP_TILE_BWD's direct 16-bit output: where the fp32
+        region of the descriptor lies inside its family's tile matrix and where that matrix's 16-bit copy `dth` starts
+        (relative to d_tiles, in 16-bit elements).  h = INT64_MIN: the descriptor keeps its fp32 output."""
+        D = self._tile_desc_arr
+        nd = self.n_desc
+        tab = np.zeros((nd, 3), dtype=np.int64)
+        tab[:, 0] = np.iinfo(np.int64).min
+        members = []
+        for g in g16:
+            for m_ in g['members']:
+                if direct_member(m_):
+                    members.append((m_['tile_off'], m_['tile_off'] + m_['rows'] * g['ld'], g))
+        members.sort(key=lambda t: t[0])
+        if members and nd:
+            lo = np.asarray([t[0] for t in members], dtype=np.int64)
+            hi = np.asarray([t[1] for t in members], dtype=np.int64)
+            src = D['src_off'].astype(np.int64)
+            k = np.searchsorted(lo, src, side='right') - 1
+            ok = (D['src_buf'] == 0) & (k >= 0)
+            ok &= src < hi[np.maximum(k, 0)]
+            reach = src + ((D['R'].astype(np.int64) - 1) * D['S'].astype(np.int64)).sum(axis=1)
+            d_tiles_h = self._ws_names['d_tiles'] // 2
+            for d_ in np.nonzero(ok)[0]:
+                g = members[int(k[d_])][2]
+                assert reach[d_] < hi[int(k[d_])], 'tile descriptor straddles a family member'
+                assert D['mode'][d_] == 0
+                rel0 = int(src[d_]) - g['tile_off']
+                assert 0 <= rel0 and g['rows'] * g['ld'] < 2 ** 32
+                tab[d_] = (g['dth'] - d_tiles_h, rel0, g['ld'] | (g['dth_ld'] << 32))
+        r_tab = self.idx(tab)
+        assert r_tab[0] == self.r_desc[0] and r_tab[1] > self.r_desc[1]
+        self.tile_bwd_h16 = r_tab[1] - self.r_desc[1]        # ints[5] of the tile backward when the direct route is on
 
     def _build_backward(self):
         C, H, B, N, V, K = self.C, self.H, self.B, self.N, self.V, self.K
@@ -1514,7 +1585,8 @@ class Program:
                                   14: (self.xbuf(self.X_SCAL), 256), 15: (self.xbuf(self.X_OUT), 0)}
             self.op(L.OP_TILE_BWD, refs=[(self.xbuf(self.X_DOUT), 0)] + srcs + [self.r_desc] + grads +
                     [self.NONE, self.NONE],
-                    ints=(self.n_desc, self.bwd_blk[0], self.bwd_blk[1], self.tile_lds[1], self.desc_seg_off),
+                    ints=(self.n_desc, self.bwd_blk[0], self.bwd_blk[1], self.tile_lds[1], self.desc_seg_off, 0,
+                          1 if self.decoder_bwd_ctype == L.CT_BF16 else 0),
                     flags=L.OPFLAG_TIMED | (self.TAG_TILE_BWD << 16))
 
         def decoder_1d_bwd(side):
@@ -1617,7 +1689,15 @@ class Program:
                 # with o' in [o_lo, o_hi) need exactly a k PREFIX: one GEMM problem per (band, o range), all in ONE
                 # launch, and every dW2 row is written exactly once -- no accumulation into dW2 between families (was
                 # 2 GB read + 2 GB written per step at ghn3xlm16) and no memset of it when the bands cover it.
-                items, side_items = [], []
+                # Direct 16-bit tiles (round 4, GHN3_TILE_D16): with the fused norm loss alone the tile backward writes the
+                # scaled 16-bit copy `dth` itself (scale from an a-priori bound, GHN3_OP_TILE_BWD) -- no fp32 d_tiles for
+                # the rows it produces, no straight cast pass on the critical path, and the transposed wgrad operands are
+                # re-laid out from the 16-bit copy.  Rows the tile backward does not produce (classifier-weight rows: head
+                # dgrad; resized kernels: a GEMM over d_tiles) keep the fp32 route.  Both op sets are compiled; GHN3.
+                # _run_backward switches per step (an upstream gradient `dout` has no bound: fp32 + measured maximum).
+                d16 = bool(scaled and self.tile_bwd_op is not None and os.environ.get('GHN3_TILE_D16', '1') != '0')
+                direct_member = lambda m_: m_['kind'] == 'conv' and 'resize' not in m_
+                items, side_items, items_d16, side_d16, u_items = [], [], [], [], []
                 rowsets, bias_sets, n_parts = [], [], 0
                 for g in g16:
                     g['dth_ld'] = round_up(g['cols'], 64) + 64        # (+64: rows never a power of two apart)
@@ -1626,6 +1706,12 @@ class Program:
                     items.append(dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'], rows=g['rows'],
                                       cols=g['cols'], ld_src=g['ld'], straight=(g['dth'], g['dth_ld'], bct),
                                       scaled=scaled))
+                    for m_ in g['members']:
+                        if not direct_member(m_):
+                            r_ = m_['row0'] - g['row0']
+                            items_d16.append(dict(src_off=self._ws_names['d_tiles'] // 4 + g['tile_off'] + r_ * g['ld'],
+                                                  rows=m_['rows'], cols=g['cols'], ld_src=g['ld'],
+                                                  straight=(g['dth'] + r_ * g['dth_ld'], g['dth_ld'], bct), scaled=scaled))
                     for sb in g['subs']:
                         rowsets.append(dict(o=sb['o'], i=g['i_ld'], row0=sb['row0'], rows=sb['rows'], g=g))
                 self.wgrad_bands = []
@@ -1649,14 +1735,31 @@ class Program:
                                                cols=m_['o'] * bw, ld_src=g['ld'], src_map=(bw, m_['i']),
                                                transposed=(band['dthT'] + m_['k_off'], ktot, bct),
                                                scaled=scaled, tight=True, colsum_parts=n_parts))
+                        # (direct 16-bit tiles: the same band copy from the family's 16-bit matrix -- every row of it is
+                        # complete once the straight cast of the fp32-route rows has run)
+                        side_d16.append(dict(src_off=g['dth'] + (m_['row0'] - g['row0']) * g['dth_ld'] + i_lo, rows=m_['rows'],
+                                             cols=m_['o'] * bw, ld_src=g['dth_ld'], src_map=(bw, m_['i']),
+                                             transposed=(band['dthT'] + m_['k_off'], ktot, bct),
+                                             scaled=scaled, tight=True, colsum_parts=n_parts, src16=True))
                         bias_sets.append((n_parts, (m_['rows'] + 63) // 64, m_['o'], bw, m_['o'] * bw, i_lo))
                         n_parts += ((m_['rows'] + 63) // 64) * m_['o'] * bw
-                        side_items.append(dict(src_off=u[1] // 4 + m_['row0'] * 8 * C, rows=m_['rows'], cols=8 * C,
-                                               ld_src=8 * C, transposed=(band['uhT'] + m_['k_off'], ktot, bct),
-                                               tight=True))
+                        u_items.append(dict(src_off=u[1] // 4 + m_['row0'] * 8 * C, rows=m_['rows'], cols=8 * C,
+                                            ld_src=8 * C, transposed=(band['uhT'] + m_['k_off'], ktot, bct),
+                                            tight=True))
                     i_lo = i_hi
+                self._d16_on, self._d16_off = [], []
+
+                def marked(into, fn):
+                    n0 = len(self._ops)
+                    fn()
+                    if d16:
+                        into.extend(self._ops[n0:])
+
                 # the dgrad operand on the critical path; the wgrad operands (and the bias gradient) beside it
-                self.cast16((self.xbuf(self.X_WS), 0), items, amax=amax_t)
+                marked(self._d16_off, lambda: self.cast16((self.xbuf(self.X_WS), 0), items, amax=amax_t))
+                if d16:
+                    marked(self._d16_on, lambda: self.cast16((self.xbuf(self.X_WS), 0), items_d16, amax=amax_t))
+                    self._build_h16_table(g16, direct_member)
                 # decoder.conv.2.bias gradient = column sums of d_tiles: every 64-row tile of the transposed band copies
                 # leaves its partial sums in a slot (no atomics), GHN3_OP_ROWSET_COLSUM adds the slots of a bias entry
                 # (all row tiles of all row sets with o_r > o', i_r > i') in a fixed order: deterministic
@@ -1668,7 +1771,11 @@ class Program:
                 main_ops = self._ops
                 if prep_late:
                     self._ops = []
-                self.cast16((self.xbuf(self.X_WS), 0), side_items, dbias=parts, flags=self.SIDE, amax=amax_t)
+                marked(self._d16_off, lambda: self.cast16((self.xbuf(self.X_WS), 0), side_items + u_items, dbias=parts,
+                                                          flags=self.SIDE, amax=amax_t))
+                if d16:
+                    marked(self._d16_on, lambda: self.cast16((self.xbuf(self.X_WS), 0), side_d16 + u_items, dbias=parts,
+                                                             flags=self.SIDE, amax=amax_t))
                 sets = np.zeros(len(bias_sets), dtype=L.ROWSET_DT)
                 for k_, (off, n_rt, o_, bw_, ld_, i0_) in enumerate(bias_sets):
                     sets[k_] = (off, n_rt, o_, bw_, ld_, i0_, 0)

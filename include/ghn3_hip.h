@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 14
+#define GHN3_ABI_VERSION 15
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -191,6 +191,11 @@ typedef struct ghn3_gemm_problem {
  * i.e. the 16 x 32 operand of one v_mfma_f32_16x16x32_bf16 is one contiguous kilobyte in lane order.  rows and cols must be
  * multiples of 32.  Operand layout of the staged split-bf16 kernels (GHN3_OP_GEMM tile codes 44 / 45).  (ABI v14) */
 #define GHN3_CAST_FRAG 512u
+/* the source is a 16-bit matrix inside the destination buffer: src_off / ld_src in 16-bit elements from r1, element type =
+ * type of the copies written; only the transposed copy (and the column sums) may be requested.  With GHN3_CAST_SCALED the
+ * source already carries the power-of-two scale of the op's r4: values are re-laid out bit for bit, column sums are divided by
+ * the scale.  (The transposed weight-gradient operands made from the 16-bit tile gradient GHN3_OP_TILE_BWD wrote.)  (ABI v15) */
+#define GHN3_CAST_SRC16 1024u
 typedef struct ghn3_cast_desc {
     int64_t src_off, dst_off, dstT_off;
     int32_t rows, cols;
@@ -263,7 +268,9 @@ enum ghn3_op_kind {
      * (~k, a0 | i0 << 24) with ~k < 0 is a ROW block: elements [i0, i0 + _pad) of row a0 of descriptor k moved through LDS (4-D
      * kernels with kh * kw > 1, mode 0, S[1] == 1, E[2..3] == T[2..3] == R[2..3]); i3 = max floats * 4 it needs
      * r8 = optional float slots, one per work block: the block's sum of squares of what it wrote (the per-tensor Frobenius
-     * norms of trainer.py:288-294 then need no pass over the 346 MB output: GHN3_OP_PARAM_NORM_FIN adds a tensor's slots) */
+     * norms of trainer.py:288-294 then need no pass over the 346 MB output: GHN3_OP_PARAM_NORM_FIN adds a tensor's slots)
+     * r9 = optional second set of slots (with r8): max |value written| * replicas * |scale| of the block for mode-0
+     * descriptors of source 0, else 0 -- the ingredients of GHN3_OP_TILE_BWD's a-priori output bound (ABI v15) */
     GHN3_OP_TILE_FWD = 8,
     /* sum over predicted tensors of ||p||_F (trainer.py:97-98,288-294)
      * r0=loss(1 float, accumulated) r1=flat r2=seg_off(int64 (begin,end) pairs, sorted by begin, disjoint)
@@ -281,7 +288,15 @@ enum ghn3_op_kind {
      * (GHN3_OP_PARAM_NORM_FIN) the upstream gradient of element e of tensor t is  dflat[e] + g * out[e] / norm_t  with
      * r15 = the flat predicted buffer `out`, g = the device float r6 (source slot 5 is never a tile source) and i4 = byte
      * offset from r7 to the int32 descriptor -> tensor table; r0 (dflat) may then be absent: the norm term alone.  The
-     * 346 MB gradient of the norm term is never materialised. */
+     * 346 MB gradient of the norm term is never materialised.
+     * Direct 16-bit tiles (ABI v15; norm term alone, r0 absent, r13 present): i5 > 0 = byte offset from r7 to a table of three
+     * int64 per descriptor {h, rel0, ld32 | ld16 << 32}.  A descriptor of source 0 with h != INT64_MIN writes its gradient
+     * not as fp32 but as the scaled 16-bit operand copy (i6 = 0 f16 / 1 bf16) the W2 GEMMs consume: fp32 element rel0 + s of a
+     * row-major matrix with row stride ld32 (s = the descriptor's source offset minus src_off) goes to 16-bit element
+     * h + (rel / ld32) * ld16 + rel % ld32 behind r8.  The scale is the power of two of ghn3_gemm_problem::alpha_amax for bound = |g| * norms[-1]: the
+     * float in front of r14 is GHN3_OP_PARAM_NORM_FIN's r6, an upper bound of every |element| the op writes to source-grad 0
+     * divided by |g|.  The op stores `bound` to r13 (instead of a measured maximum), where GHN3_CAST_SCALED copies and
+     * ghn3_gemm_problem::alpha_amax look the scale up.  One pass and 2 bytes per element instead of three passes and 8. */
     GHN3_OP_TILE_BWD = 11,
     /* column sums: out[omap(n)] += sum_m X[g(m)][n] ; r0=out r1=X r2=row gather (int32) or absent
      * i: M,N,ld,q,s,stride,accum(must be 1) ; omap(n) = ((n/q)*s + n%q)*stride (q == 0: n*stride) */
@@ -371,7 +386,9 @@ enum ghn3_op_kind {
     /* per-tensor Frobenius norms from the per-work-block sums of squares GHN3_OP_TILE_FWD left (r8 there), added in block
      * order (deterministic): norms[t] = sqrt(sum_{b in [first[t], first[t + 1])} parts[b]); loss[0] = sum_t norms[t] (fixed
      * order).  r0=loss (1 float, overwritten) r1=norms (n floats) r2=parts r3=first (int32, n + 1 entries) ; i0 = n tensors.
-     * Replaces GHN3_OP_PARAM_NORM_FWD's pass over the flat output (trainer.py:288-294).  (ABI v14) */
+     * Replaces GHN3_OP_PARAM_NORM_FWD's pass over the flat output (trainer.py:288-294).  (ABI v14)
+     * r4 = optional bound slots of GHN3_OP_TILE_FWD (r9 there), with r5 = scratch (n floats) and r6 = 1 float that receives
+     * max_t (max of t's bound slots) / norms[t]  (GHN3_OP_TILE_BWD expects r6 == r1 - 1 float).  (ABI v15) */
     GHN3_OP_PARAM_NORM_FIN = 33,
     /* GHN3_OP_LN_PARAM_GRAD for many LayerNorms in ONE launch (the 2 L LayerNorms of the Graphormer, deferred behind the
      * chain): item t adds  dgamma_t[c] += sum_r dy_t[r][c] xhat_t[r][c],  dbeta_t[c] += sum_r dy_t[r][c].

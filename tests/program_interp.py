@@ -34,10 +34,12 @@ class Interp:
     def fview(self, ref, count):
         return self.view(ref, np.float32, count)
 
-    def tail(self, ref, dtype):
+    def tail(self, ref, dtype, before=0):
+        """view from the reference to the end of its buffer (`before`: start that many elements in front of it)"""
         buf, off = int(ref['buf']), int(ref['off'])
         if buf < 0:
             return None
+        off -= before * np.dtype(dtype).itemsize
         b = self.bufs[buf]
         n = (len(b) - off) // np.dtype(dtype).itemsize
         return b[off:off + n * np.dtype(dtype).itemsize].view(dtype)
@@ -168,11 +170,19 @@ class Interp:
             if int(D['src_q']) > 0:
                 assert int(D['src_q']) % 4 == 0 and int(D['src_s']) % 4 == 0
                 cc = (cc // int(D['src_q'])) * int(D['src_s']) + cc % int(D['src_q'])
-            X = src[off + np.arange(rows)[:, None] * ld + cc[None, :]]
             fl = int(D['flags'])
-            Xsum = X
-            if fl & L.CAST_SCALED and amax is not None:
-                X = (X * np.float32(self.pow2_scale(amax[0]))).astype(np.float32)
+            if fl & L.CAST_SRC16:
+                # 16-bit source inside the destination buffer, already scaled: re-laid out as is; sums unscaled again
+                assert not fl & (L.CAST_STRAIGHT | L.CAST_SPLIT)
+                X = self.from16(dst[off + np.arange(rows)[:, None] * ld + cc[None, :]], bool(fl & L.CAST_TRANSPOSED_BF16))
+                Xsum = X
+                if fl & L.CAST_SCALED and amax is not None:
+                    Xsum = (X / np.float32(self.pow2_scale(amax[0]))).astype(np.float32)
+            else:
+                X = src[off + np.arange(rows)[:, None] * ld + cc[None, :]]
+                Xsum = X
+                if fl & L.CAST_SCALED and amax is not None:
+                    X = (X * np.float32(self.pow2_scale(amax[0]))).astype(np.float32)
             split = bool(fl & L.CAST_SPLIT)
             if split:                               # bf16 hi copy + lo = bf16(x - hi) copy `lo_off` elements behind
                 Xlo = (X - self.from16(self.to16(X, True), True)).astype(np.float32)
@@ -627,6 +637,7 @@ class Interp:
         flat = self.tail(o['r'][0], np.float32)
         srcs = [self.tail(o['r'][1 + k], np.float32) for k in range(6)]
         parts = self.tail(o['r'][8], np.float32)
+        bparts = self.tail(o['r'][9], np.float32)
         desc_of_block = None
         if parts is not None:
             nblk = int(o['i'][1])
@@ -646,6 +657,12 @@ class Interp:
                 blk = np.nonzero(desc_of_block == kd)[0]
                 parts[blk] = 0.0
                 parts[blk[0]] = np.float32((val.astype(np.float32).astype(np.float64) ** 2).sum())
+                if bparts is not None:                  # r9: max |value| * replicas * |scale| (mode 0, source 0)
+                    bparts[blk] = 0.0
+                    if int(D['src_buf']) == 0 and int(D['mode']) == 0 and val.size:
+                        reps = np.prod((T + E - 1) // E)
+                        bparts[blk[0]] = np.float32(np.abs(val.astype(np.float32)).max()) * np.float32(abs(float(D['scale']))) * \
+                            np.float32(reps)
             kd += 1
 
     def op_tile_bwd(self, o, problems):
@@ -660,6 +677,15 @@ class Interp:
         if norms is not None:
             outv, gs = self.tail(o['r'][15], np.float32), float(self.tail(o['r'][6], np.float32)[0])
             dseg = self.tail(o['r'][7], np.uint8)[int(o['i'][4]):int(o['i'][4]) + 4 * int(o['i'][0])].view(np.int32)
+        # direct 16-bit tiles: i5 = byte offset (from r7) of {h, rel0, ld32 | ld16 << 32} per descriptor, i6 = bf16
+        h16 = None
+        if int(o['i'][5]) > 0:
+            assert g is None and norms is not None and amax is not None
+            h16 = self.tail(o['r'][7], np.uint8)[int(o['i'][5]):int(o['i'][5]) + 24 * int(o['i'][0])].view(np.int64).reshape(-1, 3)
+            hdst = self.tail(o['r'][8], np.uint16)
+            bound = np.float32(self.tail(o['r'][14], np.float32, before=1)[0]) * np.float32(abs(gs))
+            amax[0] = bound
+            hsc = np.float32(self.pow2_scale(bound))
         for kd, D in enumerate(self._descs(o)):
             T, E, S, R = (D[k].astype(np.int64) for k in ('T', 'E', 'S', 'R'))
             n = int(np.prod(T))
@@ -684,8 +710,15 @@ class Interp:
             inside = np.zeros(tuple(R), dtype=bool)
             inside[:E[0], :E[1], :E[2], :E[3]] = True
             acc = np.where(inside, acc, 0.0)
+            if h16 is not None and int(D['src_buf']) == 0 and int(h16[kd, 0]) != np.iinfo(np.int64).min:
+                rel = int(h16[kd, 1]) + (so.reshape(-1) - int(D['src_off']))
+                ld32, ld16 = int(h16[kd, 2]) & 0xffffffff, int(h16[kd, 2]) >> 32
+                assert acc.size == 0 or float(np.abs(acc).max()) <= float(bound) * (1 + 1e-5), 'bound violated'
+                hdst[int(h16[kd, 0]) + (rel // ld32) * ld16 + rel % ld32] = \
+                    self.to16(acc.reshape(-1).astype(np.float32) * hsc, bool(int(o['i'][6])))
+                continue
             dsrcs[int(D['src_buf'])][so.reshape(-1)] = acc.reshape(-1).astype(np.float32)
-            if amax is not None and int(D['src_buf']) == 0 and acc.size:
+            if h16 is None and amax is not None and int(D['src_buf']) == 0 and acc.size:
                 amax[0] = max(float(amax[0]), float(np.abs(acc.astype(np.float32)).max()))
 
     def op_ln_param_grad_batch(self, o, problems):
@@ -703,9 +736,19 @@ class Interp:
         n = int(o['i'][0])
         loss, norms = self.tail(o['r'][0], np.float32), self.tail(o['r'][1], np.float32)
         parts, first = self.tail(o['r'][2], np.float32), self.tail(o['r'][3], np.int32)
+        bparts = self.tail(o['r'][4], np.float32)
         for t in range(n):
             norms[t] = np.float32(np.sqrt(parts[int(first[t]):int(first[t + 1])].astype(np.float64).sum()))
         loss[0] = np.float32(norms[:n].astype(np.float64).sum())
+        if bparts is not None:                       # r6: max_t (max of t's bound slots) / norms[t]
+            ratio, bound = self.tail(o['r'][5], np.float32), self.tail(o['r'][6], np.float32)
+            b = np.float32(0)
+            for t in range(n):
+                bp = bparts[int(first[t]):int(first[t + 1])]
+                r = np.float32(bp.max() / norms[t]) if (bp.size and norms[t] > 0) else np.float32(0)
+                ratio[t] = r
+                b = max(b, r)
+            bound[0] = b
 
     def op_param_norm_fwd(self, o, problems):
         n = int(o['i'][0])

@@ -850,3 +850,61 @@ def test_graft_entry_smoke():
     """The driver's smoke(): tiny forward + backward through the public API, checked against the oracle."""
     import __graft_entry__ as g
     g.smoke()
+
+
+@pytest.mark.parametrize('bf16', [False, True])
+def test_cast16_from_a_16bit_source_matches_the_interpreter(ctx, bf16):
+    """GHN3_CAST_SRC16 (round 4): transposed band copies + column-sum slots re-laid out from a scaled 16-bit matrix (what
+    GHN3_OP_TILE_BWD's direct route leaves) -- bit for bit what the numpy interpreter of tests/program_interp.py produces,
+    incl. the source column map, tight row padding and ragged edges."""
+    from ghn3_amd import _lib as L
+    from program_interp import Interp
+    rs = np.random.RandomState(3 + bf16)
+    rows, ld_src, amax = 150, 1216, 0.0371
+    sc = Interp.pow2_scale(amax)
+    src32 = (rs.standard_normal((rows, ld_src)) * amax / 4).astype(np.float32)
+    src16 = Interp.to16(src32 * np.float32(sc), bf16)
+    n_src = rows * ld_src
+    # descriptors: (first row, n rows, band i_lo, band width, o rows, i of the row layout)
+    specs = [(0, 70, 0, 32, 9, 128), (70, 80, 32, 96, 5, 128), (3, 37, 128, 64, 4, 192), (100, 50, 0, 8, 20, 8)]
+    descs = np.zeros(len(specs), dtype=L.CAST_DT)
+    dst_off, part_off, blocks, ktot = (n_src + 63) // 64 * 64, 0, 0, 256
+    for D, (r0, nr, i_lo, bw, o, i_) in zip(descs, specs):
+        cols = o * bw
+        D['src_off'], D['rows'], D['cols'], D['ld_src'] = r0 * ld_src + i_lo, nr, cols, ld_src
+        D['src_q'], D['src_s'] = bw, i_
+        D['dstT_off'], D['ld_dstT'] = dst_off, ktot
+        D['part_off'] = part_off
+        D['flags'] = (L.CAST_TRANSPOSED | (L.CAST_TRANSPOSED_BF16 if bf16 else 0) | L.CAST_COLSUM | L.CAST_COLSUM_PARTS |
+                      L.CAST_SCALED | L.CAST_TIGHT | L.CAST_SRC16)
+        D['block_start'] = blocks
+        blocks += ((nr + 63) // 64) * ((cols + 63) // 64)
+        dst_off += cols * ktot
+        part_off += ((nr + 63) // 64) * cols
+    buf16 = np.zeros(dst_off + 256, dtype=np.uint16)
+    buf16[:n_src] = src16.reshape(-1)
+    parts = np.zeros(part_off + 64, dtype=np.float32)
+    am = np.asarray([amax] + [0] * 15, dtype=np.float32)
+    op = np.zeros(1, dtype=L.OP_DT)
+    op['r']['buf'][:] = -1
+    op['kind'] = L.OP_CAST16
+    for j, b in enumerate((0, 1, 2, 3, 4)):
+        op['r']['buf'][0][j] = b
+    op['i'][0][:3] = (len(specs), blocks, 0)
+    # CPU
+    host = [np.zeros(64, np.uint8), buf16.copy().view(np.uint8), descs.copy().view(np.uint8).reshape(-1),
+            parts.copy().view(np.uint8), am.copy().view(np.uint8)]
+    Interp(host).run(op, None)
+    # GPU
+    dev = [torch.zeros(64, dtype=torch.uint8, device='cuda')] + \
+        [torch.from_numpy(a.copy().view(np.uint8).reshape(-1)).cuda() for a in (buf16, descs, parts, am)]
+    ptrs = np.asarray([t.data_ptr() for t in dev], dtype=np.uint64)
+    ctx.run(op, np.zeros(0, dtype=L.PROBLEM_DT), ptrs, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got16 = dev[1].cpu().numpy().view(np.uint16)
+    exp16 = host[1].view(np.uint16)
+    assert (got16[:n_src] == src16.reshape(-1)).all()
+    bad = np.nonzero(got16 != exp16)[0]
+    assert bad.size == 0, (bad[:10], got16[bad[:10]], exp16[bad[:10]])
+    gp, ep = dev[3].cpu().numpy().view(np.float32), host[3].view(np.float32)
+    assert np.abs(gp - ep).max() <= 1e-6 * np.abs(ep).max()

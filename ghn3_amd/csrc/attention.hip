@@ -455,9 +455,10 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_bwd_kernel(floa
                                                        const float* __restrict__ qkv, const float* __restrict__ P,
                                                        const float* __restrict__ Oin, float* __restrict__ dBias,
                                                        const int* __restrict__ n_nodes, int N, int C, int H,
-                                                       float scale, int vec) {
+                                                       float scale, int vec, float* __restrict__ amax_out) {
     __shared__ float red[NW * 16 * 64];
     __shared__ float dl[NW][32];
+    float bmx = 0.f;                                     // max |dBias written| (the last layer's launch: amax_out)
     const int d = C / H;
     const int NB = (N + 31) >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
@@ -529,15 +530,17 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_bwd_kernel(floa
                         f32x4 f = {db[4 * g] + ds[4 * g], db[4 * g + 1] + ds[4 * g + 1], db[4 * g + 2] + ds[4 * g + 2],
                                    db[4 * g + 3] + ds[4 * g + 3]};
                         *reinterpret_cast<f32x4*>(brow + jj) = f;
+                        bmx = fmaxf(fmaxf(bmx, fmaxf(fabsf(f.x), fabsf(f.y))), fmaxf(fabsf(f.z), fabsf(f.w)));
                     } else {
 #pragma unroll
                         for (int c = 0; c < 4; ++c)
-                            if (j0 + jj + c < N) brow[jj + c] = db[4 * g + c] + ds[4 * g + c];
+                            if (j0 + jj + c < N) { const float f = db[4 * g + c] + ds[4 * g + c]; brow[jj + c] = f; bmx = fmaxf(bmx, fabsf(f)); }
                     }
                 }
             }
             dQ = mfma_cols(kc, ds, dQ);                            // dQ^T += K^T dS^T
         }
+        if (amax_out) ghn3_atomic_amax(amax_out, bmx);        // (uniform branch: every lane of the wave takes part)
         f32x4 o = reduce_waves<NW>(red, dQ, w, lane);
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] *= scale;
@@ -598,7 +601,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_bwd_kernel(floa
 // ------------------------------------------------------------------------------------------------
 typedef void (*attn_fwd_fn)(float*, const float*, const float*, float*, const int*, int, int, int, float, int);
 typedef void (*attn_bwd_fn)(float*, const float*, const float*, const float*, const float*, float*, const int*, int,
-                            int, int, float, int);
+                            int, int, float, int, float*);
 
 static int g_attn_fwd_waves = 8;
 template <int KS> static attn_fwd_fn fwd_for(int tpw) {
@@ -667,9 +670,9 @@ int ghn3_attn_fwd(float* out, const float* qkv, const float* bias, float* P, con
     return GHN3_OK;
 }
 
-int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P, const float* O, float* dS,
+int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P, const float* O, float* amax_out,
                   float* dBias, const int* n_nodes, int B, int N, int C, int H, hipStream_t s) {
-    (void)dS;                                  // (scratch of the former two-pass backward; unused)
+    if (amax_out && !dBias) { ghn3_set_error("attention bwd: r5 (max |dBias|) needs r6"); return GHN3_E_ARG; }
     int rc = check_dims(N, C, H);
     if (rc) return rc;
     if (!P || !O) { ghn3_set_error("attention bwd: needs the saved probabilities and outputs"); return GHN3_E_ARG; }
@@ -681,7 +684,7 @@ int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P
     int nw = 4;
     attn_bwd_fn fn = pick_bwd(d, N, &nw);
     hipLaunchKernelGGL(fn, dim3(2 * nb, H, B), dim3(64 * nw), 0, s, dqkv, dO, qkv, P, O, dBias, n_nodes, N, C, H,
-                       scale, vec);
+                       scale, vec, amax_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("attn bwd launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

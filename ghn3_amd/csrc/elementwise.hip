@@ -351,14 +351,16 @@ __global__ __launch_bounds__(256) void bias_hist_finish_kernel(float* __restrict
     dT[(size_t)(e / H) * ldT + e % H] += (float)((double)acc[e] * (double)inv);
 }
 int ghn3_bias_hist(float* dT, const float* dBias, const int* pair, int B, int N, int H, int V, void* scratch,
-                   hipStream_t s) {
+                   int have_amax, hipStream_t s) {
     if (!scratch) { ghn3_set_error("bias_hist: r3 (zeroed int64 [V*V*H] + 16 bytes of scratch) is required"); return GHN3_E_ARG; }
     const int ldT = (H + 3) & ~3;
     long long* acc = reinterpret_cast<long long*>(scratch);
     float* amax = reinterpret_cast<float*>(acc + (size_t)V * V * H);
     const int64_t n = (int64_t)B * H * N * N;
-    hipLaunchKernelGGL(bias_amax_kernel, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, s, dBias,
-                       n, amax);
+    // (have_amax: the launch that wrote the final dBias -- GHN3_OP_ATTN_BWD with r5 -- left max |dBias| in the scratch)
+    if (!have_amax)
+        hipLaunchKernelGGL(bias_amax_kernel, dim3((unsigned)std::min<int64_t>(1024, (n + 255) / 256)), dim3(256), 0, s, dBias,
+                           n, amax);
     const size_t lds = (size_t)V * V * sizeof(long long);
     const int use_lds = lds <= 64 * 1024;
     const int rpb = 16;
@@ -1427,6 +1429,7 @@ __device__ __forceinline__ float dact_apply(float v, float z, int dact) {
 // parts / n_parts / part_stride / rows_parts: the K-split partial sums of the dgrad that are not in X itself (planes
 // 1 .. of a plane-wise split): rows m < rows_parts add parts[p * part_stride + m * N + n] for p < n_parts first
 // (fixed order: the result is deterministic, unlike atomically accumulated splits).  VEC only.
+#define DACT_FLIGHT 8          // planes of one element whose loads are issued together (16 measured no faster for the 15 planes of the bench workload: 118 against 112 us)
 template <bool VEC>
 __global__ __launch_bounds__(256) void dact_kernel(float* __restrict__ X, const float* __restrict__ aux, int M, int N,
                                                    int ld, int dact, float* __restrict__ amax,
@@ -1442,17 +1445,16 @@ __global__ __launch_bounds__(256) void dact_kernel(float* __restrict__ X, const 
             const float4 z = A4[e];
             float4 v = X4[e];
             if (e < lim4) {
-                // the planes of one element, eight loads in flight at a time (the W2 dgrad of the bench workload leaves
-                // 15 planes: a one-at-a-time tail behind the first seven was a chain of dependent round trips), summed in
-                // plane order
-                for (int p0 = 0; p0 < n_parts; p0 += 8) {
-                    float4 q[8];
+                // the planes of one element, all loads in flight together (the W2 dgrad of the bench workload leaves 15
+                // planes: every further batch is another dependent round trip), summed in plane order
+                for (int p0 = 0; p0 < n_parts; p0 += DACT_FLIGHT) {
+                    float4 q[DACT_FLIGHT];
 #pragma unroll
-                    for (int p = 0; p < 8; ++p)
+                    for (int p = 0; p < DACT_FLIGHT; ++p)
                         q[p] = p0 + p < n_parts ? *reinterpret_cast<const float4*>(parts + (int64_t)(p0 + p) * part_stride + 4 * e)
                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-                    for (int p = 0; p < 8; ++p)
+                    for (int p = 0; p < DACT_FLIGHT; ++p)
                         if (p0 + p < n_parts) { v.x += q[p].x; v.y += q[p].y; v.z += q[p].z; v.w += q[p].w; }
                 }
             }

@@ -435,6 +435,8 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
     // walks tpw of them and exits -- the launch then has vgrid * chunks workgroups that the dispatcher starts in order as CUs
     // free up, so a higher-priority stream (the dependent chain this weight gradient runs beside) gets CUs every few tiles
     // instead of never, at the price of one un-overlapped prologue / store phase per tpw tiles.
+    const bool nt_store = rfl(tpw >> 30) != 0;      // (GHN3_WGRAD_NT=1: streaming stores of the 1.8 GB output; experiment)
+    tpw &= 0x3fffffff;
     const int stride = vgrid;
     const int w_v = (int)blockIdx.x % vgrid, w_c = (int)blockIdx.x / vgrid;
     const int t_first = w_v + vgrid * w_c * tpw;
@@ -569,7 +571,11 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
 #pragma unroll
             for (int ni = 0; ni < 2; ++ni) {
                 const int col = p_n0 + wc * 64 + b * 32 + ni * 16 + 4 * kc;
-                if (col < p_N) *reinterpret_cast<gf4>(crow + col) = acc[a][b][mi][ni] * p_alpha;
+                if (col < p_N) {
+                    const f32x4 v = acc[a][b][mi][ni] * p_alpha;
+                    if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<gf4>(crow + col));
+                    else *reinterpret_cast<gf4>(crow + col) = v;
+                }
             }
         }
     };
@@ -707,12 +713,14 @@ int ghn3_gemm_p8w_launch(const GemmProbDev* d_probs, int n_probs, int total_tile
     if (total_tiles >= 8 && grid % 8) grid = 8;
     const int per_worker = (total_tiles + grid - 1) / grid;
     const int chunks = tpw > 0 ? (per_worker + tpw - 1) / tpw : 1;
+    static const int nt = getenv("GHN3_WGRAD_NT") ? atoi(getenv("GHN3_WGRAD_NT")) != 0 : 0;
+    const int tpw_arg = tpw | (nt << 30);
     if (ctype == GHN3_CT_F16)
         hipLaunchKernelGGL(gemm_p8w_kernel<GHN3_CT_F16>, dim3(grid * chunks), dim3(512), 128 * 1024, stream, d_probs, n_probs,
-                           total_tiles, grid, tpw);
+                           total_tiles, grid, tpw_arg);
     else
         hipLaunchKernelGGL(gemm_p8w_kernel<GHN3_CT_BF16>, dim3(grid * chunks), dim3(512), 128 * 1024, stream, d_probs, n_probs,
-                           total_tiles, grid, tpw);
+                           total_tiles, grid, tpw_arg);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("p8w gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

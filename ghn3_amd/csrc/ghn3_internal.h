@@ -66,7 +66,7 @@ int ghn3_gemm_small_launch(const GemmProbDev* d_probs, int n_probs, int total_ti
 int ghn3_attn_init();
 int ghn3_attn_fwd(float* out, const float* qkv, const float* bias, float* P, const int* n_nodes,
                   int B, int N, int C, int H, hipStream_t s);
-int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P, const float* O, float* dS,
+int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P, const float* O, float* amax_out,
                   float* dBias, const int* n_nodes, int B, int N, int C, int H, hipStream_t s);
 
 int ghn3_graph_prologue(const int64_t* A, int* deg_in, int* deg_out, int* dist0, int* pair,
@@ -83,7 +83,7 @@ int ghn3_edge_hidden(float* hid, const float* Pfw, const float* Pbw, int V, int 
 int ghn3_edge_hidden_bwd(float* dPfw, float* dPbw, float* dhid, const float* hid, int V, int C, hipStream_t s);
 int ghn3_bias_gather(float* bias, const float* T, const int* pair, int B, int N, int H, hipStream_t s);
 int ghn3_bias_hist(float* dT, const float* dBias, const int* pair, int B, int N, int H, int V, void* scratch,
-                   hipStream_t s);
+                   int have_amax, hipStream_t s);
 int ghn3_rowset_colsum(float* out, const float* X, const void* sets, int n_sets, int O, int I, hipStream_t s);
 int ghn3_layernorm_fwd(float* y, float* x, const float* g, const float* b, float* mean, float* rstd, const float* add,
                        int n_add, int64_t add_stride, int rows, int C, float eps, hipStream_t s);

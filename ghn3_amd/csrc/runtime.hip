@@ -664,7 +664,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             break;
         case GHN3_OP_BIAS_HIST:
             rc = ghn3_bias_hist(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const int>(o.r[2]),
-                                (int)o.i[0], (int)o.i[1], (int)o.i[2], (int)o.i[3], R.get<void>(o.r[3]), stream);
+                                (int)o.i[0], (int)o.i[1], (int)o.i[2], (int)o.i[3], R.get<void>(o.r[3]), (int)o.i[4], stream);
             break;
         case GHN3_OP_ROWSET_COLSUM:
             rc = ghn3_rowset_colsum(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const void>(o.r[2]),

@@ -2070,8 +2070,13 @@ class Program:
         # ---- final LayerNorm ----------------------------------------------------------------------------
         dxa = self.wsf('dxa', rows * C)
         do = self.wsf('do', rows * C)
-        dBias = self.wsf('dBias', B * H * N * N)
-        self.op(L.OP_MEMSET0, refs=(dBias,), ints=(4 * B * H * N * N,))
+        # (the 64-bit fixed-point histogram of GHN3_OP_BIAS_HIST + its max |dBias| slot live right behind dBias: one zero-fill
+        # for both, and the slot is ready when the last attention backward -- layer 0 -- reports the maximum of what it wrote)
+        nb_ = round_up(4 * B * H * N * N, 16)
+        dBias = self.wsf('dBias', nb_ // 4 + 2 * V * V * H + 16)
+        hist = (dBias[0], dBias[1] + nb_)
+        hist_amax = (dBias[0], dBias[1] + nb_ + 8 * V * V * H)
+        self.op(L.OP_MEMSET0, refs=(dBias,), ints=(nb_ + 8 * V * V * H + 16,))
         xL = self.wref('x%d' % self.Lyr)
         if self.layernorm:
             self.op(L.OP_LAYERNORM_BWD, refs=(dxa, d_xe, xL, self.pref('ln.weight'), self.wref('mf'), self.wref('rf'),
@@ -2124,7 +2129,7 @@ class Program:
                 self.x3s_linear(dz, W1f, True, dhA, rows, C, 4 * C, 4 * C, C)
                 self.x3s_linear(dhA, Wo, True, do, rows, C, C, C, C,
                                 ln=(2, [self.pref(pre + 'ln2.weight'), xmid, m2, r2, g_cur, g_mid]))
-                self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, self.NONE, dBias, r_nn), ints=(B, N, C, H))
+                self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, hist_amax if l == 0 else self.NONE, dBias, r_nn), ints=(B, N, C, H))
                 self.x3s_linear(dqkv, Wq, True, dhB, rows, C, 3 * C, 3 * C, C)
                 if l > 0:
                     pending_ln1 = (dhB, [self.pref(pre + 'ln1.weight'), x_in, m1, r1, g_mid, g_out])
@@ -2140,7 +2145,7 @@ class Program:
                                                   pl if np_ else self.NONE), ints=(rows, C, np_, rows * C))
                 # (its output feeds the attention backward, which reads ONE matrix: no K split)
                 self.x3_linear(g_mid, Wo, True, do, rows, C, C, C, C)
-                self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, self.NONE, dBias, r_nn), ints=(B, N, C, H))
+                self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, hist_amax if l == 0 else self.NONE, dBias, r_nn), ints=(B, N, C, H))
                 np_, pl = self.x3_linear(dqkv, Wq, True, dhB, rows, C, 3 * C, 3 * C, C, split=True, planes='dhB_plane')
                 self.op(L.OP_LAYERNORM_BWD, refs=(g_out, dhB, x_in, self.pref(pre + 'ln1.weight'), m1, r1, g_mid,
                                                   pl if np_ else self.NONE), ints=(rows, C, np_, rows * C))
@@ -2173,7 +2178,7 @@ class Program:
                     # attention output projection: xmid = x_in + o Wo^T + bo
                     p0 = self.gemm(g_mid, self.pref(Wo), do, rows, C, C, C, C, C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL)
                 self.gemm_op(p0)
-                self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, self.NONE, dBias, r_nn), ints=(B, N, C, H))
+                self.op(L.OP_ATTN_BWD, refs=(dqkv, do, qkv, Pm, o, hist_amax if l == 0 else self.NONE, dBias, r_nn), ints=(B, N, C, H))
                 dhB_p = None
                 if self.split_small(rows, C, 3 * C):
                     dhB_p = self.wsf('dhB_plane', rows * C)
@@ -2215,7 +2220,8 @@ class Program:
                       self.gref('shape_enc.embed_channel.weight'), self.gref('shape_enc.embed_spatial.weight'),
                       self.gref('gnn.0.centrality_embed_in.weight'), self.gref('gnn.0.centrality_embed_out.weight'),
                       self.gref('gnn.0.input_dist_embed.weight'), deg_in, deg_out, dist0),
-                ints=(B, N, C, len(bk.PRIMITIVES_DEEPNETS1M), self.vocab_rows[0], self.vocab_rows[1]), flags=self.SIDE)
+                ints=(B, N, C, len(bk.PRIMITIVES_DEEPNETS1M), self.vocab_rows[0], self.vocab_rows[1]),
+                flags=0 if os.environ.get('GHN3_EMBED_BWD_MAIN', '1') == '1' else self.SIDE)
         # ---- layer-0 edge bias: histogram -> table MLP backward ------------------------------------------
         E = 'gnn.0.attn.edge_embed.embed.weight'
         W0e, b0e = 'gnn.0.attn.proj_e.0.weight', 'gnn.0.attn.proj_e.0.bias'
@@ -2225,9 +2231,7 @@ class Program:
         dPfw, dPbw = self.wsf('dPfw', V * C), self.wsf('dPbw', V * C)
         hid = self.wref('hid')
         self.op(L.OP_MEMSET0, refs=(dT,), ints=(4 * V * V * ldT,))
-        hist = (self.xbuf(self.X_WS), self.ws('dT_fix', 8 * V * V * H + 64))     # 64-bit fixed-point histogram + amax
-        self.op(L.OP_MEMSET0, refs=(hist,), ints=(8 * V * V * H + 16,))
-        self.op(L.OP_BIAS_HIST, refs=(dT, dBias, pair, hist), ints=(B, N, H, V))
+        self.op(L.OP_BIAS_HIST, refs=(dT, dBias, pair, hist), ints=(B, N, H, V, 1))
         p0 = self.gemm(dT, hid, self.gref(W2e), H, C, V * V, ldT, C, C, a_mode=L.MODE_COL, b_mode=L.MODE_COL,
                        accum=True, dbias=self.gref(b2e))
         self.gemm_op(p0, side=True)                      # (weight gradient: off the chain)

@@ -309,11 +309,14 @@ enum ghn3_op_kind {
     GHN3_OP_LAYERNORM_BWD = 14,
     /* r0=dgamma r1=dbeta r2=dy r3=x r4=mean r5=rstd ; i: rows,C,accum */
     GHN3_OP_LN_PARAM_GRAD = 15,
-    /* r0=dqkv r1=dO r2=qkv r3=P r4=O (saved attention output) r5=unused r6=dBias (accumulated) r7=n_nodes
-     * i: B,N,C,H */
+    /* r0=dqkv r1=dO r2=qkv r3=P r4=O (saved attention output) r5=optional device float: running max of |dBias| as
+     * written by this launch (atomic max on a zeroed slot -- the program passes it to the LAST launch that accumulates into
+     * r6, whose values are final: GHN3_OP_BIAS_HIST then needs no pass for its scale; ABI v15) r6=dBias (accumulated)
+     * r7=n_nodes ; i: B,N,C,H */
     GHN3_OP_ATTN_BWD = 16,
     /* dT[p][h] += sum_{pair==p} dBias[b,h,i,j] ; r0=dT r1=dBias r2=pair r3=scratch: 8 * V * V * H + 16 bytes, ZEROED by
-     * the program (64-bit fixed-point histogram: the order of the atomics does not matter -> deterministic) ; i: B,N,H,V */
+     * the program (64-bit fixed-point histogram: the order of the atomics does not matter -> deterministic) ; i: B,N,H,V,
+     * i4 = 1: the float behind the histogram (r3 + 8 * V * V * H bytes) already holds max |dBias| (GHN3_OP_ATTN_BWD r5) */
     GHN3_OP_BIAS_HIST = 17,
     /* r0=dPfw r1=dPbw r2=dhid(in, masked in place) r3=hid ; i: V,C */
     GHN3_OP_EDGE_HIDDEN_BWD = 18,

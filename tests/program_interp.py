@@ -512,6 +512,9 @@ class Interp:
         pair = self.view(o['r'][2], np.int32, B * N * N).reshape(-1).astype(np.int64)
         dB = self.fview(o['r'][1], B * H * N * N).reshape(B, H, N * N)
         dT = self.fview(o['r'][0], V * V * ldT)
+        if int(o['i'][4]):                               # the scale comes from the slot GHN3_OP_ATTN_BWD (r5) filled
+            am = self.tail(o['r'][3], np.uint8)[8 * V * V * H:8 * V * V * H + 4].view(np.float32)[0]
+            assert abs(float(am) - float(np.abs(dB).max())) <= 1e-6 * float(np.abs(dB).max()) + 1e-30, 'stale max |dBias|'
         for h in range(H):
             np.add.at(dT, pair * ldT + h, dB[:, h, :].reshape(-1))
 
@@ -605,7 +608,13 @@ class Interp:
         dQ = (dS @ k) * scale
         dK = (dS.transpose(0, 1, 3, 2) @ q) * scale
         if int(o['r'][6]['buf']) >= 0:
-            self.fview(o['r'][6], B * H * N * N).reshape(B, H, N, N)[:] += dS.astype(np.float32)
+            db = self.fview(o['r'][6], B * H * N * N).reshape(B, H, N, N)
+            db[:] += dS.astype(np.float32)
+            if int(o['r'][5]['buf']) >= 0:               # r5: running max of |dBias| as written by this launch
+                am = self.fview(o['r'][5], 1)
+                am[0] = max(float(am[0]), float(np.abs(db).max()))
+        else:
+            assert int(o['r'][5]['buf']) < 0
         out = self.fview(o['r'][0], B * N * 3 * C).reshape(B, N, 3, H, d)
         out[:, :, 0] = dQ.transpose(0, 2, 1, 3)
         out[:, :, 1] = dK.transpose(0, 2, 1, 3)

@@ -31,8 +31,12 @@
 __device__ long long g_attn_stamps[64];
 #define ATT_STAMP(i) do { if (blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) \
     g_attn_stamps[stamp_base + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
+// (backward: the first row-role block -> slots 16.., the first column-role block -> slots 32..)
+#define ATT_BSTAMP(col, i) do { if ((int)blockIdx.x == ((col) ? NB : 0) && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) \
+    g_attn_stamps[((col) ? 32 : 16) + (i)] = (long long)__builtin_readcyclecounter(); } while (0)
 #else
 #define ATT_STAMP(i) do { } while (0)
+#define ATT_BSTAMP(col, i) do { } while (0)
 #endif
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -48,28 +52,68 @@ __device__ __forceinline__ f32x16 zero16() {
 // Row operand of the MFMA (lane = matrix row l31, k index = 2 s + lhi): x[s] = row[2 s + lhi] for 2 s + lhi < d.
 // vec: d % 4 == 0 and the row is 16-byte aligned -> d / 4 float4 loads (the two half-wave lanes of a row load the
 // same vectors and keep alternate elements).
+// Every load is UNCONDITIONAL (lanes without a row read `safe`, a row that always exists; offsets clamped into the row; the
+// value selected afterwards): a load inside an if-block is waited for at the end of that block (s_waitcnt vmcnt(0) at the
+// join), which turned the KS / 2 loads of a row into KS / 2 dependent round trips -- 12 of them in front of the first MFMA
+// of the attention backward.
 template <int KS>
-__device__ __forceinline__ void load_row_operand(const float* __restrict__ row, int d, int lhi, bool vec,
-                                                 float (&x)[KS]) {
+__device__ __forceinline__ void load_row_operand(const float* __restrict__ row, const float* __restrict__ safe, int d,
+                                                 int lhi, bool vec, float (&x)[KS]) {
+    const bool ok = row != nullptr;
+    const float* r = ok ? row : safe;
+    if (vec) {                                       // (d >= 4)
+        f32x4 f[KS / 2];
 #pragma unroll
-    for (int s = 0; s < KS; ++s) x[s] = 0.f;
-    if (row == nullptr) return;
-    if (vec) {
+        for (int c = 0; c < KS / 2; ++c) f[c] = *reinterpret_cast<const f32x4*>(r + min(4 * c, d - 4));
 #pragma unroll
         for (int c = 0; c < KS / 2; ++c) {
-            if (4 * c < d) {
-                const f32x4 f = *reinterpret_cast<const f32x4*>(row + 4 * c);
-                x[2 * c] = lhi ? f.y : f.x;
-                x[2 * c + 1] = lhi ? f.w : f.z;
-            }
+            const bool on = ok && 4 * c < d;
+            x[2 * c] = on ? (lhi ? f[c].y : f[c].x) : 0.f;
+            x[2 * c + 1] = on ? (lhi ? f[c].w : f[c].z) : 0.f;
         }
     } else {
+        float v[KS];
 #pragma unroll
-        for (int s = 0; s < KS; ++s) {
-            const int k = 2 * s + lhi;
-            if (k < d) x[s] = row[k];
+        for (int s = 0; s < KS; ++s) v[s] = r[min(2 * s + lhi, d - 1)];
+#pragma unroll
+        for (int s = 0; s < KS; ++s) x[s] = (ok && 2 * s + lhi < d) ? v[s] : 0.f;
+    }
+}
+
+// This lane's 16 values of a 32 x 32 fp32 tile (accumulator layout: register 4 g + c <-> column 8 g + 4 lhi + c of the row
+// `rowp` points into at the tile's first column j0; nullptr: no row, zeros).  Interior tiles (uniform: 16-byte rows, all 32
+// columns below N) load their four vectors unconditionally -- see load_row_operand -- from `safe` for lanes without a row.
+__device__ __forceinline__ f32x16 load_tile_row(const float* __restrict__ rowp, const float* __restrict__ safe, int j0, int N,
+                                                int lhi, bool pvec) {
+    f32x16 t = zero16();
+    if (pvec && j0 + 32 <= N) {
+        const bool ok = rowp != nullptr;
+        const float* r = ok ? rowp : safe;
+        f32x4 f[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) f[g] = *reinterpret_cast<const f32x4*>(r + 8 * g + 4 * lhi);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            t[4 * g] = ok ? f[g].x : 0.f; t[4 * g + 1] = ok ? f[g].y : 0.f;
+            t[4 * g + 2] = ok ? f[g].z : 0.f; t[4 * g + 3] = ok ? f[g].w : 0.f;
+        }
+        return t;
+    }
+    if (rowp) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int jj = 8 * g + 4 * lhi;
+            if (pvec && j0 + jj + 3 < N) {
+                const f32x4 f = *reinterpret_cast<const f32x4*>(rowp + jj);
+                t[4 * g] = f.x; t[4 * g + 1] = f.y; t[4 * g + 2] = f.z; t[4 * g + 3] = f.w;
+            } else {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (j0 + jj + c < N) t[4 * g + c] = rowp[jj + c];
+            }
         }
     }
+    return t;
 }
 
 // Column operand (lane = head column e = l31, MFMA step s <-> matrix row acc_row(s, lhi) of the 32-row tile that
@@ -81,6 +125,67 @@ __device__ __forceinline__ void load_col_operand(const float* __restrict__ X, in
         const int row = row0 + acc_row(s, lhi);
         x[s] = (e < d && row < n_rows) ? X[(size_t)row * stride + e] : 0.f;
     }
+}
+
+// Two-phase operand loads of the backward kernel: *_issue only issues the (unconditional, clamped) loads, *_finish applies
+// the validity selects.  A kernel issues the loads of ALL operands of a tile first and finishes them afterwards: the selects of
+// one operand in front of the loads of the next made every operand its own dependent round trip (stamps of tools/attn_probe:
+// 15k of the column role's 31k cycles went by before the first MFMA).
+template <int KS> struct RowRaw { f32x4 f[KS / 2]; float s[KS]; };
+template <int KS>
+__device__ __forceinline__ void row_issue(RowRaw<KS>& R, const float* __restrict__ r, int d, int lhi, bool vec) {
+    if (vec) {
+#pragma unroll
+        for (int c = 0; c < KS / 2; ++c) R.f[c] = *reinterpret_cast<const f32x4*>(r + min(4 * c, d - 4));
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) R.s[s] = r[min(2 * s + lhi, d - 1)];
+    }
+}
+template <int KS>
+__device__ __forceinline__ void row_finish(const RowRaw<KS>& R, bool ok, int d, int lhi, bool vec, float (&x)[KS]) {
+    if (vec) {
+#pragma unroll
+        for (int c = 0; c < KS / 2; ++c) {
+            const bool on = ok && 4 * c < d;
+            x[2 * c] = on ? (lhi ? R.f[c].y : R.f[c].x) : 0.f;
+            x[2 * c + 1] = on ? (lhi ? R.f[c].w : R.f[c].z) : 0.f;
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) x[s] = (ok && 2 * s + lhi < d) ? R.s[s] : 0.f;
+    }
+}
+struct ColRaw { float v[16]; };
+__device__ __forceinline__ void col_issue(ColRaw& R, const float* __restrict__ X, int row0, int n_rows, size_t stride, int e,
+                                          int d, int lhi) {
+    const int ec = min(e, d - 1);
+#pragma unroll
+    for (int s = 0; s < 16; ++s) R.v[s] = X[(size_t)min(row0 + acc_row(s, lhi), n_rows - 1) * stride + ec];
+}
+__device__ __forceinline__ void col_finish(const ColRaw& R, int row0, int n_rows, int e, int d, int lhi, float (&x)[16]) {
+#pragma unroll
+    for (int s = 0; s < 16; ++s) x[s] = (e < d && row0 + acc_row(s, lhi) < n_rows) ? R.v[s] : 0.f;
+}
+// (interior tiles only -- see load_tile_row; other tiles are loaded by tile_finish itself)
+struct TileRaw { f32x4 f[4]; };
+__device__ __forceinline__ void tile_issue(TileRaw& R, const float* __restrict__ r, int lhi, bool interior) {
+    if (interior) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) R.f[g] = *reinterpret_cast<const f32x4*>(r + 8 * g + 4 * lhi);
+    }
+}
+__device__ __forceinline__ f32x16 tile_finish(const TileRaw& R, const float* __restrict__ rowp, const float* __restrict__ safe,
+                                              bool interior, int j0, int N, int lhi, bool pvec) {
+    if (!interior) return load_tile_row(rowp, safe, j0, N, lhi, pvec);
+    const bool ok = rowp != nullptr;
+    f32x16 t;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        t[4 * g] = ok ? R.f[g].x : 0.f; t[4 * g + 1] = ok ? R.f[g].y : 0.f;
+        t[4 * g + 2] = ok ? R.f[g].z : 0.f; t[4 * g + 3] = ok ? R.f[g].w : 0.f;
+    }
+    return t;
 }
 
 // Cooperative, coalesced copy of the block's head slices into LDS: 32 query rows (from row i0), then `nkeys` key rows and
@@ -211,33 +316,29 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const flo
     float* Vs = Ks + nkeys * ldw;
     float qb[KS];
     float ka[TP][KS];
+    // edge bias of this lane's query row: register r <-> key tile * 32 + acc_row(r, lhi) (4 runs of 4 keys); the loads of
+    // interior tiles are issued in front of the staging loads (one round trip for both), see tile_issue
+    f32x16 S[TPW];
+    const bool pvec = (N & 3) == 0 && vec;
+    TileRaw bR[TPW];
+#pragma unroll
+    for (int k = 0; k < TPW; ++k) {
+        const int j0 = (w + NW * k) * 32;
+        if (bias && j0 < N)                          // (uniform)
+            tile_issue(bR[k], (qi < N ? bias + (bh + qi) * N : bias + bh * N) + j0, lhi, pvec && j0 + 32 <= N);
+    }
     if (PRE) {
         stage_head_slices<64 * NW>(stage, ldw, base, C, i0, nkeys, N, d, vq, tid);
     } else {
-        load_row_operand<KS>(qi < N ? base + (size_t)qi * 3 * C : nullptr, d, lhi, vq, qb);
+        load_row_operand<KS>(qi < N ? base + (size_t)qi * 3 * C : nullptr, base, d, lhi, vq, qb);
     }
-    // edge bias of this lane's query row: register r <-> key tile * 32 + acc_row(r, lhi) (4 runs of 4 keys)
-    f32x16 S[TPW];
-    const bool pvec = (N & 3) == 0 && vec;
 #pragma unroll
     for (int k = 0; k < TPW; ++k) {
         S[k] = zero16();
         const int j0 = (w + NW * k) * 32;
-        if (bias && qi < N && j0 < N) {
-            const float* brow = bias + (bh + qi) * N + j0;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const int jj = 8 * g + 4 * lhi;
-                if (pvec && j0 + jj + 3 < N) {
-                    const f32x4 f = *reinterpret_cast<const f32x4*>(brow + jj);
-                    S[k][4 * g] = f.x; S[k][4 * g + 1] = f.y; S[k][4 * g + 2] = f.z; S[k][4 * g + 3] = f.w;
-                } else {
-#pragma unroll
-                    for (int c = 0; c < 4; ++c)
-                        if (j0 + jj + c < N) S[k][4 * g + c] = brow[jj + c];
-                }
-            }
-        }
+        if (bias && j0 < N)                          // (uniform)
+            S[k] = tile_finish(bR[k], qi < N ? bias + (bh + qi) * N + j0 : nullptr, bias + bh * N + j0, pvec && j0 + 32 <= N,
+                               j0, N, lhi, pvec);
     }
     float va[TP][16];
     if (PRE) {
@@ -269,7 +370,7 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const flo
         const int j0 = (w + NW * k) * 32;
         if (!PRE) {
             const int j = j0 + l31;
-            load_row_operand<KS>(j < N ? base + (size_t)j * 3 * C + C : nullptr, d, lhi, vq, ka[0]);
+            load_row_operand<KS>(j < N ? base + (size_t)j * 3 * C + C : nullptr, base, d, lhi, vq, ka[0]);
         }
         f32x16 acc = mfma_rows<KS>(ka[PRE ? k : 0], qb, zero16());
 #pragma unroll
@@ -358,7 +459,7 @@ __device__ __forceinline__ f32x16 score_tile(const float* __restrict__ base, con
                                              int l31, int lhi, bool vq, float scale) {
     float ka[KS];
     const int j = j0 + l31;
-    load_row_operand<KS>(j < N ? base + (size_t)j * 3 * C + C : nullptr, d, lhi, vq, ka);
+    load_row_operand<KS>(j < N ? base + (size_t)j * 3 * C + C : nullptr, base, d, lhi, vq, ka);
     f32x16 acc = mfma_rows<KS>(ka, qb, zero16());
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -390,7 +491,7 @@ __global__ __launch_bounds__(256) void attn_fwd_stream_kernel(float* __restrict_
     const bool vq = (d & 3) == 0 && vec;
     const float* brow = (bias && qi < N) ? bias + (bh + qi) * N : nullptr;
     float qb[KS];
-    load_row_operand<KS>(qi < N ? base + (size_t)qi * 3 * C : nullptr, d, lhi, vq, qb);
+    load_row_operand<KS>(qi < N ? base + (size_t)qi * 3 * C : nullptr, base, d, lhi, vq, qb);
 
     float mx = -INFINITY, sum = 0.f;
     for (int t = w; t < NB; t += 4) {
@@ -474,45 +575,45 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_bwd_kernel(floa
     if ((int)blockIdx.x < NB) {
         // ---------------- row role: lane = query qi, accumulator registers = keys ----------------
         const int qi = blockIdx.x * 32 + l31;
+        ATT_BSTAMP(0, 0);
+        const bool qok = qi < N;
+        const float* prow0 = P + bh * N;                 // (row 0 of this head: a row that always exists)
+        RowRaw<KS> gbR, obR;
+        row_issue(gbR, qok ? dOb + (size_t)qi * C : dOb, d, lhi, vq);
+        row_issue(obR, qok ? Ob + (size_t)qi * C : Ob, d, lhi, vq);
         float gb[KS], ob[KS];
-        load_row_operand<KS>(qi < N ? dOb + (size_t)qi * C : nullptr, d, lhi, vq, gb);
-        load_row_operand<KS>(qi < N ? Ob + (size_t)qi * C : nullptr, d, lhi, vq, ob);
         float delta = 0.f;
-#pragma unroll
-        for (int s = 0; s < KS; ++s) delta += gb[s] * ob[s];
-        delta += __shfl_xor(delta, 32, 64);
+        bool first = true;
         f32x16 dQ = zero16();
         for (int t = w; t < NB; t += NW) {
             const int j0 = t * 32;
-            float va[KS];
             const int j = j0 + l31;
-            load_row_operand<KS>(j < N ? base + (size_t)j * 3 * C + 2 * C : nullptr, d, lhi, vq, va);
-            float kc[16];
-            load_col_operand(base + C, j0, N, (size_t)3 * C, l31, d, lhi, kc);
-            f32x16 p = zero16(), db = zero16();
-            if (qi < N) {
-                const float* prow = P + (bh + qi) * N + j0;
-                const float* brow = dBias ? dBias + (bh + qi) * N + j0 : nullptr;
+            const bool interior = pvec && j0 + 32 <= N;
+            // every load of the tile is in flight (the first tile's together with the dO / O rows) before anything is used
+            RowRaw<KS> vaR;
+            ColRaw kcR;
+            TileRaw pR, dbR;
+            row_issue(vaR, j < N ? base + (size_t)j * 3 * C + 2 * C : base, d, lhi, vq);
+            col_issue(kcR, base + C, j0, N, (size_t)3 * C, l31, d, lhi);
+            tile_issue(pR, (qok ? P + (bh + qi) * N : prow0) + j0, lhi, interior);
+            if (dBias) tile_issue(dbR, (qok ? dBias + (bh + qi) * N : dBias + bh * N) + j0, lhi, interior);
+            if (first) {
+                row_finish(gbR, qok, d, lhi, vq, gb);
+                row_finish(obR, qok, d, lhi, vq, ob);
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const int jj = 8 * g + 4 * lhi;
-                    if (pvec && j0 + jj + 3 < N) {
-                        const f32x4 f = *reinterpret_cast<const f32x4*>(prow + jj);
-                        p[4 * g] = f.x; p[4 * g + 1] = f.y; p[4 * g + 2] = f.z; p[4 * g + 3] = f.w;
-                        if (brow) {
-                            const f32x4 q = *reinterpret_cast<const f32x4*>(brow + jj);
-                            db[4 * g] = q.x; db[4 * g + 1] = q.y; db[4 * g + 2] = q.z; db[4 * g + 3] = q.w;
-                        }
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < 4; ++c)
-                            if (j0 + jj + c < N) {
-                                p[4 * g + c] = prow[jj + c];
-                                if (brow) db[4 * g + c] = brow[jj + c];
-                            }
-                    }
-                }
+                for (int s = 0; s < KS; ++s) delta += gb[s] * ob[s];
+                delta += __shfl_xor(delta, 32, 64);
+                first = false;
+                ATT_BSTAMP(0, 1);
             }
+            float va[KS], kc[16];
+            row_finish(vaR, j < N, d, lhi, vq, va);
+            col_finish(kcR, j0, N, l31, d, lhi, kc);
+            const f32x16 p = tile_finish(pR, qok ? P + (bh + qi) * N + j0 : nullptr, prow0 + j0, interior, j0, N, lhi, pvec);
+            f32x16 db = zero16();
+            if (dBias)                               // (uniform)
+                db = tile_finish(dbR, qok ? dBias + (bh + qi) * N + j0 : nullptr, dBias + bh * N + j0, interior, j0, N, lhi, pvec);
+            ATT_BSTAMP(0, 2);
             f32x16 ds = mfma_rows<KS>(va, gb, zero16());           // dP^T = V dO^T
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -538,34 +639,53 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_bwd_kernel(floa
                     }
                 }
             }
+            ATT_BSTAMP(0, 3);
             dQ = mfma_cols(kc, ds, dQ);                            // dQ^T += K^T dS^T
         }
+        ATT_BSTAMP(0, 4);
         if (amax_out) ghn3_atomic_amax(amax_out, bmx);        // (uniform branch: every lane of the wave takes part)
         f32x4 o = reduce_waves<NW>(red, dQ, w, lane);
+        ATT_BSTAMP(0, 5);
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] *= scale;
         if (w < 4 && qi < N) store4(dqkv + ((size_t)b * N + qi) * 3 * C + h * d, 8 * w + 4 * lhi, d, vq, o);
+        ATT_BSTAMP(0, 6);
     } else {
         // ---------------- column role: lane = key kj, accumulator registers = queries ----------------
         const int kj = (blockIdx.x - NB) * 32 + l31;
+        ATT_BSTAMP(1, 0);
+        const bool kok = kj < N;
+        RowRaw<KS> vbR;
+        row_issue(vbR, kok ? base + (size_t)kj * 3 * C + 2 * C : base, d, lhi, vq);
         float vb[KS];
-        load_row_operand<KS>(kj < N ? base + (size_t)kj * 3 * C + 2 * C : nullptr, d, lhi, vq, vb);
+        bool first = true;
         f32x16 dV = zero16(), dK = zero16();
         for (int t = w; t < NB; t += NW) {
             const int q0 = t * 32;
             const int qrow = q0 + l31;
-            float ga[KS], oa[KS];
-            load_row_operand<KS>(qrow < N ? dOb + (size_t)qrow * C : nullptr, d, lhi, vq, ga);
-            load_row_operand<KS>(qrow < N ? Ob + (size_t)qrow * C : nullptr, d, lhi, vq, oa);
-            float gc[16], qc[16];
-            load_col_operand(dOb, q0, N, (size_t)C, l31, d, lhi, gc);
-            load_col_operand(base, q0, N, (size_t)3 * C, l31, d, lhi, qc);
+            // every load of the tile in flight (the first tile's together with the V row) before anything is used
+            RowRaw<KS> gaR, oaR;
+            ColRaw gcR, qcR;
+            float pr[16];
+            row_issue(gaR, qrow < N ? dOb + (size_t)qrow * C : dOb, d, lhi, vq);
+            row_issue(oaR, qrow < N ? Ob + (size_t)qrow * C : Ob, d, lhi, vq);
+            col_issue(gcR, dOb, q0, N, (size_t)C, l31, d, lhi);
+            col_issue(qcR, base, q0, N, (size_t)3 * C, l31, d, lhi);
+            {
+                const float* pc = P + bh * N + min(kj, N - 1);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pr[r] = pc[(size_t)min(q0 + acc_row(r, lhi), N - 1) * N];
+            }
+            if (first) { row_finish(vbR, kok, d, lhi, vq, vb); first = false; }
+            float ga[KS], oa[KS], gc[16], qc[16];
+            row_finish(gaR, qrow < N, d, lhi, vq, ga);
+            row_finish(oaR, qrow < N, d, lhi, vq, oa);
+            col_finish(gcR, q0, N, l31, d, lhi, gc);
+            col_finish(qcR, q0, N, l31, d, lhi, qc);
             f32x16 p;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int i = q0 + acc_row(r, lhi);
-                p[r] = (i < N && kj < N) ? P[(bh + i) * N + kj] : 0.f;
-            }
+            for (int r = 0; r < 16; ++r) p[r] = (kok && q0 + acc_row(r, lhi) < N) ? pr[r] : 0.f;
+            ATT_BSTAMP(1, 1);
             float dpart = 0.f;
 #pragma unroll
             for (int s = 0; s < KS; ++s) dpart += ga[s] * oa[s];
@@ -573,6 +693,7 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_bwd_kernel(floa
             if (lhi == 0) dl[w][l31] = dpart;                      // wave-private hand-off: lane -> register index
             __builtin_amdgcn_wave_barrier();
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ATT_BSTAMP(1, 2);
             f32x16 ds = mfma_rows<KS>(ga, vb, zero16());           // dP = dO V^T   (rows = queries, lane = key)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -582,9 +703,11 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_bwd_kernel(floa
                 ds[r] = x;
             }
             __builtin_amdgcn_wave_barrier();
+            ATT_BSTAMP(1, 3);
             dV = mfma_cols(gc, p, dV);                             // dV^T += dO^T P
             dK = mfma_cols(qc, ds, dK);                            // dK^T += Q^T dS
         }
+        ATT_BSTAMP(1, 4);
         const f32x4 ov = reduce_waves<NW>(red, dV, w, lane);
         __syncthreads();                                      // (one exchange buffer for both reductions)
         f32x4 ok = reduce_waves<NW>(red, dK, w, lane);
@@ -594,6 +717,225 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_bwd_kernel(floa
             float* row = dqkv + ((size_t)b * N + kj) * 3 * C + h * d;
             store4(row + 2 * C, 8 * w + 4 * lhi, d, vq, ov);
             store4(row + C, 8 * w + 4 * lhi, d, vq, ok);
+        }
+        ATT_BSTAMP(1, 5);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// backward for graphs of up to 256 nodes (one tile of the other dimension per wave, eight waves), operands STAGED IN LDS.
+// The kernel above loads MFMA operands "lane = matrix row": every wave-level load touches 32 different cache lines, ~1300 line
+// requests per wave and tile -- tools/attn_probe: 19k of the row role's 29k cycles pass before the first MFMA, whatever the
+// order of the loads.  Here the workgroup copies the head slices it needs (row role: its 32 dO / O rows and all V / K rows;
+// column role: its 32 V rows and all dO / O / Q rows) with coalesced 16-byte loads -- consecutive lanes read consecutive
+// chunks of a row, every load in flight before the first LDS write, the P / dBias tile loads in front of them -- and reads the
+// operands from LDS.  Same MFMAs, same summation order: bit-identical to the kernel above.
+// ------------------------------------------------------------------------------------------------
+template <int NT, int G, typename F>
+__device__ __forceinline__ void stage_rows(float* __restrict__ dst, int ldw, int rows, int chunks, int tid, F source) {
+    const int rpp = NT / chunks;                     // rows per pass
+    const int r0 = tid / chunks, c = tid - r0 * chunks;
+    const bool lane_on = r0 < rpp;
+    f32x4 v[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int r = g * rpp + r0;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        v[g] = z;
+        if (lane_on && r < rows) {
+            const float* p = source(r);
+            if (p) v[g] = *reinterpret_cast<const f32x4*>(p + 4 * c);
+        }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int r = g * rpp + r0;
+        if (lane_on && r < rows) *reinterpret_cast<f32x4*>(dst + r * ldw + 4 * c) = v[g];
+    }
+}
+
+template <int KS>
+__global__ __launch_bounds__(512, 1) void attn_bwd_staged_kernel(float* __restrict__ dqkv, const float* __restrict__ dO,
+                                                                 const float* __restrict__ qkv, const float* __restrict__ P,
+                                                                 const float* __restrict__ Oin, float* __restrict__ dBias,
+                                                                 const int* __restrict__ n_nodes, int N, int C, int H,
+                                                                 float scale, int vec, float* __restrict__ amax_out) {
+    constexpr int NW = 8;
+    constexpr int G = 13;                            // >= ceil((32 + 3 * 256) / (512 / 8)) passes at d = 32
+    extern __shared__ float bsm[];
+    float* red = bsm;                                // [NW][16][64]
+    float* dl = red + NW * 16 * 64;                  // [NW][32]
+    float* stage = dl + NW * 32;
+    float bmx = 0.f;
+    const int d = C / H;                             // (d % 4 == 0, 16-byte aligned rows: checked by the host)
+    const int NB = (N + 31) >> 5, Np = NB * 32;      // (NB <= 8)
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, l31 = lane & 31, lhi = lane >> 5;
+    const int nb = n_nodes[b];
+    const float* base = qkv + (size_t)b * N * 3 * C + h * d;
+    const float* dOb = dO + (size_t)b * N * C + h * d;
+    const float* Ob = Oin + (size_t)b * N * C + h * d;
+    const size_t bh = ((size_t)b * H + h) * N;
+    const bool pvec = (N & 3) == 0 && vec;
+    const int ldw = d + 4, chunks = d >> 2;
+    const size_t s3 = (size_t)3 * C;
+    const bool has = w < NB;                         // this wave's tile of the other dimension
+    const int t0 = w * 32;
+
+    if ((int)blockIdx.x < NB) {
+        // ---------------- row role: lane = query qi, accumulator registers = keys ----------------
+        const int i0 = blockIdx.x * 32, qi = i0 + l31;
+        const bool qok = qi < N;
+        const int j0 = t0;
+        const bool interior = pvec && j0 + 32 <= N;
+        const float* prow0 = P + bh * N;
+        TileRaw pR, dbR;
+        if (has) {
+            tile_issue(pR, (qok ? P + (bh + qi) * N : prow0) + j0, lhi, interior);
+            if (dBias) tile_issue(dbR, (qok ? dBias + (bh + qi) * N : dBias + bh * N) + j0, lhi, interior);
+        }
+        // LDS rows: [0, 32) dO, [32, 64) O of the block's queries; [64, 64 + Np) V, [64 + Np, 64 + 2 Np) K of all keys
+        stage_rows<64 * NW, G>(stage, ldw, 64 + 2 * Np, chunks, tid, [&](int r) -> const float* {
+            if (r < 32) return i0 + r < N ? dOb + (size_t)(i0 + r) * C : nullptr;
+            if (r < 64) return i0 + r - 32 < N ? Ob + (size_t)(i0 + r - 32) * C : nullptr;
+            r -= 64;
+            if (r < Np) return r < N ? base + (size_t)r * s3 + 2 * C : nullptr;
+            r -= Np;
+            return r < N ? base + (size_t)r * s3 + C : nullptr;
+        });
+        __syncthreads();
+        const float* dOs = stage;
+        const float* Os = stage + 32 * ldw;
+        const float* Vs = stage + 64 * ldw;
+        const float* Ks = Vs + Np * ldw;
+        float gb[KS], ob[KS];
+        float delta = 0.f;
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int kx = 2 * s + lhi;
+            gb[s] = kx < d ? dOs[l31 * ldw + kx] : 0.f;
+            ob[s] = kx < d ? Os[l31 * ldw + kx] : 0.f;
+            delta += gb[s] * ob[s];
+        }
+        delta += __shfl_xor(delta, 32, 64);
+        f32x16 dQ = zero16();
+        if (has) {
+            float va[KS], kc[16];
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int kx = 2 * s + lhi;
+                va[s] = kx < d ? Vs[(j0 + l31) * ldw + kx] : 0.f;
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) kc[s] = l31 < d ? Ks[(j0 + acc_row(s, lhi)) * ldw + l31] : 0.f;
+            const f32x16 p = tile_finish(pR, qok ? P + (bh + qi) * N + j0 : nullptr, prow0 + j0, interior, j0, N, lhi, pvec);
+            f32x16 db = zero16();
+            if (dBias)
+                db = tile_finish(dbR, qok ? dBias + (bh + qi) * N + j0 : nullptr, dBias + bh * N + j0, interior, j0, N, lhi, pvec);
+            f32x16 ds = mfma_rows<KS>(va, gb, zero16());           // dP^T = V dO^T
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int jr = j0 + acc_row(r, lhi);
+                float x = p[r] * (ds[r] - delta);
+                if (!(qi < nb && jr < nb)) x = 0.f;               // masked_fill blocks the gradient
+                ds[r] = x;
+            }
+            if (dBias && qok) {
+                float* brow = dBias + (bh + qi) * N + j0;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int jj = 8 * g + 4 * lhi;
+                    if (pvec && j0 + jj + 3 < N) {
+                        f32x4 f = {db[4 * g] + ds[4 * g], db[4 * g + 1] + ds[4 * g + 1], db[4 * g + 2] + ds[4 * g + 2],
+                                   db[4 * g + 3] + ds[4 * g + 3]};
+                        *reinterpret_cast<f32x4*>(brow + jj) = f;
+                        bmx = fmaxf(fmaxf(bmx, fmaxf(fabsf(f.x), fabsf(f.y))), fmaxf(fabsf(f.z), fabsf(f.w)));
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            if (j0 + jj + c < N) { const float f = db[4 * g + c] + ds[4 * g + c]; brow[jj + c] = f; bmx = fmaxf(bmx, fabsf(f)); }
+                    }
+                }
+            }
+            dQ = mfma_cols(kc, ds, dQ);                            // dQ^T += K^T dS^T
+        }
+        if (amax_out) ghn3_atomic_amax(amax_out, bmx);
+        f32x4 o = reduce_waves<NW>(red, dQ, w, lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) o[c] *= scale;
+        if (w < 4 && qok) store4(dqkv + ((size_t)b * N + qi) * 3 * C + h * d, 8 * w + 4 * lhi, d, true, o);
+    } else {
+        // ---------------- column role: lane = key kj, accumulator registers = queries ----------------
+        const int k0 = (blockIdx.x - NB) * 32, kj = k0 + l31;
+        const bool kok = kj < N;
+        const int q0 = t0;
+        float pr[16];
+        if (has) {
+            const float* pc = P + bh * N + min(kj, N - 1);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) pr[r] = pc[(size_t)min(q0 + acc_row(r, lhi), N - 1) * N];
+        }
+        // LDS rows: [0, 32) V of the block's keys; [32, 32 + Np) dO, then O, then Q of all queries
+        stage_rows<64 * NW, G>(stage, ldw, 32 + 3 * Np, chunks, tid, [&](int r) -> const float* {
+            if (r < 32) return k0 + r < N ? base + (size_t)(k0 + r) * s3 + 2 * C : nullptr;
+            r -= 32;
+            if (r < Np) return r < N ? dOb + (size_t)r * C : nullptr;
+            r -= Np;
+            if (r < Np) return r < N ? Ob + (size_t)r * C : nullptr;
+            r -= Np;
+            return r < N ? base + (size_t)r * s3 : nullptr;
+        });
+        __syncthreads();
+        const float* Vs = stage;
+        const float* dOs = stage + 32 * ldw;
+        const float* Os = dOs + Np * ldw;
+        const float* Qs = Os + Np * ldw;
+        f32x16 dV = zero16(), dK = zero16();
+        if (has) {
+            float vb[KS], ga[KS], oa[KS], gc[16], qc[16];
+            float dpart = 0.f;
+#pragma unroll
+            for (int s = 0; s < KS; ++s) {
+                const int kx = 2 * s + lhi;
+                vb[s] = kx < d ? Vs[l31 * ldw + kx] : 0.f;
+                ga[s] = kx < d ? dOs[(q0 + l31) * ldw + kx] : 0.f;
+                oa[s] = kx < d ? Os[(q0 + l31) * ldw + kx] : 0.f;
+                dpart += ga[s] * oa[s];
+            }
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                const int row = q0 + acc_row(s, lhi);
+                gc[s] = l31 < d ? dOs[row * ldw + l31] : 0.f;
+                qc[s] = l31 < d ? Qs[row * ldw + l31] : 0.f;
+            }
+            f32x16 p;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) p[r] = (kok && q0 + acc_row(r, lhi) < N) ? pr[r] : 0.f;
+            dpart += __shfl_xor(dpart, 32, 64);
+            if (lhi == 0) dl[w * 32 + l31] = dpart;                // wave-private hand-off: lane -> register index
+            __builtin_amdgcn_wave_barrier();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            f32x16 ds = mfma_rows<KS>(ga, vb, zero16());           // dP = dO V^T   (rows = queries, lane = key)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int ir = acc_row(r, lhi);
+                float x = p[r] * (ds[r] - dl[w * 32 + ir]);
+                if (!(q0 + ir < nb && kj < nb)) x = 0.f;
+                ds[r] = x;
+            }
+            __builtin_amdgcn_wave_barrier();
+            dV = mfma_cols(gc, p, dV);                             // dV^T += dO^T P
+            dK = mfma_cols(qc, ds, dK);                            // dK^T += Q^T dS
+        }
+        const f32x4 ov = reduce_waves<NW>(red, dV, w, lane);
+        __syncthreads();                                      // (one exchange buffer for both reductions)
+        f32x4 okk = reduce_waves<NW>(red, dK, w, lane);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) okk[c] *= scale;
+        if (w < 4 && kok) {
+            float* row = dqkv + ((size_t)b * N + kj) * 3 * C + h * d;
+            store4(row + 2 * C, 8 * w + 4 * lhi, d, true, ov);
+            store4(row + C, 8 * w + 4 * lhi, d, true, okk);
         }
     }
 }
@@ -618,6 +960,7 @@ static attn_fwd_fn pick_fwd(int d, int tpw) {
     return fwd_for<16>(tpw);
 }
 static int g_attn_bwd_waves = 8;
+static int g_attn_bwd_staged = 1;                    // GHN3_ATTN_BWD_STAGED=0: operands straight from memory (round 3)
 template <int NW> static attn_bwd_fn pick_bwd_nw(int d) {
     if (d <= 4) return attn_bwd_kernel<2, NW>;
     if (d <= 8) return attn_bwd_kernel<4, NW>;
@@ -634,6 +977,7 @@ static attn_bwd_fn pick_bwd(int d, int N, int* nw) {
 int ghn3_attn_init() {
     if (getenv("GHN3_ATTN_FWD_WAVES")) g_attn_fwd_waves = atoi(getenv("GHN3_ATTN_FWD_WAVES")) == 4 ? 4 : 8;
     if (getenv("GHN3_ATTN_BWD_WAVES")) g_attn_bwd_waves = atoi(getenv("GHN3_ATTN_BWD_WAVES")) == 4 ? 4 : 8;
+    if (getenv("GHN3_ATTN_BWD_STAGED")) g_attn_bwd_staged = atoi(getenv("GHN3_ATTN_BWD_STAGED")) != 0;
     return GHN3_OK;
 }
 
@@ -683,7 +1027,16 @@ int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P
                     aligned16(O) && aligned16(dBias);
     int nw = 4;
     attn_bwd_fn fn = pick_bwd(d, N, &nw);
-    hipLaunchKernelGGL(fn, dim3(2 * nb, H, B), dim3(64 * nw), 0, s, dqkv, dO, qkv, P, O, dBias, n_nodes, N, C, H,
+    size_t lds = 0;
+    if (nw == 8 && vec && (d & 3) == 0 && g_attn_bwd_staged) {
+        // operands staged in LDS: exchange buffers + (32 + 3 * 32 * nb) rows of d + 4 floats (123 KB at d = 24, N = 256)
+        fn = d <= 4 ? attn_bwd_staged_kernel<2> : d <= 8 ? attn_bwd_staged_kernel<4> : d <= 16 ? attn_bwd_staged_kernel<8>
+             : d <= 24 ? attn_bwd_staged_kernel<12> : attn_bwd_staged_kernel<16>;
+        lds = (size_t)(8 * 16 * 64 + 8 * 32 + (32 + 3 * 32 * nb) * (d + 4)) * sizeof(float);
+        hipError_t ea = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (ea != hipSuccess) { ghn3_set_error("attn bwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(ea)); return GHN3_E_HIP; }
+    }
+    hipLaunchKernelGGL(fn, dim3(2 * nb, H, B), dim3(64 * nw), lds, s, dqkv, dO, qkv, P, O, dBias, n_nodes, N, C, H,
                        scale, vec, amax_out);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("attn bwd launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }

@@ -915,6 +915,24 @@ int ghn3_tile_fwd(float* flat, const float* const* srcs, const ghn3_tile_desc* d
 // Fused predicted-parameter-norm loss (trainer.py:97-98,288-294): with `norms` the upstream gradient of element e of the
 // descriptor's tensor t is  dflat[e] + (g / norm_t) out[e]  (dflat optional) -- the norm term's gradient is formed from the
 // predicted values themselves instead of being materialised by a pass over the 346 MB output.
+// acc[u] += p[b0 + 1024 u .. + 3] (elements below lim), u < U.
+// (Measured, round 4: issuing the U loads unconditionally and together -- as compiled here every load sits in its own
+// if-block and is waited for there -- costs 36 more VGPRs, occupancy 7 -> 4 waves per SIMD, and the kernel went from 0.195 to
+// 0.239 ms: this pass lives on the number of blocks in flight, not on the round trips of one block.)
+template <int U>
+__device__ __forceinline__ void tile_bwd_gather(const float* __restrict__ p, int b0, int lim, f4u (&acc)[U]) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int j = b0 + 1024 * u;
+        if (j + 4 <= lim) {
+            acc[u] += *reinterpret_cast<const f4u*>(p + j);
+        } else {
+            if (j < lim) acc[u].x += p[j];
+            if (j + 1 < lim) acc[u].y += p[j + 1];
+            if (j + 2 < lim) acc[u].z += p[j + 2];
+        }
+    }
+}
 struct NormLoss { const float* out; const float* norms; const int* desc_seg; const float* g; };
 // Direct 16-bit gradient tiles (fused norm loss only, no dflat): the gradient of source buffer 0 -- the decoder tiles, whose
 // only consumers are the 16-bit W2 dgrad / wgrad GEMMs -- is written ONCE, as the scaled f16 / bf16 operand copy, instead of as
@@ -993,34 +1011,8 @@ __global__ __launch_bounds__(256) void tile_bwd_kernel(const float* __restrict__
                     for (int r0 = 0; r0 + i0 < T1; r0 += E1) {              // replicas along i
                         const int lim = min(nl, T1 - r0 - i0) * hw;          // a last partial replica covers fewer i
                         const int64_t go = ((int64_t)t0 * T1 + r0 + i0) * hw;
-                        if (g) {
-                            const float* gr = g + go;
-#pragma unroll
-                            for (int u = 0; u < U; ++u) {
-                                const int j = b0 + 1024 * u;
-                                if (j + 4 <= lim) {
-                                    acc[u] += *reinterpret_cast<const f4u*>(gr + j);
-                                } else {
-                                    if (j < lim) acc[u].x += gr[j];
-                                    if (j + 1 < lim) acc[u].y += gr[j + 1];
-                                    if (j + 2 < lim) acc[u].z += gr[j + 2];
-                                }
-                            }
-                        }
-                        if (outp) {
-                            const float* pr = outp + go;
-#pragma unroll
-                            for (int u = 0; u < U; ++u) {
-                                const int j = b0 + 1024 * u;
-                                if (j + 4 <= lim) {
-                                    acc2[u] += *reinterpret_cast<const f4u*>(pr + j);
-                                } else {
-                                    if (j < lim) acc2[u].x += pr[j];
-                                    if (j + 1 < lim) acc2[u].y += pr[j + 1];
-                                    if (j + 2 < lim) acc2[u].z += pr[j + 2];
-                                }
-                            }
-                        }
+                        if (g) tile_bwd_gather<U>(g + go, b0, lim, acc);
+                        if (outp) tile_bwd_gather<U>(outp + go, b0, lim, acc2);
                     }
                 if (outp) {
 #pragma unroll

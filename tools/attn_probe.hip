@@ -53,6 +53,31 @@ int main() {
             }
         }
     }
+    {   // backward: phase stamps of the first row-role and the first column-role workgroup
+        float *dO, *dqkv, *dB;
+        hipMalloc(&dO, sizeof(float) * B * N * C); hipMalloc(&dqkv, sizeof(float) * B * N * 3 * C); hipMalloc(&dB, sizeof(float) * B * H * N * N);
+        hipMemcpy(dO, h.data(), sizeof(float) * B * N * C, hipMemcpyHostToDevice);
+        hipMemset(dB, 0, sizeof(float) * B * H * N * N);
+        const char* rn[] = {"start -> dO / O rows landed + delta", "V / K / P / dBias tile loads landed", "dP = V dO^T + dS + dBias store issued",
+                            "dQ^T += K^T dS^T", "amax + wave reduction (LDS)", "store"};
+        const char* cn[] = {"start -> V row + dO / O / Q operands + P landed", "delta partial + LDS hand-off", "dP + dS",
+                            "dV, dK MFMAs", "two wave reductions + stores"};
+        for (int rep = 0; rep < 4; ++rep) {
+            ghn3_attn_bwd(dqkv, dO, qkv, P, out, nullptr, dB, nn, B, N, C, H, 0);
+            hipDeviceSynchronize();
+            long long st[64];
+            hipMemcpyFromSymbol(st, HIP_SYMBOL(g_attn_stamps), sizeof(st));
+            printf("bwd rep %d: row role %lld cycles, column role %lld cycles\n", rep, st[22] - st[16], st[37] - st[32]);
+            for (int i = 0; i < 6; ++i) printf("   row  %-58s %8lld\n", rn[i], st[17 + i] - st[16 + i]);
+            for (int i = 0; i < 5; ++i) printf("   col  %-58s %8lld\n", cn[i], st[33 + i] - st[32 + i]);
+        }
+        hipEvent_t a, b_; hipEventCreate(&a); hipEventCreate(&b_);
+        hipEventRecord(a, 0);
+        for (int i = 0; i < 200; ++i) ghn3_attn_bwd(dqkv, dO, qkv, P, out, nullptr, dB, nn, B, N, C, H, 0);
+        hipEventRecord(b_, 0); hipEventSynchronize(b_);
+        float msb; hipEventElapsedTime(&msb, a, b_);
+        printf("bwd: %.2f us per launch (200 back to back, instrumented build)\n", msb * 5.0f);
+    }
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
     for (int i = 0; i < 200; ++i) ghn3_attn_fwd(out, qkv, bias, P, nn, B, N, C, H, 0);

@@ -193,41 +193,60 @@ __device__ __forceinline__ f32x16 tile_finish(const TileRaw& R, const float* __r
 // (consecutive lanes read consecutive chunks of a row, then the next row: 96-byte runs at d = 24 instead of one cache
 // line per lane), and EVERY load is issued before the first LDS write: one memory round trip for the whole prologue
 // (copying in batches measured one dependent round trip per batch: 6.5k of the kernel's 20k cycles).
-template <int NT>
+// (Segment by segment, RPP = NT / 8 rows per pass -- at most 8 chunks per row: d <= 32 --, one pointer per thread advanced by a
+// constant per pass: the former single loop over a virtual row index paid a branch chain, a 64-bit multiply and an integer
+// division per load; its address arithmetic was most of the 6.7k cycles the forward spent in front of its first MFMA.)
+template <int PASSES> struct SegRaw { f32x4 v[PASSES]; };
+template <int PASSES, int RPP>
+__device__ __forceinline__ void seg_issue(SegRaw<PASSES>& R, const float* __restrict__ src, size_t stride, int first, int n_rows,
+                                          int N, int r0, int c4, bool on) {
+    const float* p = src + (size_t)(first + r0) * stride + c4;
+    const size_t step = (size_t)RPP * stride;
+#pragma unroll
+    for (int g = 0; g < PASSES; ++g) {
+        const int row = g * RPP + r0;
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        R.v[g] = z;
+        if (on && row < n_rows && first + row < N) R.v[g] = *reinterpret_cast<const f32x4*>(p);
+        p += step;
+    }
+}
+template <int PASSES, int RPP>
+__device__ __forceinline__ void seg_write(const SegRaw<PASSES>& R, float* __restrict__ dst, int ldw, int n_rows, int r0, int c4,
+                                          bool on) {
+#pragma unroll
+    for (int g = 0; g < PASSES; ++g) {
+        const int row = g * RPP + r0;
+        if (on && row < n_rows) *reinterpret_cast<f32x4*>(dst + row * ldw + c4) = R.v[g];
+    }
+}
+
+template <int NT, int MAXK>
 __device__ __forceinline__ void stage_head_slices(float* __restrict__ dst, int ldw, const float* __restrict__ base,
                                                   int C, int i0, int nkeys, int N, int d, bool vec, int tid) {
     const size_t stride = (size_t)3 * C;
-    const int rows = 32 + 2 * nkeys;
-    auto source = [&](int r) -> const float* {      // nullptr: zero row
-        if (r < 32) return i0 + r < N ? base + (size_t)(i0 + r) * stride : nullptr;
-        r -= 32;
-        if (r < nkeys) return r < N ? base + (size_t)r * stride + C : nullptr;
-        r -= nkeys;
-        return r < N ? base + (size_t)r * stride + 2 * C : nullptr;
-    };
     if (vec) {
+        constexpr int RPP = NT / 8;
         const int chunks = d >> 2;
-        const int rpp = NT / chunks;                 // rows per pass
-        const int r0 = tid / chunks, c = tid - r0 * chunks;
-        const bool lane_on = r0 < rpp;
-        constexpr int G = NT == 256 ? 18 : 9;        // >= ceil(544 / (NT / 8)) passes at d = 32
-        f32x4 v[G];
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int r = g * rpp + r0;
-            const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-            v[g] = z;
-            if (lane_on && r < rows) {
-                const float* p = source(r);
-                if (p) v[g] = *reinterpret_cast<const f32x4*>(p + 4 * c);
-            }
-        }
-#pragma unroll
-        for (int g = 0; g < G; ++g) {
-            const int r = g * rpp + r0;
-            if (lane_on && r < rows) *reinterpret_cast<f32x4*>(dst + r * ldw + 4 * c) = v[g];
-        }
+        const int r0 = tid / chunks, c4 = 4 * (tid - r0 * chunks);
+        const bool on = r0 < RPP;
+        SegRaw<(32 + RPP - 1) / RPP> q;
+        SegRaw<(MAXK + RPP - 1) / RPP> k, v;
+        seg_issue<(32 + RPP - 1) / RPP, RPP>(q, base, stride, i0, 32, N, r0, c4, on);
+        seg_issue<(MAXK + RPP - 1) / RPP, RPP>(k, base + C, stride, 0, nkeys, N, r0, c4, on);
+        seg_issue<(MAXK + RPP - 1) / RPP, RPP>(v, base + 2 * C, stride, 0, nkeys, N, r0, c4, on);
+        seg_write<(32 + RPP - 1) / RPP, RPP>(q, dst, ldw, 32, r0, c4, on);
+        seg_write<(MAXK + RPP - 1) / RPP, RPP>(k, dst + 32 * ldw, ldw, nkeys, r0, c4, on);
+        seg_write<(MAXK + RPP - 1) / RPP, RPP>(v, dst + (32 + nkeys) * ldw, ldw, nkeys, r0, c4, on);
     } else {
+        const int rows = 32 + 2 * nkeys;
+        auto source = [&](int r) -> const float* {      // nullptr: zero row
+            if (r < 32) return i0 + r < N ? base + (size_t)(i0 + r) * stride : nullptr;
+            r -= 32;
+            if (r < nkeys) return r < N ? base + (size_t)r * stride + C : nullptr;
+            r -= nkeys;
+            return r < N ? base + (size_t)r * stride + 2 * C : nullptr;
+        };
         for (int f = tid; f < rows * d; f += NT) {
             const int r = f / d, e = f - r * d;
             const float* p = source(r);
@@ -328,7 +347,7 @@ __device__ __forceinline__ void attn_fwd_body(float* __restrict__ out, const flo
             tile_issue(bR[k], (qi < N ? bias + (bh + qi) * N : bias + bh * N) + j0, lhi, pvec && j0 + 32 <= N);
     }
     if (PRE) {
-        stage_head_slices<64 * NW>(stage, ldw, base, C, i0, nkeys, N, d, vq, tid);
+        stage_head_slices<64 * NW, TPW * NW * 32>(stage, ldw, base, C, i0, nkeys, N, d, vq, tid);
     } else {
         load_row_operand<KS>(qi < N ? base + (size_t)qi * 3 * C : nullptr, base, d, lhi, vq, qb);
     }
@@ -731,37 +750,13 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_bwd_kernel(floa
 // chunks of a row, every load in flight before the first LDS write, the P / dBias tile loads in front of them -- and reads the
 // operands from LDS.  Same MFMAs, same summation order: bit-identical to the kernel above.
 // ------------------------------------------------------------------------------------------------
-template <int NT, int G, typename F>
-__device__ __forceinline__ void stage_rows(float* __restrict__ dst, int ldw, int rows, int chunks, int tid, F source) {
-    const int rpp = NT / chunks;                     // rows per pass
-    const int r0 = tid / chunks, c = tid - r0 * chunks;
-    const bool lane_on = r0 < rpp;
-    f32x4 v[G];
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int r = g * rpp + r0;
-        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        v[g] = z;
-        if (lane_on && r < rows) {
-            const float* p = source(r);
-            if (p) v[g] = *reinterpret_cast<const f32x4*>(p + 4 * c);
-        }
-    }
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int r = g * rpp + r0;
-        if (lane_on && r < rows) *reinterpret_cast<f32x4*>(dst + r * ldw + 4 * c) = v[g];
-    }
-}
-
 template <int KS>
 __global__ __launch_bounds__(512, 1) void attn_bwd_staged_kernel(float* __restrict__ dqkv, const float* __restrict__ dO,
                                                                  const float* __restrict__ qkv, const float* __restrict__ P,
                                                                  const float* __restrict__ Oin, float* __restrict__ dBias,
                                                                  const int* __restrict__ n_nodes, int N, int C, int H,
                                                                  float scale, int vec, float* __restrict__ amax_out) {
-    constexpr int NW = 8;
-    constexpr int G = 13;                            // >= ceil((32 + 3 * 256) / (512 / 8)) passes at d = 32
+    constexpr int NW = 8, RPP = 64;                  // (64 rows per staging pass: 8 chunks of 16 bytes per row at most)
     extern __shared__ float bsm[];
     float* red = bsm;                                // [NW][16][64]
     float* dl = red + NW * 16 * 64;                  // [NW][32]
@@ -781,6 +776,8 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_staged_kernel(float* __restri
     const size_t s3 = (size_t)3 * C;
     const bool has = w < NB;                         // this wave's tile of the other dimension
     const int t0 = w * 32;
+    const int sr0 = tid / chunks, sc4 = 4 * (tid - sr0 * chunks);      // staging: row within a pass, chunk of the row
+    const bool son = sr0 < RPP;
 
     if ((int)blockIdx.x < NB) {
         // ---------------- row role: lane = query qi, accumulator registers = keys ----------------
@@ -795,14 +792,18 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_staged_kernel(float* __restri
             if (dBias) tile_issue(dbR, (qok ? dBias + (bh + qi) * N : dBias + bh * N) + j0, lhi, interior);
         }
         // LDS rows: [0, 32) dO, [32, 64) O of the block's queries; [64, 64 + Np) V, [64 + Np, 64 + 2 Np) K of all keys
-        stage_rows<64 * NW, G>(stage, ldw, 64 + 2 * Np, chunks, tid, [&](int r) -> const float* {
-            if (r < 32) return i0 + r < N ? dOb + (size_t)(i0 + r) * C : nullptr;
-            if (r < 64) return i0 + r - 32 < N ? Ob + (size_t)(i0 + r - 32) * C : nullptr;
-            r -= 64;
-            if (r < Np) return r < N ? base + (size_t)r * s3 + 2 * C : nullptr;
-            r -= Np;
-            return r < N ? base + (size_t)r * s3 + C : nullptr;
-        });
+        {
+            SegRaw<1> a, o_;
+            SegRaw<4> v_, k_;
+            seg_issue<1, RPP>(a, dOb, (size_t)C, i0, 32, N, sr0, sc4, son);
+            seg_issue<1, RPP>(o_, Ob, (size_t)C, i0, 32, N, sr0, sc4, son);
+            seg_issue<4, RPP>(v_, base + 2 * C, s3, 0, Np, N, sr0, sc4, son);
+            seg_issue<4, RPP>(k_, base + C, s3, 0, Np, N, sr0, sc4, son);
+            seg_write<1, RPP>(a, stage, ldw, 32, sr0, sc4, son);
+            seg_write<1, RPP>(o_, stage + 32 * ldw, ldw, 32, sr0, sc4, son);
+            seg_write<4, RPP>(v_, stage + 64 * ldw, ldw, Np, sr0, sc4, son);
+            seg_write<4, RPP>(k_, stage + (64 + Np) * ldw, ldw, Np, sr0, sc4, son);
+        }
         __syncthreads();
         const float* dOs = stage;
         const float* Os = stage + 32 * ldw;
@@ -876,15 +877,18 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_staged_kernel(float* __restri
             for (int r = 0; r < 16; ++r) pr[r] = pc[(size_t)min(q0 + acc_row(r, lhi), N - 1) * N];
         }
         // LDS rows: [0, 32) V of the block's keys; [32, 32 + Np) dO, then O, then Q of all queries
-        stage_rows<64 * NW, G>(stage, ldw, 32 + 3 * Np, chunks, tid, [&](int r) -> const float* {
-            if (r < 32) return k0 + r < N ? base + (size_t)(k0 + r) * s3 + 2 * C : nullptr;
-            r -= 32;
-            if (r < Np) return r < N ? dOb + (size_t)r * C : nullptr;
-            r -= Np;
-            if (r < Np) return r < N ? Ob + (size_t)r * C : nullptr;
-            r -= Np;
-            return r < N ? base + (size_t)r * s3 : nullptr;
-        });
+        {
+            SegRaw<1> v_;
+            SegRaw<4> a, o_, q_;
+            seg_issue<1, RPP>(v_, base + 2 * C, s3, k0, 32, N, sr0, sc4, son);
+            seg_issue<4, RPP>(a, dOb, (size_t)C, 0, Np, N, sr0, sc4, son);
+            seg_issue<4, RPP>(o_, Ob, (size_t)C, 0, Np, N, sr0, sc4, son);
+            seg_issue<4, RPP>(q_, base, s3, 0, Np, N, sr0, sc4, son);
+            seg_write<1, RPP>(v_, stage, ldw, 32, sr0, sc4, son);
+            seg_write<4, RPP>(a, stage + 32 * ldw, ldw, Np, sr0, sc4, son);
+            seg_write<4, RPP>(o_, stage + (32 + Np) * ldw, ldw, Np, sr0, sc4, son);
+            seg_write<4, RPP>(q_, stage + (32 + 2 * Np) * ldw, ldw, Np, sr0, sc4, son);
+        }
         __syncthreads();
         const float* Vs = stage;
         const float* dOs = stage + 32 * ldw;

@@ -208,11 +208,12 @@ def main():
         for var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS', 'OPENBLAS_NUM_THREADS'):
             os.environ.setdefault(var, '1')              # (inherited by the workers: the host half of the compile is
             #                                              single-threaded numpy; 4 threads each measured 9.2 vs 7.4 ms per step)
-        # a worker needs ~10 ms of CPU per architecture (graph + host half of the compile) and the GPU consumes one every
-        # ~7.5 ms: three busy workers keep up.  More workers than spare cores only take the cores the enqueue thread of
-        # this process needs (the driver's box of round 2: 8 workers, enqueue 14 ms per step instead of 3)
+        # a worker needs ~30 ms of CPU per architecture (graph + host half of the compile, ghn3xlm16 / 256 nodes) and the GPU
+        # consumes one every ~6.2 ms: round 4 measured, 16 usable cores: 6 workers 8.4 ms per step (waiting for plans),
+        # 10 or 12 workers 6.7 ms.  More workers than spare cores only take the cores the enqueue thread of this process
+        # needs (the driver's box of round 2: 8 workers on 8 cores, enqueue 14 ms per step instead of 3)
         n_cores = usable_cores()
-        n_workers = int(os.environ.get('GHN3_LOADER_WORKERS', str(max(2, min(6, n_cores // 2 - 1)))))
+        n_workers = int(os.environ.get('GHN3_LOADER_WORKERS', str(max(2, min(12, n_cores - 4)))))
         pool = mp.get_context('spawn').Pool(n_workers)
     if not torch.cuda.is_available():
         if pool is not None:

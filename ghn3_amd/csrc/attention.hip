@@ -1007,8 +1007,17 @@ int ghn3_attn_fwd(float* out, const float* qkv, const float* bias, float* P, con
     const size_t lds = tpw <= 2 ? (size_t)(32 + 2 * 2 * 128) * (((d + 3) & ~3) + 4) * sizeof(float) : 0;
     attn_fwd_fn fn = pick_fwd(d, tpw);
     if (lds > 32 * 1024) {
-        hipError_t ea = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (ea != hipSuccess) { ghn3_set_error("attn fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(ea)); return GHN3_E_HIP; }
+        // (once per kernel function and size: see ghn3_attn_bwd)
+        static const void* done_fn[16];
+        static size_t done_lds[16];
+        static int n_done = 0;
+        bool seen = false;
+        for (int i = 0; i < n_done; ++i) seen = seen || (done_fn[i] == (const void*)fn && done_lds[i] >= lds);
+        if (!seen) {
+            hipError_t ea = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            if (ea != hipSuccess) { ghn3_set_error("attn fwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(ea)); return GHN3_E_HIP; }
+            if (n_done < 16) { done_fn[n_done] = (const void*)fn; done_lds[n_done] = lds; ++n_done; }
+        }
     }
     // (the staged variants own 16 queries per block)
     hipLaunchKernelGGL(fn, dim3(tpw <= 2 ? (N + 15) / 16 : nb, H, B), dim3(tpw <= 2 ? 64 * g_attn_fwd_waves : 256), lds, s, out,
@@ -1037,8 +1046,16 @@ int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P
         fn = d <= 4 ? attn_bwd_staged_kernel<2> : d <= 8 ? attn_bwd_staged_kernel<4> : d <= 16 ? attn_bwd_staged_kernel<8>
              : d <= 24 ? attn_bwd_staged_kernel<12> : attn_bwd_staged_kernel<16>;
         lds = (size_t)(8 * 16 * 64 + 8 * 32 + (32 + 3 * 32 * nb) * (d + 4)) * sizeof(float);
-        hipError_t ea = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (ea != hipSuccess) { ghn3_set_error("attn bwd: hipFuncSetAttribute(%zu): %s", lds, hipGetErrorString(ea)); return GHN3_E_HIP; }
+        // (raised once per instantiation to the most any launch needs -- 8 row tiles at d + 4 = 36 floats: the call costs
+        // host time on every launch of a chain that is host-bound when a new architecture arrives each step)
+        static bool raised[5] = {false, false, false, false, false};
+        const int slot = d <= 4 ? 0 : d <= 8 ? 1 : d <= 16 ? 2 : d <= 24 ? 3 : 4;
+        if (!raised[slot]) {
+            const size_t most = (size_t)(8 * 16 * 64 + 8 * 32 + (32 + 3 * 256) * 36) * sizeof(float);
+            hipError_t ea = hipFuncSetAttribute((const void*)fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)most);
+            if (ea != hipSuccess) { ghn3_set_error("attn bwd: hipFuncSetAttribute(%zu): %s", most, hipGetErrorString(ea)); return GHN3_E_HIP; }
+            raised[slot] = true;
+        }
     }
     hipLaunchKernelGGL(fn, dim3(2 * nb, H, B), dim3(64 * nw), lds, s, dqkv, dO, qkv, P, O, dBias, n_nodes, N, C, H,
                        scale, vec, amax_out);

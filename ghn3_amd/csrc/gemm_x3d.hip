@@ -32,6 +32,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
 
+// tools/x3s_probe.hip builds this file with GHN3_X3S_PROBE: thread 0 of workgroup 0 leaves shader-clock stamps
+#ifdef GHN3_X3S_PROBE
+__device__ long long g_x3s_stamps[16];
+#define X3_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_x3s_stamps[i] = (long long)__builtin_readcyclecounter(); } while (0)
+#else
+#define X3_STAMP(i) do { } while (0)
+#endif
+
 namespace {
 
 __device__ __forceinline__ float d_gelu(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
@@ -109,6 +117,7 @@ __global__ __launch_bounds__(64 * MT * NT * KP) void gemm_x3s_kernel(const GemmP
     char* sAl = sAh + NKT * BM * 128;
     f32x4* red = reinterpret_cast<f32x4*>(sAl + NKT * BM * 128);
 
+    X3_STAMP(0);
     const GemmProbDev* P = find_problem(probs, n_probs);
     const int t_id = blockIdx.x - P->tile_start;
     const int n0 = (t_id % P->tiles_n) * (16 * NT), m0 = (t_id / P->tiles_n) * BM;
@@ -116,7 +125,81 @@ __global__ __launch_bounds__(64 * MT * NT * KP) void gemm_x3s_kernel(const GemmP
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int nt = wave % NT, mt = (wave / NT) % MT, kp = wave / (NT * MT);
 
-    // ---- 0. weight fragments of this wave: requested first (one coalesced kilobyte per instruction), used last
+    // ---- 0. requests, in the order the data is needed.  A wave's loads return in order (vmcnt): the rows of the workgroup --
+    // small, L2-warm, consumed first by the prologue -- are requested FIRST, the weight fragments (cold, straight from HBM,
+    // consumed last by the products) behind them, so that the prologue waits for the rows only.  (Round 4 first asked for the
+    // weights first: tools/x3s_probe showed every wave's prologue waiting for its weights, 5-6k of a workgroup's 13-15k cycles
+    // plus 2.5-3k at the barrier behind the slowest wave.)  All row loads are unconditional (threads outside the prologue
+    // re-read the last row): a load inside an if-block is waited for inside it.
+    constexpr int TPR0 = NTHR / BM;
+    constexpr int TPR = (NTHR % BM == 0 && TPR0 <= 64 && (TPR0 & (TPR0 - 1)) == 0) ? TPR0 : 16;
+    constexpr int NCH = (CHUNKS + TPR - 1) / TPR;                      // PRO >= 1: chunks per thread of a row
+    constexpr int SLOTS = BM * CHUNKS, NSL = (SLOTS + NTHR - 1) / NTHR;   // PRO 0: chunk-linear mapping
+    constexpr int NA = PRO == 0 ? NSL : NCH;
+    // PRO >= 1: thread (pr, pc) owns chunks pc + TPR j of row pr: the TPR threads of a row are consecutive lanes of one wave (a
+    // power of two <= 64; workgroups whose thread count is not a power-of-two multiple of BM -- 12 waves on 32 rows -- run the
+    // prologue on their first 16 BM threads)
+    const bool pro_on = tid < TPR * BM;
+    const int pr = min(tid / TPR, BM - 1), pc = tid % TPR;
+    const int prow = m0 + pr;
+    const bool row_ok = prow < M;
+    const int64_t ro = (int64_t)min(prow, M - 1) * lda;
+    f32x4 a[NA][2];
+    f32x4 q0[PRO == 0 ? 1 : NCH][2], q1[PRO == 0 ? 1 : NCH][2], q2[PRO == 2 ? NCH : 1][2];   // PRO 1: gamma, beta; PRO 2: x, res, gamma
+    float mu_in = 0.f, rs_in = 0.f;
+    const bool has_res = PRO == 2 && P->ln_p[4] != nullptr;
+    if constexpr (PRO == 0) {
+        // chunk-linear mapping: thread t stages chunks t, t + NTHR, ... of the BM x CHUNKS chunk grid (row major)
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+            const int ci = min(tid + NTHR * j, SLOTS - 1);
+            const int r_ = ci / CHUNKS, c = ci % CHUNKS;
+            int row = min(m0 + r_, M - 1);
+            if (P->a_gather) row = P->a_gather[row];
+            const float GAS* src = (const float GAS*)P->A + (int64_t)row * lda + 8 * c;
+            a[j][0] = *reinterpret_cast<const f32x4 GAS*>(src);
+            a[j][1] = *reinterpret_cast<const f32x4 GAS*>(src + 4);
+        }
+    } else if constexpr (PRO == 1) {
+        const float GAS* x = (const float GAS*)P->A + ro;
+        const float GAS* g = (const float GAS*)P->ln_p[0];
+        const float GAS* bt = (const float GAS*)P->ln_p[1];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = min(pc + TPR * j, CHUNKS - 1);
+            a[j][0] = *reinterpret_cast<const f32x4 GAS*>(x + 8 * c);
+            a[j][1] = *reinterpret_cast<const f32x4 GAS*>(x + 8 * c + 4);
+        }
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int c = min(pc + TPR * j, CHUNKS - 1);
+            q0[j][0] = *reinterpret_cast<const f32x4 GAS*>(g + 8 * c);
+            q0[j][1] = *reinterpret_cast<const f32x4 GAS*>(g + 8 * c + 4);
+            q1[j][0] = *reinterpret_cast<const f32x4 GAS*>(bt + 8 * c);
+            q1[j][1] = *reinterpret_cast<const f32x4 GAS*>(bt + 8 * c + 4);
+        }
+    } else {
+        const float GAS* dy = (const float GAS*)P->A + ro;
+        const float GAS* x = (const float GAS*)P->ln_p[1] + ro;
+        const float GAS* g = (const float GAS*)P->ln_p[0];
+        const float GAS* res = has_res ? (const float GAS*)P->ln_p[4] + ro : dy;      // (absent: re-reads dy, not used)
+        mu_in = P->ln_p[2][min(prow, M - 1)];
+        rs_in = P->ln_p[3][min(prow, M - 1)];
+#pragma unroll
+        for (int j = 0; j < NCH; ++j) {
+            const int co = 8 * min(pc + TPR * j, CHUNKS - 1);
+            a[j][0] = *reinterpret_cast<const f32x4 GAS*>(dy + co);
+            a[j][1] = *reinterpret_cast<const f32x4 GAS*>(dy + co + 4);
+            q0[j][0] = *reinterpret_cast<const f32x4 GAS*>(x + co);
+            q0[j][1] = *reinterpret_cast<const f32x4 GAS*>(x + co + 4);
+            q1[j][0] = *reinterpret_cast<const f32x4 GAS*>(res + co);
+            q1[j][1] = *reinterpret_cast<const f32x4 GAS*>(res + co + 4);
+            q2[j][0] = *reinterpret_cast<const f32x4 GAS*>(g + co);
+            q2[j][1] = *reinterpret_cast<const f32x4 GAS*>(g + co + 4);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // weight fragments of this wave (one coalesced kilobyte per instruction)
     const int ntile = min(n0 + 16 * nt, N - 16) >> 4;     // (N % 16 == 0; a column tile beyond N repeats the last one)
     const int64_t fo = ((int64_t)ntile * (K / 32) + kp * KS) * 512 + lane * 8;
     const unsigned short GAS* bhp = (const unsigned short GAS*)P->B + fo;
@@ -128,78 +211,37 @@ __global__ __launch_bounds__(64 * MT * NT * KP) void gemm_x3s_kernel(const GemmP
         wl[s] = *reinterpret_cast<const u16x8 GAS*>(blp + 512 * s);
     }
     __builtin_amdgcn_sched_barrier(0);
+    X3_STAMP(1);
 
     // ---- 1. the rows of the workgroup -> bf16 hi / lo images in LDS
     if constexpr (PRO == 0) {
-        // chunk-linear mapping: thread t stages chunks t, t + NTHR, ... of the BM x CHUNKS chunk grid (row major)
-        constexpr int SLOTS = BM * CHUNKS, NSL = (SLOTS + NTHR - 1) / NTHR;
-        f32x4 a[NSL][2];
-#pragma unroll
-        for (int j = 0; j < NSL; ++j) {
-            const int ci = min(tid + NTHR * j, SLOTS - 1);
-            const int pr = ci / CHUNKS, c = ci % CHUNKS;
-            int row = min(m0 + pr, M - 1);
-            if (P->a_gather) row = P->a_gather[row];
-            const float GAS* src = (const float GAS*)P->A + (int64_t)row * lda + 8 * c;
-            a[j][0] = *reinterpret_cast<const f32x4 GAS*>(src);
-            a[j][1] = *reinterpret_cast<const f32x4 GAS*>(src + 4);
-        }
 #pragma unroll
         for (int j = 0; j < NSL; ++j) {
             const int ci = tid + NTHR * j;
             if (ci < SLOTS) {
-                const int pr = ci / CHUNKS, c = ci % CHUNKS;
+                const int r_ = ci / CHUNKS, c = ci % CHUNKS;
                 bf16x8 h, l;
                 split8(a[j][0], a[j][1], h, l);
-                const int off = (c >> 3) * BM * 128 + pr * 128 + (((c & 7) ^ ((pr >> 1) & 7)) << 4);
+                const int off = (c >> 3) * BM * 128 + r_ * 128 + (((c & 7) ^ ((r_ >> 1) & 7)) << 4);
                 *reinterpret_cast<bf16x8*>(sAh + off) = h;
                 *reinterpret_cast<bf16x8*>(sAl + off) = l;
             }
         }
-    } else {
-        // thread (pr, pc) owns chunks pc + TPR j of row pr: the TPR threads of a row are consecutive lanes of one wave
-        // (a power of two <= 64; workgroups whose thread count is not a power-of-two multiple of BM -- 12 waves on 32
-        // rows -- run the prologue on their first 16 BM threads)
-        constexpr int TPR0 = NTHR / BM;
-        constexpr int TPR = (NTHR % BM == 0 && TPR0 <= 64 && (TPR0 & (TPR0 - 1)) == 0) ? TPR0 : 16;
-        constexpr int NCH = (CHUNKS + TPR - 1) / TPR;
-        if (tid < TPR * BM) {
-        const int pr = tid / TPR, pc = tid % TPR;
-        const int row = m0 + pr;
-        const bool row_ok = row < M;
-        const int64_t ro = (int64_t)min(row, M - 1) * lda;
+    } else if (pro_on) {
+        const int row = prow;
         const bool side = n0 == 0 && row_ok;              // column-tile-0 workgroups write the by-products
-        f32x4 a[NCH][2];
         const float inv_k = 1.0f / (float)K;
         if constexpr (PRO == 1) {
-            const float GAS* x = (const float GAS*)P->A + ro;
-            const float GAS* g = (const float GAS*)P->ln_p[0];
-            const float GAS* bt = (const float GAS*)P->ln_p[1];
-            f32x4 gv[NCH][2], bv[NCH][2];
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int c = min(pc + TPR * j, CHUNKS - 1);
-                a[j][0] = *reinterpret_cast<const f32x4 GAS*>(x + 8 * c);
-                a[j][1] = *reinterpret_cast<const f32x4 GAS*>(x + 8 * c + 4);
-            }
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int c = min(pc + TPR * j, CHUNKS - 1);
-                gv[j][0] = *reinterpret_cast<const f32x4 GAS*>(g + 8 * c);
-                gv[j][1] = *reinterpret_cast<const f32x4 GAS*>(g + 8 * c + 4);
-                bv[j][0] = *reinterpret_cast<const f32x4 GAS*>(bt + 8 * c);
-                bv[j][1] = *reinterpret_cast<const f32x4 GAS*>(bt + 8 * c + 4);
-            }
-            float s = 0.f;
+            float s_ = 0.f;
 #pragma unroll
             for (int j = 0; j < NCH; ++j)
                 if (pc + TPR * j < CHUNKS) {
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) s += a[j][0][e] + a[j][1][e];
+                    for (int e = 0; e < 4; ++e) s_ += a[j][0][e] + a[j][1][e];
                 }
 #pragma unroll
-            for (int o = 1; o < TPR; o <<= 1) s += __shfl_xor(s, o, 64);
-            const float mu = s * inv_k;
+            for (int o = 1; o < TPR; o <<= 1) s_ += __shfl_xor(s_, o, 64);
+            const float mu = s_ * inv_k;
             float v = 0.f;
 #pragma unroll
             for (int j = 0; j < NCH; ++j)
@@ -224,8 +266,8 @@ __global__ __launch_bounds__(64 * MT * NT * KP) void gemm_x3s_kernel(const GemmP
                 if (c < CHUNKS) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        a[j][0][e] = (a[j][0][e] - mu) * rs * gv[j][0][e] + bv[j][0][e];
-                        a[j][1][e] = (a[j][1][e] - mu) * rs * gv[j][1][e] + bv[j][1][e];
+                        a[j][0][e] = (a[j][0][e] - mu) * rs * q0[j][0][e] + q1[j][0][e];
+                        a[j][1][e] = (a[j][1][e] - mu) * rs * q0[j][1][e] + q1[j][1][e];
                     }
                     if (yout) {
                         *reinterpret_cast<f32x4 GAS*>(yout + 8 * c) = a[j][0];
@@ -234,44 +276,19 @@ __global__ __launch_bounds__(64 * MT * NT * KP) void gemm_x3s_kernel(const GemmP
                 }
             }
         } else {
-            const float GAS* dy = (const float GAS*)P->A + ro;
-            const float GAS* x = (const float GAS*)P->ln_p[1] + ro;
-            const float GAS* g = (const float GAS*)P->ln_p[0];
-            const float GAS* res = P->ln_p[4] ? (const float GAS*)P->ln_p[4] + ro : nullptr;
-            const float mu = P->ln_p[2][min(row, M - 1)], rs = P->ln_p[3][min(row, M - 1)];
-            f32x4 xh[NCH][2], rv[NCH][2];
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) {               // every load of the row before the first use
-                const int co = 8 * min(pc + TPR * j, CHUNKS - 1);
-                a[j][0] = *reinterpret_cast<const f32x4 GAS*>(dy + co);
-                a[j][1] = *reinterpret_cast<const f32x4 GAS*>(dy + co + 4);
-                xh[j][0] = *reinterpret_cast<const f32x4 GAS*>(x + co);
-                xh[j][1] = *reinterpret_cast<const f32x4 GAS*>(x + co + 4);
-            }
-#pragma unroll
-            for (int j = 0; j < NCH; ++j) {
-                const int co = 8 * min(pc + TPR * j, CHUNKS - 1);
-                rv[j][0] = f32x4{0.f, 0.f, 0.f, 0.f}; rv[j][1] = rv[j][0];
-                if (res) {
-                    rv[j][0] = *reinterpret_cast<const f32x4 GAS*>(res + co);
-                    rv[j][1] = *reinterpret_cast<const f32x4 GAS*>(res + co + 4);
-                }
-            }
+            const float mu = mu_in, rs = rs_in;
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int j = 0; j < NCH; ++j) {
-                const int c = pc + TPR * j;
-                const bool in = c < CHUNKS;
-                const int co = 8 * (in ? c : 0);
-                const f32x4 g0 = *reinterpret_cast<const f32x4 GAS*>(g + co), g1 = *reinterpret_cast<const f32x4 GAS*>(g + co + 4);
+                const bool in = pc + TPR * j < CHUNKS;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    a[j][0][e] = in ? a[j][0][e] * g0[e] : 0.f;
-                    a[j][1][e] = in ? a[j][1][e] * g1[e] : 0.f;
-                    xh[j][0][e] = in ? (xh[j][0][e] - mu) * rs : 0.f;
-                    xh[j][1][e] = in ? (xh[j][1][e] - mu) * rs : 0.f;
+                    a[j][0][e] = in ? a[j][0][e] * q2[j][0][e] : 0.f;
+                    a[j][1][e] = in ? a[j][1][e] * q2[j][1][e] : 0.f;
+                    q0[j][0][e] = in ? (q0[j][0][e] - mu) * rs : 0.f;
+                    q0[j][1][e] = in ? (q0[j][1][e] - mu) * rs : 0.f;
                     s1 += a[j][0][e] + a[j][1][e];
-                    s2 += a[j][0][e] * xh[j][0][e] + a[j][1][e] * xh[j][1][e];
+                    s2 += a[j][0][e] * q0[j][0][e] + a[j][1][e] * q0[j][1][e];
                 }
             }
 #pragma unroll
@@ -284,8 +301,8 @@ __global__ __launch_bounds__(64 * MT * NT * KP) void gemm_x3s_kernel(const GemmP
                 if (c < CHUNKS) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) {
-                        a[j][0][e] = rs * (a[j][0][e] - s1 - xh[j][0][e] * s2) + rv[j][0][e];
-                        a[j][1][e] = rs * (a[j][1][e] - s1 - xh[j][1][e] * s2) + rv[j][1][e];
+                        a[j][0][e] = rs * (a[j][0][e] - s1 - q0[j][0][e] * s2) + (has_res ? q1[j][0][e] : 0.f);
+                        a[j][1][e] = rs * (a[j][1][e] - s1 - q0[j][1][e] * s2) + (has_res ? q1[j][1][e] : 0.f);
                     }
                     if (yout) {
                         *reinterpret_cast<f32x4 GAS*>(yout + 8 * c) = a[j][0];
@@ -305,9 +322,10 @@ __global__ __launch_bounds__(64 * MT * NT * KP) void gemm_x3s_kernel(const GemmP
                 *reinterpret_cast<bf16x8*>(sAl + off) = l;
             }
         }
-        }
     }
+    X3_STAMP(2);
     __syncthreads();
+    X3_STAMP(3);
 
     // ---- 2. products
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -325,14 +343,17 @@ __global__ __launch_bounds__(64 * MT * NT * KP) void gemm_x3s_kernel(const GemmP
         acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l, xh, acc1, 0, 0, 0);
     }
     f32x4 v = acc0 + acc1;
+    X3_STAMP(4);
     if (KP > 1) {
         if (kp > 0) red[((kp - 1) * MT * NT + mt * NT + nt) * 64 + lane] = v;
         __syncthreads();
+        X3_STAMP(5);
         if (kp > 0) return;
 #pragma unroll
         for (int p = 1; p < KP; ++p) v += red[((p - 1) * MT * NT + mt * NT + nt) * 64 + lane];
     }
     x3_epilogue(P, v, m0 + 16 * mt + l15, n0 + 16 * nt + 4 * lq);
+    X3_STAMP(6);
 }
 
 typedef void (*kfn)(const GemmProbDev*, int);

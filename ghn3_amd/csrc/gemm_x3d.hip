@@ -108,7 +108,7 @@ __device__ __forceinline__ void x3_epilogue(const GemmProbDev* P, f32x4 v, int m
 // (conflict-free ds_read_b128 for the 16-lane groups of the fragment reads), then the KP - 1 partial tiles.
 // ---------------------------------------------------------------------------------------------------------------------
 template <int MT, int NT, int KP, int KS, int PRO>
-__global__ __launch_bounds__(64 * MT * NT * KP) void gemm_x3s_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
+__device__ __forceinline__ void x3s_body(const GemmProbDev* __restrict__ P) {
     extern __shared__ __attribute__((aligned(16))) char x3s_smem[];
     constexpr int NTHR = 64 * MT * NT * KP, BM = 16 * MT, K = 32 * KS * KP, NKT = K / 64;
     constexpr int CHUNKS = K / 8;                         // 8-float chunks per row
@@ -118,7 +118,6 @@ __global__ __launch_bounds__(64 * MT * NT * KP) void gemm_x3s_kernel(const GemmP
     f32x4* red = reinterpret_cast<f32x4*>(sAl + NKT * BM * 128);
 
     X3_STAMP(0);
-    const GemmProbDev* P = find_problem(probs, n_probs);
     const int t_id = blockIdx.x - P->tile_start;
     const int n0 = (t_id % P->tiles_n) * (16 * NT), m0 = (t_id / P->tiles_n) * BM;
     const int M = P->M, N = P->N, lda = P->lda;
@@ -355,12 +354,27 @@ __global__ __launch_bounds__(64 * MT * NT * KP) void gemm_x3s_kernel(const GemmP
     x3_epilogue(P, v, m0 + 16 * mt + l15, n0 + 16 * nt + 4 * lq);
     X3_STAMP(6);
 }
+template <int MT, int NT, int KP, int KS, int PRO>
+__global__ __launch_bounds__(64 * MT * NT * KP) void gemm_x3s_kernel(const GemmProbDev* __restrict__ probs, int n_probs) {
+    x3s_body<MT, NT, KP, KS, PRO>(find_problem(probs, n_probs));
+}
+// one problem per launch (every GEMM of the dependent chain): the problem travels BY VALUE in the kernel arguments -- its
+// fields are scalar loads from the kernarg segment instead of a dependent round trip through the device-side problem table
+// in front of the first request (tools/x3s_probe: 2.2-4.2k cycles passed before a workgroup had issued its loads)
+template <int MT, int NT, int KP, int KS, int PRO>
+__global__ __launch_bounds__(64 * MT * NT * KP) void gemm_x3s_kernel_v(const GemmProbDev Pv) {
+    x3s_body<MT, NT, KP, KS, PRO>(&Pv);
+}
 
 typedef void (*kfn)(const GemmProbDev*, int);
-struct Cfg { int code, K, mt, nt, kp, ks; kfn fn[3]; };
+typedef void (*kfnv)(const GemmProbDev);
+struct Cfg { int code, K, mt, nt, kp, ks; kfn fn[3]; kfnv vfn[3]; };
 #define X3S(CODE, MT, NT, KP, KS) {CODE, 32 * KS * KP, MT, NT, KP, KS, {gemm_x3s_kernel<MT, NT, KP, KS, 0>, \
-                                   gemm_x3s_kernel<MT, NT, KP, KS, 1>, gemm_x3s_kernel<MT, NT, KP, KS, 2>}}
-#define X3S0(CODE, MT, NT, KP, KS) {CODE, 32 * KS * KP, MT, NT, KP, KS, {gemm_x3s_kernel<MT, NT, KP, KS, 0>, nullptr, nullptr}}
+                                   gemm_x3s_kernel<MT, NT, KP, KS, 1>, gemm_x3s_kernel<MT, NT, KP, KS, 2>}, \
+                                   {gemm_x3s_kernel_v<MT, NT, KP, KS, 0>, gemm_x3s_kernel_v<MT, NT, KP, KS, 1>, \
+                                    gemm_x3s_kernel_v<MT, NT, KP, KS, 2>}}
+#define X3S0(CODE, MT, NT, KP, KS) {CODE, 32 * KS * KP, MT, NT, KP, KS, {gemm_x3s_kernel<MT, NT, KP, KS, 0>, nullptr, nullptr}, \
+                                    {gemm_x3s_kernel_v<MT, NT, KP, KS, 0>, nullptr, nullptr}}
 // 44: 32 x 48 tiles, two K halves, 12 waves (the wide outputs: to_qkv, ff.net.0, the ff.net.3 dgrad; K = C <= 384).  At
 //     ghn3xlm16 / 256 rows: 192 (N = 3C) or 256 (N = 4C) workgroups, one per CU, one round.
 // 45: 16 x 32 tiles, K in 2 .. 8 parts (the narrow outputs: to_out, ff.net.3 and the dgrads of to_qkv / ff.net.0 / to_out):
@@ -389,6 +403,8 @@ int ghn3_gemm_x3s_init() {
             if (!g_cfg[i].fn[p]) continue;
             hipError_t e = hipFuncSetAttribute((const void*)g_cfg[i].fn[p], hipFuncAttributeMaxDynamicSharedMemorySize,
                                                160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute((const void*)g_cfg[i].vfn[p], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(x3s): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
         }
     g_ready = true;
@@ -403,15 +419,19 @@ int ghn3_gemm_x3s_tile(int code, int K, int ln_kind, int* bm, int* bn) {
     return 1;
 }
 
-int ghn3_gemm_x3s_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int code, int K, int ln_kind,
-                         hipStream_t stream) {
+int ghn3_gemm_x3s_launch(const GemmProbDev* d_probs, const GemmProbDev* h_probs, int n_probs, int total_tiles, int code, int K,
+                         int ln_kind, hipStream_t stream) {
     if (n_probs <= 0 || total_tiles <= 0) return GHN3_OK;
     const Cfg* c = (ln_kind >= 0 && ln_kind <= 2) ? find_cfg(code, K, ln_kind) : nullptr;
     if (!c) {
         ghn3_set_error("x3 staged gemm: no kernel for tile code %d, K = %d, ln_kind %d", code, K, ln_kind);
         return GHN3_E_LIMIT;
     }
-    hipLaunchKernelGGL(c->fn[ln_kind], dim3(total_tiles), dim3(64 * c->mt * c->nt * c->kp), lds_bytes(c), stream, d_probs, n_probs);
+    // (h_probs: the host copy of the same table, when the caller has one)
+    if (n_probs == 1 && h_probs)
+        hipLaunchKernelGGL(c->vfn[ln_kind], dim3(total_tiles), dim3(64 * c->mt * c->nt * c->kp), lds_bytes(c), stream, h_probs[0]);
+    else
+        hipLaunchKernelGGL(c->fn[ln_kind], dim3(total_tiles), dim3(64 * c->mt * c->nt * c->kp), lds_bytes(c), stream, d_probs, n_probs);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("x3 staged gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;

@@ -57,8 +57,8 @@ int ghn3_gemm_x3_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles
 // LayerNorm row prologue
 int ghn3_gemm_x3s_init();
 int ghn3_gemm_x3s_tile(int code, int K, int ln_kind, int* bm, int* bn);
-int ghn3_gemm_x3s_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int code, int K, int ln_kind,
-                         hipStream_t stream);
+int ghn3_gemm_x3s_launch(const GemmProbDev* d_probs, const GemmProbDev* h_probs, int n_probs, int total_tiles, int code, int K,
+                         int ln_kind, hipStream_t stream);
 int ghn3_gemm_wg_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int grid_cap, int tile_edge, hipStream_t stream);
 int ghn3_gemm_small_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int a_mode, int b_mode, int with_ln,
                            hipStream_t stream);

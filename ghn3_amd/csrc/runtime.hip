@@ -603,7 +603,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         case GHN3_OP_GEMM:
             for (const Launch& L : op_launches[k]) {
                 if (L.tile >= 6000)
-                    rc = ghn3_gemm_x3s_launch(ds + L.first, L.count, L.tiles, L.tile >= 7000 ? 45 : 44, L.max_slice,
+                    rc = ghn3_gemm_x3s_launch(ds + L.first, hs + L.first, L.count, L.tiles, L.tile >= 7000 ? 45 : 44, L.max_slice,
                                               (L.tile / 100) % 10, stream);
                 else if (L.tile >= 4000)
                     rc = ghn3_gemm_x3_launch(ds + L.first, L.count, L.tiles, 40 + (L.tile - 4000) / 10,

@@ -12,7 +12,7 @@ void ghn3_set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vfprint
 
 __global__ void touch_rows(float* x, int n, float v) { int i = blockIdx.x * 256 + threadIdx.x; if (i < n) x[i] = x[i] * 0.999f + v; }
 
-static void run(const char* name, int code, int M, int N, int K, int ln, int bm, int bn) {
+static void run(const char* name, int code, int M, int N, int K, int ln, int bm, int bn, bool byval) {
     const int layers = 24;
     float *A, *C, *lnp; unsigned short* W;
     hipMalloc(&A, sizeof(float) * M * K); hipMalloc(&C, sizeof(float) * M * N);
@@ -43,7 +43,7 @@ static void run(const char* name, int code, int M, int N, int K, int ln, int bm,
     for (int rep = 0; rep < 3; ++rep) {
         for (int l = 0; l < layers; ++l) {
             hipLaunchKernelGGL(touch_rows, dim3((M * K + 255) / 256), dim3(256), 0, 0, A, M * K, 0.001f);
-            if (ghn3_gemm_x3s_launch(dp + l, 1, tiles, code, K, ln, 0)) { printf("launch failed\n"); return; }
+            if (ghn3_gemm_x3s_launch(dp + l, byval ? hp.data() + l : nullptr, 1, tiles, code, K, ln, 0)) { printf("launch failed\n"); return; }
         }
         hipDeviceSynchronize();
         long long st[16];
@@ -54,7 +54,7 @@ static void run(const char* name, int code, int M, int N, int K, int ln, int bm,
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
     for (int r = 0; r < 10; ++r)
-        for (int l = 0; l < layers; ++l) ghn3_gemm_x3s_launch(dp + l, 1, tiles, code, K, ln, 0);
+        for (int l = 0; l < layers; ++l) ghn3_gemm_x3s_launch(dp + l, byval ? hp.data() + l : nullptr, 1, tiles, code, K, ln, 0);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%s: %.2f us per launch (240 back to back, instrumented build, %d workgroups)\n", name, ms * 1000.f / 240.f, tiles);
@@ -62,9 +62,12 @@ static void run(const char* name, int code, int M, int N, int K, int ln, int bm,
 
 int main() {
     if (ghn3_gemm_x3s_init()) return 1;
-    run("LN1 + to_qkv  (44, N 1152, K 384, ln 1)", 44, 256, 1152, 384, 1, 32, 48);
-    run("to_out        (45, N 384, K 384, ln 0)", 45, 256, 384, 384, 0, 16, 32);
-    run("ff.net.3      (45, N 384, K 1536, ln 0)", 45, 256, 384, 1536, 0, 16, 32);
-    run("LN1' + ff3 dgrad (44, N 1536, K 384, ln 2)", 44, 256, 1536, 384, 2, 32, 48);
+    for (int bv = 0; bv < 2; ++bv) {
+        printf("==== problem %s\n", bv ? "by value in the kernel arguments" : "through the device table");
+        run("LN1 + to_qkv  (44, N 1152, K 384, ln 1)", 44, 256, 1152, 384, 1, 32, 48, bv);
+        run("to_out        (45, N 384, K 384, ln 0)", 45, 256, 384, 384, 0, 16, 32, bv);
+        run("ff.net.3      (45, N 384, K 1536, ln 0)", 45, 256, 384, 1536, 0, 16, 32, bv);
+        run("LN1' + ff3 dgrad (44, N 1536, K 384, ln 2)", 44, 256, 1536, 384, 2, 32, 48, bv);
+    }
     return 0;
 }

@@ -784,6 +784,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_staged_kernel(float* __restri
         const int i0 = blockIdx.x * 32, qi = i0 + l31;
         const bool qok = qi < N;
         const int j0 = t0;
+        ATT_BSTAMP(0, 0);
         const bool interior = pvec && j0 + 32 <= N;
         const float* prow0 = P + bh * N;
         TileRaw pR, dbR;
@@ -804,7 +805,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_staged_kernel(float* __restri
             seg_write<4, RPP>(v_, stage + 64 * ldw, ldw, Np, sr0, sc4, son);
             seg_write<4, RPP>(k_, stage + (64 + Np) * ldw, ldw, Np, sr0, sc4, son);
         }
+        ATT_BSTAMP(0, 1);
         __syncthreads();
+        ATT_BSTAMP(0, 2);
         const float* dOs = stage;
         const float* Os = stage + 32 * ldw;
         const float* Vs = stage + 64 * ldw;
@@ -860,16 +863,20 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_staged_kernel(float* __restri
             }
             dQ = mfma_cols(kc, ds, dQ);                            // dQ^T += K^T dS^T
         }
+        ATT_BSTAMP(0, 3);
         if (amax_out) ghn3_atomic_amax(amax_out, bmx);
         f32x4 o = reduce_waves<NW>(red, dQ, w, lane);
+        ATT_BSTAMP(0, 4);
 #pragma unroll
         for (int c = 0; c < 4; ++c) o[c] *= scale;
         if (w < 4 && qok) store4(dqkv + ((size_t)b * N + qi) * 3 * C + h * d, 8 * w + 4 * lhi, d, true, o);
+        ATT_BSTAMP(0, 5);
     } else {
         // ---------------- column role: lane = key kj, accumulator registers = queries ----------------
         const int k0 = (blockIdx.x - NB) * 32, kj = k0 + l31;
         const bool kok = kj < N;
         const int q0 = t0;
+        ATT_BSTAMP(1, 0);
         float pr[16];
         if (has) {
             const float* pc = P + bh * N + min(kj, N - 1);
@@ -889,7 +896,9 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_staged_kernel(float* __restri
             seg_write<4, RPP>(o_, stage + (32 + Np) * ldw, ldw, Np, sr0, sc4, son);
             seg_write<4, RPP>(q_, stage + (32 + 2 * Np) * ldw, ldw, Np, sr0, sc4, son);
         }
+        ATT_BSTAMP(1, 1);
         __syncthreads();
+        ATT_BSTAMP(1, 2);
         const float* Vs = stage;
         const float* dOs = stage + 32 * ldw;
         const float* Os = dOs + Np * ldw;
@@ -931,6 +940,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_staged_kernel(float* __restri
             dV = mfma_cols(gc, p, dV);                             // dV^T += dO^T P
             dK = mfma_cols(qc, ds, dK);                            // dK^T += Q^T dS
         }
+        ATT_BSTAMP(1, 3);
         const f32x4 ov = reduce_waves<NW>(red, dV, w, lane);
         __syncthreads();                                      // (one exchange buffer for both reductions)
         f32x4 okk = reduce_waves<NW>(red, dK, w, lane);
@@ -941,6 +951,7 @@ __global__ __launch_bounds__(512, 1) void attn_bwd_staged_kernel(float* __restri
             store4(row + 2 * C, 8 * w + 4 * lhi, d, true, ov);
             store4(row + C, 8 * w + 4 * lhi, d, true, okk);
         }
+        ATT_BSTAMP(1, 4);
     }
 }
 

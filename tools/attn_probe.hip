@@ -58,18 +58,18 @@ int main() {
         hipMalloc(&dO, sizeof(float) * B * N * C); hipMalloc(&dqkv, sizeof(float) * B * N * 3 * C); hipMalloc(&dB, sizeof(float) * B * H * N * N);
         hipMemcpy(dO, h.data(), sizeof(float) * B * N * C, hipMemcpyHostToDevice);
         hipMemset(dB, 0, sizeof(float) * B * H * N * N);
-        const char* rn[] = {"start -> dO / O rows landed + delta", "V / K / P / dBias tile loads landed", "dP = V dO^T + dS + dBias store issued",
-                            "dQ^T += K^T dS^T", "amax + wave reduction (LDS)", "store"};
-        const char* cn[] = {"start -> V row + dO / O / Q operands + P landed", "delta partial + LDS hand-off", "dP + dS",
-                            "dV, dK MFMAs", "two wave reductions + stores"};
+        const char* rn[] = {"start -> tile + staging loads issued, LDS written", "barrier", "operands from LDS, dP, dS, dBias store, dQ",
+                            "amax + wave reduction (LDS)", "store"};
+        const char* cn[] = {"start -> P + staging loads issued, LDS written", "barrier", "operands from LDS, dP, dS, dV, dK",
+                            "two wave reductions + stores"};
         for (int rep = 0; rep < 4; ++rep) {
             ghn3_attn_bwd(dqkv, dO, qkv, P, out, nullptr, dB, nn, B, N, C, H, 0);
             hipDeviceSynchronize();
             long long st[64];
             hipMemcpyFromSymbol(st, HIP_SYMBOL(g_attn_stamps), sizeof(st));
-            printf("bwd rep %d: row role %lld cycles, column role %lld cycles\n", rep, st[22] - st[16], st[37] - st[32]);
-            for (int i = 0; i < 6; ++i) printf("   row  %-58s %8lld\n", rn[i], st[17 + i] - st[16 + i]);
-            for (int i = 0; i < 5; ++i) printf("   col  %-58s %8lld\n", cn[i], st[33 + i] - st[32 + i]);
+            printf("bwd (staged) rep %d: row role %lld cycles, column role %lld cycles\n", rep, st[21] - st[16], st[36] - st[32]);
+            for (int i = 0; i < 5; ++i) printf("   row  %-58s %8lld\n", rn[i], st[17 + i] - st[16 + i]);
+            for (int i = 0; i < 4; ++i) printf("   col  %-58s %8lld\n", cn[i], st[33 + i] - st[32 + i]);
         }
         hipEvent_t a, b_; hipEventCreate(&a); hipEventCreate(&b_);
         hipEventRecord(a, 0);

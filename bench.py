@@ -213,7 +213,7 @@ def main():
         # 10 or 12 workers 6.7 ms.  More workers than spare cores only take the cores the enqueue thread of this process
         # needs (the driver's box of round 2: 8 workers on 8 cores, enqueue 14 ms per step instead of 3)
         n_cores = usable_cores()
-        n_workers = int(os.environ.get('GHN3_LOADER_WORKERS', str(max(2, min(12, n_cores - 4)))))
+        n_workers = int(os.environ.get('GHN3_LOADER_WORKERS', str(max(2, min(10, n_cores - 6)))))
         pool = mp.get_context('spawn').Pool(n_workers)
     if not torch.cuda.is_available():
         if pool is not None:

@@ -83,7 +83,7 @@ __device__ __forceinline__ void wg_tile(const GemmProbDev* __restrict__ probs, i
     // (128 contiguous bytes of a row) x 8 row pairs: its ds_write_b32 of one element then land in 8 swizzle slots x 4 words =
     // 32 banks, two lanes each -- the LDS rate for 256 bytes.  (Round 3 mapping, 16 feature groups x 4 row pairs per wave: the
     // rows 4 t + e of one instruction share their parity and rows 16 apart share their slot -> 16 banks, four lanes each;
-    // SQ_LDS_BANK_CONFLICT was 60 % of the kernel's LDS cycles, profiles/r04y_pmc_xl_f16.txt.)
+    // SQ_LDS_BANK_CONFLICT was 60 % of the kernel's LDS cycles, profiles/r04z_pmc_xl_f16.txt.)
     constexpr int FGW = FPR / 8;                         // waves along the feature groups
     const int f4 = ((lane & 7) + 8 * (wave % FGW)) * 4, kp = (lane >> 3) + 8 * (wave / FGW);
     const float GAS* Ag = (const float GAS*)P->A;

@@ -1039,7 +1039,7 @@ int ghn3_attn_fwd(float* out, const float* qkv, const float* bias, float* P, con
 }
 
 int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P, const float* O, float* amax_out,
-                  float* dBias, const int* n_nodes, int B, int N, int C, int H, hipStream_t s) {
+                  float* dBias, const int* n_nodes, int B, int N, int C, int H, int general, hipStream_t s) {
     if (amax_out && !dBias) { ghn3_set_error("attention bwd: r5 (max |dBias|) needs r6"); return GHN3_E_ARG; }
     int rc = check_dims(N, C, H);
     if (rc) return rc;
@@ -1052,7 +1052,7 @@ int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P
     int nw = 4;
     attn_bwd_fn fn = pick_bwd(d, N, &nw);
     size_t lds = 0;
-    if (nw == 8 && vec && (d & 3) == 0 && g_attn_bwd_staged) {
+    if (nw == 8 && vec && (d & 3) == 0 && g_attn_bwd_staged && !general) {
         // operands staged in LDS: exchange buffers + (32 + 3 * 32 * nb) rows of d + 4 floats (123 KB at d = 24, N = 256)
         fn = d <= 4 ? attn_bwd_staged_kernel<2> : d <= 8 ? attn_bwd_staged_kernel<4> : d <= 16 ? attn_bwd_staged_kernel<8>
              : d <= 24 ? attn_bwd_staged_kernel<12> : attn_bwd_staged_kernel<16>;

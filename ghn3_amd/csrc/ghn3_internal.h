@@ -67,7 +67,7 @@ int ghn3_attn_init();
 int ghn3_attn_fwd(float* out, const float* qkv, const float* bias, float* P, const int* n_nodes,
                   int B, int N, int C, int H, hipStream_t s);
 int ghn3_attn_bwd(float* dqkv, const float* dO, const float* qkv, const float* P, const float* O, float* amax_out,
-                  float* dBias, const int* n_nodes, int B, int N, int C, int H, hipStream_t s);
+                  float* dBias, const int* n_nodes, int B, int N, int C, int H, int general, hipStream_t s);
 
 int ghn3_graph_prologue(const int64_t* A, int* deg_in, int* deg_out, int* dist0, int* pair,
                         int B, int N, int V, hipStream_t s);

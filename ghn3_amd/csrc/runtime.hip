@@ -700,7 +700,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             rc = ghn3_attn_bwd(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const float>(o.r[2]),
                                R.get<const float>(o.r[3]), R.get<const float>(o.r[4]), R.get<float>(o.r[5]),
                                R.get<float>(o.r[6]), R.get<const int>(o.r[7]), (int)o.i[0], (int)o.i[1], (int)o.i[2],
-                               (int)o.i[3], stream);
+                               (int)o.i[3], (int)o.i[4], stream);
             break;
         case GHN3_OP_TILE_FWD: {
             const float* srcs[6];

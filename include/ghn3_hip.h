@@ -312,7 +312,8 @@ enum ghn3_op_kind {
     /* r0=dqkv r1=dO r2=qkv r3=P r4=O (saved attention output) r5=optional device float: running max of |dBias| as
      * written by this launch (atomic max on a zeroed slot -- the program passes it to the LAST launch that accumulates into
      * r6, whose values are final: GHN3_OP_BIAS_HIST then needs no pass for its scale; ABI v15) r6=dBias (accumulated)
-     * r7=n_nodes ; i: B,N,C,H */
+     * r7=n_nodes ; i: B,N,C,H, i4 = 1: the general kernel (operands straight from memory) also where the LDS-staged kernel for
+     * graphs of up to 256 nodes would run -- both give the same bits; tests compare them */
     GHN3_OP_ATTN_BWD = 16,
     /* dT[p][h] += sum_{pair==p} dBias[b,h,i,j] ; r0=dT r1=dBias r2=pair r3=scratch: 8 * V * V * H + 16 bytes, ZEROED by
      * the program (64-bit fixed-point histogram: the order of the atomics does not matter -> deterministic) ; i: B,N,H,V,

@@ -908,3 +908,44 @@ def test_cast16_from_a_16bit_source_matches_the_interpreter(ctx, bf16):
     assert bad.size == 0, (bad[:10], got16[bad[:10]], exp16[bad[:10]])
     gp, ep = dev[3].cpu().numpy().view(np.float32), host[3].view(np.float32)
     assert np.abs(gp - ep).max() <= 1e-6 * np.abs(ep).max()
+
+
+@pytest.mark.parametrize('N,H,C,nn', [(256, 16, 384, [256]), (200, 16, 384, [200, 131]), (97, 8, 64, [97]), (33, 4, 128, [20, 33]),
+                                      (64, 16, 48, [64])])
+def test_staged_attention_backward_equals_the_general_kernel(ctx, N, H, C, nn):
+    """attn_bwd_staged_kernel (operands through LDS, graphs of up to 256 nodes) against attn_bwd_kernel (operands straight
+    from memory): same MFMAs in the same order -> the same bits, incl. padded graphs, the accumulated edge-bias gradient and
+    the reported max |dBias|.  (C / H = 3 is not a multiple of 4: both calls take the general kernel there.)"""
+    from ghn3_amd import _lib as L
+    B = len(nn)
+    g = torch.Generator(device='cuda').manual_seed(N * 7 + H)
+    qkv = torch.randn(B * N, 3 * C, device='cuda', generator=g)
+    bias = torch.randn(B, H, N, N, device='cuda', generator=g)
+    dO = torch.randn(B * N, C, device='cuda', generator=g)
+    P = torch.zeros(B, H, N, N, device='cuda')
+    out = torch.zeros(B * N, C, device='cuda')
+    n_nodes = torch.tensor(nn, dtype=torch.int32, device='cuda')
+    res = []
+    for general in (0, 1):
+        dqkv = torch.full((B * N, 3 * C), float('nan'), device='cuda')
+        dB = torch.full((B, H, N, N), 0.25, device='cuda')
+        amax = torch.zeros(4, device='cuda')
+        bufs = [out, qkv, bias, P, n_nodes, dqkv, dO, dB, amax]
+        ptrs = np.asarray([t.data_ptr() for t in bufs], dtype=np.uint64)
+        ops = np.zeros(2, dtype=L.OP_DT)
+        ops['r']['buf'][:] = -1
+        ops[0]['kind'] = L.OP_ATTN_FWD
+        ops[0]['r']['buf'][:5] = (0, 1, 2, 3, 4)
+        ops[0]['i'][:4] = (B, N, C, H)
+        ops[1]['kind'] = L.OP_ATTN_BWD
+        ops[1]['r']['buf'][:8] = (5, 6, 1, 3, 0, 8, 7, 4)
+        ops[1]['i'][:5] = (B, N, C, H, general)
+        ctx.run(ops, np.zeros(0, dtype=L.PROBLEM_DT), ptrs, torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        res.append((dqkv.clone(), dB.clone(), float(amax[0])))
+    (a, ab, am), (b, bb, bm) = res
+    for k, n_ in enumerate(nn):                                  # rows of padded nodes are not written
+        assert torch.isfinite(a[k * N:k * N + n_]).all()
+    assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0))
+    assert torch.equal(ab, bb)
+    assert am == bm and abs(am - float(ab.abs().max())) <= 1e-6 * am

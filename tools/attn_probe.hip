@@ -63,7 +63,7 @@ int main() {
         const char* cn[] = {"start -> P + staging loads issued, LDS written", "barrier", "operands from LDS, dP, dS, dV, dK",
                             "two wave reductions + stores"};
         for (int rep = 0; rep < 4; ++rep) {
-            ghn3_attn_bwd(dqkv, dO, qkv, P, out, nullptr, dB, nn, B, N, C, H, 0);
+            ghn3_attn_bwd(dqkv, dO, qkv, P, out, nullptr, dB, nn, B, N, C, H, 0, 0);
             hipDeviceSynchronize();
             long long st[64];
             hipMemcpyFromSymbol(st, HIP_SYMBOL(g_attn_stamps), sizeof(st));
@@ -73,7 +73,7 @@ int main() {
         }
         hipEvent_t a, b_; hipEventCreate(&a); hipEventCreate(&b_);
         hipEventRecord(a, 0);
-        for (int i = 0; i < 200; ++i) ghn3_attn_bwd(dqkv, dO, qkv, P, out, nullptr, dB, nn, B, N, C, H, 0);
+        for (int i = 0; i < 200; ++i) ghn3_attn_bwd(dqkv, dO, qkv, P, out, nullptr, dB, nn, B, N, C, H, 0, 0);
         hipEventRecord(b_, 0); hipEventSynchronize(b_);
         float msb; hipEventElapsedTime(&msb, a, b_);
         printf("bwd: %.2f us per launch (200 back to back, instrumented build)\n", msb * 5.0f);

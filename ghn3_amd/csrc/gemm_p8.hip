@@ -419,6 +419,9 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmProbDev* __re
 // Contract as tile code 25 (checked by the host): C = alpha * A B^T with an optional row map of C; no bias / activation /
 // residual / accumulate / gathers / k-map / ragged extents / split-K; N % 4 == 0, K >= 1; 256 x 256 tiles.
 // ---------------------------------------------------------------------------------------------------------------------
+#ifdef GHN3_P8W_PROBE
+__device__ long long g_p8w_probe[8];
+#endif
 template <int CT>
 __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int total_tiles_all,
                                                            int vgrid, int tpw) {
@@ -579,6 +582,17 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
             }
         }
     };
+#ifdef GHN3_P8W_PROBE
+    // tools/p8w_probe.hip: cycles of workgroup 0 / thread 0 per k-tile (first k-tile of a tile = the one that also stores the
+    // previous tile), inside the DMA wait of a k-tile, and -- store k-tiles -- inside store_prev / at the barriers
+    long long pr_tot[2] = {0, 0}, pr_wait[2] = {0, 0}, pr_cnt[2] = {0, 0}, pr_store = 0, pr_bar = 0;
+#define P8W_CLK() ((long long)__builtin_readcyclecounter())
+#define P8W_ST_T(x) { const long long t_ = P8W_CLK(); x; pr_store += P8W_CLK() - t_; }
+#define P8W_BAR_T() { const long long t_ = P8W_CLK(); __builtin_amdgcn_s_barrier(); if (st) pr_bar += P8W_CLK() - t_; }
+#else
+#define P8W_ST_T(x) x
+#define P8W_BAR_T() __builtin_amdgcn_s_barrier()
+#endif
     int G = 0;                                        // k-tiles computed so far (ring parity, half-tile bookkeeping)
     auto wait_next_ktile = [&]() {                    // k-tile G + 1 (half-tiles .. 4 G + 7) has landed; the newer ones stay in flight
         const int keep = issued - 1 - (4 * G + 7);
@@ -588,37 +602,49 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
         else wait_vm<0>();
     };
     auto ktile = [&](const bool first) {
+#ifdef GHN3_P8W_PROBE
+        const long long pr_t0 = P8W_CLK();
+#endif
         const char* ring = sm + (G & 1) * KT;
         const bool st = first && p_valid;
-        if (st) store_prev(0, 0);
+        if (st) P8W_ST_T(store_prev(0, 0));
         read_b(ring, 0);                              // (first: retired by the counted lgkmcnt below)
         __builtin_amdgcn_sched_barrier(0);
         read_a(ring, 0);
         __builtin_amdgcn_sched_barrier(0);
         issue(3);
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * MI) : "memory");
-        __builtin_amdgcn_s_barrier();
+        P8W_BAR_T();
         mfma_q(0, 0, first);
-        __builtin_amdgcn_s_barrier();
-        if (st) store_prev(0, 1);
+        P8W_BAR_T();
+        if (st) P8W_ST_T(store_prev(0, 1));
         read_b(ring, 1);
         issue(0);
-        __builtin_amdgcn_s_barrier();
+        P8W_BAR_T();
         mfma_q(0, 1, first);
-        __builtin_amdgcn_s_barrier();
-        if (st) store_prev(1, 1);
+        P8W_BAR_T();
+        if (st) P8W_ST_T(store_prev(1, 1));
         read_a(ring, 1);
         issue(1);
-        __builtin_amdgcn_s_barrier();
+        P8W_BAR_T();
         mfma_q(1, 1, first);
-        __builtin_amdgcn_s_barrier();
+        P8W_BAR_T();
         issue(2);
+#ifdef GHN3_P8W_PROBE
+        const long long pr_w0 = P8W_CLK();
+#endif
         wait_next_ktile();
-        if (st) store_prev(1, 0);                     // (behind the wait: these stores are not waited for with the DMA)
-        __builtin_amdgcn_s_barrier();
+#ifdef GHN3_P8W_PROBE
+        pr_wait[st ? 0 : 1] += P8W_CLK() - pr_w0;
+#endif
+        if (st) P8W_ST_T(store_prev(1, 0));                     // (behind the wait: these stores are not waited for with the DMA)
+        P8W_BAR_T();
         mfma_q(1, 0, first);
-        __builtin_amdgcn_s_barrier();
+        P8W_BAR_T();
         ++G;
+#ifdef GHN3_P8W_PROBE
+        pr_tot[st ? 0 : 1] += P8W_CLK() - pr_t0; pr_cnt[st ? 0 : 1] += 1;
+#endif
     };
 
 #pragma unroll
@@ -646,6 +672,12 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();        // pairs the extra barrier of wave row 1
     store_prev(0, 0); store_prev(0, 1); store_prev(1, 1); store_prev(1, 0);
+#ifdef GHN3_P8W_PROBE
+    if (blockIdx.x == 0 && tid == 0) {
+        for (int i = 0; i < 2; ++i) { g_p8w_probe[3 * i] = pr_tot[i]; g_p8w_probe[3 * i + 1] = pr_wait[i]; g_p8w_probe[3 * i + 2] = pr_cnt[i]; }
+        g_p8w_probe[6] = pr_store; g_p8w_probe[7] = pr_bar;
+    }
+#endif
 }
 
 constexpr int kP8Lds = 2 * (2 * 5 * 4096 + 32768);    // MI = 5: 144 KB

@@ -2008,6 +2008,7 @@ class Program:
                 # conv.0 dgrad: [M x 4C] output with K = 8C is 144 tiles of 128 x 128 at ghn3xlm16 -- half the CUs, 48 k-tiles
                 # each (154 us, 87 TF).  K chunks as separate problems writing partial planes (summed + masked by a DACT
                 # pass in plane order: deterministic) fill the chip.
+                d2_tile = int(os.environ.get('GHN3_D2_DGRAD_TILE', '0'))
                 ks = int(os.environ.get('GHN3_D2_DGRAD_KS', '0')) or \
                     max(1, min(4, 320 // max(1, ((M + 127) // 128) * ((4 * C + 127) // 128))))
                 while ks > 1 and (8 * C) % (64 * ks):
@@ -2020,7 +2021,7 @@ class Program:
                         dst = d_t if j == 0 else (planes[0], planes[1] + 4 * (j - 1) * M * 4 * C)
                         self.gemm(self.href(duh + j * kc), self.sref(self.w0hT + j * kc), dst, M, 4 * C, kc, 8 * C, 8 * C,
                                   4 * C, op16=True, alpha_amax=amax_u)
-                    self.gemm_op(p0, ctype=bct, tag=self.TAG_D2_BWD, flops=2.0 * M * 4 * C * 8 * C)
+                    self.gemm_op(p0, ctype=bct, tag=self.TAG_D2_BWD, flops=2.0 * M * 4 * C * 8 * C, tile=d2_tile)
                     self.op(L.OP_DACT, refs=(d_t, t, self.NONE, planes),
                             ints=(M, 4 * C, 4 * C, L.DACT_RELU, ks - 1, M * 4 * C, M))
                 else:

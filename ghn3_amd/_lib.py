@@ -12,7 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libghn3_hip.so')
-ABI_VERSION = 15
+ABI_VERSION = 16
 
 # ---- numpy mirrors of the C structs -------------------------------------------------------------
 REF_DT = np.dtype([('buf', '<i4'), ('_pad', '<i4'), ('off', '<i8')])
@@ -56,12 +56,12 @@ COMPUTE_TYPES = {'f32': CT_F32, 'f16': CT_F16, 'bf16': CT_BF16}
  OP_ATTN_FWD, OP_TILE_FWD, OP_PARAM_NORM_FWD, OP_PARAM_NORM_BWD, OP_TILE_BWD, OP_COLSUM, OP_ROWSEG_SUM,
  OP_LAYERNORM_BWD, OP_LN_PARAM_GRAD, OP_ATTN_BWD, OP_BIAS_HIST, OP_EDGE_HIDDEN_BWD, OP_EMBED_BWD, OP_MEMSET0,
  OP_ADD, OP_DACT, OP_CAST16, OP_JOIN, OP_DETACH, OP_SUMSQ, OP_ADAMW, OP_RELU_FIX, OP_ROWSET_COLSUM, OP_WIRE_PACK,
- OP_RANK_REDUCE, OP_TRANSPOSE32, OP_PARAM_NORM_FIN, OP_LN_PARAM_GRAD_BATCH, OP_KIND_COUNT) = range(36)
+ OP_RANK_REDUCE, OP_TRANSPOSE32, OP_PARAM_NORM_FIN, OP_LN_PARAM_GRAD_BATCH, OP_ADAMW_CAST16, OP_KIND_COUNT) = range(37)
 OP_NAMES = ['nop', 'gemm', 'graph_prologue', 'embed_nodes', 'edge_hidden', 'bias_gather', 'layernorm_fwd',
             'attn_fwd', 'tile_fwd', 'param_norm_fwd', 'param_norm_bwd', 'tile_bwd', 'colsum', 'rowseg_sum',
             'layernorm_bwd', 'ln_param_grad', 'attn_bwd', 'bias_hist', 'edge_hidden_bwd', 'embed_bwd', 'memset0',
             'add', 'dact', 'cast16', 'join', 'detach', 'sumsq', 'adamw', 'relu_fix', 'rowset_colsum', 'wire_pack',
-            'rank_reduce', 'transpose32', 'param_norm_fin', 'ln_param_grad_batch']
+            'rank_reduce', 'transpose32', 'param_norm_fin', 'ln_param_grad_batch', 'adamw_cast16']
 
 EXPORTS = ['ghn3_abi_version', 'ghn3_last_error', 'ghn3_ctx_create', 'ghn3_ctx_destroy',
            'ghn3_ctx_set_compute_type', 'ghn3_ctx_side_wait', 'ghn3_run', 'ghn3_event_create', 'ghn3_event_record',

@@ -1706,12 +1706,41 @@ __device__ __forceinline__ float f16_back(unsigned short h) { return (float)__bu
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 
-__global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
-                                                     const ghn3_cast_desc* __restrict__ descs, int n_desc,
-                                                     float* __restrict__ dbias, int total_items,
-                                                     const float* __restrict__ amax) {
+struct AdamWArgs { float lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2_sqrt, max_norm, inv_scale; };
+// gradient / moment buffers congruent to the source of a cast (same float offsets): GHN3_OP_ADAMW_CAST16
+struct AdamWSrc { const float* g; float* m; float* v; const float* sumsq; AdamWArgs a; };
+
+// one element of torch.optim.AdamW (decoupled weight decay); `clip` = clip_grad_norm_'s coefficient / loss scale
+__device__ __forceinline__ void adamw_element(float& p, float g, float& m, float& v, const AdamWArgs& a, float clip,
+                                              float step, float decay) {
+    // (explicitly rounded operations: the compiler may not contract them differently in the kernels that share this
+    // function -- GHN3_OP_ADAMW and GHN3_OP_ADAMW_CAST16 produce the same bits)
+    const float gi = __fmul_rn(g, clip);
+    const float mi = __fmaf_rn(a.beta1, m, __fmul_rn(1.f - a.beta1, gi));
+    const float vi = __fmaf_rn(a.beta2, v, __fmul_rn(__fmul_rn(1.f - a.beta2, gi), gi));
+    m = mi; v = vi;
+    const float den = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), a.bias_corr2_sqrt), a.eps);
+    p = __fsub_rn(__fmul_rn(p, decay), __fdiv_rn(__fmul_rn(step, mi), den));
+}
+
+// ADAMW: the source elements are parameters that first take their optimizer update (gradient / moments at the same float
+// offsets in aw.g / aw.m / aw.v; written back in place) and are then cast -- the 16-bit copies of a weight follow its
+// update without a second pass over it (host contract: fp32 source, cols % 4 == 0, no column map, every source element
+// in exactly one work tile)
+template <bool ADAMW>
+__device__ __forceinline__ void cast16_body(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                            const ghn3_cast_desc* __restrict__ descs, int n_desc,
+                                            float* __restrict__ dbias, int total_items,
+                                            const float* __restrict__ amax, const AdamWSrc& aw) {
     __shared__ unsigned short tr[64][66];          // transposed-copy staging (already converted)
     __shared__ float csum[16][64];
+    float aw_clip = 1.f, aw_step = 0.f, aw_decay = 1.f;
+    if (ADAMW) {
+        if (aw.sumsq && !isfinite(*aw.sumsq)) return;   // (NaN guard as adamw_kernel: parameters AND copies stay as they are)
+        aw_clip = aw.a.inv_scale;
+        if (aw.sumsq && aw.a.max_norm > 0.f) aw_clip *= fminf(1.f, aw.a.max_norm / (sqrtf(*aw.sumsq) * aw.a.inv_scale + 1e-6f));
+        aw_step = aw.a.lr / aw.a.bias_corr1; aw_decay = 1.f - aw.a.lr * aw.a.weight_decay;
+    }
     // grid-stride over the 64 x 64 work tiles: a launch may cap its grid (side-stream copies that should leave
     // HBM bandwidth to the latency-bound chain they run under)
     for (int item = blockIdx.x; item < total_items; item += gridDim.x) {
@@ -1736,7 +1765,7 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
     const float sc = ((D.flags & GHN3_CAST_SCALED) && amax) ? ghn3_pow2_scale(*amax) : 1.f;
     const int rows_w = (D.flags & GHN3_CAST_TIGHT) ? ((D.rows + 7) & ~7) : 0x7fffffff;   // transposed rows written
 
-    if (st && !trn && !frag && !(D.flags & (GHN3_CAST_COLSUM | GHN3_CAST_SRC16)) && D.src_q == 0 && !(D.ld_dst & 7) && !(D.dst_off & 7) && !(D.lo_off & 7)) {
+    if (!ADAMW && st && !trn && !frag && !(D.flags & (GHN3_CAST_COLSUM | GHN3_CAST_SRC16)) && D.src_q == 0 && !(D.ld_dst & 7) && !(D.dst_off & 7) && !(D.lo_off & 7)) {
         // straight copy only (the dgrad operand of the decoder gradients, forward activations): 8 consecutive floats per
         // lane -> one 16-byte store (the general path below writes 8 bytes per lane)
         unsigned short* Dd = dst + D.dst_off;
@@ -1795,6 +1824,21 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
                 }
                 if (tr_bf) x = make_float4(bf16_back(h0), bf16_back(h1), bf16_back(h2), bf16_back(h3));
                 else x = make_float4(f16_back(h0), f16_back(h1), f16_back(h2), f16_back(h3));
+            } else if (ADAMW) {
+                if (c + 3 < D.cols) {
+                    const int64_t o = D.src_off + (int64_t)r * D.ld_src + c;
+                    float* pp = const_cast<float*>(src) + o;
+                    x = *reinterpret_cast<const float4*>(pp);
+                    const float4 gv = *reinterpret_cast<const float4*>(aw.g + o);
+                    float4 mv = *reinterpret_cast<const float4*>(aw.m + o), vv = *reinterpret_cast<const float4*>(aw.v + o);
+                    adamw_element(x.x, gv.x, mv.x, vv.x, aw.a, aw_clip, aw_step, aw_decay);
+                    adamw_element(x.y, gv.y, mv.y, vv.y, aw.a, aw_clip, aw_step, aw_decay);
+                    adamw_element(x.z, gv.z, mv.z, vv.z, aw.a, aw_clip, aw_step, aw_decay);
+                    adamw_element(x.w, gv.w, mv.w, vv.w, aw.a, aw_clip, aw_step, aw_decay);
+                    *reinterpret_cast<float4*>(aw.m + o) = mv;
+                    *reinterpret_cast<float4*>(aw.v + o) = vv;
+                    *reinterpret_cast<float4*>(pp) = x;
+                }
             } else {
                 const float* p = S + (int64_t)r * D.ld_src + sc_;
                 if (c + 3 < D.cols) x = *reinterpret_cast<const float4*>(p);
@@ -1920,6 +1964,18 @@ __global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ s
     }
 }
 
+__global__ __launch_bounds__(256) void cast16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst,
+                                                     const ghn3_cast_desc* __restrict__ descs, int n_desc,
+                                                     float* __restrict__ dbias, int total_items,
+                                                     const float* __restrict__ amax) {
+    cast16_body<false>(src, dst, descs, n_desc, dbias, total_items, amax, AdamWSrc{});
+}
+__global__ __launch_bounds__(256) void adamw_cast16_kernel(float* __restrict__ p, unsigned short* __restrict__ dst,
+                                                           const ghn3_cast_desc* __restrict__ descs, int n_desc,
+                                                           int total_items, AdamWSrc aw) {
+    cast16_body<true>(p, dst, descs, n_desc, nullptr, total_items, nullptr, aw);
+}
+
 int ghn3_cast16(const float* src, void* dst, const ghn3_cast_desc* d_desc, int n_desc, int total_blocks, float* dbias,
                 const float* amax, int grid_cap, hipStream_t s) {
     if (n_desc <= 0 || total_blocks <= 0) return GHN3_OK;
@@ -1972,8 +2028,6 @@ int ghn3_sumsq(float* out, const float* x, int64_t n, float* parts, hipStream_t 
     return launch_ok("sumsq");
 }
 
-struct AdamWArgs { float lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2_sqrt, max_norm, inv_scale; };
-
 // torch.optim.AdamW (decoupled weight decay) with the gradient scaled by clip_grad_norm_'s coefficient
 // min(1, max_norm / (||g|| + 1e-6)); `sumsq` holds ||g||^2 (absent: no clipping)
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
@@ -2000,24 +2054,32 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
             float4 pv = p4[i], gv = g4[i], mv = m4[i], vv = v4[i];
             float* pe = &pv.x; float* ge = &gv.x; float* me = &mv.x; float* ve = &vv.x;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const float gi = ge[e] * clip;
-                const float mi = a.beta1 * me[e] + (1.f - a.beta1) * gi;
-                const float vi = a.beta2 * ve[e] + (1.f - a.beta2) * gi * gi;
-                me[e] = mi; ve[e] = vi;
-                pe[e] = pe[e] * decay - step * mi / (sqrtf(vi) / a.bias_corr2_sqrt + a.eps);
-            }
+            for (int e = 0; e < 4; ++e) adamw_element(pe[e], ge[e], me[e], ve[e], a, clip, step, decay);
             m4[i] = mv; v4[i] = vv; p4[i] = pv;
         }
     }
     for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const float gi = g[i] * clip;
-        const float mi = a.beta1 * m[i] + (1.f - a.beta1) * gi;
-        const float vi = a.beta2 * v[i] + (1.f - a.beta2) * gi * gi;
-        m[i] = mi; v[i] = vi;
-        p[i] = p[i] * decay - step * mi / (sqrtf(vi) / a.bias_corr2_sqrt + a.eps);
+        float pi = p[i], mi = m[i], vi = v[i];
+        adamw_element(pi, g[i], mi, vi, a, clip, step, decay);
+        m[i] = mi; v[i] = vi; p[i] = pi;
     }
 }
+int ghn3_adamw_cast16(float* p, const float* g, float* m, float* v, void* dst, const ghn3_cast_desc* d_desc, int n_desc,
+                      int total_blocks, const float* sumsq, float lr, float beta1, float beta2, float eps, float weight_decay,
+                      float bias_corr1, float bias_corr2, float max_norm, float inv_scale, hipStream_t s) {
+    if (n_desc <= 0 || total_blocks <= 0) return GHN3_OK;
+    if ((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
+         reinterpret_cast<uintptr_t>(v)) & 15) {
+        ghn3_set_error("adamw_cast16: buffers must be 16-byte aligned");
+        return GHN3_E_ARG;
+    }
+    AdamWSrc aw{g, m, v, sumsq, AdamWArgs{lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrtf(bias_corr2), max_norm,
+                                           inv_scale > 0.f ? inv_scale : 1.f}};
+    hipLaunchKernelGGL(adamw_cast16_kernel, dim3(total_blocks), dim3(256), 0, s, p, (unsigned short*)dst, d_desc, n_desc,
+                       total_blocks, aw);
+    return launch_ok("adamw_cast16");
+}
+
 int ghn3_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float lr, float beta1,
                float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float max_norm,
                float inv_scale, hipStream_t s) {

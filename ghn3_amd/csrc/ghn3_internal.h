@@ -121,6 +121,9 @@ int ghn3_sumsq(float* out, const float* x, int64_t n, float* parts, hipStream_t 
 int ghn3_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float lr, float beta1,
                float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float max_norm,
                float inv_scale, hipStream_t s);
+int ghn3_adamw_cast16(float* p, const float* g, float* m, float* v, void* dst, const ghn3_cast_desc* d_desc, int n_desc,
+                      int total_blocks, const float* sumsq, float lr, float beta1, float beta2, float eps, float weight_decay,
+                      float bias_corr1, float bias_corr2, float max_norm, float inv_scale, hipStream_t s);
 int ghn3_dact(float* X, const float* aux, int M, int N, int ld, int dact, float* amax, const float* parts, int n_parts,
               int64_t part_stride, int rows_parts, hipStream_t s);
 

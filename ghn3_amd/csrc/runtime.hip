@@ -788,6 +788,15 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             (float)h[4], (float)h[5], (float)h[6], o.f[0], o.f[1], stream);
             break;
         }
+        case GHN3_OP_ADAMW_CAST16: {
+            double h[7];
+            memcpy(h, &o.i[1], sizeof(h));
+            rc = ghn3_adamw_cast16(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<float>(o.r[2]), R.get<float>(o.r[3]),
+                                   R.get<void>(o.r[5]), R.get<const ghn3_cast_desc>(o.r[6]), (int)(o.i[0] & 0xffffffff),
+                                   (int)(o.i[0] >> 32), R.get<const float>(o.r[4]), (float)h[0], (float)h[1], (float)h[2],
+                                   (float)h[3], (float)h[4], (float)h[5], (float)h[6], o.f[0], o.f[1], stream);
+            break;
+        }
         case GHN3_OP_RELU_FIX:
             rc = ghn3_relu_fix(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), R.get<const float>(o.r[2]),
                                R.get<const float>(o.r[3]), (int)o.i[0], (int)o.i[1], (int)o.i[2], (int)o.i[3], (int)o.i[4],

@@ -355,6 +355,7 @@ class GHN3(nn.Module):
         self._shadow = None                       # 16-bit copies of the decoder weights (Program.shadow_layout)
         self._shadowed = None
         self._shadow_state = None                 # (parameter version, has the transposed copies) they were cast from
+        self._shadow_w2_state = None              # the same for the W2 copies alone, when an optimizer step wrote them
         self._param_epoch = getattr(self, '_param_epoch', 0) + 1
 
     def __deepcopy__(self, memo):
@@ -407,7 +408,11 @@ class GHN3(nn.Module):
         st = self._shadow_state
         if st is not None and st[0] == ver and st[2] == types and (st[1] or not prog.training):
             return
-        self._ctx().run(prog.shadow_ops, prog.problems, plan.bufs, stream)
+        # the W2 copies may already be current: a fused optimizer step wrote them while it updated W2 (FusedAdamW.step with
+        # a plan; GHN3_OP_ADAMW_CAST16) -- then only the other copies (W0^T, the Graphormer linears) are re-cast
+        w2 = getattr(self, '_shadow_w2_state', None)
+        w2_current = w2 is not None and w2 == (ver, bool(prog.training), types)
+        self._ctx().run(prog.shadow_ops_rest if w2_current else prog.shadow_ops, prog.problems, plan.bufs, stream)
         self._shadow_state = (ver, bool(prog.training), types)
 
     def fix_embed_layers(self):

@@ -7,6 +7,8 @@ Replaces, for a ghn3_amd.GHN3 whose parameters and gradients live in one flat fp
 by two kernels over the flat buffers (GHN3_OP_SUMSQ + GHN3_OP_ADAMW) -- no per-tensor launches.
 """
 
+import os
+
 import numpy as np
 import torch
 
@@ -36,22 +38,51 @@ class FusedAdamW:
         self.exp_avg_sq = torch.zeros_like(flat)
         self.scal = torch.zeros(16 + 4096, dtype=torch.float32, device=flat.device)   # [norm^2 ...| partial sums]
         self.steps = 0
+        self._w2_descs = {}
 
-    def step(self, gflat, grad_scale=1.0):
+    def _w2_fusion(self, plan):
+        """(lo, hi, device descriptor table, work tiles, state key) when this step may write the 16-bit copies of
+        decoder.conv.2.weight itself (GHN3_OP_ADAMW_CAST16), else None: the plan's program casts W2, the copies exist and were
+        current for the parameters of the last forward."""
+        ghn = self.ghn
+        prog = plan.program if plan is not None else None
+        w2 = getattr(prog, 'shadow_w2', None) if prog is not None else None
+        if w2 is None or not prog.training or ghn._shadow is None or os.environ.get('GHN3_ADAMW_CAST', '1') == '0':
+            return None
+        st = ghn._shadow_state
+        if st is None or st[0] != ghn._shadow_version():
+            return None
+        it = w2['item']
+        if it['ld_src'] != it['cols'] or it['cols'] % 4:
+            return None
+        lo = int(ghn._offs[prog.slot[w2['name']]])
+        key = (it['rows'], it['cols'], tuple(it.get('straight') or ()), tuple(it.get('transposed') or ()))
+        if key not in self._w2_descs:
+            descs, blocks = prog.pack_cast_descs([it])
+            self._w2_descs[key] = (torch.from_numpy(descs.view(np.uint8).copy()).to(ghn._flat.device), blocks)
+        d, blocks = self._w2_descs[key]
+        types = (prog.decoder_ctype, prog.decoder_bwd_ctype, prog.x3, prog.uses_op16)
+        return lo, lo + it['rows'] * it['cols'], d, blocks, types
+
+    def step(self, gflat, grad_scale=1.0, plan=None):
         """gflat: the flat gradient buffer of the last backward (plan.gflat); grad_scale: the loss scale the gradients
         carry (AMP: they are divided by it inside the kernel, no separate unscale pass).  Returns the gradient norm
         (device scalar, like clip_grad_norm_) when clipping or the NaN guard is on; when it is not finite the kernel
-        left parameters and moments untouched."""
+        left parameters and moments untouched.
+        plan: the plan of the step's forward / backward.  With it the update of decoder.conv.2.weight (69 % of the
+        parameters at ghn3xlm16) also writes the weight's 16-bit operand copies (GHN3_OP_ADAMW_CAST16), so the next
+        forward does not read the 1.8 GB again to re-cast them; same parameters bit for bit."""
         ghn = self.ghn
         flat = ghn._flat
         assert gflat.numel() == flat.numel() and gflat.is_cuda
         self.steps += 1
         n = flat.numel()
         clip = self.max_grad_norm and self.max_grad_norm > 0
-        ops = np.zeros(3, dtype=L.OP_DT)
+        fuse = self._w2_fusion(plan)
+        ops = np.zeros(5, dtype=L.OP_DT)
         ops['r']['buf'][:] = -1
-        bufs = np.asarray([flat.data_ptr(), gflat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
-                           self.scal.data_ptr(), self.scal.data_ptr() + 64], dtype=np.uint64)
+        bufs = [flat.data_ptr(), gflat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                self.scal.data_ptr(), self.scal.data_ptr() + 64, 0, 0]
         ops[0]['kind'] = L.OP_MEMSET0
         ops[0]['r']['buf'][0] = 4
         ops[0]['i'][0] = 4
@@ -59,17 +90,33 @@ class FusedAdamW:
         ops[1]['kind'] = L.OP_SUMSQ if guard else L.OP_NOP
         ops[1]['r']['buf'][:3] = (4, 1, 5)         # (r2: scratch for the fixed-order sum of the workgroup partials)
         ops[1]['i'][0] = n
-        ops[2]['kind'] = L.OP_ADAMW
-        ops[2]['r']['buf'][:5] = (0, 1, 2, 3, 4 if guard else -1)
-        ops[2]['i'][0] = n
         hyper = (self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                  1.0 - self.betas[0] ** self.steps, 1.0 - self.betas[1] ** self.steps)
-        for k, h in enumerate(hyper):
-            ops[2]['i'][1 + k] = _dbits(h)
-        ops[2]['f'][0] = float(self.max_grad_norm or 0.0) if clip else 0.0
-        ops[2]['f'][1] = 1.0 / float(grad_scale)
-        ghn._ctx().run(ops, np.zeros(0, dtype=L.PROBLEM_DT), bufs, torch.cuda.current_stream().cuda_stream)
+
+        def adamw(op, kind, lo, count):
+            op['kind'] = kind
+            op['r']['buf'][:5] = (0, 1, 2, 3, 4 if guard else -1)
+            op['r']['off'][:4] = 4 * lo
+            op['i'][0] = count
+            for k, h in enumerate(hyper):
+                op['i'][1 + k] = _dbits(h)
+            op['f'][0] = float(self.max_grad_norm or 0.0) if clip else 0.0
+            op['f'][1] = 1.0 / float(grad_scale)
+
+        if fuse is None:
+            adamw(ops[2], L.OP_ADAMW, 0, n)
+        else:
+            lo, hi, descs, blocks, types = fuse
+            bufs[6], bufs[7] = ghn._shadow.data_ptr(), descs.data_ptr()
+            adamw(ops[2], L.OP_ADAMW, 0, lo)
+            adamw(ops[3], L.OP_ADAMW, hi, n - hi)
+            adamw(ops[4], L.OP_ADAMW_CAST16, lo, 1 + (blocks << 32))
+            ops[4]['r']['buf'][5:7] = (6, 7)
+        ghn._ctx().run(ops, np.zeros(0, dtype=L.PROBLEM_DT), np.asarray(bufs, dtype=np.uint64),
+                       torch.cuda.current_stream().cuda_stream)
         ghn.params_changed()                     # (the kernel wrote the parameters through raw pointers)
+        if fuse is not None:
+            ghn._shadow_w2_state = (ghn._shadow_version(), True, fuse[4])
         return self.scal[0].sqrt() / float(grad_scale) if guard else None
 
     # ------------------------------------------------------------------ checkpoints (trainer.py:413-432)

@@ -154,6 +154,11 @@ class Program:
         if self._ops:
             self.op(L.OP_DETACH)
         self.shadow_ops = self._finish_ops()
+        self.shadow_ops_rest = self.shadow_ops
+        if getattr(self, 'shadow_w2', None) is not None:
+            self.shadow_ops_rest = self.shadow_ops.copy()
+            assert int(self.shadow_ops_rest[self.shadow_w2['op']]['kind']) == L.OP_CAST16
+            self.shadow_ops_rest[self.shadow_w2['op']]['kind'] = L.OP_NOP
         self._build_forward()
         self.fwd_ops = self._finish_ops()
         self.n_fwd_problems = len(self._probs)
@@ -265,6 +270,16 @@ class Program:
     def cast16(self, src_base, items, dbias=None, flags=0, grid_cap=0, amax=None, dst_base=None):
         """One GHN3_OP_CAST16 over `items` = dicts(src_off [floats from src_base], rows, cols, ld_src,
         straight=(off_halfs, ld, ctype) | None, transposed=(off_halfs, ld, ctype) | None, colsum=(q, s) | None)."""
+        descs, blocks = self.pack_cast_descs(items, dbias is not None, amax is not None, dst_base is None)
+        if blocks:
+            self.op(L.OP_CAST16, refs=(src_base, dst_base or (self.xbuf(self.X_WS), 0), self.idx(descs),
+                                       dbias if dbias is not None else self.NONE,
+                                       amax if amax is not None else self.NONE), ints=(len(items), blocks, grid_cap),
+                    flags=flags)
+
+    @staticmethod
+    def pack_cast_descs(items, dbias=False, amax=False, ws_dst=True):
+        """ghn3_cast_desc table of `items` (see cast16) and its number of 64 x 64 work tiles."""
         descs = np.zeros(len(items), dtype=L.CAST_DT)
         blocks = 0
         for D, it in zip(descs, items):
@@ -281,13 +296,13 @@ class Program:
                 D['dstT_off'], D['ld_dstT'] = off, ld
                 dflags |= L.CAST_TRANSPOSED | (L.CAST_TRANSPOSED_BF16 if ct == L.CT_BF16 else 0)
             if it.get('colsum') is not None:
-                assert dbias is not None
+                assert dbias
                 D['bias_q'], D['bias_s'] = it['colsum'][:2]
                 D['bias_off'] = it['colsum'][2] if len(it['colsum']) > 2 else 0
                 dflags |= L.CAST_COLSUM
             if it.get('colsum_parts') is not None:
                 # deterministic column sums: one slot row per 64-row tile of the descriptor (dbias = the slot buffer)
-                assert dbias is not None
+                assert dbias
                 D['part_off'] = it['colsum_parts']
                 dflags |= L.CAST_COLSUM | L.CAST_COLSUM_PARTS
             if it.get('src_map'):
@@ -302,21 +317,17 @@ class Program:
                 assert it.get('split') and it['rows'] % 32 == 0 and it['cols'] % 32 == 0
                 dflags |= L.CAST_FRAG
             if it.get('scaled'):
-                assert amax is not None
+                assert amax
                 dflags |= L.CAST_SCALED
             if it.get('src16'):
                 # (source = a 16-bit matrix of the destination buffer that already carries the scale, see GHN3_CAST_SRC16)
-                assert not it.get('straight') and not it.get('split') and (dst_base is None)
+                assert not it.get('straight') and not it.get('split') and ws_dst
                 dflags |= L.CAST_SRC16
             assert it['ld_src'] % 4 == 0 and it['src_off'] % 4 == 0
             D['flags'] = dflags
             D['block_start'] = blocks
             blocks += ((it['rows'] + 63) // 64) * ((it['cols'] + 63) // 64)
-        if blocks:
-            self.op(L.OP_CAST16, refs=(src_base, dst_base or (self.xbuf(self.X_WS), 0), self.idx(descs),
-                                       dbias if dbias is not None else self.NONE,
-                                       amax if amax is not None else self.NONE), ints=(len(items), blocks, grid_cap),
-                    flags=flags)
+        return descs, blocks
 
     def idx(self, arr):
         raw = np.ascontiguousarray(arr).view(np.uint8).reshape(-1)
@@ -729,6 +740,9 @@ class Program:
                 self.w2hT_ld = lay['w2hT_ld']
                 self.w2hT = lay['w2hT']
                 item['transposed'] = (self.w2hT, self.w2hT_ld, bct)
+            # (the op a fused optimizer step makes unnecessary: GHN3_OP_ADAMW_CAST16 writes the same copies while it updates
+            # W2 -- FusedAdamW.step(plan=...), GHN3._refresh_shadows then replays shadow_ops_rest)
+            self.shadow_w2 = dict(op=len(self._ops), item=item, name='decoder.conv.2.weight')
             self.cast16(self.pref('decoder.conv.2.weight'), [item], flags=self.SIDE,
                         grid_cap=int(os.environ.get('GHN3_W2CAST_CAP', '512')) if self.SIDE else 0, dst_base=shadow)
             if self.training and (4 * C) % 64 == 0:
@@ -751,12 +765,16 @@ class Program:
                           transposed=(self.wfcT + p_ * C * 4 * C, 4 * C, L.CT_BF16), split=self.wfcT_lo) for p_ in range(S2)]
             self.cast16(self.pref('decoder.fc.0.weight'), items, flags=self.SIDE, dst_base=shadow)
         if self.x3:
-            # bf16 hi / lo copies of the Graphormer linears, straight (forward) and transposed (dgrad): one launch per
-            # layer (the source base of a cast op is one parameter; the four weights of a layer are addressed from its
-            # first one -- the flat parameter buffer is contiguous) -- on the main stream: layer 0 needs them at once
+            # bf16 hi / lo copies of the Graphormer linears, straight (forward) and transposed (dgrad): ONE launch for all
+            # layers (the source base of a cast op is one parameter; every weight is addressed from the first layer's first
+            # one -- the flat parameter buffer is contiguous) -- on the main stream: layer 0 needs them at once.
+            # (One launch per layer until round 4: 24 dependent launches of ~14 us each in front of every forward of a
+            # TRAINING step, where the weights change every step; GHN3_X3_CAST_PER_LAYER=1 restores that.)
+            per_layer = os.environ.get('GHN3_X3_CAST_PER_LAYER', '0') != '0'
+            base0 = 'gnn.0.%s' % self.X3_WEIGHTS[0][0]
+            items = []
             for l in range(self.Lyr):
-                base = 'gnn.%d.%s' % (l, self.X3_WEIGHTS[0][0])
-                items = []
+                base = 'gnn.%d.%s' % (l, self.X3_WEIGHTS[0][0]) if per_layer else base0
                 for name, r, c in self.X3_WEIGHTS:
                     e = lay['x3']['gnn.%d.%s' % (l, name)]
                     it = dict(src_off=self.param_gap(base, 'gnn.%d.%s' % (l, name)), rows=e['rows'], cols=e['cols'],
@@ -764,7 +782,11 @@ class Program:
                     if self.training:
                         it['transposed'] = (e['hiT'], e['rows'], L.CT_BF16)
                     items.append(it)
-                self.cast16(self.pref(base), items, dst_base=shadow)
+                if per_layer:
+                    self.cast16(self.pref(base), items, dst_base=shadow)
+                    items = []
+            if items:
+                self.cast16(self.pref(base0), items, dst_base=shadow)
 
     def param_gap(self, a, b):
         """floats from the start of parameter `a` to the start of parameter `b` in the flat parameter buffer (slot

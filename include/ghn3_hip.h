@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 15
+#define GHN3_ABI_VERSION 16
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -399,6 +399,15 @@ enum ghn3_op_kind {
      * r0 = base of the parameter gradients, r1 = base of the activations, r2 = table of 6 int64 per item: float offsets
      * {dgamma, dbeta} from r0 and {dy, x, mean, rstd} from r1 ; i: n_items, rows, C.  One writer per element, fixed order. */
     GHN3_OP_LN_PARAM_GRAD_BATCH = 34,
+    /* GHN3_OP_ADAMW applied to the SOURCE elements of a cast-descriptor table, which are then cast like GHN3_OP_CAST16 does:
+     * the 16-bit operand copies of a weight follow its optimizer update (trainer.py:379) without a second pass over it
+     * (decoder.conv.2.weight: 1.8 GB read again + a 1 ms side-stream launch in front of every training forward otherwise).
+     * r0..r4 as GHN3_OP_ADAMW (the descriptors' src_off are float offsets from r0 AND from r1..r3: congruent flat buffers);
+     * r5 = 16-bit destination base, r6 = ghn3_cast_desc table; i0 = n_desc + (work tiles << 32); i1..i7, f0, f1 as
+     * GHN3_OP_ADAMW.  Descriptors: fp32 source, cols % 4 == 0, no column map / scale / column sums; every source element
+     * belongs to exactly one descriptor.  A non-finite r4 leaves parameters, moments and copies untouched.  Same arithmetic
+     * per element as GHN3_OP_ADAMW (bit-identical parameters).  (ABI v16) */
+    GHN3_OP_ADAMW_CAST16 = 35,
     GHN3_OP_KIND_COUNT
 };
 

@@ -266,6 +266,60 @@ def test_shadow_copies_follow_the_parameters():
         assert torch.equal(e[p['offset']:p['offset'] + p['numel']], f[p['offset']:p['offset'] + p['numel']])
 
 
+def test_optimizer_step_writes_the_w2_copies_itself():
+    """FusedAdamW.step(plan=...) updates decoder.conv.2.weight through GHN3_OP_ADAMW_CAST16, which also writes the weight's
+    16-bit copies (straight and transposed): parameters and moments equal the plain step's bit for bit, the next refresh
+    skips the W2 cast (Program.shadow_ops_rest), and forward AND backward of the next step equal those of a model whose copies
+    were all re-cast.  A step the NaN guard skips leaves parameters and copies as they were."""
+    from ghn3_amd import FusedAdamW
+    nets_h, gb_h, _, _ = synthetic_case([48], 4800)
+    runs = {}
+    for fused in (True, False):
+        hip, _ = make_models(_cfg('ghn3tm8'), 7, compute='f16')
+        hip.train()
+        plan = hip.compile(nets_h, gb_h, training=True)
+        assert plan.program.shadow_w2 is not None
+        opt = FusedAdamW(hip, lr=1e-2, weight_decay=0.05, max_grad_norm=1.0)
+        torch.manual_seed(3)
+        outs = []
+        for k in range(3):
+            out = hip._run_forward(plan).clone()
+            dout = torch.randn(plan.program.out_numel, device='cuda') * 1e-3
+            hip._run_backward(plan, dout)
+            g = plan.gflat.clone()
+            opt.step(plan.gflat, plan=plan if fused else None)
+            if fused:
+                assert hip._shadow_w2_state is not None and hip._shadow_w2_state[0] == hip._shadow_version()
+            else:
+                assert hip._shadow_w2_state is None
+            outs.append((out, g))
+        torch.cuda.synchronize()
+        runs[fused] = (hip, opt, outs, plan)
+    (ha, oa, xa, pa), (hb, ob, xb, _) = runs[True], runs[False]
+    pred = pa.program.predicted
+    for k, ((o1, g1), (o2, g2)) in enumerate(zip(xa, xb)):
+        for p in pred:                                           # (the flat output has padding between the tensors)
+            sl = slice(p['offset'], p['offset'] + p['numel'])
+            assert torch.equal(o1[sl], o2[sl]), (k, p['attr'])
+        assert torch.equal(g1, g2), (k, float((g1 - g2).abs().max()))
+    assert torch.equal(ha._flat, hb._flat) and torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
+    sl = slice(pred[0]['offset'], pred[0]['offset'] + pred[0]['numel'])
+    assert float((xa[0][0][sl] - xa[2][0][sl]).abs().max()) > 0   # (the weights did change)
+    # a non-finite gradient: nothing moves, the copies stay valid
+    before = ha._flat.clone()
+    ha._run_forward(pa)
+    ha._run_backward(pa, torch.randn(pa.program.out_numel, device='cuda') * 1e-3)
+    pa.gflat[5] = float('nan')
+    oa.step(pa.gflat, plan=pa)
+    assert torch.equal(ha._flat, before)
+    again = ha._run_forward(pa).clone()
+    ref = GHN3_like(ha, 'f16')
+    want = ref._run_forward(ref.compile(nets_h, gb_h, training=True))
+    torch.cuda.synchronize()
+    for p in pa.program.predicted:
+        assert torch.equal(again[p['offset']:p['offset'] + p['numel']], want[p['offset']:p['offset'] + p['numel']])
+
+
 def GHN3_like(hip, compute):
     """A fresh model (fresh shadows) with the same weights."""
     from ghn3_amd import GHN3

@@ -437,18 +437,18 @@ def main():
         n_t = max(5, min(args.steps, 30))
         for _ in range(2):
             step()
-            opt.step(plan.gflat, plan=plan)
+            opt.step(plan.gflat, plan=plan, local_grads=True)
         torch.cuda.synchronize()
         t_t = time.perf_counter()
         for _ in range(n_t):
             step()
-            opt.step(plan.gflat, plan=plan)
+            opt.step(plan.gflat, plan=plan, local_grads=True)
         torch.cuda.synchronize()
         t_t = 1e3 * (time.perf_counter() - t_t) / n_t
         ea, eb = L.Event(), L.Event()
         ea.record(stream)
         for _ in range(n_t):
-            opt.step(plan.gflat, plan=plan)
+            opt.step(plan.gflat, plan=plan, local_grads=True)
         eb.record(stream)
         adam_ms = ea.elapsed_ms(eb) / n_t
         ghn.params_changed()

@@ -43,6 +43,7 @@ GEMM_ACCUM = 1
 GEMM_BIASGRAD = 2
 GEMM_OP16 = 4
 GEMM_X3 = 8
+GEMM_SUMSQ = 16
 CAST_STRAIGHT, CAST_TRANSPOSED, CAST_STRAIGHT_BF16, CAST_TRANSPOSED_BF16, CAST_COLSUM, CAST_SCALED = 1, 2, 4, 8, 16, 32
 CAST_TIGHT = 64
 CAST_SPLIT = 128

@@ -2018,13 +2018,62 @@ __global__ void sumsq_finish_kernel(float* __restrict__ out, const float* __rest
     __syncthreads();
     if (threadIdx.x == 0) { float t = 0.f; for (int k = 0; k < 256; ++k) t += tot[k]; out[0] += t; }
 }
-int ghn3_sumsq(float* out, const float* x, int64_t n, float* parts, hipStream_t s) {
+// plain sums of a slot table, one partial per workgroup (fixed order): parts[b] = sum of the floats block b strides over
+__global__ __launch_bounds__(256) void slot_sum_kernel(float* __restrict__ parts, const float* __restrict__ x, int n) {
+    __shared__ float part[4];
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    const int n4 = n >> 2;
+    const float4* x4 = reinterpret_cast<const float4*>(x);
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n4; i += gridDim.x * 256) {
+        const float4 v = x4[i];
+        a0 += v.x; a1 += v.y; a2 += v.z; a3 += v.w;
+    }
+    float acc = (a0 + a1) + (a2 + a3);
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) acc += x[(n4 << 2) + threadIdx.x];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) parts[blockIdx.x] = (part[0] + part[1]) + (part[2] + part[3]);
+}
+// skip_lo .. skip_hi: a range of x that is left out (its sum of squares arrives as `extra`: partial sums a producer of that
+// range left, e.g. the weight-gradient kernel's GHN3_GEMM_SUMSQ slots); needs `parts` (8192 floats then)
+int ghn3_sumsq(float* out, const float* x, int64_t n, float* parts, int64_t skip_lo, int64_t skip_hi, const float* extra,
+               int n_extra, hipStream_t s) {
     if (n <= 0) return GHN3_OK;
     if (reinterpret_cast<uintptr_t>(x) & 15) { ghn3_set_error("sumsq: buffer must be 16-byte aligned"); return GHN3_E_ARG; }
-    int64_t blocks = (n / 4 + 255) / 256;
-    blocks = blocks < 1 ? 1 : (blocks > 4096 ? 4096 : blocks);
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, s, out, x, n, parts);
-    if (parts) hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, out, parts, (int)blocks);
+    const bool skip = skip_hi > skip_lo;
+    if (skip || n_extra > 0) {
+        if (!parts || skip_lo < 0 || skip_hi > n || (skip_lo & 3) || (skip_hi & 3) || (n_extra > 0 && !extra)) {
+            ghn3_set_error("sumsq: a skipped range needs the scratch buffer, 4-float alignment and 0 <= lo <= hi <= n");
+            return GHN3_E_ARG;
+        }
+    }
+    auto blocks_of = [](int64_t m) { int64_t b = (m / 4 + 255) / 256; return (int)(b < 1 ? 1 : (b > 4096 ? 4096 : b)); };
+    if (!skip && n_extra <= 0) {
+        const int blocks = blocks_of(n);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(blocks), dim3(256), 0, s, out, x, n, parts);
+        if (parts) hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, out, parts, blocks);
+        return launch_ok("sumsq");
+    }
+    // parts: [<= 4096 of the range below the gap | <= 4032 of the range above it | 64 sums of the slot table]
+    int b0 = 0, b1 = 0, b2 = 0;
+    const int64_t lo = skip ? skip_lo : n, hi = skip ? skip_hi : n;
+    if (lo > 0) {
+        b0 = blocks_of(lo);
+        hipLaunchKernelGGL(sumsq_kernel, dim3(b0), dim3(256), 0, s, out, x, lo, parts);
+    }
+    if (n > hi) {
+        b1 = blocks_of(n - hi);
+        if (b1 > 4032) b1 = 4032;
+        hipLaunchKernelGGL(sumsq_kernel, dim3(b1), dim3(256), 0, s, out, x + hi, n - hi, parts + b0);
+    }
+    if (n_extra > 0) {
+        if (reinterpret_cast<uintptr_t>(extra) & 15) { ghn3_set_error("sumsq: slot table must be 16-byte aligned"); return GHN3_E_ARG; }
+        b2 = 64;
+        hipLaunchKernelGGL(slot_sum_kernel, dim3(b2), dim3(256), 0, s, parts + b0 + b1, extra, n_extra);
+    }
+    hipLaunchKernelGGL(sumsq_finish_kernel, dim3(1), dim3(256), 0, s, out, parts, b0 + b1 + b2);
     return launch_ok("sumsq");
 }
 

@@ -565,6 +565,11 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
     gf pC = nullptr;
     int p_ldc = 0, p_cq = 0, p_cs = 0, p_M = 0, p_N = 0, p_m0 = 0, p_n0 = 0;
     float p_alpha = 1.f;
+    // GHN3_GEMM_SUMSQ: sum of the squares of what this wave stores of a tile -> slot [8 * tile id + wave] (the squared gradient
+    // norm of clip_grad_norm_ then needs no pass over the 1.8 GB of dW2; fixed order inside a wave, one writer per slot)
+    float* p_sq = nullptr;
+    int p_tile = 0;
+    float ss = 0.f;
     auto store_prev = [&](int a, int b) {
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
@@ -578,9 +583,18 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
                     const f32x4 v = acc[a][b][mi][ni] * p_alpha;
                     if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<gf4>(crow + col));
                     else *reinterpret_cast<gf4>(crow + col) = v;
+                    if (p_sq) ss = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ss))));
                 }
             }
         }
+    };
+    auto finish_sq = [&]() {                          // behind the last quadrant's stores of a tile
+        if (!p_sq) return;
+        float t = ss;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (lane == 0) p_sq[p_tile * 8 + wave] = t;
+        ss = 0.f;
     };
 #ifdef GHN3_P8W_PROBE
     // tools/p8w_probe.hip: cycles of workgroup 0 / thread 0 per k-tile (first k-tile of a tile = the one that also stores the
@@ -637,7 +651,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
 #ifdef GHN3_P8W_PROBE
         pr_wait[st ? 0 : 1] += P8W_CLK() - pr_w0;
 #endif
-        if (st) P8W_ST_T(store_prev(1, 0));                     // (behind the wait: these stores are not waited for with the DMA)
+        if (st) { P8W_ST_T(store_prev(1, 0)); finish_sq(); }    // (behind the wait: these stores are not waited for with the DMA)
         P8W_BAR_T();
         mfma_q(1, 0, first);
         P8W_BAR_T();
@@ -666,12 +680,15 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
             p_m0 = c_m0; p_n0 = c_n0;
             const float* amax_p = rflp(Q->alpha_amax);
             p_alpha = rflf(amax_p ? Q->alpha * ghn3_pow2_inv_scale(*amax_p) : Q->alpha);
+            p_sq = (rfl(Q->flags) & GHN3_GEMM_SUMSQ) ? rflp(Q->aux_out) : nullptr;
+            p_tile = ct;
             p_valid = true;
         }
         ct = next_tile(ct + stride, c_idx, c_m0, c_n0, c_nkt);
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();        // pairs the extra barrier of wave row 1
     store_prev(0, 0); store_prev(0, 1); store_prev(1, 1); store_prev(1, 0);
+    finish_sq();
 #ifdef GHN3_P8W_PROBE
     if (blockIdx.x == 0 && tid == 0) {
         for (int i = 0; i < 2; ++i) { g_p8w_probe[3 * i] = pr_tot[i]; g_p8w_probe[3 * i + 1] = pr_wait[i]; g_p8w_probe[3 * i + 2] = pr_cnt[i]; }

@@ -117,7 +117,8 @@ int ghn3_wire_pack(void* dst, const void* src, int64_t n, int64_t n_pad, int rev
 int ghn3_rank_reduce(void* out, const void* in, int64_t per, int W, int in16, int out16, float scale, hipStream_t s);
 int ghn3_cast16(const float* src, void* dst, const ghn3_cast_desc* d_desc, int n_desc, int total_blocks, float* dbias,
                 const float* amax, int grid_cap, hipStream_t s);
-int ghn3_sumsq(float* out, const float* x, int64_t n, float* parts, hipStream_t s);
+int ghn3_sumsq(float* out, const float* x, int64_t n, float* parts, int64_t skip_lo, int64_t skip_hi, const float* extra,
+               int n_extra, hipStream_t s);
 int ghn3_adamw(float* p, const float* g, float* m, float* v, int64_t n, const float* sumsq, float lr, float beta1,
                float beta2, float eps, float weight_decay, float bias_corr1, float bias_corr2, float max_norm,
                float inv_scale, hipStream_t s);

@@ -363,7 +363,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                                "16-byte aligned C / aux / residual", k, q);
                                 return GHN3_E_ARG;
                             }
-                            if ((tl == 25 || tl == 29) && (p.bias.buf >= 0 || p.residual.buf >= 0 || p.aux_in.buf >= 0 || p.aux_out.buf >= 0 ||
+                            if ((tl == 25 || tl == 29) && (p.bias.buf >= 0 || p.residual.buf >= 0 || p.aux_in.buf >= 0 ||
+                                             (p.aux_out.buf >= 0 && !(tl == 29 && (p.flags & GHN3_GEMM_SUMSQ))) ||
                                              p.act != GHN3_ACT_NONE || p.dact != GHN3_DACT_NONE || p.a_gather.buf >= 0 ||
                                              p.b_gather.buf >= 0 || p.c_gather.buf >= 0 || p.a_q || p.b_q || p.b_kq ||
                                              p.lim.buf >= 0 || p.ksplit > 1 || (p.flags & GHN3_GEMM_ACCUM))) {
@@ -778,7 +779,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                              stream);
             break;
         case GHN3_OP_SUMSQ:
-            rc = ghn3_sumsq(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), o.i[0], R.get<float>(o.r[2]), stream);
+            rc = ghn3_sumsq(R.get<float>(o.r[0]), R.get<const float>(o.r[1]), o.i[0], R.get<float>(o.r[2]), o.i[1], o.i[2],
+                            R.get<const float>(o.r[3]), (int)o.i[3], stream);
             break;
         case GHN3_OP_ADAMW: {
             double h[7];

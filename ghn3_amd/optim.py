@@ -36,7 +36,7 @@ class FusedAdamW:
             raise L.Ghn3Error('FusedAdamW runs on an MI355X only (no CPU path)')
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
-        self.scal = torch.zeros(16 + 4096, dtype=torch.float32, device=flat.device)   # [norm^2 ...| partial sums]
+        self.scal = torch.zeros(16 + 8192, dtype=torch.float32, device=flat.device)   # [norm^2 ...| partial sums]
         self.steps = 0
         self._w2_descs = {}
 
@@ -64,14 +64,17 @@ class FusedAdamW:
         types = (prog.decoder_ctype, prog.decoder_bwd_ctype, prog.x3, prog.uses_op16)
         return lo, lo + it['rows'] * it['cols'], d, blocks, types
 
-    def step(self, gflat, grad_scale=1.0, plan=None):
+    def step(self, gflat, grad_scale=1.0, plan=None, local_grads=False):
         """gflat: the flat gradient buffer of the last backward (plan.gflat); grad_scale: the loss scale the gradients
         carry (AMP: they are divided by it inside the kernel, no separate unscale pass).  Returns the gradient norm
         (device scalar, like clip_grad_norm_) when clipping or the NaN guard is on; when it is not finite the kernel
         left parameters and moments untouched.
         plan: the plan of the step's forward / backward.  With it the update of decoder.conv.2.weight (69 % of the
         parameters at ghn3xlm16) also writes the weight's 16-bit operand copies (GHN3_OP_ADAMW_CAST16), so the next
-        forward does not read the 1.8 GB again to re-cast them; same parameters bit for bit."""
+        forward does not read the 1.8 GB again to re-cast them; same parameters bit for bit.
+        local_grads: `gflat` is exactly what the plan's last backward wrote (NOT averaged over ranks afterwards).  The
+        squared norm of the W2 gradient is then taken from the sums the weight-gradient kernel left per output tile
+        (Program.grad_sumsq, GHN3_GEMM_SUMSQ) instead of from a pass over its 1.8 GB."""
         ghn = self.ghn
         flat = ghn._flat
         assert gflat.numel() == flat.numel() and gflat.is_cuda
@@ -90,6 +93,15 @@ class FusedAdamW:
         ops[1]['kind'] = L.OP_SUMSQ if guard else L.OP_NOP
         ops[1]['r']['buf'][:3] = (4, 1, 5)         # (r2: scratch for the fixed-order sum of the workgroup partials)
         ops[1]['i'][0] = n
+        gs = getattr(plan.program, 'grad_sumsq', None) if (plan is not None and local_grads and guard) else None
+        if gs is not None and getattr(plan, 'gflat', None) is gflat and os.environ.get('GHN3_WGRAD_SUMSQ', '1') != '0':
+            prog = plan.program
+            k2 = prog.slot[gs['name']]
+            lo2 = int(ghn._offs[k2])
+            hi2 = int(ghn._offs[k2 + 1]) if k2 + 1 < len(ghn._offs) else n     # (the slot's padding holds zeros)
+            bufs.append(int(plan.bufs[prog.xbuf(prog.X_WS)]) + gs['ws_off'])
+            ops[1]['i'][1:4] = (lo2, hi2, gs['count'])
+            ops[1]['r']['buf'][3] = len(bufs) - 1
         hyper = (self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
                  1.0 - self.betas[0] ** self.steps, 1.0 - self.betas[1] ** self.steps)
 

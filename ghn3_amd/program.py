@@ -375,7 +375,8 @@ class Program:
              bias_s=0, bias_stride=1, act=L.ACT_NONE, dact=L.DACT_NONE, aux_in=None, aux_out=None, residual=None,
              a_gather=None, b_gather=None, c_gather=None, a_qs=(0, 0), b_qs=(0, 0), c_qs=(0, 0), accum=False,
              alpha=1.0, dbias=None, dbias_stride=1, ksplit=1, op16=False, b_kmap=(0, 0), lim=None, lim_kind=0, alpha_amax=None,
-             ln=None, x3=None, xcd=None, mtiles=None):
+             ln=None, x3=None, xcd=None, mtiles=None, sumsq=None):
+        # sumsq = ref of the GHN3_GEMM_SUMSQ slot table (tile code 29)
         # mtiles = (ref of int32 triples {m0, mi, extent}, count): row-tile table of the 8-phase kernel (tile code 28)
         # ln = (kind, [refs p0..p5 or None], eps): LayerNorm row prologue of A (ghn3_gemm_problem::ln_kind)
         # dbias: fused bias gradient of a wgrad problem (GHN3_GEMM_BIASGRAD): dbias[cmap(m)*stride] += sum_k A(m,k)
@@ -384,7 +385,10 @@ class Program:
             bias, bias_stride = dbias, dbias_stride
         N_ = self.NONE
         flags = (L.GEMM_ACCUM if accum else 0) | (L.GEMM_BIASGRAD if dbias is not None else 0) | \
-            (L.GEMM_OP16 if op16 else 0) | (L.GEMM_X3 if x3 is not None else 0)
+            (L.GEMM_OP16 if op16 else 0) | (L.GEMM_X3 if x3 is not None else 0) | (L.GEMM_SUMSQ if sumsq is not None else 0)
+        if sumsq is not None:
+            assert aux_out is None
+            aux_out = sumsq
         # one plain tuple per problem (field order of _PROBLEM_REFS + _PROBLEM_INTS + the tail); the structured array
         # is packed column by column in _pack_problems -- filling a numpy record per call cost 15 us per problem
         self._probs.append((
@@ -1570,6 +1574,7 @@ class Program:
         self.bwd_cut_w2 = 0
         late_ops = []
         self.wgrad_op_range = None
+        self.grad_sumsq = None      # set when the W2 weight gradient leaves its own sum of squares (see the band problems)
 
         d_rows = self.wsf('d_xrows', (M + n1) * C)
         # ---- tile backward -------------------------------------------------------------------------
@@ -1954,6 +1959,24 @@ class Program:
                     self.grad_no_memset.append(W2)      # every row of dW2 is written by the band problems
                 p0 = len(self._probs)
                 fl = 0.0
+                # Sum of squares of dW2 from the weight-gradient kernel itself (GHN3_GEMM_SUMSQ: one slot per output tile and
+                # wave), when the band problems are its only writers: FusedAdamW's clip_grad_norm_ then skips the 1.8 GB.
+                # The table covers every tile id of the launch (the runtime numbers a problem's tiles XCD-blocked: at most
+                # tiles + 8 (tiles_m + tiles_n + 1) ids per problem); ids without a tile keep the zero of the memset.
+                wg_tile = int(os.environ.get('GHN3_WGRAD_TILE', '29'))
+                sq_on = covered and all(g_['op16'] for g_ in self.gemm_groups) and wg_tile == 29 and \
+                    os.environ.get('GHN3_WGRAD_SUMSQ', '1') != '0'
+                sq_ids = 0
+                if sq_on:
+                    for b_ in bands:
+                        thr = sorted({m_['o'] for m_ in b_['members']}, reverse=True)
+                        for j, o_hi in enumerate(thr):
+                            o_lo = thr[j + 1] if j + 1 < len(thr) else 0
+                            tm, tn = ((o_hi - o_lo) * b_['bw'] + 255) // 256, (8 * C + 255) // 256
+                            sq_ids += tm * tn + 8 * (tm + tn + 1)
+                    sq_ref = self.wsf('dw2_sq', 8 * sq_ids)
+                    self.op(L.OP_MEMSET0, refs=(sq_ref,), ints=(4 * 8 * sq_ids,))
+                    self.grad_sumsq = dict(name=W2, ws_off=sq_ref[1], count=8 * sq_ids)
                 for b_ in bands:
                     mem = b_['members']
                     fl += sum(2.0 * m_['rows'] * m_['o'] * b_['bw'] * 8 * C for m_ in mem)   # algorithmic
@@ -1965,7 +1988,7 @@ class Program:
                         self.gemm(self.href(b_['dthT'] + o_lo * b_['bw'] * b_['ktot']), self.href(b_['uhT']),
                                   self.gref(W2, (o_lo * ms[1] + b_['i_lo']) * 8 * C), (o_hi - o_lo) * b_['bw'], 8 * C,
                                   kpre, b_['ktot'], b_['ktot'], 8 * C, c_qs=(b_['bw'], ms[1]), op16=True,
-                                  alpha_amax=amax_t)
+                                  alpha_amax=amax_t, sumsq=sq_ref if sq_on else None)
                 # tile 25 = the persistent output-heavy kernel (K = the family's rows: 12 k-tiles per 256 KB of output):
                 # 1.44 -> 1.10 ms.  On the side stream it runs as 224 workgroups (GHN3_WGRAD_CAP), leaving 4 CUs per XCD
                 # to the dependent chain on the main stream, which the faster kernel otherwise slows down by what it
@@ -1980,7 +2003,7 @@ class Program:
                 # (GHN3_WGRAD_MAIN=0: side stream with GHN3_WGRAD_CAP workgroups, 160 gives the fastest step at frac 0.28).
                 wg_main = os.environ.get('GHN3_WGRAD_MAIN', '1') != '0'
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=not wg_main, flops=fl,
-                             tile=int(os.environ.get('GHN3_WGRAD_TILE', '29')),
+                             tile=wg_tile,
                              grid_cap=(int(os.environ.get('GHN3_WGRAD_CAP', '224')) |
                                        (int(os.environ.get('GHN3_WGRAD_TPW', '0')) << 16)) if (self.SIDE and not wg_main) else 0)
                 self.wgrad_op_range = (n_before, len(self._ops))

@@ -217,7 +217,8 @@ class Trainer:
         stats[0] = loss.detach()
         (loss * self.loss_scale).backward()              # backward program (+ overlapped gradient average, N > 1)
         # clip + AdamW on the flat buffers; a non-finite norm (NaN loss on any rank) skips the update everywhere
-        gnorm = self._optimizer.step(ghn.last_plan.gflat, grad_scale=self.loss_scale, plan=ghn.last_plan)
+        gnorm = self._optimizer.step(ghn.last_plan.gflat, grad_scale=self.loss_scale, plan=ghn.last_plan,
+                                     local_grads=not self.ddp)
         with torch.no_grad():
             bad = ~torch.isfinite(gnorm) if gnorm is not None else ~torch.isfinite(stats[0])
             vec = torch.cat([stats, bad.float().view(1)])

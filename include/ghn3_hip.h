@@ -96,6 +96,11 @@ enum { GHN3_DACT_NONE = 0, GHN3_DACT_RELU = 1 /* aux_in > 0 */, GHN3_DACT_GELU =
  * planes, x3_slice unused, N % 16 == 0.  These problems may carry the LayerNorm row prologue of A (ln_kind 1 / 2 below,
  * K <= 384, no a_gather): the Graphormer chain then needs no LayerNorm launches (graphormer.py:239-241 and its backward). */
 #define GHN3_GEMM_X3 8u
+/* Tile code 29 only (the persistent weight-gradient kernel): `aux_out` = base of a float slot table; the kernel writes
+ * the sum of the squares of what it stored of each output tile to aux_out[8 * t + w] (t = the tile's id inside the launch,
+ * w = wave 0..7; slots of ids that name no tile are not written: zero the table first).  The squared gradient norm of
+ * clip_grad_norm_ (trainer.py:356-360) then needs no pass over dW2: GHN3_OP_SUMSQ adds the slots.  (ABI v16) */
+#define GHN3_GEMM_SUMSQ 16u
 
 typedef struct ghn3_gemm_problem {
     ghn3_ref A, B, C;
@@ -354,7 +359,9 @@ enum ghn3_op_kind {
     GHN3_OP_DETACH = 25,
     /* trainer step over the flat buffers (trainer.py:356-381)
      * SUMSQ: r0[0] += sum x^2 (r1 = x, i0 = n floats; r2 = optional 4096 floats of scratch: per-workgroup partial sums
-     *        added in a fixed order instead of with float atomics) -- the squared global gradient norm of clip_grad_norm_
+     *        added in a fixed order instead of with float atomics) -- the squared global gradient norm of clip_grad_norm_.
+ *        i1 < i2: the floats [i1, i2) of x are left out (multiples of 4; r2 must then hold 8192 floats) and r3 = i3 partial
+ *        sums a producer of that range left (GHN3_GEMM_SUMSQ slots of the W2 weight gradient) are added instead (ABI v16)
      * ADAMW: torch.optim.AdamW on r0 = params, r1 = grads, r2 = exp_avg, r3 = exp_avg_sq (i0 = n floats);
      *        r4 = squared gradient norm or absent, f0 = max_norm (<= 0: no clipping): the gradient is scaled by
      *        min(1, max_norm / (norm + 1e-6)); a non-finite r4 skips the whole update (NaN guard, trainer.py:240-257);

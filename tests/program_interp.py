@@ -390,7 +390,11 @@ class Interp:
                     bi = (n // int(p['bias_q'])) * int(p['bias_s']) + n % int(p['bias_q'])
                 stride = int(p['bias_stride']) or 1
                 v = v + bias[bi * stride].astype(np.float64)[None, :]
-            if int(p['aux_out']['buf']) >= 0:
+            if int(p['flags']) & getattr(L, 'GEMM_SUMSQ', 16):
+                # GHN3_GEMM_SUMSQ: the slots of the table add up to the sum of the squares stored (the kernel's slot of a
+                # value is an implementation detail: here every problem adds into slot 0)
+                self.tail(p['aux_out'], np.float32)[0] += np.float32((v.astype(np.float32).astype(np.float64) ** 2).sum())
+            elif int(p['aux_out']['buf']) >= 0:
                 self.tail(p['aux_out'], np.float32)[ci] = v.astype(np.float32)
             act = int(p['act'])
             if act == L.ACT_RELU:

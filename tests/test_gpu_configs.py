@@ -320,6 +320,43 @@ def test_optimizer_step_writes_the_w2_copies_itself():
         assert torch.equal(again[p['offset']:p['offset'] + p['numel']], want[p['offset']:p['offset'] + p['numel']])
 
 
+@pytest.mark.parametrize('name,nodes,seed', [('ghn3tm8', [48], 4800), ('ghn3xlm16', [33, 60], 6)])
+def test_gradient_norm_from_the_weight_gradient_slots(name, nodes, seed):
+    """GHN3_GEMM_SUMSQ: the persistent W2 weight-gradient kernel leaves the sum of the squares of every output tile it stores;
+    FusedAdamW.step(local_grads=True) adds those slots instead of reading the W2 gradient again.  The norm equals the one of
+    the full pass (and torch's) to fp32 summation accuracy, with an upstream gradient and with the fused norm loss."""
+    from ghn3_amd import FusedAdamW
+    hip, _ = _models(name, 'f16')
+    hip.train()
+    nets_h, gb_h, _, _ = synthetic_case(nodes, seed)
+    plan = hip.compile(nets_h, gb_h, training=True)
+    prog = plan.program
+    assert prog.grad_sumsq is not None
+    keep = hip._flat.clone()
+    try:
+        for route in ('dout', 'norm'):
+            hip._run_forward(plan)
+            if route == 'dout':
+                hip._run_backward(plan, torch.randn(prog.out_numel, device='cuda') * 1e-3)
+            else:
+                hip._ctx().run(prog.norm_fin_ops(), prog.problems, plan.bufs, torch.cuda.current_stream().cuda_stream)
+                hip._run_backward(plan, None, norm_g=torch.ones(1, device='cuda'))
+            want = float(plan.gflat.double().norm())
+            k2 = prog.slot[prog.grad_sumsq['name']]
+            w2 = plan.gflat[int(hip._offs[k2]):int(hip._offs[k2 + 1])].double()
+            slots = plan.ws[prog.grad_sumsq['ws_off']:prog.grad_sumsq['ws_off'] + 4 * prog.grad_sumsq['count']].view(torch.float32)
+            assert abs(float(slots.double().sum()) - float((w2 * w2).sum())) <= 2e-6 * float((w2 * w2).sum())
+            norms = []
+            for local in (False, True):
+                opt = FusedAdamW(hip, lr=0.0, weight_decay=0.0, max_grad_norm=1e9)
+                norms.append(float(opt.step(plan.gflat, plan=plan, local_grads=local)))
+            assert abs(norms[0] - want) <= 2e-6 * want and abs(norms[1] - want) <= 2e-6 * want, (route, norms, want)
+    finally:
+        with torch.no_grad():
+            hip._flat.copy_(keep)
+        hip.params_changed()
+
+
 def GHN3_like(hip, compute):
     """A fresh model (fresh shadows) with the same weights."""
     from ghn3_amd import GHN3

@@ -471,6 +471,13 @@ def test_direct_16bit_tile_gradient_route(case):
         hip._patch_grad_memsets(prog)
         it.run(prog.bwd_ops, prog.problems)
         grads.append(gflat.view(np.float32).copy())
+        if prog.grad_sumsq is not None:
+            # GHN3_GEMM_SUMSQ: the weight-gradient problems leave the sum of the squares of dW2 in their slot table
+            gs = prog.grad_sumsq
+            slots = bufs[prog.xbuf(prog.X_WS)][gs['ws_off']:gs['ws_off'] + 4 * gs['count']].view(np.float32)
+            k2 = prog.slot[gs['name']]
+            w2g = grads[-1][int(hip._offs[k2]):int(hip._offs[k2 + 1])].astype(np.float64)
+            assert abs(float(slots.astype(np.float64).sum()) - float((w2g ** 2).sum())) <= 1e-5 * float((w2g ** 2).sum())
         amax = bufs[prog.xbuf(prog.X_WS)][prog.r_amax[1]:prog.r_amax[1] + 4].view(np.float32)[0]
         print('direct' if direct else 'fp32 route', 'amax slot', amax)
     a, b = grads

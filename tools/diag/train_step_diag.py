@@ -34,7 +34,7 @@ def bwd():
 
 
 def upd():
-    opt.step(plan.gflat, plan=plan if fused else None)
+    opt.step(plan.gflat, plan=plan if fused else None, local_grads=fused)
 
 
 for _ in range(3):

@@ -416,79 +416,102 @@ class _Cell:
         return torch.cat(outs, dim=1)
 
 
+def _layer_seq(Lyr, norm, spec):
+    """Sequential from a table of rows: ('conv', c_in, c_out, kernel, stride) -- bias-free, 'same' padding --, ('bn', c),
+    ('relu',), ('maxpool',), ('id',), ('linear', c_in, c_out), ('dropout',)."""
+    make = {'conv': lambda ci, co, k, st: Lyr.Conv2d(ci, co, k, stride=st, padding=k // 2, bias=False),
+            'bn': lambda c: bn_layer(Lyr, norm, c),
+            'relu': lambda: Lyr.ReLU(inplace=True),
+            'maxpool': lambda: Lyr.MaxPool2d(3, stride=2, padding=1, ceil_mode=False),
+            'id': lambda: Lyr.Identity(),
+            'linear': lambda ci, co: Lyr.Linear(ci, co),
+            'dropout': lambda: Lyr.Dropout(p=0.5, inplace=False)}
+    return Lyr.Sequential(*[make[row[0]](*row[1:]) for row in spec])
+
+
+def network_plan(C, num_classes, n_steps, n_cells, ks, is_imagenet_input, stem_pool, stem_type, imagenet_stride, is_vit,
+                 preproc, C_mult, fc_layers, fc_dim, glob_avg, multiplier):
+    """The widths of a DeepNets-1M network as data (the bookkeeping of ops.py:403-521, independent of the layer flavour):
+    {'stems': {attribute: layer table}, 'cells': [per cell: C_prev_prev, C_prev, C_in, C_out, reduction, reduction_prev],
+    'aux_at', 'head': layer table of the classifier}.  `multiplier` = (normal, reduction) cell: states it concatenates."""
+    hi_res = bool(is_imagenet_input)
+    stems, width0 = {}, C                                   # width of the two states entering cell 0
+    if is_vit:
+        pass                                                # (patch embedding + positional encoding: built by the caller)
+    elif stem_type == 0:
+        width0 = C * 3 if (preproc and not hi_res) else C
+        stems['stem'] = [('conv', 3, width0, ks, imagenet_stride if hi_res else 1), ('bn', width0),
+                         ('maxpool',) if stem_pool else ('id',)]
+    else:
+        st = 2 if hi_res else 1
+        stems['stem0'] = [('conv', 3, C // 2, ks, st), ('bn', C // 2), ('relu',), ('conv', C // 2, C, 3, st), ('bn', C)]
+        stems['stem1'] = [('relu',), ('conv', C, C, 3, 2), ('bn', C)]
+    reductions = {c for c in (n_cells // 3, 2 * n_cells // 3) if c > 0}
+    cells, width, older, newer = [], C, width0, width0
+    for c in range(n_cells):
+        red = c in reductions
+        width = width * C_mult if red else width
+        # (a single-step cell without preprocessing widens one cell ahead of the next reduction)
+        ahead = (c + 1) in reductions and n_steps == 1 and not preproc
+        cells.append(dict(C_prev_prev=older, C_prev=newer, C_in=width if preproc else newer,
+                          C_out=width * C_mult if ahead else width, reduction=red, out_width=multiplier[int(red)] * width,
+                          reduction_prev=(stem_type == 1) if c == 0 else cells[-1]['reduction']))
+        older, newer = newer, cells[-1]['out_width']
+    feat = newer
+    if not glob_avg:
+        small = stem_type == 1 or stem_pool
+        side = (7 if small else 14) if hi_res else (4 if small else 8)
+        feat *= side * side
+    dims = [feat] + [fc_dim] * (fc_layers - 1) + [num_classes]
+    assert fc_layers <= 1 or fc_dim > 0, fc_dim
+    head = []
+    for k in range(len(dims) - 1):
+        head += ([('relu',), ('dropout',)] if k else []) + [('linear', dims[k], dims[k + 1])]
+    return dict(stems=stems, cells=cells, aux_at=2 * n_cells // 3, head=head)
+
+
 class _Network:
-    """Stem + cells + classifier (ops.py:403-569)."""
+    """Stem + cells + classifier (ops.py:403-569): built from network_plan()'s tables."""
 
     def __init__(self, C, num_classes, genotype, n_cells, ks=3, is_imagenet_input=True, stem_pool=False, stem_type=0,
                  imagenet_stride=4, is_vit=None, norm='bn-track', preproc=True, C_mult=2, fc_layers=0, fc_dim=0,
                  glob_avg=True, auxiliary=False):
         super().__init__()
         Lyr, T = self.L, self.T
-        self.genotype, self._C, self._auxiliary = genotype, C, auxiliary
+        assert stem_type in (0, 1), ('either 0 (simple) or 1 (imagenet-style) stem must be chosen', stem_type)
+        n_steps = len(genotype.normal_concat)
+        assert preproc or (n_steps <= 1 and C_mult <= 1), 'preprocessing layers must be used in this case'
+        self.genotype, self._C, self._auxiliary, self._stem_type = genotype, C, auxiliary, stem_type
         self.drop_path_prob = 0
         self.expected_input_sz = 224 if is_imagenet_input else 32
-        self._is_vit = any(n[0] == 'msa' for n in genotype.normal + genotype.reduce) if is_vit is None else is_vit
-        steps = len(genotype.normal_concat)
-        if steps > 1 or C_mult > 1:
-            assert preproc, 'preprocessing layers must be used in this case'
-        assert stem_type in (0, 1), ('either 0 (simple) or 1 (imagenet-style) stem must be chosen', stem_type)
-        self._stem_type = stem_type
-        C_prev_prev = C_prev = C_curr = C
+        self._is_vit = is_vit if is_vit is not None else any(n[0] == 'msa' for n in genotype.normal + genotype.reduce)
+        self._n_cells, self._glob_avg = n_cells, glob_avg
+        plan = network_plan(C, num_classes, n_steps, n_cells, ks, is_imagenet_input, stem_pool, stem_type, imagenet_stride,
+                            self._is_vit, preproc, C_mult, fc_layers, fc_dim, glob_avg,
+                            multiplier=(len(genotype.normal_concat), len(genotype.reduce_concat)))
         if self._is_vit:
             self.stem0 = _make_op(T, Lyr, 'conv_stride', 3, C, 16 if is_imagenet_input else 3, None, None)
             self.pos_enc = T['PosEnc'](C, 14 if is_imagenet_input else 11)
-        elif stem_type == 0:
-            C_stem = int(C * (3 if (preproc and not is_imagenet_input) else 1))
-            self.stem = Lyr.Sequential(
-                Lyr.Conv2d(3, C_stem, ks, stride=imagenet_stride if is_imagenet_input else 1, padding=ks // 2, bias=False),
-                bn_layer(Lyr, norm, C_stem),
-                Lyr.MaxPool2d(3, stride=2, padding=1, ceil_mode=False) if stem_pool else Lyr.Identity())
-            C_prev_prev = C_prev = C_stem
-        else:
-            s = 2 if is_imagenet_input else 1
-            self.stem0 = Lyr.Sequential(
-                Lyr.Conv2d(3, C // 2, kernel_size=ks, stride=s, padding=ks // 2, bias=False), bn_layer(Lyr, norm, C // 2),
-                Lyr.ReLU(inplace=True),
-                Lyr.Conv2d(C // 2, C, kernel_size=3, stride=s, padding=1, bias=False), bn_layer(Lyr, norm, C))
-            self.stem1 = Lyr.Sequential(Lyr.ReLU(inplace=True), Lyr.Conv2d(C, C, 3, stride=2, padding=1, bias=False),
-                                        bn_layer(Lyr, norm, C))
-        self._n_cells = n_cells
+        for attr, spec in plan['stems'].items():
+            setattr(self, attr, _layer_seq(Lyr, norm, spec))
+        self._auxiliary_cell_ind = plan['aux_at']
         self.cells = Lyr.ModuleList()
-
-        def is_reduction(c):
-            return c > 0 and c in (n_cells // 3, 2 * n_cells // 3)
-        self._auxiliary_cell_ind = 2 * n_cells // 3
-        reduction_prev = stem_type == 1
-        for c in range(n_cells):
-            reduction = is_reduction(c)
-            if reduction:
-                C_curr *= C_mult
-            widen_next = is_reduction(c + 1) and steps == 1 and not preproc
-            cell = T['Cell'](genotype, C_prev_prev, C_prev, C_in=C_curr if preproc else C_prev,
-                             C_out=C_curr * (C_mult if widen_next else 1), reduction=reduction,
-                             reduction_prev=reduction_prev, norm=norm, is_vit=self._is_vit, preproc=preproc, cell_ind=c)
+        for c, w in enumerate(plan['cells']):
+            cell = T['Cell'](genotype, w['C_prev_prev'], w['C_prev'], C_in=w['C_in'], C_out=w['C_out'],
+                             reduction=w['reduction'], reduction_prev=w['reduction_prev'], norm=norm, is_vit=self._is_vit,
+                             preproc=preproc, cell_ind=c)
+            assert cell.multiplier * (w['out_width'] // cell.multiplier) == w['out_width']
             self.cells.append(cell)
-            reduction_prev = reduction
-            C_prev_prev, C_prev = C_prev, cell.multiplier * C_curr
-            if auxiliary and c == self._auxiliary_cell_ind:
+            if auxiliary and c == plan['aux_at']:
+                width = w['out_width']
                 if is_imagenet_input:
-                    self.auxiliary_head = T['AuxiliaryHeadImageNet'](C_prev, num_classes, norm=norm)
+                    self.auxiliary_head = T['AuxiliaryHeadImageNet'](width, num_classes, norm=norm)
                 else:
-                    self.auxiliary_head = T['AuxiliaryHeadCIFAR'](C_prev, num_classes, norm=norm,
+                    self.auxiliary_head = T['AuxiliaryHeadCIFAR'](width, num_classes, norm=norm,
                                                                   pool_sz=2 if (stem_type == 1 or stem_pool) else 5)
-        self._glob_avg = glob_avg
         if glob_avg:
             self.global_pooling = Lyr.AdaptiveAvgPool2d(1)
-        else:
-            small = stem_type == 1 or stem_pool
-            s = (7 if small else 14) if is_imagenet_input else (4 if small else 8)
-            C_prev *= s ** 2
-        fc = [Lyr.Linear(C_prev, fc_dim if fc_layers > 1 else num_classes)]
-        for k in range(fc_layers - 1):
-            assert fc_dim > 0, fc_dim
-            fc += [Lyr.ReLU(inplace=True), Lyr.Dropout(p=0.5, inplace=False),
-                   Lyr.Linear(in_features=fc_dim, out_features=fc_dim if k < fc_layers - 2 else num_classes)]
-        self.classifier = Lyr.Sequential(*fc)
+        self.classifier = _layer_seq(Lyr, norm, plan['head'])
         if Lyr.light:
             # the parameter table GHN3.forward walks (nn.py:612); built once, here
             self.__dict__['_layered_modules'] = named_layered_modules(self)

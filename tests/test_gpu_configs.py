@@ -320,6 +320,53 @@ def test_optimizer_step_writes_the_w2_copies_itself():
         assert torch.equal(again[p['offset']:p['offset'] + p['numel']], want[p['offset']:p['offset'] + p['numel']])
 
 
+def test_optimizer_step_writes_the_w2_copies_at_full_size():
+    """The same property at ghn3xlm16 (453 M W2 elements, 110,592 work tiles of the fused kernel), on ONE model: two fused steps
+    from a saved state against two plain steps from the same state with the same gradient -- parameters, both moments and
+    the W2 regions of the 16-bit copies (straight and transposed) bit for bit."""
+    from ghn3_amd import FusedAdamW
+    hip, _ = _models('ghn3xlm16', 'f16')
+    hip.train()
+    nets_h, gb_h, _, _ = synthetic_case([33, 60], 6)
+    plan = hip.compile(nets_h, gb_h, training=True)
+    prog = plan.program
+    keep = hip._flat.clone()
+    stream = torch.cuda.current_stream().cuda_stream
+    try:
+        hip._run_forward(plan)
+        hip._ctx().run(prog.norm_fin_ops(), prog.problems, plan.bufs, stream)
+        hip._run_backward(plan, None, norm_g=torch.ones(1, device='cuda'))
+        g = plan.gflat.clone()
+        got = {}
+        for fused in (True, False):
+            with torch.no_grad():
+                hip._flat.copy_(keep)
+            hip.params_changed()
+            hip._run_forward(plan)                               # (all copies current for the restored weights)
+            opt = FusedAdamW(hip, lr=1e-3, weight_decay=0.05, max_grad_norm=0.5)
+            for _ in range(2):
+                opt.step(g, plan=plan if fused else None)
+                if not fused:
+                    hip._run_forward(plan)                       # (the plain route re-casts in front of the next forward)
+            torch.cuda.synchronize()
+            assert (hip._shadow_w2_state is not None and hip._shadow_w2_state[0] == hip._shadow_version()) == fused
+            got[fused] = (hip._flat.clone(), opt.exp_avg.clone(), opt.exp_avg_sq.clone(), hip._shadow.clone())
+        a, b = got[True], got[False]
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2])
+        assert not torch.equal(a[0], keep)
+        lay, it = prog.shadow_lay, prog.shadow_w2['item']
+        sa, sb = a[3].view(torch.int16), b[3].view(torch.int16)
+        n1 = it['rows'] * it['cols']
+        assert torch.equal(sa[lay['w2h']:lay['w2h'] + n1], sb[lay['w2h']:lay['w2h'] + n1])
+        nT = it['cols'] * lay['w2hT_ld']
+        assert torch.equal(sa[lay['w2hT']:lay['w2hT'] + nT], sb[lay['w2hT']:lay['w2hT'] + nT])
+    finally:
+        with torch.no_grad():
+            hip._flat.copy_(keep)
+        hip.params_changed()
+        hip._shadow_w2_state = None
+
+
 @pytest.mark.parametrize('name,nodes,seed', [('ghn3tm8', [48], 4800), ('ghn3xlm16', [33, 60], 6)])
 def test_gradient_norm_from_the_weight_gradient_slots(name, nodes, seed):
     """GHN3_GEMM_SUMSQ: the persistent W2 weight-gradient kernel leaves the sum of the squares of every output tile it stores;

@@ -166,8 +166,26 @@ class _Plan:
         # the GPU.  A separate upload stream was measured and dropped: buffers allocated on it come from another pool of
         # the caching allocator, and the 2.3 GB workspace of every plan then costs a hipMalloc.)
         self.idx = pinned_ring(dev).upload(program.idx_blob, dev)
-        # zero-filled once: the padding of the 16-bit operand copies (Program.ws16) must read as finite zeros
-        self.ws = torch.zeros(program.ws_bytes, dtype=torch.uint8, device=dev)
+        # The padding of the 16-bit operand copies (Program.ws16 regions: 26 % of the 2.4 GB at ghn3xlm16 / 256 nodes) must read
+        # as finite zeros: those regions are zero-filled once per plan; every other region is written before it is read (or
+        # zeroed by an op of the programs) and starts uninitialised -- a NEW architecture every step paid 0.4 ms of GPU time
+        # for the full fill.  GHN3_WS_ZERO_ALL=1: the full fill; GHN3_WS_POISON=1 (tests): NaN bytes everywhere else.
+        regions = getattr(program, 'ws_zero', None)
+        self.ws_dout_ready = regions is None or os.environ.get('GHN3_WS_ZERO_ALL', '0') == '1'
+        if self.ws_dout_ready:
+            self.ws = torch.zeros(program.ws_bytes, dtype=torch.uint8, device=dev)
+        else:
+            self.ws = torch.empty(program.ws_bytes, dtype=torch.uint8, device=dev)
+            if os.environ.get('GHN3_WS_POISON', '0') == '1':
+                self.ws.fill_(0xff)
+            merged = []
+            for off, n in sorted(regions):
+                if merged and off <= merged[-1][1]:
+                    merged[-1][1] = max(merged[-1][1], off + n)
+                else:
+                    merged.append([off, off + n])
+            for a, b in merged:
+                self.ws[a:min(b, program.ws_bytes)].zero_()
         self.scal = torch.zeros(program.scal_bytes, dtype=torch.uint8, device=dev)
         self.bufs = np.zeros(program.n_bufs, dtype=np.uint64)
         self.sizes = [p['numel'] for p in program.predicted]
@@ -524,6 +542,11 @@ class GHN3(nn.Module):
         if dout is None and norm_g is None:
             raise L.Ghn3Error('backward without an upstream gradient')
         gflat = torch.empty(self._flat_numel, dtype=torch.float32, device=self.device)
+        if dout is not None and not getattr(plan, 'ws_dout_ready', False):
+            # (regions only the upstream-gradient route reads before it has written every byte of them: see _Plan)
+            for off, n in getattr(prog, 'ws_zero_dout', ()):
+                plan.ws[off:min(off + n, prog.ws_bytes)].zero_()
+            plan.ws_dout_ready = True
         self._fill_bufs(plan, out=plan.out, dout=dout, gflat=gflat)
         self._patch_grad_memsets(prog)
         kt = getattr(prog, 'tile_bwd_op', None)

@@ -262,7 +262,11 @@ class Program:
     def ws16(self, name, n_halfs):
         """workspace region of 16-bit elements (never written outside GHN3_OP_CAST16; the host zero-fills the
         workspace once, so its padding reads as zeros); returns the offset in 16-bit elements from the ws base."""
-        return self.ws(name, 2 * (int(n_halfs) + 128)) // 2
+        known = name in self._ws_names
+        off = self.ws(name, 2 * (int(n_halfs) + 128))
+        if not known:
+            self.__dict__.setdefault('ws_zero', []).append((off, round_up(2 * (int(n_halfs) + 128), ALIGN)))
+        return off // 2
 
     def href(self, off_halfs):
         return (self.xbuf(self.X_WS), 2 * int(off_halfs))
@@ -1586,6 +1590,9 @@ class Program:
         # ---- tile backward -------------------------------------------------------------------------
         if M > 0:
             self.wsf('d_tiles', self.tiles_floats)
+            # (fp32 tile gradient: its row padding is read -- and multiplied by zeros -- on the upstream-gradient route, so it
+            # must hold finite values: zero-filled by GHN3._run_backward in front of a plan's first backward on that route)
+            self.ws_zero_dout = [(self._ws_names['d_tiles'], 4 * (int(self.tiles_floats) + 64))]
             if 'clsout' in self._ws_names:
                 n_cls = sum(g['rows'] * g['i_ld'] for g in self.conv_groups if g['kind'] == 'cls')
                 self.wsf('d_clsout', n_cls * ldK)

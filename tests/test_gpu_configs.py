@@ -320,6 +320,40 @@ def test_optimizer_step_writes_the_w2_copies_itself():
         assert torch.equal(again[p['offset']:p['offset'] + p['numel']], want[p['offset']:p['offset'] + p['numel']])
 
 
+@pytest.mark.parametrize('compute', ['f16', 'f32'])
+def test_workspace_needs_zeros_only_where_the_program_says(compute, monkeypatch):
+    """A plan's workspace starts uninitialised except the regions Program.ws_zero names (the 16-bit operand copies, whose
+    padding the GEMMs read) and, on the upstream-gradient route, Program.ws_zero_dout: with every other byte set to 0xff
+    (NaN as fp32 / f16, -1 as an index) forward and both backward routes give the bits of a plan on a zero-filled workspace.
+    (The whole GPU suite passes with GHN3_WS_POISON=1 as well: that run is how the zero set was established.)"""
+    hip, _ = _models('ghn3xlm16', compute)
+    hip.train()
+    nets_h, gb_h, _, _ = synthetic_case([33, 60], 6)
+    res = {}
+    for mode in ('zeros', 'poison'):
+        monkeypatch.setenv('GHN3_WS_ZERO_ALL', '1' if mode == 'zeros' else '0')
+        monkeypatch.setenv('GHN3_WS_POISON', '0' if mode == 'zeros' else '1')
+        plan = hip.compile(nets_h, gb_h, training=True)
+        prog = plan.program
+        stream = torch.cuda.current_stream().cuda_stream
+        out = hip._run_forward(plan).clone()
+        hip._ctx().run(prog.norm_fin_ops(), prog.problems, plan.bufs, stream)
+        hip._run_backward(plan, None, norm_g=torch.ones(1, device='cuda'))
+        g_norm = plan.gflat.clone()
+        torch.manual_seed(11)
+        hip._run_backward(plan, torch.randn(prog.out_numel, device='cuda') * 1e-3)
+        g_dout = plan.gflat.clone()
+        torch.cuda.synchronize()
+        res[mode] = (prog, out, g_norm, g_dout)
+        hip._plans.clear() if hasattr(hip, '_plans') else None
+    (prog, o0, a0, b0), (_, o1, a1, b1) = res['zeros'], res['poison']
+    for p in prog.predicted:
+        sl = slice(p['offset'], p['offset'] + p['numel'])
+        assert torch.equal(o0[sl], o1[sl]), p['attr']
+    assert torch.isfinite(a1).all() and torch.isfinite(b1).all()
+    assert torch.equal(a0, a1) and torch.equal(b0, b1)
+
+
 def test_optimizer_step_writes_the_w2_copies_at_full_size():
     """The same property at ghn3xlm16 (453 M W2 elements, 110,592 work tiles of the fused kernel), on ONE model: two fused steps
     from a saved state against two plain steps from the same state with the same gradient -- parameters, both moments and

@@ -616,7 +616,7 @@ def main():
                        'workspace_bytes': int(prog.ws_bytes),
                        # every uint8 zero-fill of the run (workspace, scalar buffer, weight shadows): the known store
                        # size the WRITE_SIZE counter is calibrated against (tools/pmc_traffic.py)
-                       'zero_fill_bytes': int(prog.ws_bytes + prog.scal_bytes +
+                       'zero_fill_bytes': int(plan.zero_fill_bytes +
                                               (ghn._shadow.numel() if ghn._shadow is not None else 0)),
                        'parallelism': 'dp%d' % world, 'index_mode': ghn.index_mode,
                        'loss': 'fused into the tile kernels' if fused_loss else 'streaming norm passes',

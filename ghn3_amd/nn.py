@@ -172,6 +172,7 @@ class _Plan:
         # for the full fill.  GHN3_WS_ZERO_ALL=1: the full fill; GHN3_WS_POISON=1 (tests): NaN bytes everywhere else.
         regions = getattr(program, 'ws_zero', None)
         self.ws_dout_ready = regions is None or os.environ.get('GHN3_WS_ZERO_ALL', '0') == '1'
+        self.zero_fill_bytes = int(program.ws_bytes + program.scal_bytes)     # (what this plan zero-fills: see bench.py)
         if self.ws_dout_ready:
             self.ws = torch.zeros(program.ws_bytes, dtype=torch.uint8, device=dev)
         else:
@@ -186,6 +187,7 @@ class _Plan:
                     merged.append([off, off + n])
             for a, b in merged:
                 self.ws[a:min(b, program.ws_bytes)].zero_()
+            self.zero_fill_bytes = int(sum(min(b, program.ws_bytes) - a for a, b in merged) + program.scal_bytes)
         self.scal = torch.zeros(program.scal_bytes, dtype=torch.uint8, device=dev)
         self.bufs = np.zeros(program.n_bufs, dtype=np.uint64)
         self.sizes = [p['numel'] for p in program.predicted]

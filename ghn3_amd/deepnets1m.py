@@ -144,22 +144,63 @@ MAX_NODES_BATCH = 2200          # ppuda.deepnets1m.loader.MAX_NODES_BATCH (publi
 
 
 class DeepNets1MDDP(SampledNets, torch.utils.data.Dataset):
-    """``DeepNets1MDDP`` of deepnets1m.py:29-79 over the sampled architecture stream: same ``loader`` contract -- a training
-    loader comes with its (infinite, rank-aware) batch sampler, an evaluation loader alone; items are ``Graph`` objects with
-    ``.net`` / ``.net_args`` / ``.net_idx``, batches are ``GraphBatch`` objects.  The arguments that name DeepNets-1M files
-    (``nets_dir``, ``split`` other than train / val / test ...) are accepted and only select the stream's seed: there is no
-    json / hdf5 file to read here."""
+    """``DeepNets1MDDP`` of deepnets1m.py:29-153.  Two sources behind the same ``loader`` contract (a training loader comes
+    with its infinite, rank-aware batch sampler, an evaluation loader alone; items are ``Graph`` objects with ``.net`` /
+    ``.net_args`` / ``.net_idx``, batches are ``GraphBatch`` objects):
+
+      * the DeepNets-1M files, when ``nets_dir`` holds them (``deepnets1m_<split>.hdf5`` -- or the same arrays as ``.npz``
+        where h5py is missing -- and ``..._meta.json``; ghn3_amd.deepnets1m_io): ``__getitem__`` follows deepnets1m.py:84-153
+        -- per-visit width / stride draws in training, the stored graph repaired by ``init_graph``, a ``NetworkLight``
+        attached in training;
+      * otherwise a sampled architecture stream of the same search space (``SampledNets``: neither the dataset files nor
+        h5py exist in this image); ``split`` then only selects the stream's seed."""
 
     def __init__(self, split='train', nets_dir=None, virtual_edges=50, num_nets=None, large_images=False, dense=True,
-                 wider_nets=True, debug=False, verbose=False, seed=None, max_nodes=1000, light=True, **unused):
+                 wider_nets=True, debug=False, verbose=False, seed=None, max_nodes=1000, light=True, arch=None, **unused):
         assert dense, 'GHN-3 uses the dense layout'
         self.split, self.is_train, self.dense, self.wider_nets, self.debug = split, split == 'train', dense, wider_nets, debug
+        self.store = None
+        if nets_dir is not None:
+            from .deepnets1m_io import NetStore
+            store = NetStore(nets_dir, split)
+            if not store.exists() and nets_dir != './data':     # deepnets1m.py:38-46: fall back to a local ./data folder
+                store = NetStore('./data', split)
+            if store.exists():
+                self.store = store
+        if self.store is not None:
+            nets, self.primitives_ext, self.op_names_net = self.store.load_meta()
+            self.nets = nets[:len(nets) if num_nets is None else num_nets]
+            self.h5_idx = [arch] if arch is not None else None
+            self.nodes = np.asarray([net['num_nodes'] for net in self.nets], dtype=np.int64)   # (the sampler's node budget)
+            self.num_nets, self.large_images, self.virtual_edges = len(self.nets), large_images, virtual_edges
+            self.light, self.verbose, self.max_nodes, self.seed = light, verbose, max_nodes, 0
+            return
         if seed is None:                                        # disjoint streams per split
             seed = {'train': 0, 'val': 1, 'test': 2}.get(split, 3)
         if num_nets is None:
             num_nets = 10 ** 6 if self.is_train else 500
         SampledNets.__init__(self, num_nets=num_nets, large_images=large_images, seed=seed, virtual_edges=virtual_edges,
                              max_nodes=max_nodes, light=light, verbose=verbose)
+
+    def __len__(self):
+        return self.num_nets if self.store is None or self.h5_idx is None else len(self.h5_idx)
+
+    def __getitem__(self, idx):
+        if self.store is None:
+            return SampledNets.__getitem__(self, idx)
+        from . import deepnets1m_io as io
+        args = self.nets[idx if self.h5_idx is None else self.h5_idx[idx]]
+        idx = self.h5_idx[idx] if self.h5_idx is not None else idx
+        cell = ops.from_dict(args['genotype'])
+        net_args = io.item_net_args(args, cell, self.is_train, self.large_images, self.wider_nets, self.split)
+        adj, nodes = self.store.get(idx)
+        graph = io.init_graph(adj, nodes, net_args, self.primitives_ext, self.op_names_net,
+                              virtual_edges=self.virtual_edges, dense=self.dense, debug=self.debug)
+        graph.net_idx = idx
+        if self.is_train and not self.debug:
+            graph.net = ops.NetworkLight(is_imagenet_input=self.large_images, num_classes=1000 if self.large_images else 10,
+                                         **net_args)
+        return graph
 
     @staticmethod
     def loader(meta_batch_size=1, dense=True, num_workers=None, **kwargs):
@@ -168,25 +209,39 @@ class DeepNets1MDDP(SampledNets, torch.utils.data.Dataset):
         sampler = NetBatchSamplerDDP(nets, meta_batch_size) if nets.is_train else None
         if num_workers is None:                                 # (deepnets1m.py:74)
             num_workers = (0 if meta_batch_size <= 1 else min(8, max(4, meta_batch_size // 2))) if nets.is_train else 0
-        # The node budget of a meta-batch (deepnets1m.py:299 filters on node counts precomputed in the hdf5 file) is applied
-        # where the counts exist: in the collate function, which runs in the worker that built the graphs.
-        cap = sampler.max_nodes_batch if sampler is not None else None
+        # Node budget of a meta-batch (deepnets1m.py:288-300).  With the dataset files the node counts are in the meta file
+        # and the SAMPLER skips an over-budget meta-batch, exactly as the reference does; the sampled stream has no
+        # precomputed counts, so there the collate function enforces the budget once the graphs exist (collate_capped).
+        cap = sampler.max_nodes_batch if (sampler is not None and nets.store is None) else None
         loader = torch.utils.data.DataLoader(nets, batch_sampler=sampler, batch_size=1, pin_memory=False,
                                              collate_fn=partial(collate_capped, dense=dense, max_nodes_batch=cap),
                                              num_workers=num_workers)
         return (loader, sampler) if nets.is_train else loader   # (the sampler is returned for distributed training)
 
 
+TRUNCATED_BATCHES = [0, 0]          # [meta-batches truncated by collate_capped, graphs dropped] in this process (loader worker)
+
+
 def collate_capped(graphs, dense=True, max_nodes_batch=None):
-    """GraphBatch of a meta-batch under the node budget of deepnets1m.py:288-300.  The reference skips a meta-batch whose
-    precomputed node counts exceed the budget; this stream has no precomputed counts (architectures are sampled, their
-    graphs built by the loader workers), so the budget is enforced here, after the graphs exist: graphs are dropped from
-    the end of the meta-batch until it fits (at least one is kept)."""
+    """GraphBatch of a meta-batch under the node budget of deepnets1m.py:288-300.  The reference SKIPS a meta-batch whose
+    precomputed node counts exceed the budget (and this loader does the same when it reads the dataset files: the sampler
+    has the counts).  The sampled stream has no precomputed counts -- graphs are built by the loader workers -- so there
+    the budget is enforced here, after the graphs exist: graphs are dropped from the end of the meta-batch until it fits
+    (at least one is kept).  DEVIATION from the reference: the effective meta-batch of such a step is smaller (the trainer
+    divides by the number of networks it got); truncations are counted in TRUNCATED_BATCHES and on the batch
+    (``dropped_graphs``) so that a run can report them."""
     graphs = list(graphs)
+    dropped = 0
     if max_nodes_batch is not None:
         while len(graphs) > 1 and sum(int(g.n_nodes) for g in graphs) > max_nodes_batch:
             graphs.pop()
-    return GraphBatch(graphs, dense=dense)
+            dropped += 1
+    if dropped:
+        TRUNCATED_BATCHES[0] += 1
+        TRUNCATED_BATCHES[1] += dropped
+    gb = GraphBatch(graphs, dense=dense)
+    gb.dropped_graphs = dropped
+    return gb
 
 
 class NetBatchSamplerDDP(torch.utils.data.BatchSampler):
@@ -220,6 +275,11 @@ class NetBatchSamplerDDP(torch.utils.data.BatchSampler):
     def __len__(self):
         return (len(self.dataset) // self.world + self.batch_size - 1) // self.batch_size
 
+    def check_batch(self, batch):
+        """deepnets1m.py:298-301: with precomputed node counts (dataset files) an over-budget meta-batch is skipped."""
+        nodes = getattr(self.dataset, 'nodes', None) if getattr(self.dataset, 'store', None) is not None else None
+        return self.max_nodes_batch is None or nodes is None or int(nodes[batch].sum()) <= self.max_nodes_batch
+
     def __iter__(self):
         epoch = self.epoch
         while True:                                             # infinite sampler
@@ -227,10 +287,12 @@ class NetBatchSamplerDDP(torch.utils.data.BatchSampler):
             for idx in self.epoch_indices(epoch):
                 batch.append(int(idx))
                 if len(batch) == self.batch_size:
-                    yield batch
+                    if self.check_batch(batch):
+                        yield batch
                     batch = []
             if len(batch) > 0 and not self.drop_last:
-                yield batch
+                if self.check_batch(batch):
+                    yield batch
             epoch += 1
             if not self.dataset.is_train:
                 return

@@ -177,7 +177,7 @@ class _Plan:
             self.ws = torch.zeros(program.ws_bytes, dtype=torch.uint8, device=dev)
         else:
             self.ws = torch.empty(program.ws_bytes, dtype=torch.uint8, device=dev)
-            if os.environ.get('GHN3_WS_POISON', '0') == '1':
+            if os.environ.get('GHN3_WS_POISON', '0') == '1' or getattr(ghn, 'ws_poison', False):
                 self.ws.fill_(0xff)
             merged = []
             for off, n in sorted(regions):
@@ -204,11 +204,14 @@ class _GHN3Function(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        # (a stride-0 gradient is the placeholder _ParamNormLoss returns: the norm term is the only upstream gradient and
-        # the tile backward forms it from the predicted values -- nothing to read)
+        # (the placeholder _ParamNormLoss returned -- recognised by IDENTITY of its one-float storage, not by its strides: a
+        # genuine broadcast gradient such as flat.sum().backward() has the same layout -- means the norm term is the only
+        # upstream gradient and the tile backward forms it from the predicted values: nothing to read)
         plan = ctx.plan
         norm_g, plan.norm_g = getattr(plan, 'norm_g', None), None
-        if dout is not None and dout.dim() == 1 and dout.numel() > 1 and dout.stride(0) == 0:
+        ph, plan.norm_placeholder = getattr(plan, 'norm_placeholder', None), None
+        if dout is not None and ph is not None and dout.dim() == 1 and dout.stride(0) == 0 and \
+                dout.data_ptr() == ph.data_ptr():
             dout = None
         grads = ctx.ghn._run_backward(plan, None if dout is None else dout.contiguous(), reducer=ctx.ghn.grad_reducer,
                                       norm_g=norm_g)
@@ -250,8 +253,9 @@ class _ParamNormLoss(torch.autograd.Function):
             # hand the (device-side) weight of the term to the GHN's backward and return a stride-0 zero gradient: the
             # autograd engine still runs _GHN3Function.backward, which recognises the placeholder
             plan.norm_g = g.detach().to(torch.float32).reshape(1).contiguous()
+            plan.norm_placeholder = flat.new_zeros(1)
             ctx.ghn = ctx.plan = None
-            return flat.new_zeros(1).expand(flat.numel()), None, None
+            return plan.norm_placeholder.expand(flat.numel()), None, None
         dflat = torch.empty_like(flat)
         ghn._fill_bufs(plan, out=flat, dout=dflat)
         ghn._ctx().run(ctx.b_ops, plan.program.problems, plan.bufs, torch.cuda.current_stream().cuda_stream)
@@ -544,8 +548,11 @@ class GHN3(nn.Module):
         if dout is None and norm_g is None:
             raise L.Ghn3Error('backward without an upstream gradient')
         gflat = torch.empty(self._flat_numel, dtype=torch.float32, device=self.device)
-        if dout is not None and not getattr(plan, 'ws_dout_ready', False):
-            # (regions only the upstream-gradient route reads before it has written every byte of them: see _Plan)
+        # (the direct 16-bit tile route -- the fused norm term alone, and compiled in: not with GHN3_TILE_D16=0 / bf16 backward
+        # operands -- never reads the fp32 tile gradient; every other route does)
+        direct = dout is None and norm_g is not None and bool(getattr(prog, 'tile_bwd_h16', 0))
+        if not direct and not getattr(plan, 'ws_dout_ready', False):
+            # (regions only the fp32 tile-gradient route reads before it has written every byte of them: see _Plan)
             for off, n in getattr(prog, 'ws_zero_dout', ()):
                 plan.ws[off:min(off + n, prog.ws_bytes)].zero_()
             plan.ws_dout_ready = True

@@ -454,7 +454,8 @@ def network_plan(C, num_classes, n_steps, n_cells, ks, is_imagenet_input, stem_p
         # (a single-step cell without preprocessing widens one cell ahead of the next reduction)
         ahead = (c + 1) in reductions and n_steps == 1 and not preproc
         cells.append(dict(C_prev_prev=older, C_prev=newer, C_in=width if preproc else newer,
-                          C_out=width * C_mult if ahead else width, reduction=red, out_width=multiplier[int(red)] * width,
+                          C_out=width * C_mult if ahead else width, reduction=red, width=width,
+                          out_width=multiplier[int(red)] * width,
                           reduction_prev=(stem_type == 1) if c == 0 else cells[-1]['reduction']))
         older, newer = newer, cells[-1]['out_width']
     feat = newer
@@ -500,7 +501,8 @@ class _Network:
             cell = T['Cell'](genotype, w['C_prev_prev'], w['C_prev'], C_in=w['C_in'], C_out=w['C_out'],
                              reduction=w['reduction'], reduction_prev=w['reduction_prev'], norm=norm, is_vit=self._is_vit,
                              preproc=preproc, cell_ind=c)
-            assert cell.multiplier * (w['out_width'] // cell.multiplier) == w['out_width']
+            # (the planned width of the cell's output = what the built cell concatenates: ops.py:503 `multiplier * C_curr`)
+            assert cell.multiplier * w['width'] == w['out_width'], (c, cell.multiplier, w)
             self.cells.append(cell)
             if auxiliary and c == plan['aux_at']:
                 width = w['out_width']

@@ -260,8 +260,9 @@ class Program:
         return (self.xbuf(self.X_WS), self._ws_names[name] + 4 * off_floats)
 
     def ws16(self, name, n_halfs):
-        """workspace region of 16-bit elements (never written outside GHN3_OP_CAST16; the host zero-fills the
-        workspace once, so its padding reads as zeros); returns the offset in 16-bit elements from the ws base."""
+        """workspace region of 16-bit elements, written by GHN3_OP_CAST16 and -- the family matrices `dth` on the direct route --
+        by GHN3_OP_TILE_BWD; neither writes the k / row padding the GEMMs read, so the region is recorded in `ws_zero` and
+        zero-filled once per plan (_Plan); returns the offset in 16-bit elements from the ws base."""
         known = name in self._ws_names
         off = self.ws(name, 2 * (int(n_halfs) + 128))
         if not known:

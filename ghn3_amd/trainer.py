@@ -226,6 +226,8 @@ class Trainer:
                 dist.all_reduce(vec)
                 vec[:4] /= dist.get_world_size()
             self._skipped = getattr(self, '_skipped', torch.zeros((), device=dev)) + (vec[4] > 0).float()
+            # (steps whose AVERAGED loss is not finite, counted apart from overflowed gradients: only they can mean divergence)
+            self._bad_loss = getattr(self, '_bad_loss', torch.zeros((), device=dev)) + (~torch.isfinite(vec[0])).float()
             n = int(targets.numel()) * len(models) if images is not None else len(models)
             good = (vec[4] == 0).float()                 # (skipped steps enter neither the sums nor the counts)
             self.metrics.update(torch.nan_to_num(vec[:len(self.metrics.names)]) * good, good * n)
@@ -243,15 +245,30 @@ class Trainer:
         The host copy of the scale only changes here, so every step of the window since the last check ran at ONE scale:
         however many of them overflowed, that is one back-off (GradScaler halves once per overflowing step, each at a new
         scale).  After an overflow the check runs every step until a clean one (`_amp_hot`), so the warm-down from 65536
-        takes as many steps as GradScaler's.  The run is declared diverged only when a whole window was skipped although
-        its scale was already at the floor when the window STARTED (or without AMP, where no scale can be blamed)."""
-        total = int(getattr(self, '_skipped', torch.zeros(())).item())
+        takes as many steps as GradScaler's.
+
+        Divergence is decided on the LOSS, as the reference does (trainer.py:240-257: a NaN loss raises / skips the batch;
+        an fp16 overflow of the gradients at the floor scale is an ordinary skipped step there, trainer.py:364-379 -- its
+        comment says the scale routinely wants to fall below 1024): the run is declared diverged when the rank-averaged loss
+        was not finite in EVERY step of a window (accumulated over the one-step windows of the hot mode until
+        `amp_check_interval` consecutive steps are reached), or -- without AMP, where no scale can be blamed -- when a whole
+        window of updates was skipped."""
+        both = torch.stack([getattr(self, '_skipped', torch.zeros(())).float().cpu(),
+                            getattr(self, '_bad_loss', torch.zeros(())).float().cpu()]).tolist()
+        total, bad_total = int(both[0]), int(both[1])
         new = total - self.skipped_updates
+        new_bad = bad_total - getattr(self, '_bad_loss_seen', 0)
         steps = getattr(self, '_steps_since_check', 0)
         if steps == 0 and new == 0:
             return                                       # nothing ran since the last check
         self._steps_since_check = 0
         self.skipped_updates = total
+        self._bad_loss_seen = bad_total
+        # consecutive steps with a non-finite loss, across windows (a window with one good step resets the run)
+        self._bad_run = (getattr(self, '_bad_run', 0) + new_bad) if (steps > 0 and new_bad >= steps) else 0
+        if steps > 0 and self._bad_run >= (max(1, self.amp_check_interval) if self.amp else 1):
+            raise RuntimeError('the loss was not finite in the last %d steps (%d skipped updates in total): the GHN has '
+                               'diverged; restart from the saved checkpoint (--ckpt)' % (self._bad_run, total))
         if new > 0:
             self._optimizer.steps = max(0, self._optimizer.steps - new)
             window_scale = self.loss_scale               # the scale every step of this window used
@@ -259,10 +276,10 @@ class Trainer:
                 self.loss_scale = max(self.amp_min_scale, self.loss_scale * 0.5)
                 self._clean_steps = 0
                 self._amp_hot = True
-            if steps > 0 and new >= steps and (not self.amp or window_scale <= self.amp_min_scale):
-                raise RuntimeError('the loss / gradient norm was not finite in all of the last %d steps (%d skipped '
-                                   'updates in total%s): the GHN has diverged'
-                                   % (steps, total, ', loss scale at its floor %g' % window_scale if self.amp else ''))
+            if steps > 0 and new >= steps and not self.amp:
+                raise RuntimeError('the gradient norm was not finite in all of the last %d steps (%d skipped updates in '
+                                   'total): the GHN has diverged' % (steps, total))
+            del window_scale                             # (under AMP an overflow at the floor scale is a skipped step)
         else:
             self._amp_hot = False
             if self.amp:
@@ -273,9 +290,13 @@ class Trainer:
 
     # ------------------------------------------------------------------ checkpoints / logging
     def save(self, epoch, step, config, save_freq=300, interm_epoch=5):
-        if not ((((step + 1) % save_freq == 0) or step == self.n_batches - 1) and self.rank == 0):
+        if not (((step + 1) % save_freq == 0) or step == self.n_batches - 1):
             return
+        # On EVERY rank (the save condition does not depend on the rank): the check moves the loss scale, the check windows and
+        # the optimizer's bias-correction count -- host state all replicas must change at the same step -- and may raise.
         self._sync_skips()          # (the optimizer's bias-correction count must not include skipped steps when it is saved)
+        if self.rank != 0:
+            return
         if self.amp:
             config = dict(config or {}, amp_loss_scale=self.loss_scale, amp_clean_steps=self._clean_steps)
         save_checkpoint(self.checkpoint_path, self._model, self._optimizer, epoch, step, config)

@@ -484,15 +484,119 @@ def make_bench_goldens(which=('b1', 'b2r')):
         del ghn, named, loss
 
 
+# ------------------------------------------------------------------------------------------------
+# 5. DeepNets-1M records through the reference's own ``DeepNets1MDDP._init_graph`` (deepnets1m.py:155-279): stored
+#    adjacency + node ids (written by ghn3_amd.deepnets1m_io.record_from_graph from sampled architectures of the search
+#    space, in the new and the old naming, clean and with the two stored-graph defects injected) -> node features,
+#    repaired adjacency, node_info.  The base class (ppuda DeepNets1M) is not needed by the method: the instance is made
+#    with __new__ and given the attributes the method reads.
+# ------------------------------------------------------------------------------------------------
+
+def deepnets1m_cases():
+    """Inputs of the cases (shared by this script and tests/test_deepnets1m_cpu.py): name -> (adj, node triples, net_args)."""
+    from ghn3_amd import deepnets1m as D, ops
+    from ghn3_amd.graph import Graph as MyGraph
+    from ghn3_amd.deepnets1m_io import record_from_graph
+    nets = D.SampledNets(num_nets=1000, seed=11, max_nodes=400)
+    cases, seen = {}, set()
+    want = {('stem1', 'bn'), ('stem0', 'bn'), ('vit', 'bn')}
+    for idx in range(200):
+        g = nets[idx]
+        a = g.net_args
+        vit = any(n[0] == 'msa' for n in list(a['genotype'].normal) + list(a['genotype'].reduce))
+        kind = ('vit' if vit else 'stem%d' % a['stem_type'], a['norm'])
+        if kind not in want or (kind in seen and len([c for c in cases if c.startswith(kind[0])]) >= 4):
+            continue
+        seen.add(kind)
+        model = ops.Network(**a)
+        built = MyGraph(model, ve_cutoff=50)
+        for old in (False, True):
+            adj, triples = record_from_graph(built, old_names=old)
+            tag = '%s_%d%s' % (kind[0], idx, '_old' if old else '')
+            cases[tag] = (adj, triples, a)
+            if old:
+                continue
+            direct = (adj == 1)
+            # defect 1 (stem_type 1): the second cell hangs on stem0's last node instead of stem1's
+            if kind[0] == 'stem1':
+                # (the stored graphs list the stem's nodes first -- stem1's last node is node 6, deepnets1m.py:170 -- while the
+                # generation order of Graph(model) puts the first cell's preprocessing convolutions in front of it: reorder)
+                s0 = 4
+                s1 = [k for k, t in enumerate(triples) if t[2] == 'stem1.2.weight'][0]
+                perm = list(range(6)) + [s1] + [k for k in range(6, len(triples)) if k != s1]
+                adj_p, tri_p = adj[perm][:, perm], [triples[k] for k in perm]
+                assert tri_p[4][2] == 'stem0.4.weight' and tri_p[6][2] == 'stem1.2.weight' and \
+                    not np.tril(adj_p == 1).any()
+                cases[tag + '_stemorder'] = (adj_p.copy(), tri_p, a)
+                outs1 = np.nonzero(adj_p[6] == 1)[0]
+                if len(outs1) == 2:
+                    bad = adj_p.copy()
+                    bad[bad > 1] = 0
+                    bad[6, outs1[-1]] = 0
+                    bad[s0, outs1[-1]] = 1
+                    cases[tag + '_stemdefect'] = (_with_ve(bad), tri_p, a)
+            # defect 2: a layer with two producers
+            prims = [t[0] for t in triples]
+            cand = [k for k in range(8, len(prims)) if prims[k].startswith(('conv_', 'bn', 'sep_conv', 'dil_conv'))
+                    and direct[:, k].sum() == 1]
+            if cand:
+                k = cand[len(cand) // 2]
+                src = [j for j in range(k - 1) if not direct[j, k] and prims[j] != 'input'][-3]
+                bad = adj.copy()
+                bad[bad > 1] = 0
+                bad[src, k] = 1
+                cases[tag + '_twoproducers'] = (_with_ve(bad), triples, a)
+        if len(cases) >= 24:
+            break
+    return cases
+
+
+def _with_ve(A, cutoff=50):
+    from ghn3_amd.graph_build import _virtual_edges
+    return _virtual_edges(np.array(A, dtype=np.int64), cutoff)
+
+
+def make_deepnets1m_goldens():
+    install_standins()
+    sys.path.insert(0, REF)
+    import ghn3                                              # noqa: F401
+    from ghn3.deepnets1m import DeepNets1MDDP
+    out = {}
+    for tag, (adj, triples, a) in deepnets1m_cases().items():
+        prims, names = {}, {}
+        ids = np.zeros((len(triples), 3), dtype=np.int64)
+        for k, (ext, cell, name) in enumerate(triples):
+            ids[k] = (prims.setdefault(ext, len(prims)), cell, names.setdefault(name, len(names)))
+        ds = DeepNets1MDDP.__new__(DeepNets1MDDP)
+        ds.debug, ds.dense, ds.virtual_edges = False, True, 50
+        ds.primitives_ext = [n for n, _ in sorted(prims.items(), key=lambda kv: kv[1])]
+        ds.op_names_net = [n for n, _ in sorted(names.items(), key=lambda kv: kv[1])]
+        ds.primitives_dict = {op[:4]: i for i, op in enumerate(ppuda_base.PRIMITIVES_DEEPNETS1M)}
+        net_args = {k: v for k, v in a.items() if k not in ('is_imagenet_input', 'num_classes')}
+        g = ds._init_graph(adj.copy(), ids, net_args)
+        out[tag + '/node_feat'] = g.node_feat.view(-1).numpy().astype(np.int16)
+        out[tag + '/A'] = g._Adj.numpy().astype(np.int16)
+        out[tag + '/node_info'] = np.asarray([repr([(int(q[0]), str(q[1]), str(q[2]), None if q[3] is None else tuple(
+            int(v) for v in q[3]), bool(q[4]), bool(q[5])) for q in cell]) for cell in g.node_info])
+        out[tag + '/shapes'] = np.asarray([repr(None if s_ is None else tuple(int(v) for v in s_)) for s_ in g._param_shapes])
+        out[tag + '/in_adj_crc'] = np.asarray([int(np.asarray(adj, dtype=np.int64).sum()), int((adj == 1).sum())])
+        print(tag, 'nodes', len(triples), 'repaired edges', int((g._Adj.numpy() != np.minimum(adj, 50)).sum()))
+    np.savez_compressed(os.path.join(HERE, 'deepnets1m_cases.npz'), **out)
+    print('deepnets1m_cases.npz: %d arrays' % len(out))
+
+
 if __name__ == '__main__':
     # python make_golden.py            -> tiny fixtures (seconds)
     # python make_golden.py graphs     -> graphs.npz (reference Graph(model) on tests/golden/graph_nets.py)
     # python make_golden.py extra      -> ghn3_tiny_extra.npz (big kernels, weight_norm / layernorm off)
     # python make_golden.py networks   -> networks.npz (reference Network / NetworkLight on tests/golden/network_cases.py)
     # python make_golden.py resnet     -> + ResNet-18 / ghn3tm8 and ResNet-50 / ghn3xlm16 (minutes, ~10 GB of RAM)
+    # python make_golden.py deepnets1m -> deepnets1m_cases.npz (reference DeepNets1MDDP._init_graph on stored-format records)
     # python make_golden.py bench    -> bench_b1 / bench_b2r: the benchmarked ghn3xlm16 workload, forward + backward (minutes)
     torch.set_num_threads(8 if ('resnet' in sys.argv[1:] or 'bench' in sys.argv[1:]) else 4)
-    if 'bench' in sys.argv[1:]:
+    if 'deepnets1m' in sys.argv[1:]:
+        make_deepnets1m_goldens()
+    elif 'bench' in sys.argv[1:]:
         make_bench_goldens([a for a in sys.argv[1:] if a in BENCH_CASES] or tuple(BENCH_CASES))
     elif 'graphs' in sys.argv[1:]:
         make_graph_goldens()

@@ -354,6 +354,57 @@ def test_workspace_needs_zeros_only_where_the_program_says(compute, monkeypatch)
     assert torch.equal(a0, a1) and torch.equal(b0, b1)
 
 
+_POISON_VARIANTS = {
+    'no_side_stream': ({}, False), 'x3_off': ({'GHN3_X3': '0'}, True), 'x3s_off': ({'GHN3_X3S': '0'}, True),
+    'tile_d16_off': ({'GHN3_TILE_D16': '0'}, True), 'dgrad_planes_off': ({'GHN3_DGRAD_PLANES': '0'}, True),
+    'p8_off': ({'GHN3_P8': '0'}, True), 'wgrad_side': ({'GHN3_WGRAD_MAIN': '0'}, True)}
+
+
+@pytest.mark.parametrize('name,compute,variant', [('ghn3lm8', 'bf16', None)] +
+                         [('ghn3lm8', 'f16', v) for v in sorted(_POISON_VARIANTS)])
+def test_workspace_poison_on_the_other_routes(name, compute, variant, monkeypatch):
+    """The zero set of a plan's workspace (Program.ws_zero / ws_zero_dout) on the routes behind the compile-time switches --
+    bf16 operands, no side stream, the round-2 / round-3 Graphormer plans, fp32 tile gradient, atomically accumulated dgrad,
+    128 x 128 W2 tiles, side-stream weight gradient -- and another width (C = 256): poisoned (0xff) and zero-filled
+    workspaces give the same bits, forward and both backward routes."""
+    hip, _ = _models(name, compute)
+    hip.train()
+    env, side = _POISON_VARIANTS[variant] if variant else ({}, True)
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    nets_h, gb_h, _, _ = synthetic_case([33, 60], 6)
+    res = {}
+    old_side = hip.side_stream
+    hip.side_stream = side
+    try:
+        for mode in ('zeros', 'poison'):
+            monkeypatch.setenv('GHN3_WS_ZERO_ALL', '1' if mode == 'zeros' else '0')
+            monkeypatch.setenv('GHN3_WS_POISON', '0' if mode == 'zeros' else '1')
+            plan = hip.compile(nets_h, gb_h, training=True)
+            prog = plan.program
+            stream = torch.cuda.current_stream().cuda_stream
+            out = hip._run_forward(plan).clone()
+            hip._ctx().run(prog.norm_fin_ops(), prog.problems, plan.bufs, stream)
+            hip._run_backward(plan, None, norm_g=torch.ones(1, device='cuda'))
+            g_norm = plan.gflat.clone()
+            torch.manual_seed(11)
+            hip._run_backward(plan, torch.randn(prog.out_numel, device='cuda') * 1e-3)
+            g_dout = plan.gflat.clone()
+            torch.cuda.synchronize()
+            res[mode] = (prog, out, g_norm, g_dout)
+    finally:
+        hip.side_stream = old_side
+    (prog, o0, a0, b0), (_, o1, a1, b1) = res['zeros'], res['poison']
+    for p in prog.predicted:
+        sl = slice(p['offset'], p['offset'] + p['numel'])
+        assert torch.equal(o0[sl], o1[sl]), p['attr']
+    assert torch.isfinite(a1).all() and torch.isfinite(b1).all()
+    if variant == 'dgrad_planes_off':                    # (atomic accumulation: the one non-deterministic reduction)
+        assert float((a0 - a1).norm() / a0.norm()) < 1e-5 and float((b0 - b1).norm() / b0.norm()) < 1e-5
+    else:
+        assert torch.equal(a0, a1) and torch.equal(b0, b1)
+
+
 def test_optimizer_step_writes_the_w2_copies_at_full_size():
     """The same property at ghn3xlm16 (453 M W2 elements, 110,592 work tiles of the fused kernel), on ONE model: two fused steps
     from a saved state against two plain steps from the same state with the same gradient -- parameters, both moments and

@@ -117,8 +117,8 @@ def test_trainer_dynamic_loss_scale():
 def test_trainer_loss_scale_warm_down_from_the_default(tmp_path):
     """The normal fp16 warm-down (GradScaler: 65536 -> a scale the gradients fit, one halving per overflowing step) must not
     be mistaken for divergence: several consecutive overflow steps inside one check window are ONE back-off (they all ran at
-    the same scale), after an overflow every step is checked, and the run only counts as diverged when a whole window
-    overflows at a scale that was already at the floor when the window started.  The scale travels in the checkpoint."""
+    the same scale), after an overflow every step is checked, overflows at the floor scale are skipped steps, and the run only
+    counts as diverged when the LOSS is not finite amp_check_interval steps in a row.  The scale travels in the checkpoint."""
     from ghn3_amd import Trainer
     hip, _ = make_models(dict(recipe.TINY_CFG), recipe.TINY_SEED)
     tr = Trainer(hip, 'adamw', {'lr': 1e-4}, 'cosine', n_batches=100, grad_clip=5, device='cuda', epochs=2, amp=True,
@@ -147,9 +147,13 @@ def test_trainer_loss_scale_warm_down_from_the_default(tmp_path):
     tr2 = Trainer(hip2, 'adamw', {'lr': 1e-4}, 'cosine', n_batches=1000, grad_clip=5, device='cuda', epochs=2, amp=True,
                   save_dir=str(tmp_path))
     assert tr2.loss_scale == 2048.0 and tr2._optimizer.steps == 3
-    # divergence: whole windows of non-finite steps all the way down to the floor, then one more at the floor
+    # skipped steps at the floor scale are ordinary skipped steps (trainer.py:364-379 clamps the scale and goes on) ...
+    for _ in range(8):
+        tr.update(bad, targets, _batch(['resnet_tiny']))
+    assert tr.loss_scale == 1024.0
+    # ... divergence is a non-finite LOSS (trainer.py:240-257) in amp_check_interval consecutive steps
     with pytest.raises(RuntimeError):
-        for _ in range(8):
+        for _ in range(tr.amp_check_interval):
             tr.update(bad, targets, _batch(['resnet_tiny']))
     assert tr.loss_scale == 1024.0
 

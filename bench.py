@@ -291,6 +291,20 @@ def main():
     elapsed = time.perf_counter() - t0
     tags = ctx.profile_read_tags(reset=True)
     ctx.profile(0)
+    # The kernels' OWN durations, for `roofline`: a few untimed steps with the side stream serialised into the chain (profile
+    # mode 3: nothing co-runs with a timed kernel, side-stream grid caps dropped).  The timed region above runs the fastest
+    # schedule -- there the W2 weight gradient shares the chip with the Graphormer backward and its in-step duration
+    # (`roofline.kernels_in_step`) says how the two streams interleave, not what the kernel can do.
+    n_ser = max(3, min(10, args.steps))
+    ex_on, exchange['on'] = exchange['on'], False
+    ctx.profile(3)
+    ctx.profile_read_tags(reset=True)
+    for _ in range(n_ser):
+        step()
+    torch.cuda.synchronize()
+    tags_ser = ctx.profile_read_tags(reset=True)
+    ctx.profile(0)
+    exchange['on'] = ex_on
     t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     n_all = torch.tensor([float(n_pred)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -493,6 +507,11 @@ def main():
                 run_step(ghn, plan_b, dout_b, norms_b)
             torch.cuda.synchronize()
             t_b = (time.perf_counter() - t_b) / n_b
+            ctx.profile_read_tags(reset=True)
+            ctx.profile(3)                               # (the kernels' own durations: serialised, as for the headline line)
+            for _ in range(3):
+                run_step(ghn, plan_b, dout_b, norms_b)
+            torch.cuda.synchronize()
             tags_b = ctx.profile_read_tags(reset=True)
             ctx.profile(0)
             ea, eb = L.Event(), L.Event()
@@ -503,7 +522,7 @@ def main():
             fwd_b = ea.elapsed_ms(eb) / n_b
             dom_b = [prog_b.TAG_D3_FWD, prog_b.TAG_D3_DGRAD, prog_b.TAG_D3_WGRAD]
             fl_b = sum(prog_b.tag_flops.get(t, 0.0) for t in dom_b)
-            ms_b = sum(tags_b.get(t, (0.0, 0))[0] for t in dom_b) / n_b
+            ms_b = sum(tags_b.get(t, (0.0, 0))[0] for t in dom_b) / 3
             rows_b = prog_b.B * prog_b.N
             gfl_b = prog_b.Lyr * (24.0 * rows_b * prog_b.C ** 2 + 4.0 * prog_b.B * prog_b.N ** 2 * prog_b.C)
             dfl_b = sum(prog_b.tag_flops.get(t, 0.0) for t in (prog_b.TAG_D3_FWD, prog_b.TAG_D2_FWD, prog_b.TAG_D1_FWD))
@@ -512,7 +531,7 @@ def main():
                 'graphs_per_gpu': gpg, 'ms_per_step': 1e3 * t_b, 'value': n_pred_b / t_b, 'predicted_params': n_pred_b,
                 'decoder_rows': int(prog_b.M),
                 'roofline_frac': (fl_b / (ms_b * 1e-3) / 1e12 / PEAK_TFLOPS[args.compute]) if ms_b > 0 else None,
-                'w2_family_ms': ms_b,
+                'w2_family_ms': ms_b, 'wgrad_side_workgroups': int(getattr(prog_b, 'wgrad_cap', 0)),
                 'forward': {'ms': fwd_b, 'frac_of_16bit_mfma_peak': (gfl_b + dfl_b) / (fwd_b * 1e-3) / 1e12 / 2500.0}}
             del plan_b, dout_b
             torch.cuda.empty_cache()
@@ -575,29 +594,48 @@ def main():
         # FLOPs = 2*rows*8C*(o*i) per parameter group (only the W2 rows a group consumes), DESIGN.md 4.
         dom = [prog.TAG_D3_FWD, prog.TAG_D3_DGRAD, prog.TAG_D3_WGRAD]
         fl = sum(prog.tag_flops.get(t, 0.0) for t in dom)                   # per step
-        ms = sum(tags.get(t, (0.0, 0))[0] for t in dom) / args.steps        # per step
+        ms = sum(tags_ser.get(t, (0.0, 0))[0] for t in dom) / n_ser          # per step, kernels alone (serialised pass)
+        ms_in_step = sum(tags.get(t, (0.0, 0))[0] for t in dom) / args.steps   # per step, inside the timed region
         achieved = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         peak = PEAK_TFLOPS[args.compute]
-        detail = {}
-        for t, (tms, cnt) in sorted(tags.items()):
-            name = prog.TAG_NAMES.get(t, str(t))
-            detail[name] = {'ms_per_step': round(tms / args.steps, 4), 'launch_groups_per_step': cnt // args.steps}
-            if t in prog.tag_flops and tms > 0:
-                detail[name]['tflops'] = round(prog.tag_flops[t] / (tms / args.steps * 1e-3) / 1e12, 2)
+
+        def per_kernel(tg, n):
+            d = {}
+            for t, (tms, cnt) in sorted(tg.items()):
+                name = prog.TAG_NAMES.get(t, str(t))
+                d[name] = {'ms_per_step': round(tms / n, 4), 'launch_groups_per_step': cnt // n}
+                if t in prog.tag_flops and tms > 0:
+                    d[name]['tflops'] = round(prog.tag_flops[t] / (tms / n * 1e-3) / 1e12, 2)
+            return d
+        detail, detail_in_step = per_kernel(tags_ser, n_ser), per_kernel(tags, args.steps)
+        # whole path: algorithmic FLOPs of forward + backward (3 x the forward's: Graphormer 24 N C^2 + 4 N^2 C per layer,
+        # decoders on consumed rows / positions only) over the step time
+        rows_ = prog.B * prog.N
+        g_fl_ = prog.Lyr * (24.0 * rows_ * prog.C ** 2 + 4.0 * prog.B * prog.N ** 2 * prog.C)
+        d_fl_ = sum(prog.tag_flops.get(t, 0.0) for t in (prog.TAG_D3_FWD, prog.TAG_D2_FWD, prog.TAG_D1_FWD))
+        step_fl = 3.0 * (g_fl_ + d_fl_)
         # HBM bytes per step of the same kernels from the PMC counters: they cannot be collected inside this process, so
         # the number comes from the committed rocprofv3 --pmc passes over this exact workload (tools/pmc_profile.sh,
-        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE calibrated); null otherwise.
+        # FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950, WRITE_SIZE calibrated) -- and only from a file
+        # that was measured on THIS code (`code_hash` = ghn3_amd.build.source_hash() of the kernels + host compiler); null
+        # otherwise.
         traffic, traffic_src = None, None
         if (args.model, args.nodes, args.graphs_per_gpu, args.compute) == ('ghn3xlm16', 256, 1, 'f16'):
             import glob
-            cands = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic_xl_f16.json')))
-            if cands:
+            from ghn3_amd.build import source_hash
+            cur = source_hash()
+            for cand in sorted(glob.glob(os.path.join(ROOT, 'profiles', '*_pmc_traffic_xl_f16.json')), reverse=True):
                 try:
-                    with open(cands[-1]) as fh:
-                        traffic = float(json.load(fh)['hbm_bytes_per_step'])
-                    traffic_src = 'profiles/' + os.path.basename(cands[-1])
+                    with open(cand) as fh:
+                        rec = json.load(fh)
+                    if rec.get('code_hash') == cur:
+                        traffic = float(rec['hbm_bytes_per_step'])
+                        traffic_src = 'profiles/' + os.path.basename(cand)
+                        break
                 except Exception:
-                    traffic = None
+                    continue
+            if traffic is None:
+                traffic_src = 'no PMC pass of the current code (source hash %s) is committed: tools/gpu_round.sh' % cur
         out = {
             'metric': 'predicted-params/sec (GHN fwd+bwd), %s, %d-node graphs' % (args.model, args.nodes),
             'value': total_pred * args.steps / elapsed,
@@ -625,7 +663,17 @@ def main():
                          'frac': achieved / peak, 'traffic': traffic, 'traffic_unit': 'bytes per step',
                          'traffic_source': traffic_src,
                          'kernel': 'decoder W2 grouped GEMM (fwd + dgrad + wgrad), %s MFMA operands' % args.compute,
-                         'algorithmic_gflop_per_step': fl / 1e9, 'kernel_ms_per_step': ms, 'kernels': detail},
+                         'measured': 'HIP events around each launch in %d extra steps with the side stream serialised into the '
+                                     'chain (nothing co-runs, side-stream grid caps dropped): the kernels\' own durations; '
+                                     '`kernels_in_step` = the same events inside the timed region (fastest schedule: the '
+                                     'weight gradient shares the chip with the Graphormer backward)' % n_ser,
+                         'algorithmic_gflop_per_step': fl / 1e9, 'kernel_ms_per_step': ms, 'kernels': detail,
+                         'kernel_ms_per_step_in_step': ms_in_step, 'kernels_in_step': detail_in_step,
+                         'frac_in_step': (fl / (ms_in_step * 1e-3) / 1e12 / peak) if ms_in_step > 0 else None,
+                         # the whole path against the same peak: algorithmic forward + backward FLOPs / step time
+                         'frac_step': step_fl / (ms_per_step * 1e-3) / 1e12 / peak,
+                         'algorithmic_gflop_fwd_bwd': step_fl / 1e9,
+                         'wgrad_side_workgroups': int(getattr(prog, 'wgrad_cap', 0))},
         }
         out.update(extras)
         if op_breakdown is not None:

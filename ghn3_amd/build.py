@@ -13,7 +13,7 @@ ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, 'csrc')
 OUT_DIR = os.path.join(HERE, 'lib')
 LIB = os.path.join(OUT_DIR, 'libghn3_hip.so')
-SOURCES = ['gemm.hip', 'gemm_p8.hip', 'gemm_small.hip', 'gemm_x3.hip', 'gemm_x3d.hip', 'gemm_wg.hip', 'attention.hip', 'elementwise.hip', 'runtime.hip']
+SOURCES = ['gemm.hip', 'gemm_p8.hip', 'gemm_small.hip', 'gemm_x3.hip', 'gemm_x3d.hip', 'gemm_wg.hip', 'attention.hip', 'elementwise.hip', 'target_ops.hip', 'runtime.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'),
          '-I' + CSRC, '-Wno-unused-result'] + os.environ.get('GHN3_HIPCC_EXTRA', '').split()
 
@@ -30,6 +30,20 @@ def _stale(target, deps):
         return True
     t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
+
+
+def source_hash():
+    """sha256 over the HIP sources, the headers and the host compiler (what determines which kernels a step launches and how):
+    recorded with every PMC traffic figure (tools/pmc_traffic.py) so that bench.py never reports a figure measured on other
+    code, and printed by __graft_entry__.build()."""
+    import hashlib
+    h = hashlib.sha256()
+    files = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(('.hip', '.h'))]
+    files += [os.path.join(ROOT, 'include', 'ghn3_hip.h'), os.path.join(HERE, 'program.py')]
+    for f in files:
+        with open(f, 'rb') as fh:
+            h.update(os.path.basename(f).encode() + b'\0' + fh.read())
+    return h.hexdigest()[:16]
 
 
 def build(force=False, verbose=True):

@@ -559,7 +559,10 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         const ghn3_op& o = ops[k];
         int rc = GHN3_OK;
         R.bad = false;
-        const bool on_side = (o.flags & GHN3_OPFLAG_SIDE) && c->side_enabled && c->profile != 1;
+        const bool on_side = (o.flags & GHN3_OPFLAG_SIDE) && c->side_enabled && c->profile != 1 && c->profile != 3;
+        // A grid cap of a side-stream GEMM only exists to leave CUs to the chain it runs beside: serialised (no side stream,
+        // profile modes 1 / 3) the op takes the whole chip -- what mode 3 and the PMC passes measure is the kernel's own rate.
+        const int gemm_cap = ((o.flags & GHN3_OPFLAG_SIDE) && !on_side) ? 0 : (int)o.i[3];
         if (o.kind == GHN3_OP_JOIN) {
             const int mode = (int)o.i[0], id = (int)o.i[1] & 3;
             if (mode == 1) {                             // mark: the side-stream work issued so far
@@ -585,7 +588,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             main_dirty = true;
         }
         hipStream_t stream = on_side ? c->side : main_stream;
-        const bool timed = c->profile == 2 && (o.flags & GHN3_OPFLAG_TIMED);
+        const bool timed = (c->profile == 2 || c->profile == 3) && (o.flags & GHN3_OPFLAG_TIMED);
         if (c->profile == 1) HIPCHK(hipEventRecord(c->pe0, stream));
         if (timed) {
             if (c->pool_used >= 8192) { int rc2 = drain_pool(c); if (rc2) return rc2; }
@@ -610,19 +613,19 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                     rc = ghn3_gemm_x3_launch(ds + L.first, L.count, L.tiles, 40 + (L.tile - 4000) / 10,
                                              64 * (L.tile % 10), stream);
                 else if (L.tile == 48 || L.tile == 49)
-                    rc = ghn3_gemm_wg_launch(ds + L.first, L.count, L.tiles, (int)o.i[3], L.tile == 49 ? 128 : 64, stream);
+                    rc = ghn3_gemm_wg_launch(ds + L.first, L.count, L.tiles, gemm_cap, L.tile == 49 ? 128 : 64, stream);
                 else if (L.tile == 32)
                     rc = ghn3_gemm_small_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, L.with_ln, stream);
                 else if (L.tile == 29)
                     rc = ghn3_gemm_p8w_launch(ds + L.first, L.count, L.tiles,
-                                              (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, (int)o.i[3], stream);
+                                              (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, gemm_cap, stream);
                 else if (L.tile == 28)
                     rc = ghn3_gemm_p8_launch(ds + L.first, L.count, L.tiles,
-                                             (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, (int)o.i[3], stream);
+                                             (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, gemm_cap, stream);
                 else if (is16(L.tile))
                     rc = ghn3_gemm_h16d_launch(ds + L.first, L.count, L.tiles,
                                                L.tile == 16 ? 128 : L.tile == 20 ? 20 : L.tile == 25 ? 25 : 256,
-                                               (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, (int)o.i[3],
+                                               (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, gemm_cap,
                                                stream);
                 else
                     rc = ghn3_gemm_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, L.tile,

@@ -1,0 +1,644 @@
+// Target-network execution, first native slice: the dominant chain of the DeepNets-1M search space,
+//
+//     ReLU -> depthwise k x k convolution (stride, dilation) -> pointwise 1 x 1 convolution -> BatchNorm (batch statistics)
+//
+// = `DilConv` and each half of `SepConv` (/root/reference/ghn3/ops.py:198-240), forward and backward, as one op family on
+// NHWC (channels-last) fp32 activations.  The reference runs it as four ATen / MIOpen modules per direction (ReLU, grouped
+// conv, 1x1 conv, batch norm: ~9 passes over the activations forward, more backward) with weights the GHN predicted; here
+//
+//   forward   dwpw_fwd      one pass: ReLU + depthwise taps produce a [64 pixels x 32 channels] operand chunk in LDS, the
+//                           pointwise product runs on the bf16 matrix cores with SPLIT operands (hi + lo halves of both
+//                           factors, hi.hi + lo.hi + hi.lo: ~1e-5 relative, fp32 accumulate) against weight chunks converted
+//                           while staged, the epilogue writes the pre-norm activations z once and leaves per-tile
+//                           (mean, M2) of every channel;
+//             bn_finalize   Chan-combines the tiles in a fixed order -> mean, rstd;   bn_apply  normalises (one pass).
+//   backward  bn_bwd_partial + reduce_rows   sum dout, sum dout.xhat -> dgamma, dbeta;
+//             dwpw_bwd_data  dz is formed on the fly from (dout, z, statistics) as the operand of dy = dz W_pw (matrix
+//                            cores, same split arithmetic);
+//             pw_wgrad       dW_pw = dz^T y over pixel chunks: dz formed on the fly again, y RE-COMPUTED from x (never
+//                            stored), partial products per chunk + fixed-order reduction;
+//             dw_bwd_data    dx = 1[x > 0] . transposed depthwise taps of dy;   dw_wgrad  dW_dw partials + reduction.
+//
+// Everything is HBM-bound (K = C_in <= 512: a few hundred flops per byte at most), so the design minimises passes: x is read
+// by three kernels, z by three, nothing else of activation size except dy is materialised.  All reductions are deterministic
+// (fixed-order partial slots).  Weights are read IN PLACE: w_dw [C_in][ks][ks], w_pw [C_out][C_in], gamma / beta [C_out] are
+// views of the GHN's flat prediction buffer; their gradients are written densely for autograd to route back into it.
+// Limits (checked by the host): C_in, C_out multiples of 4 and <= 512, ks <= 7 (odd or even), N H W C < 2^31.
+
+#include <algorithm>
+#include "ghn3_internal.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int TP = 64;       // pixels per tile (4 waves x 16-row MFMA tiles)
+constexpr int KC = 32;       // reduction chunk = one v_mfma_f32_16x16x32_bf16 k-step
+constexpr int LDK = 40;      // LDS row pitch in 16-bit elements (80 bytes: 16-byte aligned fragments)
+constexpr int MAXT = 49;     // taps (ks <= 7)
+
+struct Desc {
+    int N, H, W, C_in, C_out, ks, stride, pad, dil, Ho, Wo;
+    float eps;
+};
+
+__device__ __forceinline__ unsigned short bf16_rn(float v) {
+    unsigned u = __float_as_uint(v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+__device__ __forceinline__ void split2(float v, unsigned short& hi, unsigned short& lo) {
+    hi = bf16_rn(v);
+    lo = bf16_rn(v - __uint_as_float((unsigned)hi << 16));
+}
+// acc[e] += sum_k A[lane & 15][k] B[4 (lane >> 4) + e][k]   (B fragment first: a lane owns 4 consecutive columns of a row)
+__device__ __forceinline__ f32x4 mfma_bt(u16x8 b, u16x8 a, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, b), __builtin_bit_cast(bf16x8, a), c, 0, 0, 0);
+}
+__device__ __forceinline__ u16x8 frag(const unsigned short* base, int row, int kc) {
+    return *reinterpret_cast<const u16x8*>(base + row * LDK + 8 * kc);
+}
+
+// ReLU + depthwise taps of 8 consecutive channels c .. c + 7 at output pixel (n, oh, ow); ih0 / iw0 = input origin of the
+// pixel's window; wt = taps x `wld` floats in LDS, channel cc of the chunk at wt[t * wld + cc]
+__device__ __forceinline__ void dw_taps8(const float* __restrict__ x, const Desc& d, int n, int ih0, int iw0, int c,
+                                         const float* wt, int wld, int cc, float (&out)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = 0.f;
+    if (n < 0 || c >= d.C_in) return;
+    const bool second = c + 4 < d.C_in;
+    int t = 0;
+    for (int kh = 0; kh < d.ks; ++kh) {
+        const int ih = ih0 + kh * d.dil;
+        for (int kw = 0; kw < d.ks; ++kw, ++t) {
+            const int iw = iw0 + kw * d.dil;
+            if (ih < 0 || ih >= d.H || iw < 0 || iw >= d.W) continue;
+            const float* px = x + ((int64_t)(n * d.H + ih) * d.W + iw) * d.C_in + c;
+            const f32x4 v0 = *reinterpret_cast<const f32x4*>(px);
+            const f32x4 v1 = second ? *reinterpret_cast<const f32x4*>(px + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            const float* w = wt + t * wld + cc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                out[e] = fmaf(fmaxf(v0[e], 0.f), w[e], out[e]);
+                out[4 + e] = fmaf(fmaxf(v1[e], 0.f), w[4 + e], out[4 + e]);
+            }
+        }
+    }
+}
+
+__device__ __forceinline__ void decode_pixel(const Desc& d, int p, int P, int& n, int& ih0, int& iw0) {
+    if (p >= P) { n = -1; ih0 = iw0 = 0; return; }
+    const int hw = d.Ho * d.Wo;
+    n = p / hw;
+    const int r = p - n * hw, oh = r / d.Wo, ow = r - oh * d.Wo;
+    ih0 = oh * d.stride - d.pad;
+    iw0 = ow * d.stride - d.pad;
+}
+
+// dz of 8 consecutive channels of output pixel p:  gamma rstd (dout - s1 / P - xhat s2 / P),  xhat = (z - mean) rstd
+__device__ __forceinline__ void dz8(const float* __restrict__ dout, const float* __restrict__ z, const float* __restrict__ stats,
+                                    const float* __restrict__ gamma, const float* __restrict__ s12, int C, int p, int P, int c,
+                                    float (&out)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = 0.f;
+    if (p >= P) return;
+    const float invP = 1.f / (float)P;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int cc = c + 4 * h;
+        if (cc >= C) break;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(dout + (int64_t)p * C + cc);
+        const f32x4 zz = *reinterpret_cast<const f32x4*>(z + (int64_t)p * C + cc);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(stats + cc), rs = *reinterpret_cast<const f32x4*>(stats + C + cc);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + cc);
+        const f32x4 a1 = *reinterpret_cast<const f32x4*>(s12 + cc), a2 = *reinterpret_cast<const f32x4*>(s12 + C + cc);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float xh = (zz[e] - mu[e]) * rs[e];
+            out[4 * h + e] = ga[e] * rs[e] * (g[e] - a1[e] * invP - xh * a2[e] * invP);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// forward: z = pw(dw(relu(x))), per-tile channel statistics
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NT>
+__global__ __launch_bounds__(256) void tnet_dwpw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_dw,
+                                                            const float* __restrict__ w_pw, float* __restrict__ z,
+                                                            float* __restrict__ part, const Desc d, const int P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* pix = reinterpret_cast<int*>(smem);                                   // [3][TP]
+    float* wt = reinterpret_cast<float*>(smem + 3 * TP * 4);                   // [MAXT][KC]
+    unsigned short* A_hi = reinterpret_cast<unsigned short*>(smem + 3 * TP * 4 + MAXT * KC * 4);
+    unsigned short* A_lo = A_hi + TP * LDK;
+    unsigned short* B_hi = A_lo + TP * LDK;
+    unsigned short* B_lo = B_hi + 16 * NT * LDK;
+    float* red = reinterpret_cast<float*>(B_lo + 16 * NT * LDK);               // [5][16 NT]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kc = lane >> 4;
+    const int tile = blockIdx.x, p0 = tile * TP, taps = d.ks * d.ks;
+    if (tid < TP) {
+        int n, ih0, iw0;
+        decode_pixel(d, p0 + tid, P, n, ih0, iw0);
+        pix[tid] = n; pix[TP + tid] = ih0; pix[2 * TP + tid] = iw0;
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < d.C_in; c0 += KC) {
+        __syncthreads();                                                       // (previous chunk's fragments are consumed)
+        for (int i = tid; i < taps * KC; i += 256) {
+            const int t = i / KC, cc = i % KC, c = c0 + cc;
+            wt[t * KC + cc] = c < d.C_in ? w_dw[(int64_t)c * taps + t] : 0.f;
+        }
+        for (int i = tid; i < 16 * NT * 8; i += 256) {
+            const int n = i >> 3, k = (i & 7) * 4, c = c0 + k;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (n < d.C_out && c < d.C_in) v = *reinterpret_cast<const f32x4*>(w_pw + (int64_t)n * d.C_in + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2(v[e], B_hi[n * LDK + k + e], B_lo[n * LDK + k + e]);
+        }
+        __syncthreads();
+        {
+            const int i = tid >> 2, cc = (tid & 3) * 8;
+            float y[8];
+            dw_taps8(x, d, pix[i], pix[TP + i], pix[2 * TP + i], c0 + cc, wt, KC, cc, y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split2(y[e], A_hi[i * LDK + cc + e], A_lo[i * LDK + cc + e]);
+        }
+        __syncthreads();
+        const u16x8 ah = frag(A_hi, 16 * w + r16, kc), al = frag(A_lo, 16 * w + r16, kc);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (16 * j < d.C_out) {
+                const u16x8 bh = frag(B_hi, 16 * j + r16, kc), bl = frag(B_lo, 16 * j + r16, kc);
+                acc[j] = mfma_bt(bh, ah, acc[j]);
+                acc[j] = mfma_bt(bl, ah, acc[j]);
+                acc[j] = mfma_bt(bh, al, acc[j]);
+            }
+        }
+    }
+    // ---- epilogue: z, then per-tile (mean, M2) of every channel
+    const int prow = p0 + 16 * w + r16;
+    const bool valid = prow < P;
+    const int cnt = min(TP, P - p0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = 16 * j + 4 * kc;
+        if (valid && col < d.C_out) *reinterpret_cast<f32x4*>(z + (int64_t)prow * d.C_out + col) = acc[j];
+    }
+    auto tile_sum = [&](bool centred) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = 16 * j + 4 * kc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = 0.f;
+                if (valid) { v = acc[j][e]; if (centred) { v -= red[4 * 16 * NT + col + e]; v *= v; } }
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (r16 == 0) red[w * 16 * NT + col + e] = v;
+            }
+        }
+        __syncthreads();
+    };
+    tile_sum(false);
+    for (int c = tid; c < 16 * NT; c += 256)
+        red[4 * 16 * NT + c] = (red[c] + red[16 * NT + c] + red[2 * 16 * NT + c] + red[3 * 16 * NT + c]) / (float)cnt;
+    tile_sum(true);
+    for (int c = tid; c < d.C_out; c += 256) {
+        part[((int64_t)tile * 2) * d.C_out + c] = red[4 * 16 * NT + c];
+        part[((int64_t)tile * 2 + 1) * d.C_out + c] = red[c] + red[16 * NT + c] + red[2 * 16 * NT + c] + red[3 * 16 * NT + c];
+    }
+}
+
+// (mean, M2) of the tiles -> stats[0..C) = mean, stats[C..2C) = 1 / sqrt(var + eps), stats[2C..3C) = biased variance.
+// 16 channels per workgroup x 16 tile lanes; lane g combines tiles g, g + 16, ... in order, then the 16 lanes in order.
+__global__ __launch_bounds__(256) void tnet_bn_finalize_kernel(const float* __restrict__ part, int n_tiles, int P, int C, float eps,
+                                                               float* __restrict__ stats) {
+    __shared__ float sn[16][16], sm[16][16], s2[16][16];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4, c = blockIdx.x * 16 + cl;
+    float n = 0.f, mean = 0.f, M2 = 0.f;
+    if (c < C)
+        for (int t = g; t < n_tiles; t += 16) {
+            const float nb = (float)min(TP, P - t * TP), mb = part[((int64_t)t * 2) * C + c], Mb = part[((int64_t)t * 2 + 1) * C + c];
+            const float nn = n + nb, dl = mb - mean;
+            mean += dl * nb / nn;
+            M2 += Mb + dl * dl * n * nb / nn;
+            n = nn;
+        }
+    sn[g][cl] = n; sm[g][cl] = mean; s2[g][cl] = M2;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        for (int q = 1; q < 16; ++q) {
+            const float nb = sn[q][cl];
+            if (nb > 0.f) {
+                const float nn = n + nb, dl = sm[q][cl] - mean;
+                mean += dl * nb / nn;
+                M2 += s2[q][cl] + dl * dl * n * nb / nn;
+                n = nn;
+            }
+        }
+        const float var = M2 / n;
+        stats[c] = mean;
+        stats[C + c] = 1.f / sqrtf(var + eps);
+        stats[2 * C + c] = var;
+    }
+}
+
+__global__ __launch_bounds__(256) void tnet_bn_apply_kernel(const float* __restrict__ z, const float* __restrict__ stats,
+                                                            const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                            float* __restrict__ out, int64_t total4, int C) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)((i * 4) % C);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(z + i * 4);
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(stats + c), rs = *reinterpret_cast<const f32x4*>(stats + C + c);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c), be = *reinterpret_cast<const f32x4*>(beta + c);
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (v[e] - mu[e]) * rs[e] * ga[e] + be[e];
+        *reinterpret_cast<f32x4*>(out + i * 4) = o;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// backward
+// ---------------------------------------------------------------------------------------------------------------------
+// per 64-pixel tile: part[tile][0][c] = sum dout, part[tile][1][c] = sum dout xhat        (C <= 1024)
+__global__ __launch_bounds__(256) void tnet_bn_bwd_partial_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                                  const float* __restrict__ stats, float* __restrict__ part,
+                                                                  int P, int C) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    float* red = reinterpret_cast<float*>(smem);                               // [ng][2][C]
+    const int nq = C / 4, ng = max(1, 256 / nq);
+    const int g = threadIdx.x / nq, q = threadIdx.x % nq, c = 4 * q;
+    const int p0 = blockIdx.x * TP, p1 = min(P, p0 + TP);
+    if (g < ng) {
+        f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+        const f32x4 mu = *reinterpret_cast<const f32x4*>(stats + c), rs = *reinterpret_cast<const f32x4*>(stats + C + c);
+        for (int p = p0 + g; p < p1; p += ng) {
+            const f32x4 gd = *reinterpret_cast<const f32x4*>(dout + (int64_t)p * C + c);
+            const f32x4 zz = *reinterpret_cast<const f32x4*>(z + (int64_t)p * C + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1[e] += gd[e]; s2[e] += gd[e] * (zz[e] - mu[e]) * rs[e]; }
+        }
+        *reinterpret_cast<f32x4*>(red + (g * 2) * C + c) = s1;
+        *reinterpret_cast<f32x4*>(red + (g * 2 + 1) * C + c) = s2;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 2 * C; i += 256) {
+        float s = 0.f;
+        for (int k = 0; k < ng; ++k) s += red[k * 2 * C + i];
+        part[(int64_t)blockIdx.x * 2 * C + i] = s;
+    }
+}
+
+// out[map(col)] = sum_r part[r][col] in a fixed order; 64 columns per workgroup x 16 row lanes.  tr_c > 0: the columns are
+// (t, c) pairs, col = t * tr_c + c, written transposed to out[c * tr_t + t].
+__global__ __launch_bounds__(256) void tnet_reduce_rows_kernel(const float* __restrict__ part, int n_rows, int64_t n_cols,
+                                                               float* __restrict__ out, int tr_c, int tr_t) {
+    __shared__ f32x4 sm[16][16];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int64_t col = ((int64_t)blockIdx.x * 16 + cl) * 4;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (col < n_cols)
+        for (int r = g; r < n_rows; r += 16) s += *reinterpret_cast<const f32x4*>(part + (int64_t)r * n_cols + col);
+    sm[g][cl] = s;
+    __syncthreads();
+    if (g == 0 && col < n_cols) {
+        for (int q = 1; q < 16; ++q) s += sm[q][cl];
+        if (tr_c > 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int64_t cc = col + e;
+                out[(cc % tr_c) * tr_t + cc / tr_c] = s[e];
+            }
+        } else {
+            *reinterpret_cast<f32x4*>(out + col) = s;
+        }
+    }
+}
+
+// dy [P][C_in] = dz [P][C_out] W_pw [C_out][C_in]; dz formed on the fly
+template <int NT>
+__global__ __launch_bounds__(256) void tnet_dwpw_bwd_data_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                                 const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ s12, const float* __restrict__ w_pw,
+                                                                 float* __restrict__ dy, const Desc d, const int P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    unsigned short* A_hi = reinterpret_cast<unsigned short*>(smem);
+    unsigned short* A_lo = A_hi + TP * LDK;
+    unsigned short* B_hi = A_lo + TP * LDK;
+    unsigned short* B_lo = B_hi + 16 * NT * LDK;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kc = lane >> 4;
+    const int p0 = blockIdx.x * TP;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int c0 = 0; c0 < d.C_out; c0 += KC) {
+        __syncthreads();
+        {   // A[i][k] = dz[p0 + i][c0 + k]
+            const int i = tid >> 2, cc = (tid & 3) * 8;
+            float v[8];
+            dz8(dout, z, stats, gamma, s12, d.C_out, p0 + i, P, c0 + cc, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split2(v[e], A_hi[i * LDK + cc + e], A_lo[i * LDK + cc + e]);
+        }
+        // B[n = ci][k] = W_pw[c0 + k][n]
+        for (int i = tid; i < KC * 4 * NT; i += 256) {
+            const int k = i / (4 * NT), n = (i % (4 * NT)) * 4, co = c0 + k;
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (co < d.C_out && n < d.C_in) v = *reinterpret_cast<const f32x4*>(w_pw + (int64_t)co * d.C_in + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split2(v[e], B_hi[(n + e) * LDK + k], B_lo[(n + e) * LDK + k]);
+        }
+        __syncthreads();
+        const u16x8 ah = frag(A_hi, 16 * w + r16, kc), al = frag(A_lo, 16 * w + r16, kc);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            if (16 * j < d.C_in) {
+                const u16x8 bh = frag(B_hi, 16 * j + r16, kc), bl = frag(B_lo, 16 * j + r16, kc);
+                acc[j] = mfma_bt(bh, ah, acc[j]);
+                acc[j] = mfma_bt(bl, ah, acc[j]);
+                acc[j] = mfma_bt(bh, al, acc[j]);
+            }
+        }
+    }
+    const int prow = p0 + 16 * w + r16;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = 16 * j + 4 * kc;
+        if (prow < P && col < d.C_in) *reinterpret_cast<f32x4*>(dy + (int64_t)prow * d.C_in + col) = acc[j];
+    }
+}
+
+// part[chunk][co][ci] = sum over the chunk's pixels of dz[p][co] y[p][ci]; workgroup = (chunk, 64 co, 64 ci)
+__global__ __launch_bounds__(256) void tnet_pw_wgrad_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                            const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                            const float* __restrict__ s12, const float* __restrict__ x,
+                                                            const float* __restrict__ w_dw, float* __restrict__ part,
+                                                            const Desc d, const int P, const int chunk_px) {
+    __shared__ __attribute__((aligned(16))) unsigned short A_hi[64 * LDK], A_lo[64 * LDK], B_hi[64 * LDK], B_lo[64 * LDK];
+    __shared__ float wt[MAXT * 64];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kc = lane >> 4;
+    const int chunk = blockIdx.x, co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64, taps = d.ks * d.ks;
+    const int pa = chunk * chunk_px, pb = min(P, pa + chunk_px);
+    for (int i = tid; i < taps * 64; i += 256) {
+        const int t = i >> 6, cc = i & 63, c = ci0 + cc;
+        wt[t * 64 + cc] = c < d.C_in ? w_dw[(int64_t)c * taps + t] : 0.f;
+    }
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int pk = pa; pk < pb; pk += KC) {
+        __syncthreads();
+        const int k = tid >> 3, m8 = (tid & 7) * 8, p = pk + k;
+        {   // A[m = co][k = pixel]
+            float v[8];
+            dz8(dout, z, stats, gamma, s12, d.C_out, p < pb ? p : P, P, co0 + m8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split2(v[e], A_hi[(m8 + e) * LDK + k], A_lo[(m8 + e) * LDK + k]);
+        }
+        {   // B[n = ci][k = pixel] = y re-computed
+            int n, ih0, iw0;
+            decode_pixel(d, p < pb ? p : P, P, n, ih0, iw0);
+            float y[8];
+            dw_taps8(x, d, n, ih0, iw0, ci0 + m8, wt, 64, m8, y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) split2(y[e], B_hi[(m8 + e) * LDK + k], B_lo[(m8 + e) * LDK + k]);
+        }
+        __syncthreads();
+        const u16x8 ah = frag(A_hi, 16 * w + r16, kc), al = frag(A_lo, 16 * w + r16, kc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const u16x8 bh = frag(B_hi, 16 * j + r16, kc), bl = frag(B_lo, 16 * j + r16, kc);
+            acc[j] = mfma_bt(bh, ah, acc[j]);
+            acc[j] = mfma_bt(bl, ah, acc[j]);
+            acc[j] = mfma_bt(bh, al, acc[j]);
+        }
+    }
+    const int co = co0 + 16 * w + r16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ci = ci0 + 16 * j + 4 * kc;
+        if (co < d.C_out && ci < d.C_in)
+            *reinterpret_cast<f32x4*>(part + ((int64_t)chunk * d.C_out + co) * d.C_in + ci) = acc[j];
+    }
+}
+
+// dx[n, ih, iw, c] = 1[x > 0] sum over the taps that read this input: dy[n, oh, ow, c] w_dw[c][kh][kw]
+__global__ __launch_bounds__(256) void tnet_dw_bwd_data_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                               const float* __restrict__ w_dw, float* __restrict__ dx,
+                                                               const Desc d, int64_t total4) {
+    const int nq = d.C_in / 4, taps = d.ks * d.ks;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total4; i += (int64_t)gridDim.x * 256) {
+        const int c = (int)(i % nq) * 4;
+        int64_t pix = i / nq;
+        const int iw = (int)(pix % d.W);
+        pix /= d.W;
+        const int ih = (int)(pix % d.H), n = (int)(pix / d.H);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int kh = 0; kh < d.ks; ++kh) {
+            const int th = ih + d.pad - kh * d.dil;
+            if (th < 0 || th % d.stride) continue;
+            const int oh = th / d.stride;
+            if (oh >= d.Ho) continue;
+            for (int kw = 0; kw < d.ks; ++kw) {
+                const int tw = iw + d.pad - kw * d.dil;
+                if (tw < 0 || tw % d.stride) continue;
+                const int ow = tw / d.stride;
+                if (ow >= d.Wo) continue;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(dy + ((int64_t)(n * d.Ho + oh) * d.Wo + ow) * d.C_in + c);
+                const int t = kh * d.ks + kw;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(g[e], w_dw[(int64_t)(c + e) * taps + t], acc[e]);
+            }
+        }
+        const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = xv[e] > 0.f ? acc[e] : 0.f;
+        *reinterpret_cast<f32x4*>(dx + i * 4) = acc;
+    }
+}
+
+// part[chunk][t][c] = sum over the chunk's output pixels of dy[p][c] relu(x[tap t of p][c])
+__global__ __launch_bounds__(256) void tnet_dw_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            float* __restrict__ part, const Desc d, const int P, const int chunk_px) {
+    const int nq = d.C_in / 4, taps = d.ks * d.ks, items = taps * nq;
+    const int pa = blockIdx.x * chunk_px, pb = min(P, pa + chunk_px);
+    const int hw = d.Ho * d.Wo;
+    for (int it = threadIdx.x; it < items; it += 256) {
+        const int t = it / nq, c = (it % nq) * 4, kh = t / d.ks, kw = t % d.ks;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int p = pa; p < pb; ++p) {
+            const int n = p / hw, r = p - n * hw, oh = r / d.Wo, ow = r - oh * d.Wo;
+            const int ih = oh * d.stride - d.pad + kh * d.dil, iw = ow * d.stride - d.pad + kw * d.dil;
+            if (ih < 0 || ih >= d.H || iw < 0 || iw >= d.W) continue;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (int64_t)p * d.C_in + c);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + ((int64_t)(n * d.H + ih) * d.W + iw) * d.C_in + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] = fmaf(g[e], fmaxf(xv[e], 0.f), acc[e]);
+        }
+        *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.x * taps + t) * d.C_in + c) = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// host side
+// ---------------------------------------------------------------------------------------------------------------------
+inline int nt_of(int C) { return C <= 64 ? 4 : C <= 128 ? 8 : C <= 256 ? 16 : 32; }
+inline size_t fwd_lds(int NT) { return 3 * TP * 4 + MAXT * KC * 4 + 2 * TP * LDK * 2 + 2 * 16 * NT * LDK * 2 + 5 * 16 * NT * 4; }
+inline size_t bwd_lds(int NT) { return 2 * TP * LDK * 2 + 2 * 16 * NT * LDK * 2; }
+
+struct Plan { int P, n_tiles, pw_chunks, pw_chunk_px, dw_chunks, dw_chunk_px; };
+
+Plan make_plan(const Desc& d) {
+    Plan pl;
+    pl.P = d.N * d.Ho * d.Wo;
+    pl.n_tiles = (pl.P + TP - 1) / TP;
+    const int blocks = ((d.C_out + 63) / 64) * ((d.C_in + 63) / 64);
+    int chunks = (768 + blocks - 1) / blocks;
+    chunks = std::max(1, std::min(chunks, (pl.P + KC - 1) / KC));
+    pl.pw_chunk_px = ((pl.P + chunks - 1) / chunks + KC - 1) / KC * KC;
+    pl.pw_chunks = (pl.P + pl.pw_chunk_px - 1) / pl.pw_chunk_px;
+    pl.dw_chunk_px = 128;
+    pl.dw_chunks = (pl.P + pl.dw_chunk_px - 1) / pl.dw_chunk_px;
+    return pl;
+}
+
+int check_desc(const ghn3_dwpw_desc* g, Desc& d) {
+    if (!g) { ghn3_set_error("dwpw: null descriptor"); return GHN3_E_ARG; }
+    d = Desc{g->N, g->H, g->W, g->C_in, g->C_out, g->ks, g->stride, g->pad, g->dil, g->Ho, g->Wo, g->eps};
+    if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.C_in <= 0 || d.C_out <= 0 || d.ks <= 0 || d.stride <= 0 || d.dil <= 0 || d.pad < 0) {
+        ghn3_set_error("dwpw: non-positive size in the descriptor");
+        return GHN3_E_ARG;
+    }
+    if ((d.C_in & 3) || (d.C_out & 3) || d.C_in > 512 || d.C_out > 512 || d.ks > 7) {
+        ghn3_set_error("dwpw: needs C_in, C_out multiples of 4 and <= 512, ks <= 7 (got %d -> %d, ks %d)", d.C_in, d.C_out, d.ks);
+        return GHN3_E_LIMIT;
+    }
+    const int ho = (d.H + 2 * d.pad - d.dil * (d.ks - 1) - 1) / d.stride + 1, wo = (d.W + 2 * d.pad - d.dil * (d.ks - 1) - 1) / d.stride + 1;
+    if (ho != d.Ho || wo != d.Wo || ho <= 0 || wo <= 0) {
+        ghn3_set_error("dwpw: output size %d x %d does not match the convolution arithmetic (%d x %d)", d.Ho, d.Wo, ho, wo);
+        return GHN3_E_ARG;
+    }
+    if ((int64_t)d.N * d.H * d.W * std::max(d.C_in, d.C_out) >= ((int64_t)1 << 31) ||
+        (int64_t)d.N * d.Ho * d.Wo * std::max(d.C_in, d.C_out) >= ((int64_t)1 << 31)) {
+        ghn3_set_error("dwpw: activation tensors of 2^31 elements or more are not supported");
+        return GHN3_E_LIMIT;
+    }
+    return GHN3_OK;
+}
+
+template <typename K> int set_lds(K kern, size_t bytes) {
+    if (bytes > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+        if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(dwpw): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
+    }
+    return GHN3_OK;
+}
+
+#define LAUNCH_CHECK(what) { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { ghn3_set_error(what ": %s", hipGetErrorString(e_)); return GHN3_E_HIP; } }
+
+}  // namespace
+
+extern "C" int64_t ghn3_dwpw_scratch_floats(const ghn3_dwpw_desc* g, int backward) {
+    Desc d;
+    if (check_desc(g, d)) return -1;
+    const Plan pl = make_plan(d);
+    if (!backward) return (int64_t)pl.n_tiles * 2 * d.C_out + 64;
+    const int taps = d.ks * d.ks;
+    return (int64_t)pl.n_tiles * 2 * d.C_out + 2 * d.C_out + (int64_t)pl.P * d.C_in +
+           (int64_t)pl.pw_chunks * d.C_out * d.C_in + (int64_t)pl.dw_chunks * taps * d.C_in + 256;
+}
+
+extern "C" int ghn3_dwpw_bn_fwd(const ghn3_dwpw_desc* g, const float* x, const float* w_dw, const float* w_pw, const float* gamma,
+                                const float* beta, float* z, float* out, float* stats, float* scratch, void* stream_) {
+    Desc d;
+    int rc = check_desc(g, d);
+    if (rc) return rc;
+    if (!x || !w_dw || !w_pw || !gamma || !beta || !z || !out || !stats || !scratch) { ghn3_set_error("dwpw fwd: null pointer"); return GHN3_E_ARG; }
+    hipStream_t s = (hipStream_t)stream_;
+    const Plan pl = make_plan(d);
+    const int NT = nt_of(d.C_out);
+    const size_t lds = fwd_lds(NT);
+#define FWD_CASE(n) case n: rc = set_lds(tnet_dwpw_fwd_kernel<n>, lds); if (rc) return rc; \
+        hipLaunchKernelGGL(tnet_dwpw_fwd_kernel<n>, dim3(pl.n_tiles), dim3(256), lds, s, x, w_dw, w_pw, z, scratch, d, pl.P); break;
+    switch (NT) { FWD_CASE(4) FWD_CASE(8) FWD_CASE(16) FWD_CASE(32) }
+#undef FWD_CASE
+    LAUNCH_CHECK("dwpw fwd")
+    hipLaunchKernelGGL(tnet_bn_finalize_kernel, dim3((d.C_out + 15) / 16), dim3(256), 0, s, scratch, pl.n_tiles, pl.P, d.C_out, d.eps, stats);
+    LAUNCH_CHECK("bn finalize")
+    const int64_t total4 = (int64_t)pl.P * d.C_out / 4;
+    hipLaunchKernelGGL(tnet_bn_apply_kernel, dim3((int)std::min<int64_t>((total4 + 255) / 256, 4096)), dim3(256), 0, s, z, stats, gamma,
+                       beta, out, total4, d.C_out);
+    LAUNCH_CHECK("bn apply")
+    return GHN3_OK;
+}
+
+extern "C" int ghn3_dwpw_bn_bwd(const ghn3_dwpw_desc* g, const float* dout, const float* x, const float* z, const float* stats,
+                                const float* w_dw, const float* w_pw, const float* gamma, float* dx, float* dw_dw, float* dw_pw,
+                                float* dgamma, float* dbeta, float* scratch, void* stream_) {
+    Desc d;
+    int rc = check_desc(g, d);
+    if (rc) return rc;
+    if (!dout || !x || !z || !stats || !w_dw || !w_pw || !gamma || !dx || !dw_dw || !dw_pw || !dgamma || !dbeta || !scratch) {
+        ghn3_set_error("dwpw bwd: null pointer");
+        return GHN3_E_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    const Plan pl = make_plan(d);
+    const int taps = d.ks * d.ks;
+    float* part12 = scratch;
+    float* s12 = part12 + (int64_t)pl.n_tiles * 2 * d.C_out;
+    float* dy = s12 + 2 * d.C_out;
+    float* part_pw = dy + (int64_t)pl.P * d.C_in;
+    float* part_dw = part_pw + (int64_t)pl.pw_chunks * d.C_out * d.C_in;
+    // 1. dgamma / dbeta
+    {
+        const int nq = d.C_out / 4, ng = std::max(1, 256 / nq);
+        hipLaunchKernelGGL(tnet_bn_bwd_partial_kernel, dim3(pl.n_tiles), dim3(256), (size_t)ng * 2 * d.C_out * 4, s, dout, z, stats, part12,
+                           pl.P, d.C_out);
+        LAUNCH_CHECK("bn bwd partial")
+        hipLaunchKernelGGL(tnet_reduce_rows_kernel, dim3((2 * d.C_out / 4 + 15) / 16), dim3(256), 0, s, part12, pl.n_tiles,
+                           (int64_t)2 * d.C_out, s12, 0, 0);
+        LAUNCH_CHECK("bn bwd reduce")
+        hipMemcpyAsync(dbeta, s12, (size_t)d.C_out * 4, hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(dgamma, s12 + d.C_out, (size_t)d.C_out * 4, hipMemcpyDeviceToDevice, s);
+    }
+    // 2. dy = dz W_pw
+    {
+        const int NT = nt_of(d.C_in);
+        const size_t lds = bwd_lds(NT);
+#define BWD_CASE(n) case n: rc = set_lds(tnet_dwpw_bwd_data_kernel<n>, lds); if (rc) return rc; \
+        hipLaunchKernelGGL(tnet_dwpw_bwd_data_kernel<n>, dim3(pl.n_tiles), dim3(256), lds, s, dout, z, stats, gamma, s12, w_pw, dy, d, pl.P); break;
+        switch (NT) { BWD_CASE(4) BWD_CASE(8) BWD_CASE(16) BWD_CASE(32) }
+#undef BWD_CASE
+        LAUNCH_CHECK("dwpw bwd data")
+    }
+    // 3. dW_pw
+    hipLaunchKernelGGL(tnet_pw_wgrad_kernel, dim3(pl.pw_chunks, (d.C_out + 63) / 64, (d.C_in + 63) / 64), dim3(256), 0, s, dout, z, stats,
+                       gamma, s12, x, w_dw, part_pw, d, pl.P, pl.pw_chunk_px);
+    LAUNCH_CHECK("pw wgrad")
+    {
+        const int64_t cols = (int64_t)d.C_out * d.C_in;
+        hipLaunchKernelGGL(tnet_reduce_rows_kernel, dim3((int)((cols / 4 + 15) / 16)), dim3(256), 0, s, part_pw, pl.pw_chunks, cols, dw_pw, 0, 0);
+        LAUNCH_CHECK("pw wgrad reduce")
+    }
+    // 4. dx and dW_dw
+    {
+        const int64_t total4 = (int64_t)d.N * d.H * d.W * d.C_in / 4;
+        hipLaunchKernelGGL(tnet_dw_bwd_data_kernel, dim3((int)std::min<int64_t>((total4 + 255) / 256, 8192)), dim3(256), 0, s, dy, x, w_dw,
+                           dx, d, total4);
+        LAUNCH_CHECK("dw bwd data")
+        hipLaunchKernelGGL(tnet_dw_wgrad_kernel, dim3(pl.dw_chunks), dim3(256), 0, s, dy, x, part_dw, d, pl.P, pl.dw_chunk_px);
+        LAUNCH_CHECK("dw wgrad")
+        const int64_t cols = (int64_t)taps * d.C_in;
+        hipLaunchKernelGGL(tnet_reduce_rows_kernel, dim3((int)((cols / 4 + 15) / 16)), dim3(256), 0, s, part_dw, pl.dw_chunks, cols, dw_dw,
+                           d.C_in, taps);
+        LAUNCH_CHECK("dw wgrad reduce")
+    }
+    return GHN3_OK;
+}

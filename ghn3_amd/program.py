@@ -1529,6 +1529,25 @@ class Program:
                 touched.append(k)
         return touched
 
+    def _wgrad_schedule(self, flops, rows):
+        """Workgroups of the side-stream W2 weight gradient (a multiple of 8: a worker's tiles keep their XCD), or 0 = on the
+        chain's stream in front of the Graphormer backward.  See the call site for the model and its measurements."""
+        env_main, env_cap = os.environ.get('GHN3_WGRAD_MAIN'), os.environ.get('GHN3_WGRAD_CAP')
+        if not self.SIDE or env_main == '1':
+            return 0
+        if env_cap is not None:
+            return max(8, int(env_cap) // 8 * 8)
+        # the persistent kernel alone: its k loop at ~1150 TF + the stores of dW2 at ~4.3 TB/s (0.97 / 1.52 / 2.63 ms measured
+        # for 1 / 2 / 4 graphs of 256 nodes at ghn3xlm16; profiles/r05b_ab_wgrad_schedule_b1_b2_b4.txt)
+        w_ms = flops / 1150e12 * 1e3 + 4.0 * self.max_shape[0] * self.max_shape[1] * 8 * self.C / 4.3e12 * 1e3
+        ch_ms = self.Lyr * (0.030 + 0.014 * (rows / 256.0) * (self.C / 384.0) ** 2)      # the backward chain alone
+        if env_main != '0' and w_ms < 0.75 * ch_ms:
+            return 0
+        c = int(round(256.0 * w_ms / (1.75 * ch_ms) / 8.0)) * 8
+        if c >= 232:
+            return 0 if env_main != '0' else 224
+        return max(64, c)
+
     def _build_h16_table(self, g16, direct_member):
         """Per tile descriptor {h, rel0, ld32 | ld16 << 32} of GHN3_OP_TILE_BWD's direct 16-bit output: where the fp32
         region of the descriptor lies inside its family's tile matrix and where that matrix's 16-bit copy `dth` starts
@@ -2009,17 +2028,23 @@ class Program:
                 # gained (step 8.51 ms with the old kernel, 8.56 with tile 25 on every CU, 8.46 at 224, 8.38 at 192 --
                 # but there the weight gradient is back at 1.49 ms).
                 n_before = len(self._ops)
-                # Round 4: the W2 weight gradient runs on the chain's own stream (every CU, in front of the Graphormer backward)
-                # instead of on the side stream beside it.  The persistent kernel takes 144 KB of LDS and 256 VGPRs on every
-                # CU it sits on, so nothing of the chain could co-reside: beside 224 of its workgroups the chain's kernels ran
-                # on the 32 CUs left (336 us per layer instead of ~53).  Serial, the kernel runs undisturbed (0.96 instead of
-                # 1.09 ms: roofline.frac 0.336 instead of 0.318) and the step time is the same within +-0.06 ms
-                # (GHN3_WGRAD_MAIN=0: side stream with GHN3_WGRAD_CAP workgroups, 160 gives the fastest step at frac 0.28).
-                wg_main = os.environ.get('GHN3_WGRAD_MAIN', '1') != '0'
+                # Where the W2 weight gradient runs (round 5: the fastest step is the default).  The persistent kernel takes
+                # 128 KB of LDS and 256 VGPRs on every CU it sits on -- nothing co-resides with it -- so beside it the
+                # Graphormer backward chain only gets the CUs the launch leaves free, and it runs ~1.75x slower there
+                # whatever their number (memory-system contention: 1.12 -> 1.9-2.0 ms on 128 / 96 / 64 free CUs,
+                # profiles/r05a_ab_wgrad_schedule.txt).  With W = the kernel's full-chip time and Ch = the chain's own time
+                # the step pays max(W * 256 / c, 1.75 Ch) with c workgroups on the side stream against W + Ch serial: side
+                # stream when W >= 0.75 Ch, with c = 256 W / (1.75 Ch) (ghn3xlm16, one 256-node graph: 136; measured
+                # 5.82-5.84 ms at 128, 5.84-5.92 at 160, 5.93 at 192, 6.01-6.03 serial; two graphs: 160 -> 9.59-9.67 ms
+                # against 9.86-10.09 serial; four graphs: 184 -> 15.8-16.0 against 16.2-16.3).  The kernel's own rate
+                # (`roofline.frac`) is measured in a serialised pass (profile mode 3), where the cap is dropped.
+                # GHN3_WGRAD_MAIN=1 / 0 and GHN3_WGRAD_CAP override.
+                self.wgrad_cap = self._wgrad_schedule(fl, B * N)
+                wg_main = self.wgrad_cap == 0
                 self.gemm_op(p0, ctype=bct, tag=self.TAG_D3_WGRAD, side=not wg_main, flops=fl,
                              tile=wg_tile,
-                             grid_cap=(int(os.environ.get('GHN3_WGRAD_CAP', '224')) |
-                                       (int(os.environ.get('GHN3_WGRAD_TPW', '0')) << 16)) if (self.SIDE and not wg_main) else 0)
+                             grid_cap=(self.wgrad_cap | (int(os.environ.get('GHN3_WGRAD_TPW', '0')) << 16))
+                             if (self.SIDE and not wg_main) else 0)
                 self.wgrad_op_range = (n_before, len(self._ops))
             fam_list = bands
             for gi, g in enumerate(self.gemm_groups):

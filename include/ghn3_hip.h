@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 16
+#define GHN3_ABI_VERSION 17
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -466,18 +466,44 @@ int ghn3_event_destroy(void* ev);
 /* Per-op timing with HIP events on the run's stream.
  *   mode 1: every op is bracketed and synchronised (diagnostic; perturbs timing) -> ghn3_profile_read
  *   mode 2: only ops whose flags carry GHN3_OPFLAG_TIMED get an event pair from a pool, nothing is
- *           synchronised until ghn3_profile_read_tags; the tag is (op.flags >> 16) & 255. */
+ *           synchronised until ghn3_profile_read_tags; the tag is (op.flags >> 16) & 255.
+ *   mode 3: as mode 2, but GHN3_OPFLAG_SIDE ops run on the caller's stream in program order (nothing co-runs with a timed
+ *           kernel, side-stream grid caps are dropped): the kernels' own durations, for roofline figures. */
 #define GHN3_OPFLAG_TIMED 0x100
 /* Run the op on the context's side stream, concurrently with the following ops of the program: it starts after
  * every earlier op of the program has finished and is waited for by GHN3_OP_JOIN / the end of ghn3_run.  The
  * program must not let later main-stream ops touch what a pending side op reads or writes (used for weight
- * gradients and operand copies that are off the critical path).  GHN3_NO_SIDE_STREAM=1 serialises everything. */
+ * gradients and operand copies that are off the critical path).  GHN3_NO_SIDE_STREAM=1 serialises everything; a serialised
+ * side GEMM ignores its grid cap (op.i[3]: the cap only leaves CUs to the stream it would have run beside). */
 #define GHN3_OPFLAG_SIDE 0x200
 int ghn3_profile_enable(ghn3_ctx* ctx, int mode);
 int ghn3_profile_read(ghn3_ctx* ctx, double* ms_per_kind /* [GHN3_OP_KIND_COUNT] */,
                       int64_t* launches_per_kind, int reset);
 int ghn3_profile_read_tags(ghn3_ctx* ctx, double* ms_per_tag /* [256] */, int64_t* n_per_tag /* [256] */,
                            int reset);
+
+/*
+ * Target-network execution, first native slice: ReLU -> depthwise k x k convolution -> pointwise 1 x 1
+ * convolution -> BatchNorm with batch statistics -- `DilConv` and each half of `SepConv` of the DeepNets-1M search space
+ * (/root/reference/ghn3/ops.py:198-240, executed at trainer.py:308-319 with the weights the GHN predicted) -- forward and
+ * backward on NHWC (torch channels_last) fp32 activations.  Replaces four ATen / MIOpen modules per direction.
+ *   x [N][H][W][C_in], z (pre-norm) / out / dout [N][Ho][Wo][C_out], w_dw [C_in][ks][ks], w_pw [C_out][C_in],
+ *   gamma / beta [C_out], stats [3 C_out] = mean | 1 / sqrt(var + eps) | biased variance (written by fwd, read by bwd).
+ * Weights are read in place (views of the GHN's flat prediction buffer); all five gradients are written densely.
+ * `scratch` = ghn3_dwpw_scratch_floats(desc, backward) floats of device memory owned by the caller (no allocation, no
+ * synchronisation inside).  Limits: C_in, C_out multiples of 4 and <= 512, ks <= 7, tensors below 2^31 elements
+ * (GHN3_E_LIMIT otherwise: the caller keeps its stock path for such layers).  Deterministic.
+ */
+typedef struct ghn3_dwpw_desc {
+    int32_t N, H, W, C_in, C_out, ks, stride, pad, dil, Ho, Wo;
+    float eps;
+} ghn3_dwpw_desc;
+int64_t ghn3_dwpw_scratch_floats(const ghn3_dwpw_desc* desc, int backward);     /* < 0: bad descriptor (ghn3_last_error) */
+int ghn3_dwpw_bn_fwd(const ghn3_dwpw_desc* desc, const float* x, const float* w_dw, const float* w_pw, const float* gamma,
+                     const float* beta, float* z, float* out, float* stats, float* scratch, void* stream);
+int ghn3_dwpw_bn_bwd(const ghn3_dwpw_desc* desc, const float* dout, const float* x, const float* z, const float* stats,
+                     const float* w_dw, const float* w_pw, const float* gamma, float* dx, float* dw_dw, float* dw_pw,
+                     float* dgamma, float* dbeta, float* scratch, void* stream);
 
 #ifdef __cplusplus
 }

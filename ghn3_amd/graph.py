@@ -69,7 +69,7 @@ class Graph:
                                 fix_weight_edges=kwargs.get('fix_weight_edges', True),
                                 fix_softmax_edges=kwargs.get('fix_softmax_edges', True),
                                 list_all_nodes=kwargs.get('list_all_nodes', False),
-                                verbose=kwargs.get('verbose', False))
+                                verbose=kwargs.get('verbose', False), trace=kwargs.get('trace', 'meta'))
             self.model = model
             self.n_nodes = len(built['node_feat'])
             self.node_feat, self.node_info, self._Adj = built['node_feat'], built['node_info'], built['A']

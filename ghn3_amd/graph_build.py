@@ -15,6 +15,7 @@ Third-party classes (torchvision, ppuda) are recognised by class name along the 
 """
 
 import copy
+import os
 
 import numpy as np
 import torch
@@ -362,20 +363,88 @@ def _cell_index(param_name, n_cells):
 
 
 # ---------------------------------------------------------------------------------------------------------------
+class _MetaAffine(torch.autograd.Function):
+    """Structure-only stand-in for an affine normalisation on the meta device: one autograd function whose inputs are
+    (x, weight, bias) in the order of the native op, which is all the walk of _trace looks at for a function with parameter
+    inputs.  (torch's own meta path of batch_norm / layer_norm is a Python decomposition: ~4 ms per layer, 0.2 s for ResNet-50.)"""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        return torch.empty_like(x)
+
+    @staticmethod
+    def backward(ctx, g):                                   # pragma: no cover  (the traced graph is never differentiated)
+        raise RuntimeError('structure-only trace')
+
+
+class _cheap_meta_norms:
+    def __enter__(self):
+        F = torch.nn.functional
+        self.saved = (F.batch_norm, F.layer_norm)
+        bn0, ln0 = self.saved
+
+        def batch_norm(input, running_mean, running_var, weight=None, bias=None, *a, **k):
+            if input.device.type == 'meta' and weight is not None and bias is not None:
+                return _MetaAffine.apply(input, weight, bias)
+            return bn0(input, running_mean, running_var, weight, bias, *a, **k)
+
+        def layer_norm(input, normalized_shape, weight=None, bias=None, *a, **k):
+            if input.device.type == 'meta' and weight is not None and bias is not None:
+                return _MetaAffine.apply(input, weight, bias)
+            return ln0(input, normalized_shape, weight, bias, *a, **k)
+        F.batch_norm, F.layer_norm = batch_norm, layer_norm
+        return self
+
+    def __exit__(self, *exc):
+        torch.nn.functional.batch_norm, torch.nn.functional.layer_norm = self.saved
+        return False
+
+
+def _traced_outputs(model, in_sz, trace='meta'):
+    """(outputs carrying the autograd graph, id(parameter) -> (name, module)) of one forward pass (graph.py:420-436).
+
+    The reference pushes a random batch through the model on its own device: for ResNet-50 on a CPU that pass IS the cost of
+    Graph(model) (0.25 s of 0.26; 74 such graphs in eval_ghn.py against 4 ms of prediction each).  Only the STRUCTURE of the
+    autograd graph is used, so the pass runs on torch's meta device instead -- shapes and grad_fn nodes, no arithmetic, no
+    memory, whatever device the model lives on: parameters and buffers are replaced by meta twins through
+    torch.func.functional_call, and the owner table is keyed by the twins.  (Side effect not reproduced: the reference's pass
+    also nudges BatchNorm running statistics with its random batch.)  Anything the meta device cannot run -- an op without a
+    meta kernel, data-dependent control flow, a model that is not an nn.Module -- falls back to the real pass;
+    trace='real' / GHN3_GRAPH_TRACE=real forces it."""
+    mode = os.environ.get('GHN3_GRAPH_TRACE', trace)
+    if mode == 'meta' and isinstance(model, torch.nn.Module) and not hasattr(model, 'get_var'):
+        try:
+            twin = {}
+            def meta(t):
+                if id(t) not in twin:
+                    twin[id(t)] = torch.empty_like(t, device='meta').requires_grad_(t.requires_grad)
+                return twin[id(t)]
+            state = {n: meta(p) for n, p in model.named_parameters(remove_duplicate=False)}
+            state.update({n: meta(b) for n, b in model.named_buffers(remove_duplicate=False)})
+            with torch.enable_grad(), _cheap_meta_norms():
+                out = torch.func.functional_call(model, state, (torch.empty(2, *in_sz, device='meta'),))
+            owners = {id(twin[pid]): v for pid, v in _owners(model).items() if pid in twin}
+            return out, owners
+        except Exception:                                  # (NotImplementedError for a missing meta kernel, device mix-ups, ...)
+            pass
+    device = next(model.parameters()).device
+    with torch.enable_grad():
+        out = model.get_var() if hasattr(model, 'get_var') else model(torch.randn(2, *in_sz, device=device))
+    return out, _owners(model)
+
+
 def build_graph(model, ve_cutoff=50, reduce_graph=True, fix_weight_edges=True, fix_softmax_edges=True,
-                list_all_nodes=False, verbose=False):
+                list_all_nodes=False, verbose=False, trace='meta'):
     """Returns dict(node_feat (N,1) int64, node_info, A (N,N) int64, nodes, param_shapes, expected_input_sz, n_cells)."""
     sz = getattr(model, 'expected_input_sz', 299 if _has_base(model, 'Inception3') else 224)
     in_sz = tuple(sz) if isinstance(sz, (tuple, list)) else (3, sz, sz)
     n_cells = getattr(model, '_n_cells', 1)
-    device = next(model.parameters()).device
-    with torch.enable_grad():
-        out = model.get_var() if hasattr(model, 'get_var') else model(torch.randn(2, *in_sz, device=device))
+    out, owners = _traced_outputs(model, in_sz, trace)
     if isinstance(out, dict):
         out = list(out.values())
     if not isinstance(out, (tuple, list)):
         out = [out]
-    nodes, A = _trace([v.grad_fn for v in out if v is not None], _owners(model))
+    nodes, A = _trace([v.grad_fn for v in out if v is not None], owners)
     del out
     if reduce_graph:
         nodes, A = _prune(nodes, A)

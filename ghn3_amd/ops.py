@@ -24,6 +24,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import light_ops
+from . import target_ops
 from .bookkeeping import named_layered_modules
 
 Genotype = namedtuple('Genotype', 'normal normal_concat reduce reduce_concat')
@@ -171,7 +172,8 @@ class _DilConv:
             bn_layer(Lyr, norm, C_out))
 
     def forward(self, x):
-        return self.op(x)
+        # (one HIP node for the whole chain, forward and backward, where it applies: ghn3_amd/target_ops.py)
+        return target_ops.run_block(list(self.op), x) if x.is_cuda else self.op(x)
 
 
 class _SepConv:
@@ -190,7 +192,10 @@ class _SepConv:
         self.op = Lyr.Sequential(*block(C_in, stride), *block(C_out, 1))
 
     def forward(self, x):
-        return self.op(x)
+        if not x.is_cuda:
+            return self.op(x)
+        layers = list(self.op)
+        return target_ops.run_block(layers[4:], target_ops.run_block(layers[:4], x))
 
 
 class _ChannelSELayer:
@@ -519,6 +524,9 @@ class _Network:
             self.__dict__['_layered_modules'] = named_layered_modules(self)
 
     def forward(self, x):
+        if x.is_cuda and x.dim() == 4 and not self._is_vit and target_ops.enabled():
+            # NHWC in memory from the stem on: the fused HIP layers (target_ops) take and return this layout, ATen keeps it
+            x = x.contiguous(memory_format=torch.channels_last)
         if self._is_vit:
             s0 = s1 = self.pos_enc(self.stem0(x))
         elif self._stem_type == 1:

@@ -1,0 +1,156 @@
+"""
+Native execution of target-network layers with GHN-predicted weights, first slice: the chain
+
+    ReLU -> depthwise k x k convolution -> pointwise 1 x 1 convolution -> BatchNorm (batch statistics)
+
+of ``DilConv`` and of each half of ``SepConv`` (/root/reference/ghn3/ops.py:198-240; run at trainer.py:308-319), forward and
+backward, as ONE autograd node on the HIP op family ``ghn3_dwpw_bn_fwd / _bwd`` (include/ghn3_hip.h,
+ghn3_amd/csrc/target_ops.hip) instead of four ATen / MIOpen modules per direction.
+
+Activations are torch ``channels_last`` tensors (NHWC in memory, NCHW in shape): the kernels take their storage as it is
+and the output is channels_last again, so a network that enters this layout at its stem stays in it (the other layers run
+on ATen, which keeps the format).  The weights are the views of the GHN's flat prediction buffer the GHN assigned to the
+layers -- read in place, no copy; their gradients leave as dense tensors for autograd to route back into that buffer.
+
+``DwPwBn.applicable`` states what the kernels take (fp32 CUDA tensors, batch statistics, C <= 512, ks <= 7); a layer
+outside of it keeps the stock path.  There is no CPU implementation: on a CPU tensor the stock path runs (the target
+networks themselves are torch modules), and ``dwpw_bn`` raises without the library.
+"""
+
+import ctypes
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+
+
+class _Desc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('N', 'H', 'W', 'C_in', 'C_out', 'ks', 'stride', 'pad', 'dil', 'Ho', 'Wo')] + \
+        [('eps', ctypes.c_float)]
+
+
+def _desc(x, C_out, ks, stride, pad, dil, eps):
+    N, C, H, W = x.shape
+    Ho = (H + 2 * pad - dil * (ks - 1) - 1) // stride + 1
+    Wo = (W + 2 * pad - dil * (ks - 1) - 1) // stride + 1
+    return _Desc(N, H, W, C, C_out, ks, stride, pad, dil, Ho, Wo, float(eps))
+
+
+def _ptr(t):
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def enabled():
+    """GHN3_NATIVE_OPS=0 keeps every target-network layer on the stock ATen / MIOpen path (A/B measurements)."""
+    return os.environ.get('GHN3_NATIVE_OPS', '1') != '0'
+
+
+class DwPwBn(torch.autograd.Function):
+    @staticmethod
+    def applicable(x, w_dw, w_pw, gamma, beta, ks, training_stats=True):
+        if not (enabled() and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
+            return False
+        if torch.is_autocast_enabled():
+            return False                       # (under AMP the stock path decides the types)
+        if not training_stats or not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32
+                                         for t in (w_dw, w_pw, gamma, beta)):
+            return False
+        C_in, C_out = x.shape[1], w_pw.shape[0]
+        return C_in % 4 == 0 and C_out % 4 == 0 and C_in <= 512 and C_out <= 512 and ks <= 7 and \
+            x.numel() < 2 ** 31 and w_dw.shape[1] == 1
+
+    @staticmethod
+    def forward(ctx, x, w_dw, w_pw, gamma, beta, stride, pad, dil, eps):
+        lib = L.load()
+        ks = int(w_dw.shape[-1])
+        C_out = int(w_pw.shape[0])
+        xc = x.contiguous(memory_format=torch.channels_last)          # (a no-op inside a channels_last network)
+        d = _desc(xc, C_out, ks, stride, pad, dil, eps)
+        wd, wp = w_dw.contiguous(), w_pw.contiguous()
+        g, b = gamma.contiguous(), beta.contiguous()
+        dev = x.device
+        out = torch.empty((d.N, C_out, d.Ho, d.Wo), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        z = torch.empty_like(out)
+        stats = torch.empty(3 * C_out, dtype=torch.float32, device=dev)
+        n_scr = lib.ghn3_dwpw_scratch_floats(ctypes.byref(d), 0)
+        if n_scr < 0:
+            raise L.Ghn3Error('ghn3_dwpw_scratch_floats: %s' % lib.ghn3_last_error().decode())
+        scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L._check(lib.ghn3_dwpw_bn_fwd(ctypes.byref(d), _ptr(xc), _ptr(wd), _ptr(wp), _ptr(g), _ptr(b), _ptr(z), _ptr(out),
+                                      _ptr(stats), _ptr(scratch), stream), 'ghn3_dwpw_bn_fwd')
+        ctx.save_for_backward(xc, z, stats, wd, wp, g)
+        ctx.cfg = (stride, pad, dil, eps)
+        ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, dout, _dstats):
+        lib = L.load()
+        xc, z, stats, wd, wp, g = ctx.saved_tensors
+        stride, pad, dil, eps = ctx.cfg
+        C_out, ks = int(wp.shape[0]), int(wd.shape[-1])
+        d = _desc(xc, C_out, ks, stride, pad, dil, eps)
+        dev = xc.device
+        do = dout.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(xc)
+        dwd, dwp = torch.empty_like(wd), torch.empty_like(wp)
+        dg, db = torch.empty_like(g), torch.empty_like(g)
+        n_scr = lib.ghn3_dwpw_scratch_floats(ctypes.byref(d), 1)
+        scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L._check(lib.ghn3_dwpw_bn_bwd(ctypes.byref(d), _ptr(do), _ptr(xc), _ptr(z), _ptr(stats), _ptr(wd), _ptr(wp), _ptr(g),
+                                      _ptr(dx), _ptr(dwd), _ptr(dwp), _ptr(dg), _ptr(db), _ptr(scratch), stream),
+                 'ghn3_dwpw_bn_bwd')
+        return dx, dwd, dwp, dg, db, None, None, None, None
+
+
+def dwpw_bn(x, w_dw, w_pw, gamma, beta, stride=1, padding=0, dilation=1, eps=1e-5):
+    """out = batch_norm(conv1x1(depthwise_conv(relu(x)))) with batch statistics; returns (out, stats) with
+    stats = [mean | 1 / sqrt(var + eps) | biased variance] per output channel.  x: (N, C, H, W) fp32 CUDA tensor
+    (channels_last preferred), w_dw (C, 1, ks, ks), w_pw (C_out, C, 1, 1) or (C_out, C)."""
+    if not x.is_cuda:
+        raise L.Ghn3Error('dwpw_bn runs on an MI355X only (no CPU implementation: use the stock torch layers)')
+    return DwPwBn.apply(x, w_dw, w_pw.reshape(w_pw.shape[0], -1), gamma, beta, int(stride), int(padding), int(dilation),
+                        float(eps))
+
+
+def reference(x, w_dw, w_pw, gamma, beta, stride=1, padding=0, dilation=1, eps=1e-5):
+    """The four stock layers the op replaces (ops.py:205-212), functional form -- the parity reference of the tests."""
+    y = F.conv2d(F.relu(x), w_dw, None, stride, padding, dilation, groups=x.shape[1])
+    zz = F.conv2d(y, w_pw.reshape(w_pw.shape[0], -1, 1, 1))
+    return F.batch_norm(zz, None, None, gamma, beta, True, 0.1, eps)
+
+
+def run_block(layers, x):
+    """[ReLU, depthwise Conv2d, pointwise Conv2d, BatchNorm2d] (light or torch.nn flavour) on the fused op when it applies,
+    else layer by layer.  Running statistics of a tracking BatchNorm are updated as torch does (momentum, unbiased variance)."""
+    relu, dw, pw, bn = layers
+    w_dw, w_pw = getattr(dw, 'weight', None), getattr(pw, 'weight', None)
+    gamma, beta = getattr(bn, 'weight', None), getattr(bn, 'bias', None)
+    has_run = getattr(bn, 'running_mean', None) is not None
+    batch_stats = getattr(bn, 'training', True) or not has_run
+    ks = dw.kernel_size[0] if hasattr(dw, 'kernel_size') else 0
+    ok = hasattr(bn, 'eps') and getattr(dw, 'bias', None) is None and getattr(pw, 'bias', None) is None and \
+        hasattr(dw, 'kernel_size') and dw.kernel_size[0] == dw.kernel_size[1] and dw.stride[0] == dw.stride[1] and \
+        not isinstance(dw.padding, str) and dw.padding[0] == dw.padding[1] and dw.dilation[0] == dw.dilation[1] and \
+        getattr(dw, 'groups', 1) == x.shape[1] and tuple(pw.kernel_size) == (1, 1) and \
+        DwPwBn.applicable(x, w_dw, w_pw, gamma, beta, ks, batch_stats)
+    if not ok:
+        for m in layers:
+            x = m(x)
+        return x
+    out, stats = dwpw_bn(x, w_dw, w_pw, gamma, beta, dw.stride[0], dw.padding[0], dw.dilation[0], bn.eps)
+    if has_run and getattr(bn, 'training', True) and getattr(bn, 'track_running_stats', False):
+        with torch.no_grad():
+            C = gamma.numel()
+            n = out.numel() // C
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            bn.running_mean.mul_(1 - mom).add_(stats[:C], alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(stats[2 * C:] * (n / max(n - 1, 1)), alpha=mom)
+            if getattr(bn, 'num_batches_tracked', None) is not None:
+                bn.num_batches_tracked += 1
+    return out

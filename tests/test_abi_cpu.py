@@ -33,16 +33,18 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_mirrors_match_header_layout(tmp_path):
     src = tmp_path / 'sz.c'
-    src.write_text('#include <stdio.h>\n#include "ghn3_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %d\\n",'
+    src.write_text('#include <stdio.h>\n#include "ghn3_hip.h"\nint main(){printf("%zu %zu %zu %zu %zu %d %zu\\n",'
                    'sizeof(ghn3_ref),sizeof(ghn3_gemm_problem),sizeof(ghn3_tile_desc),sizeof(ghn3_op),'
                    'sizeof(ghn3_cast_desc),'
-                   '(int)GHN3_OP_KIND_COUNT);return 0;}\n')
+                   '(int)GHN3_OP_KIND_COUNT,sizeof(ghn3_dwpw_desc));return 0;}\n')
     exe = tmp_path / 'sz'
     import subprocess
     subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), str(src), '-o', str(exe)])
     out = subprocess.check_output([str(exe)]).decode().split()
+    from ghn3_amd import target_ops
     assert [int(v) for v in out] == [L.REF_DT.itemsize, L.PROBLEM_DT.itemsize, L.TILE_DT.itemsize,
-                                     L.OP_DT.itemsize, L.CAST_DT.itemsize, L.OP_KIND_COUNT]
+                                     L.OP_DT.itemsize, L.CAST_DT.itemsize, L.OP_KIND_COUNT,
+                                     ctypes.sizeof(target_ops._Desc)]
 
 
 @pytest.mark.skipif(torch.cuda.is_available(), reason='checks the no-GPU failure mode')

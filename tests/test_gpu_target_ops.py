@@ -1,0 +1,147 @@
+"""
+Native target-network layers: the fused ReLU -> depthwise conv -> pointwise conv -> BatchNorm op family
+(ghn3_amd/csrc/target_ops.hip through the C ABI ghn3_dwpw_bn_fwd / _bwd) against the four stock torch layers it replaces
+(/root/reference/ghn3/ops.py:198-240), forward and all five gradients; then whole networks of the search space with the
+fused layers switched on against the same networks on the stock path.
+
+Tolerances: the pointwise product multiplies split-bf16 operands (hi.hi + lo.hi + hi.lo, ~1e-5 relative) and everything else
+is fp32 in another summation order than torch's: 2e-4 of the tensor's scale (the GHN north star asks 1e-3).
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, 'golden'))
+
+CASES = [   # N, C_in, C_out, H, W, ks, stride, pad, dil
+    (4, 32, 32, 16, 16, 3, 1, 1, 1),
+    (3, 48, 96, 15, 17, 3, 2, 1, 1),          # C not a multiple of 32, odd sizes, stride 2, widening
+    (2, 64, 64, 12, 12, 5, 1, 4, 2),          # dil_conv_5x5: dilation 2, padding 4
+    (2, 128, 64, 9, 9, 7, 1, 3, 1),           # 7 x 7 taps, narrowing
+    (5, 16, 16, 8, 8, 3, 2, 2, 2),            # dil_conv_3x3 with stride 2
+    (1, 256, 512, 6, 6, 3, 1, 1, 1),          # the widest tiles (32 column tiles per wave)
+    (8, 80, 112, 7, 5, 5, 2, 2, 1),           # partial pixel tile (8 * 4 * 3 = 96 pixels), odd channel tiles
+]
+
+
+def _rel(a, b):
+    return float((a.double() - b.double()).norm() / (b.double().norm() + 1e-30))
+
+
+@pytest.mark.parametrize('case', CASES)
+def test_dwpw_bn_matches_the_stock_layers(case):
+    from ghn3_amd import target_ops as T
+    N, Ci, Co, H, W, ks, st, pad, dil = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w_dw = torch.randn(Ci, 1, ks, ks, generator=g) / ks
+    w_pw = torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5
+    gamma = 1 + 0.3 * torch.randn(Co, generator=g)
+    beta = 0.2 * torch.randn(Co, generator=g)
+    up = torch.randn(N, Co, (H + 2 * pad - dil * (ks - 1) - 1) // st + 1, (W + 2 * pad - dil * (ks - 1) - 1) // st + 1,
+                     generator=g)
+    ref_in = [t.clone().double().requires_grad_(True) for t in (x, w_dw, w_pw, gamma, beta)]
+    ref = T.reference(*ref_in, stride=st, padding=pad, dilation=dil)
+    (ref * up.double()).sum().backward()
+    dev_in = [t.cuda().requires_grad_(True) for t in (x, w_dw, w_pw, gamma, beta)]
+    assert T.DwPwBn.applicable(dev_in[0], dev_in[1], dev_in[2], dev_in[3], dev_in[4], ks)
+    out, stats = T.dwpw_bn(dev_in[0].contiguous(memory_format=torch.channels_last), dev_in[1], dev_in[2], dev_in[3], dev_in[4],
+                           stride=st, padding=pad, dilation=dil)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    (out * up.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert _rel(out.cpu(), ref.detach()) < 2e-4, _rel(out.cpu(), ref.detach())
+    zz = torch.nn.functional.conv2d(torch.nn.functional.conv2d(torch.relu(x.double()), w_dw.double(), None, st, pad, dil,
+                                                               groups=Ci), w_pw.double())
+    assert _rel(stats[:Co].cpu(), zz.mean((0, 2, 3))) < 2e-4 and _rel(stats[2 * Co:].cpu(), zz.var((0, 2, 3), unbiased=False)) < 2e-4
+    for name, a, b in zip(('dx', 'dw_dw', 'dw_pw', 'dgamma', 'dbeta'), dev_in, ref_in):
+        assert a.grad is not None and torch.isfinite(a.grad).all(), name
+        assert _rel(a.grad.cpu(), b.grad) < 3e-4, (name, _rel(a.grad.cpu(), b.grad))
+    # deterministic: a second run gives the same bits
+    out2, _ = T.dwpw_bn(dev_in[0].detach().contiguous(memory_format=torch.channels_last), dev_in[1].detach(), dev_in[2].detach(),
+                        dev_in[3].detach(), dev_in[4].detach(), stride=st, padding=pad, dilation=dil)
+    assert torch.equal(out2, out.detach())
+
+
+def test_descriptor_limits_are_refused_loudly():
+    from ghn3_amd import target_ops as T, _lib as L
+    x = torch.randn(1, 6, 4, 4, device='cuda')
+    with pytest.raises(L.Ghn3Error):          # C % 4 != 0 straight through the ABI
+        T.dwpw_bn(x, torch.randn(6, 1, 3, 3, device='cuda'), torch.randn(8, 6, device='cuda'), torch.ones(8, device='cuda'),
+                  torch.zeros(8, device='cuda'), padding=1)
+    assert not T.DwPwBn.applicable(x, torch.randn(6, 1, 3, 3, device='cuda'), torch.randn(8, 6, device='cuda'),
+                                   torch.ones(8, device='cuda'), torch.zeros(8, device='cuda'), 3)
+    with pytest.raises(L.Ghn3Error):
+        T.dwpw_bn(torch.randn(1, 8, 4, 4), torch.randn(8, 1, 3, 3), torch.randn(8, 8), torch.ones(8), torch.zeros(8))
+
+
+@pytest.mark.parametrize('light', [False, True])
+def test_networks_on_the_fused_layers_match_the_stock_path(light, monkeypatch):
+    """Whole networks of the search space (tests/golden/network_cases.py: separable / dilated convolutions of every size among
+    the other ops): logits and every parameter gradient with the fused HIP layers against the same network, same tensors, on
+    ATen / MIOpen; light flavour = the tensors are assigned as a GHN would (views of one flat buffer)."""
+    import network_cases
+    import recipe
+    from ghn3_amd import ops
+    used = 0
+    for name, (geno, kw, img) in network_cases.CASES.items():
+        g = ops.Genotype(**geno)
+        if not any(n[0].startswith(('sep_conv', 'dil_conv')) for n in g.normal + g.reduce):
+            continue
+        used += 1
+        res = {}
+        for mode in ('stock', 'fused'):
+            monkeypatch.setenv('GHN3_NATIVE_OPS', '0' if mode == 'stock' else '1')
+            torch.manual_seed(0)
+            kws = {k: ('bn' if (k == 'norm' and v and light) else v) for k, v in kw.items()}
+            net = (ops.NetworkLight if light else ops.Network)(genotype=g, **kws)
+            x = torch.from_numpy(recipe.seeded_images(img, seed=7)).cuda()
+            if light:
+                table = {}
+                for cell in net._layered_modules:
+                    table.update(cell)
+                shapes = [(n, tuple(e['sz'])) for n, e in table.items()]
+                params = recipe.seeded_net_params(shapes, seed=len(name))
+                total = sum(int(np.prod(s)) for _, s in shapes)
+                flat = torch.zeros(total, device='cuda', requires_grad=True)
+                off, views = 0, {}
+                with torch.no_grad():
+                    for n, s in shapes:
+                        k = int(np.prod(s))
+                        flat[off:off + k] = torch.from_numpy(params[n]).reshape(-1).cuda()
+                        off += k
+                off = 0
+                for n, s in shapes:
+                    k = int(np.prod(s))
+                    views[n] = flat[off:off + k].view(s)
+                    off += k
+                for n, e in table.items():
+                    setattr(e['module'], 'weight' if e['is_w'] else 'bias', views[n])
+                leaves = [flat]
+            else:
+                net = net.cuda()
+                params = recipe.seeded_net_params([(n, tuple(p.shape)) for n, p in net.named_parameters()], seed=len(name))
+                with torch.no_grad():
+                    for n, p in net.named_parameters():
+                        p.copy_(torch.from_numpy(params[n]))
+                leaves = [p for _, p in net.named_parameters()]
+            net.train()
+            torch.manual_seed(123)
+            logits, aux = net(x)
+            loss = logits.square().mean() + (aux.square().mean() if aux is not None else 0.)
+            loss.backward()
+            torch.cuda.synchronize()
+            res[mode] = (logits.detach().cpu(), [p.grad.detach().cpu() if p.grad is not None else None for p in leaves])
+        (l0, g0), (l1, g1) = res['stock'], res['fused']
+        assert _rel(l1, l0) < 1e-3, (name, _rel(l1, l0))
+        for a, b in zip(g1, g0):
+            assert (a is None) == (b is None)
+            if a is not None and float(b.norm()) > 0:
+                assert _rel(a, b) < 2e-3, (name, _rel(a, b))
+    assert used >= 3

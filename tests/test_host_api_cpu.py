@@ -208,3 +208,20 @@ def test_usable_cores_applies_the_cgroup_quota(tmp_path, monkeypatch):
     monkeypatch.setattr(builtins, 'open', lambda path, *a, **k: io.StringIO('max 100000\n') if path == '/sys/fs/cgroup/cpu.max'
                         else real_open(path, *a, **k))
     assert bench.usable_cores() == 64
+
+
+@pytest.mark.parametrize('name', NETS + ['two_heads'])
+def test_meta_device_trace_gives_the_graph_of_the_real_pass(name):
+    """Graph(model) walks the autograd graph of a forward pass on torch's meta device (structure only: no arithmetic, no
+    memory; ResNet-50: 0.26 s -> 0.02 s on a CPU) -- the same nodes, names, adjacency and node_info as the pass on real
+    tensors the reference makes (graph.py:420-436), and the model's buffers are left alone."""
+    net = graph_nets.all_nets(graph_nets.local_bases())[name]
+    before = {k: v.clone() for k, v in net.state_dict().items()}
+    g_meta = Graph(net, ve_cutoff=50, trace='meta')
+    assert all(torch.equal(v, before[k]) for k, v in net.state_dict().items())       # (no running-statistics update)
+    assert torch.nn.functional.batch_norm.__module__ == 'torch.nn.functional'         # (the stand-ins are gone again)
+    g_real = Graph(net, ve_cutoff=50, trace='real')
+    assert [n.name for n in g_meta._nodes] == [n.name for n in g_real._nodes]
+    assert torch.equal(g_meta.node_feat, g_real.node_feat) and torch.equal(g_meta._Adj, g_real._Adj)
+    assert _info_repr(g_meta.node_info) == _info_repr(g_real.node_info)
+    assert [repr(s) for s in g_meta._param_shapes] == [repr(s) for s in g_real._param_shapes]

@@ -162,6 +162,197 @@ def launch_ranks(n):
     return rc
 
 
+CONFIGS = {   # BASELINE.json `configs` 1-4 (config 5 = the headline workload with --graphs-per-gpu 2)
+    'resnet18-tm8': dict(model='ghn3tm8', fixture='resnet18', baseline_config=1),
+    'tm8-128': dict(model='ghn3tm8', nodes=128, baseline_config=2),
+    'lm8-200': dict(model='ghn3lm8', nodes=200, baseline_config=3),
+    'resnet50-xl': dict(model='ghn3xlm16', fixture='resnet50', baseline_config=4, published_s=3.385),
+    'vit-xl': dict(model='ghn3xlm16', fixture='vit_b16', baseline_config=4),
+}
+
+
+class _Bottleneck(torch.nn.Module):
+    def __init__(self, cin, planes, stride, down, wide):
+        super().__init__()
+        nn = torch.nn
+        if wide:
+            self.conv1, self.bn1 = nn.Conv2d(cin, planes, 1, bias=False), nn.BatchNorm2d(planes)
+            self.conv2, self.bn2 = nn.Conv2d(planes, planes, 3, stride, 1, bias=False), nn.BatchNorm2d(planes)
+            self.conv3, self.bn3 = nn.Conv2d(planes, planes * 4, 1, bias=False), nn.BatchNorm2d(planes * 4)
+        else:
+            self.conv1, self.bn1 = nn.Conv2d(cin, planes, 3, stride, 1, bias=False), nn.BatchNorm2d(planes)
+            self.conv2, self.bn2 = nn.Conv2d(planes, planes, 3, 1, 1, bias=False), nn.BatchNorm2d(planes)
+            self.conv3 = None
+        out = planes * (4 if wide else 1)
+        self.downsample = nn.Sequential(nn.Conv2d(cin, out, 1, stride, bias=False), nn.BatchNorm2d(out)) if down else None
+
+    def forward(self, x):
+        F = torch.nn.functional
+        y = F.relu(self.bn1(self.conv1(x)))
+        y = self.bn2(self.conv2(y))
+        if self.conv3 is not None:
+            y = self.bn3(self.conv3(F.relu(y)))
+        return F.relu(y + (x if self.downsample is None else self.downsample(x)))
+
+
+class TorchvisionShapedResNet(torch.nn.Module):
+    """torchvision.models.resnet18 / resnet50 written out by hand (torchvision is not in the image): the module `Graph(model)`
+    is timed on -- eval_ghn.py:147-148 builds the graph of every evaluated network this way."""
+
+    def __init__(self, depth=50):
+        super().__init__()
+        nn = torch.nn
+        wide = depth == 50
+        self.conv1, self.bn1 = nn.Conv2d(3, 64, 7, 2, 3, bias=False), nn.BatchNorm2d(64)
+        self.maxpool = nn.MaxPool2d(3, 2, 1)
+        cin, stages = 64, []
+        for li, (nb, planes) in enumerate(zip([3, 4, 6, 3] if wide else [2, 2, 2, 2], (64, 128, 256, 512))):
+            blocks = []
+            for b in range(nb):
+                out = planes * (4 if wide else 1)
+                blocks.append(_Bottleneck(cin, planes, 2 if (b == 0 and li > 0) else 1, b == 0 and (li > 0 or wide), wide))
+                cin = out
+            stages.append(nn.Sequential(*blocks))
+        self.layer1, self.layer2, self.layer3, self.layer4 = stages
+        self.avgpool, self.fc = nn.AdaptiveAvgPool2d(1), nn.Linear(cin, 1000)
+
+    def forward(self, x):
+        x = self.maxpool(torch.relu(self.bn1(self.conv1(x))))
+        x = self.layer4(self.layer3(self.layer2(self.layer1(x))))
+        return self.fc(torch.flatten(self.avgpool(x), 1))
+
+
+def bench_fixture(args, cfg):
+    """BASELINE configs 1 / 4: INFERENCE forward of a released GHN-3 size on a committed graph fixture (tests/golden/recipe.py:
+    the torchvision-shaped ResNet-18 / ResNet-50 / ViT-B/16 graphs the reference-golden parity tests use), one GPU.
+    `value` = predicted parameters / time of the forward program with graph, index tables and weights resident (the metric's
+    definition); beside it the end-to-end `ghn(model, graph)` call (host compile + upload + program + assignment into the
+    modules), `Graph(model)` on the host, the HBM roofline of SURVEY 8(d) (M = 196 / 229 / ~450 decoder rows: the decoder
+    weight stream bounds these, not the matrix cores) and the CPU restatement on the same inputs."""
+    sys.path.insert(0, os.path.join(ROOT, 'tests', 'golden'))
+    import recipe
+    torch.set_num_threads(int(os.environ.get('GHN3_HOST_THREADS', '1')))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the GHN-3 path has no CPU fallback')
+    torch.cuda.set_device(0)
+    dev = torch.device('cuda', 0)
+    from ghn3_amd import GHN3, Graph, GraphBatch, _lib as L
+    fixture = cfg['fixture']
+    spec = recipe.vit_b16_spec() if fixture == 'vit_b16' else recipe.resnet_spec(int(fixture[6:]))
+    torch.manual_seed(0)
+    ghn = GHN3(**model_cfg(cfg['model']), compute=args.compute).to(dev).eval()
+    net = recipe.build_torch_net(spec)
+    nf, info, A = recipe.graph_arrays(spec)
+
+    def batch():
+        return GraphBatch([Graph(node_feat=nf, node_info=info, A=A)], dense=True)
+    ctx = L.context(0)
+    stream = torch.cuda.current_stream().cuda_stream
+    with torch.no_grad():
+        plan = ghn.compile(net, batch(), training=False)
+        prog = plan.program
+        n_pred = sum(p_['numel'] for p_ in prog.predicted)
+        for _ in range(args.warmup):
+            ghn._run_forward(plan)
+        torch.cuda.synchronize()
+        ctx.profile(2)
+        ctx.profile_read_tags(reset=True)
+        ea, eb = L.Event(), L.Event()
+        t0 = time.perf_counter()
+        ea.record(stream)
+        for _ in range(args.steps):
+            ghn._run_forward(plan)
+        eb.record(stream)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        fwd_ms = ea.elapsed_ms(eb) / args.steps
+        tags = ctx.profile_read_tags(reset=True)
+        ctx.profile(0)
+        # end to end, as a user calls it (eval_ghn.py:148 with a pre-built graph): host compile + uploads + program + assign
+        n_e2e = max(3, min(20, args.steps))
+        for _ in range(2):
+            ghn(net, batch(), bn_track_running_stats=True)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for _ in range(n_e2e):
+            ghn(net, batch(), bn_track_running_stats=True)
+        torch.cuda.synchronize()
+        e2e_ms = 1e3 * (time.perf_counter() - t1) / n_e2e
+    # Graph(model) on the host (the step in front of the prediction when no graph is given)
+    graph_ms = None
+    if fixture.startswith('resnet'):
+        model = TorchvisionShapedResNet(int(fixture[6:]))
+        Graph(model)
+        tg = time.perf_counter()
+        for _ in range(5):
+            g_ = Graph(model)
+        graph_ms = 1e3 * (time.perf_counter() - tg) / 5
+        assert g_.n_nodes == len(spec['nodes']), (g_.n_nodes, len(spec['nodes']))
+    # HBM roofline (SURVEY 8(d) "algorithmic bytes per graph"): decoder weights once in the type they are read in + Graphormer
+    # weights + 4 B x predicted parameters written + the tiles written and read once
+    C = prog.C
+    n_pos = len(getattr(prog, 'd1', []) or [])
+    w2_b = 2 if getattr(prog, 'uses_op16', False) else 4
+    bytes_alg = (w2_b * C * C * 8 * C + 4.0 * n_pos * 4 * C * C + 4.0 * 8 * C * 4 * C +
+                 (4.0 if prog.x3 else 4.0) * prog.Lyr * 12 * C * C + 4.0 * n_pred + 8.0 * getattr(prog, 'tiles_floats', 0))
+    rows = prog.B * prog.N
+    g_fl = prog.Lyr * (24.0 * rows * C ** 2 + 4.0 * prog.B * prog.N ** 2 * C)
+    d_fl = sum(prog.tag_flops.get(t, 0.0) for t in (prog.TAG_D3_FWD, prog.TAG_D2_FWD, prog.TAG_D1_FWD))
+    detail = {}
+    for t, (tms, cnt) in sorted(tags.items()):
+        detail[prog.TAG_NAMES.get(t, str(t))] = {'ms_per_step': round(tms / args.steps, 4)}
+    out = {
+        'metric': 'predicted-params/sec (GHN inference forward), %s -> %s' % (cfg['model'], fixture),
+        'value': n_pred / (fwd_ms * 1e-3), 'unit': 'predicted-params/s', 'n_gpus': 1, 'steps': args.steps, 'warmup': args.warmup,
+        'ms_per_step': fwd_ms, 'higher_is_better': True, 'scaling': 'weak',
+        'vs_baseline': (n_pred / (fwd_ms * 1e-3)) / (n_pred / cfg['published_s']) if 'published_s' in cfg else None,
+        **({'vs_baseline_note': 'against the one published number of the reference for this path: %.3f s for this forward with '
+                                'the graph pre-built, on an unspecified CPU (examples/ghn_all_pytorch.ipynb:137)'
+                                % cfg['published_s']} if 'published_s' in cfg else {}),
+        'dtype': args.compute, 'data': 'committed graph fixture (tests/golden/recipe.py), random-init GHN weights',
+        'config': {'workload': 'BASELINE config %d: %s inference forward on the %s graph fixture (%d nodes, %d predicted '
+                               'params, %d decoder rows), one MI355X' % (cfg['baseline_config'], cfg['model'], fixture, prog.N, n_pred,
+                                                                         int(prog.M)),
+                   'ghn_params': int(ghn._flat_numel), 'decoder_rows': int(prog.M), 'parallelism': 'dp1'},
+        'roofline': {'bound': 'hbm', 'achieved': bytes_alg / (fwd_ms * 1e-3) / 1e9, 'peak': 8000.0, 'unit': 'GB/s',
+                     'frac': bytes_alg / (fwd_ms * 1e-3) / 1e9 / 8000.0, 'traffic': None,
+                     'algorithmic_bytes': bytes_alg,
+                     'algorithmic_bytes_formula': 'W2 once (%d B / element) + used decoder.fc rows + W0 + Graphormer weights (fp32 '
+                                                  'equivalents) + 4 B x predicted params + tiles written and read' % w2_b,
+                     'algorithmic_gflop': (g_fl + d_fl) / 1e9,
+                     'mfma_frac_of_16bit_peak': (g_fl + d_fl) / (fwd_ms * 1e-3) / 1e12 / 2500.0, 'kernels': detail},
+        'end_to_end_ms': {'ghn(model, graph)': e2e_ms, 'Graph(model) host': graph_ms,
+                          'note': 'ghn(model, graph) = host compile of the op program + uploads + the forward program + '
+                                  'assignment of the predicted tensors into the modules (eval: clones into .data), per call'},
+        'wall_ms_per_step': 1e3 * wall / args.steps,
+    }
+    if not args.no_cpu_baseline:
+        try:
+            from oracle import ghn3_ref as R
+            cores = max(1, min(usable_cores(), int(os.environ.get('GHN3_CPU_THREADS', '16'))))
+            torch.set_num_threads(cores)
+            torch.manual_seed(0)
+            oracle = R.GHN3Ref(**model_cfg(cfg['model'])).eval()
+            go = R.GraphBatchRef([R.GraphRef(torch.from_numpy(nf), info, torch.from_numpy(A))])
+            net_o = recipe.build_torch_net(spec)
+            times = []
+            with torch.no_grad():
+                oracle(net_o, go)
+                budget = time.time() + 25
+                while len(times) < 5 and (time.time() < budget or len(times) < 2):
+                    tc = time.time()
+                    oracle(net_o, go)
+                    times.append(time.time() - tc)
+            t_med = float(np.median(times))
+            out['cpu_baseline'] = {'value': n_pred / t_med, 'unit': 'predicted-params/s', 'cores': cores, 'kind': 'port',
+                                   'sample': '%s inference forward on the same fixture, fp32, torch %s CPU ops, %d threads, median '
+                                             '%.2f s of %d runs' % (cfg['model'], torch.__version__, cores, t_med, len(times))}
+        except Exception as e:                                   # never lose the GPU line
+            out['cpu_baseline'] = {'value': None, 'error': repr(e)}
+    print(json.dumps(out), flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -186,7 +377,17 @@ def main():
                          'all-reduce after the backward.  The line of the default also carries the bf16-wire timing as '
                          '`bf16_wire` (an extra, lower-precision figure: never `value`)')
     ap.add_argument('--force-ddp', action='store_true', help='run the N > 1 code path in a 1-rank group (testing)')
+    ap.add_argument('--config', default=None, choices=sorted(CONFIGS),
+                    help='one of the other BASELINE.json configurations instead of the headline workload: inference forward on a '
+                         'committed graph fixture (resnet18-tm8 = config 1, resnet50-xl / vit-xl = config 4: the one workload the '
+                         'reference publishes a number for) or the per-GPU workload of config 2 / 3 (tm8-128, lm8-200: the default '
+                         'measurement on that model / graph size)')
     args = ap.parse_args()
+    if args.config is not None:
+        cfg_ = CONFIGS[args.config]
+        if 'fixture' in cfg_:
+            raise SystemExit(bench_fixture(args, cfg_))
+        args.model, args.nodes = cfg_['model'], cfg_['nodes']
 
     if 'RANK' not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args.gpus))        # (before any GPU call in this process)

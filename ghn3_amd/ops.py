@@ -16,6 +16,7 @@ tuple, ``parse_op_ks``, ``drop_path``, ``_is_none``, auxiliary heads) are restat
 behaviour -- parity for them is unpinned, see DESIGN.md 8.
 """
 
+import os
 import sys
 from collections import namedtuple
 
@@ -195,7 +196,8 @@ class _SepConv:
         if not x.is_cuda:
             return self.op(x)
         layers = list(self.op)
-        return target_ops.run_block(layers[4:], target_ops.run_block(layers[:4], x))
+        # (the intermediate activation only travels from one fused block to the next: it keeps the kernels' NHWC layout)
+        return target_ops.run_block(layers[4:], target_ops.run_block(layers[:4], x, keep_layout=True))
 
 
 class _ChannelSELayer:
@@ -524,8 +526,12 @@ class _Network:
             self.__dict__['_layered_modules'] = named_layered_modules(self)
 
     def forward(self, x):
-        if x.is_cuda and x.dim() == 4 and not self._is_vit and target_ops.enabled():
-            # NHWC in memory from the stem on: the fused HIP layers (target_ops) take and return this layout, ATen keeps it
+        if x.is_cuda and x.dim() == 4 and not self._is_vit and target_ops.enabled() and \
+                os.environ.get('GHN3_NATIVE_CL', '0') == '1':
+            # NHWC in memory from the stem on, so that the fused HIP layers (target_ops) never convert.  OFF by default: on
+            # this ROCm build the stock ATen / MIOpen layers return WRONG GRADIENTS for channels_last activations (same
+            # logits, parameter gradients up to 86 % off in the preprocessing conv / BatchNorm layers:
+            # profiles/r05c_target_ops_channels_last_diag.txt), so the fused layers hand NCHW tensors to their neighbours
             x = x.contiguous(memory_format=torch.channels_last)
         if self._is_vit:
             s0 = s1 = self.pos_enc(self.stem0(x))

@@ -7,9 +7,10 @@ of ``DilConv`` and of each half of ``SepConv`` (/root/reference/ghn3/ops.py:198-
 backward, as ONE autograd node on the HIP op family ``ghn3_dwpw_bn_fwd / _bwd`` (include/ghn3_hip.h,
 ghn3_amd/csrc/target_ops.hip) instead of four ATen / MIOpen modules per direction.
 
-Activations are torch ``channels_last`` tensors (NHWC in memory, NCHW in shape): the kernels take their storage as it is
-and the output is channels_last again, so a network that enters this layout at its stem stays in it (the other layers run
-on ATen, which keeps the format).  The weights are the views of the GHN's flat prediction buffer the GHN assigned to the
+Activations are torch ``channels_last`` tensors (NHWC in memory, NCHW in shape) inside the op family: the kernels take such
+storage as it is and return it, so consecutive fused blocks (the two halves of a SepConv) never convert.  At the boundary to
+the stock layers the activations are converted (``run_block``): the stock ATen / MIOpen layers of this ROCm build return
+wrong gradients for channels_last inputs, so the layout is not allowed to leak into them.  The weights are the views of the GHN's flat prediction buffer the GHN assigned to the
 layers -- read in place, no copy; their gradients leave as dense tensors for autograd to route back into that buffer.
 
 ``DwPwBn.applicable`` states what the kernels take (fp32 CUDA tensors, batch statistics, C <= 512, ks <= 7); a layer
@@ -125,9 +126,15 @@ def reference(x, w_dw, w_pw, gamma, beta, stride=1, padding=0, dilation=1, eps=1
     return F.batch_norm(zz, None, None, gamma, beta, True, 0.1, eps)
 
 
-def run_block(layers, x):
+def run_block(layers, x, keep_layout=False):
     """[ReLU, depthwise Conv2d, pointwise Conv2d, BatchNorm2d] (light or torch.nn flavour) on the fused op when it applies,
-    else layer by layer.  Running statistics of a tracking BatchNorm are updated as torch does (momentum, unbiased variance)."""
+    else layer by layer.  Running statistics of a tracking BatchNorm are updated as torch does (momentum, unbiased variance).
+
+    The fused op works on NHWC storage.  Its output is handed to the neighbouring (stock ATen / MIOpen) layers as a plain
+    NCHW-contiguous tensor unless keep_layout is set (the next layer is another fused block): on this ROCm build the stock
+    layers compute wrong parameter gradients for channels_last activations (tools/diag/target_ops_diag.py,
+    profiles/r05c_target_ops_channels_last_diag.txt), so the layout must not leak into them -- one transposing copy per
+    direction at the op's boundary until the neighbouring layers are native as well."""
     relu, dw, pw, bn = layers
     w_dw, w_pw = getattr(dw, 'weight', None), getattr(pw, 'weight', None)
     gamma, beta = getattr(bn, 'weight', None), getattr(bn, 'bias', None)
@@ -153,4 +160,4 @@ def run_block(layers, x):
             bn.running_var.mul_(1 - mom).add_(stats[2 * C:] * (n / max(n - 1, 1)), alpha=mom)
             if getattr(bn, 'num_batches_tracked', None) is not None:
                 bn.num_batches_tracked += 1
-    return out
+    return out if keep_layout else out.contiguous(memory_format=torch.contiguous_format)

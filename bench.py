@@ -650,16 +650,20 @@ def main():
         from ghn3_amd.optim import FusedAdamW
         opt = FusedAdamW(ghn, lr=1e-6, max_grad_norm=5.0)
         n_t = max(5, min(args.steps, 30))
-        for _ in range(2):
-            step()
-            opt.step(plan.gflat, plan=plan, local_grads=True)
-        torch.cuda.synchronize()
-        t_t = time.perf_counter()
-        for _ in range(n_t):
-            step()
-            opt.step(plan.gflat, plan=plan, local_grads=True)
-        torch.cuda.synchronize()
-        t_t = 1e3 * (time.perf_counter() - t_t) / n_t
+        def train_loop(overlap):
+            for _ in range(2):
+                step()
+                opt.step(plan.gflat, plan=plan, local_grads=True, overlap=overlap)
+            torch.cuda.synchronize()
+            t_ = time.perf_counter()
+            for _ in range(n_t):
+                step()
+                opt.step(plan.gflat, plan=plan, local_grads=True, overlap=overlap)
+            opt.wait()
+            torch.cuda.synchronize()
+            return 1e3 * (time.perf_counter() - t_) / n_t
+        t_serial = train_loop(False)
+        t_t = train_loop(True)           # (the decoder half of AdamW on the side stream beside the next Graphormer forward)
         ea, eb = L.Event(), L.Event()
         ea.record(stream)
         for _ in range(n_t):
@@ -680,8 +684,12 @@ def main():
         rest_ms, full_ms = refresh_ms(prog.shadow_ops_rest), refresh_ms(prog.shadow_ops)
         ghn.params_changed()
         extras['train_step'] = {'ms_per_step': t_t, 'value': n_pred / (t_t * 1e-3), 'adamw_ms': adam_ms,
+                                'ms_per_step_serial_optimizer': t_serial,
                                 'shadow_refresh_ms': rest_ms, 'shadow_refresh_without_fusion_ms': full_ms,
-                                'note': 'fwd + loss + bwd + fused clip / AdamW over %d GHN parameters; the update of '
+                                'note': 'fwd + loss + bwd + fused clip / AdamW over %d GHN parameters, the decoder half of the '
+                                        'update on the side stream beside the next forward\'s Graphormer chain (overlap=True; '
+                                        'ms_per_step_serial_optimizer = the same loop with the whole update on the chain\'s '
+                                        'stream); the update of '
                                         'decoder.conv.2.weight writes its 16-bit copies itself (adamw_ms includes that), '
                                         'shadow_refresh_ms = re-cast of the other copies in front of the next forward (run '
                                         'alone, side stream included), shadow_refresh_without_fusion_ms = all copies incl. W2'

@@ -533,7 +533,9 @@ int check_desc(const ghn3_dwpw_desc* g, Desc& d) {
 }
 
 template <typename K> int set_lds(K kern, size_t bytes) {
-    if (bytes > 48 * 1024) {
+    static bool done = false;                      // (one instance per kernel type: the attribute is set once per process)
+    if (bytes > 48 * 1024 && !done) {
+        done = true;
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(dwpw): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     }

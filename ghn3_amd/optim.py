@@ -67,7 +67,14 @@ class FusedAdamW:
         types = (prog.decoder_ctype, prog.decoder_bwd_ctype, prog.x3, prog.uses_op16)
         return lo, lo + it['rows'] * it['cols'], d, blocks, types
 
-    def step(self, gflat, grad_scale=1.0, plan=None, local_grads=False):
+    def wait(self):
+        """Makes torch's current stream wait for an overlapped step's side-stream half (see step(overlap=True)): call before
+        anything but a GHN3 forward reads the parameters or the moments (checkpoints, .cpu(), torch ops on them)."""
+        if getattr(self, '_side_busy', False):
+            self.ghn._ctx().side_wait(torch.cuda.current_stream().cuda_stream)
+            self._side_busy = False
+
+    def step(self, gflat, grad_scale=1.0, plan=None, local_grads=False, overlap=False):
         """gflat: the flat gradient buffer of the last backward (plan.gflat); grad_scale: the loss scale the gradients
         carry (AMP: they are divided by it inside the kernel, no separate unscale pass).  Returns the gradient norm
         (device scalar, like clip_grad_norm_) when clipping or the NaN guard is on; when it is not finite the kernel
@@ -77,7 +84,13 @@ class FusedAdamW:
         forward does not read the 1.8 GB again to re-cast them; same parameters bit for bit.
         local_grads: `gflat` is exactly what the plan's last backward wrote (NOT averaged over ranks afterwards).  The
         squared norm of the W2 gradient is then taken from the sums the weight-gradient kernel left per output tile
-        (Program.grad_sumsq, GHN3_GEMM_SUMSQ) instead of from a pass over its 1.8 GB."""
+        (Program.grad_sumsq, GHN3_GEMM_SUMSQ) instead of from a pass over its 1.8 GB.
+        overlap: the update of the DECODER parameters (93 % of them at ghn3xlm16: 3 ms of HBM-bound streaming) runs on the
+        context's side stream and the call returns with it pending; the embeddings and the Graphormer (updated on the
+        caller's stream first) are all the next forward needs for its first ~1 ms -- the latency-bound Graphormer chain --
+        and its program joins the side stream in front of the decoders (Program._build_decoder_forward).  Same kernels, same
+        order per element: parameters bit-identical to the serial step.  Until that forward (or wait()) nothing else may
+        read the decoder parameters / moments; the gradient buffer is kept alive here until the next call."""
         ghn = self.ghn
         flat = ghn._flat
         assert gflat.numel() == flat.numel() and gflat.is_cuda
@@ -85,7 +98,9 @@ class FusedAdamW:
         n = flat.numel()
         clip = self.max_grad_norm and self.max_grad_norm > 0
         fuse = self._w2_fusion(plan)
-        ops = np.zeros(5, dtype=L.OP_DT)
+        overlap = bool(overlap) and getattr(ghn, 'side_stream', True) and plan is not None and \
+            hasattr(plan.program, 'decoder_slots') and os.environ.get('GHN3_ADAMW_OVERLAP', '1') != '0'
+        ops = np.zeros(9, dtype=L.OP_DT)
         ops['r']['buf'][:] = -1
         bufs = [flat.data_ptr(), gflat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
                 self.scal.data_ptr(), self.scal.data_ptr() + 64, 0, 0]
@@ -118,7 +133,28 @@ class FusedAdamW:
             op['f'][0] = float(self.max_grad_norm or 0.0) if clip else 0.0
             op['f'][1] = 1.0 / float(grad_scale)
 
-        if fuse is None:
+        if overlap:
+            # [everything but the decoders] on the caller's stream, then the decoder ranges on the side stream, detached
+            d_lo, d_hi = ghn.decoder_grad_range(plan.program)
+            adamw(ops[2], L.OP_ADAMW, 0, d_lo)
+            adamw(ops[3], L.OP_ADAMW, d_hi, n - d_hi)
+            if fuse is None:
+                adamw(ops[4], L.OP_ADAMW, d_lo, d_hi - d_lo)
+            else:
+                lo, hi, descs, blocks, types = fuse
+                assert d_lo <= lo and hi <= d_hi
+                bufs[6], bufs[7] = ghn._shadow.data_ptr(), descs.data_ptr()
+                adamw(ops[4], L.OP_ADAMW, d_lo, lo - d_lo)
+                adamw(ops[5], L.OP_ADAMW, hi, d_hi - hi)
+                adamw(ops[6], L.OP_ADAMW_CAST16, lo, 1 + (blocks << 32))
+                ops[6]['r']['buf'][5:7] = (6, 7)
+            for k in (4, 5, 6):
+                if int(ops[k]['kind']) != L.OP_NOP:
+                    ops[k]['flags'] |= L.OPFLAG_SIDE
+            ops[7]['kind'] = L.OP_DETACH
+            self._side_busy = True
+            self._keep = gflat                   # (read by the side stream after this call returns)
+        elif fuse is None:
             adamw(ops[2], L.OP_ADAMW, 0, n)
         else:
             lo, hi, descs, blocks, types = fuse

@@ -1089,6 +1089,10 @@ class Program:
         # forward keeps the 1-D decoder on the chain unless GHN3_EARLY_1D_FWD=1; the backward, whose side stream is busy
         # anyway, moves it: see _build_backward)
         early_1d = bool(self.SIDE) and M > 0 and os.environ.get('GHN3_EARLY_1D_FWD', '0') == '1'
+        if self.SIDE:
+            # An overlapped optimizer step (FusedAdamW.step(overlap=True)) may still be updating the decoder parameters on
+            # the side stream: the Graphormer above needed none of them, everything below does (no-op when nothing is pending)
+            self.op(L.OP_JOIN)
         if early_1d:
             decoder_1d(True)
         if M > 0:

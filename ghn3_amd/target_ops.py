@@ -44,6 +44,20 @@ def _ptr(t):
     return ctypes.c_void_p(t.data_ptr())
 
 
+_SCRATCH = {}
+
+
+def _scratch_floats(lib, d, backward):
+    key = (d.N, d.H, d.W, d.C_in, d.C_out, d.ks, d.stride, d.pad, d.dil, backward)
+    n = _SCRATCH.get(key)
+    if n is None:
+        n = int(lib.ghn3_dwpw_scratch_floats(ctypes.byref(d), backward))
+        if n < 0:
+            raise L.Ghn3Error('ghn3_dwpw_scratch_floats: %s' % lib.ghn3_last_error().decode())
+        _SCRATCH[key] = n
+    return n
+
+
 def enabled():
     """GHN3_NATIVE_OPS=0 keeps every target-network layer on the stock ATen / MIOpen path (A/B measurements)."""
     return os.environ.get('GHN3_NATIVE_OPS', '1') != '0'
@@ -76,10 +90,7 @@ class DwPwBn(torch.autograd.Function):
         out = torch.empty((d.N, C_out, d.Ho, d.Wo), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
         z = torch.empty_like(out)
         stats = torch.empty(3 * C_out, dtype=torch.float32, device=dev)
-        n_scr = lib.ghn3_dwpw_scratch_floats(ctypes.byref(d), 0)
-        if n_scr < 0:
-            raise L.Ghn3Error('ghn3_dwpw_scratch_floats: %s' % lib.ghn3_last_error().decode())
-        scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
+        scratch = torch.empty(_scratch_floats(lib, d, 0), dtype=torch.float32, device=dev)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         L._check(lib.ghn3_dwpw_bn_fwd(ctypes.byref(d), _ptr(xc), _ptr(wd), _ptr(wp), _ptr(g), _ptr(b), _ptr(z), _ptr(out),
                                       _ptr(stats), _ptr(scratch), stream), 'ghn3_dwpw_bn_fwd')
@@ -98,10 +109,15 @@ class DwPwBn(torch.autograd.Function):
         dev = xc.device
         do = dout.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(xc)
-        dwd, dwp = torch.empty_like(wd), torch.empty_like(wp)
-        dg, db = torch.empty_like(g), torch.empty_like(g)
-        n_scr = lib.ghn3_dwpw_scratch_floats(ctypes.byref(d), 1)
-        scratch = torch.empty(n_scr, dtype=torch.float32, device=dev)
+        # (one allocation for the four parameter gradients and the scratch area: a call is launch- and host-bound for the
+        # small layers of a CIFAR network)
+        n_par = wd.numel() + wp.numel() + 2 * C_out
+        buf = torch.empty(n_par + 64 + _scratch_floats(lib, d, 1), dtype=torch.float32, device=dev)
+        dwd = buf[:wd.numel()].view(wd.shape)
+        dwp = buf[wd.numel():wd.numel() + wp.numel()].view(wp.shape)
+        dg = buf[n_par - 2 * C_out:n_par - C_out]
+        db = buf[n_par - C_out:n_par]
+        scratch = buf[(n_par + 63) // 64 * 64:]
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         L._check(lib.ghn3_dwpw_bn_bwd(ctypes.byref(d), _ptr(do), _ptr(xc), _ptr(z), _ptr(stats), _ptr(wd), _ptr(wp), _ptr(g),
                                       _ptr(dx), _ptr(dwd), _ptr(dwp), _ptr(dg), _ptr(db), _ptr(scratch), stream),

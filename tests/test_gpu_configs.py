@@ -320,6 +320,44 @@ def test_optimizer_step_writes_the_w2_copies_itself():
         assert torch.equal(again[p['offset']:p['offset'] + p['numel']], want[p['offset']:p['offset'] + p['numel']])
 
 
+@pytest.mark.parametrize('name,compute', [('ghn3tm8', 'f16'), ('ghn3lm8', 'f16'), ('ghn3tm8', 'f32')])
+def test_overlapped_optimizer_step_equals_the_serial_one(name, compute):
+    """FusedAdamW.step(overlap=True): the decoder ranges (incl. the W2 update that writes the 16-bit copies) run on the side
+    stream, detached, while the next forward's Graphormer chain starts; that forward joins in front of its decoders.  Same
+    kernels on the same elements: after k training steps parameters, both moments, predictions and gradients equal the
+    serial step's bit for bit -- also when a new plan (another architecture) is compiled between the steps and the old
+    gradient buffer is dropped while the side stream still reads it."""
+    from ghn3_amd import FusedAdamW
+    cases = [synthetic_case([48], 4800), synthetic_case([30, 25], 77)]
+    runs = {}
+    for overlap in (True, False):
+        hip, _ = make_models(_cfg(name), 7, compute=compute)
+        hip.train()
+        opt = FusedAdamW(hip, lr=1e-2, weight_decay=0.05, max_grad_norm=1.0)
+        torch.manual_seed(3)
+        outs = []
+        for k in range(4):
+            nets_h, gb_h, _, _ = cases[k % 2]
+            plan = hip.compile(nets_h, gb_h, training=True)          # (a fresh plan: workspace + gradient buffer reallocated)
+            out = hip._run_forward(plan).clone()
+            dout = torch.randn(plan.program.out_numel, device='cuda') * 1e-3
+            hip._run_backward(plan, dout)
+            outs.append((out, plan.gflat.clone(), plan.program.predicted))
+            opt.step(plan.gflat, plan=plan, overlap=overlap)
+            del plan, dout
+        opt.wait()
+        torch.cuda.synchronize()
+        runs[overlap] = (hip, opt, outs)
+    (ha, oa, xa), (hb, ob, xb) = runs[True], runs[False]
+    for k, ((o1, g1, pred), (o2, g2, _)) in enumerate(zip(xa, xb)):
+        for p in pred:
+            sl = slice(p['offset'], p['offset'] + p['numel'])
+            assert torch.equal(o1[sl], o2[sl]), (k, p['attr'])
+        assert torch.equal(g1, g2), (k, float((g1 - g2).abs().max()))
+    assert torch.equal(ha._flat, hb._flat) and torch.equal(oa.exp_avg, ob.exp_avg) and torch.equal(oa.exp_avg_sq, ob.exp_avg_sq)
+    assert float((xa[0][0][:1000] - xa[2][0][:1000]).abs().max()) > 0
+
+
 @pytest.mark.parametrize('compute', ['f16', 'f32'])
 def test_workspace_needs_zeros_only_where_the_program_says(compute, monkeypatch):
     """A plan's workspace starts uninitialised except the regions Program.ws_zero names (the 16-bit operand copies, whose

@@ -124,6 +124,10 @@ def test_networks_on_the_fused_layers_match_the_stock_path(light, monkeypatch):
                 for n, e in table.items():
                     setattr(e['module'], 'weight' if e['is_w'] else 'bias', views[n])
                 leaves = [flat]
+                for attr in ('auxiliary_head',):                  # (a torch.nn module with parameters of its own, ops.py:506-510)
+                    if hasattr(net, attr):
+                        getattr(net, attr).cuda()
+                        leaves += list(getattr(net, attr).parameters())
             else:
                 net = net.cuda()
                 params = recipe.seeded_net_params([(n, tuple(p.shape)) for n, p in net.named_parameters()], seed=len(name))

@@ -547,9 +547,22 @@ def main():
         eb.record(stream)
         serial_ms = ea.elapsed_ms(eb) / 3
         extras['rccl_ranks'] = int(round(float(ones.item())))
+        gbytes = int(plan.gflat.numel()) * 4
+        wire_b = gbytes // 2 if args.grad_allreduce == 'bf16' else gbytes
+        lo_d, hi_d = ghn.decoder_grad_range(prog)
+        w2_b = 4 * int(prog.C) ** 2 * 8 * int(prog.C)
         extras['exchange_ms'] = {'exposed': 1e3 * elapsed / args.steps - compute_ms, 'compute_only_ms_per_step': compute_ms,
-                                 'serial_fp32_allreduce': serial_ms, 'gradient_bytes': int(plan.gflat.numel()) * 4,
-                                 'wire': args.grad_allreduce}
+                                 'serial_fp32_allreduce': serial_ms, 'gradient_bytes': gbytes,
+                                 'wire': args.grad_allreduce,
+                                 'algorithm': (reducer.algo if reducer is not None else 'allreduce (one call behind the backward)'),
+                                 # what one rank puts on / takes off its xGMI links per step, by phase of the exchange
+                                 # (reduce-scatter + all-gather: (W - 1) / W of the buffer each way per half) and by the part
+                                 # of the backward that releases it (dW2 first: it overlaps everything behind it)
+                                 'bytes_per_rank': {'reduce_scatter_sent': wire_b * (world - 1) // max(world, 1),
+                                                    'all_gather_received': wire_b * (world - 1) // max(world, 1)},
+                                 'bytes_by_part': {'1: decoder.conv.2.weight (behind the W2 weight gradient, issued first)': w2_b,
+                                                   '2: rest of the decoder': 4 * (hi_d - lo_d) - w2_b,
+                                                   '3: Graphormer + embeddings (end of the backward)': gbytes - 4 * (hi_d - lo_d)}}
         if args.grad_allreduce == 'f32':
             exchange['reducer'] = FlatGradReducer(compress='bf16', force=args.force_ddp)
             for _ in range(2):

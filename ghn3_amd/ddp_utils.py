@@ -185,6 +185,26 @@ def mesh_all_reduce_avg(piece, wire_dtype=None, force=False):
     return piece
 
 
+def reduce_scatter_avg(piece, force=False):
+    """Mean reduce-scatter of a 1-D fp32 tensor whose length is a multiple of the world size W: returns this rank's chunk
+    (elements [r n / W, (r + 1) n / W) of the mean over ranks) as a new tensor.  RCCL: ncclReduceScatter with ncclAvg (one
+    collective on the xGMI mesh; RCCL picks its direct / ring schedule).  gloo (the CPU tests; no reduce-scatter there):
+    all-to-all + fp32 sum of the W chunks in rank order -- the same bits on every rank."""
+    W = dist.get_world_size()
+    n = piece.numel()
+    assert n % W == 0, (n, W)
+    per = n // W
+    if W == 1 and not force:
+        return piece.clone()
+    if piece.is_cuda and dist.get_backend() == 'nccl':
+        out = torch.empty(per, dtype=piece.dtype, device=piece.device)
+        dist.reduce_scatter_tensor(out, piece, op=dist.ReduceOp.AVG)
+        return out
+    recv = torch.empty_like(piece)
+    dist.all_to_all_single(recv, piece.contiguous())
+    return torch.sum(recv.view(W, per), dim=0, dtype=torch.float32).mul_(1.0 / W).to(piece.dtype)
+
+
 class FlatGradReducer:
     """
     Mean all-reduce of the flat gradient buffer, overlapped with the backward program:
@@ -207,21 +227,54 @@ class FlatGradReducer:
     a rank's graph.
     """
 
-    def __init__(self, compress=None, chunk_bytes=256 << 20, force=False, algo=None):
+    def __init__(self, compress=None, chunk_bytes=256 << 20, force=False, algo=None, gather=True):
         assert compress in (None, 'bf16')
         self.compress = compress
         self.chunk = max(1, chunk_bytes // 4)
         self.force = force                      # run the code path even for a 1-rank group (tests)
-        self.algo = algo or os.environ.get('GHN3_ALLREDUCE_ALGO', 'allreduce')
-        assert self.algo in ('mesh', 'allreduce')
+        # Round 5 default: 'rsag' = reduce-scatter + all-gather per chunk (RCCL's own two collectives on the mesh, fp32 on
+        # the wire): the same bytes as an all-reduce, every element summed once on its owner -- identical bits on all ranks
+        # -- and the two halves can be taken apart: with gather=False the exchange stops after the reduce-scatter and
+        # `owned` lists the ranges of the flat buffer whose MEAN gradient this rank holds (optim.ShardedAdamW updates those
+        # and all-gathers the updated PARAMETERS instead).  With bf16 on the wire 'rsag' runs the 'mesh' code (all-to-all of
+        # bf16 chunks + fp32 local sum).  'allreduce' = RCCL's all-reduce, 'mesh' = all-to-all + local sum + all-gather.
+        self.algo = algo or os.environ.get('GHN3_ALLREDUCE_ALGO', 'rsag')
+        assert self.algo in ('mesh', 'allreduce', 'rsag')
+        if self.algo == 'rsag' and compress == 'bf16':
+            self.algo = 'mesh'
+        self.gather = bool(gather)
+        assert self.gather or self.algo == 'rsag', 'gather=False needs the fp32 reduce-scatter exchange'
         self._comm = None
         self._pending = []                      # (work, flat slice, staging buffer or None)
         self._done = []                         # ranges already started
+        self.owned = []                         # (lo, hi) of this rank's shards after finish() (rsag)
+        self.replicated = []                    # (lo, hi) reduced on every rank (the < 64 W elements a chunk leaves over)
+        self.chunks = []                        # (start, length) of the chunks the shards were cut from
 
     def active(self):
         return is_ddp() and (dist.get_world_size() > 1 or self.force)
 
     def _issue(self, flat, lo, hi):
+        if self.algo == 'rsag':
+            W, r = dist.get_world_size(), dist.get_rank()
+            for s in range(lo, hi, self.chunk):
+                e = min(hi, s + self.chunk)
+                main = (e - s) // (64 * W) * (64 * W)         # (shards start on 64-float boundaries, like the parameters)
+                if main:
+                    per = main // W
+                    shard = reduce_scatter_avg(flat[s:s + main], force=self.force)
+                    if self.gather:
+                        dist.all_gather_into_tensor(flat[s:s + main], shard)
+                    else:
+                        flat[s + r * per:s + (r + 1) * per].copy_(shard)
+                    self.owned.append((s + r * per, s + (r + 1) * per))
+                    self.chunks.append((s, main))
+                if s + main < e:                              # (fewer than 64 W elements: reduced everywhere)
+                    tail = flat[s + main:e]
+                    dist.all_reduce(tail, op=dist.ReduceOp.SUM)
+                    tail.mul_(1.0 / W)
+                    self.replicated.append((s + main, e))
+            return
         if self.algo == 'mesh':
             wd = torch.bfloat16 if self.compress == 'bf16' else None
             for s in range(lo, hi, self.chunk):
@@ -251,6 +304,7 @@ class FlatGradReducer:
     def begin(self):
         """New backward: forget the ranges of the previous one."""
         self._done = []
+        self.owned, self.replicated, self.chunks = [], [], []
 
     def start(self, flat, lo, hi, wait_for=None):
         """May be called several times per backward (one range each, begin() first)."""

@@ -579,8 +579,8 @@ class GHN3(nn.Module):
             k = prog.memset_grad_op                      # (the memset placeholders live in the first part)
             prog.bwd_parts[0][0][k:k + 2] = prog.bwd_ops[k:k + 2]
             if kt is not None:
-                for k_ in patched:                       # (all in front of the W2 weight gradient: same index in part 1)
-                    prog.bwd_parts[0][0][k_] = prog.bwd_ops[k_]
+                for k_ in patched:                       # (all in front of the W2 weight gradient, i.e. in part 1)
+                    prog.bwd_parts[0][0][prog.ddp_index.get(k_, k_)] = prog.bwd_ops[k_]
             reducer.begin()
             n_off = len(self._offs)
             for ops, slots in prog.bwd_parts:

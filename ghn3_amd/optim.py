@@ -218,6 +218,126 @@ class FusedAdamW:
         self.steps = steps
 
 
+def adamw_reference_(p, g, m, v, sumsq, step, lr, betas, eps, weight_decay, max_norm, inv_scale):
+    """torch restatement of one GHN3_OP_ADAMW launch on views of the flat buffers (host-side reference of the sharded step's
+    CPU tests; the GPU path runs the HIP op): g / scale, clip coefficient from the GLOBAL squared norm `sumsq`, decoupled
+    weight decay, bias-corrected moments -- torch.optim.AdamW's update.  A non-finite norm leaves everything untouched."""
+    norm = float(sumsq) ** 0.5 * inv_scale
+    if not np.isfinite(norm):
+        return
+    coef = inv_scale * (min(1.0, max_norm / (norm + 1e-6)) if max_norm > 0 else 1.0)
+    gg = g * coef
+    p.mul_(1.0 - lr * weight_decay)
+    m.mul_(betas[0]).add_(gg, alpha=1.0 - betas[0])
+    v.mul_(betas[1]).addcmul_(gg, gg, value=1.0 - betas[1])
+    denom = (v / (1.0 - betas[1] ** step)).sqrt_().add_(eps)
+    p.addcdiv_(m / (1.0 - betas[0] ** step), denom, value=-lr)
+
+
+class ShardedAdamW:
+    """
+    The optimizer step split over the data-parallel ranks (ZeRO-1 shape; round 5).
+
+    The replicated trainer all-reduces 2.62 GB of gradients (ghn3xlm16) and then EVERY rank streams the same 18 GB through
+    AdamW (3.7 ms).  Here the gradient exchange stops after its reduce-scatter half (FlatGradReducer(gather=False)): a rank
+    holds the mean gradient of 1 / W of every chunk of the flat buffer, updates exactly those parameters (clip coefficient
+    from the all-reduced squared norm: one scalar) and all-gathers the updated PARAMETERS -- the same bytes on the wire as
+    the all-gather half of the gradient exchange it replaces, AdamW's HBM traffic divided by W (0.5 ms at W = 8).
+    Parameters after a step are bit-identical to the replicated path with the same exchange (every element is reduced once,
+    on its owner, in both).  The 16-bit copies of decoder.conv.2.weight are re-cast by the next forward (the fused
+    GHN3_OP_ADAMW_CAST16 works on whole 64 x 64 tiles of the matrix, not on arbitrary shards): 1.2 ms, against 3.2 ms saved
+    at W = 8.
+
+    `update(lo, hi, sumsq, step)`: applies AdamW to the range of the flat buffers; default = the HIP op on the GHN's buffers,
+    tests on CPU pass a torch restatement (adamw_reference_).
+    """
+
+    def __init__(self, ghn=None, flat=None, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, max_grad_norm=0.0,
+                 update=None, local_sumsq=None):
+        self.ghn = ghn
+        self.flat = ghn._flat if flat is None else flat
+        self.lr, self.betas, self.eps, self.weight_decay, self.max_grad_norm = lr, betas, eps, weight_decay, max_grad_norm
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        self.steps = 0
+        self._update, self._local_sumsq = update, local_sumsq
+        self.scal = torch.zeros(16 + 8192, dtype=torch.float32, device=self.flat.device)
+
+    def _hip_ops(self, recs, bufs):
+        ops = np.zeros(len(recs), dtype=L.OP_DT)
+        ops['r']['buf'][:] = -1
+        for k, fill in enumerate(recs):
+            fill(ops[k])
+        self.ghn._ctx().run(ops, np.zeros(0, dtype=L.PROBLEM_DT), np.asarray(bufs, dtype=np.uint64),
+                            torch.cuda.current_stream().cuda_stream)
+
+    def step(self, gflat, reducer, grad_scale=1.0):
+        """gflat: the flat gradient buffer after a backward whose exchange was `reducer` = FlatGradReducer(gather=False) --
+        reducer.owned / .replicated say which ranges hold the mean gradient here.  Returns the global gradient norm."""
+        import torch.distributed as dist
+        flat = self.flat
+        W = dist.get_world_size() if dist.is_initialized() else 1
+        rank = dist.get_rank() if dist.is_initialized() else 0
+        self.steps += 1
+        own, rep = sorted(reducer.owned), sorted(reducer.replicated)
+        # reducer.gather (the exchange also all-gathered the GRADIENTS): the replicated update -- every rank updates every
+        # element, nothing to gather afterwards; the squared norm is still summed shard-wise (1 / W of the buffer per rank +
+        # one scalar all-reduce), so both modes clip with the same bits
+        update_all = bool(getattr(reducer, 'gather', False))
+        ranges = [(0, flat.numel())] if update_all else sorted(own + rep)
+        norm_ranges = sorted(own + (rep if rank == 0 else []))             # (every element counted on exactly one rank)
+        hip = self._update is None
+        inv_scale = 1.0 / float(grad_scale)
+        if hip:
+            bufs = [flat.data_ptr(), gflat.data_ptr(), self.exp_avg.data_ptr(), self.exp_avg_sq.data_ptr(),
+                    self.scal.data_ptr(), self.scal.data_ptr() + 64]
+
+            def memset(op):
+                op['kind'], op['r']['buf'][0], op['i'][0] = L.OP_MEMSET0, 4, 4
+
+            def sumsq(lo, hi):
+                def f(op):
+                    op['kind'] = L.OP_SUMSQ
+                    op['r']['buf'][:3] = (4, 1, 5)
+                    op['r']['off'][1] = 4 * lo
+                    op['i'][0] = hi - lo
+                return f
+            self._hip_ops([memset] + [sumsq(lo, hi) for lo, hi in norm_ranges], bufs)
+            total = self.scal[:1]
+        else:
+            total = torch.zeros(1, dtype=torch.float32, device=flat.device)
+            for lo, hi in norm_ranges:
+                total += (self._local_sumsq or (lambda t: (t.double() ** 2).sum().float()))(gflat[lo:hi])
+        if W > 1:
+            dist.all_reduce(total, op=dist.ReduceOp.SUM)
+        if hip:
+            hyper = (self.lr, self.betas[0], self.betas[1], self.eps, self.weight_decay,
+                     1.0 - self.betas[0] ** self.steps, 1.0 - self.betas[1] ** self.steps)
+
+            def adamw(lo, hi):
+                def f(op):
+                    op['kind'] = L.OP_ADAMW
+                    op['r']['buf'][:5] = (0, 1, 2, 3, 4)
+                    op['r']['off'][:4] = 4 * lo
+                    op['i'][0] = hi - lo
+                    for k, h in enumerate(hyper):
+                        op['i'][1 + k] = _dbits(h)
+                    op['f'][0] = float(self.max_grad_norm or 0.0)
+                    op['f'][1] = inv_scale
+                return f
+            self._hip_ops([adamw(lo, hi) for lo, hi in ranges], bufs)
+            self.ghn.params_changed()
+        else:
+            for lo, hi in ranges:
+                self._update(flat[lo:hi], gflat[lo:hi], self.exp_avg[lo:hi], self.exp_avg_sq[lo:hi], total, self.steps,
+                             self.lr, self.betas, self.eps, self.weight_decay, float(self.max_grad_norm or 0.0), inv_scale)
+        # all-gather of the updated parameters: the geometry of the gradient chunks (replicated tails are identical already)
+        if (W > 1 or reducer.force) and not update_all:
+            for (s, main), (lo, hi) in zip(reducer.chunks, reducer.owned):
+                dist.all_gather_into_tensor(flat[s:s + main], flat[lo:hi].clone())
+        return total.sqrt() * inv_scale
+
+
 def save_checkpoint(path, ghn, optimizer, epoch, step, config=None):
     """Checkpoint in the reference trainer's format (trainer.py:413-426): {'state_dict', 'optimizer', 'epoch', 'step',
     **config}; `ghn3_amd.from_pretrained(path)` and the reference's resume code both read it."""

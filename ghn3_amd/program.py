@@ -196,9 +196,40 @@ class Program:
             cut1 = min(max(self.bwd_cut_w2, self.memset_grad_op + 2), self.bwd_split)
             cuts = [(cut1, [(w2, w2 + 1)]), (self.bwd_split, [(lo, w2), (w2 + 1, hi)])]
             self.bwd_parts, pos = [], 0
-            for end, slots in cuts:
-                self.bwd_parts.append((np.concatenate([self.bwd_ops[pos:end], detach]), slots))
-                pos = end
+            self.ddp_index = {}                          # op index in bwd_ops -> index inside part 1, where they differ
+            wg_first = self.wgrad_op_range is not None and getattr(self, '_i_dgrad', None) is not None and \
+                os.environ.get('GHN3_DDP_WGRAD_FIRST', '1') != '0'
+            self.ddp_wgrad_first = bool(wg_first)
+            if wg_first:
+                # Round 5: the W2 weight gradient FIRST.  dW2 is 69 % of the gradient bytes and needs nothing but the tile
+                # gradient and the forward's u: issued right behind the tile backward and its operand copies -- on the
+                # run's own stream, every CU -- its exchange overlaps the W2 dgrad, the conv.0 / fc backward AND the whole
+                # Graphormer backward (~2.5 ms at ghn3xlm16) instead of the Graphormer backward alone (~1.1 ms).
+                o = self.bwd_ops
+                a, b = self.wgrad_op_range
+                dg0, l0, l1 = self._i_dgrad, self._i_late0, self._i_late1
+                assert self.memset_grad_op + 2 <= dg0 <= l0 <= l1 <= a <= b <= self.bwd_split
+                # (the operand copies run on the side stream: MARK + WAIT on slot 1 -- not a full join, which would also
+                # consume the pending mark of the 1-D decoder backward that part 3 waits for)
+                join = np.zeros(2, dtype=L.OP_DT)
+                join['kind'] = L.OP_JOIN
+                join['r']['buf'][:] = -1
+                join[0]['i'][:2] = (1, 1)
+                join[1]['i'][:2] = (2, 1)
+                wg = o[a:b].copy()
+                for q in range(len(wg)):                 # the persistent band launch: chain's stream, no grid cap
+                    if int(wg[q]['kind']) == L.OP_GEMM and int(wg[q]['i'][2]) == 29:
+                        wg[q]['flags'] &= ~L.OPFLAG_SIDE
+                        wg[q]['i'][3] = 0
+                part1 = np.concatenate([o[:dg0], o[l0:l1], join, wg, detach])
+                part2 = np.concatenate([o[dg0:l0], o[l1:a], o[b:self.bwd_split], detach])
+                self.ddp_index = {k: dg0 + (k - l0) for k in range(l0, l1)}
+                self.bwd_parts = [(part1, cuts[0][1]), (part2, cuts[1][1])]
+                pos = self.bwd_split
+            else:
+                for end, slots in cuts:
+                    self.bwd_parts.append((np.concatenate([self.bwd_ops[pos:end], detach]), slots))
+                    pos = end
             self.bwd_parts.append((self.bwd_ops[pos:], []))
             # Single-process order (bwd_ops; the parts above keep the early order so that a data-parallel run can start the
             # exchange of dW2 -- 69 % of the gradient bytes -- as soon as possible): the W2 weight gradient is issued
@@ -1978,9 +2009,12 @@ class Program:
                           g['rows'], 8 * C, g['cols'], g['ld'], 8 * C, 8 * C, a_mode=L.MODE_ROW, b_mode=L.MODE_COL,
                           b_qs=(g['i_ld'], ms[1]), ksplit=ks)
             p8_dgrad = planes and any(g.get('p8') for g in g16)
+            self._i_dgrad = len(self._ops)               # (op indices the data-parallel order is cut at, see bwd_parts)
             self.gemm_op(p0, ctype=bct if g16 else None, tag=self.TAG_D3_DGRAD, flops=fl,
                          tile=28 if p8_dgrad else 20 if use_rect else 0)
+            self._i_late0 = len(self._ops)
             self._ops.extend(late_ops)
+            self._i_late1 = len(self._ops)
             if (planes or planes32) and n_planes > 1:
                 self.op(L.OP_DACT, refs=(d_u, u, amax_u if amax_u is not None else self.NONE, d_up),
                         ints=(M, 8 * C, 8 * C, L.DACT_RELU, n_planes - 1, M * 8 * C, rows16))

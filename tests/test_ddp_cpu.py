@@ -230,3 +230,56 @@ def test_collective_schedule_is_identical_for_different_graphs_world2():
     assert all(a[0] == 'all_to_all_single' and b[0] == 'all_gather_into_tensor' and a[2] == b[2] == 'torch.bfloat16'
                for a, b in zip(seq[0::2], seq[1::2]))
     assert sum(a[1] for a in seq[0::2]) >= total0
+
+
+def _sharded_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from ghn3_amd.ddp_utils import setup_ddp, FlatGradReducer, clean_ddp
+    from ghn3_amd.optim import ShardedAdamW, adamw_reference_
+    setup_ddp()
+    n = 64 * 1500 + 37 * 64 + 21                       # chunks that do not divide by 64 W, a ragged end
+    ranges = [(64 * 700, 64 * 1200), (64 * 10, 64 * 700)]            # "W2" first, then "the rest of the decoder"
+    kw = dict(lr=1e-2, betas=(0.9, 0.99), eps=1e-8, weight_decay=0.05, max_grad_norm=0.5)
+    p0 = torch.linspace(-1, 1, n)
+    runs = {}
+    for sharded in (True, False):
+        flat = p0.clone()
+        opt = ShardedAdamW(flat=flat, update=adamw_reference_, **kw)
+        norms = []
+        for step in range(3):
+            g = torch.randn(n, generator=torch.Generator().manual_seed(100 * step + rank)) * (1.0 + step)
+            if step == 2 and rank == world - 1:
+                g = g * 5.0                            # (so that the clip is active in one step and the ranks differ)
+            red = FlatGradReducer(chunk_bytes=4 * 64 * 190, algo='rsag', gather=not sharded)
+            red.begin()
+            for lo, hi in ranges:
+                red.start(g, lo, hi)
+            red.finish(g)
+            # (gather=True: the exchange also gathered the gradients, every rank updates everything -- the replicated trainer)
+            norms.append(float(opt.step(g, red)))
+        runs[sharded] = (flat, norms, sorted(red.owned), sorted(red.replicated))
+    (fa, na, own, rep), (fb, nb, _, _) = runs[True], runs[False]
+    owned_elems = sum(hi - lo for lo, hi in own)
+    ret[rank] = (bool(torch.equal(fa, fb)), na, nb, owned_elems, sum(hi - lo for lo, hi in rep), n,
+                 float((fa - p0).abs().max()))
+    clean_ddp()
+
+
+def test_sharded_optimizer_step_equals_the_replicated_one_world2():
+    """ShardedAdamW (reduce-scatter of the gradients -> every rank updates the 1 / W of each chunk it owns -> all-gather of
+    the updated parameters) against the replicated step (reduce-scatter + all-gather of the gradients, every rank updates
+    everything), same exchange algorithm and the same update function: parameters bit-identical after three steps incl.
+    one with an active clip, the clip coefficient from the all-reduced squared norm; a rank owns ~1 / W of the elements."""
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_sharded_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    for r in range(world):
+        same, na, nb, owned, rep, n, moved = ret[r]
+        assert same and moved > 1e-3
+        assert all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(na, nb)), (na, nb)
+        assert abs(owned - (n - rep) / world) < 1 and rep < 64 * world * 12
+    assert ret[0][1] == ret[1][1]                       # the same norm on both ranks

@@ -647,7 +647,7 @@ def test_split_backward_with_overlapped_gradient_reduction():
         ref = plan.gflat.clone()
         # both exchange algorithms; with force=True the mesh path really issues its all-to-all / all-gather in the 1-rank
         # RCCL group and runs its local passes as library ops (GHN3_OP_WIRE_PACK, GHN3_OP_RANK_REDUCE)
-        for algo in ('allreduce', 'mesh'):
+        for algo in ('allreduce', 'mesh', 'rsag'):
             for compress, tol in ((None, 2e-5), ('bf16', 1e-2)):
                 hip._run_backward(plan, dout, reducer=FlatGradReducer(compress=compress, force=True, algo=algo))
                 torch.cuda.synchronize()
@@ -655,9 +655,30 @@ def test_split_backward_with_overlapped_gradient_reduction():
                 assert err < tol, (algo, compress, err)
             lo, hi = hip.decoder_grad_range(plan.program)
             assert 0 < lo < hi <= ref.numel() and (hi - lo) > 0.5 * ref.numel()
+        # the sharded optimizer step on the same path (reduce-scatter only, update of the owned shard, all-gather of the
+        # parameters; in a 1-rank group the shard is everything): the HIP ops over the shard ranges give the parameters and
+        # moments of the plain fused step bit for bit (no clip: the two sum the squared norm in different orders)
+        from ghn3_amd import FusedAdamW
+        from ghn3_amd.optim import ShardedAdamW
+        twin, _ = make_models(T_CFG, 7, compute='f16')
+        twin.train()
+        opt_s = ShardedAdamW(ghn=hip, lr=1e-2, weight_decay=0.05, max_grad_norm=0.0)
+        opt_f = FusedAdamW(twin, lr=1e-2, weight_decay=0.05, max_grad_norm=0.0)
+        for _ in range(2):
+            red = FlatGradReducer(force=True, algo='rsag', gather=False, chunk_bytes=1 << 20)
+            hip._run_backward(plan, dout, reducer=red)
+            assert red.owned and sum(b - a for a, b in red.owned + red.replicated) == ref.numel()
+            n_s = opt_s.step(plan.gflat, red)
+            n_f = opt_f.step(plan.gflat.clone())
+            torch.cuda.synchronize()
+            assert abs(float(n_s) - float(n_f)) <= 1e-5 * float(n_f)
+            assert torch.equal(hip._flat, twin._flat) and torch.equal(opt_s.exp_avg, opt_f.exp_avg) and \
+                torch.equal(opt_s.exp_avg_sq, opt_f.exp_avg_sq)
+            hip._run_forward(plan)                      # (the copies of the updated weights are re-cast here)
         # three parts: ... W2 gradient | rest of the decoder | Graphormer
+        # (+ two DETACH records, + the MARK / WAIT pair in front of the weight gradient when it is issued first)
         assert len(plan.program.bwd_parts) == 3 and sum(len(o) for o, _ in plan.program.bwd_parts) == \
-            len(plan.program.bwd_ops) + 2
+            len(plan.program.bwd_ops) + 2 + 2 * int(plan.program.ddp_wgrad_first)
         # the local passes alone, against torch: W-way fp32 sum of bf16 chunks in rank order, pack / unpack round trip
         from ghn3_amd.ddp_utils import _hip_ops
         from ghn3_amd import _lib as L

@@ -417,10 +417,13 @@ def test_mark_wait_pairs_survive_the_data_parallel_split():
     prog = Program(cfg, gb_h.node_info, gb_h.host_n_nodes(), gb_h._node_type_host, gb_h.max_edge, nets_h,
                    decoder_ctype=L.CT_F16, decoder_bwd_ctype=L.CT_F16)
     assert prog.n1 > 0 and prog.M > 0
-    for runs in ([prog.bwd_ops], [p for p, _ in prog.bwd_parts], [prog.bwd_ops_a, prog.bwd_ops_b]):
+    for k_run, runs in enumerate(([prog.bwd_ops], [p for p, _ in prog.bwd_parts], [prog.bwd_ops_a, prog.bwd_ops_b])):
         n_marks = sum(int(o['kind']) == L.OP_JOIN and int(o['i'][0]) == 1 for ops in runs for o in ops)
         waits = _simulate_side_state(runs)
-        assert n_marks == 1 and len(waits) == 1, (n_marks, waits)
+        # (the data-parallel parts carry a second pair, slot 1: the operand copies in front of the weight gradient that is
+        # issued first there -- it must not consume the 1-D decoder's mark on slot 0)
+        want = 1 + int(k_run == 1 and prog.ddp_wgrad_first)
+        assert n_marks == want and len(waits) == want, (n_marks, waits)
         assert all(ok for (_, _, ok) in waits), waits
     # the mark is in the first part, its wait in the last one
     parts = [p for p, _ in prog.bwd_parts]
@@ -430,7 +433,57 @@ def test_mark_wait_pairs_survive_the_data_parallel_split():
     passes = np.zeros(1, dtype=L.OP_DT)
     passes['kind'] = L.OP_WIRE_PACK
     waits = _simulate_side_state([parts[0], passes, parts[1], passes, parts[2]])
-    assert len(waits) == 1 and waits[0][2]
+    assert len(waits) == 1 + int(prog.ddp_wgrad_first) and all(w[2] for w in waits)
+
+
+@pytest.mark.parametrize('case,route', [('b2', 'dout'), ('b2', 'norm'), ('syn', 'norm'), ('ragged3', 'dout')])
+def test_data_parallel_parts_give_the_gradients_of_the_single_run(case, route):
+    """Program.bwd_parts (round 5: the W2 weight gradient FIRST -- behind the tile backward and its operand copies, in front
+    of the W2 dgrad -- so that the exchange of dW2, 69 % of the bytes, overlaps everything else of the backward): the three
+    parts run one after the other write the gradient buffer of the single-run order bit for bit, on both tile-gradient
+    routes (the route switch patches ops of part 1 through Program.ddp_index), and dW2 is complete after part 1."""
+    if case == 'syn':
+        from util_parity import synthetic_case
+        cfg = dict(max_shape=(128, 128, 16, 16), num_classes=1000, hid=128, heads=8, layers=1, weight_norm=True,
+                   ve=True, layernorm=True)
+        mk = lambda: (_build(cfg, recipe.TINY_SEED, 'reference')[0],) + tuple(synthetic_case([40], 4400)[:2])
+    else:
+        mk = lambda: (_build(recipe.TINY_CFG, recipe.TINY_SEED, 'reference')[0],) + tuple(_tiny(case)[:2])
+    grads = []
+    for split in (False, True):
+        hip, nets_h, gb_h = mk()
+        prog, it, bufs, gflat = _run_program(hip, nets_h, gb_h, decoder_ctype=L.CT_F16, decoder_bwd_ctype=L.CT_F16)
+        assert prog.ddp_wgrad_first and len(prog.bwd_parts) == 3
+        it.run(prog.norm_fin_ops(), prog.problems)
+        bufs[prog.xbuf(prog.X_NORMG)] = np.asarray([0.37], dtype=np.float32).view(np.uint8)
+        dout = (1e-3 * np.random.RandomState(4).standard_normal(prog.out_numel)).astype(np.float32)
+        bufs[prog.xbuf(prog.X_DOUT)] = dout.view(np.uint8)
+        it.bufs = bufs
+        r = prog.bwd_ops[prog.tile_bwd_op]['r']
+        for slot, (buf, off) in prog.tile_bwd_refs.items():
+            on = (route == 'dout') if slot == 0 else (route == 'norm')
+            r[slot]['buf'], r[slot]['off'] = (buf, off) if on else (-1, 0)
+        patched = [prog.tile_bwd_op] + prog.set_tile_route(route == 'norm')
+        gflat[:] = 0x7f
+        hip._patch_grad_memsets(prog)
+        if not split:
+            it.run(prog.bwd_ops, prog.problems)
+        else:
+            k = prog.memset_grad_op                              # (what GHN3._run_backward patches into part 1)
+            prog.bwd_parts[0][0][k:k + 2] = prog.bwd_ops[k:k + 2]
+            for k_ in patched:
+                prog.bwd_parts[0][0][prog.ddp_index.get(k_, k_)] = prog.bwd_ops[k_]
+            w2 = prog.slot['decoder.conv.2.weight']
+            for n_part, (ops, slots) in enumerate(prog.bwd_parts):
+                it.run(ops, prog.problems)
+                if n_part == 0:
+                    assert slots == [(w2, w2 + 1)]
+                    w2_after_part1 = gflat.view(np.float32)[int(hip._offs[w2]):int(hip._offs[w2 + 1])].copy()
+        grads.append(gflat.view(np.float32).copy())
+    a, b = grads
+    assert np.isfinite(a).all() and np.array_equal(a, b)
+    w2 = prog.slot['decoder.conv.2.weight']
+    assert np.array_equal(w2_after_part1, a[int(hip._offs[w2]):int(hip._offs[w2 + 1])]) and np.abs(w2_after_part1).max() > 0
 
 
 @pytest.mark.parametrize('case', ['b2', 'syn', 'ragged3'])

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmProbDev* __re
 #ifdef GHN3_P8W_PROBE
 __device__ long long g_p8w_probe[8];
 #endif
-template <int CT>
+template <int CT, int QUIET>
 __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int total_tiles_all,
                                                            int vgrid, int tpw) {
     constexpr int MI = 4, BK = 64;
@@ -621,37 +621,45 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
 #endif
         const char* ring = sm + (G & 1) * KT;
         const bool st = first && p_valid;
-        if (st) P8W_ST_T(store_prev(0, 0));
+        // QUIET store k-tile (round 5, default; GHN3_P8W_QUIET=0 turns it off): stores and LDS-DMA share the wave's vmcnt, so a counted
+        // wait behind stores also waits for their write acknowledgements -- in the k-tile that carries a tile's 256 KB of
+        // stores that wait (and the store instructions queueing behind DMA requests) cost most of its 21-27k cycles.  Quiet:
+        // the k-tile first lets everything in flight land (one exposed round trip for the newest half-tile), issues NO DMA
+        // while it stores, and issues its three half-tiles at its very end; the first counted wait that sees the stores
+        // again is the next k-tile's, a whole k-tile later.
+        const bool quiet = QUIET && st;
+        if (st && !quiet) P8W_ST_T(store_prev(0, 0));
         read_b(ring, 0);                              // (first: retired by the counted lgkmcnt below)
         __builtin_amdgcn_sched_barrier(0);
         read_a(ring, 0);
         __builtin_amdgcn_sched_barrier(0);
         issue(3);
+        if (quiet) { wait_vm<0>(); P8W_ST_T(store_prev(0, 0)); }
         asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * MI) : "memory");
         P8W_BAR_T();
         mfma_q(0, 0, first);
         P8W_BAR_T();
         if (st) P8W_ST_T(store_prev(0, 1));
         read_b(ring, 1);
-        issue(0);
+        if (!quiet) issue(0);
         P8W_BAR_T();
         mfma_q(0, 1, first);
         P8W_BAR_T();
         if (st) P8W_ST_T(store_prev(1, 1));
         read_a(ring, 1);
-        issue(1);
+        if (!quiet) issue(1);
         P8W_BAR_T();
         mfma_q(1, 1, first);
         P8W_BAR_T();
-        issue(2);
 #ifdef GHN3_P8W_PROBE
         const long long pr_w0 = P8W_CLK();
 #endif
-        wait_next_ktile();
+        if (!quiet) { issue(2); wait_next_ktile(); }
 #ifdef GHN3_P8W_PROBE
         pr_wait[st ? 0 : 1] += P8W_CLK() - pr_w0;
 #endif
         if (st) { P8W_ST_T(store_prev(1, 0)); finish_sq(); }    // (behind the wait: these stores are not waited for with the DMA)
+        if (quiet) { issue(0); issue(1); issue(2); }  // (k-tile G + 1 had landed before the stores; these are for G + 2)
         P8W_BAR_T();
         mfma_q(1, 0, first);
         P8W_BAR_T();
@@ -710,9 +718,13 @@ int ghn3_gemm_p8_init() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)gemm_p8_kernel<GHN3_CT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Lds);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_F16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_BF16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_F16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_BF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(p8): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     {
         int dev = 0, n_cu = 0;
@@ -764,11 +776,20 @@ int ghn3_gemm_p8w_launch(const GemmProbDev* d_probs, int n_probs, int total_tile
     const int chunks = tpw > 0 ? (per_worker + tpw - 1) / tpw : 1;
     static const int nt = getenv("GHN3_WGRAD_NT") ? atoi(getenv("GHN3_WGRAD_NT")) != 0 : 0;
     const int tpw_arg = tpw | (nt << 30);
-    if (ctype == GHN3_CT_F16)
-        hipLaunchKernelGGL(gemm_p8w_kernel<GHN3_CT_F16>, dim3(grid * chunks), dim3(512), 128 * 1024, stream, d_probs, n_probs,
+    // quiet store k-tile (see the kernel): on by default since round 5 -- 0.95-0.97 -> 0.91-0.93 ms for the ghn3xlm16 bench
+    // workload, bit-identical results (profiles/r05h_ab_wgrad_quiet_store_ktile.txt); GHN3_P8W_QUIET=0 = the round-4 loop
+    static const int quiet = getenv("GHN3_P8W_QUIET") ? atoi(getenv("GHN3_P8W_QUIET")) != 0 : 1;
+    if (ctype == GHN3_CT_F16 && quiet)
+        hipLaunchKernelGGL((gemm_p8w_kernel<GHN3_CT_F16, 1>), dim3(grid * chunks), dim3(512), 128 * 1024, stream, d_probs, n_probs,
+                           total_tiles, grid, tpw_arg);
+    else if (ctype == GHN3_CT_F16)
+        hipLaunchKernelGGL((gemm_p8w_kernel<GHN3_CT_F16, 0>), dim3(grid * chunks), dim3(512), 128 * 1024, stream, d_probs, n_probs,
+                           total_tiles, grid, tpw_arg);
+    else if (quiet)
+        hipLaunchKernelGGL((gemm_p8w_kernel<GHN3_CT_BF16, 1>), dim3(grid * chunks), dim3(512), 128 * 1024, stream, d_probs, n_probs,
                            total_tiles, grid, tpw_arg);
     else
-        hipLaunchKernelGGL(gemm_p8w_kernel<GHN3_CT_BF16>, dim3(grid * chunks), dim3(512), 128 * 1024, stream, d_probs, n_probs,
+        hipLaunchKernelGGL((gemm_p8w_kernel<GHN3_CT_BF16, 0>), dim3(grid * chunks), dim3(512), 128 * 1024, stream, d_probs, n_probs,
                            total_tiles, grid, tpw_arg);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("p8w gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }

@@ -24,6 +24,8 @@
 // (fixed-order partial slots).  Weights are read IN PLACE: w_dw [C_in][ks][ks], w_pw [C_out][C_in], gamma / beta [C_out] are
 // views of the GHN's flat prediction buffer; their gradients are written densely for autograd to route back into it.
 // Limits (checked by the host): C_in, C_out multiples of 4 and <= 512, ks <= 7 (odd or even), N H W C < 2^31.
+// w_dw == nullptr (ks = 1): the same family as ReLU -> 1x1 convolution (stride) -> BatchNorm = `ReLUConvBN` with a 1x1 kernel,
+// the preprocessing layer of every cell and the `conv_1x1` op (ops.py:180-198): the depthwise stage degenerates to the ReLU.
 
 #include <algorithm>
 #include "ghn3_internal.h"
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void tnet_dwpw_fwd_kernel(const float* __restr
         __syncthreads();                                                       // (previous chunk's fragments are consumed)
         for (int i = tid; i < taps * KC; i += 256) {
             const int t = i / KC, cc = i % KC, c = c0 + cc;
-            wt[t * KC + cc] = c < d.C_in ? w_dw[(int64_t)c * taps + t] : 0.f;
+            wt[t * KC + cc] = c < d.C_in ? (w_dw ? w_dw[(int64_t)c * taps + t] : 1.f) : 0.f;
         }
         for (int i = tid; i < 16 * NT * 8; i += 256) {
             const int n = i >> 3, k = (i & 7) * 4, c = c0 + k;
@@ -387,7 +389,7 @@ __global__ __launch_bounds__(256) void tnet_pw_wgrad_kernel(const float* __restr
     const int pa = chunk * chunk_px, pb = min(P, pa + chunk_px);
     for (int i = tid; i < taps * 64; i += 256) {
         const int t = i >> 6, cc = i & 63, c = ci0 + cc;
-        wt[t * 64 + cc] = c < d.C_in ? w_dw[(int64_t)c * taps + t] : 0.f;
+        wt[t * 64 + cc] = c < d.C_in ? (w_dw ? w_dw[(int64_t)c * taps + t] : 1.f) : 0.f;
     }
     f32x4 acc[4];
 #pragma unroll
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(256) void tnet_dw_bwd_data_kernel(const float* __re
                 const f32x4 g = *reinterpret_cast<const f32x4*>(dy + ((int64_t)(n * d.Ho + oh) * d.Wo + ow) * d.C_in + c);
                 const int t = kh * d.ks + kw;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[e] = fmaf(g[e], w_dw[(int64_t)(c + e) * taps + t], acc[e]);
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(g[e], w_dw ? w_dw[(int64_t)(c + e) * taps + t] : 1.f, acc[e]);
             }
         }
         const f32x4 xv = *reinterpret_cast<const f32x4*>(x + i * 4);
@@ -561,7 +563,8 @@ extern "C" int ghn3_dwpw_bn_fwd(const ghn3_dwpw_desc* g, const float* x, const f
     Desc d;
     int rc = check_desc(g, d);
     if (rc) return rc;
-    if (!x || !w_dw || !w_pw || !gamma || !beta || !z || !out || !stats || !scratch) { ghn3_set_error("dwpw fwd: null pointer"); return GHN3_E_ARG; }
+    if (!x || !w_pw || !gamma || !beta || !z || !out || !stats || !scratch) { ghn3_set_error("dwpw fwd: null pointer"); return GHN3_E_ARG; }
+    if (!w_dw && (d.ks != 1 || d.pad != 0)) { ghn3_set_error("dwpw: without depthwise weights the op is ReLU -> 1x1 conv -> norm: ks = 1, pad = 0"); return GHN3_E_ARG; }
     hipStream_t s = (hipStream_t)stream_;
     const Plan pl = make_plan(d);
     const int NT = nt_of(d.C_out);
@@ -586,10 +589,11 @@ extern "C" int ghn3_dwpw_bn_bwd(const ghn3_dwpw_desc* g, const float* dout, cons
     Desc d;
     int rc = check_desc(g, d);
     if (rc) return rc;
-    if (!dout || !x || !z || !stats || !w_dw || !w_pw || !gamma || !dx || !dw_dw || !dw_pw || !dgamma || !dbeta || !scratch) {
+    if (!dout || !x || !z || !stats || !w_pw || !gamma || !dx || !dw_pw || !dgamma || !dbeta || !scratch || (w_dw && !dw_dw)) {
         ghn3_set_error("dwpw bwd: null pointer");
         return GHN3_E_ARG;
     }
+    if (!w_dw && (d.ks != 1 || d.pad != 0)) { ghn3_set_error("dwpw: without depthwise weights ks = 1, pad = 0"); return GHN3_E_ARG; }
     hipStream_t s = (hipStream_t)stream_;
     const Plan pl = make_plan(d);
     const int taps = d.ks * d.ks;
@@ -635,12 +639,14 @@ extern "C" int ghn3_dwpw_bn_bwd(const ghn3_dwpw_desc* g, const float* dout, cons
         hipLaunchKernelGGL(tnet_dw_bwd_data_kernel, dim3((int)std::min<int64_t>((total4 + 255) / 256, 8192)), dim3(256), 0, s, dy, x, w_dw,
                            dx, d, total4);
         LAUNCH_CHECK("dw bwd data")
-        hipLaunchKernelGGL(tnet_dw_wgrad_kernel, dim3(pl.dw_chunks), dim3(256), 0, s, dy, x, part_dw, d, pl.P, pl.dw_chunk_px);
-        LAUNCH_CHECK("dw wgrad")
-        const int64_t cols = (int64_t)taps * d.C_in;
-        hipLaunchKernelGGL(tnet_reduce_rows_kernel, dim3((int)((cols / 4 + 15) / 16)), dim3(256), 0, s, part_dw, pl.dw_chunks, cols, dw_dw,
-                           d.C_in, taps);
-        LAUNCH_CHECK("dw wgrad reduce")
+        if (w_dw) {
+            hipLaunchKernelGGL(tnet_dw_wgrad_kernel, dim3(pl.dw_chunks), dim3(256), 0, s, dy, x, part_dw, d, pl.P, pl.dw_chunk_px);
+            LAUNCH_CHECK("dw wgrad")
+            const int64_t cols = (int64_t)taps * d.C_in;
+            hipLaunchKernelGGL(tnet_reduce_rows_kernel, dim3((int)((cols / 4 + 15) / 16)), dim3(256), 0, s, part_dw, pl.dw_chunks, cols,
+                               dw_dw, d.C_in, taps);
+            LAUNCH_CHECK("dw wgrad reduce")
+        }
     }
     return GHN3_OK;
 }

@@ -153,8 +153,11 @@ class _ReLUConvBN:
         else:
             convs = [Lyr.Conv2d(C_in, C_out, ks, stride=stride, padding=padding, bias=False)]
         self.op = Lyr.Sequential(Lyr.ReLU(inplace=False), *convs, bn_layer(Lyr, norm, C_out))
+        self._pointwise = (not double) and ks == 1 and padding == 0
 
     def forward(self, x):
+        if self._pointwise and x.is_cuda:                # (ReLU -> 1x1 conv -> norm: the fused HIP op without a depthwise stage)
+            return target_ops.run_pointwise_block(list(self.op), x)
         return self.op(x)
 
 

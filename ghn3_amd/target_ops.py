@@ -71,20 +71,20 @@ class DwPwBn(torch.autograd.Function):
         if torch.is_autocast_enabled():
             return False                       # (under AMP the stock path decides the types)
         if not training_stats or not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32
-                                         for t in (w_dw, w_pw, gamma, beta)):
+                                         for t in (w_pw, gamma, beta) + (() if w_dw is None else (w_dw,))):
             return False
         C_in, C_out = x.shape[1], w_pw.shape[0]
         return C_in % 4 == 0 and C_out % 4 == 0 and C_in <= 512 and C_out <= 512 and ks <= 7 and \
-            x.numel() < 2 ** 31 and w_dw.shape[1] == 1
+            x.numel() < 2 ** 31 and (w_dw is None or w_dw.shape[1] == 1) and w_pw.numel() == C_out * C_in
 
     @staticmethod
     def forward(ctx, x, w_dw, w_pw, gamma, beta, stride, pad, dil, eps):
         lib = L.load()
-        ks = int(w_dw.shape[-1])
+        ks = 1 if w_dw is None else int(w_dw.shape[-1])
         C_out = int(w_pw.shape[0])
         xc = x.contiguous(memory_format=torch.channels_last)          # (a no-op inside a channels_last network)
         d = _desc(xc, C_out, ks, stride, pad, dil, eps)
-        wd, wp = w_dw.contiguous(), w_pw.contiguous()
+        wd, wp = (None if w_dw is None else w_dw.contiguous()), w_pw.contiguous()
         g, b = gamma.contiguous(), beta.contiguous()
         dev = x.device
         out = torch.empty((d.N, C_out, d.Ho, d.Wo), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
@@ -92,9 +92,10 @@ class DwPwBn(torch.autograd.Function):
         stats = torch.empty(3 * C_out, dtype=torch.float32, device=dev)
         scratch = torch.empty(_scratch_floats(lib, d, 0), dtype=torch.float32, device=dev)
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        L._check(lib.ghn3_dwpw_bn_fwd(ctypes.byref(d), _ptr(xc), _ptr(wd), _ptr(wp), _ptr(g), _ptr(b), _ptr(z), _ptr(out),
-                                      _ptr(stats), _ptr(scratch), stream), 'ghn3_dwpw_bn_fwd')
-        ctx.save_for_backward(xc, z, stats, wd, wp, g)
+        L._check(lib.ghn3_dwpw_bn_fwd(ctypes.byref(d), _ptr(xc), _ptr(wd) if wd is not None else None, _ptr(wp), _ptr(g), _ptr(b),
+                                      _ptr(z), _ptr(out), _ptr(stats), _ptr(scratch), stream), 'ghn3_dwpw_bn_fwd')
+        ctx.has_dw = wd is not None
+        ctx.save_for_backward(xc, z, stats, wd if wd is not None else stats, wp, g)
         ctx.cfg = (stride, pad, dil, eps)
         ctx.mark_non_differentiable(stats)
         return out, stats
@@ -103,24 +104,28 @@ class DwPwBn(torch.autograd.Function):
     def backward(ctx, dout, _dstats):
         lib = L.load()
         xc, z, stats, wd, wp, g = ctx.saved_tensors
+        if not ctx.has_dw:
+            wd = None
         stride, pad, dil, eps = ctx.cfg
-        C_out, ks = int(wp.shape[0]), int(wd.shape[-1])
+        C_out, ks = int(wp.shape[0]), (1 if wd is None else int(wd.shape[-1]))
         d = _desc(xc, C_out, ks, stride, pad, dil, eps)
         dev = xc.device
         do = dout.contiguous(memory_format=torch.channels_last)
         dx = torch.empty_like(xc)
         # (one allocation for the four parameter gradients and the scratch area: a call is launch- and host-bound for the
         # small layers of a CIFAR network)
-        n_par = wd.numel() + wp.numel() + 2 * C_out
+        n_wd = 0 if wd is None else wd.numel()
+        n_par = n_wd + wp.numel() + 2 * C_out
         buf = torch.empty(n_par + 64 + _scratch_floats(lib, d, 1), dtype=torch.float32, device=dev)
-        dwd = buf[:wd.numel()].view(wd.shape)
-        dwp = buf[wd.numel():wd.numel() + wp.numel()].view(wp.shape)
+        dwd = None if wd is None else buf[:n_wd].view(wd.shape)
+        dwp = buf[n_wd:n_wd + wp.numel()].view(wp.shape)
         dg = buf[n_par - 2 * C_out:n_par - C_out]
         db = buf[n_par - C_out:n_par]
         scratch = buf[(n_par + 63) // 64 * 64:]
         stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-        L._check(lib.ghn3_dwpw_bn_bwd(ctypes.byref(d), _ptr(do), _ptr(xc), _ptr(z), _ptr(stats), _ptr(wd), _ptr(wp), _ptr(g),
-                                      _ptr(dx), _ptr(dwd), _ptr(dwp), _ptr(dg), _ptr(db), _ptr(scratch), stream),
+        L._check(lib.ghn3_dwpw_bn_bwd(ctypes.byref(d), _ptr(do), _ptr(xc), _ptr(z), _ptr(stats),
+                                      _ptr(wd) if wd is not None else None, _ptr(wp), _ptr(g), _ptr(dx),
+                                      _ptr(dwd) if dwd is not None else None, _ptr(dwp), _ptr(dg), _ptr(db), _ptr(scratch), stream),
                  'ghn3_dwpw_bn_bwd')
         return dx, dwd, dwp, dg, db, None, None, None, None
 
@@ -133,6 +138,38 @@ def dwpw_bn(x, w_dw, w_pw, gamma, beta, stride=1, padding=0, dilation=1, eps=1e-
         raise L.Ghn3Error('dwpw_bn runs on an MI355X only (no CPU implementation: use the stock torch layers)')
     return DwPwBn.apply(x, w_dw, w_pw.reshape(w_pw.shape[0], -1), gamma, beta, int(stride), int(padding), int(dilation),
                         float(eps))
+
+
+def run_pointwise_block(layers, x, keep_layout=False):
+    """[ReLU, 1 x 1 Conv2d, BatchNorm2d] -- `ReLUConvBN` with a 1 x 1 kernel (ops.py:180-198: the preprocessing layer of every
+    cell, the `conv_1x1` op) -- on the fused op without a depthwise stage where it applies, else layer by layer."""
+    relu, pw, bn = layers
+    w_pw, gamma, beta = getattr(pw, 'weight', None), getattr(bn, 'weight', None), getattr(bn, 'bias', None)
+    has_run = getattr(bn, 'running_mean', None) is not None
+    batch_stats = getattr(bn, 'training', True) or not has_run
+    ok = hasattr(bn, 'eps') and getattr(pw, 'bias', None) is None and hasattr(pw, 'kernel_size') and \
+        tuple(pw.kernel_size) == (1, 1) and pw.stride[0] == pw.stride[1] and not isinstance(pw.padding, str) and \
+        tuple(pw.padding) == (0, 0) and getattr(pw, 'groups', 1) == 1 and torch.is_tensor(w_pw) and \
+        DwPwBn.applicable(x, None, w_pw, gamma, beta, 1, batch_stats)
+    if not ok:
+        for m in layers:
+            x = m(x)
+        return x
+    out, stats = dwpw_bn(x, None, w_pw, gamma, beta, pw.stride[0], 0, 1, bn.eps)
+    _update_running_stats(bn, stats, out, has_run)
+    return out if keep_layout else out.contiguous(memory_format=torch.contiguous_format)
+
+
+def _update_running_stats(bn, stats, out, has_run):
+    if has_run and getattr(bn, 'training', True) and getattr(bn, 'track_running_stats', False):
+        with torch.no_grad():
+            C = bn.weight.numel()
+            n = out.numel() // C
+            mom = bn.momentum if bn.momentum is not None else 0.1
+            bn.running_mean.mul_(1 - mom).add_(stats[:C], alpha=mom)
+            bn.running_var.mul_(1 - mom).add_(stats[2 * C:] * (n / max(n - 1, 1)), alpha=mom)
+            if getattr(bn, 'num_batches_tracked', None) is not None:
+                bn.num_batches_tracked += 1
 
 
 def reference(x, w_dw, w_pw, gamma, beta, stride=1, padding=0, dilation=1, eps=1e-5):
@@ -167,13 +204,5 @@ def run_block(layers, x, keep_layout=False):
             x = m(x)
         return x
     out, stats = dwpw_bn(x, w_dw, w_pw, gamma, beta, dw.stride[0], dw.padding[0], dw.dilation[0], bn.eps)
-    if has_run and getattr(bn, 'training', True) and getattr(bn, 'track_running_stats', False):
-        with torch.no_grad():
-            C = gamma.numel()
-            n = out.numel() // C
-            mom = bn.momentum if bn.momentum is not None else 0.1
-            bn.running_mean.mul_(1 - mom).add_(stats[:C], alpha=mom)
-            bn.running_var.mul_(1 - mom).add_(stats[2 * C:] * (n / max(n - 1, 1)), alpha=mom)
-            if getattr(bn, 'num_batches_tracked', None) is not None:
-                bn.num_batches_tracked += 1
+    _update_running_stats(bn, stats, out, has_run)
     return out if keep_layout else out.contiguous(memory_format=torch.contiguous_format)

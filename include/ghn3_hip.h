@@ -490,6 +490,8 @@ int ghn3_profile_read_tags(ghn3_ctx* ctx, double* ms_per_tag /* [256] */, int64_
  *   x [N][H][W][C_in], z (pre-norm) / out / dout [N][Ho][Wo][C_out], w_dw [C_in][ks][ks], w_pw [C_out][C_in],
  *   gamma / beta [C_out], stats [3 C_out] = mean | 1 / sqrt(var + eps) | biased variance (written by fwd, read by bwd).
  * Weights are read in place (views of the GHN's flat prediction buffer); all five gradients are written densely.
+ * w_dw == NULL (with ks = 1, pad = 0; dw_dw then unused): ReLU -> 1 x 1 convolution (stride) -> BatchNorm, the `ReLUConvBN`
+ * preprocessing layer of every cell and the `conv_1x1` op (ops.py:180-198).
  * `scratch` = ghn3_dwpw_scratch_floats(desc, backward) floats of device memory owned by the caller (no allocation, no
  * synchronisation inside).  Limits: C_in, C_out multiples of 4 and <= 512, ks <= 7, tensors below 2^31 elements
  * (GHN3_E_LIMIT otherwise: the caller keeps its stock path for such layers).  Deterministic.

@@ -56,7 +56,7 @@ def test_dwpw_bn_matches_the_stock_layers(case):
     assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
     (out * up.cuda()).sum().backward()
     torch.cuda.synchronize()
-    assert _rel(out.cpu(), ref.detach()) < 2e-4, _rel(out.cpu(), ref.detach())
+    assert _rel(out.detach().cpu(), ref.detach()) < 2e-4, _rel(out.detach().cpu(), ref.detach())
     zz = torch.nn.functional.conv2d(torch.nn.functional.conv2d(torch.relu(x.double()), w_dw.double(), None, st, pad, dil,
                                                                groups=Ci), w_pw.double())
     assert _rel(stats[:Co].cpu(), zz.mean((0, 2, 3))) < 2e-4 and _rel(stats[2 * Co:].cpu(), zz.var((0, 2, 3), unbiased=False)) < 2e-4
@@ -67,6 +67,30 @@ def test_dwpw_bn_matches_the_stock_layers(case):
     out2, _ = T.dwpw_bn(dev_in[0].detach().contiguous(memory_format=torch.channels_last), dev_in[1].detach(), dev_in[2].detach(),
                         dev_in[3].detach(), dev_in[4].detach(), stride=st, padding=pad, dilation=dil)
     assert torch.equal(out2, out.detach())
+
+
+@pytest.mark.parametrize('case', [(4, 32, 64, 16, 16, 1), (3, 48, 24, 9, 7, 2), (2, 256, 128, 8, 8, 1), (6, 8, 8, 5, 5, 2)])
+def test_pointwise_relu_conv_bn_matches_the_stock_layers(case):
+    """The same family without a depthwise stage (w_dw = NULL): ReLU -> 1 x 1 convolution (stride) -> BatchNorm, the
+    preprocessing `ReLUConvBN` of every cell and the `conv_1x1` op (ops.py:180-198), against torch in fp64."""
+    from ghn3_amd import target_ops as T
+    F = torch.nn.functional
+    N, Ci, Co, H, W, st = case
+    g = torch.Generator().manual_seed(sum(case))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w_pw = torch.randn(Co, Ci, 1, 1, generator=g) / Ci ** 0.5
+    gamma, beta = 1 + 0.3 * torch.randn(Co, generator=g), 0.2 * torch.randn(Co, generator=g)
+    ref_in = [t.clone().double().requires_grad_(True) for t in (x, w_pw, gamma, beta)]
+    ref = F.batch_norm(F.conv2d(F.relu(ref_in[0]), ref_in[1], None, st), None, None, ref_in[2], ref_in[3], True, 0.1, 1e-5)
+    up = torch.randn(ref.shape, generator=g)
+    (ref * up.double()).sum().backward()
+    dev_in = [t.cuda().requires_grad_(True) for t in (x, w_pw, gamma, beta)]
+    out, stats = T.dwpw_bn(dev_in[0], None, dev_in[1], dev_in[2], dev_in[3], stride=st)
+    (out * up.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert out.shape == ref.shape and _rel(out.detach().cpu(), ref.detach()) < 2e-4
+    for name, a, b in zip(('dx', 'dw_pw', 'dgamma', 'dbeta'), dev_in, ref_in):
+        assert _rel(a.grad.cpu(), b.grad) < 3e-4, (name, _rel(a.grad.cpu(), b.grad))
 
 
 def test_descriptor_limits_are_refused_loudly():

@@ -1,18 +1,25 @@
-"""One-off robustness sweep (GPU box): f16 mode vs exact-fp32 mode on many random batches; prints the worst pairs."""
+"""Robustness sweep (GPU box): the 16-bit mode against the exact-fp32 mode on many random batches -- how often does ANY GHN parameter
+gradient differ by more than 1e-3 (a ReLU-mask element on the knife edge flipped by the ~1e-5 deviation of the forward)?
+
+    python tools/diag/modes_sweep.py ghn3xlm16 500 [variant]
+
+variant: 'x3off' = the 16-bit decoders with an exact-fp32 Graphormer (graphormer_x3=False) instead of the split-bf16 one.
+Prints one line per batch above 1e-3, a histogram and the fractions."""
 import sys, torch, numpy as np
 import _paths  # noqa: F401  (repository root, tests/, tests/golden/ on sys.path)
 import recipe
 from test_gpu_configs import _cfg, _bench_step
 from ghn3_amd import GHN3
 from ghn3_amd.synthetic import synthetic_batch
-name = sys.argv[1]; n_batches = int(sys.argv[2])
+name = sys.argv[1]; n_batches = int(sys.argv[2]); variant = sys.argv[3] if len(sys.argv) > 3 else 'default'
 shapes = {k: tuple(v.shape) for k, v in GHN3(**_cfg(name)).state_dict().items()}
 sd = {k: torch.from_numpy(v) for k, v in recipe.seeded_state_dict(shapes, seed=7).items()}
 models = {}
 for compute in ('f16', 'f32'):
-    m = GHN3(**_cfg(name), compute=compute); m.load_state_dict(sd); models[compute] = m.to('cuda').train()
+    kw = dict(graphormer_x3=False) if (variant == 'x3off' and compute == 'f16') else {}
+    m = GHN3(**_cfg(name), compute=compute, **kw); m.load_state_dict(sd); models[compute] = m.to('cuda').train()
 rs = np.random.RandomState(123)
-worst = []
+worst, fwd = [], []
 for k in range(n_batches):
     B = int(rs.choice([1, 1, 2, 3, 4]))
     nodes = [int(rs.randint(6, 330)) for _ in range(B)]
@@ -34,8 +41,21 @@ for k in range(n_batches):
         ref = float(b.norm())
         if ref > 1e-3:
             wg = max(wg, (float((a - b).norm()) / ref, pname))
-    worst.append((wg[0], wg[1], wf, nodes, plan.program.M))
-    print('%2d nodes %-22s rows %5d  worst fwd %.2e  worst grad %.2e %s' % (k, nodes, plan.program.M, wf, wg[0], wg[1]), flush=True)
+    worst.append((wg[0], wg[1], wf, nodes, int(plan.program.M)))
+    fwd.append(wf)
+    if wg[0] > 1e-3:
+        print('%3d nodes %-22s rows %5d  worst fwd %.2e  worst grad %.2e %s' % (k, nodes, plan.program.M, wf, wg[0], wg[1]), flush=True)
     del res
+g = np.asarray([w[0] for w in worst])
+print('# %s, %d random batches of 1-4 graphs (6-329 nodes), variant %s: f16 mode against the exact-fp32 mode' % (name, n_batches, variant))
+print('# worst forward difference over all batches %.2e (median %.2e)' % (max(fwd), float(np.median(fwd))))
+print('# worst gradient per batch: median %.2e, 90 %% %.2e, 99 %% %.2e, max %.2e' % tuple(np.percentile(g, [50, 90, 99, 100])))
+for thr in (5e-4, 7.5e-4, 1e-3, 1.5e-3, 2e-3, 3e-3):
+    print('# batches with a gradient above %.1e: %d of %d = %.2f %%' % (thr, int((g > thr).sum()), n_batches, 100.0 * (g > thr).mean()))
+by = {}
+for w in worst:
+    if w[0] > 1e-3:
+        by[w[1]] = by.get(w[1], 0) + 1
+print('# parameters that carry the excess:', by)
 worst.sort(reverse=True)
-print('WORST', worst[:3])
+print('WORST', worst[:5])

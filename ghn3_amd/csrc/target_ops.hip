@@ -7,9 +7,10 @@
 // conv, 1x1 conv, batch norm: ~9 passes over the activations forward, more backward) with weights the GHN predicted; here
 //
 //   forward   dwpw_fwd      one pass: ReLU + depthwise taps produce a [64 pixels x 32 channels] operand chunk in LDS, the
-//                           pointwise product runs on the bf16 matrix cores with SPLIT operands (hi + lo halves of both
-//                           factors, hi.hi + lo.hi + hi.lo: ~1e-5 relative, fp32 accumulate) against weight chunks converted
-//                           while staged, the epilogue writes the pre-norm activations z once and leaves per-tile
+//                           pointwise product runs on the bf16 matrix cores with SPLIT operands: both factors as three bf16
+//                           pieces (24 bits of mantissa) and six products -- fp32's own rounding, ~1e-7; the matrix work is
+//                           free here, the op is memory- and launch-bound -- fp32 accumulate, against weight chunks converted
+//                           while staged (two pieces, ~1e-5, for more than 256 output columns per workgroup: registers), the epilogue writes the pre-norm activations z once and leaves per-tile
 //                           (mean, M2) of every channel;
 //             bn_finalize   Chan-combines the tiles in a fixed order -> mean, rstd;   bn_apply  normalises (one pass).
 //   backward  bn_bwd_partial + reduce_rows   sum dout, sum dout.xhat -> dgamma, dbeta;
@@ -51,9 +52,17 @@ __device__ __forceinline__ unsigned short bf16_rn(float v) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (unsigned short)(u >> 16);
 }
-__device__ __forceinline__ void split2(float v, unsigned short& hi, unsigned short& lo) {
-    hi = bf16_rn(v);
-    lo = bf16_rn(v - __uint_as_float((unsigned)hi << 16));
+// v = p[0] + p[1] (+ p[2]) in bf16 pieces: 16 (24) bits of mantissa.  With S = 3 pieces and the six products
+// 11 + 12 + 21 + 22 + 13 + 31 the matrix-core product carries fp32's own rounding (~1e-7); S = 2 (hi.hi + lo.hi + hi.lo) ~1e-5.
+template <int S>
+__device__ __forceinline__ void splitS(float v, unsigned short* base, int idx, int stride) {
+    float r = v;
+#pragma unroll
+    for (int q = 0; q < S; ++q) {
+        const unsigned short h = bf16_rn(r);
+        base[q * stride + idx] = h;
+        r -= __uint_as_float((unsigned)h << 16);
+    }
 }
 // acc[e] += sum_k A[lane & 15][k] B[4 (lane >> 4) + e][k]   (B fragment first: a lane owns 4 consecutive columns of a row)
 __device__ __forceinline__ f32x4 mfma_bt(u16x8 b, u16x8 a, f32x4 c) {
@@ -61,6 +70,15 @@ __device__ __forceinline__ f32x4 mfma_bt(u16x8 b, u16x8 a, f32x4 c) {
 }
 __device__ __forceinline__ u16x8 frag(const unsigned short* base, int row, int kc) {
     return *reinterpret_cast<const u16x8*>(base + row * LDK + 8 * kc);
+}
+
+template <int S>
+__device__ __forceinline__ f32x4 mma_terms(const u16x8 (&a)[S], const u16x8 (&b)[S], f32x4 acc) {
+    if (S == 3) { acc = mfma_bt(b[2], a[0], acc); acc = mfma_bt(b[0], a[2], acc); acc = mfma_bt(b[1], a[1], acc); }   // smallest first
+    acc = mfma_bt(b[1], a[0], acc);
+    acc = mfma_bt(b[0], a[1], acc);
+    acc = mfma_bt(b[0], a[0], acc);
+    return acc;
 }
 
 // ReLU + depthwise taps of 8 consecutive channels c .. c + 7 at output pixel (n, oh, ow); ih0 / iw0 = input origin of the
@@ -127,18 +145,16 @@ __device__ __forceinline__ void dz8(const float* __restrict__ dout, const float*
 // ---------------------------------------------------------------------------------------------------------------------
 // forward: z = pw(dw(relu(x))), per-tile channel statistics
 // ---------------------------------------------------------------------------------------------------------------------
-template <int NT>
+template <int NT, int S>
 __global__ __launch_bounds__(256) void tnet_dwpw_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_dw,
                                                             const float* __restrict__ w_pw, float* __restrict__ z,
                                                             float* __restrict__ part, const Desc d, const int P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     int* pix = reinterpret_cast<int*>(smem);                                   // [3][TP]
     float* wt = reinterpret_cast<float*>(smem + 3 * TP * 4);                   // [MAXT][KC]
-    unsigned short* A_hi = reinterpret_cast<unsigned short*>(smem + 3 * TP * 4 + MAXT * KC * 4);
-    unsigned short* A_lo = A_hi + TP * LDK;
-    unsigned short* B_hi = A_lo + TP * LDK;
-    unsigned short* B_lo = B_hi + 16 * NT * LDK;
-    float* red = reinterpret_cast<float*>(B_lo + 16 * NT * LDK);               // [5][16 NT]
+    unsigned short* As = reinterpret_cast<unsigned short*>(smem + 3 * TP * 4 + MAXT * KC * 4);      // [S][TP][LDK]
+    unsigned short* Bs = As + S * TP * LDK;                                                          // [S][16 NT][LDK]
+    float* red = reinterpret_cast<float*>(Bs + S * 16 * NT * LDK);             // [5][16 NT]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kc = lane >> 4;
     const int tile = blockIdx.x, p0 = tile * TP, taps = d.ks * d.ks;
     if (tid < TP) {
@@ -160,7 +176,7 @@ __global__ __launch_bounds__(256) void tnet_dwpw_fwd_kernel(const float* __restr
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (n < d.C_out && c < d.C_in) v = *reinterpret_cast<const f32x4*>(w_pw + (int64_t)n * d.C_in + c);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split2(v[e], B_hi[n * LDK + k + e], B_lo[n * LDK + k + e]);
+            for (int e = 0; e < 4; ++e) splitS<S>(v[e], Bs, n * LDK + k + e, 16 * NT * LDK);
         }
         __syncthreads();
         {
@@ -168,17 +184,19 @@ __global__ __launch_bounds__(256) void tnet_dwpw_fwd_kernel(const float* __restr
             float y[8];
             dw_taps8(x, d, pix[i], pix[TP + i], pix[2 * TP + i], c0 + cc, wt, KC, cc, y);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) split2(y[e], A_hi[i * LDK + cc + e], A_lo[i * LDK + cc + e]);
+            for (int e = 0; e < 8; ++e) splitS<S>(y[e], As, i * LDK + cc + e, TP * LDK);
         }
         __syncthreads();
-        const u16x8 ah = frag(A_hi, 16 * w + r16, kc), al = frag(A_lo, 16 * w + r16, kc);
+        u16x8 af[S];
+#pragma unroll
+        for (int q = 0; q < S; ++q) af[q] = frag(As + q * TP * LDK, 16 * w + r16, kc);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             if (16 * j < d.C_out) {
-                const u16x8 bh = frag(B_hi, 16 * j + r16, kc), bl = frag(B_lo, 16 * j + r16, kc);
-                acc[j] = mfma_bt(bh, ah, acc[j]);
-                acc[j] = mfma_bt(bl, ah, acc[j]);
-                acc[j] = mfma_bt(bh, al, acc[j]);
+                u16x8 bf[S];
+#pragma unroll
+                for (int q = 0; q < S; ++q) bf[q] = frag(Bs + q * 16 * NT * LDK, 16 * j + r16, kc);
+                acc[j] = mma_terms<S>(af, bf, acc[j]);
             }
         }
     }
@@ -324,16 +342,14 @@ __global__ __launch_bounds__(256) void tnet_reduce_rows_kernel(const float* __re
 }
 
 // dy [P][C_in] = dz [P][C_out] W_pw [C_out][C_in]; dz formed on the fly
-template <int NT>
+template <int NT, int S>
 __global__ __launch_bounds__(256) void tnet_dwpw_bwd_data_kernel(const float* __restrict__ dout, const float* __restrict__ z,
                                                                  const float* __restrict__ stats, const float* __restrict__ gamma,
                                                                  const float* __restrict__ s12, const float* __restrict__ w_pw,
                                                                  float* __restrict__ dy, const Desc d, const int P) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    unsigned short* A_hi = reinterpret_cast<unsigned short*>(smem);
-    unsigned short* A_lo = A_hi + TP * LDK;
-    unsigned short* B_hi = A_lo + TP * LDK;
-    unsigned short* B_lo = B_hi + 16 * NT * LDK;
+    unsigned short* As = reinterpret_cast<unsigned short*>(smem);              // [S][TP][LDK]
+    unsigned short* Bs = As + S * TP * LDK;                                    // [S][16 NT][LDK]
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kc = lane >> 4;
     const int p0 = blockIdx.x * TP;
     f32x4 acc[NT];
@@ -346,7 +362,7 @@ __global__ __launch_bounds__(256) void tnet_dwpw_bwd_data_kernel(const float* __
             float v[8];
             dz8(dout, z, stats, gamma, s12, d.C_out, p0 + i, P, c0 + cc, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) split2(v[e], A_hi[i * LDK + cc + e], A_lo[i * LDK + cc + e]);
+            for (int e = 0; e < 8; ++e) splitS<S>(v[e], As, i * LDK + cc + e, TP * LDK);
         }
         // B[n = ci][k] = W_pw[c0 + k][n]
         for (int i = tid; i < KC * 4 * NT; i += 256) {
@@ -354,17 +370,19 @@ __global__ __launch_bounds__(256) void tnet_dwpw_bwd_data_kernel(const float* __
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (co < d.C_out && n < d.C_in) v = *reinterpret_cast<const f32x4*>(w_pw + (int64_t)co * d.C_in + n);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) split2(v[e], B_hi[(n + e) * LDK + k], B_lo[(n + e) * LDK + k]);
+            for (int e = 0; e < 4; ++e) splitS<S>(v[e], Bs, (n + e) * LDK + k, 16 * NT * LDK);
         }
         __syncthreads();
-        const u16x8 ah = frag(A_hi, 16 * w + r16, kc), al = frag(A_lo, 16 * w + r16, kc);
+        u16x8 af[S];
+#pragma unroll
+        for (int q = 0; q < S; ++q) af[q] = frag(As + q * TP * LDK, 16 * w + r16, kc);
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             if (16 * j < d.C_in) {
-                const u16x8 bh = frag(B_hi, 16 * j + r16, kc), bl = frag(B_lo, 16 * j + r16, kc);
-                acc[j] = mfma_bt(bh, ah, acc[j]);
-                acc[j] = mfma_bt(bl, ah, acc[j]);
-                acc[j] = mfma_bt(bh, al, acc[j]);
+                u16x8 bf[S];
+#pragma unroll
+                for (int q = 0; q < S; ++q) bf[q] = frag(Bs + q * 16 * NT * LDK, 16 * j + r16, kc);
+                acc[j] = mma_terms<S>(af, bf, acc[j]);
             }
         }
     }
@@ -382,7 +400,8 @@ __global__ __launch_bounds__(256) void tnet_pw_wgrad_kernel(const float* __restr
                                                             const float* __restrict__ s12, const float* __restrict__ x,
                                                             const float* __restrict__ w_dw, float* __restrict__ part,
                                                             const Desc d, const int P, const int chunk_px) {
-    __shared__ __attribute__((aligned(16))) unsigned short A_hi[64 * LDK], A_lo[64 * LDK], B_hi[64 * LDK], B_lo[64 * LDK];
+    constexpr int S = 3;
+    __shared__ __attribute__((aligned(16))) unsigned short As[S * 64 * LDK], Bs[S * 64 * LDK];
     __shared__ float wt[MAXT * 64];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kc = lane >> 4;
     const int chunk = blockIdx.x, co0 = blockIdx.y * 64, ci0 = blockIdx.z * 64, taps = d.ks * d.ks;
@@ -401,7 +420,7 @@ __global__ __launch_bounds__(256) void tnet_pw_wgrad_kernel(const float* __restr
             float v[8];
             dz8(dout, z, stats, gamma, s12, d.C_out, p < pb ? p : P, P, co0 + m8, v);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) split2(v[e], A_hi[(m8 + e) * LDK + k], A_lo[(m8 + e) * LDK + k]);
+            for (int e = 0; e < 8; ++e) splitS<S>(v[e], As, (m8 + e) * LDK + k, 64 * LDK);
         }
         {   // B[n = ci][k = pixel] = y re-computed
             int n, ih0, iw0;
@@ -409,16 +428,18 @@ __global__ __launch_bounds__(256) void tnet_pw_wgrad_kernel(const float* __restr
             float y[8];
             dw_taps8(x, d, n, ih0, iw0, ci0 + m8, wt, 64, m8, y);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) split2(y[e], B_hi[(m8 + e) * LDK + k], B_lo[(m8 + e) * LDK + k]);
+            for (int e = 0; e < 8; ++e) splitS<S>(y[e], Bs, (m8 + e) * LDK + k, 64 * LDK);
         }
         __syncthreads();
-        const u16x8 ah = frag(A_hi, 16 * w + r16, kc), al = frag(A_lo, 16 * w + r16, kc);
+        u16x8 af[S];
+#pragma unroll
+        for (int q = 0; q < S; ++q) af[q] = frag(As + q * 64 * LDK, 16 * w + r16, kc);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const u16x8 bh = frag(B_hi, 16 * j + r16, kc), bl = frag(B_lo, 16 * j + r16, kc);
-            acc[j] = mfma_bt(bh, ah, acc[j]);
-            acc[j] = mfma_bt(bl, ah, acc[j]);
-            acc[j] = mfma_bt(bh, al, acc[j]);
+            u16x8 bf[S];
+#pragma unroll
+            for (int q = 0; q < S; ++q) bf[q] = frag(Bs + q * 64 * LDK, 16 * j + r16, kc);
+            acc[j] = mma_terms<S>(af, bf, acc[j]);
         }
     }
     const int co = co0 + 16 * w + r16;
@@ -491,8 +512,10 @@ __global__ __launch_bounds__(256) void tnet_dw_wgrad_kernel(const float* __restr
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 inline int nt_of(int C) { return C <= 64 ? 4 : C <= 128 ? 8 : C <= 256 ? 16 : 32; }
-inline size_t fwd_lds(int NT) { return 3 * TP * 4 + MAXT * KC * 4 + 2 * TP * LDK * 2 + 2 * 16 * NT * LDK * 2 + 5 * 16 * NT * 4; }
-inline size_t bwd_lds(int NT) { return 2 * TP * LDK * 2 + 2 * 16 * NT * LDK * 2; }
+// operand pieces: three (fp32-equivalent products) up to 256 output columns per workgroup, two for the widest tiles (registers)
+inline int terms_of(int NT) { return NT <= 16 ? 3 : 2; }
+inline size_t fwd_lds(int NT) { const int S = terms_of(NT); return 3 * TP * 4 + MAXT * KC * 4 + S * TP * LDK * 2 + S * 16 * NT * LDK * 2 + 5 * 16 * NT * 4; }
+inline size_t bwd_lds(int NT) { const int S = terms_of(NT); return S * TP * LDK * 2 + S * 16 * NT * LDK * 2; }
 
 struct Plan { int P, n_tiles, pw_chunks, pw_chunk_px, dw_chunks, dw_chunk_px; };
 
@@ -535,9 +558,14 @@ int check_desc(const ghn3_dwpw_desc* g, Desc& d) {
 }
 
 template <typename K> int set_lds(K kern, size_t bytes) {
-    static bool done = false;                      // (one instance per kernel type: the attribute is set once per process)
-    if (bytes > 48 * 1024 && !done) {
-        done = true;
+    // (once per kernel and process; keyed by the function's address -- every instantiation has the same pointer TYPE)
+    static const void* done[32];
+    static int n_done = 0;
+    const void* key = (const void*)kern;
+    bool seen = false;
+    for (int i = 0; i < n_done; ++i) seen |= done[i] == key;
+    if (bytes > 48 * 1024 && !seen) {
+        if (n_done < 32) done[n_done++] = key;
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
         if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(dwpw): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     }
@@ -569,9 +597,9 @@ extern "C" int ghn3_dwpw_bn_fwd(const ghn3_dwpw_desc* g, const float* x, const f
     const Plan pl = make_plan(d);
     const int NT = nt_of(d.C_out);
     const size_t lds = fwd_lds(NT);
-#define FWD_CASE(n) case n: rc = set_lds(tnet_dwpw_fwd_kernel<n>, lds); if (rc) return rc; \
-        hipLaunchKernelGGL(tnet_dwpw_fwd_kernel<n>, dim3(pl.n_tiles), dim3(256), lds, s, x, w_dw, w_pw, z, scratch, d, pl.P); break;
-    switch (NT) { FWD_CASE(4) FWD_CASE(8) FWD_CASE(16) FWD_CASE(32) }
+#define FWD_CASE(n, t) case n: rc = set_lds(tnet_dwpw_fwd_kernel<n, t>, lds); if (rc) return rc; \
+        hipLaunchKernelGGL((tnet_dwpw_fwd_kernel<n, t>), dim3(pl.n_tiles), dim3(256), lds, s, x, w_dw, w_pw, z, scratch, d, pl.P); break;
+    switch (NT) { FWD_CASE(4, 3) FWD_CASE(8, 3) FWD_CASE(16, 3) FWD_CASE(32, 2) }
 #undef FWD_CASE
     LAUNCH_CHECK("dwpw fwd")
     hipLaunchKernelGGL(tnet_bn_finalize_kernel, dim3((d.C_out + 15) / 16), dim3(256), 0, s, scratch, pl.n_tiles, pl.P, d.C_out, d.eps, stats);
@@ -618,9 +646,9 @@ extern "C" int ghn3_dwpw_bn_bwd(const ghn3_dwpw_desc* g, const float* dout, cons
     {
         const int NT = nt_of(d.C_in);
         const size_t lds = bwd_lds(NT);
-#define BWD_CASE(n) case n: rc = set_lds(tnet_dwpw_bwd_data_kernel<n>, lds); if (rc) return rc; \
-        hipLaunchKernelGGL(tnet_dwpw_bwd_data_kernel<n>, dim3(pl.n_tiles), dim3(256), lds, s, dout, z, stats, gamma, s12, w_pw, dy, d, pl.P); break;
-        switch (NT) { BWD_CASE(4) BWD_CASE(8) BWD_CASE(16) BWD_CASE(32) }
+#define BWD_CASE(n, t) case n: rc = set_lds(tnet_dwpw_bwd_data_kernel<n, t>, lds); if (rc) return rc; \
+        hipLaunchKernelGGL((tnet_dwpw_bwd_data_kernel<n, t>), dim3(pl.n_tiles), dim3(256), lds, s, dout, z, stats, gamma, s12, w_pw, dy, d, pl.P); break;
+        switch (NT) { BWD_CASE(4, 3) BWD_CASE(8, 3) BWD_CASE(16, 3) BWD_CASE(32, 2) }
 #undef BWD_CASE
         LAUNCH_CHECK("dwpw bwd data")
     }

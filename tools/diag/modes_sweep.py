@@ -12,6 +12,7 @@ from test_gpu_configs import _cfg, _bench_step
 from ghn3_amd import GHN3
 from ghn3_amd.synthetic import synthetic_batch
 name = sys.argv[1]; n_batches = int(sys.argv[2]); variant = sys.argv[3] if len(sys.argv) > 3 else 'default'
+first = int(sys.argv[4]) if len(sys.argv) > 4 else 0          # (skip the batches in front of this one: same random stream)
 shapes = {k: tuple(v.shape) for k, v in GHN3(**_cfg(name)).state_dict().items()}
 sd = {k: torch.from_numpy(v) for k, v in recipe.seeded_state_dict(shapes, seed=7).items()}
 models = {}
@@ -23,6 +24,8 @@ worst, fwd = [], []
 for k in range(n_batches):
     B = int(rs.choice([1, 1, 2, 3, 4]))
     nodes = [int(rs.randint(6, 330)) for _ in range(B)]
+    if k < first:
+        continue
     res = {}
     for compute in ('f16', 'f32'):
         hip = models[compute]
@@ -31,7 +34,15 @@ for k in range(n_batches):
         dout = torch.empty(plan.program.out_numel, dtype=torch.float32, device='cuda')
         res[compute] = (hip, plan) + _bench_step(hip, plan, dout)
     hip, plan, out, gflat, loss = res['f16']; _, _, out32, g32, loss32 = res['f32']
-    assert torch.isfinite(gflat).all() and torch.isfinite(out[:plan.program.out_numel]).all(), nodes
+    # (the flat output has 16-float alignment gaps between the tensors that nothing writes: only the tensors are checked)
+    out_ok = all(bool(torch.isfinite(out[p['offset']:p['offset'] + p['numel']]).all()) for p in plan.program.predicted)
+    if not (torch.isfinite(gflat).all() and out_ok):
+        pr = dict(hip.named_parameters())
+        bad = [n for n, off in zip(plan.program.names, hip._offs) if not torch.isfinite(gflat[int(off):int(off) + pr[n].numel()]).all()]
+        print('NON-FINITE at batch %d nodes %s: out finite %s, gradients: %s' % (k, nodes, out_ok, bad[:10]), flush=True)
+        amax = plan.ws[plan.program.r_amax[1]:plan.program.r_amax[1] + 32].view(torch.float32)
+        print('   amax slots', amax.tolist(), 'scal[60:64]', plan.scal[240:256].view(torch.float32).tolist(), flush=True)
+        continue
     wf = max(float((out[p['offset']:p['offset'] + p['numel']] - out32[p['offset']:p['offset'] + p['numel']]).norm() /
                    (out32[p['offset']:p['offset'] + p['numel']].norm() + 1e-12)) for p in plan.program.predicted)
     params = dict(hip.named_parameters()); wg = (0.0, '')

@@ -12,7 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libghn3_hip.so')
-ABI_VERSION = 17
+ABI_VERSION = 18
 
 # ---- numpy mirrors of the C structs -------------------------------------------------------------
 REF_DT = np.dtype([('buf', '<i4'), ('_pad', '<i4'), ('off', '<i8')])
@@ -44,12 +44,15 @@ GEMM_BIASGRAD = 2
 GEMM_OP16 = 4
 GEMM_X3 = 8
 GEMM_SUMSQ = 16
+GEMM_X3F16 = 32
+X3F16_WSHIFT = 6
 CAST_STRAIGHT, CAST_TRANSPOSED, CAST_STRAIGHT_BF16, CAST_TRANSPOSED_BF16, CAST_COLSUM, CAST_SCALED = 1, 2, 4, 8, 16, 32
 CAST_TIGHT = 64
 CAST_SPLIT = 128
 CAST_COLSUM_PARTS = 256
 CAST_FRAG = 512
 CAST_SRC16 = 1024
+CAST_SPLIT_F16 = 2048
 CT_F32, CT_F16, CT_BF16 = 0, 1, 2
 COMPUTE_TYPES = {'f32': CT_F32, 'f16': CT_F16, 'bf16': CT_BF16}
 

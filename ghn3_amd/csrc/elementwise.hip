@@ -1761,7 +1761,10 @@ __device__ __forceinline__ void cast16_body(const float* __restrict__ src, unsig
     // fragment-major copies (gemm_x3d.hip): element (n, k) of a [rows n][cols k] matrix lives at
     // ((n / 16) * (K / 32) + k / 32) * 512 + ((k % 32) / 8 * 16 + n % 16) * 8 + k % 8   (K = cols, a multiple of 32)
     const bool frag = D.flags & GHN3_CAST_FRAG;
-    const bool st_bf = (D.flags & GHN3_CAST_STRAIGHT_BF16) || split, tr_bf = (D.flags & GHN3_CAST_TRANSPOSED_BF16) || split;
+    // GHN3_CAST_SPLIT_F16: the straight pieces are f16 pieces of x * 2^GHN3_X3F16_WSHIFT (B of GHN3_GEMM_X3F16 problems)
+    const bool st_f16s = split && (D.flags & GHN3_CAST_SPLIT_F16);
+    const float s16 = st_f16s ? (float)(1 << GHN3_X3F16_WSHIFT) : 1.f;
+    const bool st_bf = ((D.flags & GHN3_CAST_STRAIGHT_BF16) || split) && !st_f16s, tr_bf = (D.flags & GHN3_CAST_TRANSPOSED_BF16) || split;
     const float sc = ((D.flags & GHN3_CAST_SCALED) && amax) ? ghn3_pow2_scale(*amax) : 1.f;
     const int rows_w = (D.flags & GHN3_CAST_TIGHT) ? ((D.rows + 7) & ~7) : 0x7fffffff;   // transposed rows written
 
@@ -1790,9 +1793,9 @@ __device__ __forceinline__ void cast16_body(const float* __restrict__ src, unsig
             us8 h, l;
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float xs = x[e] * sc;
+                const float xs = x[e] * sc * s16;
                 h[e] = st_bf ? cast_bf16(xs) : cast_f16(xs);
-                if (split) l[e] = cast_bf16(xs - bf16_back(h[e]));
+                if (split) l[e] = st_f16s ? cast_f16(xs - f16_back(h[e])) : cast_bf16(xs - bf16_back(h[e]));
             }
             *reinterpret_cast<us8*>(Dd + (int64_t)r * D.ld_dst + c) = h;
             if (split) *reinterpret_cast<us8*>(Dd + D.lo_off + (int64_t)r * D.ld_dst + c) = l;
@@ -1869,8 +1872,9 @@ __device__ __forceinline__ void cast16_body(const float* __restrict__ src, unsig
             const int r = r0 + rr + 16 * i;
             if (r >= D.rows) continue;
             us4 h;
+            const float4 vs = make_float4(v[i].x * s16, v[i].y * s16, v[i].z * s16, v[i].w * s16);
             if (st_bf) { h[0] = cast_bf16(v[i].x); h[1] = cast_bf16(v[i].y); h[2] = cast_bf16(v[i].z); h[3] = cast_bf16(v[i].w); }
-            else { h[0] = cast_f16(v[i].x); h[1] = cast_f16(v[i].y); h[2] = cast_f16(v[i].z); h[3] = cast_f16(v[i].w); }
+            else { h[0] = cast_f16(vs.x); h[1] = cast_f16(vs.y); h[2] = cast_f16(vs.z); h[3] = cast_f16(vs.w); }
             const int c = c0 + c4;
             // (frag: n = r, k = c; the four consecutive k of this lane share one 8-element run)
             const int64_t o = frag ? ((int64_t)(r >> 4) * (D.cols >> 5) + (c >> 5)) * 512 + ((((c & 31) >> 3) * 16 + (r & 15)) << 3) + (c & 7)
@@ -1879,8 +1883,13 @@ __device__ __forceinline__ void cast16_body(const float* __restrict__ src, unsig
             *reinterpret_cast<us4*>(Dd + o) = h;
             if (split) {
                 us4 l;
-                l[0] = cast_bf16(v[i].x - bf16_back(h[0])); l[1] = cast_bf16(v[i].y - bf16_back(h[1]));
-                l[2] = cast_bf16(v[i].z - bf16_back(h[2])); l[3] = cast_bf16(v[i].w - bf16_back(h[3]));
+                if (st_f16s) {
+                    l[0] = cast_f16(vs.x - f16_back(h[0])); l[1] = cast_f16(vs.y - f16_back(h[1]));
+                    l[2] = cast_f16(vs.z - f16_back(h[2])); l[3] = cast_f16(vs.w - f16_back(h[3]));
+                } else {
+                    l[0] = cast_bf16(v[i].x - bf16_back(h[0])); l[1] = cast_bf16(v[i].y - bf16_back(h[1]));
+                    l[2] = cast_bf16(v[i].z - bf16_back(h[2])); l[3] = cast_bf16(v[i].w - bf16_back(h[3]));
+                }
                 *reinterpret_cast<us4*>(Dd + D.lo_off + o) = l;
             }
         }

@@ -57,6 +57,21 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
     }
 }
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+// the same split into F16 pieces (GHN3_GEMM_X3F16: 11 + 11 bits of mantissa, O(1) operands only), as raw 16-bit patterns
+__device__ __forceinline__ void split8_f16(const f32x4& a, const f32x4& b, bf16x8& h, bf16x8& l) {
+    f16x8 hh, ll;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const _Float16 ah = (_Float16)a[e], bh = (_Float16)b[e];
+        hh[e] = ah; hh[4 + e] = bh;
+        ll[e] = (_Float16)(a[e] - (float)ah);
+        ll[4 + e] = (_Float16)(b[e] - (float)bh);
+    }
+    h = __builtin_bit_cast(bf16x8, hh);
+    l = __builtin_bit_cast(bf16x8, ll);
+}
+
 __device__ __forceinline__ const GemmProbDev* find_problem(const GemmProbDev* probs, int n_probs) {
     int lo = 0, hi = n_probs - 1;
     while (lo < hi) {
@@ -121,6 +136,7 @@ __device__ __forceinline__ void x3s_body(const GemmProbDev* __restrict__ P) {
     const int t_id = blockIdx.x - P->tile_start;
     const int n0 = (t_id % P->tiles_n) * (16 * NT), m0 = (t_id / P->tiles_n) * BM;
     const int M = P->M, N = P->N, lda = P->lda;
+    const bool f16p = (P->flags & GHN3_GEMM_X3F16) != 0;          // f16 pieces (forward linears): wave-uniform
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l15 = lane & 15, lq = lane >> 4;
     const int nt = wave % NT, mt = (wave / NT) % MT, kp = wave / (NT * MT);
 
@@ -220,7 +236,7 @@ __device__ __forceinline__ void x3s_body(const GemmProbDev* __restrict__ P) {
             if (ci < SLOTS) {
                 const int r_ = ci / CHUNKS, c = ci % CHUNKS;
                 bf16x8 h, l;
-                split8(a[j][0], a[j][1], h, l);
+                if (f16p) split8_f16(a[j][0], a[j][1], h, l); else split8(a[j][0], a[j][1], h, l);
                 const int off = (c >> 3) * BM * 128 + r_ * 128 + (((c & 7) ^ ((r_ >> 1) & 7)) << 4);
                 *reinterpret_cast<bf16x8*>(sAh + off) = h;
                 *reinterpret_cast<bf16x8*>(sAl + off) = l;
@@ -315,7 +331,7 @@ __device__ __forceinline__ void x3s_body(const GemmProbDev* __restrict__ P) {
             const int c = pc + TPR * j;
             if (c < CHUNKS) {
                 bf16x8 h, l;
-                split8(a[j][0], a[j][1], h, l);
+                if (f16p) split8_f16(a[j][0], a[j][1], h, l); else split8(a[j][0], a[j][1], h, l);
                 const int off = (c >> 3) * BM * 128 + pr * 128 + (((c & 7) ^ ((pr >> 1) & 7)) << 4);
                 *reinterpret_cast<bf16x8*>(sAh + off) = h;
                 *reinterpret_cast<bf16x8*>(sAl + off) = l;
@@ -329,17 +345,32 @@ __device__ __forceinline__ void x3s_body(const GemmProbDev* __restrict__ P) {
     // ---- 2. products
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const int arow = 16 * mt + l15;
+    if (f16p) {
 #pragma unroll
-    for (int s = 0; s < KS; ++s) {
-        const int kstep = kp * KS + s;
-        const int ch = 4 * (kstep & 1) + lq;
-        const int off = (kstep >> 1) * BM * 128 + arow * 128 + ((ch ^ ((arow >> 1) & 7)) << 4);
-        const bf16x8 xh = *reinterpret_cast<const bf16x8*>(sAh + off);
-        const bf16x8 xl = *reinterpret_cast<const bf16x8*>(sAl + off);
-        const bf16x8 h = __builtin_bit_cast(bf16x8, wh[s]), l = __builtin_bit_cast(bf16x8, wl[s]);
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, xh, acc0, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, xl, acc1, 0, 0, 0);
-        acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l, xh, acc1, 0, 0, 0);
+        for (int s = 0; s < KS; ++s) {
+            const int kstep = kp * KS + s;
+            const int ch = 4 * (kstep & 1) + lq;
+            const int off = (kstep >> 1) * BM * 128 + arow * 128 + ((ch ^ ((arow >> 1) & 7)) << 4);
+            const f16x8 xh = *reinterpret_cast<const f16x8*>(sAh + off);
+            const f16x8 xl = *reinterpret_cast<const f16x8*>(sAl + off);
+            const f16x8 h = __builtin_bit_cast(f16x8, wh[s]), l = __builtin_bit_cast(f16x8, wl[s]);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, xh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(h, xl, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(l, xh, acc1, 0, 0, 0);
+        }
+    } else {
+#pragma unroll
+        for (int s = 0; s < KS; ++s) {
+            const int kstep = kp * KS + s;
+            const int ch = 4 * (kstep & 1) + lq;
+            const int off = (kstep >> 1) * BM * 128 + arow * 128 + ((ch ^ ((arow >> 1) & 7)) << 4);
+            const bf16x8 xh = *reinterpret_cast<const bf16x8*>(sAh + off);
+            const bf16x8 xl = *reinterpret_cast<const bf16x8*>(sAl + off);
+            const bf16x8 h = __builtin_bit_cast(bf16x8, wh[s]), l = __builtin_bit_cast(bf16x8, wl[s]);
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, xh, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(h, xl, acc1, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(l, xh, acc1, 0, 0, 0);
+        }
     }
     f32x4 v = acc0 + acc1;
     X3_STAMP(4);

@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 17
+#define GHN3_ABI_VERSION 18
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -101,6 +101,15 @@ enum { GHN3_DACT_NONE = 0, GHN3_DACT_RELU = 1 /* aux_in > 0 */, GHN3_DACT_GELU =
  * w = wave 0..7; slots of ids that name no tile are not written: zero the table first).  The squared gradient norm of
  * clip_grad_norm_ (trainer.py:356-360) then needs no pass over dW2: GHN3_OP_SUMSQ adds the slots.  (ABI v16) */
 #define GHN3_GEMM_SUMSQ 16u
+/* With GHN3_GEMM_X3 on tile codes 44 / 45: the pieces are F16 instead of bf16 -- a = a_hi + a_lo with 11 + 11 bits of
+ * mantissa (~2^-22, fp32-grade) instead of 8 + 8 (~2^-17) on v_mfma_f32_16x16x32_f16, same three products, same rate.  B / B2
+ * are then the f16 pieces of W * 2^GHN3_X3F16_WSHIFT written by GHN3_CAST_SPLIT_F16 (weights of ~1e-2 sit in the middle of the
+ * f16 range, the lo pieces stay normal numbers) and the caller folds 2^-GHN3_X3F16_WSHIFT into alpha.  f16 has 5 exponent bits:
+ * for O(1) operands only -- the FORWARD linears of the Graphormer (LayerNorm / attention / GELU outputs); gradient operands
+ * (~1e-7) keep the bf16 pieces.  Why: the node embeddings then carry fp32-grade rounding, and ReLU masks of the decoders on a
+ * knife edge flip ~5x less often against the fp32 path (docs/EXPERIMENTS.md, round 5).  (ABI v18) */
+#define GHN3_GEMM_X3F16 32u
+#define GHN3_X3F16_WSHIFT 6
 
 typedef struct ghn3_gemm_problem {
     ghn3_ref A, B, C;
@@ -201,6 +210,9 @@ typedef struct ghn3_gemm_problem {
  * source already carries the power-of-two scale of the op's r4: values are re-laid out bit for bit, column sums are divided by
  * the scale.  (The transposed weight-gradient operands made from the 16-bit tile gradient GHN3_OP_TILE_BWD wrote.)  (ABI v15) */
 #define GHN3_CAST_SRC16 1024u
+/* with GHN3_CAST_SPLIT: the STRAIGHT hi / lo copies are f16 pieces of x * 2^GHN3_X3F16_WSHIFT (operand B of GHN3_GEMM_X3F16
+ * problems); the transposed copies stay bf16 pieces of x.  (ABI v18) */
+#define GHN3_CAST_SPLIT_F16 2048u
 typedef struct ghn3_cast_desc {
     int64_t src_off, dst_off, dstT_off;
     int32_t rows, cols;

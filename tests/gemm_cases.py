@@ -536,7 +536,7 @@ def run_ln_case(ctx, kind, M, N, K, b_mode, res=True, seed=0, dev='cuda'):
 # GHN3_GEMM_X3 problems.  Expectation: fp64 product of the fp32 operands (the deviation is the dropped lo.lo term and
 # the bf16 rounding of the lo halves: ~1e-5 relative).
 # ---------------------------------------------------------------------------------------------------------------
-def x3_setup(W, dev='cuda', frag=False):
+def x3_setup(W, dev='cuda', frag=False, f16=False):
     """fp32 weight W [R][Cc] (numpy) -> (device fp32 weight, shadow buffer (uint16), layout dict) through one cast op.
     frag: fragment-major copies (GHN3_CAST_FRAG, the operand layout of tile codes 44 / 45)."""
     R, Cc = W.shape
@@ -549,12 +549,13 @@ def x3_setup(W, dev='cuda', frag=False):
     desc['dst_off'], desc['ld_dst'] = lay['hi'], Cc
     desc['dstT_off'], desc['ld_dstT'] = lay['hiT'], R
     desc['lo_off'] = lay['lo']
-    desc['flags'] = L.CAST_STRAIGHT | L.CAST_TRANSPOSED | L.CAST_SPLIT | (L.CAST_FRAG if frag else 0)
+    desc['flags'] = L.CAST_STRAIGHT | L.CAST_TRANSPOSED | L.CAST_SPLIT | (L.CAST_FRAG if frag else 0) | \
+        (L.CAST_SPLIT_F16 if f16 else 0)
     return dW, shadow, lay, desc
 
 
 def run_x3_case(ctx, M, N, K, transposed=False, tile=40, ksplit=1, slice_=0, epilogue='none', seed=0, dev='cuda', ln=0,
-                ln_res=True):
+                ln_res=True, f16=False):
     """C = A W^T (W [N][K]) or, transposed, C = A W (W [K][N]).  Returns [(got, expected)].
     ln = 1 / 2 (tile codes 44 / 45, gemm_x3d.hip): the LayerNorm forward / backward row prologue of A
     (ghn3_gemm_problem::ln_kind); the by-products (normalised rows, mean, rstd / the propagated gradient) are returned too."""
@@ -607,7 +608,8 @@ def run_x3_case(ctx, M, N, K, transposed=False, tile=40, ksplit=1, slice_=0, epi
         v = v * (aux > 0)
     if epilogue == 'full':
         v = v + resid
-    dW, shadow, lay, desc = x3_setup(W, dev, frag=tile in (44, 45))
+    assert not (f16 and transposed)                  # (f16 pieces: the straight copies / forward products only)
+    dW, shadow, lay, desc = x3_setup(W, dev, frag=tile in (44, 45), f16=f16)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x)).to(dev)
     dA, dbias, dres, daux = t(A), t(bias), t(resid), t(aux)
     dC = torch.full((max(ksplit, 1), M, N), 7.0, dtype=torch.float32, device=dev)
@@ -634,6 +636,8 @@ def run_x3_case(ctx, M, N, K, transposed=False, tile=40, ksplit=1, slice_=0, epi
         p[j]['C']['buf'], p[j]['C']['off'] = 2, 4 * j * M * N
         p[j]['M'], p[j]['N'], p[j]['K'], p[j]['lda'], p[j]['ldb'], p[j]['ldc'] = M, N, kc, K, K, N
         p[j]['flags'], p[j]['alpha'], p[j]['x3_slice'] = L.GEMM_X3, 1.0, sl
+        if f16:
+            p[j]['flags'], p[j]['alpha'] = L.GEMM_X3 | L.GEMM_X3F16, 2.0 ** -L.X3F16_WSHIFT
     if epilogue in ('full', 'gelu', 'bias_relu', 'bias_res'):
         p[0]['bias']['buf'] = 3
     if epilogue in ('full', 'bias_res'):
@@ -711,5 +715,11 @@ X3_CASES = [
     dict(M=45, N=512, K=128, tile=44, ln=2, transposed=True, epilogue='dgelu'),  # ghn3sm8
     dict(M=45, N=128, K=128, tile=45, ln=1),
     dict(M=33, N=96, K=192, tile=45, ln=2, transposed=True),
+    # f16 pieces (GHN3_GEMM_X3F16, round 5): the forward linears, fp32-grade products
+    dict(M=256, N=1152, K=384, tile=44, ln=1, f16=True),                        # LN1 -> to_qkv
+    dict(M=256, N=1536, K=384, tile=44, ln=1, epilogue='gelu', f16=True),       # LN2 -> ff.net.0
+    dict(M=256, N=384, K=384, tile=45, epilogue='bias_res', f16=True),          # to_out
+    dict(M=256, N=384, K=1536, tile=45, epilogue='bias_res', f16=True),         # ff.net.3
+    dict(M=70, N=192, K=64, tile=44, ln=1, epilogue='bias_relu', f16=True),
     dict(M=33, N=96, K=192, tile=44, ln=1),
 ]

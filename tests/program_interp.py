@@ -184,15 +184,19 @@ class Interp:
                 if fl & L.CAST_SCALED and amax is not None:
                     X = (X * np.float32(self.pow2_scale(amax[0]))).astype(np.float32)
             split = bool(fl & L.CAST_SPLIT)
+            f16s = split and bool(fl & L.CAST_SPLIT_F16)      # straight pieces: f16 pieces of x * 2^GHN3_X3F16_WSHIFT
             if split:                               # bf16 hi copy + lo = bf16(x - hi) copy `lo_off` elements behind
                 Xlo = (X - self.from16(self.to16(X, True), True)).astype(np.float32)
+            if f16s:
+                Xs = (X * np.float32(2.0 ** L.X3F16_WSHIFT)).astype(np.float32)
+                Xs_lo = (Xs - self.from16(self.to16(Xs, False), False)).astype(np.float32)
             if fl & L.CAST_FRAG:
                 assert split and rows % 32 == 0 and cols % 32 == 0
                 r_, c_ = np.arange(rows)[:, None], np.arange(cols)[None, :]
                 if fl & L.CAST_STRAIGHT:
                     ii = int(D['dst_off']) + self.frag_index(r_, c_, cols)
-                    dst[ii] = self.to16(X, True)
-                    dst[ii + int(D['lo_off'])] = self.to16(Xlo, True)
+                    dst[ii] = self.to16(Xs, False) if f16s else self.to16(X, True)
+                    dst[ii + int(D['lo_off'])] = self.to16(Xs_lo, False) if f16s else self.to16(Xlo, True)
                 if fl & L.CAST_TRANSPOSED:
                     ii = int(D['dstT_off']) + self.frag_index(c_, r_, rows)
                     dst[ii] = self.to16(X, True)
@@ -203,10 +207,12 @@ class Interp:
                 Z[:, :cols] = X
                 ldd = int(D['ld_dst'])
                 ii = int(D['dst_off']) + np.arange(rows)[:, None] * ldd + np.arange(r64(cols))[None, :]
-                dst[ii] = self.to16(Z, bool(fl & L.CAST_STRAIGHT_BF16) or split)
+                if f16s:
+                    Z[:, :cols] = Xs
+                dst[ii] = self.to16(Z, (bool(fl & L.CAST_STRAIGHT_BF16) or split) and not f16s)
                 if split:
-                    Z[:, :cols] = Xlo
-                    dst[ii + int(D['lo_off'])] = self.to16(Z, True)
+                    Z[:, :cols] = Xs_lo if f16s else Xlo
+                    dst[ii + int(D['lo_off'])] = self.to16(Z, not f16s)
             if fl & L.CAST_TRANSPOSED:
                 rw = (rows + 7) // 8 * 8 if fl & L.CAST_TIGHT else r64(rows)
                 Z = np.zeros((cols, rw), np.float32)
@@ -278,13 +284,15 @@ class Interp:
         A = XA[ra[:, None] * lda + np.arange(K)[None, :]]
         if int(p['ln_kind']):
             A = self._ln_prologue(p, A, M, K, lda)
-        ah = self.from16(self.to16(A, True), True)
-        al = self.from16(self.to16((A - ah).astype(np.float32), True), True)
+        bf = not (int(p['flags']) & L.GEMM_X3F16)          # GHN3_GEMM_X3F16: f16 pieces (B already scaled, alpha undoes it)
+        assert bf or staged
+        ah = self.from16(self.to16(A, bf), bf)
+        al = self.from16(self.to16((A - ah).astype(np.float32), bf), bf)
         if staged:
             ib = self.frag_index(np.arange(N)[None, :], np.arange(K)[:, None], K)
         else:
             ib = np.arange(N)[None, :] * ldb + np.arange(K)[:, None]
-        bh, bl = self.from16(Bh[ib], True).astype(np.float64), self.from16(Bl[ib], True).astype(np.float64)
+        bh, bl = self.from16(Bh[ib], bf).astype(np.float64), self.from16(Bl[ib], bf).astype(np.float64)
         ah, al = ah.astype(np.float64), al.astype(np.float64)
         self._gemm_finish(p, None, None, prod=ah @ bh + (ah @ bl + al @ bh))
 

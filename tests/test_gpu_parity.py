@@ -75,7 +75,8 @@ def test_split_bf16_gemm_cases(ctx):
         for j, (got, exp) in enumerate(run_x3_case(ctx, seed=k, **case)):
             assert np.isfinite(got).all(), (case, j)
             err = rel_l2(got, exp)
-            assert err < 3e-5, (case, j, err)
+            # (f16 pieces -- GHN3_GEMM_X3F16, the forward linears -- carry 11 + 11 bits: fp32-grade products)
+            assert err < (2e-6 if case.get('f16') else 3e-5), (case, j, err)
 
 
 def _run_forward(hip, nets, gb, training=False):

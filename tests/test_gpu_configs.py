@@ -602,14 +602,12 @@ def test_bench_workload_against_the_reference_itself(case, compute, tol_f, tol_g
     two-graph batch (b2r: 90 + 170 nodes, quirk Q1 at XL width), loss = sum of Frobenius norms of the predicted tensors
     (trainer.py:97-98,288-294): per predicted tensor its norm and 2048 sampled elements, per GHN parameter the gradient
     norm and 2048 sampled elements.  Exact-fp32 mode: 1e-4 / 3e-4; benchmarked f16 mode: north star 1e-3 on every
-    predicted tensor and, on the benchmark graph, on every parameter gradient.  The ragged batch's f16 GRADIENTS get 1.5e-3:
-    measured (tools/diag/x3s_vs_x3.py, r04): the staged split-bf16 plan and the round-3 plan agree on every forward
-    activation to 2e-5, yet ONE row of d_xe (node 88 of graph 0, its classifier-weight row) differs by 2 % -- a single ReLU
-    mask element of the classifier tile on a knife edge, flipped by a 1e-5 difference of the node embeddings -- which shifts
-    every Graphormer gradient by the same 7e-4 (top layers included).  With the Graphormer in exact fp32 (GHN3_X3=0) the same
-    f16 decoder agrees with the reference to < 6e-4 on this batch, the round-3 split-bf16 plan happens to as well."""
-    if case == 'b2r' and compute == 'f16':
-        tol_g = 1.5e-3
+    predicted tensor and on every parameter gradient, on both batches.  (Round 4 had to give the ragged batch's f16 gradients
+    1.5e-3: with bf16 pieces in the Graphormer's forward linears the node embeddings sat ~1e-5 from the fp32 path, and ONE ReLU
+    mask element of the classifier tile on a knife edge -- node 88 of graph 0 -- flipped, which shifted every Graphormer
+    gradient by 7e-4.  Round 5: the forward linears multiply f16 pieces, fp32-grade (GHN3_GEMM_X3F16); the gate is 1e-3 again.
+    Over 500 random batches against the fp32 mode: 4.8 % -> 0.8 % of the batches with any gradient above 1e-3,
+    profiles/r05_modes_sweep_*.)"""
     import os
     import recipe
     from ghn3_amd import GHN3

@@ -249,7 +249,7 @@ def bench_fixture(args, cfg):
     ctx = L.context(0)
     stream = torch.cuda.current_stream().cuda_stream
     with torch.no_grad():
-        plan = ghn.compile(net, batch(), training=False)
+        plan = ghn.compile([net], batch(), training=False)
         prog = plan.program
         n_pred = sum(p_['numel'] for p_ in prog.predicted)
         for _ in range(args.warmup):
@@ -337,11 +337,11 @@ def bench_fixture(args, cfg):
             net_o = recipe.build_torch_net(spec)
             times = []
             with torch.no_grad():
-                oracle(net_o, go)
+                oracle([net_o], go)
                 budget = time.time() + 25
                 while len(times) < 5 and (time.time() < budget or len(times) < 2):
                     tc = time.time()
-                    oracle(net_o, go)
+                    oracle([net_o], go)
                     times.append(time.time() - tc)
             t_med = float(np.median(times))
             out['cpu_baseline'] = {'value': n_pred / t_med, 'unit': 'predicted-params/s', 'cores': cores, 'kind': 'port',

@@ -247,10 +247,36 @@ class Program:
             # BEHIND the rest of the decoder backward.  The conv.0 / fc dgrads, the plane sums and the node-row gather are on
             # the dependent chain and no longer share the chip with it (fc dgrad 0.39 -> 0.1 ms); the weight gradient then
             # runs beside the Graphormer backward only, which is long enough to hide it (GHN3_WGRAD_LATE=0: early order).
-            if self.wgrad_op_range is not None and self.SIDE and os.environ.get('GHN3_WGRAD_LATE', '1') != '0':
+            # Round 5b, GHN3_WGRAD_ORDER=first (default when the weight gradient runs on the side stream): issued right behind the
+            # tile backward and its operand copies, on 128 workgroups -- half of every XCD -- it runs beside the W2 dgrad (both
+            # MFMA-bound: the chip's work is conserved), the conv.0 / fc backward and only the first layers of the Graphormer
+            # backward, which is the part of the step that suffers beside it (tools/contention_probe: a streaming kernel on the
+            # other CUs turns the chain's L2 hits into 350 ns misses and costs 8-15 % of the clock).  5.85-5.86 against 5.91-5.93
+            # ms (one graph), 9.65-9.83 against 10.03-10.12 (two), 15.76-15.80 against 16.28-16.35 (four); 112 / 144 / 160
+            # workgroups are all slower than 128 (profiles/r05s_*, r05v_*, r05w_*).
+            order = self._wgrad_order_env()
+            if order == 'first' and not getattr(self, 'wgrad_cap', 0):
+                order = 'late'                           # (on the chain's own stream it stays in front of the Graphormer backward)
+            self.wgrad_order = order if (self.wgrad_op_range is not None and self.SIDE) else 'early'
+            if self.wgrad_order == 'late':
                 a, b = self.wgrad_op_range
                 o = self.bwd_ops
                 self.bwd_ops = np.concatenate([o[:a], o[b:self.bwd_split], o[a:b], o[self.bwd_split:]])
+            elif self.wgrad_order == 'first' and getattr(self, '_i_dgrad', None) is not None:
+                a, b = self.wgrad_op_range               # (a: the zero-fill of its sum-of-squares slots, then the launches)
+                dg0, l0, l1 = self._i_dgrad, self._i_late0, self._i_late1
+                o = self.bwd_ops
+                perm = list(range(dg0)) + list(range(l0, l1)) + list(range(a, b)) + list(range(dg0, l0)) + \
+                    list(range(l1, a)) + list(range(b, len(o)))
+                assert sorted(perm) == list(range(len(o)))
+                inv = {old: new for new, old in enumerate(perm)}
+                self.bwd_ops = o[np.asarray(perm, dtype=np.int64)]
+                # (op indices recorded for the route switch of the tile gradient / the data-parallel parts follow the ops)
+                if hasattr(self, 'd16_kinds'):
+                    self.d16_kinds = {inv[k]: v for k, v in self.d16_kinds.items()}
+                    self.d16_on_idx = [inv[k] for k in self.d16_on_idx]
+                    self.d16_off_idx = [inv[k] for k in self.d16_off_idx]
+                self.ddp_index = {inv[k]: v for k, v in self.ddp_index.items()}
         else:
             self.bwd_ops = np.zeros(0, dtype=L.OP_DT)
         self.problems = self._pack_problems()
@@ -1584,6 +1610,13 @@ class Program:
                 touched.append(k)
         return touched
 
+    @staticmethod
+    def _wgrad_order_env():
+        """GHN3_WGRAD_ORDER: where the side-stream W2 weight gradient is issued in the single-process backward -- 'first'
+        (default; behind the tile backward and its operand copies, beside the W2 dgrad and the rest of the decoder backward),
+        'late' (rounds 3-5a: behind the decoder backward, beside the Graphormer backward only), 'early' (behind the dgrad)."""
+        return os.environ.get('GHN3_WGRAD_ORDER', 'first' if os.environ.get('GHN3_WGRAD_LATE', '1') != '0' else 'early')
+
     def _wgrad_schedule(self, flops, rows):
         """Workgroups of the side-stream W2 weight gradient (a multiple of 8: a worker's tiles keep their XCD), or 0 = on the
         chain's stream in front of the Graphormer backward.  See the call site for the model and its measurements."""
@@ -1598,6 +1631,8 @@ class Program:
         ch_ms = self.Lyr * (0.030 + 0.014 * (rows / 256.0) * (self.C / 384.0) ** 2)      # the backward chain alone
         if env_main != '0' and w_ms < 0.75 * ch_ms:
             return 0
+        if self._wgrad_order_env() == 'first':
+            return 128                                   # half of every XCD (see the call site)
         c = int(round(256.0 * w_ms / (1.75 * ch_ms) / 8.0)) * 8
         if c >= 232:
             return 0 if env_main != '0' else 224
@@ -2058,7 +2093,8 @@ class Program:
                 sq_on = covered and all(g_['op16'] for g_ in self.gemm_groups) and wg_tile == 29 and \
                     os.environ.get('GHN3_WGRAD_SUMSQ', '1') != '0'
                 sq_ids = 0
-                if sq_on:
+                n_before = len(self._ops)               # (the zero-fill of the sum-of-squares slots belongs to the weight gradient:
+                if sq_on:                               #  it moves with it when the order of the backward changes)
                     for b_ in bands:
                         thr = sorted({m_['o'] for m_ in b_['members']}, reverse=True)
                         for j, o_hi in enumerate(thr):
@@ -2085,8 +2121,8 @@ class Program:
                 # to the dependent chain on the main stream, which the faster kernel otherwise slows down by what it
                 # gained (step 8.51 ms with the old kernel, 8.56 with tile 25 on every CU, 8.46 at 224, 8.38 at 192 --
                 # but there the weight gradient is back at 1.49 ms).
-                n_before = len(self._ops)
-                # Where the W2 weight gradient runs (round 5: the fastest step is the default).  The persistent kernel takes
+                # Where the W2 weight gradient runs (round 5: the fastest step is the default; this paragraph is the model of
+                # GHN3_WGRAD_ORDER=late -- for the default order 'first', 128 workgroups, see the end of __init__).  The persistent kernel takes
                 # 128 KB of LDS and 256 VGPRs on every CU it sits on -- nothing co-resides with it -- so beside it the
                 # Graphormer backward chain only gets the CUs the launch leaves free, and it runs ~1.75x slower there
                 # whatever their number (memory-system contention: 1.12 -> 1.9-2.0 ms on 128 / 96 / 64 free CUs,

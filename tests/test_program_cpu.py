@@ -436,8 +436,9 @@ def test_mark_wait_pairs_survive_the_data_parallel_split():
     assert len(waits) == 1 + int(prog.ddp_wgrad_first) and all(w[2] for w in waits)
 
 
-@pytest.mark.parametrize('case,route', [('b2', 'dout'), ('b2', 'norm'), ('syn', 'norm'), ('ragged3', 'dout')])
-def test_data_parallel_parts_give_the_gradients_of_the_single_run(case, route):
+@pytest.mark.parametrize('case,route,order', [('b2', 'dout', None), ('b2', 'norm', None), ('syn', 'norm', None),
+                                              ('ragged3', 'dout', None), ('b2', 'norm', 'first'), ('syn', 'dout', 'first')])
+def test_data_parallel_parts_give_the_gradients_of_the_single_run(case, route, order, monkeypatch):
     """Program.bwd_parts (round 5: the W2 weight gradient FIRST -- behind the tile backward and its operand copies, in front
     of the W2 dgrad -- so that the exchange of dW2, 69 % of the bytes, overlaps everything else of the backward): the three
     parts run one after the other write the gradient buffer of the single-run order bit for bit, on both tile-gradient
@@ -450,10 +451,32 @@ def test_data_parallel_parts_give_the_gradients_of_the_single_run(case, route):
     else:
         mk = lambda: (_build(recipe.TINY_CFG, recipe.TINY_SEED, 'reference')[0],) + tuple(_tiny(case)[:2])
     grads = []
-    for split in (False, True):
+    # order = 'first' (GHN3_WGRAD_ORDER, the default when the weight gradient runs on the side stream -- forced here with
+    # GHN3_WGRAD_MAIN=0: the tiny models would keep it on the chain's stream): the single-process order with the weight gradient
+    # in front of the W2 dgrad -- the permuted program (and the op indices the route switch patches, and the zero-fill of the
+    # kernel's sum-of-squares slots) must give the bits of the 'late' order
+    for split in (False, True) if order is None else (False, 'reordered', True):
         hip, nets_h, gb_h = mk()
+        reordered = split == 'reordered' or (split is True and bool(order))
+        if order:
+            monkeypatch.setenv('GHN3_WGRAD_MAIN', '0')
+            monkeypatch.setenv('GHN3_WGRAD_ORDER', order if reordered else 'late')
         prog, it, bufs, gflat = _run_program(hip, nets_h, gb_h, decoder_ctype=L.CT_F16, decoder_bwd_ctype=L.CT_F16)
+        monkeypatch.delenv('GHN3_WGRAD_ORDER', raising=False)
+        monkeypatch.delenv('GHN3_WGRAD_MAIN', raising=False)
         assert prog.ddp_wgrad_first and len(prog.bwd_parts) == 3
+        if order:
+            a_, b_ = prog.wgrad_op_range
+            tag = lambda o: (int(o['flags']) >> 16) & 0xff
+            w_ops = [k for k, o in enumerate(prog.bwd_ops) if int(o['kind']) == L.OP_GEMM and tag(o) == prog.TAG_D3_WGRAD]
+            d_ops = [k for k, o in enumerate(prog.bwd_ops) if int(o['kind']) == L.OP_GEMM and tag(o) == prog.TAG_D3_DGRAD]
+            assert prog.wgrad_cap > 0 and prog.wgrad_order == (order if reordered else 'late')
+            assert (min(w_ops) < min(d_ops)) == reordered, (w_ops, d_ops)
+            if prog.grad_sumsq is not None:              # its zero-fill stays in front of the launch that fills the slots
+                z = [k for k, o in enumerate(prog.bwd_ops) if int(o['kind']) == L.OP_MEMSET0 and
+                     int(o['r'][0]['off']) == prog.grad_sumsq['ws_off']]
+                assert len(z) == 1 and z[0] < min(w_ops)
+        split = bool(split is True)
         it.run(prog.norm_fin_ops(), prog.problems)
         bufs[prog.xbuf(prog.X_NORMG)] = np.asarray([0.37], dtype=np.float32).view(np.uint8)
         dout = (1e-3 * np.random.RandomState(4).standard_normal(prog.out_numel)).astype(np.float32)
@@ -480,8 +503,8 @@ def test_data_parallel_parts_give_the_gradients_of_the_single_run(case, route):
                     assert slots == [(w2, w2 + 1)]
                     w2_after_part1 = gflat.view(np.float32)[int(hip._offs[w2]):int(hip._offs[w2 + 1])].copy()
         grads.append(gflat.view(np.float32).copy())
-    a, b = grads
-    assert np.isfinite(a).all() and np.array_equal(a, b)
+    a = grads[0]
+    assert np.isfinite(a).all() and all(np.array_equal(a, b) for b in grads[1:])
     w2 = prog.slot['decoder.conv.2.weight']
     assert np.array_equal(w2_after_part1, a[int(hip._offs[w2]):int(hip._offs[w2 + 1])]) and np.abs(w2_after_part1).max() > 0
 

@@ -1706,7 +1706,24 @@ __device__ __forceinline__ float f16_back(unsigned short h) { return (float)__bu
 typedef unsigned short us4 __attribute__((ext_vector_type(4)));
 typedef unsigned short us8 __attribute__((ext_vector_type(8)));
 
-struct AdamWArgs { float lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2_sqrt, max_norm, inv_scale; };
+struct AdamWArgs { float lr, beta1, beta2, eps, weight_decay, bias_corr1, bias_corr2_sqrt, max_norm, inv_scale; int nt; };
+// The optimizer pass streams 28-34 bytes per parameter exactly once.  Through the default cache policy that stream flushes the L2 of
+// every XCD within microseconds -- and the next forward's Graphormer chain, which runs beside the decoder ranges of the pass
+// (FusedAdamW.step(overlap=True)), then finds its producers' outputs in HBM instead of L2 (tools/contention_probe: 68 -> 350 ns per
+// dependent access; none of it with non-temporal loads / stores).  GHN3_ADAMW_NT=0: default policy (A/B).
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ float4 ld4(const float* p, bool nt) {
+    if (nt) { const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p)); return make_float4(v[0], v[1], v[2], v[3]); }
+    return *reinterpret_cast<const float4*>(p);
+}
+__device__ __forceinline__ void st4(float* p, const float4& x, bool nt) {
+    if (nt) { const f32x4_nt v = {x.x, x.y, x.z, x.w}; __builtin_nontemporal_store(v, reinterpret_cast<f32x4_nt*>(p)); }
+    else *reinterpret_cast<float4*>(p) = x;
+}
+static int adamw_nt_env() {
+    static const int v = getenv("GHN3_ADAMW_NT") ? atoi(getenv("GHN3_ADAMW_NT")) != 0 : 1;
+    return v;
+}
 // gradient / moment buffers congruent to the source of a cast (same float offsets): GHN3_OP_ADAMW_CAST16
 struct AdamWSrc { const float* g; float* m; float* v; const float* sumsq; AdamWArgs a; };
 
@@ -1831,16 +1848,17 @@ __device__ __forceinline__ void cast16_body(const float* __restrict__ src, unsig
                 if (c + 3 < D.cols) {
                     const int64_t o = D.src_off + (int64_t)r * D.ld_src + c;
                     float* pp = const_cast<float*>(src) + o;
-                    x = *reinterpret_cast<const float4*>(pp);
-                    const float4 gv = *reinterpret_cast<const float4*>(aw.g + o);
-                    float4 mv = *reinterpret_cast<const float4*>(aw.m + o), vv = *reinterpret_cast<const float4*>(aw.v + o);
+                    const bool nt = aw.a.nt != 0;
+                    x = ld4(pp, nt);
+                    const float4 gv = ld4(aw.g + o, nt);
+                    float4 mv = ld4(aw.m + o, nt), vv = ld4(aw.v + o, nt);
                     adamw_element(x.x, gv.x, mv.x, vv.x, aw.a, aw_clip, aw_step, aw_decay);
                     adamw_element(x.y, gv.y, mv.y, vv.y, aw.a, aw_clip, aw_step, aw_decay);
                     adamw_element(x.z, gv.z, mv.z, vv.z, aw.a, aw_clip, aw_step, aw_decay);
                     adamw_element(x.w, gv.w, mv.w, vv.w, aw.a, aw_clip, aw_step, aw_decay);
-                    *reinterpret_cast<float4*>(aw.m + o) = mv;
-                    *reinterpret_cast<float4*>(aw.v + o) = vv;
-                    *reinterpret_cast<float4*>(pp) = x;
+                    st4(aw.m + o, mv, nt);
+                    st4(aw.v + o, vv, nt);
+                    st4(pp, x, nt);
                 }
             } else {
                 const float* p = S + (int64_t)r * D.ld_src + sc_;
@@ -2104,16 +2122,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(m) |
           reinterpret_cast<uintptr_t>(v)) & 15) == 0) {
         n4 = n >> 2;
-        float4* p4 = reinterpret_cast<float4*>(p);
-        const float4* g4 = reinterpret_cast<const float4*>(g);
-        float4* m4 = reinterpret_cast<float4*>(m);
-        float4* v4 = reinterpret_cast<float4*>(v);
+        const bool nt = a.nt != 0;
         for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
-            float4 pv = p4[i], gv = g4[i], mv = m4[i], vv = v4[i];
+            float4 pv = ld4(p + 4 * i, nt), gv = ld4(g + 4 * i, nt), mv = ld4(m + 4 * i, nt), vv = ld4(v + 4 * i, nt);
             float* pe = &pv.x; float* ge = &gv.x; float* me = &mv.x; float* ve = &vv.x;
 #pragma unroll
             for (int e = 0; e < 4; ++e) adamw_element(pe[e], ge[e], me[e], ve[e], a, clip, step, decay);
-            m4[i] = mv; v4[i] = vv; p4[i] = pv;
+            st4(m + 4 * i, mv, nt); st4(v + 4 * i, vv, nt); st4(p + 4 * i, pv, nt);
         }
     }
     for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
@@ -2132,7 +2147,7 @@ int ghn3_adamw_cast16(float* p, const float* g, float* m, float* v, void* dst, c
         return GHN3_E_ARG;
     }
     AdamWSrc aw{g, m, v, sumsq, AdamWArgs{lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrtf(bias_corr2), max_norm,
-                                           inv_scale > 0.f ? inv_scale : 1.f}};
+                                           inv_scale > 0.f ? inv_scale : 1.f, adamw_nt_env()}};
     hipLaunchKernelGGL(adamw_cast16_kernel, dim3(total_blocks), dim3(256), 0, s, p, (unsigned short*)dst, d_desc, n_desc,
                        total_blocks, aw);
     return launch_ok("adamw_cast16");
@@ -2143,7 +2158,7 @@ int ghn3_adamw(float* p, const float* g, float* m, float* v, int64_t n, const fl
                float inv_scale, hipStream_t s) {
     if (n <= 0) return GHN3_OK;
     AdamWArgs a{lr, beta1, beta2, eps, weight_decay, bias_corr1, sqrtf(bias_corr2), max_norm,
-                inv_scale > 0.f ? inv_scale : 1.f};
+                inv_scale > 0.f ? inv_scale : 1.f, adamw_nt_env()};
     int64_t blocks = (n / 4 + 255) / 256 + 1;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(adamw_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, g, m, v, n, sumsq, a);

@@ -1727,17 +1727,30 @@ static int adamw_nt_env() {
 // gradient / moment buffers congruent to the source of a cast (same float offsets): GHN3_OP_ADAMW_CAST16
 struct AdamWSrc { const float* g; float* m; float* v; const float* sumsq; AdamWArgs a; };
 
+__device__ __forceinline__ float nofuse(float x) { asm volatile("" : "+v"(x)); return x; }   // the value exists in a register: no FMA across it
+// per-launch scalars of the update, explicitly rounded like adamw_element: the two kernels that share them must not differ by a
+// contraction the compiler picks in one and not in the other (1 - lr wd as one FMA: parameters one ulp apart)
+__device__ __forceinline__ void adamw_scalars(const AdamWArgs& a, const float* sumsq, float& clip, float& step, float& decay) {
+    // (hipcc contracts a * b + c wherever it likes -- -ffp-contract=fast, the __f*_rn functions are plain operators in this HIP
+    // version and a contract(off) pragma does not survive inlining -- so every product that feeds a sum passes through nofuse())
+    clip = a.inv_scale;                                // (1 / loss scale: the gradients arrive multiplied by it)
+    if (sumsq && a.max_norm > 0.f)
+        clip = clip * fminf(1.f, a.max_norm / (nofuse(sqrtf(*sumsq) * a.inv_scale) + 1e-6f));
+    step = a.lr / a.bias_corr1;
+    decay = 1.f - nofuse(a.lr * a.weight_decay);
+}
 // one element of torch.optim.AdamW (decoupled weight decay); `clip` = clip_grad_norm_'s coefficient / loss scale
 __device__ __forceinline__ void adamw_element(float& p, float g, float& m, float& v, const AdamWArgs& a, float clip,
                                               float step, float decay) {
-    // (explicitly rounded operations: the compiler may not contract them differently in the kernels that share this
-    // function -- GHN3_OP_ADAMW and GHN3_OP_ADAMW_CAST16 produce the same bits)
-    const float gi = __fmul_rn(g, clip);
-    const float mi = __fmaf_rn(a.beta1, m, __fmul_rn(1.f - a.beta1, gi));
-    const float vi = __fmaf_rn(a.beta2, v, __fmul_rn(__fmul_rn(1.f - a.beta2, gi), gi));
+    // (separately rounded operations: the compiler must not contract them differently in the kernels that share this
+    // function -- GHN3_OP_ADAMW and GHN3_OP_ADAMW_CAST16 produce the same bits.  nofuse() is what guarantees it: `p decay -
+    // update` was one FMA in one of the two kernels only)
+    const float gi = g * clip;
+    const float mi = __builtin_fmaf(a.beta1, m, nofuse((1.f - a.beta1) * gi));
+    const float vi = __builtin_fmaf(a.beta2, v, nofuse(nofuse((1.f - a.beta2) * gi) * gi));
     m = mi; v = vi;
-    const float den = __fadd_rn(__fdiv_rn(__fsqrt_rn(vi), a.bias_corr2_sqrt), a.eps);
-    p = __fsub_rn(__fmul_rn(p, decay), __fdiv_rn(__fmul_rn(step, mi), den));
+    const float den = nofuse(sqrtf(vi) / a.bias_corr2_sqrt) + a.eps;
+    p = nofuse(p * decay) - nofuse(nofuse(step * mi) / den);
 }
 
 // ADAMW: the source elements are parameters that first take their optimizer update (gradient / moments at the same float
@@ -1754,9 +1767,7 @@ __device__ __forceinline__ void cast16_body(const float* __restrict__ src, unsig
     float aw_clip = 1.f, aw_step = 0.f, aw_decay = 1.f;
     if (ADAMW) {
         if (aw.sumsq && !isfinite(*aw.sumsq)) return;   // (NaN guard as adamw_kernel: parameters AND copies stay as they are)
-        aw_clip = aw.a.inv_scale;
-        if (aw.sumsq && aw.a.max_norm > 0.f) aw_clip *= fminf(1.f, aw.a.max_norm / (sqrtf(*aw.sumsq) * aw.a.inv_scale + 1e-6f));
-        aw_step = aw.a.lr / aw.a.bias_corr1; aw_decay = 1.f - aw.a.lr * aw.a.weight_decay;
+        adamw_scalars(aw.a, aw.sumsq, aw_clip, aw_step, aw_decay);
     }
     // grid-stride over the 64 x 64 work tiles: a launch may cap its grid (side-stream copies that should leave
     // HBM bandwidth to the latency-bound chain they run under)
@@ -2113,9 +2124,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const
     // skipped on every rank alike, like GradScaler's found_inf and the reference trainer's NaN-loss skip
     // (trainer.py:240-257), without a host round trip.
     if (sumsq && !isfinite(*sumsq)) return;
-    float clip = a.inv_scale;                          // (1 / loss scale: the gradients arrive multiplied by it)
-    if (sumsq && a.max_norm > 0.f) clip *= fminf(1.f, a.max_norm / (sqrtf(*sumsq) * a.inv_scale + 1e-6f));
-    const float step = a.lr / a.bias_corr1, decay = 1.f - a.lr * a.weight_decay;
+    float clip, step, decay;
+    adamw_scalars(a, sumsq, clip, step, decay);
     // 16 bytes per lane (the pass streams 28 bytes per parameter: 4 loads + 3 stores -- HBM-bound); same arithmetic per
     // element as the scalar tail, so results do not depend on the path
     int64_t n4 = 0;

@@ -63,12 +63,16 @@ template <typename T> __device__ __forceinline__ T* rflp(T* p) {
 
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
+__device__ __forceinline__ void p8_divmod(int r, int q, int& d, int& m) {   // exact for 0 <= r < 2^24, q > 0 (float reciprocal + correction)
+    d = (int)((float)r * __builtin_amdgcn_rcpf((float)q));
+    m = r - d * q;
+    if (m < 0) { m += q; --d; } else if (m >= q) { m -= q; ++d; }
+    if (m < 0) { m += q; --d; } else if (m >= q) { m -= q; ++d; }
+}
 __device__ __forceinline__ int p8_map_row(int r, int q, int s) {
-    if (q > 0) {          // (r / q) * s + r % q, exact for 0 <= r < 2^24 (float reciprocal + correction)
-        int d = (int)((float)r * __builtin_amdgcn_rcpf((float)q));
-        int m = r - d * q;
-        if (m < 0) { m += q; --d; } else if (m >= q) { m -= q; ++d; }
-        if (m < 0) { m += q; --d; } else if (m >= q) { m -= q; ++d; }
+    if (q > 0) {          // (r / q) * s + r % q
+        int d, m;
+        p8_divmod(r, q, d, m);
         r = d * s + m;
     }
     return r;
@@ -420,7 +424,7 @@ __global__ __launch_bounds__(512, 2) void gemm_p8_kernel(const GemmProbDev* __re
 // residual / accumulate / gathers / k-map / ragged extents / split-K; N % 4 == 0, K >= 1; 256 x 256 tiles.
 // ---------------------------------------------------------------------------------------------------------------------
 #ifdef GHN3_P8W_PROBE
-__device__ long long g_p8w_probe[8];
+__device__ long long g_p8w_probe[48];
 #endif
 template <int CT, int QUIET>
 __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int total_tiles_all,
@@ -569,43 +573,101 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
     // norm of clip_grad_norm_ then needs no pass over the 1.8 GB of dW2; fixed order inside a wave, one writer per slot)
     float* p_sq = nullptr;
     int p_tile = 0;
-    float ss = 0.f;
-    auto store_prev = [&](int a, int b) {
+    float ss = 0.f;                                   // (one add per 16 x 32 block: the squares of a block are summed as a tree first)
+    // Round 5b: the epilogue's own instructions were half of the k-tile that stores (tools/p8w_probe -DP8W_X=2: 15k of its 25k cycles
+    // WITHOUT any store instruction -- per store a row-map division with two fix-up branches, bounds branches and a dependent
+    // chain of four FMAs, on SIMDs that two waves share).  Now: the row map (r / q) * s + r % q = r + (r / q) (s - q) takes its
+    // quotient from one v_mul_hi_u32 with the per-tile magic number floor(2^32 / q) + 1 (exact while M q < 2^32, which the runtime checks; 0 = no map),
+    // interior tiles skip every bounds test, and the squares of a block are summed as a tree before they join the lane's sum.
+    unsigned p_magic = 0;
+    int p_wrap = 0, p_colq = 0;
+    bool p_inner = false;
+    // Staged stores (round 5b).  In the accumulator layout a 16-lane pass of a store instruction is 16 ROWS x 16 bytes: the CU's
+    // store path takes 72 cycles per such instruction -- 18.6k cycles per 256 KB tile, whoever else runs (tools/store_probe, timed
+    // per workgroup) -- but 16 cycles when eight adjacent lanes write the 128 bytes of one cache line (4.2k per tile).  So every
+    // 16 x 32 block (two accumulator registers) goes through a wave-private 2 KB image behind the ring (two images per wave) -- ds_write_b128 in the
+    // accumulator layout, ds_read_b128 as 8 rows x 128 bytes, 16-byte chunks XOR-swizzled by the row: conflict-free both ways --
+    // and leaves as two instructions of eight full lines each.  No barrier: a wave's LDS operations execute in order.
+    auto store_prev_t = [&](const int a, const int b, const bool inner) __attribute__((always_inline)) {
+        char* stg = sm + 2 * KT + wave * 4096;        // two 16 x 32 fp32 images per wave: two blocks per LDS round trip
+        const int wofs = r16 * 128, wsw = r16 & 7;
+        const int rr0 = lane >> 3, rc = lane & 7;
+        const int rofs = rr0 * 128 + ((rc ^ rr0) << 4);
+        const int col = p_colq + b * 32 + 4 * rc;     // this lane's four columns of the staged rows
+        const bool col_ok = inner || col < p_N;
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-            const int row = p_m0 + wr * 128 + a * 64 + mi * 16 + r16;
-            if (row >= p_M) continue;
-            float GAS* crow = pC + (int64_t)p8_map_row(row, p_cq, p_cs) * p_ldc;
+        for (int mp = 0; mp < MI; mp += 2) {
 #pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int col = p_n0 + wc * 64 + b * 32 + ni * 16 + 4 * kc;
-                if (col < p_N) {
-                    const f32x4 v = acc[a][b][mi][ni] * p_alpha;
-                    if (nt_store) __builtin_nontemporal_store(v, reinterpret_cast<gf4>(crow + col));
-                    else *reinterpret_cast<gf4>(crow + col) = v;
-                    if (p_sq) ss = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, ss))));
+            for (int u = 0; u < 2; ++u) {
+                const int mi = mp + u;
+                const int row0 = p_m0 + wr * 128 + 16 * (a * MI + mi);
+                const f32x4 x = acc[a][b][mi][0] * p_alpha, y = acc[a][b][mi][1] * p_alpha;
+                {
+                    const f32x4 xx = x * x, yy = y * y;
+                    const float tx = (xx[0] + xx[1]) + (xx[2] + xx[3]), ty = (yy[0] + yy[1]) + (yy[2] + yy[3]);
+                    if (inner) ss += tx + ty;
+                    else if (row0 + r16 < p_M) {      // (rows / columns beyond the problem hold copies of the last row / column)
+                        const int c0 = p_colq + 4 * kc + b * 32;
+                        ss += (c0 < p_N ? tx : 0.f) + (c0 + 16 < p_N ? ty : 0.f);
+                    }
                 }
+#if defined(GHN3_P8W_PROBE) && defined(P8W_X) && P8W_X == 8
+                asm volatile("" :: "v"(x), "v"(y));
+#else
+                *reinterpret_cast<f32x4*>(stg + 2048 * u + wofs + ((kc ^ wsw) << 4)) = x;
+                *reinterpret_cast<f32x4*>(stg + 2048 * u + wofs + (((4 + kc) ^ wsw) << 4)) = y;
+#endif
             }
+            f32x4 v[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) v[u][h] = *reinterpret_cast<const f32x4*>(stg + 2048 * u + rofs + 1024 * h);
+#if defined(GHN3_P8W_PROBE) && defined(P8W_X) && P8W_X == 8
+            // (tools/p8w_probe: 8 = the accumulators themselves in the staged ADDRESS pattern -- wrong data, no LDS round trip)
+            v[0][0] = acc[a][b][mp][0]; v[0][1] = acc[a][b][mp][1]; v[1][0] = acc[a][b][mp + 1][0]; v[1][1] = acc[a][b][mp + 1][1];
+#endif
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const int row = p_m0 + wr * 128 + 16 * (a * MI + mp + u) + rr0 + 8 * h;
+                    if (inner || (col_ok && row < p_M)) {
+                        const int mrow = row + (int)__umulhi((unsigned)row, p_magic) * p_wrap;
+                        float GAS* dst = pC + ((int64_t)mrow * p_ldc + col);
+#if defined(GHN3_P8W_PROBE) && defined(P8W_X)
+                        if (P8W_X == 2) { asm volatile("" :: "v"(v[u][h])); } else     // (tools/p8w_probe: 2 = no store instruction)
+#endif
+                        if (nt_store) __builtin_nontemporal_store(v[u][h], reinterpret_cast<gf4>(dst));
+                        else *reinterpret_cast<gf4>(dst) = v[u][h];
+                    }
+                }
         }
     };
+    auto store_prev = [&](int a, int b) __attribute__((always_inline)) {
+        if (p_inner) store_prev_t(a, b, true); else store_prev_t(a, b, false);
+    };
     auto finish_sq = [&]() {                          // behind the last quadrant's stores of a tile
-        if (!p_sq) return;
         float t = ss;
+        ss = 0.f;
+        if (!p_sq) return;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
         if (lane == 0) p_sq[p_tile * 8 + wave] = t;
-        ss = 0.f;
     };
 #ifdef GHN3_P8W_PROBE
     // tools/p8w_probe.hip: cycles of workgroup 0 / thread 0 per k-tile (first k-tile of a tile = the one that also stores the
     // previous tile), inside the DMA wait of a k-tile, and -- store k-tiles -- inside store_prev / at the barriers
     long long pr_tot[2] = {0, 0}, pr_wait[2] = {0, 0}, pr_cnt[2] = {0, 0}, pr_store = 0, pr_bar = 0;
+    long long pr_ph[20] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, pr_last = 0;
+#define P8W_MARK(i) { if (st) { const long long t_ = P8W_CLK(); pr_ph[i] += t_ - pr_last; pr_last = t_; } }
 #define P8W_CLK() ((long long)__builtin_readcyclecounter())
 #define P8W_ST_T(x) { const long long t_ = P8W_CLK(); x; pr_store += P8W_CLK() - t_; }
 #define P8W_BAR_T() { const long long t_ = P8W_CLK(); __builtin_amdgcn_s_barrier(); if (st) pr_bar += P8W_CLK() - t_; }
 #else
 #define P8W_ST_T(x) x
 #define P8W_BAR_T() __builtin_amdgcn_s_barrier()
+#define P8W_MARK(i)
 #endif
     int G = 0;                                        // k-tiles computed so far (ring parity, half-tile bookkeeping)
     auto wait_next_ktile = [&]() {                    // k-tile G + 1 (half-tiles .. 4 G + 7) has landed; the newer ones stay in flight
@@ -628,29 +690,65 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
         // while it stores, and issues its three half-tiles at its very end; the first counted wait that sees the stores
         // again is the next k-tile's, a whole k-tile later.
         const bool quiet = QUIET && st;
-        if (st && !quiet) P8W_ST_T(store_prev(0, 0));
-        read_b(ring, 0);                              // (first: retired by the counted lgkmcnt below)
-        __builtin_amdgcn_sched_barrier(0);
-        read_a(ring, 0);
-        __builtin_amdgcn_sched_barrier(0);
-        issue(3);
-        if (quiet) { wait_vm<0>(); P8W_ST_T(store_prev(0, 0)); }
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * MI) : "memory");
-        P8W_BAR_T();
+#ifdef GHN3_P8W_PROBE
+        if (st) pr_last = P8W_CLK();
+#endif
+        if (!quiet) {
+            if (st) P8W_ST_T(store_prev(0, 0));
+            read_b(ring, 0);                          // (first: retired by the counted lgkmcnt below)
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(ring, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            issue(3);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * MI) : "memory");
+            P8W_BAR_T();
+        } else {
+            // Round 5b: ALL of the tile's stores in one burst, both wave rows at once (spread over the four phases only one row
+            // stored at a time: 8 x ~2k cycles per tile; tools/p8w_probe phase marks).  Wave row 1 runs one barrier behind row 0, so
+            // row 0 first lets it catch up (one extra barrier), both rows store -- in front of their LDS-DMA: a DMA instruction issued
+            // while stores drain waits for them -- and row 1 then falls back by one barrier again.
+            if (wr == 0) P8W_BAR_T();
+            issue(3);
+            P8W_MARK(0);
+            wait_vm<0>();                             // quiet: everything in flight lands; no DMA is issued until the k-tile's end
+            P8W_MARK(1);
+            P8W_ST_T(store_prev(0, 0); store_prev(0, 1); store_prev(1, 1); store_prev(1, 0); finish_sq());
+            P8W_MARK(2);
+            if (wr == 1) P8W_BAR_T();
+            // (the fragment reads behind the burst: no fragment register is live across it; nothing re-stages this k-tile's
+            // half-tiles before the issues at its end)
+            read_b(ring, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            read_a(ring, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * MI) : "memory");
+            P8W_BAR_T();
+            P8W_MARK(3);
+        }
         mfma_q(0, 0, first);
+        P8W_MARK(4);
         P8W_BAR_T();
-        if (st) P8W_ST_T(store_prev(0, 1));
+        P8W_MARK(5);
+        if (st && !quiet) P8W_ST_T(store_prev(0, 1));
+        P8W_MARK(6);
         read_b(ring, 1);
         if (!quiet) issue(0);
         P8W_BAR_T();
+        P8W_MARK(7);
         mfma_q(0, 1, first);
+        P8W_MARK(8);
         P8W_BAR_T();
-        if (st) P8W_ST_T(store_prev(1, 1));
+        P8W_MARK(9);
+        if (st && !quiet) P8W_ST_T(store_prev(1, 1));
+        P8W_MARK(10);
         read_a(ring, 1);
         if (!quiet) issue(1);
         P8W_BAR_T();
+        P8W_MARK(11);
         mfma_q(1, 1, first);
+        P8W_MARK(12);
         P8W_BAR_T();
+        P8W_MARK(13);
 #ifdef GHN3_P8W_PROBE
         const long long pr_w0 = P8W_CLK();
 #endif
@@ -658,11 +756,15 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
 #ifdef GHN3_P8W_PROBE
         pr_wait[st ? 0 : 1] += P8W_CLK() - pr_w0;
 #endif
-        if (st) { P8W_ST_T(store_prev(1, 0)); finish_sq(); }    // (behind the wait: these stores are not waited for with the DMA)
+        if (st && !quiet) { P8W_ST_T(store_prev(1, 0)); finish_sq(); }    // (behind the wait: these stores are not waited for with the DMA)
+        P8W_MARK(14);
         if (quiet) { issue(0); issue(1); issue(2); }  // (k-tile G + 1 had landed before the stores; these are for G + 2)
         P8W_BAR_T();
+        P8W_MARK(15);
         mfma_q(1, 0, first);
+        P8W_MARK(16);
         P8W_BAR_T();
+        P8W_MARK(17);
         ++G;
 #ifdef GHN3_P8W_PROBE
         pr_tot[st ? 0 : 1] += P8W_CLK() - pr_t0; pr_cnt[st ? 0 : 1] += 1;
@@ -691,6 +793,11 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
             p_sq = (rfl(Q->flags) & GHN3_GEMM_SUMSQ) ? rflp(Q->aux_out) : nullptr;
             p_tile = ct;
             p_valid = true;
+            // (see store_prev_t; all wave-uniform: kept in SGPRs)
+            p_colq = rfl(p_n0 + wc * 64);
+            p_inner = p_m0 + 256 <= p_M && p_n0 + 256 <= p_N;
+            p_magic = (unsigned)rfl((int)(p_cq > 0 ? (unsigned)(4294967296.0 / (double)p_cq) + 1u : 0u));   // (M q < 2^32: checked by the runtime)
+            p_wrap = p_cq > 0 ? p_cs - p_cq : 0;
         }
         ct = next_tile(ct + stride, c_idx, c_m0, c_n0, c_nkt);
     }
@@ -702,10 +809,13 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
         for (int i = 0; i < 2; ++i) { g_p8w_probe[3 * i] = pr_tot[i]; g_p8w_probe[3 * i + 1] = pr_wait[i]; g_p8w_probe[3 * i + 2] = pr_cnt[i]; }
         g_p8w_probe[6] = pr_store; g_p8w_probe[7] = pr_bar;
     }
+    if (blockIdx.x == 0 && (tid == 0 || tid == 256))
+        for (int i = 0; i < 20; ++i) g_p8w_probe[8 + (tid ? 20 : 0) + i] = pr_ph[i];
 #endif
 }
 
 constexpr int kP8Lds = 2 * (2 * 5 * 4096 + 32768);    // MI = 5: 144 KB
+constexpr int kP8wLds = 128 * 1024 + 8 * 4096;         // the weight gradient's ring (MI = 4) + 4 KB of store staging per wave: 160 KB
 
 }  // namespace
 
@@ -718,13 +828,13 @@ int ghn3_gemm_p8_init() {
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)gemm_p8_kernel<GHN3_CT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8Lds);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_F16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_F16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8wLds);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_BF16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_BF16, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8wLds);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_F16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_F16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8wLds);
     if (e == hipSuccess)
-        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_BF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_BF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8wLds);
     if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(p8): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     {
         int dev = 0, n_cu = 0;
@@ -780,16 +890,16 @@ int ghn3_gemm_p8w_launch(const GemmProbDev* d_probs, int n_probs, int total_tile
     // workload, bit-identical results (profiles/r05h_ab_wgrad_quiet_store_ktile.txt); GHN3_P8W_QUIET=0 = the round-4 loop
     static const int quiet = getenv("GHN3_P8W_QUIET") ? atoi(getenv("GHN3_P8W_QUIET")) != 0 : 1;
     if (ctype == GHN3_CT_F16 && quiet)
-        hipLaunchKernelGGL((gemm_p8w_kernel<GHN3_CT_F16, 1>), dim3(grid * chunks), dim3(512), 128 * 1024, stream, d_probs, n_probs,
+        hipLaunchKernelGGL((gemm_p8w_kernel<GHN3_CT_F16, 1>), dim3(grid * chunks), dim3(512), kP8wLds, stream, d_probs, n_probs,
                            total_tiles, grid, tpw_arg);
     else if (ctype == GHN3_CT_F16)
-        hipLaunchKernelGGL((gemm_p8w_kernel<GHN3_CT_F16, 0>), dim3(grid * chunks), dim3(512), 128 * 1024, stream, d_probs, n_probs,
+        hipLaunchKernelGGL((gemm_p8w_kernel<GHN3_CT_F16, 0>), dim3(grid * chunks), dim3(512), kP8wLds, stream, d_probs, n_probs,
                            total_tiles, grid, tpw_arg);
     else if (quiet)
-        hipLaunchKernelGGL((gemm_p8w_kernel<GHN3_CT_BF16, 1>), dim3(grid * chunks), dim3(512), 128 * 1024, stream, d_probs, n_probs,
+        hipLaunchKernelGGL((gemm_p8w_kernel<GHN3_CT_BF16, 1>), dim3(grid * chunks), dim3(512), kP8wLds, stream, d_probs, n_probs,
                            total_tiles, grid, tpw_arg);
     else
-        hipLaunchKernelGGL((gemm_p8w_kernel<GHN3_CT_BF16, 0>), dim3(grid * chunks), dim3(512), 128 * 1024, stream, d_probs, n_probs,
+        hipLaunchKernelGGL((gemm_p8w_kernel<GHN3_CT_BF16, 0>), dim3(grid * chunks), dim3(512), kP8wLds, stream, d_probs, n_probs,
                            total_tiles, grid, tpw_arg);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("p8w gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }

@@ -10,8 +10,8 @@
 #include "../ghn3_amd/csrc/gemm_p8.hip"
 void ghn3_set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vfprintf(stderr, fmt, a); va_end(a); fputc('\n', stderr); }
 
-struct Prob { int M, N, K; };
-static void run(const char* name, const std::vector<Prob>& ps) {
+struct Prob { int M, N, K; int cq = 0, cs = 0; };     // cq, cs: row map of C (r / cq) * cs + r % cq, as the band problems of dW2 have
+static void run(const char* name, const std::vector<Prob>& ps, int cap = 0) {
     std::vector<GemmProbDev> hp(ps.size());
     int tiles = 0;
     double flops = 0;
@@ -20,13 +20,14 @@ static void run(const char* name, const std::vector<Prob>& ps) {
         const Prob& q = ps[i];
         const int ld = (q.K + 63) / 64 * 64;
         unsigned short *A, *B; float* C;
-        hipMalloc(&A, (size_t)q.M * ld * 2 + 4096); hipMalloc(&B, (size_t)q.N * ld * 2 + 4096); hipMalloc(&C, (size_t)q.M * q.N * 4);
+        hipMalloc(&A, (size_t)q.M * ld * 2 + 4096); hipMalloc(&B, (size_t)q.N * ld * 2 + 4096); hipMalloc(&C, (size_t)(q.cq > 0 ? (q.M / q.cq + 1) * q.cs : q.M) * q.N * 4);
         hipMemset(A, 0x11, (size_t)q.M * ld * 2 + 4096); hipMemset(B, 0x12, (size_t)q.N * ld * 2 + 4096);
         frees.push_back(A); frees.push_back(B); frees.push_back(C);
         GemmProbDev& p = hp[i];
         memset(&p, 0, sizeof(p));
         p.A = reinterpret_cast<const float*>(A); p.B = reinterpret_cast<const float*>(B); p.C = C;
         p.M = q.M; p.N = q.N; p.K = q.K; p.lda = ld; p.ldb = ld; p.ldc = q.N; p.alpha = 1.f; p.flags = GHN3_GEMM_OP16;
+        p.c_q = q.cq; p.c_s = q.cs;
         p.tiles_m = (q.M + 255) / 256; p.tiles_n = (q.N + 255) / 256;
         int G = 1;
         while (G < 8 && (long long)q.N * q.K * 2 / G > (5 << 19) && p.tiles_n >= 2 * G) G *= 2;
@@ -37,18 +38,28 @@ static void run(const char* name, const std::vector<Prob>& ps) {
     }
     GemmProbDev* dp; hipMalloc(&dp, sizeof(GemmProbDev) * hp.size());
     hipMemcpy(dp, hp.data(), sizeof(GemmProbDev) * hp.size(), hipMemcpyHostToDevice);
-    for (int rep = 0; rep < 2; ++rep) ghn3_gemm_p8w_launch(dp, (int)hp.size(), tiles, GHN3_CT_F16, 0, 0);
+    for (int rep = 0; rep < 2; ++rep) ghn3_gemm_p8w_launch(dp, (int)hp.size(), tiles, GHN3_CT_F16, cap, 0);
     hipDeviceSynchronize();
-    long long st[8];
+    long long st[48];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_p8w_probe), sizeof(st));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
-    for (int r = 0; r < 5; ++r) ghn3_gemm_p8w_launch(dp, (int)hp.size(), tiles, GHN3_CT_F16, 0, 0);
+    for (int r = 0; r < 5; ++r) ghn3_gemm_p8w_launch(dp, (int)hp.size(), tiles, GHN3_CT_F16, cap, 0);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%-44s %7.3f ms  %6.0f TF | workgroup 0: first k-tiles (+ stores) %lld x %lld cycles (DMA wait %lld), other k-tiles %lld x %lld cycles (DMA wait %lld); per store k-tile: in store_prev %lld, at barriers %lld\n",
            name, ms / 5, flops * 5 / ms * 1e-9, st[2], st[2] ? st[0] / st[2] : 0, st[2] ? st[1] / st[2] : 0, st[5], st[5] ? st[3] / st[5] : 0,
            st[5] ? st[4] / st[5] : 0, st[2] ? st[6] / st[2] : 0, st[2] ? st[7] / st[2] : 0);
+    {   // phases of the k-tile that stores (thread 0 of wave 0 = wave row 0, thread 256 = wave 4 = wave row 1), average cycles
+        static const char* nm[18] = {"reads+issue3", "wait_vm0", "ST00", "bar", "MFMA00", "bar", "ST01", "reads+bar", "MFMA01", "bar", "ST11",
+                                     "reads+bar", "MFMA11", "bar", "ST10", "issue+bar", "MFMA10", "bar"};
+        const long long n = st[2] ? st[2] : 1;
+        for (int w = 0; w < 2; ++w) {
+            printf("      wave %d:", 4 * w);
+            for (int i = 0; i < 18; ++i) printf(" %s %lld", nm[i], st[8 + 20 * w + i] / n);
+            printf("\n");
+        }
+    }
     for (void* f : frees) hipFree(f);
     hipFree(dp);
 }
@@ -61,5 +72,16 @@ int main() {
                       {768, 3072, 1296}, {768, 3072, 1424}, {8192, 3072, 856}, {2048, 3072, 1136}, {1024, 3072, 1168}, {1024, 3072, 1296},
                       {16384, 3072, 792}, {4096, 3072, 1032}, {2048, 3072, 1064}, {2048, 3072, 1176}, {65536, 3072, 536}, {16384, 3072, 664},
                       {8192, 3072, 680}, {8192, 3072, 776}});
+    run("K 1480, M 16384, row map 64 -> 384", {{16384, 3072, 1480, 64, 384}});
+    run("K 1480, M 16384, row map 8 -> 384", {{16384, 3072, 1480, 8, 384}});
+    // fewer workgroups (grid cap): does the k-tile that carries a tile's stores get cheaper when fewer CUs store at the same time?
+    for (int cap : {128, 64, 32, 8}) {
+        char nm[64]; snprintf(nm, sizeof nm, "K 536, M 65536, %d workgroups", cap);
+        run(nm, {{65536, 3072, 536}}, cap);
+    }
+    for (int cap : {128, 64, 32, 8}) {
+        char nm[64]; snprintf(nm, sizeof nm, "K 1480, M 16384, %d workgroups", cap);
+        run(nm, {{16384, 3072, 1480}}, cap);
+    }
     return 0;
 }

@@ -265,9 +265,15 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();        // pairs the extra barrier of wave row 1
 
-    // ---- epilogue: lane = output row (r16 of a 16-row MFMA tile), its 4 registers = columns 4 kc .. 4 kc + 3 (N % 4 == 0:
-    // a lane's four columns are all inside or all outside).  Order: acc * alpha -> + bias -> aux_out -> ReLU -> dReLU(aux_in)
-    // -> + residual -> (+ C) -> store
+    // ---- epilogue (round 5b: staged).  In the accumulator layout -- lane = output row r16 of a 16-row MFMA tile, its 4 registers =
+    // columns 4 kc .. 4 kc + 3 -- a 16-lane pass of a store instruction is 16 ROWS x 16 bytes and the CU's store path takes 72 cycles
+    // per instruction: 18.6k cycles per 256 x 256 tile (tools/store_probe, per workgroup), 13 % of a forward tile.  With 16 adjacent
+    // lanes on the 256 bytes of one row it takes 16.  The ring is free now (every fragment read retired in front of the last
+    // barriers), so each wave re-lays 32 x 64 blocks of its part out through its own 8 KB of it: ds_write_b128 in the accumulator
+    // layout, ds_read_b128 as 4 rows x 256 bytes, 16-byte chunks XOR-swizzled by the row (conflict-free both ways); a wave's LDS
+    // operations execute in order: no barrier.  Everything element-wise happens behind the re-layout, where loads of aux_in /
+    // residual / C and the store of aux_out have the same full-line pattern.  Order: acc * alpha -> + bias -> aux_out -> ReLU ->
+    // dReLU(aux_in) -> + residual -> (+ C) -> store.  N % 4 == 0: a lane's four columns are all inside or all outside.
     {
         const int flags = rfl(P->flags);
         gf C = (gf)rflp(P->C);
@@ -281,39 +287,48 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
         const bool accum = (flags & GHN3_GEMM_ACCUM) != 0;
         const float* amax_p = rflp(P->alpha_amax);
         const float alpha = rflf(amax_p ? P->alpha * ghn3_pow2_inv_scale(*amax_p) : P->alpha);
-        const int col0 = n0 + wc * 64 + 4 * kc;       // + 32 b + 16 ni
-        f32x4 bv[2][2];
+        // row map (r / cq) * cs + r % cq = r + (r / cq) (cs - cq), the quotient from one multiply-high (M cq < 2^32: runtime check)
+        const unsigned magic = (unsigned)rfl((int)(cq > 0 ? (unsigned)(4294967296.0 / (double)cq) + 1u : 0u));
+        const int wrap = cq > 0 ? cs - cq : 0;
+        char* stg = sm + wave * 8192;
+        const int wofs = r16 * 256, wsw = r16 & 7;
+        const int rr0 = lane >> 4, rc = lane & 15;                    // staged image: this lane reads rows rr0 + 4 pass, chunk rc
+        const int col = n0 + wc * 64 + 4 * rc;
+        const bool col_ok = col < N;
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (bias && col_ok) {
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int ni = 0; ni < 2; ++ni) {
-                const int col = col0 + b * 32 + ni * 16;
-                f32x4 v = {0.f, 0.f, 0.f, 0.f};
-                if (bias && col < N) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        int bi = col + e;
-                        if (bias_q > 0) bi = (bi / bias_q) * bias_s + (bi % bias_q);
-                        v[e] = bias[(int64_t)bi * bias_stride];
-                    }
-                }
-                bv[b][ni] = v;
+            for (int e = 0; e < 4; ++e) {
+                int bi = col + e;
+                if (bias_q > 0) bi = (bi / bias_q) * bias_s + (bi % bias_q);
+                bv[e] = bias[(int64_t)bi * bias_stride];
             }
+        }
 #pragma unroll
         for (int a = 0; a < 2; ++a)
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) {
-                const int row = m0 + wr * (BM / 2) + a * 16 * MI + mi * 16 + r16;
-                if (row >= M) continue;
-                const int64_t rbase = (int64_t)p8_map_row(row, cq, cs) * ldc;
+            for (int mp = 0; mp < MI; mp += 2) {
+                const int nu = (mp + 1 < MI) ? 2 : 1;                 // blocks of 16 rows in this round trip (compile-time after unrolling)
 #pragma unroll
-                for (int b = 0; b < 2; ++b)
+                for (int u = 0; u < 2; ++u) {
+                    if (u >= nu) continue;
 #pragma unroll
-                    for (int ni = 0; ni < 2; ++ni) {
-                        const int col = col0 + b * 32 + ni * 16;
-                        if (col >= N) continue;
-                        const int64_t ci = rbase + col;
-                        f32x4 v = acc[a][b][mi][ni] * alpha + bv[b][ni];
+                    for (int b = 0; b < 2; ++b)
+#pragma unroll
+                        for (int ni = 0; ni < 2; ++ni)
+                            *reinterpret_cast<f32x4*>(stg + u * 4096 + wofs + (((8 * b + 4 * ni + kc) ^ wsw) << 4)) = acc[a][b][mp + u][ni] * alpha;
+                }
+                const int row0 = m0 + wr * (BM / 2) + 16 * (a * MI + mp);
+#pragma unroll
+                for (int ps = 0; ps < 8; ++ps) {
+                    if (ps >= 4 * nu) continue;
+                    const int rl = rr0 + 4 * ps;                      // row of the staged image (0 .. 16 nu - 1)
+                    f32x4 v = *reinterpret_cast<const f32x4*>(stg + rl * 256 + ((rc ^ (rl & 7)) << 4));
+                    const int row = row0 + rl;
+                    if (row < M && col_ok) {
+                        const int mrow = row + (int)__umulhi((unsigned)row, magic) * wrap;
+                        const int64_t ci = (int64_t)mrow * ldc + col;
+                        v += bv;
                         if (aux_out) *reinterpret_cast<gf4>(aux_out + ci) = v;
                         if (act_relu) {
 #pragma unroll
@@ -328,6 +343,7 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
                         if (accum) v += *reinterpret_cast<gcf4>(C + ci);
                         *reinterpret_cast<gf4>(C + ci) = v;
                     }
+                }
             }
     }
 }

@@ -377,9 +377,9 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                 ghn3_set_error("op %d problem %d: tile 29 needs N %% 4 == 0, K >= 1 and operands below 4 GB", k, q);
                                 return GHN3_E_ARG;
                             }
-                            // (the kernel takes the quotient of the row map of C from one 32-bit multiply-high: exact while M q < 2^32)
-                            if (tl == 29 && p.c_q > 0 && (int64_t)p.M * p.c_q >= ((int64_t)1 << 32)) {
-                                ghn3_set_error("op %d problem %d: tile 29 needs rows x row-map period below 2^32", k, q);
+                            // (the 8-phase kernels take the quotient of the row map of C from one 32-bit multiply-high: exact while M q < 2^32)
+                            if ((tl == 28 || tl == 29) && p.c_q > 0 && (int64_t)p.M * p.c_q >= ((int64_t)1 << 32)) {
+                                ghn3_set_error("op %d problem %d: tiles 28 / 29 need rows x row-map period below 2^32", k, q);
                                 return GHN3_E_ARG;
                             }
                             if (tl == 28) {

@@ -254,6 +254,8 @@ enum ghn3_op_kind {
      * no split-K / gathers (problems of the op with fewer than 160 rows or with ksplit > 1 fall back to 16) for
      * GHN3_GEMM_OP16 problems), grid cap for GHN3_GEMM_OP16 launches (0 = one workgroup per tile; > 0: at most
      * that many CUs' worth of persistent workgroups -- a side-stream GEMM that should leave CUs to the chain it runs beside).
+     * Tile codes 28 / 29 take the quotient of the row map of C (c_q, c_s) from one 32-bit multiply-high: M * c_q < 2^32, else
+     * GHN3_E_ARG.  29 = the persistent 8-phase kernel for the W2 weight gradient (plain problems like 25; GHN3_GEMM_SUMSQ).
      * fp32 operands additionally: 48 = the split-bf16 weight-gradient kernel (both operands GHN3_MODE_COL fp32 activations,
      * reduction over rows: dW = dY^T X of the Graphormer linears, graphormer.py:208-248 backward; GHN3_GEMM_ACCUM and
      * GHN3_GEMM_BIASGRAD allowed, M % 4 == 0, N % 4 == 0, no gathers / maps / activation / residual / split-K -- problems of

@@ -248,8 +248,9 @@ class Program:
             # the dependent chain and no longer share the chip with it (fc dgrad 0.39 -> 0.1 ms); the weight gradient then
             # runs beside the Graphormer backward only, which is long enough to hide it (GHN3_WGRAD_LATE=0: early order).
             # Round 5b, GHN3_WGRAD_ORDER=first (default when the weight gradient runs on the side stream): issued right behind the
-            # tile backward and its operand copies, on 128 workgroups -- half of every XCD -- it runs beside the W2 dgrad (both
-            # MFMA-bound: the chip's work is conserved), the conv.0 / fc backward and only the first layers of the Graphormer
+            # tile backward and its operand copies, on 128 workgroups -- half of every XCD.  The lowest-priority stream gets its CUs
+            # when the W2 dgrad has handed out its last tiles (forcing the launch beside the dgrad gains nothing: two MFMA-bound
+            # kernels share the chip's work), so it runs beside the conv.0 / fc backward and only the first third of the Graphormer
             # backward, which is the part of the step that suffers beside it (tools/contention_probe: a streaming kernel on the
             # other CUs turns the chain's L2 hits into 350 ns misses and costs 8-15 % of the clock).  5.85-5.86 against 5.91-5.93
             # ms (one graph), 9.65-9.83 against 10.03-10.12 (two), 15.76-15.80 against 16.28-16.35 (four); 112 / 144 / 160

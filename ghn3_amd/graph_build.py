@@ -370,17 +370,42 @@ class _MetaAffine(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b):
-        return torch.empty_like(x)
+        return torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)   # (empty_like is a Python reference on meta)
 
     @staticmethod
     def backward(ctx, g):                                   # pragma: no cover  (the traced graph is never differentiated)
         raise RuntimeError('structure-only trace')
 
 
+def _meta_unary(op_name):
+    """Structure-only stand-in for a unary activation on the meta device: an autograd function `<op_name>` whose node is named
+    `<op_name>Backward` like the native one (`ReluBackward0` ...; the walk and the pruning rules only look at the part in front of
+    'Backward').  torch's meta path of these ops is a Python reference implementation: 0.5-3 ms per call (relu 0.5-1.3, gelu 1.1,
+    hardtanh / relu6 2.0, hardsigmoid 2.4, hardswish 3.2) -- 49 ReLUs are 60 % of Graph(ResNet-50)."""
+    def forward(ctx, x):
+        return torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)   # (empty_like is a Python reference on meta)
+
+    def backward(ctx, g):                                   # pragma: no cover  (the traced graph is never differentiated)
+        raise RuntimeError('structure-only trace')
+    return type(op_name, (torch.autograd.Function,), {'forward': staticmethod(forward), 'backward': staticmethod(backward)})
+
+
+_META_UNARY = {'relu': _meta_unary('Relu'), 'gelu': _meta_unary('Gelu'), 'hardswish': _meta_unary('Hardswish'),
+               'hardtanh': _meta_unary('Hardtanh'), 'relu6': _meta_unary('Hardtanh'), 'hardsigmoid': _meta_unary('Hardsigmoid'),
+               'leaky_relu': _meta_unary('LeakyRelu'), 'elu': _meta_unary('Elu')}
+
+
 class _cheap_meta_norms:
     def __enter__(self):
         F = torch.nn.functional
         self.saved = (F.batch_norm, F.layer_norm)
+        self.saved_unary = {k: getattr(F, k) for k in _META_UNARY}
+        for k, fn_cls in _META_UNARY.items():
+            def unary(input, *a, _f0=self.saved_unary[k], _cls=fn_cls, **kw):
+                if isinstance(input, torch.Tensor) and input.device.type == 'meta' and input.requires_grad:
+                    return _cls.apply(input)
+                return _f0(input, *a, **kw)
+            setattr(F, k, unary)
         bn0, ln0 = self.saved
 
         def batch_norm(input, running_mean, running_var, weight=None, bias=None, *a, **k):
@@ -397,6 +422,8 @@ class _cheap_meta_norms:
 
     def __exit__(self, *exc):
         torch.nn.functional.batch_norm, torch.nn.functional.layer_norm = self.saved
+        for k, f0 in self.saved_unary.items():
+            setattr(torch.nn.functional, k, f0)
         return False
 
 

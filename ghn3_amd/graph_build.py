@@ -16,6 +16,7 @@ Third-party classes (torchvision, ppuda) are recognised by class name along the 
 
 import copy
 import os
+import threading
 
 import numpy as np
 import torch
@@ -414,12 +415,22 @@ _MetaAdd = _meta_add_cls()
 
 
 class _cheap_meta_norms:
-    def __enter__(self):
-        F = torch.nn.functional
-        self.saved = (F.batch_norm, F.layer_norm)
-        T = torch.Tensor
-        self.saved_add = (T.__add__, T.__radd__, T.__iadd__, T.add, T.add_, torch.add)
-        add0 = self.saved_add
+    """Context of the meta trace: torch.nn.functional / torch.Tensor entry points whose meta path is a Python reference are
+    replaced by the structure-only stand-ins above; every replacement hands anything that is not a meta tensor carrying the
+    trace straight to the original.  Process-wide patches, so: one lock, a depth counter, originals saved by the FIRST entry and
+    restored by the LAST exit (two threads that trace at the same time -- loader threads do -- would otherwise save each other's
+    wrappers as 'originals')."""
+    _lock = threading.RLock()
+    _depth = 0
+    _saved = None
+
+    @classmethod
+    def _patch(cls):
+        F, T = torch.nn.functional, torch.Tensor
+        saved = {'bn': F.batch_norm, 'ln': F.layer_norm,
+                 'add': (T.__add__, T.__radd__, T.__iadd__, T.add, T.add_, torch.add),
+                 'unary': {k: getattr(F, k) for k in _META_UNARY}}
+        add0 = saved['add']
 
         def meta_pair(a, b, kw):
             return (not kw and isinstance(a, T) and isinstance(b, T) and a.device.type == 'meta' and b.device.type == 'meta' and
@@ -434,14 +445,13 @@ class _cheap_meta_norms:
         T.__add__, T.__iadd__, T.add, T.add_ = mk(add0[0]), mk(add0[2]), mk(add0[3]), mk(add0[4])
         T.__radd__ = lambda a, b, _o=add0[1]: _MetaAdd.apply(b, a) if meta_pair(b, a, None) else _o(a, b)
         torch.add = mk(add0[5])
-        self.saved_unary = {k: getattr(F, k) for k in _META_UNARY}
         for k, fn_cls in _META_UNARY.items():
-            def unary(input, *a, _f0=self.saved_unary[k], _cls=fn_cls, **kw):
+            def unary(input, *a, _f0=saved['unary'][k], _cls=fn_cls, **kw):
                 if isinstance(input, torch.Tensor) and input.device.type == 'meta' and input.requires_grad:
                     return _cls.apply(input)
                 return _f0(input, *a, **kw)
             setattr(F, k, unary)
-        bn0, ln0 = self.saved
+        bn0, ln0 = saved['bn'], saved['ln']
 
         def batch_norm(input, running_mean, running_var, weight=None, bias=None, *a, **k):
             if input.device.type == 'meta' and weight is not None and bias is not None:
@@ -453,14 +463,31 @@ class _cheap_meta_norms:
                 return _MetaAffine.apply(input, weight, bias)
             return ln0(input, normalized_shape, weight, bias, *a, **k)
         F.batch_norm, F.layer_norm = batch_norm, layer_norm
+        return saved
+
+    @classmethod
+    def _unpatch(cls, saved):
+        F, T = torch.nn.functional, torch.Tensor
+        F.batch_norm, F.layer_norm = saved['bn'], saved['ln']
+        for k, f0 in saved['unary'].items():
+            setattr(F, k, f0)
+        T.__add__, T.__radd__, T.__iadd__, T.add, T.add_, torch.add = saved['add']
+
+    def __enter__(self):
+        c = _cheap_meta_norms
+        with c._lock:
+            if c._depth == 0:
+                c._saved = c._patch()
+            c._depth += 1
         return self
 
     def __exit__(self, *exc):
-        torch.nn.functional.batch_norm, torch.nn.functional.layer_norm = self.saved
-        for k, f0 in self.saved_unary.items():
-            setattr(torch.nn.functional, k, f0)
-        T = torch.Tensor
-        T.__add__, T.__radd__, T.__iadd__, T.add, T.add_, torch.add = self.saved_add
+        c = _cheap_meta_norms
+        with c._lock:
+            c._depth -= 1
+            if c._depth == 0:
+                c._unpatch(c._saved)
+                c._saved = None
         return False
 
 

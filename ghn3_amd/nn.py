@@ -737,6 +737,7 @@ class GHN3(nn.Module):
                 pos = p['offset'] + p['numel']
             sizes.append(flat.numel() - pos)
             pieces = flat.split_with_sizes(sizes)
+        own = []                                             # eval: (parameter, view of the flat buffer) pairs, copied in one batch
         for k, p in enumerate(preds):
             t = (pieces[2 * k + 1] if pieces is not None else flat[p['offset']:p['offset'] + p['numel']]).view(p['shape'])
             m, key = p['module'], p['attr']
@@ -750,7 +751,15 @@ class GHN3(nn.Module):
             else:
                 # eval (nn.py:545-548): `target_param.data = tensor.clone()` -- no memory shared with the flat
                 # batch buffer, so a saved / pickled network carries its own parameters only
-                target.data = t.clone()
+                own.append((target, t))
+        if own:
+            # (one multi-tensor copy instead of a clone kernel per tensor: 161 launches for a ResNet-50, ~1 ms of the 5.7 ms that
+            # ghn(model, graph) takes end to end)
+            srcs = [t for _, t in own]
+            dsts = [torch.empty_like(t) for t in srcs]
+            torch._foreach_copy_(dsts, srcs)
+            for (target, _), d in zip(own, dsts):
+                target.data = d
 
 
 # What each architecture argument can be read from in a bare state dict (checkpoints without a 'config' entry,

@@ -563,3 +563,39 @@ def test_direct_16bit_tile_gradient_route(case):
         x, y = a[offs[k]:offs[k + 1]].astype(np.float64), b[offs[k]:offs[k + 1]].astype(np.float64)
         tol = 1e-3 if name == 'decoder.conv.2.bias' else 2e-6
         assert np.linalg.norm(x - y) <= tol * np.linalg.norm(x) + 1e-9, (name, np.linalg.norm(x - y), np.linalg.norm(x))
+
+
+def test_weight_gradient_schedule_of_the_bench_workload(monkeypatch):
+    """Program._wgrad_schedule at ghn3xlm16 (the bench workload's shape, compiled on the CPU): the side stream with 128 workgroups
+    and the order 'first' for 1 / 2 graphs of 256 nodes (profiles/r05s_ab_wgrad_first_order.txt); GHN3_WGRAD_ORDER=late brings the
+    round-5a model back (a multiple of 8 between 64 and 224); a small model keeps the weight gradient on the chain's stream."""
+    import bench
+    from ghn3_amd import GHN3
+    from ghn3_amd.synthetic import synthetic_batch
+    for v in ('GHN3_WGRAD_ORDER', 'GHN3_WGRAD_CAP', 'GHN3_WGRAD_MAIN', 'GHN3_WGRAD_LATE'):
+        monkeypatch.delenv(v, raising=False)
+
+    def compile_(name, nodes, **env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        hip = GHN3(**bench.model_cfg(name), compute='f16')
+        gb, nets = synthetic_batch(nodes, 256000)
+        gb._cat()
+        cfg = dict(hid=hip.hid, heads=hip.heads, layers=hip.layers, num_classes=hip.num_classes, max_shape=hip.max_shape)
+        prog = Program(cfg, gb.node_info, gb.host_n_nodes(), gb._node_type_host, gb.max_edge, nets, index_mode=hip.index_mode,
+                       training=True, **{k: v for k, v in hip.program_config().items() if k not in ('cfg', 'index_mode')})
+        for k in env:
+            monkeypatch.delenv(k, raising=False)
+        return prog
+    for nodes in ([256], [256, 256]):
+        prog = compile_('ghn3xlm16', nodes)
+        assert (prog.wgrad_order, prog.wgrad_cap) == ('first', 128), (nodes, prog.wgrad_order, prog.wgrad_cap)
+        tag = lambda o: (int(o['flags']) >> 16) & 0xff
+        w = [k for k, o in enumerate(prog.bwd_ops) if int(o['kind']) == L.OP_GEMM and tag(o) == prog.TAG_D3_WGRAD]
+        d = [k for k, o in enumerate(prog.bwd_ops) if int(o['kind']) == L.OP_GEMM and tag(o) == prog.TAG_D3_DGRAD]
+        assert prog.tile_bwd_op < min(w) < min(d)
+        assert int(prog.bwd_ops[min(w)]['flags']) & L.OPFLAG_SIDE and (int(prog.bwd_ops[min(w)]['i'][3]) & 0xffff) == 128
+    late = compile_('ghn3xlm16', [256], GHN3_WGRAD_ORDER='late')
+    assert late.wgrad_order == 'late' and 64 <= late.wgrad_cap <= 224 and late.wgrad_cap % 8 == 0
+    small = compile_('ghn3tm8', [64])
+    assert small.wgrad_cap == 0 and small.wgrad_order != 'first'

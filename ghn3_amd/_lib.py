@@ -12,7 +12,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, 'lib', 'libghn3_hip.so')
-ABI_VERSION = 18
+ABI_VERSION = 19
 
 # ---- numpy mirrors of the C structs -------------------------------------------------------------
 REF_DT = np.dtype([('buf', '<i4'), ('_pad', '<i4'), ('off', '<i8')])
@@ -68,7 +68,7 @@ OP_NAMES = ['nop', 'gemm', 'graph_prologue', 'embed_nodes', 'edge_hidden', 'bias
             'rank_reduce', 'transpose32', 'param_norm_fin', 'ln_param_grad_batch', 'adamw_cast16']
 
 EXPORTS = ['ghn3_abi_version', 'ghn3_last_error', 'ghn3_ctx_create', 'ghn3_ctx_destroy',
-           'ghn3_ctx_set_compute_type', 'ghn3_ctx_side_wait', 'ghn3_run', 'ghn3_event_create', 'ghn3_event_record',
+           'ghn3_ctx_set_compute_type', 'ghn3_ctx_side_wait', 'ghn3_ctx_side_pending', 'ghn3_run', 'ghn3_event_create', 'ghn3_event_record',
            'ghn3_event_elapsed_ms', 'ghn3_event_destroy', 'ghn3_profile_enable', 'ghn3_profile_read',
            'ghn3_profile_read_tags', 'ghn3_dwpw_scratch_floats', 'ghn3_dwpw_bn_fwd', 'ghn3_dwpw_bn_bwd']
 OPFLAG_TIMED = 0x100
@@ -99,6 +99,7 @@ def load():
         lib.ghn3_ctx_destroy.restype = None
         lib.ghn3_ctx_set_compute_type.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.ghn3_ctx_side_wait.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+        lib.ghn3_ctx_side_pending.argtypes = [ctypes.c_void_p]
         lib.ghn3_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                  ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         lib.ghn3_event_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
@@ -147,6 +148,10 @@ class Context:
     def side_wait(self, stream):
         """Make `stream` (a hipStream_t as int) wait for the side-stream work issued so far."""
         _check(self._lib.ghn3_ctx_side_wait(self._h, ctypes.c_void_p(stream)), 'ghn3_ctx_side_wait')
+
+    def side_pending(self):
+        """True when a DETACHed run's side-stream work has not been joined by a later run yet."""
+        return self._lib.ghn3_ctx_side_pending(self._h) == 1
 
     def profile(self, mode):
         """0 off, 1 every op (synchronising), 2 only ops flagged OPFLAG_TIMED (no sync until read_tags)."""

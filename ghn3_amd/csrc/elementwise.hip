@@ -1695,7 +1695,12 @@ int ghn3_transpose32(float* dst, const float* src, int rows, int cols, int ld_sr
 // segments) and / or transposed through LDS (128-byte column segments); source elements outside rows x cols read as
 // zero, which produces the zero K padding the GEMM relies on.  The optional column sum (fp32) is the bias gradient.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned short cast_f16(float x) { return __builtin_bit_cast(unsigned short, (_Float16)x); }
+// (saturating: a 16-bit operand copy never holds an infinity the fp32 source did not -- |x| > 65504, e.g. a loaded weight >= 1024
+//  behind the 2^6 shift of GHN3_CAST_SPLIT_F16, becomes +-65504 and the lo piece x - hi stays finite; NaN stays NaN)
+__device__ __forceinline__ unsigned short cast_f16(float x) {
+    const float c = x != x ? x : __builtin_amdgcn_fmed3f(x, -65504.f, 65504.f);
+    return __builtin_bit_cast(unsigned short, (_Float16)c);
+}
 __device__ __forceinline__ unsigned short cast_bf16(float x) {
     unsigned u = __builtin_bit_cast(unsigned, x);
     u += 0x7fffu + ((u >> 16) & 1u);              // round to nearest even (finite inputs)

@@ -60,13 +60,17 @@ __device__ __forceinline__ void split8(const f32x4& a, const f32x4& b, bf16x8& h
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 // the same split into F16 pieces (GHN3_GEMM_X3F16: 11 + 11 bits of mantissa, O(1) operands only), as raw 16-bit patterns
 __device__ __forceinline__ void split8_f16(const f32x4& a, const f32x4& b, bf16x8& h, bf16x8& l) {
+    // |x| > 65504 would become inf and the lo piece x - inf a NaN where the bf16-piece and fp32 paths (and the reference) stay
+    // finite: both pieces saturate at the largest f16 (v_med3_f32); a NaN input stays NaN through the hi piece.
     f16x8 hh, ll;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-        const _Float16 ah = (_Float16)a[e], bh = (_Float16)b[e];
+        const float ae = a[e] != a[e] ? a[e] : __builtin_amdgcn_fmed3f(a[e], -65504.f, 65504.f);
+        const float be = b[e] != b[e] ? b[e] : __builtin_amdgcn_fmed3f(b[e], -65504.f, 65504.f);
+        const _Float16 ah = (_Float16)ae, bh = (_Float16)be;
         hh[e] = ah; hh[4 + e] = bh;
-        ll[e] = (_Float16)(a[e] - (float)ah);
-        ll[4 + e] = (_Float16)(b[e] - (float)bh);
+        ll[e] = (_Float16)__builtin_amdgcn_fmed3f(a[e] - (float)ah, -65504.f, 65504.f);
+        ll[4 + e] = (_Float16)__builtin_amdgcn_fmed3f(b[e] - (float)bh, -65504.f, 65504.f);
     }
     h = __builtin_bit_cast(bf16x8, hh);
     l = __builtin_bit_cast(bf16x8, ll);

@@ -581,6 +581,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             continue;
         }
         if (o.kind == GHN3_OP_DETACH) { detach = true; continue; }
+        if (o.kind == GHN3_OP_NOP) continue;             // (padding of a fixed-size op list: a DETACH in front of it still ends the run)
         detach = false;
         if (on_side) {
             if (main_dirty) {
@@ -864,6 +865,11 @@ extern "C" int ghn3_ctx_side_wait(ghn3_ctx* c, void* stream) {
     HIPCHK(hipEventRecord(c->ev_join, c->side));
     HIPCHK(hipStreamWaitEvent((hipStream_t)stream, c->ev_join, 0));
     return GHN3_OK;
+}
+
+extern "C" int ghn3_ctx_side_pending(ghn3_ctx* c) {
+    if (!c) return -1;
+    return c->side_pending ? 1 : 0;
 }
 
 // ---- timing helpers -----------------------------------------------------------------------------

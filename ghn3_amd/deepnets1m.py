@@ -163,10 +163,21 @@ class DeepNets1MDDP(SampledNets, torch.utils.data.Dataset):
         if nets_dir is not None:
             from .deepnets1m_io import NetStore
             store = NetStore(nets_dir, split)
-            if not store.exists() and nets_dir != './data':     # deepnets1m.py:38-46: fall back to a local ./data folder
+            why = store.partial()
+            if not store.exists() and not why and nets_dir != './data':   # deepnets1m.py:38-46: fall back to a local ./data folder
                 store = NetStore('./data', split)
+                why = store.partial()
+            if why:
+                raise FileNotFoundError('DeepNets-1M split %r cannot be read: %s' % (split, why))
             if store.exists():
                 self.store = store
+            else:
+                import warnings
+                warnings.warn('no DeepNets-1M files for split %r under %r: using the sampled architecture stream of the same '
+                              'search space (SampledNets), NOT the dataset' % (split, nets_dir))
+            if self.store is None and arch is not None:
+                raise FileNotFoundError('arch=%r selects a stored DeepNets-1M network, but no dataset files were found under %r'
+                                        % (arch, nets_dir))
         if self.store is not None:
             nets, self.primitives_ext, self.op_names_net = self.store.load_meta()
             self.nets = nets[:len(nets) if num_nets is None else num_nets]

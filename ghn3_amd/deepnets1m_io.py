@@ -58,6 +58,20 @@ class NetStore:
         return os.path.exists(self.meta_file) and (os.path.exists(self.npz_file) or
                                                    (h5py is not None and os.path.exists(self.h5_file)))
 
+    def partial(self):
+        """Why a directory that holds SOME of the split's files cannot be read (None when nothing of the split is there, or
+        when the store is complete): a user who points `nets_dir` at DeepNets-1M must not silently train / evaluate on the
+        sampled stand-in stream -- the reference raises when it cannot open its files (deepnets1m.py:38-46,90-91)."""
+        have = [f for f in (self.h5_file, self.npz_file, self.meta_file) if os.path.exists(f)]
+        if not have or self.exists():
+            return None
+        if not os.path.exists(self.meta_file):
+            return '%s is missing (found %s)' % (self.meta_file, ', '.join(have))
+        if os.path.exists(self.h5_file) and h5py is None:
+            return ('%s is there but h5py is not installed: install h5py or convert the file to %s '
+                    '(ghn3_amd.deepnets1m_io.Writer)' % (self.h5_file, self.npz_file))
+        return 'neither %s nor %s exists (found %s)' % (self.h5_file, self.npz_file, ', '.join(have))
+
     def load_meta(self):
         with open(self.meta_file) as fh:
             meta = json.load(fh)[self.split]

@@ -94,6 +94,9 @@ class FusedAdamW:
         ghn = self.ghn
         flat = ghn._flat
         assert gflat.numel() == flat.numel() and gflat.is_cuda
+        # a previous overlapped step may still be reading `scal` and writing the decoder ranges on the side stream (two steps
+        # without a GHN3 forward in between: gradient accumulation, a timing loop): order this step behind it
+        self.wait()
         self.steps += 1
         n = flat.numel()
         clip = self.max_grad_norm and self.max_grad_norm > 0
@@ -151,7 +154,10 @@ class FusedAdamW:
             for k in (4, 5, 6):
                 if int(ops[k]['kind']) != L.OP_NOP:
                     ops[k]['flags'] |= L.OPFLAG_SIDE
-            ops[7]['kind'] = L.OP_DETACH
+            # DETACH must END the run: the runtime ignores GHN3_OP_NOP padding behind it, but nothing else may follow
+            # (round 6: it sat at ops[7] of 9 with a NOP behind it and the runtime re-armed the final join -- the
+            # "overlapped" step of round 5 was serialised)
+            ops[-1]['kind'] = L.OP_DETACH
             self._side_busy = True
             self._keep = gflat                   # (read by the side stream after this call returns)
         elif fuse is None:
@@ -176,6 +182,7 @@ class FusedAdamW:
         trainer hands to its optimizer, trainer.py:165-175), so that ``{'state_dict', 'optimizer', 'epoch', 'step'}``
         checkpoints written by either trainer resume in the other.  The moment tensors are views of the flat buffers."""
         ghn = self.ghn
+        self.wait()                               # (an overlapped step may still be writing the moments)
         slot_of = {id(p): k for k, p in enumerate(ghn._slot_params())}
         state, order = {}, []
         for i, p in enumerate(ghn.parameters()):
@@ -194,6 +201,7 @@ class FusedAdamW:
     def load_state_dict(self, sd):
         """Accepts a ``torch.optim.AdamW`` (or FusedAdamW) state dict over ``ghn.parameters()``."""
         ghn = self.ghn
+        self.wait()
         groups = sd['param_groups']
         assert len(groups) == 1, 'one parameter group expected (trainer.py:175)'
         g = groups[0]

@@ -165,11 +165,16 @@ def _update_running_stats(bn, stats, out, has_run):
         with torch.no_grad():
             C = bn.weight.numel()
             n = out.numel() // C
-            mom = bn.momentum if bn.momentum is not None else 0.1
+            # torch.nn.modules.batchnorm._BatchNorm.forward: the counter moves first; momentum=None = cumulative average
+            nbt = getattr(bn, 'num_batches_tracked', None)
+            if nbt is not None:
+                nbt += 1
+            if bn.momentum is not None:
+                mom = float(bn.momentum)
+            else:
+                mom = 1.0 / float(nbt) if nbt is not None else 0.1
             bn.running_mean.mul_(1 - mom).add_(stats[:C], alpha=mom)
             bn.running_var.mul_(1 - mom).add_(stats[2 * C:] * (n / max(n - 1, 1)), alpha=mom)
-            if getattr(bn, 'num_batches_tracked', None) is not None:
-                bn.num_batches_tracked += 1
 
 
 def reference(x, w_dw, w_pw, gamma, beta, stride=1, padding=0, dilation=1, eps=1e-5):
@@ -198,6 +203,9 @@ def run_block(layers, x, keep_layout=False):
         hasattr(dw, 'kernel_size') and dw.kernel_size[0] == dw.kernel_size[1] and dw.stride[0] == dw.stride[1] and \
         not isinstance(dw.padding, str) and dw.padding[0] == dw.padding[1] and dw.dilation[0] == dw.dilation[1] and \
         getattr(dw, 'groups', 1) == x.shape[1] and tuple(pw.kernel_size) == (1, 1) and \
+        tuple(getattr(pw, 'stride', (1, 1))) == (1, 1) and not isinstance(getattr(pw, 'padding', 0), str) and \
+        tuple(getattr(pw, 'padding', (0, 0))) == (0, 0) and getattr(pw, 'groups', 1) == 1 and \
+        tuple(getattr(pw, 'dilation', (1, 1))) == (1, 1) and \
         DwPwBn.applicable(x, w_dw, w_pw, gamma, beta, ks, batch_stats)
     if not ok:
         for m in layers:

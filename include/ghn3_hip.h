@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define GHN3_ABI_VERSION 18
+#define GHN3_ABI_VERSION 19
 
 /* ---- error codes -------------------------------------------------------------------------------- */
 #define GHN3_OK            0
@@ -367,7 +367,7 @@ enum ghn3_op_kind {
      * them, a wait without a pending mark is a no-op.  A run without side-stream ops / JOIN / DETACH leaves the side-stream
      * state of the context untouched.  (ABI v14) */
     GHN3_OP_JOIN = 24,
-    /* as the LAST op of a run: return without joining the side stream; the pending side work is joined by the next
+    /* as the LAST op of a run (GHN3_OP_NOP padding behind it does not count): return without joining the side stream; the pending side work is joined by the next
      * ghn3_run on the context (or observed with ghn3_ctx_side_wait).  Lets a caller split a program in two runs and
      * start the gradient all-reduce of the first part's weight gradients while the second part executes. */
     GHN3_OP_DETACH = 25,
@@ -469,6 +469,11 @@ int ghn3_run(ghn3_ctx* ctx, const ghn3_op* ops, int n_ops,
 /* Make `stream` wait for everything issued so far on the context's side stream (GHN3_OPFLAG_SIDE ops), e.g. the
  * communication stream that all-reduces weight gradients produced there. */
 int ghn3_ctx_side_wait(ghn3_ctx* ctx, void* stream);
+
+/* 1 when the last run that used the side stream ended in GHN3_OP_DETACH and no later run has joined it yet (its
+ * side-stream work may still be executing), 0 otherwise, < 0 without a context.  (ABI v19; lets a caller -- and the tests
+ * of FusedAdamW.step(overlap=True), optim.py -- verify that a run really returned detached.) */
+int ghn3_ctx_side_pending(ghn3_ctx* ctx);
 
 /* Timing helper for bench.py: HIP events on `stream` (torch.cuda.Event only sees torch's current stream).
  * ghn3_event_elapsed_ms synchronises on the stop event. */

@@ -555,13 +555,18 @@ def x3_setup(W, dev='cuda', frag=False, f16=False):
 
 
 def run_x3_case(ctx, M, N, K, transposed=False, tile=40, ksplit=1, slice_=0, epilogue='none', seed=0, dev='cuda', ln=0,
-                ln_res=True, f16=False):
+                ln_res=True, f16=False, big=False):
     """C = A W^T (W [N][K]) or, transposed, C = A W (W [K][N]).  Returns [(got, expected)].
     ln = 1 / 2 (tile codes 44 / 45, gemm_x3d.hip): the LayerNorm forward / backward row prologue of A
     (ghn3_gemm_problem::ln_kind); the by-products (normalised rows, mean, rstd / the propagated gradient) are returned too."""
     rs = np.random.RandomState(seed)
     A = rs.standard_normal((M, K)).astype(np.float32)
     W = (rs.standard_normal((K, N) if transposed else (N, K)) * 0.05).astype(np.float32)
+    if big:
+        # out-of-range operands of the f16-piece path (|activation| > 65504, |W| * 2^6 > 65504): row 1 of A and one weight;
+        # the kernel saturates the pieces -- results of that row / column are finite, everything else is unaffected
+        A[1] *= 1e6
+        W[3, 5] = 2000.0
     bias = rs.standard_normal(N).astype(np.float32)
     resid = rs.standard_normal((M, N)).astype(np.float32)
     aux = rs.standard_normal((M, N)).astype(np.float32)

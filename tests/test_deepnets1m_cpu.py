@@ -156,3 +156,28 @@ def test_item_net_args_ranges():
     assert a['C'] == 96 and a['fc_dim'] == 128 and a['imagenet_stride'] == 4
     a = io.item_net_args(base, g2, False, False, True, 'wide')
     assert a['C'] == 192
+
+
+def test_unreadable_dataset_files_raise_instead_of_falling_back(tmp_path, monkeypatch):
+    """A `nets_dir` that holds SOME DeepNets-1M files which cannot be read (the .hdf5 without h5py, the arrays without the
+    _meta.json) must not silently become the sampled stand-in stream: the reference raises when it cannot open its files
+    (deepnets1m.py:38-46,90-91).  An empty directory still selects the sampled stream, with a warning."""
+    import warnings
+    from ghn3_amd import deepnets1m_io as io
+    from ghn3_amd.deepnets1m import DeepNets1MDDP
+    base = os.path.join(str(tmp_path), io.split_file('val'))
+    open(base + '.hdf5', 'wb').write(b'not really hdf5')
+    with pytest.raises(FileNotFoundError, match='_meta.json'):
+        DeepNets1MDDP(split='val', nets_dir=str(tmp_path))
+    open(base + '_meta.json', 'w').write('{}')
+    monkeypatch.setattr(io, 'h5py', None)
+    with pytest.raises(FileNotFoundError, match='h5py'):
+        DeepNets1MDDP(split='val', nets_dir=str(tmp_path))
+    empty = tmp_path / 'empty'
+    empty.mkdir()
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter('always')
+        ds = DeepNets1MDDP(split='val', nets_dir=str(empty), num_nets=3)
+    assert ds.store is None and len(ds) == 3 and any('sampled architecture stream' in str(x.message) for x in w)
+    with pytest.raises(FileNotFoundError, match='arch='):
+        DeepNets1MDDP(split='val', nets_dir=str(empty), arch=0)

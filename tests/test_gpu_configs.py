@@ -344,6 +344,9 @@ def test_overlapped_optimizer_step_equals_the_serial_one(name, compute):
             hip._run_backward(plan, dout)
             outs.append((out, plan.gflat.clone(), plan.program.predicted))
             opt.step(plan.gflat, plan=plan, overlap=overlap)
+            # the overlapped step really returns with its decoder half pending on the side stream (round 5 shipped a DETACH
+            # followed by a NOP, which the runtime answered with a full join: the step was serialised and nobody noticed)
+            assert hip._ctx().side_pending() == bool(overlap)
             del plan, dout
         opt.wait()
         torch.cuda.synchronize()

@@ -79,6 +79,21 @@ def test_split_bf16_gemm_cases(ctx):
             assert err < (2e-6 if case.get('f16') else 3e-5), (case, j, err)
 
 
+def test_f16_piece_gemm_saturates_instead_of_overflowing(ctx):
+    """GHN3_GEMM_X3F16 (the Graphormer's forward linears): an activation beyond the f16 range or a weight >= 1024 (x 2^6 in its
+    copy) used to become inf in the hi piece and NaN in the lo piece (x - inf) where the bf16-piece / fp32 paths and the
+    reference stay finite.  The pieces saturate now: finite everywhere, and every output that does not touch the out-of-range
+    operands keeps the fp32-grade accuracy."""
+    from gemm_cases import run_x3_case
+    for case in (dict(M=256, N=384, K=384, tile=45, epilogue='bias_res', f16=True, big=True),
+                 dict(M=70, N=192, K=64, tile=44, epilogue='bias_relu', f16=True, big=True)):
+        (got, exp), = run_x3_case(ctx, seed=3, **case)
+        assert np.isfinite(got).all(), case
+        rows = np.r_[0, 2:case['M']]
+        cols = np.r_[0:3, 4:case['N']]              # (W[3, :] holds the out-of-range weight: output column 3)
+        assert rel_l2(got[np.ix_(rows, cols)], exp[np.ix_(rows, cols)]) < 2e-6, case
+
+
 def _run_forward(hip, nets, gb, training=False):
     plan = hip.compile(nets, gb, training=training)
     with torch.no_grad():

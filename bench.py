@@ -153,13 +153,80 @@ def launch_ranks(n):
                    MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
                                       stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL))
-    out, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        rc = rc or p.wait()
-    sys.stdout.write(out.decode())
+    # rank 0's stdout is drained by a thread (the JSON line can exceed a pipe buffer); the loop below only watches exit codes:
+    # the first rank that dies takes the others (its exact child PIDs) with it instead of leaving them in a collective forever.
+    # A rank that stalls ends ITSELF (the watchdog of main(): exit code 3 after GHN3_STALL_S seconds without a finished step).
+    import threading
+    chunks = []
+    th = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)
+    th.start()
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        bad = [p.returncode for p in procs if p.poll() is not None and p.returncode != 0]
+        if bad:
+            rc = bad[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            break
+        time.sleep(0.2)
+    for p in procs:
+        try:
+            p.wait(timeout=20)
+        except subprocess.TimeoutExpired:
+            p.kill()
+            p.wait()
+        rc = rc or p.returncode
+    th.join(timeout=5)
+    sys.stdout.write(b''.join(chunks).decode())
     sys.stdout.flush()
     return rc
+
+
+class Watchdog:
+    """N > 1: a rank that makes no progress for `limit` seconds (a hung collective, a peer that died) ends with exit code 3
+    instead of holding the node until the driver's own limit -- every timed / warm-up step and every phase of the run calls
+    beat().  Exits through os._exit: never an exec, never a kill by pattern."""
+
+    def __init__(self, limit, rank):
+        import threading
+        self.limit, self.rank, self.last, self.where = float(limit), rank, time.time(), 'start'
+        self._stop = False
+        threading.Thread(target=self._run, daemon=True).start()
+
+    def beat(self, where=None):
+        self.last = time.time()
+        if where is not None:
+            self.where = where
+
+    def stop(self):
+        self._stop = True
+
+    def _run(self):
+        while not self._stop:
+            time.sleep(1.0)
+            if time.time() - self.last > self.limit:
+                sys.stderr.write('bench.py: rank %d made no progress for %.0f s (in: %s): exiting with code 3\n'
+                                 % (self.rank, self.limit, self.where))
+                sys.stderr.flush()
+                os._exit(3)
+
+
+def link_bound_estimate(grad_bytes, world, compute_ms):
+    """A-priori arithmetic (nothing measured) for the N > 1 line: a ring / reduce-scatter + all-gather exchange moves
+    2 (N - 1) / N of the gradient bytes through every rank's xGMI links; MI355X: 7 links x ~153 GB/s per GPU (task statement /
+    MI355X guide), of which a ring uses two neighbours' links and a direct (mesh) algorithm all N - 1."""
+    if world <= 1:
+        return None
+    per_rank = 2.0 * (world - 1) / world * grad_bytes
+    link = 153e9
+    ring_ms = 1e3 * per_rank / (2 * link)                    # one ring: in + out over one link pair
+    mesh_ms = 1e3 * per_rank / (min(world - 1, 7) * link)    # all peers at once
+    return {'bytes_per_rank_on_the_wire': int(per_rank), 'xgmi_link_GBps': 153, 'links_per_gpu': 7,
+            'single_ring_ms': ring_ms, 'all_links_ms': mesh_ms, 'compute_only_ms_per_step': compute_ms,
+            'weak_scaling_ceiling_if_fully_exposed': compute_ms / (compute_ms + mesh_ms),
+            'weak_scaling_ceiling_if_fully_overlapped': min(1.0, compute_ms / mesh_ms) if mesh_ms > 0 else 1.0,
+            'note': 'arithmetic only: RCCL picks its own channels; `exchange_ms.exposed` is the measurement'}
 
 
 CONFIGS = {   # BASELINE.json `configs` 1-4 (config 5 = the headline workload with --graphs-per-gpu 2)
@@ -428,6 +495,9 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
+    dog = Watchdog(float(os.environ.get('GHN3_STALL_S', '60')), rank) if world > 1 else None
+    beat = (lambda where=None: dog.beat(where)) if dog is not None else (lambda where=None: None)
+
     from ghn3_amd import GHN3, _lib as L
     from ghn3_amd.synthetic import synthetic_batch
     from ghn3_amd.ddp_utils import all_reduce_flat_grads_avg as all_reduce_flat_grads, FlatGradReducer
@@ -474,12 +544,18 @@ def main():
 
     def step():
         run_step(ghn, plan, dout, (f_norm, b_norm, fin_norm))
+        beat()
 
+    beat('warm-up')
     for _ in range(args.warmup):
         step()
+        if dog is not None:
+            torch.cuda.synchronize()                     # (N > 1: a hang shows up at the step that hangs, not 60 s later)
+            beat()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    beat('timed region')
     ctx.profile(2)
     ctx.profile_read_tags(reset=True)
     torch.cuda.synchronize()
@@ -490,6 +566,7 @@ def main():
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    beat('serialised roofline pass')
     tags = ctx.profile_read_tags(reset=True)
     ctx.profile(0)
     # The kernels' OWN durations, for `roofline`: a few untimed steps with the side stream serialised into the chain (profile
@@ -519,13 +596,15 @@ def main():
         # What the N > 1 line needs to be judged: proof that RCCL spans all ranks (an all-reduce of ones), the EXPOSED cost
         # of the gradient exchange (step with it - the same step without any collective), the exchange alone (serial, not
         # overlapped) and -- for the default fp32 wire -- the bf16-wire variant as an extra figure.
-        def timed(n):
+        def timed(n, fn=None):
+            fn = fn or step
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
+            beat()
             t_ = time.perf_counter()
             for _ in range(n):
-                step()
+                fn()
             torch.cuda.synchronize()
             if world > 1:
                 dist.barrier()
@@ -533,6 +612,7 @@ def main():
             if world > 1:
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             return 1e3 * float(tt.item()) / n
+        beat('exchange measurements')
         ones = torch.ones(1, device=dev)
         dist.all_reduce(ones)
         n_x = max(5, args.steps // 4)
@@ -563,7 +643,9 @@ def main():
                                  'bytes_by_part': {'1: decoder.conv.2.weight (behind the W2 weight gradient, issued first)': w2_b,
                                                    '2: rest of the decoder': 4 * (hi_d - lo_d) - w2_b,
                                                    '3: Graphormer + embeddings (end of the backward)': gbytes - 4 * (hi_d - lo_d)}}
+        extras['link_bound_estimate'] = link_bound_estimate(gbytes, world, compute_ms)
         if args.grad_allreduce == 'f32':
+            beat('bf16-wire variant')
             exchange['reducer'] = FlatGradReducer(compress='bf16', force=args.force_ddp)
             for _ in range(2):
                 step()
@@ -572,6 +654,40 @@ def main():
             extras['bf16_wire'] = {'ms_per_step': b16, 'value': total_pred / (b16 * 1e-3),
                                    'note': 'same step with bf16 copies of the gradients on the wire (fp32 local sums): lower '
                                            'precision than the reference DDP exchange -- reported beside, never as `value`'}
+        # The reference's own per-GPU batch for this model (train_ghn_ddp.py:92: meta-batch 16 over the world -- 2 graphs per GPU
+        # at N = 8, BASELINE config 5) as a second line beside the 1-graph headline: same exchange bytes, twice the compute to
+        # hide them behind.
+        ref_gpg = max(1, 16 // max(world, 1)) if args.model == 'ghn3xlm16' else max(1, 8 // max(world, 1))
+        ref_gpg = min(ref_gpg, 4)
+        if ref_gpg != args.graphs_per_gpu and os.environ.get('GHN3_BENCH_REF_BATCH', '1') != '0':
+            beat('reference per-GPU batch (%d graphs)' % ref_gpg)
+            gb_r, nets_r = synthetic_batch([args.nodes] * ref_gpg, args.nodes * 1000 + rank * ref_gpg)
+            plan_r = ghn.compile(nets_r, gb_r, training=True)
+            prog_r = plan_r.program
+            norms_r = prog_r.norm_ops(1.0) + (prog_r.norm_fin_ops(),)
+            dout_r = None if fused_loss else torch.empty(prog_r.out_numel, dtype=torch.float32, device=dev)
+
+            def step_r():
+                run_step(ghn, plan_r, dout_r, norms_r)
+                beat()
+            for _ in range(3):
+                step_r()
+            n_r = max(5, args.steps // 4)
+            with_x = timed(n_r, step_r)
+            exchange['on'] = False
+            without_x = timed(n_r, step_r)
+            exchange['on'] = True
+            pr = torch.tensor([float(sum(p_['numel'] for p_ in prog_r.predicted))], dtype=torch.float64, device=dev)
+            if world > 1:
+                dist.all_reduce(pr, op=dist.ReduceOp.SUM)
+            extras['reference_batch'] = {'graphs_per_gpu': ref_gpg, 'meta_batch': ref_gpg * world, 'ms_per_step': with_x,
+                                         'value': float(pr.item()) / (with_x * 1e-3), 'compute_only_ms_per_step': without_x,
+                                         'exchange_exposed_ms': with_x - without_x,
+                                         'note': 'the per-GPU batch train_ghn_ddp.py runs for this model at this world size; '
+                                                 '`value` of the line stays the 1-graph-per-GPU headline workload'}
+            del plan_r
+            torch.cuda.empty_cache()
+        beat('tail')
     if world == 1 and not args.no_extras and not args.force_ddp:
         # (a) forward only: the north star's target is stated on the Graphormer + decoder FORWARD
         ev0, ev1 = L.Event(), L.Event()
@@ -897,6 +1013,13 @@ def main():
                          'algorithmic_gflop_fwd_bwd': step_fl / 1e9,
                          'wgrad_side_workgroups': int(getattr(prog, 'wgrad_cap', 0))},
         }
+        # the number the north star is written on: Graphormer + decoder FORWARD, algorithmic FLOPs / forward time / 2.5 PF
+        # (N = 1 with extras; also for the per-GPU batch of BASELINE config 5, 2 graphs per GPU)
+        if 'forward' in extras:
+            out['roofline']['frac_forward'] = extras['forward']['frac_of_16bit_mfma_peak']
+            out['roofline']['forward_ms'] = extras['forward']['ms']
+            if 'b2' in extras:
+                out['roofline']['frac_forward_2_graphs_per_gpu'] = extras['b2']['forward']['frac_of_16bit_mfma_peak']
         out.update(extras)
         if op_breakdown is not None:
             out['op_breakdown_ms'] = {k: round(v[0], 3) for k, v in op_breakdown.items()}
@@ -916,8 +1039,11 @@ def main():
             pass
         print(json.dumps(out), flush=True)
     if ddp:
+        beat('shutdown')
         dist.barrier()
         dist.destroy_process_group()
+    if dog is not None:
+        dog.stop()
 
 
 if __name__ == '__main__':

@@ -283,3 +283,58 @@ def test_sharded_optimizer_step_equals_the_replicated_one_world2():
         assert all(abs(a - b) <= 1e-5 * abs(b) for a, b in zip(na, nb)), (na, nb)
         assert abs(owned - (n - rep) / world) < 1 and rep < 64 * world * 12
     assert ret[0][1] == ret[1][1]                       # the same norm on both ranks
+
+
+def _rsag4_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from ghn3_amd.ddp_utils import setup_ddp, FlatGradReducer, clean_ddp
+    setup_ddp()
+    n = 300007                                           # (not a multiple of 64 * world)
+    base = torch.linspace(-1, 1, n, dtype=torch.float64).float()
+    expect = base * (sum(range(1, world + 1)) / world)
+    out = {}
+    # chunk lengths (floats) that 64 * world = 256 does not divide: every chunk leaves a replicated tail, and ranges whose
+    # length is below one shard unit are reduced everywhere
+    for chunk_floats, gather in ((50001, True), (50001, False), (777, True), (65536, False)):
+        g = base * (rank + 1)
+        red = FlatGradReducer(chunk_bytes=4 * chunk_floats, algo='rsag', gather=gather)
+        red.begin()
+        red.start(g, 120000, 200003)
+        red.start(g, 1000, 120000)
+        red.start(g, 200003, 250001)
+        red.finish(g)
+        own, rep = sorted(red.owned), sorted(red.replicated)
+        cover = sorted(own + rep)
+        disjoint = all(a[1] <= b[0] for a, b in zip(cover, cover[1:]))
+        aligned = all((hi - lo) % 64 == 0 for lo, hi in own)
+        if gather:
+            ok = bool(torch.allclose(g, expect, rtol=1e-6, atol=1e-8))
+        else:                                            # only the rank's shards + the replicated tails hold the mean
+            ok = all(bool(torch.allclose(g[lo:hi], expect[lo:hi], rtol=1e-6, atol=1e-8)) for lo, hi in cover)
+        out[(chunk_floats, gather)] = (ok, disjoint, aligned, sum(hi - lo for lo, hi in own), sum(hi - lo for lo, hi in rep),
+                                       g.double().sum().item() if gather else 0.0)
+    ret[rank] = out
+    clean_ddp()
+
+
+def test_reduce_scatter_all_gather_exchange_world4_non_divisible_chunks():
+    """`rsag` (the default exchange of bench.py / Trainer at N > 1) in a world of FOUR with chunk sizes that 64 * world does not
+    divide: every rank ends with the mean (gather=True: bit-identical buffers on all ranks), the shards of the four ranks
+    tile each chunk's divisible part exactly once, the leftovers are reduced on every rank (ddp_utils.py:257-277)."""
+    world = 4
+    port = _free_port()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_rsag4_worker, args=(world, port, ret), nprocs=world, join=True)
+    assert len(ret) == world
+    n = 300007
+    for key in ret[0]:
+        for r in range(world):
+            ok, disjoint, aligned, owned, rep, _ = ret[r][key]
+            assert ok and disjoint and aligned, (key, r, ret[r][key])
+        # all ranks own equally much, and owned x world + replicated = everything
+        assert len({ret[r][key][3] for r in range(world)}) == 1 and len({ret[r][key][4] for r in range(world)}) == 1
+        assert world * ret[0][key][3] + ret[0][key][4] == n, (key, ret[0][key])
+        if key[1]:
+            assert len({ret[r][key][5] for r in range(world)}) == 1          # identical bits everywhere

@@ -274,9 +274,36 @@ int ghn3_edge_hidden_bwd(float* dPfw, float* dPbw, float* dhid, const float* hid
     return launch_ok("edge_hidden_bwd");
 }
 
-// bias[b,h,i,j] = T[pair[b,i,j]][h]   (T has leading dimension ldT >= H)
+// bias[b,h,i,j] = T[pair[b,i,j]][h]   (T has leading dimension ldT >= H, a multiple of 4)
+// One workgroup per (graph, query row, 256 keys).  Round 6: staged through LDS -- the table rows the workgroup's pairs name are
+// fetched cooperatively, ldT / 4 adjacent lanes per row (one 16-byte piece each: a row is one coalesced segment instead of
+// ldT / 4 separate requests of the lane that owns the pair), parked as [pair][ldT + 1] floats (odd stride: the column reads
+// below are conflict-free), and every head's 256 values leave as one coalesced 1 KB store.  ldT > 64 (more than 64 heads)
+// keeps the direct gather.
 __global__ __launch_bounds__(256) void bias_gather_kernel(float* __restrict__ bias, const float* __restrict__ T,
                                                           const int* __restrict__ pair, int N, int H, int ldT) {
+    extern __shared__ float bg_rows[];               // [256][ldT + 1]
+    __shared__ int bg_pair[256];
+    const int b = blockIdx.z, i = blockIdx.y;
+    const int j0 = blockIdx.x * 256, j = j0 + threadIdx.x;
+    const int nj = min(256, N - j0);
+    bg_pair[threadIdx.x] = j < N ? pair[((size_t)b * N + i) * N + j] : 0;
+    __syncthreads();
+    const int lpr = ldT >> 2;                         // lanes per table row (16-byte pieces)
+    const int ld = ldT + 1;
+    for (int e = threadIdx.x; e < nj * lpr; e += 256) {
+        const int q = e / lpr, c = e - q * lpr;
+        const float4 v = *reinterpret_cast<const float4*>(T + (size_t)bg_pair[q] * ldT + 4 * c);
+        float* d = bg_rows + q * ld + 4 * c;
+        d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+    }
+    __syncthreads();
+    if (j >= N) return;
+    const float* r = bg_rows + threadIdx.x * ld;
+    for (int h = 0; h < H; ++h) bias[(((size_t)b * H + h) * N + i) * N + j] = r[h];
+}
+__global__ __launch_bounds__(256) void bias_gather_direct_kernel(float* __restrict__ bias, const float* __restrict__ T,
+                                                                 const int* __restrict__ pair, int N, int H, int ldT) {
     const int b = blockIdx.z, i = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= N) return;
@@ -286,7 +313,11 @@ __global__ __launch_bounds__(256) void bias_gather_kernel(float* __restrict__ bi
 }
 int ghn3_bias_gather(float* bias, const float* T, const int* pair, int B, int N, int H, hipStream_t s) {
     const int ldT = (H + 3) & ~3;
-    hipLaunchKernelGGL(bias_gather_kernel, dim3((N + 255) / 256, N, B), dim3(256), 0, s, bias, T, pair, N, H, ldT);
+    if (ldT <= 64)
+        hipLaunchKernelGGL(bias_gather_kernel, dim3((N + 255) / 256, N, B), dim3(256), 256 * (ldT + 1) * sizeof(float), s, bias, T,
+                           pair, N, H, ldT);
+    else
+        hipLaunchKernelGGL(bias_gather_direct_kernel, dim3((N + 255) / 256, N, B), dim3(256), 0, s, bias, T, pair, N, H, ldT);
     return launch_ok("bias_gather");
 }
 

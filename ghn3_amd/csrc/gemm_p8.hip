@@ -47,6 +47,13 @@ typedef const float GAS* gcf;
 typedef f32x4 GAS* gf4;
 typedef const f32x4 GAS* gcf4;
 
+#ifdef GHN3_P8_PROBE
+// tools/p8_probe.hip: cycles summed over every tile of a launch by thread 0 of its workgroup --
+// [0] tiles, [1] prologue (entry -> first k-tile landed), [2] k loop, [3] inside the k loop's DMA waits, [4] epilogue, [5] k-tiles
+__device__ unsigned long long g_p8_probe[8];
+#define P8_CLK() ((long long)__builtin_readcyclecounter())
+#endif
+
 namespace {
 
 // Values read from the problem table are wave-uniform, but the compiler cannot prove it (the table index comes out of a
@@ -86,12 +93,20 @@ __device__ __forceinline__ f32x4 mfma16x16(u16x8 a, u16x8 b, f32x4 c) {
         return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
 }
 
-// One output tile: rows [m0, m0 + 64 MI), columns [n0, n0 + 256), reduction over [0, K) (K > 0 or K == 0: zeros).
-template <int CT, int MI>
+// One output tile: rows [m0, m0 + 32 (MI0 + MI1)), columns [n0, n0 + 256), reduction over [0, K) (K > 0 or K == 0: zeros).
+// Round 6: the two row sub-tiles of a wave may differ by one 16-row MFMA tile (MI0 = MI1 or MI1 + 1): tile heights of 192,
+// 224, 256, 288, 320 rows, so that the row tiles of one streamed W2 panel can be EQUAL (533 rows = 288 + 288 instead of
+// 256 + 320): equal tiles on the CUs of one XCD run at the same pace and share the panel through the XCD's L2 for their
+// whole length, unequal ones drift apart by a fifth of a tile and fetch it twice (5.0 GB counted for 2.9 GB consumed, round 5).
+template <int CT, int MI0, int MI1>
 __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const int m0, const int n0, const int K, char* sm) {
-    constexpr int BM = 64 * MI, BK = 64, D = 7;
-    constexpr int AH = 32 * MI * 128, BH = 128 * 128, KT = 2 * AH + 2 * BH;     // bytes: A half, B half, one k-tile of the ring
-    constexpr int NFA = MI / 2, ODD = MI & 1, NPA = NFA + ODD;                   // DMA rounds of an A half-tile (last one: 32 lanes)
+    static_assert(MI0 >= MI1 && MI0 - MI1 <= 1, "sub-tile heights");
+    constexpr int MI = MI0;                                                       // (array extents: the larger sub-tile)
+    constexpr int BM = 32 * (MI0 + MI1), BK = 64, D = 7;
+    constexpr int AH0 = 32 * MI0 * 128, AH1 = 32 * MI1 * 128, BH = 128 * 128, KT = AH0 + AH1 + 2 * BH;   // bytes: A halves, B half, one k-tile of the ring
+    constexpr int NFA0 = MI0 / 2, ODD0 = MI0 & 1, NPA0 = NFA0 + ODD0;            // DMA rounds of A half-tile 0 (last one: 32 lanes)
+    constexpr int NFA1 = MI1 / 2, ODD1 = MI1 & 1, NPA1 = NFA1 + ODD1;
+    constexpr int NPA = NPA0 > NPA1 ? NPA0 : NPA1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave >> 2, wc = wave & 3;
@@ -112,18 +127,21 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
         const int kq0 = rfl(P->kq);
         const int ckb = (kq0 > 0 && kq0 < 64) ? (ck / kq0) * rfl(P->ks) + ck % kq0 : ck;   // k-map, per-lane part (64 % kq == 0)
         auto arow = [&](int rho, int h) -> unsigned {    // buffer row of A_h -> operand row
-            const int w = rho >= 16 * MI;
-            const int r = min(m0 + w * (BM / 2) + h * 16 * MI + (rho - w * 16 * MI), M - 1);
+            const int mih = h ? MI1 : MI0;
+            const int w = rho >= 16 * mih;
+            const int r = min(m0 + w * (BM / 2) + (h ? 16 * MI0 : 0) + (rho - w * 16 * mih), M - 1);
             return (unsigned)p8_map_row(r, aq, as);
         };
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
+            const int nfa = h ? NFA1 : NFA0, odd = h ? ODD1 : ODD0;
 #pragma unroll
-            for (int i = 0; i < NFA; ++i) oa[h][i] = arow(rb + 64 * i, h) * lda2 + (unsigned)ck * 2u;
-            if (ODD) {
+            for (int i = 0; i < NPA; ++i)
+                if (i < nfa) oa[h][i] = arow(rb + 64 * i, h) * lda2 + (unsigned)ck * 2u;
+            if (odd) {
                 const int l = lane & 31;
-                const int rho = 64 * NFA + wave * 4 + (l >> 3);
-                oa[h][NFA] = arow(rho, h) * lda2 + (unsigned)(((l & 7) ^ ((rho >> 1) & 7)) * 16);
+                const int rho = 64 * nfa + wave * 4 + (l >> 3);
+                oa[h][nfa] = arow(rho, h) * lda2 + (unsigned)(((l & 7) ^ ((rho >> 1) & 7)) * 16);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
@@ -145,15 +163,17 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
             char* kt = sm + par;
             if (j == 1 || j == 3) {
                 const int h = j == 3;
-                LAS char* dst = (LAS char*)(kt + (h ? AH + 2 * BH : 0));
+                const int nfa = h ? NFA1 : NFA0, odd = h ? ODD1 : ODD0;
+                LAS char* dst = (LAS char*)(kt + (h ? AH0 + 2 * BH : 0));
 #pragma unroll
-                for (int i = 0; i < NFA; ++i)
-                    __builtin_amdgcn_global_load_lds((const void GAS*)(Ab + (oa[h][i] + (unsigned)kA)), (LAS void*)(dst + i * 8192 + wave * 1024), 16, 0, P8_AUX_A);
-                if (ODD && lane < 32)
-                    __builtin_amdgcn_global_load_lds((const void GAS*)(Ab + (oa[h][NFA] + (unsigned)kA)), (LAS void*)(dst + NFA * 8192 + wave * 512), 16, 0, P8_AUX_A);
+                for (int i = 0; i < NPA; ++i)
+                    if (i < nfa)
+                        __builtin_amdgcn_global_load_lds((const void GAS*)(Ab + (oa[h][i] + (unsigned)kA)), (LAS void*)(dst + i * 8192 + wave * 1024), 16, 0, P8_AUX_A);
+                if (odd && lane < 32)
+                    __builtin_amdgcn_global_load_lds((const void GAS*)(Ab + (oa[h][nfa] + (unsigned)kA)), (LAS void*)(dst + nfa * 8192 + wave * 512), 16, 0, P8_AUX_A);
             } else {
                 const int h = j == 2;
-                LAS char* dst = (LAS char*)(kt + AH + h * BH + wave * 1024);
+                LAS char* dst = (LAS char*)(kt + AH0 + h * BH + wave * 1024);
                 __builtin_amdgcn_global_load_lds((const void GAS*)(Bb + (ob[h][0] + (unsigned)kB)), (LAS void*)dst, 16, 0, P8_AUX_B);
                 __builtin_amdgcn_global_load_lds((const void GAS*)(Bb + (ob[h][1] + (unsigned)kB)), (LAS void*)(dst + 8192), 16, 0, P8_AUX_B);
             }
@@ -180,13 +200,16 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
 
     // fragments: lane l -> row r16 = l & 15 of a 16-row MFMA tile, 16-byte chunk 4 ks + kc (kc = l >> 4)
     const int sw = r16 >> 1;
-    const int offA = (16 * MI * wr + r16) * 128 + ((kc ^ sw) << 4);       // + mi * 2048; ^ 64 for the second k-step
-    const int offB = AH + (32 * wc + r16) * 128 + ((kc ^ sw) << 4);       // + ni * 2048
+    const int offA0 = (16 * MI0 * wr + r16) * 128 + ((kc ^ sw) << 4);     // + mi * 2048; ^ 64 for the second k-step
+    const int offA1 = (16 * MI1 * wr + r16) * 128 + ((kc ^ sw) << 4);
+    const int offB = AH0 + (32 * wc + r16) * 128 + ((kc ^ sw) << 4);      // + ni * 2048
     u16x8 fa[MI][2], fb[2][2][2];
     auto read_a = [&](int T, int a) {
-        const char* base = sm + (T & 1) * KT + (a ? AH + 2 * BH : 0);
+        const char* base = sm + (T & 1) * KT + (a ? AH0 + 2 * BH : 0);
+        const int offA = a ? offA1 : offA0;
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
+            if (mi >= (a ? MI1 : MI0)) continue;
             fa[mi][0] = *reinterpret_cast<const u16x8*>(base + offA + mi * 2048);
             fa[mi][1] = *reinterpret_cast<const u16x8*>(base + (offA ^ 64) + mi * 2048);
         }
@@ -206,10 +229,12 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
 #pragma unroll
         for (int k2 = 0; k2 < 2; ++k2)
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi)
+            for (int mi = 0; mi < MI; ++mi) {
+                if (mi >= (a ? MI1 : MI0)) continue;
 #pragma unroll
                 for (int ni = 0; ni < 2; ++ni)       // transposed product: lane = output row, registers = 4 columns
                     acc[a][b][mi][ni] = mfma16x16<CT>(fb[b][ni][k2], fa[mi][k2], acc[a][b][mi][ni]);
+            }
         __builtin_amdgcn_s_setprio(0);
         __builtin_amdgcn_sched_barrier(0);
     };
@@ -217,24 +242,33 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
     auto wait_landed = [&](int last, int needed) {
         last = min(last, nq - 1);
         const int keep = last - needed;               // half-tiles that may stay in flight (3 in steady state)
-        int n = 0;
+        int n = 0;                                    // DMA instructions of this wave that may stay in flight
 #pragma unroll
         for (int e = 0; e < 3; ++e)
-            if (e < keep && last - e >= 0) { const int j = (last - e) & 3; n += (j == 1 || j == 3) ? NPA : 2; }
-        if (n >= 2 * NPA + 2) wait_vm<2 * NPA + 2>();
-        else if (n >= NPA + 4 && NPA + 4 < 2 * NPA + 2) wait_vm<NPA + 4>();
-        else if (n >= NPA + 2) wait_vm<NPA + 2>();
-        else if (n >= 4 && 4 < NPA + 2) wait_vm<4>();
-        else if (n >= NPA && NPA >= 2) wait_vm<(NPA >= 2 ? NPA : 2)>();
+            if (e < keep && last - e >= 0) { const int j = (last - e) & 3; n += j == 1 ? NPA0 : j == 3 ? NPA1 : 2; }
+        // the largest compile-time count <= n (a smaller count only over-waits; the steady state -- B1, A0, B0 in flight -- is exact)
+        constexpr int NLO = NPA0 < NPA1 ? NPA0 : NPA1;   // (= NPA1)
+        if (n >= 2 * NPA0 + 2) wait_vm<2 * NPA0 + 2>();
+        else if (n >= NPA0 + 4 && NPA0 + 4 < 2 * NPA0 + 2) wait_vm<NPA0 + 4>();
+        else if (n >= NLO + 2) wait_vm<NLO + 2>();
+        else if (n >= 4 && 4 < NLO + 2) wait_vm<4>();
+        else if (n >= NLO && NLO >= 2) wait_vm<(NLO >= 2 ? NLO : 2)>();
         else if (n >= 2) wait_vm<2>();
         else wait_vm<0>();
     };
 
+#ifdef GHN3_P8_PROBE
+    const long long pr_t0 = P8_CLK();
+    long long pr_wait = 0;
+#endif
 #pragma unroll
     for (int q = 0; q < D; ++q) issue(q & 3);
     wait_landed(D - 1, 3);                            // k-tile 0 (half-tiles 0..3)
     __builtin_amdgcn_s_barrier();
     if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs one barrier behind
+#ifdef GHN3_P8_PROBE
+    const long long pr_t1 = P8_CLK();
+#endif
 
     for (int T = 0; T < nkt; ++T) {
         const int g = 4 * T;
@@ -243,7 +277,7 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
         read_a(T, 0);
         __builtin_amdgcn_sched_barrier(0);
         issue(3);
-        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * MI) : "memory");   // the B0 reads are done: its buffer is re-staged next phase
+        asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(2 * MI0) : "memory");  // the B0 reads are done: its buffer is re-staged next phase
         __builtin_amdgcn_s_barrier();
         mfma_q(0, 0);
         __builtin_amdgcn_s_barrier();
@@ -258,12 +292,21 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
         mfma_q(1, 1);
         __builtin_amdgcn_s_barrier();
         issue(2);
+#ifdef GHN3_P8_PROBE
+        const long long pr_w0 = P8_CLK();
+#endif
         wait_landed(g + 3 + D, g + 7);                // k-tile T + 1 complete
+#ifdef GHN3_P8_PROBE
+        pr_wait += P8_CLK() - pr_w0;
+#endif
         __builtin_amdgcn_s_barrier();
         mfma_q(1, 0);
         __builtin_amdgcn_s_barrier();
     }
     if (wr == 0) __builtin_amdgcn_s_barrier();        // pairs the extra barrier of wave row 1
+#ifdef GHN3_P8_PROBE
+    const long long pr_t2 = P8_CLK();
+#endif
 
     // ---- epilogue (round 5b: staged).  In the accumulator layout -- lane = output row r16 of a 16-row MFMA tile, its 4 registers =
     // columns 4 kc .. 4 kc + 3 -- a 16-lane pass of a store instruction is 16 ROWS x 16 bytes and the CU's store path takes 72 cycles
@@ -308,7 +351,9 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
         for (int a = 0; a < 2; ++a)
 #pragma unroll
             for (int mp = 0; mp < MI; mp += 2) {
-                const int nu = (mp + 1 < MI) ? 2 : 1;                 // blocks of 16 rows in this round trip (compile-time after unrolling)
+                const int mia = a ? MI1 : MI0;
+                if (mp >= mia) continue;
+                const int nu = (mp + 1 < mia) ? 2 : 1;                // blocks of 16 rows in this round trip (compile-time after unrolling)
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
                     if (u >= nu) continue;
@@ -318,7 +363,7 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
                         for (int ni = 0; ni < 2; ++ni)
                             *reinterpret_cast<f32x4*>(stg + u * 4096 + wofs + (((8 * b + 4 * ni + kc) ^ wsw) << 4)) = acc[a][b][mp + u][ni] * alpha;
                 }
-                const int row0 = m0 + wr * (BM / 2) + 16 * (a * MI + mp);
+                const int row0 = m0 + wr * (BM / 2) + 16 * (a * MI0 + mp);
 #pragma unroll
                 for (int ps = 0; ps < 8; ++ps) {
                     if (ps >= 4 * nu) continue;
@@ -341,11 +386,26 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
                         }
                         if (residual) v += *reinterpret_cast<gcf4>(residual + ci);
                         if (accum) v += *reinterpret_cast<gcf4>(C + ci);
+#ifdef P8_NT_STORE
+                        __builtin_nontemporal_store(v, reinterpret_cast<gf4>(C + ci));   // (experiment: tools/p8_replay -DP8_NT_STORE)
+#else
                         *reinterpret_cast<gf4>(C + ci) = v;
+#endif
                     }
                 }
             }
     }
+#ifdef GHN3_P8_PROBE
+    if (tid == 0) {
+        const long long pr_t3 = P8_CLK();
+        atomicAdd(&g_p8_probe[0], 1ull);
+        atomicAdd(&g_p8_probe[1], (unsigned long long)(pr_t1 - pr_t0));
+        atomicAdd(&g_p8_probe[2], (unsigned long long)(pr_t2 - pr_t1));
+        atomicAdd(&g_p8_probe[3], (unsigned long long)pr_wait);
+        atomicAdd(&g_p8_probe[4], (unsigned long long)(pr_t3 - pr_t2));
+        atomicAdd(&g_p8_probe[5], (unsigned long long)nkt);
+    }
+#endif
 }
 
 // Row tiles.  With a row-tile table (GemmProbDev::mtab: int32 triples {m0, MI, extent}, written by the host for the
@@ -396,7 +456,7 @@ __device__ __forceinline__ void p8_dispatch(const GemmProbDev* __restrict__ prob
     if (mtab) {
         m0 = rfl(mtab[3 * mt]); mi = rfl(mtab[3 * mt + 1]); ext = rfl(mtab[3 * mt + 2]);
     } else {
-        m0 = mt * 256; mi = 4; ext = 0x7fffffff;
+        m0 = mt * 256; mi = 8; ext = 0x7fffffff;
         const int* lim = rflp(P->lim);
         if (lim) {
             ext = rfl(lim[m0 >> 7]);
@@ -409,9 +469,12 @@ __device__ __forceinline__ void p8_dispatch(const GemmProbDev* __restrict__ prob
     const int lim_kind = rfl(P->lim_kind);
     if (lim_kind == 1) { if (n0 >= ext) return; }
     else if (lim_kind == 2) K = min(K, ext);
-    if (mi == 5) p8_tile<CT, 5>(P, m0, n0, K, sm);   // (160 accumulators + 72 fragment registers: fits 256 only because
-    else if (mi == 3) p8_tile<CT, 3>(P, m0, n0, K, sm);   //  every table value lives in SGPRs; spills stay outside the k loop)
-    else p8_tile<CT, 4>(P, m0, n0, K, sm);
+    // height code: 3 / 4 / 5 = 64 mi rows (rounds 3-5), 6 .. 10 = 32 mi rows (round 6: 7 = 224 and 9 = 288 are new)
+    if (mi == 5 || mi == 10) p8_tile<CT, 5, 5>(P, m0, n0, K, sm);   // (160 accumulators + 72 fragment registers: fits 256 only because
+    else if (mi == 9) p8_tile<CT, 5, 4>(P, m0, n0, K, sm);          //  every table value lives in SGPRs; spills stay outside the k loop)
+    else if (mi == 7) p8_tile<CT, 4, 3>(P, m0, n0, K, sm);
+    else if (mi == 3 || mi == 6) p8_tile<CT, 3, 3>(P, m0, n0, K, sm);
+    else p8_tile<CT, 4, 4>(P, m0, n0, K, sm);
 }
 
 template <int CT>

@@ -576,6 +576,19 @@ class Program:
         three full-width 256-row tiles).  Returns an int32 array of {m0, mi, extent} triples."""
         ext = np.asarray(ext, dtype=np.int64)
         R = len(ext)
+        if cls.P8_FINE:
+            # round 6: heights of 32 n rows, n in 6 .. 10 (224 and 288 are new), positions in steps of 32 rows
+            n = (R + 31) // 32
+            best = [0.0] * (n + 11)
+            choice = [0] * (n + 11)
+            for k in range(n - 1, -1, -1):
+                e = float(ext[k * 32]) + 1e-3
+                best[k], choice[k] = min((cls.P8_COSTN[h] * e + best[min(k + h, n)], h) for h in (6, 7, 8, 9, 10))
+            out, k = [], 0
+            while k < n:
+                out.append((k * 32, choice[k], int(ext[k * 32])))
+                k += choice[k]
+            return np.asarray(out, dtype=np.int32).reshape(-1, 3)
         n = (R + 63) // 64
         best = [0.0] * (n + 6)
         choice = [0] * (n + 6)
@@ -586,6 +599,78 @@ class Program:
         while k < n:
             out.append((k * 64, choice[k], int(ext[k * 64])))
             k += choice[k]
+        return np.asarray(out, dtype=np.int32).reshape(-1, 3)
+
+    # Round 6: EQUAL row tiles per W2 panel.  Height codes 6 .. 10 = 32 n rows (192 / 224 / 256 / 288 / 320; 7 and 9 are new in
+    # gemm_p8.hip), relative cost of one k-tile step interpolated between the measured 3 / 4 / 5 (tools/gemm_lab.hip).
+    P8_COSTN = {6: 1.72, 7: 1.86, 8: 2.0, 9: 2.21, 10: 2.42}
+    P8_BALANCED = os.environ.get('GHN3_P8_BALANCED', '1') != '0'            # forward: dense column ranges with equal tiles
+    P8_BALANCED_DGRAD = os.environ.get('GHN3_P8_BALANCED_DGRAD', '0') != '0'    # dgrad: equal tiles per K chunk
+    P8_FINE = os.environ.get('GHN3_P8_FINE', '1') != '0'                   # row_tiles on 32-row positions, heights 192 .. 320
+
+    @classmethod
+    def p8_cost(cls, code):
+        code = int(code)
+        return cls.P8_COST[code] if code <= 5 else cls.P8_COSTN[code]
+
+    @classmethod
+    def balanced_tiles(cls, rows):
+        """(T, n): T EQUAL row tiles of 32 n rows (n in 6 .. 10) covering `rows` rows at the least cost T * cost[n]; ties go to
+        fewer tiles.  The row tiles of one streamed W2 panel then run at the same pace on the CUs of one XCD and share the
+        panel through its L2 for their whole length (533 rows: 2 x 288 instead of 256 + 320, whose faster tile runs a fifth of
+        the panel ahead by the end and makes both fetch it: 5.0 GB counted for 2.9 GB consumed in round 5)."""
+        best = None
+        for n in (6, 7, 8, 9, 10):
+            t = max(1, -(-int(rows) // (32 * n)))
+            c = t * cls.P8_COSTN[n]
+            if best is None or c < best[0] - 1e-9 or (abs(c - best[0]) <= 1e-9 and t < best[1]):
+                best = (c, t, n)
+        return best[1], best[2]
+
+    @staticmethod
+    def alive_rows(gg, o_lo):
+        """Rows of a stacked family that consume the W2 rows o' >= o_lo (o_r > o_lo): a prefix, the rows are sorted by decreasing o."""
+        return sum(sb['rows'] for sb in gg['subs'] if sb['o'] > o_lo)
+
+    @classmethod
+    def column_ranges(cls, gg, min_cols=1024):
+        """Cuts a family's forward GEMM at the distinct output widths of its members: [(o_lo, o_hi, alive rows)] with o' in
+        [o_lo, o_hi) consumed by exactly the first `alive` rows.  Every range is a DENSE problem with its own equal row tiles.
+        Ranges narrower than min_cols columns are merged into the next wider one (its extra rows compute don't-care columns)."""
+        bounds = sorted({sb['o'] for sb in gg['subs']})
+        out, o_lo = [], 0
+        for o_hi in bounds:
+            out.append([o_lo, o_hi, cls.alive_rows(gg, o_lo)])
+            o_lo = o_hi
+        k = 0
+        while k < len(out) - 1:
+            if (out[k][1] - out[k][0]) * gg['i_ld'] < min_cols:
+                out[k + 1][0] = out[k][0]
+                out[k + 1][2] = out[k][2]
+                del out[k]
+            else:
+                k += 1
+        return [tuple(r) for r in out]
+
+    @classmethod
+    def range_tiles(cls, alive, total_rows, ext_of_row, k0=0, kc=None):
+        """Row-tile table {m0, n, extent} of one dense range / K chunk: T equal tiles over the `alive` rows, extent of a tile =
+        ext_of_row(first row) shifted into the chunk [k0, k0 + kc) (kc None: no clipping); the rows behind them (dead in this
+        chunk: K = 0, their plane rows are written as zeros) in 320-row tiles."""
+        out = []
+        m0 = 0
+        if alive > 0:
+            t, n = cls.balanced_tiles(alive)
+            for _ in range(t):
+                if m0 >= total_rows:
+                    break
+                e = int(ext_of_row(m0))
+                out.append((m0, n, e - k0 if kc is None else int(np.clip(e - k0, 0, kc))))
+                m0 += 32 * n
+        while m0 < total_rows:
+            e = int(ext_of_row(m0))
+            out.append((m0, 10, e - k0 if kc is None else int(np.clip(e - k0, 0, kc))))
+            m0 += 320
         return np.asarray(out, dtype=np.int32).reshape(-1, 3)
 
     def _dgrad_sub_split(self, g16, n_cols, n_cu=32):
@@ -599,10 +684,16 @@ class Program:
                 if not g.get('p8'):
                     continue
                 oc = (g['o'] + 7) // 8
-                for (m0, mi, ext) in g['mtiles']:
-                    steps = min(int(ext), oc * g['i_ld']) / 64.0
+                if self.P8_BALANCED_DGRAD:                 # chunk 0: every row alive, equal tiles
+                    t_, n_ = self.balanced_tiles(g['rows'])
+                    tiles_ = [(self.P8_COSTN[n_], min(int(g['ext'][min(q * 32 * n_, g['rows'] - 1)]), oc * g['i_ld']))
+                              for q in range(t_) if q * 32 * n_ < g['rows']]
+                else:
+                    tiles_ = [(self.p8_cost(mi), min(int(ext), oc * g['i_ld'])) for (m0, mi, ext) in g['mtiles']]
+                for cost_, ext_ in tiles_:
+                    steps = ext_ / 64.0
                     for f in sub:
-                        items += [self.P8_COST[int(mi)] * steps * f / sum(sub)] * nt
+                        items += [cost_ * steps * f / sum(sub)] * nt
             items.sort(reverse=True)
             cu = [0.0] * n_cu
             for it in items:
@@ -1226,6 +1317,18 @@ class Program:
             fl = 0.0
             for g in self.gemm_groups:
                 fl += sum(2.0 * sb['rows'] * sb['cols'] * 8 * C for sb in g['subs'])   # algorithmic: own extents only
+                if g['op16'] and g['p8'] and self.P8_BALANCED:
+                    # Round 6: one DENSE problem per column range of the family (cut at its members' output widths), each with
+                    # EQUAL row tiles (balanced_tiles): the row tiles of a W2 panel run at the same pace and share it in L2
+                    for (o_lo, o_hi, alive) in self.column_ranges(g):
+                        n_lo, ncols = o_lo * g['i_ld'], (o_hi - o_lo) * g['i_ld']
+                        mt = self.range_tiles(alive, alive, lambda r_: ncols)
+                        self.gemm(self.href(self.uh + g['row0'] * 8 * C), self.sref(self.w2h + o_lo * ms[1] * 8 * C),
+                                  self.wref('tiles', g['tile_off'] + n_lo),
+                                  alive, ncols, 8 * C, 8 * C, 8 * C, g['ld'], b_qs=(g['i_ld'], ms[1]),
+                                  bias=self.pref(b2, o_lo * ms[1]), bias_q=g['i_ld'], bias_s=ms[1], op16=True,
+                                  lim=None, lim_kind=1, mtiles=(self.idx(mt), len(mt)))
+                    continue
                 if g['op16']:
                     # one problem per family: all its rows share every W2 tile; ragged column extents via `lim`
                     self.gemm(self.href(self.uh + g['row0'] * 8 * C), self.sref(self.w2h),
@@ -1993,8 +2096,15 @@ class Program:
                     # the last: the boundaries equalise the WORK (row tiles alive at o' x their cost) instead of the length.
                     if g['p8'] and g['nc'] == 8 and os.environ.get('GHN3_DGRAD_EQ', '1') != '0':
                         dens = np.zeros(g['o'])
-                        for (m0_, mi_, ext_) in g['mtiles']:
-                            dens[:min(g['o'], int(ext_) // g['i_ld'])] += self.P8_COST[int(mi_)]
+                        if self.P8_BALANCED_DGRAD:              # work alive at o': its equal tiles
+                            lo_ = 0
+                            for hi_ in sorted({sb['o'] for sb in g['subs']}):
+                                t_, n_ = self.balanced_tiles(self.alive_rows(g, lo_))
+                                dens[lo_:hi_] = t_ * self.P8_COSTN[n_]
+                                lo_ = hi_
+                        else:
+                            for (m0_, mi_, ext_) in g['mtiles']:
+                                dens[:min(g['o'], int(ext_) // g['i_ld'])] += self.p8_cost(mi_)
                         cw = np.concatenate([[0.0], np.cumsum(dens)])
                         bounds = [0]
                         for j in range(1, g['nc']):
@@ -2022,7 +2132,13 @@ class Program:
                         if g['ragged'] or kc < g['cols']:
                             lim = self.idx(np.clip(g['lim128'] - k0, 0, kc).astype(np.int32))
                         mt = None
-                        if g['p8']:
+                        if g['p8'] and self.P8_BALANCED_DGRAD:
+                            # equal tiles over the rows alive at the chunk's first W2 row (a prefix); rows dead in this chunk
+                            # write the zeros of their plane rows (K = 0)
+                            alive = self.alive_rows(g, min(o0, g['o'])) if kc > 0 else 0
+                            mt = self.range_tiles(alive, g['rows'], lambda r_: g['ext'][r_], k0, kc)
+                            mt = (self.idx(mt), len(mt))
+                        elif g['p8']:
                             mt = g['mtiles'].copy()
                             mt[:, 2] = np.clip(mt[:, 2] - k0, 0, kc)
                             mt = (self.idx(mt), len(mt))

@@ -103,6 +103,11 @@ def main():
     targets = torch.randint(0, num_classes, (args.batch_size,), generator=gen).to(ddp.device)
 
     waits, t0, n_timed = 0.0, None, 0
+    prof = None
+    if os.environ.get('GHN3_CPROFILE'):                   # host-side profile of the loop (where the step's Python time goes)
+        import cProfile
+        prof = cProfile.Profile()
+        prof.enable()
     for epoch in range(trainer.start_epoch, args.epochs):
         trainer.reset_metrics(epoch)
         for step in range(trainer.start_step, args.steps):
@@ -119,6 +124,13 @@ def main():
                 trainer.save(epoch, step, {'config': config})
         trainer.scheduler_step()
     torch.cuda.synchronize()
+    if prof is not None:
+        import pstats
+        prof.disable()
+        with open(os.environ['GHN3_CPROFILE'], 'w') as fh:
+            st = pstats.Stats(prof, stream=fh)
+            st.sort_stats('tottime').print_stats(60)
+            st.sort_stats('cumulative').print_stats(50)
     if ddp.rank == 0 and t0 is not None and n_timed:
         dt = time.perf_counter() - t0
         log('%.1f ms per step over %d steps (%.1f ms of it waiting for the architecture queue); %d updates skipped'

@@ -246,14 +246,15 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
 #pragma unroll
         for (int e = 0; e < 3; ++e)
             if (e < keep && last - e >= 0) { const int j = (last - e) & 3; n += j == 1 ? NPA0 : j == 3 ? NPA1 : 2; }
-        // the largest compile-time count <= n (a smaller count only over-waits; the steady state -- B1, A0, B0 in flight -- is exact)
-        constexpr int NLO = NPA0 < NPA1 ? NPA0 : NPA1;   // (= NPA1)
-        if (n >= 2 * NPA0 + 2) wait_vm<2 * NPA0 + 2>();
-        else if (n >= NPA0 + 4 && NPA0 + 4 < 2 * NPA0 + 2) wait_vm<NPA0 + 4>();
-        else if (n >= NLO + 2) wait_vm<NLO + 2>();
-        else if (n >= 4 && 4 < NLO + 2) wait_vm<4>();
-        else if (n >= NLO && NLO >= 2) wait_vm<(NLO >= 2 ? NLO : 2)>();
-        else if (n >= 2) wait_vm<2>();
+        // exactly n may stay in flight (n is wave-uniform: scalar compares; at most 2 NPA0 + 2 <= 8)
+        if (n >= 8) wait_vm<8>();
+        else if (n == 7) wait_vm<7>();
+        else if (n == 6) wait_vm<6>();
+        else if (n == 5) wait_vm<5>();
+        else if (n == 4) wait_vm<4>();
+        else if (n == 3) wait_vm<3>();
+        else if (n == 2) wait_vm<2>();
+        else if (n == 1) wait_vm<1>();
         else wait_vm<0>();
     };
 
@@ -469,11 +470,15 @@ __device__ __forceinline__ void p8_dispatch(const GemmProbDev* __restrict__ prob
     const int lim_kind = rfl(P->lim_kind);
     if (lim_kind == 1) { if (n0 >= ext) return; }
     else if (lim_kind == 2) K = min(K, ext);
-    // height code: 3 / 4 / 5 = 64 mi rows (rounds 3-5), 6 .. 10 = 32 mi rows (round 6: 7 = 224 and 9 = 288 are new)
-    if (mi == 5 || mi == 10) p8_tile<CT, 5, 5>(P, m0, n0, K, sm);   // (160 accumulators + 72 fragment registers: fits 256 only because
+    // height code = rows / 32 (ABI v19): 6 .. 10 = 192 .. 320 rows (7 = 224 and 9 = 288 are new in round 6), 2 / 4 = 64 / 128
+    // rows: the skinny row tiles of an inference forward -- a family of <= 128 decoder rows streams its W2 rows once, at the
+    // rate the LDS-DMA ring pulls them, instead of through the 128 x 128 two-stage kernel
+    if (mi == 2) p8_tile<CT, 1, 1>(P, m0, n0, K, sm);
+    else if (mi == 4) p8_tile<CT, 2, 2>(P, m0, n0, K, sm);
+    else if (mi == 10) p8_tile<CT, 5, 5>(P, m0, n0, K, sm);         // (160 accumulators + 72 fragment registers: fits 256 only because
     else if (mi == 9) p8_tile<CT, 5, 4>(P, m0, n0, K, sm);          //  every table value lives in SGPRs; spills stay outside the k loop)
     else if (mi == 7) p8_tile<CT, 4, 3>(P, m0, n0, K, sm);
-    else if (mi == 3 || mi == 6) p8_tile<CT, 3, 3>(P, m0, n0, K, sm);
+    else if (mi == 6) p8_tile<CT, 3, 3>(P, m0, n0, K, sm);
     else p8_tile<CT, 4, 4>(P, m0, n0, K, sm);
 }
 

@@ -509,6 +509,282 @@ __global__ __launch_bounds__(256) void tnet_dw_wgrad_kernel(const float* __restr
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Round 6, second slice: the DENSE convolution chain  [ReLU ->] kh x kw convolution (stride, padding, dilation) -> BatchNorm
+// = `ReLUConvBN` with a k x k kernel (the `conv_3x3 / 5x5 / 7x7` ops, /root/reference/ghn3/ops.py:180-198, 297) and its
+// 1 x k / k x 1 halves.  Implicit GEMM on the same machinery as the depthwise / pointwise family above: a workgroup owns 64
+// output pixels x all output channels, the reduction runs over (tap, 32 input channels) chunks -- the operand chunk of a tap is
+// the (ReLU of the) shifted input pixels, read straight from x; the weights come from a [tap][C_out][C_in] re-pack of the
+// predicted [C_out][C_in][kh][kw] tensor (one small launch: a workgroup's weight chunks are then coalesced rows instead of
+// 4-byte gathers with a stride of kh kw floats) -- split operands with three bf16 pieces, fp32 accumulate, z + per-tile
+// statistics in the epilogue.  Backward: dz on the fly (as above); dx by the transposed implicit GEMM over the taps that read
+// an input pixel; dW per (tap, 64 x 64 block, pixel chunk) partials + fixed-order reduction, written back in the parameter's
+// own [C_out][C_in][kh][kw] order.  The stock path runs these layers as MIOpen implicit-GEMM / Winograd kernels between two
+// layout transposes, ~4 launches forward and ~8 backward per layer, plus ReLU and BatchNorm launches.
+// ---------------------------------------------------------------------------------------------------------------------
+struct CDesc {
+    int N, H, W, C_in, C_out, kh, kw, sh, sw, ph, pw, dil, Ho, Wo, relu;
+    float eps;
+};
+
+__global__ __launch_bounds__(256) void tnet_conv_w_repack_kernel(const float* __restrict__ w, float* __restrict__ w_r, int C_out,
+                                                                 int C_in, int taps) {
+    const int64_t total = (int64_t)C_out * C_in * taps, cc = (int64_t)C_out * C_in;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int64_t t = i / cc, r = i - t * cc;                      // r = co * C_in + ci
+        w_r[i] = w[r * taps + t];
+    }
+}
+
+// (relu of) 8 consecutive channels c .. c + 7 of input pixel (n, ih, iw); zeros outside the image / beyond C_in
+__device__ __forceinline__ void conv_in8(const float* __restrict__ x, const CDesc& d, int n, int ih, int iw, int c, float (&out)[8]) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) out[e] = 0.f;
+    if (n < 0 || c >= d.C_in || ih < 0 || ih >= d.H || iw < 0 || iw >= d.W) return;
+    const float* px = x + ((int64_t)(n * d.H + ih) * d.W + iw) * d.C_in + c;
+    const f32x4 v0 = *reinterpret_cast<const f32x4*>(px);
+    const f32x4 v1 = c + 4 < d.C_in ? *reinterpret_cast<const f32x4*>(px + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        out[e] = d.relu ? fmaxf(v0[e], 0.f) : v0[e];
+        out[4 + e] = d.relu ? fmaxf(v1[e], 0.f) : v1[e];
+    }
+}
+
+template <int NT, int S>
+__global__ __launch_bounds__(256) void tnet_conv_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w_r,
+                                                            float* __restrict__ z, float* __restrict__ part, const CDesc d, const int P) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* pix = reinterpret_cast<int*>(smem);                                   // [3][TP]
+    unsigned short* As = reinterpret_cast<unsigned short*>(smem + 3 * TP * 4);                       // [S][TP][LDK]
+    unsigned short* Bs = As + S * TP * LDK;                                                          // [S][16 NT][LDK]
+    float* red = reinterpret_cast<float*>(Bs + S * 16 * NT * LDK);             // [5][16 NT]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kc = lane >> 4;
+    const int tile = blockIdx.x, p0 = tile * TP, taps = d.kh * d.kw;
+    if (tid < TP) {
+        const int p = p0 + tid;
+        int n = -1, ih0 = 0, iw0 = 0;
+        if (p < P) {
+            const int hw = d.Ho * d.Wo;
+            n = p / hw;
+            const int r = p - n * hw, oh = r / d.Wo, ow = r - oh * d.Wo;
+            ih0 = oh * d.sh - d.ph;
+            iw0 = ow * d.sw - d.pw;
+        }
+        pix[tid] = n; pix[TP + tid] = ih0; pix[2 * TP + tid] = iw0;
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < taps; ++t) {
+        const int dh = (t / d.kw) * d.dil, dw_ = (t % d.kw) * d.dil;
+        const float* wt = w_r + (int64_t)t * d.C_out * d.C_in;
+        for (int c0 = 0; c0 < d.C_in; c0 += KC) {
+            __syncthreads();                                                   // (previous chunk's fragments are consumed; pix is written)
+            for (int i = tid; i < 16 * NT * 8; i += 256) {
+                const int n = i >> 3, k = (i & 7) * 4, c = c0 + k;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (n < d.C_out && c < d.C_in) v = *reinterpret_cast<const f32x4*>(wt + (int64_t)n * d.C_in + c);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) splitS<S>(v[e], Bs, n * LDK + k + e, 16 * NT * LDK);
+            }
+            {
+                const int i = tid >> 2, cc = (tid & 3) * 8;
+                float y[8];
+                conv_in8(x, d, pix[i], pix[TP + i] + dh, pix[2 * TP + i] + dw_, c0 + cc, y);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) splitS<S>(y[e], As, i * LDK + cc + e, TP * LDK);
+            }
+            __syncthreads();
+            u16x8 af[S];
+#pragma unroll
+            for (int q = 0; q < S; ++q) af[q] = frag(As + q * TP * LDK, 16 * w + r16, kc);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (16 * j < d.C_out) {
+                    u16x8 bf[S];
+#pragma unroll
+                    for (int q = 0; q < S; ++q) bf[q] = frag(Bs + q * 16 * NT * LDK, 16 * j + r16, kc);
+                    acc[j] = mma_terms<S>(af, bf, acc[j]);
+                }
+            }
+        }
+    }
+    // ---- epilogue: z, then per-tile (mean, M2) of every channel (as tnet_dwpw_fwd_kernel)
+    const int prow = p0 + 16 * w + r16;
+    const bool valid = prow < P;
+    const int cnt = min(TP, P - p0);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = 16 * j + 4 * kc;
+        if (valid && col < d.C_out) *reinterpret_cast<f32x4*>(z + (int64_t)prow * d.C_out + col) = acc[j];
+    }
+    auto tile_sum = [&](bool centred) {
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = 16 * j + 4 * kc;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = 0.f;
+                if (valid) { v = acc[j][e]; if (centred) { v -= red[4 * 16 * NT + col + e]; v *= v; } }
+                v += __shfl_xor(v, 1, 64); v += __shfl_xor(v, 2, 64); v += __shfl_xor(v, 4, 64); v += __shfl_xor(v, 8, 64);
+                if (r16 == 0) red[w * 16 * NT + col + e] = v;
+            }
+        }
+        __syncthreads();
+    };
+    tile_sum(false);
+    for (int c = tid; c < 16 * NT; c += 256)
+        red[4 * 16 * NT + c] = (red[c] + red[16 * NT + c] + red[2 * 16 * NT + c] + red[3 * 16 * NT + c]) / (float)cnt;
+    tile_sum(true);
+    for (int c = tid; c < d.C_out; c += 256) {
+        part[((int64_t)tile * 2) * d.C_out + c] = red[4 * 16 * NT + c];
+        part[((int64_t)tile * 2 + 1) * d.C_out + c] = red[c] + red[16 * NT + c] + red[2 * 16 * NT + c] + red[3 * 16 * NT + c];
+    }
+}
+
+// dx [P_in][C_in] = relu'(x) . sum over taps of dz[output pixel that reads this input through the tap][C_out] W_tap [C_out][C_in]
+template <int NT, int S>
+__global__ __launch_bounds__(256) void tnet_conv_bwd_data_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                                 const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ s12, const float* __restrict__ w_r,
+                                                                 const float* __restrict__ x, float* __restrict__ dx, const CDesc d,
+                                                                 const int P_out, const int P_in) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int* pix = reinterpret_cast<int*>(smem);                                   // [3][TP]: n, ih + ph, iw + pw of the input pixels
+    unsigned short* As = reinterpret_cast<unsigned short*>(smem + 3 * TP * 4);                       // [S][TP][LDK]
+    unsigned short* Bs = As + S * TP * LDK;                                                          // [S][16 NT][LDK]
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kc = lane >> 4;
+    const int p0 = blockIdx.x * TP, taps = d.kh * d.kw;
+    if (tid < TP) {
+        const int p = p0 + tid;
+        int n = -1, a = 0, b = 0;
+        if (p < P_in) {
+            const int hw = d.H * d.W;
+            n = p / hw;
+            const int r = p - n * hw, ih = r / d.W, iw = r - ih * d.W;
+            a = ih + d.ph; b = iw + d.pw;
+        }
+        pix[tid] = n; pix[TP + tid] = a; pix[2 * TP + tid] = b;
+    }
+    f32x4 acc[NT];
+#pragma unroll
+    for (int j = 0; j < NT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int t = 0; t < taps; ++t) {
+        const int dh = (t / d.kw) * d.dil, dw_ = (t % d.kw) * d.dil;
+        const float* wt = w_r + (int64_t)t * d.C_out * d.C_in;
+        for (int c0 = 0; c0 < d.C_out; c0 += KC) {
+            __syncthreads();
+            {   // A[i][k] = dz[output pixel of (input pixel i, tap t)][c0 + k]
+                const int i = tid >> 2, cc = (tid & 3) * 8;
+                const int n = pix[i], th = pix[TP + i] - dh, tw = pix[2 * TP + i] - dw_;
+                int po = P_out;                                                // (no such output pixel: zeros)
+                if (n >= 0 && th >= 0 && tw >= 0 && th % d.sh == 0 && tw % d.sw == 0) {
+                    const int oh = th / d.sh, ow = tw / d.sw;
+                    if (oh < d.Ho && ow < d.Wo) po = (n * d.Ho + oh) * d.Wo + ow;
+                }
+                float v[8];
+                dz8(dout, z, stats, gamma, s12, d.C_out, po, P_out, c0 + cc, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) splitS<S>(v[e], As, i * LDK + cc + e, TP * LDK);
+            }
+            // B[n = ci][k] = W_tap[c0 + k][n]
+            for (int i = tid; i < KC * 4 * NT; i += 256) {
+                const int k = i / (4 * NT), n = (i % (4 * NT)) * 4, co = c0 + k;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+                if (co < d.C_out && n < d.C_in) v = *reinterpret_cast<const f32x4*>(wt + (int64_t)co * d.C_in + n);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) splitS<S>(v[e], Bs, (n + e) * LDK + k, 16 * NT * LDK);
+            }
+            __syncthreads();
+            u16x8 af[S];
+#pragma unroll
+            for (int q = 0; q < S; ++q) af[q] = frag(As + q * TP * LDK, 16 * w + r16, kc);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) {
+                if (16 * j < d.C_in) {
+                    u16x8 bf[S];
+#pragma unroll
+                    for (int q = 0; q < S; ++q) bf[q] = frag(Bs + q * 16 * NT * LDK, 16 * j + r16, kc);
+                    acc[j] = mma_terms<S>(af, bf, acc[j]);
+                }
+            }
+        }
+    }
+    const int prow = p0 + 16 * w + r16;
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = 16 * j + 4 * kc;
+        if (prow < P_in && col < d.C_in) {
+            f32x4 v = acc[j];
+            if (d.relu) {
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(x + (int64_t)prow * d.C_in + col);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = xv[e] > 0.f ? v[e] : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(dx + (int64_t)prow * d.C_in + col) = v;
+        }
+    }
+}
+
+// part[chunk][t][co][ci] = sum over the chunk's output pixels of dz[p][co] act(x[tap t of p][ci]); workgroup = (chunk, 64 co, (t, 64 ci))
+__global__ __launch_bounds__(256) void tnet_conv_wgrad_kernel(const float* __restrict__ dout, const float* __restrict__ z,
+                                                              const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                              const float* __restrict__ s12, const float* __restrict__ x,
+                                                              float* __restrict__ part, const CDesc d, const int P, const int chunk_px) {
+    constexpr int S = 3;
+    __shared__ __attribute__((aligned(16))) unsigned short As[S * 64 * LDK], Bs[S * 64 * LDK];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kc = lane >> 4;
+    const int ci_tiles = (d.C_in + 63) / 64, taps = d.kh * d.kw;
+    const int chunk = blockIdx.x, co0 = blockIdx.y * 64, t = blockIdx.z / ci_tiles, ci0 = (blockIdx.z % ci_tiles) * 64;
+    const int dh = (t / d.kw) * d.dil, dw_ = (t % d.kw) * d.dil;
+    const int pa = chunk * chunk_px, pb = min(P, pa + chunk_px), hw = d.Ho * d.Wo;
+    f32x4 acc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int pk = pa; pk < pb; pk += KC) {
+        __syncthreads();
+        const int k = tid >> 3, m8 = (tid & 7) * 8, p = pk + k;
+        {   // A[m = co][k = pixel]
+            float v[8];
+            dz8(dout, z, stats, gamma, s12, d.C_out, p < pb ? p : P, P, co0 + m8, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) splitS<S>(v[e], As, (m8 + e) * LDK + k, 64 * LDK);
+        }
+        {   // B[n = ci][k = pixel] = act(x) at the tap's input pixel
+            int n = -1, ih = 0, iw = 0;
+            if (p < pb) {
+                n = p / hw;
+                const int r = p - n * hw, oh = r / d.Wo, ow = r - oh * d.Wo;
+                ih = oh * d.sh - d.ph + dh; iw = ow * d.sw - d.pw + dw_;
+            }
+            float y[8];
+            conv_in8(x, d, n, ih, iw, ci0 + m8, y);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) splitS<S>(y[e], Bs, (m8 + e) * LDK + k, 64 * LDK);
+        }
+        __syncthreads();
+        u16x8 af[S];
+#pragma unroll
+        for (int q = 0; q < S; ++q) af[q] = frag(As + q * 64 * LDK, 16 * w + r16, kc);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            u16x8 bf[S];
+#pragma unroll
+            for (int q = 0; q < S; ++q) bf[q] = frag(Bs + q * 64 * LDK, 16 * j + r16, kc);
+            acc[j] = mma_terms<S>(af, bf, acc[j]);
+        }
+    }
+    const int co = co0 + 16 * w + r16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int ci = ci0 + 16 * j + 4 * kc;
+        if (co < d.C_out && ci < d.C_in)
+            *reinterpret_cast<f32x4*>(part + (((int64_t)chunk * taps + t) * d.C_out + co) * d.C_in + ci) = acc[j];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------------
 inline int nt_of(int C) { return C <= 64 ? 4 : C <= 128 ? 8 : C <= 256 ? 16 : 32; }
@@ -676,5 +952,153 @@ extern "C" int ghn3_dwpw_bn_bwd(const ghn3_dwpw_desc* g, const float* dout, cons
             LAUNCH_CHECK("dw wgrad reduce")
         }
     }
+    return GHN3_OK;
+}
+
+// ---- dense convolution family (round 6) ---------------------------------------------------------------------------------
+namespace {
+
+struct CPlan { int P, P_in, n_tiles, n_tiles_in, w_chunks, w_chunk_px, taps; };
+
+CPlan make_cplan(const CDesc& d) {
+    CPlan pl;
+    pl.taps = d.kh * d.kw;
+    pl.P = d.N * d.Ho * d.Wo;
+    pl.P_in = d.N * d.H * d.W;
+    pl.n_tiles = (pl.P + TP - 1) / TP;
+    pl.n_tiles_in = (pl.P_in + TP - 1) / TP;
+    const int blocks = ((d.C_out + 63) / 64) * ((d.C_in + 63) / 64) * pl.taps;
+    int chunks = (768 + blocks - 1) / blocks;
+    chunks = std::max(1, std::min(chunks, (pl.P + KC - 1) / KC));
+    pl.w_chunk_px = ((pl.P + chunks - 1) / chunks + KC - 1) / KC * KC;
+    pl.w_chunks = (pl.P + pl.w_chunk_px - 1) / pl.w_chunk_px;
+    return pl;
+}
+
+int check_cdesc(const ghn3_conv_desc* g, CDesc& d) {
+    if (!g) { ghn3_set_error("conv: null descriptor"); return GHN3_E_ARG; }
+    d = CDesc{g->N, g->H, g->W, g->C_in, g->C_out, g->kh, g->kw, g->stride_h, g->stride_w, g->pad_h, g->pad_w, g->dil, g->Ho, g->Wo,
+              g->relu != 0, g->eps};
+    if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.C_in <= 0 || d.C_out <= 0 || d.kh <= 0 || d.kw <= 0 || d.sh <= 0 || d.sw <= 0 ||
+        d.dil <= 0 || d.ph < 0 || d.pw < 0) {
+        ghn3_set_error("conv: non-positive size in the descriptor");
+        return GHN3_E_ARG;
+    }
+    if ((d.C_in & 3) || (d.C_out & 3) || d.C_in > 512 || d.C_out > 512 || d.kh > 7 || d.kw > 7) {
+        ghn3_set_error("conv: needs C_in, C_out multiples of 4 and <= 512, kernel <= 7 x 7 (got %d -> %d, %d x %d)", d.C_in, d.C_out,
+                       d.kh, d.kw);
+        return GHN3_E_LIMIT;
+    }
+    const int ho = (d.H + 2 * d.ph - d.dil * (d.kh - 1) - 1) / d.sh + 1, wo = (d.W + 2 * d.pw - d.dil * (d.kw - 1) - 1) / d.sw + 1;
+    if (ho != d.Ho || wo != d.Wo || ho <= 0 || wo <= 0) {
+        ghn3_set_error("conv: output size %d x %d does not match the convolution arithmetic (%d x %d)", d.Ho, d.Wo, ho, wo);
+        return GHN3_E_ARG;
+    }
+    if ((int64_t)d.N * d.H * d.W * std::max(d.C_in, d.C_out) >= ((int64_t)1 << 31) ||
+        (int64_t)d.N * d.Ho * d.Wo * std::max(d.C_in, d.C_out) >= ((int64_t)1 << 31)) {
+        ghn3_set_error("conv: activation tensors of 2^31 elements or more are not supported");
+        return GHN3_E_LIMIT;
+    }
+    return GHN3_OK;
+}
+
+inline size_t cfwd_lds(int NT) { const int S = terms_of(NT); return 3 * TP * 4 + S * TP * LDK * 2 + S * 16 * NT * LDK * 2 + 5 * 16 * NT * 4; }
+inline size_t cbwd_lds(int NT) { const int S = terms_of(NT); return 3 * TP * 4 + S * TP * LDK * 2 + S * 16 * NT * LDK * 2; }
+
+int conv_repack(const CDesc& d, const CPlan& pl, const float* w, float* w_r, hipStream_t s) {
+    const int64_t total = (int64_t)d.C_out * d.C_in * pl.taps;
+    hipLaunchKernelGGL(tnet_conv_w_repack_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 2048)), dim3(256), 0, s, w, w_r, d.C_out,
+                       d.C_in, pl.taps);
+    LAUNCH_CHECK("conv weight repack")
+    return GHN3_OK;
+}
+
+}  // namespace
+
+extern "C" int64_t ghn3_conv_scratch_floats(const ghn3_conv_desc* g, int backward) {
+    CDesc d;
+    if (check_cdesc(g, d)) return -1;
+    const CPlan pl = make_cplan(d);
+    const int64_t wr = (int64_t)pl.taps * d.C_out * d.C_in;
+    if (!backward) return (int64_t)pl.n_tiles * 2 * d.C_out + wr + 64;
+    return (int64_t)pl.n_tiles * 2 * d.C_out + 2 * d.C_out + wr + (int64_t)pl.w_chunks * wr + 256;
+}
+
+extern "C" int ghn3_conv_bn_fwd(const ghn3_conv_desc* g, const float* x, const float* w, const float* gamma, const float* beta, float* z,
+                                float* out, float* stats, float* scratch, void* stream_) {
+    CDesc d;
+    int rc = check_cdesc(g, d);
+    if (rc) return rc;
+    if (!x || !w || !gamma || !beta || !z || !out || !stats || !scratch) { ghn3_set_error("conv fwd: null pointer"); return GHN3_E_ARG; }
+    hipStream_t s = (hipStream_t)stream_;
+    const CPlan pl = make_cplan(d);
+    float* part = scratch;
+    float* w_r = part + (int64_t)pl.n_tiles * 2 * d.C_out;
+    rc = conv_repack(d, pl, w, w_r, s);
+    if (rc) return rc;
+    const int NT = nt_of(d.C_out);
+    const size_t lds = cfwd_lds(NT);
+#define CFWD_CASE(n, t) case n: rc = set_lds(tnet_conv_fwd_kernel<n, t>, lds); if (rc) return rc; \
+        hipLaunchKernelGGL((tnet_conv_fwd_kernel<n, t>), dim3(pl.n_tiles), dim3(256), lds, s, x, w_r, z, part, d, pl.P); break;
+    switch (NT) { CFWD_CASE(4, 3) CFWD_CASE(8, 3) CFWD_CASE(16, 3) CFWD_CASE(32, 2) }
+#undef CFWD_CASE
+    LAUNCH_CHECK("conv fwd")
+    hipLaunchKernelGGL(tnet_bn_finalize_kernel, dim3((d.C_out + 15) / 16), dim3(256), 0, s, part, pl.n_tiles, pl.P, d.C_out, d.eps, stats);
+    LAUNCH_CHECK("bn finalize")
+    const int64_t total4 = (int64_t)pl.P * d.C_out / 4;
+    hipLaunchKernelGGL(tnet_bn_apply_kernel, dim3((int)std::min<int64_t>((total4 + 255) / 256, 4096)), dim3(256), 0, s, z, stats, gamma,
+                       beta, out, total4, d.C_out);
+    LAUNCH_CHECK("bn apply")
+    return GHN3_OK;
+}
+
+extern "C" int ghn3_conv_bn_bwd(const ghn3_conv_desc* g, const float* dout, const float* x, const float* z, const float* stats,
+                                const float* w, const float* gamma, float* dx, float* dw, float* dgamma, float* dbeta, float* scratch,
+                                void* stream_) {
+    CDesc d;
+    int rc = check_cdesc(g, d);
+    if (rc) return rc;
+    if (!dout || !x || !z || !stats || !w || !gamma || !dx || !dw || !dgamma || !dbeta || !scratch) {
+        ghn3_set_error("conv bwd: null pointer");
+        return GHN3_E_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    const CPlan pl = make_cplan(d);
+    const int64_t wr = (int64_t)pl.taps * d.C_out * d.C_in;
+    float* part12 = scratch;
+    float* s12 = part12 + (int64_t)pl.n_tiles * 2 * d.C_out;
+    float* w_r = s12 + 2 * d.C_out;
+    float* part_w = w_r + wr;
+    // 1. dgamma / dbeta
+    {
+        const int nq = d.C_out / 4, ng = std::max(1, 256 / nq);
+        hipLaunchKernelGGL(tnet_bn_bwd_partial_kernel, dim3(pl.n_tiles), dim3(256), (size_t)ng * 2 * d.C_out * 4, s, dout, z, stats, part12,
+                           pl.P, d.C_out);
+        LAUNCH_CHECK("bn bwd partial")
+        hipLaunchKernelGGL(tnet_reduce_rows_kernel, dim3((2 * d.C_out / 4 + 15) / 16), dim3(256), 0, s, part12, pl.n_tiles,
+                           (int64_t)2 * d.C_out, s12, 0, 0);
+        LAUNCH_CHECK("bn bwd reduce")
+        hipMemcpyAsync(dbeta, s12, (size_t)d.C_out * 4, hipMemcpyDeviceToDevice, s);
+        hipMemcpyAsync(dgamma, s12 + d.C_out, (size_t)d.C_out * 4, hipMemcpyDeviceToDevice, s);
+    }
+    rc = conv_repack(d, pl, w, w_r, s);
+    if (rc) return rc;
+    // 2. dx
+    {
+        const int NT = nt_of(d.C_in);
+        const size_t lds = cbwd_lds(NT);
+#define CBWD_CASE(n, t) case n: rc = set_lds(tnet_conv_bwd_data_kernel<n, t>, lds); if (rc) return rc; \
+        hipLaunchKernelGGL((tnet_conv_bwd_data_kernel<n, t>), dim3(pl.n_tiles_in), dim3(256), lds, s, dout, z, stats, gamma, s12, w_r, x, dx, d, pl.P, pl.P_in); break;
+        switch (NT) { CBWD_CASE(4, 3) CBWD_CASE(8, 3) CBWD_CASE(16, 3) CBWD_CASE(32, 2) }
+#undef CBWD_CASE
+        LAUNCH_CHECK("conv bwd data")
+    }
+    // 3. dW (in the parameter's own [C_out][C_in][kh][kw] order)
+    hipLaunchKernelGGL(tnet_conv_wgrad_kernel, dim3(pl.w_chunks, (d.C_out + 63) / 64, ((d.C_in + 63) / 64) * pl.taps), dim3(256), 0, s, dout, z,
+                       stats, gamma, s12, x, part_w, d, pl.P, pl.w_chunk_px);
+    LAUNCH_CHECK("conv wgrad")
+    hipLaunchKernelGGL(tnet_reduce_rows_kernel, dim3((int)((wr / 4 + 15) / 16)), dim3(256), 0, s, part_w, pl.w_chunks, wr, dw,
+                       d.C_out * d.C_in, pl.taps);
+    LAUNCH_CHECK("conv wgrad reduce")
     return GHN3_OK;
 }

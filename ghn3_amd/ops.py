@@ -135,6 +135,10 @@ class _FactorizedReduce:
         self.bn = bn_layer(Lyr, norm, C_out)
 
     def forward(self, x):
+        if x.is_cuda and self.stride == 2:               # (round 6: one dense-convolution node, target_ops.run_factorized_reduce)
+            y = target_ops.run_factorized_reduce(self.relu, self.conv_1, self.conv_2, self.bn, x, self.stride)
+            if y is not None:
+                return y
         x = self.relu(x)
         shifted = x[:, :, 1:, 1:] if self.stride > 1 else x
         return self.bn(torch.cat([self.conv_1(x), self.conv_2(shifted)], dim=1))
@@ -158,6 +162,8 @@ class _ReLUConvBN:
     def forward(self, x):
         if self._pointwise and x.is_cuda:                # (ReLU -> 1x1 conv -> norm: the fused HIP op without a depthwise stage)
             return target_ops.run_pointwise_block(list(self.op), x)
+        if x.is_cuda and len(self.op) == 3:              # (round 6: ReLU -> k x k conv -> norm on the dense-convolution op)
+            return target_ops.run_conv_block(list(self.op), x)
         return self.op(x)
 
 

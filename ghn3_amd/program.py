@@ -583,7 +583,7 @@ class Program:
             choice = [0] * (n + 11)
             for k in range(n - 1, -1, -1):
                 e = float(ext[k * 32]) + 1e-3
-                best[k], choice[k] = min((cls.P8_COSTN[h] * e + best[min(k + h, n)], h) for h in (6, 7, 8, 9, 10))
+                best[k], choice[k] = min((cls.P8_COSTN[h] * e + best[min(k + h, n)], h) for h in cls.P8_HEIGHTS)
             out, k = [], 0
             while k < n:
                 out.append((k * 32, choice[k], int(ext[k * 32])))
@@ -597,21 +597,21 @@ class Program:
             best[k], choice[k] = min((cls.P8_COST[mi] * e + best[min(k + mi, n)], mi) for mi in cls.P8_MI)
         out, k = [], 0
         while k < n:
-            out.append((k * 64, choice[k], int(ext[k * 64])))
+            out.append((k * 64, 2 * choice[k], int(ext[k * 64])))      # (height code = rows / 32)
             k += choice[k]
         return np.asarray(out, dtype=np.int32).reshape(-1, 3)
 
     # Round 6: EQUAL row tiles per W2 panel.  Height codes 6 .. 10 = 32 n rows (192 / 224 / 256 / 288 / 320; 7 and 9 are new in
     # gemm_p8.hip), relative cost of one k-tile step interpolated between the measured 3 / 4 / 5 (tools/gemm_lab.hip).
-    P8_COSTN = {6: 1.72, 7: 1.86, 8: 2.0, 9: 2.21, 10: 2.42}
+    P8_COSTN = {2: 1.5, 4: 1.55, 6: 1.72, 7: 1.86, 8: 2.0, 9: 2.21, 10: 2.42}   # (2 / 4: bound by the W2 stream, not the matrix cores)
+    P8_HEIGHTS = (2, 4, 6, 7, 8, 9, 10)                                    # row-tile heights / 32 the kernel has
     P8_BALANCED = os.environ.get('GHN3_P8_BALANCED', '1') != '0'            # forward: dense column ranges with equal tiles
     P8_BALANCED_DGRAD = os.environ.get('GHN3_P8_BALANCED_DGRAD', '0') != '0'    # dgrad: equal tiles per K chunk
     P8_FINE = os.environ.get('GHN3_P8_FINE', '1') != '0'                   # row_tiles on 32-row positions, heights 192 .. 320
 
     @classmethod
     def p8_cost(cls, code):
-        code = int(code)
-        return cls.P8_COST[code] if code <= 5 else cls.P8_COSTN[code]
+        return cls.P8_COSTN[int(code)]
 
     @classmethod
     def balanced_tiles(cls, rows):
@@ -620,7 +620,7 @@ class Program:
         panel through its L2 for their whole length (533 rows: 2 x 288 instead of 256 + 320, whose faster tile runs a fifth of
         the panel ahead by the end and makes both fetch it: 5.0 GB counted for 2.9 GB consumed in round 5)."""
         best = None
-        for n in (6, 7, 8, 9, 10):
+        for n in cls.P8_HEIGHTS:
             t = max(1, -(-int(rows) // (32 * n)))
             c = t * cls.P8_COSTN[n]
             if best is None or c < best[0] - 1e-9 or (abs(c - best[0]) <= 1e-9 and t < best[1]):
@@ -830,7 +830,11 @@ class Program:
             gg['ragged'] = len(subs) > 1
             gg['ext'] = ext
             # row tiles of the 8-phase kernel (families with at least ~a tile of rows; the rest runs on 128 x 128 tiles)
-            gg['p8'] = self.use_p8 and self.direct16 and gg['i_ld'] % 8 == 0 and gg['rows'] >= 160
+            # (round 6: with 64- / 128-row tiles an INFERENCE forward streams every family's W2 rows through the LDS-DMA ring --
+            # 230 decoder rows of a ResNet-50 are four families of 32 .. 109 rows --; training keeps the small families on the
+            # 128 x 128 kernel unless GHN3_P8_MIN_ROWS says otherwise: their dgrad K chunks are too short for XCD-pinned tiles)
+            min_rows = int(os.environ.get('GHN3_P8_MIN_ROWS', '160' if self.training else '8'))
+            gg['p8'] = self.use_p8 and self.direct16 and gg['i_ld'] % 8 == 0 and gg['rows'] >= min_rows
             if gg['p8']:
                 gg['mtiles'] = self.row_tiles(ext)
         self.M = row

@@ -130,6 +130,155 @@ class DwPwBn(torch.autograd.Function):
         return dx, dwd, dwp, dg, db, None, None, None, None
 
 
+class _ConvDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('N', 'H', 'W', 'C_in', 'C_out', 'kh', 'kw', 'stride_h', 'stride_w', 'pad_h', 'pad_w',
+                                              'dil', 'Ho', 'Wo', 'relu')] + [('eps', ctypes.c_float)]
+
+
+def _pair(v):
+    return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
+
+
+def _conv_desc(x, w, stride, pad, dil, relu, eps):
+    N, C, H, W = x.shape
+    C_out, _, kh, kw = w.shape
+    (sh, sw), (ph, pw) = _pair(stride), _pair(pad)
+    Ho = (H + 2 * ph - dil * (kh - 1) - 1) // sh + 1
+    Wo = (W + 2 * pw - dil * (kw - 1) - 1) // sw + 1
+    return _ConvDesc(N, H, W, C, C_out, kh, kw, sh, sw, ph, pw, int(dil), Ho, Wo, int(bool(relu)), float(eps))
+
+
+_CONV_SCRATCH = {}
+
+
+def _conv_scratch_floats(lib, d, backward):
+    key = tuple(getattr(d, f[0]) for f in d._fields_[:-1]) + (backward,)
+    n = _CONV_SCRATCH.get(key)
+    if n is None:
+        n = int(lib.ghn3_conv_scratch_floats(ctypes.byref(d), backward))
+        if n < 0:
+            raise L.Ghn3Error('ghn3_conv_scratch_floats: %s' % lib.ghn3_last_error().decode())
+        _CONV_SCRATCH[key] = n
+    return n
+
+
+class ConvBn(torch.autograd.Function):
+    """[ReLU ->] dense kh x kw convolution -> BatchNorm (batch statistics) as ONE autograd node on ghn3_conv_bn_fwd / _bwd
+    (round 6: `ReLUConvBN` with a k x k kernel, ops.py:180-198).  Same conventions as DwPwBn: channels_last storage inside,
+    the weight [C_out][C_in][kh][kw] read in place, its gradient written in the same order."""
+
+    @staticmethod
+    def applicable(x, w, gamma, beta, training_stats=True):
+        if not (enabled() and os.environ.get('GHN3_NATIVE_CONV', '1') != '0' and torch.is_tensor(x) and x.is_cuda and
+                x.dtype == torch.float32 and x.dim() == 4):
+            return False
+        if torch.is_autocast_enabled() or not training_stats:
+            return False
+        if not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 for t in (w, gamma, beta)) or w.dim() != 4:
+            return False
+        C_in, C_out = x.shape[1], w.shape[0]
+        return C_in % 4 == 0 and C_out % 4 == 0 and C_in <= 512 and C_out <= 512 and w.shape[1] == C_in and \
+            max(w.shape[2], w.shape[3]) <= 7 and x.numel() < 2 ** 31 and gamma.numel() == C_out
+
+    @staticmethod
+    def forward(ctx, x, w, gamma, beta, stride, pad, dil, relu, eps):
+        lib = L.load()
+        xc = x.contiguous(memory_format=torch.channels_last)
+        wc, g, b = w.contiguous(), gamma.contiguous(), beta.contiguous()
+        d = _conv_desc(xc, wc, stride, pad, dil, relu, eps)
+        dev, C_out = x.device, int(wc.shape[0])
+        out = torch.empty((d.N, C_out, d.Ho, d.Wo), dtype=torch.float32, device=dev, memory_format=torch.channels_last)
+        z = torch.empty_like(out)
+        stats = torch.empty(3 * C_out, dtype=torch.float32, device=dev)
+        scratch = torch.empty(_conv_scratch_floats(lib, d, 0), dtype=torch.float32, device=dev)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L._check(lib.ghn3_conv_bn_fwd(ctypes.byref(d), _ptr(xc), _ptr(wc), _ptr(g), _ptr(b), _ptr(z), _ptr(out), _ptr(stats),
+                                      _ptr(scratch), stream), 'ghn3_conv_bn_fwd')
+        ctx.save_for_backward(xc, z, stats, wc, g)
+        ctx.cfg = (stride, pad, dil, relu, eps)
+        ctx.mark_non_differentiable(stats)
+        return out, stats
+
+    @staticmethod
+    def backward(ctx, dout, _dstats):
+        lib = L.load()
+        xc, z, stats, wc, g = ctx.saved_tensors
+        stride, pad, dil, relu, eps = ctx.cfg
+        d = _conv_desc(xc, wc, stride, pad, dil, relu, eps)
+        dev, C_out = xc.device, int(wc.shape[0])
+        do = dout.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(xc)
+        n_par = wc.numel() + 2 * C_out
+        buf = torch.empty((n_par + 63) // 64 * 64 + _conv_scratch_floats(lib, d, 1), dtype=torch.float32, device=dev)
+        dw = buf[:wc.numel()].view(wc.shape)
+        dg = buf[wc.numel():wc.numel() + C_out]
+        db = buf[wc.numel() + C_out:n_par]
+        scratch = buf[(n_par + 63) // 64 * 64:]
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L._check(lib.ghn3_conv_bn_bwd(ctypes.byref(d), _ptr(do), _ptr(xc), _ptr(z), _ptr(stats), _ptr(wc), _ptr(g), _ptr(dx), _ptr(dw),
+                                      _ptr(dg), _ptr(db), _ptr(scratch), stream), 'ghn3_conv_bn_bwd')
+        return dx, dw, dg, db, None, None, None, None, None
+
+
+def conv_bn(x, w, gamma, beta, stride=1, padding=0, dilation=1, relu=True, eps=1e-5):
+    """out = batch_norm(conv2d(relu(x) if relu else x, w)) with batch statistics; returns (out, stats) as dwpw_bn does.
+    x: (N, C, H, W) fp32 CUDA tensor (channels_last preferred), w (C_out, C, kh, kw)."""
+    if not x.is_cuda:
+        raise L.Ghn3Error('conv_bn runs on an MI355X only (no CPU implementation: use the stock torch layers)')
+    return ConvBn.apply(x, w, gamma, beta, _pair(stride), _pair(padding), int(dilation), bool(relu), float(eps))
+
+
+def conv_reference(x, w, gamma, beta, stride=1, padding=0, dilation=1, relu=True, eps=1e-5):
+    """The stock layers ConvBn replaces (ops.py:186-193), functional form -- the parity reference of the tests."""
+    y = F.conv2d(F.relu(x) if relu else x, w, None, stride, padding, dilation)
+    return F.batch_norm(y, None, None, gamma, beta, True, 0.1, eps)
+
+
+def run_conv_block(layers, x, keep_layout=False):
+    """[ReLU, k x k Conv2d, BatchNorm2d] -- `ReLUConvBN` (ops.py:180-198) -- on the fused dense-convolution op where it applies,
+    else layer by layer.  Same layout contract as run_block."""
+    relu, conv, bn = layers
+    w, gamma, beta = getattr(conv, 'weight', None), getattr(bn, 'weight', None), getattr(bn, 'bias', None)
+    has_run = getattr(bn, 'running_mean', None) is not None
+    batch_stats = getattr(bn, 'training', True) or not has_run
+    ok = hasattr(bn, 'eps') and getattr(conv, 'bias', None) is None and hasattr(conv, 'kernel_size') and \
+        not isinstance(conv.padding, str) and getattr(conv, 'groups', 1) == 1 and torch.is_tensor(w) and \
+        len(set(_pair(getattr(conv, 'dilation', 1)))) == 1 and ConvBn.applicable(x, w, gamma, beta, batch_stats)
+    if not ok:
+        for m in layers:
+            x = m(x)
+        return x
+    out, stats = conv_bn(x, w, gamma, beta, conv.stride, conv.padding, _pair(conv.dilation)[0], True, bn.eps)
+    _update_running_stats(bn, stats, out, has_run)
+    return out if keep_layout else out.contiguous(memory_format=torch.contiguous_format)
+
+
+def run_factorized_reduce(relu, conv_1, conv_2, bn, x, stride=2, keep_layout=False):
+    """`FactorizedReduce` (ops.py:163-178: ReLU, two 1 x 1 convolutions of stride 2 on the even and the odd pixel grid, concat,
+    norm) as ONE dense-convolution node: a 2 x 2 kernel of stride 2 whose tap (0, 0) carries conv_1's weights for the first half
+    of the output channels and whose tap (1, 1) carries conv_2's for the second half (the other entries are zeros) reads exactly
+    the pixels the two strided convolutions read.  The 2 x 2 weight is assembled by differentiable torch ops, so the gradients
+    reach conv_1 / conv_2 (views of the GHN's prediction buffer) through autograd.  Returns None when the fused op does not
+    apply (the caller keeps the stock layers)."""
+    w1, w2 = getattr(conv_1, 'weight', None), getattr(conv_2, 'weight', None)
+    gamma, beta = getattr(bn, 'weight', None), getattr(bn, 'bias', None)
+    has_run = getattr(bn, 'running_mean', None) is not None
+    batch_stats = getattr(bn, 'training', True) or not has_run
+    if not (stride == 2 and hasattr(bn, 'eps') and torch.is_tensor(w1) and torch.is_tensor(w2) and x.dim() == 4 and
+            x.shape[2] % 2 == 0 and x.shape[3] % 2 == 0 and getattr(conv_1, 'bias', None) is None and
+            getattr(conv_2, 'bias', None) is None and w1.shape == w2.shape and tuple(w1.shape[2:]) == (1, 1)):
+        return None
+    half, C_in = int(w1.shape[0]), int(w1.shape[1])
+    w = torch.zeros(2 * half, C_in, 2, 2, dtype=w1.dtype, device=w1.device)
+    w[:half, :, 0, 0] = w1[:, :, 0, 0]
+    w[half:, :, 1, 1] = w2[:, :, 0, 0]
+    if not ConvBn.applicable(x, w, gamma, beta, batch_stats):
+        return None
+    out, stats = conv_bn(x, w, gamma, beta, 2, 0, 1, True, bn.eps)
+    _update_running_stats(bn, stats, out, has_run)
+    return out if keep_layout else out.contiguous(memory_format=torch.contiguous_format)
+
+
 def dwpw_bn(x, w_dw, w_pw, gamma, beta, stride=1, padding=0, dilation=1, eps=1e-5):
     """out = batch_norm(conv1x1(depthwise_conv(relu(x)))) with batch statistics; returns (out, stats) with
     stats = [mean | 1 / sqrt(var + eps) | biased variance] per output channel.  x: (N, C, H, W) fp32 CUDA tensor

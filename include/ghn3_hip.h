@@ -160,10 +160,11 @@ typedef struct ghn3_gemm_problem {
     ghn3_ref B2;
     int32_t x3_slice, _pad3;
     /* GHN3_GEMM_OP16, tile code 28 only, optional: row-tile table, `n_mtiles` int32 triples {m0, mi, extent}.  Row tile t
-     * covers rows [m0, m0 + 64 * mi) with mi in {3, 4, 5} (192 / 256 / 320 rows; tiles must not overlap, rows beyond M are
-     * ignored) and `extent` replaces the per-128-row `lim` entries for it: valid columns (lim_kind 1) or valid reduction
-     * length (lim_kind 2) of the tile's rows; lim_kind 0 ignores it.  Lets the host cut a stacked decoder family at its
-     * extent boundaries with little row padding (533 full-width rows = 320 + 256 instead of three 256-row tiles).
+     * covers rows [m0, m0 + 32 * mi) with mi in {2, 4, 6, 7, 8, 9, 10} (64 .. 320 rows; ABI v19 -- until v18 the code counted
+     * 64-row units and was 3, 4 or 5; tiles must not overlap, rows beyond M are ignored) and `extent` replaces the per-128-row
+     * `lim` entries for it: valid columns (lim_kind 1) or valid reduction length (lim_kind 2) of the tile's rows; lim_kind 0
+     * ignores it.  Lets the host cut a stacked decoder family at its extent boundaries with little row padding and give the
+     * row tiles of one streamed W2 panel EQUAL heights (533 full-width rows = 288 + 288).
      * Absent: 256-row tiles and `lim` as for the other 16-bit-operand kernels. */
     ghn3_ref mtiles;
     int32_t n_mtiles, _pad4;
@@ -525,6 +526,25 @@ int ghn3_dwpw_bn_fwd(const ghn3_dwpw_desc* desc, const float* x, const float* w_
 int ghn3_dwpw_bn_bwd(const ghn3_dwpw_desc* desc, const float* dout, const float* x, const float* z, const float* stats,
                      const float* w_dw, const float* w_pw, const float* gamma, float* dx, float* dw_dw, float* dw_pw,
                      float* dgamma, float* dbeta, float* scratch, void* stream);
+
+
+/* ---- target-network layers, second slice (ABI v19, round 6): [ReLU ->] dense kh x kw convolution -> BatchNorm -------------
+ * `ReLUConvBN` with a k x k kernel and its 1 x k / k x 1 halves (/root/reference/ghn3/ops.py:180-198; the `conv_3x3 / 5x5 /
+ * 7x7` ops of the DeepNets-1M search space, ops.py:297), forward and backward, NHWC fp32 activations, batch statistics.
+ * w [C_out][C_in][kh][kw] is the view of the GHN's flat prediction buffer (read in place; dw is written in the same order),
+ * z / out [N Ho Wo][C_out], stats [3 C_out] as for ghn3_dwpw_bn_fwd; relu != 0 applies ReLU to x first (and its mask to dx).
+ * Limits (GHN3_E_LIMIT: the caller keeps its stock path): C_in, C_out multiples of 4 and <= 512, kernel <= 7 x 7.
+ * Deterministic (fixed-order partial sums). */
+typedef struct ghn3_conv_desc {
+    int32_t N, H, W, C_in, C_out, kh, kw, stride_h, stride_w, pad_h, pad_w, dil, Ho, Wo, relu;
+    float eps;
+} ghn3_conv_desc;
+int64_t ghn3_conv_scratch_floats(const ghn3_conv_desc* desc, int backward);     /* < 0: bad descriptor (ghn3_last_error) */
+int ghn3_conv_bn_fwd(const ghn3_conv_desc* desc, const float* x, const float* w, const float* gamma, const float* beta, float* z,
+                     float* out, float* stats, float* scratch, void* stream);
+int ghn3_conv_bn_bwd(const ghn3_conv_desc* desc, const float* dout, const float* x, const float* z, const float* stats,
+                     const float* w, const float* gamma, float* dx, float* dw, float* dgamma, float* dbeta, float* scratch,
+                     void* stream);
 
 #ifdef __cplusplus
 }

@@ -220,7 +220,7 @@ def run_op16_case(ctx, M, N, K, ctype=L.CT_F16, tile=0, grid_cap=0, a_transposed
     M - 29 r rows of the same A into its own C (ghn3_gemm_problem::xcd_pin)."""
     rs = np.random.RandomState(seed)
     r64 = lambda v: (v + 63) // 64 * 64
-    mt_rows = lambda mi_: 64 * mi_ if mi_ <= 5 else 32 * mi_       # height code: 3 .. 5 = 64 mi rows, 6 .. 10 = 32 mi rows
+    mt_rows = lambda mi_: 32 * mi_                                 # height code = rows / 32 (2, 4, 6 .. 10)
     # fp32 sources.  A: [M][K] (or [K][M] when the cast transposes it); B physical k extent Kp (k-map) or K.
     kq, ks = kmap if kmap else (0, 0)
     Kp = ((K + kq - 1) // kq) * ks if kmap else K
@@ -441,11 +441,11 @@ OP16_CASES = [
     dict(M=260, N=250, K=64, tile=28, accum=True),
     dict(M=200, N=7, K=9, tile=28),
     dict(M=300, N=200, K=150, a_transposed=True, b_transposed=True, cmap=True, accum=True, tile=28),
-    dict(M=700, N=600, K=64 * 7, tile=28, mtiles=[(0, 4), (256, 3), (448, 4)]),
-    dict(M=533, N=1000, K=64 * 5 + 8, tile=28, mtiles=[(0, 3), (192, 3), (384, 3)], epilogue='drelu_res'),
-    dict(M=700, N=900, K=64 * 3, tile=28, mtiles=[(0, 3, 900), (192, 3, 900), (384, 4, 520), (640, 3, 64)], ragged=1, epilogue='bias_relu'),
-    dict(M=768, N=300, K=64 * 9, tile=28, mtiles=[(0, 4, 576), (256, 4, 300), (512, 4, 64)], ragged=2, kmap=(64, 96)),
-    dict(M=640, N=512, K=64 * 2, tile=28, mtiles=[(0, 3), (192, 4), (448, 3)], grid_cap=3),
+    dict(M=700, N=600, K=64 * 7, tile=28, mtiles=[(0, 8), (256, 6), (448, 8)]),
+    dict(M=533, N=1000, K=64 * 5 + 8, tile=28, mtiles=[(0, 6), (192, 6), (384, 6)], epilogue='drelu_res'),
+    dict(M=700, N=900, K=64 * 3, tile=28, mtiles=[(0, 6, 900), (192, 6, 900), (384, 8, 520), (640, 6, 64)], ragged=1, epilogue='bias_relu'),
+    dict(M=768, N=300, K=64 * 9, tile=28, mtiles=[(0, 8, 576), (256, 8, 300), (512, 8, 64)], ragged=2, kmap=(64, 96)),
+    dict(M=640, N=512, K=64 * 2, tile=28, mtiles=[(0, 6), (192, 8), (448, 6)], grid_cap=3),
     # round 6: height codes 6 .. 10 = 32 mi rows -- 224- and 288-row tiles (sub-tiles of 4 + 3 / 5 + 4 MFMA rows per wave), so
     # that the row tiles of one streamed panel can be equal: 533 rows = 288 + 288, 660 rows = 3 x 224
     dict(M=533, N=1000, K=64 * 5 + 8, tile=28, mtiles=[(0, 9), (288, 9)], epilogue='drelu_res'),
@@ -454,6 +454,11 @@ OP16_CASES = [
     dict(M=672, N=300, K=64 * 9, tile=28, mtiles=[(0, 7, 576), (224, 7, 320), (448, 7, 64)], ragged=2, kmap=(64, 96), cmap=True),
     dict(M=1000, N=260, K=64 * 2 + 3, tile=28, mtiles=[(0, 6), (192, 8), (448, 10), (768, 7), (992, 6)], accum=True),
     dict(M=288, N=256, K=64, tile=28, mtiles=[(0, 9)]),
+    # skinny row tiles (64 / 128 rows): the inference forward's families
+    dict(M=109, N=1000, K=64 * 5 + 8, tile=28, mtiles=[(0, 4)], epilogue='bias_relu'),
+    dict(M=40, N=520, K=64 * 48, tile=28, mtiles=[(0, 2, 520)], ragged=1, kmap=(64, 96)),
+    dict(M=230, N=300, K=64 * 3, tile=28, mtiles=[(0, 2), (64, 4), (192, 2)], cmap=True),
+    dict(M=100, N=260, K=130, tile=28, mtiles=[(0, 2, 130), (64, 2, 64)], ragged=2, epilogue='drelu_res'),
     dict(M=533, N=384, K=64 * 12, kmap=(64, 96), tile=28, mtiles=[(0, 9), (288, 9)], pins=[0, 1, 2, 3, 4, 5, 6, 7]),
     dict(M=533, N=384, K=64 * 12, kmap=(64, 96), tile=28, pins=[0, 1, 2, 3, 4, 5, 6, 7]),
     dict(M=700, N=300, K=130, tile=28, pins=[1, None, 6, 6, 3, None, None, 1, 4, 4], grid_cap=3),

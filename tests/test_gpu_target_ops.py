@@ -93,6 +93,98 @@ def test_pointwise_relu_conv_bn_matches_the_stock_layers(case):
         assert _rel(a.grad.cpu(), b.grad) < 3e-4, (name, _rel(a.grad.cpu(), b.grad))
 
 
+CONV_CASES = [   # N, C_in, C_out, H, W, (kh, kw), (sh, sw), (ph, pw), dil, relu
+    (4, 32, 32, 16, 16, (3, 3), (1, 1), (1, 1), 1, True),
+    (3, 48, 96, 15, 17, (3, 3), (2, 2), (1, 1), 1, True),       # C not a multiple of 32, odd sizes, stride 2, widening
+    (2, 64, 64, 12, 12, (5, 5), (1, 1), (2, 2), 1, True),       # conv_5x5
+    (2, 128, 64, 9, 9, (7, 7), (1, 1), (3, 3), 1, True),        # conv_7x7, narrowing
+    (5, 16, 24, 8, 8, (3, 3), (2, 2), (1, 1), 1, False),        # no ReLU in front (a stem-like convolution)
+    (1, 256, 512, 6, 6, (3, 3), (1, 1), (1, 1), 1, True),       # the widest tiles
+    (8, 80, 112, 7, 5, (5, 5), (2, 2), (2, 2), 1, True),        # partial pixel tiles
+    (2, 32, 48, 10, 10, (1, 7), (1, 2), (0, 3), 1, True),       # the 1 x k half of a `conv2` pair, asymmetric stride
+    (2, 32, 48, 10, 10, (7, 1), (2, 1), (3, 0), 1, True),
+    (3, 24, 40, 11, 11, (3, 3), (1, 1), (2, 2), 2, True),       # dilation 2
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES)
+def test_conv_bn_matches_the_stock_layers(case):
+    """ghn3_conv_bn_fwd / _bwd (round 6: ReLU -> dense k x k convolution -> BatchNorm as one node, ops.py:180-198) against the
+    stock torch layers in fp64: output, batch statistics and all four gradients; deterministic."""
+    from ghn3_amd import target_ops as T
+    N, Ci, Co, H, W, ks, st, pad, dil, relu = case
+    g = torch.Generator().manual_seed(N + Ci + Co + H + W + sum(ks) + sum(st))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, ks[0], ks[1], generator=g) / (Ci * ks[0] * ks[1]) ** 0.5
+    gamma = 1 + 0.3 * torch.randn(Co, generator=g)
+    beta = 0.2 * torch.randn(Co, generator=g)
+    ref_in = [t.clone().double().requires_grad_(True) for t in (x, w, gamma, beta)]
+    ref = T.conv_reference(*ref_in, stride=st, padding=pad, dilation=dil, relu=relu)
+    up = torch.randn(ref.shape, generator=g)
+    (ref * up.double()).sum().backward()
+    dev_in = [t.cuda().requires_grad_(True) for t in (x, w, gamma, beta)]
+    assert T.ConvBn.applicable(*dev_in)
+    out, stats = T.conv_bn(dev_in[0].contiguous(memory_format=torch.channels_last), dev_in[1], dev_in[2], dev_in[3], stride=st,
+                           padding=pad, dilation=dil, relu=relu)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    (out * up.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert _rel(out.detach().cpu(), ref.detach()) < 2e-4, _rel(out.detach().cpu(), ref.detach())
+    zz = torch.nn.functional.conv2d(torch.relu(x.double()) if relu else x.double(), w.double(), None, st, pad, dil)
+    assert _rel(stats[:Co].cpu(), zz.mean((0, 2, 3))) < 2e-4 and _rel(stats[2 * Co:].cpu(), zz.var((0, 2, 3), unbiased=False)) < 2e-4
+    for name, a, b in zip(('dx', 'dw', 'dgamma', 'dbeta'), dev_in, ref_in):
+        assert a.grad is not None and torch.isfinite(a.grad).all(), name
+        assert a.grad.shape == b.grad.shape and _rel(a.grad.cpu(), b.grad) < 3e-4, (name, _rel(a.grad.cpu(), b.grad))
+    out2, _ = T.conv_bn(dev_in[0].detach().contiguous(memory_format=torch.channels_last), dev_in[1].detach(), dev_in[2].detach(),
+                        dev_in[3].detach(), stride=st, padding=pad, dilation=dil, relu=relu)
+    assert torch.equal(out2, out.detach())
+
+
+def test_relu_conv_bn_module_runs_on_the_dense_op(monkeypatch):
+    """`ReLUConvBN` with a 3 x 3 kernel (the search space's `conv_3x3`): the module's forward goes through ONE fused node, matches the
+    stock layers and updates the running statistics as torch does."""
+    from ghn3_amd import ops, target_ops as T
+    res = {}
+    for mode in ('stock', 'fused'):
+        monkeypatch.setenv('GHN3_NATIVE_OPS', '0' if mode == 'stock' else '1')
+        torch.manual_seed(5)
+        m = ops.ReLUConvBN(32, 48, 3, 2, 1)
+        m.op[2] = torch.nn.BatchNorm2d(48)              # (a TRACKING norm: the search space's own layers do not track)
+        m = m.cuda().train()
+        x = torch.randn(6, 32, 12, 12, device='cuda', requires_grad=True)
+        y = m(x)
+        up = torch.randn(y.shape, generator=torch.Generator().manual_seed(9)).cuda()
+        (y * up).sum().backward()                        # (not mean(y^2): that is constant behind a BatchNorm, its gradient pure round-off)
+        bn = list(m.op)[-1]
+        res[mode] = (y.detach().cpu(), x.grad.cpu(), [p.grad.cpu() for p in m.parameters()], bn.running_mean.cpu(), bn.running_var.cpu(),
+                     type(y.grad_fn).__name__)
+    assert 'ConvBn' in res['fused'][5] or 'Clone' in res['fused'][5] or 'Contiguous' in res['fused'][5], res['fused'][5]
+    assert _rel(res['fused'][0], res['stock'][0]) < 2e-4 and _rel(res['fused'][1], res['stock'][1]) < 5e-4
+    for a, b in zip(res['fused'][2], res['stock'][2]):
+        assert _rel(a, b) < 5e-4
+    assert _rel(res['fused'][3], res['stock'][3]) < 1e-4 and _rel(res['fused'][4], res['stock'][4]) < 1e-4
+
+
+def test_factorized_reduce_runs_as_one_dense_convolution(monkeypatch):
+    """`FactorizedReduce` (ops.py:163-178) on the fused path = a 2 x 2 stride-2 convolution assembled from the two 1 x 1 weights:
+    output and every gradient (input, both convolution weights, norm) against the stock layers."""
+    from ghn3_amd import ops
+    res = {}
+    for mode in ('stock', 'fused'):
+        monkeypatch.setenv('GHN3_NATIVE_OPS', '0' if mode == 'stock' else '1')
+        torch.manual_seed(11)
+        m = ops.FactorizedReduce(24, 40).cuda().train()
+        x = torch.randn(5, 24, 14, 10, device='cuda', requires_grad=True)
+        y = m(x)
+        up = torch.randn(y.shape, generator=torch.Generator().manual_seed(2)).cuda()
+        (y * up).sum().backward()
+        res[mode] = (y.detach().cpu(), x.grad.cpu(), [p.grad.cpu() for p in m.parameters()])
+    assert res['fused'][0].shape == res['stock'][0].shape == (5, 40, 7, 5)
+    assert _rel(res['fused'][0], res['stock'][0]) < 2e-4 and _rel(res['fused'][1], res['stock'][1]) < 5e-4
+    for a, b in zip(res['fused'][2], res['stock'][2]):
+        assert a.shape == b.shape and _rel(a, b) < 5e-4
+
+
 def test_descriptor_limits_are_refused_loudly():
     from ghn3_amd import target_ops as T, _lib as L
     x = torch.randn(1, 6, 4, 4, device='cuda')
@@ -116,7 +208,7 @@ def test_networks_on_the_fused_layers_match_the_stock_path(light, monkeypatch):
     used = 0
     for name, (geno, kw, img) in network_cases.CASES.items():
         g = ops.Genotype(**geno)
-        if not any(n[0].startswith(('sep_conv', 'dil_conv')) for n in g.normal + g.reduce):
+        if not any(n[0].startswith(('sep_conv', 'dil_conv', 'conv_')) for n in g.normal + g.reduce):
             continue
         used += 1
         res = {}

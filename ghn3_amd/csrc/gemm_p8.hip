@@ -68,6 +68,8 @@ template <typename T> __device__ __forceinline__ T* rflp(T* p) {
     return reinterpret_cast<T*>(((uint64_t)hi << 32) | lo);
 }
 
+template <int N> struct P8Int { static constexpr int value = N; };
+
 template <int N> __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
 __device__ __forceinline__ void p8_divmod(int r, int q, int& d, int& m) {   // exact for 0 <= r < 2^24, q > 0 (float reciprocal + correction)
@@ -240,12 +242,30 @@ __device__ __forceinline__ void p8_tile(const GemmProbDev* __restrict__ P, const
     };
     // everything up to half-tile `needed` has landed (this thread's pieces); `last` = newest half-tile issued so far
     auto wait_landed = [&](int last, int needed) {
+#ifndef P8_OLD_WAIT
+        // steady state (both call sites: `last` = a B1 half-tile, three half-tiles B0 / A0 / B1 stay in flight): ONE scalar compare
+        // in front of the counted wait -- the k loop is sensitive to every scalar branch here, all eight waves pass it between two
+        // barriers: the round-5 selection chain cost 180 of a k-tile's 2850 cycles, a nine-way chain of exact counts 380
+        // (tools/p8_replay, profiles/r06m_*); peeling the last k-tiles off into their own loop body bought nothing more
+        if (last <= nq - 1) { wait_vm<NPA0 + 4>(); return; }
+#endif
         last = min(last, nq - 1);
         const int keep = last - needed;               // half-tiles that may stay in flight (3 in steady state)
         int n = 0;                                    // DMA instructions of this wave that may stay in flight
 #pragma unroll
         for (int e = 0; e < 3; ++e)
             if (e < keep && last - e >= 0) { const int j = (last - e) & 3; n += j == 1 ? NPA0 : j == 3 ? NPA1 : 2; }
+#ifdef P8_OLD_WAIT
+        constexpr int NLO = NPA0 < NPA1 ? NPA0 : NPA1;
+        if (n >= 2 * NPA0 + 2) wait_vm<2 * NPA0 + 2>();
+        else if (n >= NPA0 + 4 && NPA0 + 4 < 2 * NPA0 + 2) wait_vm<NPA0 + 4>();
+        else if (n >= NLO + 2) wait_vm<NLO + 2>();
+        else if (n >= 4 && 4 < NLO + 2) wait_vm<4>();
+        else if (n >= NLO && NLO >= 2) wait_vm<(NLO >= 2 ? NLO : 2)>();
+        else if (n >= 2) wait_vm<2>();
+        else wait_vm<0>();
+        return;
+#endif
         // exactly n may stay in flight (n is wave-uniform: scalar compares; at most 2 NPA0 + 2 <= 8)
         if (n >= 8) wait_vm<8>();
         else if (n == 7) wait_vm<7>();
@@ -898,6 +918,317 @@ __global__ __launch_bounds__(512, 2) void gemm_p8w_kernel(const GemmProbDev* __r
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Tile code 30 (round 6): the persistent weight-gradient stream with TWO accumulator sets -- the stores of a finished tile
+// leave during the WHOLE next tile instead of in one burst that stops the matrix cores.
+//
+// Why.  dW2 band problems are output-heavy: K = the family's rows (9 .. 24 k-tiles) against 256 KB of fp32 per 256 x 256 tile.
+// In gemm_p8w_kernel a tile's stores are one quiet burst inside the first k-tile of the next tile: 19k cycles against 2.7k for
+// a k-tile, and the DMA ring is empty behind it (the next k-tiles wait 500 cycles each): the K = 536 problems -- 44 % of the
+// tiles of the bench step -- run at 600 TF, 36 % of their cycles in the burst (tools/p8w_probe, profiles/r06o_*).  The
+// accumulators cannot leave earlier (one set) nor faster (a CU's store path + 64 MB per chip-wide burst).
+// Here a tile is 256 x 128: 64 accumulator registers per lane, so TWO sets fit the 128 the 256 x 256 tile used.  A finished
+// tile's set is copied aside (64 v_mov) and drained one 16 x 32 block per k-tile of the NEXT tile -- through the wave-private
+// LDS image, two full-line store instructions per block -- while the matrix cores work on the other set.  Nothing stalls for
+// stores; the counted DMA wait of a k-tile sees the two store instructions of the previous k-tile, a whole k-tile old.
+//   * 8 waves: wave row wr = wave >> 2 (128 rows), wave column wc = wave & 3 (32 columns); sub-tiles a = 0, 1 (64 rows each).
+//   * k-tile (64 k) = TWO phases: Q(a = 0) then Q(a = 1), 16 MFMAs each (4 row tiles x 2 column tiles x 2 k-steps) -- the
+//     phase length of the 256 x 256 kernels; the B fragments (32 columns) are read once per k-tile.
+//   * LDS: ring of THREE k-tiles x [A0 | B | A1] (16 KB each, 128-byte rows, XOR-swizzled chunks as above) = 144 KB + 2 KB of
+//     store staging per wave = 160 KB.  k-tile G issues the three pieces of k-tile G + 2 (B and A0 in phase 0, A1 in phase
+//     1) into the buffers k-tile G - 1 was read from a k-tile earlier; its wait leaves exactly these six instructions in flight.
+//   * The DMA stream continues across tiles (issue side two k-tiles ahead of the compute side), the first MFMA of a quadrant
+//     of a new tile takes C = 0 as an inline constant.
+// Contract as tile code 29; tiles are 256 x 128 (the runtime numbers them with 128-column tiles).
+// ---------------------------------------------------------------------------------------------------------------------
+template <int CT>
+__global__ __launch_bounds__(512, 2) void gemm_p8d_kernel(const GemmProbDev* __restrict__ probs, int n_probs, int total_tiles_all,
+                                                           int vgrid) {
+    constexpr int MI = 4, BK = 64;
+    constexpr int PIECE = 128 * 128, KT = 3 * PIECE;            // bytes: one piece (A0 / B / A1), one k-tile of the ring
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    char* sm = reinterpret_cast<char*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = rfl(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int r16 = lane & 15, kc = lane >> 4;
+    const int stride = vgrid;
+    const int t_first = (int)blockIdx.x;
+    const int total_tiles = total_tiles_all;
+
+    // first valid tile at or behind id t (XCD-blocked order as tile code 29, 128-column tiles) -> problem, origin, k-tiles
+    auto next_tile = [&](int t, int& idx, int& m0, int& n0, int& nkt) -> int {
+        for (; t < total_tiles; t += stride) {
+            int lo = 0, hi = n_probs - 1;
+            while (lo < hi) {
+                const int mid = (lo + hi + 1) >> 1;
+                if (rfl(probs[mid].tile_start) <= t) lo = mid; else hi = mid - 1;
+            }
+            const GemmProbDev* Q = probs + lo;
+            const int tl = t - rfl(Q->tile_start), x = tl & 7, grp = tl >> 3;
+            const int G = rfl(Q->xcd_cols), Gm = 8 / G;
+            const int tn = rfl(Q->tiles_n), tm = rfl(Q->tiles_m);
+            const int npg = (tn + G - 1) / G;
+            const int nt = (x % G) * npg + grp % npg, mt = (grp / npg) * Gm + x / G;
+            if (nt >= tn || mt >= tm) continue;
+            idx = lo; m0 = mt * 256; n0 = nt * 128; nkt = (rfl(Q->K) + BK - 1) / BK;
+            return t;
+        }
+        return total_tiles;
+    };
+
+    // ---- issue side -------------------------------------------------------------------------------------------------
+    int i_idx = 0, i_m0 = 0, i_n0 = 0, i_nkt = 0;
+    int it = next_tile(t_first, i_idx, i_m0, i_n0, i_nkt);
+    if (it >= total_tiles) return;                    // (uniform over the workgroup)
+    int c_idx = i_idx, c_m0 = i_m0, c_n0 = i_n0, c_nkt = i_nkt, ct = it;
+
+    unsigned oa[2][2], ob[2];
+    const char GAS* Ab = nullptr;
+    const char GAS* Bb = nullptr;
+    const int slot = tid & 7, rb = tid >> 3;
+    const unsigned ck2 = (unsigned)((slot ^ ((rb >> 1) & 7)) * 16);
+    auto load_issue_tile = [&]() {
+        const GemmProbDev* Q = probs + i_idx;
+        Ab = (const char GAS*)rflp(Q->A);
+        Bb = (const char GAS*)rflp(Q->B);
+        const int M = rfl(Q->M), N = rfl(Q->N);
+        const unsigned lda2 = (unsigned)rfl(Q->lda) * 2u, ldb2 = (unsigned)rfl(Q->ldb) * 2u;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int rho = rb + 64 * i;              // buffer row 0 .. 127: wave row rho >> 6, row rho & 63 of its sub-tile
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                oa[h][i] = (unsigned)min(i_m0 + 128 * (rho >> 6) + 64 * h + (rho & 63), M - 1) * lda2 + ck2;
+            ob[i] = (unsigned)min(i_n0 + rho, N - 1) * ldb2 + ck2;
+        }
+    };
+    load_issue_tile();
+    bool i_live = true;
+    int kA = 0, i_left = i_nkt, islot = 0, issued = 0;   // k byte offset, k-tiles left to issue, ring slot (bytes), PIECES issued
+    auto issue = [&](const int j) {                   // j = piece of the k-tile being issued: 0 = B, 1 = A0, 2 = A1
+        if (!i_live) return;
+        char* kt = sm + islot;
+        if (j == 0) {
+            LAS char* dst = (LAS char*)(kt + PIECE + wave * 1024);
+            __builtin_amdgcn_global_load_lds((const void GAS*)(Bb + (ob[0] + (unsigned)kA)), (LAS void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void GAS*)(Bb + (ob[1] + (unsigned)kA)), (LAS void*)(dst + 8192), 16, 0, 0);
+        } else {
+            const int h = j == 2;
+            LAS char* dst = (LAS char*)(kt + (h ? 2 * PIECE : 0) + wave * 1024);
+            __builtin_amdgcn_global_load_lds((const void GAS*)(Ab + (oa[h][0] + (unsigned)kA)), (LAS void*)dst, 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const void GAS*)(Ab + (oa[h][1] + (unsigned)kA)), (LAS void*)(dst + 8192), 16, 0, 0);
+        }
+        ++issued;
+        if (j == 2) {
+            kA += 128;
+            islot = islot == 2 * KT ? 0 : islot + KT;
+            if (--i_left == 0) {                      // the issue side moves on to the workgroup's next tile
+                it = next_tile(it + stride, i_idx, i_m0, i_n0, i_nkt);
+                i_live = it < total_tiles;
+                if (i_live) { load_issue_tile(); kA = 0; i_left = i_nkt; }
+            }
+        }
+    };
+
+    // ---- compute side -----------------------------------------------------------------------------------------------
+    f32x4 acc[2][MI][2], prv[2][MI][2];
+    const int sw = r16 >> 1;
+    const int offA = (64 * wr + r16) * 128 + ((kc ^ sw) << 4);            // + mi * 2048 (inside piece A_a); ^ 64: second k-step
+    const int offB = PIECE + (32 * wc + r16) * 128 + ((kc ^ sw) << 4);    // + ni * 2048
+    u16x8 fa[MI][2], fb[2][2];
+    auto read_a = [&](const char* ring, int a) {
+        const char* base = ring + (a ? 2 * PIECE : 0);
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+            fa[mi][0] = *reinterpret_cast<const u16x8*>(base + offA + mi * 2048);
+            fa[mi][1] = *reinterpret_cast<const u16x8*>(base + (offA ^ 64) + mi * 2048);
+        }
+    };
+    auto read_b = [&](const char* ring) {
+#pragma unroll
+        for (int ni = 0; ni < 2; ++ni) {
+            fb[ni][0] = *reinterpret_cast<const u16x8*>(ring + offB + ni * 2048);
+            fb[ni][1] = *reinterpret_cast<const u16x8*>(ring + (offB ^ 64) + ni * 2048);
+        }
+    };
+    auto mfma_q = [&](int a, const bool first) {      // first: the quadrant starts from zero (inline constant C)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+        const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 2; ++ni)
+                    acc[a][mi][ni] = mfma16x16<CT>(fb[ni][k2], fa[mi][k2], (first && k2 == 0) ? z : acc[a][mi][ni]);
+        __builtin_amdgcn_s_setprio(0);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+
+    // previous tile of this workgroup: its accumulators sit in prv[][][] and leave block by block
+    bool p_valid = false;
+    gf pC = nullptr;
+    int p_ldc = 0, p_M = 0, p_N = 0, p_m0 = 0, p_tile = 0, p_colq = 0, p_wrap = 0;
+    unsigned p_magic = 0;
+    bool p_inner = false;
+    float p_alpha = 1.f;
+    float* p_sq = nullptr;
+    float ss = 0.f;
+    // block q (0 .. 7) = rows 16 (4 a + mi) .. + 15 of the wave row x the wave's 32 columns: through the wave-private 2 KB image
+    // (ds_write_b128 in the accumulator layout, ds_read_b128 as 8 rows x 128 bytes, chunks XOR-swizzled by the row: conflict-free
+    // both ways; a wave's LDS operations execute in order: no barrier), out as two instructions of eight full lines each
+    auto drain_block = [&](const int a, const int mi) __attribute__((always_inline)) {
+        char* stg = sm + 3 * KT + wave * 2048;
+        const int wofs = r16 * 128, wsw = r16 & 7;
+        const int rr0 = lane >> 3, rc = lane & 7;
+        const int rofs = rr0 * 128 + ((rc ^ rr0) << 4);
+        const int col = p_colq + 4 * rc;
+        const int row0 = p_m0 + wr * 128 + 16 * (a * MI + mi);
+        const f32x4 x = prv[a][mi][0] * p_alpha, y = prv[a][mi][1] * p_alpha;
+        {
+            const f32x4 xx = x * x, yy = y * y;
+            const float tx = (xx[0] + xx[1]) + (xx[2] + xx[3]), ty = (yy[0] + yy[1]) + (yy[2] + yy[3]);
+            if (p_inner) ss += tx + ty;
+            else if (row0 + r16 < p_M) {              // (rows / columns beyond the problem hold copies of the last row / column)
+                const int c0 = p_colq + 4 * kc;
+                ss += (c0 < p_N ? tx : 0.f) + (c0 + 16 < p_N ? ty : 0.f);
+            }
+        }
+        *reinterpret_cast<f32x4*>(stg + wofs + ((kc ^ wsw) << 4)) = x;
+        *reinterpret_cast<f32x4*>(stg + wofs + (((4 + kc) ^ wsw) << 4)) = y;
+        f32x4 v[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) v[h] = *reinterpret_cast<const f32x4*>(stg + rofs + 1024 * h);
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int row = row0 + rr0 + 8 * h;
+            if (p_inner || (col < p_N && row < p_M)) {
+                const int mrow = row + (int)__umulhi((unsigned)row, p_magic) * p_wrap;
+                *reinterpret_cast<gf4>(pC + ((int64_t)mrow * p_ldc + col)) = v[h];
+            }
+        }
+    };
+    auto finish_sq = [&]() {                          // behind the last block of a tile
+        float t = ss;
+        ss = 0.f;
+        if (!p_sq) return;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) t += __shfl_xor(t, o, 64);
+        if (lane == 0) p_sq[p_tile * 8 + wave] = t;
+    };
+
+    int G = 0;                                        // k-tiles computed so far
+    int cslot = 0;                                    // ring slot (bytes) of k-tile G
+    // k-tile G + 1 (pieces .. 3 G + 5) has landed; the newer pieces stay in flight (two DMA instructions each; store
+    // instructions of the previous k-tile are older than all of them)
+    auto wait_next_ktile = [&]() {
+        const int keep = issued - (3 * G + 6);
+        if (keep >= 3) wait_vm<6>();
+        else if (keep == 2) wait_vm<4>();
+        else if (keep == 1) wait_vm<2>();
+        else wait_vm<0>();
+    };
+    // Q: block of the previous tile this k-tile drains (compile time; < 0: none)
+    auto ktile = [&](const bool first, const auto qc) __attribute__((always_inline)) {
+        constexpr int Q = decltype(qc)::value;
+        const char* ring = sm + cslot;
+        read_b(ring);
+        __builtin_amdgcn_sched_barrier(0);
+        read_a(ring, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(0);
+        issue(1);
+        __builtin_amdgcn_s_barrier();
+        mfma_q(0, first);
+        __builtin_amdgcn_s_barrier();
+        read_a(ring, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        issue(2);
+        wait_next_ktile();
+        if (Q >= 0) {
+            if (p_valid) {
+                drain_block(Q >> 2, Q & 3);
+                if (Q == 7) { finish_sq(); p_valid = false; }
+            }
+        }
+        __builtin_amdgcn_s_barrier();
+        mfma_q(1, first);
+        __builtin_amdgcn_s_barrier();
+        ++G;
+        cslot = cslot == 2 * KT ? 0 : cslot + KT;
+    };
+
+    // prologue: k-tiles 0 and 1 of the stream (six pieces); k-tile 0 must have landed
+    issue(0); issue(1); issue(2);
+    issue(0); issue(1); issue(2);
+    {
+        const int keep = issued - 3;
+        if (keep >= 3) wait_vm<6>(); else if (keep == 2) wait_vm<4>(); else if (keep == 1) wait_vm<2>(); else wait_vm<0>();
+    }
+    __builtin_amdgcn_s_barrier();
+    if (wr == 1) __builtin_amdgcn_s_barrier();        // wave row 1 runs one barrier behind
+
+#define P8D_Q(n) P8Int<n>{}
+    while (ct < total_tiles) {
+        // the first eight k-tiles of a tile drain one block of the previous tile each; shorter tiles drain the rest in a burst
+        ktile(true, P8D_Q(0));
+        if (c_nkt > 1) ktile(false, P8D_Q(1));
+        if (c_nkt > 2) ktile(false, P8D_Q(2));
+        if (c_nkt > 3) ktile(false, P8D_Q(3));
+        if (c_nkt > 4) ktile(false, P8D_Q(4));
+        if (c_nkt > 5) ktile(false, P8D_Q(5));
+        if (c_nkt > 6) ktile(false, P8D_Q(6));
+        if (c_nkt > 7) ktile(false, P8D_Q(7));
+        for (int kt = 8; kt < c_nkt; ++kt) ktile(false, P8D_Q(-1));
+        if (p_valid) {                                // (fewer than eight k-tiles: the remaining blocks now)
+            if (c_nkt <= 1) drain_block(0, 1);
+            if (c_nkt <= 2) drain_block(0, 2);
+            if (c_nkt <= 3) drain_block(0, 3);
+            if (c_nkt <= 4) drain_block(1, 0);
+            if (c_nkt <= 5) drain_block(1, 1);
+            if (c_nkt <= 6) drain_block(1, 2);
+            drain_block(1, 3);
+            finish_sq();
+            p_valid = false;
+        }
+        {                                             // this tile's accumulators move aside and leave during the next tile
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+                    for (int ni = 0; ni < 2; ++ni) prv[a][mi][ni] = acc[a][mi][ni];
+            const GemmProbDev* Q = probs + c_idx;
+            pC = (gf)rflp(Q->C);
+            p_ldc = rfl(Q->ldc); p_M = rfl(Q->M); p_N = rfl(Q->N);
+            p_m0 = c_m0;
+            const int cq = rfl(Q->c_q), cs = rfl(Q->c_s);
+            const float* amax_p = rflp(Q->alpha_amax);
+            p_alpha = rflf(amax_p ? Q->alpha * ghn3_pow2_inv_scale(*amax_p) : Q->alpha);
+            p_sq = (rfl(Q->flags) & GHN3_GEMM_SUMSQ) ? rflp(Q->aux_out) : nullptr;
+            p_tile = ct;
+            p_valid = true;
+            p_colq = rfl(c_n0 + wc * 32);
+            p_inner = c_m0 + 256 <= p_M && c_n0 + 128 <= p_N;
+            p_magic = (unsigned)rfl((int)(cq > 0 ? (unsigned)(4294967296.0 / (double)cq) + 1u : 0u));   // (M q < 2^32: checked by the runtime)
+            p_wrap = cq > 0 ? cs - cq : 0;
+        }
+        ct = next_tile(ct + stride, c_idx, c_m0, c_n0, c_nkt);
+    }
+#undef P8D_Q
+    if (wr == 0) __builtin_amdgcn_s_barrier();        // pairs the extra barrier of wave row 1
+    if (p_valid) {
+        drain_block(0, 0); drain_block(0, 1); drain_block(0, 2); drain_block(0, 3);
+        drain_block(1, 0); drain_block(1, 1); drain_block(1, 2); drain_block(1, 3);
+        finish_sq();
+    }
+}
+
+constexpr int kP8dLds = 3 * 3 * 128 * 128 + 8 * 2048;   // ring of three k-tiles + 2 KB of store staging per wave: 160 KB
+
 constexpr int kP8Lds = 2 * (2 * 5 * 4096 + 32768);    // MI = 5: 144 KB
 constexpr int kP8wLds = 128 * 1024 + 8 * 4096;         // the weight gradient's ring (MI = 4) + 4 KB of store staging per wave: 160 KB
 
@@ -919,6 +1250,10 @@ int ghn3_gemm_p8_init() {
         e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_F16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8wLds);
     if (e == hipSuccess)
         e = hipFuncSetAttribute((const void*)gemm_p8w_kernel<GHN3_CT_BF16, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8wLds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)gemm_p8d_kernel<GHN3_CT_F16>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8dLds);
+    if (e == hipSuccess)
+        e = hipFuncSetAttribute((const void*)gemm_p8d_kernel<GHN3_CT_BF16>, hipFuncAttributeMaxDynamicSharedMemorySize, kP8dLds);
     if (e != hipSuccess) { ghn3_set_error("hipFuncSetAttribute(p8): %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     {
         int dev = 0, n_cu = 0;
@@ -987,5 +1322,30 @@ int ghn3_gemm_p8w_launch(const GemmProbDev* d_probs, int n_probs, int total_tile
                            total_tiles, grid, tpw_arg);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { ghn3_set_error("p8w gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
+    return GHN3_OK;
+}
+
+// tile code 30: persistent stream with two accumulator sets, 256 x 128 tiles (one workgroup per CU, or per CU the caller leaves
+// to this launch; a multiple of 8 so that a workgroup's tiles keep their XCD)
+int ghn3_gemm_p8d_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int ctype, int grid_cap, hipStream_t stream) {
+    if (n_probs <= 0 || total_tiles <= 0) return GHN3_OK;
+    if (ctype != GHN3_CT_F16 && ctype != GHN3_CT_BF16) {
+        ghn3_set_error("8-phase GEMM needs compute type f16 or bf16 (got %d)", ctype);
+        return GHN3_E_ARG;
+    }
+    int rc = ghn3_gemm_p8_init();
+    if (rc) return rc;
+    grid_cap &= 0xffff;
+    int grid = grid_cap > 0 ? grid_cap : g_p8_n_cu;
+    if (grid > total_tiles) grid = total_tiles;
+    grid = grid >= 8 ? grid / 8 * 8 : grid;
+    if (grid < 8) grid = 8 < total_tiles ? 8 : total_tiles;     // (fewer than 8 tiles: one workgroup each)
+    if (total_tiles >= 8 && grid % 8) grid = 8;
+    if (ctype == GHN3_CT_F16)
+        hipLaunchKernelGGL(gemm_p8d_kernel<GHN3_CT_F16>, dim3(grid), dim3(512), kP8dLds, stream, d_probs, n_probs, total_tiles, grid);
+    else
+        hipLaunchKernelGGL(gemm_p8d_kernel<GHN3_CT_BF16>, dim3(grid), dim3(512), kP8dLds, stream, d_probs, n_probs, total_tiles, grid);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { ghn3_set_error("p8d gemm launch: %s", hipGetErrorString(e)); return GHN3_E_HIP; }
     return GHN3_OK;
 }

@@ -49,6 +49,8 @@ int ghn3_gemm_p8_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles
                         hipStream_t stream);
 int ghn3_gemm_p8w_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int ctype, int grid_cap,
                          hipStream_t stream);
+int ghn3_gemm_p8d_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int ctype, int grid_cap,
+                         hipStream_t stream);
 int ghn3_gemm_x3_init();
 int ghn3_gemm_x3_tile(int code, int slice, int* bm, int* bn);
 int ghn3_gemm_x3_launch(const GemmProbDev* d_probs, int n_probs, int total_tiles, int code, int slice,

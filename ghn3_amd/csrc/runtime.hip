@@ -216,7 +216,7 @@ static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
     if (p.flags & GHN3_GEMM_OP16) {
         // tile codes 16 / 24 = the 16-bit-operand kernel with 128 x 128 / 256 x 256 tiles.  The big tile has twice
         // the arithmetic intensity but runs one 512-thread block per CU: it needs enough tiles to fill the chip.
-        if (forced == 16 || forced == 24 || forced == 20 || forced == 25 || forced == 29) return forced;
+        if (forced == 16 || forced == 24 || forced == 20 || forced == 25 || forced == 29 || forced == 30) return forced;
         // 28 = the 8-phase kernel ((192 | 256 | 320) x 256 tiles): everything it can take that has at least ~a tile of rows;
         // the rest of the op (small families, atomically split problems) stays on the 128 x 128 kernel
         if (forced == 28) {
@@ -250,7 +250,7 @@ static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
 }
 
 struct Launch { int a_mode, b_mode, tile, first, count, tiles, with_ln, max_slice; };
-static inline bool is16(int tl) { return tl == 16 || tl == 24 || tl == 20 || tl == 25 || tl == 28 || tl == 29; }   // 16-bit-operand kernels
+static inline bool is16(int tl) { return tl == 16 || tl == 24 || tl == 20 || tl == 25 || tl == 28 || tl == 29 || tl == 30; }   // 16-bit-operand kernels
 
 extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_gemm_problem* problems, int n_problems,
                         void* const* bufs, int n_bufs, void* stream_) {
@@ -296,8 +296,8 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                 for (int bm = 0; bm < 2; ++bm)
                     for (int tl : codes) {
                         Launch L{am, bm, tl, (int)pos, 0, 0, 0, 0};
-                        int te = tl == 16 ? 128 : (tl == 24 || tl == 20 || tl == 25 || tl == 28 || tl == 29) ? 256 : tl == 48 ? 64 : tl == 49 ? 128 : tl;   // tile edge (rows)
-                        int te_n = tl == 20 ? 128 : te;                                        // (columns)
+                        int te = tl == 16 ? 128 : (tl == 24 || tl == 20 || tl == 25 || tl == 28 || tl == 29 || tl == 30) ? 256 : tl == 48 ? 64 : tl == 49 ? 128 : tl;   // tile edge (rows)
+                        int te_n = (tl == 20 || tl == 30) ? 128 : te;                                        // (columns)
                         const bool x3 = tl >= 4000;
                         const bool x3old = x3 && tl < 5000;
                         if (x3old && !ghn3_gemm_x3_tile(40 + (tl - 4000) / 10, 64 * (tl % 10), &te, &te_n)) {
@@ -363,22 +363,22 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                                                "16-byte aligned C / aux / residual", k, q);
                                 return GHN3_E_ARG;
                             }
-                            if ((tl == 25 || tl == 29) && (p.bias.buf >= 0 || p.residual.buf >= 0 || p.aux_in.buf >= 0 ||
-                                             (p.aux_out.buf >= 0 && !(tl == 29 && (p.flags & GHN3_GEMM_SUMSQ))) ||
+                            if ((tl == 25 || tl == 29 || tl == 30) && (p.bias.buf >= 0 || p.residual.buf >= 0 || p.aux_in.buf >= 0 ||
+                                             (p.aux_out.buf >= 0 && !((tl == 29 || tl == 30) && (p.flags & GHN3_GEMM_SUMSQ))) ||
                                              p.act != GHN3_ACT_NONE || p.dact != GHN3_DACT_NONE || p.a_gather.buf >= 0 ||
                                              p.b_gather.buf >= 0 || p.c_gather.buf >= 0 || p.a_q || p.b_q || p.b_kq ||
                                              p.lim.buf >= 0 || p.ksplit > 1 || (p.flags & GHN3_GEMM_ACCUM))) {
-                                ghn3_set_error("op %d problem %d: tile 25 / 29 (persistent output-heavy kernels) take plain "
+                                ghn3_set_error("op %d problem %d: tile 25 / 29 / 30 (persistent output-heavy kernels) take plain "
                                                "problems only: C = alpha A B^T with an optional row map of C", k, q);
                                 return GHN3_E_ARG;
                             }
-                            if (tl == 29 && ((p.N & 3) || p.K < 1 || (int64_t)p.M * p.lda * 2 >= (int64_t)0xfff00000 ||
+                            if ((tl == 29 || tl == 30) && ((p.N & 3) || p.K < 1 || (int64_t)p.M * p.lda * 2 >= (int64_t)0xfff00000 ||
                                              (int64_t)p.N * p.ldb * 2 >= (int64_t)0xfff00000)) {
                                 ghn3_set_error("op %d problem %d: tile 29 needs N %% 4 == 0, K >= 1 and operands below 4 GB", k, q);
                                 return GHN3_E_ARG;
                             }
                             // (the 8-phase kernels take the quotient of the row map of C from one 32-bit multiply-high: exact while M q < 2^32)
-                            if ((tl == 28 || tl == 29) && p.c_q > 0 && (int64_t)p.M * p.c_q >= ((int64_t)1 << 32)) {
+                            if ((tl == 28 || tl == 29 || tl == 30) && p.c_q > 0 && (int64_t)p.M * p.c_q >= ((int64_t)1 << 32)) {
                                 ghn3_set_error("op %d problem %d: tiles 28 / 29 need rows x row-map period below 2^32", k, q);
                                 return GHN3_E_ARG;
                             }
@@ -486,7 +486,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                             g.xcd_cols = 0;
                             if (pin_x >= 0) {
                                 // (ids were reserved above: [0, pin_end))
-                            } else if (tl == 25 || tl == 29) {
+                            } else if (tl == 25 || tl == 29 || tl == 30) {
                                 // XCD-blocked order of the persistent kernel: the 8 XCDs form a (8 / G) x G grid; an XCD
                                 // works on every (8 / G)-th row tile and on one of G column groups, chosen so that its
                                 // share of B stays in its 4 MB L2 while the A tiles stream through once per column group
@@ -622,6 +622,9 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
                     rc = ghn3_gemm_wg_launch(ds + L.first, L.count, L.tiles, gemm_cap, L.tile == 49 ? 128 : 64, stream);
                 else if (L.tile == 32)
                     rc = ghn3_gemm_small_launch(ds + L.first, L.count, L.tiles, L.a_mode, L.b_mode, L.with_ln, stream);
+                else if (L.tile == 30)
+                    rc = ghn3_gemm_p8d_launch(ds + L.first, L.count, L.tiles,
+                                              (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, gemm_cap, stream);
                 else if (L.tile == 29)
                     rc = ghn3_gemm_p8w_launch(ds + L.first, L.count, L.tiles,
                                               (o.flags & 0xff) ? ((o.flags & 0xff) - 1) : c->ctype, gemm_cap, stream);

@@ -2211,7 +2211,8 @@ class Program:
                 # The table covers every tile id of the launch (the runtime numbers a problem's tiles XCD-blocked: at most
                 # tiles + 8 (tiles_m + tiles_n + 1) ids per problem); ids without a tile keep the zero of the memset.
                 wg_tile = int(os.environ.get('GHN3_WGRAD_TILE', '29'))
-                sq_on = covered and all(g_['op16'] for g_ in self.gemm_groups) and wg_tile == 29 and \
+                wg_tn = 128 if wg_tile == 30 else 256     # (column width of the kernel's tiles: its tile ids index the slots)
+                sq_on = covered and all(g_['op16'] for g_ in self.gemm_groups) and wg_tile in (29, 30) and \
                     os.environ.get('GHN3_WGRAD_SUMSQ', '1') != '0'
                 sq_ids = 0
                 n_before = len(self._ops)               # (the zero-fill of the sum-of-squares slots belongs to the weight gradient:
@@ -2220,7 +2221,7 @@ class Program:
                         thr = sorted({m_['o'] for m_ in b_['members']}, reverse=True)
                         for j, o_hi in enumerate(thr):
                             o_lo = thr[j + 1] if j + 1 < len(thr) else 0
-                            tm, tn = ((o_hi - o_lo) * b_['bw'] + 255) // 256, (8 * C + 255) // 256
+                            tm, tn = ((o_hi - o_lo) * b_['bw'] + 255) // 256, (8 * C + wg_tn - 1) // wg_tn
                             sq_ids += tm * tn + 8 * (tm + tn + 1)
                     sq_ref = self.wsf('dw2_sq', 8 * sq_ids)
                     self.op(L.OP_MEMSET0, refs=(sq_ref,), ints=(4 * 8 * sq_ids,))

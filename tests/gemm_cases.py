@@ -410,6 +410,17 @@ OP16_CASES = [
     dict(M=700, N=3072 // 4, K=64, tile=25, grid_cap=2, cmap=True),
     dict(M=5, N=7, K=9, tile=25),
     dict(M=2048, N=1024, K=768, a_transposed=True, b_transposed=True, tile=25, grid_cap=5),
+    # tile code 30 (round 6, an experiment kept behind GHN3_WGRAD_TILE=30): the persistent stream with two accumulator sets
+    # (256 x 128 tiles; the stores of a tile leave during the next one): short / long reductions (fewer / more than the eight
+    # k-tiles the drain is spread over), row map, ragged edges, grid caps
+    dict(M=300, N=520, K=150, tile=30),
+    dict(M=1100, N=1300, K=512, tile=30, grid_cap=3),
+    dict(M=1100, N=780, K=64 * 3, tile=30, grid_cap=2),
+    dict(M=700, N=3072 // 4, K=64, tile=30, grid_cap=2, cmap=True),
+    dict(M=5, N=7 * 4, K=9, tile=30),
+    dict(M=2048, N=1024, K=768, a_transposed=True, b_transposed=True, tile=30, grid_cap=5),
+    dict(M=2100, N=1156, K=64 * 9 + 24, tile=30, cmap=True),
+    dict(M=520, N=384, K=64 * 24, tile=30, grid_cap=8),
     # the persistent 8-phase stream (tile code 29): the DMA stream continues across tile boundaries, a tile's stores are
     # deferred into the next tile's first k-tile; one / two / many k-tiles per tile (stream shorter than the look-ahead),
     # more tiles than workgroups, a row map of C, ragged M / N

@@ -551,7 +551,7 @@ def test_f16_mode_agrees_with_the_fp32_mode_on_varied_batches(name, batches):
     very ragged batches (six nodes is the smallest synthetic graph), N > 256 (other attention instantiation) -- the f16 operand mode (8-phase kernels with row-tile
     tables, pinned / sub-split dgrad chunks, persistent weight-gradient stream, split-bf16 Graphormer GEMMs) against the
     exact-fp32 mode of the same library, which the oracle tests pin at smaller sizes: every predicted tensor within 1e-3,
-    every parameter gradient within 1.5e-3, everything finite.  (Weights: the seeded state dict of the oracle tests.  With
+    every parameter gradient within 1e-3 (one documented pair at 1.2e-3), everything finite.  (Weights: the seeded state dict of the oracle tests.  With
     torch's default initialisation one hidden unit of decoder_1d had a pre-activation of 3e-6 rms on the -- identical --
     padded rows that quirk Q1 makes 68 bias / norm nodes read: its ReLU mask differs between any two arithmetics that differ at
     1e-5, the gradients downstream of it by 1 %.  Measured, understood, not a defect of either mode: tools/diag/modes_diag*.py.)"""
@@ -589,11 +589,68 @@ def test_f16_mode_agrees_with_the_fp32_mode_on_varied_batches(name, batches):
             a, b = gflat[int(off):int(off) + n], g32[int(off):int(off) + n]
             err, ref = float((a - b).norm()), float(b.norm())
             worst_g = max(worst_g, err / (ref + 1e-4))
-            # (1.5e-3: the worst measured pair is dW2 on the [6, 12, 256] batch at 1.05e-3 -- three chained f16 roundings
-            # over a batch whose gradients span four decades; the oracle-size cases above hold the 1e-3 gate)
-            assert err < 1.5e-3 * ref + 1e-5, (nodes, pname, err, ref)
+            # (gate 1e-3; ONE batch of this list is a documented tail case of the f16 operands: dW2 on [6, 12, 256] sits at
+            # 1.05e-3 -- a weight gradient whose per-row contributions cancel to a fifth of their random-sign sum, so the
+            # 2^-11 rounding of the two 16-bit operands shows at 2-3x its typical share; test_f16_gradient_tail_... below
+            # quantifies how often that happens)
+            gate = 1.2e-3 if (nodes == [6, 12, 256] and pname == 'decoder.conv.2.weight') else 1e-3
+            assert err < gate * ref + 1e-5, (nodes, pname, err, ref)
         print('%s %s: f16 vs fp32 mode, worst gradient rel-L2 %.2e' % (name, nodes, worst_g))
         del res
+
+
+def test_f16_gradient_tail_on_forty_random_batches():
+    """The robustness sweep of tools/diag/modes_sweep.py as a test: the first 40 batches of its random stream (1-4 graphs of
+    6-329 nodes, ghn3xlm16, seeded weights) in the f16 mode against the exact-fp32 mode of the same library.  Gates: every
+    predicted tensor within 1e-3; every parameter gradient within 1e-3 on every one of the 40 batches.  Measured over 500
+    batches of the same stream (profiles/r05z_modes_sweep_*, r06l_*): median worst gradient 3.5e-4, 99 % below 8.9e-4, 0.7-0.8 %
+    of the batches above 1e-3 -- always decoder.conv.2.weight, max 2.83e-3 (batch 198, one 65-node graph): a weight gradient
+    whose row contributions cancel far below their random-sign sum, where the 2^-11 rounding of the 16-bit operands is not
+    averaged down.  That batch is run here too, with its measured bound (3e-3), so that a regression of the tail is seen."""
+    from ghn3_amd import GHN3
+    from ghn3_amd.synthetic import synthetic_batch
+    import recipe
+    name = 'ghn3xlm16'
+    shapes = {k: tuple(v.shape) for k, v in GHN3(**_cfg(name)).state_dict().items()}
+    sd = {k: torch.from_numpy(v) for k, v in recipe.seeded_state_dict(shapes, seed=7).items()}
+    models = {}
+    for compute in ('f16', 'f32'):
+        m = GHN3(**_cfg(name), compute=compute)
+        m.load_state_dict(sd)
+        models[compute] = m.to('cuda').train()
+    rs = np.random.RandomState(123)
+    stream = []
+    for k in range(199):
+        B = int(rs.choice([1, 1, 2, 3, 4]))
+        stream.append((k, [int(rs.randint(6, 330)) for _ in range(B)]))
+    worst = []
+    for k, nodes in stream[:40] + [stream[198]]:
+        res = {}
+        for compute in ('f16', 'f32'):
+            hip = models[compute]
+            gb, nets = synthetic_batch(nodes, 5000 + 31 * k)
+            plan = hip.compile(nets, gb, training=True)
+            dout = torch.empty(plan.program.out_numel, dtype=torch.float32, device='cuda')
+            res[compute] = (hip, plan) + _bench_step(hip, plan, dout)
+        hip, plan, out, gflat, _ = res['f16']
+        _, _, out32, g32, _ = res['f32']
+        assert torch.isfinite(gflat).all(), (k, nodes)
+        for p in plan.program.predicted:
+            a, b = out[p['offset']:p['offset'] + p['numel']], out32[p['offset']:p['offset'] + p['numel']]
+            assert float((a - b).norm() / (b.norm() + 1e-12)) < 1e-3, (k, nodes, p['attr'])
+        params = dict(hip.named_parameters())
+        wg = (0.0, '')
+        for pname, off in zip(plan.program.names, hip._offs):
+            n = params[pname].numel()
+            a, b = gflat[int(off):int(off) + n], g32[int(off):int(off) + n]
+            ref = float(b.norm())
+            if ref > 1e-3:
+                wg = max(wg, (float((a - b).norm()) / ref, pname))
+        worst.append((k, nodes, wg))
+        del res
+    for k, nodes, (e, pname) in worst:
+        assert e < (3e-3 if k == 198 else 1e-3), (k, nodes, e, pname)
+    assert worst[-1][2][1] == 'decoder.conv.2.weight' or worst[-1][2][0] < 1e-3     # (the tail lives in dW2 and nowhere else)
 
 
 @pytest.mark.parametrize('case', ['b1', 'b2r'])

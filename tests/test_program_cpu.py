@@ -599,3 +599,40 @@ def test_weight_gradient_schedule_of_the_bench_workload(monkeypatch):
     assert late.wgrad_order == 'late' and 64 <= late.wgrad_cap <= 224 and late.wgrad_cap % 8 == 0
     small = compile_('ghn3tm8', [64])
     assert small.wgrad_cap == 0 and small.wgrad_order != 'first'
+
+
+def test_balanced_row_tiles_and_column_ranges():
+    """Round 6 tilings of the 8-phase W2 kernels (host logic only): equal row tiles per streamed panel, dense column ranges cut at
+    the members' output widths, the fine-grained dynamic program of the dgrad, and the rows every range / chunk covers."""
+    from ghn3_amd.program import Program
+    # 533 full-width rows: 2 x 288 (not 256 + 320); 660 / 672 rows: 3 x 224; 768: 3 x 256; small families: one skinny tile
+    assert Program.balanced_tiles(533) == (2, 9) and Program.balanced_tiles(660) == (3, 7) and Program.balanced_tiles(768) == (3, 8)
+    assert Program.balanced_tiles(109) == (1, 4) and Program.balanced_tiles(40) == (1, 2) and Program.balanced_tiles(256) == (1, 8)
+    for rows in (1, 63, 64, 65, 191, 192, 193, 320, 321, 1421, 3273):
+        t, n = Program.balanced_tiles(rows)
+        assert n in Program.P8_HEIGHTS and t * 32 * n >= rows and (t - 1) * 32 * n < rows
+    fam = dict(i_ld=384, rows=768, subs=[dict(o=384, rows=533), dict(o=128, rows=127), dict(o=64, rows=12), dict(o=32, rows=96)])
+    rng = Program.column_ranges(fam)
+    assert rng == [(0, 32, 768), (32, 64, 672), (64, 128, 660), (128, 384, 533)]
+    assert sum((hi - lo) * fam['i_ld'] * alive for lo, hi, alive in rng) == sum(sb['o'] * fam['i_ld'] * sb['rows'] for sb in fam['subs'])
+    # a narrow range is merged into the next wider one (its rows compute a few don't-care columns)
+    fam2 = dict(i_ld=8, rows=100, subs=[dict(o=64, rows=60), dict(o=16, rows=40)])
+    assert Program.column_ranges(fam2) == [(0, 64, 100)]
+    # row tables: equal tiles over the alive rows, 320-row zero-fill tiles behind them, extents shifted into the K chunk
+    ext = np.asarray([147456] * 533 + [49152] * 127 + [24576] * 12 + [12288] * 96)
+    mt = Program.range_tiles(533, 768, lambda r: ext[r], k0=49152 + 1024, kc=4096)
+    assert mt.tolist() == [[0, 9, 4096], [288, 9, 4096], [576, 10, 0]]
+    mt = Program.range_tiles(768, 768, lambda r: ext[r], k0=0, kc=12288)
+    assert mt[:, 1].tolist() == [8, 8, 8] and mt[:, 2].tolist() == [12288, 12288, 12288]
+    # the dgrad's dynamic program on 32-row positions never pays more than the 64-row one of rounds 3-5
+    fine = Program.row_tiles(ext)
+    assert fine[:, 0].tolist() == sorted(fine[:, 0].tolist()) and int(fine[-1, 0]) + 32 * int(fine[-1, 1]) >= 768
+    cost = lambda t: sum(Program.P8_COSTN[int(n)] * float(e) for _, n, e in t)
+    old = [(0, 8, 147456), (256, 10, 147456), (576, 6, 49152)]
+    assert cost(fine) <= cost(old) + 1e-6
+    covered = np.zeros(768, bool)
+    for m0, n, e in fine:
+        assert not covered[m0:m0 + 32 * n].any()
+        covered[m0:m0 + 32 * n] = True
+        assert int(ext[m0]) == int(e)                  # a tile pays for (and is cut at) the extent of its first row
+    assert covered.all()

@@ -24,6 +24,7 @@ static void fill_rand(unsigned short* p, size_t n, unsigned seed) {
     for (size_t o = 0; o < n; o += h.size()) hipMemcpy(p + o, h.data(), 2 * std::min(h.size(), n - o), hipMemcpyHostToDevice);
 }
 
+static int g_cap = 0;
 static void replay(const char* path, int reps) {
     FILE* f = fopen(path, "r");
     if (!f) { printf("%s: cannot open\n", path); return; }
@@ -93,13 +94,13 @@ static void replay(const char* path, int reps) {
     if (n_pinned) for (int x = 0; x < 8; ++x) { hp[x].pin_first = pin_first[x]; hp[x].pin_count = pin_count[x]; }
     GemmProbDev* dp; hipMalloc(&dp, sizeof(GemmProbDev) * hp.size());
     hipMemcpy(dp, hp.data(), sizeof(GemmProbDev) * hp.size(), hipMemcpyHostToDevice);
-    for (int rep = 0; rep < 2; ++rep) ghn3_gemm_p8_launch(dp, n, tiles, GHN3_CT_F16, 0, 0);
+    for (int rep = 0; rep < 2; ++rep) ghn3_gemm_p8_launch(dp, n, tiles, GHN3_CT_F16, g_cap, 0);
     hipDeviceSynchronize();
     unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0}, st[8];
     hipMemcpyToSymbol(HIP_SYMBOL(g_p8_probe), z, sizeof(z));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
-    for (int r = 0; r < reps; ++r) ghn3_gemm_p8_launch(dp, n, tiles, GHN3_CT_F16, 0, 0);
+    for (int r = 0; r < reps; ++r) ghn3_gemm_p8_launch(dp, n, tiles, GHN3_CT_F16, g_cap, 0);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_p8_probe), sizeof(st));
@@ -110,6 +111,8 @@ static void replay(const char* path, int reps) {
 }
 
 int main(int argc, char** argv) {
+    // GHN3_REPLAY_CAP: grid cap of the launch (0 = one workgroup per tile id; 256 = persistent, one per CU, ids strided)
+    if (getenv("GHN3_REPLAY_CAP")) g_cap = atoi(getenv("GHN3_REPLAY_CAP"));
     for (int i = 1; i < argc; ++i) replay(argv[i], 5);
     return 0;
 }

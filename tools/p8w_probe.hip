@@ -11,6 +11,10 @@
 void ghn3_set_error(const char* fmt, ...) { va_list a; va_start(a, fmt); vfprintf(stderr, fmt, a); va_end(a); fputc('\n', stderr); }
 
 struct Prob { int M, N, K; int cq = 0, cs = 0; };     // cq, cs: row map of C (r / cq) * cs + r % cq, as the band problems of dW2 have
+static int g_kernel = 29;     // P8W_KERNEL=30: gemm_p8d_kernel (two accumulator sets, 256 x 128 tiles)
+static int launch(const GemmProbDev* dp, int n, int tiles, int cap) {
+    return g_kernel == 30 ? ghn3_gemm_p8d_launch(dp, n, tiles, GHN3_CT_F16, cap, 0) : ghn3_gemm_p8w_launch(dp, n, tiles, GHN3_CT_F16, cap, 0);
+}
 static void run(const char* name, const std::vector<Prob>& ps, int cap = 0) {
     std::vector<GemmProbDev> hp(ps.size());
     int tiles = 0;
@@ -28,7 +32,7 @@ static void run(const char* name, const std::vector<Prob>& ps, int cap = 0) {
         p.A = reinterpret_cast<const float*>(A); p.B = reinterpret_cast<const float*>(B); p.C = C;
         p.M = q.M; p.N = q.N; p.K = q.K; p.lda = ld; p.ldb = ld; p.ldc = q.N; p.alpha = 1.f; p.flags = GHN3_GEMM_OP16;
         p.c_q = q.cq; p.c_s = q.cs;
-        p.tiles_m = (q.M + 255) / 256; p.tiles_n = (q.N + 255) / 256;
+        p.tiles_m = (q.M + 255) / 256; p.tiles_n = g_kernel == 30 ? (q.N + 127) / 128 : (q.N + 255) / 256;
         int G = 1;
         while (G < 8 && (long long)q.N * q.K * 2 / G > (5 << 19) && p.tiles_n >= 2 * G) G *= 2;
         p.xcd_cols = G;
@@ -38,13 +42,13 @@ static void run(const char* name, const std::vector<Prob>& ps, int cap = 0) {
     }
     GemmProbDev* dp; hipMalloc(&dp, sizeof(GemmProbDev) * hp.size());
     hipMemcpy(dp, hp.data(), sizeof(GemmProbDev) * hp.size(), hipMemcpyHostToDevice);
-    for (int rep = 0; rep < 2; ++rep) ghn3_gemm_p8w_launch(dp, (int)hp.size(), tiles, GHN3_CT_F16, cap, 0);
+    for (int rep = 0; rep < 2; ++rep) launch(dp, (int)hp.size(), tiles, cap);
     hipDeviceSynchronize();
     long long st[48];
     hipMemcpyFromSymbol(st, HIP_SYMBOL(g_p8w_probe), sizeof(st));
     hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
     hipEventRecord(e0, 0);
-    for (int r = 0; r < 5; ++r) ghn3_gemm_p8w_launch(dp, (int)hp.size(), tiles, GHN3_CT_F16, cap, 0);
+    for (int r = 0; r < 5; ++r) launch(dp, (int)hp.size(), tiles, cap);
     hipEventRecord(e1, 0); hipEventSynchronize(e1);
     float ms; hipEventElapsedTime(&ms, e0, e1);
     printf("%-44s %7.3f ms  %6.0f TF | workgroup 0: first k-tiles (+ stores) %lld x %lld cycles (DMA wait %lld), other k-tiles %lld x %lld cycles (DMA wait %lld); per store k-tile: in store_prev %lld, at barriers %lld\n",
@@ -65,6 +69,8 @@ static void run(const char* name, const std::vector<Prob>& ps, int cap = 0) {
 }
 
 int main() {
+    if (getenv("P8W_KERNEL")) g_kernel = atoi(getenv("P8W_KERNEL"));
+    printf("kernel: tile code %d\n", g_kernel);
     run("K 536 (9 k-tiles), M 65536", {{65536, 3072, 536}});
     run("K 1480 (24 k-tiles), M 16384", {{16384, 3072, 1480}});
     run("K 3072 (48 k-tiles), M 8192", {{8192, 3072, 3072}});

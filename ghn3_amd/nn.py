@@ -572,7 +572,12 @@ class GHN3(nn.Module):
         elif norm_g is not None:
             raise L.Ghn3Error('the fused norm loss needs a plan with predicted tensors')
         stream = torch.cuda.current_stream().cuda_stream
-        if reducer is None:
+        # GHN3_BWD_PARTS=1 (experiment, round 6): a single process runs the data-parallel ORDER too -- tile backward -> operand
+        # copies -> the persistent weight gradient on the run's own stream and every CU -> dgrad -> rest of the decoder ->
+        # Graphormer backward.  Measured alternating on one box (profiles/r06s_*): 6.12 ms per step against 5.90 for the default
+        # side-stream schedule at one graph, 10.16 / 9.82 at two, 16.27 / 15.96 at four: slower everywhere, off.
+        use_parts = reducer is not None or (len(getattr(prog, 'bwd_parts', ())) > 1 and os.environ.get('GHN3_BWD_PARTS', '0') == '1')
+        if not use_parts:
             self._ctx().run(prog.bwd_ops, prog.problems, plan.bufs, stream)
         else:
             ctx = self._ctx()
@@ -581,16 +586,20 @@ class GHN3(nn.Module):
             if kt is not None:
                 for k_ in patched:                       # (all in front of the W2 weight gradient, i.e. in part 1)
                     prog.bwd_parts[0][0][prog.ddp_index.get(k_, k_)] = prog.bwd_ops[k_]
-            reducer.begin()
+            if reducer is not None:
+                reducer.begin()
             n_off = len(self._offs)
             for ops, slots in prog.bwd_parts:
                 ctx.run(ops, prog.problems, plan.bufs, stream)
+                if reducer is None:
+                    continue
                 for s_lo, s_hi in slots:                 # gradients complete once the side stream has drained
                     if s_hi > s_lo:
                         reducer.start(gflat, int(self._offs[s_lo]),
                                       int(self._offs[s_hi]) if s_hi < n_off else int(self._flat_numel),
                                       wait_for=ctx.side_wait)
-            reducer.finish(gflat)
+            if reducer is not None:
+                reducer.finish(gflat)
         plan.gflat = gflat
         pieces = gflat.split_with_sizes(self._split_sizes)
         return [pieces[2 * k].view(p.shape) for k, p in enumerate(self._slot_params())]

@@ -517,7 +517,10 @@ def main():
         os.environ.setdefault('MASTER_PORT', '29533')
         dist.init_process_group('nccl', rank=rank, world_size=world)
 
-    dog = Watchdog(float(os.environ.get('GHN3_STALL_S', '60')), rank) if world > 1 else None
+    # (60 s without a finished step ends a rank; until the FIRST step has finished -- RCCL builds its communicators inside it,
+    # tens of seconds on an 8-GPU node -- the limit is five times that)
+    stall_s = float(os.environ.get('GHN3_STALL_S', '60'))
+    dog = Watchdog(5 * stall_s, rank) if world > 1 else None
     beat = (lambda where=None: dog.beat(where)) if dog is not None else (lambda where=None: None)
 
     from ghn3_amd import GHN3, _lib as L
@@ -574,9 +577,12 @@ def main():
         if dog is not None:
             torch.cuda.synchronize()                     # (N > 1: a hang shows up at the step that hangs, not 60 s later)
             beat()
+            dog.limit = stall_s
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
+    if dog is not None and args.warmup > 0:
+        dog.limit = stall_s
     beat('timed region')
     # The timed region runs WITHOUT per-launch events (round 6): the HIP events of profile mode 2 around the nine tagged launch
     # groups of a step -- on two streams -- cost 0.05-0.12 ms of a 5.8 ms step (profiles/r06t_*: 5.82-5.89 with, 5.77 without, same

@@ -96,7 +96,7 @@ enum { GHN3_DACT_NONE = 0, GHN3_DACT_RELU = 1 /* aux_in > 0 */, GHN3_DACT_GELU =
  * planes, x3_slice unused, N % 16 == 0.  These problems may carry the LayerNorm row prologue of A (ln_kind 1 / 2 below,
  * K <= 384, no a_gather): the Graphormer chain then needs no LayerNorm launches (graphormer.py:239-241 and its backward). */
 #define GHN3_GEMM_X3 8u
-/* Tile code 29 only (the persistent weight-gradient kernel): `aux_out` = base of a float slot table; the kernel writes
+/* Tile codes 29 / 30 only (the persistent weight-gradient kernels): `aux_out` = base of a float slot table; the kernel writes
  * the sum of the squares of what it stored of each output tile to aux_out[8 * t + w] (t = the tile's id inside the launch,
  * w = wave 0..7; slots of ids that name no tile are not written: zero the table first).  The squared gradient norm of
  * clip_grad_norm_ (trainer.py:356-360) then needs no pass over dW2: GHN3_OP_SUMSQ adds the slots.  (ABI v16) */
@@ -251,12 +251,15 @@ enum ghn3_op_kind {
     GHN3_OP_NOP = 0,
     /* i: first_problem, n_problems, tile (0 auto / 32 / 64 / 128 for fp32 operands; 0 auto / 16 = 128x128 / 24 = 256x256 /
      * 20 = 256x128 with a three-stage ring / 25 = persistent 256x256 for output-heavy PLAIN problems (C = alpha A B^T,
-     * optional row map of C: short K, e.g. the W2 weight gradient) / 28 = the 8-phase kernel, (192 | 256 | 320) x 256 tiles,
-     * no split-K / gathers (problems of the op with fewer than 160 rows or with ksplit > 1 fall back to 16) for
+     * optional row map of C: short K, e.g. the W2 weight gradient) / 28 = the 8-phase kernel, (64 .. 320) x 256 tiles in steps
+     * the row-tile table names (`mtiles`), no split-K / gathers (problems of the op with fewer than 160 rows or with
+     * ksplit > 1 fall back to 16) for
      * GHN3_GEMM_OP16 problems), grid cap for GHN3_GEMM_OP16 launches (0 = one workgroup per tile; > 0: at most
      * that many CUs' worth of persistent workgroups -- a side-stream GEMM that should leave CUs to the chain it runs beside).
      * Tile codes 28 / 29 take the quotient of the row map of C (c_q, c_s) from one 32-bit multiply-high: M * c_q < 2^32, else
      * GHN3_E_ARG.  29 = the persistent 8-phase kernel for the W2 weight gradient (plain problems like 25; GHN3_GEMM_SUMSQ).
+     * 30 (ABI v19) = the same stream on 256 x 128 tiles with two accumulator sets: the stores of a finished tile leave during
+     * the next tile (contract of 29; the slot table of GHN3_GEMM_SUMSQ is indexed by ITS tile ids, 128-column tiles).
      * fp32 operands additionally: 48 = the split-bf16 weight-gradient kernel (both operands GHN3_MODE_COL fp32 activations,
      * reduction over rows: dW = dY^T X of the Graphormer linears, graphormer.py:208-248 backward; GHN3_GEMM_ACCUM and
      * GHN3_GEMM_BIASGRAD allowed, M % 4 == 0, N % 4 == 0, no gathers / maps / activation / residual / split-K -- problems of

@@ -92,6 +92,14 @@ def test_ghn3xlm16_f16_forward_backward_vs_oracle(nodes, seed):
     _fwd_bwd_vs_oracle('ghn3xlm16', nodes, seed, 'f16', 1e-3, 1e-3)
 
 
+def test_ghn3xlm16_bench_graph_at_full_size_vs_oracle():
+    """The HEADLINE workload itself, unsampled (round 6): ghn3xlm16 on bench.py's seeded 256-node graph (1421 decoder rows, 86.5 M
+    predicted parameters), f16 mode -- EVERY predicted tensor and EVERY GHN parameter gradient in full against the CPU oracle
+    (~60 s of host time), 1e-3 each.  The reference-golden test of the same graph (bench_b1) compares norms + 2048 samples per
+    tensor against the reference class; the oracle is pinned to that class by the golden fixtures at smaller sizes."""
+    _fwd_bwd_vs_oracle('ghn3xlm16', [256], 256000, 'f16', 1e-3, 1e-3)
+
+
 @pytest.mark.parametrize('nodes,seed', [([48], 48000), ([25, 40], 41000), ([150], 150000), ([60, 35, 90], 63000)])
 def test_ghn3lm8_f16_forward_backward_vs_oracle(nodes, seed):
     """Config 3's model: ghn3lm8 (C = 256, 12 layers, 16 heads of 16) forward + backward vs the oracle.  The 150-node graph

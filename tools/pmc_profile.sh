@@ -11,9 +11,9 @@ mkdir -p gpurun_out
 export TMPDIR=/tmp
 export GHN3_NO_SIDE_STREAM=1
 OUT=gpurun_out/${TAG}_pmc_xl_f16.txt
-STEPS=2; WARM=1; NSER=3       # (bench.py ends with max(3, min(10, steps)) serialised, untimed steps for `roofline`: they run the same kernels)
+STEPS=2; WARM=1; NINST=3; NSER=3       # (bench.py: warm-up + timed steps, then max(3, min(10, steps)) instrumented and as many serialised, untimed steps: they all run the same kernels)
 : > $OUT
-echo "# GHN3_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-extras (ghn3xlm16 N=256, f16 mode; side stream serialised so that counters are per kernel); sums over the $((STEPS+WARM+NSER)) steps of the run (warm-up + timed + the serialised roofline pass)" >> $OUT
+echo "# GHN3_NO_SIDE_STREAM=1 rocprofv3 --kernel-trace --pmc <counters> -- python3 bench.py --steps $STEPS --warmup $WARM --no-cpu-baseline --no-extras (ghn3xlm16 N=256, f16 mode; side stream serialised so that counters are per kernel); sums over the $((STEPS+WARM+NINST+NSER)) steps of the run (warm-up + timed + instrumented + the serialised roofline pass)" >> $OUT
 for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES SQ_WAVES SQ_INSTS_MFMA" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY"; do
   name=$(echo $set | cut -d' ' -f1)
   rm -rf /tmp/pmc_$name
@@ -27,6 +27,6 @@ for set in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE S
   fi
 done
 F=$(find /tmp/pmc_FETCH_SIZE -name "*.db" | head -1); W=$(find /tmp/pmc_WRITE_SIZE -name "*.db" | head -1)
-python3 tools/pmc_traffic.py "$F" "$W" $((STEPS+WARM+NSER)) /tmp/pmc_bench_WRITE_SIZE.json > gpurun_out/${TAG}_pmc_traffic_xl_f16.json
+python3 tools/pmc_traffic.py "$F" "$W" $((STEPS+WARM+NINST+NSER)) /tmp/pmc_bench_WRITE_SIZE.json > gpurun_out/${TAG}_pmc_traffic_xl_f16.json
 cat gpurun_out/${TAG}_pmc_traffic_xl_f16.json
 cut -c1-250 $OUT | head -40

@@ -14,6 +14,7 @@ Differences from the reference, all additive: the classes live at module level (
 """
 
 import numbers
+import os
 import operator
 from collections import OrderedDict
 from itertools import islice
@@ -197,6 +198,17 @@ class ModuleList(_Container):
 
 
 # ---- parameter-free layers ---------------------------------------------------------------------------
+def _stock_layout(x):
+    """Round 6 ("lazy layout"): the fused HIP layers of ghn3_amd.target_ops hand their NHWC (channels_last) activations on as
+    they are -- element-wise ops, concatenation and the next fused layer take them without a copy -- and the stock layers
+    that are WRONG on channels_last tensors on this ROCm build convert, here: MIOpen convolution / BatchNorm (wrong parameter
+    gradients, profiles/r05c_*) and ATen's max / average pooling (wrong input gradients: tools/diag/lazy_layout_diag.py,
+    profiles/r06v_*).  A no-op for the NCHW tensors of a network without fused layers."""
+    if x.is_cuda and x.dim() == 4 and not x.is_contiguous():
+        return x.contiguous()
+    return x
+
+
 class AvgPool2d(ModuleEmpty):
     def __init__(self, kernel_size, stride=None, padding=0, ceil_mode=False, count_include_pad=True,
                  divisor_override=None):
@@ -206,8 +218,8 @@ class AvgPool2d(ModuleEmpty):
         self.count_include_pad, self.divisor_override = count_include_pad, divisor_override
 
     def forward(self, x):
-        return F.avg_pool2d(x, self.kernel_size, self.stride, self.padding, self.ceil_mode, self.count_include_pad,
-                            self.divisor_override)
+        return F.avg_pool2d(_stock_layout(x), self.kernel_size, self.stride, self.padding, self.ceil_mode,
+                            self.count_include_pad, self.divisor_override)
 
 
 class MaxPool2d(ModuleEmpty):
@@ -218,8 +230,8 @@ class MaxPool2d(ModuleEmpty):
         self.return_indices, self.ceil_mode = return_indices, ceil_mode
 
     def forward(self, x):
-        return F.max_pool2d(x, self.kernel_size, self.stride, self.padding, self.dilation, ceil_mode=self.ceil_mode,
-                            return_indices=self.return_indices)
+        return F.max_pool2d(_stock_layout(x), self.kernel_size, self.stride, self.padding, self.dilation,
+                            ceil_mode=self.ceil_mode, return_indices=self.return_indices)
 
 
 class AdaptiveAvgPool2d(ModuleEmpty):
@@ -228,7 +240,7 @@ class AdaptiveAvgPool2d(ModuleEmpty):
         self.output_size = output_size
 
     def forward(self, x):
-        return F.adaptive_avg_pool2d(x, self.output_size)
+        return F.adaptive_avg_pool2d(_stock_layout(x), self.output_size)
 
 
 class ReLU(ModuleEmpty):
@@ -290,7 +302,7 @@ class Conv2d(Module):
         self.bias = [out_channels] if bias else None
 
     def forward(self, x):
-        return F.conv2d(x, self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+        return F.conv2d(_stock_layout(x), self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
 
 
 class Linear(Module):
@@ -323,6 +335,7 @@ class BatchNorm2d(Module):
     def forward(self, x):
         use_running = (not self.training) or self.track_running_stats
         batch_stats = self.training or (self.running_mean is None and self.running_var is None)
+        x = _stock_layout(x)
         return F.batch_norm(x, self.running_mean if use_running else None, self.running_var if use_running else None,
                             self.weight, self.bias, batch_stats, 0.0 if self.momentum is None else self.momentum,
                             self.eps)

@@ -58,6 +58,15 @@ def _scratch_floats(lib, d, backward):
     return n
 
 
+def lazy_layout(*layers):
+    """True when a fused block may hand its NHWC output on as it is: every layer of the block is of the light flavour (whose stock
+    Conv2d / BatchNorm2d convert a channels_last input themselves, light_ops._stock_layout) and GHN3_NATIVE_LAZY_LAYOUT is not 0.
+    torch.nn-flavour networks keep the conversion at the fused block's boundary."""
+    if os.environ.get('GHN3_NATIVE_LAZY_LAYOUT', '1') == '0':
+        return False
+    return all(not isinstance(m, torch.nn.Module) for m in layers)
+
+
 def enabled():
     """GHN3_NATIVE_OPS=0 keeps every target-network layer on the stock ATen / MIOpen path (A/B measurements)."""
     return os.environ.get('GHN3_NATIVE_OPS', '1') != '0'
@@ -250,7 +259,7 @@ def run_conv_block(layers, x, keep_layout=False):
         return x
     out, stats = conv_bn(x, w, gamma, beta, conv.stride, conv.padding, _pair(conv.dilation)[0], True, bn.eps)
     _update_running_stats(bn, stats, out, has_run)
-    return out if keep_layout else out.contiguous(memory_format=torch.contiguous_format)
+    return out if (keep_layout or lazy_layout(conv, bn)) else out.contiguous(memory_format=torch.contiguous_format)
 
 
 def run_factorized_reduce(relu, conv_1, conv_2, bn, x, stride=2, keep_layout=False):
@@ -276,7 +285,7 @@ def run_factorized_reduce(relu, conv_1, conv_2, bn, x, stride=2, keep_layout=Fal
         return None
     out, stats = conv_bn(x, w, gamma, beta, 2, 0, 1, True, bn.eps)
     _update_running_stats(bn, stats, out, has_run)
-    return out if keep_layout else out.contiguous(memory_format=torch.contiguous_format)
+    return out if (keep_layout or lazy_layout(conv_1, conv_2, bn)) else out.contiguous(memory_format=torch.contiguous_format)
 
 
 def dwpw_bn(x, w_dw, w_pw, gamma, beta, stride=1, padding=0, dilation=1, eps=1e-5):
@@ -306,7 +315,7 @@ def run_pointwise_block(layers, x, keep_layout=False):
         return x
     out, stats = dwpw_bn(x, None, w_pw, gamma, beta, pw.stride[0], 0, 1, bn.eps)
     _update_running_stats(bn, stats, out, has_run)
-    return out if keep_layout else out.contiguous(memory_format=torch.contiguous_format)
+    return out if (keep_layout or lazy_layout(pw, bn)) else out.contiguous(memory_format=torch.contiguous_format)
 
 
 def _update_running_stats(bn, stats, out, has_run):
@@ -362,4 +371,4 @@ def run_block(layers, x, keep_layout=False):
         return x
     out, stats = dwpw_bn(x, w_dw, w_pw, gamma, beta, dw.stride[0], dw.padding[0], dw.dilation[0], bn.eps)
     _update_running_stats(bn, stats, out, has_run)
-    return out if keep_layout else out.contiguous(memory_format=torch.contiguous_format)
+    return out if (keep_layout or lazy_layout(dw, pw, bn)) else out.contiguous(memory_format=torch.contiguous_format)

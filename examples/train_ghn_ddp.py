@@ -29,12 +29,16 @@ def _draw(task):
     """Worker: one rank's share of one meta-batch (host only)."""
     from ghn3_amd.deepnets1m import SampledNets
     from ghn3_amd.graph import GraphBatch
-    step, rank, per_rank, meta, kw = task
+    step, rank, per_rank, meta, kw, pcfg = task
     nets = SampledNets(**kw)
     base = step * meta + rank * per_rank
     gb = GraphBatch([nets[base + k] for k in range(per_rank)], dense=True)
     gb._cat()
     gb.graphs = None                 # (the per-graph copies of what _cat stacked: half of the pickle)
+    if pcfg is not None:
+        # the GHN's host compile for this batch (index tables, tile descriptors, the op lists: 25-30 ms of Python per step)
+        # happens here too, off the training process's critical path -- Trainer.update's ghn(...) call picks it up
+        gb.precompile(pcfg, training=True, predict_class_layers=True, reduce_graph=True)
     return gb
 
 
@@ -93,7 +97,8 @@ def main():
     # the architecture stream is a pure function of (seed, step): a resumed run continues at the checkpointed position
     # instead of replaying the architectures of step 0 onwards
     first = trainer.start_epoch * args.steps + trainer.start_step
-    queue = pool.imap(_draw, [(st, ddp.rank, per_rank, args.meta_batch_size, kw) for st in range(first, total + 1)])
+    pcfg = ghn.program_config() if os.environ.get('GHN3_WORKER_COMPILE', '1') != '0' else None
+    queue = pool.imap(_draw, [(st, ddp.rank, per_rank, args.meta_batch_size, kw, pcfg) for st in range(first, total + 1)])
     log('training %s (%d parameters) on %d sampled architectures per step, %d x %d images'
         % (args.model, sum(p.numel() for p in ghn.parameters()), args.meta_batch_size, args.batch_size,
            224 if args.imagenet else 32))

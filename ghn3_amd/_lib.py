@@ -68,7 +68,7 @@ OP_NAMES = ['nop', 'gemm', 'graph_prologue', 'embed_nodes', 'edge_hidden', 'bias
             'rank_reduce', 'transpose32', 'param_norm_fin', 'ln_param_grad_batch', 'adamw_cast16']
 
 EXPORTS = ['ghn3_abi_version', 'ghn3_last_error', 'ghn3_ctx_create', 'ghn3_ctx_destroy',
-           'ghn3_ctx_set_compute_type', 'ghn3_ctx_side_wait', 'ghn3_ctx_side_pending', 'ghn3_run', 'ghn3_event_create', 'ghn3_event_record',
+           'ghn3_ctx_set_compute_type', 'ghn3_ctx_side_wait', 'ghn3_ctx_side_pending', 'ghn3_ctx_cache_stats', 'ghn3_run', 'ghn3_event_create', 'ghn3_event_record',
            'ghn3_event_elapsed_ms', 'ghn3_event_destroy', 'ghn3_profile_enable', 'ghn3_profile_read',
            'ghn3_profile_read_tags', 'ghn3_dwpw_scratch_floats', 'ghn3_dwpw_bn_fwd', 'ghn3_dwpw_bn_bwd',
            'ghn3_conv_scratch_floats', 'ghn3_conv_bn_fwd', 'ghn3_conv_bn_bwd']
@@ -101,6 +101,7 @@ def load():
         lib.ghn3_ctx_set_compute_type.argtypes = [ctypes.c_void_p, ctypes.c_int]
         lib.ghn3_ctx_side_wait.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
         lib.ghn3_ctx_side_pending.argtypes = [ctypes.c_void_p]
+        lib.ghn3_ctx_cache_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         lib.ghn3_run.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_int,
                                  ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
         lib.ghn3_event_create.argtypes = [ctypes.POINTER(ctypes.c_void_p)]
@@ -157,6 +158,12 @@ class Context:
     def side_pending(self):
         """True when a DETACHed run's side-stream work has not been joined by a later run yet."""
         return self._lib.ghn3_ctx_side_pending(self._h) == 1
+
+    def cache_stats(self):
+        """(hits, misses) of ghn3_run's store of resolved problem tables since the context was created."""
+        h, m = ctypes.c_int64(0), ctypes.c_int64(0)
+        _check(self._lib.ghn3_ctx_cache_stats(self._h, ctypes.byref(h), ctypes.byref(m)), 'ghn3_ctx_cache_stats')
+        return int(h.value), int(m.value)
 
     def profile(self, mode):
         """0 off, 1 every op (synchronising), 2 only ops flagged OPFLAG_TIMED (no sync until read_tags)."""

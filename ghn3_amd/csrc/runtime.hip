@@ -31,10 +31,30 @@ extern "C" int ghn3_abi_version(void) { return GHN3_ABI_VERSION; }
         }                                                                             \
     } while (0)
 
-static const int kStageSlots = 8;
+static const int kStageSlots = 16;
+
+struct Launch { int a_mode, b_mode, tile, first, count, tiles, with_ln, max_slice; };
+
+// What a staging slot's table was resolved from (copies of the caller's arrays) and the launch groups that came out: a run with
+// the same ops, problems and buffer pointers -- every step of a training loop once the allocator has settled -- reuses the
+// table already on the device: no host resolve (hundreds of problems, ~0.3 ms at ghn3xlm16) and no 100 KB upload in front
+// of the run's first kernel (the blit kernels of that copy sat in the stream: ~50 us per run).
+struct SlotCache {
+    bool valid = false;
+    uint64_t stamp = 0;
+    int n_ops = 0, n_problems = 0, n_bufs = 0;
+    std::vector<ghn3_op> ops;
+    std::vector<ghn3_gemm_problem> problems;
+    std::vector<void*> bufs;
+    std::vector<std::vector<Launch>> launches;
+    hipStream_t up_stream = nullptr;   // the stream the table was uploaded on
+};
 
 struct ghn3_ctx {
-    // ring of staging slots for resolved GEMM problem tables
+    // staging slots for resolved GEMM problem tables (least recently used one is overwritten)
+    SlotCache* cache;
+    uint64_t clock;
+    uint64_t cache_hits, cache_misses;
     GemmProbDev* h_stage[kStageSlots];
     GemmProbDev* d_stage[kStageSlots];
     hipEvent_t ev[kStageSlots];        // the slot's upload has completed (host buffer reusable)
@@ -43,7 +63,6 @@ struct ghn3_ctx {
     bool done_used[kStageSlots];
     hipStream_t copy;                  // problem tables are uploaded here, ahead of the stream that will read them
     size_t cap;            // problems per slot
-    int next;
     int ctype;             // compute type for GEMM operands
     // profiling: 0 off, 1 = every op bracketed + synchronised (diagnostic), 2 = only ops carrying
     // GHN3_OPFLAG_TIMED get an event pair from a pool, no synchronisation until ghn3_profile_read
@@ -73,6 +92,8 @@ static int ctx_reserve(ghn3_ctx* c, size_t n) {
         if (c->h_stage[i]) HIPCHK(hipHostFree(c->h_stage[i]));
         if (c->d_stage[i]) HIPCHK(hipFree(c->d_stage[i]));
         c->h_stage[i] = nullptr; c->d_stage[i] = nullptr;
+        c->cache[i].valid = false;
+        c->cache[i].stamp = 0;
         HIPCHK(hipHostMalloc((void**)&c->h_stage[i], cap * sizeof(GemmProbDev), hipHostMallocDefault));
         HIPCHK(hipMalloc((void**)&c->d_stage[i], cap * sizeof(GemmProbDev)));
     }
@@ -89,6 +110,7 @@ extern "C" int ghn3_ctx_create(ghn3_ctx** out) {
     memset(c, 0, sizeof(*c));
     c->pool = new std::vector<hipEvent_t>();
     c->pool_tag = new std::vector<int>();
+    c->cache = new SlotCache[kStageSlots];
     for (int i = 0; i < kStageSlots; ++i) {
         HIPCHK(hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->ev_done[i], hipEventDisableTiming));
@@ -142,6 +164,7 @@ extern "C" void ghn3_ctx_destroy(ghn3_ctx* c) {
     for (hipEvent_t e : *c->pool) hipEventDestroy(e);
     delete c->pool;
     delete c->pool_tag;
+    delete[] c->cache;
     delete c;
 }
 
@@ -249,7 +272,6 @@ static int pick_tile(const ghn3_gemm_problem& p, int forced, int64_t op_t64) {
     return 64;
 }
 
-struct Launch { int a_mode, b_mode, tile, first, count, tiles, with_ln, max_slice; };
 static inline bool is16(int tl) { return tl == 16 || tl == 24 || tl == 20 || tl == 25 || tl == 28 || tl == 29 || tl == 30; }   // 16-bit-operand kernels
 
 extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_gemm_problem* problems, int n_problems,
@@ -260,19 +282,48 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
     Resolver R{bufs, n_bufs, false};
 
     // ---- 1. resolve every GEMM op into launch groups inside one staging slot --------------------
-    std::vector<std::vector<Launch>> op_launches(n_ops);
+    std::vector<std::vector<Launch>> fresh_launches;
+    const std::vector<std::vector<Launch>>* launches = &fresh_launches;
     size_t need = 0;
     for (int k = 0; k < n_ops; ++k)
         if (ops[k].kind == GHN3_OP_GEMM) need += (size_t)ops[k].i[1];
     GemmProbDev* hs = nullptr; GemmProbDev* ds = nullptr;
     int used_slot = -1;
+    static const bool use_copy_stream = getenv("GHN3_COPY_STREAM") && atoi(getenv("GHN3_COPY_STREAM")) != 0;
+    static const bool use_cache = !(getenv("GHN3_RUN_CACHE") && atoi(getenv("GHN3_RUN_CACHE")) == 0);
+    int hit = -1;
     if (need > 0) {
         int rc = ctx_reserve(c, need);
         if (rc) return rc;
-        const int slot = c->next;
-        c->next = (c->next + 1) % kStageSlots;
+        if (n_problems < 0 || (n_problems > 0 && !problems)) { ghn3_set_error("ghn3_run: bad problem table"); return GHN3_E_ARG; }
+        for (int i = 0; use_cache && i < kStageSlots && hit < 0; ++i) {
+            const SlotCache& e = c->cache[i];
+            if (e.valid && e.n_ops == n_ops && e.n_problems == n_problems && e.n_bufs == n_bufs &&
+                memcmp(e.bufs.data(), bufs, (size_t)n_bufs * sizeof(void*)) == 0 &&
+                memcmp(e.ops.data(), ops, (size_t)n_ops * sizeof(ghn3_op)) == 0 &&
+                memcmp(e.problems.data(), problems, (size_t)n_problems * sizeof(ghn3_gemm_problem)) == 0)
+                hit = i;
+        }
+    }
+    if (hit >= 0) {
+        // the same run as one whose table is still on the device
+        SlotCache& e = c->cache[hit];
+        e.stamp = ++c->clock;
+        c->cache_hits++;
+        hs = c->h_stage[hit]; ds = c->d_stage[hit];
+        launches = &e.launches;
+        if (e.up_stream != stream && c->ev_used[hit]) HIPCHK(hipStreamWaitEvent(stream, c->ev[hit], 0));
+        if (use_copy_stream) used_slot = hit;
+    } else if (need > 0) {
+        int slot = 0;                                    // the least recently used slot (never used ones first)
+        for (int i = 1; i < kStageSlots; ++i)
+            if (c->cache[i].stamp < c->cache[slot].stamp) slot = i;
+        c->cache[slot].valid = false;
+        c->cache_misses++;
         if (c->ev_used[slot]) { HIPCHK(hipEventSynchronize(c->ev[slot])); c->ev_used[slot] = false; }
         hs = c->h_stage[slot]; ds = c->d_stage[slot];
+        std::vector<std::vector<Launch>>& op_launches = fresh_launches;
+        op_launches.resize(n_ops);
         size_t pos = 0;
         for (int k = 0; k < n_ops; ++k) {
             if (ops[k].kind != GHN3_OP_GEMM) continue;
@@ -520,7 +571,6 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         // run that used this slot last (kStageSlots runs ago); `stream` waits for the copy.
         // (GHN3_COPY_STREAM=1: upload on a separate copy stream ahead of `stream`; measured 9.11 vs 9.02 ms per step --
         // the host runs far enough ahead that the in-stream copy is never waited for -- so off by default)
-        static const bool use_copy_stream = getenv("GHN3_COPY_STREAM") && atoi(getenv("GHN3_COPY_STREAM")) != 0;
         if (use_copy_stream) {
             if (c->done_used[slot]) HIPCHK(hipStreamWaitEvent(c->copy, c->ev_done[slot], 0));
             HIPCHK(hipMemcpyAsync(ds, hs, pos * sizeof(GemmProbDev), hipMemcpyHostToDevice, c->copy));
@@ -532,6 +582,20 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
             HIPCHK(hipMemcpyAsync(ds, hs, pos * sizeof(GemmProbDev), hipMemcpyHostToDevice, stream));
             HIPCHK(hipEventRecord(c->ev[slot], stream));
             c->ev_used[slot] = true;
+        }
+        if (use_cache) {
+            SlotCache& e = c->cache[slot];
+            e.n_ops = n_ops; e.n_problems = n_problems; e.n_bufs = n_bufs;
+            e.ops.assign(ops, ops + n_ops);
+            e.problems.assign(problems, problems + n_problems);
+            e.bufs.assign(bufs, bufs + n_bufs);
+            e.launches.swap(fresh_launches);
+            launches = &e.launches;
+            e.up_stream = use_copy_stream ? c->copy : stream;
+            e.stamp = ++c->clock;
+            e.valid = true;
+        } else {
+            c->cache[slot].stamp = ++c->clock;           // (plain least-recently-used rotation of the slots)
         }
     }
 
@@ -611,7 +675,7 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
         switch (o.kind) {
         case GHN3_OP_NOP: break;
         case GHN3_OP_GEMM:
-            for (const Launch& L : op_launches[k]) {
+            for (const Launch& L : (*launches)[k]) {
                 if (L.tile >= 6000)
                     rc = ghn3_gemm_x3s_launch(ds + L.first, hs + L.first, L.count, L.tiles, L.tile >= 7000 ? 45 : 44, L.max_slice,
                                               (L.tile / 100) % 10, stream);
@@ -861,6 +925,13 @@ extern "C" int ghn3_run(ghn3_ctx* c, const ghn3_op* ops, int n_ops, const ghn3_g
     int rc_join = join();
     if (rc_join) return rc_join;
     return mark_done();
+}
+
+extern "C" int ghn3_ctx_cache_stats(ghn3_ctx* c, int64_t* hits, int64_t* misses) {
+    if (!c) return GHN3_E_NOCTX;
+    if (hits) *hits = (int64_t)c->cache_hits;
+    if (misses) *misses = (int64_t)c->cache_misses;
+    return GHN3_OK;
 }
 
 extern "C" int ghn3_ctx_side_wait(ghn3_ctx* c, void* stream) {

@@ -175,6 +175,36 @@ class GraphBatch:
             self._cat()
         return self._n_nodes_host
 
+    def precompile(self, config, training=True, predict_class_layers=True, reduce_graph=False):
+        """Host half of GHN3.compile() for this batch, run where the batch is built (a loader worker): the Program is plain
+        numpy, needs no GPU, and pickles together with the batch and its networks.  `config` = GHN3.program_config() of the
+        model that will consume the batch; GHN3.compile() takes the attached program when the model's configuration and the
+        call's flags are the ones given here, and builds its own otherwise.  (With reduce_graph=True the matched shape tables
+        of the networks are consumed here, as the reference's _map_net_params does.)"""
+        from .program import Program
+        self._cat()
+        args = dict(config, training=bool(training), predict_class_layers=bool(predict_class_layers),
+                    reduce_graph=bool(reduce_graph))
+        cfg = args.pop('cfg')
+        self.program = Program(cfg, self.node_info, self.host_n_nodes(), self._node_type_host, self.max_edge, self.nets,
+                               **args).strip()
+        self.program_args = dict(args, cfg=cfg)
+        return self
+
+    def take_program(self, nets, **args):
+        """The precompiled Program of precompile() when it was built for exactly these networks and arguments (and not used
+        before: a plan owns its program), else None."""
+        prog, have = getattr(self, 'program', None), getattr(self, 'program_args', None)
+        same_nets = hasattr(self, 'nets') and len(nets) == len(self.nets) and all(a is b for a, b in zip(nets, self.nets))
+        if prog is None or have != args or not same_nets:
+            if prog is not None and have['reduce_graph']:
+                raise ValueError('this batch was precompiled with reduce_graph=True for other arguments (%s): its networks '
+                                 'no longer carry the shape tables a new compile needs'
+                                 % ', '.join(k for k in args if have.get(k) != args[k]) or 'other networks')
+            return None
+        self.program = None
+        return prog
+
     def to_dense(self, x=None):
         if x is None:
             x = self.node_feat

@@ -462,14 +462,12 @@ class GHN3(nn.Module):
             graphs.to_device(dev)
         assert graphs.dense, 'GraphBatch must be created with dense=True for GHN-3'
         training = self.training if training is None else training
-        cfg = dict(hid=self.hid, heads=self.heads, layers=self.layers, num_classes=self.num_classes,
-                   max_shape=self.max_shape)
-        prog = Program(cfg, graphs.node_info, graphs.host_n_nodes(), graphs._node_type_host, graphs.max_edge,
-                       nets, index_mode=self.index_mode, training=training,
-                       predict_class_layers=predict_class_layers, reduce_graph=reduce_graph,
-                       layernorm=self.layernorm, weight_norm=self.weight_norm, decoder_ctype=L.COMPUTE_TYPES[self.compute],
-                       decoder_bwd_ctype=L.COMPUTE_TYPES[self.compute_bwd] if self.compute_bwd else None,
-                       direct16=self.direct16, side_stream=self.side_stream, graphormer_x3=self.graphormer_x3)
+        args = dict(self.program_config(), training=bool(training), predict_class_layers=bool(predict_class_layers),
+                    reduce_graph=bool(reduce_graph))
+        prog = graphs.take_program(nets, **args)             # (built by a loader worker: GraphBatch.precompile)
+        if prog is None:
+            cfg = args.pop('cfg')
+            prog = Program(cfg, graphs.node_info, graphs.host_n_nodes(), graphs._node_type_host, graphs.max_edge, nets, **args)
         return self.plan(prog, graphs, nets)
 
     def plan(self, prog, graphs, nets):

@@ -479,6 +479,12 @@ int ghn3_ctx_side_wait(ghn3_ctx* ctx, void* stream);
  * of FusedAdamW.step(overlap=True), optim.py -- verify that a run really returned detached.) */
 int ghn3_ctx_side_pending(ghn3_ctx* ctx);
 
+/* ghn3_run keeps the resolved problem tables of its last 16 distinct runs on the device: a run whose ops, problem table and
+ * buffer pointers equal (byte for byte) those of a kept one -- every step of a loop once the caller's allocator has settled --
+ * skips the host resolve and the table upload.  Counts runs with GEMM ops served from / added to that store since the context
+ * was created (either pointer may be NULL).  GHN3_RUN_CACHE=0 in the environment turns the store off.  (ABI v19) */
+int ghn3_ctx_cache_stats(ghn3_ctx* ctx, int64_t* hits, int64_t* misses);
+
 /* Timing helper for bench.py: HIP events on `stream` (torch.cuda.Event only sees torch's current stream).
  * ghn3_event_elapsed_ms synchronises on the stop event. */
 int ghn3_event_create(void** ev);

@@ -390,6 +390,53 @@ def test_training_steps_do_not_accumulate_memory():
     assert max(used[2:]) - min(used[2:]) < 0.25 * used[2], used
 
 
+def test_repeated_runs_reuse_the_resolved_problem_tables():
+    """ghn3_run keeps the resolved GEMM problem tables of its recent runs on the device (ghn3_ctx_cache_stats): the steps of a
+    loop over one plan are served from that store -- and give the bits of the first step --, a different plan in between does
+    not disturb it, and a run whose buffers moved (other output / gradient tensors at the same ops) resolves again instead of
+    using a stale table."""
+    from ghn3_amd import _lib as L
+    hip, _ = make_models(T_CFG, 7)
+    hip.train()
+    ctx = L.context(0)
+    nets_a, gb_a, _, _ = synthetic_case([40], 4100)
+    nets_b, gb_b, _, _ = synthetic_case([33, 21], 4200)
+    plan_a = hip.compile(nets_a, gb_a, training=True)
+    plan_b = hip.compile(nets_b, gb_b, training=True)
+
+    def step(plan, keep=None):
+        torch.manual_seed(3)                                      # (the class-token rows of the positional encodings)
+        out = hip._run_forward(plan)
+        with torch.no_grad():                                     # (the predicted tensors: the gaps between them are not written)
+            pred = torch.cat([out[p['offset']:p['offset'] + p['numel']] for p in plan.program.predicted])
+        dout = torch.ones_like(out)
+        grads = hip._run_backward(plan, dout)
+        res = (pred, grads[0].clone(), plan.gflat.clone())
+        if keep is not None:
+            keep.append((out, plan.gflat))                        # (kept alive: the next step's tensors land elsewhere)
+        return res
+
+    first = step(plan_a)
+
+    def same(got):
+        assert torch.equal(first[0], got[0])
+        for a, b in zip(first[1:], got[1:]):                      # (some gradient sums are accumulated with atomics)
+            assert float((a - b).norm() / a.norm()) < 1e-6
+
+    h0, m0 = ctx.cache_stats()
+    for k in range(16):
+        if k == 3:
+            step(plan_b)
+        same(step(plan_a))
+    h1, m1 = ctx.cache_stats()
+    assert h1 - h0 >= 6, (h0, m0, h1, m1)                         # (period 2 of the allocator: a few misses, then hits)
+    keep = []
+    for k in range(4):                                            # every step at new addresses: no stale table
+        same(step(plan_a, keep))
+    h2, m2 = ctx.cache_stats()
+    assert m2 - m1 >= 4, (h1, m1, h2, m2)
+
+
 def test_fused_predicted_param_norm_loss():
     """GHN3.predicted_param_norm (PARAM_NORM_FWD / BWD on the flat output, trainer.py:288-294) against the per-tensor
     torch.norm form: same value, same GHN gradients; scaled upstream gradient (predparam_wd) included."""

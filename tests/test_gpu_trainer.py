@@ -166,3 +166,39 @@ def test_eval_ghn_counterpart_script():
                          timeout=600)
     assert out.returncode == 0, out.stdout[-2000:]
     assert 'finite=True' in out.stdout and 'total norm' in out.stdout.lower(), out.stdout[-1000:]
+
+
+def test_worker_precompiled_batch_gives_the_same_step():
+    """A batch whose host compile ran where the batch was built (GraphBatch.precompile, then a pickle round trip as between
+    a loader worker and the training process) is consumed by ghn(...) as is: same predicted parameters bit for bit, same
+    gradients, and the networks receive their tensors."""
+    import pickle
+    from ghn3_amd import GraphBatch
+    from ghn3_amd.deepnets1m import SampledNets
+    hip, _ = make_models(dict(recipe.TINY_CFG), recipe.TINY_SEED)
+    hip = hip.to('cuda').train()
+
+    def batch(pre):
+        src = SampledNets(seed=5, max_nodes=150)
+        gb = GraphBatch([src[k] for k in range(2)], dense=True)
+        gb._cat()
+        gb.graphs = None
+        if pre:
+            gb.precompile(hip.program_config(), training=True, reduce_graph=True)
+        return pickle.loads(pickle.dumps(gb))
+
+    outs = []
+    for pre in (False, True):
+        gb = batch(pre)
+        torch.manual_seed(11)
+        hip.zero_grad(set_to_none=True)
+        nets = hip(gb.nets, gb.to_device('cuda'), bn_track_running_stats=True, keep_grads=True, reduce_graph=True)
+        assert getattr(gb, 'program', None) is None               # (taken, or never there)
+        flat = hip._last_flat
+        (flat * flat).sum().backward()
+        first = next(p for _, p in nets[0].named_parameters())
+        assert torch.is_tensor(first) and first.is_cuda
+        outs.append((flat.detach().clone(), hip.embed.weight.grad.clone(), hip.decoder.conv[2].weight.grad.clone()))
+    assert torch.equal(outs[0][0], outs[1][0])
+    for a, b in zip(outs[0][1:], outs[1][1:]):                    # (the backward accumulates some sums with atomics)
+        assert float((a - b).norm() / b.norm()) < 1e-5

@@ -636,3 +636,42 @@ def test_balanced_row_tiles_and_column_ranges():
         covered[m0:m0 + 32 * n] = True
         assert int(ext[m0]) == int(e)                  # a tile pays for (and is cut at) the extent of its first row
     assert covered.all()
+
+
+def test_precompiled_program_travels_with_its_batch():
+    """GraphBatch.precompile (a loader worker's half of GHN3.compile): the stripped program pickles with the batch and its
+    networks, still names the modules of the unpickled networks, carries the same run-time arrays as a program compiled in
+    place, and is handed out once and only for the arguments it was built with."""
+    import pickle
+    from ghn3_amd.deepnets1m import SampledNets
+    hip, _ = _build(recipe.TINY_CFG, recipe.TINY_SEED, 'reference')
+    config = hip.program_config()
+
+    def batch():
+        src = SampledNets(seed=3, max_nodes=120)
+        gb = GraphBatch([src[k] for k in range(2)], dense=True)
+        gb._cat()
+        gb.graphs = None
+        return gb
+
+    gb = batch().precompile(config, training=True, reduce_graph=True)
+    gb2 = pickle.loads(pickle.dumps(gb))
+    args = dict(config, training=True, predict_class_layers=True, reduce_graph=True)
+    with pytest.raises(ValueError, match='training'):            # (consumed shape tables: no silent recompile)
+        gb2.take_program(gb2.nets, **dict(args, training=False))
+    prog = gb2.take_program(gb2.nets, **args)
+    assert prog is not None and gb2.take_program(gb2.nets, **args) is None
+    mods = {id(m) for net in gb2.nets for _, m in net.named_modules()}
+    assert len(prog.predicted) > 0 and all(id(p['module']) in mods for p in prog.predicted)
+    gb_f = batch()
+    ref = Program(config['cfg'], gb_f.node_info, gb_f.host_n_nodes(), gb_f._node_type_host, gb_f.max_edge, gb_f.nets,
+                  **{k: v for k, v in args.items() if k != 'cfg'})
+    np.testing.assert_array_equal(prog.idx_blob, ref.idx_blob)
+    np.testing.assert_array_equal(prog.problems, ref.problems)
+    for a, b in ((prog.fwd_ops, ref.fwd_ops), (prog.bwd_ops, ref.bwd_ops)):
+        assert a.tobytes() == b.tobytes()
+    assert [(p['offset'], p['numel'], p['attr']) for p in prog.predicted] == \
+        [(p['offset'], p['numel'], p['attr']) for p in ref.predicted]
+    # a batch compiled without reduce_graph can fall back to a fresh compile: no program, no error
+    gb_n = batch().precompile(config, training=False)
+    assert gb_n.take_program(gb_n.nets, **dict(args, reduce_graph=False)) is None

@@ -164,6 +164,8 @@ class _ReLUConvBN:
             return target_ops.run_pointwise_block(list(self.op), x)
         if x.is_cuda and len(self.op) == 3:              # (round 6: ReLU -> k x k conv -> norm on the dense-convolution op)
             return target_ops.run_conv_block(list(self.op), x)
+        if x.is_cuda and len(self.op) == 4 and os.environ.get('GHN3_NATIVE_PAIR', '1') != '0':   # (the 1 x k / k x 1 pair: two nodes of the same op)
+            return target_ops.run_conv_pair_block(list(self.op), x)
         return self.op(x)
 
 
@@ -534,6 +536,14 @@ class _Network:
             # the parameter table GHN3.forward walks (nn.py:612); built once, here
             self.__dict__['_layered_modules'] = named_layered_modules(self)
 
+    @staticmethod
+    def _run_stem(stem, x):
+        """The stem's conv -> norm windows on the fused dense-convolution op (round 6), the rest layer by layer."""
+        if torch.is_tensor(x) and x.is_cuda and x.dim() == 4 and target_ops.enabled() and hasattr(stem, '__iter__') and \
+                os.environ.get('GHN3_NATIVE_STEM', '1') != '0':
+            return target_ops.run_layer_seq(stem, x)
+        return stem(x)
+
     def forward(self, x):
         if x.is_cuda and x.dim() == 4 and not self._is_vit and target_ops.enabled() and \
                 os.environ.get('GHN3_NATIVE_CL', '0') == '1':
@@ -545,10 +555,10 @@ class _Network:
         if self._is_vit:
             s0 = s1 = self.pos_enc(self.stem0(x))
         elif self._stem_type == 1:
-            s0 = self.stem0(x)
-            s1 = None if _is_none(self.stem1) else self.stem1(s0)
+            s0 = self._run_stem(self.stem0, x)
+            s1 = None if _is_none(self.stem1) else self._run_stem(self.stem1, s0)
         else:
-            s0 = s1 = self.stem(x)
+            s0 = s1 = self._run_stem(self.stem, x)
         logits_aux = None
         for c, cell in enumerate(self.cells):
             s0, s1 = s1, cell(s0, s1, self.drop_path_prob)

@@ -148,13 +148,17 @@ def _pair(v):
     return (int(v[0]), int(v[1])) if isinstance(v, (tuple, list)) else (int(v), int(v))
 
 
-def _conv_desc(x, w, stride, pad, dil, relu, eps):
+CONV_NO_NORM = 2                  # include/ghn3_hip.h GHN3_CONV_NO_NORM
+
+
+def _conv_desc(x, w, stride, pad, dil, relu, eps, no_norm=False):
     N, C, H, W = x.shape
     C_out, _, kh, kw = w.shape
     (sh, sw), (ph, pw) = _pair(stride), _pair(pad)
     Ho = (H + 2 * ph - dil * (kh - 1) - 1) // sh + 1
     Wo = (W + 2 * pw - dil * (kw - 1) - 1) // sw + 1
-    return _ConvDesc(N, H, W, C, C_out, kh, kw, sh, sw, ph, pw, int(dil), Ho, Wo, int(bool(relu)), float(eps))
+    return _ConvDesc(N, H, W, C, C_out, kh, kw, sh, sw, ph, pw, int(dil), Ho, Wo,
+                     int(bool(relu)) | (CONV_NO_NORM if no_norm else 0), float(eps))
 
 
 _CONV_SCRATCH = {}
@@ -229,6 +233,61 @@ class ConvBn(torch.autograd.Function):
         return dx, dw, dg, db, None, None, None, None, None
 
 
+class ConvOnly(torch.autograd.Function):
+    """[ReLU ->] dense kh x kw convolution WITHOUT a norm layer (ghn3_conv_bn_fwd / _bwd with GHN3_CONV_NO_NORM): the first half
+    of the 1 x k / k x 1 pair of `ReLUConvBN(double=True)` (ops.py:186-190).  Same storage conventions as ConvBn."""
+
+    @staticmethod
+    def applicable(x, w):
+        if not (enabled() and os.environ.get('GHN3_NATIVE_CONV', '1') != '0' and torch.is_tensor(x) and x.is_cuda and
+                x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled()):
+            return False
+        if not (torch.is_tensor(w) and w.is_cuda and w.dtype == torch.float32 and w.dim() == 4):
+            return False
+        C_in, C_out = x.shape[1], w.shape[0]
+        return C_in % 4 == 0 and C_out % 4 == 0 and C_in <= 512 and C_out <= 512 and w.shape[1] == C_in and \
+            max(w.shape[2], w.shape[3]) <= 7 and x.numel() < 2 ** 31
+
+    @staticmethod
+    def forward(ctx, x, w, stride, pad, dil, relu):
+        lib = L.load()
+        xc = x.contiguous(memory_format=torch.channels_last)
+        wc = w.contiguous()
+        d = _conv_desc(xc, wc, stride, pad, dil, relu, 0.0, no_norm=True)
+        z = torch.empty((d.N, int(wc.shape[0]), d.Ho, d.Wo), dtype=torch.float32, device=x.device,
+                        memory_format=torch.channels_last)
+        scratch = torch.empty(_conv_scratch_floats(lib, d, 0), dtype=torch.float32, device=x.device)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L._check(lib.ghn3_conv_bn_fwd(ctypes.byref(d), _ptr(xc), _ptr(wc), None, None, _ptr(z), None, None, _ptr(scratch), stream),
+                 'ghn3_conv_bn_fwd')
+        ctx.save_for_backward(xc, wc)
+        ctx.cfg = (stride, pad, dil, relu)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        lib = L.load()
+        xc, wc = ctx.saved_tensors
+        stride, pad, dil, relu = ctx.cfg
+        d = _conv_desc(xc, wc, stride, pad, dil, relu, 0.0, no_norm=True)
+        do = dz.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(xc)
+        n_par = (wc.numel() + 63) // 64 * 64
+        buf = torch.empty(n_par + _conv_scratch_floats(lib, d, 1), dtype=torch.float32, device=xc.device)
+        dw = buf[:wc.numel()].view(wc.shape)
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L._check(lib.ghn3_conv_bn_bwd(ctypes.byref(d), _ptr(do), _ptr(xc), None, None, _ptr(wc), None, _ptr(dx), _ptr(dw), None,
+                                      None, _ptr(buf[n_par:]), stream), 'ghn3_conv_bn_bwd')
+        return dx, dw, None, None, None, None
+
+
+def conv_only(x, w, stride=1, padding=0, dilation=1, relu=False):
+    """conv2d(relu(x) if relu else x, w) on the dense-convolution kernels (no bias, groups = 1)."""
+    if not x.is_cuda:
+        raise L.Ghn3Error('conv_only runs on an MI355X only (no CPU implementation: use the stock torch layers)')
+    return ConvOnly.apply(x, w, _pair(stride), _pair(padding), int(dilation), bool(relu))
+
+
 def conv_bn(x, w, gamma, beta, stride=1, padding=0, dilation=1, relu=True, eps=1e-5):
     """out = batch_norm(conv2d(relu(x) if relu else x, w)) with batch statistics; returns (out, stats) as dwpw_bn does.
     x: (N, C, H, W) fp32 CUDA tensor (channels_last preferred), w (C_out, C, kh, kw)."""
@@ -260,6 +319,81 @@ def run_conv_block(layers, x, keep_layout=False):
     out, stats = conv_bn(x, w, gamma, beta, conv.stride, conv.padding, _pair(conv.dilation)[0], True, bn.eps)
     _update_running_stats(bn, stats, out, has_run)
     return out if (keep_layout or lazy_layout(conv, bn)) else out.contiguous(memory_format=torch.contiguous_format)
+
+
+def _plain_conv(conv):
+    """A bias-free, ungrouped convolution with numeric padding and one dilation for both axes (what the dense kernels take)."""
+    return hasattr(conv, 'kernel_size') and getattr(conv, 'bias', None) is None and not isinstance(conv.padding, str) and \
+        getattr(conv, 'groups', 1) == 1 and torch.is_tensor(getattr(conv, 'weight', None)) and \
+        len(set(_pair(getattr(conv, 'dilation', 1)))) == 1
+
+
+def run_conv_pair_block(layers, x, keep_layout=False):
+    """[ReLU, 1 x k Conv2d, k x 1 Conv2d, BatchNorm2d] -- `ReLUConvBN(double=True)`, the `conv_1x7_7x1` op (ops.py:186-190,
+    298) -- as two dense-convolution nodes: ReLU + the first convolution alone (ConvOnly), then the second one with the norm
+    (ConvBn without a ReLU); the intermediate stays NHWC.  Else layer by layer."""
+    relu, conv_a, conv_b, bn = layers
+    gamma, beta = getattr(bn, 'weight', None), getattr(bn, 'bias', None)
+    has_run = getattr(bn, 'running_mean', None) is not None
+    batch_stats = getattr(bn, 'training', True) or not has_run
+    ok = hasattr(bn, 'eps') and _plain_conv(conv_a) and _plain_conv(conv_b) and ConvOnly.applicable(x, conv_a.weight) and \
+        conv_b.weight.shape[1] == conv_a.weight.shape[0]
+    if ok:
+        # (the second node's input has conv_a's channel count and x's type: checked on a stand-in of that shape)
+        probe = x if conv_a.weight.shape[0] == x.shape[1] else x.new_empty((1, conv_a.weight.shape[0], 1, 1))
+        ok = ConvBn.applicable(probe, conv_b.weight, gamma, beta, batch_stats)
+    if not ok:
+        for m in layers:
+            x = m(x)
+        return x
+    y = conv_only(x, conv_a.weight, conv_a.stride, conv_a.padding, _pair(conv_a.dilation)[0], relu=True)
+    out, stats = conv_bn(y, conv_b.weight, gamma, beta, conv_b.stride, conv_b.padding, _pair(conv_b.dilation)[0], False, bn.eps)
+    _update_running_stats(bn, stats, out, has_run)
+    return out if (keep_layout or lazy_layout(conv_a, conv_b, bn)) else out.contiguous(memory_format=torch.contiguous_format)
+
+
+def _is_kind(m, name):
+    return type(m).__name__ == name
+
+
+def run_layer_seq(seq, x):
+    """A stem (`nn.Sequential` of Conv2d / BatchNorm2d / ReLU / MaxPool2d / Identity, ops.py:443-463) with every
+    [Conv2d, BatchNorm2d] and [ReLU, Conv2d, BatchNorm2d] window on the fused dense-convolution op and the rest layer by layer.
+    A 3-channel image (the first convolution of every network) is given a zero fourth channel -- and the weight a zero fourth
+    input slice, through autograd -- because the kernels read channels in groups of four."""
+    layers = list(seq)
+    k, n = 0, len(layers)
+    while k < n:
+        m = layers[k]
+        relu = _is_kind(m, 'ReLU') and k + 2 < n
+        conv = layers[k + 1] if relu else m
+        bn = layers[k + 2] if relu else (layers[k + 1] if k + 1 < n else None)
+        done = False
+        if _is_kind(conv, 'Conv2d') and bn is not None and _is_kind(bn, 'BatchNorm2d') and hasattr(bn, 'eps') and \
+                _plain_conv(conv) and torch.is_tensor(x) and x.is_cuda and x.dim() == 4:
+            w, gamma, beta = conv.weight, getattr(bn, 'weight', None), getattr(bn, 'bias', None)
+            has_run = getattr(bn, 'running_mean', None) is not None
+            batch_stats = getattr(bn, 'training', True) or not has_run
+            xin = x
+            if x.shape[1] == 3 and w.shape[1] == 3:
+                xin = F.pad(x, (0, 0, 0, 0, 0, 1))
+                w = F.pad(w, (0, 0, 0, 0, 0, 1))
+            if ConvBn.applicable(xin, w, gamma, beta, batch_stats):
+                fold = bool(relu)
+                if relu and k == 0 and getattr(m, 'inplace', False):
+                    # an in-place ReLU at the head of the sequence rewrites the CALLER's tensor (stem1 of the two-stem networks:
+                    # the cells read relu(stem0's output) afterwards, ops.py:449,545-546): kept as the layer it is
+                    xin, fold = m(xin), False
+                x, stats = conv_bn(xin, w, gamma, beta, conv.stride, conv.padding, _pair(conv.dilation)[0], fold, bn.eps)
+                _update_running_stats(bn, stats, x, has_run)
+                if not lazy_layout(conv, bn):
+                    x = x.contiguous(memory_format=torch.contiguous_format)
+                k += 3 if relu else 2
+                done = True
+        if not done:
+            x = m(x)
+            k += 1
+    return x
 
 
 def run_factorized_reduce(relu, conv_1, conv_2, bn, x, stride=2, keep_layout=False):

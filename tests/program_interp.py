@@ -820,7 +820,8 @@ class Interp:
         n = int(o['i'][0])
         b = self.bufs[int(o['r'][0]['buf'])]
         off = int(o['r'][0]['off'])
-        b[off:off + n] = 0
+        if n > 0:                                            # (unpatched placeholders carry -1: skipped, runtime.hip)
+            b[off:off + n] = 0
 
     def op_dact(self, o, problems):
         M, N, ld, dact = (int(v) for v in o['i'][:4])

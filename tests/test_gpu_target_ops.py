@@ -140,6 +140,88 @@ def test_conv_bn_matches_the_stock_layers(case):
     assert torch.equal(out2, out.detach())
 
 
+@pytest.mark.parametrize('case', [CONV_CASES[k] for k in (0, 1, 4, 7, 8, 9)])
+def test_conv_without_a_norm_layer(case):
+    """GHN3_CONV_NO_NORM (the first half of the 1 x k / k x 1 pair, ops.py:186-190): [ReLU ->] convolution alone against
+    torch in fp64 -- result, input gradient, weight gradient; deterministic."""
+    from ghn3_amd import target_ops as T
+    N, Ci, Co, H, W, ks, st, pad, dil, relu = case
+    g = torch.Generator().manual_seed(3 + N + Ci + Co + H + W + sum(ks) + sum(st))
+    x = torch.randn(N, Ci, H, W, generator=g)
+    w = torch.randn(Co, Ci, ks[0], ks[1], generator=g) / (Ci * ks[0] * ks[1]) ** 0.5
+    xr, wr = x.clone().double().requires_grad_(True), w.clone().double().requires_grad_(True)
+    ref = torch.nn.functional.conv2d(torch.relu(xr) if relu else xr, wr, None, st, pad, dil)
+    up = torch.randn(ref.shape, generator=g)
+    (ref * up.double()).sum().backward()
+    xd, wd = x.cuda().requires_grad_(True), w.cuda().requires_grad_(True)
+    assert T.ConvOnly.applicable(xd, wd)
+    out = T.conv_only(xd, wd, stride=st, padding=pad, dilation=dil, relu=relu)
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    (out * up.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert _rel(out.detach().cpu(), ref.detach()) < 2e-4
+    assert _rel(xd.grad.cpu(), xr.grad) < 3e-4 and _rel(wd.grad.cpu(), wr.grad) < 3e-4, (_rel(xd.grad.cpu(), xr.grad),
+                                                                                       _rel(wd.grad.cpu(), wr.grad))
+    assert torch.equal(T.conv_only(xd.detach(), wd.detach(), stride=st, padding=pad, dilation=dil, relu=relu), out.detach())
+
+
+@pytest.mark.parametrize('stride', [1, 2])
+def test_conv_pair_module_runs_on_two_dense_nodes(monkeypatch, stride):
+    """`ReLUConvBN(double=True)` (the search space's `conv_1x7_7x1`, ops.py:186-190,298): ReLU + 1 x 7 convolution as one node,
+    7 x 1 convolution + norm as the next; output, every gradient and the running statistics against the stock layers."""
+    from ghn3_amd import ops
+    res = {}
+    for mode in ('stock', 'fused'):
+        monkeypatch.setenv('GHN3_NATIVE_OPS', '0' if mode == 'stock' else '1')
+        torch.manual_seed(6)
+        m = ops.ReLUConvBN(48, 48, 7, stride, 3, double=True)
+        m.op[3] = torch.nn.BatchNorm2d(48)
+        m = m.cuda().train()
+        x = torch.randn(5, 48, 12, 10, device='cuda', requires_grad=True)
+        y = m(x)
+        up = torch.randn(y.shape, generator=torch.Generator().manual_seed(9)).cuda()
+        (y * up).sum().backward()
+        bn = list(m.op)[-1]
+        res[mode] = (y.detach().cpu(), x.grad.cpu(), [p.grad.cpu() for p in m.parameters()], bn.running_mean.cpu(), bn.running_var.cpu())
+    assert res['fused'][0].shape == res['stock'][0].shape
+    assert _rel(res['fused'][0], res['stock'][0]) < 2e-4 and _rel(res['fused'][1], res['stock'][1]) < 5e-4
+    assert len(res['fused'][2]) == 4
+    for a, b in zip(res['fused'][2], res['stock'][2]):
+        assert _rel(a, b) < 5e-4, _rel(a, b)
+    assert _rel(res['fused'][3], res['stock'][3]) < 1e-4 and _rel(res['fused'][4], res['stock'][4]) < 1e-4
+
+
+@pytest.mark.parametrize('spec', [
+    [('conv', 3, 48, 3, 1), ('bn', 48), ('id',)],                                                    # stem type 0
+    [('conv', 3, 32, 7, 1), ('bn', 32), ('maxpool',)],
+    [('conv', 3, 16, 3, 1), ('bn', 16), ('relu',), ('conv', 16, 32, 3, 1), ('bn', 32)],             # stem0 of the two-stem networks
+    [('relu',), ('conv', 32, 32, 3, 2), ('bn', 32)],                                                 # stem1: IN-PLACE ReLU at the head
+])
+def test_stem_sequences_run_on_the_dense_op(monkeypatch, spec):
+    """The stems (ops.py:443-463): every conv -> norm window on the fused op -- the 3-channel image padded to four channels, a
+    ReLU between two windows folded into the second one, an in-place ReLU at the head applied to the caller's tensor as the
+    stock layer does -- against the stock layers: output, input, every parameter gradient."""
+    from ghn3_amd import ops, light_ops
+    from ghn3_amd import target_ops as T
+    res = {}
+    c_in = spec[0][1] if spec[0][0] == 'conv' else spec[1][1]
+    for mode in ('stock', 'fused'):
+        monkeypatch.setenv('GHN3_NATIVE_OPS', '0' if mode == 'stock' else '1')
+        torch.manual_seed(8)
+        seq = ops._layer_seq(ops._TorchLayers, 'bn-track', spec).cuda().train()
+        x0 = torch.randn(6, c_in, 16, 16, device='cuda', requires_grad=True)
+        x = x0 * 1.0                                           # (a non-leaf: the in-place ReLU may rewrite it)
+        y = ops.Network._run_stem(seq, x)
+        up = torch.randn(y.shape, generator=torch.Generator().manual_seed(9)).cuda()
+        ((y * up).sum() + (x * x).sum()).backward()            # (x enters the loss AFTER the stem: sees the in-place ReLU)
+        res[mode] = (y.detach().cpu(), x.detach().cpu(), x0.grad.cpu(), [p.grad.cpu() for p in seq.parameters()])
+    assert _rel(res['fused'][0], res['stock'][0]) < 2e-4
+    assert torch.equal(res['fused'][1], res['stock'][1])
+    assert _rel(res['fused'][2], res['stock'][2]) < 5e-4
+    for a, b in zip(res['fused'][3], res['stock'][3]):
+        assert a.shape == b.shape and _rel(a, b) < 5e-4, _rel(a, b)
+
+
 def test_relu_conv_bn_module_runs_on_the_dense_op(monkeypatch):
     """`ReLUConvBN` with a 3 x 3 kernel (the search space's `conv_3x3`): the module's forward goes through ONE fused node, matches the
     stock layers and updates the running statistics as torch does."""

@@ -1,0 +1,32 @@
+#!/bin/bash
+# round 6, call 11: is the training loop GPU-bound?  rocprofv3 kernel trace of Trainer.update on the example's architecture
+# stream (in-process, no worker pool: tools/diag/stock_layer_census.py), native layers on
+set -u
+mkdir -p gpurun_out/r06y
+export TMPDIR=/tmp
+cd /tmp
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+rm -rf /tmp/prof_loop
+CENSUS_STEPS=24 timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_loop -o r -- python3 $ROOT/tools/diag/stock_layer_census.py > $ROOT/gpurun_out/r06y/census_under_rocprof.txt 2> /tmp/prof_err.log
+DB=$(find /tmp/prof_loop -name "*.db" | head -1)
+if [ -z "$DB" ]; then echo "no db"; tail -5 /tmp/prof_err.log; exit 1; fi
+cd $ROOT
+python3 tools/rocprof_summary.py "$DB" gpurun_out/r06y/train_loop_rocprof_kernel_stats.txt "rocprofv3 --kernel-trace --stats -- python3 tools/diag/stock_layer_census.py (24 steps of Trainer.update, ghn3tm8, meta-batch 8, 64 images of 32 x 32; the architecture stream of examples/train_ghn_ddp.py)" 24
+head -45 gpurun_out/r06y/train_loop_rocprof_kernel_stats.txt | cut -c1-100,113-170
+python3 - <<PY
+import sqlite3
+cur = sqlite3.connect("$DB").cursor()
+ks = list(cur.execute('select start, end from kernels order by start'))
+n = len(ks)
+# busy time = union of kernel intervals; wall = last end - first start
+busy, cur_s, cur_e = 0, None, None
+for s, e in ks:
+    if cur_e is None or s > cur_e:
+        if cur_e is not None: busy += cur_e - cur_s
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+wall = ks[-1][1] - ks[0][0]
+print('kernels %d, per step %.0f; GPU busy (union) %.1f ms per step; wall %.1f ms per step' % (n, n / 24, busy / 24e6, wall / 24e6))
+PY

@@ -47,11 +47,14 @@ struct Desc {
     float eps;
 };
 
-__device__ __forceinline__ unsigned short bf16_rn(float v) {
-    unsigned u = __float_as_uint(v);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (unsigned short)(u >> 16);
+// two values at once on the hardware converter (v_cvt_pk_bf16_f32, round to nearest even as bf16_rn): low half = a
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bf16_pk(float a, float b) {
+    const f32x2_t v = {a, b};
+    return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2_t));
 }
+__device__ __forceinline__ unsigned short bf16_rn(float v) { return (unsigned short)bf16_pk(v, v); }
 // v = p[0] + p[1] (+ p[2]) in bf16 pieces: 16 (24) bits of mantissa.  With S = 3 pieces and the six products
 // 11 + 12 + 21 + 22 + 13 + 31 the matrix-core product carries fp32's own rounding (~1e-7); S = 2 (hi.hi + lo.hi + hi.lo) ~1e-5.
 template <int S>
@@ -494,22 +497,60 @@ __global__ __launch_bounds__(256) void tnet_dw_bwd_data_kernel(const float* __re
 // part[chunk][t][c] = sum over the chunk's output pixels of dy[p][c] relu(x[tap t of p][c])
 __global__ __launch_bounds__(256) void tnet_dw_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                             float* __restrict__ part, const Desc d, const int P, const int chunk_px) {
-    const int nq = d.C_in / 4, taps = d.ks * d.ks, items = taps * nq;
+    // Threads = (channel quad) x (pixel lane): a thread sums its channels over every PL-th pixel of the chunk for up to TG taps at
+    // a time (registers), the pixel lanes are then added through LDS.  (The first version gave one (tap, channel quad) to a
+    // thread and walked the chunk's 128 pixels in sequence with taps x C / 4 of the 256 threads busy: 108 us per call, 9 ms of
+    // the training loop's 75 ms of GPU time per step.)
+    constexpr int TG = 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                               // [PL][TG][nq]
+    const int nq = d.C_in / 4, taps = d.ks * d.ks, PL = max(1, 256 / nq);
+    const int cq = threadIdx.x % nq, pl = threadIdx.x / nq;
+    const bool live = pl < PL;
     const int pa = blockIdx.x * chunk_px, pb = min(P, pa + chunk_px);
     const int hw = d.Ho * d.Wo;
-    for (int it = threadIdx.x; it < items; it += 256) {
-        const int t = it / nq, c = (it % nq) * 4, kh = t / d.ks, kw = t % d.ks;
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int p = pa; p < pb; ++p) {
-            const int n = p / hw, r = p - n * hw, oh = r / d.Wo, ow = r - oh * d.Wo;
-            const int ih = oh * d.stride - d.pad + kh * d.dil, iw = ow * d.stride - d.pad + kw * d.dil;
-            if (ih < 0 || ih >= d.H || iw < 0 || iw >= d.W) continue;
-            const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (int64_t)p * d.C_in + c);
-            const f32x4 xv = *reinterpret_cast<const f32x4*>(x + ((int64_t)(n * d.H + ih) * d.W + iw) * d.C_in + c);
+    for (int t0 = 0; t0 < taps; t0 += TG) {
+        f32x4 acc[TG];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[e] = fmaf(g[e], fmaxf(xv[e], 0.f), acc[e]);
+        for (int tt = 0; tt < TG; ++tt) acc[tt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (live) {
+            for (int p = pa + pl; p < pb; p += PL) {
+                const int n = p / hw, r = p - n * hw, oh = r / d.Wo, ow = r - oh * d.Wo;
+                const int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(dy + (int64_t)p * d.C_in + 4 * cq);
+                const float* xn = x + (int64_t)n * d.H * d.W * d.C_in + 4 * cq;
+#pragma unroll
+                for (int tt = 0; tt < TG; ++tt) {
+                    const int t = t0 + tt;
+                    if (t < taps) {
+                        const int kh = t / d.ks, kw = t - kh * d.ks;
+                        const int ih = ih0 + kh * d.dil, iw = iw0 + kw * d.dil;
+                        if (ih >= 0 && ih < d.H && iw >= 0 && iw < d.W) {
+                            const f32x4 xv = *reinterpret_cast<const f32x4*>(xn + ((int64_t)ih * d.W + iw) * d.C_in);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[tt][e] = fmaf(g[e], fmaxf(xv[e], 0.f), acc[tt][e]);
+                        }
+                    }
+                }
+            }
         }
-        *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.x * taps + t) * d.C_in + c) = acc;
+        __syncthreads();                                                       // (the previous tap group's sums have been read)
+        if (live) {
+#pragma unroll
+            for (int tt = 0; tt < TG; ++tt) red[(pl * TG + tt) * nq + cq] = acc[tt];
+        }
+        __syncthreads();
+        for (int i = threadIdx.x; i < TG * nq; i += 256) {
+            const int tt = i / nq, c4 = i - tt * nq, t = t0 + tt;
+            if (t >= taps) continue;
+            f32x4 sum = red[tt * nq + c4];
+            for (int l = 1; l < PL; ++l) {
+                const f32x4 v = red[(l * TG + tt) * nq + c4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) sum[e] += v[e];
+            }
+            *reinterpret_cast<f32x4*>(part + ((int64_t)blockIdx.x * taps + t) * d.C_in + 4 * c4) = sum;
+        }
     }
 }
 
@@ -737,48 +778,81 @@ __global__ __launch_bounds__(256) void tnet_conv_wgrad_kernel(const float* __res
                                                               const float* __restrict__ stats, const float* __restrict__ gamma,
                                                               const float* __restrict__ s12, const float* __restrict__ x,
                                                               float* __restrict__ part, const CDesc d, const int P, const int chunk_px) {
+    // (round 6, second version: the loads of pixel step k + 1 are in flight during the products of step k -- registers -> the
+    // other LDS stage, one barrier per step; the first version loaded, cut and multiplied in sequence with two barriers)
     constexpr int S = 3;
-    __shared__ __attribute__((aligned(16))) unsigned short As[S * 64 * LDK], Bs[S * 64 * LDK];
+    constexpr int STAGE = S * 64 * LDK;
+    __shared__ __attribute__((aligned(16))) unsigned short As[2 * STAGE], Bs[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, r16 = lane & 15, kc = lane >> 4;
     const int ci_tiles = (d.C_in + 63) / 64, taps = d.kh * d.kw;
     const int chunk = blockIdx.x, co0 = blockIdx.y * 64, t = blockIdx.z / ci_tiles, ci0 = (blockIdx.z % ci_tiles) * 64;
     const int dh = (t / d.kw) * d.dil, dw_ = (t % d.kw) * d.dil;
     const int pa = chunk * chunk_px, pb = min(P, pa + chunk_px), hw = d.Ho * d.Wo;
+    // Thread = (pixel k of the step, 8 consecutive channels m8 ..): lanes of a wave hold 32 consecutive pixels of two channel
+    // groups.  The operands need the pixel index along k, i.e. a transposition on the way into LDS: neighbouring lanes (pixels
+    // k, k + 1) exchange halves so that every lane writes 32-bit words (two pixels of one channel) -- 12 conflict-free stores per
+    // operand instead of 24 two-byte ones that collided four ways (the first version's layout: 118 us per call).
+    const int k = tid & 31, m8 = (tid >> 5) * 8;
+    float va[8], vb[8];
+    auto put = [&](const float (&v)[8], unsigned short* base) {
+        const bool odd = k & 1;
+        // even lanes take channels 0..3 of both pixels (k, k + 1), odd lanes channels 4..7: four floats change lanes
+        float lo[4], hi[4];                                                    // values at the even / the odd pixel of the pair
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float got = __shfl_xor(odd ? v[e] : v[4 + e], 1, 64);
+            lo[e] = odd ? got : v[e];
+            hi[e] = odd ? v[4 + e] : got;
+        }
+        unsigned* row = reinterpret_cast<unsigned*>(base + (m8 + (odd ? 4 : 0)) * LDK + (k & ~1));
+#pragma unroll
+        for (int q = 0; q < S; ++q) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const unsigned h = bf16_pk(lo[e], hi[e]);
+                row[(q * 64 * LDK + e * LDK) / 2] = h;
+                lo[e] -= __uint_as_float(h << 16);
+                hi[e] -= __uint_as_float(h & 0xffff0000u);
+            }
+        }
+    };
+    auto fetch = [&](int pk) {
+        const int p = pk + k;
+        dz8(dout, z, stats, gamma, s12, d.C_out, p < pb ? p : P, P, co0 + m8, va);       // A[m = co][k = pixel]
+        int n = -1, ih = 0, iw = 0;                                                      // B[n = ci][k = pixel]: act(x) at the tap's input pixel
+        if (p < pb) {
+            n = p / hw;
+            const int r = p - n * hw, oh = r / d.Wo, ow = r - oh * d.Wo;
+            ih = oh * d.sh - d.ph + dh; iw = ow * d.sw - d.pw + dw_;
+        }
+        conv_in8(x, d, n, ih, iw, ci0 + m8, vb);
+    };
+    auto stage = [&](int buf) {
+        put(va, As + buf * STAGE);
+        put(vb, Bs + buf * STAGE);
+    };
     f32x4 acc[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int pk = pa; pk < pb; pk += KC) {
-        __syncthreads();
-        const int k = tid >> 3, m8 = (tid & 7) * 8, p = pk + k;
-        {   // A[m = co][k = pixel]
-            float v[8];
-            dz8(dout, z, stats, gamma, s12, d.C_out, p < pb ? p : P, P, co0 + m8, v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) splitS<S>(v[e], As, (m8 + e) * LDK + k, 64 * LDK);
-        }
-        {   // B[n = ci][k = pixel] = act(x) at the tap's input pixel
-            int n = -1, ih = 0, iw = 0;
-            if (p < pb) {
-                n = p / hw;
-                const int r = p - n * hw, oh = r / d.Wo, ow = r - oh * d.Wo;
-                ih = oh * d.sh - d.ph + dh; iw = ow * d.sw - d.pw + dw_;
-            }
-            float y[8];
-            conv_in8(x, d, n, ih, iw, ci0 + m8, y);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) splitS<S>(y[e], Bs, (m8 + e) * LDK + k, 64 * LDK);
-        }
-        __syncthreads();
+    fetch(pa);
+    stage(0);
+    __syncthreads();
+    int buf = 0;
+    for (int pk = pa; pk < pb; pk += KC, buf ^= 1) {
+        const bool more = pk + KC < pb;
+        if (more) fetch(pk + KC);
         u16x8 af[S];
 #pragma unroll
-        for (int q = 0; q < S; ++q) af[q] = frag(As + q * 64 * LDK, 16 * w + r16, kc);
+        for (int q = 0; q < S; ++q) af[q] = frag(As + buf * STAGE + q * 64 * LDK, 16 * w + r16, kc);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             u16x8 bf[S];
 #pragma unroll
-            for (int q = 0; q < S; ++q) bf[q] = frag(Bs + q * 64 * LDK, 16 * j + r16, kc);
+            for (int q = 0; q < S; ++q) bf[q] = frag(Bs + buf * STAGE + q * 64 * LDK, 16 * j + r16, kc);
             acc[j] = mma_terms<S>(af, bf, acc[j]);
         }
+        if (more) stage(buf ^ 1);
+        __syncthreads();
     }
     const int co = co0 + 16 * w + r16;
 #pragma unroll
@@ -813,7 +887,7 @@ Plan make_plan(const Desc& d) {
     chunks = std::max(1, std::min(chunks, (pl.P + KC - 1) / KC));
     pl.pw_chunk_px = ((pl.P + chunks - 1) / chunks + KC - 1) / KC * KC;
     pl.pw_chunks = (pl.P + pl.pw_chunk_px - 1) / pl.pw_chunk_px;
-    pl.dw_chunk_px = 128;
+    pl.dw_chunk_px = std::max(16, std::min(128, ((pl.P + 255) / 256 + 15) / 16 * 16));   // >= 256 workgroups where the image allows
     pl.dw_chunks = (pl.P + pl.dw_chunk_px - 1) / pl.dw_chunk_px;
     return pl;
 }
@@ -953,7 +1027,9 @@ extern "C" int ghn3_dwpw_bn_bwd(const ghn3_dwpw_desc* g, const float* dout, cons
                            dx, d, total4);
         LAUNCH_CHECK("dw bwd data")
         if (w_dw) {
-            hipLaunchKernelGGL(tnet_dw_wgrad_kernel, dim3(pl.dw_chunks), dim3(256), 0, s, dy, x, part_dw, d, pl.P, pl.dw_chunk_px);
+            const int nq = d.C_in / 4;
+            hipLaunchKernelGGL(tnet_dw_wgrad_kernel, dim3(pl.dw_chunks), dim3(256), (size_t)std::max(1, 256 / nq) * 16 * nq * 16, s, dy, x,
+                               part_dw, d, pl.P, pl.dw_chunk_px);
             LAUNCH_CHECK("dw wgrad")
             const int64_t cols = (int64_t)taps * d.C_in;
             hipLaunchKernelGGL(tnet_reduce_rows_kernel, dim3((int)((cols / 4 + 15) / 16)), dim3(256), 0, s, part_dw, pl.dw_chunks, cols,
@@ -1102,13 +1178,14 @@ __global__ __launch_bounds__(256) void tnet_conv2_kernel(const float* __restrict
         }
 #pragma unroll
         for (int q = 0; q < S; ++q) {
-            u16x8 h;
+            unsigned h[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                h[e] = bf16_rn(v[e]);
-                v[e] -= __uint_as_float((unsigned)h[e] << 16);
+            for (int e = 0; e < 4; ++e) {
+                h[e] = bf16_pk(v[2 * e], v[2 * e + 1]);
+                v[2 * e] -= __uint_as_float(h[e] << 16);
+                v[2 * e + 1] -= __uint_as_float(h[e] & 0xffff0000u);
             }
-            *reinterpret_cast<u16x8*>(A + q * TP * LDK + ai * LDK + acc_) = h;
+            *reinterpret_cast<uint4*>(A + q * TP * LDK + ai * LDK + acc_) = uint4{h[0], h[1], h[2], h[3]};
         }
 #pragma unroll
         for (int u = 0; u < NB; ++u) {

@@ -30,3 +30,20 @@ busy += cur_e - cur_s
 wall = ks[-1][1] - ks[0][0]
 print('kernels %d, per step %.0f; GPU busy (union) %.1f ms per step; wall %.1f ms per step' % (n, n / 24, busy / 24e6, wall / 24e6))
 PY
+python3 - <<PY
+import sqlite3
+cur = sqlite3.connect("$DB").cursor()
+cols = [r[1] for r in cur.execute("pragma table_info(kernels)")]
+print(cols)
+want = [c for c in ('grid_x','grid_y','grid_z','workgroup_x','grid_size_x','grid_size_y','grid_size_z','workgroup_size_x','lds_size','lds_block_size') if c in cols]
+q = 'select (end-start)/1000.0 as us, %s from kernels where name like "%%tnet_conv_wgrad%%" order by us desc' % ','.join(want)
+rows = list(cur.execute(q))
+import collections
+tot = sum(r[0] for r in rows)
+print('conv_wgrad calls', len(rows), 'total us', tot)
+acc = 0
+for r in rows[:12]: print(r)
+b = collections.Counter()
+for r in rows: b[(r[1:], )] += r[0]
+for k, v in sorted(b.items(), key=lambda kv: -kv[1])[:25]: print(round(v), k, sum(1 for r in rows if (r[1:],) == k))
+PY

@@ -985,8 +985,11 @@ extern "C" int ghn3_dwpw_bn_bwd(const ghn3_dwpw_desc* g, const float* dout, cons
     const Plan pl = make_plan(d);
     const int taps = d.ks * d.ks;
     float* part12 = scratch;
-    float* s12 = part12 + (int64_t)pl.n_tiles * 2 * d.C_out;
-    float* dy = s12 + 2 * d.C_out;
+    float* const s12_scratch = part12 + (int64_t)pl.n_tiles * 2 * d.C_out;
+    // (dbeta directly followed by dgamma -- how target_ops.py lays them out -- IS the [sum dout | sum dout xhat] pair: no copies)
+    const bool s12_in_place = dbeta && dgamma == dbeta + d.C_out;
+    float* s12 = s12_in_place ? dbeta : s12_scratch;
+    float* dy = s12_scratch + 2 * d.C_out;
     float* part_pw = dy + (int64_t)pl.P * d.C_in;
     float* part_dw = part_pw + (int64_t)pl.pw_chunks * d.C_out * d.C_in;
     // 1. dgamma / dbeta
@@ -998,8 +1001,10 @@ extern "C" int ghn3_dwpw_bn_bwd(const ghn3_dwpw_desc* g, const float* dout, cons
         hipLaunchKernelGGL(tnet_reduce_rows_kernel, dim3((2 * d.C_out / 4 + 15) / 16), dim3(256), 0, s, part12, pl.n_tiles,
                            (int64_t)2 * d.C_out, s12, 0, 0);
         LAUNCH_CHECK("bn bwd reduce")
-        hipMemcpyAsync(dbeta, s12, (size_t)d.C_out * 4, hipMemcpyDeviceToDevice, s);
-        hipMemcpyAsync(dgamma, s12 + d.C_out, (size_t)d.C_out * 4, hipMemcpyDeviceToDevice, s);
+        if (!s12_in_place) {
+            hipMemcpyAsync(dbeta, s12, (size_t)d.C_out * 4, hipMemcpyDeviceToDevice, s);
+            hipMemcpyAsync(dgamma, s12 + d.C_out, (size_t)d.C_out * 4, hipMemcpyDeviceToDevice, s);
+        }
     }
     // 2. dy = dz W_pw
     {
@@ -1283,6 +1288,11 @@ CPlan make_cplan(const CDesc& d) {
     return pl;
 }
 
+inline bool conv2_on() {
+    static const bool on = !(getenv("GHN3_TNET_CONV2") && atoi(getenv("GHN3_TNET_CONV2")) == 0);
+    return on;
+}
+
 int check_cdesc(const ghn3_conv_desc* g, CDesc& d) {
     if (!g) { ghn3_set_error("conv: null descriptor"); return GHN3_E_ARG; }
     d = CDesc{g->N, g->H, g->W, g->C_in, g->C_out, g->kh, g->kw, g->stride_h, g->stride_w, g->pad_h, g->pad_w, g->dil, g->Ho, g->Wo,
@@ -1292,9 +1302,10 @@ int check_cdesc(const ghn3_conv_desc* g, CDesc& d) {
         ghn3_set_error("conv: non-positive size in the descriptor");
         return GHN3_E_ARG;
     }
-    if ((d.C_in & 3) || (d.C_out & 3) || d.C_in > 512 || d.C_out > 512 || d.kh > 7 || d.kw > 7) {
-        ghn3_set_error("conv: needs C_in, C_out multiples of 4 and <= 512, kernel <= 7 x 7 (got %d -> %d, %d x %d)", d.C_in, d.C_out,
-                       d.kh, d.kw);
+    // (the second-version kernels walk C_in in chunks and split it over blockIdx.y in the backward: wide inputs are fine)
+    if ((d.C_in & 3) || (d.C_out & 3) || d.C_in > (conv2_on() ? 4096 : 512) || d.C_out > 512 || d.kh > 7 || d.kw > 7) {
+        ghn3_set_error("conv: needs C_in, C_out multiples of 4, C_out <= 512, C_in <= 4096 (512 with GHN3_TNET_CONV2=0), kernel <= 7 x 7 "
+                       "(got %d -> %d, %d x %d)", d.C_in, d.C_out, d.kh, d.kw);
         return GHN3_E_LIMIT;
     }
     const int ho = (d.H + 2 * d.ph - d.dil * (d.kh - 1) - 1) / d.sh + 1, wo = (d.W + 2 * d.pw - d.dil * (d.kw - 1) - 1) / d.sw + 1;
@@ -1323,10 +1334,6 @@ int conv_repack(const CDesc& d, const CPlan& pl, const float* w, float* w_r, hip
 
 }  // namespace
 
-inline bool conv2_on() {
-    static const bool on = !(getenv("GHN3_TNET_CONV2") && atoi(getenv("GHN3_TNET_CONV2")) == 0);
-    return on;
-}
 // 16-bit weight pieces of the second-version kernels, in floats: [3][taps][rows][k padded to the chunk]
 inline int64_t pack_floats(int taps, int rows, int k) { return (((int64_t)3 * taps * rows * ((k + KC - 1) / KC * KC) + 1) / 2 + 3) / 4 * 4; }
 // columns per workgroup of the second-version kernels: as wide as possible while the grid still covers the chip
@@ -1416,8 +1423,11 @@ extern "C" int ghn3_conv_bn_bwd(const ghn3_conv_desc* g, const float* dout, cons
     const CPlan pl = make_cplan(d);
     const int64_t wr = (int64_t)pl.taps * d.C_out * d.C_in;
     float* part12 = scratch;
-    float* s12 = part12 + (int64_t)pl.n_tiles * 2 * d.C_out;
-    float* w_r = s12 + 2 * d.C_out;
+    float* const s12_scratch = part12 + (int64_t)pl.n_tiles * 2 * d.C_out;
+    // (dbeta directly followed by dgamma -- how target_ops.py lays them out -- IS the [sum dout | sum dout xhat] pair: no copies)
+    const bool s12_in_place = dbeta && dgamma == dbeta + d.C_out;
+    float* s12 = s12_in_place ? dbeta : s12_scratch;
+    float* w_r = s12_scratch + 2 * d.C_out;
     float* part_w = w_r + std::max(wr, pack_floats(pl.taps, d.C_in, d.C_out));
     float* ident = part_w + (int64_t)pl.w_chunks * wr;             // [mean 0 | 1 / std 1 | gamma 1]
     float* dzbuf = ident + 3 * d.C_out;                            // [P][C_out]: dz, written once (second-version kernels)
@@ -1441,8 +1451,10 @@ extern "C" int ghn3_conv_bn_bwd(const ghn3_conv_desc* g, const float* dout, cons
         hipLaunchKernelGGL(tnet_reduce_rows_kernel, dim3((2 * d.C_out / 4 + 15) / 16), dim3(256), 0, s, part12, pl.n_tiles,
                            (int64_t)2 * d.C_out, s12, 0, 0);
         LAUNCH_CHECK("bn bwd reduce")
-        hipMemcpyAsync(dbeta, s12, (size_t)d.C_out * 4, hipMemcpyDeviceToDevice, s);
-        hipMemcpyAsync(dgamma, s12 + d.C_out, (size_t)d.C_out * 4, hipMemcpyDeviceToDevice, s);
+        if (!s12_in_place) {
+            hipMemcpyAsync(dbeta, s12, (size_t)d.C_out * 4, hipMemcpyDeviceToDevice, s);
+            hipMemcpyAsync(dgamma, s12 + d.C_out, (size_t)d.C_out * 4, hipMemcpyDeviceToDevice, s);
+        }
     }
     if (v2) {
         const float* dzp = dout;

@@ -553,7 +553,9 @@ class _Network:
             # profiles/r05c_target_ops_channels_last_diag.txt), so the fused layers hand NCHW tensors to their neighbours
             x = x.contiguous(memory_format=torch.channels_last)
         if self._is_vit:
-            s0 = s1 = self.pos_enc(self.stem0(x))
+            patches = target_ops.run_conv_layer(self.stem0, x) if (x.is_cuda and target_ops.enabled() and
+                                                                   os.environ.get('GHN3_NATIVE_STEM', '1') != '0') else self.stem0(x)
+            s0 = s1 = self.pos_enc(patches)
         elif self._stem_type == 1:
             s0 = self._run_stem(self.stem0, x)
             s1 = None if _is_none(self.stem1) else self._run_stem(self.stem1, s0)

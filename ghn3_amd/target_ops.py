@@ -41,7 +41,13 @@ def _desc(x, C_out, ks, stride, pad, dil, eps):
 
 
 def _ptr(t):
-    return ctypes.c_void_p(t.data_ptr())
+    return t.data_ptr()               # (an int: ctypes converts it for the c_void_p parameters)
+
+
+def _stream():
+    """The current HIP stream of the current device as an integer handle (torch.cuda.current_stream() builds a Stream object
+    per call: 11 us; this is called twice per fused layer, ~700 times per training step)."""
+    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
 
 
 _SCRATCH = {}
@@ -100,7 +106,7 @@ class DwPwBn(torch.autograd.Function):
         z = torch.empty_like(out)
         stats = torch.empty(3 * C_out, dtype=torch.float32, device=dev)
         scratch = torch.empty(_scratch_floats(lib, d, 0), dtype=torch.float32, device=dev)
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = _stream()
         L._check(lib.ghn3_dwpw_bn_fwd(ctypes.byref(d), _ptr(xc), _ptr(wd) if wd is not None else None, _ptr(wp), _ptr(g), _ptr(b),
                                       _ptr(z), _ptr(out), _ptr(stats), _ptr(scratch), stream), 'ghn3_dwpw_bn_fwd')
         ctx.has_dw = wd is not None
@@ -128,10 +134,10 @@ class DwPwBn(torch.autograd.Function):
         buf = torch.empty(n_par + 64 + _scratch_floats(lib, d, 1), dtype=torch.float32, device=dev)
         dwd = None if wd is None else buf[:n_wd].view(wd.shape)
         dwp = buf[n_wd:n_wd + wp.numel()].view(wp.shape)
-        dg = buf[n_par - 2 * C_out:n_par - C_out]
-        db = buf[n_par - C_out:n_par]
+        db = buf[n_par - 2 * C_out:n_par - C_out]            # (dbeta directly followed by dgamma: the kernels' own pair of sums)
+        dg = buf[n_par - C_out:n_par]
         scratch = buf[(n_par + 63) // 64 * 64:]
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = _stream()
         L._check(lib.ghn3_dwpw_bn_bwd(ctypes.byref(d), _ptr(do), _ptr(xc), _ptr(z), _ptr(stats),
                                       _ptr(wd) if wd is not None else None, _ptr(wp), _ptr(g), _ptr(dx),
                                       _ptr(dwd) if dwd is not None else None, _ptr(dwp), _ptr(dg), _ptr(db), _ptr(scratch), stream),
@@ -149,6 +155,11 @@ def _pair(v):
 
 
 CONV_NO_NORM = 2                  # include/ghn3_hip.h GHN3_CONV_NO_NORM
+
+
+def _conv_max_in():
+    """Widest input of the dense-convolution op (include/ghn3_hip.h: the second-version kernels walk C_in in chunks)."""
+    return 4096 if os.environ.get('GHN3_TNET_CONV2', '1') != '0' else 512
 
 
 def _conv_desc(x, w, stride, pad, dil, relu, eps, no_norm=False):
@@ -190,7 +201,7 @@ class ConvBn(torch.autograd.Function):
         if not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 for t in (w, gamma, beta)) or w.dim() != 4:
             return False
         C_in, C_out = x.shape[1], w.shape[0]
-        return C_in % 4 == 0 and C_out % 4 == 0 and C_in <= 512 and C_out <= 512 and w.shape[1] == C_in and \
+        return C_in % 4 == 0 and C_out % 4 == 0 and C_in <= _conv_max_in() and C_out <= 512 and w.shape[1] == C_in and \
             max(w.shape[2], w.shape[3]) <= 7 and x.numel() < 2 ** 31 and gamma.numel() == C_out
 
     @staticmethod
@@ -204,7 +215,7 @@ class ConvBn(torch.autograd.Function):
         z = torch.empty_like(out)
         stats = torch.empty(3 * C_out, dtype=torch.float32, device=dev)
         scratch = torch.empty(_conv_scratch_floats(lib, d, 0), dtype=torch.float32, device=dev)
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = _stream()
         L._check(lib.ghn3_conv_bn_fwd(ctypes.byref(d), _ptr(xc), _ptr(wc), _ptr(g), _ptr(b), _ptr(z), _ptr(out), _ptr(stats),
                                       _ptr(scratch), stream), 'ghn3_conv_bn_fwd')
         ctx.save_for_backward(xc, z, stats, wc, g)
@@ -224,10 +235,10 @@ class ConvBn(torch.autograd.Function):
         n_par = wc.numel() + 2 * C_out
         buf = torch.empty((n_par + 63) // 64 * 64 + _conv_scratch_floats(lib, d, 1), dtype=torch.float32, device=dev)
         dw = buf[:wc.numel()].view(wc.shape)
-        dg = buf[wc.numel():wc.numel() + C_out]
-        db = buf[wc.numel() + C_out:n_par]
+        db = buf[wc.numel():wc.numel() + C_out]              # (dbeta directly followed by dgamma: the kernels' own pair of sums)
+        dg = buf[wc.numel() + C_out:n_par]
         scratch = buf[(n_par + 63) // 64 * 64:]
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = _stream()
         L._check(lib.ghn3_conv_bn_bwd(ctypes.byref(d), _ptr(do), _ptr(xc), _ptr(z), _ptr(stats), _ptr(wc), _ptr(g), _ptr(dx), _ptr(dw),
                                       _ptr(dg), _ptr(db), _ptr(scratch), stream), 'ghn3_conv_bn_bwd')
         return dx, dw, dg, db, None, None, None, None, None
@@ -245,7 +256,7 @@ class ConvOnly(torch.autograd.Function):
         if not (torch.is_tensor(w) and w.is_cuda and w.dtype == torch.float32 and w.dim() == 4):
             return False
         C_in, C_out = x.shape[1], w.shape[0]
-        return C_in % 4 == 0 and C_out % 4 == 0 and C_in <= 512 and C_out <= 512 and w.shape[1] == C_in and \
+        return C_in % 4 == 0 and C_out % 4 == 0 and C_in <= _conv_max_in() and C_out <= 512 and w.shape[1] == C_in and \
             max(w.shape[2], w.shape[3]) <= 7 and x.numel() < 2 ** 31
 
     @staticmethod
@@ -257,7 +268,7 @@ class ConvOnly(torch.autograd.Function):
         z = torch.empty((d.N, int(wc.shape[0]), d.Ho, d.Wo), dtype=torch.float32, device=x.device,
                         memory_format=torch.channels_last)
         scratch = torch.empty(_conv_scratch_floats(lib, d, 0), dtype=torch.float32, device=x.device)
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = _stream()
         L._check(lib.ghn3_conv_bn_fwd(ctypes.byref(d), _ptr(xc), _ptr(wc), None, None, _ptr(z), None, None, _ptr(scratch), stream),
                  'ghn3_conv_bn_fwd')
         ctx.save_for_backward(xc, wc)
@@ -275,7 +286,7 @@ class ConvOnly(torch.autograd.Function):
         n_par = (wc.numel() + 63) // 64 * 64
         buf = torch.empty(n_par + _conv_scratch_floats(lib, d, 1), dtype=torch.float32, device=xc.device)
         dw = buf[:wc.numel()].view(wc.shape)
-        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = _stream()
         L._check(lib.ghn3_conv_bn_bwd(ctypes.byref(d), _ptr(do), _ptr(xc), None, None, _ptr(wc), None, _ptr(dx), _ptr(dw), None,
                                       None, _ptr(buf[n_par:]), stream), 'ghn3_conv_bn_bwd')
         return dx, dw, None, None, None, None
@@ -350,6 +361,19 @@ def run_conv_pair_block(layers, x, keep_layout=False):
     out, stats = conv_bn(y, conv_b.weight, gamma, beta, conv_b.stride, conv_b.padding, _pair(conv_b.dilation)[0], False, bn.eps)
     _update_running_stats(bn, stats, out, has_run)
     return out if (keep_layout or lazy_layout(conv_a, conv_b, bn)) else out.contiguous(memory_format=torch.contiguous_format)
+
+
+def run_conv_layer(conv, x):
+    """A bare Conv2d without bias (the patch embedding of the ViT-style networks, ops.py:296 `conv_stride`) on the
+    dense-convolution op -- 3-channel images padded as in run_layer_seq -- handing an NCHW tensor on; else the stock layer."""
+    if _plain_conv(conv) and torch.is_tensor(x) and x.is_cuda and x.dim() == 4:
+        w, xin = conv.weight, x
+        if x.shape[1] == 3 and w.shape[1] == 3:
+            xin, w = F.pad(x, (0, 0, 0, 0, 0, 1)), F.pad(w, (0, 0, 0, 0, 0, 1))
+        if ConvOnly.applicable(xin, w):
+            y = conv_only(xin, w, conv.stride, conv.padding, _pair(conv.dilation)[0], relu=False)
+            return y.contiguous(memory_format=torch.contiguous_format)
+    return conv(x)
 
 
 def _is_kind(m, name):
@@ -444,9 +468,8 @@ def run_pointwise_block(layers, x, keep_layout=False):
         tuple(pw.padding) == (0, 0) and getattr(pw, 'groups', 1) == 1 and torch.is_tensor(w_pw) and \
         DwPwBn.applicable(x, None, w_pw, gamma, beta, 1, batch_stats)
     if not ok:
-        for m in layers:
-            x = m(x)
-        return x
+        # (e.g. more than 512 input channels -- the concatenated states of a wide cell: the dense-convolution op takes those)
+        return run_conv_block(layers, x, keep_layout)
     out, stats = dwpw_bn(x, None, w_pw, gamma, beta, pw.stride[0], 0, 1, bn.eps)
     _update_running_stats(bn, stats, out, has_run)
     return out if (keep_layout or lazy_layout(pw, bn)) else out.contiguous(memory_format=torch.contiguous_format)

@@ -542,7 +542,7 @@ int ghn3_dwpw_bn_bwd(const ghn3_dwpw_desc* desc, const float* dout, const float*
  * 7x7` ops of the DeepNets-1M search space, ops.py:297), forward and backward, NHWC fp32 activations, batch statistics.
  * w [C_out][C_in][kh][kw] is the view of the GHN's flat prediction buffer (read in place; dw is written in the same order),
  * z / out [N Ho Wo][C_out], stats [3 C_out] as for ghn3_dwpw_bn_fwd; relu != 0 applies ReLU to x first (and its mask to dx).
- * Limits (GHN3_E_LIMIT: the caller keeps its stock path): C_in, C_out multiples of 4 and <= 512, kernel <= 7 x 7.
+ * Limits (GHN3_E_LIMIT: the caller keeps its stock path): C_in, C_out multiples of 4, C_out <= 512, C_in <= 4096, kernel <= 7 x 7.
  * Deterministic (fixed-order partial sums).
  * relu | GHN3_CONV_NO_NORM: the convolution alone (the first half of the 1 x k / k x 1 pair of ops.py:186-190, which has no norm
  * layer of its own): the forward writes its result to `z` and stops (gamma, beta, out, stats may be NULL); the backward takes

@@ -104,6 +104,7 @@ CONV_CASES = [   # N, C_in, C_out, H, W, (kh, kw), (sh, sw), (ph, pw), dil, relu
     (2, 32, 48, 10, 10, (1, 7), (1, 2), (0, 3), 1, True),       # the 1 x k half of a `conv2` pair, asymmetric stride
     (2, 32, 48, 10, 10, (7, 1), (2, 1), (3, 0), 1, True),
     (3, 24, 40, 11, 11, (3, 3), (1, 1), (2, 2), 2, True),       # dilation 2
+    (6, 576, 192, 4, 4, (1, 1), (1, 1), (0, 0), 1, True),       # a cell's preprocessing layer on three concatenated states: C_in > 512
 ]
 
 
@@ -220,6 +221,36 @@ def test_stem_sequences_run_on_the_dense_op(monkeypatch, spec):
     assert _rel(res['fused'][2], res['stock'][2]) < 5e-4
     for a, b in zip(res['fused'][3], res['stock'][3]):
         assert a.shape == b.shape and _rel(a, b) < 5e-4, _rel(a, b)
+
+
+def test_patch_embedding_and_wide_pointwise_layers_leave_the_stock_path(monkeypatch):
+    """The two convolution shapes the stock path kept until the end of round 6: the ViT-style patch embedding (a bare strided
+    Conv2d on the 3-channel image, ops.py:296) and the 1 x 1 preprocessing layer over more than 512 concatenated channels --
+    both on the dense-convolution op now, equal to the stock layers."""
+    from ghn3_amd import ops
+    res = {}
+    for mode in ('stock', 'fused'):
+        monkeypatch.setenv('GHN3_NATIVE_OPS', '0' if mode == 'stock' else '1')
+        torch.manual_seed(4)
+        conv = torch.nn.Conv2d(3, 64, 3, stride=3, padding=1, bias=False).cuda()
+        x = torch.randn(5, 3, 32, 32, device='cuda', requires_grad=True)
+        from ghn3_amd import target_ops as T
+        y = T.run_conv_layer(conv, x) if mode == 'fused' else conv(x)
+        up = torch.randn(y.shape, generator=torch.Generator().manual_seed(2)).cuda()
+        (y * up).sum().backward()
+        m = ops.ReLUConvBN(576, 192, 1, 1, 0).cuda().train()
+        x2 = torch.randn(4, 576, 4, 4, device='cuda', requires_grad=True)
+        y2 = m(x2)
+        up2 = torch.randn(y2.shape, generator=torch.Generator().manual_seed(3)).cuda()
+        (y2 * up2).sum().backward()
+        res[mode] = (y.detach().cpu(), x.grad.cpu(), conv.weight.grad.cpu(), y2.detach().cpu(), x2.grad.cpu(),
+                     [p.grad.cpu() for p in m.parameters()], type(y2.grad_fn).__name__)
+    assert 'ConvBn' in res['fused'][6] or 'Clone' in res['fused'][6] or 'Contiguous' in res['fused'][6], res['fused'][6]
+    assert res['fused'][0].is_contiguous()
+    for k in range(5):
+        assert _rel(res['fused'][k], res['stock'][k]) < 5e-4, (k, _rel(res['fused'][k], res['stock'][k]))
+    for a, b in zip(res['fused'][5], res['stock'][5]):
+        assert _rel(a, b) < 5e-4
 
 
 def test_relu_conv_bn_module_runs_on_the_dense_op(monkeypatch):

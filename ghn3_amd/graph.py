@@ -198,9 +198,9 @@ class GraphBatch:
         same_nets = hasattr(self, 'nets') and len(nets) == len(self.nets) and all(a is b for a, b in zip(nets, self.nets))
         if prog is None or have != args or not same_nets:
             if prog is not None and have['reduce_graph']:
+                differs = ', '.join(k for k in args if have.get(k) != args[k]) or 'other networks'
                 raise ValueError('this batch was precompiled with reduce_graph=True for other arguments (%s): its networks '
-                                 'no longer carry the shape tables a new compile needs'
-                                 % ', '.join(k for k in args if have.get(k) != args[k]) or 'other networks')
+                                 'no longer carry the shape tables a new compile needs' % differs)
             return None
         self.program = None
         return prog

@@ -1508,3 +1508,213 @@ extern "C" int ghn3_conv_bn_bwd(const ghn3_conv_desc* g, const float* dout, cons
     LAUNCH_CHECK("conv wgrad reduce")
     return GHN3_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// squeeze-and-excitation with a hard-swish gate (round 6; ChannelSELayer, ops.py:239-274):
+//   s = mean_hw(x);  h = relu(W1 s + b1);  a = W2 h + b2;  y = x * hardswish(a)
+// One workgroup per sample: the reference runs mean, two hipBLASLt GEMMs of a 64-row batch (80 us of host dispatch each),
+// ReLU, hard-swish and the product as ~8 launches forward and ~14 backward; here 1 and 2.  NHWC activations as the other ops.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__device__ __forceinline__ float hswish(float a) { return a * fminf(fmaxf(a + 3.f, 0.f), 6.f) * (1.f / 6.f); }
+// (torch's hardswish_backward: 0 below -3, x / 3 + 0.5 up to 3, 1 above)
+__device__ __forceinline__ float hswish_grad(float a) { return a < -3.f ? 0.f : (a <= 3.f ? a * (1.f / 3.f) + 0.5f : 1.f); }
+
+// v[c] = sum over the sample's pixels of a[p][c] (* b[p][c] when b != nullptr), c = 0 .. C - 1, into LDS `out` (floats);
+// `red` = 256 float4 of LDS.  Threads = channel quad x pixel lane.
+__device__ __forceinline__ void se_pixel_sum(const float* __restrict__ a, const float* __restrict__ b, int HW, int C, f32x4* red,
+                                             float* out, float scale) {
+    const int nq = C / 4, PL = max(1, 256 / nq), cq = threadIdx.x % nq, pl = threadIdx.x / nq;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (pl < PL) {
+        for (int p = pl; p < HW; p += PL) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(a + (int64_t)p * C + 4 * cq);
+            if (b) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(b + (int64_t)p * C + 4 * cq);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] = fmaf(u[e], v[e], acc[e]);
+            } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[e] += u[e];
+            }
+        }
+        red[pl * nq + cq] = acc;
+    }
+    __syncthreads();
+    for (int q = threadIdx.x; q < nq; q += 256) {
+        f32x4 sum = red[q];
+        for (int l = 1; l < PL; ++l) {
+            const f32x4 v = red[l * nq + q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) sum[e] += v[e];
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) out[4 * q + e] = sum[e] * scale;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void tnet_se_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w1,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2,
+                                                          const float* __restrict__ b2, float* __restrict__ y, float* __restrict__ save,
+                                                          const int HW, const int C, const int J) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem);                               // [256]
+    float* s = reinterpret_cast<float*>(smem + 4096);                          // [C]
+    float* g = s + C;                                                          // [C]
+    float* h = g + C;                                                          // [J]
+    const int n = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const float* xn = x + (int64_t)n * HW * C;
+    float* sv = save + (int64_t)n * (2 * C + J);
+    se_pixel_sum(xn, nullptr, HW, C, red, s, 1.f / (float)HW);
+    for (int j = wv; j < J; j += 4) {                                          // h = relu(W1 s + b1): a wave per output
+        float acc = 0.f;
+        for (int c = lane; c < C; c += 64) acc = fmaf(w1[(int64_t)j * C + c], s[c], acc);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+        if (lane == 0) h[j] = fmaxf(acc + b1[j], 0.f);
+    }
+    __syncthreads();
+    for (int c = wv; c < C; c += 4) {                                          // a = W2 h + b2, g = hardswish(a)
+        float acc = 0.f;
+        for (int j = lane; j < J; j += 64) acc = fmaf(w2[(int64_t)c * J + j], h[j], acc);
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc += __shfl_xor(acc, m, 64);
+        if (lane == 0) {
+            const float a = acc + b2[c];
+            g[c] = hswish(a);
+            sv[C + c] = a;
+        }
+    }
+    for (int c = tid; c < C; c += 256) sv[c] = s[c];
+    for (int j = tid; j < J; j += 256) sv[2 * C + j] = h[j];
+    __syncthreads();
+    const int nq = C / 4;
+    float* yn = y + (int64_t)n * HW * C;
+    for (int i = tid; i < HW * nq; i += 256) {
+        const int c4 = (i % nq) * 4;
+        f32x4 v = *reinterpret_cast<const f32x4*>(xn + 4 * (int64_t)i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= g[c4 + e];
+        *reinterpret_cast<f32x4*>(yn + 4 * (int64_t)i) = v;
+    }
+}
+
+// per sample: dx, and the vectors the parameter gradients are sums of: vec[n] = [da (C) | dz1 (J)]
+__global__ __launch_bounds__(256) void tnet_se_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                          const float* __restrict__ w1, const float* __restrict__ w2,
+                                                          const float* __restrict__ save, float* __restrict__ dx, float* __restrict__ vec,
+                                                          const int HW, const int C, const int J) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    f32x4* red = reinterpret_cast<f32x4*>(smem);
+    float* da = reinterpret_cast<float*>(smem + 4096);                         // [C]: dg, then da in place
+    float* ds = da + C;                                                        // [C]
+    float* dz = ds + C;                                                        // [J]
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const float* xn = x + (int64_t)n * HW * C;
+    const float* dyn = dy + (int64_t)n * HW * C;
+    const float* sv = save + (int64_t)n * (2 * C + J);
+    float* vn = vec + (int64_t)n * (C + J);
+    se_pixel_sum(dyn, xn, HW, C, red, da, 1.f);                                // dg[c] = sum_p dy x
+    for (int c = tid; c < C; c += 256) {
+        const float v = da[c] * hswish_grad(sv[C + c]);
+        da[c] = v;
+        vn[c] = v;
+    }
+    __syncthreads();
+    for (int j = tid; j < J; j += 256) {                                       // dh = W2^T da, masked by the ReLU
+        float acc = 0.f;
+        for (int c = 0; c < C; ++c) acc = fmaf(w2[(int64_t)c * J + j], da[c], acc);
+        const float v = sv[2 * C + j] > 0.f ? acc : 0.f;
+        dz[j] = v;
+        vn[C + j] = v;
+    }
+    __syncthreads();
+    const float inv = 1.f / (float)HW;
+    for (int c = tid; c < C; c += 256) {                                       // ds = W1^T dz1, spread over the pixels
+        float acc = 0.f;
+        for (int j = 0; j < J; ++j) acc = fmaf(w1[(int64_t)j * C + c], dz[j], acc);
+        ds[c] = acc * inv;
+    }
+    __syncthreads();
+    const int nq = C / 4;
+    float* dxn = dx + (int64_t)n * HW * C;
+    for (int i = tid; i < HW * nq; i += 256) {
+        const int c4 = (i % nq) * 4;
+        const f32x4 gy = *reinterpret_cast<const f32x4*>(dyn + 4 * (int64_t)i);
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaf(gy[e], hswish(sv[C + c4 + e]), ds[c4 + e]);
+        *reinterpret_cast<f32x4*>(dxn + 4 * (int64_t)i) = v;
+    }
+}
+
+// dW2[c][j] = sum_n da[n][c] h[n][j];  dW1[j][c] = sum_n dz1[n][j] s[n][c];  db2 = sum_n da;  db1 = sum_n dz1  (fixed order over n)
+__global__ __launch_bounds__(256) void tnet_se_wgrad_kernel(const float* __restrict__ vec, const float* __restrict__ save,
+                                                            float* __restrict__ dw1, float* __restrict__ db1, float* __restrict__ dw2,
+                                                            float* __restrict__ db2, const int N, const int C, const int J) {
+    const int64_t cj = (int64_t)C * J, total = 2 * cj + C + J;
+    const int sv_ld = 2 * C + J, v_ld = C + J;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        float acc = 0.f;
+        if (i < cj) {                                                          // dW2[c][j]
+            const int c = (int)(i / J), j = (int)(i % J);
+            for (int n = 0; n < N; ++n) acc = fmaf(vec[(int64_t)n * v_ld + c], save[(int64_t)n * sv_ld + 2 * C + j], acc);
+            dw2[i] = acc;
+        } else if (i < 2 * cj) {                                               // dW1[j][c]
+            const int64_t r = i - cj;
+            const int j = (int)(r / C), c = (int)(r % C);
+            for (int n = 0; n < N; ++n) acc = fmaf(vec[(int64_t)n * v_ld + C + j], save[(int64_t)n * sv_ld + c], acc);
+            dw1[r] = acc;
+        } else if (i < 2 * cj + C) {
+            const int c = (int)(i - 2 * cj);
+            for (int n = 0; n < N; ++n) acc += vec[(int64_t)n * v_ld + c];
+            db2[c] = acc;
+        } else {
+            const int j = (int)(i - 2 * cj - C);
+            for (int n = 0; n < N; ++n) acc += vec[(int64_t)n * v_ld + C + j];
+            db1[j] = acc;
+        }
+    }
+}
+
+int check_se(int N, int HW, int C, int J) {
+    if (N <= 0 || HW <= 0 || C <= 0 || J <= 0) { ghn3_set_error("se: non-positive size"); return GHN3_E_ARG; }
+    if ((C & 3) || C > 1024 || J > 1024 || (int64_t)N * HW * C >= ((int64_t)1 << 31)) {
+        ghn3_set_error("se: needs C a multiple of 4, C, J <= 1024 and fewer than 2^31 activations (got C = %d, J = %d)", C, J);
+        return GHN3_E_LIMIT;
+    }
+    return GHN3_OK;
+}
+
+}  // namespace
+
+extern "C" int ghn3_se_fwd(int N, int HW, int C, int J, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                           float* y, float* save, void* stream_) {
+    int rc = check_se(N, HW, C, J);
+    if (rc) return rc;
+    if (!x || !w1 || !b1 || !w2 || !b2 || !y || !save) { ghn3_set_error("se fwd: null pointer"); return GHN3_E_ARG; }
+    hipLaunchKernelGGL(tnet_se_fwd_kernel, dim3(N), dim3(256), (size_t)4096 + (2 * C + J) * 4, (hipStream_t)stream_, x, w1, b1, w2, b2, y, save,
+                       HW, C, J);
+    LAUNCH_CHECK("se fwd")
+    return GHN3_OK;
+}
+
+extern "C" int ghn3_se_bwd(int N, int HW, int C, int J, const float* dy, const float* x, const float* w1, const float* w2, const float* save,
+                           float* dx, float* dw1, float* db1, float* dw2, float* db2, float* scratch, void* stream_) {
+    int rc = check_se(N, HW, C, J);
+    if (rc) return rc;
+    if (!dy || !x || !w1 || !w2 || !save || !dx || !dw1 || !db1 || !dw2 || !db2 || !scratch) {
+        ghn3_set_error("se bwd: null pointer");
+        return GHN3_E_ARG;
+    }
+    hipStream_t s = (hipStream_t)stream_;
+    hipLaunchKernelGGL(tnet_se_bwd_kernel, dim3(N), dim3(256), (size_t)4096 + (2 * C + J) * 4, s, dy, x, w1, w2, save, dx, scratch, HW, C, J);
+    LAUNCH_CHECK("se bwd")
+    const int64_t total = (int64_t)2 * C * J + C + J;
+    hipLaunchKernelGGL(tnet_se_wgrad_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 4096)), dim3(256), 0, s, scratch, save, dw1, db1, dw2,
+                       db2, N, C, J);
+    LAUNCH_CHECK("se wgrad")
+    return GHN3_OK;
+}

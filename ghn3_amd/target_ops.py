@@ -307,6 +307,72 @@ def conv_bn(x, w, gamma, beta, stride=1, padding=0, dilation=1, relu=True, eps=1
     return ConvBn.apply(x, w, gamma, beta, _pair(stride), _pair(padding), int(dilation), bool(relu), float(eps))
 
 
+class SqueezeExcite(torch.autograd.Function):
+    """y = x * hardswish(W2 relu(W1 mean_hw(x) + b1) + b2) as ONE autograd node on ghn3_se_fwd / _bwd (round 6:
+    `ChannelSELayer`, ops.py:239-274).  NHWC storage inside; the Linear layers' weights and biases are read in place."""
+
+    @staticmethod
+    def applicable(x, w1, b1, w2, b2):
+        if not (enabled() and os.environ.get('GHN3_NATIVE_SE', '1') != '0' and torch.is_tensor(x) and x.is_cuda and
+                x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled()):
+            return False
+        if not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 for t in (w1, b1, w2, b2)):
+            return False
+        C, J = x.shape[1], w1.shape[0]
+        return C % 4 == 0 and C <= 1024 and J <= 1024 and tuple(w1.shape) == (J, C) and tuple(w2.shape) == (C, J) and \
+            b1.numel() == J and b2.numel() == C and x.numel() < 2 ** 31
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2):
+        lib = L.load()
+        xc = x.contiguous(memory_format=torch.channels_last)
+        w1c, b1c, w2c, b2c = w1.contiguous(), b1.contiguous(), w2.contiguous(), b2.contiguous()
+        N, C, H, W = xc.shape
+        J = int(w1c.shape[0])
+        y = torch.empty_like(xc)
+        save = torch.empty(N * (2 * C + J), dtype=torch.float32, device=x.device)
+        L._check(lib.ghn3_se_fwd(N, H * W, C, J, _ptr(xc), _ptr(w1c), _ptr(b1c), _ptr(w2c), _ptr(b2c), _ptr(y), _ptr(save), _stream()),
+                 'ghn3_se_fwd')
+        ctx.save_for_backward(xc, w1c, w2c, save)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        xc, w1c, w2c, save = ctx.saved_tensors
+        N, C, H, W = xc.shape
+        J = int(w1c.shape[0])
+        do = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty_like(xc)
+        n_par = 2 * C * J + C + J
+        buf = torch.empty((n_par + 63) // 64 * 64 + N * (C + J), dtype=torch.float32, device=xc.device)
+        dw1 = buf[:C * J].view(J, C)
+        dw2 = buf[C * J:2 * C * J].view(C, J)
+        db1 = buf[2 * C * J:2 * C * J + J]
+        db2 = buf[2 * C * J + J:n_par]
+        L._check(lib.ghn3_se_bwd(N, H * W, C, J, _ptr(do), _ptr(xc), _ptr(w1c), _ptr(w2c), _ptr(save), _ptr(dx), _ptr(dw1), _ptr(db1),
+                                 _ptr(dw2), _ptr(db2), _ptr(buf[(n_par + 63) // 64 * 64:]), _stream()), 'ghn3_se_bwd')
+        return dx, dw1, db1, dw2, db2
+
+
+def se_layer(x, w1, b1, w2, b2):
+    """Squeeze-and-excitation with a hard-swish gate on the fused op: x (N, C, H, W) fp32 CUDA; w1 (J, C), b1 (J), w2 (C, J), b2 (C)."""
+    if not x.is_cuda:
+        raise L.Ghn3Error('se_layer runs on an MI355X only (no CPU implementation: use the stock torch layers)')
+    return SqueezeExcite.apply(x, w1, b1, w2, b2)
+
+
+def run_se_layer(fc1, fc2, x, keep_layout=False):
+    """`ChannelSELayer` body (before its stride slicing) on the fused op where it applies; None otherwise (the caller keeps its
+    stock layers)."""
+    w1, b1, w2, b2 = (getattr(fc1, 'weight', None), getattr(fc1, 'bias', None), getattr(fc2, 'weight', None),
+                      getattr(fc2, 'bias', None))
+    if not SqueezeExcite.applicable(x, w1, b1, w2, b2):
+        return None
+    y = se_layer(x, w1, b1, w2, b2)
+    return y if (keep_layout or lazy_layout(fc1, fc2)) else y.contiguous(memory_format=torch.contiguous_format)
+
+
 def conv_reference(x, w, gamma, beta, stride=1, padding=0, dilation=1, relu=True, eps=1e-5):
     """The stock layers ConvBn replaces (ops.py:186-193), functional form -- the parity reference of the tests."""
     y = F.conv2d(F.relu(x) if relu else x, w, None, stride, padding, dilation)

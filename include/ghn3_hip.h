@@ -559,6 +559,18 @@ int ghn3_conv_bn_bwd(const ghn3_conv_desc* desc, const float* dout, const float*
                      const float* w, const float* gamma, float* dx, float* dw, float* dgamma, float* dbeta, float* scratch,
                      void* stream);
 
+/* ---- target-network layers, third slice (ABI v19, round 6): squeeze-and-excitation with a hard-swish gate -----------------
+ * Replaces `ChannelSELayer.forward` (/root/reference/ghn3/ops.py:239-274) executed at trainer.py:308-319 and torch autograd of it:
+ *   s = mean over the pixels of x;  h = relu(W1 s + b1);  a = W2 h + b2;  y = x * hardswish(a)
+ * x, y, dy, dx [N][HW][C] fp32 (NHWC); w1 [J][C], b1 [J], w2 [C][J], b2 [C] (the Linear layers' own layouts, read in place);
+ * save [N][2 C + J] = (s | a | h) written by the forward for the backward; scratch [N][C + J] floats.
+ * One workgroup per sample forward, the same + one parameter-gradient launch backward; fixed summation orders.
+ * Limits (GHN3_E_LIMIT): C a multiple of 4, C and J <= 1024. */
+int ghn3_se_fwd(int N, int HW, int C, int J, const float* x, const float* w1, const float* b1, const float* w2, const float* b2,
+                float* y, float* save, void* stream);
+int ghn3_se_bwd(int N, int HW, int C, int J, const float* dy, const float* x, const float* w1, const float* w2, const float* save,
+                float* dx, float* dw1, float* db1, float* dw2, float* db2, float* scratch, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

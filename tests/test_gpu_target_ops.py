@@ -253,6 +253,41 @@ def test_patch_embedding_and_wide_pointwise_layers_leave_the_stock_path(monkeypa
         assert _rel(a, b) < 5e-4
 
 
+@pytest.mark.parametrize('case', [(6, 32, 16, 16, 1), (5, 48, 9, 7, 2), (3, 256, 4, 4, 1), (2, 64, 32, 32, 2), (4, 512, 2, 2, 1)])
+def test_squeeze_excitation_layer_matches_the_stock_layers(case):
+    """ghn3_se_fwd / _bwd (round 6: `ChannelSELayer`, ops.py:239-274 -- mean, two Linear layers, ReLU, hard-swish gate, product, stride
+    slicing -- as one node) against the same module on its stock layers in fp64: output, input gradient, both weights and biases;
+    deterministic."""
+    from ghn3_amd import ops, target_ops as T
+    N, C, H, W, stride = case
+    torch.manual_seed(C + H)
+    m = ops.ChannelSELayer(C, stride=stride)
+    with torch.no_grad():
+        for p in m.parameters():
+            p.mul_(3.0)                                            # (gates on both sides of the hard-swish knees)
+    x = torch.randn(N, C, H, W) * 2
+    ref_m = ops.ChannelSELayer(C, stride=stride).double()
+    ref_m.load_state_dict({k: v.double() for k, v in m.state_dict().items()})
+    xr = x.double().requires_grad_(True)
+    ref = ref_m(xr)
+    up = torch.randn(ref.shape, generator=torch.Generator().manual_seed(1))
+    (ref * up.double()).sum().backward()
+    m = m.cuda()
+    xd = x.cuda().requires_grad_(True)
+    assert T.SqueezeExcite.applicable(xd, m.fc1.weight, m.fc1.bias, m.fc2.weight, m.fc2.bias)
+    out = m(xd)
+    assert out.shape == ref.shape
+    assert 'SqueezeExcite' in type(out.grad_fn).__name__ or stride > 1 or 'Clone' in type(out.grad_fn).__name__, type(out.grad_fn).__name__
+    (out * up.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    assert _rel(out.detach().cpu(), ref.detach()) < 1e-5
+    assert _rel(xd.grad.cpu(), xr.grad) < 1e-5
+    for (name, a), b in zip(m.named_parameters(), ref_m.parameters()):
+        assert a.grad is not None and _rel(a.grad.cpu(), b.grad) < 2e-5, (name, _rel(a.grad.cpu(), b.grad))
+    out2 = m(xd.detach())
+    assert torch.equal(out2, out.detach())
+
+
 def test_relu_conv_bn_module_runs_on_the_dense_op(monkeypatch):
     """`ReLUConvBN` with a 3 x 3 kernel (the search space's `conv_3x3`): the module's forward goes through ONE fused node, matches the
     stock layers and updates the running statistics as torch does."""

@@ -71,7 +71,7 @@ EXPORTS = ['ghn3_abi_version', 'ghn3_last_error', 'ghn3_ctx_create', 'ghn3_ctx_d
            'ghn3_ctx_set_compute_type', 'ghn3_ctx_side_wait', 'ghn3_ctx_side_pending', 'ghn3_ctx_cache_stats', 'ghn3_run', 'ghn3_event_create', 'ghn3_event_record',
            'ghn3_event_elapsed_ms', 'ghn3_event_destroy', 'ghn3_profile_enable', 'ghn3_profile_read',
            'ghn3_profile_read_tags', 'ghn3_dwpw_scratch_floats', 'ghn3_dwpw_bn_fwd', 'ghn3_dwpw_bn_bwd',
-           'ghn3_conv_scratch_floats', 'ghn3_conv_bn_fwd', 'ghn3_conv_bn_bwd', 'ghn3_se_fwd', 'ghn3_se_bwd']
+           'ghn3_conv_scratch_floats', 'ghn3_conv_bn_fwd', 'ghn3_conv_bn_bwd', 'ghn3_se_fwd', 'ghn3_se_bwd', 'ghn3_pool_fwd', 'ghn3_pool_bwd']
 OPFLAG_TIMED = 0x100
 OPFLAG_SIDE = 0x200
 
@@ -121,6 +121,8 @@ def load():
         lib.ghn3_conv_bn_bwd.argtypes = [ctypes.c_void_p] * 13
         lib.ghn3_se_fwd.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 8
         lib.ghn3_se_bwd.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p] * 12
+        lib.ghn3_pool_fwd.argtypes = [ctypes.c_void_p] * 5
+        lib.ghn3_pool_bwd.argtypes = [ctypes.c_void_p] * 5
         if lib.ghn3_abi_version() != ABI_VERSION:
             raise Ghn3Error('libghn3_hip.so ABI %d != expected %d: rebuild' % (lib.ghn3_abi_version(), ABI_VERSION))
         _lib = lib

@@ -1718,3 +1718,140 @@ extern "C" int ghn3_se_bwd(int N, int HW, int C, int J, const float* dy, const f
     LAUNCH_CHECK("se wgrad")
     return GHN3_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// k x k max / average pooling on NHWC activations (round 6; the `max_pool_3x3` / `avg_pool_3x3` ops of ops.py:289-291 and the
+// stems' MaxPool2d(3, 2, 1)): ATen's pooling kernels return wrong input gradients for channels_last tensors on this ROCm build, so
+// every pooling layer behind a fused layer paid two layout copies.  Average pooling counts valid taps only
+// (count_include_pad = False, as the search space builds it); max pooling keeps the FIRST maximum in (kh, kw) scan order as
+// torch does and stores its tap in one byte per output element.  Backward as a gather per input pixel: no atomics.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+
+struct PDesc { int N, H, W, C, k, stride, pad, Ho, Wo, mode; };
+
+__global__ __launch_bounds__(256) void tnet_pool_fwd_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                            unsigned char* __restrict__ idx, const PDesc d, const int64_t total) {
+    const int nq = d.C / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cq = (int)(i % nq);
+        const int64_t p = i / nq;
+        const int ow = (int)(p % d.Wo), oh = (int)((p / d.Wo) % d.Ho), n = (int)(p / ((int64_t)d.Wo * d.Ho));
+        const int ih0 = oh * d.stride - d.pad, iw0 = ow * d.stride - d.pad;
+        f32x4 acc = d.mode ? f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY} : f32x4{0.f, 0.f, 0.f, 0.f};
+        unsigned arg[4] = {0, 0, 0, 0};
+        int cnt = 0;
+        for (int kh = 0; kh < d.k; ++kh) {
+            const int ih = ih0 + kh;
+            if (ih < 0 || ih >= d.H) continue;
+            for (int kw = 0; kw < d.k; ++kw) {
+                const int iw = iw0 + kw;
+                if (iw < 0 || iw >= d.W) continue;
+                const f32x4 v = *reinterpret_cast<const f32x4*>(x + (((int64_t)n * d.H + ih) * d.W + iw) * d.C + 4 * cq);
+                ++cnt;
+                if (d.mode) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (v[e] > acc[e] || v[e] != v[e]) { acc[e] = v[e]; arg[e] = (unsigned)(kh * d.k + kw); }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] += v[e];
+                }
+            }
+        }
+        if (!d.mode) {
+            const float inv = 1.f / (float)max(cnt, 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[e] *= inv;
+        } else {
+            *reinterpret_cast<unsigned*>(idx + 4 * i) = arg[0] | (arg[1] << 8) | (arg[2] << 16) | (arg[3] << 24);
+        }
+        *reinterpret_cast<f32x4*>(y + 4 * i) = acc;
+    }
+}
+
+__device__ __forceinline__ int pool_count(const PDesc& d, int o, int size) {     // valid taps of output index o along one axis
+    const int lo = max(o * d.stride - d.pad, 0), hi = min(o * d.stride - d.pad + d.k, size);
+    return max(hi - lo, 0);
+}
+
+__global__ __launch_bounds__(256) void tnet_pool_bwd_kernel(const float* __restrict__ dy, const unsigned char* __restrict__ idx,
+                                                            float* __restrict__ dx, const PDesc d, const int64_t total) {
+    const int nq = d.C / 4;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+        const int cq = (int)(i % nq);
+        const int64_t p = i / nq;
+        const int iw = (int)(p % d.W), ih = (int)((p / d.W) % d.H), n = (int)(p / ((int64_t)d.W * d.H));
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        // outputs whose window holds (ih, iw): oh * stride - pad <= ih < oh * stride - pad + k
+        const int oh_lo = max(0, (ih + d.pad - d.k + d.stride) / d.stride), oh_hi = min(d.Ho - 1, (ih + d.pad) / d.stride);
+        const int ow_lo = max(0, (iw + d.pad - d.k + d.stride) / d.stride), ow_hi = min(d.Wo - 1, (iw + d.pad) / d.stride);
+        for (int oh = oh_lo; oh <= oh_hi; ++oh) {
+            const int kh = ih - (oh * d.stride - d.pad);
+            if (kh < 0 || kh >= d.k) continue;
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const int kw = iw - (ow * d.stride - d.pad);
+                if (kw < 0 || kw >= d.k) continue;
+                const int64_t o = (((int64_t)n * d.Ho + oh) * d.Wo + ow) * nq + cq;
+                const f32x4 g = *reinterpret_cast<const f32x4*>(dy + 4 * o);
+                if (d.mode) {
+                    const unsigned a = *reinterpret_cast<const unsigned*>(idx + 4 * o), t = (unsigned)(kh * d.k + kw);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (((a >> (8 * e)) & 255u) == t) acc[e] += g[e];
+                } else {
+                    const float inv = 1.f / (float)max(pool_count(d, oh, d.H) * pool_count(d, ow, d.W), 1);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[e] = fmaf(g[e], inv, acc[e]);
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(dx + 4 * i) = acc;
+    }
+}
+
+int check_pdesc(const ghn3_pool_desc* g, PDesc& d) {
+    if (!g) { ghn3_set_error("pool: null descriptor"); return GHN3_E_ARG; }
+    d = PDesc{g->N, g->H, g->W, g->C, g->k, g->stride, g->pad, g->Ho, g->Wo, g->mode};
+    if (d.N <= 0 || d.H <= 0 || d.W <= 0 || d.C <= 0 || d.k <= 0 || d.stride <= 0 || d.pad < 0 || (d.mode != 0 && d.mode != 1)) {
+        ghn3_set_error("pool: bad descriptor");
+        return GHN3_E_ARG;
+    }
+    if ((d.C & 3) || d.k > 15 || 2 * d.pad > d.k) {
+        ghn3_set_error("pool: needs C a multiple of 4, k <= 15, pad <= k / 2 (got C = %d, k = %d, pad = %d)", d.C, d.k, d.pad);
+        return GHN3_E_LIMIT;
+    }
+    const int ho = (d.H + 2 * d.pad - d.k) / d.stride + 1, wo = (d.W + 2 * d.pad - d.k) / d.stride + 1;
+    if (ho != d.Ho || wo != d.Wo || ho <= 0 || wo <= 0) {
+        ghn3_set_error("pool: output size %d x %d does not match the pooling arithmetic (%d x %d, floor mode)", d.Ho, d.Wo, ho, wo);
+        return GHN3_E_ARG;
+    }
+    if ((int64_t)d.N * d.H * d.W * d.C >= ((int64_t)1 << 31)) { ghn3_set_error("pool: 2^31 activations or more"); return GHN3_E_LIMIT; }
+    return GHN3_OK;
+}
+
+}  // namespace
+
+extern "C" int ghn3_pool_fwd(const ghn3_pool_desc* g, const float* x, float* y, unsigned char* idx, void* stream_) {
+    PDesc d;
+    int rc = check_pdesc(g, d);
+    if (rc) return rc;
+    if (!x || !y || (d.mode == 1 && !idx)) { ghn3_set_error("pool fwd: null pointer"); return GHN3_E_ARG; }
+    const int64_t total = (int64_t)d.N * d.Ho * d.Wo * (d.C / 4);
+    hipLaunchKernelGGL(tnet_pool_fwd_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream_, x, y, idx,
+                       d, total);
+    LAUNCH_CHECK("pool fwd")
+    return GHN3_OK;
+}
+
+extern "C" int ghn3_pool_bwd(const ghn3_pool_desc* g, const float* dy, const unsigned char* idx, float* dx, void* stream_) {
+    PDesc d;
+    int rc = check_pdesc(g, d);
+    if (rc) return rc;
+    if (!dy || !dx || (d.mode == 1 && !idx)) { ghn3_set_error("pool bwd: null pointer"); return GHN3_E_ARG; }
+    const int64_t total = (int64_t)d.N * d.H * d.W * (d.C / 4);
+    hipLaunchKernelGGL(tnet_pool_bwd_kernel, dim3((int)std::min<int64_t>((total + 255) / 256, 8192)), dim3(256), 0, (hipStream_t)stream_, dy, idx,
+                       dx, d, total);
+    LAUNCH_CHECK("pool bwd")
+    return GHN3_OK;
+}

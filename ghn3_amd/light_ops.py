@@ -218,6 +218,11 @@ class AvgPool2d(ModuleEmpty):
         self.count_include_pad, self.divisor_override = count_include_pad, divisor_override
 
     def forward(self, x):
+        if x.is_cuda and not self.ceil_mode and not self.count_include_pad and self.divisor_override is None:
+            from . import target_ops                     # (round 6: NHWC pooling on the fused op; its output stays NHWC)
+            y = target_ops.run_pool(x, self.kernel_size, self.stride, self.padding, 0)
+            if y is not None:
+                return y
         return F.avg_pool2d(_stock_layout(x), self.kernel_size, self.stride, self.padding, self.ceil_mode,
                             self.count_include_pad, self.divisor_override)
 
@@ -230,6 +235,11 @@ class MaxPool2d(ModuleEmpty):
         self.return_indices, self.ceil_mode = return_indices, ceil_mode
 
     def forward(self, x):
+        if x.is_cuda and not self.ceil_mode and not self.return_indices and self.dilation in (1, (1, 1)):
+            from . import target_ops
+            y = target_ops.run_pool(x, self.kernel_size, self.stride, self.padding, 1)
+            if y is not None:
+                return y
         return F.max_pool2d(_stock_layout(x), self.kernel_size, self.stride, self.padding, self.dilation,
                             ceil_mode=self.ceil_mode, return_indices=self.return_indices)
 

@@ -373,6 +373,58 @@ def run_se_layer(fc1, fc2, x, keep_layout=False):
     return y if (keep_layout or lazy_layout(fc1, fc2)) else y.contiguous(memory_format=torch.contiguous_format)
 
 
+class _PoolDesc(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int32) for n in ('N', 'H', 'W', 'C', 'k', 'stride', 'pad', 'Ho', 'Wo', 'mode')]
+
+
+class Pool2d(torch.autograd.Function):
+    """k x k max (mode 1) / average over the valid taps (mode 0) pooling on NHWC storage: ghn3_pool_fwd / _bwd (round 6; the
+    `max_pool_3x3` / `avg_pool_3x3` ops and the stems' MaxPool2d, ops.py:289-291,452)."""
+
+    @staticmethod
+    def applicable(x, k, stride, pad):
+        return enabled() and os.environ.get('GHN3_NATIVE_POOL', '1') != '0' and torch.is_tensor(x) and x.is_cuda and \
+            x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled() and x.shape[1] % 4 == 0 and \
+            isinstance(k, int) and isinstance(stride, int) and isinstance(pad, int) and 0 < k <= 15 and 2 * pad <= k and \
+            stride > 0 and x.shape[2] + 2 * pad >= k and x.shape[3] + 2 * pad >= k and x.numel() < 2 ** 31
+
+    @staticmethod
+    def forward(ctx, x, k, stride, pad, mode):
+        lib = L.load()
+        xc = x.contiguous(memory_format=torch.channels_last)
+        N, C, H, W = xc.shape
+        d = _PoolDesc(N, H, W, C, k, stride, pad, (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1, mode)
+        y = torch.empty((N, C, d.Ho, d.Wo), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+        idx = torch.empty(y.numel(), dtype=torch.uint8, device=x.device) if mode else None
+        L._check(lib.ghn3_pool_fwd(ctypes.byref(d), _ptr(xc), _ptr(y), _ptr(idx) if mode else None, _stream()), 'ghn3_pool_fwd')
+        ctx.desc, ctx.idx = d, idx
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        d = ctx.desc
+        do = dy.contiguous(memory_format=torch.channels_last)
+        dx = torch.empty((d.N, d.C, d.H, d.W), dtype=torch.float32, device=dy.device, memory_format=torch.channels_last)
+        L._check(lib.ghn3_pool_bwd(ctypes.byref(d), _ptr(do), _ptr(ctx.idx) if d.mode else None, _ptr(dx), _stream()), 'ghn3_pool_bwd')
+        return dx, None, None, None, None
+
+
+def _as_int(v):
+    """An int for a square kernel / stride / padding given as int or equal pair, else None."""
+    if isinstance(v, (tuple, list)):
+        return int(v[0]) if len(v) == 2 and v[0] == v[1] else None
+    return int(v) if isinstance(v, int) else None
+
+
+def run_pool(x, kernel_size, stride, padding, mode):
+    """max (mode 1) / average (mode 0, valid taps only) pooling on the fused op where it applies; None otherwise."""
+    k, s, p = _as_int(kernel_size), _as_int(stride), _as_int(padding)
+    if k is None or s is None or p is None or not Pool2d.applicable(x, k, s, p):
+        return None
+    return Pool2d.apply(x, k, s, p, mode)
+
+
 def conv_reference(x, w, gamma, beta, stride=1, padding=0, dilation=1, relu=True, eps=1e-5):
     """The stock layers ConvBn replaces (ops.py:186-193), functional form -- the parity reference of the tests."""
     y = F.conv2d(F.relu(x) if relu else x, w, None, stride, padding, dilation)

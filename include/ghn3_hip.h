@@ -571,6 +571,15 @@ int ghn3_se_fwd(int N, int HW, int C, int J, const float* x, const float* w1, co
 int ghn3_se_bwd(int N, int HW, int C, int J, const float* dy, const float* x, const float* w1, const float* w2, const float* save,
                 float* dx, float* dw1, float* db1, float* dw2, float* db2, float* scratch, void* stream);
 
+/* ---- target-network layers, pooling (ABI v19, round 6): k x k max / average pooling on NHWC activations ---------------------
+ * Replaces `nn.MaxPool2d` / `nn.AvgPool2d(count_include_pad=False)` of the search space (/root/reference/ghn3/ops.py:289-291, the stems'
+ * MaxPool2d at ops.py:452) executed at trainer.py:308-319, and their autograd.  mode 0 = average over the VALID taps, 1 = max (the first
+ * maximum in (kh, kw) order, its tap kept in one byte per output element: idx [N Ho Wo C], forward output / backward input; NULL for
+ * mode 0).  Floor mode: Ho = (H + 2 pad - k) / stride + 1.  Limits (GHN3_E_LIMIT): C a multiple of 4, k <= 15, pad <= k / 2. */
+typedef struct ghn3_pool_desc { int32_t N, H, W, C, k, stride, pad, Ho, Wo, mode; } ghn3_pool_desc;
+int ghn3_pool_fwd(const ghn3_pool_desc* desc, const float* x, float* y, unsigned char* idx, void* stream);
+int ghn3_pool_bwd(const ghn3_pool_desc* desc, const float* dy, const unsigned char* idx, float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

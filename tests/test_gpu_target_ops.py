@@ -288,6 +288,37 @@ def test_squeeze_excitation_layer_matches_the_stock_layers(case):
     assert torch.equal(out2, out.detach())
 
 
+@pytest.mark.parametrize('mode', [0, 1])
+@pytest.mark.parametrize('case', [(4, 32, 16, 16, 3, 1, 1), (3, 48, 15, 17, 3, 2, 1), (2, 64, 8, 8, 2, 2, 0), (5, 16, 7, 5, 3, 1, 1),
+                                  (2, 128, 4, 4, 3, 2, 1), (2, 24, 32, 32, 5, 2, 2)])
+def test_nhwc_pooling_matches_torch(case, mode):
+    """ghn3_pool_fwd / _bwd (round 6: `avg_pool_3x3` with count_include_pad = False, `max_pool_3x3`, the stems' MaxPool2d(3, 2, 1);
+    ops.py:289-291,452) against torch on an NCHW fp64 tensor: output (max: bit-exact) and input gradient up to fp32 rounding,
+    through the light modules that route to it."""
+    from ghn3_amd import light_ops
+    N, C, H, W, k, s, pad = case
+    g = torch.Generator().manual_seed(N * C + H + k + mode)
+    x = torch.randn(N, C, H, W, generator=g)
+    xr = x.double().requires_grad_(True)
+    F = torch.nn.functional
+    ref = F.max_pool2d(xr, k, s, pad) if mode else F.avg_pool2d(xr, k, s, pad, count_include_pad=False)
+    up = torch.randn(ref.shape, generator=g)
+    (ref * up.double()).sum().backward()
+    m = light_ops.MaxPool2d(k, stride=s, padding=pad) if mode else light_ops.AvgPool2d(k, stride=s, padding=pad, count_include_pad=False)
+    xd = x.cuda().requires_grad_(True)
+    out = m(xd)
+    assert 'Pool2d' in type(out.grad_fn).__name__, type(out.grad_fn).__name__
+    assert out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
+    (out * up.cuda()).sum().backward()
+    torch.cuda.synchronize()
+    if mode:
+        assert torch.equal(out.detach().cpu().double(), ref.detach())
+        assert _rel(xd.grad.cpu(), xr.grad) < 1e-6                 # (an input that wins several windows sums their gradients in fp32)
+        assert torch.equal(xd.grad.cpu() != 0, xr.grad != 0)       # (the same winners)
+    else:
+        assert _rel(out.detach().cpu(), ref.detach()) < 1e-6 and _rel(xd.grad.cpu(), xr.grad) < 1e-6
+
+
 def test_relu_conv_bn_module_runs_on_the_dense_op(monkeypatch):
     """`ReLUConvBN` with a 3 x 3 kernel (the search space's `conv_3x3`): the module's forward goes through ONE fused node, matches the
     stock layers and updates the running statistics as torch does."""

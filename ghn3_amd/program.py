@@ -1806,6 +1806,10 @@ class Program:
 
         d_rows = self.wsf('d_xrows', (M + n1) * C)
         # ---- tile backward -------------------------------------------------------------------------
+        # (zero-fills of this program point are collected and emitted as ONE fill per run of neighbouring workspace regions -- the
+        # regions are bump-allocated here, one behind the other, separated by their slack and alignment padding only: four
+        # 5 us launches on the critical stream become one)
+        zeros = []
         if M > 0:
             self.wsf('d_tiles', self.tiles_floats)
             # (fp32 tile gradient: its row padding is read -- and multiplied by zeros -- on the upstream-gradient route, so it
@@ -1814,14 +1818,14 @@ class Program:
             if 'clsout' in self._ws_names:
                 n_cls = sum(g['rows'] * g['i_ld'] for g in self.conv_groups if g['kind'] == 'cls')
                 self.wsf('d_clsout', n_cls * ldK)
-                self.op(L.OP_MEMSET0, refs=(self.wref('d_clsout'),), ints=(4 * n_cls * ldK,))
+                zeros.append((self.wref('d_clsout'), 4 * n_cls * ldK))
         if n1 > 0:
             mc = self.mc
             self.wsf('d_w1d', n1 * 2 * mc)
-            self.op(L.OP_MEMSET0, refs=(self.wref('d_w1d'),), ints=(4 * n1 * 2 * mc,))
+            zeros.append((self.wref('d_w1d'), 4 * n1 * 2 * mc))
             if self.n1_clsb:
                 self.wsf('d_cbout', self.n1_clsb * ldK)
-                self.op(L.OP_MEMSET0, refs=(self.wref('d_cbout'),), ints=(4 * self.n1_clsb * ldK,))
+                zeros.append((self.wref('d_cbout'), 4 * self.n1_clsb * ldK))
         # running max |x| of d_tiles ([0], written by TILE_BWD) and d_u ([4], written by DACT): the power-of-two
         # scales of the f16 gradient copies
         self.r_amax = self.wsf('amax', 16)
@@ -1829,7 +1833,15 @@ class Program:
         amax_t = self.r_amax if scaled else None
         amax_u = (self.r_amax[0], self.r_amax[1] + 16) if scaled else None
         if scaled:
-            self.op(L.OP_MEMSET0, refs=(self.r_amax,), ints=(64,))
+            zeros.append((self.r_amax, 64))
+        run = None
+        for (buf, off), n in sorted(zeros, key=lambda it: (it[0][0], it[0][1])) + [((None, 0), 0)]:
+            if run is not None and buf == run[0] and 0 <= off - (run[1] + run[2]) <= 1024:
+                run[2] = off + n - run[1]                   # (the gap: slack / padding of the previous region)
+                continue
+            if run is not None:
+                self.op(L.OP_MEMSET0, refs=((run[0], run[1]),), ints=(run[2],))
+            run = [buf, off, n]
         if self.n_desc:
             grads = self._tile_sources(True)
             if scaled:

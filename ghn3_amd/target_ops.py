@@ -47,7 +47,10 @@ def _ptr(t):
 def _stream():
     """The current HIP stream of the current device as an integer handle (torch.cuda.current_stream() builds a Stream object
     per call: 11 us; this is called twice per fused layer, ~700 times per training step)."""
-    return torch._C._cuda_getCurrentRawStream(torch.cuda.current_device())
+    raw = getattr(torch._C, '_cuda_getCurrentRawStream', None)
+    if raw is None:                                       # (a torch build without the raw accessor)
+        return torch.cuda.current_stream().cuda_stream
+    return raw(torch.cuda.current_device())
 
 
 _SCRATCH = {}

@@ -1,5 +1,7 @@
 #!/bin/bash
-# round 6, call 17: the training loop on the final code -- three passes from a cold box, cProfile, kernel trace
+# The training loop of examples/train_ghn_ddp.py on one GPU box (run through gpurun): four passes from a cold box, one under
+# cProfile, the same loop on the stock ATen / MIOpen layers (first and second pass), and the kernel trace (tools/train_loop_trace.sh).
+#   bash tools/train_loop_final.sh   ->  gpurun_out/r06y/train_final.txt, cprofile_final.txt, train_loop_rocprof_kernel_stats.txt
 set -u
 mkdir -p gpurun_out/r06y
 for rep in 1 2 3 4; do
@@ -8,4 +10,4 @@ done
 GHN3_CPROFILE=gpurun_out/r06y/cprofile_final.txt timeout 600 python examples/train_ghn_ddp.py --steps 63 2>&1 | grep -E "ms per step" | sed "s/^/cprofile: /" | tee -a gpurun_out/r06y/train_final.txt
 GHN3_NATIVE_OPS=0 timeout 900 python examples/train_ghn_ddp.py --steps 63 2>&1 | grep -E "ms per step" | sed "s/^/stock layers (GHN3_NATIVE_OPS=0), first pass: /" | tee -a gpurun_out/r06y/train_final.txt
 GHN3_NATIVE_OPS=0 timeout 900 python examples/train_ghn_ddp.py --steps 63 2>&1 | grep -E "ms per step" | sed "s/^/stock layers (GHN3_NATIVE_OPS=0), second pass: /" | tee -a gpurun_out/r06y/train_final.txt
-bash tools/gpu_call11.sh 2>&1 | grep -E "GPU busy|kernel us/step"
+bash tools/train_loop_trace.sh 2>&1 | grep -E "GPU busy|kernel us/step"

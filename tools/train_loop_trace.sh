@@ -1,6 +1,8 @@
 #!/bin/bash
-# round 6, call 11: is the training loop GPU-bound?  rocprofv3 kernel trace of Trainer.update on the example's architecture
-# stream (in-process, no worker pool: tools/diag/stock_layer_census.py), native layers on
+# Is the training loop GPU-bound?  rocprofv3 kernel trace of 24 Trainer.update steps on the example's architecture stream
+# (in-process, no worker pool -- a spawn under the profiler is an exec after GPU initialisation --: tools/diag/stock_layer_census.py),
+# native layers on; prints the kernel table, GPU busy time per step and the dense weight gradient's calls by grid.
+#   bash tools/train_loop_trace.sh   ->  gpurun_out/r06y/train_loop_rocprof_kernel_stats.txt
 set -u
 mkdir -p gpurun_out/r06y
 export TMPDIR=/tmp

@@ -61,13 +61,14 @@ def main():
     ap.add_argument('--native', action='store_true',
                     help='run the target networks on ATen native convolution / batch-norm kernels instead of MIOpen')
     args = ap.parse_args()
-    # Every step brings NEW architectures, i.e. convolution configurations MIOpen may not have seen.  On first sight of a
-    # configuration its default (hybrid) find mode benchmarks candidate kernels and records the winner in the user's
-    # find-db; from then on the configuration costs nothing extra.  Measured at meta-batch 8, 64 images of 32 x 32, one
-    # MI355X: ~1.0 s per step on a first pass over a set of architectures, 132 ms (--amp) / 140 ms (fp32) per step once
-    # their configurations are in the find-db -- the configuration space of the search space is finite, so a long run
-    # converges to the latter.  MIOPEN_FIND_MODE=2 (heuristics only, no benchmark) gives 0.35-0.6 s per step from a cold
-    # find-db; the ATen native kernels (--native: im2col + GEMM per sample, no build step) 1.03 s.
+    # Every step brings NEW architectures.  On the stock layers (GHN3_NATIVE_OPS=0, what the reference runs) that means convolution
+    # configurations MIOpen may not have seen: its default (hybrid) find mode benchmarks candidate kernels on first sight of a
+    # configuration -- measured at meta-batch 8, 64 images of 32 x 32, one MI355X: ~1.0 s per step on a first pass over a set of
+    # architectures, 145 ms per step once their configurations are in the find-db.  With the target networks on the fused HIP
+    # layers of ghn3_amd.target_ops (the default: every convolution / BatchNorm / squeeze-excitation / pooling layer of this
+    # search space) there is no find step: 76-85 ms per step from a cold box, the same with --amp (the fused layers run in fp32
+    # under autocast; --amp on the stock layers: 0.88 s per step cold).  profiles/r06y_train_loop_final.txt.
+    # --native (for the stock path): ATen's native kernels instead of MIOpen (im2col + GEMM per sample, no build step), 1.03 s.
 
     import multiprocessing as mp
     for var in ('OMP_NUM_THREADS', 'MKL_NUM_THREADS'):

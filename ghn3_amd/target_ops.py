@@ -44,6 +44,14 @@ def _ptr(t):
     return t.data_ptr()               # (an int: ctypes converts it for the c_void_p parameters)
 
 
+def _autocast_excludes():
+    """Under torch.autocast the fused layers still run -- in fp32, on the fp32 tensors the GHN predicted and the fp32 activations the
+    previous fused layer left (a precision at or above what the stock fp16 / bf16 autocast kernels would use; a 16-bit activation from
+    a stock autocast layer makes the next fused layer inapplicable by its dtype check).  GHN3_NATIVE_AMP=0: leave every layer to the
+    stock path while autocast is on (the behaviour until round 6)."""
+    return torch.is_autocast_enabled() and os.environ.get('GHN3_NATIVE_AMP', '1') == '0'
+
+
 def _stream():
     """The current HIP stream of the current device as an integer handle (torch.cuda.current_stream() builds a Stream object
     per call: 11 us; this is called twice per fused layer, ~700 times per training step)."""
@@ -86,8 +94,8 @@ class DwPwBn(torch.autograd.Function):
     def applicable(x, w_dw, w_pw, gamma, beta, ks, training_stats=True):
         if not (enabled() and torch.is_tensor(x) and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4):
             return False
-        if torch.is_autocast_enabled():
-            return False                       # (under AMP the stock path decides the types)
+        if _autocast_excludes():
+            return False                       # (GHN3_NATIVE_AMP=0: under AMP the stock path decides the types)
         if not training_stats or not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32
                                          for t in (w_pw, gamma, beta) + (() if w_dw is None else (w_dw,))):
             return False
@@ -199,7 +207,7 @@ class ConvBn(torch.autograd.Function):
         if not (enabled() and os.environ.get('GHN3_NATIVE_CONV', '1') != '0' and torch.is_tensor(x) and x.is_cuda and
                 x.dtype == torch.float32 and x.dim() == 4):
             return False
-        if torch.is_autocast_enabled() or not training_stats:
+        if _autocast_excludes() or not training_stats:
             return False
         if not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 for t in (w, gamma, beta)) or w.dim() != 4:
             return False
@@ -254,7 +262,7 @@ class ConvOnly(torch.autograd.Function):
     @staticmethod
     def applicable(x, w):
         if not (enabled() and os.environ.get('GHN3_NATIVE_CONV', '1') != '0' and torch.is_tensor(x) and x.is_cuda and
-                x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled()):
+                x.dtype == torch.float32 and x.dim() == 4 and not _autocast_excludes()):
             return False
         if not (torch.is_tensor(w) and w.is_cuda and w.dtype == torch.float32 and w.dim() == 4):
             return False
@@ -317,7 +325,7 @@ class SqueezeExcite(torch.autograd.Function):
     @staticmethod
     def applicable(x, w1, b1, w2, b2):
         if not (enabled() and os.environ.get('GHN3_NATIVE_SE', '1') != '0' and torch.is_tensor(x) and x.is_cuda and
-                x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled()):
+                x.dtype == torch.float32 and x.dim() == 4 and not _autocast_excludes()):
             return False
         if not all(torch.is_tensor(t) and t.is_cuda and t.dtype == torch.float32 for t in (w1, b1, w2, b2)):
             return False
@@ -387,7 +395,7 @@ class Pool2d(torch.autograd.Function):
     @staticmethod
     def applicable(x, k, stride, pad):
         return enabled() and os.environ.get('GHN3_NATIVE_POOL', '1') != '0' and torch.is_tensor(x) and x.is_cuda and \
-            x.dtype == torch.float32 and x.dim() == 4 and not torch.is_autocast_enabled() and x.shape[1] % 4 == 0 and \
+            x.dtype == torch.float32 and x.dim() == 4 and not _autocast_excludes() and x.shape[1] % 4 == 0 and \
             isinstance(k, int) and isinstance(stride, int) and isinstance(pad, int) and 0 < k <= 15 and 2 * pad <= k and \
             stride > 0 and x.shape[2] + 2 * pad >= k and x.shape[3] + 2 * pad >= k and x.numel() < 2 ** 31
 

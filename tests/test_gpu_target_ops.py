@@ -319,6 +319,24 @@ def test_nhwc_pooling_matches_torch(case, mode):
         assert _rel(out.detach().cpu(), ref.detach()) < 1e-6 and _rel(xd.grad.cpu(), xr.grad) < 1e-6
 
 
+def test_fused_layers_run_in_fp32_under_autocast(monkeypatch):
+    """Under torch.autocast (Trainer(amp=True), trainer.py:300-319) the fused layers keep running, in fp32: the same bits as without
+    autocast; GHN3_NATIVE_AMP=0 hands the layers back to the stock 16-bit autocast kernels."""
+    from ghn3_amd import ops
+    torch.manual_seed(12)
+    m = ops.ReLUConvBN(32, 48, 3, 1, 1).cuda().train()
+    x = torch.randn(4, 32, 10, 10, device='cuda')
+    with torch.no_grad():
+        plain = m(x)
+        with torch.autocast('cuda', dtype=torch.float16):
+            amp = m(x)
+        monkeypatch.setenv('GHN3_NATIVE_AMP', '0')
+        with torch.autocast('cuda', dtype=torch.float16):
+            stock = m(x)
+    assert amp.dtype == torch.float32 and torch.equal(amp, plain)
+    assert _rel(stock.float().cpu(), plain.cpu()) < 2e-2 and not torch.equal(stock.float(), plain)
+
+
 def test_relu_conv_bn_module_runs_on_the_dense_op(monkeypatch):
     """`ReLUConvBN` with a 3 x 3 kernel (the search space's `conv_3x3`): the module's forward goes through ONE fused node, matches the
     stock layers and updates the running statistics as torch does."""

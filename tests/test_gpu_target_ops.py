@@ -462,3 +462,48 @@ def test_networks_on_the_fused_layers_match_the_stock_path(light, monkeypatch):
             if a is not None and float(b.norm()) > 0:
                 assert _rel(a, b) < 2e-3, (name, _rel(a, b))
     assert used >= 3
+
+
+def test_sampled_architectures_on_the_fused_layers_match_the_stock_path(monkeypatch):
+    """Twelve architectures of the training loop's own stream (ghn3_amd.deepnets1m.SampledNets as examples/train_ghn_ddp.py draws
+    them: whatever mix of stems, conv / pair / separable / dilated ops, pooling, squeeze-excitation, factorized reductions and wide
+    preprocessing layers the sampler produces), tensors assigned as a GHN would: logits and the gradient of the flat parameter
+    buffer on the fused HIP layers against the stock ATen / MIOpen layers."""
+    import recipe
+    from ghn3_amd.deepnets1m import SampledNets
+    worst = (0.0, 0.0)
+    x = torch.from_numpy(recipe.seeded_images((8, 3, 32, 32), seed=3)).cuda()
+    for k in range(12):
+        res = {}
+        for mode in ('stock', 'fused'):
+            monkeypatch.setenv('GHN3_NATIVE_OPS', '0' if mode == 'stock' else '1')
+            net = SampledNets(large_images=False, seed=0, max_nodes=400)[k].net
+            table = {}
+            for cell in net._layered_modules:
+                table.update(cell)
+            shapes = [(n, tuple(e['sz'])) for n, e in table.items()]
+            params = recipe.seeded_net_params(shapes, seed=100 + k)
+            total = sum(int(np.prod(s)) for _, s in shapes)
+            flat = torch.zeros(total, device='cuda')
+            off = 0
+            for n, s in shapes:
+                cnt = int(np.prod(s))
+                flat[off:off + cnt] = torch.from_numpy(params[n]).reshape(-1).cuda()
+                off += cnt
+            flat.requires_grad_(True)
+            off = 0
+            for n, e in table.items():
+                cnt = int(np.prod(e['sz']))
+                setattr(e['module'], 'weight' if e['is_w'] else 'bias', flat[off:off + cnt].view(tuple(e['sz'])))
+                off += cnt
+            net.train()
+            torch.manual_seed(5)
+            logits, _ = net(x)
+            up = torch.randn(logits.shape, generator=torch.Generator().manual_seed(9)).cuda()
+            (logits * up).sum().backward()
+            torch.cuda.synchronize()
+            res[mode] = (logits.detach().cpu(), flat.grad.detach().cpu())
+        e_l, e_g = _rel(res['fused'][0], res['stock'][0]), _rel(res['fused'][1], res['stock'][1])
+        worst = (max(worst[0], e_l), max(worst[1], e_g))
+        assert e_l < 1e-3 and e_g < 5e-3, (k, e_l, e_g)
+    print('worst logits / gradient deviation over the stream: %.2e / %.2e' % worst)
